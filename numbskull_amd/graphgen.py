@@ -1,0 +1,306 @@
+"""Synthetic factor-graph builders and the DeepDive binary writer.
+
+The reference ships one fixture generator, ising/ising.cpp (a C++ program that writes
+``graph.{meta,weights,variables,factors}``; format at ising.cpp:88-130, reader at
+numbskull/dataloading.py:103-237).  This module produces the same graphs as numpy record
+arrays (ready for ``NumbSkull.loadFactorGraph``) with vectorised code that scales to the
+10M-50M-variable benchmark configurations, and writes/reads the same on-disk format.
+
+Every builder returns ``(weight, variable, factor, fmap, domain_mask, edges)`` -- the
+positional arguments of ``NumbSkull.loadFactorGraph`` (numbskull.py:192-194).
+"""
+
+import os
+
+import numpy as np
+
+from .numbskulltypes import Weight, Variable, Factor, FactorToVar
+
+FUNC_EQUAL, FUNC_ISTRUE = 3, 4
+
+
+def ising_grid(nrows, ncols, weight=0.1, fixed=True, two_weights=False, evidence=None,
+               initial=None):
+    """N x M Ising grid of binary variables with EQUAL factors to the up and left neighbour.
+
+    Same graph as the (commented-out) generator at ising/ising.cpp:134-199: variable id
+    ``i*M+j``; for every cell, in row-major order, first the factor to the cell above
+    ``(i*M+j, (i-1)*M+j)`` when ``i>0``, then the factor to the left ``(i*M+j, i*M+j-1)``
+    when ``j>0``; featureValue 1, equalPredicate 0.
+
+    ``two_weights``: weight 0 on vertical and weight 1 on horizontal edges (the learning
+    variant of benchmark config #3); otherwise a single weight 0.
+    ``evidence``: optional int array (nrows*ncols) -> every variable becomes evidence with
+    that initial value.  ``initial`` sets initialValue of query variables.
+    """
+    n, m = int(nrows), int(ncols)
+    nvar = n * m
+    variable = np.zeros(nvar, Variable)
+    variable["cardinality"] = 2
+    if evidence is not None:
+        variable["isEvidence"] = 1
+        variable["initialValue"] = np.asarray(evidence, np.int64).reshape(nvar)
+    elif initial is not None:
+        variable["initialValue"] = np.asarray(initial, np.int64).reshape(nvar)
+
+    nw = 2 if two_weights else 1
+    wrec = np.zeros(nw, Weight)
+    wrec["isFixed"] = bool(fixed)
+    wrec["initialValue"] = weight
+
+    ii, jj = np.divmod(np.arange(nvar, dtype=np.int64), m)
+    has_up = ii > 0
+    has_left = jj > 0
+    nfac_of = has_up.astype(np.int64) + has_left.astype(np.int64)
+    first = np.cumsum(nfac_of) - nfac_of          # id of the first factor emitted by a cell
+    nfactor = int(nfac_of.sum())
+
+    factor = np.zeros(nfactor, Factor)
+    factor["factorFunction"] = FUNC_EQUAL
+    factor["featureValue"] = 1.0
+    factor["arity"] = 2
+    factor["ftv_offset"] = 2 * np.arange(nfactor, dtype=np.int64)
+    fmap = np.zeros(2 * nfactor, FactorToVar)
+
+    me = np.arange(nvar, dtype=np.int64)
+    up_f = first[has_up]
+    fmap["vid"][2 * up_f] = me[has_up]
+    fmap["vid"][2 * up_f + 1] = me[has_up] - m
+    left_f = first[has_left] + has_up[has_left]
+    fmap["vid"][2 * left_f] = me[has_left]
+    fmap["vid"][2 * left_f + 1] = me[has_left] - 1
+    if two_weights:
+        factor["weightId"][left_f] = 1
+
+    return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), 2 * nfactor
+
+
+def ising_pairs(npairs, a=1.0, b=1.0, c=0.5, seed=0):
+    """Independent 2-variable evidence pairs for weight recovery (ising/ising.cpp:202-318).
+
+    Pair i is variables (2i, 2i+1), both evidence, drawn from
+    p(x,y) ~ exp(a*s(x) + b*s(y) + c*s(x==y)), s(t)=+1 if t else -1; three free weights
+    (initial 0): ISTRUE(x) -> w0, ISTRUE(y) -> w1, EQUAL(x,y) -> w2.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    z = np.exp([-a - b + c, -a + b - c, a - b - c, a + b + c])
+    idx = np.searchsorted(np.cumsum(z) / z.sum(), rng.random(npairs), side="left").clip(0, 3)
+    nvar = 2 * npairs
+    variable = np.zeros(nvar, Variable)
+    variable["isEvidence"] = 1
+    variable["cardinality"] = 2
+    variable["initialValue"][0::2] = (idx >= 2)
+    variable["initialValue"][1::2] = (idx % 2 == 1)
+    wrec = np.zeros(3, Weight)
+    factor = np.zeros(3 * npairs, Factor)
+    factor["featureValue"] = 1.0
+    factor["factorFunction"] = np.tile([FUNC_ISTRUE, FUNC_ISTRUE, FUNC_EQUAL], npairs)
+    factor["weightId"] = np.tile([0, 1, 2], npairs)
+    factor["arity"] = np.tile([1, 1, 2], npairs)
+    factor["ftv_offset"] = np.cumsum(factor["arity"]) - factor["arity"]
+    fmap = np.zeros(4 * npairs, FactorToVar)
+    base = 2 * np.arange(npairs, dtype=np.int64)
+    fmap["vid"][0::4] = base
+    fmap["vid"][1::4] = base + 1
+    fmap["vid"][2::4] = base
+    fmap["vid"][3::4] = base + 1
+    return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), 4 * npairs
+
+
+def lf_graph(prior, accuracy, copies, seed=0):
+    """Data-programming generative model used by the reference's test_lf_learning.py:22-126.
+
+    ``copies`` x (one hidden binary label y + n labelling-function outputs, cardinality 3,
+    dataType 0, evidence).  Factors: DP_GEN_CLASS_PRIOR(y) -> weight 0 (initial 0) and
+    DP_GEN_LF_ACCURACY(y, lf_i) -> weight i+1 (initial 1).  Evidence is sampled from the
+    exact joint with ``prior``/``accuracy`` planted.
+    """
+    n = len(accuracy)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    states = 2 * 3 ** n
+    logp = np.zeros(states)
+    decoded = np.zeros((states, n + 1), np.int64)
+    for s in range(states):
+        y, rest = s % 2, s // 2
+        decoded[s, 0] = y
+        e = prior * (2 * y - 1)
+        for j in range(n):
+            lf = rest % 3
+            rest //= 3
+            decoded[s, j + 1] = lf
+            e += accuracy[j] * (lf - 1) * (2 * y - 1)
+        logp[s] = e
+    cdf = np.cumsum(np.exp(logp))
+    cdf /= cdf[-1]
+    pick = np.searchsorted(cdf, rng.random(copies), side="left").clip(0, states - 1)
+
+    nvar = copies * (1 + n)
+    nfac = copies * (1 + n)
+    nedge = copies * (1 + 2 * n)
+    wrec = np.zeros(1 + n, Weight)
+    wrec["initialValue"] = 1.0
+    wrec["initialValue"][0] = 0.0
+    variable = np.zeros(nvar, Variable)
+    factor = np.zeros(nfac, Factor)
+    fmap = np.zeros(nedge, FactorToVar)
+    factor["featureValue"] = 1.0
+    for cp in range(copies):
+        v0, f0, e0 = cp * (1 + n), cp * (1 + n), cp * (1 + 2 * n)
+        variable[v0]["cardinality"] = 2
+        factor[f0]["factorFunction"] = 18
+        factor[f0]["arity"] = 1
+        factor[f0]["ftv_offset"] = e0
+        fmap[e0]["vid"] = v0
+        for i in range(n):
+            vi = v0 + 1 + i
+            variable[vi]["isEvidence"] = 1
+            variable[vi]["initialValue"] = decoded[pick[cp], 1 + i]
+            variable[vi]["cardinality"] = 3
+            fi = f0 + 1 + i
+            factor[fi]["factorFunction"] = 21
+            factor[fi]["weightId"] = 1 + i
+            factor[fi]["arity"] = 2
+            factor[fi]["ftv_offset"] = e0 + 1 + 2 * i
+            fmap[e0 + 1 + 2 * i]["vid"] = v0
+            fmap[e0 + 2 + 2 * i]["vid"] = vi
+    return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
+
+
+def mixed_lr_graph(nvar, seed=20240603, nweights=None, window=1024, global_frac=0.01,
+                   evidence_frac=0.5, cat_frac=0.25):
+    """Mixed-arity logistic-regression-style graph (benchmark config #5).
+
+    75 % boolean / 25 % categorical (dataType 1, cardinality 3..8) variables, half of them
+    evidence.  Each variable v heads ``1+min(Poisson(2),15)`` factors of arity 1..4
+    (p = .4/.3/.2/.1) whose other members are drawn from the id window ``[v-1024, v+1024]``
+    (99 %) or uniformly (1 %).  Function: arity 1 -> ISTRUE; all-boolean -> OR or IMPLY_MLN;
+    any categorical member -> OR_CAT / IMPLY_MLN_CAT / AND_CAT, with ``dense_equal_to``
+    uniform over each member's domain.  ``weightId = floor(nweights*u^2)``, all free,
+    initial 0.  IMPLY_MLN* need the library's ``head_by_vid`` lookup (the reference's
+    literal head indexing is out of range on such graphs, inference.py:243).
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nvar = int(nvar)
+    if nweights is None:
+        nweights = max(1, min(10 ** 6, nvar // 50))
+    is_cat = rng.random(nvar) < cat_frac
+    card = np.where(is_cat, rng.integers(3, 9, nvar), 2).astype(np.int64)
+    variable = np.zeros(nvar, Variable)
+    variable["dataType"] = is_cat
+    variable["cardinality"] = card
+    ev = rng.random(nvar) < evidence_frac
+    variable["isEvidence"] = ev
+    variable["initialValue"] = np.where(ev, (rng.random(nvar) * card).astype(np.int64), 0)
+
+    nf_of = 1 + np.minimum(rng.poisson(2.0, nvar), 15)
+    nfactor = int(nf_of.sum())
+    head = np.repeat(np.arange(nvar, dtype=np.int64), nf_of)
+    arity = rng.choice(np.array([1, 2, 3, 4]), size=nfactor, p=[.4, .3, .2, .1]).astype(np.int64)
+    off = np.cumsum(arity) - arity
+    nedge = int(arity.sum())
+
+    fmap = np.zeros(nedge, FactorToVar)
+    fac_of_edge = np.repeat(np.arange(nfactor, dtype=np.int64), arity)
+    pos = np.arange(nedge, dtype=np.int64) - off[fac_of_edge]
+    is_head = pos == arity[fac_of_edge] - 1
+    h = head[fac_of_edge]
+    local = np.clip(h + rng.integers(-window, window + 1, nedge), 0, nvar - 1)
+    glob = rng.integers(0, nvar, nedge)
+    other = np.where(rng.random(nedge) < global_frac, glob, local)
+    vid = np.where(is_head, h, other)
+    fmap["vid"] = vid
+    fmap["dense_equal_to"] = (rng.random(nedge) * card[vid]).astype(np.int64)
+
+    any_cat = np.zeros(nfactor, np.bool_)
+    np.logical_or.at(any_cat, fac_of_edge, is_cat[vid])
+    r = rng.random(nfactor)
+    func = np.where(arity == 1, FUNC_ISTRUE, np.where(r < 0.5, 1, 13))          # OR / IMPLY_MLN
+    func_cat = np.where(r < 1 / 3, 14, np.where(r < 2 / 3, 17, 12))             # OR_CAT/IMPLY_MLN_CAT/AND_CAT
+    func = np.where(any_cat, func_cat, func)
+    factor = np.zeros(nfactor, Factor)
+    factor["factorFunction"] = func
+    factor["weightId"] = np.minimum((nweights * rng.random(nfactor) ** 2).astype(np.int64),
+                                    nweights - 1)
+    factor["featureValue"] = 1.0
+    factor["arity"] = arity
+    factor["ftv_offset"] = off
+    wrec = np.zeros(nweights, Weight)
+    return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
+
+
+# --------------------------------------------------------------------------------------------
+# DeepDive binary format (big-endian), SURVEY.md Appendix B
+# --------------------------------------------------------------------------------------------
+_W_DISK = np.dtype([("weightId", ">i8"), ("isFixed", "u1"), ("initialValue", ">f8")])
+_V_DISK = np.dtype([("variableId", ">i8"), ("isEvidence", "u1"), ("initialValue", ">i8"),
+                    ("dataType", ">i2"), ("cardinality", ">i8")])
+assert _W_DISK.itemsize == 17 and _V_DISK.itemsize == 27
+
+
+def write_graph(directory, weight, variable, factor, fmap, domains=None):
+    """Write ``graph.{meta,weights,variables,factors[,domains]}`` in the format the
+    reference reads (dataloading.py:103-237) and ising/ising.cpp:88-130 writes.
+
+    ``domains``: optional ``{vid: sorted int array}``; when given, ``fmap.dense_equal_to``
+    and ``variable.initialValue`` are taken to be DENSE indices and are written back as
+    the original domain values (the loader re-maps them, dataloading.py:162-185,213-218).
+    """
+    os.makedirs(directory, exist_ok=True)
+    nedge = int(factor["arity"].sum())
+    with open(os.path.join(directory, "graph.meta"), "w") as f:
+        f.write("%d,%d,%d,%d" % (len(weight), len(variable), len(factor), nedge))
+
+    w = np.zeros(len(weight), _W_DISK)
+    w["weightId"] = np.arange(len(weight))
+    w["isFixed"] = weight["isFixed"]
+    w["initialValue"] = weight["initialValue"]
+    w.tofile(os.path.join(directory, "graph.weights"))
+
+    v = np.zeros(len(variable), _V_DISK)
+    v["variableId"] = np.arange(len(variable))
+    v["isEvidence"] = variable["isEvidence"].astype(np.uint8)
+    init = variable["initialValue"].copy()
+    if domains:
+        for vid, dom in domains.items():
+            init[vid] = np.asarray(dom, np.int64)[init[vid]]
+    v["initialValue"] = init
+    v["dataType"] = variable["dataType"]
+    v["cardinality"] = variable["cardinality"]
+    v.tofile(os.path.join(directory, "graph.variables"))
+
+    # graph.factors: i2 func, i8 arity, arity x (i8 vid, i8 value), i8 weightId, f8 featureValue
+    arity = factor["arity"].astype(np.int64)
+    rec_len = 2 + 8 + 16 * arity + 16
+    start = np.cumsum(rec_len) - rec_len
+    buf = np.zeros(int(rec_len.sum()), np.uint8)
+
+    def put(offsets, values, dt):
+        raw = np.ascontiguousarray(values.astype(dt)).view(np.uint8).reshape(len(values), -1)
+        idx = offsets[:, None] + np.arange(raw.shape[1])[None, :]
+        buf[idx] = raw
+
+    put(start, factor["factorFunction"], ">i2")
+    put(start + 2, arity, ">i8")
+    fac_of_edge = np.repeat(np.arange(len(factor), dtype=np.int64), arity)
+    pos = np.arange(nedge, dtype=np.int64) - (np.cumsum(arity) - arity)[fac_of_edge]
+    src = factor["ftv_offset"][fac_of_edge] + pos
+    eoff = start[fac_of_edge] + 10 + 16 * pos
+    vids = fmap["vid"][src]
+    vals = fmap["dense_equal_to"][src].copy()
+    if domains:
+        for vid, dom in domains.items():
+            sel = vids == vid
+            vals[sel] = np.asarray(dom, np.int64)[vals[sel]]
+    put(eoff, vids, ">i8")
+    put(eoff + 8, vals, ">i8")
+    tail = start + 10 + 16 * arity
+    put(tail, factor["weightId"], ">i8")
+    put(tail + 8, factor["featureValue"], ">f8")
+    buf.tofile(os.path.join(directory, "graph.factors"))
+
+    if domains:
+        with open(os.path.join(directory, "graph.domains"), "wb") as f:
+            for vid in sorted(domains):
+                dom = np.asarray(domains[vid], np.int64)
+                np.array([vid, len(dom)], ">i8").tofile(f)
+                dom.astype(">i8").tofile(f)

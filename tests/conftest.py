@@ -1,0 +1,28 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return load
+
+
+def graph_from(npz, tag):
+    """(weight, variable, factor, fmap, domain_mask, edges) stored by tools/make_goldens.py"""
+    return (npz[tag + "_in_weight"], npz[tag + "_in_variable"], npz[tag + "_in_factor"],
+            npz[tag + "_in_fmap"], npz[tag + "_in_domain_mask"], int(npz[tag + "_in_edges"]))
