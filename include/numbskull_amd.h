@@ -1,0 +1,161 @@
+/*
+ * numbskull_amd.h -- C-ABI of the MI355X-native Gibbs-sweep engine (libnumbskull_amd.so).
+ *
+ * The reference (HazyResearch/numbskull) has no FFI layer: its seam is the three
+ * run_pool(...) call sites in numbskull/factorgraph.py
+ *     :141  burn-in   -> inference.gibbsthread(..., burnin=True)
+ *     :163  inference -> inference.gibbsthread(..., burnin=False)
+ *     :202  learning  -> learning.learnthread(...)
+ * whose callee signatures are inference.py:10-13 and learning.py:12-16.  A maintainer makes the
+ * reference GPU-backed by replacing those three calls with nsk_gibbs_sweeps / nsk_learn_sweeps on
+ * a handle created from the very arrays FactorGraph already owns (INTEGRATION.md shows the ctypes
+ * stub).  Everything crosses this boundary as plain pointers and sizes; the record layouts are
+ * the reference's packed numpy dtypes (numbskulltypes.py:11-39), so record arrays are passed by
+ * pointer without conversion.
+ *
+ * Conventions: every function returns NSK_OK (0) or a negative NSK_E_* code; nsk_last_error()
+ * returns a thread-local human-readable message for the last failure.  Host pointers stay owned
+ * by the caller; the library owns device memory.  One in-flight call per handle.
+ */
+#ifndef NUMBSKULL_AMD_H
+#define NUMBSKULL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSK_OK 0
+#define NSK_E_INVALID (-1)      /* bad argument / inconsistent sizes                              */
+#define NSK_E_FACTOR_FUNC (-2)  /* unknown factorFunction: reference raises NotImplementedError
+                                   (inference.py:410-413)                                         */
+#define NSK_E_INDEX (-3)        /* an index the reference would fault on (IndexError)             */
+#define NSK_E_DEVICE (-4)       /* HIP runtime failure or no usable device                        */
+#define NSK_E_RANGE (-5)        /* a value does not fit the device representation                 */
+#define NSK_E_NOMEM (-6)
+
+/* ---- record layouts = numbskull/numbskulltypes.py:11-39 (packed) ---- */
+#pragma pack(push, 1)
+typedef struct { uint8_t isFixed; double initialValue; } nsk_weight;                  /*  9 B */
+typedef struct { int8_t isEvidence; int64_t initialValue; int16_t dataType;
+                 int64_t cardinality; int64_t vtf_offset; } nsk_variable;             /* 27 B */
+typedef struct { int16_t factorFunction; int64_t weightId; double featureValue;
+                 int64_t arity; int64_t ftv_offset; } nsk_factor;                     /* 34 B */
+typedef struct { int64_t vid; int64_t dense_equal_to; } nsk_ftv;                      /* 16 B */
+typedef struct { int64_t value; int64_t factor_index_offset;
+                 int64_t factor_index_length; } nsk_vtf;                              /* 24 B */
+#pragma pack(pop)
+
+/* nsk_graph_desc.flags */
+#define NSK_FLAG_HEAD_BY_VID 1  /* IMPLY_MLN / IMPLY_NATURAL_CAT / IMPLY_MLN_CAT read their head as
+                                   var_value[fmap[l].vid] instead of the reference's literal
+                                   var_value[l] (inference.py:243,277,292)                        */
+
+/* scan orders (nsk_set_scan) */
+#define NSK_SCAN_CHROMATIC 0    /* colour classes in parallel, Philox uniforms (default)          */
+#define NSK_SCAN_SEQUENTIAL 1   /* one lane, variable-id order, MT19937: the reference's own
+                                   trajectory (validation only; slow)                             */
+
+/* The arrays a FactorGraph is constructed from (factorgraph.py:30-37). */
+typedef struct {
+    int64_t nweight, nvar, nfactor, nedge, nvtf, nfactor_index;
+    const nsk_weight *weight;
+    const nsk_variable *variable;
+    const nsk_factor *factor;
+    const nsk_ftv *fmap;
+    const nsk_vtf *vmap;
+    const int64_t *factor_index;
+    int32_t flags;
+    int32_t device;        /* HIP device ordinal                                                  */
+    int64_t own_begin;     /* this handle samples variables [own_begin, own_end); the rest are     */
+    int64_t own_end;       /* ghosts (= the reference's isEvidence==4, inference.py:21-23)         */
+} nsk_graph_desc;
+
+typedef struct nsk_graph nsk_graph;
+
+/* Replaces FactorGraph.__init__'s state setup (factorgraph.py:39-63): validates the graph
+ * (unknown factor functions -> NSK_E_FACTOR_FUNC, out-of-range indices -> NSK_E_INDEX), colours
+ * it, compiles the device layout and uploads it.  State starts as the reference's: values and
+ * evidence-chain values = initialValue, weights = initialValue, counts = 0. */
+int nsk_graph_create(const nsk_graph_desc *desc, nsk_graph **out);
+int nsk_graph_destroy(nsk_graph *g);
+
+/* Host <-> device state sync.  Arrays are the FactorGraph attributes var_value[0],
+ * var_value_evid[0], weight_value[0], count (factorgraph.py:46-53); NULL = leave alone. */
+int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_value_evid,
+                     const double *weight_value, const int64_t *count);
+int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid,
+                       double *weight_value, int64_t *count);
+
+/* RNG: chromatic scan draws from Philox4x32-10 keyed by `seed` with counter
+ * (variable id, stream, sweep index); the sweep index starts at `sweep0` and advances by one per
+ * sweep of any kind.  Sequential scan seeds MT19937 like np.random.seed(seed); random.seed(seed). */
+int nsk_set_seed(nsk_graph *g, uint64_t seed, uint64_t sweep0);
+int nsk_set_scan(nsk_graph *g, int scan);
+
+/* Replaces run_pool(gibbsthread) at factorgraph.py:141 (burnin=1) and :163 (burnin=0):
+ * `nsweeps` epochs of gibbsthread (inference.py:10-33) over the owned variables. */
+int nsk_gibbs_sweeps(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin);
+
+/* Replaces the epoch loop around run_pool(learnthread) at factorgraph.py:194-206: `nsweeps`
+ * epochs of learnthread/sample_and_sgd (learning.py:12-125), step *= decay after each. */
+int nsk_learn_sweeps(nsk_graph *g, int64_t nsweeps, double step, double decay,
+                     int regularization, double reg_param, int64_t truncation,
+                     int learn_non_evidence);
+
+/* Introspection used by tests, bench and the multi-GPU host code. */
+typedef struct {
+    int64_t nvar, nowned, ncolors, value_bytes, device_bytes;
+    int64_t nfast, ngeneric;          /* variables on the inlined / the generic kernel path       */
+    double alg_bytes_inference;       /* algorithmic bytes per sweep       */
+    double alg_bytes_learning;
+    int64_t sweeps_done;
+} nsk_graph_info;
+int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
+int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);
+
+/* Host-only planning (no GPU touched): validate + colour the graph exactly as nsk_graph_create
+ * would and report the colours / sizes.  `color` (nvar entries, may be NULL) gets -1 for variables
+ * this handle does not sample. */
+int nsk_graph_plan(const nsk_graph_desc *desc, int32_t *color, nsk_graph_info *info);
+
+/* HIP-event bracket on the library's stream: elapsed ms and number of sweep-kernel launches
+ * between begin and end (bench.py's roofline leg). */
+int nsk_profile_begin(nsk_graph *g);
+int nsk_profile_end(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches);
+
+/* Multi-GPU plumbing: raw device addresses of the value arrays (element size = value_bytes,
+ * indexed by variable id) so the host can all-gather owned slices with RCCL, and the stream the
+ * library launches on. */
+#define NSK_BUF_VALUE 0
+#define NSK_BUF_VALUE_EVID 1
+#define NSK_BUF_WEIGHT 2
+int nsk_device_buffer(nsk_graph *g, int which, void **ptr, int64_t *nbytes);
+int nsk_set_stream(nsk_graph *g, void *hip_stream);
+int nsk_synchronize(nsk_graph *g);
+
+/* ---- host-side index build and file parsing (no GPU needed) ---- */
+/* dataloading.compute_var_map (dataloading.py:16-81), native and O(edges). */
+int nsk_compute_var_map(int64_t nvar, const nsk_variable *variable, int64_t nfactor,
+                        const nsk_factor *factor, int64_t nedge, const nsk_ftv *fmap,
+                        int64_t nvtf, nsk_vtf *vmap, int64_t nfactor_index, int64_t *factor_index,
+                        const uint8_t *domain_mask, const int64_t *factors_to_skip, int64_t nskip);
+/* dataloading.load_factors (dataloading.py:196-235) on the raw bytes of graph.factors. */
+int nsk_parse_factors(const uint8_t *data, int64_t nbytes, int64_t nfactor, int64_t nedge,
+                      nsk_factor *factor, nsk_ftv *fmap, const uint8_t *domain_mask,
+                      const nsk_variable *variable, int64_t nvar, const nsk_vtf *vmap);
+
+/* Self-test hooks: run the device exp / Philox on caller data (parity tests vs the oracle). */
+int nsk_selftest_exp(int device, const double *x, double *y, int64_t n);
+int nsk_selftest_philox(int device, uint64_t seed, uint64_t sweep, uint32_t stream, int64_t n,
+                        uint32_t *out /* 4*n words, counter c0 = 0..n-1 */);
+
+int nsk_device_count(int *count);
+const char *nsk_last_error(void);
+const char *nsk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

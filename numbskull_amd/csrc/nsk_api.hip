@@ -1,0 +1,761 @@
+// nsk_api.hip -- sweep kernels (gfx950) and the C-ABI entry points of include/numbskull_amd.h.
+//
+// Replaces the callee side of the reference's three run_pool(...) call sites
+// (numbskull/factorgraph.py:141,163,202): gibbsthread (inference.py:10-33) and
+// learnthread/sample_and_sgd (learning.py:12-125).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/numbskull_amd.h"
+#include "nsk_compile.h"
+#include "nsk_device.h"
+
+using namespace nsk;
+
+// =============================================================================================
+// kernels
+// =============================================================================================
+#define NSK_BLOCK 256
+
+// One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
+// gibbsthread's loop body (inference.py:20-33) for that variable.
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_phase(DevGraph<VT> g, int pbegin, int pend,
+                                                           int sample_evidence, int burnin,
+                                                           uint32_t k0, uint32_t k1, uint32_t s0,
+                                                           uint32_t s1) {
+    const int p = pbegin + (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (p >= pend) return;
+    const uint32_t info = g.p_info[p];
+    const int ev = NSK_INFO_EV(info);
+    if (!(ev == 0 || sample_evidence)) return;          // inference.py:24 (ev == 4 never gets a position)
+    const int v = g.p_vid[p];
+    const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));
+    g.val[v] = (VT)nv;
+    if (!burnin) {                                      // inference.py:29-33
+        const int base = g.p_cnt[p];
+        if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
+        else g.cnt[base + nv] += 1;
+    }
+}
+
+// One colour class of one learning sweep: sample_and_sgd (learning.py:46-125) per variable with the
+// weights frozen for the phase; gradients go to the fixed-point accumulators, k_apply_weights
+// turns them into the weight update at the end of the phase (DESIGN.md "device-mode learning").
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_phase(DevGraph<VT> g, int pbegin, int pend,
+                                                           int regularization, double inv_trunc,
+                                                           int learn_non_evidence, uint32_t k0,
+                                                           uint32_t k1, uint32_t s0, uint32_t s1) {
+    const int p = pbegin + (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    bool more = false, truncate = false;
+    int v = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
+    if (p < pend) {
+        const uint32_t info = g.p_info[p];
+        const int ev = NSK_INFO_EV(info);
+        const int slot0 = g.p_slot[p];
+        v = g.p_vid[p];
+        const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+        if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
+        else evidence = (int)g.p_init[p];                                                     // 61-62
+        g.val_evid[v] = (VT)evidence;
+        proposal = draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
+        g.val[v] = (VT)proposal;
+        if (learn_non_evidence || ev == 1) {                                                  // 71-72
+            if (regularization == 1) {                                                        // 90
+                const u32x4 t = philox4x32(k0, k1, (uint32_t)v, 1u, s0, s1);
+                truncate = u53(t.x, t.y) < inv_trunc;
+            }
+            const int step = NSK_INFO_DT1(info);
+            a = g.slot_off[slot0 + step * evidence];
+            ae = g.slot_off[slot0 + step * evidence + 1];
+            if (step && evidence != proposal) {
+                b = g.slot_off[slot0 + proposal];
+                be = g.slot_off[slot0 + proposal + 1];
+            }
+            more = (a < ae) || (b < be);
+        }
+    }
+    // union of the two sorted-unique lists (learning.py:76-95), one factor per iteration; the loop
+    // is wave-uniform so that accumulate_gradient can reduce across the wave
+    while (__ballot(more)) {
+        bool have = false;
+        int wid = 0;
+        long long gfix = 0;
+        if (more) {
+            const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
+            const int fb = b < be ? g.fidx[b] : 0x7fffffff;
+            const int fid = fa < fb ? fa : fb;
+            if (fa == fid) a++;
+            if (fb == fid) b++;
+            more = (a < ae) || (b < be);
+            wid = g.f_wid[fid];
+            if (!g.w_fixed[wid]) {                                                            // 100-101
+                const double p0 = eval_factor(g, fid, v, evidence, g.val_evid);
+                const double p1 = eval_factor(g, fid, v, proposal, g.val);
+                const double gradient = (p1 - p0) * g.f_feat[fid];                            // 109
+                gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
+                have = true;
+            }
+        }
+        accumulate_gradient(g, have, wid, gfix, truncate);
+    }
+}
+
+// End of a learning phase: fold the accumulated visits of every weight into its value
+// (learning.py:110-125 applied to the batch; DESIGN.md gives the closed forms).
+__global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
+                                                             uint32_t *T, int nweight, double step,
+                                                             int regularization, double reg_param,
+                                                             double truncation) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i >= nweight) return;
+    const uint32_t k = K[i];
+    if (k == 0) return;
+    const double Gf = (double)G[i] * (1.0 / 4294967296.0);
+    double x = w[i];
+    if (regularization == 2) {
+        const double a = 1.0 / (1.0 + reg_param * step);
+        x = powi_det(a, (unsigned long long)k) * x;
+        x = x - step * Gf;
+    } else if (regularization == 1) {
+        x = x - step * Gf;
+        const uint32_t t = T[i];
+        if (t > 0) {
+            const double l1 = (reg_param * step * truncation) * (double)t;
+            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
+        }
+    } else {
+        x = x - step * Gf;
+    }
+    w[i] = x;
+    G[i] = 0; K[i] = 0; T[i] = 0;
+}
+
+// int32 per-call tally deltas -> int64 master copy (the host-visible `count`)
+__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts(int32_t *delta, long long *total, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i >= n) return;
+    total[i] += (long long)delta[i];
+    delta[i] = 0;
+}
+
+__global__ void k_selftest_exp(const double *x, double *y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = nsk_exp(x[i]);
+}
+
+__global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t s0, uint32_t s1,
+                                  long long n, uint32_t *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32x4 r = philox4x32(k0, k1, (uint32_t)i, stream, s0, s1);
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+// ---- sequential validation scan: one lane walks variable ids in order with MT19937 -----------
+template <typename VT>
+__global__ void k_seq_gibbs(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rng, int nsweeps,
+                            int sample_evidence, int burnin) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int s = 0; s < nsweeps; s++) {
+        for (int v = 0; v < g.nvar; v++) {
+            const int p = v_pos[v];
+            if (p < 0) continue;
+            const uint32_t info = g.p_info[p];
+            if (!(NSK_INFO_EV(info) == 0 || sample_evidence)) continue;
+            // the reference fills Z first and draws its uniform afterwards; draw_sample only needs
+            // u at the very end, and nothing else consumes the stream in between
+            const double u = mt_res53(np_rng);
+            const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u);
+            g.val[v] = (VT)nv;
+            if (!burnin) {
+                const int base = g.p_cnt[p];
+                if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
+                else g.cnt[base + nv] += 1;
+            }
+        }
+    }
+}
+
+template <typename VT>
+__global__ void k_seq_learn(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rng, MTState *py_rng,
+                            int nsweeps, double step, double decay, int regularization,
+                            double reg_param, double truncation, int learn_non_evidence) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int s = 0; s < nsweeps; s++) {
+        for (int v = 0; v < g.nvar; v++) {
+            const int p = v_pos[v];
+            if (p < 0) continue;
+            const uint32_t info = g.p_info[p];
+            const int ev = NSK_INFO_EV(info);
+            const int slot0 = g.p_slot[p];
+            int evidence;
+            if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, mt_res53(np_rng));
+            else evidence = (int)g.p_init[p];
+            g.val_evid[v] = (VT)evidence;
+            const int proposal = draw_sample(g, v, info, slot0, g.val, mt_res53(np_rng));
+            g.val[v] = (VT)proposal;
+            if (!learn_non_evidence && ev != 1) continue;
+            const int st = NSK_INFO_DT1(info);
+            int a = g.slot_off[slot0 + st * evidence], ae = g.slot_off[slot0 + st * evidence + 1];
+            int b = 0, be = 0;
+            if (st && evidence != proposal) {
+                b = g.slot_off[slot0 + proposal];
+                be = g.slot_off[slot0 + proposal + 1];
+            }
+            bool truncate = false;
+            if (regularization == 1) truncate = mt_res53(py_rng) < 1.0 / truncation;
+            while (a < ae || b < be) {          // sorted, de-duplicated union == learning.py:76-98
+                const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
+                const int fb = b < be ? g.fidx[b] : 0x7fffffff;
+                const int fid = fa < fb ? fa : fb;
+                if (fa == fid) a++;
+                if (fb == fid) b++;
+                const int wid = g.f_wid[fid];
+                if (g.w_fixed[wid]) continue;
+                const double p0 = eval_factor(g, fid, v, evidence, g.val_evid);
+                const double p1 = eval_factor(g, fid, v, proposal, g.val);
+                const double gradient = (p1 - p0) * g.f_feat[fid];
+                double w = g.w[wid];
+                if (regularization == 2) {
+                    w *= (1.0 / (1.0 + reg_param * step));
+                    w -= step * gradient;
+                } else if (regularization == 1) {
+                    w -= step * gradient;
+                    if (truncate) {
+                        const double l1delta = reg_param * step * truncation;
+                        w = (w > 0) ? fmax(0.0, w - l1delta) : fmin(0.0, w + l1delta);
+                    }
+                } else {
+                    w -= step * gradient;
+                }
+                g.w[wid] = w;
+            }
+        }
+        step *= decay;
+    }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+namespace nsk { void set_error(const std::string &m) { g_err = m; } }
+
+#define HIPCHECK(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(NSK_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+struct nsk_graph {
+    Compiled c;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<void *> allocs;
+    int64_t device_bytes = 0;
+    // device arrays
+    int32_t *p_vid = nullptr, *p_slot = nullptr, *p_cnt = nullptr, *slot_off = nullptr, *fidx = nullptr;
+    uint32_t *p_info = nullptr, *f_head = nullptr;
+    void *p_init = nullptr;
+    int32_t *f_off = nullptr, *f_wid = nullptr, *m_vid = nullptr, *m_deo = nullptr, *v_card = nullptr,
+            *v_pos = nullptr;
+    double *f_feat = nullptr, *w = nullptr, *logtab = nullptr;
+    uint8_t *w_fixed = nullptr;
+    void *val = nullptr, *val_evid = nullptr;
+    int32_t *cnt = nullptr;
+    long long *cnt_total = nullptr, *G = nullptr;
+    uint32_t *K = nullptr, *T = nullptr;
+    MTState *mt_np = nullptr, *mt_py = nullptr;
+    // run state
+    uint64_t seed = 0, sweep = 0;
+    int scan = NSK_SCAN_CHROMATIC;
+    bool cnt_dirty = false;
+    int64_t sweeps_done = 0;
+    // profiling bracket
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t launches = 0, launches_at_begin = 0;
+};
+
+template <typename T>
+static int dev_alloc(nsk_graph *g, T **ptr, size_t n) {
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(NSK_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    g->allocs.push_back(p);
+    g->device_bytes += (int64_t)bytes;
+    *ptr = (T *)p;
+    return NSK_OK;
+}
+
+template <typename T>
+static int dev_upload(nsk_graph *g, T **ptr, const std::vector<T> &h) {
+    int rc = dev_alloc(g, ptr, h.size());
+    if (rc) return rc;
+    if (!h.empty()) HIPCHECK(hipMemcpyAsync(*ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, g->stream));
+    return NSK_OK;
+}
+
+// narrow int32 host values to the device value type (int8 / int32) and upload
+static int upload_values(nsk_graph *g, void *dst, const int32_t *src, size_t n) {
+    if (g->c.vbytes == 4) {
+        if (n) HIPCHECK(hipMemcpyAsync(dst, src, n * 4, hipMemcpyHostToDevice, g->stream));
+        HIPCHECK(hipStreamSynchronize(g->stream));
+        return NSK_OK;
+    }
+    std::vector<int8_t> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = (int8_t)src[i];
+    if (n) HIPCHECK(hipMemcpyAsync(dst, tmp.data(), n, hipMemcpyHostToDevice, g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    return NSK_OK;
+}
+
+static void mt_seed_numpy(MTState &s, uint32_t seed) {      // np.random.seed(int): init_genrand
+    s.mt[0] = seed;
+    for (int i = 1; i < 624; i++) s.mt[i] = 1812433253u * (s.mt[i - 1] ^ (s.mt[i - 1] >> 30)) + (uint32_t)i;
+    s.idx = 624;
+}
+
+static void mt_seed_python(MTState &s, uint64_t seed) {     // random.seed(int): init_by_array
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    int keylen = key[1] ? 2 : 1;
+    mt_seed_numpy(s, 19650218u);
+    int i = 1, j = 0;
+    for (int k = 624; k; k--) {
+        s.mt[i] = (s.mt[i] ^ ((s.mt[i - 1] ^ (s.mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { s.mt[0] = s.mt[623]; i = 1; }
+        if (j >= keylen) j = 0;
+    }
+    for (int k = 623; k; k--) {
+        s.mt[i] = (s.mt[i] ^ ((s.mt[i - 1] ^ (s.mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { s.mt[0] = s.mt[623]; i = 1; }
+    }
+    s.mt[0] = 0x80000000u;
+    s.idx = 624;
+}
+
+template <typename VT>
+static DevGraph<VT> view(nsk_graph *g) {
+    DevGraph<VT> d;
+    d.p_vid = g->p_vid; d.p_info = g->p_info; d.p_slot = g->p_slot; d.p_cnt = g->p_cnt;
+    d.p_init = (const VT *)g->p_init;
+    d.slot_off = g->slot_off; d.fidx = g->fidx;
+    d.f_head = g->f_head; d.f_off = g->f_off; d.f_wid = g->f_wid; d.f_feat = g->f_feat;
+    d.m_vid = g->m_vid; d.m_deo = g->m_deo; d.v_card = g->v_card;
+    d.w = g->w; d.w_fixed = g->w_fixed; d.logtab = g->logtab;
+    d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
+    d.G = g->G; d.K = g->K; d.T = g->T;
+    d.nvar = (int32_t)g->c.nvar;
+    d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
+    return d;
+}
+
+extern "C" {
+
+const char *nsk_last_error(void) { return g_err.c_str(); }
+const char *nsk_version(void) { return "numbskull_amd 0.1.1 (gfx950)"; }
+
+int nsk_device_count(int *count) {
+    if (!count) return fail(NSK_E_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(NSK_E_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    return NSK_OK;
+}
+
+int nsk_graph_destroy(nsk_graph *g) {
+    if (!g) return NSK_OK;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (void *p : g->allocs) (void)hipFree(p);
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    return NSK_OK;
+}
+
+static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
+    std::string err;
+    int rc = compile_graph(desc, g->c, err);
+    if (rc) return fail(rc, err);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(NSK_E_DEVICE, "no HIP device available: the Gibbs sweep runs on the GPU only "
+                                  "(there is no CPU fallback)");
+    if (desc->device < 0 || desc->device >= ndev) return fail(NSK_E_INVALID, "device ordinal out of range");
+    g->device = desc->device;
+    HIPCHECK(hipSetDevice(g->device));
+    HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    g->own_stream = true;
+    HIPCHECK(hipEventCreate(&g->ev0));
+    HIPCHECK(hipEventCreate(&g->ev1));
+    Compiled &c = g->c;
+#define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
+    UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
+    UP(f_head); UP(f_off); UP(f_wid); UP(f_feat); UP(m_vid); UP(m_deo); UP(v_card); UP(v_pos);
+    UP(w_fixed); UP(logtab);
+#undef UP
+    rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
+    const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
+    uint8_t *tmp = nullptr;
+    rc = dev_alloc(g, &tmp, npos * vb); if (rc) return rc; g->p_init = tmp;
+    rc = dev_alloc(g, &tmp, nvar * vb); if (rc) return rc; g->val = tmp;
+    rc = dev_alloc(g, &tmp, nvar * vb); if (rc) return rc; g->val_evid = tmp;
+    rc = upload_values(g, g->p_init, c.p_init.data(), npos); if (rc) return rc;
+    rc = upload_values(g, g->val, c.v_init.data(), nvar); if (rc) return rc;
+    rc = upload_values(g, g->val_evid, c.v_init.data(), nvar); if (rc) return rc;
+    rc = dev_alloc(g, &g->cnt, (size_t)c.ncount); if (rc) return rc;
+    rc = dev_alloc(g, &g->cnt_total, (size_t)c.ncount); if (rc) return rc;
+    rc = dev_alloc(g, &g->G, (size_t)c.nweight); if (rc) return rc;
+    rc = dev_alloc(g, &g->K, (size_t)c.nweight); if (rc) return rc;
+    rc = dev_alloc(g, &g->T, (size_t)c.nweight); if (rc) return rc;
+    rc = dev_alloc(g, &g->mt_np, 1); if (rc) return rc;
+    rc = dev_alloc(g, &g->mt_py, 1); if (rc) return rc;
+    HIPCHECK(hipMemsetAsync(g->cnt, 0, (c.ncount ? c.ncount : 1) * sizeof(int32_t), g->stream));
+    HIPCHECK(hipMemsetAsync(g->cnt_total, 0, (c.ncount ? c.ncount : 1) * sizeof(long long), g->stream));
+    HIPCHECK(hipMemsetAsync(g->G, 0, (c.nweight ? c.nweight : 1) * sizeof(long long), g->stream));
+    HIPCHECK(hipMemsetAsync(g->K, 0, (c.nweight ? c.nweight : 1) * sizeof(uint32_t), g->stream));
+    HIPCHECK(hipMemsetAsync(g->T, 0, (c.nweight ? c.nweight : 1) * sizeof(uint32_t), g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    return nsk_set_seed(g, 0, 0);
+}
+
+int nsk_graph_create(const nsk_graph_desc *desc, nsk_graph **out) {
+    if (!desc || !out) return fail(NSK_E_INVALID, "null argument");
+    *out = nullptr;
+    nsk_graph *g = new nsk_graph();
+    int rc = create_impl(desc, g);
+    if (rc) {
+        std::string keep = g_err;
+        nsk_graph_destroy(g);
+        g_err = keep;
+        return rc;
+    }
+    *out = g;
+    return NSK_OK;
+}
+
+int nsk_set_seed(nsk_graph *g, uint64_t seed, uint64_t sweep0) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    g->seed = seed;
+    g->sweep = sweep0;
+    MTState a, b;
+    mt_seed_numpy(a, (uint32_t)seed);
+    mt_seed_python(b, seed);
+    HIPCHECK(hipMemcpyAsync(g->mt_np, &a, sizeof(MTState), hipMemcpyHostToDevice, g->stream));
+    HIPCHECK(hipMemcpyAsync(g->mt_py, &b, sizeof(MTState), hipMemcpyHostToDevice, g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    return NSK_OK;
+}
+
+int nsk_set_scan(nsk_graph *g, int scan) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (scan != NSK_SCAN_CHROMATIC && scan != NSK_SCAN_SEQUENTIAL) return fail(NSK_E_INVALID, "unknown scan order");
+    if (scan == NSK_SCAN_SEQUENTIAL && (g->c.own_begin != 0 || g->c.own_end != g->c.nvar))
+        return fail(NSK_E_INVALID, "sequential scan needs the whole graph on one handle");
+    g->scan = scan;
+    return NSK_OK;
+}
+
+int nsk_set_stream(nsk_graph *g, void *hip_stream) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    if (g->own_stream) { HIPCHECK(hipStreamDestroy(g->stream)); g->own_stream = false; }
+    g->stream = (hipStream_t)hip_stream;
+    return NSK_OK;
+}
+
+int nsk_synchronize(nsk_graph *g) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    return NSK_OK;
+}
+
+static int fold_counts(nsk_graph *g) {
+    if (!g->cnt_dirty) return NSK_OK;
+    const int n = (int)g->c.ncount;
+    if (n > 0)
+        k_fold_counts<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+            g->cnt, g->cnt_total, n);
+    HIPCHECK(hipGetLastError());
+    g->cnt_dirty = false;
+    return NSK_OK;
+}
+
+}  // extern "C"
+
+template <typename VT>
+static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
+    DevGraph<VT> d = view<VT>(g);
+    if (g->scan == NSK_SCAN_SEQUENTIAL) {
+        k_seq_gibbs<VT><<<dim3(1), dim3(64), 0, g->stream>>>(d, g->v_pos, g->mt_np, (int)nsweeps,
+                                                            sample_evidence, burnin);
+        HIPCHECK(hipGetLastError());
+        g->launches++;
+        g->sweep += (uint64_t)nsweeps;
+    } else {
+        const size_t nphase = g->c.phase_start.size() - 1;
+        for (int64_t s = 0; s < nsweeps; s++) {
+            for (size_t ph = 0; ph < nphase; ph++) {
+                const int b = (int)g->c.phase_start[ph], e = (int)g->c.phase_start[ph + 1];
+                if (e <= b) continue;
+                k_gibbs_phase<VT><<<dim3((e - b + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                    d, b, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                    (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                g->launches++;
+            }
+            g->sweep++;
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    if (!burnin) g->cnt_dirty = true;
+    g->sweeps_done += nsweeps;
+    return NSK_OK;
+}
+
+extern "C" int nsk_gibbs_sweeps(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
+    if (nsweeps == 0) return NSK_OK;
+    HIPCHECK(hipSetDevice(g->device));
+    return g->c.vbytes == 1 ? gibbs_impl<int8_t>(g, nsweeps, sample_evidence, burnin)
+                            : gibbs_impl<int32_t>(g, nsweeps, sample_evidence, burnin);
+}
+
+template <typename VT>
+static int learn_impl(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                      double reg_param, int64_t truncation, int learn_non_evidence) {
+    DevGraph<VT> d = view<VT>(g);
+    if (g->scan == NSK_SCAN_SEQUENTIAL) {
+        k_seq_learn<VT><<<dim3(1), dim3(64), 0, g->stream>>>(d, g->v_pos, g->mt_np, g->mt_py, (int)nsweeps,
+                                                            step, decay, regularization, reg_param,
+                                                            (double)truncation, learn_non_evidence);
+        HIPCHECK(hipGetLastError());
+        g->launches++;
+        g->sweep += (uint64_t)nsweeps;
+    } else {
+        const size_t nphase = g->c.phase_start.size() - 1;
+        const int nw = (int)g->c.nweight;
+        for (int64_t s = 0; s < nsweeps; s++) {
+            for (size_t ph = 0; ph < nphase; ph++) {
+                const int b = (int)g->c.phase_start[ph], e = (int)g->c.phase_start[ph + 1];
+                if (e <= b) continue;
+                k_learn_phase<VT><<<dim3((e - b + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                    d, b, e, regularization, 1.0 / (double)truncation, learn_non_evidence,
+                    (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep,
+                    (uint32_t)(g->sweep >> 32));
+                g->launches++;
+                if (nw > 0)
+                    k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation);
+            }
+            g->sweep++;
+            step *= decay;                                   // factorgraph.py:206
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    g->sweeps_done += nsweeps;
+    return NSK_OK;
+}
+
+extern "C" {
+
+int nsk_learn_sweeps(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                     double reg_param, int64_t truncation, int learn_non_evidence) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
+    if (regularization == 1 && truncation == 0) return fail(NSK_E_INVALID, "truncation must be non-zero (ZeroDivisionError in the reference)");
+    if (nsweeps == 0) return NSK_OK;
+    HIPCHECK(hipSetDevice(g->device));
+    return g->c.vbytes == 1
+               ? learn_impl<int8_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence)
+               : learn_impl<int32_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence);
+}
+
+int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_value_evid,
+                     const double *weight_value, const int64_t *count) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    const size_t nvar = (size_t)g->c.nvar;
+    const int64_t lo = g->c.vbytes == 1 ? -128 : INT32_MIN, hi = g->c.vbytes == 1 ? 127 : INT32_MAX;
+    const int64_t *srcs[2] = {var_value, var_value_evid};
+    void *dsts[2] = {g->val, g->val_evid};
+    std::vector<int32_t> tmp;
+    for (int k = 0; k < 2; k++) {
+        if (!srcs[k]) continue;
+        tmp.resize(nvar);
+        for (size_t i = 0; i < nvar; i++) {
+            if (srcs[k][i] < lo || srcs[k][i] > hi)
+                return fail(NSK_E_RANGE, "variable value does not fit the device value type");
+            tmp[i] = (int32_t)srcs[k][i];
+        }
+        int rc = upload_values(g, dsts[k], tmp.data(), nvar);
+        if (rc) return rc;
+    }
+    if (weight_value && g->c.nweight)
+        HIPCHECK(hipMemcpyAsync(g->w, weight_value, (size_t)g->c.nweight * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    if (count && g->c.ncount) {
+        HIPCHECK(hipMemcpyAsync(g->cnt_total, count, (size_t)g->c.ncount * sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
+        HIPCHECK(hipMemsetAsync(g->cnt, 0, (size_t)g->c.ncount * sizeof(int32_t), g->stream));
+        g->cnt_dirty = false;
+    }
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    return NSK_OK;
+}
+
+static int download_values(nsk_graph *g, const void *src, int64_t *dst) {
+    const size_t nvar = (size_t)g->c.nvar;
+    if (g->c.vbytes == 1) {
+        std::vector<int8_t> tmp(nvar);
+        if (nvar) HIPCHECK(hipMemcpyAsync(tmp.data(), src, nvar, hipMemcpyDeviceToHost, g->stream));
+        HIPCHECK(hipStreamSynchronize(g->stream));
+        for (size_t i = 0; i < nvar; i++) dst[i] = tmp[i];
+    } else {
+        std::vector<int32_t> tmp(nvar);
+        if (nvar) HIPCHECK(hipMemcpyAsync(tmp.data(), src, nvar * 4, hipMemcpyDeviceToHost, g->stream));
+        HIPCHECK(hipStreamSynchronize(g->stream));
+        for (size_t i = 0; i < nvar; i++) dst[i] = tmp[i];
+    }
+    return NSK_OK;
+}
+
+int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid, double *weight_value,
+                       int64_t *count) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    int rc;
+    if (var_value && (rc = download_values(g, g->val, var_value))) return rc;
+    if (var_value_evid && (rc = download_values(g, g->val_evid, var_value_evid))) return rc;
+    if (weight_value && g->c.nweight)
+        HIPCHECK(hipMemcpyAsync(weight_value, g->w, (size_t)g->c.nweight * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    if (count) {
+        if ((rc = fold_counts(g))) return rc;
+        if (g->c.ncount)
+            HIPCHECK(hipMemcpyAsync(count, g->cnt_total, (size_t)g->c.ncount * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+    }
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    return NSK_OK;
+}
+
+static void fill_info(const Compiled &c, nsk_graph_info *info) {
+    info->nvar = c.nvar;
+    info->nowned = c.npos;
+    info->ncolors = (int64_t)c.phase_start.size() - 1;
+    info->value_bytes = c.vbytes;
+    info->device_bytes = 0;
+    info->nfast = 0;
+    info->ngeneric = c.npos;
+    info->alg_bytes_inference = c.alg_bytes_inference;
+    info->alg_bytes_learning = c.alg_bytes_learning;
+    info->sweeps_done = 0;
+}
+
+int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
+    if (!g || !info) return fail(NSK_E_INVALID, "null argument");
+    fill_info(g->c, info);
+    info->device_bytes = g->device_bytes;
+    info->sweeps_done = g->sweeps_done;
+    return NSK_OK;
+}
+
+int nsk_graph_plan(const nsk_graph_desc *desc, int32_t *color, nsk_graph_info *info) {
+    if (!desc) return fail(NSK_E_INVALID, "null argument");
+    Compiled c;
+    std::string err;
+    int rc = compile_graph(desc, c, err);
+    if (rc) return fail(rc, err);
+    if (color && c.nvar) memcpy(color, c.color.data(), (size_t)c.nvar * sizeof(int32_t));
+    if (info) fill_info(c, info);
+    return NSK_OK;
+}
+
+int nsk_graph_get_colors(nsk_graph *g, int32_t *color) {
+    if (!g || !color) return fail(NSK_E_INVALID, "null argument");
+    if (g->c.nvar) memcpy(color, g->c.color.data(), (size_t)g->c.nvar * sizeof(int32_t));
+    return NSK_OK;
+}
+
+int nsk_profile_begin(nsk_graph *g) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    g->launches_at_begin = g->launches;
+    HIPCHECK(hipEventRecord(g->ev0, g->stream));
+    return NSK_OK;
+}
+
+int nsk_profile_end(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    HIPCHECK(hipEventRecord(g->ev1, g->stream));
+    HIPCHECK(hipEventSynchronize(g->ev1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    if (elapsed_ms) *elapsed_ms = (double)ms;
+    if (kernel_launches) *kernel_launches = g->launches - g->launches_at_begin;
+    return NSK_OK;
+}
+
+int nsk_device_buffer(nsk_graph *g, int which, void **ptr, int64_t *nbytes) {
+    if (!g || !ptr) return fail(NSK_E_INVALID, "null argument");
+    switch (which) {
+    case NSK_BUF_VALUE: *ptr = g->val; if (nbytes) *nbytes = g->c.nvar * g->c.vbytes; return NSK_OK;
+    case NSK_BUF_VALUE_EVID: *ptr = g->val_evid; if (nbytes) *nbytes = g->c.nvar * g->c.vbytes; return NSK_OK;
+    case NSK_BUF_WEIGHT: *ptr = g->w; if (nbytes) *nbytes = g->c.nweight * 8; return NSK_OK;
+    default: return fail(NSK_E_INVALID, "unknown buffer id");
+    }
+}
+
+int nsk_selftest_exp(int device, const double *x, double *y, int64_t n) {
+    if (n < 0 || (n && (!x || !y))) return fail(NSK_E_INVALID, "bad argument");
+    if (n == 0) return NSK_OK;
+    HIPCHECK(hipSetDevice(device));
+    double *dx = nullptr, *dy = nullptr;
+    HIPCHECK(hipMalloc((void **)&dx, n * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dy, n * sizeof(double)));
+    HIPCHECK(hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice));
+    k_selftest_exp<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(dx, dy, n);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpy(y, dy, n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy);
+    return NSK_OK;
+}
+
+int nsk_selftest_philox(int device, uint64_t seed, uint64_t sweep, uint32_t stream, int64_t n,
+                        uint32_t *out) {
+    if (n < 0 || (n && !out)) return fail(NSK_E_INVALID, "bad argument");
+    if (n == 0) return NSK_OK;
+    HIPCHECK(hipSetDevice(device));
+    uint32_t *d = nullptr;
+    HIPCHECK(hipMalloc((void **)&d, 4 * n * sizeof(uint32_t)));
+    k_selftest_philox<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(
+        (uint32_t)seed, (uint32_t)(seed >> 32), stream, (uint32_t)sweep, (uint32_t)(sweep >> 32), n, d);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpy(out, d, 4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return NSK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// nsk_compile.cpp -- validate + colour + lay out a factor graph for the device.
+//
+// Input: the arrays a reference FactorGraph is built from (factorgraph.py:30-37) in their packed
+// numpy layouts.  Output: the SoA device layout of DESIGN.md.  Nothing here runs per sweep.
+#include "nsk_compile.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace nsk {
+
+bool known_function(int fn) {
+    switch (fn) {
+    case -1: case 0: case 1: case 2: case 3: case 4: case 7: case 8: case 9:
+    case 12: case 13: case 14: case 15: case 16: case 17:
+    case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26:
+    case 30:
+        return true;
+    default:
+        return false;
+    }
+}
+
+static bool is_cat_function(int fn) { return fn == 12 || (fn >= 14 && fn <= 17); }
+static bool literal_head_function(int fn) { return fn == 13 || fn == 16 || fn == 17; }
+
+static std::string fmt(const char *f, long long a = 0, long long b = 0, long long c = 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), f, a, b, c);
+    return std::string(buf);
+}
+
+int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
+    const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
+    const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
+    const int64_t LIM = (int64_t)1 << 31;
+    if (nvar < 0 || nfac < 0 || nedge < 0 || nw < 0 || nvtf < 0 || nfi < 0) {
+        err = "negative size in graph descriptor";
+        return NSK_E_INVALID;
+    }
+    if (nvar >= LIM - 1 || nfac >= LIM - 1 || nedge >= LIM - 1 || nw >= LIM - 1 || nfi >= LIM - 1 ||
+        nvtf >= LIM - 1) {
+        err = "graph too large for 32-bit device indices";
+        return NSK_E_RANGE;
+    }
+    if ((nvar && !d->variable) || (nfac && !d->factor) || (nedge && !d->fmap) || (nw && !d->weight) ||
+        (nvtf && !d->vmap) || (nfi && !d->factor_index)) {
+        err = "null array in graph descriptor";
+        return NSK_E_INVALID;
+    }
+    c.nvar = nvar; c.nfactor = nfac; c.nedge = nedge; c.nweight = nw; c.flags = d->flags;
+    int64_t ob = d->own_begin, oe = d->own_end;
+    if (ob == 0 && oe == 0) oe = nvar;
+    if (ob < 0 || oe > nvar || ob > oe) {
+        err = "owned range outside [0, nvar]";
+        return NSK_E_INVALID;
+    }
+    c.own_begin = ob; c.own_end = oe;
+    const bool head_by_vid = (d->flags & NSK_FLAG_HEAD_BY_VID) != 0;
+
+    // ---- variables ---------------------------------------------------------------------------
+    c.v_card.resize(nvar); c.v_init.resize(nvar); c.cstart.resize(nvar + 1);
+    int64_t maxcard = 1, minval = 0, maxval = 0, cs = 0;
+    for (int64_t v = 0; v < nvar; v++) {
+        const nsk_variable &var = d->variable[v];
+        if (var.cardinality < 1 || var.cardinality >= ((int64_t)1 << 22)) {
+            err = fmt("variable %lld: cardinality %lld not in [1, 2^22)", v, var.cardinality);
+            return NSK_E_RANGE;
+        }
+        int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+        if (var.vtf_offset < 0 || var.vtf_offset + nslots > nvtf) {
+            err = fmt("variable %lld: vtf_offset %lld outside vmap", v, var.vtf_offset);
+            return NSK_E_INDEX;
+        }
+        if (var.initialValue < INT32_MIN || var.initialValue > INT32_MAX) {
+            err = fmt("variable %lld: initialValue does not fit int32", v);
+            return NSK_E_RANGE;
+        }
+        c.v_card[v] = (int32_t)var.cardinality;
+        c.v_init[v] = (int32_t)var.initialValue;
+        maxcard = std::max(maxcard, var.cardinality);
+        minval = std::min(minval, var.initialValue);
+        maxval = std::max(maxval, var.initialValue);
+        c.cstart[v] = cs;
+        cs += var.cardinality == 2 ? 1 : var.cardinality;      // factorgraph.py:41-45
+    }
+    c.cstart[nvar] = cs;
+    if (cs >= LIM - 1) {
+        err = "tally array too large for 32-bit device indices";
+        return NSK_E_RANGE;
+    }
+    c.ncount = cs;
+    c.vbytes = (maxcard <= 127 && minval >= -128 && maxval <= 127) ? 1 : 4;
+
+    // ---- weights -----------------------------------------------------------------------------
+    c.w_init.resize(nw); c.w_fixed.resize(nw);
+    for (int64_t i = 0; i < nw; i++) {
+        c.w_init[i] = d->weight[i].initialValue;
+        c.w_fixed[i] = d->weight[i].isFixed ? 1 : 0;
+    }
+
+    // ---- factors and edges: narrow copies; validated lazily for factors that are reachable ----
+    c.f_head.resize(nfac); c.f_off.resize(nfac); c.f_wid.resize(nfac); c.f_feat.resize(nfac);
+    for (int64_t f = 0; f < nfac; f++) {
+        const nsk_factor &fa = d->factor[f];
+        int64_t ar = fa.arity;
+        if (ar < 0) ar = 0;
+        if (ar >= ((int64_t)1 << 24)) {
+            err = fmt("factor %lld: arity %lld too large", f, fa.arity);
+            return NSK_E_RANGE;
+        }
+        c.f_head[f] = ((uint32_t)ar << 8) | (uint32_t)((fa.factorFunction + 1) & 0xff);
+        c.f_off[f] = (int32_t)std::max<int64_t>(std::min<int64_t>(fa.ftv_offset, LIM - 2), -1);
+        c.f_wid[f] = (int32_t)std::max<int64_t>(std::min<int64_t>(fa.weightId, LIM - 2), -1);
+        c.f_feat[f] = fa.featureValue;
+    }
+    c.m_vid.resize(nedge); c.m_deo.resize(nedge);
+    for (int64_t l = 0; l < nedge; l++) {
+        int64_t vid = d->fmap[l].vid, deo = d->fmap[l].dense_equal_to;
+        c.m_vid[l] = (vid < 0 || vid >= nvar) ? -1 : (int32_t)vid;
+        c.m_deo[l] = (int32_t)std::max<int64_t>(std::min<int64_t>(deo, INT32_MAX), INT32_MIN);
+    }
+
+    // ---- which variables does this handle sample? -------------------------------------------
+    std::vector<uint8_t> sampled(nvar, 0);
+    for (int64_t v = ob; v < oe; v++) sampled[v] = d->variable[v].isEvidence != 4;   // inference.py:21-23
+
+    // ---- validate every factor reachable from a sampled variable ------------------------------
+    std::vector<uint8_t> checked(nfac, 0);
+    int64_t max_ratio_arity = 0;
+    auto check_factor = [&](int64_t f) -> int {
+        if (checked[f]) return NSK_OK;
+        checked[f] = 1;
+        const nsk_factor &fa = d->factor[f];
+        const int fn = fa.factorFunction;
+        if (!known_function(fn)) {
+            err = fmt("Factor function %lld (used in factor %lld) is not implemented.", fn, f);
+            return NSK_E_FACTOR_FUNC;
+        }
+        if (fn == -1) return NSK_OK;
+        const int64_t s = fa.ftv_offset, e = fa.ftv_offset + fa.arity;
+        if (fa.arity < 0 || s < 0 || e > nedge) {
+            err = fmt("factor %lld: members [%lld, %lld) outside fmap", f, s, e);
+            return NSK_E_INDEX;
+        }
+        if (fa.weightId < 0 || fa.weightId >= nw) {
+            err = fmt("factor %lld: weightId %lld outside weights", f, fa.weightId);
+            return NSK_E_INDEX;
+        }
+        int64_t need = 0;       // member positions the function reads regardless of arity
+        switch (fn) {
+        case 3: need = 1; break;
+        case 0: case 7: case 8: case 9: case 13: case 16: case 17:
+            if (fa.arity < 1) { err = fmt("factor %lld: function %lld needs arity >= 1", f, fn); return NSK_E_INDEX; }
+            break;
+        case 18: case 19: case 20: case 30: need = 1; break;
+        case 21: case 22: case 25: case 26: need = 2; break;
+        case 23: case 24: need = 3; break;
+        default: break;
+        }
+        const int64_t last = std::max(e, s + need);
+        if (s + need > nedge) {
+            err = fmt("factor %lld: function %lld reads member %lld beyond fmap", f, fn, s + need - 1);
+            return NSK_E_INDEX;
+        }
+        for (int64_t l = s; l < last; l++) {
+            if (d->fmap[l].vid < 0 || d->fmap[l].vid >= nvar) {
+                err = fmt("factor %lld: member variable %lld outside variables", f, d->fmap[l].vid);
+                return NSK_E_INDEX;
+            }
+        }
+        if (fn == 30) {   // UFO reads member (value of first member) - 1
+            int64_t reach = s + d->variable[d->fmap[s].vid].cardinality - 2;
+            if (reach >= nedge) { err = fmt("factor %lld: UFO member index beyond fmap", f); return NSK_E_INDEX; }
+            for (int64_t l = s; l <= reach; l++)
+                if (d->fmap[l].vid < 0 || d->fmap[l].vid >= nvar) {
+                    err = fmt("factor %lld: member variable outside variables", f);
+                    return NSK_E_INDEX;
+                }
+        }
+        if (literal_head_function(fn) && !head_by_vid && e - 1 >= nvar) {
+            err = fmt("factor %lld: the reference reads var_value[%lld] for the head of function %lld "
+                      "(inference.py:243,277,292), outside the variable array; pass NSK_FLAG_HEAD_BY_VID "
+                      "for the fmap[l].vid lookup", f, e - 1, fn);
+            return NSK_E_INDEX;
+        }
+        if (fn == 8) max_ratio_arity = std::max(max_ratio_arity, fa.arity);
+        return NSK_OK;
+    };
+
+    for (int64_t v = 0; v < nvar; v++) {
+        if (!sampled[v]) continue;
+        const nsk_variable &var = d->variable[v];
+        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+        for (int64_t k = 0; k < nslots; k++) {
+            const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+            if (vt.factor_index_length < 0 || vt.factor_index_offset < 0 ||
+                vt.factor_index_offset + vt.factor_index_length > nfi) {
+                err = fmt("variable %lld: factor list outside factor_index", v);
+                return NSK_E_INDEX;
+            }
+            for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                if (f < 0 || f >= nfac) {
+                    err = fmt("variable %lld: factor id %lld outside factors", v, f);
+                    return NSK_E_INDEX;
+                }
+                int rc = check_factor(f);
+                if (rc) return rc;
+            }
+        }
+    }
+    c.logtab.resize((size_t)max_ratio_arity + 2);
+    c.logtab[0] = 0.0;
+    for (size_t k = 1; k < c.logtab.size(); k++) c.logtab[k] = std::log((double)k);   // math.log, inference.py:222
+
+    // ---- colouring: no two variables of a colour may read each other ---------------------------
+    // reads(v) = members of every factor in v's lists (+ the literal head index variable)
+    auto for_each_read = [&](int64_t v, auto &&fn_) {
+        const nsk_variable &var = d->variable[v];
+        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+        for (int64_t k = 0; k < nslots; k++) {
+            const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+            for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                const nsk_factor &fa = d->factor[f];
+                const int fnid = fa.factorFunction;
+                if (fnid == -1) continue;
+                int64_t need = (fnid == 21 || fnid == 22 || fnid == 25 || fnid == 26) ? 2
+                             : (fnid == 23 || fnid == 24) ? 3 : (fnid >= 18 && fnid <= 20) ? 1 : 0;
+                int64_t s = fa.ftv_offset, e = std::max(s + fa.arity, s + need);
+                if (fnid == 30) e = std::max(e, s + d->variable[d->fmap[s].vid].cardinality - 1);
+                for (int64_t l = s; l < e; l++) fn_(d->fmap[l].vid);
+                if (literal_head_function(fnid) && !head_by_vid) fn_(s + fa.arity - 1);
+            }
+        }
+    };
+
+    c.color.assign(nvar, -1);
+    std::vector<int64_t> stamp(1, -1);
+    int32_t ncolors = 0;
+    for (int64_t v = 0; v < nvar; v++) {
+        if (!sampled[v]) continue;
+        for_each_read(v, [&](int64_t b) {
+            if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
+        });
+        int32_t col = 0;
+        while (col < ncolors && stamp[col] == v) col++;
+        if (col == ncolors) { ncolors++; stamp.push_back(-1); }
+        c.color[v] = col;
+    }
+    // the greedy pass assumes reads are symmetric (true for compute_var_map output); verify, and
+    // repair with explicit reverse-read lists when a raw index is asymmetric
+    bool conflict = false;
+    for (int64_t v = 0; v < nvar && !conflict; v++) {
+        if (!sampled[v]) continue;
+        for_each_read(v, [&](int64_t b) {
+            if (b != v && c.color[b] == c.color[v]) conflict = true;
+        });
+    }
+    if (conflict) {
+        std::vector<int64_t> rcount(nvar + 1, 0);
+        for (int64_t v = 0; v < nvar; v++)
+            if (sampled[v]) for_each_read(v, [&](int64_t b) { if (b != v) rcount[b + 1]++; });
+        for (int64_t v = 0; v < nvar; v++) rcount[v + 1] += rcount[v];
+        std::vector<int32_t> readers((size_t)rcount[nvar]);
+        std::vector<int64_t> fill(rcount.begin(), rcount.end() - 1);
+        for (int64_t v = 0; v < nvar; v++)
+            if (sampled[v]) for_each_read(v, [&](int64_t b) { if (b != v) readers[fill[b]++] = (int32_t)v; });
+        std::fill(c.color.begin(), c.color.end(), -1);
+        stamp.assign(1, -1);
+        ncolors = 0;
+        for (int64_t v = 0; v < nvar; v++) {
+            if (!sampled[v]) continue;
+            for_each_read(v, [&](int64_t b) {
+                if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
+            });
+            for (int64_t j = rcount[v]; j < rcount[v + 1]; j++) {
+                int32_t a = readers[j];
+                if (c.color[a] >= 0) stamp[c.color[a]] = v;
+            }
+            int32_t col = 0;
+            while (col < ncolors && stamp[col] == v) col++;
+            if (col == ncolors) { ncolors++; stamp.push_back(-1); }
+            c.color[v] = col;
+        }
+    }
+
+    // ---- positions: colour-major, id order inside a colour -------------------------------------
+    c.phase_start.assign((size_t)ncolors + 1, 0);
+    for (int64_t v = 0; v < nvar; v++)
+        if (c.color[v] >= 0) c.phase_start[c.color[v] + 1]++;
+    for (int32_t k = 0; k < ncolors; k++) c.phase_start[k + 1] += c.phase_start[k];
+    c.npos = c.phase_start[ncolors];
+    c.p_vid.resize(c.npos); c.p_info.resize(c.npos); c.p_slot.resize(c.npos);
+    c.p_cnt.resize(c.npos); c.p_init.resize(c.npos);
+    c.v_pos.assign(nvar, -1);
+    {
+        std::vector<int64_t> next(c.phase_start.begin(), c.phase_start.end() - 1);
+        for (int64_t v = 0; v < nvar; v++)
+            if (c.color[v] >= 0) {
+                int64_t p = next[c.color[v]]++;
+                c.p_vid[p] = (int32_t)v;
+                c.v_pos[v] = (int32_t)p;
+            }
+    }
+    int64_t nslot = 0, nlist = 0;
+    for (int64_t p = 0; p < c.npos; p++) {
+        const nsk_variable &var = d->variable[c.p_vid[p]];
+        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+        for (int64_t k = 0; k < nslots; k++) nlist += d->vmap[var.vtf_offset + k].factor_index_length;
+        nslot += nslots;
+    }
+    if (nslot >= LIM - 1 || nlist >= LIM - 1) {
+        err = "inverted index too large for 32-bit device indices";
+        return NSK_E_RANGE;
+    }
+    c.nslot = nslot;
+    c.slot_off.resize(nslot + 1);
+    c.fidx.resize(nlist);
+    const int64_t s_i = 4, s_v = c.vbytes, s_c = 4;
+    const bool big_w = nw * 8 > (4 << 20);
+    double bytes_inf = 0, bytes_learn = 0;
+    std::vector<int64_t> uni;
+    int64_t si = 0, li = 0;
+    for (int64_t p = 0; p < c.npos; p++) {
+        const int64_t v = c.p_vid[p];
+        const nsk_variable &var = d->variable[v];
+        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+        c.p_info[p] = ((uint32_t)var.cardinality << 9) | ((var.dataType != 0) ? 0x100u : 0u) |
+                      (uint32_t)(uint8_t)var.isEvidence;
+        c.p_slot[p] = (int32_t)si;
+        c.p_cnt[p] = (int32_t)c.cstart[v];
+        c.p_init[p] = c.v_init[v];
+        uni.clear();
+        for (int64_t k = 0; k < nslots; k++) {
+            const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+            c.slot_off[si++] = (int32_t)li;
+            for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                c.fidx[li++] = (int32_t)f;
+                uni.push_back(f);
+            }
+        }
+        if (nslots > 1) {
+            std::sort(uni.begin(), uni.end());
+            uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+        }
+        // algorithmic bytes of this update, SURVEY.md section 8(d)
+        double bi = 2 + s_i + s_v, bl = 0;
+        for (int64_t f : uni) {
+            const nsk_factor &fa = d->factor[f];
+            const double ar = (double)std::max<int64_t>(fa.arity, 0);
+            bi += s_i + 10 + ar * s_i + (is_cat_function(fa.factorFunction) ? ar * s_i : 0) +
+                  (ar - 1) * s_v + (big_w ? 8 : 0);
+            bl += (ar - 1) * s_v + 8 + 1 +
+                  ((big_w && fa.weightId >= 0 && fa.weightId < nw && !c.w_fixed[fa.weightId]) ? 16 : 0);
+        }
+        bytes_inf += bi + 2 * s_c;
+        bytes_learn += bi + bl + s_v;
+    }
+    c.slot_off[si] = (int32_t)li;
+    c.alg_bytes_inference = bytes_inf;
+    c.alg_bytes_learning = bytes_learn;
+    return NSK_OK;
+}
+
+}  // namespace nsk

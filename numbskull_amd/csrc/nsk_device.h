@@ -1,0 +1,434 @@
+// nsk_device.h -- device-side building blocks of the Gibbs sweep (gfx950).
+//
+// Everything here is the per-variable rule of the reference, restated for one GPU lane:
+//   eval_factor   numbskull/inference.py:149-413
+//   potential     numbskull/inference.py:55-71
+//   draw_sample   numbskull/inference.py:36-52
+// plus the two generators (Philox4x32-10 for the chromatic scan, MT19937 for the sequential
+// validation scan) and the deterministic exp whose algorithm is specified in DESIGN.md so that
+// the CPU oracle reproduces it bit for bit.  Compiled with -ffp-contract=off: products and sums
+// are rounded separately exactly like the reference's float64 arithmetic; every fused
+// multiply-add below is an explicit fma().
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nsk {
+
+// ------------------------------------------------------------------------------------------
+// factor function ids (inference.py:74-143)
+// ------------------------------------------------------------------------------------------
+enum : int {
+    F_NOOP = -1, F_IMPLY_NATURAL = 0, F_OR = 1, F_AND = 2, F_EQUAL = 3, F_ISTRUE = 4,
+    F_LINEAR = 7, F_RATIO = 8, F_LOGICAL = 9, F_AND_CAT = 12, F_IMPLY_MLN = 13, F_OR_CAT = 14,
+    F_EQUAL_CAT_CONST = 15, F_IMPLY_NATURAL_CAT = 16, F_IMPLY_MLN_CAT = 17,
+    F_DP_GEN_CLASS_PRIOR = 18, F_DP_GEN_LF_PRIOR = 19, F_DP_GEN_LF_PROPENSITY = 20,
+    F_DP_GEN_LF_ACCURACY = 21, F_DP_GEN_LF_CLASS_PROPENSITY = 22, F_DP_GEN_DEP_FIXING = 23,
+    F_DP_GEN_DEP_REINFORCING = 24, F_DP_GEN_DEP_EXCLUSIVE = 25, F_DP_GEN_DEP_SIMILAR = 26,
+    F_UFO = 30
+};
+
+// p_info word of a variable: cardinality << 9 | (dataType != 0) << 8 | (uint8) isEvidence
+#define NSK_INFO_CARD(i) ((int)((i) >> 9))
+#define NSK_INFO_DT1(i) (((i) >> 8) & 1u)
+#define NSK_INFO_EV(i) ((int)(int8_t)((i) & 0xffu))
+// f_head word of a factor: arity << 8 | (uint8)(factorFunction + 1)
+#define NSK_FHEAD_FUNC(h) ((int)((h) & 0xffu) - 1)
+#define NSK_FHEAD_ARITY(h) ((int)((h) >> 8))
+
+#define NSK_ZLOCAL 16      // cardinalities up to this keep their running sums in registers/scratch
+#define NSK_GRAD_SCALE 4294967296.0   // gradients accumulate as Q31.32 fixed point (order-free)
+
+// ------------------------------------------------------------------------------------------
+// deterministic exp -- same operation sequence as oracle/nsk_oracle.c:orc_exp_det
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pow2i(int k) {
+    return __longlong_as_double((long long)(k + 1023) << 52);
+}
+
+__device__ __forceinline__ double nsk_exp(double x) {
+    if (x != x) return x;
+    if (x > 709.782712893384) return __longlong_as_double(0x7ff0000000000000LL);
+    if (x < -745.1332191019412) return 0.0;
+    const double INV_LN2 = 1.4426950408889634;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double kf = rint(x * INV_LN2);
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int k = (int)kf;
+    int k1 = k / 2;
+    int k2 = k - k1;
+    return (p * pow2i(k1)) * pow2i(k2);
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10, counter = (variable id, stream, sweep lo, sweep hi), key = seed
+// ------------------------------------------------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                                            uint32_t c2, uint32_t c3) {
+#pragma unroll
+    for (int round = 0; round < 10; round++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+// 53-bit uniform in [0,1) from two 32-bit words: the genrand_res53 construction that
+// np.random.rand() / random.random() use (inference.py:50, learning.py:90)
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// MT19937 (sequential validation scan only; one lane)
+// ------------------------------------------------------------------------------------------
+struct MTState { uint32_t mt[624]; int idx; };
+
+__device__ inline uint32_t mt_next(MTState *s) {
+    if (s->idx >= 624) {
+        uint32_t *mt = s->mt;
+        int kk;
+        for (kk = 0; kk < 624 - 397; kk++) {
+            uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        for (; kk < 623; kk++) {
+            uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        s->idx = 0;
+    }
+    uint32_t y = s->mt[s->idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+__device__ inline double mt_res53(MTState *s) {
+    uint32_t a = mt_next(s);
+    uint32_t b = mt_next(s);
+    return u53(a, b);
+}
+
+// ------------------------------------------------------------------------------------------
+// device view of a compiled graph (layout: DESIGN.md "Data layout in HBM")
+// ------------------------------------------------------------------------------------------
+template <typename VT>
+struct DevGraph {
+    // per position (owned variables in colour-major order)
+    const int32_t *p_vid;       // variable id
+    const uint32_t *p_info;     // cardinality / dataType / isEvidence
+    const int32_t *p_slot;      // first slot of the variable in slot_off
+    const int32_t *p_cnt;       // cstart[vid]: base index into the tally
+    const VT *p_init;           // initialValue (evidence value of the evidence chain)
+    // inverted index, compacted and laid out in position order
+    const int32_t *slot_off;    // [nslot+1] offsets into fidx
+    const int32_t *fidx;        // sorted-unique factor ids per (variable, value) slot
+    // per factor
+    const uint32_t *f_head;     // arity << 8 | function+1
+    const int32_t *f_off;       // ftv_offset
+    const int32_t *f_wid;       // weightId
+    const double *f_feat;       // featureValue
+    // per edge
+    const int32_t *m_vid;
+    const int32_t *m_deo;       // dense_equal_to
+    // per variable id
+    const int32_t *v_card;      // cardinality (data-programming "abstain" lookups)
+    // weights
+    double *w;
+    const uint8_t *w_fixed;
+    const double *logtab;       // log(k), k = 0..: RATIO's math.log(res) computed on the host
+    // state
+    VT *val;                    // var_value[0]
+    VT *val_evid;               // var_value_evid[0]
+    int32_t *cnt;               // tally delta since the last fold into the int64 master copy
+    // learning accumulators (per weight)
+    long long *G;               // fixed-point gradient sum
+    uint32_t *K;                // visits
+    uint32_t *T;                // truncating visits (L1)
+    int32_t nvar;
+    int32_t head_by_vid;
+};
+
+// member value at absolute edge index l with the sampled variable hypothetically at `value`
+template <typename VT>
+__device__ __forceinline__ int member(const DevGraph<VT> &g, int l, int var_samp, int value,
+                                      const VT *__restrict__ val) {
+    int vid = g.m_vid[l];
+    return vid == var_samp ? value : (int)val[vid];
+}
+
+// head of IMPLY_MLN / IMPLY_NATURAL_CAT / IMPLY_MLN_CAT: literal reference indexing reads
+// var_value[l] with l the ABSOLUTE EDGE INDEX (inference.py:243,277,292); NSK_FLAG_HEAD_BY_VID
+// selects the intended fmap[l].vid.  nsk_graph_create has verified l < nvar in literal mode.
+template <typename VT>
+__device__ __forceinline__ int head_member(const DevGraph<VT> &g, int l, int var_samp, int value,
+                                           const VT *__restrict__ val) {
+    int vid = g.m_vid[l];
+    if (vid == var_samp) return value;
+    return (int)val[g.head_by_vid ? vid : l];
+}
+
+// eval_factor (inference.py:149-413).  nsk_graph_create rejects unknown function ids and
+// out-of-range member positions, so no error path is needed here.
+template <typename VT>
+__device__ inline double eval_factor(const DevGraph<VT> &g, int fid, int var_samp, int value,
+                                     const VT *__restrict__ val) {
+    const uint32_t head = g.f_head[fid];
+    const int fn = NSK_FHEAD_FUNC(head);
+    const int s = g.f_off[fid];
+    const int e = s + NSK_FHEAD_ARITY(head);
+    switch (fn) {
+    case F_NOOP:
+        return 0.0;
+    case F_EQUAL: {                                             // 184-192
+        int v = member(g, s, var_samp, value, val);
+        for (int l = s + 1; l < e; l++)
+            if (v != member(g, l, var_samp, value, val)) return -1.0;
+        return 1.0;
+    }
+    case F_AND:
+    case F_ISTRUE:                                              // 193-200
+        for (int l = s; l < e; l++)
+            if (member(g, l, var_samp, value, val) == 0) return -1.0;
+        return 1.0;
+    case F_OR:                                                  // 177-183
+        for (int l = s; l < e; l++)
+            if (member(g, l, var_samp, value, val) == 1) return 1.0;
+        return -1.0;
+    case F_IMPLY_NATURAL: {                                     // 162-176 (the loop covers the head)
+        for (int l = s; l < e; l++)
+            if (member(g, l, var_samp, value, val) == 0) return 0.0;
+        return member(g, e - 1, var_samp, value, val) ? 1.0 : -1.0;
+    }
+    case F_LINEAR:
+    case F_RATIO:
+    case F_LOGICAL: {                                           // 201-231
+        int hd = member(g, e - 1, var_samp, value, val);
+        int res = 0;
+        for (int l = s; l < e - 1; l++) {
+            if (member(g, l, var_samp, value, val) == hd) {
+                if (fn == F_LOGICAL) return 1.0;
+                res++;
+            }
+        }
+        if (fn == F_LINEAR) return (double)res;
+        if (fn == F_RATIO) return g.logtab[res + 1];
+        return 0.0;
+    }
+    case F_IMPLY_MLN: {                                         // 232-246
+        for (int l = s; l < e - 1; l++)
+            if (member(g, l, var_samp, value, val) == 0) return 1.0;
+        return head_member(g, e - 1, var_samp, value, val) ? 1.0 : 0.0;
+    }
+    case F_AND_CAT:
+    case F_EQUAL_CAT_CONST:                                     // 251-258
+        for (int l = s; l < e; l++)
+            if (member(g, l, var_samp, value, val) != g.m_deo[l]) return 0.0;
+        return 1.0;
+    case F_OR_CAT:                                              // 259-265
+        for (int l = s; l < e; l++)
+            if (member(g, l, var_samp, value, val) == g.m_deo[l]) return 1.0;
+        return -1.0;
+    case F_IMPLY_NATURAL_CAT: {                                 // 266-280
+        for (int l = s; l < e - 1; l++)
+            if (member(g, l, var_samp, value, val) != g.m_deo[l]) return 0.0;
+        return head_member(g, e - 1, var_samp, value, val) == g.m_deo[e - 1] ? 1.0 : -1.0;
+    }
+    case F_IMPLY_MLN_CAT: {                                     // 281-295
+        for (int l = s; l < e - 1; l++)
+            if (member(g, l, var_samp, value, val) != g.m_deo[l]) return 1.0;
+        return head_member(g, e - 1, var_samp, value, val) == g.m_deo[e - 1] ? 1.0 : 0.0;
+    }
+    case F_DP_GEN_CLASS_PRIOR:                                  // 301-305
+        return member(g, s, var_samp, value, val) == 1 ? 1.0 : -1.0;
+    case F_DP_GEN_LF_PRIOR: {                                   // 306-315
+        int l0 = member(g, s, var_samp, value, val);
+        return l0 == 2 ? -1.0 : (l0 == 0 ? 0.0 : 1.0);
+    }
+    case F_DP_GEN_LF_PROPENSITY: {                              // 316-320
+        int l0 = member(g, s, var_samp, value, val);
+        return l0 == g.v_card[g.m_vid[s]] - 1 ? 0.0 : 1.0;
+    }
+    case F_DP_GEN_LF_ACCURACY:
+    case F_DP_GEN_LF_CLASS_PROPENSITY: {                        // 321-346
+        int y = member(g, s, var_samp, value, val);
+        int l1 = member(g, s + 1, var_samp, value, val);
+        if (l1 == g.v_card[g.m_vid[s + 1]] - 1) return 0.0;
+        if (fn == F_DP_GEN_LF_ACCURACY) return y == l1 ? 1.0 : -1.0;
+        return y == 1 ? 1.0 : -1.0;
+    }
+    case F_DP_GEN_DEP_FIXING:
+    case F_DP_GEN_DEP_REINFORCING: {                            // 347-380
+        int y = member(g, s, var_samp, value, val);
+        int l1 = member(g, s + 1, var_samp, value, val);
+        int l2 = member(g, s + 2, var_samp, value, val);
+        if (l1 == g.v_card[g.m_vid[s + 1]] - 1) return l2 != 1 ? -1.0 : 0.0;
+        if (fn == F_DP_GEN_DEP_FIXING) {
+            if (l1 == 0 && l2 == 1 && y == 1) return 1.0;
+            if (l1 == 1 && l2 == 0 && y == 0) return 1.0;
+        } else {
+            if (l1 == 0 && l2 == 0 && y == 0) return 1.0;
+            if (l1 == 1 && l2 == 1 && y == 1) return 1.0;
+        }
+        return 0.0;
+    }
+    case F_DP_GEN_DEP_EXCLUSIVE: {                              // 381-387
+        int l1 = member(g, s, var_samp, value, val);
+        int l2 = member(g, s + 1, var_samp, value, val);
+        int abstain = g.v_card[g.m_vid[s]] - 1;
+        return (l1 == abstain || l2 == abstain) ? 0.0 : -1.0;
+    }
+    case F_DP_GEN_DEP_SIMILAR:                                  // 388-393
+        return member(g, s, var_samp, value, val) == member(g, s + 1, var_samp, value, val)
+                   ? 1.0 : 0.0;
+    case F_UFO: {                                               // 398-405
+        int v = member(g, s, var_samp, value, val);
+        if (v == 0) return 0.0;
+        return (double)member(g, s + v - 1, var_samp, value, val);
+    }
+    default:
+        return 0.0;
+    }
+}
+
+// potential (inference.py:55-71): sum over the slot's factor list, in list order, each term
+// rounded (product) and then added -- no contraction, so the float64 result equals the
+// reference's.
+template <typename VT>
+__device__ inline double potential(const DevGraph<VT> &g, int var_samp, int value, int slot,
+                                   const VT *__restrict__ val) {
+    double p = 0.0;
+    const int b = g.slot_off[slot], e = g.slot_off[slot + 1];
+    for (int k = b; k < e; k++) {
+        const int fid = g.fidx[k];
+        const double t = g.w[g.f_wid[fid]] * eval_factor(g, fid, var_samp, value, val);
+        p = p + t;
+    }
+    return p;
+}
+
+// draw_sample (inference.py:36-52) given the uniform u: Z[k] = running sum of exp(potential),
+// z = u * Z[card-1], result = first k with Z[k] >= z (0 if none, like np.argmax of all-False).
+template <typename VT>
+__device__ inline int draw_sample(const DevGraph<VT> &g, int var_samp, uint32_t info, int slot0,
+                                  const VT *__restrict__ val, double u) {
+    const int card = NSK_INFO_CARD(info);
+    const int step = NSK_INFO_DT1(info);          // dataType 1: one factor list per value
+    if (card == 2) {
+        const double z0 = nsk_exp(potential(g, var_samp, 0, slot0, val));
+        const double z1 = z0 + nsk_exp(potential(g, var_samp, 1, slot0 + step, val));
+        const double z = u * z1;
+        return (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    }
+    if (card <= NSK_ZLOCAL) {
+        double Z[NSK_ZLOCAL];
+        double acc = 0.0;
+        for (int k = 0; k < card; k++) {
+            const double ek = nsk_exp(potential(g, var_samp, k, slot0 + step * k, val));
+            acc = (k == 0) ? ek : acc + ek;
+            Z[k] = acc;
+        }
+        const double z = u * acc;
+        for (int k = 0; k < card; k++)
+            if (Z[k] >= z) return k;
+        return 0;
+    }
+    // large domains: two passes, the second recomputes the identical running sums
+    double acc = 0.0;
+    for (int k = 0; k < card; k++) {
+        const double ek = nsk_exp(potential(g, var_samp, k, slot0 + step * k, val));
+        acc = (k == 0) ? ek : acc + ek;
+    }
+    const double z = u * acc;
+    double run = 0.0;
+    for (int k = 0; k < card; k++) {
+        const double ek = nsk_exp(potential(g, var_samp, k, slot0 + step * k, val));
+        run = (k == 0) ? ek : run + ek;
+        if (run >= z) return k;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave-level helpers (64 lanes)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Add one (weight, gradient) visit per participating lane into the per-weight accumulators.
+// Must be called by all 64 lanes of the wave (converged); `have` marks participating lanes.
+// Lanes sharing the leader's weight id are reduced in registers first, so a graph whose weights
+// are shared by every factor (the Ising grid) issues one atomic per wave instead of 64.
+template <typename VT>
+__device__ __forceinline__ void accumulate_gradient(const DevGraph<VT> &g, bool have, int wid,
+                                                    long long gfix, bool trunc) {
+    const unsigned long long mask = __ballot(have);
+    if (mask == 0) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    const int lw = __shfl(wid, leader, 64);
+    const bool same = have && (wid == lw);
+    const unsigned long long smask = __ballot(same);
+    const int nsame = __popcll(smask);
+    if (nsame >= 4) {
+        const long long sum = wave_sum_i64(same ? gfix : 0LL);
+        const int nt = __popcll(__ballot(same && trunc));
+        if ((int)(threadIdx.x & 63) == leader) {
+            atomicAdd((unsigned long long *)&g.G[lw], (unsigned long long)sum);
+            atomicAdd(&g.K[lw], (uint32_t)nsame);
+            if (nt) atomicAdd(&g.T[lw], (uint32_t)nt);
+        }
+        have = have && !same;
+    }
+    if (have) {
+        atomicAdd((unsigned long long *)&g.G[wid], (unsigned long long)gfix);
+        atomicAdd(&g.K[wid], 1u);
+        if (trunc) atomicAdd(&g.T[wid], 1u);
+    }
+}
+
+// a^k by binary exponentiation: the operation sequence of oracle powi_det
+__device__ __forceinline__ double powi_det(double a, unsigned long long k) {
+    double r = 1.0, b = a;
+    while (k) {
+        if (k & 1) r *= b;
+        k >>= 1;
+        if (k) b *= b;
+    }
+    return r;
+}
+
+}  // namespace nsk

@@ -1,0 +1,309 @@
+"""FactorGraph: owner of the graph/state arrays and driver of burn-in, inference and learning.
+
+Keeps the public face of the reference class (numbskull/factorgraph.py:27-229: constructor
+signature, attributes, method names, text dumps) so that callers -- the CLI, the reference's
+smoke scripts, code that patches ``var_value`` / ``weight_value`` between epochs -- keep working.
+What changed is what happens below ``burnIn`` / ``inference`` / ``learn``: the reference fans
+``gibbsthread`` / ``learnthread`` out over a thread pool (run_pool, factorgraph.py:13-24, called
+at :141, :163, :202); here those three call sites go through the C-ABI to HIP kernels on the
+MI355X.  Host arrays are uploaded when a call starts and downloaded when it returns, so in-place
+edits between calls are honoured exactly like in the reference.
+"""
+
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _lib
+from .timer import Timer
+
+
+class FactorGraph(object):
+    """A factor graph resident on one MI355X.
+
+    Positional parameters are the reference's (factorgraph.py:30-31).  Keyword-only extras:
+    ``device`` (HIP ordinal), ``seed`` (Philox key / MT19937 seed), ``scan`` ("chromatic" or
+    "sequential"), ``head_by_vid`` (intended head lookup for IMPLY_MLN-type factors instead of
+    the literal inference.py:243 indexing), ``own_range`` ((begin, end) variable ids sampled by
+    this handle when the graph is range-partitioned over several GPUs).
+    """
+
+    def __init__(self, weight, variable, factor, fmap, vmap, factor_index, var_copies,
+                 weight_copies, fid, workers, *, device=0, seed=0, scan="chromatic",
+                 head_by_vid=False, own_range=None):
+        self.weight, self.variable, self.factor = weight, variable, factor
+        self.fmap, self.vmap, self.factor_index = fmap, vmap, factor_index
+
+        nvar = variable.shape[0]
+        card = variable["cardinality"].astype(np.int64)
+        # tally layout: one slot for a binary variable, `cardinality` slots otherwise
+        self.cstart = np.zeros(nvar + 1, np.int64)
+        np.cumsum(np.where(card == 2, 1, card), out=self.cstart[1:])
+        ncount = int(self.cstart[nvar])
+        self.count = np.zeros(ncount, np.int64)
+
+        init = variable["initialValue"]
+        self.var_value_evid = np.tile(init, (var_copies, 1))
+        self.var_value = np.tile(init, (var_copies, 1))
+        self.weight_value = np.tile(weight["initialValue"], (weight_copies, 1))
+
+        # scratch arrays of the reference's CPU threads; kept for attribute compatibility only
+        self.Z = np.zeros((workers, int(card.max()) if nvar else 0))
+        longest = int(vmap["factor_index_length"].max()) if vmap.size else 0
+        self.fids = np.zeros((workers, 2 * longest), factor_index.dtype)
+
+        self.fid = fid
+        assert workers > 0
+        self.threads = workers          # accepted for compatibility; the GPU ignores it
+        self.threadpool = None
+        self.marginals = np.zeros(ncount)
+        self.inference_epoch_time = 0.0
+        self.inference_total_time = 0.0
+        self.learning_epoch_time = 0.0
+        self.learning_total_time = 0.0
+
+        self.device = int(device)
+        self.seed = int(seed)
+        self.scan = scan
+        self.head_by_vid = bool(head_by_vid)
+        self.own_range = own_range
+        self._handle = None
+        self._keep = None
+
+    # ------------------------------------------------------------------ device handle
+    def _descriptor(self):
+        """nsk_graph_desc over the arrays this object owns (plus the arrays kept alive)."""
+        arrays = [_lib.as_c(a) for a in (self.weight, self.variable, self.factor, self.fmap,
+                                         self.vmap)]
+        fi = _lib.as_c(self.factor_index, np.int64)
+        sizes = (9, 27, 34, 16, 24)
+        for a, s in zip(arrays, sizes):
+            if a.dtype.itemsize != s:
+                raise TypeError("record array with itemsize %d, expected %d" % (a.dtype.itemsize, s))
+        w, v, f, fm, vm = arrays
+        ob, oe = self.own_range if self.own_range is not None else (0, 0)
+        desc = _lib.GraphDesc(len(w), len(v), len(f), len(fm), len(vm), len(fi),
+                              w.ctypes.data, v.ctypes.data, f.ctypes.data, fm.ctypes.data,
+                              vm.ctypes.data, fi.ctypes.data,
+                              _lib.FLAG_HEAD_BY_VID if self.head_by_vid else 0, self.device,
+                              int(ob), int(oe))
+        return desc, (arrays, fi)
+
+    def plan(self):
+        """Host-only: validate and colour the graph as the device build would (no GPU needed).
+        Returns (color[nvar] with -1 for variables this handle does not sample, info dict)."""
+        desc, keep = self._descriptor()
+        color = np.zeros(self.variable.shape[0], np.int32)
+        inf = _lib.GraphInfo()
+        _lib.check(_lib.lib().nsk_graph_plan(C.byref(desc), _lib.ptr(color), C.byref(inf)))
+        return color, {k: getattr(inf, k) for k, _ in inf._fields_}
+
+    def _engine(self):
+        """Create (once) the device-side graph.  Fails loudly without a GPU."""
+        if self._handle is not None:
+            return self._handle
+        L = _lib.lib()
+        desc, keep = self._descriptor()
+        h = C.c_void_p()
+        _lib.check(L.nsk_graph_create(C.byref(desc), C.byref(h)))
+        self._handle = h
+        self._keep = keep
+        _lib.check(L.nsk_set_seed(h, self.seed, 0))
+        scan = {"chromatic": _lib.SCAN_CHROMATIC, "sequential": _lib.SCAN_SEQUENTIAL}[self.scan]
+        _lib.check(L.nsk_set_scan(h, scan))
+        return h
+
+    def close(self):
+        if self._handle is not None:
+            _lib.lib().nsk_graph_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_seed(self, seed, sweep0=0):
+        self.seed = int(seed)
+        if self._handle is not None:
+            _lib.check(_lib.lib().nsk_set_seed(self._handle, self.seed, int(sweep0)))
+
+    def info(self):
+        inf = _lib.GraphInfo()
+        _lib.check(_lib.lib().nsk_graph_get_info(self._engine(), C.byref(inf)))
+        return {k: getattr(inf, k) for k, _ in inf._fields_}
+
+    def colors(self):
+        out = np.zeros(self.variable.shape[0], np.int32)
+        _lib.check(_lib.lib().nsk_graph_get_colors(self._engine(), _lib.ptr(out)))
+        return out
+
+    def _push(self, var_copy, weight_copy):
+        vv = _lib.as_c(self.var_value[var_copy], np.int64)
+        ve = _lib.as_c(self.var_value_evid[var_copy], np.int64)
+        wv = _lib.as_c(self.weight_value[weight_copy], np.float64)
+        cnt = _lib.as_c(self.count, np.int64)
+        _lib.check(_lib.lib().nsk_state_upload(self._engine(), _lib.ptr(vv), _lib.ptr(ve),
+                                               _lib.ptr(wv), _lib.ptr(cnt)))
+
+    def _pull(self, var_copy, weight_copy, values=True, weights=True, count=True):
+        n, nw = self.variable.shape[0], self.weight.shape[0]
+        vv = np.empty(n, np.int64) if values else None
+        ve = np.empty(n, np.int64) if values else None
+        wv = np.empty(nw, np.float64) if weights else None
+        cnt = np.empty(self.count.shape[0], np.int64) if count else None
+        _lib.check(_lib.lib().nsk_state_download(self._engine(), _lib.ptr(vv), _lib.ptr(ve),
+                                                 _lib.ptr(wv), _lib.ptr(cnt)))
+        if values:
+            self.var_value[var_copy][:] = vv
+            self.var_value_evid[var_copy][:] = ve
+        if weights:
+            self.weight_value[weight_copy][:] = wv
+        if count:
+            self.count[:] = cnt
+
+    # ------------------------------------------------------------------ reference API
+    def clear(self):
+        self.count[:] = 0
+
+    def getWeights(self, weight_copy=0):
+        return self.weight_value[weight_copy][:]
+
+    def getMarginals(self, varIds=None):
+        return self.marginals if not varIds else self.marginals[varIds]
+
+    def diagnostics(self, epochs):
+        print('Inference took %.03f sec.' % self.inference_total_time)
+        epochs = epochs or 1
+        bins = 10
+        assert self.count.min(initial=0) >= 0
+        assert self.count.max(initial=0) <= epochs
+        which = np.minimum(self.count * bins // epochs, bins - 1)
+        hist = np.bincount(which, minlength=bins)
+        for i in range(bins):
+            print("Prob. " + str(i / 10.0) + ".." + str((i + 1) / 10.0) + ": \
+                  " + str(hist[i]) + " variables")
+
+    def diagnosticsLearning(self, weight_copy=0):
+        print('Learning epoch took %.03f sec.' % self.learning_epoch_time)
+        print("Weights:")
+        for i, w in enumerate(self.weight):
+            print("    weightId:", i)
+            print("        isFixed:", w["isFixed"])
+            print("        weight: ", self.weight_value[weight_copy][i])
+            print()
+
+    def _sweep(self, nsweeps, sample_evidence, burnin):
+        h = self._engine()
+        _lib.check(_lib.lib().nsk_gibbs_sweeps(h, int(nsweeps), int(bool(sample_evidence)),
+                                               int(bool(burnin))))
+
+    def burnIn(self, epochs, sample_evidence, diagnostics=False, var_copy=0, weight_copy=0):
+        """factorgraph.py:129-143 -- `epochs` sweeps that do not touch the tally."""
+        if diagnostics:
+            print("FACTOR " + str(self.fid) + ": STARTED BURN-IN...")
+        if epochs > 0:
+            self._push(var_copy, weight_copy)
+            self._sweep(epochs, sample_evidence, True)
+            self._pull(var_copy, weight_copy, weights=False, count=False)
+        if diagnostics:
+            print("FACTOR " + str(self.fid) + ": DONE WITH BURN-IN")
+
+    def inference(self, burnin_epochs, epochs, sample_evidence=False, diagnostics=False,
+                  var_copy=0, weight_copy=0):
+        """factorgraph.py:145-175."""
+        if burnin_epochs > 0:
+            self.burnIn(burnin_epochs, sample_evidence, diagnostics=diagnostics,
+                        var_copy=var_copy, weight_copy=weight_copy)
+        if diagnostics:
+            print("FACTOR " + str(self.fid) + ": STARTED INFERENCE")
+        if epochs > 0:
+            L, h = _lib.lib(), self._engine()
+            self._push(var_copy, weight_copy)
+            if diagnostics:     # per-epoch timing lines, like the reference prints them
+                for ep in range(epochs):
+                    with Timer() as timer:
+                        self._sweep(1, sample_evidence, False)
+                        _lib.check(L.nsk_synchronize(h))
+                    self.inference_epoch_time = timer.interval
+                    self.inference_total_time += timer.interval
+                    print('Inference epoch #%d took %.03f sec.' % (ep, self.inference_epoch_time))
+            else:
+                with Timer() as timer:
+                    self._sweep(epochs, sample_evidence, False)
+                    _lib.check(L.nsk_synchronize(h))
+                self.inference_epoch_time = timer.interval / epochs
+                self.inference_total_time += timer.interval
+            self._pull(var_copy, weight_copy, weights=False)
+        if diagnostics:
+            print("FACTOR " + str(self.fid) + ": DONE WITH INFERENCE")
+        if epochs != 0:
+            self.marginals = self.count / float(epochs)
+        if diagnostics:
+            self.diagnostics(epochs)
+
+    def learn(self, burnin_epochs, epochs, stepsize, decay, regularization, reg_param, truncation,
+              diagnostics=False, verbose=False, learn_non_evidence=False, var_copy=0,
+              weight_copy=0):
+        """factorgraph.py:177-208."""
+        if burnin_epochs > 0:
+            self.burnIn(burnin_epochs, True, diagnostics=diagnostics, var_copy=var_copy,
+                        weight_copy=weight_copy)
+        if diagnostics:
+            print("FACTOR " + str(self.fid) + ": STARTED LEARNING")
+        if epochs > 0:
+            L, h = _lib.lib(), self._engine()
+            self._push(var_copy, weight_copy)
+            args = (int(regularization), float(reg_param), int(truncation),
+                    int(bool(learn_non_evidence)))
+            if diagnostics:
+                for ep in range(epochs):
+                    print("FACTOR " + str(self.fid) + ": EPOCH #" + str(ep))
+                    print("Current stepsize = " + str(stepsize))
+                    if verbose:
+                        self._pull(var_copy, weight_copy, values=False, count=False)
+                        self.diagnosticsLearning(weight_copy)
+                    sys.stdout.flush()
+                    with Timer() as timer:
+                        _lib.check(L.nsk_learn_sweeps(h, 1, float(stepsize), float(decay), *args))
+                        _lib.check(L.nsk_synchronize(h))
+                    self.learning_epoch_time = timer.interval
+                    self.learning_total_time += timer.interval
+                    stepsize *= decay
+            else:
+                with Timer() as timer:
+                    _lib.check(L.nsk_learn_sweeps(h, int(epochs), float(stepsize), float(decay),
+                                                  *args))
+                    _lib.check(L.nsk_synchronize(h))
+                self.learning_epoch_time = timer.interval / epochs
+                self.learning_total_time += timer.interval
+            self._pull(var_copy, weight_copy, count=False)
+        if diagnostics:
+            print("FACTOR " + str(self.fid) + ": DONE WITH LEARNING")
+
+    def dump_weights(self, fout, weight_copy=0):
+        """<wid, weight> text file (factorgraph.py:210-214)."""
+        w = self.weight_value[weight_copy]
+        with open(fout, 'w') as out:
+            out.write("".join('%d %f\n' % (i, w[i]) for i in range(self.weight.shape[0])))
+
+    def dump_probabilities(self, fout, epochs):
+        """<vid, value, prob> text file (factorgraph.py:216-229): binary variables print the
+        probability of value 1, others one line per domain value."""
+        epochs = epochs or 1
+        card = self.variable["cardinality"]
+        with open(fout, 'w') as out:
+            if np.all(card == 2):
+                prob = self.count[self.cstart[:-1]] / float(epochs)
+                out.write("".join('%d %d %.3f\n' % (i, 1, p) for i, p in enumerate(prob)))
+                return
+            for i, v in enumerate(self.variable):
+                if v["cardinality"] == 2:
+                    out.write('%d %d %.3f\n' % (i, 1, float(self.count[self.cstart[i]]) / epochs))
+                    continue
+                for k in range(v["cardinality"]):
+                    prob = float(self.count[self.cstart[i] + k]) / epochs
+                    out.write('%d %d %.3f\n' % (i, self.vmap[v["vtf_offset"] + k]["value"], prob))
+

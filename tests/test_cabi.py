@@ -1,0 +1,166 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/numbskull_amd.h declares,
+the host entry points (index build, parsers, graph validation) behave like the reference, and the
+product never reaches into oracle/."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import graph_from, GOLDEN, REPO
+import numbskull_amd
+from numbskull_amd import _lib, dataloading, graphgen
+from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar, VarToFactor
+from util import quiet, session
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "numbskull_amd.h")).read()
+    declared = set(re.findall(r"\b(nsk_[a-z_0-9]+)\s*\(", header))
+    declared -= {"nsk_graph_desc", "nsk_graph_info"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in _lib.lib().nsk_version()
+
+
+def test_record_layouts_match_header():
+    header = open(os.path.join(REPO, "include", "numbskull_amd.h")).read()
+    for name, dt in (("nsk_weight", Weight), ("nsk_variable", Variable), ("nsk_factor", Factor),
+                     ("nsk_ftv", FactorToVar), ("nsk_vtf", VarToFactor)):
+        m = re.search(r"\}\s*%s;\s*/\*\s*(\d+) B" % name, header)
+        assert m and int(m.group(1)) == dt.itemsize, name
+
+
+def test_product_does_not_touch_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "numbskull_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp", ".c")) or fn == "Makefile":
+                text = open(os.path.join(root, fn)).read()
+                for line in text.splitlines():
+                    if re.search(r"^\s*(from|import)\s+oracle|#include.*oracle|libnsk_oracle", line):
+                        raise AssertionError("%s reaches into oracle/: %s" % (fn, line))
+
+
+@pytest.mark.parametrize("tag", ["grid4x5", "mixed", "skiplast", "pairs", "lf"])
+def test_compute_var_map_matches_reference(golden, tag):
+    z = golden("g2_index_build.npz")
+    w, v, f, fm, dm, _ = graph_from(z, tag)
+    skip = z[tag + "_in_factors_to_skip"] if tag + "_in_factors_to_skip" in z.files \
+        else np.empty(0, np.int64)
+    v = v.copy()
+    nedges = int(f["arity"].sum() - f["arity"][skip].sum())
+    vmap, fi = dataloading.new_index(v, nedges)
+    dataloading.compute_var_map(v, f, fm, vmap, fi, dm, skip)
+    assert np.array_equal(v, z[tag + "_out_variable"])
+    assert np.array_equal(vmap, z[tag + "_out_vmap"])
+    assert np.array_equal(fi, z[tag + "_out_factor_index"])
+
+
+def test_compute_var_map_index_error_like_reference():
+    # skipping a factor whose members are not in the last slot overflows factor_index in the
+    # reference (IndexError, dataloading.py:64)
+    w, v, f, fm, dm, _ = graphgen.ising_grid(3, 3)
+    skip = np.array([0], np.int64)
+    vmap, fi = dataloading.new_index(v, int(f["arity"].sum()) - 2)
+    with pytest.raises(IndexError):
+        dataloading.compute_var_map(v, f, fm, vmap, fi, dm, skip)
+
+
+@pytest.mark.parametrize("name", ["coin", "domains"])
+def test_file_loader_matches_reference(golden, name):
+    z = golden("g2_index_build.npz")
+    d = os.path.join(GOLDEN, "test_coin" if name == "coin" else "domains_graph")
+    ns = numbskull_amd.NumbSkull(directory=d, quiet=True)
+    quiet(ns.loadFGFromFile)
+    fg = ns.factorGraphs[0]
+    for attr in ("weight", "variable", "factor", "fmap", "vmap", "factor_index", "cstart"):
+        assert np.array_equal(getattr(fg, attr), z["%s_out_%s" % (name, attr)]), attr
+    assert np.array_equal(fg.var_value[0], fg.variable["initialValue"])
+    assert fg.weight_value.shape == (1, len(fg.weight))
+
+
+def test_meta_with_trailing_path_fields(tmp_path):
+    """The reference's own test/graph.meta carries 4 extra path fields."""
+    src = os.path.join(GOLDEN, "test_coin")
+    for fn in ("graph.weights", "graph.variables", "graph.factors"):
+        (tmp_path / fn).write_bytes(open(os.path.join(src, fn), "rb").read())
+    (tmp_path / "graph.meta").write_text(open(os.path.join(src, "graph.meta.orig")).read())
+    ns = numbskull_amd.NumbSkull(directory=str(tmp_path), quiet=True)
+    quiet(ns.loadFGFromFile)
+    assert len(ns.factorGraphs[0].variable) == 18
+
+
+def test_writer_roundtrip(tmp_path):
+    g = graphgen.ising_pairs(7, seed=1)
+    graphgen.write_graph(str(tmp_path), g[0], g[1], g[2], g[3])
+    ns = numbskull_amd.NumbSkull(directory=str(tmp_path), quiet=True)
+    quiet(ns.loadFGFromFile)
+    fg = ns.factorGraphs[0]
+    assert np.array_equal(fg.weight, g[0])
+    for k in ("isEvidence", "initialValue", "dataType", "cardinality"):
+        assert np.array_equal(fg.variable[k], g[1][k])
+    assert np.array_equal(fg.factor, g[2])
+    assert np.array_equal(fg.fmap, g[3])
+
+
+def test_reads_reference_generator_output(tmp_path):
+    """oracle/_ref/ising is the reference's own ising/ising.cpp compiled where it lies; our loader
+    must read what it writes (skipped where the reference tree never existed)."""
+    exe = os.path.join(REPO, "oracle", "_ref", "ising")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ising not built")
+    import subprocess
+    subprocess.check_call([exe], cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    ns = numbskull_amd.NumbSkull(directory=str(tmp_path), quiet=True)
+    quiet(ns.loadFGFromFile)
+    fg = ns.factorGraphs[0]
+    assert len(fg.variable) == 2000 and len(fg.factor) == 3000 and len(fg.weight) == 3
+    assert set(np.unique(fg.factor["factorFunction"])) == {3, 4}
+    assert np.all(fg.variable["isEvidence"] == 1)
+    # and our writer emits the same bytes for the same graph
+    out = tmp_path / "again"
+    graphgen.write_graph(str(out), fg.weight, fg.variable, fg.factor, fg.fmap)
+    for fn in ("graph.weights", "graph.variables", "graph.factors", "graph.meta"):
+        assert (out / fn).read_bytes() == (tmp_path / fn).read_bytes(), fn
+
+
+def test_unknown_factor_function_raises_not_implemented():
+    """inference.py:410-413 raises NotImplementedError; validation happens at graph creation,
+    before any device is touched, so this runs without a GPU."""
+    g = list(graphgen.ising_grid(3, 3))
+    g[2] = g[2].copy()
+    g[2]["factorFunction"][2] = 5
+    ns, fg = session(tuple(g))
+    with pytest.raises(NotImplementedError):
+        fg.inference(0, 1)
+
+
+def test_literal_head_index_out_of_range_raises_index_error():
+    g = graphgen.mixed_lr_graph(300, seed=1)
+    ns, fg = session(g)
+    with pytest.raises(IndexError):
+        fg.inference(0, 1)
+
+
+def test_fails_loudly_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    ns, fg = session(graphgen.ising_grid(4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fg.inference(0, 1)
+
+
+def test_factor_table_and_api_surface():
+    from numbskull_amd import inference, numbskull
+    assert inference.FACTORS["IMPLY_MLN"] == 13 and inference.FUNC_UFO == 30
+    assert len(inference.FACTORS) == 25
+    ns = numbskull_amd.NumbSkull(n_inference_epoch=7, quiet=True)
+    assert ns.n_inference_epoch == 7 and ns.sample_evidence is True and ns.nthreads == 1
+    assert ns.stepsize == 0.01 and ns.decay == 0.95 and ns.regularization == 2
+    assert [o["dest"] for _, o in numbskull.flags] == ["sample_evidence", "learn_non_evidence",
+                                                       "quiet", "verbose"]
+    assert numbskull_amd.__version__.startswith("0.1.1")

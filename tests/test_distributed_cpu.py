@@ -1,0 +1,161 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes run the SAME host code the GPU ranks run
+(shard formula, host-only graph planning with an owned range, exchange_values /
+merge_weight_deltas from numbskull_amd/distributed.py); the per-variable compute is stood in by
+the CPU oracle (tests may use it).  The result must equal a single-process emulation of the
+partitioned semantics: every rank samples its own range against the values the others had at the
+end of the previous sweep."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import graphgen, session, oracle_of, phases_from_colors, check_coloring
+from numbskull_amd.distributed import (shard_range, exchange_values, merge_weight_deltas)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _graph(kind):
+    if kind == "grid":
+        return graphgen.ising_grid(16, 16, weight=0.4)
+    if kind == "ragged":       # 225 variables: shards of 112 and 113 -> broadcast fallback
+        return graphgen.ising_grid(15, 15, weight=0.4)
+    rng = np.random.default_rng(2)
+    return graphgen.ising_grid(12, 12, weight=0.1, fixed=False, two_weights=True,
+                               evidence=rng.integers(0, 2, 144))
+
+
+def _rank_sweeps(rank, world, kind, nsweeps, learn, exchange):
+    """What one rank does; `exchange(values, values_evid, weights, start)` is the collective step."""
+    g = _graph(kind)
+    nvar = len(g[1])
+    ns, fg = session(g, seed=21)
+    fg.own_range = shard_range(rank, world, nvar)
+    color, info = fg.plan()
+    lo, hi = fg.own_range
+    assert np.all(color[:lo] == -1) and np.all(color[hi:] == -1) and np.all(color[lo:hi] >= 0)
+    assert info["nowned"] == hi - lo
+    check_coloring(fg, color)
+    order, ps = phases_from_colors(color)
+    og = oracle_of(fg)
+    vv, ve, wv, cnt = og.initial_state()
+    step = 0.01
+    for s in range(nsweeps):
+        start = wv.copy()
+        if learn:
+            assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 21, s) == 0
+            step *= 0.9
+        else:
+            assert og.gibbs_dev(order, ps, vv, wv, cnt, 21, s, True) == 0
+        exchange(vv, ve, wv, start)
+    return vv, ve, wv, cnt
+
+
+def _worker(rank, world, port, kind, nsweeps, learn, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def exchange(vv, ve, wv, start):
+        nvar = len(vv)
+        for arr in (vv, ve) if learn else (vv,):
+            t = torch.from_numpy(arr.astype(np.int8))
+            exchange_values(dist, t, world, nvar)
+            arr[:] = t.numpy()
+        if learn:
+            tw = torch.from_numpy(wv)
+            merge_weight_deltas(dist, tw, torch.from_numpy(start))
+    vv, ve, wv, cnt = _rank_sweeps(rank, world, kind, nsweeps, learn, exchange)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), vv=vv, ve=ve, wv=wv, cnt=cnt)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _emulate(world, kind, nsweeps, learn):
+    """Single-process statement of the same semantics (stale ghosts, delta-sum weights)."""
+    g = _graph(kind)
+    nvar = len(g[1])
+    ranks = []
+    for r in range(world):
+        ns, fg = session(g, seed=21)
+        fg.own_range = shard_range(r, world, nvar)
+        color, _ = fg.plan()
+        og = oracle_of(fg)
+        ranks.append((og, phases_from_colors(color), og.initial_state(), fg.own_range))
+    step = 0.01
+    for s in range(nsweeps):
+        starts = [st[2].copy() for _, _, st, _ in ranks]
+        for og, (order, ps), (vv, ve, wv, cnt), _ in ranks:
+            if learn:
+                og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 21, s)
+            else:
+                og.gibbs_dev(order, ps, vv, wv, cnt, 21, s, True)
+        step *= 0.9
+        for _, _, (vv, ve, wv, cnt), (lo, hi) in ranks:          # owners publish their slices
+            for _, _, (vv2, ve2, _, _), _ in ranks:
+                vv2[lo:hi] = vv[lo:hi]
+                ve2[lo:hi] = ve[lo:hi]
+        if learn:
+            total = sum(st[2] - s0 for (_, _, st, _), s0 in zip(ranks, starts))
+            for (_, _, st, _), s0 in zip(ranks, starts):
+                st[2][:] = s0 + total
+    return ranks
+
+
+@pytest.mark.parametrize("kind,learn", [("grid", False), ("ragged", False), ("learn", True)])
+def test_two_rank_gloo_matches_emulation(tmp_path, kind, learn):
+    world, nsweeps = 2, 5
+    mp.spawn(_worker, args=(world, _free_port(), kind, nsweeps, learn, str(tmp_path)), nprocs=world,
+             join=True)
+    ranks = _emulate(world, kind, nsweeps, learn)
+    got = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        _, _, (vv, ve, wv, cnt), (lo, hi) = ranks[r]
+        assert np.array_equal(got[r]["vv"], vv), (kind, r)
+        assert np.array_equal(got[r]["cnt"], cnt)
+        if learn:
+            assert np.array_equal(got[r]["ve"], ve)
+            assert np.allclose(got[r]["wv"], wv, rtol=0, atol=1e-15)
+    # replicas agree with each other after the exchange
+    assert np.array_equal(got[0]["vv"], got[1]["vv"])
+    if learn:
+        assert np.array_equal(got[0]["wv"], got[1]["wv"])
+        assert np.any(got[0]["wv"] != 0.1)
+
+
+def test_shard_formula_is_the_references():
+    # inference.py:17-18: start = shardID*nvar//nshards, end = (shardID+1)*nvar//nshards
+    for nvar in (0, 1, 7, 225, 10 ** 7):
+        for world in (1, 2, 3, 8):
+            b = [shard_range(r, world, nvar) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == nvar
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert all((r * nvar) // world == b[r][0] for r in range(world))
+
+
+def test_plan_colours_every_kind_of_graph():
+    for g, hbv in ((graphgen.ising_grid(9, 14), False), (graphgen.ising_pairs(30), False),
+                   (graphgen.lf_graph(0.1, [1.0, 0.5, 0.2], 6), False),
+                   (graphgen.mixed_lr_graph(2000, seed=8), True)):
+        ns, fg = session(g, head_by_vid=hbv)
+        color, info = fg.plan()
+        assert color.min() >= 0 and info["nowned"] == len(g[1])
+        assert info["ncolors"] == color.max() + 1
+        check_coloring(fg, color, hbv)
+    g = graphgen.ising_grid(50, 40)
+    color, info = session(g)[1].plan()
+    degree = 2.0 * len(g[2]) / 2000
+    # B_inf = 2 + 4 + degree*23 + 1 + 8 (106.9 B/update at degree 3.996)
+    assert info["ncolors"] == 2
+    assert abs(info["alg_bytes_inference"] / 2000 - (15 + 23 * degree)) < 1e-9

@@ -1,0 +1,382 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against
+
+  (1) the REFERENCE's own traces (tests/golden, captured from HazyResearch/numbskull) with the
+      sequential scan -- same trajectory, bit-exact on values / tallies / weights;
+  (2) the CPU oracle's device mode with the chromatic scan -- bit-exact on values, tallies and
+      weights for every factor function, regulariser and data type;
+  (3) exact marginals by enumeration -- |delta marginal| within the sampling tolerance stated
+      in each test.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import graph_from, GOLDEN
+from numbskull_amd import _lib, graphgen
+from util import (orc, quiet, session, oracle_of, phases_from_colors, check_coloring,
+                  exact_marginals)
+import numbskull_amd
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------
+# device primitives
+# ------------------------------------------------------------------------------------------
+def test_device_exp_equals_oracle_exp_bitwise():
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-50, 50, 400000), rng.uniform(-745.2, 709.8, 100000),
+                        rng.normal(0, 2, 400000),
+                        [0.0, -0.0, 1.0, -1.0, 709.782712893384, 709.79, -745.13, -745.14, -708.4,
+                         -720.0, np.inf, -np.inf, 1e-310, 5e-324]])
+    y = np.empty_like(x)
+    _lib.check(_lib.lib().nsk_selftest_exp(0, _lib.ptr(x), _lib.ptr(y), len(x)))
+    want = orc.exp_det(x[:20000])
+    assert np.array_equal(y[:20000].view(np.uint64), want.view(np.uint64))
+    tail = orc.exp_det(x[-5000:])
+    assert np.array_equal(y[-5000:].view(np.uint64), tail.view(np.uint64))
+    # and within 1 ulp of libm everywhere
+    ref = np.exp(x)
+    ok = np.abs(y - ref) <= np.spacing(ref)
+    assert np.all(ok | (np.isinf(ref) & np.isinf(y)))
+
+
+def test_device_philox_equals_oracle():
+    n = 4096
+    out = np.zeros(4 * n, np.uint32)
+    seed, sweep = 0x0123456789abcdef, 0x00000007deadbeef
+    _lib.check(_lib.lib().nsk_selftest_philox(0, seed, sweep, 1, n, _lib.ptr(out)))
+    for i in (0, 1, 2, 63, 64, 1000, n - 1):
+        want = orc.philox(seed & 0xffffffff, seed >> 32, i, 1, sweep & 0xffffffff, sweep >> 32)
+        assert out[4 * i:4 * i + 4].tolist() == want
+
+
+# ------------------------------------------------------------------------------------------
+# (1) sequential scan == the reference's own trajectory
+# ------------------------------------------------------------------------------------------
+G3_TAGS = ["grid4x5_w05", "grid32_w01", "mixed", "mixed_noev", "lf", "headquirk"]
+
+
+@pytest.mark.parametrize("tag", G3_TAGS)
+def test_sequential_inference_matches_reference_trace(golden, tag):
+    z = golden("g3_inference.npz")
+    seed, burn = int(z[tag + "_seed"]), int(z[tag + "_burn"])
+    se = bool(z[tag + "_sample_evidence"])
+    ns, fg = session(graph_from(z, tag), scan="sequential", seed=seed)
+    vals, counts = z[tag + "_var_value"], z[tag + "_count"]
+    fg.burnIn(burn, se)
+    assert np.array_equal(fg.var_value[0], vals[0])
+    for e in range(len(counts)):
+        fg.inference(0, 1, se)
+        assert np.array_equal(fg.var_value[0], vals[e + 1]), (tag, e)
+        assert np.array_equal(fg.count, counts[e]), (tag, e)
+    assert np.array_equal(fg.marginals, counts[-1] / 1.0)
+
+
+def _g4_cases():
+    for tag in ("pairs", "mixed", "lf"):
+        for reg in (0, 1, 2):
+            for lne in (0, 1):
+                for k in ((1, 3) if reg == 1 else (1,)):
+                    yield tag, reg, lne, k
+
+
+@pytest.mark.parametrize("tag,reg,lne,trunc", list(_g4_cases()))
+def test_sequential_learning_matches_reference_trace(golden, tag, reg, lne, trunc):
+    z = golden("g4_learning.npz")
+    name = "%s_r%d_l%d_k%d" % (tag, reg, lne, trunc)
+    ns, fg = session(graph_from(z, tag), scan="sequential", seed=int(z[name + "_seed"]))
+    ws, vvs, ves = z[name + "_weights"], z[name + "_var_value"], z[name + "_var_value_evid"]
+    # all 8 epochs in ONE call: the decay loop runs inside the library (factorgraph.py:206)
+    fg.learn(0, len(ws) - 1, 0.05, 0.9, reg, 0.02, trunc, learn_non_evidence=bool(lne))
+    assert np.array_equal(fg.var_value[0], vvs[-1])
+    assert np.array_equal(fg.var_value_evid[0], ves[-1])
+    assert np.array_equal(fg.weight_value[0], ws[-1]), (fg.weight_value[0], ws[-1])
+
+
+def test_config1_cli_run_matches_reference(golden, tmp_path):
+    """BASELINE config #1: `numbskull test -l 10 -i 10` (README.md:27), seed 1234."""
+    z = golden("g4_learning.npz")
+    coin = os.path.join(GOLDEN, "test_coin")
+    ns = quiet(numbskull_amd.numbskull.load,
+               [coin, "-l", "10", "-i", "10", "-o", str(tmp_path), "--quiet",
+                "--scan", "sequential", "--seed", "1234"])
+    quiet(ns.learning)
+    quiet(ns.inference)
+    fg = ns.factorGraphs[0]
+    assert np.array_equal(fg.weight_value[0], z["coin_cli_weights"])
+    assert abs(fg.weight_value[0][0] - 0.330407) < 1e-6
+    assert np.array_equal(fg.count, z["coin_cli_count"])
+    assert fg.count.tolist() == [7, 6, 8, 4, 7, 7, 4, 6, 7, 8, 6, 5, 6, 7, 8, 8, 10, 7]
+    assert np.array_equal(fg.var_value[0], z["coin_cli_var_value"])
+    assert np.array_equal(fg.var_value_evid[0], z["coin_cli_var_value_evid"])
+    assert (tmp_path / "inference_result.out.text").read_text() == str(z["coin_cli_probs_text"])
+    assert (tmp_path / "inference_result.out.weights.text").read_text() == \
+        str(z["coin_cli_weights_text"])
+
+
+def test_reference_test_py_parameters(golden):
+    """The reference's test.py run (-l 100 -i 100 -s 0.01 --regularization 2 -r 0.1), one thread."""
+    z = golden("g4_learning.npz")
+    coin = os.path.join(GOLDEN, "test_coin")
+    ns = quiet(numbskull_amd.numbskull.load,
+               [coin, "-l", "100", "-i", "100", "-s", "0.01", "--regularization", "2", "-r", "0.1",
+                "--quiet", "--scan", "sequential", "--seed", "99"])
+    quiet(ns.learning, 0, False)
+    quiet(ns.inference, 0, False)
+    assert np.array_equal(ns.factorGraphs[0].weight_value[0], z["coin_testpy_weights"])
+    assert np.array_equal(ns.factorGraphs[0].count, z["coin_testpy_count"])
+
+
+# ------------------------------------------------------------------------------------------
+# (2) chromatic scan == oracle device mode, bit for bit
+# ------------------------------------------------------------------------------------------
+def _small_graphs(golden):
+    z3, z4 = golden("g3_inference.npz"), golden("g4_learning.npz")
+    return {
+        "grid4x5": (graph_from(z3, "grid4x5_w05"), False),
+        "grid32": (graph_from(z3, "grid32_w05"), False),
+        "mixed": (graph_from(z3, "mixed"), False),
+        "lf": (graph_from(z3, "lf"), False),
+        "headquirk": (graph_from(z3, "headquirk"), False),
+        "headquirk_vid": (graph_from(z3, "headquirk"), True),
+        "pairs": (graph_from(z4, "pairs"), False),
+        "grid57x33": (graphgen.ising_grid(57, 33, weight=0.3), False),
+        "lr3000": (graphgen.mixed_lr_graph(3000, seed=5, nweights=40), True),
+        "lr_bigcard": (_big_cardinality_graph(), False),
+    }
+
+
+def _big_cardinality_graph():
+    """cardinalities 20 and 200: exercises the two-pass draw and the int32 value type"""
+    g = list(graphgen.mixed_lr_graph(400, seed=3, nweights=9))
+    var = g[1].copy()
+    cat = np.nonzero(var["dataType"] == 1)[0]
+    var["cardinality"][cat[::2]] = 20
+    var["cardinality"][cat[1::2]] = 200
+    var["initialValue"] = np.minimum(var["initialValue"], var["cardinality"] - 1)
+    fm = g[3].copy()
+    fm["dense_equal_to"] = fm["dense_equal_to"] % var["cardinality"][fm["vid"]]
+    g[1], g[3] = var, fm
+    # the head lookup quirk needs edge index < nvar: keep only non-IMPLY functions
+    fac = g[2].copy()
+    fac["factorFunction"][fac["factorFunction"] == 13] = 1
+    fac["factorFunction"][fac["factorFunction"] == 17] = 14
+    g[2] = fac
+    return tuple(g)
+
+
+GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
+          "lr3000", "lr_bigcard"]
+
+
+@pytest.mark.parametrize("name", GRAPHS)
+@pytest.mark.parametrize("sample_evidence", [True, False])
+def test_chromatic_inference_equals_oracle(golden, name, sample_evidence):
+    g, hbv = _small_graphs(golden)[name]
+    ns, fg = session(g, seed=77, head_by_vid=hbv)
+    og = oracle_of(fg, hbv)
+    color = fg.colors()
+    check_coloring(fg, color, hbv)
+    order, ps = phases_from_colors(color)
+    vv, _, wv, cnt = og.initial_state()
+    sweep = 0
+    fg.burnIn(3, sample_evidence)
+    for _ in range(3):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 77, sweep, sample_evidence, burnin=True) == 0
+        sweep += 1
+    assert np.array_equal(fg.var_value[0], vv)
+    for rounds in (1, 4):
+        fg.inference(0, rounds, sample_evidence)
+        for _ in range(rounds):
+            assert og.gibbs_dev(order, ps, vv, wv, cnt, 77, sweep, sample_evidence) == 0
+            sweep += 1
+        assert np.array_equal(fg.var_value[0], vv), name
+        assert np.array_equal(fg.count, cnt), name
+
+
+@pytest.mark.parametrize("name", ["mixed", "lf", "pairs", "grid32", "lr3000", "lr_bigcard",
+                                  "headquirk"])
+@pytest.mark.parametrize("reg,trunc", [(0, 1), (1, 1), (1, 3), (2, 1)])
+@pytest.mark.parametrize("lne", [False, True])
+def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
+    g, hbv = _small_graphs(golden)[name]
+    if name == "grid32":                      # make the grid learnable: free weight, evidence
+        w = g[0].copy()
+        w["isFixed"] = False
+        rng = np.random.default_rng(1)
+        g = graphgen.ising_grid(32, 32, weight=0.2, fixed=False, two_weights=True,
+                                evidence=rng.integers(0, 2, 32 * 32))
+    ns, fg = session(g, seed=5, head_by_vid=hbv)
+    og = oracle_of(fg, hbv)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, _ = og.initial_state()
+    step, decay, sweep = 0.01, 0.9, 0
+    for chunk in (1, 3):
+        fg.learn(0, chunk, step, decay, reg, 0.05, trunc, learn_non_evidence=lne)
+        for _ in range(chunk):
+            assert og.learn_dev(order, ps, vv, ve, wv, step, reg, 0.05, trunc, lne, 5, sweep) == 0
+            step *= decay
+            sweep += 1
+        assert np.array_equal(fg.var_value[0], vv), name
+        assert np.array_equal(fg.var_value_evid[0], ve), name
+        assert np.array_equal(fg.weight_value[0], wv), (name, fg.weight_value[0], wv)
+    assert np.any(wv != og.weight["initialValue"]) or og.weight["isFixed"].all()
+
+
+def test_learning_then_inference_continue_from_state(golden):
+    """learning leaves var_value where inference picks up and host-side edits
+    between calls are honoured (the distributed reference patches arrays in place)."""
+    g, _ = _small_graphs(golden)["mixed"]
+    ns, fg = session(g, seed=9)
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, cnt = og.initial_state()
+    fg.learn(0, 2, 0.02, 0.95, 2, 0.01, 1)
+    step = 0.02
+    for s in range(2):
+        og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 9, s)
+        step *= 0.95
+    # patch state on the host, as numbskull_master.py:213-224 does between epochs
+    fg.var_value[0][::2] = 0
+    fg.weight_value[0][0] += 0.5
+    vv[::2] = 0
+    wv[0] += 0.5
+    fg.inference(1, 5, True)
+    og.gibbs_dev(order, ps, vv, wv, cnt, 9, 2, True, burnin=True)
+    for s in range(5):
+        og.gibbs_dev(order, ps, vv, wv, cnt, 9, 3 + s, True)
+    assert np.array_equal(fg.var_value[0], vv)
+    assert np.array_equal(fg.count, cnt)
+    fg.clear()
+    assert not fg.count.any()
+
+
+def test_ghost_variables_are_skipped(golden):
+    """isEvidence == 4 ("not owned", inference.py:21-23) and own_range both exclude variables."""
+    g = list(_small_graphs(golden)["grid32"][0])
+    var = g[1].copy()
+    var["isEvidence"][100:300] = 4
+    g[1] = var
+    ns, fg = session(tuple(g), seed=3)
+    og = oracle_of(fg)
+    color = fg.colors()
+    assert np.all(color[100:300] == -1) and np.all(color[:100] >= 0)
+    order, ps = phases_from_colors(color)
+    vv, _, wv, cnt = og.initial_state()
+    fg.inference(0, 6, True)
+    for s in range(6):
+        og.gibbs_dev(order, ps, vv, wv, cnt, 3, s, True)
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+    assert not fg.count[100:300].any()
+
+
+# ------------------------------------------------------------------------------------------
+# (3) statistics: sampled marginals vs exact enumeration (RNG-independent)
+# ------------------------------------------------------------------------------------------
+def _boolean_zoo():
+    """9 boolean variables under every boolean factor function (dataType 0: the Gibbs conditional
+    is the exact conditional of the joint, so enumeration gives the stationary marginals)."""
+    from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar
+    spec = [(4, [0]), (3, [0, 1]), (1, [1, 2, 3]), (2, [2, 4]), (0, [3, 5, 6]), (7, [4, 5, 7]),
+            (8, [6, 7, 8]), (9, [8, 0, 1]), (13, [2, 6, 8]), (3, [5, 7]), (4, [8])]
+    nvar = 9
+    variable = np.zeros(nvar, Variable)
+    variable["cardinality"] = 2
+    factor = np.zeros(len(spec), Factor)
+    fmap = np.zeros(sum(len(m) for _, m in spec), FactorToVar)
+    e = 0
+    for i, (fn, members) in enumerate(spec):
+        factor[i] = (fn, i % 4, 1.0, len(members), e)
+        for m in members:
+            fmap[e]["vid"] = m
+            e += 1
+    weight = np.zeros(4, Weight)
+    weight["initialValue"] = [0.6, -0.5, 0.9, 0.3]
+    return weight, variable, factor, fmap, np.zeros(nvar, np.bool_), e
+
+
+def test_marginals_match_exact_enumeration(golden):
+    """Sampled vs enumerated marginals (RNG-free ground truth) on a 4x3 Ising grid (w=0.5), a
+    graph with every boolean factor function, and the data-programming graph: 200k chromatic
+    sweeps; a marginal's standard error is <= 0.5/sqrt(N_eff) ~ 2.5e-3 at N_eff ~ N/5, so the
+    tolerance is 0.01."""
+    lf = graphgen.lf_graph(0.3, [1.0, 0.5], 3, seed=4)
+    for g, hbv in ((graphgen.ising_grid(4, 3, weight=0.5), False), (_boolean_zoo(), True),
+                   (lf, False)):
+        ns, fg = session(g, seed=123, head_by_vid=hbv)
+        og = oracle_of(fg, hbv)
+        fg.inference(100, 200000, True)
+        exact = exact_marginals(og, og.weight["initialValue"].astype(float))
+        for v, p in exact.items():
+            c0 = int(fg.cstart[v])
+            if len(p) == 2:
+                got = fg.marginals[c0]
+                assert abs(got - p[1]) < 0.01, (v, got, p[1])
+            else:
+                got = fg.marginals[c0:c0 + len(p)]
+                assert np.max(np.abs(got - p)) < 0.01, (v, got, p)
+
+
+def test_chromatic_and_sequential_agree_statistically():
+    """Same stationary distribution from both scan orders: mean magnetisation of a 24x24 grid,
+    w=0.2 (well inside the disordered phase), 3000 sweeps each; tolerance 0.01."""
+    g = graphgen.ising_grid(24, 24, weight=0.2)
+    res = []
+    for scan in ("chromatic", "sequential"):
+        ns, fg = session(g, seed=42, scan=scan)
+        fg.inference(50, 3000 if scan == "chromatic" else 300, True)
+        res.append(fg.marginals.mean())
+    assert abs(res[0] - 0.5) < 0.01 and abs(res[1] - 0.5) < 0.03
+
+
+# ------------------------------------------------------------------------------------------
+# full-size properties (BASELINE configs #2/#3 shapes)
+# ------------------------------------------------------------------------------------------
+def test_full_size_grid_properties():
+    """1000x1000 grid (config #2): determinism under a seed, tally bounds, symmetry, and agreement
+    of one block of rows with the oracle (bit-exact) after several sweeps."""
+    g = graphgen.ising_grid(1000, 1000, weight=0.1)
+    ns, fg = session(g, seed=20240601)
+    info = fg.info()
+    assert info["ncolors"] == 2 and info["nowned"] == 1000000 and info["value_bytes"] == 1
+    assert abs(info["alg_bytes_inference"] / 1e6 - 106.9) < 0.1
+    fg.inference(5, 20, True)
+    assert fg.count.min() >= 0 and fg.count.max() <= 20
+    assert abs(fg.marginals.mean() - 0.5) < 0.01
+    ns2, fg2 = session(g, seed=20240601)
+    fg2.inference(5, 20, True)
+    assert np.array_equal(fg.count, fg2.count) and np.array_equal(fg.var_value, fg2.var_value)
+    ns3, fg3 = session(g, seed=1)
+    fg3.inference(5, 20, True)
+    assert not np.array_equal(fg.count, fg3.count)
+    # oracle on the full grid for 3 sweeps (seconds), bit-exact
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, _, wv, cnt = og.initial_state()
+    ns4, fg4 = session(g, seed=8)
+    fg4.inference(1, 2, True)
+    og.gibbs_dev(order, ps, vv, wv, cnt, 8, 0, True, burnin=True)
+    og.gibbs_dev(order, ps, vv, wv, cnt, 8, 1, True)
+    og.gibbs_dev(order, ps, vv, wv, cnt, 8, 2, True)
+    assert np.array_equal(fg4.var_value[0], vv) and np.array_equal(fg4.count, cnt)
+
+
+def test_zero_weight_grid_is_uniform():
+    g = graphgen.ising_grid(300, 300, weight=0.0)
+    ns, fg = session(g, seed=4)
+    fg.inference(0, 400, True)
+    assert abs(fg.marginals.mean() - 0.5) < 2e-3
+    assert abs(fg.marginals.std() - 0.5 / np.sqrt(400)) < 2e-3
+
+
+def test_learning_recovers_planted_pair_weights():
+    """ising.cpp:202-318 scenario (known-answer 2): weights (1, 1, 0.5) planted;
+    mini-batch phases of 1000 visits need step*batch < 2, so step 1e-3."""
+    g = graphgen.ising_pairs(1000, 1.0, 1.0, 0.5, seed=7)
+    ns, fg = session(g, seed=7)
+    fg.learn(0, 600, 1e-3, 0.995, 2, 1e-3, 1)
+    w = fg.weight_value[0]
+    assert abs(w[0] - 1.0) < 0.25 and abs(w[1] - 1.0) < 0.25 and abs(w[2] - 0.5) < 0.25, w

@@ -1,0 +1,94 @@
+"""Shared helpers of the parity tests."""
+
+import io
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numbskull_amd                                   # noqa: E402
+from numbskull_amd import graphgen                     # noqa: E402
+from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar   # noqa: E402
+from oracle import binding as orc                      # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def session(g, **kw):
+    """NumbSkull session + its FactorGraph for a (weight, variable, factor, fmap, dm, edges) tuple."""
+    kw.setdefault("quiet", True)
+    ns = numbskull_amd.NumbSkull(**kw)
+    w, v, f, fm, dm, edges = [x.copy() if isinstance(x, np.ndarray) else x for x in g]
+    ns.loadFactorGraph(w, v, f, fm, dm, int(edges))
+    return ns, ns.factorGraphs[0]
+
+
+def oracle_of(fg, head_by_vid=False):
+    """Oracle view of the arrays a product FactorGraph holds."""
+    return orc.Graph(fg.weight, fg.variable, fg.factor, fg.fmap, fg.vmap, fg.factor_index,
+                     head_by_vid=head_by_vid)
+
+
+def phases_from_colors(color):
+    """Colour-major visiting order the oracle's device mode needs: (order, phase_start)."""
+    color = np.asarray(color)
+    sampled = np.nonzero(color >= 0)[0]
+    order = sampled[np.argsort(color[sampled], kind="stable")]
+    ncol = int(color.max()) + 1 if len(sampled) else 0
+    phase_start = np.zeros(ncol + 1, np.int64)
+    np.cumsum(np.bincount(color[sampled], minlength=ncol), out=phase_start[1:])
+    return order.astype(np.int64), phase_start
+
+
+def check_coloring(fg, color, head_by_vid=False):
+    """No two sampled variables of one colour may share a factor (or be tied by the literal
+    head index of IMPLY_MLN-type factors)."""
+    f, fm = fg.factor, fg.fmap
+    for fid in range(len(f)):
+        s, a = int(f[fid]["ftv_offset"]), int(f[fid]["arity"])
+        members = set(int(x) for x in fm["vid"][s:s + a])
+        if int(f[fid]["factorFunction"]) in (13, 16, 17) and not head_by_vid:
+            members.add(s + a - 1)
+        cols = [color[m] for m in members if color[m] >= 0]
+        assert len(cols) == len(set(cols)), ("colour clash in factor", fid)
+
+
+def exact_marginals(og, weight_value, sample_mask=None):
+    """Brute-force marginals of a tiny graph from the oracle's potentials: enumerates every
+    assignment of the sampled variables (others fixed at initialValue)."""
+    var = og.variable
+    n = len(var)
+    free = [i for i in range(n) if sample_mask is None or sample_mask[i]]
+    cards = [int(var[i]["cardinality"]) for i in free]
+    total = int(np.prod(cards))
+    assert total <= 1 << 18
+    base = var["initialValue"].astype(np.int64).copy()
+    nf = len(og.factor)
+    logp = np.zeros(total)
+    states = np.zeros((total, len(free)), np.int64)
+    for s in range(total):
+        x, r = base.copy(), s
+        for j, i in enumerate(free):
+            x[i] = r % cards[j]
+            states[s, j] = x[i]
+            r //= cards[j]
+        e = 0.0
+        for fid in range(nf):
+            rc, val = og.eval_factor(fid, -1, 0, x)
+            assert rc == 0
+            e += weight_value[int(og.factor[fid]["weightId"])] * val
+        logp[s] = e
+    p = np.exp(logp - logp.max())
+    p /= p.sum()
+    out = {}
+    for j, i in enumerate(free):
+        out[i] = np.array([p[states[:, j] == k].sum() for k in range(cards[j])])
+    return out
