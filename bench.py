@@ -66,9 +66,9 @@ def cpu_baseline(fg, learning, budget_s=20.0):
     rc = run(1)
     t1 = time.time() - t0
     assert rc == 0
-    extra = int(max(0, min(20, (budget_s - t1) // max(t1, 1e-3))))
     total_t, total_n = t1, 1
-    if extra > 0:
+    while total_t < budget_s * 0.6:            # a bounded sample: ~10-20 s of CPU work
+        extra = int(max(1, min(200, (budget_s * 0.75 - total_t) // max(total_t / total_n, 1e-3))))
         t0 = time.time()
         run(extra)
         total_t += time.time() - t0
