@@ -45,6 +45,87 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_phase(DevGraph<VT> g, int p
     }
 }
 
+// Fast path of one colour class: binary variables whose factors are symmetric boolean functions.
+// One wave owns 64 consecutive positions and walks their inlined adjacency tile: every stream word
+// is one coalesced 256-byte load for the wave; member words are followed by a 1-byte gather of the
+// neighbour's value.  Words are fetched NSK_CHUNK at a time so that the stream loads, then the
+// gathers, are all in flight together.  Same arithmetic, in the same order, as k_gibbs_phase.
+#define NSK_CHUNK 8
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pbegin, int pend,
+                                                          int wb_base, int nblocks,
+                                                          int sample_evidence, int burnin,
+                                                          uint32_t k0, uint32_t k1, uint32_t s0,
+                                                          uint32_t s1) {
+    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
+    if (lb < 0) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6);
+    const int p = pbegin + wave * 64 + lane;
+    if (p - lane >= pend) return;                         // whole wave beyond the range
+    const bool valid = p < pend;
+    const uint32_t info = valid ? g.p_info[p] : 0u;
+    const int v = valid ? g.p_vid[p] : 0;
+    const uint32_t off = g.wb_off[wb_base + wave];
+    const int len = (int)g.wb_len[wb_base + wave];        // wave-uniform
+    const uint32_t *sp = g.adj + off + lane;
+
+    double p0 = 0.0, p1 = 0.0;
+    FactorAcc acc;
+    acc.rem = 0; acc.func = F_NOOP; acc.w = 0.0; acc.first = -1;
+    acc.allnz = true; acc.any1 = false; acc.alleq = true;
+    for (int j0 = 0; j0 < len; j0 += NSK_CHUNK) {
+        uint32_t wd[NSK_CHUNK];
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++)
+            wd[i] = (j0 + i < len) ? sp[(size_t)(j0 + i) * 64] : NSK_PAD_WORD;
+        // which words are members?  (pure ALU on the words just loaded)
+        bool ismem[NSK_CHUNK];
+        int r = acc.rem;
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) {
+            ismem[i] = r > 0;
+            if (r > 0) r--;
+            else if (wd[i] != NSK_PAD_WORD) r = NSK_HDR_NOTHER(wd[i]);
+        }
+        int xv[NSK_CHUNK];
+        double wv[NSK_CHUNK];
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) {
+            xv[i] = ismem[i] ? (int)g.val[wd[i]] : 0;
+            wv[i] = (!ismem[i] && wd[i] != NSK_PAD_WORD) ? g.w[NSK_HDR_WID(wd[i])] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) {
+            bool done = false;
+            if (ismem[i]) {
+                acc.member(xv[i]);
+                done = acc.rem == 0;
+            } else if (wd[i] != NSK_PAD_WORD) {
+                acc.start(wd[i], wv[i]);
+                done = acc.rem == 0;
+            }
+            if (done) {
+                double e0, e1;
+                acc.values(e0, e1);
+                const double t0 = acc.w * e0, t1 = acc.w * e1;
+                p0 = p0 + t0;
+                p1 = p1 + t1;
+            }
+        }
+    }
+    if (!valid) return;
+    const int ev = NSK_INFO_EV(info);
+    if (!(ev == 0 || sample_evidence)) return;
+    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const double z0 = nsk_exp(p0);
+    const double z1 = z0 + nsk_exp(p1);
+    const double z = u53(rr.x, rr.y) * z1;
+    const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    g.val[v] = (VT)nv;
+    if (!burnin) g.cnt_pos[p] += nv;
+}
+
 // One colour class of one learning sweep: sample_and_sgd (learning.py:46-125) per variable with the
 // weights frozen for the phase; gradients go to the fixed-point accumulators, k_apply_weights
 // turns them into the weight update at the end of the phase (DESIGN.md "device-mode learning").
@@ -157,6 +238,18 @@ __global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stream, uin
     if (i >= n) return;
     const u32x4 r = philox4x32(k0, k1, (uint32_t)i, stream, s0, s1);
     out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+// position-indexed tally deltas of the fast path -> int64 master copy at cstart[vid]
+__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(int32_t *cnt_pos, const int32_t *p_cnt,
+                                                               long long *total, int npos) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i >= npos) return;
+    const int d = cnt_pos[i];
+    if (d) {
+        total[p_cnt[i]] += (long long)d;
+        cnt_pos[i] = 0;
+    }
 }
 
 // ---- sequential validation scan: one lane walks variable ids in order with MT19937 -----------
@@ -277,7 +370,8 @@ struct nsk_graph {
     double *f_feat = nullptr, *w = nullptr, *logtab = nullptr;
     uint8_t *w_fixed = nullptr;
     void *val = nullptr, *val_evid = nullptr;
-    int32_t *cnt = nullptr;
+    int32_t *cnt = nullptr, *cnt_pos = nullptr;
+    uint32_t *adj = nullptr, *wb_off = nullptr, *wb_len = nullptr;
     long long *cnt_total = nullptr, *G = nullptr;
     uint32_t *K = nullptr, *T = nullptr;
     MTState *mt_np = nullptr, *mt_py = nullptr;
@@ -362,6 +456,7 @@ static DevGraph<VT> view(nsk_graph *g) {
     d.w = g->w; d.w_fixed = g->w_fixed; d.logtab = g->logtab;
     d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
     d.G = g->G; d.K = g->K; d.T = g->T;
+    d.adj = g->adj; d.wb_off = g->wb_off; d.wb_len = g->wb_len; d.cnt_pos = g->cnt_pos;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
     return d;
@@ -413,7 +508,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
     UP(f_head); UP(f_off); UP(f_wid); UP(f_feat); UP(m_vid); UP(m_deo); UP(v_card); UP(v_pos);
-    UP(w_fixed); UP(logtab);
+    UP(w_fixed); UP(logtab); UP(adj); UP(wb_off); UP(wb_len);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
@@ -426,6 +521,8 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = upload_values(g, g->val_evid, c.v_init.data(), nvar); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_total, (size_t)c.ncount); if (rc) return rc;
+    rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos); if (rc) return rc;
+    HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (c.npos ? c.npos : 1) * sizeof(int32_t), g->stream));
     rc = dev_alloc(g, &g->G, (size_t)c.nweight); if (rc) return rc;
     rc = dev_alloc(g, &g->K, (size_t)c.nweight); if (rc) return rc;
     rc = dev_alloc(g, &g->T, (size_t)c.nweight); if (rc) return rc;
@@ -500,6 +597,10 @@ static int fold_counts(nsk_graph *g) {
     if (n > 0)
         k_fold_counts<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
             g->cnt, g->cnt_total, n);
+    const int np = (int)g->c.npos;
+    if (np > 0 && g->c.nfast > 0)
+        k_fold_counts_pos<<<dim3((np + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+            g->cnt_pos, g->p_cnt, g->cnt_total, np);
     HIPCHECK(hipGetLastError());
     g->cnt_dirty = false;
     return NSK_OK;
@@ -520,12 +621,22 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
         const size_t nphase = g->c.phase_start.size() - 1;
         for (int64_t s = 0; s < nsweeps; s++) {
             for (size_t ph = 0; ph < nphase; ph++) {
-                const int b = (int)g->c.phase_start[ph], e = (int)g->c.phase_start[ph + 1];
-                if (e <= b) continue;
-                k_gibbs_phase<VT><<<dim3((e - b + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                    d, b, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
-                    (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
-                g->launches++;
+                const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
+                const int e = (int)g->c.phase_start[ph + 1];
+                if (fe > fb) {      // inlined-adjacency kernel
+                    const int nblocks = (fe - fb + NSK_BLOCK - 1) / NSK_BLOCK;
+                    k_gibbs_fast<VT><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        d, fb, fe, (int)g->c.phase_wb_base[ph], nblocks, sample_evidence, burnin,
+                        (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep,
+                        (uint32_t)(g->sweep >> 32));
+                    g->launches++;
+                }
+                if (e > fe) {       // generic CSR kernel
+                    k_gibbs_phase<VT><<<dim3((e - fe + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        d, fe, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                    g->launches++;
+                }
             }
             g->sweep++;
         }
@@ -620,6 +731,7 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
     if (count && g->c.ncount) {
         HIPCHECK(hipMemcpyAsync(g->cnt_total, count, (size_t)g->c.ncount * sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
         HIPCHECK(hipMemsetAsync(g->cnt, 0, (size_t)g->c.ncount * sizeof(int32_t), g->stream));
+        if (g->c.npos) HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (size_t)g->c.npos * sizeof(int32_t), g->stream));
         g->cnt_dirty = false;
     }
     HIPCHECK(hipStreamSynchronize(g->stream));
@@ -666,8 +778,8 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->ncolors = (int64_t)c.phase_start.size() - 1;
     info->value_bytes = c.vbytes;
     info->device_bytes = 0;
-    info->nfast = 0;
-    info->ngeneric = c.npos;
+    info->nfast = c.nfast;
+    info->ngeneric = c.npos - c.nfast;
     info->alg_bytes_inference = c.alg_bytes_inference;
     info->alg_bytes_learning = c.alg_bytes_learning;
     info->sweeps_done = 0;

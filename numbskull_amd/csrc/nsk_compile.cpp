@@ -139,14 +139,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             err = fmt("Factor function %lld (used in factor %lld) is not implemented.", fn, f);
             return NSK_E_FACTOR_FUNC;
         }
+        if (fa.weightId < 0 || fa.weightId >= nw) {      // potential() reads it even for NOOP
+            err = fmt("factor %lld: weightId %lld outside weights", f, fa.weightId);
+            return NSK_E_INDEX;
+        }
         if (fn == -1) return NSK_OK;
         const int64_t s = fa.ftv_offset, e = fa.ftv_offset + fa.arity;
         if (fa.arity < 0 || s < 0 || e > nedge) {
             err = fmt("factor %lld: members [%lld, %lld) outside fmap", f, s, e);
-            return NSK_E_INDEX;
-        }
-        if (fa.weightId < 0 || fa.weightId >= nw) {
-            err = fmt("factor %lld: weightId %lld outside weights", f, fa.weightId);
             return NSK_E_INDEX;
         }
         int64_t need = 0;       // member positions the function reads regardless of arity
@@ -288,23 +288,110 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
     }
 
-    // ---- positions: colour-major, id order inside a colour -------------------------------------
+    // ---- fast-path eligibility (DESIGN.md "fast path"): a binary dataType-0 variable whose every
+    // factor is a symmetric boolean function it is a member of, with <= 6 other members and a
+    // weight id below 2^24; and featureValue == 1 so that learning can use the same stream.
+    std::vector<uint8_t> fast(nvar, 0);
+    auto fast_function = [](int fn) { return fn == -1 || (fn >= 0 && fn <= 4); };
+    for (int64_t v = 0; v < nvar; v++) {
+        if (c.color[v] < 0) continue;
+        const nsk_variable &var = d->variable[v];
+        if (var.cardinality != 2 || var.dataType != 0) continue;
+        const nsk_vtf &vt = d->vmap[var.vtf_offset];
+        bool ok = vt.factor_index_length <= 4096;
+        for (int64_t j = 0; ok && j < vt.factor_index_length; j++) {
+            const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
+            if (!fast_function(fa.factorFunction) || fa.weightId >= (1 << 24) || fa.featureValue != 1.0 ||
+                fa.arity > 64) { ok = false; break; }
+            if (fa.factorFunction == -1) continue;
+            int64_t others = 0;
+            bool member = false;
+            for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++) {
+                if (d->fmap[l].vid == v) member = true; else others++;
+            }
+            if (!member || others > 6) ok = false;
+        }
+        fast[v] = ok;
+    }
+
+    // ---- positions: colour-major; inside a colour the fast variables first, id order ----------
     c.phase_start.assign((size_t)ncolors + 1, 0);
+    c.phase_fast_end.assign((size_t)ncolors, 0);
     for (int64_t v = 0; v < nvar; v++)
-        if (c.color[v] >= 0) c.phase_start[c.color[v] + 1]++;
+        if (c.color[v] >= 0) {
+            c.phase_start[c.color[v] + 1]++;
+            if (fast[v]) c.phase_fast_end[c.color[v]]++;
+        }
     for (int32_t k = 0; k < ncolors; k++) c.phase_start[k + 1] += c.phase_start[k];
+    for (int32_t k = 0; k < ncolors; k++) c.phase_fast_end[k] += c.phase_start[k];
     c.npos = c.phase_start[ncolors];
     c.p_vid.resize(c.npos); c.p_info.resize(c.npos); c.p_slot.resize(c.npos);
     c.p_cnt.resize(c.npos); c.p_init.resize(c.npos);
     c.v_pos.assign(nvar, -1);
     {
-        std::vector<int64_t> next(c.phase_start.begin(), c.phase_start.end() - 1);
+        std::vector<int64_t> next_fast(c.phase_start.begin(), c.phase_start.end() - 1);
+        std::vector<int64_t> next_gen(c.phase_fast_end);
         for (int64_t v = 0; v < nvar; v++)
             if (c.color[v] >= 0) {
-                int64_t p = next[c.color[v]]++;
+                int64_t p = fast[v] ? next_fast[c.color[v]]++ : next_gen[c.color[v]]++;
                 c.p_vid[p] = (int32_t)v;
                 c.v_pos[v] = (int32_t)p;
             }
+    }
+    // ---- inlined adjacency streams of the fast variables, one column-major tile per 64 positions
+    c.phase_wb_base.assign((size_t)ncolors + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++)
+        c.phase_wb_base[k + 1] = c.phase_wb_base[k] + (c.phase_fast_end[k] - c.phase_start[k] + 63) / 64;
+    const int64_t nwb = c.phase_wb_base[ncolors];
+    c.wb_off.assign((size_t)nwb, 0); c.wb_len.assign((size_t)nwb, 0);
+    {
+        auto lane_words = [&](int64_t v, std::vector<uint32_t> *out) -> int64_t {
+            const nsk_variable &var = d->variable[v];
+            const nsk_vtf &vt = d->vmap[var.vtf_offset];
+            int64_t n = 0;
+            for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
+                uint32_t others = 0;
+                if (fa.factorFunction != -1)
+                    for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++)
+                        if (d->fmap[l].vid != v) others++;
+                if (out) {
+                    out->push_back(((uint32_t)(fa.factorFunction + 1) << 27) | (others << 24) |
+                                   (uint32_t)fa.weightId);
+                    if (fa.factorFunction != -1)
+                        for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++)
+                            if (d->fmap[l].vid != v) out->push_back((uint32_t)d->fmap[l].vid);
+                }
+                n += 1 + others;
+            }
+            return n;
+        };
+        uint64_t total = 0;
+        for (int32_t k = 0; k < ncolors; k++) {
+            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
+                int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+                int64_t len = 0;
+                for (int64_t p = p0; p < p1; p++) len = std::max(len, lane_words(c.p_vid[p], nullptr));
+                c.wb_off[c.phase_wb_base[k] + b] = (uint32_t)total;
+                c.wb_len[c.phase_wb_base[k] + b] = (uint32_t)len;
+                total += (uint64_t)len * 64;
+                if (total >= ((uint64_t)1 << 32)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
+            }
+        }
+        c.adj.assign((size_t)total, 0xFFFFFFFFu);
+        std::vector<uint32_t> words;
+        for (int32_t k = 0; k < ncolors; k++) {
+            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
+                int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+                const uint64_t off = c.wb_off[c.phase_wb_base[k] + b];
+                for (int64_t p = p0; p < p1; p++) {
+                    words.clear();
+                    lane_words(c.p_vid[p], &words);
+                    for (size_t j = 0; j < words.size(); j++) c.adj[off + 64 * j + (p - p0)] = words[j];
+                    c.nfast++;
+                }
+            }
+        }
     }
     int64_t nslot = 0, nlist = 0;
     for (int64_t p = 0; p < c.npos; p++) {

@@ -21,6 +21,15 @@ struct Compiled {
     // colouring
     std::vector<int32_t> color;         // [nvar], -1 = not sampled by this handle
     std::vector<int64_t> phase_start;   // [ncolors+1] positions
+    // Inside a phase the "fast" variables (binary, symmetric boolean factors: inlined adjacency
+    // streams) come first, the rest (generic CSR kernel) after: [phase_start, phase_fast_end) fast.
+    std::vector<int64_t> phase_fast_end;   // [ncolors]
+    std::vector<int64_t> phase_wb_base;    // [ncolors+1] first wave-block of each phase
+    std::vector<uint32_t> wb_off;          // [nwb] word offset of a wave-block's stream
+    std::vector<uint32_t> wb_len;          // [nwb] words per lane (column-major: word j of lane i
+                                           //       at wb_off + 64*j + i)
+    std::vector<uint32_t> adj;             // inlined adjacency words (DESIGN.md "fast path")
+    int64_t nfast = 0;
     // per position
     std::vector<int32_t> p_vid, p_slot, p_cnt;
     std::vector<uint32_t> p_info;

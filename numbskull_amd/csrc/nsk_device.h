@@ -176,9 +176,75 @@ struct DevGraph {
     long long *G;               // fixed-point gradient sum
     uint32_t *K;                // visits
     uint32_t *T;                // truncating visits (L1)
+    // fast path: inlined adjacency streams (DESIGN.md "fast path") and a position-indexed tally
+    const uint32_t *adj;        // words; column-major 64-lane tiles
+    const uint32_t *wb_off;     // [nwb] first word of a wave-block's tile
+    const uint32_t *wb_len;     // [nwb] words per lane
+    int32_t *cnt_pos;           // [npos] tally delta of binary fast-path variables, by position
     int32_t nvar;
     int32_t head_by_vid;
 };
+
+// ------------------------------------------------------------------------------------------
+// fast path: stream words
+//   header  = (function+1) << 27 | nother << 24 | weightId      (0xFFFFFFFF = padding)
+//   member  = variable id of a member other than the sampled variable
+// The sampled variable is binary and a member of every factor in its stream; all functions are
+// symmetric boolean ones, so a factor's value for candidate k follows from three facts about
+// the OTHER members: all non-zero? any == 1? all equal (and to what)?
+// ------------------------------------------------------------------------------------------
+#define NSK_PAD_WORD 0xFFFFFFFFu
+#define NSK_HDR_FUNC(h) ((int)((h) >> 27) - 1)
+#define NSK_HDR_NOTHER(h) ((int)(((h) >> 24) & 7u))
+#define NSK_HDR_WID(h) ((int)((h) & 0xFFFFFFu))
+
+struct FactorAcc {
+    double w;
+    int func, rem, first;
+    bool allnz, any1, alleq;
+    __device__ __forceinline__ void start(uint32_t hdr, double weight) {
+        func = NSK_HDR_FUNC(hdr); rem = NSK_HDR_NOTHER(hdr); w = weight;
+        first = -1; allnz = true; any1 = false; alleq = true;
+    }
+    __device__ __forceinline__ void member(int x) {
+        allnz = allnz && (x != 0);
+        any1 = any1 || (x == 1);
+        if (first < 0) first = x; else alleq = alleq && (x == first);
+        rem--;
+    }
+    // value of the factor with the sampled variable at 0 / at 1 (inference.py:162-200)
+    __device__ __forceinline__ void values(double &e0, double &e1) const {
+        switch (func) {
+        case F_EQUAL:
+            e0 = (alleq && (first < 0 || first == 0)) ? 1.0 : -1.0;
+            e1 = (alleq && (first < 0 || first == 1)) ? 1.0 : -1.0;
+            break;
+        case F_AND:
+        case F_ISTRUE:
+            e0 = -1.0; e1 = allnz ? 1.0 : -1.0;
+            break;
+        case F_OR:
+            e0 = any1 ? 1.0 : -1.0; e1 = 1.0;
+            break;
+        case F_IMPLY_NATURAL:
+            e0 = 0.0; e1 = allnz ? 1.0 : 0.0;
+            break;
+        default:            // NOOP
+            e0 = 0.0; e1 = 0.0;
+            break;
+        }
+    }
+};
+
+// blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, not a
+// contract): give every XCD one contiguous eighth of the logical blocks so that the value lines
+// neighbouring waves share are fetched into one L2 instead of eight.  Launch 8*ceil(n/8) blocks;
+// returns -1 for the surplus.
+__device__ __forceinline__ int xcd_logical_block(int b, int nblocks) {
+    const int per = (nblocks + 7) >> 3;
+    const int lb = (b & 7) * per + (b >> 3);
+    return lb < nblocks ? lb : -1;
+}
 
 // member value at absolute edge index l with the sampled variable hypothetically at `value`
 template <typename VT>
