@@ -155,6 +155,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    copy_gbs = None
+    if rank == 0:
+        cg = C.c_double()
+        if L.nsk_selftest_stream(local_rank, 1 << 30, 16, 10, C.byref(cg)) == 0:
+            copy_gbs = cg.value           # achievable HBM copy rate on this GPU, same run
     if rank == 0:
         alg_sweep = info["alg_bytes_learning"] if learning else info["alg_bytes_inference"]
         nlaunch = max(1, launches.value)
@@ -183,7 +188,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_update": alg_sweep * world / nvar,
-                         "kernel": "k_learn_phase" if learning else "k_gibbs_phase",
+                         "kernel": "k_learn_phase" if learning else
+                         ("k_gibbs_fast" if info["nfast"] else "k_gibbs_phase"),
+                         "stream_copy_GBs": copy_gbs,
                          "launches": nlaunch, "avg_launch_us": launch_s * 1e6},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -24,7 +24,7 @@ SYMBOLS = (
     "nsk_set_seed", "nsk_set_scan", "nsk_gibbs_sweeps", "nsk_learn_sweeps", "nsk_graph_get_info",
     "nsk_graph_get_colors", "nsk_graph_plan", "nsk_profile_begin", "nsk_profile_end", "nsk_device_buffer",
     "nsk_set_stream", "nsk_synchronize", "nsk_compute_var_map", "nsk_parse_factors",
-    "nsk_selftest_exp", "nsk_selftest_philox", "nsk_device_count", "nsk_last_error", "nsk_version",
+    "nsk_selftest_exp", "nsk_selftest_philox", "nsk_selftest_stream", "nsk_device_count", "nsk_last_error", "nsk_version",
 )
 
 
@@ -87,6 +87,7 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.nsk_device_count.argtypes = [C.POINTER(C.c_int)]
         L.nsk_selftest_exp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        L.nsk_selftest_stream.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.nsk_selftest_philox.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64,
                                           C.c_void_p]
         _lib = L

@@ -45,32 +45,21 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_phase(DevGraph<VT> g, int p
     }
 }
 
+// ---------------------------------------------------------------------------------------------
 // Fast path of one colour class: binary variables whose factors are symmetric boolean functions.
-// One wave owns 64 consecutive positions and walks their inlined adjacency tile: every stream word
-// is one coalesced 256-byte load for the wave; member words are followed by a 1-byte gather of the
+// One wave owns 64 consecutive positions and walks their inlined adjacency tile; every stream word
+// is one coalesced 256-byte load for the wave, member words are followed by a 1-byte gather of the
 // neighbour's value.  Words are fetched NSK_CHUNK at a time so that the stream loads, then the
-// gathers, are all in flight together.  Same arithmetic, in the same order, as k_gibbs_phase.
+// gathers, are all in flight together.  Same float64 operations, in the same order, as
+// k_gibbs_phase (potential(): product, then add, in factor-list order).
+// ---------------------------------------------------------------------------------------------
 #define NSK_CHUNK 8
-template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pbegin, int pend,
-                                                          int wb_base, int nblocks,
-                                                          int sample_evidence, int burnin,
-                                                          uint32_t k0, uint32_t k1, uint32_t s0,
-                                                          uint32_t s1) {
-    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
-    if (lb < 0) return;
-    const int lane = (int)(threadIdx.x & 63);
-    const int wave = lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6);
-    const int p = pbegin + wave * 64 + lane;
-    if (p - lane >= pend) return;                         // whole wave beyond the range
-    const bool valid = p < pend;
-    const uint32_t info = valid ? g.p_info[p] : 0u;
-    const int v = valid ? g.p_vid[p] : 0;
-    const uint32_t off = g.wb_off[wb_base + wave];
-    const int len = (int)g.wb_len[wb_base + wave];        // wave-uniform
-    const uint32_t *sp = g.adj + off + lane;
 
-    double p0 = 0.0, p1 = 0.0;
+// Tile with per-lane headers: every lane parses its own word sequence.
+template <typename VT>
+__device__ __forceinline__ void tile_potentials_dynamic(const DevGraph<VT> &g, const VT *val,
+                                                        const uint32_t *sp, int len, double &p0,
+                                                        double &p1) {
     FactorAcc acc;
     acc.rem = 0; acc.func = F_NOOP; acc.w = 0.0; acc.first = -1;
     acc.allnz = true; acc.any1 = false; acc.alleq = true;
@@ -79,8 +68,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
 #pragma unroll
         for (int i = 0; i < NSK_CHUNK; i++)
             wd[i] = (j0 + i < len) ? sp[(size_t)(j0 + i) * 64] : NSK_PAD_WORD;
-        // which words are members?  (pure ALU on the words just loaded)
-        bool ismem[NSK_CHUNK];
+        bool ismem[NSK_CHUNK];          // pure ALU on the words just loaded
         int r = acc.rem;
 #pragma unroll
         for (int i = 0; i < NSK_CHUNK; i++) {
@@ -92,7 +80,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
         double wv[NSK_CHUNK];
 #pragma unroll
         for (int i = 0; i < NSK_CHUNK; i++) {
-            xv[i] = ismem[i] ? (int)g.val[wd[i]] : 0;
+            xv[i] = ismem[i] ? (int)val[wd[i]] : 0;
             wv[i] = (!ismem[i] && wd[i] != NSK_PAD_WORD) ? g.w[NSK_HDR_WID(wd[i])] : 0.0;
         }
 #pragma unroll
@@ -114,6 +102,99 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
             }
         }
     }
+}
+
+// Uniform tile: the header sequence is shared by the 64 lanes, so the factor state machine
+// (function, members left, weight) lives in scalar registers and every branch is wave-uniform;
+// the stream holds member words only.
+template <typename VT>
+__device__ __forceinline__ void tile_potentials_uniform(const DevGraph<VT> &g, const VT *val,
+                                                        const uint32_t *sp, int len, int hb, int nent,
+                                                        double &p0, double &p1) {
+    int e = -1, rem = 0, func = F_NOOP, m = 0;          // wave-uniform
+    double w = 0.0;
+    int first = -1;
+    bool allnz = true, any1 = false, alleq = true;
+    auto finish = [&]() {
+        double e0, e1;
+        switch (func) {
+        case F_EQUAL:
+            e0 = (alleq && (first < 0 || first == 0)) ? 1.0 : -1.0;
+            e1 = (alleq && (first < 0 || first == 1)) ? 1.0 : -1.0;
+            break;
+        case F_AND:
+        case F_ISTRUE: e0 = -1.0; e1 = allnz ? 1.0 : -1.0; break;
+        case F_OR: e0 = any1 ? 1.0 : -1.0; e1 = 1.0; break;
+        case F_IMPLY_NATURAL: e0 = 0.0; e1 = allnz ? 1.0 : 0.0; break;
+        default: e0 = 0.0; e1 = 0.0; break;
+        }
+        const double t0 = w * e0, t1 = w * e1;
+        p0 = p0 + t0;
+        p1 = p1 + t1;
+    };
+    auto advance = [&]() {              // open the next entry; entries without members close at once
+        for (;;) {
+            e++;
+            if (e >= nent) { rem = -1; return; }
+            const uint32_t h = __builtin_amdgcn_readfirstlane(g.tile_hdr[hb + e]);
+            func = NSK_HDR_FUNC(h);
+            rem = NSK_HDR_NOTHER(h);
+            w = g.w[NSK_HDR_WID(h)];
+            m = 0; first = -1; allnz = true; any1 = false; alleq = true;
+            if (rem > 0) return;
+            finish();
+        }
+    };
+    advance();
+    for (int j0 = 0; j0 < len; j0 += NSK_CHUNK) {
+        uint32_t wd[NSK_CHUNK];
+        int xv[NSK_CHUNK];
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) wd[i] = (j0 + i < len) ? sp[(size_t)(j0 + i) * 64] : 0u;
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) xv[i] = (j0 + i < len) ? (int)val[wd[i]] : 0;
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) {
+            if (j0 + i < len && rem > 0) {
+                const int x = xv[i];
+                allnz = allnz && (x != 0);
+                any1 = any1 || (x == 1);
+                if (m == 0) first = x; else alleq = alleq && (x == first);
+                m++;
+                if (--rem == 0) { finish(); advance(); }
+            }
+        }
+    }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pbegin, int pend,
+                                                          int wb_base, int nblocks,
+                                                          int sample_evidence, int burnin,
+                                                          uint32_t k0, uint32_t k1, uint32_t s0,
+                                                          uint32_t s1) {
+    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
+    if (lb < 0) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    const int p = pbegin + wave * 64 + lane;
+    if (pbegin + wave * 64 >= pend) return;               // whole wave beyond the range
+    const bool valid = p < pend;
+    const uint32_t info = valid ? g.p_info[p] : 0u;
+    const int v = valid ? g.p_vid[p] : 0;
+    const int wb = wb_base + wave;
+    const uint32_t off = __builtin_amdgcn_readfirstlane(g.wb_off[wb]);
+    const int len = (int)__builtin_amdgcn_readfirstlane(g.wb_len[wb]);
+    const uint32_t hb = __builtin_amdgcn_readfirstlane(g.wb_hdr[wb]);
+    const uint32_t *sp = g.adj + off + lane;
+
+    double p0 = 0.0, p1 = 0.0;
+    if (hb != NSK_PAD_WORD)
+        tile_potentials_uniform(g, g.val, sp, len, (int)hb,
+                                (int)__builtin_amdgcn_readfirstlane(g.wb_nent[wb]), p0, p1);
+    else
+        tile_potentials_dynamic(g, g.val, sp, len, p0, p1);
+
     if (!valid) return;
     const int ev = NSK_INFO_EV(info);
     if (!(ev == 0 || sample_evidence)) return;
@@ -123,7 +204,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     const double z = u53(rr.x, rr.y) * z1;
     const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     g.val[v] = (VT)nv;
-    if (!burnin) g.cnt_pos[p] += nv;
+    if (!burnin) g.cnt_pos[p] += (uint8_t)nv;
 }
 
 // One colour class of one learning sweep: sample_and_sgd (learning.py:46-125) per variable with the
@@ -227,6 +308,13 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts(int32_t *delta, long 
     delta[i] = 0;
 }
 
+template <typename T>
+__global__ __launch_bounds__(NSK_BLOCK) void k_stream_copy(const T *__restrict__ src, T *__restrict__ dst,
+                                                           long long n) {
+    const long long stride = (long long)gridDim.x * NSK_BLOCK;
+    for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 __global__ void k_selftest_exp(const double *x, double *y, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = nsk_exp(x[i]);
@@ -241,7 +329,7 @@ __global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stream, uin
 }
 
 // position-indexed tally deltas of the fast path -> int64 master copy at cstart[vid]
-__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(int32_t *cnt_pos, const int32_t *p_cnt,
+__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(uint8_t *cnt_pos, const int32_t *p_cnt,
                                                                long long *total, int npos) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= npos) return;
@@ -370,8 +458,11 @@ struct nsk_graph {
     double *f_feat = nullptr, *w = nullptr, *logtab = nullptr;
     uint8_t *w_fixed = nullptr;
     void *val = nullptr, *val_evid = nullptr;
-    int32_t *cnt = nullptr, *cnt_pos = nullptr;
-    uint32_t *adj = nullptr, *wb_off = nullptr, *wb_len = nullptr;
+    int32_t *cnt = nullptr;
+    uint8_t *cnt_pos = nullptr;
+    int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
+    uint32_t *adj = nullptr, *wb_off = nullptr, *wb_len = nullptr, *wb_hdr = nullptr, *wb_nent = nullptr,
+             *tile_hdr = nullptr;
     long long *cnt_total = nullptr, *G = nullptr;
     uint32_t *K = nullptr, *T = nullptr;
     MTState *mt_np = nullptr, *mt_py = nullptr;
@@ -457,6 +548,7 @@ static DevGraph<VT> view(nsk_graph *g) {
     d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
     d.G = g->G; d.K = g->K; d.T = g->T;
     d.adj = g->adj; d.wb_off = g->wb_off; d.wb_len = g->wb_len; d.cnt_pos = g->cnt_pos;
+    d.wb_hdr = g->wb_hdr; d.wb_nent = g->wb_nent; d.tile_hdr = g->tile_hdr;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
     return d;
@@ -508,7 +600,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
     UP(f_head); UP(f_off); UP(f_wid); UP(f_feat); UP(m_vid); UP(m_deo); UP(v_card); UP(v_pos);
-    UP(w_fixed); UP(logtab); UP(adj); UP(wb_off); UP(wb_len);
+    UP(w_fixed); UP(logtab); UP(adj); UP(wb_off); UP(wb_len); UP(wb_hdr); UP(wb_nent); UP(tile_hdr);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
@@ -522,7 +614,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &g->cnt, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_total, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos); if (rc) return rc;
-    HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (c.npos ? c.npos : 1) * sizeof(int32_t), g->stream));
+    HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (c.npos ? c.npos : 1), g->stream));
     rc = dev_alloc(g, &g->G, (size_t)c.nweight); if (rc) return rc;
     rc = dev_alloc(g, &g->K, (size_t)c.nweight); if (rc) return rc;
     rc = dev_alloc(g, &g->T, (size_t)c.nweight); if (rc) return rc;
@@ -591,16 +683,22 @@ int nsk_synchronize(nsk_graph *g) {
     return NSK_OK;
 }
 
+static int fold_position_tally(nsk_graph *g) {
+    const int np = (int)g->c.npos;
+    if (np > 0 && g->c.nfast > 0 && g->pos_tally_sweeps > 0)
+        k_fold_counts_pos<<<dim3((np + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+            g->cnt_pos, g->p_cnt, g->cnt_total, np);
+    g->pos_tally_sweeps = 0;
+    return NSK_OK;
+}
+
 static int fold_counts(nsk_graph *g) {
     if (!g->cnt_dirty) return NSK_OK;
     const int n = (int)g->c.ncount;
     if (n > 0)
         k_fold_counts<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
             g->cnt, g->cnt_total, n);
-    const int np = (int)g->c.npos;
-    if (np > 0 && g->c.nfast > 0)
-        k_fold_counts_pos<<<dim3((np + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-            g->cnt_pos, g->p_cnt, g->cnt_total, np);
+    fold_position_tally(g);
     HIPCHECK(hipGetLastError());
     g->cnt_dirty = false;
     return NSK_OK;
@@ -639,6 +737,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 }
             }
             g->sweep++;
+            if (!burnin && ++g->pos_tally_sweeps == 255) fold_position_tally(g);   // uint8 tally is full
         }
         HIPCHECK(hipGetLastError());
     }
@@ -731,7 +830,8 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
     if (count && g->c.ncount) {
         HIPCHECK(hipMemcpyAsync(g->cnt_total, count, (size_t)g->c.ncount * sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
         HIPCHECK(hipMemsetAsync(g->cnt, 0, (size_t)g->c.ncount * sizeof(int32_t), g->stream));
-        if (g->c.npos) HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (size_t)g->c.npos * sizeof(int32_t), g->stream));
+        if (g->c.npos) HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (size_t)g->c.npos, g->stream));
+        g->pos_tally_sweeps = 0;
         g->cnt_dirty = false;
     }
     HIPCHECK(hipStreamSynchronize(g->stream));
@@ -867,6 +967,34 @@ int nsk_selftest_philox(int device, uint64_t seed, uint64_t sweep, uint32_t stre
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpy(out, d, 4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     (void)hipFree(d);
+    return NSK_OK;
+}
+
+int nsk_selftest_stream(int device, int64_t nbytes, int width, int iters, double *gbytes_per_s) {
+    if (nbytes < 4096 || (width != 4 && width != 16) || iters < 1 || !gbytes_per_s) return fail(NSK_E_INVALID, "bad argument");
+    HIPCHECK(hipSetDevice(device));
+    nbytes &= ~(int64_t)4095;
+    void *a = nullptr, *b = nullptr;
+    HIPCHECK(hipMalloc(&a, nbytes));
+    HIPCHECK(hipMalloc(&b, nbytes));
+    HIPCHECK(hipMemset(a, 1, nbytes));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    const long long n = nbytes / width;
+    const int grid = 256 * 8;
+    for (int it = -1; it < iters; it++) {
+        if (it == 0) HIPCHECK(hipEventRecord(e0, 0));
+        if (width == 4) k_stream_copy<uint32_t><<<dim3(grid), dim3(NSK_BLOCK)>>>((const uint32_t *)a, (uint32_t *)b, n);
+        else k_stream_copy<uint4><<<dim3(grid), dim3(NSK_BLOCK)>>>((const uint4 *)a, (uint4 *)b, n);
+    }
+    HIPCHECK(hipEventRecord(e1, 0));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    *gbytes_per_s = 2.0 * (double)nbytes * iters / ((double)ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
     return NSK_OK;
 }
 

@@ -366,28 +366,70 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
             return n;
         };
+        // pass 1: shape of every tile.  Uniform tile = all its lanes have the same header sequence.
+        c.wb_hdr.assign((size_t)nwb, 0xFFFFFFFFu);
+        c.wb_nent.assign((size_t)nwb, 0);
+        std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
+        std::vector<uint32_t> words, hdrs, hdrs0;
+        auto headers_of = [&](const std::vector<uint32_t> &w, std::vector<uint32_t> &h) {
+            h.clear();
+            for (size_t j = 0; j < w.size();) {
+                h.push_back(w[j]);
+                j += 1 + ((w[j] >> 24) & 7u);
+            }
+        };
         uint64_t total = 0;
         for (int32_t k = 0; k < ncolors; k++) {
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
-                int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+                const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+                const int64_t wb = c.phase_wb_base[k] + b;
                 int64_t len = 0;
-                for (int64_t p = p0; p < p1; p++) len = std::max(len, lane_words(c.p_vid[p], nullptr));
-                c.wb_off[c.phase_wb_base[k] + b] = (uint32_t)total;
-                c.wb_len[c.phase_wb_base[k] + b] = (uint32_t)len;
+                bool uniform = true;
+                for (int64_t p = p0; p < p1; p++) {
+                    words.clear();
+                    lane_words(c.p_vid[p], &words);
+                    len = std::max<int64_t>(len, (int64_t)words.size());
+                    headers_of(words, p == p0 ? hdrs0 : hdrs);
+                    if (p != p0 && hdrs != hdrs0) uniform = false;
+                }
+                if (uniform && hdrs0.size() <= 0xFFFF) {
+                    auto it = hdr_pool.find(hdrs0);
+                    if (it == hdr_pool.end()) {
+                        it = hdr_pool.emplace(hdrs0, (uint32_t)c.tile_hdr.size()).first;
+                        c.tile_hdr.insert(c.tile_hdr.end(), hdrs0.begin(), hdrs0.end());
+                    }
+                    c.wb_hdr[wb] = it->second;
+                    c.wb_nent[wb] = (uint32_t)hdrs0.size();
+                    len -= (int64_t)hdrs0.size();            // members only
+                }
+                c.wb_off[wb] = (uint32_t)total;
+                c.wb_len[wb] = (uint32_t)len;
                 total += (uint64_t)len * 64;
                 if (total >= ((uint64_t)1 << 32)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
             }
         }
+        if (c.tile_hdr.empty()) c.tile_hdr.push_back(0);
+        // pass 2: fill the tiles (padding lanes of a uniform tile read variable 0: harmless)
         c.adj.assign((size_t)total, 0xFFFFFFFFu);
-        std::vector<uint32_t> words;
         for (int32_t k = 0; k < ncolors; k++) {
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
-                int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
-                const uint64_t off = c.wb_off[c.phase_wb_base[k] + b];
+                const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+                const int64_t wb = c.phase_wb_base[k] + b;
+                const uint64_t off = c.wb_off[wb];
+                const bool uniform = c.wb_hdr[wb] != 0xFFFFFFFFu;
+                if (uniform)
+                    for (uint64_t j = 0; j < (uint64_t)c.wb_len[wb] * 64; j++) c.adj[off + j] = 0;
                 for (int64_t p = p0; p < p1; p++) {
                     words.clear();
                     lane_words(c.p_vid[p], &words);
-                    for (size_t j = 0; j < words.size(); j++) c.adj[off + 64 * j + (p - p0)] = words[j];
+                    size_t out = 0;
+                    for (size_t j = 0; j < words.size();) {
+                        const uint32_t nother = (words[j] >> 24) & 7u;
+                        if (!uniform) c.adj[off + 64 * (out++) + (p - p0)] = words[j];
+                        for (uint32_t m = 1; m <= nother; m++)
+                            c.adj[off + 64 * (out++) + (p - p0)] = words[j + m];
+                        j += 1 + nother;
+                    }
                     c.nfast++;
                 }
             }

@@ -4,6 +4,7 @@
 
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,11 @@ struct Compiled {
     std::vector<uint32_t> wb_len;          // [nwb] words per lane (column-major: word j of lane i
                                            //       at wb_off + 64*j + i)
     std::vector<uint32_t> adj;             // inlined adjacency words (DESIGN.md "fast path")
+    // A tile whose 64 lanes share one header sequence (same function, member count and weight per
+    // entry) keeps the headers once, in tile_hdr, and its stream holds member words only.
+    std::vector<uint32_t> wb_hdr;          // [nwb] offset into tile_hdr, 0xFFFFFFFF = per-lane headers
+    std::vector<uint32_t> wb_nent;         // [nwb] entries of a uniform tile
+    std::vector<uint32_t> tile_hdr;
     int64_t nfast = 0;
     // per position
     std::vector<int32_t> p_vid, p_slot, p_cnt;

@@ -180,7 +180,11 @@ struct DevGraph {
     const uint32_t *adj;        // words; column-major 64-lane tiles
     const uint32_t *wb_off;     // [nwb] first word of a wave-block's tile
     const uint32_t *wb_len;     // [nwb] words per lane
-    int32_t *cnt_pos;           // [npos] tally delta of binary fast-path variables, by position
+    const uint32_t *wb_hdr;     // [nwb] offset into tile_hdr (uniform tile) or NSK_PAD_WORD
+    const uint32_t *wb_nent;    // [nwb] entries of a uniform tile
+    const uint32_t *tile_hdr;   // shared header sequences of uniform tiles
+    uint8_t *cnt_pos;           // [npos] tally delta of binary fast-path variables, by position
+                                //        (folded into the int64 master copy every 255 sweeps)
     int32_t nvar;
     int32_t head_by_vid;
 };
