@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -58,16 +59,16 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_phase(DevGraph<VT> g, int p
 // Tile with per-lane headers: every lane parses its own word sequence.
 template <typename VT>
 __device__ __forceinline__ void tile_potentials_dynamic(const DevGraph<VT> &g, const VT *val,
-                                                        const uint32_t *sp, int len, double &p0,
+                                                        const uint4 *sp, int len, double &p0,
                                                         double &p1) {
     FactorAcc acc;
     acc.rem = 0; acc.func = F_NOOP; acc.w = 0.0; acc.first = -1;
     acc.allnz = true; acc.any1 = false; acc.alleq = true;
     for (int j0 = 0; j0 < len; j0 += NSK_CHUNK) {
-        uint32_t wd[NSK_CHUNK];
-#pragma unroll
-        for (int i = 0; i < NSK_CHUNK; i++)
-            wd[i] = (j0 + i < len) ? sp[(size_t)(j0 + i) * 64] : NSK_PAD_WORD;
+        const uint4 qa = sp[(size_t)(j0 / 4) * 64];
+        const uint4 qb = (j0 + 4 < len) ? sp[(size_t)(j0 / 4 + 1) * 64]
+                                        : uint4{NSK_PAD_WORD, NSK_PAD_WORD, NSK_PAD_WORD, NSK_PAD_WORD};
+        const uint32_t wd[NSK_CHUNK] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
         bool ismem[NSK_CHUNK];          // pure ALU on the words just loaded
         int r = acc.rem;
 #pragma unroll
@@ -104,67 +105,105 @@ __device__ __forceinline__ void tile_potentials_dynamic(const DevGraph<VT> &g, c
     }
 }
 
-// Uniform tile: the header sequence is shared by the 64 lanes, so the factor state machine
-// (function, members left, weight) lives in scalar registers and every branch is wave-uniform;
-// the stream holds member words only.
-template <typename VT>
+// Uniform tile: all 64 lanes share one slot program (<= 8 member slots).  The program words and
+// the per-slot weight terms (prog_w: weight*value for a satisfied / unsatisfied entry, already
+// multiplied by k_refresh_prog_weights) arrive by scalar loads, the member ids by one or two
+// 16-byte loads per lane, the neighbour values by byte gathers.  The per-slot update is
+// straight-line boolean algebra: program flags are wave-uniform, lane facts are lane masks.
+// Padding slots (program word 0) and slots that do not close an entry add an exact 0.0.
+struct SlotState {
+    int first;
+    bool allnz, any1, alleq;
+};
+
+__device__ __forceinline__ void slot_step(SlotState &st, uint32_t s, double thi, double tlo, int x,
+                                          double &p0, double &p1) {
+    const bool F = (s >> 27) & 1u, ig = (s >> 29) & 1u;          // uniform
+    const uint32_t code = (s >> 24) & 7u;
+    const bool nz = ig || (x != 0), one = !ig && (x == 1);
+    st.alleq = F || (st.alleq && (x == st.first));
+    st.allnz = (F || st.allnz) && nz;
+    st.any1 = (!F && st.any1) || one;
+    st.first = F ? x : st.first;
+    // "satisfied" for candidate 0 / 1 (inference.py:162-200)
+    const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
+    const bool b0 = (isEq && st.alleq && (ig || st.first == 0)) || (isOr && st.any1);
+    const bool b1 = (isEq && st.alleq && (ig || st.first == 1)) || (isAnd && st.allnz) || isOr;
+    p0 = p0 + (b0 ? thi : tlo);
+    p1 = p1 + (b1 ? thi : tlo);
+}
+
+// Entries with exactly one other member and one function code for the whole tile (the shape of
+// pairwise models such as the Ising grid): no state, two compares per slot.
+template <int CODE>
+__device__ __forceinline__ void pair_step(double thi, double tlo, int x, double &p0, double &p1) {
+    bool b0, b1;
+    if (CODE == 4) { b0 = x == 0; b1 = x == 1; }            // EQUAL
+    else if (CODE == 2) { b0 = x == 1; b1 = true; }          // OR
+    else { b0 = false; b1 = x != 0; }                        // AND / ISTRUE / IMPLY_NATURAL
+    p0 = p0 + (b0 ? thi : tlo);
+    p1 = p1 + (b1 ? thi : tlo);
+}
+
+template <typename VT, int KIND>
 __device__ __forceinline__ void tile_potentials_uniform(const DevGraph<VT> &g, const VT *val,
-                                                        const uint32_t *sp, int len, int hb, int nent,
+                                                        const uint4 *sp, int len, uint32_t prog,
                                                         double &p0, double &p1) {
-    int e = -1, rem = 0, func = F_NOOP, m = 0;          // wave-uniform
-    double w = 0.0;
-    int first = -1;
-    bool allnz = true, any1 = false, alleq = true;
-    auto finish = [&]() {
-        double e0, e1;
-        switch (func) {
-        case F_EQUAL:
-            e0 = (alleq && (first < 0 || first == 0)) ? 1.0 : -1.0;
-            e1 = (alleq && (first < 0 || first == 1)) ? 1.0 : -1.0;
-            break;
-        case F_AND:
-        case F_ISTRUE: e0 = -1.0; e1 = allnz ? 1.0 : -1.0; break;
-        case F_OR: e0 = any1 ? 1.0 : -1.0; e1 = 1.0; break;
-        case F_IMPLY_NATURAL: e0 = 0.0; e1 = allnz ? 1.0 : 0.0; break;
-        default: e0 = 0.0; e1 = 0.0; break;
-        }
-        const double t0 = w * e0, t1 = w * e1;
-        p0 = p0 + t0;
-        p1 = p1 + t1;
-    };
-    auto advance = [&]() {              // open the next entry; entries without members close at once
-        for (;;) {
-            e++;
-            if (e >= nent) { rem = -1; return; }
-            const uint32_t h = __builtin_amdgcn_readfirstlane(g.tile_hdr[hb + e]);
-            func = NSK_HDR_FUNC(h);
-            rem = NSK_HDR_NOTHER(h);
-            w = g.w[NSK_HDR_WID(h)];
-            m = 0; first = -1; allnz = true; any1 = false; alleq = true;
-            if (rem > 0) return;
-            finish();
-        }
-    };
-    advance();
-    for (int j0 = 0; j0 < len; j0 += NSK_CHUNK) {
-        uint32_t wd[NSK_CHUNK];
-        int xv[NSK_CHUNK];
+    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
+    if (len <= 0) return;
+    SlotState st = {0, true, false, true};
+    const uint4 qa = sp[0];
+    uint32_t sl[4];
+    double th[4], tl[4];
 #pragma unroll
-        for (int i = 0; i < NSK_CHUNK; i++) wd[i] = (j0 + i < len) ? sp[(size_t)(j0 + i) * 64] : 0u;
+    for (int i = 0; i < 4; i++) { sl[i] = KIND ? 0u : pp[i]; th[i] = tw[2 * i]; tl[i] = tw[2 * i + 1]; }
+    const int x0 = (int)val[qa.x], x1 = (int)val[qa.y], x2 = (int)val[qa.z], x3 = (int)val[qa.w];
+    if (KIND) {
+        pair_step<KIND>(th[0], tl[0], x0, p0, p1);
+        pair_step<KIND>(th[1], tl[1], x1, p0, p1);
+        pair_step<KIND>(th[2], tl[2], x2, p0, p1);
+        pair_step<KIND>(th[3], tl[3], x3, p0, p1);
+    } else {
+        slot_step(st, sl[0], th[0], tl[0], x0, p0, p1);
+        slot_step(st, sl[1], th[1], tl[1], x1, p0, p1);
+        slot_step(st, sl[2], th[2], tl[2], x2, p0, p1);
+        slot_step(st, sl[3], th[3], tl[3], x3, p0, p1);
+    }
+    if (len > 4) {
+        const uint4 qb = sp[64];
 #pragma unroll
-        for (int i = 0; i < NSK_CHUNK; i++) xv[i] = (j0 + i < len) ? (int)val[wd[i]] : 0;
-#pragma unroll
-        for (int i = 0; i < NSK_CHUNK; i++) {
-            if (j0 + i < len && rem > 0) {
-                const int x = xv[i];
-                allnz = allnz && (x != 0);
-                any1 = any1 || (x == 1);
-                if (m == 0) first = x; else alleq = alleq && (x == first);
-                m++;
-                if (--rem == 0) { finish(); advance(); }
-            }
+        for (int i = 0; i < 4; i++) { sl[i] = KIND ? 0u : pp[4 + i]; th[i] = tw[8 + 2 * i]; tl[i] = tw[9 + 2 * i]; }
+        const int x4 = (int)val[qb.x], x5 = (int)val[qb.y], x6 = (int)val[qb.z], x7 = (int)val[qb.w];
+        if (KIND) {
+            pair_step<KIND>(th[0], tl[0], x4, p0, p1);
+            pair_step<KIND>(th[1], tl[1], x5, p0, p1);
+            pair_step<KIND>(th[2], tl[2], x6, p0, p1);
+            pair_step<KIND>(th[3], tl[3], x7, p0, p1);
+        } else {
+            slot_step(st, sl[0], th[0], tl[0], x4, p0, p1);
+            slot_step(st, sl[1], th[1], tl[1], x5, p0, p1);
+            slot_step(st, sl[2], th[2], tl[2], x6, p0, p1);
+            slot_step(st, sl[3], th[3], tl[3], x7, p0, p1);
         }
     }
+}
+
+// prog_w[2i], prog_w[2i+1] = weight * (value when satisfied, value when not) of program word i, or
+// (0, 0) when the slot does not close an entry.  The products are the reference's own
+// `weight * eval_factor` (inference.py:68-70), so adding them reproduces potential() exactly.
+__global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32_t *prog, const double *w,
+                                                                    double *prog_w, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i >= n) return;
+    const uint32_t s = prog[i];
+    const uint32_t code = (s >> 24) & 7u;
+    const bool last = (s >> 28) & 1u;
+    const double hi = code == 0u ? 0.0 : 1.0;
+    const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+    const double wt = w[s & 0xFFFFFFu];
+    prog_w[2 * i] = last ? wt * hi : 0.0;
+    prog_w[2 * i + 1] = last ? wt * lo : 0.0;
 }
 
 template <typename VT>
@@ -182,19 +221,22 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     const bool valid = p < pend;
     const uint32_t info = valid ? g.p_info[p] : 0u;
     const int v = valid ? g.p_vid[p] : 0;
-    const int wb = wb_base + wave;
-    const uint32_t off = __builtin_amdgcn_readfirstlane(g.wb_off[wb]);
-    const int len = (int)__builtin_amdgcn_readfirstlane(g.wb_len[wb]);
-    const uint32_t hb = __builtin_amdgcn_readfirstlane(g.wb_hdr[wb]);
-    const uint32_t *sp = g.adj + off + lane;
+    const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + wave));
+    const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
+    const uint4 *sp = g.adj + td.x + lane;
+    const int len = (int)td.y;
+    // the tally byte is fetched now so that its latency overlaps the tile walk
+    const uint8_t tally = (valid && !burnin) ? g.cnt_pos[p] : (uint8_t)0;
 
     double p0 = 0.0, p1 = 0.0;
-    if (hb != NSK_PAD_WORD)
-        tile_potentials_uniform(g, g.val, sp, len, (int)hb,
-                                (int)__builtin_amdgcn_readfirstlane(g.wb_nent[wb]), p0, p1);
-    else
-        tile_potentials_dynamic(g, g.val, sp, len, p0, p1);
-
+    if (td.z == NSK_PAD_WORD) tile_potentials_dynamic(g, g.val, sp, len, p0, p1);
+    else {
+        const uint32_t kind = (td.w >> 8) & 7u;              // wave-uniform
+        if (kind == 4u) tile_potentials_uniform<VT, 4>(g, g.val, sp, len, td.z, p0, p1);
+        else if (kind == 0u) tile_potentials_uniform<VT, 0>(g, g.val, sp, len, td.z, p0, p1);
+        else if (kind == 2u) tile_potentials_uniform<VT, 2>(g, g.val, sp, len, td.z, p0, p1);
+        else tile_potentials_uniform<VT, 3>(g, g.val, sp, len, td.z, p0, p1);
+    }
     if (!valid) return;
     const int ev = NSK_INFO_EV(info);
     if (!(ev == 0 || sample_evidence)) return;
@@ -204,7 +246,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     const double z = u53(rr.x, rr.y) * z1;
     const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     g.val[v] = (VT)nv;
-    if (!burnin) g.cnt_pos[p] += (uint8_t)nv;
+    if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
 }
 
 // One colour class of one learning sweep: sample_and_sgd (learning.py:46-125) per variable with the
@@ -461,8 +503,8 @@ struct nsk_graph {
     int32_t *cnt = nullptr;
     uint8_t *cnt_pos = nullptr;
     int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
-    uint32_t *adj = nullptr, *wb_off = nullptr, *wb_len = nullptr, *wb_hdr = nullptr, *wb_nent = nullptr,
-             *tile_hdr = nullptr;
+    uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr;
+    double *prog_w = nullptr;
     long long *cnt_total = nullptr, *G = nullptr;
     uint32_t *K = nullptr, *T = nullptr;
     MTState *mt_np = nullptr, *mt_py = nullptr;
@@ -547,8 +589,9 @@ static DevGraph<VT> view(nsk_graph *g) {
     d.w = g->w; d.w_fixed = g->w_fixed; d.logtab = g->logtab;
     d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
     d.G = g->G; d.K = g->K; d.T = g->T;
-    d.adj = g->adj; d.wb_off = g->wb_off; d.wb_len = g->wb_len; d.cnt_pos = g->cnt_pos;
-    d.wb_hdr = g->wb_hdr; d.wb_nent = g->wb_nent; d.tile_hdr = g->tile_hdr;
+    d.adj = (const uint4 *)g->adj; d.tiles = (const uint4 *)g->tiles; d.tile_hdr = g->tile_hdr;
+    d.prog_w = g->prog_w;
+    d.cnt_pos = g->cnt_pos;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
     return d;
@@ -600,7 +643,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
     UP(f_head); UP(f_off); UP(f_wid); UP(f_feat); UP(m_vid); UP(m_deo); UP(v_card); UP(v_pos);
-    UP(w_fixed); UP(logtab); UP(adj); UP(wb_off); UP(wb_len); UP(wb_hdr); UP(wb_nent); UP(tile_hdr);
+    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
@@ -614,6 +657,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &g->cnt, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_total, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos); if (rc) return rc;
+    rc = dev_alloc(g, &g->prog_w, 2 * c.tile_hdr.size()); if (rc) return rc;
     HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (c.npos ? c.npos : 1), g->stream));
     rc = dev_alloc(g, &g->G, (size_t)c.nweight); if (rc) return rc;
     rc = dev_alloc(g, &g->K, (size_t)c.nweight); if (rc) return rc;
@@ -683,6 +727,15 @@ int nsk_synchronize(nsk_graph *g) {
     return NSK_OK;
 }
 
+// the fast path reads weights through prog_w: rebuild it whenever weights may have changed (start
+// of every sweep call -- the host may have written the weight buffer -- and after every update)
+static void refresh_prog_weights(nsk_graph *g) {
+    const int n = (int)g->c.tile_hdr.size();
+    if (n > 0 && g->c.nfast > 0 && g->c.nweight > 0)
+        k_refresh_prog_weights<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+            g->tile_hdr, g->w, g->prog_w, n);
+}
+
 static int fold_position_tally(nsk_graph *g) {
     const int np = (int)g->c.npos;
     if (np > 0 && g->c.nfast > 0 && g->pos_tally_sweeps > 0)
@@ -717,6 +770,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
         g->sweep += (uint64_t)nsweeps;
     } else {
         const size_t nphase = g->c.phase_start.size() - 1;
+        refresh_prog_weights(g);
         for (int64_t s = 0; s < nsweeps; s++) {
             for (size_t ph = 0; ph < nphase; ph++) {
                 const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];

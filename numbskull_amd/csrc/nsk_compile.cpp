@@ -343,91 +343,108 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     for (int32_t k = 0; k < ncolors; k++)
         c.phase_wb_base[k + 1] = c.phase_wb_base[k] + (c.phase_fast_end[k] - c.phase_start[k] + 63) / 64;
     const int64_t nwb = c.phase_wb_base[ncolors];
-    c.wb_off.assign((size_t)nwb, 0); c.wb_len.assign((size_t)nwb, 0);
+    c.tiles.assign((size_t)nwb * 4 + 4, 0);
     {
-        auto lane_words = [&](int64_t v, std::vector<uint32_t> *out) -> int64_t {
+        // words of one lane: per factor of the variable, in list order, a header then the ids of
+        // the members other than the variable itself
+        auto lane_words = [&](int64_t v, std::vector<uint32_t> &out) {
+            out.clear();
             const nsk_variable &var = d->variable[v];
             const nsk_vtf &vt = d->vmap[var.vtf_offset];
-            int64_t n = 0;
             for (int64_t j = 0; j < vt.factor_index_length; j++) {
                 const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
+                const size_t at = out.size();
+                out.push_back(0);
                 uint32_t others = 0;
                 if (fa.factorFunction != -1)
                     for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++)
-                        if (d->fmap[l].vid != v) others++;
-                if (out) {
-                    out->push_back(((uint32_t)(fa.factorFunction + 1) << 27) | (others << 24) |
-                                   (uint32_t)fa.weightId);
-                    if (fa.factorFunction != -1)
-                        for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++)
-                            if (d->fmap[l].vid != v) out->push_back((uint32_t)d->fmap[l].vid);
-                }
-                n += 1 + others;
+                        if (d->fmap[l].vid != v) { out.push_back((uint32_t)d->fmap[l].vid); others++; }
+                out[at] = ((uint32_t)(fa.factorFunction + 1) << 27) | (others << 24) | (uint32_t)fa.weightId;
             }
-            return n;
         };
-        // pass 1: shape of every tile.  Uniform tile = all its lanes have the same header sequence.
-        c.wb_hdr.assign((size_t)nwb, 0xFFFFFFFFu);
-        c.wb_nent.assign((size_t)nwb, 0);
-        std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
-        std::vector<uint32_t> words, hdrs, hdrs0;
         auto headers_of = [&](const std::vector<uint32_t> &w, std::vector<uint32_t> &h) {
             h.clear();
-            for (size_t j = 0; j < w.size();) {
-                h.push_back(w[j]);
-                j += 1 + ((w[j] >> 24) & 7u);
-            }
+            for (size_t j = 0; j < w.size(); j += 1 + ((w[j] >> 24) & 7u)) h.push_back(w[j]);
         };
-        uint64_t total = 0;
+        // pass 1: shape of every tile.  Uniform tile = all its lanes have the same header sequence.
+        std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
+        std::vector<uint32_t> words, hdrs, hdrs0, prog;
+        uint64_t total4 = 0;                      // stream size in 16-byte units
         for (int32_t k = 0; k < ncolors; k++) {
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
                 const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
-                const int64_t wb = c.phase_wb_base[k] + b;
+                uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
                 int64_t len = 0;
                 bool uniform = true;
                 for (int64_t p = p0; p < p1; p++) {
-                    words.clear();
-                    lane_words(c.p_vid[p], &words);
+                    lane_words(c.p_vid[p], words);
                     len = std::max<int64_t>(len, (int64_t)words.size());
                     headers_of(words, p == p0 ? hdrs0 : hdrs);
                     if (p != p0 && hdrs != hdrs0) uniform = false;
                 }
-                if (uniform && hdrs0.size() <= 0xFFFF) {
-                    auto it = hdr_pool.find(hdrs0);
-                    if (it == hdr_pool.end()) {
-                        it = hdr_pool.emplace(hdrs0, (uint32_t)c.tile_hdr.size()).first;
-                        c.tile_hdr.insert(c.tile_hdr.end(), hdrs0.begin(), hdrs0.end());
+                td[2] = 0xFFFFFFFFu;
+                // slot program of a uniform tile: one word per member slot (an entry without other
+                // members still gets one, ignored, slot):
+                //   weightId | code << 24 | first << 27 | last << 28 | ignore << 29
+                //   code: 0 NOOP, 1 IMPLY_NATURAL, 2 OR, 3 AND/ISTRUE, 4 EQUAL
+                int64_t nslots = 0;
+                for (uint32_t h : hdrs0) nslots += std::max<int64_t>(1, (h >> 24) & 7u);
+                if (uniform && nslots <= 8 && p1 > p0) {
+                    prog.clear();
+                    for (uint32_t h : hdrs0) {
+                        const int fn = (int)(h >> 27) - 1;
+                        const uint32_t code = fn == 3 ? 4u : (fn == 2 || fn == 4) ? 3u : fn == 1 ? 2u : fn == 0 ? 1u : 0u;
+                        const uint32_t no = (h >> 24) & 7u, wid = h & 0xFFFFFFu;
+                        for (uint32_t m = 0; m < std::max(1u, no); m++)
+                            prog.push_back(wid | (code << 24) | ((m == 0 ? 1u : 0u) << 27) |
+                                           ((m + 1 >= no ? 1u : 0u) << 28) | ((no == 0 ? 1u : 0u) << 29));
                     }
-                    c.wb_hdr[wb] = it->second;
-                    c.wb_nent[wb] = (uint32_t)hdrs0.size();
-                    len -= (int64_t)hdrs0.size();            // members only
+                    auto it = hdr_pool.find(prog);
+                    if (it == hdr_pool.end()) {
+                        it = hdr_pool.emplace(prog, (uint32_t)c.tile_hdr.size()).first;
+                        c.tile_hdr.insert(c.tile_hdr.end(), prog.begin(), prog.end());
+                        c.tile_hdr.resize((c.tile_hdr.size() + 7) / 8 * 8, 0u);   // pad: NOOP, weight 0
+                    }
+                    // kind: every entry has exactly one other member and the same function code ->
+                    // the kernel runs a specialised, table-free step (code in bits 8..10)
+                    uint32_t kind = prog.empty() ? 0u : (prog[0] >> 24) & 7u;
+                    for (uint32_t wdp : prog)
+                        if (((wdp >> 24) & 7u) != kind || ((wdp >> 27) & 7u) != 3u) kind = 0;
+                    td[2] = it->second;
+                    td[3] = (uint32_t)nslots | (kind << 8);
+                    len = nslots;
                 }
-                c.wb_off[wb] = (uint32_t)total;
-                c.wb_len[wb] = (uint32_t)len;
-                total += (uint64_t)len * 64;
-                if (total >= ((uint64_t)1 << 32)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
+                len = (len + 3) / 4 * 4;
+                td[0] = (uint32_t)total4;
+                td[1] = (uint32_t)len;
+                total4 += (uint64_t)(len / 4) * 64;
+                if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
             }
         }
-        if (c.tile_hdr.empty()) c.tile_hdr.push_back(0);
-        // pass 2: fill the tiles (padding lanes of a uniform tile read variable 0: harmless)
-        c.adj.assign((size_t)total, 0xFFFFFFFFu);
+        c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
+        // pass 2: fill the tiles.  Padding: member slots read variable 0 (harmless) in uniform
+        // tiles, 0xFFFFFFFF in tiles with per-lane headers.
+        c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);
         for (int32_t k = 0; k < ncolors; k++) {
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
                 const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
-                const int64_t wb = c.phase_wb_base[k] + b;
-                const uint64_t off = c.wb_off[wb];
-                const bool uniform = c.wb_hdr[wb] != 0xFFFFFFFFu;
+                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                const uint64_t base = (uint64_t)td[0] * 4;
+                const bool uniform = td[2] != 0xFFFFFFFFu;
                 if (uniform)
-                    for (uint64_t j = 0; j < (uint64_t)c.wb_len[wb] * 64; j++) c.adj[off + j] = 0;
+                    for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = 0;
                 for (int64_t p = p0; p < p1; p++) {
-                    words.clear();
-                    lane_words(c.p_vid[p], &words);
+                    lane_words(c.p_vid[p], words);
                     size_t out = 0;
+                    auto put = [&](uint32_t word) {
+                        c.adj[base + 256 * (out / 4) + 4 * (uint64_t)(p - p0) + (out % 4)] = word;
+                        out++;
+                    };
                     for (size_t j = 0; j < words.size();) {
                         const uint32_t nother = (words[j] >> 24) & 7u;
-                        if (!uniform) c.adj[off + 64 * (out++) + (p - p0)] = words[j];
-                        for (uint32_t m = 1; m <= nother; m++)
-                            c.adj[off + 64 * (out++) + (p - p0)] = words[j + m];
+                        if (!uniform) put(words[j]);
+                        else if (nother == 0) put(0u);            // the ignored slot of a member-less entry
+                        for (uint32_t m = 1; m <= nother; m++) put(words[j + m]);
                         j += 1 + nother;
                     }
                     c.nfast++;

@@ -26,14 +26,17 @@ struct Compiled {
     // streams) come first, the rest (generic CSR kernel) after: [phase_start, phase_fast_end) fast.
     std::vector<int64_t> phase_fast_end;   // [ncolors]
     std::vector<int64_t> phase_wb_base;    // [ncolors+1] first wave-block of each phase
-    std::vector<uint32_t> wb_off;          // [nwb] word offset of a wave-block's stream
-    std::vector<uint32_t> wb_len;          // [nwb] words per lane (column-major: word j of lane i
-                                           //       at wb_off + 64*j + i)
+    // One 16-byte descriptor per wave-block ("tile" = 64 consecutive fast positions):
+    //   [0] offset of the tile's stream in 16-byte units   [1] words per lane (multiple of 4)
+    //   [2] offset into tile_hdr of a uniform tile's slot program, 0xFFFFFFFF = per-lane headers
+    //   [3] member slots of a uniform tile
+    // Stream layout: chunk c of lane i (4 words = one 16-byte load) at 16*(off + 64*c + i).
+    std::vector<uint32_t> tiles;           // [4*nwb]
     std::vector<uint32_t> adj;             // inlined adjacency words (DESIGN.md "fast path")
     // A tile whose 64 lanes share one header sequence (same function, member count and weight per
-    // entry) keeps the headers once, in tile_hdr, and its stream holds member words only.
-    std::vector<uint32_t> wb_hdr;          // [nwb] offset into tile_hdr, 0xFFFFFFFF = per-lane headers
-    std::vector<uint32_t> wb_nent;         // [nwb] entries of a uniform tile
+    // entry) with at most 8 member slots is "uniform": its stream holds member words only and its
+    // per-slot program (weight id, function code, first/last/ignore flags; nsk_compile.cpp) is kept
+    // once in tile_hdr, padded to 8 words, for the scalar unit to read.
     std::vector<uint32_t> tile_hdr;
     int64_t nfast = 0;
     // per position

@@ -177,12 +177,12 @@ struct DevGraph {
     uint32_t *K;                // visits
     uint32_t *T;                // truncating visits (L1)
     // fast path: inlined adjacency streams (DESIGN.md "fast path") and a position-indexed tally
-    const uint32_t *adj;        // words; column-major 64-lane tiles
-    const uint32_t *wb_off;     // [nwb] first word of a wave-block's tile
-    const uint32_t *wb_len;     // [nwb] words per lane
-    const uint32_t *wb_hdr;     // [nwb] offset into tile_hdr (uniform tile) or NSK_PAD_WORD
-    const uint32_t *wb_nent;    // [nwb] entries of a uniform tile
-    const uint32_t *tile_hdr;   // shared header sequences of uniform tiles
+    const uint4 *adj;           // stream: chunk c of lane i of a tile at adj[off + 64*c + i]
+    const uint4 *tiles;         // [nwb] {stream offset, words per lane, tile_hdr offset | PAD, entries}
+    const uint32_t *tile_hdr;   // slot programs of uniform tiles, padded to 8 words
+    const double *prog_w;       // [2 * |tile_hdr|] per program word: weight * value when the entry
+                                //  is satisfied / unsatisfied (0, 0 unless the slot closes an entry);
+                                //  refreshed by k_refresh_prog_weights whenever weights change
     uint8_t *cnt_pos;           // [npos] tally delta of binary fast-path variables, by position
                                 //        (folded into the int64 master copy every 255 sweeps)
     int32_t nvar;
@@ -198,6 +198,10 @@ struct DevGraph {
 // the OTHER members: all non-zero? any == 1? all equal (and to what)?
 // ------------------------------------------------------------------------------------------
 #define NSK_PAD_WORD 0xFFFFFFFFu
+// Wave-uniform, read-only data (tile descriptors, shared headers, weights) is read through the
+// constant address space so that it travels on the scalar path (s_load) instead of occupying 64
+// lanes of the vector memory pipeline.
+#define NSK_SCALAR __attribute__((address_space(4)))
 #define NSK_HDR_FUNC(h) ((int)((h) >> 27) - 1)
 #define NSK_HDR_NOTHER(h) ((int)(((h) >> 24) & 7u))
 #define NSK_HDR_WID(h) ((int)((h) & 0xFFFFFFu))
