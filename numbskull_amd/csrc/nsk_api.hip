@@ -5,6 +5,7 @@
 // learnthread/sample_and_sgd (learning.py:12-125).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,11 @@ using namespace nsk;
 // kernels
 // =============================================================================================
 #define NSK_BLOCK 256
+// persistent grids of the learning kernels (rows of the SMALLW partial-sum tables)
+#define NSK_LEARN_FAST_BLOCKS 1024
+#define NSK_LEARN_LIST_BLOCKS 256
+#define NSK_LEARN_GEN_BLOCKS 1024
+#define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS)
 
 // One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
 // gibbsthread's loop body (inference.py:20-33) for that variable.
@@ -249,71 +255,281 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
 }
 
-// One colour class of one learning sweep: sample_and_sgd (learning.py:46-125) per variable with the
-// weights frozen for the phase; gradients go to the fixed-point accumulators, k_apply_weights
-// turns them into the weight update at the end of the phase (DESIGN.md "device-mode learning").
-template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_learn_phase(DevGraph<VT> g, int pbegin, int pend,
-                                                           int regularization, double inv_trunc,
-                                                           int learn_non_evidence, uint32_t k0,
-                                                           uint32_t k1, uint32_t s0, uint32_t s1) {
-    const int p = pbegin + (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    bool more = false, truncate = false;
-    int v = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
-    if (p < pend) {
-        const uint32_t info = g.p_info[p];
-        const int ev = NSK_INFO_EV(info);
-        const int slot0 = g.p_slot[p];
-        v = g.p_vid[p];
-        const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-        if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
-        else evidence = (int)g.p_init[p];                                                     // 61-62
-        g.val_evid[v] = (VT)evidence;
-        proposal = draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
-        g.val[v] = (VT)proposal;
-        if (learn_non_evidence || ev == 1) {                                                  // 71-72
-            if (regularization == 1) {                                                        // 90
-                const u32x4 t = philox4x32(k0, k1, (uint32_t)v, 1u, s0, s1);
-                truncate = u53(t.x, t.y) < inv_trunc;
-            }
-            const int step = NSK_INFO_DT1(info);
-            a = g.slot_off[slot0 + step * evidence];
-            ae = g.slot_off[slot0 + step * evidence + 1];
-            if (step && evidence != proposal) {
-                b = g.slot_off[slot0 + proposal];
-                be = g.slot_off[slot0 + proposal + 1];
-            }
-            more = (a < ae) || (b < be);
-        }
+// ---------------------------------------------------------------------------------------------
+// Learning.  One colour class of one learning sweep = sample_and_sgd (learning.py:46-125) for every
+// variable of the class with the weights frozen; gradients go to per-weight fixed-point sums and
+// the weight update for the whole class is applied afterwards (DESIGN.md "device-mode learning").
+// ---------------------------------------------------------------------------------------------
+struct LearnParams {
+    int regularization, learn_non_evidence;
+    double inv_trunc;
+    uint32_t k0, k1, s0, s1;
+    int row_base;               // first row of this launch in the partial-sum tables (SMALLW)
+};
+
+// per-block accumulation tables in LDS (SMALLW) or the global accumulators
+template <bool SMALLW, typename VT>
+__device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem) {
+    GradSink sk;
+    if (SMALLW) {
+        const int nw = g.nweight;
+        sk.G = (long long *)smem;
+        sk.K = (uint32_t *)(smem + 8 * (size_t)nw);
+        sk.T = sk.K + nw;
+        for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) { sk.G[i] = 0; sk.K[i] = 0; sk.T[i] = 0; }
+        __syncthreads();
+    } else {
+        sk.G = g.G; sk.K = g.K; sk.T = g.T;
     }
-    // union of the two sorted-unique lists (learning.py:76-95), one factor per iteration; the loop
-    // is wave-uniform so that accumulate_gradient can reduce across the wave
-    while (__ballot(more)) {
-        bool have = false;
-        int wid = 0;
-        long long gfix = 0;
-        if (more) {
-            const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
-            const int fb = b < be ? g.fidx[b] : 0x7fffffff;
-            const int fid = fa < fb ? fa : fb;
-            if (fa == fid) a++;
-            if (fb == fid) b++;
-            more = (a < ae) || (b < be);
-            wid = g.f_wid[fid];
-            if (!g.w_fixed[wid]) {                                                            // 100-101
-                const double p0 = eval_factor(g, fid, v, evidence, g.val_evid);
-                const double p1 = eval_factor(g, fid, v, proposal, g.val);
-                const double gradient = (p1 - p0) * g.f_feat[fid];                            // 109
-                gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
-                have = true;
-            }
-        }
-        accumulate_gradient(g, have, wid, gfix, truncate);
+    return sk;
+}
+
+template <bool SMALLW, typename VT>
+__device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink &sk, int row) {
+    if (!SMALLW) return;
+    __syncthreads();
+    const int nw = g.nweight;
+    for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) {
+        g.part_G[(size_t)row * nw + i] = sk.G[i];
+        g.part_K[(size_t)row * nw + i] = sk.K[i];
+        g.part_T[(size_t)row * nw + i] = sk.T[i];
     }
 }
 
-// End of a learning phase: fold the accumulated visits of every weight into its value
-// (learning.py:110-125 applied to the batch; DESIGN.md gives the closed forms).
+// Generic learning kernel.  Work items are 64-position groups: item i covers positions
+// pbegin + 64 i (range mode) or list[i] (list mode: the per-lane-header tiles of the fast range),
+// clipped at pend.  A persistent grid strides over the items so that SMALLW blocks flush once.
+template <typename VT, bool SMALLW>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_phase(DevGraph<VT> g, int pbegin, int pend,
+                                                           const uint32_t *list, int nitems,
+                                                           LearnParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
+    for (int item = wave0; item < nitems; item += nwaves) {
+        const int p = (list ? (int)list[item] : pbegin + 64 * item) + lane;
+        bool more = false, truncate = false;
+        int v = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
+        if (p < pend) {
+            const uint32_t info = g.p_info[p];
+            const int ev = NSK_INFO_EV(info);
+            const int slot0 = g.p_slot[p];
+            v = g.p_vid[p];
+            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+            if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
+            else evidence = (int)g.p_init[p];                                                     // 61-62
+            g.val_evid[v] = (VT)evidence;
+            proposal = draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
+            g.val[v] = (VT)proposal;
+            if (lp.learn_non_evidence || ev == 1) {                                               // 71-72
+                if (lp.regularization == 1) {                                                     // 90
+                    const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+                    truncate = u53(t.x, t.y) < lp.inv_trunc;
+                }
+                const int step = NSK_INFO_DT1(info);
+                a = g.slot_off[slot0 + step * evidence];
+                ae = g.slot_off[slot0 + step * evidence + 1];
+                if (step && evidence != proposal) {
+                    b = g.slot_off[slot0 + proposal];
+                    be = g.slot_off[slot0 + proposal + 1];
+                }
+                more = (a < ae) || (b < be);
+            }
+        }
+        // union of the two sorted-unique lists (learning.py:76-95), one factor per iteration; the
+        // loop is wave-uniform so that accumulate_gradient can reduce across the wave
+        while (__ballot(more)) {
+            bool have = false;
+            int wid = 0;
+            long long gfix = 0;
+            if (more) {
+                const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
+                const int fb = b < be ? g.fidx[b] : 0x7fffffff;
+                const int fid = fa < fb ? fa : fb;
+                if (fa == fid) a++;
+                if (fb == fid) b++;
+                more = (a < ae) || (b < be);
+                wid = g.f_wid[fid];
+                if (!g.w_fixed[wid]) {                                                            // 100-101
+                    const double p0 = eval_factor(g, fid, v, evidence, g.val_evid);
+                    const double p1 = eval_factor(g, fid, v, proposal, g.val);
+                    const double gradient = (p1 - p0) * g.f_feat[fid];                            // 109
+                    gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
+                    have = true;
+                }
+            }
+            accumulate_gradient(sk, have, wid, gfix, truncate);
+        }
+    }
+    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+}
+
+// "satisfied" bits of one slot for the sampled variable at 0 / at 1; the generic flavour keeps
+// the running facts about the entry's other members in `st` (same algebra as slot_step).
+__device__ __forceinline__ void slot_sat(SlotState &st, uint32_t s, int x, bool &b0, bool &b1) {
+    const bool F = (s >> 27) & 1u, ig = (s >> 29) & 1u;
+    const uint32_t code = (s >> 24) & 7u;
+    const bool nz = ig || (x != 0), one = !ig && (x == 1);
+    st.alleq = F || (st.alleq && (x == st.first));
+    st.allnz = (F || st.allnz) && nz;
+    st.any1 = (!F && st.any1) || one;
+    st.first = F ? x : st.first;
+    const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
+    b0 = (isEq && st.alleq && (ig || st.first == 0)) || (isOr && st.any1);
+    b1 = (isEq && st.alleq && (ig || st.first == 1)) || (isAnd && st.allnz) || isOr;
+}
+
+template <int CODE>
+__device__ __forceinline__ void pair_sat(int x, bool &b0, bool &b1) {
+    if (CODE == 4) { b0 = x == 0; b1 = x == 1; }
+    else if (CODE == 2) { b0 = x == 1; b1 = true; }
+    else { b0 = false; b1 = x != 0; }
+}
+
+// One uniform tile of the learning sweep.  Both chains are walked together: x from var_value (free
+// chain), xe from var_value_evid; per closing slot the satisfied bits for candidates 0/1 are kept
+// in lane bitfields so that, once evidence and proposal are known, the entry's gradient over the
+// wave is (hi - lo) * (popcount(free satisfied) - popcount(evidence satisfied)): two scalar
+// popcounts, one accumulator update per entry per wave.
+template <typename VT, int KIND>
+__device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
+                                           int len, uint32_t prog, int p, bool valid,
+                                           const LearnParams &lp) {
+    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
+    const uint32_t info = valid ? g.p_info[p] : 0u;
+    const int v = valid ? g.p_vid[p] : 0;
+    const int ev = NSK_INFO_EV(info);
+    const int init = valid ? (int)g.p_init[p] : 0;
+    const bool need_evid = __ballot(valid && ev != 1) != 0;          // wave-uniform
+
+    double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+    uint32_t B0 = 0, B1 = 0, C0 = 0, C1 = 0;                           // bit i: slot i satisfied
+    SlotState sf = {0, true, false, true}, se = {0, true, false, true};
+    uint32_t sl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) sl[i] = pp[i];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (half * 4 < len) {                                            // scalar
+            const uint4 q = sp[half * 64];
+            const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+            int x[4], xe[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { x[i] = (int)g.val[wd[i]]; xe[i] = (int)g.val_evid[wd[i]]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = half * 4 + i;
+                const double thi = tw[2 * j], tlo = tw[2 * j + 1];
+                bool b0, b1, c0, c1;
+                if (KIND) { pair_sat<KIND>(x[i], b0, b1); pair_sat<KIND>(xe[i], c0, c1); }
+                else { slot_sat(sf, sl[j], x[i], b0, b1); slot_sat(se, sl[j], xe[i], c0, c1); }
+                p0 = p0 + (b0 ? thi : tlo);
+                p1 = p1 + (b1 ? thi : tlo);
+                if (need_evid) {
+                    q0 = q0 + (c0 ? thi : tlo);
+                    q1 = q1 + (c1 ? thi : tlo);
+                }
+                B0 |= (b0 ? 1u : 0u) << j; B1 |= (b1 ? 1u : 0u) << j;
+                C0 |= (c0 ? 1u : 0u) << j; C1 |= (c1 ? 1u : 0u) << j;
+            }
+        }
+    }
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    int evidence = init;                                                  // learning.py:61-62
+    if (need_evid && ev != 1) {                                           // 54-58
+        const double z0 = nsk_exp(q0), z1 = z0 + nsk_exp(q1);
+        const double z = u53(r.z, r.w) * z1;
+        evidence = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    }
+    const double z0 = nsk_exp(p0), z1 = z0 + nsk_exp(p1);                 // 66-70
+    const double z = u53(r.x, r.y) * z1;
+    const int proposal = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    if (valid) {
+        g.val_evid[v] = (VT)evidence;
+        g.val[v] = (VT)proposal;
+    }
+    const bool part = valid && (lp.learn_non_evidence || ev == 1);        // 71-72
+    bool truncate = false;
+    if (lp.regularization == 1) {                                         // 90
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
+    }
+    const unsigned long long pm = __ballot(part);
+    if (pm == 0) return;
+    const uint32_t satf = proposal ? B1 : B0, sate = evidence ? C1 : C0;
+    const uint32_t nk = (uint32_t)__popcll(pm), nt = (uint32_t)__popcll(__ballot(truncate));
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t s = sl[j];
+        const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
+        if (j < len && closes && !fixed) {
+            const uint32_t code = (s >> 24) & 7u;
+            const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
+            const int nf = __popcll(__ballot(part && ((satf >> j) & 1u)));
+            const int ne = __popcll(__ballot(part && ((sate >> j) & 1u)));
+            if ((threadIdx.x & 63) == 0) {
+                const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
+                const int wid = (int)(s & 0xFFFFFFu);
+                atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)dG);
+                atomicAdd(&sk.K[wid], nk);
+                if (nt) atomicAdd(&sk.T[wid], nt);
+            }
+        }
+    }
+}
+
+// Learning over the uniform tiles of a colour class (tiles with per-lane headers are left to
+// k_learn_phase in list mode).  Each wave takes a contiguous run of tiles.
+template <typename VT, bool SMALLW>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pbegin, int pend,
+                                                          int wb_base, int ntiles, LearnParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
+    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
+    const int per = (ntiles + nwaves - 1) / nwaves;
+    const int t1 = min(ntiles, (wave0 + 1) * per);
+    for (int t = wave0 * per; t < t1; t++) {
+        const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
+        const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
+        if (td.z == NSK_PAD_WORD) continue;                  // per-lane headers: generic kernel's job
+        const int p = pbegin + t * 64 + lane;
+        const bool valid = p < pend;
+        const uint4 *sp = g.adj + td.x + lane;
+        const uint32_t kind = (td.w >> 8) & 7u;
+        if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+        else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+        else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+        else learn_tile<VT, 3>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+    }
+    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+}
+
+// The weight update of learning.py:110-125 applied to a whole colour class at once
+// (DESIGN.md "device-mode learning" gives the closed forms; the oracle restates them).
+__device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
+                                               int regularization, double reg_param, double truncation) {
+    const double Gf = (double)G * (1.0 / 4294967296.0);
+    if (regularization == 2) {
+        const double a = 1.0 / (1.0 + reg_param * step);
+        x = powi_det(a, (unsigned long long)k) * x;
+        x = x - step * Gf;
+    } else if (regularization == 1) {
+        x = x - step * Gf;
+        if (t > 0) {
+            const double l1 = (reg_param * step * truncation) * (double)t;
+            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
+        }
+    } else {
+        x = x - step * Gf;
+    }
+    return x;
+}
+
 __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
                                                              uint32_t *T, int nweight, double step,
                                                              int regularization, double reg_param,
@@ -322,24 +538,26 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long lon
     if (i >= nweight) return;
     const uint32_t k = K[i];
     if (k == 0) return;
-    const double Gf = (double)G[i] * (1.0 / 4294967296.0);
-    double x = w[i];
-    if (regularization == 2) {
-        const double a = 1.0 / (1.0 + reg_param * step);
-        x = powi_det(a, (unsigned long long)k) * x;
-        x = x - step * Gf;
-    } else if (regularization == 1) {
-        x = x - step * Gf;
-        const uint32_t t = T[i];
-        if (t > 0) {
-            const double l1 = (reg_param * step * truncation) * (double)t;
-            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
-        }
-    } else {
-        x = x - step * Gf;
-    }
-    w[i] = x;
+    w[i] = apply_update(w[i], G[i], k, T[i], step, regularization, reg_param, truncation);
     G[i] = 0; K[i] = 0; T[i] = 0;
+}
+
+// SMALLW flavour: one wave per weight adds up the per-block rows, then applies the update.
+__global__ __launch_bounds__(64) void k_apply_weights_rows(double *w, const long long *part_G,
+                                                           const uint32_t *part_K, const uint32_t *part_T,
+                                                           int nrows, int nweight, double step,
+                                                           int regularization, double reg_param,
+                                                           double truncation) {
+    const int i = (int)blockIdx.x, lane = (int)threadIdx.x;
+    long long G = 0, K = 0, T = 0;
+    for (int r = lane; r < nrows; r += 64) {
+        G += part_G[(size_t)r * nweight + i];
+        K += (long long)part_K[(size_t)r * nweight + i];
+        T += (long long)part_T[(size_t)r * nweight + i];
+    }
+    G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
+    if (lane == 0 && K > 0)
+        w[i] = apply_update(w[i], G, (uint32_t)K, (uint32_t)T, step, regularization, reg_param, truncation);
 }
 
 // int32 per-call tally deltas -> int64 master copy (the host-visible `count`)
@@ -505,6 +723,10 @@ struct nsk_graph {
     int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
     uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr;
     double *prog_w = nullptr;
+    uint32_t *dyn_tiles = nullptr;
+    long long *part_G = nullptr;       // SMALLW: rows of per-block partial sums
+    uint32_t *part_K = nullptr, *part_T = nullptr;
+    bool smallw = false;
     long long *cnt_total = nullptr, *G = nullptr;
     uint32_t *K = nullptr, *T = nullptr;
     MTState *mt_np = nullptr, *mt_py = nullptr;
@@ -591,6 +813,8 @@ static DevGraph<VT> view(nsk_graph *g) {
     d.G = g->G; d.K = g->K; d.T = g->T;
     d.adj = (const uint4 *)g->adj; d.tiles = (const uint4 *)g->tiles; d.tile_hdr = g->tile_hdr;
     d.prog_w = g->prog_w;
+    d.part_G = g->part_G; d.part_K = g->part_K; d.part_T = g->part_T;
+    d.nweight = (int32_t)g->c.nweight;
     d.cnt_pos = g->cnt_pos;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
@@ -643,7 +867,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
     UP(f_head); UP(f_off); UP(f_wid); UP(f_feat); UP(m_vid); UP(m_deo); UP(v_card); UP(v_pos);
-    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr);
+    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
@@ -658,6 +882,13 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &g->cnt_total, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos); if (rc) return rc;
     rc = dev_alloc(g, &g->prog_w, 2 * c.tile_hdr.size()); if (rc) return rc;
+    g->smallw = c.nweight > 0 && c.nweight <= NSK_SMALLW;
+    if (g->smallw) {
+        const size_t cells = (size_t)NSK_LEARN_ROWS * (size_t)c.nweight;
+        rc = dev_alloc(g, &g->part_G, cells); if (rc) return rc;
+        rc = dev_alloc(g, &g->part_K, cells); if (rc) return rc;
+        rc = dev_alloc(g, &g->part_T, cells); if (rc) return rc;
+    }
     HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (c.npos ? c.npos : 1), g->stream));
     rc = dev_alloc(g, &g->G, (size_t)c.nweight); if (rc) return rc;
     rc = dev_alloc(g, &g->K, (size_t)c.nweight); if (rc) return rc;
@@ -809,11 +1040,76 @@ extern "C" int nsk_gibbs_sweeps(nsk_graph *g, int64_t nsweeps, int sample_eviden
                             : gibbs_impl<int32_t>(g, nsweeps, sample_evidence, burnin);
 }
 
+template <typename VT, bool SMALLW>
+static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                           double reg_param, int64_t truncation, int learn_non_evidence) {
+    DevGraph<VT> d = view<VT>(g);
+    const size_t nphase = g->c.phase_start.size() - 1;
+    const int nw = (int)g->c.nweight;
+    const size_t shmem = SMALLW ? (size_t)nw * 16 : 0;
+    LearnParams lp;
+    lp.regularization = regularization;
+    lp.learn_non_evidence = learn_non_evidence;
+    lp.inv_trunc = 1.0 / (double)truncation;
+    lp.k0 = (uint32_t)g->seed; lp.k1 = (uint32_t)(g->seed >> 32);
+    refresh_prog_weights(g);
+    for (int64_t s = 0; s < nsweeps; s++) {
+        lp.s0 = (uint32_t)g->sweep; lp.s1 = (uint32_t)(g->sweep >> 32);
+        for (size_t ph = 0; ph < nphase; ph++) {
+            const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
+            const int e = (int)g->c.phase_start[ph + 1];
+            if (e <= fb) continue;
+            int rows = 0;
+            const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
+            const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
+            if (ntiles > ndyn) {        // uniform tiles: inlined-adjacency learning kernel
+                const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (ntiles + 3) / 4);
+                lp.row_base = rows;
+                k_learn_fast<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], ntiles, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (ndyn > 0) {             // tiles with per-lane headers: generic kernel, list mode
+                const int grid = std::min(NSK_LEARN_LIST_BLOCKS, (ndyn + 3) / 4);
+                lp.row_base = rows;
+                k_learn_phase<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                    d, fb, fe, g->dyn_tiles + g->c.phase_dyn_base[ph], ndyn, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (e > fe) {               // variables outside the fast path: generic kernel, range mode
+                const int nitems = (e - fe + 63) / 64;
+                const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
+                lp.row_base = rows;
+                k_learn_phase<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                    d, fe, e, nullptr, nitems, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (nw > 0) {
+                if (SMALLW)
+                    k_apply_weights_rows<<<dim3(nw), dim3(64), 0, g->stream>>>(
+                        g->w, g->part_G, g->part_K, g->part_T, rows, nw, step, regularization, reg_param,
+                        (double)truncation);
+                else
+                    k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation);
+                refresh_prog_weights(g);
+            }
+        }
+        g->sweep++;
+        step *= decay;                                   // factorgraph.py:206
+    }
+    HIPCHECK(hipGetLastError());
+    return NSK_OK;
+}
+
 template <typename VT>
 static int learn_impl(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
                       double reg_param, int64_t truncation, int learn_non_evidence) {
-    DevGraph<VT> d = view<VT>(g);
     if (g->scan == NSK_SCAN_SEQUENTIAL) {
+        DevGraph<VT> d = view<VT>(g);
         k_seq_learn<VT><<<dim3(1), dim3(64), 0, g->stream>>>(d, g->v_pos, g->mt_np, g->mt_py, (int)nsweeps,
                                                             step, decay, regularization, reg_param,
                                                             (double)truncation, learn_non_evidence);
@@ -821,25 +1117,11 @@ static int learn_impl(nsk_graph *g, int64_t nsweeps, double step, double decay, 
         g->launches++;
         g->sweep += (uint64_t)nsweeps;
     } else {
-        const size_t nphase = g->c.phase_start.size() - 1;
-        const int nw = (int)g->c.nweight;
-        for (int64_t s = 0; s < nsweeps; s++) {
-            for (size_t ph = 0; ph < nphase; ph++) {
-                const int b = (int)g->c.phase_start[ph], e = (int)g->c.phase_start[ph + 1];
-                if (e <= b) continue;
-                k_learn_phase<VT><<<dim3((e - b + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                    d, b, e, regularization, 1.0 / (double)truncation, learn_non_evidence,
-                    (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep,
-                    (uint32_t)(g->sweep >> 32));
-                g->launches++;
-                if (nw > 0)
-                    k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation);
-            }
-            g->sweep++;
-            step *= decay;                                   // factorgraph.py:206
-        }
-        HIPCHECK(hipGetLastError());
+        int rc = g->smallw ? learn_chromatic<VT, true>(g, nsweeps, step, decay, regularization, reg_param,
+                                                       truncation, learn_non_evidence)
+                           : learn_chromatic<VT, false>(g, nsweeps, step, decay, regularization, reg_param,
+                                                        truncation, learn_non_evidence);
+        if (rc) return rc;
     }
     g->sweeps_done += nsweeps;
     return NSK_OK;

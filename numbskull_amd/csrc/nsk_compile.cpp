@@ -385,7 +385,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 td[2] = 0xFFFFFFFFu;
                 // slot program of a uniform tile: one word per member slot (an entry without other
                 // members still gets one, ignored, slot):
-                //   weightId | code << 24 | first << 27 | last << 28 | ignore << 29
+                //   weightId | code << 24 | first << 27 | last << 28 | ignore << 29 | weight fixed << 30
                 //   code: 0 NOOP, 1 IMPLY_NATURAL, 2 OR, 3 AND/ISTRUE, 4 EQUAL
                 int64_t nslots = 0;
                 for (uint32_t h : hdrs0) nslots += std::max<int64_t>(1, (h >> 24) & 7u);
@@ -397,7 +397,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         const uint32_t no = (h >> 24) & 7u, wid = h & 0xFFFFFFu;
                         for (uint32_t m = 0; m < std::max(1u, no); m++)
                             prog.push_back(wid | (code << 24) | ((m == 0 ? 1u : 0u) << 27) |
-                                           ((m + 1 >= no ? 1u : 0u) << 28) | ((no == 0 ? 1u : 0u) << 29));
+                                           ((m + 1 >= no ? 1u : 0u) << 28) | ((no == 0 ? 1u : 0u) << 29) |
+                                           ((c.w_fixed[wid] ? 1u : 0u) << 30));
                     }
                     auto it = hdr_pool.find(prog);
                     if (it == hdr_pool.end()) {
@@ -409,7 +410,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     // the kernel runs a specialised, table-free step (code in bits 8..10)
                     uint32_t kind = prog.empty() ? 0u : (prog[0] >> 24) & 7u;
                     for (uint32_t wdp : prog)
-                        if (((wdp >> 24) & 7u) != kind || ((wdp >> 27) & 7u) != 3u) kind = 0;
+                        if (((wdp >> 24) & 7u) != kind || ((wdp >> 27) & 7u) != 3u) kind = 0;   // first+last, not ignored
                     td[2] = it->second;
                     td[3] = (uint32_t)nslots | (kind << 8);
                     len = nslots;
@@ -422,6 +423,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
         }
         c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
+        c.phase_dyn_base.assign((size_t)ncolors + 1, 0);
+        for (int32_t k = 0; k < ncolors; k++) {
+            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++)
+                if (c.tiles[4 * (c.phase_wb_base[k] + b) + 2] == 0xFFFFFFFFu)
+                    c.dyn_tiles.push_back((uint32_t)(c.phase_start[k] + 64 * b));
+            c.phase_dyn_base[k + 1] = (int64_t)c.dyn_tiles.size();
+        }
+        if (c.dyn_tiles.empty()) c.dyn_tiles.push_back(0);
         // pass 2: fill the tiles.  Padding: member slots read variable 0 (harmless) in uniform
         // tiles, 0xFFFFFFFF in tiles with per-lane headers.
         c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);

@@ -38,6 +38,10 @@ struct Compiled {
     // per-slot program (weight id, function code, first/last/ignore flags; nsk_compile.cpp) is kept
     // once in tile_hdr, padded to 8 words, for the scalar unit to read.
     std::vector<uint32_t> tile_hdr;
+    // first positions of the tiles with per-lane headers, per phase (the learning sweep hands
+    // them to the generic kernel): dyn_tiles[phase_dyn_base[k] .. phase_dyn_base[k+1])
+    std::vector<uint32_t> dyn_tiles;
+    std::vector<int64_t> phase_dyn_base;
     int64_t nfast = 0;
     // per position
     std::vector<int32_t> p_vid, p_slot, p_cnt;

@@ -39,6 +39,7 @@ enum : int {
 
 #define NSK_ZLOCAL 16      // cardinalities up to this keep their running sums in registers/scratch
 #define NSK_GRAD_SCALE 4294967296.0   // gradients accumulate as Q31.32 fixed point (order-free)
+#define NSK_SMALLW 256      // graphs with at most this many weights accumulate per block in LDS
 
 // ------------------------------------------------------------------------------------------
 // deterministic exp -- same operation sequence as oracle/nsk_oracle.c:orc_exp_det
@@ -172,10 +173,14 @@ struct DevGraph {
     VT *val;                    // var_value[0]
     VT *val_evid;               // var_value_evid[0]
     int32_t *cnt;               // tally delta since the last fold into the int64 master copy
-    // learning accumulators (per weight)
+    // learning accumulators (per weight), global flavour
     long long *G;               // fixed-point gradient sum
     uint32_t *K;                // visits
     uint32_t *T;                // truncating visits (L1)
+    // learning accumulators, row-of-partials flavour (graphs with <= NSK_SMALLW weights)
+    long long *part_G;          // [rows][nweight]
+    uint32_t *part_K, *part_T;
+    int32_t nweight;
     // fast path: inlined adjacency streams (DESIGN.md "fast path") and a position-indexed tally
     const uint4 *adj;           // stream: chunk c of lane i of a tile at adj[off + 64*c + i]
     const uint4 *tiles;         // [nwb] {stream offset, words per lane, tile_hdr offset | PAD, entries}
@@ -463,12 +468,20 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
     return v;
 }
 
-// Add one (weight, gradient) visit per participating lane into the per-weight accumulators.
-// Must be called by all 64 lanes of the wave (converged); `have` marks participating lanes.
-// Lanes sharing the leader's weight id are reduced in registers first, so a graph whose weights
-// are shared by every factor (the Ising grid) issues one atomic per wave instead of 64.
-template <typename VT>
-__device__ __forceinline__ void accumulate_gradient(const DevGraph<VT> &g, bool have, int wid,
+// Where a block sends its (weight, gradient) visits.  Graphs with few weights (every factor of an
+// Ising grid shares one or two) would serialise millions of same-address global atomics, so their
+// blocks accumulate in LDS tables and write one row of partial sums each (k_apply_weights_rows
+// adds the rows up); graphs with many weights use the global accumulators directly.
+struct GradSink {
+    long long *G;       // fixed-point gradient sums (Q31.32: order-independent, hence deterministic)
+    uint32_t *K;        // visits
+    uint32_t *T;        // truncating visits (L1)
+};
+
+// Add one (weight, gradient) visit per participating lane.  Must be called by all 64 lanes of the
+// wave (converged); `have` marks participating lanes.  Lanes sharing the leader's weight id are
+// reduced in registers first.
+__device__ __forceinline__ void accumulate_gradient(const GradSink &sk, bool have, int wid,
                                                     long long gfix, bool trunc) {
     const unsigned long long mask = __ballot(have);
     if (mask == 0) return;
@@ -481,16 +494,16 @@ __device__ __forceinline__ void accumulate_gradient(const DevGraph<VT> &g, bool 
         const long long sum = wave_sum_i64(same ? gfix : 0LL);
         const int nt = __popcll(__ballot(same && trunc));
         if ((int)(threadIdx.x & 63) == leader) {
-            atomicAdd((unsigned long long *)&g.G[lw], (unsigned long long)sum);
-            atomicAdd(&g.K[lw], (uint32_t)nsame);
-            if (nt) atomicAdd(&g.T[lw], (uint32_t)nt);
+            atomicAdd((unsigned long long *)&sk.G[lw], (unsigned long long)sum);
+            atomicAdd(&sk.K[lw], (uint32_t)nsame);
+            if (nt) atomicAdd(&sk.T[lw], (uint32_t)nt);
         }
         have = have && !same;
     }
     if (have) {
-        atomicAdd((unsigned long long *)&g.G[wid], (unsigned long long)gfix);
-        atomicAdd(&g.K[wid], 1u);
-        if (trunc) atomicAdd(&g.T[wid], 1u);
+        atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)gfix);
+        atomicAdd(&sk.K[wid], 1u);
+        if (trunc) atomicAdd(&sk.T[wid], 1u);
     }
 }
 
