@@ -145,8 +145,24 @@ def _small_graphs(golden):
         "pairs": (graph_from(z4, "pairs"), False),
         "grid57x33": (graphgen.ising_grid(57, 33, weight=0.3), False),
         "lr3000": (graphgen.mixed_lr_graph(3000, seed=5, nweights=40), True),
+        # > 256 weights: gradients go through global atomics instead of per-block LDS tables
+        "lr_manyw": (graphgen.mixed_lr_graph(3000, seed=6, nweights=1500), True),
+        "pairs_manyw": (_pairs_many_weights(), False),
         "lr_bigcard": (_big_cardinality_graph(), False),
     }
+
+
+def _pairs_many_weights():
+    """pair model with one weight per pair for the EQUAL factors (600 weights): uniform tiles are
+    impossible (every lane has its own weight id) -> per-lane-header tiles in learning"""
+    g = list(graphgen.ising_pairs(300, seed=2))
+    fac = g[2].copy()
+    eq = np.nonzero(fac["factorFunction"] == 3)[0]
+    fac["weightId"][eq] = 3 + np.arange(len(eq))
+    from numbskull_amd.numbskulltypes import Weight
+    g[0] = np.zeros(3 + len(eq), Weight)
+    g[2] = fac
+    return tuple(g)
 
 
 def _big_cardinality_graph():
@@ -169,7 +185,7 @@ def _big_cardinality_graph():
 
 
 GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
-          "lr3000", "lr_bigcard"]
+          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw"]
 
 
 @pytest.mark.parametrize("name", GRAPHS)
@@ -198,7 +214,7 @@ def test_chromatic_inference_equals_oracle(golden, name, sample_evidence):
 
 
 @pytest.mark.parametrize("name", ["mixed", "lf", "pairs", "grid32", "lr3000", "lr_bigcard",
-                                  "headquirk"])
+                                  "headquirk", "lr_manyw", "pairs_manyw"])
 @pytest.mark.parametrize("reg,trunc", [(0, 1), (1, 1), (1, 3), (2, 1)])
 @pytest.mark.parametrize("lne", [False, True])
 def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
@@ -225,6 +241,17 @@ def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
         assert np.array_equal(fg.weight_value[0], wv), (name, fg.weight_value[0], wv)
     learns = lne or np.any(og.variable["isEvidence"] == 1)
     assert np.any(wv != og.weight["initialValue"]) or og.weight["isFixed"].all() or not learns
+
+
+def test_fast_and_generic_paths_are_both_exercised(golden):
+    graphs = _small_graphs(golden)
+    ns, fg = session(graphs["grid57x33"][0])
+    assert fg.info()["nfast"] == 57 * 33 and fg.info()["ngeneric"] == 0
+    ns, fg = session(graphs["lr3000"][0], head_by_vid=True)
+    info = fg.info()
+    assert info["nfast"] > 50 and info["ngeneric"] > 200
+    ns, fg = session(graphs["mixed"][0])
+    assert fg.info()["ngeneric"] > 0
 
 
 def test_learning_then_inference_continue_from_state(golden):
@@ -381,3 +408,95 @@ def test_learning_recovers_planted_pair_weights():
     fg.learn(0, 600, 1e-3, 0.995, 2, 1e-3, 1)
     w = fg.weight_value[0]
     assert abs(w[0] - 1.0) < 0.25 and abs(w[1] - 1.0) < 0.25 and abs(w[2] - 0.5) < 0.25, w
+
+
+# ------------------------------------------------------------------------------------------
+# multi-GPU plumbing, exercised on one GPU
+# ------------------------------------------------------------------------------------------
+def test_partitioned_sampler_wraps_library_buffers():
+    """PartitionedSampler exposes the library's value / weight buffers to torch without copies and
+    runs the library on torch's stream."""
+    import torch
+    from numbskull_amd.distributed import PartitionedSampler
+    g = graphgen.ising_grid(64, 64, weight=0.3)
+    ns, fg = session(g, seed=5)
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, _, wv, cnt = og.initial_state()
+    s = PartitionedSampler(fg, None, torch, 0, 1)
+    s.gibbs(4)
+    torch.cuda.synchronize()
+    for k in range(4):
+        og.gibbs_dev(order, ps, vv, wv, cnt, 5, k, True)
+    assert np.array_equal(s.val.cpu().numpy().astype(np.int64), vv)
+    assert s.w.cpu().numpy().tolist() == wv.tolist()
+    fg._pull(0, 0)
+    assert np.array_equal(fg.count, cnt)
+
+
+@pytest.mark.parametrize("learn", [False, True])
+def test_two_partitions_on_one_gpu_match_emulation(learn):
+    """Two handles own the two halves of the variable range (own_range = the reference's shard
+    formula); after every sweep the owned slices are copied into the other handle's buffers --
+    the all-gather of the multi-GPU run -- and weights merge as w_start + sum of deltas.  Must equal
+    the oracle's emulation of the same partitioned semantics."""
+    import torch
+    from numbskull_amd.distributed import PartitionedSampler, shard_range
+    rng = np.random.default_rng(3)
+    if learn:
+        g = graphgen.ising_grid(20, 24, weight=0.1, fixed=False, two_weights=True,
+                                evidence=rng.integers(0, 2, 480))
+    else:
+        g = graphgen.ising_grid(20, 24, weight=0.4)
+    nvar, world, nsweeps = 480, 2, 5
+    parts, oracles = [], []
+    for r in range(world):
+        ns = numbskull_amd.NumbSkull(quiet=True, seed=31)
+        w, v, f, fm, dm, edges = [x.copy() if isinstance(x, np.ndarray) else x for x in g]
+        ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=shard_range(r, world, nvar))
+        fg = ns.factorGraphs[0]
+        parts.append(PartitionedSampler(fg, None, torch, r, 1))
+        color = fg.colors()
+        lo, hi = shard_range(r, world, nvar)
+        assert np.all(color[:lo] == -1) and np.all(color[hi:] == -1) and np.all(color[lo:hi] >= 0)
+        og = oracle_of(fg)
+        oracles.append((og, phases_from_colors(color), og.initial_state(), (lo, hi)))
+    step = 0.01
+    for s in range(nsweeps):
+        starts = [p.w.clone() for p in parts]
+        ostarts = [st[2].copy() for _, _, st, _ in oracles]
+        for p in parts:
+            if learn:
+                p.learn(1, step, 1.0, 2, 0.01, 1)
+            else:
+                p.gibbs(1)
+        for og, (order, ps), (vv, ve, wv, cnt), _ in oracles:
+            if learn:
+                og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 31, s)
+            else:
+                og.gibbs_dev(order, ps, vv, wv, cnt, 31, s, True)
+        step *= 0.9
+        torch.cuda.synchronize()
+        for r in range(world):                      # "all-gather": owners publish their slices
+            lo, hi = shard_range(r, world, nvar)
+            for q in range(world):
+                if q != r:
+                    parts[q].val[lo:hi] = parts[r].val[lo:hi]
+                    parts[q].val_evid[lo:hi] = parts[r].val_evid[lo:hi]
+                    oracles[q][2][0][lo:hi] = oracles[r][2][0][lo:hi]
+                    oracles[q][2][1][lo:hi] = oracles[r][2][1][lo:hi]
+        if learn:                                   # w = w_start + sum of deltas
+            total = sum(p.w - s0 for p, s0 in zip(parts, starts))
+            for p, s0 in zip(parts, starts):
+                p.w.copy_(s0 + total)
+            ototal = sum(st[2] - s0 for (_, _, st, _), s0 in zip(oracles, ostarts))
+            for (_, _, st, _), s0 in zip(oracles, ostarts):
+                st[2][:] = s0 + ototal
+        torch.cuda.synchronize()
+    for r in range(world):
+        vv, ve, wv, cnt = oracles[r][2]
+        assert np.array_equal(parts[r].val.cpu().numpy().astype(np.int64), vv)
+        if learn:
+            assert np.array_equal(parts[r].val_evid.cpu().numpy().astype(np.int64), ve)
+            assert np.allclose(parts[r].w.cpu().numpy(), wv, rtol=0, atol=1e-15)
+    assert torch.equal(parts[0].val, parts[1].val)

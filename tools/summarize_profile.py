@@ -80,3 +80,10 @@ for k, c in summary["pmc"].items():
         c["hbm_bytes_per_launch"] = fb + wb
         print("%s: HBM bytes/launch = %.4g (read %.4g + write %.4g), corrected" % (k, fb + wb, fb, wb))
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+# bench.py reports roofline.traffic from profiles/traffic.json: HBM bytes per launch of the dominant kernel
+dom = None
+for k, c in summary["pmc"].items():
+    if "hbm_bytes_per_launch" in c and (dom is None or "fast" in k):
+        dom = c["hbm_bytes_per_launch"]
+if dom is not None:
+    json.dump({wl: dom}, open(os.path.join(out, "traffic_%s.json" % wl), "w"))
