@@ -24,9 +24,9 @@ using namespace nsk;
 // =============================================================================================
 #define NSK_BLOCK 256
 // persistent grids of the learning kernels (rows of the SMALLW partial-sum tables)
-#define NSK_LEARN_FAST_BLOCKS 1024
-#define NSK_LEARN_LIST_BLOCKS 256
-#define NSK_LEARN_GEN_BLOCKS 1024
+#define NSK_LEARN_FAST_BLOCKS 2048
+#define NSK_LEARN_LIST_BLOCKS 512
+#define NSK_LEARN_GEN_BLOCKS 2048
 #define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS)
 
 // One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
@@ -542,22 +542,48 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long lon
     G[i] = 0; K[i] = 0; T[i] = 0;
 }
 
-// SMALLW flavour: one wave per weight adds up the per-block rows, then applies the update.
-__global__ __launch_bounds__(64) void k_apply_weights_rows(double *w, const long long *part_G,
-                                                           const uint32_t *part_K, const uint32_t *part_T,
-                                                           int nrows, int nweight, double step,
-                                                           int regularization, double reg_param,
-                                                           double truncation) {
-    const int i = (int)blockIdx.x, lane = (int)threadIdx.x;
+// SMALLW flavour: one block per weight adds up the per-block rows, applies the update and rewrites
+// the prog_w entries of the slot programs that use this weight (so no separate refresh launch).
+__global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights_rows(double *w, const long long *part_G,
+                                                                  const uint32_t *part_K, const uint32_t *part_T,
+                                                                  int nrows, int nweight, double step,
+                                                                  int regularization, double reg_param,
+                                                                  double truncation, const uint32_t *prog,
+                                                                  double *prog_w, int nprog) {
+    __shared__ long long red[3][NSK_BLOCK / 64];
+    __shared__ double wnew;
+    const int i = (int)blockIdx.x, tid = (int)threadIdx.x;
     long long G = 0, K = 0, T = 0;
-    for (int r = lane; r < nrows; r += 64) {
+    for (int r = tid; r < nrows; r += NSK_BLOCK) {
         G += part_G[(size_t)r * nweight + i];
         K += (long long)part_K[(size_t)r * nweight + i];
         T += (long long)part_T[(size_t)r * nweight + i];
     }
     G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
-    if (lane == 0 && K > 0)
-        w[i] = apply_update(w[i], G, (uint32_t)K, (uint32_t)T, step, regularization, reg_param, truncation);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = G; red[1][tid >> 6] = K; red[2][tid >> 6] = T; }
+    __syncthreads();
+    if (tid == 0) {
+        G = 0; K = 0; T = 0;
+        for (int k = 0; k < NSK_BLOCK / 64; k++) { G += red[0][k]; K += red[1][k]; T += red[2][k]; }
+        double x = w[i];
+        if (K > 0) {
+            x = apply_update(x, G, (uint32_t)K, (uint32_t)T, step, regularization, reg_param, truncation);
+            w[i] = x;
+        }
+        wnew = x;
+    }
+    __syncthreads();
+    const double x = wnew;
+    for (int j = tid; j < nprog; j += NSK_BLOCK) {
+        const uint32_t s = prog[j];
+        if ((int)(s & 0xFFFFFFu) != i) continue;
+        const uint32_t code = (s >> 24) & 7u;
+        const bool last = (s >> 28) & 1u;
+        const double hi = code == 0u ? 0.0 : 1.0;
+        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+        prog_w[2 * j] = last ? x * hi : 0.0;
+        prog_w[2 * j + 1] = last ? x * lo : 0.0;
+    }
 }
 
 // int32 per-call tally deltas -> int64 master copy (the host-visible `count`)
@@ -1088,14 +1114,16 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 g->launches++;
             }
             if (nw > 0) {
-                if (SMALLW)
-                    k_apply_weights_rows<<<dim3(nw), dim3(64), 0, g->stream>>>(
+                if (SMALLW) {
+                    k_apply_weights_rows<<<dim3(nw), dim3(NSK_BLOCK), 0, g->stream>>>(
                         g->w, g->part_G, g->part_K, g->part_T, rows, nw, step, regularization, reg_param,
-                        (double)truncation);
-                else
+                        (double)truncation, g->tile_hdr, g->prog_w,
+                        g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0);
+                } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
                         g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation);
-                refresh_prog_weights(g);
+                    refresh_prog_weights(g);
+                }
             }
         }
         g->sweep++;

@@ -329,14 +329,58 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     c.p_cnt.resize(c.npos); c.p_init.resize(c.npos);
     c.v_pos.assign(nvar, -1);
     {
-        std::vector<int64_t> next_fast(c.phase_start.begin(), c.phase_start.end() - 1);
-        std::vector<int64_t> next_gen(c.phase_fast_end);
-        for (int64_t v = 0; v < nvar; v++)
-            if (c.color[v] >= 0) {
-                int64_t p = fast[v] ? next_fast[c.color[v]]++ : next_gen[c.color[v]]++;
-                c.p_vid[p] = (int32_t)v;
-                c.v_pos[v] = (int32_t)p;
+        // Fast variables of a colour are grouped by "shape class" -- the sequence of (function,
+        // member count, weight id) of their factor lists plus their evidence flag -- so that the 64
+        // lanes of a tile share one slot program (uniform tiles).  Classes with fewer than 64
+        // members in a colour go to a common tail in id order.  Order inside a class: variable id.
+        std::vector<uint64_t> sig(nvar, 0);
+        for (int64_t v = 0; v < nvar; v++) {
+            if (c.color[v] < 0 || !fast[v]) continue;
+            const nsk_variable &var = d->variable[v];
+            const nsk_vtf &vt = d->vmap[var.vtf_offset];
+            uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence;
+            for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
+                uint64_t others = 0;
+                if (fa.factorFunction != -1)
+                    for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++)
+                        if (d->fmap[l].vid != v) others++;
+                const uint64_t word = ((uint64_t)(fa.factorFunction + 1) << 27) | (others << 24) | (uint64_t)fa.weightId;
+                h = (h ^ word) * 0x100000001b3ull;
+                h ^= h >> 29;
             }
+            sig[v] = h | 1;
+        }
+        std::vector<std::map<uint64_t, std::pair<int64_t, int64_t>>> classes((size_t)ncolors);  // sig -> (count, first vid)
+        for (int64_t v = 0; v < nvar; v++)
+            if (c.color[v] >= 0 && fast[v]) {
+                auto &e = classes[c.color[v]][sig[v]];
+                if (e.first++ == 0) e.second = v;
+            }
+        std::vector<int64_t> next_gen(c.phase_fast_end), tail_at((size_t)ncolors, 0);
+        std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors);     // class -> next position
+        for (int32_t k = 0; k < ncolors; k++) {
+            // classes of this colour ranked by first occurrence; small ones share the tail
+            std::vector<std::pair<int64_t, uint64_t>> big;
+            for (auto &kv : classes[k]) if (kv.second.first >= 64) big.push_back({kv.second.second, kv.first});
+            std::sort(big.begin(), big.end());
+            int64_t at = c.phase_start[k];
+            for (auto &b : big) { start[k][b.second] = at; at += classes[k][b.second].first; }
+            classes[k].clear();
+            tail_at[k] = at;
+        }
+        for (int64_t v = 0; v < nvar; v++) {
+            const int32_t k = c.color[v];
+            if (k < 0) continue;
+            int64_t p;
+            if (!fast[v]) p = next_gen[k]++;
+            else {
+                auto it = start[k].find(sig[v]);
+                p = (it != start[k].end()) ? it->second++ : tail_at[k]++;
+            }
+            c.p_vid[p] = (int32_t)v;
+            c.v_pos[v] = (int32_t)p;
+        }
     }
     // ---- inlined adjacency streams of the fast variables, one column-major tile per 64 positions
     c.phase_wb_base.assign((size_t)ncolors + 1, 0);
