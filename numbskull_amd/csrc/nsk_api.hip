@@ -42,6 +42,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_phase(DevGraph<VT> g, int p
     const int ev = NSK_INFO_EV(info);
     if (!(ev == 0 || sample_evidence)) return;          // inference.py:24 (ev == 4 never gets a position)
     const int v = g.p_vid[p];
+    if (v < 0) return;
     const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
     const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));
     g.val[v] = (VT)nv;
@@ -215,18 +216,24 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32
 template <typename VT>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pbegin, int pend,
                                                           int wb_base, int nblocks,
+                                                          const uint32_t *tile_list, int nlist,
                                                           int sample_evidence, int burnin,
                                                           uint32_t k0, uint32_t k1, uint32_t s0,
                                                           uint32_t s1) {
     const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
     if (lb < 0) return;
     const int lane = (int)(threadIdx.x & 63);
-    const int wave = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    int wave = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (tile_list) {                                      // list mode: the tiles outside segments
+        if (wave >= nlist) return;
+        wave = (int)__builtin_amdgcn_readfirstlane(tile_list[wave]);
+    }
     const int p = pbegin + wave * 64 + lane;
     if (pbegin + wave * 64 >= pend) return;               // whole wave beyond the range
-    const bool valid = p < pend;
+    const int v0 = p < pend ? g.p_vid[p] : -1;            // -1 also marks padding positions
+    const bool valid = v0 >= 0;
+    const int v = valid ? v0 : 0;
     const uint32_t info = valid ? g.p_info[p] : 0u;
-    const int v = valid ? g.p_vid[p] : 0;
     const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + wave));
     const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
     const uint4 *sp = g.adj + td.x + lane;
@@ -253,6 +260,68 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     g.val[v] = (VT)nv;
     if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
+}
+
+// Homogeneous segments: runs of consecutive uniform tiles with one program, slot count, kind and
+// evidence flag (the shape-class layout of nsk_compile.cpp makes whole classes such runs).  Up to
+// NSK_SEG_MAX segments of one (kind, chunk count) share a launch; everything the descriptor-driven
+// kernel fetches per tile comes from the kernel-argument table here, and the body is straight
+// line: ids, 16-byte member loads, byte gathers, compares, draw, store.
+#define NSK_SEG_MAX 8
+struct SegTable {
+    int n;
+    int tile_start[NSK_SEG_MAX + 1];      // first tile of each segment in this launch's numbering
+    int pos0[NSK_SEG_MAX];                // position of the segment's first lane
+    uint32_t adj_off[NSK_SEG_MAX];        // stream offset (16-byte units) of its first tile
+    uint32_t prog[NSK_SEG_MAX];           // slot program
+};
+
+template <typename VT, int KIND, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTable tab, int nblocks,
+                                                         int burnin, uint32_t k0, uint32_t k1,
+                                                         uint32_t s0, uint32_t s1) {
+    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
+    if (lb < 0) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int T = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (T >= tab.tile_start[tab.n]) return;
+    int sidx = 0;
+#pragma unroll
+    for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+    const int t = T - tab.tile_start[sidx];
+    const uint32_t prog = tab.prog[sidx];
+    const int p = tab.pos0[sidx] + t * 64 + lane;
+    const int v = g.p_vid[p];                             // -1: padding lane at a class end
+    const uint8_t tally = burnin ? (uint8_t)0 : g.cnt_pos[p];
+    const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
+    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    uint4 q[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];
+    int x[4 * NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        x[4 * c] = (int)g.val[q[c].x]; x[4 * c + 1] = (int)g.val[q[c].y];
+        x[4 * c + 2] = (int)g.val[q[c].z]; x[4 * c + 3] = (int)g.val[q[c].w];
+    }
+    double p0 = 0.0, p1 = 0.0;
+    SlotState st = {0, true, false, true};
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) {
+        const double thi = tw[2 * j], tlo = tw[2 * j + 1];
+        if (KIND) pair_step<KIND>(thi, tlo, x[j], p0, p1);
+        else slot_step(st, pp[j], thi, tlo, x[j], p0, p1);
+    }
+    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const double z0 = nsk_exp(p0);
+    const double z1 = z0 + nsk_exp(p1);
+    const double z = u53(rr.x, rr.y) * z1;
+    const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    if (v >= 0) {
+        g.val[v] = (VT)nv;
+        if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -312,7 +381,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_phase(DevGraph<VT> g, int p
         const int p = (list ? (int)list[item] : pbegin + 64 * item) + lane;
         bool more = false, truncate = false;
         int v = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
-        if (p < pend) {
+        if (p < pend && g.p_vid[p] >= 0) {
             const uint32_t info = g.p_info[p];
             const int ev = NSK_INFO_EV(info);
             const int slot0 = g.p_slot[p];
@@ -498,7 +567,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
         const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
         if (td.z == NSK_PAD_WORD) continue;                  // per-lane headers: generic kernel's job
         const int p = pbegin + t * 64 + lane;
-        const bool valid = p < pend;
+        const bool valid = p < pend && g.p_vid[p] >= 0;
         const uint4 *sp = g.adj + td.x + lane;
         const uint32_t kind = (td.w >> 8) & 7u;
         if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
@@ -749,7 +818,7 @@ struct nsk_graph {
     int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
     uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr;
     double *prog_w = nullptr;
-    uint32_t *dyn_tiles = nullptr;
+    uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr;
     long long *part_G = nullptr;       // SMALLW: rows of per-block partial sums
     uint32_t *part_K = nullptr, *part_T = nullptr;
     bool smallw = false;
@@ -893,7 +962,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
     UP(f_head); UP(f_off); UP(f_wid); UP(f_feat); UP(m_vid); UP(m_deo); UP(v_card); UP(v_pos);
-    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles);
+    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
@@ -1032,13 +1101,51 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
             for (size_t ph = 0; ph < nphase; ph++) {
                 const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
                 const int e = (int)g->c.phase_start[ph + 1];
-                if (fe > fb) {      // inlined-adjacency kernel
-                    const int nblocks = (fe - fb + NSK_BLOCK - 1) / NSK_BLOCK;
-                    k_gibbs_fast<VT><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        d, fb, fe, (int)g->c.phase_wb_base[ph], nblocks, sample_evidence, burnin,
-                        (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep,
-                        (uint32_t)(g->sweep >> 32));
-                    g->launches++;
+                if (fe > fb) {      // inlined-adjacency kernels
+                    const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
+                    const uint32_t S0 = (uint32_t)g->sweep, S1 = (uint32_t)(g->sweep >> 32);
+                    // segments of this colour, batched by (kind, chunks) into table launches
+                    for (int kind = 0; kind <= 4; kind++) {
+                        if (kind == 1) continue;                 // IMPLY_NATURAL shares the AND step (3)
+                        for (int nch = 1; nch <= 2; nch++) {
+                            SegTable tab;
+                            tab.n = 0; tab.tile_start[0] = 0;
+                            auto flush = [&]() {
+                                if (tab.n == 0) return;
+                                const int nb = (tab.tile_start[tab.n] + 3) / 4;
+                                const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
+#define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
+                                if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
+                                else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
+                                else if (kind == 0) { if (nch == 1) NSK_SEG(0, 1); else NSK_SEG(0, 2); }
+                                else { if (nch == 1) NSK_SEG(3, 1); else NSK_SEG(3, 2); }
+#undef NSK_SEG
+                                g->launches++;
+                                tab.n = 0;
+                            };
+                            for (const Compiled::Segment &sg : g->c.segments) {
+                                if (sg.phase != (int)ph) continue;
+                                const int k3 = sg.kind == 1 ? 3 : (int)sg.kind;
+                                if (k3 != kind || (sg.nslots > 4 ? 2 : 1) != nch) continue;
+                                if (!(sg.ev == 0 || sample_evidence)) continue;      // inference.py:24
+                                tab.pos0[tab.n] = (int)sg.pos0;
+                                tab.adj_off[tab.n] = sg.adj_off;
+                                tab.prog[tab.n] = sg.prog;
+                                tab.tile_start[tab.n + 1] = tab.tile_start[tab.n] + sg.ntiles;
+                                if (++tab.n == NSK_SEG_MAX) flush();
+                            }
+                            flush();
+                        }
+                    }
+                    const int nrest = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
+                    if (nrest > 0) {
+                        const int nblocks = (nrest + 3) / 4;
+                        k_gibbs_fast<VT><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], nblocks,
+                            g->rest_tiles + g->c.phase_rest_base[ph], nrest, sample_evidence, burnin,
+                            K0, K1, S0, S1);
+                        g->launches++;
+                    }
                 }
                 if (e > fe) {       // generic CSR kernel
                     k_gibbs_phase<VT><<<dim3((e - fe + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
@@ -1238,12 +1345,12 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
 
 static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->nvar = c.nvar;
-    info->nowned = c.npos;
+    info->nowned = c.nsampled;
     info->ncolors = (int64_t)c.phase_start.size() - 1;
     info->value_bytes = c.vbytes;
     info->device_bytes = 0;
     info->nfast = c.nfast;
-    info->ngeneric = c.npos - c.nfast;
+    info->ngeneric = c.nsampled - c.nfast;
     info->alg_bytes_inference = c.alg_bytes_inference;
     info->alg_bytes_learning = c.alg_bytes_learning;
     info->sweeps_done = 0;

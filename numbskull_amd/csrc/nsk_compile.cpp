@@ -314,25 +314,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         fast[v] = ok;
     }
 
-    // ---- positions: colour-major; inside a colour the fast variables first, id order ----------
+    // ---- positions: colour-major.  Inside a colour: the fast variables grouped by "shape class"
+    // -- the sequence of (function, member count, weight id) of their factor lists plus their
+    // evidence flag -- so that the 64 lanes of a tile share one slot program; every class with at
+    // least 64 members starts on a tile boundary (the gap is padded with empty positions,
+    // p_vid = -1); smaller classes share a tail in id order; then the generic-path variables.
+    // Order inside a class: variable id.
     c.phase_start.assign((size_t)ncolors + 1, 0);
     c.phase_fast_end.assign((size_t)ncolors, 0);
-    for (int64_t v = 0; v < nvar; v++)
-        if (c.color[v] >= 0) {
-            c.phase_start[c.color[v] + 1]++;
-            if (fast[v]) c.phase_fast_end[c.color[v]]++;
-        }
-    for (int32_t k = 0; k < ncolors; k++) c.phase_start[k + 1] += c.phase_start[k];
-    for (int32_t k = 0; k < ncolors; k++) c.phase_fast_end[k] += c.phase_start[k];
-    c.npos = c.phase_start[ncolors];
-    c.p_vid.resize(c.npos); c.p_info.resize(c.npos); c.p_slot.resize(c.npos);
-    c.p_cnt.resize(c.npos); c.p_init.resize(c.npos);
     c.v_pos.assign(nvar, -1);
     {
-        // Fast variables of a colour are grouped by "shape class" -- the sequence of (function,
-        // member count, weight id) of their factor lists plus their evidence flag -- so that the 64
-        // lanes of a tile share one slot program (uniform tiles).  Classes with fewer than 64
-        // members in a colour go to a common tail in id order.  Order inside a class: variable id.
         std::vector<uint64_t> sig(nvar, 0);
         for (int64_t v = 0; v < nvar; v++) {
             if (c.color[v] < 0 || !fast[v]) continue;
@@ -352,23 +343,46 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             sig[v] = h | 1;
         }
         std::vector<std::map<uint64_t, std::pair<int64_t, int64_t>>> classes((size_t)ncolors);  // sig -> (count, first vid)
-        for (int64_t v = 0; v < nvar; v++)
-            if (c.color[v] >= 0 && fast[v]) {
-                auto &e = classes[c.color[v]][sig[v]];
+        std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0);
+        for (int64_t v = 0; v < nvar; v++) {
+            const int32_t k = c.color[v];
+            if (k < 0) continue;
+            if (fast[v]) {
+                auto &e = classes[k][sig[v]];
                 if (e.first++ == 0) e.second = v;
+                nfast_of[k]++;
+            } else {
+                ngen_of[k]++;
             }
-        std::vector<int64_t> next_gen(c.phase_fast_end), tail_at((size_t)ncolors, 0);
-        std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors);     // class -> next position
-        for (int32_t k = 0; k < ncolors; k++) {
-            // classes of this colour ranked by first occurrence; small ones share the tail
-            std::vector<std::pair<int64_t, uint64_t>> big;
-            for (auto &kv : classes[k]) if (kv.second.first >= 64) big.push_back({kv.second.second, kv.first});
-            std::sort(big.begin(), big.end());
-            int64_t at = c.phase_start[k];
-            for (auto &b : big) { start[k][b.second] = at; at += classes[k][b.second].first; }
-            classes[k].clear();
-            tail_at[k] = at;
         }
+        std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0);
+        std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors);     // class -> next position
+        int64_t pos = 0;
+        for (int32_t k = 0; k < ncolors; k++) {
+            c.phase_start[k] = pos;
+            std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, class)
+            int64_t nbig = 0;
+            for (auto &kv : classes[k])
+                if (kv.second.first >= 64) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
+            std::sort(big.begin(), big.end());
+            for (auto &bc : big) {
+                start[k][bc.second] = pos;
+                pos += classes[k][bc.second].first;
+                pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
+            }
+            classes[k].clear();
+            tail_at[k] = pos;
+            pos += nfast_of[k] - nbig;
+            pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
+            c.phase_fast_end[k] = pos;
+            next_gen[k] = pos;
+            pos += ngen_of[k];
+        }
+        c.phase_start[ncolors] = pos;
+        c.npos = pos;
+        if (c.npos >= LIM - 1) { err = "too many positions"; return NSK_E_RANGE; }
+        c.p_vid.assign(c.npos, -1); c.p_info.assign(c.npos, 0); c.p_slot.assign(c.npos, 0);
+        c.p_cnt.assign(c.npos, 0); c.p_init.assign(c.npos, 0);
         for (int64_t v = 0; v < nvar; v++) {
             const int32_t k = c.color[v];
             if (k < 0) continue;
@@ -380,6 +394,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
             c.p_vid[p] = (int32_t)v;
             c.v_pos[v] = (int32_t)p;
+            c.nsampled++;
         }
     }
     // ---- inlined adjacency streams of the fast variables, one column-major tile per 64 positions
@@ -420,12 +435,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
                 int64_t len = 0;
                 bool uniform = true;
+                bool have0 = false;
                 for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;                  // padding position
                     lane_words(c.p_vid[p], words);
                     len = std::max<int64_t>(len, (int64_t)words.size());
-                    headers_of(words, p == p0 ? hdrs0 : hdrs);
-                    if (p != p0 && hdrs != hdrs0) uniform = false;
+                    headers_of(words, have0 ? hdrs : hdrs0);
+                    if (have0 && hdrs != hdrs0) uniform = false;
+                    have0 = true;
                 }
+                if (!have0) { hdrs0.clear(); uniform = false; }
                 td[2] = 0xFFFFFFFFu;
                 // slot program of a uniform tile: one word per member slot (an entry without other
                 // members still gets one, ignored, slot):
@@ -475,6 +494,52 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             c.phase_dyn_base[k + 1] = (int64_t)c.dyn_tiles.size();
         }
         if (c.dyn_tiles.empty()) c.dyn_tiles.push_back(0);
+        // homogeneous segments and the rest list
+        const int64_t SEG_MIN = 1;
+        c.phase_rest_base.assign((size_t)ncolors + 1, 0);
+        for (int32_t k = 0; k < ncolors; k++) {
+            const int64_t nt = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
+            auto tile_ev = [&](int64_t b, bool &full) -> int {     // common isEvidence of a tile or -999
+                const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+                full = true;                                       // padding lanes are masked in-kernel
+                int ev = -999;
+                for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;
+                    const int e2 = d->variable[c.p_vid[p]].isEvidence;
+                    if (ev == -999) ev = e2;
+                    else if (e2 != ev) return -999;
+                }
+                return ev;
+            };
+            int64_t b = 0;
+            while (b < nt) {
+                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                bool full;
+                const int ev = tile_ev(b, full);
+                int64_t e = b + 1;
+                const bool seg_ok = td[2] != 0xFFFFFFFFu && full && ev != -999 && (td[3] & 0xFFu) > 0;
+                if (seg_ok) {
+                    while (e < nt) {
+                        const uint32_t *te = &c.tiles[4 * (c.phase_wb_base[k] + e)];
+                        bool f2;
+                        if (te[2] != td[2] || te[3] != td[3] || te[1] != td[1] || tile_ev(e, f2) != ev || !f2) break;
+                        e++;
+                    }
+                }
+                if (e - b >= SEG_MIN && seg_ok) {
+                    Compiled::Segment sg;
+                    sg.phase = k; sg.pos0 = c.phase_start[k] + 64 * b; sg.ntiles = (int32_t)(e - b);
+                    sg.adj_off = td[0]; sg.prog = td[2]; sg.nslots = td[3] & 0xFFu; sg.kind = (td[3] >> 8) & 7u;
+                    sg.ev = ev;
+                    c.segments.push_back(sg);
+                } else {
+                    for (int64_t t = b; t < e; t++) c.rest_tiles.push_back((uint32_t)t);
+                }
+                b = e;
+            }
+            c.phase_rest_base[k + 1] = (int64_t)c.rest_tiles.size();
+        }
+        if (c.rest_tiles.empty()) c.rest_tiles.push_back(0);
         // pass 2: fill the tiles.  Padding: member slots read variable 0 (harmless) in uniform
         // tiles, 0xFFFFFFFF in tiles with per-lane headers.
         c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);
@@ -487,6 +552,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 if (uniform)
                     for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = 0;
                 for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;
                     lane_words(c.p_vid[p], words);
                     size_t out = 0;
                     auto put = [&](uint32_t word) {
@@ -507,6 +573,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     }
     int64_t nslot = 0, nlist = 0;
     for (int64_t p = 0; p < c.npos; p++) {
+        if (c.p_vid[p] < 0) continue;
         const nsk_variable &var = d->variable[c.p_vid[p]];
         const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
         for (int64_t k = 0; k < nslots; k++) nlist += d->vmap[var.vtf_offset + k].factor_index_length;
@@ -526,6 +593,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     int64_t si = 0, li = 0;
     for (int64_t p = 0; p < c.npos; p++) {
         const int64_t v = c.p_vid[p];
+        if (v < 0) { c.p_slot[p] = (int32_t)si; continue; }      // padding position
         const nsk_variable &var = d->variable[v];
         const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
         c.p_info[p] = ((uint32_t)var.cardinality << 9) | ((var.dataType != 0) ? 0x100u : 0u) |

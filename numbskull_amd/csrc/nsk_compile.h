@@ -15,7 +15,8 @@ namespace nsk {
 struct Compiled {
     // sizes
     int64_t nvar = 0, nweight = 0, nfactor = 0, nedge = 0, ncount = 0;
-    int64_t npos = 0, nslot = 0;
+    int64_t npos = 0, nslot = 0;    // npos counts padding positions too
+    int64_t nsampled = 0;           // variables this handle samples
     int vbytes = 1;                 // 1: int8 values, 4: int32 values
     int flags = 0;
     int64_t own_begin = 0, own_end = 0;
@@ -42,6 +43,14 @@ struct Compiled {
     // them to the generic kernel): dyn_tiles[phase_dyn_base[k] .. phase_dyn_base[k+1])
     std::vector<uint32_t> dyn_tiles;
     std::vector<int64_t> phase_dyn_base;
+    // Homogeneous segments: runs of >= NSK_SEG_MIN_TILES consecutive FULL uniform tiles with one
+    // program, slot count, kind and evidence flag.  The inference sweep launches a straight-line
+    // kernel per segment with the tile description in kernel arguments; the tiles outside any
+    // segment (rest_tiles, per phase) go through the descriptor-driven kernel.
+    struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev; };
+    std::vector<Segment> segments;
+    std::vector<uint32_t> rest_tiles;       // tile indices relative to the phase's first tile
+    std::vector<int64_t> phase_rest_base;   // [ncolors+1]
     int64_t nfast = 0;
     // per position
     std::vector<int32_t> p_vid, p_slot, p_cnt;

@@ -49,9 +49,7 @@ __device__ __forceinline__ double pow2i(int k) {
 }
 
 __device__ __forceinline__ double nsk_exp(double x) {
-    if (x != x) return x;
-    if (x > 709.782712893384) return __longlong_as_double(0x7ff0000000000000LL);
-    if (x < -745.1332191019412) return 0.0;
+    // same values as the oracle's early returns, written as selects so that no lane branches
     const double INV_LN2 = 1.4426950408889634;
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
@@ -73,9 +71,13 @@ __device__ __forceinline__ double nsk_exp(double x) {
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     int k = (int)kf;
+    k = k > 1100 ? 1100 : (k < -1100 ? -1100 : k);     // keeps pow2i's bit pattern well-formed
     int k1 = k / 2;
     int k2 = k - k1;
-    return (p * pow2i(k1)) * pow2i(k2);
+    double res = (p * pow2i(k1)) * pow2i(k2);
+    res = (x > 709.782712893384) ? __longlong_as_double(0x7ff0000000000000LL) : res;
+    res = (x < -745.1332191019412) ? 0.0 : res;
+    return (x != x) ? x : res;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -500,3 +500,36 @@ def test_two_partitions_on_one_gpu_match_emulation(learn):
             assert np.array_equal(parts[r].val_evid.cpu().numpy().astype(np.int64), ve)
             assert np.allclose(parts[r].w.cpu().numpy(), wv, rtol=0, atol=1e-15)
     assert torch.equal(parts[0].val, parts[1].val)
+
+
+def test_rccl_all_gather_on_library_memory():
+    """A 1-rank RCCL ("nccl") group runs the exact collective calls of the multi-GPU path
+    (in-place all_gather_into_tensor on the int8 value buffer the library allocated, all-reduce of
+    the float64 weight delta) -- the 8-GPU run is the driver's, this checks the API contract."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from numbskull_amd.distributed import PartitionedSampler, exchange_values, merge_weight_deltas
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g = graphgen.ising_grid(48, 50, weight=0.2, fixed=False)
+        ns, fg = session(g, seed=2)
+        ps = PartitionedSampler(fg, dist, torch, 0, 1)
+        ps.gibbs(3)
+        before = ps.val.clone()
+        exchange_values(dist, ps.val, 1, ps.nvar)
+        start = ps.w.clone()
+        ps.w += 0.25
+        merge_weight_deltas(dist, ps.w, start)
+        torch.cuda.synchronize()
+        assert torch.equal(before, ps.val)
+        assert torch.allclose(ps.w, start + 0.25)
+    finally:
+        dist.destroy_process_group()
