@@ -48,29 +48,31 @@ def ising_grid(nrows, ncols, weight=0.1, fixed=True, two_weights=False, evidence
     wrec["isFixed"] = bool(fixed)
     wrec["initialValue"] = weight
 
-    ii, jj = np.divmod(np.arange(nvar, dtype=np.int64), m)
-    has_up = ii > 0
-    has_left = jj > 0
-    nfac_of = has_up.astype(np.int64) + has_left.astype(np.int64)
-    first = np.cumsum(nfac_of) - nfac_of          # id of the first factor emitted by a cell
-    nfactor = int(nfac_of.sum())
+    # candidate factors per cell in emission order [up, left]; keep the ones that exist
+    me = np.arange(nvar, dtype=np.int64)
+    exists = np.empty((nvar, 2), np.bool_)
+    exists[:, 0] = me >= m                    # i > 0: factor to the cell above
+    exists[:, 1] = (me % m) != 0              # j > 0: factor to the left neighbour
+    other = np.empty((nvar, 2), np.int64)
+    other[:, 0] = me - m
+    other[:, 1] = me - 1
+    keep = exists.ravel()
+    first = np.repeat(me, 2)[keep]
+    second = other.ravel()[keep]
+    nfactor = int(first.shape[0])
 
     factor = np.zeros(nfactor, Factor)
     factor["factorFunction"] = FUNC_EQUAL
     factor["featureValue"] = 1.0
     factor["arity"] = 2
     factor["ftv_offset"] = 2 * np.arange(nfactor, dtype=np.int64)
-    fmap = np.zeros(2 * nfactor, FactorToVar)
-
-    me = np.arange(nvar, dtype=np.int64)
-    up_f = first[has_up]
-    fmap["vid"][2 * up_f] = me[has_up]
-    fmap["vid"][2 * up_f + 1] = me[has_up] - m
-    left_f = first[has_left] + has_up[has_left]
-    fmap["vid"][2 * left_f] = me[has_left]
-    fmap["vid"][2 * left_f + 1] = me[has_left] - 1
     if two_weights:
-        factor["weightId"][left_f] = 1
+        factor["weightId"] = np.tile(np.array([0, 1], np.int64), nvar)[keep]
+    vid = np.empty(2 * nfactor, np.int64)
+    vid[0::2] = first
+    vid[1::2] = second
+    fmap = np.zeros(2 * nfactor, FactorToVar)
+    fmap["vid"] = vid
 
     return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), 2 * nfactor
 
