@@ -7,7 +7,7 @@ CTRS=$1; shift
 OUT=$R/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/log.txt 2>&1
+rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra "$@" > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv,glob,collections
 res=collections.defaultdict(lambda: collections.defaultdict(list))

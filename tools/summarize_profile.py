@@ -81,9 +81,16 @@ for k, c in summary["pmc"].items():
         print("%s: HBM bytes/launch = %.4g (read %.4g + write %.4g), corrected" % (k, fb + wb, fb, wb))
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 # bench.py reports roofline.traffic from profiles/traffic.json: HBM bytes per launch of the dominant kernel
-dom = None
-for k, c in summary["pmc"].items():
-    if "hbm_bytes_per_launch" in c and (dom is None or "fast" in k):
-        dom = c["hbm_bytes_per_launch"]
+# dominant sweep kernel = the gibbs/learn kernel with the largest total time in the stats pass
+dom, best = None, -1.0
+for kr in summary["kernels"]:
+    if not ("k_gibbs" in kr["name"] or "k_learn" in kr["name"]):
+        continue
+    for k, c in summary["pmc"].items():
+        if k[:36] == kr["name"][:36] and "hbm_bytes_per_launch" in c and kr["total_ns"] > best:
+            dom, best = c["hbm_bytes_per_launch"], kr["total_ns"]
+            summary["dominant_kernel"] = kr["name"]
 if dom is not None:
     json.dump({wl: dom}, open(os.path.join(out, "traffic_%s.json" % wl), "w"))
+    json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+    print("dominant kernel:", summary.get("dominant_kernel"), "HBM bytes/launch", dom)
