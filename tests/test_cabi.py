@@ -164,3 +164,58 @@ def test_factor_table_and_api_surface():
     assert [o["dest"] for _, o in numbskull.flags] == ["sample_evidence", "learn_non_evidence",
                                                        "quiet", "verbose"]
     assert numbskull_amd.__version__.startswith("0.1.1")
+
+
+def _graph_from_spec(nvar, spec, card=None, weights=(0.5,)):
+    """tiny graph from [(function, [member ids])]"""
+    variable = np.zeros(nvar, Variable)
+    variable["cardinality"] = 2 if card is None else card
+    factor = np.zeros(len(spec), Factor)
+    fmap = np.zeros(sum(len(m) for _, m in spec), FactorToVar)
+    e = 0
+    for i, (fn, members) in enumerate(spec):
+        factor[i] = (fn, i % len(weights), 1.0, len(members), e)
+        for m in members:
+            fmap[e]["vid"] = m
+            e += 1
+    weight = np.zeros(len(weights), Weight)
+    weight["initialValue"] = weights
+    return weight, variable, factor, fmap, np.zeros(nvar, np.bool_), e
+
+
+def test_plan_edge_cases():
+    """empty graph, isolated variables, cardinality-1 variables, a factor over one variable twice,
+    a hub factor that forces many colours -- planning must succeed and colour validly"""
+    from util import check_coloring
+    ns, fg = session(_graph_from_spec(0, []))
+    color, info = fg.plan()
+    assert info["nowned"] == 0 and info["ncolors"] == 0 and len(color) == 0
+    ns, fg = session(_graph_from_spec(5, []))                       # no factors at all
+    color, info = fg.plan()
+    assert info["ncolors"] == 1 and info["nfast"] == 5
+    ns, fg = session(_graph_from_spec(3, [(4, [0]), (3, [1, 1]), (1, [2, 2, 0])],
+                                      card=np.array([1, 2, 2])))
+    color, info = fg.plan()
+    check_coloring(fg, color)
+    ns, fg = session(_graph_from_spec(40, [(2, list(range(40)))]))  # one AND over 40 variables
+    color, info = fg.plan()
+    assert info["ncolors"] == 40 and info["ngeneric"] == 40         # > 6 other members: generic path
+    check_coloring(fg, color)
+
+
+def test_bad_graphs_are_rejected_with_reference_like_errors():
+    g = list(_graph_from_spec(3, [(3, [0, 1])]))
+    g[3] = g[3].copy()
+    g[3]["vid"][1] = 7                                               # member outside the variables
+    with pytest.raises(IndexError):
+        session(tuple(g))                                            # compute_var_map faults first
+    g = list(_graph_from_spec(3, [(3, [0, 1])]))
+    g[2] = g[2].copy()
+    g[2]["weightId"][0] = 5
+    ns, fg = session(tuple(g))
+    with pytest.raises(IndexError):
+        fg.plan()
+    g = list(_graph_from_spec(2, [(21, [0])]))                       # DP_GEN_LF_ACCURACY reads 2 members
+    ns, fg = session(tuple(g))
+    with pytest.raises(IndexError):
+        fg.plan()

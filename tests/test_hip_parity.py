@@ -533,3 +533,60 @@ def test_rccl_all_gather_on_library_memory():
         assert torch.allclose(ps.w, start + 0.25)
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
+# edge cases
+# ------------------------------------------------------------------------------------------
+def test_edge_case_graphs_run_and_match_oracle():
+    """empty graph; isolated variables (uniform draws); cardinality-1 variables; a variable listed
+    twice in one factor; a 40-member hub factor (40 colours)"""
+    from test_cabi import _graph_from_spec
+    ns, fg = session(_graph_from_spec(0, []))
+    fg.inference(2, 3, True)
+    fg.learn(0, 2, 0.1, 0.9, 2, 0.01, 1)
+    assert fg.count.shape == (0,)
+    cases = [
+        _graph_from_spec(200, []),
+        _graph_from_spec(3, [(4, [0]), (3, [1, 1]), (1, [2, 2, 0])], card=np.array([1, 2, 2])),
+        _graph_from_spec(40, [(2, list(range(40)))]),
+        _graph_from_spec(70, [(3, [i, (i + 1) % 70]) for i in range(70)] + [(-1, [5])],
+                         weights=(0.5, -0.3)),
+    ]
+    for g in cases:
+        ns, fg = session(g, seed=13)
+        og = oracle_of(fg)
+        order, ps = phases_from_colors(fg.colors())
+        vv, ve, wv, cnt = og.initial_state()
+        fg.inference(1, 6, True)
+        og.gibbs_dev(order, ps, vv, wv, cnt, 13, 0, True, burnin=True)
+        for s in range(6):
+            og.gibbs_dev(order, ps, vv, wv, cnt, 13, 1 + s, True)
+        assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+        fg.learn(0, 3, 0.05, 0.9, 1, 0.02, 2, learn_non_evidence=True)
+        step = 0.05
+        for s in range(3):
+            og.learn_dev(order, ps, vv, ve, wv, step, 1, 0.02, 2, True, 13, 7 + s)
+            step *= 0.9
+        assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.weight_value[0], wv)
+    # isolated variables are fair coins
+    ns, fg = session(_graph_from_spec(2000, []), seed=3)
+    fg.inference(0, 500, True)
+    assert abs(fg.marginals.mean() - 0.5) < 0.005
+
+
+def test_tally_survives_more_than_255_sweeps_and_repeated_calls():
+    """the fast path tallies in uint8 per position and folds every 255 sweeps"""
+    g = graphgen.ising_grid(16, 16, weight=0.3)
+    ns, fg = session(g, seed=21)
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, _, wv, cnt = og.initial_state()
+    sweep = 0
+    for n in (300, 1, 254, 600):
+        fg.inference(0, n, True)
+        for _ in range(n):
+            og.gibbs_dev(order, ps, vv, wv, cnt, 21, sweep, True)
+            sweep += 1
+        assert np.array_equal(fg.count, cnt), n
+    assert fg.count.max() > 255
