@@ -420,10 +420,11 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_phase(DevGraph<VT> g, int p
                 if (fa == fid) a++;
                 if (fb == fid) b++;
                 more = (a < ae) || (b < be);
-                wid = g.f_wid[fid];
+                const uint4 rec = g.f_rec[fid];
+                wid = (int)rec.z;
                 if (!g.w_fixed[wid]) {                                                            // 100-101
-                    const double p0 = eval_factor(g, fid, v, evidence, g.val_evid);
-                    const double p1 = eval_factor(g, fid, v, proposal, g.val);
+                    const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
+                    const double p1 = eval_factor(g, rec, v, proposal, g.val);
                     const double gradient = (p1 - p0) * g.f_feat[fid];                            // 109
                     gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
                     have = true;
@@ -754,10 +755,11 @@ __global__ void k_seq_learn(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rn
                 const int fid = fa < fb ? fa : fb;
                 if (fa == fid) a++;
                 if (fb == fid) b++;
-                const int wid = g.f_wid[fid];
+                const uint4 rec = g.f_rec[fid];
+                const int wid = (int)rec.z;
                 if (g.w_fixed[wid]) continue;
-                const double p0 = eval_factor(g, fid, v, evidence, g.val_evid);
-                const double p1 = eval_factor(g, fid, v, proposal, g.val);
+                const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
+                const double p1 = eval_factor(g, rec, v, proposal, g.val);
                 const double gradient = (p1 - p0) * g.f_feat[fid];
                 double w = g.w[wid];
                 if (regularization == 2) {
@@ -806,9 +808,9 @@ struct nsk_graph {
     int64_t device_bytes = 0;
     // device arrays
     int32_t *p_vid = nullptr, *p_slot = nullptr, *p_cnt = nullptr, *slot_off = nullptr, *fidx = nullptr;
-    uint32_t *p_info = nullptr, *f_head = nullptr;
+    uint32_t *p_info = nullptr, *f_rec = nullptr;
     void *p_init = nullptr;
-    int32_t *f_off = nullptr, *f_wid = nullptr, *m_vid = nullptr, *m_deo = nullptr, *v_card = nullptr,
+    int32_t *m_rec = nullptr, *v_card = nullptr,
             *v_pos = nullptr;
     double *f_feat = nullptr, *w = nullptr, *logtab = nullptr;
     uint8_t *w_fixed = nullptr;
@@ -901,8 +903,8 @@ static DevGraph<VT> view(nsk_graph *g) {
     d.p_vid = g->p_vid; d.p_info = g->p_info; d.p_slot = g->p_slot; d.p_cnt = g->p_cnt;
     d.p_init = (const VT *)g->p_init;
     d.slot_off = g->slot_off; d.fidx = g->fidx;
-    d.f_head = g->f_head; d.f_off = g->f_off; d.f_wid = g->f_wid; d.f_feat = g->f_feat;
-    d.m_vid = g->m_vid; d.m_deo = g->m_deo; d.v_card = g->v_card;
+    d.f_rec = (const uint4 *)g->f_rec; d.f_feat = g->f_feat;
+    d.m_rec = (const int2 *)g->m_rec; d.v_card = g->v_card;
     d.w = g->w; d.w_fixed = g->w_fixed; d.logtab = g->logtab;
     d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
     d.G = g->G; d.K = g->K; d.T = g->T;
@@ -961,7 +963,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     Compiled &c = g->c;
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
-    UP(f_head); UP(f_off); UP(f_wid); UP(f_feat); UP(m_vid); UP(m_deo); UP(v_card); UP(v_pos);
+    UP(f_rec); UP(f_feat); UP(m_rec); UP(v_card); UP(v_pos);
     UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;

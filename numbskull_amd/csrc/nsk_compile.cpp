@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace nsk {
@@ -102,7 +103,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     }
 
     // ---- factors and edges: narrow copies; validated lazily for factors that are reachable ----
-    c.f_head.resize(nfac); c.f_off.resize(nfac); c.f_wid.resize(nfac); c.f_feat.resize(nfac);
+    c.f_rec.assign((size_t)nfac * 4 + 4, 0); c.f_feat.resize(nfac);
     for (int64_t f = 0; f < nfac; f++) {
         const nsk_factor &fa = d->factor[f];
         int64_t ar = fa.arity;
@@ -111,16 +112,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             err = fmt("factor %lld: arity %lld too large", f, fa.arity);
             return NSK_E_RANGE;
         }
-        c.f_head[f] = ((uint32_t)ar << 8) | (uint32_t)((fa.factorFunction + 1) & 0xff);
-        c.f_off[f] = (int32_t)std::max<int64_t>(std::min<int64_t>(fa.ftv_offset, LIM - 2), -1);
-        c.f_wid[f] = (int32_t)std::max<int64_t>(std::min<int64_t>(fa.weightId, LIM - 2), -1);
+        c.f_rec[4 * f] = ((uint32_t)ar << 8) | (uint32_t)((fa.factorFunction + 1) & 0xff);
+        c.f_rec[4 * f + 1] = (uint32_t)(int32_t)std::max<int64_t>(std::min<int64_t>(fa.ftv_offset, LIM - 2), -1);
+        c.f_rec[4 * f + 2] = (uint32_t)(int32_t)std::max<int64_t>(std::min<int64_t>(fa.weightId, LIM - 2), -1);
         c.f_feat[f] = fa.featureValue;
     }
-    c.m_vid.resize(nedge); c.m_deo.resize(nedge);
+    c.m_rec.assign((size_t)nedge * 2 + 2, 0);
     for (int64_t l = 0; l < nedge; l++) {
         int64_t vid = d->fmap[l].vid, deo = d->fmap[l].dense_equal_to;
-        c.m_vid[l] = (vid < 0 || vid >= nvar) ? -1 : (int32_t)vid;
-        c.m_deo[l] = (int32_t)std::max<int64_t>(std::min<int64_t>(deo, INT32_MAX), INT32_MIN);
+        c.m_rec[2 * l] = (vid < 0 || vid >= nvar) ? -1 : (int32_t)vid;
+        c.m_rec[2 * l + 1] = (int32_t)std::max<int64_t>(std::min<int64_t>(deo, INT32_MAX), INT32_MIN);
     }
 
     // ---- which variables does this handle sample? -------------------------------------------
@@ -293,8 +294,9 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // weight id below 2^24; and featureValue == 1 so that learning can use the same stream.
     std::vector<uint8_t> fast(nvar, 0);
     auto fast_function = [](int fn) { return fn == -1 || (fn >= 0 && fn <= 4); };
+    const bool no_fast = getenv("NSK_NO_FAST") != nullptr;      // diagnostic: everything on the generic path
     for (int64_t v = 0; v < nvar; v++) {
-        if (c.color[v] < 0) continue;
+        if (c.color[v] < 0 || no_fast) continue;
         const nsk_variable &var = d->variable[v];
         if (var.cardinality != 2 || var.dataType != 0) continue;
         const nsk_vtf &vt = d->vmap[var.vtf_offset];

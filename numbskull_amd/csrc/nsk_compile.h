@@ -59,10 +59,9 @@ struct Compiled {
     // inverted index
     std::vector<int32_t> slot_off, fidx;
     // per factor / edge / variable
-    std::vector<uint32_t> f_head;
-    std::vector<int32_t> f_off, f_wid;
+    std::vector<uint32_t> f_rec;        // [4*nfactor] {arity << 8 | function+1, ftv_offset, weightId, 0}
     std::vector<double> f_feat;
-    std::vector<int32_t> m_vid, m_deo;
+    std::vector<int32_t> m_rec;         // [2*nedge] {variable id, dense_equal_to}
     std::vector<int32_t> v_card, v_pos;
     std::vector<int64_t> cstart;        // [nvar+1]
     // weights

@@ -157,14 +157,11 @@ struct DevGraph {
     // inverted index, compacted and laid out in position order
     const int32_t *slot_off;    // [nslot+1] offsets into fidx
     const int32_t *fidx;        // sorted-unique factor ids per (variable, value) slot
-    // per factor
-    const uint32_t *f_head;     // arity << 8 | function+1
-    const int32_t *f_off;       // ftv_offset
-    const int32_t *f_wid;       // weightId
+    // per factor: one 16-byte record {arity << 8 | function+1, ftv_offset, weightId, 0}
+    const uint4 *f_rec;
     const double *f_feat;       // featureValue
-    // per edge
-    const int32_t *m_vid;
-    const int32_t *m_deo;       // dense_equal_to
+    // per edge: one 8-byte record {variable id, dense_equal_to}
+    const int2 *m_rec;
     // per variable id
     const int32_t *v_card;      // cardinality (data-programming "abstain" lookups)
     // weights
@@ -264,9 +261,18 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nblocks) {
 // member value at absolute edge index l with the sampled variable hypothetically at `value`
 template <typename VT>
 __device__ __forceinline__ int member(const DevGraph<VT> &g, int l, int var_samp, int value,
-                                      const VT *__restrict__ val) {
-    int vid = g.m_vid[l];
+                                      const VT *val) {
+    const int vid = g.m_rec[l].x;
     return vid == var_samp ? value : (int)val[vid];
+}
+
+// member value and its dense_equal_to in one 8-byte load (categorical functions)
+template <typename VT>
+__device__ __forceinline__ int member_deo(const DevGraph<VT> &g, int l, int var_samp, int value,
+                                          const VT *val, int &deo) {
+    const int2 m = g.m_rec[l];
+    deo = m.y;
+    return m.x == var_samp ? value : (int)val[m.x];
 }
 
 // head of IMPLY_MLN / IMPLY_NATURAL_CAT / IMPLY_MLN_CAT: literal reference indexing reads
@@ -274,21 +280,23 @@ __device__ __forceinline__ int member(const DevGraph<VT> &g, int l, int var_samp
 // selects the intended fmap[l].vid.  nsk_graph_create has verified l < nvar in literal mode.
 template <typename VT>
 __device__ __forceinline__ int head_member(const DevGraph<VT> &g, int l, int var_samp, int value,
-                                           const VT *__restrict__ val) {
-    int vid = g.m_vid[l];
-    if (vid == var_samp) return value;
-    return (int)val[g.head_by_vid ? vid : l];
+                                           const VT *val, int &deo) {
+    const int2 m = g.m_rec[l];
+    deo = m.y;
+    if (m.x == var_samp) return value;
+    return (int)val[g.head_by_vid ? m.x : l];
 }
 
 // eval_factor (inference.py:149-413).  nsk_graph_create rejects unknown function ids and
 // out-of-range member positions, so no error path is needed here.
 template <typename VT>
-__device__ inline double eval_factor(const DevGraph<VT> &g, int fid, int var_samp, int value,
-                                     const VT *__restrict__ val) {
-    const uint32_t head = g.f_head[fid];
+__device__ inline double eval_factor(const DevGraph<VT> &g, const uint4 rec, int var_samp, int value,
+                                     const VT *val) {
+    const uint32_t head = rec.x;
     const int fn = NSK_FHEAD_FUNC(head);
-    const int s = g.f_off[fid];
+    const int s = (int)rec.y;
     const int e = s + NSK_FHEAD_ARITY(head);
+    int deo;
     switch (fn) {
     case F_NOOP:
         return 0.0;
@@ -330,26 +338,26 @@ __device__ inline double eval_factor(const DevGraph<VT> &g, int fid, int var_sam
     case F_IMPLY_MLN: {                                         // 232-246
         for (int l = s; l < e - 1; l++)
             if (member(g, l, var_samp, value, val) == 0) return 1.0;
-        return head_member(g, e - 1, var_samp, value, val) ? 1.0 : 0.0;
+        return head_member(g, e - 1, var_samp, value, val, deo) ? 1.0 : 0.0;
     }
     case F_AND_CAT:
     case F_EQUAL_CAT_CONST:                                     // 251-258
         for (int l = s; l < e; l++)
-            if (member(g, l, var_samp, value, val) != g.m_deo[l]) return 0.0;
+            if (member_deo(g, l, var_samp, value, val, deo) != deo) return 0.0;
         return 1.0;
     case F_OR_CAT:                                              // 259-265
         for (int l = s; l < e; l++)
-            if (member(g, l, var_samp, value, val) == g.m_deo[l]) return 1.0;
+            if (member_deo(g, l, var_samp, value, val, deo) == deo) return 1.0;
         return -1.0;
     case F_IMPLY_NATURAL_CAT: {                                 // 266-280
         for (int l = s; l < e - 1; l++)
-            if (member(g, l, var_samp, value, val) != g.m_deo[l]) return 0.0;
-        return head_member(g, e - 1, var_samp, value, val) == g.m_deo[e - 1] ? 1.0 : -1.0;
+            if (member_deo(g, l, var_samp, value, val, deo) != deo) return 0.0;
+        return head_member(g, e - 1, var_samp, value, val, deo) == deo ? 1.0 : -1.0;
     }
     case F_IMPLY_MLN_CAT: {                                     // 281-295
         for (int l = s; l < e - 1; l++)
-            if (member(g, l, var_samp, value, val) != g.m_deo[l]) return 1.0;
-        return head_member(g, e - 1, var_samp, value, val) == g.m_deo[e - 1] ? 1.0 : 0.0;
+            if (member_deo(g, l, var_samp, value, val, deo) != deo) return 1.0;
+        return head_member(g, e - 1, var_samp, value, val, deo) == deo ? 1.0 : 0.0;
     }
     case F_DP_GEN_CLASS_PRIOR:                                  // 301-305
         return member(g, s, var_samp, value, val) == 1 ? 1.0 : -1.0;
@@ -359,13 +367,13 @@ __device__ inline double eval_factor(const DevGraph<VT> &g, int fid, int var_sam
     }
     case F_DP_GEN_LF_PROPENSITY: {                              // 316-320
         int l0 = member(g, s, var_samp, value, val);
-        return l0 == g.v_card[g.m_vid[s]] - 1 ? 0.0 : 1.0;
+        return l0 == g.v_card[g.m_rec[s].x] - 1 ? 0.0 : 1.0;
     }
     case F_DP_GEN_LF_ACCURACY:
     case F_DP_GEN_LF_CLASS_PROPENSITY: {                        // 321-346
         int y = member(g, s, var_samp, value, val);
         int l1 = member(g, s + 1, var_samp, value, val);
-        if (l1 == g.v_card[g.m_vid[s + 1]] - 1) return 0.0;
+        if (l1 == g.v_card[g.m_rec[s + 1].x] - 1) return 0.0;
         if (fn == F_DP_GEN_LF_ACCURACY) return y == l1 ? 1.0 : -1.0;
         return y == 1 ? 1.0 : -1.0;
     }
@@ -374,7 +382,7 @@ __device__ inline double eval_factor(const DevGraph<VT> &g, int fid, int var_sam
         int y = member(g, s, var_samp, value, val);
         int l1 = member(g, s + 1, var_samp, value, val);
         int l2 = member(g, s + 2, var_samp, value, val);
-        if (l1 == g.v_card[g.m_vid[s + 1]] - 1) return l2 != 1 ? -1.0 : 0.0;
+        if (l1 == g.v_card[g.m_rec[s + 1].x] - 1) return l2 != 1 ? -1.0 : 0.0;
         if (fn == F_DP_GEN_DEP_FIXING) {
             if (l1 == 0 && l2 == 1 && y == 1) return 1.0;
             if (l1 == 1 && l2 == 0 && y == 0) return 1.0;
@@ -387,7 +395,7 @@ __device__ inline double eval_factor(const DevGraph<VT> &g, int fid, int var_sam
     case F_DP_GEN_DEP_EXCLUSIVE: {                              // 381-387
         int l1 = member(g, s, var_samp, value, val);
         int l2 = member(g, s + 1, var_samp, value, val);
-        int abstain = g.v_card[g.m_vid[s]] - 1;
+        int abstain = g.v_card[g.m_rec[s].x] - 1;
         return (l1 == abstain || l2 == abstain) ? 0.0 : -1.0;
     }
     case F_DP_GEN_DEP_SIMILAR:                                  // 388-393
@@ -408,27 +416,51 @@ __device__ inline double eval_factor(const DevGraph<VT> &g, int fid, int var_sam
 // reference's.
 template <typename VT>
 __device__ inline double potential(const DevGraph<VT> &g, int var_samp, int value, int slot,
-                                   const VT *__restrict__ val) {
+                                   const VT *val) {
     double p = 0.0;
     const int b = g.slot_off[slot], e = g.slot_off[slot + 1];
     for (int k = b; k < e; k++) {
-        const int fid = g.fidx[k];
-        const double t = g.w[g.f_wid[fid]] * eval_factor(g, fid, var_samp, value, val);
+        const uint4 rec = g.f_rec[g.fidx[k]];
+        const double t = g.w[rec.z] * eval_factor(g, rec, var_samp, value, val);
         p = p + t;
     }
     return p;
+}
+
+// Both candidates of a binary dataType-0 variable share one factor list: walk it once.  The two
+// sums are accumulated exactly like two separate potential() calls would (same order, same ops).
+template <typename VT>
+__device__ inline void potential2(const DevGraph<VT> &g, int var_samp, int slot, const VT *val,
+                                  double &p0, double &p1) {
+    p0 = 0.0; p1 = 0.0;
+    const int b = g.slot_off[slot], e = g.slot_off[slot + 1];
+    for (int k = b; k < e; k++) {
+        const uint4 rec = g.f_rec[g.fidx[k]];
+        const double w = g.w[rec.z];
+        const double t0 = w * eval_factor(g, rec, var_samp, 0, val);
+        const double t1 = w * eval_factor(g, rec, var_samp, 1, val);
+        p0 = p0 + t0;
+        p1 = p1 + t1;
+    }
 }
 
 // draw_sample (inference.py:36-52) given the uniform u: Z[k] = running sum of exp(potential),
 // z = u * Z[card-1], result = first k with Z[k] >= z (0 if none, like np.argmax of all-False).
 template <typename VT>
 __device__ inline int draw_sample(const DevGraph<VT> &g, int var_samp, uint32_t info, int slot0,
-                                  const VT *__restrict__ val, double u) {
+                                  const VT *val, double u) {
     const int card = NSK_INFO_CARD(info);
     const int step = NSK_INFO_DT1(info);          // dataType 1: one factor list per value
     if (card == 2) {
-        const double z0 = nsk_exp(potential(g, var_samp, 0, slot0, val));
-        const double z1 = z0 + nsk_exp(potential(g, var_samp, 1, slot0 + step, val));
+        double p0, p1;
+        if (step) {
+            p0 = potential(g, var_samp, 0, slot0, val);
+            p1 = potential(g, var_samp, 1, slot0 + 1, val);
+        } else {
+            potential2(g, var_samp, slot0, val, p0, p1);
+        }
+        const double z0 = nsk_exp(p0);
+        const double z1 = z0 + nsk_exp(p1);
         const double z = u * z1;
         return (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     }
