@@ -37,12 +37,17 @@ WORKLOADS = {
     "ising1m": (1000, 1000, False),           # BASELINE configs[1]
     "ising10m_learn": (2500, 4000, True),     # BASELINE configs[2] learning half
     "ising1m_learn": (1000, 1000, True),
+    # 4M boolean variables, ISTRUE / OR / EQUAL factors of arity 1..3 with one weight per factor
+    # (the shape of feature-weighted DeepDive graphs): exercises the per-lane-weight shape tiles
+    "boolw4m": (2000, 2000, False),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
 
-def build_graph(rows, cols, learning, seed=20240602):
+def build_graph(rows, cols, learning, seed=20240602, name=None):
     from numbskull_amd import graphgen
+    if name == "boolw4m":
+        return graphgen.boolean_weighted_graph(rows * cols, seed=seed)
     if not learning:
         return graphgen.ising_grid(rows, cols, weight=0.1, fixed=True)
     # learning variant: two free weights, every variable evidence;
@@ -142,7 +147,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     rows, cols, learning = WORKLOADS[args.workload]
-    g = build_graph(rows, cols, learning)
+    g = build_graph(rows, cols, learning, name=args.workload)
     nvar = rows * cols
     ns = numbskull_amd.NumbSkull(quiet=True, device=local_rank, seed=args.seed)
     own = shard_range(rank, world, nvar)
@@ -213,10 +218,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%dx%d Ising grid (%d binary variables, %d EQUAL factors), %s, "
-                                   "chromatic scan, seed %d"
-                                   % (rows, cols, nvar, len(f), "learning (2 free weights, L2)"
-                                      if learning else "inference only, weight 0.1 fixed", args.seed),
+            "config": {"workload": ("%d boolean variables, %d ISTRUE/OR/EQUAL factors with one weight each, "
+                                    "inference only, chromatic scan, seed %d" % (nvar, len(f), args.seed))
+                       if args.workload == "boolw4m" else
+                       "%dx%d Ising grid (%d binary variables, %d EQUAL factors), %s, "
+                       "chromatic scan, seed %d"
+                       % (rows, cols, nvar, len(f), "learning (2 free weights, L2)"
+                          if learning else "inference only, weight 0.1 fixed", args.seed),
                        "name": args.workload, "partition": "range by variable id, %d shard(s)" % world,
                        "colors": info["ncolors"], "value_bytes": info["value_bytes"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= n) return;
     const uint32_t s = prog[i];
+    if (s >> 31) return;                                   // role word of a shape tile, not a slot
     const uint32_t code = (s >> 24) & 7u;
     const bool last = (s >> 28) & 1u;
     const double hi = code == 0u ? 0.0 : 1.0;
@@ -211,6 +212,64 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32
     const double wt = w[s & 0xFFFFFFu];
     prog_w[2 * i] = last ? wt * hi : 0.0;
     prog_w[2 * i + 1] = last ? wt * lo : 0.0;
+}
+
+// Shape tile: every lane has its own factor functions and weights (per-lane header words in the
+// stream) but all 64 lanes share the word layout -- which words are headers, which are members,
+// where entries start and end -- so the walk is driven by a scalar role program and only the
+// per-lane facts (function code, weight, member values) are vector work.  This is the shape of
+// graphs whose factors carry individual weights.
+template <typename VT>
+__device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, const VT *val,
+                                                      const uint4 *sp, int len, uint32_t prog,
+                                                      double &p0, double &p1) {
+    const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    uint32_t code = 0;                   // per lane: 0 NOOP 1 IMPLY_NATURAL 2 OR 3 AND/ISTRUE 4 EQUAL
+    double w = 0.0;
+    int first = 0;
+    bool allnz = true, any1 = false, alleq = true;
+    auto finish = [&](bool nomember) {
+        const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
+        const bool b0 = (isEq && alleq && (nomember || first == 0)) || (isOr && any1);
+        const bool b1 = (isEq && alleq && (nomember || first == 1)) || (isAnd && allnz) || isOr;
+        const double hi = code == 0u ? 0.0 : 1.0;
+        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+        const double t0 = w * (b0 ? hi : lo), t1 = w * (b1 ? hi : lo);
+        p0 = p0 + t0;
+        p1 = p1 + t1;
+    };
+    for (int c = 0; c * 4 < len; c++) {                                  // <= 4 chunks, scalar loop
+        const uint4 q = sp[(size_t)c * 64];
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+        uint32_t role[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0xFu;      // scalar; 0 = padding word
+        double wv[4];
+        int xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                                    // one gather per word
+            wv[i] = 0.0; xv[i] = 0;
+            if (role[i] & 1u) wv[i] = g.w[wd[i] & 0xFFFFFFu];
+            else if (role[i]) xv[i] = (int)val[wd[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (role[i] & 1u) {                                          // header: open an entry
+                code = (0x343210u >> (4u * (wd[i] >> 27))) & 0xFu;       // function+1 in 0..5 -> code
+                w = wv[i];
+                first = 0; allnz = true; any1 = false; alleq = true;
+                if (role[i] & 8u) finish(true);
+            } else if (role[i]) {                                        // member
+                const int x = xv[i];
+                const bool F = (role[i] & 2u) != 0;
+                alleq = F || (alleq && (x == first));
+                allnz = (F || allnz) && (x != 0);
+                any1 = (!F && any1) || (x == 1);
+                first = F ? x : first;
+                if (role[i] & 4u) finish(false);
+            }
+        }
+    }
 }
 
 template <typename VT>
@@ -245,7 +304,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     if (td.z == NSK_PAD_WORD) tile_potentials_dynamic(g, g.val, sp, len, p0, p1);
     else {
         const uint32_t kind = (td.w >> 8) & 7u;              // wave-uniform
-        if (kind == 4u) tile_potentials_uniform<VT, 4>(g, g.val, sp, len, td.z, p0, p1);
+        if (kind == 7u) tile_potentials_shape(g, g.val, sp, (int)(td.w & 0xFFu), td.z, p0, p1);
+        else if (kind == 4u) tile_potentials_uniform<VT, 4>(g, g.val, sp, len, td.z, p0, p1);
         else if (kind == 0u) tile_potentials_uniform<VT, 0>(g, g.val, sp, len, td.z, p0, p1);
         else if (kind == 2u) tile_potentials_uniform<VT, 2>(g, g.val, sp, len, td.z, p0, p1);
         else tile_potentials_uniform<VT, 3>(g, g.val, sp, len, td.z, p0, p1);
@@ -566,7 +626,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
     for (int t = wave0 * per; t < t1; t++) {
         const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
         const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
-        if (td.z == NSK_PAD_WORD) continue;                  // per-lane headers: generic kernel's job
+        if (td.z == NSK_PAD_WORD || ((td.w >> 8) & 7u) == 7u) continue;   // per-lane headers: generic kernel's job
         const int p = pbegin + t * 64 + lane;
         const bool valid = p < pend && g.p_vid[p] >= 0;
         const uint4 *sp = g.adj + td.x + lane;
@@ -646,7 +706,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights_rows(double *w, con
     const double x = wnew;
     for (int j = tid; j < nprog; j += NSK_BLOCK) {
         const uint32_t s = prog[j];
-        if ((int)(s & 0xFFFFFFu) != i) continue;
+        if ((s >> 31) || (int)(s & 0xFFFFFFu) != i) continue;
         const uint32_t code = (s >> 24) & 7u;
         const bool last = (s >> 28) & 1u;
         const double hi = code == 0u ? 0.0 : 1.0;

@@ -326,12 +326,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     c.phase_fast_end.assign((size_t)ncolors, 0);
     c.v_pos.assign(nvar, -1);
     {
-        std::vector<uint64_t> sig(nvar, 0);
+        // sig: exact program (function, member count, weight id per entry, evidence flag);
+        // shp: shape only (member count per entry, evidence flag), 0 when the variable's stream
+        //      would exceed 16 words
+        std::vector<uint64_t> sig(nvar, 0), shp(nvar, 0);
         for (int64_t v = 0; v < nvar; v++) {
             if (c.color[v] < 0 || !fast[v]) continue;
             const nsk_variable &var = d->variable[v];
             const nsk_vtf &vt = d->vmap[var.vtf_offset];
-            uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence;
+            uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence, h2 = h ^ 0x9e3779b97f4a7c15ull;
+            int64_t nwords = 0;
             for (int64_t j = 0; j < vt.factor_index_length; j++) {
                 const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
                 uint64_t others = 0;
@@ -341,10 +345,15 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 const uint64_t word = ((uint64_t)(fa.factorFunction + 1) << 27) | (others << 24) | (uint64_t)fa.weightId;
                 h = (h ^ word) * 0x100000001b3ull;
                 h ^= h >> 29;
+                h2 = (h2 ^ (others + 1)) * 0x100000001b3ull;
+                h2 ^= h2 >> 31;
+                nwords += 1 + (int64_t)others;
             }
             sig[v] = h | 1;
+            shp[v] = nwords <= 16 ? (h2 | 1) : 0;
         }
-        std::vector<std::map<uint64_t, std::pair<int64_t, int64_t>>> classes((size_t)ncolors);  // sig -> (count, first vid)
+        typedef std::map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
+        std::vector<ClassMap> classes((size_t)ncolors), shapes((size_t)ncolors);
         std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0);
         for (int64_t v = 0; v < nvar; v++) {
             const int32_t k = c.color[v];
@@ -357,22 +366,33 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 ngen_of[k]++;
             }
         }
+        // variables outside the big exact classes are grouped by shape
+        for (int64_t v = 0; v < nvar; v++) {
+            const int32_t k = c.color[v];
+            if (k < 0 || !fast[v] || shp[v] == 0) continue;
+            if (classes[k][sig[v]].first >= 64) continue;
+            auto &e = shapes[k][shp[v]];
+            if (e.first++ == 0) e.second = v;
+        }
         std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0);
-        std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors);     // class -> next position
+        std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors);
         int64_t pos = 0;
         for (int32_t k = 0; k < ncolors; k++) {
             c.phase_start[k] = pos;
-            std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, class)
             int64_t nbig = 0;
-            for (auto &kv : classes[k])
-                if (kv.second.first >= 64) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
-            std::sort(big.begin(), big.end());
-            for (auto &bc : big) {
-                start[k][bc.second] = pos;
-                pos += classes[k][bc.second].first;
-                pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
+            for (int level = 0; level < 2; level++) {
+                ClassMap &cm = level == 0 ? classes[k] : shapes[k];
+                std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, key)
+                for (auto &kv : cm)
+                    if (kv.second.first >= 64) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
+                std::sort(big.begin(), big.end());
+                for (auto &bc : big) {
+                    (level == 0 ? start[k] : start2[k])[bc.second] = pos;
+                    pos += cm[bc.second].first;
+                    pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
+                }
+                cm.clear();
             }
-            classes[k].clear();
             tail_at[k] = pos;
             pos += nfast_of[k] - nbig;
             pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
@@ -392,7 +412,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             if (!fast[v]) p = next_gen[k]++;
             else {
                 auto it = start[k].find(sig[v]);
-                p = (it != start[k].end()) ? it->second++ : tail_at[k]++;
+                if (it != start[k].end()) p = it->second++;
+                else {
+                    auto it2 = shp[v] ? start2[k].find(shp[v]) : start2[k].end();
+                    p = (it2 != start2[k].end()) ? it2->second++ : tail_at[k]++;
+                }
             }
             c.p_vid[p] = (int32_t)v;
             c.v_pos[v] = (int32_t)p;
@@ -436,17 +460,23 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
                 uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
                 int64_t len = 0;
-                bool uniform = true;
-                bool have0 = false;
+                bool uniform = true, shape_tile = false;
+                (void)shape_tile;
+                bool have0 = false, same_shape = true;
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;                  // padding position
                     lane_words(c.p_vid[p], words);
                     len = std::max<int64_t>(len, (int64_t)words.size());
                     headers_of(words, have0 ? hdrs : hdrs0);
-                    if (have0 && hdrs != hdrs0) uniform = false;
+                    if (have0 && hdrs != hdrs0) {
+                        uniform = false;
+                        if (hdrs.size() != hdrs0.size()) same_shape = false;
+                        else for (size_t j = 0; j < hdrs.size(); j++)
+                            if (((hdrs[j] ^ hdrs0[j]) >> 24) & 7u) same_shape = false;
+                    }
                     have0 = true;
                 }
-                if (!have0) { hdrs0.clear(); uniform = false; }
+                if (!have0) { hdrs0.clear(); uniform = false; same_shape = false; }
                 td[2] = 0xFFFFFFFFu;
                 // slot program of a uniform tile: one word per member slot (an entry without other
                 // members still gets one, ignored, slot):
@@ -480,6 +510,27 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     td[3] = (uint32_t)nslots | (kind << 8);
                     len = nslots;
                 }
+                if (td[2] == 0xFFFFFFFFu && same_shape && len <= 16 && len > 0) {
+                    // shape tile: per-lane headers (own function and weight) but one word layout for the
+                    // 64 lanes.  Role program, one word per stream word: 1 header | 2 first member |
+                    // 4 last member | 8 header of an entry without other members; kind 7.
+                    prog.clear();
+                    for (uint32_t h : hdrs0) {
+                        const uint32_t no = (h >> 24) & 7u;
+                        prog.push_back(1u | (no == 0 ? 8u : 0u) | 0x80000000u);   // bit 31 marks role words
+                        for (uint32_t m = 0; m < no; m++)
+                            prog.push_back((m == 0 ? 2u : 0u) | (m + 1 == no ? 4u : 0u) | 0x80000000u);
+                    }
+                    auto it = hdr_pool.find(prog);
+                    if (it == hdr_pool.end()) {
+                        it = hdr_pool.emplace(prog, (uint32_t)c.tile_hdr.size()).first;
+                        c.tile_hdr.insert(c.tile_hdr.end(), prog.begin(), prog.end());
+                        c.tile_hdr.resize((c.tile_hdr.size() + 7) / 8 * 8, 0u);
+                    }
+                    td[2] = it->second;
+                    td[3] = (uint32_t)len | (7u << 8);
+                    shape_tile = true;
+                }
                 len = (len + 3) / 4 * 4;
                 td[0] = (uint32_t)total4;
                 td[1] = (uint32_t)len;
@@ -491,7 +542,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         c.phase_dyn_base.assign((size_t)ncolors + 1, 0);
         for (int32_t k = 0; k < ncolors; k++) {
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++)
-                if (c.tiles[4 * (c.phase_wb_base[k] + b) + 2] == 0xFFFFFFFFu)
+                if (c.tiles[4 * (c.phase_wb_base[k] + b) + 2] == 0xFFFFFFFFu ||
+                    ((c.tiles[4 * (c.phase_wb_base[k] + b) + 3] >> 8) & 7u) == 7u)
                     c.dyn_tiles.push_back((uint32_t)(c.phase_start[k] + 64 * b));
             c.phase_dyn_base[k + 1] = (int64_t)c.dyn_tiles.size();
         }
@@ -519,7 +571,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 bool full;
                 const int ev = tile_ev(b, full);
                 int64_t e = b + 1;
-                const bool seg_ok = td[2] != 0xFFFFFFFFu && full && ev != -999 && (td[3] & 0xFFu) > 0;
+                const bool seg_ok = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) != 7u && full && ev != -999 &&
+                                    (td[3] & 0xFFu) > 0;
                 if (seg_ok) {
                     while (e < nt) {
                         const uint32_t *te = &c.tiles[4 * (c.phase_wb_base[k] + e)];
@@ -550,8 +603,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
                 const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
                 const uint64_t base = (uint64_t)td[0] * 4;
-                const bool uniform = td[2] != 0xFFFFFFFFu;
-                if (uniform)
+                const bool uniform = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) != 7u;
+                if (td[2] != 0xFFFFFFFFu)       // uniform and shape tiles: padding reads variable / weight 0
                     for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = 0;
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;

@@ -230,6 +230,44 @@ def mixed_lr_graph(nvar, seed=20240603, nweights=None, window=1024, global_frac=
     return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
 
 
+def boolean_weighted_graph(nvar, seed=0, window=64, factors_per_var=2.0):
+    """Boolean graph with one weight per factor: for every variable an ISTRUE prior, plus
+    ``factors_per_var * nvar`` OR / EQUAL factors of arity 2..3 over nearby variables (ids within
+    ``window``).  The shape of feature-weighted DeepDive graphs whose factors carry individual
+    weights; all weights fixed at small random values so that inference is well-conditioned."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nvar = int(nvar)
+    nextra = int(factors_per_var * nvar)
+    arity = np.concatenate([np.ones(nvar, np.int64), rng.integers(2, 4, nextra)])
+    nfactor = len(arity)
+    off = np.cumsum(arity) - arity
+    nedge = int(arity.sum())
+    func = np.concatenate([np.full(nvar, FUNC_ISTRUE, np.int64),
+                           np.where(rng.random(nextra) < 0.5, 1, FUNC_EQUAL)])
+    fac_of_edge = np.repeat(np.arange(nfactor, dtype=np.int64), arity)
+    pos = np.arange(nedge, dtype=np.int64) - off[fac_of_edge]
+    anchor = np.concatenate([np.arange(nvar, dtype=np.int64), rng.integers(0, nvar, nextra)])
+    # distinct members inside a factor: anchor, anchor+d1, anchor+d1+d2 (mod nvar)
+    step = rng.integers(1, window, nedge)
+    step[pos == 0] = 0
+    cum = np.cumsum(step)
+    vid = (anchor[fac_of_edge] + cum - cum[off[fac_of_edge]]) % nvar
+    variable = np.zeros(nvar, Variable)
+    variable["cardinality"] = 2
+    factor = np.zeros(nfactor, Factor)
+    factor["factorFunction"] = func
+    factor["weightId"] = np.arange(nfactor)
+    factor["featureValue"] = 1.0
+    factor["arity"] = arity
+    factor["ftv_offset"] = off
+    fmap = np.zeros(nedge, FactorToVar)
+    fmap["vid"] = vid
+    wrec = np.zeros(nfactor, Weight)
+    wrec["isFixed"] = True
+    wrec["initialValue"] = rng.normal(0, 0.3, nfactor)
+    return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
+
+
 # --------------------------------------------------------------------------------------------
 # DeepDive binary format (big-endian), SURVEY.md Appendix B
 # --------------------------------------------------------------------------------------------

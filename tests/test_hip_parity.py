@@ -148,8 +148,22 @@ def _small_graphs(golden):
         # > 256 weights: gradients go through global atomics instead of per-block LDS tables
         "lr_manyw": (graphgen.mixed_lr_graph(3000, seed=6, nweights=1500), True),
         "pairs_manyw": (_pairs_many_weights(), False),
+        # one weight per factor: tiles share a word layout but not weights (shape tiles)
+        "boolw": (_boolw(), False),
         "lr_bigcard": (_big_cardinality_graph(), False),
     }
+
+
+def _boolw():
+    g = list(graphgen.boolean_weighted_graph(6000, seed=4))
+    w = g[0].copy()
+    w["isFixed"] = False
+    var = g[1].copy()
+    rng = np.random.default_rng(8)
+    var["isEvidence"] = rng.random(len(var)) < 0.5
+    var["initialValue"] = rng.integers(0, 2, len(var))
+    g[0], g[1] = w, var
+    return tuple(g)
 
 
 def _pairs_many_weights():
@@ -185,7 +199,7 @@ def _big_cardinality_graph():
 
 
 GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
-          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw"]
+          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw"]
 
 
 @pytest.mark.parametrize("name", GRAPHS)
@@ -214,7 +228,7 @@ def test_chromatic_inference_equals_oracle(golden, name, sample_evidence):
 
 
 @pytest.mark.parametrize("name", ["mixed", "lf", "pairs", "grid32", "lr3000", "lr_bigcard",
-                                  "headquirk", "lr_manyw", "pairs_manyw"])
+                                  "headquirk", "lr_manyw", "pairs_manyw", "boolw"])
 @pytest.mark.parametrize("reg,trunc", [(0, 1), (1, 1), (1, 3), (2, 1)])
 @pytest.mark.parametrize("lne", [False, True])
 def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
