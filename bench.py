@@ -231,7 +231,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_update": alg_sweep * world / nvar,
                          "kernel": ("k_learn_fast" if info["nfast"] else "k_learn_phase") if learning
-                         else ("k_gibbs_fast" if info["nfast"] else "k_gibbs_phase"),
+                         else ("k_gibbs_seg" if info["nfast"] else "k_gibbs_phase"),
                          "stream_copy_GBs": copy_gbs,
                          "launches": nlaunch, "avg_launch_us": launch_s * 1e6},
         }

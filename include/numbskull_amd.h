@@ -119,6 +119,8 @@ int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */)
  * would and report the colours / sizes.  `color` (nvar entries, may be NULL) gets -1 for variables
  * this handle does not sample. */
 int nsk_graph_plan(const nsk_graph_desc *desc, int32_t *color, nsk_graph_info *info);
+/* Host-only twin of nsk_ghost_needs (vids == NULL: query the count). */
+int nsk_graph_plan_needs(const nsk_graph_desc *desc, int64_t *count, int32_t *vids);
 
 /* HIP-event bracket on the library's stream: elapsed ms and number of sweep-kernel launches
  * between begin and end (bench.py's roofline leg). */
@@ -131,8 +133,41 @@ int nsk_profile_end(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches);
 #define NSK_BUF_VALUE 0
 #define NSK_BUF_VALUE_EVID 1
 #define NSK_BUF_WEIGHT 2
+#define NSK_BUF_SEND 3         /* boundary exchange staging, after nsk_exchange_setup */
+#define NSK_BUF_RECV 4
+#define NSK_BUF_SEND_EVID 5
+#define NSK_BUF_RECV_EVID 6
 int nsk_device_buffer(nsk_graph *g, int which, void **ptr, int64_t *nbytes);
 int nsk_set_stream(nsk_graph *g, void *hip_stream);
+
+/* Boundary ("ghost") exchange for a range-partitioned graph: the reference copies owners' values to
+ * the replicas once per epoch (salt/src/numbskull_master.py:165-224); here only the values another
+ * partition actually reads travel.
+ *   nsk_ghost_needs     sorted ids of the variables outside [own_begin, own_end) that this handle's
+ *                       variables read (vids == NULL: query the count)
+ *   nsk_exchange_setup  send_vids: the owned variables some other rank reads, in the order every
+ *                       rank agreed on; recv_vids / recv_off: the same lists of all `world` ranks,
+ *                       concatenated; slot: elements reserved per rank in the gathered buffer
+ *   nsk_exchange_pack   SEND[i] = value[send_vids[i]]          (which = NSK_BUF_VALUE[_EVID])
+ *   nsk_exchange_unpack value[recv_vids[j]] = RECV[src*slot + j - recv_off[src]] for every src != rank
+ * The all-gather of SEND into RECV is done by the caller (torch.distributed) or by the native loop
+ * below. */
+int nsk_ghost_needs(nsk_graph *g, int64_t *count, int32_t *vids);
+int nsk_exchange_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, int64_t nsend,
+                       const int32_t *recv_vids, const int64_t *recv_off, int64_t slot);
+int nsk_exchange_pack(nsk_graph *g, int which);
+int nsk_exchange_unpack(nsk_graph *g, int which);
+
+/* Native RCCL loop: `nsweeps` x (sweep, pack, ncclAllGather over xGMI, unpack) enqueued on the
+ * library's stream without returning to the host language.  unique_id: the 128-byte ncclUniqueId
+ * created by nsk_comm_unique_id on rank 0 and broadcast by the caller; librccl_path: the RCCL
+ * shared object to bind (the one torch has loaded). */
+int nsk_comm_unique_id(const char *librccl_path, void *id128);
+int nsk_comm_init(nsk_graph *g, int world, int rank, const void *id128, const char *librccl_path);
+int nsk_gibbs_sweeps_exchange(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin);
+int nsk_learn_sweeps_exchange(nsk_graph *g, int64_t nsweeps, double step, double decay,
+                              int regularization, double reg_param, int64_t truncation,
+                              int learn_non_evidence);
 int nsk_synchronize(nsk_graph *g);
 
 /* ---- host-side index build and file parsing (no GPU needed) ---- */

@@ -16,14 +16,16 @@ LIB_PATH = os.path.join(_HERE, "libnumbskull_amd.so")
 OK, E_INVALID, E_FACTOR_FUNC, E_INDEX, E_DEVICE, E_RANGE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 FLAG_HEAD_BY_VID = 1
 SCAN_CHROMATIC, SCAN_SEQUENTIAL = 0, 1
-BUF_VALUE, BUF_VALUE_EVID, BUF_WEIGHT = 0, 1, 2
+BUF_VALUE, BUF_VALUE_EVID, BUF_WEIGHT, BUF_SEND, BUF_RECV, BUF_SEND_EVID, BUF_RECV_EVID = range(7)
 
 # every symbol include/numbskull_amd.h declares (tests/test_cabi.py checks the export list)
 SYMBOLS = (
     "nsk_graph_create", "nsk_graph_destroy", "nsk_state_upload", "nsk_state_download",
     "nsk_set_seed", "nsk_set_scan", "nsk_gibbs_sweeps", "nsk_learn_sweeps", "nsk_graph_get_info",
-    "nsk_graph_get_colors", "nsk_graph_plan", "nsk_profile_begin", "nsk_profile_end", "nsk_device_buffer",
-    "nsk_set_stream", "nsk_synchronize", "nsk_compute_var_map", "nsk_parse_factors",
+    "nsk_graph_get_colors", "nsk_graph_plan", "nsk_graph_plan_needs", "nsk_profile_begin", "nsk_profile_end", "nsk_device_buffer",
+    "nsk_set_stream", "nsk_synchronize", "nsk_ghost_needs", "nsk_exchange_setup", "nsk_exchange_pack",
+    "nsk_exchange_unpack", "nsk_comm_unique_id", "nsk_comm_init", "nsk_gibbs_sweeps_exchange",
+    "nsk_learn_sweeps_exchange", "nsk_compute_var_map", "nsk_parse_factors",
     "nsk_selftest_exp", "nsk_selftest_philox", "nsk_selftest_stream", "nsk_device_count", "nsk_last_error", "nsk_version",
 )
 
@@ -74,12 +76,23 @@ def lib():
         L.nsk_graph_get_info.argtypes = [C.c_void_p, C.POINTER(GraphInfo)]
         L.nsk_graph_get_colors.argtypes = [C.c_void_p, C.c_void_p]
         L.nsk_graph_plan.argtypes = [C.POINTER(GraphDesc), C.c_void_p, C.POINTER(GraphInfo)]
+        L.nsk_graph_plan_needs.argtypes = [C.POINTER(GraphDesc), C.POINTER(C.c_int64), C.c_void_p]
         L.nsk_profile_begin.argtypes = [C.c_void_p]
         L.nsk_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.nsk_device_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_int64)]
         L.nsk_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.nsk_synchronize.argtypes = [C.c_void_p]
+        L.nsk_ghost_needs.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+        L.nsk_exchange_setup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_int64]
+        L.nsk_exchange_pack.argtypes = [C.c_void_p, C.c_int]
+        L.nsk_exchange_unpack.argtypes = [C.c_void_p, C.c_int]
+        L.nsk_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p]
+        L.nsk_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]
+        L.nsk_gibbs_sweeps_exchange.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.nsk_learn_sweeps_exchange.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int,
+                                                C.c_double, C.c_int64, C.c_int]
         L.nsk_compute_var_map.argtypes = [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int64]

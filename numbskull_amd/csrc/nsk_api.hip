@@ -4,6 +4,8 @@
 // (numbskull/factorgraph.py:141,163,202): gibbsthread (inference.py:10-33) and
 // learnthread/sample_and_sgd (learning.py:12-125).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is bound at run time with dlopen
 
 #include <algorithm>
 #include <cmath>
@@ -731,6 +733,35 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_stream_copy(const T *__restrict__
     for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// ---- boundary exchange ---------------------------------------------------------------------------
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_exchange_pack(const VT *val, const int32_t *send_vids,
+                                                             VT *sendbuf, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i < n) sendbuf[i] = val[send_vids[i]];
+}
+
+// recv_src[j] = rank that owns recv_vids[j]; entries of this rank itself are skipped
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_exchange_unpack(VT *val, const int32_t *recv_vids,
+                                                               const int32_t *recv_slot, const VT *recvbuf,
+                                                               int n) {
+    const int j = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (j >= n) return;
+    const int sl = recv_slot[j];            // index into the gathered buffer, -1 = own entry
+    if (sl >= 0) val[recv_vids[j]] = recvbuf[sl];
+}
+
+// weight merge of the partitioned learning sweep: delta = w - start ... w = start + sum(delta)
+__global__ __launch_bounds__(NSK_BLOCK) void k_weight_delta(const double *w, const double *start, double *delta, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i < n) delta[i] = w[i] - start[i];
+}
+__global__ __launch_bounds__(NSK_BLOCK) void k_weight_merge(double *w, const double *start, const double *delta, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i < n) w[i] = start[i] + delta[i];
+}
+
 __global__ void k_selftest_exp(const double *x, double *y, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = nsk_exp(x[i]);
@@ -852,6 +883,20 @@ static int fail(int code, const std::string &msg) {
 }
 namespace nsk { void set_error(const std::string &m) { g_err = m; } }
 
+// RCCL entry points, bound at run time (nsk_comm_init)
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi g_rccl;
+
+
+
 #define HIPCHECK(expr)                                                                          \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -884,6 +929,16 @@ struct nsk_graph {
     long long *part_G = nullptr;       // SMALLW: rows of per-block partial sums
     uint32_t *part_K = nullptr, *part_T = nullptr;
     bool smallw = false;
+    bool weights_dirty = true;      // prog_w must be rebuilt before the next fast-path launch
+    bool weights_exposed = false;   // the weight buffer was handed out: assume it changes between calls
+    // boundary exchange (multi-GPU)
+    int xworld = 0, xrank = 0;
+    int64_t xslot = 0, xnsend = 0, xnrecv = 0;
+    int32_t *x_send_vids = nullptr, *x_recv_vids = nullptr, *x_recv_slot = nullptr;
+    void *x_send = nullptr, *x_recv = nullptr, *x_send_evid = nullptr, *x_recv_evid = nullptr;
+    double *w_start = nullptr, *w_delta = nullptr;
+    // native RCCL
+    void *rccl_lib = nullptr, *rccl_comm = nullptr;
     long long *cnt_total = nullptr, *G = nullptr;
     uint32_t *K = nullptr, *T = nullptr;
     MTState *mt_np = nullptr, *mt_py = nullptr;
@@ -999,6 +1054,7 @@ int nsk_graph_destroy(nsk_graph *g) {
     for (void *p : g->allocs) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)g->rccl_comm);
     if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
     return NSK_OK;
@@ -1117,7 +1173,9 @@ int nsk_synchronize(nsk_graph *g) {
 
 // the fast path reads weights through prog_w: rebuild it whenever weights may have changed (start
 // of every sweep call -- the host may have written the weight buffer -- and after every update)
-static void refresh_prog_weights(nsk_graph *g) {
+static void refresh_prog_weights(nsk_graph *g, bool force = false) {
+    if (!force && !g->weights_dirty && !g->weights_exposed) return;
+    g->weights_dirty = false;
     const int n = (int)g->c.tile_hdr.size();
     if (n > 0 && g->c.nfast > 0 && g->c.nweight > 0)
         k_refresh_prog_weights<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
@@ -1291,7 +1349,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
                         g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation);
-                    refresh_prog_weights(g);
+                    refresh_prog_weights(g, true);
                 }
             }
         }
@@ -1358,8 +1416,10 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
         int rc = upload_values(g, dsts[k], tmp.data(), nvar);
         if (rc) return rc;
     }
-    if (weight_value && g->c.nweight)
+    if (weight_value && g->c.nweight) {
         HIPCHECK(hipMemcpyAsync(g->w, weight_value, (size_t)g->c.nweight * sizeof(double), hipMemcpyHostToDevice, g->stream));
+        g->weights_dirty = true;
+    }
     if (count && g->c.ncount) {
         HIPCHECK(hipMemcpyAsync(g->cnt_total, count, (size_t)g->c.ncount * sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
         HIPCHECK(hipMemsetAsync(g->cnt, 0, (size_t)g->c.ncount * sizeof(int32_t), g->stream));
@@ -1437,6 +1497,17 @@ int nsk_graph_plan(const nsk_graph_desc *desc, int32_t *color, nsk_graph_info *i
     return NSK_OK;
 }
 
+int nsk_graph_plan_needs(const nsk_graph_desc *desc, int64_t *count, int32_t *vids) {
+    if (!desc || !count) return fail(NSK_E_INVALID, "null argument");
+    Compiled c;
+    std::string err;
+    int rc = compile_graph(desc, c, err);
+    if (rc) return fail(rc, err);
+    *count = (int64_t)c.ghost_needs.size();
+    if (vids && *count) memcpy(vids, c.ghost_needs.data(), (size_t)*count * sizeof(int32_t));
+    return NSK_OK;
+}
+
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color) {
     if (!g || !color) return fail(NSK_E_INVALID, "null argument");
     if (g->c.nvar) memcpy(color, g->c.color.data(), (size_t)g->c.nvar * sizeof(int32_t));
@@ -1468,7 +1539,11 @@ int nsk_device_buffer(nsk_graph *g, int which, void **ptr, int64_t *nbytes) {
     switch (which) {
     case NSK_BUF_VALUE: *ptr = g->val; if (nbytes) *nbytes = g->c.nvar * g->c.vbytes; return NSK_OK;
     case NSK_BUF_VALUE_EVID: *ptr = g->val_evid; if (nbytes) *nbytes = g->c.nvar * g->c.vbytes; return NSK_OK;
-    case NSK_BUF_WEIGHT: *ptr = g->w; if (nbytes) *nbytes = g->c.nweight * 8; return NSK_OK;
+    case NSK_BUF_WEIGHT: *ptr = g->w; if (nbytes) *nbytes = g->c.nweight * 8; g->weights_exposed = true; return NSK_OK;
+    case NSK_BUF_SEND: *ptr = g->x_send; if (nbytes) *nbytes = g->xslot * g->c.vbytes; return NSK_OK;
+    case NSK_BUF_RECV: *ptr = g->x_recv; if (nbytes) *nbytes = g->xslot * g->c.vbytes * g->xworld; return NSK_OK;
+    case NSK_BUF_SEND_EVID: *ptr = g->x_send_evid; if (nbytes) *nbytes = g->xslot * g->c.vbytes; return NSK_OK;
+    case NSK_BUF_RECV_EVID: *ptr = g->x_recv_evid; if (nbytes) *nbytes = g->xslot * g->c.vbytes * g->xworld; return NSK_OK;
     default: return fail(NSK_E_INVALID, "unknown buffer id");
     }
 }
@@ -1528,6 +1603,179 @@ int nsk_selftest_stream(int device, int64_t nbytes, int width, int iters, double
     *gbytes_per_s = 2.0 * (double)nbytes * iters / ((double)ms * 1e-3) / 1e9;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(a); (void)hipFree(b);
+    return NSK_OK;
+}
+
+int nsk_ghost_needs(nsk_graph *g, int64_t *count, int32_t *vids) {
+    if (!g || !count) return fail(NSK_E_INVALID, "null argument");
+    *count = (int64_t)g->c.ghost_needs.size();
+    if (vids && *count) memcpy(vids, g->c.ghost_needs.data(), (size_t)*count * sizeof(int32_t));
+    return NSK_OK;
+}
+
+int nsk_exchange_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, int64_t nsend,
+                       const int32_t *recv_vids, const int64_t *recv_off, int64_t slot) {
+    if (!g || world < 1 || rank < 0 || rank >= world || nsend < 0 || slot < nsend || !recv_off)
+        return fail(NSK_E_INVALID, "bad exchange description");
+    HIPCHECK(hipSetDevice(g->device));
+    const int64_t nrecv = recv_off[world];
+    for (int64_t i = 0; i < nsend; i++)
+        if (send_vids[i] < g->c.own_begin || send_vids[i] >= g->c.own_end)
+            return fail(NSK_E_INDEX, "send list names a variable this handle does not own");
+    std::vector<int32_t> rslot((size_t)nrecv);
+    for (int src = 0; src < world; src++) {
+        if (recv_off[src + 1] - recv_off[src] > slot) return fail(NSK_E_INVALID, "slot smaller than a rank's list");
+        for (int64_t j = recv_off[src]; j < recv_off[src + 1]; j++) {
+            if (recv_vids[j] < 0 || recv_vids[j] >= g->c.nvar) return fail(NSK_E_INDEX, "receive list out of range");
+            rslot[j] = src == rank ? -1 : (int32_t)(src * slot + (j - recv_off[src]));
+        }
+    }
+    g->xworld = world; g->xrank = rank; g->xslot = slot; g->xnsend = nsend; g->xnrecv = nrecv;
+    std::vector<int32_t> sv(send_vids, send_vids + nsend), rv(recv_vids, recv_vids + nrecv);
+    int rc;
+    if ((rc = dev_upload(g, &g->x_send_vids, sv))) return rc;
+    if ((rc = dev_upload(g, &g->x_recv_vids, rv))) return rc;
+    if ((rc = dev_upload(g, &g->x_recv_slot, rslot))) return rc;
+    const size_t vb = (size_t)g->c.vbytes;
+    uint8_t *t = nullptr;
+    if ((rc = dev_alloc(g, &t, (size_t)slot * vb))) return rc; g->x_send = t;
+    if ((rc = dev_alloc(g, &t, (size_t)slot * vb * world))) return rc; g->x_recv = t;
+    if ((rc = dev_alloc(g, &t, (size_t)slot * vb))) return rc; g->x_send_evid = t;
+    if ((rc = dev_alloc(g, &t, (size_t)slot * vb * world))) return rc; g->x_recv_evid = t;
+    HIPCHECK(hipMemsetAsync(g->x_send, 0, (size_t)(slot ? slot : 1) * vb, g->stream));
+    HIPCHECK(hipMemsetAsync(g->x_send_evid, 0, (size_t)(slot ? slot : 1) * vb, g->stream));
+    if ((rc = dev_alloc(g, &g->w_start, (size_t)g->c.nweight))) return rc;
+    if ((rc = dev_alloc(g, &g->w_delta, (size_t)g->c.nweight))) return rc;
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    return NSK_OK;
+}
+
+}  // extern "C"
+
+template <typename VT>
+static int exchange_kernels(nsk_graph *g, int which, bool pack) {
+    VT *val = (VT *)(which == NSK_BUF_VALUE ? g->val : g->val_evid);
+    VT *sb = (VT *)(which == NSK_BUF_VALUE ? g->x_send : g->x_send_evid);
+    VT *rb = (VT *)(which == NSK_BUF_VALUE ? g->x_recv : g->x_recv_evid);
+    if (pack) {
+        const int n = (int)g->xnsend;
+        if (n > 0)
+            k_exchange_pack<VT><<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                val, g->x_send_vids, sb, n);
+    } else {
+        const int n = (int)g->xnrecv;
+        if (n > 0)
+            k_exchange_unpack<VT><<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                val, g->x_recv_vids, g->x_recv_slot, rb, n);
+    }
+    HIPCHECK(hipGetLastError());
+    return NSK_OK;
+}
+
+extern "C" {
+
+static int exchange_step(nsk_graph *g, int which, bool pack) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (g->xworld == 0) return fail(NSK_E_INVALID, "nsk_exchange_setup has not been called");
+    if (which != NSK_BUF_VALUE && which != NSK_BUF_VALUE_EVID) return fail(NSK_E_INVALID, "bad buffer id");
+    HIPCHECK(hipSetDevice(g->device));
+    return g->c.vbytes == 1 ? exchange_kernels<int8_t>(g, which, pack) : exchange_kernels<int32_t>(g, which, pack);
+}
+
+int nsk_exchange_pack(nsk_graph *g, int which) { return exchange_step(g, which, true); }
+int nsk_exchange_unpack(nsk_graph *g, int which) { return exchange_step(g, which, false); }
+
+// ---- native RCCL loop -----------------------------------------------------------------------------
+static int load_rccl(const char *path) {
+    if (g_rccl.lib) return NSK_OK;
+    void *h = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(NSK_E_DEVICE, std::string("dlopen(librccl): ") + dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(NSK_E_DEVICE, "librccl lacks the expected symbols");
+    g_rccl.lib = h;
+    return NSK_OK;
+}
+
+#define RCCLCHECK(expr)                                                                         \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return fail(NSK_E_DEVICE, std::string(#expr) + ": " +                              \
+                        (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"));    \
+    } while (0)
+
+int nsk_comm_unique_id(const char *librccl_path, void *id128) {
+    if (!id128) return fail(NSK_E_INVALID, "null argument");
+    int rc = load_rccl(librccl_path);
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    RCCLCHECK(g_rccl.GetUniqueId((ncclUniqueId *)id128));
+    return NSK_OK;
+}
+
+int nsk_comm_init(nsk_graph *g, int world, int rank, const void *id128, const char *librccl_path) {
+    if (!g || !id128 || world < 1 || rank < 0 || rank >= world) return fail(NSK_E_INVALID, "bad argument");
+    int rc = load_rccl(librccl_path);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(g->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    RCCLCHECK(g_rccl.CommInitRank(&comm, world, id, rank));
+    g->rccl_comm = comm;
+    return NSK_OK;
+}
+
+static int native_exchange(nsk_graph *g, int which) {
+    int rc = exchange_step(g, which, true);
+    if (rc) return rc;
+    const void *sb = which == NSK_BUF_VALUE ? g->x_send : g->x_send_evid;
+    void *rb = which == NSK_BUF_VALUE ? g->x_recv : g->x_recv_evid;
+    if (g->xslot > 0)
+        RCCLCHECK(g_rccl.AllGather(sb, rb, (size_t)g->xslot, g->c.vbytes == 1 ? ncclInt8 : ncclInt32,
+                                   (ncclComm_t)g->rccl_comm, g->stream));
+    return exchange_step(g, which, false);
+}
+
+int nsk_gibbs_sweeps_exchange(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->rccl_comm || g->xworld == 0) return fail(NSK_E_INVALID, "nsk_exchange_setup / nsk_comm_init first");
+    for (int64_t s = 0; s < nsweeps; s++) {
+        int rc = nsk_gibbs_sweeps(g, 1, sample_evidence, burnin);
+        if (rc) return rc;
+        if ((rc = native_exchange(g, NSK_BUF_VALUE))) return rc;
+    }
+    return NSK_OK;
+}
+
+int nsk_learn_sweeps_exchange(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                              double reg_param, int64_t truncation, int learn_non_evidence) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->rccl_comm || g->xworld == 0) return fail(NSK_E_INVALID, "nsk_exchange_setup / nsk_comm_init first");
+    const int nw = (int)g->c.nweight;
+    for (int64_t s = 0; s < nsweeps; s++) {
+        HIPCHECK(hipSetDevice(g->device));
+        if (nw) HIPCHECK(hipMemcpyAsync(g->w_start, g->w, (size_t)nw * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+        int rc = nsk_learn_sweeps(g, 1, step, 1.0, regularization, reg_param, truncation, learn_non_evidence);
+        if (rc) return rc;
+        if ((rc = native_exchange(g, NSK_BUF_VALUE))) return rc;
+        if ((rc = native_exchange(g, NSK_BUF_VALUE_EVID))) return rc;
+        if (nw) {       // w = w_start + sum over ranks of (w - w_start): numbskull_master.py:223-224
+            const dim3 grid((nw + NSK_BLOCK - 1) / NSK_BLOCK), block(NSK_BLOCK);
+            k_weight_delta<<<grid, block, 0, g->stream>>>(g->w, g->w_start, g->w_delta, nw);
+            RCCLCHECK(g_rccl.AllReduce(g->w_delta, g->w_delta, (size_t)nw, ncclDouble, ncclSum,
+                                       (ncclComm_t)g->rccl_comm, g->stream));
+            k_weight_merge<<<grid, block, 0, g->stream>>>(g->w, g->w_start, g->w_delta, nw);
+            g->weights_dirty = true;
+        }
+        step *= decay;
+    }
     return NSK_OK;
 }
 

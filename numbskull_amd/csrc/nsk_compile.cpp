@@ -289,6 +289,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
     }
 
+    // ---- ghosts: variables outside the owned range read by a sampled variable -------------------
+    if (ob > 0 || oe < nvar) {
+        std::vector<uint8_t> need(nvar, 0);
+        for (int64_t v = 0; v < nvar; v++)
+            if (sampled[v]) for_each_read(v, [&](int64_t b) { if (b < ob || b >= oe) need[b] = 1; });
+        for (int64_t v = 0; v < nvar; v++) if (need[v]) c.ghost_needs.push_back((int32_t)v);
+    }
+
     // ---- fast-path eligibility (DESIGN.md "fast path"): a binary dataType-0 variable whose every
     // factor is a symmetric boolean function it is a member of, with <= 6 other members and a
     // weight id below 2^24; and featureValue == 1 so that learning can use the same stream.

@@ -68,6 +68,8 @@ struct Compiled {
     std::vector<double> w_init;
     std::vector<uint8_t> w_fixed;
     std::vector<double> logtab;
+    // multi-GPU: variables outside the owned range that the sampled variables read (sorted)
+    std::vector<int32_t> ghost_needs;
     // initial values by variable id
     std::vector<int32_t> v_init;
     // algorithmic traffic, bytes per sweep over the sampled variables

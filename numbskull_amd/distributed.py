@@ -8,12 +8,23 @@ Salt/TCP (numbskull_master.py:165-224); learned weights are merged as ``w += sum
 (numbskull_master.py:223-224, numbskull_minion.py:270-279).
 
 Here: rank g owns variables ``[g*n//G, (g+1)*n//G)`` -- the reference's shard formula
-(inference.py:17-18) -- and after every sweep the owned slices of the value array are
-all-gathered with ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
-the CPU tests).  Ghost values are therefore one sweep old inside a sweep, exactly the reference's
-distributed semantics.  In learning the evidence-chain values are exchanged too and the weight
-deltas of the epoch are summed with an all-reduce.
+(inference.py:17-18).  After every sweep only the **boundary** values travel: each rank packs the
+owned variables some other rank reads into a small send buffer, the buffers are all-gathered over
+RCCL/xGMI, and every rank scatters what it received into its value array.  Ghost values are
+therefore one sweep old inside a sweep, exactly the reference's distributed semantics.  In
+learning the evidence-chain values are exchanged too and the weight deltas of the epoch are summed
+with an all-reduce.
+
+Two drivers for the per-sweep loop:
+  * native (default on GPUs): the whole loop -- sweep kernels, pack, ncclAllGather, unpack -- is
+    enqueued from C++ on one stream (nsk_gibbs_sweeps_exchange), the communicator being created
+    from a ncclUniqueId that rank 0 makes and ``torch.distributed`` broadcasts;
+  * torch: ``torch.distributed.all_gather_into_tensor`` on the library's staging buffers wrapped
+    as tensors; used by the CPU (gloo) tests and as the fallback.
 """
+
+import ctypes as C
+import os
 
 import numpy as np
 
@@ -23,19 +34,36 @@ def shard_range(rank, world, nvar):
     return (rank * nvar) // world, ((rank + 1) * nvar) // world
 
 
-def exchange_values(dist, tensor, world, nvar, group=None):
-    """All-gather the owned slices of a per-variable tensor in place.  Equal shards use one
-    all_gather_into_tensor; ragged shards fall back to one broadcast per owner."""
-    bounds = [shard_range(r, world, nvar) for r in range(world)]
-    sizes = {e - b for b, e in bounds}
-    rank = dist.get_rank(group)
-    if len(sizes) == 1 and bounds[-1][1] == nvar and tensor.is_contiguous():
-        b, e = bounds[rank]
-        dist.all_gather_into_tensor(tensor[:nvar], tensor[b:e], group=group)
-        return
-    for r, (b, e) in enumerate(bounds):
-        if e > b:
-            dist.broadcast(tensor[b:e], src=r, group=group)
+def plan_boundaries(needs_per_rank, world, nvar):
+    """Boundary lists every rank agrees on.
+
+    ``needs_per_rank[r]``: sorted ids rank r reads but does not own.  Returns ``(lists, slot)``:
+    ``lists[src]`` = sorted ids owned by ``src`` that at least one other rank reads, and the common
+    slot size (max length) of the gathered buffer."""
+    allneed = np.unique(np.concatenate([np.asarray(n, np.int64) for n in needs_per_rank]
+                                       + [np.empty(0, np.int64)]))
+    lists = []
+    for src in range(world):
+        lo, hi = shard_range(src, world, nvar)
+        lists.append(allneed[(allneed >= lo) & (allneed < hi)].astype(np.int32))
+    slot = max([len(b) for b in lists] + [0])
+    return lists, slot
+
+
+def gather_needs(dist, torch, needs, world, device):
+    """All-gather the (ragged) need lists of all ranks."""
+    if world == 1:
+        return [np.asarray(needs, np.int32)]
+    n = torch.tensor([len(needs)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    width = max(sizes + [1])
+    mine = torch.full((width,), -1, dtype=torch.int32, device=device)
+    mine[:len(needs)] = torch.as_tensor(np.asarray(needs, np.int32), device=device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [o[:s].cpu().numpy() for o, s in zip(out, sizes)]
 
 
 def merge_weight_deltas(dist, weights, start, group=None):
@@ -57,12 +85,11 @@ class PartitionedSampler(object):
     """One rank's share of a range-partitioned graph.
 
     ``fg`` is a FactorGraph created with ``own_range=shard_range(rank, world, nvar)``.  The
-    library's value buffers are wrapped as torch tensors (no copies) and the library is pointed
-    at torch's current stream, so sweeps and collectives are ordered by the stream.
+    library's buffers are wrapped as torch tensors (no copies) and the library is pointed at
+    torch's current stream, so sweeps and collectives are ordered by the stream.
     """
 
-    def __init__(self, fg, dist, torch, rank, world):
-        import ctypes as C
+    def __init__(self, fg, dist, torch, rank, world, native=True):
         from . import _lib
         self.fg, self.dist, self.torch, self.rank, self.world = fg, dist, torch, rank, world
         self.L = _lib.lib()
@@ -71,34 +98,100 @@ class PartitionedSampler(object):
         self.h = h
         self.nvar = fg.variable.shape[0]
         info = fg.info()
-        typestr = {1: "|i1", 4: "<i4"}[info["value_bytes"]]
-        dev = "cuda:%d" % fg.device
-        _lib.check(self.L.nsk_set_stream(h, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        self.typestr = {1: "|i1", 4: "<i4"}[info["value_bytes"]]
+        self.dev = "cuda:%d" % fg.device
+        _lib.check(self.L.nsk_set_stream(h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+        self.val = self._wrap(_lib.BUF_VALUE, self.nvar, self.typestr)
+        self.val_evid = self._wrap(_lib.BUF_VALUE_EVID, self.nvar, self.typestr)
+        self.w = self._wrap(_lib.BUF_WEIGHT, fg.weight.shape[0], "<f8")
+        self.native = False
+        self.lists, self.slot = None, 0
+        if world > 1:
+            self.setup_exchange(native)
 
-        def wrap(which, nelem, ts):
-            p, nb = C.c_void_p(), C.c_int64()
-            _lib.check(self.L.nsk_device_buffer(h, which, C.byref(p), C.byref(nb)))
-            return torch.as_tensor(_DevicePointer(p.value, nelem, ts), device=dev)
+    def _wrap(self, which, nelem, ts):
+        p, nb = C.c_void_p(), C.c_int64()
+        self._lib.check(self.L.nsk_device_buffer(self.h, which, C.byref(p), C.byref(nb)))
+        if nelem == 0 or not p.value:
+            return self.torch.empty(0, device=self.dev)
+        return self.torch.as_tensor(_DevicePointer(p.value, nelem, ts), device=self.dev)
 
-        self.val = wrap(_lib.BUF_VALUE, self.nvar, typestr)
-        self.val_evid = wrap(_lib.BUF_VALUE_EVID, self.nvar, typestr)
-        self.w = wrap(_lib.BUF_WEIGHT, fg.weight.shape[0], "<f8")
+    def install_boundaries(self, lists, slot):
+        """Hand the agreed boundary lists to the library and wrap its staging buffers."""
+        _lib = self._lib
+        self.lists, self.slot = lists, int(slot)
+        send = np.ascontiguousarray(lists[self.rank], np.int32)
+        recv = np.ascontiguousarray(np.concatenate(lists + [np.empty(0, np.int32)]), np.int32)
+        off = np.zeros(self.world + 1, np.int64)
+        np.cumsum([len(b) for b in lists], out=off[1:])
+        _lib.check(self.L.nsk_exchange_setup(self.h, self.world, self.rank, _lib.ptr(send), len(send),
+                                             _lib.ptr(recv), _lib.ptr(off), self.slot))
+        self.send = self._wrap(_lib.BUF_SEND, self.slot, self.typestr)
+        self.recv = self._wrap(_lib.BUF_RECV, self.slot * self.world, self.typestr)
+        self.send_evid = self._wrap(_lib.BUF_SEND_EVID, self.slot, self.typestr)
+        self.recv_evid = self._wrap(_lib.BUF_RECV_EVID, self.slot * self.world, self.typestr)
+
+    def setup_exchange(self, native=True):
+        needs = self.fg.ghost_needs()
+        lists, slot = plan_boundaries(gather_needs(self.dist, self.torch, needs, self.world, self.dev),
+                                      self.world, self.nvar)
+        self.install_boundaries(lists, slot)
+        if native:
+            self.native = self._init_native()
+
+    def _init_native(self):
+        """ncclUniqueId from rank 0, broadcast with torch.distributed, ncclCommInitRank per rank."""
+        torch, dist = self.torch, self.dist
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = path if os.path.exists(path) else ""
+        uid = (C.c_uint8 * 128)()
+        ok = 1
+        if self.rank == 0:
+            ok = int(self.L.nsk_comm_unique_id(path.encode(), uid) == 0)
+        t = torch.tensor(list(bytes(uid)) + [ok], dtype=torch.uint8, device=self.dev)
+        if self.world > 1:
+            dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().numpy().tolist())
+        if raw[128] != 1:
+            return False
+        buf = (C.c_uint8 * 128).from_buffer_copy(raw[:128])
+        rc = self.L.nsk_comm_init(self.h, self.world, self.rank, buf, path.encode())
+        flag = torch.tensor([int(rc == 0)], dtype=torch.int32, device=self.dev)
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # native only if it works everywhere
+        return bool(flag.item())
+
+    # ------------------------------------------------------------------ per-sweep loops
+    def _exchange(self, which, send, recv):
+        self._lib.check(self.L.nsk_exchange_pack(self.h, which))
+        if self.slot > 0:
+            self.dist.all_gather_into_tensor(recv, send)
+        self._lib.check(self.L.nsk_exchange_unpack(self.h, which))
 
     def gibbs(self, nsweeps, sample_evidence=True, burnin=False):
-        for _ in range(nsweeps):
-            self._lib.check(self.L.nsk_gibbs_sweeps(self.h, 1, int(sample_evidence), int(burnin)))
-            if self.world > 1:
-                exchange_values(self.dist, self.val, self.world, self.nvar)
+        _lib = self._lib
+        if self.world == 1:
+            _lib.check(self.L.nsk_gibbs_sweeps(self.h, nsweeps, int(sample_evidence), int(burnin)))
+        elif self.native:
+            _lib.check(self.L.nsk_gibbs_sweeps_exchange(self.h, nsweeps, int(sample_evidence), int(burnin)))
+        else:
+            for _ in range(nsweeps):
+                _lib.check(self.L.nsk_gibbs_sweeps(self.h, 1, int(sample_evidence), int(burnin)))
+                self._exchange(_lib.BUF_VALUE, self.send, self.recv)
 
     def learn(self, nsweeps, step, decay, regularization, reg_param, truncation,
               learn_non_evidence=False):
-        for _ in range(nsweeps):
-            start = self.w.clone()
-            self._lib.check(self.L.nsk_learn_sweeps(self.h, 1, float(step), 1.0,
-                                                    int(regularization), float(reg_param),
-                                                    int(truncation), int(learn_non_evidence)))
-            if self.world > 1:
-                exchange_values(self.dist, self.val, self.world, self.nvar)
-                exchange_values(self.dist, self.val_evid, self.world, self.nvar)
+        _lib = self._lib
+        args = (int(regularization), float(reg_param), int(truncation), int(learn_non_evidence))
+        if self.world == 1:
+            _lib.check(self.L.nsk_learn_sweeps(self.h, nsweeps, float(step), float(decay), *args))
+        elif self.native:
+            _lib.check(self.L.nsk_learn_sweeps_exchange(self.h, nsweeps, float(step), float(decay), *args))
+        else:
+            for _ in range(nsweeps):
+                start = self.w.clone()
+                _lib.check(self.L.nsk_learn_sweeps(self.h, 1, float(step), 1.0, *args))
+                self._exchange(_lib.BUF_VALUE, self.send, self.recv)
+                self._exchange(_lib.BUF_VALUE_EVID, self.send_evid, self.recv_evid)
                 merge_weight_deltas(self.dist, self.w, start)
-            step *= decay
+                step *= decay

@@ -99,6 +99,23 @@ class FactorGraph(object):
         _lib.check(_lib.lib().nsk_graph_plan(C.byref(desc), _lib.ptr(color), C.byref(inf)))
         return color, {k: getattr(inf, k) for k, _ in inf._fields_}
 
+    def ghost_needs(self, host_only=False):
+        """Sorted ids of the variables outside ``own_range`` that this partition's variables read
+        (what the boundary exchange must deliver).  ``host_only`` plans without touching a GPU."""
+        L = _lib.lib()
+        n = C.c_int64()
+        if host_only:
+            desc, keep = self._descriptor()
+            _lib.check(L.nsk_graph_plan_needs(C.byref(desc), C.byref(n), None))
+            out = np.zeros(n.value, np.int32)
+            _lib.check(L.nsk_graph_plan_needs(C.byref(desc), C.byref(n), _lib.ptr(out)))
+            return out
+        h = self._engine()
+        _lib.check(L.nsk_ghost_needs(h, C.byref(n), None))
+        out = np.zeros(n.value, np.int32)
+        _lib.check(L.nsk_ghost_needs(h, C.byref(n), _lib.ptr(out)))
+        return out
+
     def _engine(self):
         """Create (once) the device-side graph.  Fails loudly without a GPU."""
         if self._handle is not None:

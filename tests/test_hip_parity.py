@@ -451,11 +451,12 @@ def test_partitioned_sampler_wraps_library_buffers():
 @pytest.mark.parametrize("learn", [False, True])
 def test_two_partitions_on_one_gpu_match_emulation(learn):
     """Two handles own the two halves of the variable range (own_range = the reference's shard
-    formula); after every sweep the owned slices are copied into the other handle's buffers --
-    the all-gather of the multi-GPU run -- and weights merge as w_start + sum of deltas.  Must equal
-    the oracle's emulation of the same partitioned semantics."""
+    formula).  After every sweep each handle packs its boundary values (nsk_exchange_pack), the
+    send buffers are copied into the other handle's gathered buffer -- the all-gather of the
+    multi-GPU run -- and unpacked (nsk_exchange_unpack); weights merge as w_start + sum of deltas.
+    Owned slices must equal the oracle's emulation of the partitioned semantics bit for bit."""
     import torch
-    from numbskull_amd.distributed import PartitionedSampler, shard_range
+    from numbskull_amd.distributed import PartitionedSampler, shard_range, plan_boundaries
     rng = np.random.default_rng(3)
     if learn:
         g = graphgen.ising_grid(20, 24, weight=0.1, fixed=False, two_weights=True,
@@ -469,37 +470,54 @@ def test_two_partitions_on_one_gpu_match_emulation(learn):
         w, v, f, fm, dm, edges = [x.copy() if isinstance(x, np.ndarray) else x for x in g]
         ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=shard_range(r, world, nvar))
         fg = ns.factorGraphs[0]
-        parts.append(PartitionedSampler(fg, None, torch, r, 1))
+        ps = PartitionedSampler(fg, None, torch, r, 1)
+        ps.world = world                               # drive the exchange by hand below
+        parts.append(ps)
         color = fg.colors()
         lo, hi = shard_range(r, world, nvar)
         assert np.all(color[:lo] == -1) and np.all(color[hi:] == -1) and np.all(color[lo:hi] >= 0)
         og = oracle_of(fg)
         oracles.append((og, phases_from_colors(color), og.initial_state(), (lo, hi)))
+    needs = [p.fg.ghost_needs() for p in parts]
+    assert all(np.array_equal(n, p.fg.ghost_needs(host_only=True)) for n, p in zip(needs, parts))
+    lists, slot = plan_boundaries(needs, world, nvar)
+    assert slot == 24 and all(len(b) == 24 for b in lists)      # one grid row on each side of the cut
+    for p in parts:
+        p.install_boundaries(lists, slot)
+    L = _lib.lib()
     step = 0.01
     for s in range(nsweeps):
         starts = [p.w.clone() for p in parts]
         ostarts = [st[2].copy() for _, _, st, _ in oracles]
         for p in parts:
             if learn:
-                p.learn(1, step, 1.0, 2, 0.01, 1)
+                _lib.check(L.nsk_learn_sweeps(p.h, 1, step, 1.0, 2, 0.01, 1, 0))
             else:
-                p.gibbs(1)
+                _lib.check(L.nsk_gibbs_sweeps(p.h, 1, 1, 0))
         for og, (order, ps), (vv, ve, wv, cnt), _ in oracles:
             if learn:
                 og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 31, s)
             else:
                 og.gibbs_dev(order, ps, vv, wv, cnt, 31, s, True)
         step *= 0.9
-        torch.cuda.synchronize()
-        for r in range(world):                      # "all-gather": owners publish their slices
+        for which, sname, rname in ((_lib.BUF_VALUE, "send", "recv"),
+                                    (_lib.BUF_VALUE_EVID, "send_evid", "recv_evid")):
+            for p in parts:
+                _lib.check(L.nsk_exchange_pack(p.h, which))
+            torch.cuda.synchronize()
+            for q in parts:                                  # the all-gather
+                for r, p in enumerate(parts):
+                    getattr(q, rname)[r * slot:(r + 1) * slot] = getattr(p, sname)
+            torch.cuda.synchronize()
+            for p in parts:
+                _lib.check(L.nsk_exchange_unpack(p.h, which))
+        for r in range(world):                               # oracle side: owners publish their slices
             lo, hi = shard_range(r, world, nvar)
             for q in range(world):
                 if q != r:
-                    parts[q].val[lo:hi] = parts[r].val[lo:hi]
-                    parts[q].val_evid[lo:hi] = parts[r].val_evid[lo:hi]
                     oracles[q][2][0][lo:hi] = oracles[r][2][0][lo:hi]
                     oracles[q][2][1][lo:hi] = oracles[r][2][1][lo:hi]
-        if learn:                                   # w = w_start + sum of deltas
+        if learn:                                            # w = w_start + sum of deltas
             total = sum(p.w - s0 for p, s0 in zip(parts, starts))
             for p, s0 in zip(parts, starts):
                 p.w.copy_(s0 + total)
@@ -509,11 +527,42 @@ def test_two_partitions_on_one_gpu_match_emulation(learn):
         torch.cuda.synchronize()
     for r in range(world):
         vv, ve, wv, cnt = oracles[r][2]
-        assert np.array_equal(parts[r].val.cpu().numpy().astype(np.int64), vv)
+        lo, hi = shard_range(r, world, nvar)
+        got = parts[r].val.cpu().numpy().astype(np.int64)
+        assert np.array_equal(got[lo:hi], vv[lo:hi])
+        other = lists[1 - r]                                 # the boundary of the other rank arrived
+        assert np.array_equal(got[other], vv[other])
         if learn:
-            assert np.array_equal(parts[r].val_evid.cpu().numpy().astype(np.int64), ve)
+            assert np.array_equal(parts[r].val_evid.cpu().numpy().astype(np.int64)[lo:hi], ve[lo:hi])
             assert np.allclose(parts[r].w.cpu().numpy(), wv, rtol=0, atol=1e-15)
-    assert torch.equal(parts[0].val, parts[1].val)
+
+
+def test_native_rccl_loop_single_rank():
+    """nsk_comm_init + nsk_gibbs_sweeps_exchange / nsk_learn_sweeps_exchange with a 1-rank
+    communicator: the native loop (sweep, pack, ncclAllGather, unpack, ncclAllReduce of weight
+    deltas) must leave a single partition exactly where the plain sweeps leave it."""
+    import torch
+    from numbskull_amd.distributed import PartitionedSampler
+    rng = np.random.default_rng(5)
+    g = graphgen.ising_grid(40, 32, weight=0.2, fixed=False, two_weights=True,
+                            evidence=rng.integers(0, 2, 1280))
+    ns, fg = session(g, seed=17)
+    ps = PartitionedSampler(fg, None, torch, 0, 1)
+    lists = [np.arange(100, 164, dtype=np.int32)]          # pretend someone reads these
+    ps.install_boundaries(lists, 64)
+    assert ps._init_native()
+    L = _lib.lib()
+    _lib.check(L.nsk_gibbs_sweeps_exchange(ps.h, 3, 1, 0))
+    _lib.check(L.nsk_learn_sweeps_exchange(ps.h, 2, 1e-3, 0.9, 2, 0.01, 1, 0))
+    torch.cuda.synchronize()
+    ns2, fg2 = session(g, seed=17)
+    fg2.inference(0, 3, True)
+    fg2.learn(0, 2, 1e-3, 0.9, 2, 0.01, 1)
+    assert np.array_equal(ps.val.cpu().numpy().astype(np.int64), fg2.var_value[0])
+    assert np.array_equal(ps.val_evid.cpu().numpy().astype(np.int64), fg2.var_value_evid[0])
+    assert np.allclose(ps.w.cpu().numpy(), fg2.weight_value[0], rtol=0, atol=1e-15)
+    assert np.array_equal(ps.send.cpu().numpy(), ps.val.cpu().numpy()[100:164])
+    assert np.array_equal(ps.recv.cpu().numpy(), ps.send.cpu().numpy())
 
 
 def test_rccl_all_gather_on_library_memory():
@@ -523,7 +572,7 @@ def test_rccl_all_gather_on_library_memory():
     import socket
     import torch
     import torch.distributed as dist
-    from numbskull_amd.distributed import PartitionedSampler, exchange_values, merge_weight_deltas
+    from numbskull_amd.distributed import PartitionedSampler, merge_weight_deltas
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -538,7 +587,10 @@ def test_rccl_all_gather_on_library_memory():
         ps = PartitionedSampler(fg, dist, torch, 0, 1)
         ps.gibbs(3)
         before = ps.val.clone()
-        exchange_values(dist, ps.val, 1, ps.nvar)
+        ps.install_boundaries([np.arange(7, 71, dtype=np.int32)], 64)
+        ps.world = 1
+        ps._exchange(_lib.BUF_VALUE, ps.send, ps.recv)       # pack, all_gather_into_tensor, unpack
+        assert torch.equal(ps.recv, ps.val[7:71])
         start = ps.w.clone()
         ps.w += 0.25
         merge_weight_deltas(dist, ps.w, start)
