@@ -19,858 +19,11 @@
 #include "nsk_compile.h"
 #include "nsk_device.h"
 
+#include "nsk_kernels_gibbs.h"
+#include "nsk_kernels_learn.h"
+#include "nsk_kernels_misc.h"
+
 using namespace nsk;
-
-// =============================================================================================
-// kernels
-// =============================================================================================
-#define NSK_BLOCK 256
-// persistent grids of the learning kernels (rows of the SMALLW partial-sum tables)
-#define NSK_LEARN_FAST_BLOCKS 2048
-#define NSK_LEARN_LIST_BLOCKS 512
-#define NSK_LEARN_GEN_BLOCKS 2048
-#define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS)
-
-// One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
-// gibbsthread's loop body (inference.py:20-33) for that variable.
-template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_phase(DevGraph<VT> g, int pbegin, int pend,
-                                                           int sample_evidence, int burnin,
-                                                           uint32_t k0, uint32_t k1, uint32_t s0,
-                                                           uint32_t s1) {
-    const int p = pbegin + (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (p >= pend) return;
-    const uint32_t info = g.p_info[p];
-    const int ev = NSK_INFO_EV(info);
-    if (!(ev == 0 || sample_evidence)) return;          // inference.py:24 (ev == 4 never gets a position)
-    const int v = g.p_vid[p];
-    if (v < 0) return;
-    const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-    const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));
-    g.val[v] = (VT)nv;
-    if (!burnin) {                                      // inference.py:29-33
-        const int base = g.p_cnt[p];
-        if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
-        else g.cnt[base + nv] += 1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fast path of one colour class: binary variables whose factors are symmetric boolean functions.
-// One wave owns 64 consecutive positions and walks their inlined adjacency tile; every stream word
-// is one coalesced 256-byte load for the wave, member words are followed by a 1-byte gather of the
-// neighbour's value.  Words are fetched NSK_CHUNK at a time so that the stream loads, then the
-// gathers, are all in flight together.  Same float64 operations, in the same order, as
-// k_gibbs_phase (potential(): product, then add, in factor-list order).
-// ---------------------------------------------------------------------------------------------
-#define NSK_CHUNK 8
-
-// Tile with per-lane headers: every lane parses its own word sequence.
-template <typename VT>
-__device__ __forceinline__ void tile_potentials_dynamic(const DevGraph<VT> &g, const VT *val,
-                                                        const uint4 *sp, int len, double &p0,
-                                                        double &p1) {
-    FactorAcc acc;
-    acc.rem = 0; acc.func = F_NOOP; acc.w = 0.0; acc.first = -1;
-    acc.allnz = true; acc.any1 = false; acc.alleq = true;
-    for (int j0 = 0; j0 < len; j0 += NSK_CHUNK) {
-        const uint4 qa = sp[(size_t)(j0 / 4) * 64];
-        const uint4 qb = (j0 + 4 < len) ? sp[(size_t)(j0 / 4 + 1) * 64]
-                                        : uint4{NSK_PAD_WORD, NSK_PAD_WORD, NSK_PAD_WORD, NSK_PAD_WORD};
-        const uint32_t wd[NSK_CHUNK] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        bool ismem[NSK_CHUNK];          // pure ALU on the words just loaded
-        int r = acc.rem;
-#pragma unroll
-        for (int i = 0; i < NSK_CHUNK; i++) {
-            ismem[i] = r > 0;
-            if (r > 0) r--;
-            else if (wd[i] != NSK_PAD_WORD) r = NSK_HDR_NOTHER(wd[i]);
-        }
-        int xv[NSK_CHUNK];
-        double wv[NSK_CHUNK];
-#pragma unroll
-        for (int i = 0; i < NSK_CHUNK; i++) {
-            xv[i] = ismem[i] ? (int)val[wd[i]] : 0;
-            wv[i] = (!ismem[i] && wd[i] != NSK_PAD_WORD) ? g.w[NSK_HDR_WID(wd[i])] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < NSK_CHUNK; i++) {
-            bool done = false;
-            if (ismem[i]) {
-                acc.member(xv[i]);
-                done = acc.rem == 0;
-            } else if (wd[i] != NSK_PAD_WORD) {
-                acc.start(wd[i], wv[i]);
-                done = acc.rem == 0;
-            }
-            if (done) {
-                double e0, e1;
-                acc.values(e0, e1);
-                const double t0 = acc.w * e0, t1 = acc.w * e1;
-                p0 = p0 + t0;
-                p1 = p1 + t1;
-            }
-        }
-    }
-}
-
-// Uniform tile: all 64 lanes share one slot program (<= 8 member slots).  The program words and
-// the per-slot weight terms (prog_w: weight*value for a satisfied / unsatisfied entry, already
-// multiplied by k_refresh_prog_weights) arrive by scalar loads, the member ids by one or two
-// 16-byte loads per lane, the neighbour values by byte gathers.  The per-slot update is
-// straight-line boolean algebra: program flags are wave-uniform, lane facts are lane masks.
-// Padding slots (program word 0) and slots that do not close an entry add an exact 0.0.
-struct SlotState {
-    int first;
-    bool allnz, any1, alleq;
-};
-
-__device__ __forceinline__ void slot_step(SlotState &st, uint32_t s, double thi, double tlo, int x,
-                                          double &p0, double &p1) {
-    const bool F = (s >> 27) & 1u, ig = (s >> 29) & 1u;          // uniform
-    const uint32_t code = (s >> 24) & 7u;
-    const bool nz = ig || (x != 0), one = !ig && (x == 1);
-    st.alleq = F || (st.alleq && (x == st.first));
-    st.allnz = (F || st.allnz) && nz;
-    st.any1 = (!F && st.any1) || one;
-    st.first = F ? x : st.first;
-    // "satisfied" for candidate 0 / 1 (inference.py:162-200)
-    const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
-    const bool b0 = (isEq && st.alleq && (ig || st.first == 0)) || (isOr && st.any1);
-    const bool b1 = (isEq && st.alleq && (ig || st.first == 1)) || (isAnd && st.allnz) || isOr;
-    p0 = p0 + (b0 ? thi : tlo);
-    p1 = p1 + (b1 ? thi : tlo);
-}
-
-// Entries with exactly one other member and one function code for the whole tile (the shape of
-// pairwise models such as the Ising grid): no state, two compares per slot.
-template <int CODE>
-__device__ __forceinline__ void pair_step(double thi, double tlo, int x, double &p0, double &p1) {
-    bool b0, b1;
-    if (CODE == 4) { b0 = x == 0; b1 = x == 1; }            // EQUAL
-    else if (CODE == 2) { b0 = x == 1; b1 = true; }          // OR
-    else { b0 = false; b1 = x != 0; }                        // AND / ISTRUE / IMPLY_NATURAL
-    p0 = p0 + (b0 ? thi : tlo);
-    p1 = p1 + (b1 ? thi : tlo);
-}
-
-template <typename VT, int KIND>
-__device__ __forceinline__ void tile_potentials_uniform(const DevGraph<VT> &g, const VT *val,
-                                                        const uint4 *sp, int len, uint32_t prog,
-                                                        double &p0, double &p1) {
-    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
-    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
-    if (len <= 0) return;
-    SlotState st = {0, true, false, true};
-    const uint4 qa = sp[0];
-    uint32_t sl[4];
-    double th[4], tl[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { sl[i] = KIND ? 0u : pp[i]; th[i] = tw[2 * i]; tl[i] = tw[2 * i + 1]; }
-    const int x0 = (int)val[qa.x], x1 = (int)val[qa.y], x2 = (int)val[qa.z], x3 = (int)val[qa.w];
-    if (KIND) {
-        pair_step<KIND>(th[0], tl[0], x0, p0, p1);
-        pair_step<KIND>(th[1], tl[1], x1, p0, p1);
-        pair_step<KIND>(th[2], tl[2], x2, p0, p1);
-        pair_step<KIND>(th[3], tl[3], x3, p0, p1);
-    } else {
-        slot_step(st, sl[0], th[0], tl[0], x0, p0, p1);
-        slot_step(st, sl[1], th[1], tl[1], x1, p0, p1);
-        slot_step(st, sl[2], th[2], tl[2], x2, p0, p1);
-        slot_step(st, sl[3], th[3], tl[3], x3, p0, p1);
-    }
-    if (len > 4) {
-        const uint4 qb = sp[64];
-#pragma unroll
-        for (int i = 0; i < 4; i++) { sl[i] = KIND ? 0u : pp[4 + i]; th[i] = tw[8 + 2 * i]; tl[i] = tw[9 + 2 * i]; }
-        const int x4 = (int)val[qb.x], x5 = (int)val[qb.y], x6 = (int)val[qb.z], x7 = (int)val[qb.w];
-        if (KIND) {
-            pair_step<KIND>(th[0], tl[0], x4, p0, p1);
-            pair_step<KIND>(th[1], tl[1], x5, p0, p1);
-            pair_step<KIND>(th[2], tl[2], x6, p0, p1);
-            pair_step<KIND>(th[3], tl[3], x7, p0, p1);
-        } else {
-            slot_step(st, sl[0], th[0], tl[0], x4, p0, p1);
-            slot_step(st, sl[1], th[1], tl[1], x5, p0, p1);
-            slot_step(st, sl[2], th[2], tl[2], x6, p0, p1);
-            slot_step(st, sl[3], th[3], tl[3], x7, p0, p1);
-        }
-    }
-}
-
-// prog_w[2i], prog_w[2i+1] = weight * (value when satisfied, value when not) of program word i, or
-// (0, 0) when the slot does not close an entry.  The products are the reference's own
-// `weight * eval_factor` (inference.py:68-70), so adding them reproduces potential() exactly.
-__global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32_t *prog, const double *w,
-                                                                    double *prog_w, int n) {
-    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (i >= n) return;
-    const uint32_t s = prog[i];
-    if (s >> 31) return;                                   // role word of a shape tile, not a slot
-    const uint32_t code = (s >> 24) & 7u;
-    const bool last = (s >> 28) & 1u;
-    const double hi = code == 0u ? 0.0 : 1.0;
-    const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
-    const double wt = w[s & 0xFFFFFFu];
-    prog_w[2 * i] = last ? wt * hi : 0.0;
-    prog_w[2 * i + 1] = last ? wt * lo : 0.0;
-}
-
-// Shape tile: every lane has its own factor functions and weights (per-lane header words in the
-// stream) but all 64 lanes share the word layout -- which words are headers, which are members,
-// where entries start and end -- so the walk is driven by a scalar role program and only the
-// per-lane facts (function code, weight, member values) are vector work.  This is the shape of
-// graphs whose factors carry individual weights.
-template <typename VT>
-__device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, const VT *val,
-                                                      const uint4 *sp, int len, uint32_t prog,
-                                                      double &p0, double &p1) {
-    const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
-    uint32_t code = 0;                   // per lane: 0 NOOP 1 IMPLY_NATURAL 2 OR 3 AND/ISTRUE 4 EQUAL
-    double w = 0.0;
-    int first = 0;
-    bool allnz = true, any1 = false, alleq = true;
-    auto finish = [&](bool nomember) {
-        const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
-        const bool b0 = (isEq && alleq && (nomember || first == 0)) || (isOr && any1);
-        const bool b1 = (isEq && alleq && (nomember || first == 1)) || (isAnd && allnz) || isOr;
-        const double hi = code == 0u ? 0.0 : 1.0;
-        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
-        const double t0 = w * (b0 ? hi : lo), t1 = w * (b1 ? hi : lo);
-        p0 = p0 + t0;
-        p1 = p1 + t1;
-    };
-    for (int c = 0; c * 4 < len; c++) {                                  // <= 4 chunks, scalar loop
-        const uint4 q = sp[(size_t)c * 64];
-        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-        uint32_t role[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0xFu;      // scalar; 0 = padding word
-        double wv[4];
-        int xv[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {                                    // one gather per word
-            wv[i] = 0.0; xv[i] = 0;
-            if (role[i] & 1u) wv[i] = g.w[wd[i] & 0xFFFFFFu];
-            else if (role[i]) xv[i] = (int)val[wd[i]];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (role[i] & 1u) {                                          // header: open an entry
-                code = (0x343210u >> (4u * (wd[i] >> 27))) & 0xFu;       // function+1 in 0..5 -> code
-                w = wv[i];
-                first = 0; allnz = true; any1 = false; alleq = true;
-                if (role[i] & 8u) finish(true);
-            } else if (role[i]) {                                        // member
-                const int x = xv[i];
-                const bool F = (role[i] & 2u) != 0;
-                alleq = F || (alleq && (x == first));
-                allnz = (F || allnz) && (x != 0);
-                any1 = (!F && any1) || (x == 1);
-                first = F ? x : first;
-                if (role[i] & 4u) finish(false);
-            }
-        }
-    }
-}
-
-template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pbegin, int pend,
-                                                          int wb_base, int nblocks,
-                                                          const uint32_t *tile_list, int nlist,
-                                                          int sample_evidence, int burnin,
-                                                          uint32_t k0, uint32_t k1, uint32_t s0,
-                                                          uint32_t s1) {
-    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
-    if (lb < 0) return;
-    const int lane = (int)(threadIdx.x & 63);
-    int wave = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
-    if (tile_list) {                                      // list mode: the tiles outside segments
-        if (wave >= nlist) return;
-        wave = (int)__builtin_amdgcn_readfirstlane(tile_list[wave]);
-    }
-    const int p = pbegin + wave * 64 + lane;
-    if (pbegin + wave * 64 >= pend) return;               // whole wave beyond the range
-    const int v0 = p < pend ? g.p_vid[p] : -1;            // -1 also marks padding positions
-    const bool valid = v0 >= 0;
-    const int v = valid ? v0 : 0;
-    const uint32_t info = valid ? g.p_info[p] : 0u;
-    const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + wave));
-    const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
-    const uint4 *sp = g.adj + td.x + lane;
-    const int len = (int)td.y;
-    // the tally byte is fetched now so that its latency overlaps the tile walk
-    const uint8_t tally = (valid && !burnin) ? g.cnt_pos[p] : (uint8_t)0;
-
-    double p0 = 0.0, p1 = 0.0;
-    if (td.z == NSK_PAD_WORD) tile_potentials_dynamic(g, g.val, sp, len, p0, p1);
-    else {
-        const uint32_t kind = (td.w >> 8) & 7u;              // wave-uniform
-        if (kind == 7u) tile_potentials_shape(g, g.val, sp, (int)(td.w & 0xFFu), td.z, p0, p1);
-        else if (kind == 4u) tile_potentials_uniform<VT, 4>(g, g.val, sp, len, td.z, p0, p1);
-        else if (kind == 0u) tile_potentials_uniform<VT, 0>(g, g.val, sp, len, td.z, p0, p1);
-        else if (kind == 2u) tile_potentials_uniform<VT, 2>(g, g.val, sp, len, td.z, p0, p1);
-        else tile_potentials_uniform<VT, 3>(g, g.val, sp, len, td.z, p0, p1);
-    }
-    if (!valid) return;
-    const int ev = NSK_INFO_EV(info);
-    if (!(ev == 0 || sample_evidence)) return;
-    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-    const double z0 = nsk_exp(p0);
-    const double z1 = z0 + nsk_exp(p1);
-    const double z = u53(rr.x, rr.y) * z1;
-    const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
-    g.val[v] = (VT)nv;
-    if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
-}
-
-// Homogeneous segments: runs of consecutive uniform tiles with one program, slot count, kind and
-// evidence flag (the shape-class layout of nsk_compile.cpp makes whole classes such runs).  Up to
-// NSK_SEG_MAX segments of one (kind, chunk count) share a launch; everything the descriptor-driven
-// kernel fetches per tile comes from the kernel-argument table here, and the body is straight
-// line: ids, 16-byte member loads, byte gathers, compares, draw, store.
-#define NSK_SEG_MAX 8
-struct SegTable {
-    int n;
-    int tile_start[NSK_SEG_MAX + 1];      // first tile of each segment in this launch's numbering
-    int pos0[NSK_SEG_MAX];                // position of the segment's first lane
-    uint32_t adj_off[NSK_SEG_MAX];        // stream offset (16-byte units) of its first tile
-    uint32_t prog[NSK_SEG_MAX];           // slot program
-};
-
-template <typename VT, int KIND, int NCH>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTable tab, int nblocks,
-                                                         int burnin, uint32_t k0, uint32_t k1,
-                                                         uint32_t s0, uint32_t s1) {
-    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
-    if (lb < 0) return;
-    const int lane = (int)(threadIdx.x & 63);
-    const int T = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
-    if (T >= tab.tile_start[tab.n]) return;
-    int sidx = 0;
-#pragma unroll
-    for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
-    const int t = T - tab.tile_start[sidx];
-    const uint32_t prog = tab.prog[sidx];
-    const int p = tab.pos0[sidx] + t * 64 + lane;
-    const int v = g.p_vid[p];                             // -1: padding lane at a class end
-    const uint8_t tally = burnin ? (uint8_t)0 : g.cnt_pos[p];
-    const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
-    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
-    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
-    uint4 q[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];
-    int x[4 * NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        x[4 * c] = (int)g.val[q[c].x]; x[4 * c + 1] = (int)g.val[q[c].y];
-        x[4 * c + 2] = (int)g.val[q[c].z]; x[4 * c + 3] = (int)g.val[q[c].w];
-    }
-    double p0 = 0.0, p1 = 0.0;
-    SlotState st = {0, true, false, true};
-#pragma unroll
-    for (int j = 0; j < 4 * NCH; j++) {
-        const double thi = tw[2 * j], tlo = tw[2 * j + 1];
-        if (KIND) pair_step<KIND>(thi, tlo, x[j], p0, p1);
-        else slot_step(st, pp[j], thi, tlo, x[j], p0, p1);
-    }
-    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-    const double z0 = nsk_exp(p0);
-    const double z1 = z0 + nsk_exp(p1);
-    const double z = u53(rr.x, rr.y) * z1;
-    const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
-    if (v >= 0) {
-        g.val[v] = (VT)nv;
-        if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Learning.  One colour class of one learning sweep = sample_and_sgd (learning.py:46-125) for every
-// variable of the class with the weights frozen; gradients go to per-weight fixed-point sums and
-// the weight update for the whole class is applied afterwards (DESIGN.md "device-mode learning").
-// ---------------------------------------------------------------------------------------------
-struct LearnParams {
-    int regularization, learn_non_evidence;
-    double inv_trunc;
-    uint32_t k0, k1, s0, s1;
-    int row_base;               // first row of this launch in the partial-sum tables (SMALLW)
-};
-
-// per-block accumulation tables in LDS (SMALLW) or the global accumulators
-template <bool SMALLW, typename VT>
-__device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem) {
-    GradSink sk;
-    if (SMALLW) {
-        const int nw = g.nweight;
-        sk.G = (long long *)smem;
-        sk.K = (uint32_t *)(smem + 8 * (size_t)nw);
-        sk.T = sk.K + nw;
-        for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) { sk.G[i] = 0; sk.K[i] = 0; sk.T[i] = 0; }
-        __syncthreads();
-    } else {
-        sk.G = g.G; sk.K = g.K; sk.T = g.T;
-    }
-    return sk;
-}
-
-template <bool SMALLW, typename VT>
-__device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink &sk, int row) {
-    if (!SMALLW) return;
-    __syncthreads();
-    const int nw = g.nweight;
-    for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) {
-        g.part_G[(size_t)row * nw + i] = sk.G[i];
-        g.part_K[(size_t)row * nw + i] = sk.K[i];
-        g.part_T[(size_t)row * nw + i] = sk.T[i];
-    }
-}
-
-// Generic learning kernel.  Work items are 64-position groups: item i covers positions
-// pbegin + 64 i (range mode) or list[i] (list mode: the per-lane-header tiles of the fast range),
-// clipped at pend.  A persistent grid strides over the items so that SMALLW blocks flush once.
-template <typename VT, bool SMALLW>
-__global__ __launch_bounds__(NSK_BLOCK) void k_learn_phase(DevGraph<VT> g, int pbegin, int pend,
-                                                           const uint32_t *list, int nitems,
-                                                           LearnParams lp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const GradSink sk = open_sink<SMALLW>(g, smem);
-    const int lane = (int)(threadIdx.x & 63);
-    const int wave0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
-    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
-    for (int item = wave0; item < nitems; item += nwaves) {
-        const int p = (list ? (int)list[item] : pbegin + 64 * item) + lane;
-        bool more = false, truncate = false;
-        int v = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
-        if (p < pend && g.p_vid[p] >= 0) {
-            const uint32_t info = g.p_info[p];
-            const int ev = NSK_INFO_EV(info);
-            const int slot0 = g.p_slot[p];
-            v = g.p_vid[p];
-            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
-            if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
-            else evidence = (int)g.p_init[p];                                                     // 61-62
-            g.val_evid[v] = (VT)evidence;
-            proposal = draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
-            g.val[v] = (VT)proposal;
-            if (lp.learn_non_evidence || ev == 1) {                                               // 71-72
-                if (lp.regularization == 1) {                                                     // 90
-                    const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
-                    truncate = u53(t.x, t.y) < lp.inv_trunc;
-                }
-                const int step = NSK_INFO_DT1(info);
-                a = g.slot_off[slot0 + step * evidence];
-                ae = g.slot_off[slot0 + step * evidence + 1];
-                if (step && evidence != proposal) {
-                    b = g.slot_off[slot0 + proposal];
-                    be = g.slot_off[slot0 + proposal + 1];
-                }
-                more = (a < ae) || (b < be);
-            }
-        }
-        // union of the two sorted-unique lists (learning.py:76-95), one factor per iteration; the
-        // loop is wave-uniform so that accumulate_gradient can reduce across the wave
-        while (__ballot(more)) {
-            bool have = false;
-            int wid = 0;
-            long long gfix = 0;
-            if (more) {
-                const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
-                const int fb = b < be ? g.fidx[b] : 0x7fffffff;
-                const int fid = fa < fb ? fa : fb;
-                if (fa == fid) a++;
-                if (fb == fid) b++;
-                more = (a < ae) || (b < be);
-                const uint4 rec = g.f_rec[fid];
-                wid = (int)rec.z;
-                if (!g.w_fixed[wid]) {                                                            // 100-101
-                    const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
-                    const double p1 = eval_factor(g, rec, v, proposal, g.val);
-                    const double gradient = (p1 - p0) * g.f_feat[fid];                            // 109
-                    gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
-                    have = true;
-                }
-            }
-            accumulate_gradient(sk, have, wid, gfix, truncate);
-        }
-    }
-    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
-}
-
-// "satisfied" bits of one slot for the sampled variable at 0 / at 1; the generic flavour keeps
-// the running facts about the entry's other members in `st` (same algebra as slot_step).
-__device__ __forceinline__ void slot_sat(SlotState &st, uint32_t s, int x, bool &b0, bool &b1) {
-    const bool F = (s >> 27) & 1u, ig = (s >> 29) & 1u;
-    const uint32_t code = (s >> 24) & 7u;
-    const bool nz = ig || (x != 0), one = !ig && (x == 1);
-    st.alleq = F || (st.alleq && (x == st.first));
-    st.allnz = (F || st.allnz) && nz;
-    st.any1 = (!F && st.any1) || one;
-    st.first = F ? x : st.first;
-    const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
-    b0 = (isEq && st.alleq && (ig || st.first == 0)) || (isOr && st.any1);
-    b1 = (isEq && st.alleq && (ig || st.first == 1)) || (isAnd && st.allnz) || isOr;
-}
-
-template <int CODE>
-__device__ __forceinline__ void pair_sat(int x, bool &b0, bool &b1) {
-    if (CODE == 4) { b0 = x == 0; b1 = x == 1; }
-    else if (CODE == 2) { b0 = x == 1; b1 = true; }
-    else { b0 = false; b1 = x != 0; }
-}
-
-// One uniform tile of the learning sweep.  Both chains are walked together: x from var_value (free
-// chain), xe from var_value_evid; per closing slot the satisfied bits for candidates 0/1 are kept
-// in lane bitfields so that, once evidence and proposal are known, the entry's gradient over the
-// wave is (hi - lo) * (popcount(free satisfied) - popcount(evidence satisfied)): two scalar
-// popcounts, one accumulator update per entry per wave.
-template <typename VT, int KIND>
-__device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
-                                           int len, uint32_t prog, int p, bool valid,
-                                           const LearnParams &lp) {
-    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
-    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
-    const uint32_t info = valid ? g.p_info[p] : 0u;
-    const int v = valid ? g.p_vid[p] : 0;
-    const int ev = NSK_INFO_EV(info);
-    const int init = valid ? (int)g.p_init[p] : 0;
-    const bool need_evid = __ballot(valid && ev != 1) != 0;          // wave-uniform
-
-    double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
-    uint32_t B0 = 0, B1 = 0, C0 = 0, C1 = 0;                           // bit i: slot i satisfied
-    SlotState sf = {0, true, false, true}, se = {0, true, false, true};
-    uint32_t sl[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) sl[i] = pp[i];
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        if (half * 4 < len) {                                            // scalar
-            const uint4 q = sp[half * 64];
-            const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-            int x[4], xe[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) { x[i] = (int)g.val[wd[i]]; xe[i] = (int)g.val_evid[wd[i]]; }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int j = half * 4 + i;
-                const double thi = tw[2 * j], tlo = tw[2 * j + 1];
-                bool b0, b1, c0, c1;
-                if (KIND) { pair_sat<KIND>(x[i], b0, b1); pair_sat<KIND>(xe[i], c0, c1); }
-                else { slot_sat(sf, sl[j], x[i], b0, b1); slot_sat(se, sl[j], xe[i], c0, c1); }
-                p0 = p0 + (b0 ? thi : tlo);
-                p1 = p1 + (b1 ? thi : tlo);
-                if (need_evid) {
-                    q0 = q0 + (c0 ? thi : tlo);
-                    q1 = q1 + (c1 ? thi : tlo);
-                }
-                B0 |= (b0 ? 1u : 0u) << j; B1 |= (b1 ? 1u : 0u) << j;
-                C0 |= (c0 ? 1u : 0u) << j; C1 |= (c1 ? 1u : 0u) << j;
-            }
-        }
-    }
-    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
-    int evidence = init;                                                  // learning.py:61-62
-    if (need_evid && ev != 1) {                                           // 54-58
-        const double z0 = nsk_exp(q0), z1 = z0 + nsk_exp(q1);
-        const double z = u53(r.z, r.w) * z1;
-        evidence = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
-    }
-    const double z0 = nsk_exp(p0), z1 = z0 + nsk_exp(p1);                 // 66-70
-    const double z = u53(r.x, r.y) * z1;
-    const int proposal = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
-    if (valid) {
-        g.val_evid[v] = (VT)evidence;
-        g.val[v] = (VT)proposal;
-    }
-    const bool part = valid && (lp.learn_non_evidence || ev == 1);        // 71-72
-    bool truncate = false;
-    if (lp.regularization == 1) {                                         // 90
-        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
-        truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
-    }
-    const unsigned long long pm = __ballot(part);
-    if (pm == 0) return;
-    const uint32_t satf = proposal ? B1 : B0, sate = evidence ? C1 : C0;
-    const uint32_t nk = (uint32_t)__popcll(pm), nt = (uint32_t)__popcll(__ballot(truncate));
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t s = sl[j];
-        const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
-        if (j < len && closes && !fixed) {
-            const uint32_t code = (s >> 24) & 7u;
-            const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
-            const int nf = __popcll(__ballot(part && ((satf >> j) & 1u)));
-            const int ne = __popcll(__ballot(part && ((sate >> j) & 1u)));
-            if ((threadIdx.x & 63) == 0) {
-                const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
-                const int wid = (int)(s & 0xFFFFFFu);
-                atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)dG);
-                atomicAdd(&sk.K[wid], nk);
-                if (nt) atomicAdd(&sk.T[wid], nt);
-            }
-        }
-    }
-}
-
-// Learning over the uniform tiles of a colour class (tiles with per-lane headers are left to
-// k_learn_phase in list mode).  Each wave takes a contiguous run of tiles.
-template <typename VT, bool SMALLW>
-__global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pbegin, int pend,
-                                                          int wb_base, int ntiles, LearnParams lp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const GradSink sk = open_sink<SMALLW>(g, smem);
-    const int lane = (int)(threadIdx.x & 63);
-    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
-    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
-    const int per = (ntiles + nwaves - 1) / nwaves;
-    const int t1 = min(ntiles, (wave0 + 1) * per);
-    for (int t = wave0 * per; t < t1; t++) {
-        const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
-        const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
-        if (td.z == NSK_PAD_WORD || ((td.w >> 8) & 7u) == 7u) continue;   // per-lane headers: generic kernel's job
-        const int p = pbegin + t * 64 + lane;
-        const bool valid = p < pend && g.p_vid[p] >= 0;
-        const uint4 *sp = g.adj + td.x + lane;
-        const uint32_t kind = (td.w >> 8) & 7u;
-        if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
-        else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
-        else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
-        else learn_tile<VT, 3>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
-    }
-    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
-}
-
-// The weight update of learning.py:110-125 applied to a whole colour class at once
-// (DESIGN.md "device-mode learning" gives the closed forms; the oracle restates them).
-__device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
-                                               int regularization, double reg_param, double truncation) {
-    const double Gf = (double)G * (1.0 / 4294967296.0);
-    if (regularization == 2) {
-        const double a = 1.0 / (1.0 + reg_param * step);
-        x = powi_det(a, (unsigned long long)k) * x;
-        x = x - step * Gf;
-    } else if (regularization == 1) {
-        x = x - step * Gf;
-        if (t > 0) {
-            const double l1 = (reg_param * step * truncation) * (double)t;
-            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
-        }
-    } else {
-        x = x - step * Gf;
-    }
-    return x;
-}
-
-__global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
-                                                             uint32_t *T, int nweight, double step,
-                                                             int regularization, double reg_param,
-                                                             double truncation) {
-    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (i >= nweight) return;
-    const uint32_t k = K[i];
-    if (k == 0) return;
-    w[i] = apply_update(w[i], G[i], k, T[i], step, regularization, reg_param, truncation);
-    G[i] = 0; K[i] = 0; T[i] = 0;
-}
-
-// SMALLW flavour: one block per weight adds up the per-block rows, applies the update and rewrites
-// the prog_w entries of the slot programs that use this weight (so no separate refresh launch).
-__global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights_rows(double *w, const long long *part_G,
-                                                                  const uint32_t *part_K, const uint32_t *part_T,
-                                                                  int nrows, int nweight, double step,
-                                                                  int regularization, double reg_param,
-                                                                  double truncation, const uint32_t *prog,
-                                                                  double *prog_w, int nprog) {
-    __shared__ long long red[3][NSK_BLOCK / 64];
-    __shared__ double wnew;
-    const int i = (int)blockIdx.x, tid = (int)threadIdx.x;
-    long long G = 0, K = 0, T = 0;
-    for (int r = tid; r < nrows; r += NSK_BLOCK) {
-        G += part_G[(size_t)r * nweight + i];
-        K += (long long)part_K[(size_t)r * nweight + i];
-        T += (long long)part_T[(size_t)r * nweight + i];
-    }
-    G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = G; red[1][tid >> 6] = K; red[2][tid >> 6] = T; }
-    __syncthreads();
-    if (tid == 0) {
-        G = 0; K = 0; T = 0;
-        for (int k = 0; k < NSK_BLOCK / 64; k++) { G += red[0][k]; K += red[1][k]; T += red[2][k]; }
-        double x = w[i];
-        if (K > 0) {
-            x = apply_update(x, G, (uint32_t)K, (uint32_t)T, step, regularization, reg_param, truncation);
-            w[i] = x;
-        }
-        wnew = x;
-    }
-    __syncthreads();
-    const double x = wnew;
-    for (int j = tid; j < nprog; j += NSK_BLOCK) {
-        const uint32_t s = prog[j];
-        if ((s >> 31) || (int)(s & 0xFFFFFFu) != i) continue;
-        const uint32_t code = (s >> 24) & 7u;
-        const bool last = (s >> 28) & 1u;
-        const double hi = code == 0u ? 0.0 : 1.0;
-        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
-        prog_w[2 * j] = last ? x * hi : 0.0;
-        prog_w[2 * j + 1] = last ? x * lo : 0.0;
-    }
-}
-
-// int32 per-call tally deltas -> int64 master copy (the host-visible `count`)
-__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts(int32_t *delta, long long *total, int n) {
-    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (i >= n) return;
-    total[i] += (long long)delta[i];
-    delta[i] = 0;
-}
-
-template <typename T>
-__global__ __launch_bounds__(NSK_BLOCK) void k_stream_copy(const T *__restrict__ src, T *__restrict__ dst,
-                                                           long long n) {
-    const long long stride = (long long)gridDim.x * NSK_BLOCK;
-    for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
-}
-
-// ---- boundary exchange ---------------------------------------------------------------------------
-template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_exchange_pack(const VT *val, const int32_t *send_vids,
-                                                             VT *sendbuf, int n) {
-    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (i < n) sendbuf[i] = val[send_vids[i]];
-}
-
-// recv_src[j] = rank that owns recv_vids[j]; entries of this rank itself are skipped
-template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_exchange_unpack(VT *val, const int32_t *recv_vids,
-                                                               const int32_t *recv_slot, const VT *recvbuf,
-                                                               int n) {
-    const int j = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (j >= n) return;
-    const int sl = recv_slot[j];            // index into the gathered buffer, -1 = own entry
-    if (sl >= 0) val[recv_vids[j]] = recvbuf[sl];
-}
-
-// weight merge of the partitioned learning sweep: delta = w - start ... w = start + sum(delta)
-__global__ __launch_bounds__(NSK_BLOCK) void k_weight_delta(const double *w, const double *start, double *delta, int n) {
-    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (i < n) delta[i] = w[i] - start[i];
-}
-__global__ __launch_bounds__(NSK_BLOCK) void k_weight_merge(double *w, const double *start, const double *delta, int n) {
-    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (i < n) w[i] = start[i] + delta[i];
-}
-
-__global__ void k_selftest_exp(const double *x, double *y, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = nsk_exp(x[i]);
-}
-
-__global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t s0, uint32_t s1,
-                                  long long n, uint32_t *out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32x4 r = philox4x32(k0, k1, (uint32_t)i, stream, s0, s1);
-    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
-}
-
-// position-indexed tally deltas of the fast path -> int64 master copy at cstart[vid]
-__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(uint8_t *cnt_pos, const int32_t *p_cnt,
-                                                               long long *total, int npos) {
-    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (i >= npos) return;
-    const int d = cnt_pos[i];
-    if (d) {
-        total[p_cnt[i]] += (long long)d;
-        cnt_pos[i] = 0;
-    }
-}
-
-// ---- sequential validation scan: one lane walks variable ids in order with MT19937 -----------
-template <typename VT>
-__global__ void k_seq_gibbs(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rng, int nsweeps,
-                            int sample_evidence, int burnin) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (int s = 0; s < nsweeps; s++) {
-        for (int v = 0; v < g.nvar; v++) {
-            const int p = v_pos[v];
-            if (p < 0) continue;
-            const uint32_t info = g.p_info[p];
-            if (!(NSK_INFO_EV(info) == 0 || sample_evidence)) continue;
-            // the reference fills Z first and draws its uniform afterwards; draw_sample only needs
-            // u at the very end, and nothing else consumes the stream in between
-            const double u = mt_res53(np_rng);
-            const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u);
-            g.val[v] = (VT)nv;
-            if (!burnin) {
-                const int base = g.p_cnt[p];
-                if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
-                else g.cnt[base + nv] += 1;
-            }
-        }
-    }
-}
-
-template <typename VT>
-__global__ void k_seq_learn(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rng, MTState *py_rng,
-                            int nsweeps, double step, double decay, int regularization,
-                            double reg_param, double truncation, int learn_non_evidence) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (int s = 0; s < nsweeps; s++) {
-        for (int v = 0; v < g.nvar; v++) {
-            const int p = v_pos[v];
-            if (p < 0) continue;
-            const uint32_t info = g.p_info[p];
-            const int ev = NSK_INFO_EV(info);
-            const int slot0 = g.p_slot[p];
-            int evidence;
-            if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, mt_res53(np_rng));
-            else evidence = (int)g.p_init[p];
-            g.val_evid[v] = (VT)evidence;
-            const int proposal = draw_sample(g, v, info, slot0, g.val, mt_res53(np_rng));
-            g.val[v] = (VT)proposal;
-            if (!learn_non_evidence && ev != 1) continue;
-            const int st = NSK_INFO_DT1(info);
-            int a = g.slot_off[slot0 + st * evidence], ae = g.slot_off[slot0 + st * evidence + 1];
-            int b = 0, be = 0;
-            if (st && evidence != proposal) {
-                b = g.slot_off[slot0 + proposal];
-                be = g.slot_off[slot0 + proposal + 1];
-            }
-            bool truncate = false;
-            if (regularization == 1) truncate = mt_res53(py_rng) < 1.0 / truncation;
-            while (a < ae || b < be) {          // sorted, de-duplicated union == learning.py:76-98
-                const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
-                const int fb = b < be ? g.fidx[b] : 0x7fffffff;
-                const int fid = fa < fb ? fa : fb;
-                if (fa == fid) a++;
-                if (fb == fid) b++;
-                const uint4 rec = g.f_rec[fid];
-                const int wid = (int)rec.z;
-                if (g.w_fixed[wid]) continue;
-                const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
-                const double p1 = eval_factor(g, rec, v, proposal, g.val);
-                const double gradient = (p1 - p0) * g.f_feat[fid];
-                double w = g.w[wid];
-                if (regularization == 2) {
-                    w *= (1.0 / (1.0 + reg_param * step));
-                    w -= step * gradient;
-                } else if (regularization == 1) {
-                    w -= step * gradient;
-                    if (truncate) {
-                        const double l1delta = reg_param * step * truncation;
-                        w = (w > 0) ? fmax(0.0, w - l1delta) : fmin(0.0, w + l1delta);
-                    }
-                } else {
-                    w -= step * gradient;
-                }
-                g.w[wid] = w;
-            }
-        }
-        step *= decay;
-    }
-}
 
 // =============================================================================================
 // host side

@@ -1,0 +1,371 @@
+// nsk_kernels_gibbs.h -- inference sweep kernels (gibbsthread, numbskull/inference.py:10-33):
+// the generic CSR kernel, the inlined-adjacency tile kernels and the homogeneous-segment kernel.
+#pragma once
+
+#include "nsk_device.h"
+
+namespace nsk {
+
+#define NSK_BLOCK 256
+// persistent grids of the learning kernels (rows of the SMALLW partial-sum tables)
+#define NSK_LEARN_FAST_BLOCKS 2048
+#define NSK_LEARN_LIST_BLOCKS 512
+#define NSK_LEARN_GEN_BLOCKS 2048
+#define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS)
+
+// One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
+// gibbsthread's loop body (inference.py:20-33) for that variable.
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_phase(DevGraph<VT> g, int pbegin, int pend,
+                                                           int sample_evidence, int burnin,
+                                                           uint32_t k0, uint32_t k1, uint32_t s0,
+                                                           uint32_t s1) {
+    const int p = pbegin + (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (p >= pend) return;
+    const uint32_t info = g.p_info[p];
+    const int ev = NSK_INFO_EV(info);
+    if (!(ev == 0 || sample_evidence)) return;          // inference.py:24 (ev == 4 never gets a position)
+    const int v = g.p_vid[p];
+    if (v < 0) return;
+    const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));
+    g.val[v] = (VT)nv;
+    if (!burnin) {                                      // inference.py:29-33
+        const int base = g.p_cnt[p];
+        if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
+        else g.cnt[base + nv] += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path of one colour class: binary variables whose factors are symmetric boolean functions.
+// One wave owns 64 consecutive positions and walks their inlined adjacency tile; every stream word
+// is one coalesced 256-byte load for the wave, member words are followed by a 1-byte gather of the
+// neighbour's value.  Words are fetched NSK_CHUNK at a time so that the stream loads, then the
+// gathers, are all in flight together.  Same float64 operations, in the same order, as
+// k_gibbs_phase (potential(): product, then add, in factor-list order).
+// ---------------------------------------------------------------------------------------------
+#define NSK_CHUNK 8
+
+// Tile with per-lane headers: every lane parses its own word sequence.
+template <typename VT>
+__device__ __forceinline__ void tile_potentials_dynamic(const DevGraph<VT> &g, const VT *val,
+                                                        const uint4 *sp, int len, double &p0,
+                                                        double &p1) {
+    FactorAcc acc;
+    acc.rem = 0; acc.func = F_NOOP; acc.w = 0.0; acc.first = -1;
+    acc.allnz = true; acc.any1 = false; acc.alleq = true;
+    for (int j0 = 0; j0 < len; j0 += NSK_CHUNK) {
+        const uint4 qa = sp[(size_t)(j0 / 4) * 64];
+        const uint4 qb = (j0 + 4 < len) ? sp[(size_t)(j0 / 4 + 1) * 64]
+                                        : uint4{NSK_PAD_WORD, NSK_PAD_WORD, NSK_PAD_WORD, NSK_PAD_WORD};
+        const uint32_t wd[NSK_CHUNK] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        bool ismem[NSK_CHUNK];          // pure ALU on the words just loaded
+        int r = acc.rem;
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) {
+            ismem[i] = r > 0;
+            if (r > 0) r--;
+            else if (wd[i] != NSK_PAD_WORD) r = NSK_HDR_NOTHER(wd[i]);
+        }
+        int xv[NSK_CHUNK];
+        double wv[NSK_CHUNK];
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) {
+            xv[i] = ismem[i] ? (int)val[wd[i]] : 0;
+            wv[i] = (!ismem[i] && wd[i] != NSK_PAD_WORD) ? g.w[NSK_HDR_WID(wd[i])] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NSK_CHUNK; i++) {
+            bool done = false;
+            if (ismem[i]) {
+                acc.member(xv[i]);
+                done = acc.rem == 0;
+            } else if (wd[i] != NSK_PAD_WORD) {
+                acc.start(wd[i], wv[i]);
+                done = acc.rem == 0;
+            }
+            if (done) {
+                double e0, e1;
+                acc.values(e0, e1);
+                const double t0 = acc.w * e0, t1 = acc.w * e1;
+                p0 = p0 + t0;
+                p1 = p1 + t1;
+            }
+        }
+    }
+}
+
+// Uniform tile: all 64 lanes share one slot program (<= 8 member slots).  The program words and
+// the per-slot weight terms (prog_w: weight*value for a satisfied / unsatisfied entry, already
+// multiplied by k_refresh_prog_weights) arrive by scalar loads, the member ids by one or two
+// 16-byte loads per lane, the neighbour values by byte gathers.  The per-slot update is
+// straight-line boolean algebra: program flags are wave-uniform, lane facts are lane masks.
+// Padding slots (program word 0) and slots that do not close an entry add an exact 0.0.
+struct SlotState {
+    int first;
+    bool allnz, any1, alleq;
+};
+
+__device__ __forceinline__ void slot_step(SlotState &st, uint32_t s, double thi, double tlo, int x,
+                                          double &p0, double &p1) {
+    const bool F = (s >> 27) & 1u, ig = (s >> 29) & 1u;          // uniform
+    const uint32_t code = (s >> 24) & 7u;
+    const bool nz = ig || (x != 0), one = !ig && (x == 1);
+    st.alleq = F || (st.alleq && (x == st.first));
+    st.allnz = (F || st.allnz) && nz;
+    st.any1 = (!F && st.any1) || one;
+    st.first = F ? x : st.first;
+    // "satisfied" for candidate 0 / 1 (inference.py:162-200)
+    const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
+    const bool b0 = (isEq && st.alleq && (ig || st.first == 0)) || (isOr && st.any1);
+    const bool b1 = (isEq && st.alleq && (ig || st.first == 1)) || (isAnd && st.allnz) || isOr;
+    p0 = p0 + (b0 ? thi : tlo);
+    p1 = p1 + (b1 ? thi : tlo);
+}
+
+// Entries with exactly one other member and one function code for the whole tile (the shape of
+// pairwise models such as the Ising grid): no state, two compares per slot.
+template <int CODE>
+__device__ __forceinline__ void pair_step(double thi, double tlo, int x, double &p0, double &p1) {
+    bool b0, b1;
+    if (CODE == 4) { b0 = x == 0; b1 = x == 1; }            // EQUAL
+    else if (CODE == 2) { b0 = x == 1; b1 = true; }          // OR
+    else { b0 = false; b1 = x != 0; }                        // AND / ISTRUE / IMPLY_NATURAL
+    p0 = p0 + (b0 ? thi : tlo);
+    p1 = p1 + (b1 ? thi : tlo);
+}
+
+template <typename VT, int KIND>
+__device__ __forceinline__ void tile_potentials_uniform(const DevGraph<VT> &g, const VT *val,
+                                                        const uint4 *sp, int len, uint32_t prog,
+                                                        double &p0, double &p1) {
+    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
+    if (len <= 0) return;
+    SlotState st = {0, true, false, true};
+    const uint4 qa = sp[0];
+    uint32_t sl[4];
+    double th[4], tl[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sl[i] = KIND ? 0u : pp[i]; th[i] = tw[2 * i]; tl[i] = tw[2 * i + 1]; }
+    const int x0 = (int)val[qa.x], x1 = (int)val[qa.y], x2 = (int)val[qa.z], x3 = (int)val[qa.w];
+    if (KIND) {
+        pair_step<KIND>(th[0], tl[0], x0, p0, p1);
+        pair_step<KIND>(th[1], tl[1], x1, p0, p1);
+        pair_step<KIND>(th[2], tl[2], x2, p0, p1);
+        pair_step<KIND>(th[3], tl[3], x3, p0, p1);
+    } else {
+        slot_step(st, sl[0], th[0], tl[0], x0, p0, p1);
+        slot_step(st, sl[1], th[1], tl[1], x1, p0, p1);
+        slot_step(st, sl[2], th[2], tl[2], x2, p0, p1);
+        slot_step(st, sl[3], th[3], tl[3], x3, p0, p1);
+    }
+    if (len > 4) {
+        const uint4 qb = sp[64];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { sl[i] = KIND ? 0u : pp[4 + i]; th[i] = tw[8 + 2 * i]; tl[i] = tw[9 + 2 * i]; }
+        const int x4 = (int)val[qb.x], x5 = (int)val[qb.y], x6 = (int)val[qb.z], x7 = (int)val[qb.w];
+        if (KIND) {
+            pair_step<KIND>(th[0], tl[0], x4, p0, p1);
+            pair_step<KIND>(th[1], tl[1], x5, p0, p1);
+            pair_step<KIND>(th[2], tl[2], x6, p0, p1);
+            pair_step<KIND>(th[3], tl[3], x7, p0, p1);
+        } else {
+            slot_step(st, sl[0], th[0], tl[0], x4, p0, p1);
+            slot_step(st, sl[1], th[1], tl[1], x5, p0, p1);
+            slot_step(st, sl[2], th[2], tl[2], x6, p0, p1);
+            slot_step(st, sl[3], th[3], tl[3], x7, p0, p1);
+        }
+    }
+}
+
+// prog_w[2i], prog_w[2i+1] = weight * (value when satisfied, value when not) of program word i, or
+// (0, 0) when the slot does not close an entry.  The products are the reference's own
+// `weight * eval_factor` (inference.py:68-70), so adding them reproduces potential() exactly.
+__global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32_t *prog, const double *w,
+                                                                    double *prog_w, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i >= n) return;
+    const uint32_t s = prog[i];
+    if (s >> 31) return;                                   // role word of a shape tile, not a slot
+    const uint32_t code = (s >> 24) & 7u;
+    const bool last = (s >> 28) & 1u;
+    const double hi = code == 0u ? 0.0 : 1.0;
+    const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+    const double wt = w[s & 0xFFFFFFu];
+    prog_w[2 * i] = last ? wt * hi : 0.0;
+    prog_w[2 * i + 1] = last ? wt * lo : 0.0;
+}
+
+// Shape tile: every lane has its own factor functions and weights (per-lane header words in the
+// stream) but all 64 lanes share the word layout -- which words are headers, which are members,
+// where entries start and end -- so the walk is driven by a scalar role program and only the
+// per-lane facts (function code, weight, member values) are vector work.  This is the shape of
+// graphs whose factors carry individual weights.
+template <typename VT>
+__device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, const VT *val,
+                                                      const uint4 *sp, int len, uint32_t prog,
+                                                      double &p0, double &p1) {
+    const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    uint32_t code = 0;                   // per lane: 0 NOOP 1 IMPLY_NATURAL 2 OR 3 AND/ISTRUE 4 EQUAL
+    double w = 0.0;
+    int first = 0;
+    bool allnz = true, any1 = false, alleq = true;
+    auto finish = [&](bool nomember) {
+        const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
+        const bool b0 = (isEq && alleq && (nomember || first == 0)) || (isOr && any1);
+        const bool b1 = (isEq && alleq && (nomember || first == 1)) || (isAnd && allnz) || isOr;
+        const double hi = code == 0u ? 0.0 : 1.0;
+        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+        const double t0 = w * (b0 ? hi : lo), t1 = w * (b1 ? hi : lo);
+        p0 = p0 + t0;
+        p1 = p1 + t1;
+    };
+    for (int c = 0; c * 4 < len; c++) {                                  // <= 4 chunks, scalar loop
+        const uint4 q = sp[(size_t)c * 64];
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+        uint32_t role[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0xFu;      // scalar; 0 = padding word
+        double wv[4];
+        int xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                                    // one gather per word
+            wv[i] = 0.0; xv[i] = 0;
+            if (role[i] & 1u) wv[i] = g.w[wd[i] & 0xFFFFFFu];
+            else if (role[i]) xv[i] = (int)val[wd[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (role[i] & 1u) {                                          // header: open an entry
+                code = (0x343210u >> (4u * (wd[i] >> 27))) & 0xFu;       // function+1 in 0..5 -> code
+                w = wv[i];
+                first = 0; allnz = true; any1 = false; alleq = true;
+                if (role[i] & 8u) finish(true);
+            } else if (role[i]) {                                        // member
+                const int x = xv[i];
+                const bool F = (role[i] & 2u) != 0;
+                alleq = F || (alleq && (x == first));
+                allnz = (F || allnz) && (x != 0);
+                any1 = (!F && any1) || (x == 1);
+                first = F ? x : first;
+                if (role[i] & 4u) finish(false);
+            }
+        }
+    }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pbegin, int pend,
+                                                          int wb_base, int nblocks,
+                                                          const uint32_t *tile_list, int nlist,
+                                                          int sample_evidence, int burnin,
+                                                          uint32_t k0, uint32_t k1, uint32_t s0,
+                                                          uint32_t s1) {
+    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
+    if (lb < 0) return;
+    const int lane = (int)(threadIdx.x & 63);
+    int wave = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (tile_list) {                                      // list mode: the tiles outside segments
+        if (wave >= nlist) return;
+        wave = (int)__builtin_amdgcn_readfirstlane(tile_list[wave]);
+    }
+    const int p = pbegin + wave * 64 + lane;
+    if (pbegin + wave * 64 >= pend) return;               // whole wave beyond the range
+    const int v0 = p < pend ? g.p_vid[p] : -1;            // -1 also marks padding positions
+    const bool valid = v0 >= 0;
+    const int v = valid ? v0 : 0;
+    const uint32_t info = valid ? g.p_info[p] : 0u;
+    const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + wave));
+    const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
+    const uint4 *sp = g.adj + td.x + lane;
+    const int len = (int)td.y;
+    // the tally byte is fetched now so that its latency overlaps the tile walk
+    const uint8_t tally = (valid && !burnin) ? g.cnt_pos[p] : (uint8_t)0;
+
+    double p0 = 0.0, p1 = 0.0;
+    if (td.z == NSK_PAD_WORD) tile_potentials_dynamic(g, g.val, sp, len, p0, p1);
+    else {
+        const uint32_t kind = (td.w >> 8) & 7u;              // wave-uniform
+        if (kind == 7u) tile_potentials_shape(g, g.val, sp, (int)(td.w & 0xFFu), td.z, p0, p1);
+        else if (kind == 4u) tile_potentials_uniform<VT, 4>(g, g.val, sp, len, td.z, p0, p1);
+        else if (kind == 0u) tile_potentials_uniform<VT, 0>(g, g.val, sp, len, td.z, p0, p1);
+        else if (kind == 2u) tile_potentials_uniform<VT, 2>(g, g.val, sp, len, td.z, p0, p1);
+        else tile_potentials_uniform<VT, 3>(g, g.val, sp, len, td.z, p0, p1);
+    }
+    if (!valid) return;
+    const int ev = NSK_INFO_EV(info);
+    if (!(ev == 0 || sample_evidence)) return;
+    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const double z0 = nsk_exp(p0);
+    const double z1 = z0 + nsk_exp(p1);
+    const double z = u53(rr.x, rr.y) * z1;
+    const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    g.val[v] = (VT)nv;
+    if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
+}
+
+// Homogeneous segments: runs of consecutive uniform tiles with one program, slot count, kind and
+// evidence flag (the shape-class layout of nsk_compile.cpp makes whole classes such runs).  Up to
+// NSK_SEG_MAX segments of one (kind, chunk count) share a launch; everything the descriptor-driven
+// kernel fetches per tile comes from the kernel-argument table here, and the body is straight
+// line: ids, 16-byte member loads, byte gathers, compares, draw, store.
+#define NSK_SEG_MAX 8
+struct SegTable {
+    int n;
+    int tile_start[NSK_SEG_MAX + 1];      // first tile of each segment in this launch's numbering
+    int pos0[NSK_SEG_MAX];                // position of the segment's first lane
+    uint32_t adj_off[NSK_SEG_MAX];        // stream offset (16-byte units) of its first tile
+    uint32_t prog[NSK_SEG_MAX];           // slot program
+};
+
+template <typename VT, int KIND, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTable tab, int nblocks,
+                                                         int burnin, uint32_t k0, uint32_t k1,
+                                                         uint32_t s0, uint32_t s1) {
+    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
+    if (lb < 0) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int T = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (T >= tab.tile_start[tab.n]) return;
+    int sidx = 0;
+#pragma unroll
+    for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+    const int t = T - tab.tile_start[sidx];
+    const uint32_t prog = tab.prog[sidx];
+    const int p = tab.pos0[sidx] + t * 64 + lane;
+    const int v = g.p_vid[p];                             // -1: padding lane at a class end
+    const uint8_t tally = burnin ? (uint8_t)0 : g.cnt_pos[p];
+    const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
+    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    uint4 q[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];
+    int x[4 * NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        x[4 * c] = (int)g.val[q[c].x]; x[4 * c + 1] = (int)g.val[q[c].y];
+        x[4 * c + 2] = (int)g.val[q[c].z]; x[4 * c + 3] = (int)g.val[q[c].w];
+    }
+    double p0 = 0.0, p1 = 0.0;
+    SlotState st = {0, true, false, true};
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) {
+        const double thi = tw[2 * j], tlo = tw[2 * j + 1];
+        if (KIND) pair_step<KIND>(thi, tlo, x[j], p0, p1);
+        else slot_step(st, pp[j], thi, tlo, x[j], p0, p1);
+    }
+    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const double z0 = nsk_exp(p0);
+    const double z1 = z0 + nsk_exp(p1);
+    const double z = u53(rr.x, rr.y) * z1;
+    const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    if (v >= 0) {
+        g.val[v] = (VT)nv;
+        if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
+    }
+}
+
+}  // namespace nsk

@@ -1,0 +1,342 @@
+// nsk_kernels_learn.h -- learning sweep kernels (learnthread / sample_and_sgd,
+// numbskull/learning.py:12-125) and the per-class weight update.
+#pragma once
+
+#include "nsk_device.h"
+#include "nsk_kernels_gibbs.h"
+
+namespace nsk {
+
+// ---------------------------------------------------------------------------------------------
+// Learning.  One colour class of one learning sweep = sample_and_sgd (learning.py:46-125) for every
+// variable of the class with the weights frozen; gradients go to per-weight fixed-point sums and
+// the weight update for the whole class is applied afterwards (DESIGN.md "device-mode learning").
+// ---------------------------------------------------------------------------------------------
+struct LearnParams {
+    int regularization, learn_non_evidence;
+    double inv_trunc;
+    uint32_t k0, k1, s0, s1;
+    int row_base;               // first row of this launch in the partial-sum tables (SMALLW)
+};
+
+// per-block accumulation tables in LDS (SMALLW) or the global accumulators
+template <bool SMALLW, typename VT>
+__device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem) {
+    GradSink sk;
+    if (SMALLW) {
+        const int nw = g.nweight;
+        sk.G = (long long *)smem;
+        sk.K = (uint32_t *)(smem + 8 * (size_t)nw);
+        sk.T = sk.K + nw;
+        for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) { sk.G[i] = 0; sk.K[i] = 0; sk.T[i] = 0; }
+        __syncthreads();
+    } else {
+        sk.G = g.G; sk.K = g.K; sk.T = g.T;
+    }
+    return sk;
+}
+
+template <bool SMALLW, typename VT>
+__device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink &sk, int row) {
+    if (!SMALLW) return;
+    __syncthreads();
+    const int nw = g.nweight;
+    for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) {
+        g.part_G[(size_t)row * nw + i] = sk.G[i];
+        g.part_K[(size_t)row * nw + i] = sk.K[i];
+        g.part_T[(size_t)row * nw + i] = sk.T[i];
+    }
+}
+
+// Generic learning kernel.  Work items are 64-position groups: item i covers positions
+// pbegin + 64 i (range mode) or list[i] (list mode: the per-lane-header tiles of the fast range),
+// clipped at pend.  A persistent grid strides over the items so that SMALLW blocks flush once.
+template <typename VT, bool SMALLW>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_phase(DevGraph<VT> g, int pbegin, int pend,
+                                                           const uint32_t *list, int nitems,
+                                                           LearnParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
+    for (int item = wave0; item < nitems; item += nwaves) {
+        const int p = (list ? (int)list[item] : pbegin + 64 * item) + lane;
+        bool more = false, truncate = false;
+        int v = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
+        if (p < pend && g.p_vid[p] >= 0) {
+            const uint32_t info = g.p_info[p];
+            const int ev = NSK_INFO_EV(info);
+            const int slot0 = g.p_slot[p];
+            v = g.p_vid[p];
+            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+            if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
+            else evidence = (int)g.p_init[p];                                                     // 61-62
+            g.val_evid[v] = (VT)evidence;
+            proposal = draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
+            g.val[v] = (VT)proposal;
+            if (lp.learn_non_evidence || ev == 1) {                                               // 71-72
+                if (lp.regularization == 1) {                                                     // 90
+                    const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+                    truncate = u53(t.x, t.y) < lp.inv_trunc;
+                }
+                const int step = NSK_INFO_DT1(info);
+                a = g.slot_off[slot0 + step * evidence];
+                ae = g.slot_off[slot0 + step * evidence + 1];
+                if (step && evidence != proposal) {
+                    b = g.slot_off[slot0 + proposal];
+                    be = g.slot_off[slot0 + proposal + 1];
+                }
+                more = (a < ae) || (b < be);
+            }
+        }
+        // union of the two sorted-unique lists (learning.py:76-95), one factor per iteration; the
+        // loop is wave-uniform so that accumulate_gradient can reduce across the wave
+        while (__ballot(more)) {
+            bool have = false;
+            int wid = 0;
+            long long gfix = 0;
+            if (more) {
+                const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
+                const int fb = b < be ? g.fidx[b] : 0x7fffffff;
+                const int fid = fa < fb ? fa : fb;
+                if (fa == fid) a++;
+                if (fb == fid) b++;
+                more = (a < ae) || (b < be);
+                const uint4 rec = g.f_rec[fid];
+                wid = (int)rec.z;
+                if (!g.w_fixed[wid]) {                                                            // 100-101
+                    const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
+                    const double p1 = eval_factor(g, rec, v, proposal, g.val);
+                    const double gradient = (p1 - p0) * g.f_feat[fid];                            // 109
+                    gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
+                    have = true;
+                }
+            }
+            accumulate_gradient(sk, have, wid, gfix, truncate);
+        }
+    }
+    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+}
+
+// "satisfied" bits of one slot for the sampled variable at 0 / at 1; the generic flavour keeps
+// the running facts about the entry's other members in `st` (same algebra as slot_step).
+__device__ __forceinline__ void slot_sat(SlotState &st, uint32_t s, int x, bool &b0, bool &b1) {
+    const bool F = (s >> 27) & 1u, ig = (s >> 29) & 1u;
+    const uint32_t code = (s >> 24) & 7u;
+    const bool nz = ig || (x != 0), one = !ig && (x == 1);
+    st.alleq = F || (st.alleq && (x == st.first));
+    st.allnz = (F || st.allnz) && nz;
+    st.any1 = (!F && st.any1) || one;
+    st.first = F ? x : st.first;
+    const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
+    b0 = (isEq && st.alleq && (ig || st.first == 0)) || (isOr && st.any1);
+    b1 = (isEq && st.alleq && (ig || st.first == 1)) || (isAnd && st.allnz) || isOr;
+}
+
+template <int CODE>
+__device__ __forceinline__ void pair_sat(int x, bool &b0, bool &b1) {
+    if (CODE == 4) { b0 = x == 0; b1 = x == 1; }
+    else if (CODE == 2) { b0 = x == 1; b1 = true; }
+    else { b0 = false; b1 = x != 0; }
+}
+
+// One uniform tile of the learning sweep.  Both chains are walked together: x from var_value (free
+// chain), xe from var_value_evid; per closing slot the satisfied bits for candidates 0/1 are kept
+// in lane bitfields so that, once evidence and proposal are known, the entry's gradient over the
+// wave is (hi - lo) * (popcount(free satisfied) - popcount(evidence satisfied)): two scalar
+// popcounts, one accumulator update per entry per wave.
+template <typename VT, int KIND>
+__device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
+                                           int len, uint32_t prog, int p, bool valid,
+                                           const LearnParams &lp) {
+    const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
+    const uint32_t info = valid ? g.p_info[p] : 0u;
+    const int v = valid ? g.p_vid[p] : 0;
+    const int ev = NSK_INFO_EV(info);
+    const int init = valid ? (int)g.p_init[p] : 0;
+    const bool need_evid = __ballot(valid && ev != 1) != 0;          // wave-uniform
+
+    double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+    uint32_t B0 = 0, B1 = 0, C0 = 0, C1 = 0;                           // bit i: slot i satisfied
+    SlotState sf = {0, true, false, true}, se = {0, true, false, true};
+    uint32_t sl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) sl[i] = pp[i];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (half * 4 < len) {                                            // scalar
+            const uint4 q = sp[half * 64];
+            const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+            int x[4], xe[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { x[i] = (int)g.val[wd[i]]; xe[i] = (int)g.val_evid[wd[i]]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = half * 4 + i;
+                const double thi = tw[2 * j], tlo = tw[2 * j + 1];
+                bool b0, b1, c0, c1;
+                if (KIND) { pair_sat<KIND>(x[i], b0, b1); pair_sat<KIND>(xe[i], c0, c1); }
+                else { slot_sat(sf, sl[j], x[i], b0, b1); slot_sat(se, sl[j], xe[i], c0, c1); }
+                p0 = p0 + (b0 ? thi : tlo);
+                p1 = p1 + (b1 ? thi : tlo);
+                if (need_evid) {
+                    q0 = q0 + (c0 ? thi : tlo);
+                    q1 = q1 + (c1 ? thi : tlo);
+                }
+                B0 |= (b0 ? 1u : 0u) << j; B1 |= (b1 ? 1u : 0u) << j;
+                C0 |= (c0 ? 1u : 0u) << j; C1 |= (c1 ? 1u : 0u) << j;
+            }
+        }
+    }
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    int evidence = init;                                                  // learning.py:61-62
+    if (need_evid && ev != 1) {                                           // 54-58
+        const double z0 = nsk_exp(q0), z1 = z0 + nsk_exp(q1);
+        const double z = u53(r.z, r.w) * z1;
+        evidence = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    }
+    const double z0 = nsk_exp(p0), z1 = z0 + nsk_exp(p1);                 // 66-70
+    const double z = u53(r.x, r.y) * z1;
+    const int proposal = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    if (valid) {
+        g.val_evid[v] = (VT)evidence;
+        g.val[v] = (VT)proposal;
+    }
+    const bool part = valid && (lp.learn_non_evidence || ev == 1);        // 71-72
+    bool truncate = false;
+    if (lp.regularization == 1) {                                         // 90
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
+    }
+    const unsigned long long pm = __ballot(part);
+    if (pm == 0) return;
+    const uint32_t satf = proposal ? B1 : B0, sate = evidence ? C1 : C0;
+    const uint32_t nk = (uint32_t)__popcll(pm), nt = (uint32_t)__popcll(__ballot(truncate));
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t s = sl[j];
+        const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
+        if (j < len && closes && !fixed) {
+            const uint32_t code = (s >> 24) & 7u;
+            const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
+            const int nf = __popcll(__ballot(part && ((satf >> j) & 1u)));
+            const int ne = __popcll(__ballot(part && ((sate >> j) & 1u)));
+            if ((threadIdx.x & 63) == 0) {
+                const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
+                const int wid = (int)(s & 0xFFFFFFu);
+                atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)dG);
+                atomicAdd(&sk.K[wid], nk);
+                if (nt) atomicAdd(&sk.T[wid], nt);
+            }
+        }
+    }
+}
+
+// Learning over the uniform tiles of a colour class (tiles with per-lane headers are left to
+// k_learn_phase in list mode).  Each wave takes a contiguous run of tiles.
+template <typename VT, bool SMALLW>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pbegin, int pend,
+                                                          int wb_base, int ntiles, LearnParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
+    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
+    const int per = (ntiles + nwaves - 1) / nwaves;
+    const int t1 = min(ntiles, (wave0 + 1) * per);
+    for (int t = wave0 * per; t < t1; t++) {
+        const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
+        const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
+        if (td.z == NSK_PAD_WORD || ((td.w >> 8) & 7u) == 7u) continue;   // per-lane headers: generic kernel's job
+        const int p = pbegin + t * 64 + lane;
+        const bool valid = p < pend && g.p_vid[p] >= 0;
+        const uint4 *sp = g.adj + td.x + lane;
+        const uint32_t kind = (td.w >> 8) & 7u;
+        if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+        else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+        else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+        else learn_tile<VT, 3>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+    }
+    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+}
+
+// The weight update of learning.py:110-125 applied to a whole colour class at once
+// (DESIGN.md "device-mode learning" gives the closed forms; the oracle restates them).
+__device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
+                                               int regularization, double reg_param, double truncation) {
+    const double Gf = (double)G * (1.0 / 4294967296.0);
+    if (regularization == 2) {
+        const double a = 1.0 / (1.0 + reg_param * step);
+        x = powi_det(a, (unsigned long long)k) * x;
+        x = x - step * Gf;
+    } else if (regularization == 1) {
+        x = x - step * Gf;
+        if (t > 0) {
+            const double l1 = (reg_param * step * truncation) * (double)t;
+            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
+        }
+    } else {
+        x = x - step * Gf;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
+                                                             uint32_t *T, int nweight, double step,
+                                                             int regularization, double reg_param,
+                                                             double truncation) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i >= nweight) return;
+    const uint32_t k = K[i];
+    if (k == 0) return;
+    w[i] = apply_update(w[i], G[i], k, T[i], step, regularization, reg_param, truncation);
+    G[i] = 0; K[i] = 0; T[i] = 0;
+}
+
+// SMALLW flavour: one block per weight adds up the per-block rows, applies the update and rewrites
+// the prog_w entries of the slot programs that use this weight (so no separate refresh launch).
+__global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights_rows(double *w, const long long *part_G,
+                                                                  const uint32_t *part_K, const uint32_t *part_T,
+                                                                  int nrows, int nweight, double step,
+                                                                  int regularization, double reg_param,
+                                                                  double truncation, const uint32_t *prog,
+                                                                  double *prog_w, int nprog) {
+    __shared__ long long red[3][NSK_BLOCK / 64];
+    __shared__ double wnew;
+    const int i = (int)blockIdx.x, tid = (int)threadIdx.x;
+    long long G = 0, K = 0, T = 0;
+    for (int r = tid; r < nrows; r += NSK_BLOCK) {
+        G += part_G[(size_t)r * nweight + i];
+        K += (long long)part_K[(size_t)r * nweight + i];
+        T += (long long)part_T[(size_t)r * nweight + i];
+    }
+    G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = G; red[1][tid >> 6] = K; red[2][tid >> 6] = T; }
+    __syncthreads();
+    if (tid == 0) {
+        G = 0; K = 0; T = 0;
+        for (int k = 0; k < NSK_BLOCK / 64; k++) { G += red[0][k]; K += red[1][k]; T += red[2][k]; }
+        double x = w[i];
+        if (K > 0) {
+            x = apply_update(x, G, (uint32_t)K, (uint32_t)T, step, regularization, reg_param, truncation);
+            w[i] = x;
+        }
+        wnew = x;
+    }
+    __syncthreads();
+    const double x = wnew;
+    for (int j = tid; j < nprog; j += NSK_BLOCK) {
+        const uint32_t s = prog[j];
+        if ((s >> 31) || (int)(s & 0xFFFFFFu) != i) continue;
+        const uint32_t code = (s >> 24) & 7u;
+        const bool last = (s >> 28) & 1u;
+        const double hi = code == 0u ? 0.0 : 1.0;
+        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+        prog_w[2 * j] = last ? x * hi : 0.0;
+        prog_w[2 * j + 1] = last ? x * lo : 0.0;
+    }
+}
+
+}  // namespace nsk

@@ -1,0 +1,164 @@
+// nsk_kernels_misc.h -- tally folding, boundary exchange, sequential validation scan and self-test
+// kernels.
+#pragma once
+
+#include "nsk_device.h"
+#include "nsk_kernels_gibbs.h"
+
+namespace nsk {
+
+// int32 per-call tally deltas -> int64 master copy (the host-visible `count`)
+__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts(int32_t *delta, long long *total, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i >= n) return;
+    total[i] += (long long)delta[i];
+    delta[i] = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NSK_BLOCK) void k_stream_copy(const T *__restrict__ src, T *__restrict__ dst,
+                                                           long long n) {
+    const long long stride = (long long)gridDim.x * NSK_BLOCK;
+    for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+// ---- boundary exchange ---------------------------------------------------------------------------
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_exchange_pack(const VT *val, const int32_t *send_vids,
+                                                             VT *sendbuf, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i < n) sendbuf[i] = val[send_vids[i]];
+}
+
+// recv_src[j] = rank that owns recv_vids[j]; entries of this rank itself are skipped
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_exchange_unpack(VT *val, const int32_t *recv_vids,
+                                                               const int32_t *recv_slot, const VT *recvbuf,
+                                                               int n) {
+    const int j = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (j >= n) return;
+    const int sl = recv_slot[j];            // index into the gathered buffer, -1 = own entry
+    if (sl >= 0) val[recv_vids[j]] = recvbuf[sl];
+}
+
+// weight merge of the partitioned learning sweep: delta = w - start ... w = start + sum(delta)
+__global__ __launch_bounds__(NSK_BLOCK) void k_weight_delta(const double *w, const double *start, double *delta, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i < n) delta[i] = w[i] - start[i];
+}
+__global__ __launch_bounds__(NSK_BLOCK) void k_weight_merge(double *w, const double *start, const double *delta, int n) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i < n) w[i] = start[i] + delta[i];
+}
+
+__global__ void k_selftest_exp(const double *x, double *y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = nsk_exp(x[i]);
+}
+
+__global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t s0, uint32_t s1,
+                                  long long n, uint32_t *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32x4 r = philox4x32(k0, k1, (uint32_t)i, stream, s0, s1);
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+// position-indexed tally deltas of the fast path -> int64 master copy at cstart[vid]
+__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(uint8_t *cnt_pos, const int32_t *p_cnt,
+                                                               long long *total, int npos) {
+    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (i >= npos) return;
+    const int d = cnt_pos[i];
+    if (d) {
+        total[p_cnt[i]] += (long long)d;
+        cnt_pos[i] = 0;
+    }
+}
+
+// ---- sequential validation scan: one lane walks variable ids in order with MT19937 -----------
+template <typename VT>
+__global__ void k_seq_gibbs(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rng, int nsweeps,
+                            int sample_evidence, int burnin) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int s = 0; s < nsweeps; s++) {
+        for (int v = 0; v < g.nvar; v++) {
+            const int p = v_pos[v];
+            if (p < 0) continue;
+            const uint32_t info = g.p_info[p];
+            if (!(NSK_INFO_EV(info) == 0 || sample_evidence)) continue;
+            // the reference fills Z first and draws its uniform afterwards; draw_sample only needs
+            // u at the very end, and nothing else consumes the stream in between
+            const double u = mt_res53(np_rng);
+            const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u);
+            g.val[v] = (VT)nv;
+            if (!burnin) {
+                const int base = g.p_cnt[p];
+                if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
+                else g.cnt[base + nv] += 1;
+            }
+        }
+    }
+}
+
+template <typename VT>
+__global__ void k_seq_learn(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rng, MTState *py_rng,
+                            int nsweeps, double step, double decay, int regularization,
+                            double reg_param, double truncation, int learn_non_evidence) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int s = 0; s < nsweeps; s++) {
+        for (int v = 0; v < g.nvar; v++) {
+            const int p = v_pos[v];
+            if (p < 0) continue;
+            const uint32_t info = g.p_info[p];
+            const int ev = NSK_INFO_EV(info);
+            const int slot0 = g.p_slot[p];
+            int evidence;
+            if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, mt_res53(np_rng));
+            else evidence = (int)g.p_init[p];
+            g.val_evid[v] = (VT)evidence;
+            const int proposal = draw_sample(g, v, info, slot0, g.val, mt_res53(np_rng));
+            g.val[v] = (VT)proposal;
+            if (!learn_non_evidence && ev != 1) continue;
+            const int st = NSK_INFO_DT1(info);
+            int a = g.slot_off[slot0 + st * evidence], ae = g.slot_off[slot0 + st * evidence + 1];
+            int b = 0, be = 0;
+            if (st && evidence != proposal) {
+                b = g.slot_off[slot0 + proposal];
+                be = g.slot_off[slot0 + proposal + 1];
+            }
+            bool truncate = false;
+            if (regularization == 1) truncate = mt_res53(py_rng) < 1.0 / truncation;
+            while (a < ae || b < be) {          // sorted, de-duplicated union == learning.py:76-98
+                const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
+                const int fb = b < be ? g.fidx[b] : 0x7fffffff;
+                const int fid = fa < fb ? fa : fb;
+                if (fa == fid) a++;
+                if (fb == fid) b++;
+                const uint4 rec = g.f_rec[fid];
+                const int wid = (int)rec.z;
+                if (g.w_fixed[wid]) continue;
+                const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
+                const double p1 = eval_factor(g, rec, v, proposal, g.val);
+                const double gradient = (p1 - p0) * g.f_feat[fid];
+                double w = g.w[wid];
+                if (regularization == 2) {
+                    w *= (1.0 / (1.0 + reg_param * step));
+                    w -= step * gradient;
+                } else if (regularization == 1) {
+                    w -= step * gradient;
+                    if (truncate) {
+                        const double l1delta = reg_param * step * truncation;
+                        w = (w > 0) ? fmax(0.0, w - l1delta) : fmin(0.0, w + l1delta);
+                    }
+                } else {
+                    w -= step * gradient;
+                }
+                g.w[wid] = w;
+            }
+        }
+        step *= decay;
+    }
+}
+
+}  // namespace nsk
