@@ -40,6 +40,10 @@ WORKLOADS = {
     # 4M boolean variables, ISTRUE / OR / EQUAL factors of arity 1..3 with one weight per factor
     # (the shape of feature-weighted DeepDive graphs): exercises the per-lane-weight shape tiles
     "boolw4m": (2000, 2000, False),
+    # scaled-down BASELINE configs[4]: mixed-arity LR graph (25 % categorical variables, ISTRUE / OR /
+    # IMPLY_MLN / OR_CAT / IMPLY_MLN_CAT / AND_CAT factors, 10^5 weights), inference and learning
+    "lr5m": (2500, 2000, False),
+    "lr5m_learn": (2500, 2000, True),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -48,6 +52,8 @@ def build_graph(rows, cols, learning, seed=20240602, name=None):
     from numbskull_amd import graphgen
     if name == "boolw4m":
         return graphgen.boolean_weighted_graph(rows * cols, seed=seed)
+    if name in ("lr5m", "lr5m_learn"):
+        return graphgen.mixed_lr_graph(rows * cols, seed=20240603)
     if not learning:
         return graphgen.ising_grid(rows, cols, weight=0.1, fixed=True)
     # learning variant: two free weights, every variable evidence;
@@ -149,7 +155,8 @@ def main():
     rows, cols, learning = WORKLOADS[args.workload]
     g = build_graph(rows, cols, learning, name=args.workload)
     nvar = rows * cols
-    ns = numbskull_amd.NumbSkull(quiet=True, device=local_rank, seed=args.seed)
+    ns = numbskull_amd.NumbSkull(quiet=True, device=local_rank, seed=args.seed,
+                                 head_by_vid=args.workload.startswith("lr"))
     own = shard_range(rank, world, nvar)
     w, v, f, fm, dm, edges = g
     import io
@@ -161,6 +168,8 @@ def main():
     info = fg.info()
     sampler = PartitionedSampler(fg, dist, torch, rank, world) if world > 1 else None
     lr = (1e-7, 0.95, 2, 0.01, 1)       # step, decay, L2, reg_param, truncation (config #3)
+    if args.workload.startswith("lr"):
+        lr = (1e-3, 0.95, 2, 0.01, 1)
 
     def run(n):
         if learning:
@@ -221,6 +230,9 @@ def main():
             "config": {"workload": ("%d boolean variables, %d ISTRUE/OR/EQUAL factors with one weight each, "
                                     "inference only, chromatic scan, seed %d" % (nvar, len(f), args.seed))
                        if args.workload == "boolw4m" else
+                       ("mixed-arity LR graph: %d variables (25%% categorical), %d factors, %d weights, %s"
+                        % (nvar, len(f), len(w), "learning" if learning else "inference"))
+                       if args.workload.startswith("lr") else
                        "%dx%d Ising grid (%d binary variables, %d EQUAL factors), %s, "
                        "chromatic scan, seed %d"
                        % (rows, cols, nvar, len(f), "learning (2 free weights, L2)"

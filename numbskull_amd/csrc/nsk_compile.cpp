@@ -383,6 +383,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             if (e.first++ == 0) e.second = v;
         }
         std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0);
+        std::vector<std::vector<int64_t>> gen_bin_start;
         std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors);
         int64_t pos = 0;
         for (int32_t k = 0; k < ncolors; k++) {
@@ -413,11 +414,40 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         if (c.npos >= LIM - 1) { err = "too many positions"; return NSK_E_RANGE; }
         c.p_vid.assign(c.npos, -1); c.p_info.assign(c.npos, 0); c.p_slot.assign(c.npos, 0);
         c.p_cnt.assign(c.npos, 0); c.p_init.assign(c.npos, 0);
+        // generic-path variables of a colour are ordered by the work of one update (factor-list
+        // lengths x arities over all candidate values, binned) so that the 64 lanes of a wave finish
+        // together; inside a bin: variable id.
+        std::vector<uint8_t> work_bin(nvar, 0);
+        for (int64_t v = 0; v < nvar; v++) {
+            if (c.color[v] < 0 || fast[v]) continue;
+            const nsk_variable &var = d->variable[v];
+            const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+            int64_t work = 0;
+            for (int64_t kk = 0; kk < nslots; kk++) {
+                const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
+                for (int64_t j = 0; j < vt.factor_index_length; j++)
+                    work += 2 + std::max<int64_t>(d->factor[d->factor_index[vt.factor_index_offset + j]].arity, 0);
+            }
+            if (var.dataType == 0) work *= var.cardinality;
+            int bin = 0;
+            while (work > 8 && bin < 40) { work = work * 3 / 4; bin++; }     // ~log_{4/3} bins
+            work_bin[v] = (uint8_t)(40 - bin);                               // heavy variables first
+        }
+        {
+            std::vector<std::vector<int64_t>> bin_count((size_t)ncolors, std::vector<int64_t>(42, 0));
+            for (int64_t v = 0; v < nvar; v++)
+                if (c.color[v] >= 0 && !fast[v]) bin_count[c.color[v]][work_bin[v] + 1]++;
+            gen_bin_start.assign((size_t)ncolors, std::vector<int64_t>(42, 0));
+            for (int32_t k = 0; k < ncolors; k++) {
+                gen_bin_start[k][0] = next_gen[k];
+                for (int b = 0; b < 41; b++) gen_bin_start[k][b + 1] = gen_bin_start[k][b] + bin_count[k][b + 1];
+            }
+        }
         for (int64_t v = 0; v < nvar; v++) {
             const int32_t k = c.color[v];
             if (k < 0) continue;
             int64_t p;
-            if (!fast[v]) p = next_gen[k]++;
+            if (!fast[v]) p = gen_bin_start[k][work_bin[v]]++;
             else {
                 auto it = start[k].find(sig[v]);
                 if (it != start[k].end()) p = it->second++;

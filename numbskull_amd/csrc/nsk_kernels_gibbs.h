@@ -7,6 +7,14 @@
 namespace nsk {
 
 #define NSK_BLOCK 256
+// min waves per SIMD requested for the generic CSR kernels (measured on the 5M mixed LR graph:
+// 8 waves + 160 B of scratch beats 4 waves with the running sums in registers by 14 %)
+#ifndef NSK_GENERIC_WAVES
+#define NSK_GENERIC_WAVES 8
+#endif
+#ifndef NSK_GENERIC_LEARN_WAVES
+#define NSK_GENERIC_LEARN_WAVES 6
+#endif
 // persistent grids of the learning kernels (rows of the SMALLW partial-sum tables)
 #define NSK_LEARN_FAST_BLOCKS 2048
 #define NSK_LEARN_LIST_BLOCKS 512
@@ -16,7 +24,7 @@ namespace nsk {
 // One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
 // gibbsthread's loop body (inference.py:20-33) for that variable.
 template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_phase(DevGraph<VT> g, int pbegin, int pend,
+__global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_WAVES) void k_gibbs_phase(DevGraph<VT> g, int pbegin, int pend,
                                                            int sample_evidence, int burnin,
                                                            uint32_t k0, uint32_t k1, uint32_t s0,
                                                            uint32_t s1) {

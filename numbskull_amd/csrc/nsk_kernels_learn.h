@@ -52,7 +52,7 @@ __device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink
 // pbegin + 64 i (range mode) or list[i] (list mode: the per-lane-header tiles of the fast range),
 // clipped at pend.  A persistent grid strides over the items so that SMALLW blocks flush once.
 template <typename VT, bool SMALLW>
-__global__ __launch_bounds__(NSK_BLOCK) void k_learn_phase(DevGraph<VT> g, int pbegin, int pend,
+__global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_phase(DevGraph<VT> g, int pbegin, int pend,
                                                            const uint32_t *list, int nitems,
                                                            LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
