@@ -420,9 +420,16 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         g->launches++;
                     }
                 }
-                if (e > fe) {       // generic CSR kernel
-                    k_gibbs_phase<VT><<<dim3((e - fe + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        d, fe, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                const int he = (int)g->c.phase_heavy_end[ph];
+                if (he > fe) {      // hubs: one wave per variable
+                    k_gibbs_heavy<VT><<<dim3((he - fe + 3) / 4), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        d, fe, he, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                    g->launches++;
+                }
+                if (e > he) {       // generic CSR kernel, one lane per variable
+                    k_gibbs_phase<VT><<<dim3((e - he + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        d, he, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
                         (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
                     g->launches++;
                 }
@@ -484,12 +491,20 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 rows += grid;
                 g->launches++;
             }
-            if (e > fe) {               // variables outside the fast path: generic kernel, range mode
-                const int nitems = (e - fe + 63) / 64;
+            const int he = (int)g->c.phase_heavy_end[ph];
+            if (he > fe) {              // hubs: one wave per variable
+                const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
+                lp.row_base = rows;
+                k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, fe, he, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (e > he) {               // variables outside the fast path: generic kernel, range mode
+                const int nitems = (e - he + 63) / 64;
                 const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
                 lp.row_base = rows;
                 k_learn_phase<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
-                    d, fe, e, nullptr, nitems, lp);
+                    d, he, e, nullptr, nitems, lp);
                 rows += grid;
                 g->launches++;
             }

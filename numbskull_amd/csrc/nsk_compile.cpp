@@ -12,6 +12,9 @@
 
 namespace nsk {
 
+// a variable whose factor lists hold at least this many entries in total is sampled by a whole wave
+static const int64_t NSK_HEAVY_LIST = 128;
+
 bool known_function(int fn) {
     switch (fn) {
     case -1: case 0: case 1: case 2: case 3: case 4: case 7: case 8: case 9:
@@ -422,25 +425,30 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             if (c.color[v] < 0 || fast[v]) continue;
             const nsk_variable &var = d->variable[v];
             const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-            int64_t work = 0;
+            int64_t work = 0, listlen = 0;
             for (int64_t kk = 0; kk < nslots; kk++) {
                 const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
+                listlen += vt.factor_index_length;
                 for (int64_t j = 0; j < vt.factor_index_length; j++)
                     work += 2 + std::max<int64_t>(d->factor[d->factor_index[vt.factor_index_offset + j]].arity, 0);
             }
             if (var.dataType == 0) work *= var.cardinality;
             int bin = 0;
-            while (work > 8 && bin < 40) { work = work * 3 / 4; bin++; }     // ~log_{4/3} bins
-            work_bin[v] = (uint8_t)(40 - bin);                               // heavy variables first
+            while (work > 8 && bin < 39) { work = work * 3 / 4; bin++; }     // ~log_{4/3} bins
+            work_bin[v] = (uint8_t)(40 - bin);                               // heavier variables first
+            // hubs: a whole wave works on one such variable (k_gibbs_heavy / k_learn_heavy)
+            if (listlen >= NSK_HEAVY_LIST && !getenv("NSK_NO_HEAVY")) work_bin[v] = 0;
         }
         {
             std::vector<std::vector<int64_t>> bin_count((size_t)ncolors, std::vector<int64_t>(42, 0));
             for (int64_t v = 0; v < nvar; v++)
                 if (c.color[v] >= 0 && !fast[v]) bin_count[c.color[v]][work_bin[v] + 1]++;
             gen_bin_start.assign((size_t)ncolors, std::vector<int64_t>(42, 0));
+            c.phase_heavy_end.assign((size_t)ncolors, 0);
             for (int32_t k = 0; k < ncolors; k++) {
                 gen_bin_start[k][0] = next_gen[k];
                 for (int b = 0; b < 41; b++) gen_bin_start[k][b + 1] = gen_bin_start[k][b] + bin_count[k][b + 1];
+                c.phase_heavy_end[k] = gen_bin_start[k][1];              // bin 0 = the hubs
             }
         }
         for (int64_t v = 0; v < nvar; v++) {

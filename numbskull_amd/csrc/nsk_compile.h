@@ -26,6 +26,9 @@ struct Compiled {
     // Inside a phase the "fast" variables (binary, symmetric boolean factors: inlined adjacency
     // streams) come first, the rest (generic CSR kernel) after: [phase_start, phase_fast_end) fast.
     std::vector<int64_t> phase_fast_end;   // [ncolors]
+    // generic range of a phase: [phase_fast_end, phase_heavy_end) hubs (one wave per variable),
+    // [phase_heavy_end, phase_start[k+1]) one lane per variable
+    std::vector<int64_t> phase_heavy_end;  // [ncolors]
     std::vector<int64_t> phase_wb_base;    // [ncolors+1] first wave-block of each phase
     // One 16-byte descriptor per wave-block ("tile" = 64 consecutive fast positions):
     //   [0] offset of the tile's stream in 16-byte units   [1] words per lane (multiple of 4)

@@ -494,6 +494,91 @@ __device__ inline int draw_sample(const DevGraph<VT> &g, int var_samp, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// wave-per-variable flavour (hubs): the 64 lanes evaluate 64 factors of the list at a time, then
+// the terms are added one by one IN LIST ORDER (lane 0's term first), so the float64 sum is the
+// very same sequence of additions the one-lane potential() performs.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_value(double x, int srclane) {      // srclane is wave-uniform
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, srclane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename VT>
+__device__ inline double wave_potential(const DevGraph<VT> &g, int var_samp, int value, int slot,
+                                        const VT *val) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int b = g.slot_off[slot], e = g.slot_off[slot + 1];
+    double p = 0.0;
+    for (int base = b; base < e; base += 64) {
+        double t = 0.0;
+        if (base + lane < e) {
+            const uint4 rec = g.f_rec[g.fidx[base + lane]];
+            t = g.w[rec.z] * eval_factor(g, rec, var_samp, value, val);
+        }
+        const int n = min(64, e - base);
+        for (int i = 0; i < n; i++) p = p + lane_value(t, i);
+    }
+    return p;
+}
+
+// both candidates of a binary dataType-0 hub in one walk of its list
+template <typename VT>
+__device__ inline void wave_potential2(const DevGraph<VT> &g, int var_samp, int slot, const VT *val,
+                                       double &p0, double &p1) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int b = g.slot_off[slot], e = g.slot_off[slot + 1];
+    p0 = 0.0; p1 = 0.0;
+    for (int base = b; base < e; base += 64) {
+        double t0 = 0.0, t1 = 0.0;
+        if (base + lane < e) {
+            const uint4 rec = g.f_rec[g.fidx[base + lane]];
+            const double w = g.w[rec.z];
+            t0 = w * eval_factor(g, rec, var_samp, 0, val);
+            t1 = w * eval_factor(g, rec, var_samp, 1, val);
+        }
+        const int n = min(64, e - base);
+        for (int i = 0; i < n; i++) { p0 = p0 + lane_value(t0, i); p1 = p1 + lane_value(t1, i); }
+    }
+}
+
+// draw_sample with wave-cooperative potentials; every lane returns the same value
+template <typename VT>
+__device__ inline int wave_draw_sample(const DevGraph<VT> &g, int var_samp, uint32_t info, int slot0,
+                                       const VT *val, double u) {
+    const int card = NSK_INFO_CARD(info);
+    const int step = NSK_INFO_DT1(info);
+    if (card == 2) {
+        double p0, p1;
+        if (step) {
+            p0 = wave_potential(g, var_samp, 0, slot0, val);
+            p1 = wave_potential(g, var_samp, 1, slot0 + 1, val);
+        } else {
+            wave_potential2(g, var_samp, slot0, val, p0, p1);
+        }
+        const double z0 = nsk_exp(p0);
+        const double z1 = z0 + nsk_exp(p1);
+        const double z = u * z1;
+        return (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    }
+    // any cardinality: two passes, the second recomputes the identical running sums
+    double acc = 0.0;
+    for (int k = 0; k < card; k++) {
+        const double ek = nsk_exp(wave_potential(g, var_samp, k, slot0 + step * k, val));
+        acc = (k == 0) ? ek : acc + ek;
+    }
+    const double z = u * acc;
+    double run = 0.0;
+    for (int k = 0; k < card; k++) {
+        const double ek = nsk_exp(wave_potential(g, var_samp, k, slot0 + step * k, val));
+        run = (k == 0) ? ek : run + ek;
+        if (run >= z) return k;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ long long wave_sum_i64(long long v) {

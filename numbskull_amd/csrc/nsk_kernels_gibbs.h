@@ -19,7 +19,8 @@ namespace nsk {
 #define NSK_LEARN_FAST_BLOCKS 2048
 #define NSK_LEARN_LIST_BLOCKS 512
 #define NSK_LEARN_GEN_BLOCKS 2048
-#define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS)
+#define NSK_LEARN_HEAVY_BLOCKS 512
+#define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS + NSK_LEARN_HEAVY_BLOCKS)
 
 // One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
 // gibbsthread's loop body (inference.py:20-33) for that variable.
@@ -42,6 +43,32 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_WAVES) void k_gibbs_phase(De
         const int base = g.p_cnt[p];
         if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
         else g.cnt[base + nv] += 1;
+    }
+}
+
+// Hubs (variables whose factor lists hold >= 128 entries): one WAVE per variable.  The lanes
+// evaluate the factors of a list 64 at a time and the terms are added in list order, so values are
+// bit-identical to the one-lane kernel; one lane draws and stores.
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_heavy(DevGraph<VT> g, int pbegin, int pend,
+                                                           int sample_evidence, int burnin,
+                                                           uint32_t k0, uint32_t k1, uint32_t s0,
+                                                           uint32_t s1) {
+    const int p = pbegin + (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+    if (p >= pend) return;                                // wave-uniform
+    const uint32_t info = g.p_info[p];
+    const int ev = NSK_INFO_EV(info);
+    const int v = g.p_vid[p];
+    if (v < 0 || !(ev == 0 || sample_evidence)) return;
+    const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const int nv = wave_draw_sample(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));
+    if ((threadIdx.x & 63) == 0) {
+        g.val[v] = (VT)nv;
+        if (!burnin) {
+            const int base = g.p_cnt[p];
+            if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
+            else g.cnt[base + nv] += 1;
+        }
     }
 }
 

@@ -150,8 +150,54 @@ def _small_graphs(golden):
         "pairs_manyw": (_pairs_many_weights(), False),
         # one weight per factor: tiles share a word layout but not weights (shape tiles)
         "boolw": (_boolw(), False),
+        # hub variables (factor lists >= 128 entries): one wave per variable
+        "hubs": (_hub_graph(), False),
         "lr_bigcard": (_big_cardinality_graph(), False),
     }
+
+
+def _hub_graph():
+    """three hubs: a boolean one under 300 OR / EQUAL / IMPLY_MLN factors, a dataType-1 categorical
+    one (cardinality 5) under 400 AND_CAT / OR_CAT factors, and a data-programming label under 200
+    labelling-function accuracy factors; leaves carry ISTRUE priors; 7 free weights"""
+    from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar
+    rng = np.random.default_rng(17)
+    nleaf_b, nleaf_c, nlf = 300, 400, 200
+    nvar = 3 + nleaf_b + nleaf_c + nlf
+    variable = np.zeros(nvar, Variable)
+    variable["cardinality"] = 2
+    variable[1]["cardinality"] = 5
+    variable[1]["dataType"] = 1
+    lf0 = 3 + nleaf_b + nleaf_c
+    variable["cardinality"][lf0:] = 3
+    variable["isEvidence"] = rng.random(nvar) < 0.6
+    variable["isEvidence"][:3] = [0, 1, 0]
+    variable["initialValue"] = (rng.random(nvar) * variable["cardinality"]).astype(np.int64)
+    spec = []
+    for i in range(nleaf_b):
+        leaf = 3 + i
+        fn = (1, 3, 13)[i % 3]
+        spec.append((fn, [leaf, 0] if i % 2 else [0, leaf], [0, 0]))
+        spec.append((4, [leaf], [0]))
+    for i in range(nleaf_c):
+        leaf = 3 + nleaf_b + i
+        fn = (12, 14)[i % 2]
+        spec.append((fn, [1, leaf], [int(rng.integers(0, 5)), int(rng.integers(0, 2))]))
+    for i in range(nlf):
+        spec.append((21, [2, lf0 + i], [0, 0]))
+    spec.append((18, [2], [0]))
+    nedge = sum(len(m) for _, m, _ in spec)
+    factor = np.zeros(len(spec), Factor)
+    fmap = np.zeros(nedge, FactorToVar)
+    e = 0
+    for i, (fn, members, deos) in enumerate(spec):
+        factor[i] = (fn, i % 7, 1.0, len(members), e)
+        for m, dq in zip(members, deos):
+            fmap[e] = (m, dq)
+            e += 1
+    weight = np.zeros(7, Weight)
+    weight["initialValue"] = rng.normal(0, 0.05, 7)
+    return weight, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
 
 
 def _boolw():
@@ -199,7 +245,7 @@ def _big_cardinality_graph():
 
 
 GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
-          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw"]
+          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw", "hubs"]
 
 
 @pytest.mark.parametrize("name", GRAPHS)
@@ -228,7 +274,7 @@ def test_chromatic_inference_equals_oracle(golden, name, sample_evidence):
 
 
 @pytest.mark.parametrize("name", ["mixed", "lf", "pairs", "grid32", "lr3000", "lr_bigcard",
-                                  "headquirk", "lr_manyw", "pairs_manyw", "boolw"])
+                                  "headquirk", "lr_manyw", "pairs_manyw", "boolw", "hubs"])
 @pytest.mark.parametrize("reg,trunc", [(0, 1), (1, 1), (1, 3), (2, 1)])
 @pytest.mark.parametrize("lne", [False, True])
 def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
