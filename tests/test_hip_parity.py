@@ -702,3 +702,68 @@ def test_tally_survives_more_than_255_sweeps_and_repeated_calls():
             sweep += 1
         assert np.array_equal(fg.count, cnt), n
     assert fg.count.max() > 255
+
+
+# ------------------------------------------------------------------------------------------
+# every factor function on the device (the reference's loadfg.py runs each one; here each one is
+# also checked against the oracle, which G1 pins to the reference)
+# ------------------------------------------------------------------------------------------
+def _all_functions_graph():
+    from numbskull_amd.inference import FACTORS
+    from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar
+    rng = np.random.default_rng(23)
+    nvar = 14
+    variable = np.zeros(nvar, Variable)
+    variable["cardinality"] = [2, 3, 2, 3, 3, 2, 3, 2, 3, 3, 2, 3, 2, 3]
+    variable["isEvidence"] = rng.random(nvar) < 0.4
+    variable["initialValue"] = (rng.random(nvar) * variable["cardinality"]).astype(np.int64)
+    funcs = sorted(FACTORS.values())
+    spec = []
+    for fn in funcs:
+        for rep in range(2):
+            members = rng.choice(nvar, size=3, replace=False).tolist()
+            spec.append((fn, members))
+    factor = np.zeros(len(spec), Factor)
+    fmap = np.zeros(3 * len(spec), FactorToVar)
+    for i, (fn, members) in enumerate(spec):
+        factor[i] = (fn, i % 5, [1.0, 0.5, 2.0][i % 3], 3, 3 * i)
+        for j, m in enumerate(members):
+            fmap[3 * i + j] = (m, int(rng.integers(0, 3)))
+    weight = np.zeros(5, Weight)
+    weight["initialValue"] = [0.4, -0.3, 0.2, 0.6, -0.5]
+    weight["isFixed"] = [False, False, True, False, False]
+    return weight, variable, factor, fmap, np.zeros(nvar, np.bool_), 3 * len(spec)
+
+
+@pytest.mark.parametrize("scan", ["chromatic", "sequential"])
+def test_every_factor_function_on_device(scan):
+    g = _all_functions_graph()
+    ns, fg = session(g, seed=41, head_by_vid=True, scan=scan)
+    assert set(int(f) for f in fg.factor["factorFunction"]) == set(numbskull_amd.inference.FACTORS.values())
+    og = oracle_of(fg, True)
+    vv, ve, wv, cnt = og.initial_state()
+    if scan == "chromatic":
+        order, ps = phases_from_colors(fg.colors())
+        fg.inference(2, 20, True)
+        for s in range(22):
+            assert og.gibbs_dev(order, ps, vv, wv, cnt, 41, s, True, burnin=s < 2) == 0
+        assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+        fg.learn(0, 10, 0.02, 0.9, 1, 0.05, 2, learn_non_evidence=True)
+        step = 0.02
+        for s in range(10):
+            assert og.learn_dev(order, ps, vv, ve, wv, step, 1, 0.05, 2, True, 41, 22 + s) == 0
+            step *= 0.9
+    else:
+        np_rng, py_rng = orc.MT(41, "numpy"), orc.MT(41, "python")
+        fg.inference(2, 20, True)
+        for s in range(22):
+            assert og.gibbs_ref(np_rng, vv, wv, cnt, True, burnin=s < 2) == 0
+        assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+        fg.learn(0, 10, 0.02, 0.9, 1, 0.05, 2, learn_non_evidence=True)
+        step = 0.02
+        for s in range(10):
+            assert og.learn_ref(np_rng, py_rng, vv, ve, wv, step, 1, 0.05, 2, True) == 0
+            step *= 0.9
+    assert np.array_equal(fg.var_value[0], vv)
+    assert np.array_equal(fg.var_value_evid[0], ve)
+    assert np.array_equal(fg.weight_value[0], wv), (fg.weight_value[0], wv)
