@@ -377,11 +377,20 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 ngen_of[k]++;
             }
         }
+        // a class gets tiles of its own when it fills at least one (64 members) -- or whatever its
+        // size when the colour has only a few small classes (then padding them costs nothing
+        // and no tile is left with mixed programs, e.g. the corner cells of a grid)
+        std::vector<int64_t> min_class((size_t)ncolors, 64);
+        for (int32_t k = 0; k < ncolors; k++) {
+            int64_t nsmall = 0;
+            for (auto &kv : classes[k]) if (kv.second.first < 64) nsmall++;
+            if (nsmall <= 16) min_class[k] = 1;
+        }
         // variables outside the big exact classes are grouped by shape
         for (int64_t v = 0; v < nvar; v++) {
             const int32_t k = c.color[v];
             if (k < 0 || !fast[v] || shp[v] == 0) continue;
-            if (classes[k][sig[v]].first >= 64) continue;
+            if (classes[k][sig[v]].first >= min_class[k]) continue;
             auto &e = shapes[k][shp[v]];
             if (e.first++ == 0) e.second = v;
         }
@@ -395,8 +404,9 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             for (int level = 0; level < 2; level++) {
                 ClassMap &cm = level == 0 ? classes[k] : shapes[k];
                 std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, key)
+                const int64_t need = level == 0 ? min_class[k] : 64;
                 for (auto &kv : cm)
-                    if (kv.second.first >= 64) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
+                    if (kv.second.first >= need) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
                 std::sort(big.begin(), big.end());
                 for (auto &bc : big) {
                     (level == 0 ? start[k] : start2[k])[bc.second] = pos;
