@@ -767,3 +767,43 @@ def test_every_factor_function_on_device(scan):
     assert np.array_equal(fg.var_value[0], vv)
     assert np.array_equal(fg.var_value_evid[0], ve)
     assert np.array_equal(fg.weight_value[0], wv), (fg.weight_value[0], wv)
+
+
+def test_marginals_within_1e_3_of_exact_after_burn_in():
+    """north_star tolerance: |delta marginal| < 1e-3 after burn-in.  4096 disjoint replicas of a 3x4
+    Ising grid (w = 0.5 horizontal, 0.3 vertical) are sampled together for 5000 sweeps after 200 of
+    burn-in: 2*10^7 samples per cell position, standard error ~3e-4; the exact marginals come from
+    enumerating one replica."""
+    from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar
+    reps, rows, cols = 4096, 3, 4
+    w1, v1, f1, fm1, _, _ = graphgen.ising_grid(rows, cols, weight=0.5, fixed=True, two_weights=True)
+    w1["initialValue"] = [0.3, 0.5]
+    # bias one corner so that marginals are not all 0.5: ISTRUE on cell 0
+    n1, nf1 = rows * cols, len(f1)
+    nvar = reps * n1
+    variable = np.zeros(nvar, Variable)
+    variable["cardinality"] = 2
+    factor = np.zeros(reps * (nf1 + 1), Factor)
+    fmap = np.zeros(reps * (2 * nf1 + 1), FactorToVar)
+    fpr, epr = nf1 + 1, 2 * nf1 + 1
+    for name in ("factorFunction", "weightId", "featureValue", "arity"):
+        block = np.concatenate([f1[name], [4 if name == "factorFunction" else 2 if name == "weightId"
+                                           else 1]])
+        factor[name] = np.tile(block, reps)
+    factor["ftv_offset"] = np.cumsum(factor["arity"]) - factor["arity"]
+    vid1 = np.concatenate([fm1["vid"], [0]])
+    fmap["vid"] = (np.tile(vid1, reps) + np.repeat(np.arange(reps) * n1, epr))
+    weight = np.zeros(3, Weight)
+    weight["initialValue"] = [0.3, 0.5, 0.4]
+    weight["isFixed"] = True
+    ns, fg = session((weight, variable, factor, fmap, np.zeros(nvar, np.bool_), len(fmap)), seed=2024)
+    fg.inference(200, 5000, True)
+    got = fg.marginals.reshape(reps, n1).mean(axis=0)
+    # exact marginals of one replica
+    single = (weight, variable[:n1].copy(), factor[:fpr].copy(), fmap[:epr].copy(),
+              np.zeros(n1, np.bool_), epr)
+    ns1, fg1 = session(single)
+    exact = exact_marginals(oracle_of(fg1), weight["initialValue"].astype(float))
+    want = np.array([exact[i][1] for i in range(n1)])
+    assert np.max(np.abs(got - want)) < 1e-3, (got, want)
+    assert abs(want[0] - 0.5) > 0.05           # the bias makes the check non-trivial
