@@ -40,6 +40,7 @@ WORKLOADS = {
     # 4M boolean variables, ISTRUE / OR / EQUAL factors of arity 1..3 with one weight per factor
     # (the shape of feature-weighted DeepDive graphs): exercises the per-lane-weight shape tiles
     "boolw4m": (2000, 2000, False),
+    "boolw4m_learn": (2000, 2000, True),
     # scaled-down BASELINE configs[4]: mixed-arity LR graph (25 % categorical variables, ISTRUE / OR /
     # IMPLY_MLN / OR_CAT / IMPLY_MLN_CAT / AND_CAT factors, 10^5 weights), inference and learning
     "lr5m": (2500, 2000, False),
@@ -50,8 +51,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
 def build_graph(rows, cols, learning, seed=20240602, name=None):
     from numbskull_amd import graphgen
-    if name == "boolw4m":
-        return graphgen.boolean_weighted_graph(rows * cols, seed=seed)
+    if name in ("boolw4m", "boolw4m_learn"):
+        g = graphgen.boolean_weighted_graph(rows * cols, seed=seed)
+        if learning:                     # free weights, half of the variables evidence
+            rng = np.random.Generator(np.random.PCG64(seed + 1))
+            g[0]["isFixed"] = False
+            g[0]["initialValue"] = 0.0
+            g[1]["isEvidence"] = rng.random(len(g[1])) < 0.5
+            g[1]["initialValue"] = rng.integers(0, 2, len(g[1]))
+        return g
     if name in ("lr5m", "lr5m_learn"):
         return graphgen.mixed_lr_graph(rows * cols, seed=20240603)
     if not learning:
@@ -168,7 +176,7 @@ def main():
     info = fg.info()
     sampler = PartitionedSampler(fg, dist, torch, rank, world) if world > 1 else None
     lr = (1e-7, 0.95, 2, 0.01, 1)       # step, decay, L2, reg_param, truncation (config #3)
-    if args.workload.startswith("lr"):
+    if args.workload.startswith("lr") or args.workload.startswith("boolw"):
         lr = (1e-3, 0.95, 2, 0.01, 1)
 
     def run(n):
@@ -229,7 +237,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("%d boolean variables, %d ISTRUE/OR/EQUAL factors with one weight each, "
                                     "inference only, chromatic scan, seed %d" % (nvar, len(f), args.seed))
-                       if args.workload == "boolw4m" else
+                       if args.workload.startswith("boolw4m") else
                        ("mixed-arity LR graph: %d variables (25%% categorical), %d factors, %d weights, %s"
                         % (nvar, len(f), len(w), "learning" if learning else "inference"))
                        if args.workload.startswith("lr") else

@@ -566,16 +566,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     td[3] = (uint32_t)nslots | (kind << 8);
                     len = nslots;
                 }
-                if (td[2] == 0xFFFFFFFFu && same_shape && len <= 16 && len > 0) {
+                if (td[2] == 0xFFFFFFFFu && same_shape && len <= 16 && len > 0 && !getenv("NSK_NO_SHAPE")) {
                     // shape tile: per-lane headers (own function and weight) but one word layout for the
-                    // 64 lanes.  Role program, one word per stream word: 1 header | 2 first member |
-                    // 4 last member | 8 header of an entry without other members; kind 7.
+                    // 64 lanes.  Role program, one word per stream word: 1 header | 8 header of an
+                    // entry without other members | 16 member | 2 first member | 4 last member; kind 7.
                     prog.clear();
                     for (uint32_t h : hdrs0) {
                         const uint32_t no = (h >> 24) & 7u;
                         prog.push_back(1u | (no == 0 ? 8u : 0u) | 0x80000000u);   // bit 31 marks role words
                         for (uint32_t m = 0; m < no; m++)
-                            prog.push_back((m == 0 ? 2u : 0u) | (m + 1 == no ? 4u : 0u) | 0x80000000u);
+                            prog.push_back(16u | (m == 0 ? 2u : 0u) | (m + 1 == no ? 4u : 0u) | 0x80000000u);
                     }
                     auto it = hdr_pool.find(prog);
                     if (it == hdr_pool.end()) {
@@ -598,8 +598,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         c.phase_dyn_base.assign((size_t)ncolors + 1, 0);
         for (int32_t k = 0; k < ncolors; k++) {
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++)
-                if (c.tiles[4 * (c.phase_wb_base[k] + b) + 2] == 0xFFFFFFFFu ||
-                    ((c.tiles[4 * (c.phase_wb_base[k] + b) + 3] >> 8) & 7u) == 7u)
+                if (c.tiles[4 * (c.phase_wb_base[k] + b) + 2] == 0xFFFFFFFFu)
                     c.dyn_tiles.push_back((uint32_t)(c.phase_start[k] + 64 * b));
             c.phase_dyn_base[k + 1] = (int64_t)c.dyn_tiles.size();
         }

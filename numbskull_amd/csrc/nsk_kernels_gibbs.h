@@ -262,14 +262,14 @@ __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, con
         const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
         uint32_t role[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0xFu;      // scalar; 0 = padding word
+        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0x1Fu;      // scalar; 0 = padding word
         double wv[4];
         int xv[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {                                    // one gather per word
             wv[i] = 0.0; xv[i] = 0;
             if (role[i] & 1u) wv[i] = g.w[wd[i] & 0xFFFFFFu];
-            else if (role[i]) xv[i] = (int)val[wd[i]];
+            else if (role[i] & 16u) xv[i] = (int)val[wd[i]];
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -278,7 +278,7 @@ __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, con
                 w = wv[i];
                 first = 0; allnz = true; any1 = false; alleq = true;
                 if (role[i] & 8u) finish(true);
-            } else if (role[i]) {                                        // member
+            } else if (role[i] & 16u) {                                  // member
                 const int x = xv[i];
                 const bool F = (role[i] & 2u) != 0;
                 alleq = F || (alleq && (x == first));

@@ -297,6 +297,126 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
     }
 }
 
+// One shape tile of the learning sweep (per-lane functions and weights, shared word layout).
+// Pass 1 walks the words for both chains, keeps the per-entry satisfied bits for candidates 0/1 in
+// lane bitfields (entry e -> bit e) and accumulates the potentials; after the draws, pass 2
+// re-reads the header words (cache hits) and adds each entry's gradient through the wave-aggregated
+// accumulators, one entry position at a time (the role program makes the positions wave-uniform).
+template <typename VT>
+__device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
+                                                 int len, uint32_t prog, int p, bool valid,
+                                                 const LearnParams &lp) {
+    const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    const uint32_t info = valid ? g.p_info[p] : 0u;
+    const int v = valid ? g.p_vid[p] : 0;
+    const int ev = NSK_INFO_EV(info);
+    const int init = valid ? (int)g.p_init[p] : 0;
+    const bool need_evid = __ballot(valid && ev != 1) != 0;
+
+    double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+    uint32_t B0 = 0, B1 = 0, C0 = 0, C1 = 0;
+    uint32_t code = 0;
+    double w = 0.0;
+    int ff = 0, fe = 0;                                        // first member value, free / evidence chain
+    bool nzf = true, onef = false, eqf = true, nze = true, onee = false, eqe = true;
+    int entry = -1;                                            // wave-uniform entry counter
+    auto close = [&](bool nomember) {
+        const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
+        const bool b0 = (isEq && eqf && (nomember || ff == 0)) || (isOr && onef);
+        const bool b1 = (isEq && eqf && (nomember || ff == 1)) || (isAnd && nzf) || isOr;
+        const bool c0 = (isEq && eqe && (nomember || fe == 0)) || (isOr && onee);
+        const bool c1 = (isEq && eqe && (nomember || fe == 1)) || (isAnd && nze) || isOr;
+        const double hi = code == 0u ? 0.0 : 1.0;
+        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+        const double t0 = w * (b0 ? hi : lo), t1 = w * (b1 ? hi : lo);
+        p0 = p0 + t0;
+        p1 = p1 + t1;
+        if (need_evid) {
+            const double s0 = w * (c0 ? hi : lo), s1 = w * (c1 ? hi : lo);
+            q0 = q0 + s0;
+            q1 = q1 + s1;
+        }
+        B0 |= (b0 ? 1u : 0u) << entry; B1 |= (b1 ? 1u : 0u) << entry;
+        C0 |= (c0 ? 1u : 0u) << entry; C1 |= (c1 ? 1u : 0u) << entry;
+    };
+    for (int c = 0; c * 4 < len; c++) {
+        const uint4 q = sp[(size_t)c * 64];
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+        uint32_t role[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0x1Fu;
+        double wv[4];
+        int xv[4], xe[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            wv[i] = 0.0; xv[i] = 0; xe[i] = 0;
+            if (role[i] & 1u) wv[i] = g.w[wd[i] & 0xFFFFFFu];
+            else if (role[i] & 16u) { xv[i] = (int)g.val[wd[i]]; xe[i] = (int)g.val_evid[wd[i]]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (role[i] & 1u) {
+                entry++;
+                code = (0x343210u >> (4u * (wd[i] >> 27))) & 0xFu;
+                w = wv[i];
+                ff = 0; fe = 0; nzf = true; onef = false; eqf = true; nze = true; onee = false; eqe = true;
+                if (role[i] & 8u) close(true);
+            } else if (role[i] & 16u) {
+                const bool F = (role[i] & 2u) != 0;
+                const int x = xv[i], y = xe[i];
+                eqf = F || (eqf && (x == ff)); nzf = (F || nzf) && (x != 0); onef = (!F && onef) || (x == 1);
+                ff = F ? x : ff;
+                eqe = F || (eqe && (y == fe)); nze = (F || nze) && (y != 0); onee = (!F && onee) || (y == 1);
+                fe = F ? y : fe;
+                if (role[i] & 4u) close(false);
+            }
+        }
+    }
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    int evidence = init;
+    if (need_evid && ev != 1) {
+        const double z0 = nsk_exp(q0), z1 = z0 + nsk_exp(q1);
+        const double z = u53(r.z, r.w) * z1;
+        evidence = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    }
+    const double z0 = nsk_exp(p0), z1 = z0 + nsk_exp(p1);
+    const double z = u53(r.x, r.y) * z1;
+    const int proposal = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+    if (valid) {
+        g.val_evid[v] = (VT)evidence;
+        g.val[v] = (VT)proposal;
+    }
+    const bool part = valid && (lp.learn_non_evidence || ev == 1);
+    bool truncate = false;
+    if (lp.regularization == 1) {
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
+    }
+    if (__ballot(part) == 0) return;
+    const uint32_t satf = proposal ? B1 : B0, sate = evidence ? C1 : C0;
+    int e2 = -1;
+    for (int c = 0; c * 4 < len; c++) {                         // pass 2: gradients, entry by entry
+        uint32_t role[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0x1Fu;
+        if (!((role[0] | role[1] | role[2] | role[3]) & 1u)) continue;      // no header in this chunk
+        const uint4 q = sp[(size_t)c * 64];
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (role[i] & 1u) {
+                e2++;
+                const int wid = (int)(wd[i] & 0xFFFFFFu);
+                const uint32_t cd = (0x343210u >> (4u * (wd[i] >> 27))) & 0xFu;
+                const long long span = cd == 0u ? 0 : (cd == 1u ? 1 : 2);          // hi - lo
+                const bool have = part && !g.w_fixed[wid];
+                const long long diff = (long long)((satf >> e2) & 1u) - (long long)((sate >> e2) & 1u);
+                accumulate_gradient(sk, have, wid, (span * diff) << 32, truncate);
+            }
+        }
+    }
+}
+
 // Learning over the uniform tiles of a colour class (tiles with per-lane headers are left to
 // k_learn_phase in list mode).  Each wave takes a contiguous run of tiles.
 template <typename VT, bool SMALLW>
@@ -312,12 +432,13 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
     for (int t = wave0 * per; t < t1; t++) {
         const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
         const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
-        if (td.z == NSK_PAD_WORD || ((td.w >> 8) & 7u) == 7u) continue;   // per-lane headers: generic kernel's job
+        if (td.z == NSK_PAD_WORD) continue;                  // mixed per-lane headers: generic kernel's job
         const int p = pbegin + t * 64 + lane;
         const bool valid = p < pend && g.p_vid[p] >= 0;
         const uint4 *sp = g.adj + td.x + lane;
         const uint32_t kind = (td.w >> 8) & 7u;
-        if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+        if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp);
+        else if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
         else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
         else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
         else learn_tile<VT, 3>(g, sk, sp, (int)td.y, td.z, p, valid, lp);

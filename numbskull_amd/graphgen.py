@@ -230,15 +230,15 @@ def mixed_lr_graph(nvar, seed=20240603, nweights=None, window=1024, global_frac=
     return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
 
 
-def boolean_weighted_graph(nvar, seed=0, window=64, factors_per_var=2.0):
+def boolean_weighted_graph(nvar, seed=0, window=64, factors_per_var=2.0, max_arity=3):
     """Boolean graph with one weight per factor: for every variable an ISTRUE prior, plus
-    ``factors_per_var * nvar`` OR / EQUAL factors of arity 2..3 over nearby variables (ids within
+    ``factors_per_var * nvar`` OR / EQUAL factors of arity 2..``max_arity`` over nearby variables (ids within
     ``window``).  The shape of feature-weighted DeepDive graphs whose factors carry individual
     weights; all weights fixed at small random values so that inference is well-conditioned."""
     rng = np.random.Generator(np.random.PCG64(seed))
     nvar = int(nvar)
     nextra = int(factors_per_var * nvar)
-    arity = np.concatenate([np.ones(nvar, np.int64), rng.integers(2, 4, nextra)])
+    arity = np.concatenate([np.ones(nvar, np.int64), rng.integers(2, max_arity + 1, nextra)])
     nfactor = len(arity)
     off = np.cumsum(arity) - arity
     nedge = int(arity.sum())

@@ -201,7 +201,7 @@ def _hub_graph():
 
 
 def _boolw():
-    g = list(graphgen.boolean_weighted_graph(6000, seed=4))
+    g = list(graphgen.boolean_weighted_graph(6000, seed=4, max_arity=5, factors_per_var=1.0))
     w = g[0].copy()
     w["isFixed"] = False
     var = g[1].copy()
