@@ -77,13 +77,15 @@ struct nsk_graph {
     uint8_t *cnt_pos = nullptr;
     int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
     uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr;
-    double *prog_w = nullptr;
+    double *prog_w = nullptr, *adj_wt = nullptr;
+    uint32_t *tile_wrow = nullptr;
     uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr;
     long long *part_G = nullptr;       // SMALLW: rows of per-block partial sums
     uint32_t *part_K = nullptr, *part_T = nullptr;
     bool smallw = false;
     bool weights_dirty = true;      // prog_w must be rebuilt before the next fast-path launch
-    bool weights_exposed = false;   // the weight buffer was handed out: assume it changes between calls
+    bool weights_exposed = false;
+    bool adj_wt_skip = false;       // learning reads weights directly: skip the shape-tile rows until the next inference   // the weight buffer was handed out: assume it changes between calls
     // boundary exchange (multi-GPU)
     int xworld = 0, xrank = 0;
     int64_t xslot = 0, xnsend = 0, xnrecv = 0;
@@ -177,7 +179,7 @@ static DevGraph<VT> view(nsk_graph *g) {
     d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
     d.G = g->G; d.K = g->K; d.T = g->T;
     d.adj = (const uint4 *)g->adj; d.tiles = (const uint4 *)g->tiles; d.tile_hdr = g->tile_hdr;
-    d.prog_w = g->prog_w;
+    d.prog_w = g->prog_w; d.adj_wt = g->adj_wt; d.tile_wrow = g->tile_wrow;
     d.part_G = g->part_G; d.part_K = g->part_K; d.part_T = g->part_T;
     d.nweight = (int32_t)g->c.nweight;
     d.cnt_pos = g->cnt_pos;
@@ -233,7 +235,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
     UP(f_rec); UP(f_feat); UP(m_rec); UP(v_card); UP(v_pos);
-    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles);
+    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
@@ -248,6 +250,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &g->cnt_total, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos); if (rc) return rc;
     rc = dev_alloc(g, &g->prog_w, 2 * c.tile_hdr.size()); if (rc) return rc;
+    rc = dev_alloc(g, &g->adj_wt, (size_t)c.nwrows * 64); if (rc) return rc;
     g->smallw = c.nweight > 0 && c.nweight <= NSK_SMALLW;
     if (g->smallw) {
         const size_t cells = (size_t)NSK_LEARN_ROWS * (size_t)c.nweight;
@@ -333,6 +336,10 @@ static void refresh_prog_weights(nsk_graph *g, bool force = false) {
     if (n > 0 && g->c.nfast > 0 && g->c.nweight > 0)
         k_refresh_prog_weights<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
             g->tile_hdr, g->w, g->prog_w, n);
+    const int nt = (int)(g->c.tiles.size() / 4) - 1;
+    if (g->c.nwrows > 0 && nt > 0 && !g->adj_wt_skip)
+        k_refresh_shape_weights<<<dim3((nt + 3) / 4), dim3(NSK_BLOCK), 0, g->stream>>>(
+            (const uint4 *)g->tiles, (const uint4 *)g->adj, g->tile_hdr, g->tile_wrow, g->w, g->adj_wt, nt);
 }
 
 static int fold_position_tally(nsk_graph *g) {
@@ -465,6 +472,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
     lp.learn_non_evidence = learn_non_evidence;
     lp.inv_trunc = 1.0 / (double)truncation;
     lp.k0 = (uint32_t)g->seed; lp.k1 = (uint32_t)(g->seed >> 32);
+    g->adj_wt_skip = true;          // the learning kernels gather weights themselves
     refresh_prog_weights(g);
     for (int64_t s = 0; s < nsweeps; s++) {
         lp.s0 = (uint32_t)g->sweep; lp.s1 = (uint32_t)(g->sweep >> 32);
@@ -524,6 +532,8 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
         g->sweep++;
         step *= decay;                                   // factorgraph.py:206
     }
+    g->adj_wt_skip = false;
+    g->weights_dirty = true;        // the next inference call rebuilds prog_w and the weight rows
     HIPCHECK(hipGetLastError());
     return NSK_OK;
 }

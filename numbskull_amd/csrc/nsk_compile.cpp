@@ -485,6 +485,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         c.phase_wb_base[k + 1] = c.phase_wb_base[k] + (c.phase_fast_end[k] - c.phase_start[k] + 63) / 64;
     const int64_t nwb = c.phase_wb_base[ncolors];
     c.tiles.assign((size_t)nwb * 4 + 4, 0);
+    c.tile_wrow.assign((size_t)nwb + 1, 0);
     {
         // words of one lane: per factor of the variable, in list order, a header then the ids of
         // the members other than the variable itself
@@ -586,6 +587,9 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     td[2] = it->second;
                     td[3] = (uint32_t)len | (7u << 8);
                     shape_tile = true;
+                    c.tile_wrow[c.phase_wb_base[k] + b] = (uint32_t)c.nwrows;
+                    c.nwrows += (int64_t)hdrs0.size();
+                    if (c.nwrows >= ((int64_t)1 << 31)) { err = "weight stream too large"; return NSK_E_RANGE; }
                 }
                 len = (len + 3) / 4 * 4;
                 td[0] = (uint32_t)total4;

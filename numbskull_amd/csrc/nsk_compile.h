@@ -36,6 +36,10 @@ struct Compiled {
     //   [3] member slots of a uniform tile
     // Stream layout: chunk c of lane i (4 words = one 16-byte load) at 16*(off + 64*c + i).
     std::vector<uint32_t> tiles;           // [4*nwb]
+    // shape tiles: first row of the tile in the materialised weight stream (adj_wt: one row of 64
+    // doubles per entry, refreshed from the weights whenever they change); 0 for other tiles
+    std::vector<uint32_t> tile_wrow;       // [nwb]
+    int64_t nwrows = 0;
     std::vector<uint32_t> adj;             // inlined adjacency words (DESIGN.md "fast path")
     // A tile whose 64 lanes share one header sequence (same function, member count and weight per
     // entry) with at most 8 member slots is "uniform": its stream holds member words only and its

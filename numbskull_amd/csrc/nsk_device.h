@@ -184,6 +184,8 @@ struct DevGraph {
     const uint4 *adj;           // stream: chunk c of lane i of a tile at adj[off + 64*c + i]
     const uint4 *tiles;         // [nwb] {stream offset, words per lane, tile_hdr offset | PAD, entries}
     const uint32_t *tile_hdr;   // slot programs of uniform tiles, padded to 8 words
+    const uint32_t *tile_wrow;  // [nwb] shape tiles: first row of the tile in adj_wt
+    double *adj_wt;             // materialised weights of shape tiles: row r, lane i at adj_wt[64 r + i]
     const double *prog_w;       // [2 * |tile_hdr|] per program word: weight * value when the entry
                                 //  is satisfied / unsatisfied (0, 0 unless the slot closes an entry);
                                 //  refreshed by k_refresh_prog_weights whenever weights change

@@ -241,11 +241,12 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32
 template <typename VT>
 __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, const VT *val,
                                                       const uint4 *sp, int len, uint32_t prog,
-                                                      double &p0, double &p1) {
+                                                      uint32_t wrow, double &p0, double &p1) {
     const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    const double *wt = g.adj_wt + (size_t)wrow * 64 + (threadIdx.x & 63);   // this lane's weight column
     uint32_t code = 0;                   // per lane: 0 NOOP 1 IMPLY_NATURAL 2 OR 3 AND/ISTRUE 4 EQUAL
     double w = 0.0;
-    int first = 0;
+    int first = 0, entry = 0;            // entry: wave-uniform
     bool allnz = true, any1 = false, alleq = true;
     auto finish = [&](bool nomember) {
         const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
@@ -262,13 +263,14 @@ __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, con
         const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
         uint32_t role[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0x1Fu;      // scalar; 0 = padding word
+        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0x1Fu;     // scalar; 0 = padding word
         double wv[4];
         int xv[4];
+        int e2 = entry;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {                                    // one gather per word
+        for (int i = 0; i < 4; i++) {                                    // one load per word
             wv[i] = 0.0; xv[i] = 0;
-            if (role[i] & 1u) wv[i] = g.w[wd[i] & 0xFFFFFFu];
+            if (role[i] & 1u) wv[i] = wt[(size_t)(e2++) * 64];           // coalesced: materialised weight
             else if (role[i] & 16u) xv[i] = (int)val[wd[i]];
         }
 #pragma unroll
@@ -276,6 +278,7 @@ __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, con
             if (role[i] & 1u) {                                          // header: open an entry
                 code = (0x343210u >> (4u * (wd[i] >> 27))) & 0xFu;       // function+1 in 0..5 -> code
                 w = wv[i];
+                entry++;
                 first = 0; allnz = true; any1 = false; alleq = true;
                 if (role[i] & 8u) finish(true);
             } else if (role[i] & 16u) {                                  // member
@@ -288,6 +291,29 @@ __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, con
                 if (role[i] & 4u) finish(false);
             }
         }
+    }
+}
+
+// adj_wt row e of a shape tile <- the weights its lanes' e-th headers name (run whenever weights
+// may have changed; the sweeps then read weights as coalesced rows instead of 64 random sectors)
+__global__ __launch_bounds__(NSK_BLOCK) void k_refresh_shape_weights(const uint4 *tiles, const uint4 *adj,
+                                                                     const uint32_t *tile_hdr,
+                                                                     const uint32_t *tile_wrow, const double *w,
+                                                                     double *adj_wt, int ntiles) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int t = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+    if (t >= ntiles) return;
+    const uint4 td = tiles[t];
+    if (td.z == NSK_PAD_WORD || ((td.w >> 8) & 7u) != 7u) return;
+    const int len = (int)(td.w & 0xFFu);
+    const uint32_t *rp = tile_hdr + td.z;
+    double *wt = adj_wt + (size_t)tile_wrow[t] * 64 + lane;
+    int entry = 0;
+    for (int c = 0; c * 4 < len; c++) {
+        const uint4 q = adj[td.x + (size_t)c * 64 + lane];
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+        for (int i = 0; i < 4; i++)
+            if (rp[4 * c + i] & 1u) wt[(size_t)(entry++) * 64] = w[wd[i] & 0xFFFFFFu];
     }
 }
 
@@ -323,7 +349,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     if (td.z == NSK_PAD_WORD) tile_potentials_dynamic(g, g.val, sp, len, p0, p1);
     else {
         const uint32_t kind = (td.w >> 8) & 7u;              // wave-uniform
-        if (kind == 7u) tile_potentials_shape(g, g.val, sp, (int)(td.w & 0xFFu), td.z, p0, p1);
+        if (kind == 7u)
+            tile_potentials_shape(g, g.val, sp, (int)(td.w & 0xFFu), td.z,
+                                  *(const NSK_SCALAR uint32_t *)(g.tile_wrow + (wb_base + wave)), p0, p1);
         else if (kind == 4u) tile_potentials_uniform<VT, 4>(g, g.val, sp, len, td.z, p0, p1);
         else if (kind == 0u) tile_potentials_uniform<VT, 0>(g, g.val, sp, len, td.z, p0, p1);
         else if (kind == 2u) tile_potentials_uniform<VT, 2>(g, g.val, sp, len, td.z, p0, p1);
