@@ -249,6 +249,7 @@ def main():
                        "colors": info["ncolors"], "value_bytes": info["value_bytes"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "actual_GBs": (traffic / launch_s / 1e9) if traffic else None,
                          "alg_bytes_per_update": alg_sweep * world / nvar,
                          "kernel": ("k_learn_fast" if info["nfast"] else "k_learn_phase") if learning
                          else ("k_gibbs_seg" if info["nfast"] else "k_gibbs_phase"),
