@@ -76,7 +76,7 @@ struct nsk_graph {
     int32_t *cnt = nullptr;
     uint8_t *cnt_pos = nullptr;
     int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
-    uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr;
+    uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr, *gstream = nullptr, *gs_off = nullptr;
     double *prog_w = nullptr, *adj_wt = nullptr;
     uint32_t *tile_wrow = nullptr;
     uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr;
@@ -173,6 +173,7 @@ static DevGraph<VT> view(nsk_graph *g) {
     d.p_vid = g->p_vid; d.p_info = g->p_info; d.p_slot = g->p_slot; d.p_cnt = g->p_cnt;
     d.p_init = (const VT *)g->p_init;
     d.slot_off = g->slot_off; d.fidx = g->fidx;
+    d.gstream = (const uint2 *)g->gstream; d.gs_off = g->gs_off;
     d.f_rec = (const uint4 *)g->f_rec; d.f_feat = g->f_feat;
     d.m_rec = (const int2 *)g->m_rec; d.v_card = g->v_card;
     d.w = g->w; d.w_fixed = g->w_fixed; d.logtab = g->logtab;
@@ -233,7 +234,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     HIPCHECK(hipEventCreate(&g->ev1));
     Compiled &c = g->c;
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
-    UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx);
+    UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx); UP(gstream); UP(gs_off);
     UP(f_rec); UP(f_feat); UP(m_rec); UP(v_card); UP(v_pos);
     UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(tile_wrow);
 #undef UP
@@ -494,7 +495,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             if (ndyn > 0) {             // tiles with per-lane headers: generic kernel, list mode
                 const int grid = std::min(NSK_LEARN_LIST_BLOCKS, (ndyn + 3) / 4);
                 lp.row_base = rows;
-                k_learn_phase<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                k_learn_phase<VT, SMALLW, false><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
                     d, fb, fe, g->dyn_tiles + g->c.phase_dyn_base[ph], ndyn, lp);
                 rows += grid;
                 g->launches++;
@@ -511,7 +512,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 const int nitems = (e - he + 63) / 64;
                 const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
                 lp.row_base = rows;
-                k_learn_phase<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                k_learn_phase<VT, SMALLW, true><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
                     d, he, e, nullptr, nitems, lp);
                 rows += grid;
                 g->launches++;

@@ -743,6 +743,66 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         bytes_learn += bi + bl + s_v;
     }
     c.slot_off[si] = (int32_t)li;
+
+    // ---- inline generic stream: for the positions handled by the one-lane generic kernels, every
+    // factor record of every slot copied in list order, members included, so that a lane reads its
+    // update sequentially instead of chasing fidx -> factor -> fmap through three arrays
+    c.gs_off.assign((size_t)nslot + 1, 0);
+    {
+        auto members_stored = [&](const nsk_factor &fa) -> int64_t {   // edges the function may read
+            const int fn = fa.factorFunction;
+            int64_t need = (fn == 21 || fn == 22 || fn == 25 || fn == 26) ? 2 : (fn == 23 || fn == 24) ? 3
+                         : (fn >= 18 && fn <= 20) ? 1 : (fn == 3 ? 1 : 0);
+            int64_t n = std::max<int64_t>(std::max<int64_t>(fa.arity, 0), need);
+            if (fn == 30 && fa.ftv_offset >= 0 && fa.ftv_offset < nedge)
+                n = std::max<int64_t>(n, d->variable[d->fmap[fa.ftv_offset].vid].cardinality - 1);
+            if (fn == -1) n = 0;
+            return n;
+        };
+        uint64_t units = 2;                       // unit 0/1 unused so that offset 0 means "none"
+        for (int32_t k = 0; k < ncolors; k++)
+            for (int64_t p = c.phase_heavy_end[k]; p < c.phase_start[k + 1]; p++) {
+                const int64_t v = c.p_vid[p];
+                if (v < 0) continue;
+                const nsk_variable &var = d->variable[v];
+                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+                for (int64_t kk = 0; kk < nslots; kk++) {
+                    const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
+                    for (int64_t j = 0; j < vt.factor_index_length; j++)
+                        units += 4 + (uint64_t)members_stored(d->factor[d->factor_index[vt.factor_index_offset + j]]);
+                }
+            }
+        if (units >= ((uint64_t)1 << 32)) { err = "inline generic stream too large"; return NSK_E_RANGE; }
+        c.gstream.assign((size_t)units * 2, 0);
+        uint64_t at = 2;
+        for (int32_t k = 0; k < ncolors; k++)
+            for (int64_t p = c.phase_heavy_end[k]; p < c.phase_start[k + 1]; p++) {
+                const int64_t v = c.p_vid[p];
+                if (v < 0) continue;
+                const nsk_variable &var = d->variable[v];
+                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+                for (int64_t kk = 0; kk < nslots; kk++) {
+                    const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
+                    c.gs_off[c.p_slot[p] + kk] = (uint32_t)at;
+                    for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                        const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                        const nsk_factor &fa = d->factor[f];
+                        const int64_t nm = members_stored(fa);
+                        uint32_t *u = &c.gstream[at * 2];
+                        u[0] = c.f_rec[4 * f]; u[1] = c.f_rec[4 * f + 2];              // head, weightId
+                        u[2] = c.f_rec[4 * f + 1]; u[3] = (uint32_t)f;                 // ftv_offset, factor id
+                        memcpy(&u[4], &fa.featureValue, 8);
+                        u[6] = (uint32_t)nm; u[7] = 0;
+                        for (int64_t m = 0; m < nm; m++) {
+                            const int64_t l = fa.ftv_offset + m;
+                            u[8 + 2 * m] = (uint32_t)c.m_rec[2 * l];
+                            u[9 + 2 * m] = (uint32_t)c.m_rec[2 * l + 1];
+                        }
+                        at += 4 + (uint64_t)nm;
+                    }
+                }
+            }
+    }
     c.alg_bytes_inference = bytes_inf;
     c.alg_bytes_learning = bytes_learn;
     return NSK_OK;

@@ -65,6 +65,9 @@ struct Compiled {
     std::vector<int32_t> p_init;        // narrowed to vbytes at upload
     // inverted index
     std::vector<int32_t> slot_off, fidx;
+    // inline generic stream (one-lane-per-variable generic kernels): see nsk_device.h gstream
+    std::vector<uint32_t> gstream;      // pairs of uint32 = 8-byte units
+    std::vector<uint32_t> gs_off;       // [nslot]
     // per factor / edge / variable
     std::vector<uint32_t> f_rec;        // [4*nfactor] {arity << 8 | function+1, ftv_offset, weightId, 0}
     std::vector<double> f_feat;

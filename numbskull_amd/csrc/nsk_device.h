@@ -162,6 +162,11 @@ struct DevGraph {
     const double *f_feat;       // featureValue
     // per edge: one 8-byte record {variable id, dense_equal_to}
     const int2 *m_rec;
+    // generic path, one lane per variable: the factor records of every slot copied inline, in list
+    // order (DESIGN.md "inline generic stream"): per factor 4 header units of 8 bytes
+    // {head, weightId} {ftv_offset, factor id} {featureValue} {members stored, 0} + members {vid, deo}
+    const uint2 *gstream;
+    const uint32_t *gs_off;     // [nslot] first unit of a slot's records (0 for slots outside this path)
     // per variable id
     const int32_t *v_card;      // cardinality (data-programming "abstain" lookups)
     // weights
@@ -262,17 +267,17 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nblocks) {
 
 // member value at absolute edge index l with the sampled variable hypothetically at `value`
 template <typename VT>
-__device__ __forceinline__ int member(const DevGraph<VT> &g, int l, int var_samp, int value,
+__device__ __forceinline__ int member(const int2 *mb, int l, int var_samp, int value,
                                       const VT *val) {
-    const int vid = g.m_rec[l].x;
+    const int vid = mb[l].x;
     return vid == var_samp ? value : (int)val[vid];
 }
 
 // member value and its dense_equal_to in one 8-byte load (categorical functions)
 template <typename VT>
-__device__ __forceinline__ int member_deo(const DevGraph<VT> &g, int l, int var_samp, int value,
+__device__ __forceinline__ int member_deo(const int2 *mb, int l, int var_samp, int value,
                                           const VT *val, int &deo) {
-    const int2 m = g.m_rec[l];
+    const int2 m = mb[l];
     deo = m.y;
     return m.x == var_samp ? value : (int)val[m.x];
 }
@@ -281,9 +286,9 @@ __device__ __forceinline__ int member_deo(const DevGraph<VT> &g, int l, int var_
 // var_value[l] with l the ABSOLUTE EDGE INDEX (inference.py:243,277,292); NSK_FLAG_HEAD_BY_VID
 // selects the intended fmap[l].vid.  nsk_graph_create has verified l < nvar in literal mode.
 template <typename VT>
-__device__ __forceinline__ int head_member(const DevGraph<VT> &g, int l, int var_samp, int value,
-                                           const VT *val, int &deo) {
-    const int2 m = g.m_rec[l];
+__device__ __forceinline__ int head_member(const DevGraph<VT> &g, const int2 *mb, int l, int var_samp,
+                                           int value, const VT *val, int &deo) {
+    const int2 m = mb[l];
     deo = m.y;
     if (m.x == var_samp) return value;
     return (int)val[g.head_by_vid ? m.x : l];
@@ -292,8 +297,8 @@ __device__ __forceinline__ int head_member(const DevGraph<VT> &g, int l, int var
 // eval_factor (inference.py:149-413).  nsk_graph_create rejects unknown function ids and
 // out-of-range member positions, so no error path is needed here.
 template <typename VT>
-__device__ inline double eval_factor(const DevGraph<VT> &g, const uint4 rec, int var_samp, int value,
-                                     const VT *val) {
+__device__ inline double eval_factor(const DevGraph<VT> &g, const uint4 rec, const int2 *mb,
+                                     int var_samp, int value, const VT *val) {
     const uint32_t head = rec.x;
     const int fn = NSK_FHEAD_FUNC(head);
     const int s = (int)rec.y;
@@ -303,32 +308,32 @@ __device__ inline double eval_factor(const DevGraph<VT> &g, const uint4 rec, int
     case F_NOOP:
         return 0.0;
     case F_EQUAL: {                                             // 184-192
-        int v = member(g, s, var_samp, value, val);
+        int v = member(mb, s, var_samp, value, val);
         for (int l = s + 1; l < e; l++)
-            if (v != member(g, l, var_samp, value, val)) return -1.0;
+            if (v != member(mb, l, var_samp, value, val)) return -1.0;
         return 1.0;
     }
     case F_AND:
     case F_ISTRUE:                                              // 193-200
         for (int l = s; l < e; l++)
-            if (member(g, l, var_samp, value, val) == 0) return -1.0;
+            if (member(mb, l, var_samp, value, val) == 0) return -1.0;
         return 1.0;
     case F_OR:                                                  // 177-183
         for (int l = s; l < e; l++)
-            if (member(g, l, var_samp, value, val) == 1) return 1.0;
+            if (member(mb, l, var_samp, value, val) == 1) return 1.0;
         return -1.0;
     case F_IMPLY_NATURAL: {                                     // 162-176 (the loop covers the head)
         for (int l = s; l < e; l++)
-            if (member(g, l, var_samp, value, val) == 0) return 0.0;
-        return member(g, e - 1, var_samp, value, val) ? 1.0 : -1.0;
+            if (member(mb, l, var_samp, value, val) == 0) return 0.0;
+        return member(mb, e - 1, var_samp, value, val) ? 1.0 : -1.0;
     }
     case F_LINEAR:
     case F_RATIO:
     case F_LOGICAL: {                                           // 201-231
-        int hd = member(g, e - 1, var_samp, value, val);
+        int hd = member(mb, e - 1, var_samp, value, val);
         int res = 0;
         for (int l = s; l < e - 1; l++) {
-            if (member(g, l, var_samp, value, val) == hd) {
+            if (member(mb, l, var_samp, value, val) == hd) {
                 if (fn == F_LOGICAL) return 1.0;
                 res++;
             }
@@ -339,52 +344,52 @@ __device__ inline double eval_factor(const DevGraph<VT> &g, const uint4 rec, int
     }
     case F_IMPLY_MLN: {                                         // 232-246
         for (int l = s; l < e - 1; l++)
-            if (member(g, l, var_samp, value, val) == 0) return 1.0;
-        return head_member(g, e - 1, var_samp, value, val, deo) ? 1.0 : 0.0;
+            if (member(mb, l, var_samp, value, val) == 0) return 1.0;
+        return head_member(g, mb, e - 1, var_samp, value, val, deo) ? 1.0 : 0.0;
     }
     case F_AND_CAT:
     case F_EQUAL_CAT_CONST:                                     // 251-258
         for (int l = s; l < e; l++)
-            if (member_deo(g, l, var_samp, value, val, deo) != deo) return 0.0;
+            if (member_deo(mb, l, var_samp, value, val, deo) != deo) return 0.0;
         return 1.0;
     case F_OR_CAT:                                              // 259-265
         for (int l = s; l < e; l++)
-            if (member_deo(g, l, var_samp, value, val, deo) == deo) return 1.0;
+            if (member_deo(mb, l, var_samp, value, val, deo) == deo) return 1.0;
         return -1.0;
     case F_IMPLY_NATURAL_CAT: {                                 // 266-280
         for (int l = s; l < e - 1; l++)
-            if (member_deo(g, l, var_samp, value, val, deo) != deo) return 0.0;
-        return head_member(g, e - 1, var_samp, value, val, deo) == deo ? 1.0 : -1.0;
+            if (member_deo(mb, l, var_samp, value, val, deo) != deo) return 0.0;
+        return head_member(g, mb, e - 1, var_samp, value, val, deo) == deo ? 1.0 : -1.0;
     }
     case F_IMPLY_MLN_CAT: {                                     // 281-295
         for (int l = s; l < e - 1; l++)
-            if (member_deo(g, l, var_samp, value, val, deo) != deo) return 1.0;
-        return head_member(g, e - 1, var_samp, value, val, deo) == deo ? 1.0 : 0.0;
+            if (member_deo(mb, l, var_samp, value, val, deo) != deo) return 1.0;
+        return head_member(g, mb, e - 1, var_samp, value, val, deo) == deo ? 1.0 : 0.0;
     }
     case F_DP_GEN_CLASS_PRIOR:                                  // 301-305
-        return member(g, s, var_samp, value, val) == 1 ? 1.0 : -1.0;
+        return member(mb, s, var_samp, value, val) == 1 ? 1.0 : -1.0;
     case F_DP_GEN_LF_PRIOR: {                                   // 306-315
-        int l0 = member(g, s, var_samp, value, val);
+        int l0 = member(mb, s, var_samp, value, val);
         return l0 == 2 ? -1.0 : (l0 == 0 ? 0.0 : 1.0);
     }
     case F_DP_GEN_LF_PROPENSITY: {                              // 316-320
-        int l0 = member(g, s, var_samp, value, val);
-        return l0 == g.v_card[g.m_rec[s].x] - 1 ? 0.0 : 1.0;
+        int l0 = member(mb, s, var_samp, value, val);
+        return l0 == g.v_card[mb[s].x] - 1 ? 0.0 : 1.0;
     }
     case F_DP_GEN_LF_ACCURACY:
     case F_DP_GEN_LF_CLASS_PROPENSITY: {                        // 321-346
-        int y = member(g, s, var_samp, value, val);
-        int l1 = member(g, s + 1, var_samp, value, val);
-        if (l1 == g.v_card[g.m_rec[s + 1].x] - 1) return 0.0;
+        int y = member(mb, s, var_samp, value, val);
+        int l1 = member(mb, s + 1, var_samp, value, val);
+        if (l1 == g.v_card[mb[s + 1].x] - 1) return 0.0;
         if (fn == F_DP_GEN_LF_ACCURACY) return y == l1 ? 1.0 : -1.0;
         return y == 1 ? 1.0 : -1.0;
     }
     case F_DP_GEN_DEP_FIXING:
     case F_DP_GEN_DEP_REINFORCING: {                            // 347-380
-        int y = member(g, s, var_samp, value, val);
-        int l1 = member(g, s + 1, var_samp, value, val);
-        int l2 = member(g, s + 2, var_samp, value, val);
-        if (l1 == g.v_card[g.m_rec[s + 1].x] - 1) return l2 != 1 ? -1.0 : 0.0;
+        int y = member(mb, s, var_samp, value, val);
+        int l1 = member(mb, s + 1, var_samp, value, val);
+        int l2 = member(mb, s + 2, var_samp, value, val);
+        if (l1 == g.v_card[mb[s + 1].x] - 1) return l2 != 1 ? -1.0 : 0.0;
         if (fn == F_DP_GEN_DEP_FIXING) {
             if (l1 == 0 && l2 == 1 && y == 1) return 1.0;
             if (l1 == 1 && l2 == 0 && y == 0) return 1.0;
@@ -395,18 +400,18 @@ __device__ inline double eval_factor(const DevGraph<VT> &g, const uint4 rec, int
         return 0.0;
     }
     case F_DP_GEN_DEP_EXCLUSIVE: {                              // 381-387
-        int l1 = member(g, s, var_samp, value, val);
-        int l2 = member(g, s + 1, var_samp, value, val);
-        int abstain = g.v_card[g.m_rec[s].x] - 1;
+        int l1 = member(mb, s, var_samp, value, val);
+        int l2 = member(mb, s + 1, var_samp, value, val);
+        int abstain = g.v_card[mb[s].x] - 1;
         return (l1 == abstain || l2 == abstain) ? 0.0 : -1.0;
     }
     case F_DP_GEN_DEP_SIMILAR:                                  // 388-393
-        return member(g, s, var_samp, value, val) == member(g, s + 1, var_samp, value, val)
+        return member(mb, s, var_samp, value, val) == member(mb, s + 1, var_samp, value, val)
                    ? 1.0 : 0.0;
     case F_UFO: {                                               // 398-405
-        int v = member(g, s, var_samp, value, val);
+        int v = member(mb, s, var_samp, value, val);
         if (v == 0) return 0.0;
-        return (double)member(g, s + v - 1, var_samp, value, val);
+        return (double)member(mb, s + v - 1, var_samp, value, val);
     }
     default:
         return 0.0;
@@ -423,7 +428,7 @@ __device__ inline double potential(const DevGraph<VT> &g, int var_samp, int valu
     const int b = g.slot_off[slot], e = g.slot_off[slot + 1];
     for (int k = b; k < e; k++) {
         const uint4 rec = g.f_rec[g.fidx[k]];
-        const double t = g.w[rec.z] * eval_factor(g, rec, var_samp, value, val);
+        const double t = g.w[rec.z] * eval_factor(g, rec, g.m_rec, var_samp, value, val);
         p = p + t;
     }
     return p;
@@ -439,16 +444,53 @@ __device__ inline void potential2(const DevGraph<VT> &g, int var_samp, int slot,
     for (int k = b; k < e; k++) {
         const uint4 rec = g.f_rec[g.fidx[k]];
         const double w = g.w[rec.z];
-        const double t0 = w * eval_factor(g, rec, var_samp, 0, val);
-        const double t1 = w * eval_factor(g, rec, var_samp, 1, val);
+        const double t0 = w * eval_factor(g, rec, g.m_rec, var_samp, 0, val);
+        const double t1 = w * eval_factor(g, rec, g.m_rec, var_samp, 1, val);
         p0 = p0 + t0;
         p1 = p1 + t1;
     }
 }
 
+// The same two functions over the inline generic stream: records of the slot are read one after
+// the other (header units, then the members), no index chasing.
+template <typename VT>
+__device__ inline double potential_inl(const DevGraph<VT> &g, int var_samp, int value, int slot,
+                                       const VT *val) {
+    double p = 0.0;
+    const int n = g.slot_off[slot + 1] - g.slot_off[slot];
+    const uint2 *r = g.gstream + g.gs_off[slot];
+    for (int k = 0; k < n; k++) {
+        const uint2 h0 = r[0], h1 = r[1], h3 = r[3];
+        const uint4 rec = {h0.x, h1.x, h0.y, 0u};
+        const double t = g.w[h0.y] * eval_factor(g, rec, (const int2 *)(r + 4) - (int)h1.x, var_samp, value, val);
+        p = p + t;
+        r += 4 + h3.x;
+    }
+    return p;
+}
+
+template <typename VT>
+__device__ inline void potential2_inl(const DevGraph<VT> &g, int var_samp, int slot, const VT *val,
+                                      double &p0, double &p1) {
+    p0 = 0.0; p1 = 0.0;
+    const int n = g.slot_off[slot + 1] - g.slot_off[slot];
+    const uint2 *r = g.gstream + g.gs_off[slot];
+    for (int k = 0; k < n; k++) {
+        const uint2 h0 = r[0], h1 = r[1], h3 = r[3];
+        const uint4 rec = {h0.x, h1.x, h0.y, 0u};
+        const int2 *mb = (const int2 *)(r + 4) - (int)h1.x;
+        const double w = g.w[h0.y];
+        const double t0 = w * eval_factor(g, rec, mb, var_samp, 0, val);
+        const double t1 = w * eval_factor(g, rec, mb, var_samp, 1, val);
+        p0 = p0 + t0;
+        p1 = p1 + t1;
+        r += 4 + h3.x;
+    }
+}
+
 // draw_sample (inference.py:36-52) given the uniform u: Z[k] = running sum of exp(potential),
 // z = u * Z[card-1], result = first k with Z[k] >= z (0 if none, like np.argmax of all-False).
-template <typename VT>
+template <typename VT, bool INL = false>
 __device__ inline int draw_sample(const DevGraph<VT> &g, int var_samp, uint32_t info, int slot0,
                                   const VT *val, double u) {
     const int card = NSK_INFO_CARD(info);
@@ -456,10 +498,11 @@ __device__ inline int draw_sample(const DevGraph<VT> &g, int var_samp, uint32_t 
     if (card == 2) {
         double p0, p1;
         if (step) {
-            p0 = potential(g, var_samp, 0, slot0, val);
-            p1 = potential(g, var_samp, 1, slot0 + 1, val);
+            p0 = (INL ? potential_inl(g, var_samp, 0, slot0, val) : potential(g, var_samp, 0, slot0, val));
+            p1 = (INL ? potential_inl(g, var_samp, 1, slot0 + 1, val) : potential(g, var_samp, 1, slot0 + 1, val));
         } else {
-            potential2(g, var_samp, slot0, val, p0, p1);
+            if (INL) potential2_inl(g, var_samp, slot0, val, p0, p1);
+            else potential2(g, var_samp, slot0, val, p0, p1);
         }
         const double z0 = nsk_exp(p0);
         const double z1 = z0 + nsk_exp(p1);
@@ -470,7 +513,8 @@ __device__ inline int draw_sample(const DevGraph<VT> &g, int var_samp, uint32_t 
         double Z[NSK_ZLOCAL];
         double acc = 0.0;
         for (int k = 0; k < card; k++) {
-            const double ek = nsk_exp(potential(g, var_samp, k, slot0 + step * k, val));
+            const double ek = nsk_exp(INL ? potential_inl(g, var_samp, k, slot0 + step * k, val)
+                                           : potential(g, var_samp, k, slot0 + step * k, val));
             acc = (k == 0) ? ek : acc + ek;
             Z[k] = acc;
         }
@@ -482,13 +526,15 @@ __device__ inline int draw_sample(const DevGraph<VT> &g, int var_samp, uint32_t 
     // large domains: two passes, the second recomputes the identical running sums
     double acc = 0.0;
     for (int k = 0; k < card; k++) {
-        const double ek = nsk_exp(potential(g, var_samp, k, slot0 + step * k, val));
+        const double ek = nsk_exp(INL ? potential_inl(g, var_samp, k, slot0 + step * k, val)
+                                           : potential(g, var_samp, k, slot0 + step * k, val));
         acc = (k == 0) ? ek : acc + ek;
     }
     const double z = u * acc;
     double run = 0.0;
     for (int k = 0; k < card; k++) {
-        const double ek = nsk_exp(potential(g, var_samp, k, slot0 + step * k, val));
+        const double ek = nsk_exp(INL ? potential_inl(g, var_samp, k, slot0 + step * k, val)
+                                           : potential(g, var_samp, k, slot0 + step * k, val));
         run = (k == 0) ? ek : run + ek;
         if (run >= z) return k;
     }
@@ -517,7 +563,7 @@ __device__ inline double wave_potential(const DevGraph<VT> &g, int var_samp, int
         double t = 0.0;
         if (base + lane < e) {
             const uint4 rec = g.f_rec[g.fidx[base + lane]];
-            t = g.w[rec.z] * eval_factor(g, rec, var_samp, value, val);
+            t = g.w[rec.z] * eval_factor(g, rec, g.m_rec, var_samp, value, val);
         }
         const int n = min(64, e - base);
         for (int i = 0; i < n; i++) p = p + lane_value(t, i);
@@ -537,8 +583,8 @@ __device__ inline void wave_potential2(const DevGraph<VT> &g, int var_samp, int 
         if (base + lane < e) {
             const uint4 rec = g.f_rec[g.fidx[base + lane]];
             const double w = g.w[rec.z];
-            t0 = w * eval_factor(g, rec, var_samp, 0, val);
-            t1 = w * eval_factor(g, rec, var_samp, 1, val);
+            t0 = w * eval_factor(g, rec, g.m_rec, var_samp, 0, val);
+            t1 = w * eval_factor(g, rec, g.m_rec, var_samp, 1, val);
         }
         const int n = min(64, e - base);
         for (int i = 0; i < n; i++) { p0 = p0 + lane_value(t0, i); p1 = p1 + lane_value(t1, i); }

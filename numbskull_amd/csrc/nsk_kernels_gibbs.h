@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_WAVES) void k_gibbs_phase(De
     const int v = g.p_vid[p];
     if (v < 0) return;
     const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-    const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));
+    const int nv = draw_sample<VT, true>(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));   // inline stream
     g.val[v] = (VT)nv;
     if (!burnin) {                                      // inference.py:29-33
         const int base = g.p_cnt[p];

@@ -51,7 +51,7 @@ __device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink
 // Generic learning kernel.  Work items are 64-position groups: item i covers positions
 // pbegin + 64 i (range mode) or list[i] (list mode: the per-lane-header tiles of the fast range),
 // clipped at pend.  A persistent grid strides over the items so that SMALLW blocks flush once.
-template <typename VT, bool SMALLW>
+template <typename VT, bool SMALLW, bool INL>
 __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_phase(DevGraph<VT> g, int pbegin, int pend,
                                                            const uint32_t *list, int nitems,
                                                            LearnParams lp) {
@@ -64,16 +64,17 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
         const int p = (list ? (int)list[item] : pbegin + 64 * item) + lane;
         bool more = false, truncate = false;
         int v = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
+        const uint2 *ra = nullptr, *rb = nullptr;        // INL: cursors into the inline records
         if (p < pend && g.p_vid[p] >= 0) {
             const uint32_t info = g.p_info[p];
             const int ev = NSK_INFO_EV(info);
             const int slot0 = g.p_slot[p];
             v = g.p_vid[p];
             const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
-            if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
-            else evidence = (int)g.p_init[p];                                                     // 61-62
+            if (ev != 1) evidence = draw_sample<VT, INL>(g, v, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
+            else evidence = (int)g.p_init[p];                                                            // 61-62
             g.val_evid[v] = (VT)evidence;
-            proposal = draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
+            proposal = draw_sample<VT, INL>(g, v, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
             g.val[v] = (VT)proposal;
             if (lp.learn_non_evidence || ev == 1) {                                               // 71-72
                 if (lp.regularization == 1) {                                                     // 90
@@ -81,11 +82,14 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
                     truncate = u53(t.x, t.y) < lp.inv_trunc;
                 }
                 const int step = NSK_INFO_DT1(info);
-                a = g.slot_off[slot0 + step * evidence];
-                ae = g.slot_off[slot0 + step * evidence + 1];
+                const int sa = slot0 + step * evidence;
+                a = g.slot_off[sa];
+                ae = g.slot_off[sa + 1];
+                if (INL) ra = g.gstream + g.gs_off[sa];
                 if (step && evidence != proposal) {
                     b = g.slot_off[slot0 + proposal];
                     be = g.slot_off[slot0 + proposal + 1];
+                    if (INL) rb = g.gstream + g.gs_off[slot0 + proposal];
                 }
                 more = (a < ae) || (b < be);
             }
@@ -97,18 +101,35 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
             int wid = 0;
             long long gfix = 0;
             if (more) {
-                const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
-                const int fb = b < be ? g.fidx[b] : 0x7fffffff;
-                const int fid = fa < fb ? fa : fb;
-                if (fa == fid) a++;
-                if (fb == fid) b++;
+                uint4 rec;
+                const int2 *mb;
+                double feat;
+                if (INL) {
+                    const int fa = a < ae ? (int)ra[1].y : 0x7fffffff;
+                    const int fb = b < be ? (int)rb[1].y : 0x7fffffff;
+                    const uint2 *r = fa <= fb ? ra : rb;
+                    const uint2 h0 = r[0], h1 = r[1], h2 = r[2];
+                    rec = uint4{h0.x, h1.x, h0.y, 0u};
+                    mb = (const int2 *)(r + 4) - (int)h1.x;
+                    feat = __longlong_as_double(((long long)h2.y << 32) | (long long)h2.x);
+                    if (fa <= fb) { ra += 4 + ra[3].x; a++; }
+                    if (fb <= fa) { rb += 4 + rb[3].x; b++; }
+                } else {
+                    const int fa = a < ae ? g.fidx[a] : 0x7fffffff;
+                    const int fb = b < be ? g.fidx[b] : 0x7fffffff;
+                    const int fid = fa < fb ? fa : fb;
+                    if (fa == fid) a++;
+                    if (fb == fid) b++;
+                    rec = g.f_rec[fid];
+                    mb = g.m_rec;
+                    feat = g.f_feat[fid];
+                }
                 more = (a < ae) || (b < be);
-                const uint4 rec = g.f_rec[fid];
                 wid = (int)rec.z;
                 if (!g.w_fixed[wid]) {                                                            // 100-101
-                    const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
-                    const double p1 = eval_factor(g, rec, v, proposal, g.val);
-                    const double gradient = (p1 - p0) * g.f_feat[fid];                            // 109
+                    const double p0 = eval_factor(g, rec, mb, v, evidence, g.val_evid);
+                    const double p1 = eval_factor(g, rec, mb, v, proposal, g.val);
+                    const double gradient = (p1 - p0) * feat;                                     // 109
                     gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
                     have = true;
                 }
@@ -170,8 +191,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_heavy(DevGraph<VT> g, int p
                 const uint4 rec = g.f_rec[fid];
                 wid = (int)rec.z;
                 if (!dup && !g.w_fixed[wid]) {
-                    const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
-                    const double p1 = eval_factor(g, rec, v, proposal, g.val);
+                    const double p0 = eval_factor(g, rec, g.m_rec, v, evidence, g.val_evid);
+                    const double p1 = eval_factor(g, rec, g.m_rec, v, proposal, g.val);
                     gfix = __double2ll_rn(((p1 - p0) * g.f_feat[fid]) * NSK_GRAD_SCALE);
                     have = true;
                 }

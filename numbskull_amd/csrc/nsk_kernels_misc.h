@@ -138,8 +138,8 @@ __global__ void k_seq_learn(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rn
                 const uint4 rec = g.f_rec[fid];
                 const int wid = (int)rec.z;
                 if (g.w_fixed[wid]) continue;
-                const double p0 = eval_factor(g, rec, v, evidence, g.val_evid);
-                const double p1 = eval_factor(g, rec, v, proposal, g.val);
+                const double p0 = eval_factor(g, rec, g.m_rec, v, evidence, g.val_evid);
+                const double p1 = eval_factor(g, rec, g.m_rec, v, proposal, g.val);
                 const double gradient = (p1 - p0) * g.f_feat[fid];
                 double w = g.w[wid];
                 if (regularization == 2) {
