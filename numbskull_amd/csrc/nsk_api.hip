@@ -62,6 +62,11 @@ struct nsk_graph {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // the kernels of one colour class are independent: hubs and generic-path variables run on side
+    // streams next to the tile kernels (fork/join with events around every colour)
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool no_overlap = getenv("NSK_NO_OVERLAP") != nullptr;     // diagnostic: one stream
     std::vector<void *> allocs;
     int64_t device_bytes = 0;
     // device arrays
@@ -212,6 +217,11 @@ int nsk_graph_destroy(nsk_graph *g) {
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)g->rccl_comm);
     if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
+    for (int i = 0; i < 2; i++) {
+        if (g->side[i]) (void)hipStreamDestroy(g->side[i]);
+        if (g->ev_join[i]) (void)hipEventDestroy(g->ev_join[i]);
+    }
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     delete g;
     return NSK_OK;
 }
@@ -230,6 +240,11 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     HIPCHECK(hipSetDevice(g->device));
     HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     g->own_stream = true;
+    for (int i = 0; i < 2; i++) {
+        HIPCHECK(hipStreamCreateWithFlags(&g->side[i], hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&g->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHECK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
     HIPCHECK(hipEventCreate(&g->ev0));
     HIPCHECK(hipEventCreate(&g->ev1));
     Compiled &c = g->c;
@@ -366,6 +381,30 @@ static int fold_counts(nsk_graph *g) {
 
 }  // extern "C"
 
+// Streams for the kernels of one colour: the tile kernels stay on the main stream; when there are
+// tile kernels to overlap with, hubs go to side stream 0 and the generic kernel to side stream 1.
+struct ColourStreams {
+    nsk_graph *g;
+    bool forked[2] = {false, false};
+    bool overlap;
+    ColourStreams(nsk_graph *g_, bool overlap_) : g(g_), overlap(overlap_) {
+        if (overlap) (void)hipEventRecord(g->ev_fork, g->stream);
+    }
+    hipStream_t side(int i) {
+        if (!overlap) return g->stream;
+        if (!forked[i]) { (void)hipStreamWaitEvent(g->side[i], g->ev_fork, 0); forked[i] = true; }
+        return g->side[i];
+    }
+    void join() {
+        for (int i = 0; i < 2; i++)
+            if (forked[i]) {
+                (void)hipEventRecord(g->ev_join[i], g->side[i]);
+                (void)hipStreamWaitEvent(g->stream, g->ev_join[i], 0);
+                forked[i] = false;
+            }
+    }
+};
+
 template <typename VT>
 static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
     DevGraph<VT> d = view<VT>(g);
@@ -382,6 +421,20 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
             for (size_t ph = 0; ph < nphase; ph++) {
                 const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
                 const int e = (int)g->c.phase_start[ph + 1];
+                const int he = (int)g->c.phase_heavy_end[ph];
+                ColourStreams cs(g, !g->no_overlap && (int)(fe > fb) + (int)(he > fe) + (int)(e > he) >= 2);
+                if (he > fe) {      // hubs: one wave per variable
+                    k_gibbs_heavy<VT><<<dim3((he - fe + 3) / 4), dim3(NSK_BLOCK), 0, cs.side(0)>>>(
+                        d, fe, he, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                    g->launches++;
+                }
+                if (e > he) {       // generic CSR kernel, one lane per variable
+                    k_gibbs_phase<VT><<<dim3((e - he + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, cs.side(1)>>>(
+                        d, he, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                    g->launches++;
+                }
                 if (fe > fb) {      // inlined-adjacency kernels
                     const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
                     const uint32_t S0 = (uint32_t)g->sweep, S1 = (uint32_t)(g->sweep >> 32);
@@ -428,19 +481,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         g->launches++;
                     }
                 }
-                const int he = (int)g->c.phase_heavy_end[ph];
-                if (he > fe) {      // hubs: one wave per variable
-                    k_gibbs_heavy<VT><<<dim3((he - fe + 3) / 4), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        d, fe, he, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
-                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
-                    g->launches++;
-                }
-                if (e > he) {       // generic CSR kernel, one lane per variable
-                    k_gibbs_phase<VT><<<dim3((e - he + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        d, he, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
-                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
-                    g->launches++;
-                }
+                cs.join();
             }
             g->sweep++;
             if (!burnin && ++g->pos_tally_sweeps == 255) fold_position_tally(g);   // uint8 tally is full
@@ -484,6 +525,24 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             int rows = 0;
             const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
+            const int he = (int)g->c.phase_heavy_end[ph];
+            ColourStreams cs(g, !g->no_overlap && (int)(fe > fb) + (int)(he > fe) + (int)(e > he) >= 2);
+            if (he > fe) {              // hubs: one wave per variable
+                const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
+                lp.row_base = rows;
+                k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(0)>>>(d, fe, he, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (e > he) {               // variables outside the fast path: generic kernel, range mode
+                const int nitems = (e - he + 63) / 64;
+                const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
+                lp.row_base = rows;
+                k_learn_phase<VT, SMALLW, true><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(1)>>>(
+                    d, he, e, nullptr, nitems, lp);
+                rows += grid;
+                g->launches++;
+            }
             if (ntiles > ndyn) {        // uniform tiles: inlined-adjacency learning kernel
                 const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (ntiles + 3) / 4);
                 lp.row_base = rows;
@@ -500,23 +559,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 rows += grid;
                 g->launches++;
             }
-            const int he = (int)g->c.phase_heavy_end[ph];
-            if (he > fe) {              // hubs: one wave per variable
-                const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
-                lp.row_base = rows;
-                k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, fe, he, lp);
-                rows += grid;
-                g->launches++;
-            }
-            if (e > he) {               // variables outside the fast path: generic kernel, range mode
-                const int nitems = (e - he + 63) / 64;
-                const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
-                lp.row_base = rows;
-                k_learn_phase<VT, SMALLW, true><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
-                    d, he, e, nullptr, nitems, lp);
-                rows += grid;
-                g->launches++;
-            }
+            cs.join();
             if (nw > 0) {
                 if (SMALLW) {
                     k_apply_weights_rows<<<dim3(nw), dim3(NSK_BLOCK), 0, g->stream>>>(

@@ -13,7 +13,9 @@
 namespace nsk {
 
 // a variable whose factor lists hold at least this many entries in total is sampled by a whole wave
-static const int64_t NSK_HEAVY_LIST = 128;
+static const int64_t NSK_HEAVY_LIST = 32;
+// ... and so is every generic-path variable of a colour class that has at most this many of them
+static const int64_t NSK_FEW_GENERIC = 32768;
 
 bool known_function(int fn) {
     switch (fn) {
@@ -327,6 +329,87 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         fast[v] = ok;
     }
 
+    // ---- general tiles (kind 6): variables of cardinality <= 8 and any dataType whose factors are
+    // boolean symmetric functions, IMPLY_MLN or the categorical *_CAT functions.  Stream words per
+    // entry: W0 = weight id; W1 = code | others << 4 | own role << 7 (1 body, 2 head of a positional
+    // function) | own dense_equal_to << 9 | owning candidate value << 14 (15 = every candidate,
+    // dataType 0; 14 = none, padding entry); then one word per other member: id |
+    // dense_equal_to << 27 (id NSK_GEN_NULL = empty slot).  Every such entry evaluates to
+    // (candidate == c) ? A : B with c, A, B known once the other members have been read.
+    auto general_code = [](int fn) -> int {
+        switch (fn) {
+        case -1: return 0; case 0: return 1; case 1: return 2; case 2: case 4: return 3; case 3: return 4;
+        case 13: return 5; case 12: case 15: return 6; case 14: return 7; case 16: return 8; case 17: return 9;
+        default: return -1;
+        }
+    };
+    const bool no_general = getenv("NSK_NO_GENERAL") != nullptr;
+    auto general_words = [&](int64_t v, std::vector<uint32_t> *out) -> bool {
+        const nsk_variable &var = d->variable[v];
+        if (var.cardinality > 8 || var.cardinality < 2) return false;
+        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+        size_t nwords = 0, nentries = 0;
+        if (out) out->clear();
+        for (int64_t k = 0; k < nslots; k++) {
+            const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+            for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
+                const int code = general_code(fa.factorFunction);
+                if (code < 0 || fa.featureValue != 1.0 || fa.arity > 64) return false;
+                const bool positional = code == 5 || code == 8 || code == 9;
+                const bool cat = code >= 6;
+                const int64_t s = fa.ftv_offset, e = s + fa.arity;
+                int64_t others = 0, self_deo = -1, self_body = 0, self_head = 0;
+                uint32_t mem[8];
+                if (code == 0 && var.dataType != 0) {         // NOOP: only "one list per factor" matters
+                    for (int64_t l = s; l < e; l++) {
+                        if (d->fmap[l].vid != v) continue;
+                        if (self_deo >= 0 && self_deo != d->fmap[l].dense_equal_to) return false;
+                        self_deo = d->fmap[l].dense_equal_to;
+                    }
+                }
+                if (code != 0) {
+                    for (int64_t l = s; l < e; l++) {
+                        const int64_t vid = d->fmap[l].vid, deo = d->fmap[l].dense_equal_to;
+                        if (vid == v) {
+                            // repeated own edges: fine while they agree on dense_equal_to where it
+                            // matters (categorical functions; dataType 1, whose lists are keyed by it)
+                            if (cat || var.dataType != 0) {
+                                if (cat && (deo < 0 || deo > 31)) return false;
+                                if (self_deo >= 0 && self_deo != deo) return false;
+                                self_deo = deo;
+                            }
+                            if (l == e - 1) self_head++; else self_body++;
+                        } else {
+                            if (others >= 6) return false;
+                            int64_t rd = vid;                                  // index the value is read at
+                            if (positional && l == e - 1 && !head_by_vid) rd = l;   // inference.py:243,277,292
+                            if (rd >= (int64_t)NSK_GEN_NULL) return false;
+                            int64_t dd = cat ? deo : 0;
+                            if (dd < 0 || dd > 31) return false;
+                            mem[others++] = (uint32_t)rd | ((uint32_t)dd << 27);
+                        }
+                    }
+                    if (self_body + self_head == 0) return false;
+                    if (positional && self_body > 0 && self_head > 0) return false;
+                }
+                const uint32_t role = !positional ? 0u : (self_head ? 2u : 1u);
+                const uint32_t kslot = var.dataType == 0 ? 15u : (uint32_t)k;
+                nwords += 2 + (size_t)others;
+                if (nwords > 120 || ++nentries > 24) return false;
+                if (out) {
+                    out->push_back((uint32_t)fa.weightId);
+                    out->push_back((uint32_t)code | ((uint32_t)others << 4) | (role << 7) |
+                                   ((uint32_t)(cat && self_deo > 0 ? self_deo : 0) << 9) | (kslot << 14));
+                    for (int64_t m = 0; m < others; m++) out->push_back(mem[m]);
+                }
+            }
+        }
+        return true;
+    };
+    for (int64_t v = 0; v < nvar; v++)
+        if (c.color[v] >= 0 && !fast[v] && !no_fast && !no_general && general_words(v, nullptr)) fast[v] = 2;
+
     // ---- positions: colour-major.  Inside a colour: the fast variables grouped by "shape class"
     // -- the sequence of (function, member count, weight id) of their factor lists plus their
     // evidence flag -- so that the 64 lanes of a tile share one slot program; every class with at
@@ -338,11 +421,15 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     c.v_pos.assign(nvar, -1);
     {
         // sig: exact program (function, member count, weight id per entry, evidence flag);
-        // shp: shape only (member count per entry, evidence flag), 0 when the variable's stream
-        //      would exceed 16 words
+        // shp: shape only (member count per entry, evidence flag), 0 when the stream would exceed
+        //      16 words.  General-tile variables are not classed: they are sorted (below).
         std::vector<uint64_t> sig(nvar, 0), shp(nvar, 0);
+        std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0), ngt_of((size_t)ncolors, 0);
         for (int64_t v = 0; v < nvar; v++) {
-            if (c.color[v] < 0 || !fast[v]) continue;
+            if (c.color[v] < 0) continue;
+            if (fast[v] == 2) { ngt_of[c.color[v]]++; continue; }
+            if (!fast[v]) { ngen_of[c.color[v]]++; continue; }
+            nfast_of[c.color[v]]++;
             const nsk_variable &var = d->variable[v];
             const nsk_vtf &vt = d->vmap[var.vtf_offset];
             uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence, h2 = h ^ 0x9e3779b97f4a7c15ull;
@@ -365,17 +452,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         typedef std::map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
         std::vector<ClassMap> classes((size_t)ncolors), shapes((size_t)ncolors);
-        std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0);
         for (int64_t v = 0; v < nvar; v++) {
             const int32_t k = c.color[v];
-            if (k < 0) continue;
-            if (fast[v]) {
-                auto &e = classes[k][sig[v]];
-                if (e.first++ == 0) e.second = v;
-                nfast_of[k]++;
-            } else {
-                ngen_of[k]++;
-            }
+            if (k < 0 || fast[v] != 1) continue;
+            auto &e = classes[k][sig[v]];
+            if (e.first++ == 0) e.second = v;
         }
         // a class gets tiles of its own when it fills at least one (64 members) -- or whatever its
         // size when the colour has only a few small classes (then padding them costs nothing
@@ -389,12 +470,23 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // variables outside the big exact classes are grouped by shape
         for (int64_t v = 0; v < nvar; v++) {
             const int32_t k = c.color[v];
-            if (k < 0 || !fast[v] || shp[v] == 0) continue;
-            if (classes[k][sig[v]].first >= min_class[k]) continue;
+            if (k < 0 || fast[v] != 1 || shp[v] == 0 || classes[k][sig[v]].first >= min_class[k]) continue;
             auto &e = shapes[k][shp[v]];
             if (e.first++ == 0) e.second = v;
         }
-        std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0);
+        // what neither an exact nor a shape class can take would end in mixed tiles with per-lane
+        // parsing: the general tiles' sorted layout serves those variables better
+        for (int64_t v = 0; v < nvar && !no_general; v++) {
+            const int32_t k = c.color[v];
+            if (k < 0 || fast[v] != 1 || classes[k][sig[v]].first >= min_class[k]) continue;
+            if (shp[v] != 0 && shapes[k][shp[v]].first >= 64) continue;
+            if (!general_words(v, nullptr)) continue;
+            if (shp[v] != 0) shapes[k][shp[v]].first--;
+            fast[v] = 2;
+            nfast_of[k]--;
+            ngt_of[k]++;
+        }
+        std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
         std::vector<std::vector<int64_t>> gen_bin_start;
         std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors);
         int64_t pos = 0;
@@ -418,6 +510,9 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             tail_at[k] = pos;
             pos += nfast_of[k] - nbig;
             pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
+            gt_at[k] = pos;                                                     // general tiles
+            pos += ngt_of[k];
+            pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
             c.phase_fast_end[k] = pos;
             next_gen[k] = pos;
             pos += ngen_of[k];
@@ -430,6 +525,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // generic-path variables of a colour are ordered by the work of one update (factor-list
         // lengths x arities over all candidate values, binned) so that the 64 lanes of a wave finish
         // together; inside a bin: variable id.
+        std::vector<uint32_t> gw;
         std::vector<uint8_t> work_bin(nvar, 0);
         for (int64_t v = 0; v < nvar; v++) {
             if (c.color[v] < 0 || fast[v]) continue;
@@ -449,6 +545,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             // hubs: a whole wave works on one such variable (k_gibbs_heavy / k_learn_heavy)
             if (listlen >= NSK_HEAVY_LIST && !getenv("NSK_NO_HEAVY")) work_bin[v] = 0;
         }
+        // a colour with few generic-path variables gives every one of them a wave: the one-lane
+        // kernel's run time is the latency of its longest serial walk however few lanes are busy
+        if (!getenv("NSK_NO_HEAVY"))
+            for (int64_t v = 0; v < nvar; v++)
+                if (c.color[v] >= 0 && !fast[v] && ngen_of[c.color[v]] <= NSK_FEW_GENERIC) work_bin[v] = 0;
         {
             std::vector<std::vector<int64_t>> bin_count((size_t)ncolors, std::vector<int64_t>(42, 0));
             for (int64_t v = 0; v < nvar; v++)
@@ -461,9 +562,34 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 c.phase_heavy_end[k] = gen_bin_start[k][1];              // bin 0 = the hubs
             }
         }
+        // general-tile variables of a colour: sorted by (entries, most other members of an entry),
+        // largest first, and cut into tiles of 64 -- a tile's layout is the maximum over its lanes,
+        // so neighbours in this order waste the least padding (SELL-C-sigma)
+        {
+            std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (-key, vid)
+            for (int64_t v = 0; v < nvar; v++) {
+                if (c.color[v] < 0 || fast[v] != 2) continue;
+                general_words(v, &gw);
+                int64_t ne = 0, mo = 0;
+                for (size_t j = 0; j < gw.size(); j += 2 + ((gw[j + 1] >> 4) & 7u)) {
+                    ne++;
+                    mo = std::max<int64_t>(mo, (gw[j + 1] >> 4) & 7u);
+                }
+                order[c.color[v]].push_back({-(ne * 8 + mo), v});
+            }
+            for (int32_t k = 0; k < ncolors; k++) {
+                std::sort(order[k].begin(), order[k].end());
+                for (auto &o : order[k]) {
+                    const int64_t p = gt_at[k]++;
+                    c.p_vid[p] = (int32_t)o.second;
+                    c.v_pos[o.second] = (int32_t)p;
+                    c.nsampled++;
+                }
+            }
+        }
         for (int64_t v = 0; v < nvar; v++) {
             const int32_t k = c.color[v];
-            if (k < 0) continue;
+            if (k < 0 || fast[v] == 2) continue;
             int64_t p;
             if (!fast[v]) p = gen_bin_start[k][work_bin[v]]++;
             else {
@@ -520,6 +646,48 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 bool uniform = true, shape_tile = false;
                 (void)shape_tile;
                 bool have0 = false, same_shape = true;
+                bool gen_tile = false;                             // general tile (kind 6)
+                for (int64_t p = p0; p < p1 && !gen_tile; p++)
+                    if (c.p_vid[p] >= 0 && fast[c.p_vid[p]] == 2) gen_tile = true;
+                if (gen_tile) {
+                    // layout shared by the 64 lanes: E entries of 2 + M words, E and M the maxima over
+                    // the lanes.  Role program: 1 weight word | 32 descriptor word (8: no member
+                    // slots) | 16 member slot | 2 first slot | 4 last slot
+                    uint32_t E = 0, M = 0, maxcard = 2;
+                    for (int64_t p = p0; p < p1; p++) {
+                        if (c.p_vid[p] < 0) continue;
+                        general_words(c.p_vid[p], &words);
+                        uint32_t ne = 0;
+                        for (size_t j = 0; j < words.size(); j += 2 + ((words[j + 1] >> 4) & 7u)) {
+                            ne++;
+                            M = std::max(M, (words[j + 1] >> 4) & 7u);
+                        }
+                        E = std::max(E, ne);
+                        maxcard = std::max(maxcard, (uint32_t)d->variable[c.p_vid[p]].cardinality);
+                    }
+                    prog.clear();
+                    for (uint32_t e = 0; e < E; e++) {
+                        prog.push_back(1u | 0x80000000u);
+                        prog.push_back(32u | (M == 0 ? 8u : 0u) | 0x80000000u);
+                        for (uint32_t m = 0; m < M; m++)
+                            prog.push_back(16u | (m == 0 ? 2u : 0u) | (m + 1 == M ? 4u : 0u) | 0x80000000u);
+                    }
+                    auto it = hdr_pool.find(prog);
+                    if (it == hdr_pool.end()) {
+                        it = hdr_pool.emplace(prog, (uint32_t)c.tile_hdr.size()).first;
+                        c.tile_hdr.insert(c.tile_hdr.end(), prog.begin(), prog.end());
+                        c.tile_hdr.resize((c.tile_hdr.size() + 7) / 8 * 8, 0u);
+                    }
+                    len = (int64_t)E * (2 + M);
+                    td[2] = it->second;
+                    td[3] = (uint32_t)len | (6u << 8) | (maxcard << 12) | (M << 16);
+                    len = (len + 3) / 4 * 4;
+                    td[0] = (uint32_t)total4;
+                    td[1] = (uint32_t)len;
+                    total4 += (uint64_t)(len / 4) * 64;
+                    if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
+                    continue;
+                }
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;                  // padding position
                     lane_words(c.p_vid[p], words);
@@ -630,7 +798,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 bool full;
                 const int ev = tile_ev(b, full);
                 int64_t e = b + 1;
-                const bool seg_ok = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) != 7u && full && ev != -999 &&
+                const bool seg_ok = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u && full && ev != -999 &&
                                     (td[3] & 0xFFu) > 0;
                 if (seg_ok) {
                     while (e < nt) {
@@ -662,17 +830,36 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
                 const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
                 const uint64_t base = (uint64_t)td[0] * 4;
-                const bool uniform = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) != 7u;
+                const bool uniform = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u;
+                const bool general = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 6u;
                 if (td[2] != 0xFFFFFFFFu)       // uniform and shape tiles: padding reads variable / weight 0
                     for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = 0;
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;
-                    lane_words(c.p_vid[p], words);
                     size_t out = 0;
                     auto put = [&](uint32_t word) {
                         c.adj[base + 256 * (out / 4) + 4 * (uint64_t)(p - p0) + (out % 4)] = word;
                         out++;
                     };
+                    if (general) {               // entries padded to M member slots, then E entries
+                        general_words(c.p_vid[p], &words);
+                        const uint32_t M = (td[3] >> 16) & 7u, E = (td[3] & 0xFFu) / (2 + M);
+                        uint32_t ne = 0;
+                        for (size_t j = 0; j < words.size(); ne++) {
+                            const uint32_t no = (words[j + 1] >> 4) & 7u;
+                            for (uint32_t m = 0; m < 2 + no; m++) put(words[j + m]);
+                            for (uint32_t m = no; m < M; m++) put(NSK_GEN_NULL);
+                            j += 2 + no;
+                        }
+                        for (; ne < E; ne++) {                        // an entry no candidate value owns
+                            put(0u);
+                            put(14u << 14);
+                            for (uint32_t m = 0; m < M; m++) put(NSK_GEN_NULL);
+                        }
+                        c.nfast++;
+                        continue;
+                    }
+                    lane_words(c.p_vid[p], words);
                     for (size_t j = 0; j < words.size();) {
                         const uint32_t nother = (words[j] >> 24) & 7u;
                         if (!uniform) put(words[j]);

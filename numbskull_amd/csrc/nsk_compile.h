@@ -10,6 +10,8 @@
 
 #include "../../include/numbskull_amd.h"
 
+#define NSK_GEN_NULL 0x7FFFFFFu     // member id of an empty slot in a general tile (kind 6)
+
 namespace nsk {
 
 struct Compiled {

@@ -317,6 +317,183 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_shape_weights(const uint4
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// General tiles (kind 6): variables of cardinality <= 8 and either dataType whose factors are the
+// symmetric boolean functions, IMPLY_MLN or the *_CAT functions (nsk_compile.cpp "general tiles").
+// The 64 lanes share a layout of E entries x (weight word, descriptor word, M member slots); code,
+// weight, members and the candidate value an entry belongs to are per lane.  With the other
+// members read, every entry is  value(candidate c) = (c == cstar) ? A : B  with A, B in {-1, 0, 1}:
+// the restatement of eval_factor (inference.py:162-200, 232-295) as facts about the other members.
+// ---------------------------------------------------------------------------------------------
+#ifndef NSK_GEN_NULL
+#define NSK_GEN_NULL 0x7FFFFFFu
+#endif
+struct GenChain {
+    bool allnz, prevall, any1, alleq, lastnz;
+    int first;
+    __device__ __forceinline__ void open() {
+        allnz = true; prevall = true; any1 = false; alleq = true; lastnz = false; first = 0;
+    }
+    // one member slot; `cat`: the function compares with dense_equal_to instead of 0 / 1
+    __device__ __forceinline__ void member(bool F, bool cat, uint32_t word, int x) {
+        if ((word & NSK_GEN_NULL) == NSK_GEN_NULL) return;            // empty slot
+        const int deo = (int)(word >> 27);
+        const bool nz = cat ? (x == deo) : (x != 0);
+        const bool one = cat ? (x == deo) : (x == 1);
+        alleq = F || (alleq && x == first);
+        first = F ? x : first;
+        prevall = allnz;
+        allnz = allnz && nz;
+        any1 = any1 || one;
+        lastnz = nz;
+    }
+    // (c == cstar) ? A : B for the entry described by descriptor word d1
+    __device__ __forceinline__ void close(uint32_t d1, int &cstar, int &A, int &B) const {
+        const uint32_t code = d1 & 15u, role = (d1 >> 7) & 3u;
+        const bool nomember = ((d1 >> 4) & 7u) == 0u;
+        const int sdeo = (int)((d1 >> 9) & 31u);
+        const bool body = role == 1u ? prevall : allnz;               // body members all true / matching
+        const bool hd = lastnz;                                       // role 1: the head is the last member
+        cstar = 0; A = 0; B = 0;
+        if (code == 1u) { B = allnz ? 1 : 0; }                                            // IMPLY_NATURAL
+        else if (code == 2u) { cstar = 1; A = 1; B = any1 ? 1 : -1; }                     // OR
+        else if (code == 3u) { A = -1; B = allnz ? 1 : -1; }                              // AND / ISTRUE
+        else if (code == 4u) { cstar = first; A = (nomember || alleq) ? 1 : -1; B = nomember ? 1 : -1; }   // EQUAL
+        else if (code == 5u) {                                                            // IMPLY_MLN
+            if (role == 1u) { A = 1; B = !body ? 1 : (hd ? 1 : 0); }
+            else { A = !allnz ? 1 : 0; B = 1; }
+        } else if (code == 6u) { cstar = sdeo; A = allnz ? 1 : 0; }                       // AND_CAT / EQUAL_CAT_CONST
+        else if (code == 7u) { cstar = sdeo; A = 1; B = any1 ? 1 : -1; }                  // OR_CAT
+        else if (code == 8u) {                                                            // IMPLY_NATURAL_CAT
+            cstar = sdeo;
+            if (role == 1u) { A = body ? (hd ? 1 : -1) : 0; }
+            else { A = allnz ? 1 : 0; B = allnz ? -1 : 0; }
+        } else if (code == 9u) {                                                          // IMPLY_MLN_CAT
+            cstar = sdeo;
+            if (role == 1u) { A = !body ? 1 : (hd ? 1 : 0); B = 1; }
+            else { A = 1; B = allnz ? 0 : 1; }
+        }
+    }
+};
+
+// Walk a general tile over one (TWO = false) or two value arrays; on_entry(weight id, descriptor,
+// chain a, chain b) runs at every entry end -- wave-uniform control flow, so it may use wave
+// collectives.  The next 16-byte chunk is requested before the gathers of the current one.
+template <typename VT, bool TWO, typename FN>
+__device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va, const VT *vb,
+                                             const uint4 *sp, int len, uint32_t prog, FN &&on_entry) {
+    const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
+    if (len <= 0) return;
+    GenChain a, b;
+    a.open(); b.open();
+    uint32_t wid = 0, d1 = 0;
+    uint4 q = sp[0];
+    for (int c = 0; c * 4 < len; c++) {
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+        if ((c + 1) * 4 < len) q = sp[(size_t)(c + 1) * 64];
+        uint32_t role[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0x3Fu;     // scalar; 0 = padding word
+        int xa[4], xb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            xa[i] = 0; xb[i] = 0;
+            if (role[i] & 16u) {
+                const uint32_t id = wd[i] & NSK_GEN_NULL;
+                const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
+                xa[i] = (int)va[at];
+                if (TWO) xb[i] = (int)vb[at];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (role[i] & 1u) wid = wd[i];
+            else if (role[i] & 32u) {
+                d1 = wd[i];
+                a.open();
+                if (TWO) b.open();
+                if (role[i] & 8u) on_entry(wid, d1, a, b);
+            } else if (role[i] & 16u) {
+                const bool F = (role[i] & 2u) != 0, cat = (d1 & 15u) >= 6u;
+                a.member(F, cat, wd[i], xa[i]);
+                if (TWO) b.member(F, cat, wd[i], xb[i]);
+                if (role[i] & 4u) on_entry(wid, d1, a, b);
+            }
+        }
+    }
+}
+
+// potentials of the candidates 0..7 of one general tile: p[c] accumulates, in list order, the
+// rounded products weight * value exactly like potential() (inference.py:55-71)
+struct GenPot {
+    double p[8];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int c = 0; c < 8; c++) p[c] = 0.0;
+    }
+    __device__ __forceinline__ void add(int maxcard, uint32_t d1, double w, int cstar, int A, int B) {
+        const int ks = (int)((d1 >> 14) & 15u);       // candidate owning the entry; 15 = all (dataType 0)
+        const double tA = w * (double)A, tB = w * (double)B;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (c >= 2 && c >= maxcard) break;        // wave-uniform
+            const bool on = ks == 15 || ks == c;
+            const double t = on ? (c == cstar ? tA : tB) : 0.0;   // +0.0 leaves the sum unchanged
+            p[c] = p[c] + t;
+        }
+    }
+    // draw_sample (inference.py:36-52): running sums of exp, first candidate with Z[k] >= u * Z[card-1]
+    __device__ __forceinline__ int draw(int maxcard, int card, double u) const {
+        double Z[8];
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            Z[k] = 0.0;
+            if (k >= 2 && k >= maxcard) break;
+            const double ek = nsk_exp(p[k]);
+            const double next = (k == 0) ? ek : acc + ek;
+            acc = k < card ? next : acc;
+            Z[k] = acc;
+        }
+        const double z = u * acc;
+        int nv = 0;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            if (k >= 2 && k >= maxcard) continue;
+            if (k < card && Z[k] >= z) nv = k;
+        }
+        return nv;
+    }
+};
+
+template <typename VT>
+__device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const uint4 *sp, uint32_t tdw,
+                                                   uint32_t prog, int p, bool valid, int sample_evidence,
+                                                   int burnin, uint32_t k0, uint32_t k1, uint32_t s0,
+                                                   uint32_t s1) {
+    const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
+    const int v = valid ? g.p_vid[p] : 0;
+    const uint32_t info = valid ? g.p_info[p] : (2u << 9);
+    GenPot pot;
+    pot.clear();
+    general_walk<VT, false>(g, g.val, g.val, sp, len, prog,
+                            [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &) {
+                                int cstar, A, B;
+                                a.close(d1, cstar, A, B);
+                                pot.add(maxcard, d1, g.w[wid], cstar, A, B);
+                            });
+    const int ev = NSK_INFO_EV(info);
+    if (!valid || !(ev == 0 || sample_evidence)) return;
+    const int card = NSK_INFO_CARD(info);
+    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const int nv = pot.draw(maxcard, card, u53(rr.x, rr.y));
+    g.val[v] = (VT)nv;
+    if (!burnin) {
+        if (card == 2) g.cnt_pos[p] = (uint8_t)(g.cnt_pos[p] + nv);
+        else g.cnt[g.p_cnt[p] + nv] += 1;
+    }
+}
+
 template <typename VT>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pbegin, int pend,
                                                           int wb_base, int nblocks,
@@ -342,6 +519,10 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
     const uint4 *sp = g.adj + td.x + lane;
     const int len = (int)td.y;
+    if (td.z != NSK_PAD_WORD && ((td.w >> 8) & 7u) == 6u) {
+        gibbs_tile_general(g, sp, td.w, td.z, p, valid, sample_evidence, burnin, k0, k1, s0, s1);
+        return;
+    }
     // the tally byte is fetched now so that its latency overlaps the tile walk
     const uint8_t tally = (valid && !burnin) ? g.cnt_pos[p] : (uint8_t)0;
 

@@ -438,6 +438,70 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
     }
 }
 
+// One general tile (kind 6) of the learning sweep: pass 1 walks both chains for the potentials,
+// the draws follow, pass 2 walks again (cache hits) and hands every entry's gradient
+// value(proposal | free chain) - value(evidence | evidence chain) to the wave-aggregated
+// accumulators.  An entry is visited when it belongs to every candidate (dataType 0) or to the
+// evidence or the proposal value -- the union of the two factor lists of learning.py:76-95 (an
+// entry is in one list only: variables whose own edges in one factor disagree on dense_equal_to
+// stay on the generic path).
+template <typename VT>
+__device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
+                                                   uint32_t tdw, uint32_t prog, int p, bool valid,
+                                                   const LearnParams &lp) {
+    const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
+    const uint32_t info = valid ? g.p_info[p] : (2u << 9);
+    const int v = valid ? g.p_vid[p] : 0;
+    const int ev = NSK_INFO_EV(info), card = NSK_INFO_CARD(info);
+    const bool need_evid = __ballot(valid && ev != 1) != 0;
+    GenPot pf, pe;
+    pf.clear(); pe.clear();
+    if (need_evid)
+        general_walk<VT, true>(g, g.val, g.val_evid, sp, len, prog,
+                               [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &b) {
+                                   int cstar, A, B;
+                                   const double w = g.w[wid];
+                                   a.close(d1, cstar, A, B);
+                                   pf.add(maxcard, d1, w, cstar, A, B);
+                                   b.close(d1, cstar, A, B);
+                                   pe.add(maxcard, d1, w, cstar, A, B);
+                               });
+    else
+        general_walk<VT, false>(g, g.val, g.val, sp, len, prog,
+                                [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &) {
+                                    int cstar, A, B;
+                                    a.close(d1, cstar, A, B);
+                                    pf.add(maxcard, d1, g.w[wid], cstar, A, B);
+                                });
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    int evidence = valid ? (int)g.p_init[p] : 0;                                       // learning.py:61-62
+    if (need_evid && ev != 1) evidence = pe.draw(maxcard, card, u53(r.z, r.w));        // 54-58
+    const int proposal = pf.draw(maxcard, card, u53(r.x, r.y));                        // 66-70
+    if (valid) {
+        g.val_evid[v] = (VT)evidence;
+        g.val[v] = (VT)proposal;
+    }
+    const bool part = valid && (lp.learn_non_evidence || ev == 1);                     // 71-72
+    bool truncate = false;
+    if (lp.regularization == 1) {
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
+    }
+    if (__ballot(part) == 0) return;
+    general_walk<VT, true>(g, g.val, g.val_evid, sp, len, prog,
+                           [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &b) {
+                               const int ks = (int)((d1 >> 14) & 15u);
+                               const bool mine = ks == 15 || ks == evidence || ks == proposal;
+                               int cf, Af, Bf, ce, Ae, Be;
+                               a.close(d1, cf, Af, Bf);
+                               b.close(d1, ce, Ae, Be);
+                               const long long diff = (long long)(proposal == cf ? Af : Bf) -
+                                                      (long long)(evidence == ce ? Ae : Be);
+                               const bool have = part && mine && !g.w_fixed[wid];      // 100-101
+                               accumulate_gradient(sk, have, (int)wid, diff * 4294967296ll, truncate);
+                           });
+}
+
 // Learning over the uniform tiles of a colour class (tiles with per-lane headers are left to
 // k_learn_phase in list mode).  Each wave takes a contiguous run of tiles.
 template <typename VT, bool SMALLW>
@@ -458,7 +522,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
         const bool valid = p < pend && g.p_vid[p] >= 0;
         const uint4 *sp = g.adj + td.x + lane;
         const uint32_t kind = (td.w >> 8) & 7u;
-        if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp);
+        if (kind == 6u) learn_tile_general<VT>(g, sk, sp, td.w, td.z, p, valid, lp);
+        else if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp);
         else if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
         else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
         else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);

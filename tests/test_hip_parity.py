@@ -153,7 +153,45 @@ def _small_graphs(golden):
         # hub variables (factor lists >= 128 entries): one wave per variable
         "hubs": (_hub_graph(), False),
         "lr_bigcard": (_big_cardinality_graph(), False),
+        # every function of the general tiles (kind 6) on dataType-0 and -1 variables of
+        # cardinality 2..8, with the literal and the by-vid head lookup
+        "gencat": (_general_tile_graph(), False),
+        "gencat_vid": (_general_tile_graph(), True),
     }
+
+
+def _general_tile_graph():
+    from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar
+    rng = np.random.default_rng(23)
+    nvar, nfactor = 6000, 1700
+    variable = np.zeros(nvar, Variable)
+    card = rng.integers(2, 9, nvar)
+    card[rng.random(nvar) < 0.03] = 30                 # too large for a general tile: generic path
+    variable["cardinality"] = card
+    variable["dataType"] = rng.random(nvar) < 0.5
+    variable["isEvidence"] = rng.random(nvar) < 0.5
+    variable["initialValue"] = (rng.random(nvar) * card).astype(np.int64)
+    funcs = np.array([-1, 0, 1, 2, 3, 4, 12, 13, 14, 15, 16, 17])
+    arity = rng.integers(1, 6, nfactor)
+    off = np.cumsum(arity) - arity
+    nedge = int(arity.sum())
+    assert nedge < nvar                                # literal head lookup reads var_value[edge index]
+    fmap = np.zeros(nedge, FactorToVar)
+    for f in range(nfactor):
+        base = int(rng.integers(0, nvar // 3))            # dense third, the rest without factors
+        members = base + rng.choice(64 if f % 8 else 4, size=arity[f], replace=bool(f % 8 == 0))   # some repeated members
+        fmap["vid"][off[f]:off[f] + arity[f]] = members
+    fmap["dense_equal_to"] = (rng.random(nedge) * card[fmap["vid"]]).astype(np.int64)
+    factor = np.zeros(nfactor, Factor)
+    factor["factorFunction"] = funcs[rng.integers(0, len(funcs), nfactor)]
+    factor["weightId"] = rng.integers(0, 30, nfactor)
+    factor["featureValue"] = 1.0
+    factor["arity"] = arity
+    factor["ftv_offset"] = off
+    weight = np.zeros(30, Weight)
+    weight["initialValue"] = rng.normal(0, 0.3, 30)
+    weight["isFixed"][::5] = True
+    return weight, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
 
 
 def _hub_graph():
@@ -245,7 +283,7 @@ def _big_cardinality_graph():
 
 
 GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
-          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw", "hubs"]
+          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat", "gencat_vid"]
 
 
 @pytest.mark.parametrize("name", GRAPHS)
@@ -274,7 +312,8 @@ def test_chromatic_inference_equals_oracle(golden, name, sample_evidence):
 
 
 @pytest.mark.parametrize("name", ["mixed", "lf", "pairs", "grid32", "lr3000", "lr_bigcard",
-                                  "headquirk", "lr_manyw", "pairs_manyw", "boolw", "hubs"])
+                                  "headquirk", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat",
+                                  "gencat_vid"])
 @pytest.mark.parametrize("reg,trunc", [(0, 1), (1, 1), (1, 3), (2, 1)])
 @pytest.mark.parametrize("lne", [False, True])
 def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
@@ -303,15 +342,47 @@ def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
     assert np.any(wv != og.weight["initialValue"]) or og.weight["isFixed"].all() or not learns
 
 
+@pytest.mark.parametrize("name,no_general,no_heavy", [
+    ("lr3000", 1, 0), ("gencat", 1, 0), ("lr3000", 1, 1), ("gencat", 1, 1), ("gencat_vid", 1, 1),
+    ("mixed", 0, 1), ("lf", 0, 1), ("lr_bigcard", 0, 1), ("headquirk", 1, 1), ("hubs", 0, 1)])
+def test_generic_kernels_alone(golden, name, no_general, no_heavy, monkeypatch):
+    """The layout heuristics send small test graphs to the tile and the wave-per-variable kernels;
+    NSK_NO_GENERAL / NSK_NO_HEAVY (diagnostic switches read at graph creation) keep the variables
+    on the wave-per-variable / the one-lane generic kernels instead: same results."""
+    if no_general:
+        monkeypatch.setenv("NSK_NO_GENERAL", "1")
+    if no_heavy:
+        monkeypatch.setenv("NSK_NO_HEAVY", "1")
+    g, hbv = _small_graphs(golden)[name]
+    ns, fg = session(g, seed=5, head_by_vid=hbv)
+    assert fg.info()["ngeneric"] > (1000 if no_general and name != "headquirk" else 0)
+    og = oracle_of(fg, hbv)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, cnt = og.initial_state()
+    fg.learn(0, 2, 0.01, 0.9, 2, 0.05, 1, learn_non_evidence=True)
+    step = 0.01
+    for sweep in range(2):
+        assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.05, 1, True, 5, sweep) == 0
+        step *= 0.9
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    assert np.array_equal(fg.weight_value[0], wv)
+    fg.inference(0, 3, True)
+    for sweep in range(2, 5):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 5, sweep, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
 def test_fast_and_generic_paths_are_both_exercised(golden):
     graphs = _small_graphs(golden)
     ns, fg = session(graphs["grid57x33"][0])
     assert fg.info()["nfast"] == 57 * 33 and fg.info()["ngeneric"] == 0
     ns, fg = session(graphs["lr3000"][0], head_by_vid=True)
     info = fg.info()
-    assert info["nfast"] > 50 and info["ngeneric"] > 200
+    assert info["nfast"] > 2000 and info["ngeneric"] > 0     # general tiles take most of it
     ns, fg = session(graphs["mixed"][0])
     assert fg.info()["ngeneric"] > 0
+    ns, fg = session(graphs["gencat"][0])
+    assert fg.info()["nfast"] > 1500 and fg.info()["ngeneric"] > 50
 
 
 def test_learning_then_inference_continue_from_state(golden):

@@ -54,6 +54,8 @@ def check_coloring(fg, color, head_by_vid=False):
     f, fm = fg.factor, fg.fmap
     for fid in range(len(f)):
         s, a = int(f[fid]["ftv_offset"]), int(f[fid]["arity"])
+        if int(f[fid]["factorFunction"]) == -1:        # NOOP reads no member: no constraint
+            continue
         members = set(int(x) for x in fm["vid"][s:s + a])
         if int(f[fid]["factorFunction"]) in (13, 16, 17) and not head_by_vid:
             members.add(s + a - 1)
