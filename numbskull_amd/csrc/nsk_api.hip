@@ -64,8 +64,8 @@ struct nsk_graph {
     bool own_stream = false;
     // the kernels of one colour class are independent: hubs and generic-path variables run on side
     // streams next to the tile kernels (fork/join with events around every colour)
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool no_overlap = getenv("NSK_NO_OVERLAP") != nullptr;     // diagnostic: one stream
     std::vector<void *> allocs;
     int64_t device_bytes = 0;
@@ -217,7 +217,7 @@ int nsk_graph_destroy(nsk_graph *g) {
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)g->rccl_comm);
     if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         if (g->side[i]) (void)hipStreamDestroy(g->side[i]);
         if (g->ev_join[i]) (void)hipEventDestroy(g->ev_join[i]);
     }
@@ -240,7 +240,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     HIPCHECK(hipSetDevice(g->device));
     HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     g->own_stream = true;
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         HIPCHECK(hipStreamCreateWithFlags(&g->side[i], hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&g->ev_join[i], hipEventDisableTiming));
     }
@@ -382,21 +382,23 @@ static int fold_counts(nsk_graph *g) {
 }  // extern "C"
 
 // Streams for the kernels of one colour: the tile kernels stay on the main stream; when there are
-// tile kernels to overlap with, hubs go to side stream 0 and the generic kernel to side stream 1.
+// tile kernels to overlap with, hubs go to side stream 0, the generic kernel to side stream 1 and
+// the categorical general tiles to side stream 2.
 struct ColourStreams {
     nsk_graph *g;
-    bool forked[2] = {false, false};
+    bool forked[3] = {false, false, false};
     bool overlap;
-    ColourStreams(nsk_graph *g_, bool overlap_) : g(g_), overlap(overlap_) {
-        if (overlap) (void)hipEventRecord(g->ev_fork, g->stream);
-    }
+    bool recorded = false;
+    ColourStreams(nsk_graph *g_, bool overlap_) : g(g_), overlap(overlap_) {}
+    // side streams must be requested before anything of the colour is put on the main stream
     hipStream_t side(int i) {
         if (!overlap) return g->stream;
+        if (!recorded) { (void)hipEventRecord(g->ev_fork, g->stream); recorded = true; }
         if (!forked[i]) { (void)hipStreamWaitEvent(g->side[i], g->ev_fork, 0); forked[i] = true; }
         return g->side[i];
     }
     void join() {
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 3; i++)
             if (forked[i]) {
                 (void)hipEventRecord(g->ev_join[i], g->side[i]);
                 (void)hipStreamWaitEvent(g->stream, g->ev_join[i], 0);
@@ -422,7 +424,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
                 const int e = (int)g->c.phase_start[ph + 1];
                 const int he = (int)g->c.phase_heavy_end[ph];
-                ColourStreams cs(g, !g->no_overlap && (int)(fe > fb) + (int)(he > fe) + (int)(e > he) >= 2);
+                ColourStreams cs(g, !g->no_overlap);
                 if (he > fe) {      // hubs: one wave per variable
                     k_gibbs_heavy<VT><<<dim3((he - fe + 3) / 4), dim3(NSK_BLOCK), 0, cs.side(0)>>>(
                         d, fe, he, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
@@ -438,6 +440,23 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 if (fe > fb) {      // inlined-adjacency kernels
                     const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
                     const uint32_t S0 = (uint32_t)g->sweep, S1 = (uint32_t)(g->sweep >> 32);
+                    const int gt0 = (int)g->c.phase_gen_tile[ph];
+                    const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
+                    const int gtb = (int)g->c.phase_gen_bin_tile[ph];
+                    if (gtb > gt0) {   // general tiles with categorical lanes
+                        const int nblocks = (gtb - gt0 + 3) / 4;
+                        k_gibbs_general<VT, 8><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, cs.side(2)>>>(
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, sample_evidence,
+                            burnin, K0, K1, S0, S1);
+                        g->launches++;
+                    }
+                    if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
+                        const int nblocks = (gt0 + ngt - gtb + 3) / 4;
+                        k_gibbs_general<VT, 2><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks,
+                            sample_evidence, burnin, K0, K1, S0, S1);
+                        g->launches++;
+                    }
                     // segments of this colour, batched by (kind, chunks) into table launches
                     for (int kind = 0; kind <= 4; kind++) {
                         if (kind == 1) continue;                 // IMPLY_NATURAL shares the AND step (3)
@@ -526,7 +545,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
             const int he = (int)g->c.phase_heavy_end[ph];
-            ColourStreams cs(g, !g->no_overlap && (int)(fe > fb) + (int)(he > fe) + (int)(e > he) >= 2);
+            ColourStreams cs(g, !g->no_overlap);
             if (he > fe) {              // hubs: one wave per variable
                 const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
                 lp.row_base = rows;
@@ -543,11 +562,29 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 rows += grid;
                 g->launches++;
             }
-            if (ntiles > ndyn) {        // uniform tiles: inlined-adjacency learning kernel
-                const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (ntiles + 3) / 4);
+            const int gt0 = (int)g->c.phase_gen_tile[ph];
+            const int gtb = (int)g->c.phase_gen_bin_tile[ph];
+            if (gtb > gt0) {            // general tiles with categorical lanes
+                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (gtb - gt0 + 3) / 4);
+                lp.row_base = rows;
+                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(2)>>>(
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (ntiles > gtb) {         // all-binary general tiles
+                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4);
+                lp.row_base = rows;
+                k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (gt0 > ndyn) {           // uniform and shape tiles: inlined-adjacency learning kernel
+                const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (gt0 + 3) / 4);
                 lp.row_base = rows;
                 k_learn_fast<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], ntiles, lp);
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, lp);
                 rows += grid;
                 g->launches++;
             }

@@ -418,6 +418,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // Order inside a class: variable id.
     c.phase_start.assign((size_t)ncolors + 1, 0);
     c.phase_fast_end.assign((size_t)ncolors, 0);
+    c.phase_gen_tile.assign((size_t)ncolors, 0);
     c.v_pos.assign(nvar, -1);
     {
         // sig: exact program (function, member count, weight id per entry, evidence flag);
@@ -511,6 +512,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             pos += nfast_of[k] - nbig;
             pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
             gt_at[k] = pos;                                                     // general tiles
+            c.phase_gen_tile[k] = (pos - c.phase_start[k]) / 64;
             pos += ngt_of[k];
             pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
             c.phase_fast_end[k] = pos;
@@ -575,7 +577,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     ne++;
                     mo = std::max<int64_t>(mo, (gw[j + 1] >> 4) & 7u);
                 }
-                order[c.color[v]].push_back({-(ne * 8 + mo), v});
+                const int64_t catv = d->variable[v].cardinality > 2 ? 1 : 0;     // categorical tiles first
+                order[c.color[v]].push_back({-((catv << 20) + ne * 8 + mo), v});
             }
             for (int32_t k = 0; k < ncolors; k++) {
                 std::sort(order[k].begin(), order[k].end());
@@ -681,6 +684,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     len = (int64_t)E * (2 + M);
                     td[2] = it->second;
                     td[3] = (uint32_t)len | (6u << 8) | (maxcard << 12) | (M << 16);
+                    if (nw * 8 > (4 << 20) && E > 0) {
+                        // a weight table beyond the L2: inference reads materialised weight rows (one
+                        // coalesced row per entry, refreshed when weights change) like the shape tiles
+                        td[3] |= 1u << 19;
+                        c.tile_wrow[c.phase_wb_base[k] + b] = (uint32_t)c.nwrows;
+                        c.nwrows += (int64_t)E;
+                        if (c.nwrows >= ((int64_t)1 << 31)) { err = "weight stream too large"; return NSK_E_RANGE; }
+                    }
                     len = (len + 3) / 4 * 4;
                     td[0] = (uint32_t)total4;
                     td[1] = (uint32_t)len;
@@ -767,6 +778,12 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
         }
         c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
+        c.phase_gen_bin_tile.assign((size_t)ncolors, 0);
+        for (int32_t k = 0; k < ncolors; k++) {
+            int64_t t = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
+            while (t > c.phase_gen_tile[k] && ((c.tiles[4 * (c.phase_wb_base[k] + t - 1) + 3] >> 12) & 15u) <= 2u) t--;
+            c.phase_gen_bin_tile[k] = t;
+        }
         c.phase_dyn_base.assign((size_t)ncolors + 1, 0);
         for (int32_t k = 0; k < ncolors; k++) {
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++)
@@ -814,7 +831,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     sg.adj_off = td[0]; sg.prog = td[2]; sg.nslots = td[3] & 0xFFu; sg.kind = (td[3] >> 8) & 7u;
                     sg.ev = ev;
                     c.segments.push_back(sg);
-                } else {
+                } else if (td[2] == 0xFFFFFFFFu || ((td[3] >> 8) & 7u) != 6u) {      // general tiles: own kernel
                     for (int64_t t = b; t < e; t++) c.rest_tiles.push_back((uint32_t)t);
                 }
                 b = e;

@@ -60,6 +60,9 @@ struct Compiled {
     std::vector<Segment> segments;
     std::vector<uint32_t> rest_tiles;       // tile indices relative to the phase's first tile
     std::vector<int64_t> phase_rest_base;   // [ncolors+1]
+    // general tiles (kind 6) are the last tiles of a colour's tile range: first one, relative
+    std::vector<int64_t> phase_gen_tile;    // [ncolors]
+    std::vector<int64_t> phase_gen_bin_tile;   // [ncolors] first of the all-binary general tiles (they come last)
     int64_t nfast = 0;
     // per position
     std::vector<int32_t> p_vid, p_slot, p_cnt;

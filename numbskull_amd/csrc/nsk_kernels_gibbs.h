@@ -20,7 +20,9 @@ namespace nsk {
 #define NSK_LEARN_LIST_BLOCKS 512
 #define NSK_LEARN_GEN_BLOCKS 2048
 #define NSK_LEARN_HEAVY_BLOCKS 512
-#define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS + NSK_LEARN_HEAVY_BLOCKS)
+#define NSK_LEARN_GENERAL_BLOCKS 2048
+#define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS + NSK_LEARN_HEAVY_BLOCKS + \
+                        NSK_LEARN_GENERAL_BLOCKS)
 
 // One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
 // gibbsthread's loop body (inference.py:20-33) for that variable.
@@ -304,7 +306,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_shape_weights(const uint4
     const int t = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
     if (t >= ntiles) return;
     const uint4 td = tiles[t];
-    if (td.z == NSK_PAD_WORD || ((td.w >> 8) & 7u) != 7u) return;
+    const uint32_t kind = (td.w >> 8) & 7u;
+    if (td.z == NSK_PAD_WORD || !(kind == 7u || (kind == 6u && ((td.w >> 19) & 1u)))) return;
+    const uint32_t mask = kind == 7u ? 0xFFFFFFu : 0xFFFFFFFFu;     // general tiles: the word is the id
     const int len = (int)(td.w & 0xFFu);
     const uint32_t *rp = tile_hdr + td.z;
     double *wt = adj_wt + (size_t)tile_wrow[t] * 64 + lane;
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_shape_weights(const uint4
         const uint4 q = adj[td.x + (size_t)c * 64 + lane];
         const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
         for (int i = 0; i < 4; i++)
-            if (rp[4 * c + i] & 1u) wt[(size_t)(entry++) * 64] = w[wd[i] & 0xFFFFFFu];
+            if (rp[4 * c + i] & 1u) wt[(size_t)(entry++) * 64] = w[wd[i] & mask];
     }
 }
 
@@ -423,19 +427,21 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
     }
 }
 
-// potentials of the candidates 0..7 of one general tile: p[c] accumulates, in list order, the
-// rounded products weight * value exactly like potential() (inference.py:55-71)
+// potentials of the candidates 0..MAXC-1 of one general tile: p[c] accumulates, in list order, the
+// rounded products weight * value exactly like potential() (inference.py:55-71).  MAXC = 2 serves
+// the tiles whose lanes are all binary (the compiler sorts those behind the categorical ones).
+template <int MAXC>
 struct GenPot {
-    double p[8];
+    double p[MAXC];
     __device__ __forceinline__ void clear() {
 #pragma unroll
-        for (int c = 0; c < 8; c++) p[c] = 0.0;
+        for (int c = 0; c < MAXC; c++) p[c] = 0.0;
     }
     __device__ __forceinline__ void add(int maxcard, uint32_t d1, double w, int cstar, int A, int B) {
         const int ks = (int)((d1 >> 14) & 15u);       // candidate owning the entry; 15 = all (dataType 0)
         const double tA = w * (double)A, tB = w * (double)B;
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
+        for (int c = 0; c < MAXC; c++) {
             if (c >= 2 && c >= maxcard) break;        // wave-uniform
             const bool on = ks == 15 || ks == c;
             const double t = on ? (c == cstar ? tA : tB) : 0.0;   // +0.0 leaves the sum unchanged
@@ -444,10 +450,10 @@ struct GenPot {
     }
     // draw_sample (inference.py:36-52): running sums of exp, first candidate with Z[k] >= u * Z[card-1]
     __device__ __forceinline__ int draw(int maxcard, int card, double u) const {
-        double Z[8];
+        double Z[MAXC];
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < MAXC; k++) {
             Z[k] = 0.0;
             if (k >= 2 && k >= maxcard) break;
             const double ek = nsk_exp(p[k]);
@@ -458,7 +464,7 @@ struct GenPot {
         const double z = u * acc;
         int nv = 0;
 #pragma unroll
-        for (int k = 7; k >= 0; k--) {
+        for (int k = MAXC - 1; k >= 0; k--) {
             if (k >= 2 && k >= maxcard) continue;
             if (k < card && Z[k] >= z) nv = k;
         }
@@ -466,22 +472,33 @@ struct GenPot {
     }
 };
 
-template <typename VT>
+template <typename VT, int MAXC>
 __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const uint4 *sp, uint32_t tdw,
-                                                   uint32_t prog, int p, bool valid, int sample_evidence,
+                                                   uint32_t prog, uint32_t wrow, int p, bool valid, int sample_evidence,
                                                    int burnin, uint32_t k0, uint32_t k1, uint32_t s0,
                                                    uint32_t s1) {
     const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
     const int v = valid ? g.p_vid[p] : 0;
     const uint32_t info = valid ? g.p_info[p] : (2u << 9);
-    GenPot pot;
+    GenPot<MAXC> pot;
     pot.clear();
-    general_walk<VT, false>(g, g.val, g.val, sp, len, prog,
-                            [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &) {
-                                int cstar, A, B;
-                                a.close(d1, cstar, A, B);
-                                pot.add(maxcard, d1, g.w[wid], cstar, A, B);
-                            });
+    if ((tdw >> 19) & 1u) {                    // materialised weight rows (large weight tables)
+        const double *wt = g.adj_wt + (size_t)wrow * 64 + (threadIdx.x & 63);
+        int entry = 0;                         // wave-uniform
+        general_walk<VT, false>(g, g.val, g.val, sp, len, prog,
+                                [&](uint32_t, uint32_t d1, const GenChain &a, const GenChain &) {
+                                    int cstar, A, B;
+                                    a.close(d1, cstar, A, B);
+                                    pot.add(maxcard, d1, wt[(size_t)(entry++) * 64], cstar, A, B);
+                                });
+    } else {
+        general_walk<VT, false>(g, g.val, g.val, sp, len, prog,
+                                [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &) {
+                                    int cstar, A, B;
+                                    a.close(d1, cstar, A, B);
+                                    pot.add(maxcard, d1, g.w[wid], cstar, A, B);
+                                });
+    }
     const int ev = NSK_INFO_EV(info);
     if (!valid || !(ev == 0 || sample_evidence)) return;
     const int card = NSK_INFO_CARD(info);
@@ -519,10 +536,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
     const uint4 *sp = g.adj + td.x + lane;
     const int len = (int)td.y;
-    if (td.z != NSK_PAD_WORD && ((td.w >> 8) & 7u) == 6u) {
-        gibbs_tile_general(g, sp, td.w, td.z, p, valid, sample_evidence, burnin, k0, k1, s0, s1);
-        return;
-    }
     // the tally byte is fetched now so that its latency overlaps the tile walk
     const uint8_t tally = (valid && !burnin) ? g.cnt_pos[p] : (uint8_t)0;
 
@@ -548,6 +561,28 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
     const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     g.val[v] = (VT)nv;
     if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
+}
+
+// The general tiles of one colour class: tiles [tile0, tile0 + ntiles) of the colour, one wave each.
+template <typename VT, int MAXC>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int pbegin, int pend,
+                                                             int wb_base, int tile0, int ntiles,
+                                                             int nblocks, int sample_evidence, int burnin,
+                                                             uint32_t k0, uint32_t k1, uint32_t s0,
+                                                             uint32_t s1) {
+    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
+    if (lb < 0) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int t = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (t >= ntiles) return;
+    const int tile = tile0 + t;
+    const int p = pbegin + tile * 64 + lane;
+    const bool valid = p < pend && g.p_vid[p] >= 0;
+    const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + tile));
+    const uint32_t tdx = tdp[0], tdz = tdp[2], tdw = tdp[3];
+    const uint32_t wrow = *(const NSK_SCALAR uint32_t *)(g.tile_wrow + (wb_base + tile));
+    gibbs_tile_general<VT, MAXC>(g, g.adj + tdx + lane, tdw, tdz, wrow, p, valid, sample_evidence, burnin, k0, k1,
+                                 s0, s1);
 }
 
 // Homogeneous segments: runs of consecutive uniform tiles with one program, slot count, kind and

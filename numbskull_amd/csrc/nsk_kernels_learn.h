@@ -445,7 +445,7 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
 // evidence or the proposal value -- the union of the two factor lists of learning.py:76-95 (an
 // entry is in one list only: variables whose own edges in one factor disagree on dense_equal_to
 // stay on the generic path).
-template <typename VT>
+template <typename VT, int MAXC>
 __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
                                                    uint32_t tdw, uint32_t prog, int p, bool valid,
                                                    const LearnParams &lp) {
@@ -454,7 +454,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
     const int v = valid ? g.p_vid[p] : 0;
     const int ev = NSK_INFO_EV(info), card = NSK_INFO_CARD(info);
     const bool need_evid = __ballot(valid && ev != 1) != 0;
-    GenPot pf, pe;
+    GenPot<MAXC> pf, pe;
     pf.clear(); pe.clear();
     if (need_evid)
         general_walk<VT, true>(g, g.val, g.val_evid, sp, len, prog,
@@ -522,12 +522,32 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
         const bool valid = p < pend && g.p_vid[p] >= 0;
         const uint4 *sp = g.adj + td.x + lane;
         const uint32_t kind = (td.w >> 8) & 7u;
-        if (kind == 6u) learn_tile_general<VT>(g, sk, sp, td.w, td.z, p, valid, lp);
-        else if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp);
+        if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp);
         else if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
         else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
         else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
         else learn_tile<VT, 3>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+    }
+    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+}
+
+// Learning over the general tiles [tile0, tile0 + ntiles) of a colour class
+template <typename VT, bool SMALLW, int MAXC>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int pbegin, int pend,
+                                                             int wb_base, int tile0, int ntiles,
+                                                             LearnParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
+    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
+    for (int t = wave0; t < ntiles; t += nwaves) {
+        const int tile = tile0 + t;
+        const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + tile));
+        const uint32_t tdx = tdp[0], tdz = tdp[2], tdw = tdp[3];
+        const int p = pbegin + tile * 64 + lane;
+        const bool valid = p < pend && g.p_vid[p] >= 0;
+        learn_tile_general<VT, MAXC>(g, sk, g.adj + tdx + lane, tdw, tdz, p, valid, lp);
     }
     close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
 }

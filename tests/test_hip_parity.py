@@ -157,10 +157,12 @@ def _small_graphs(golden):
         # cardinality 2..8, with the literal and the by-vid head lookup
         "gencat": (_general_tile_graph(), False),
         "gencat_vid": (_general_tile_graph(), True),
+        # weight table beyond 4 MB: general tiles read materialised weight rows in inference
+        "gencat_bigw": (_general_tile_graph(nweight=600000), True),
     }
 
 
-def _general_tile_graph():
+def _general_tile_graph(nweight=30):
     from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar
     rng = np.random.default_rng(23)
     nvar, nfactor = 6000, 1700
@@ -184,12 +186,12 @@ def _general_tile_graph():
     fmap["dense_equal_to"] = (rng.random(nedge) * card[fmap["vid"]]).astype(np.int64)
     factor = np.zeros(nfactor, Factor)
     factor["factorFunction"] = funcs[rng.integers(0, len(funcs), nfactor)]
-    factor["weightId"] = rng.integers(0, 30, nfactor)
+    factor["weightId"] = rng.integers(0, nweight, nfactor)
     factor["featureValue"] = 1.0
     factor["arity"] = arity
     factor["ftv_offset"] = off
-    weight = np.zeros(30, Weight)
-    weight["initialValue"] = rng.normal(0, 0.3, 30)
+    weight = np.zeros(nweight, Weight)
+    weight["initialValue"] = rng.normal(0, 0.3, nweight)
     weight["isFixed"][::5] = True
     return weight, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
 
@@ -283,7 +285,8 @@ def _big_cardinality_graph():
 
 
 GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
-          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat", "gencat_vid"]
+          "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat", "gencat_vid",
+          "gencat_bigw"]
 
 
 @pytest.mark.parametrize("name", GRAPHS)
@@ -344,7 +347,7 @@ def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
 
 @pytest.mark.parametrize("name,no_general,no_heavy", [
     ("lr3000", 1, 0), ("gencat", 1, 0), ("lr3000", 1, 1), ("gencat", 1, 1), ("gencat_vid", 1, 1),
-    ("mixed", 0, 1), ("lf", 0, 1), ("lr_bigcard", 0, 1), ("headquirk", 1, 1), ("hubs", 0, 1)])
+    ("gencat_bigw", 0, 0), ("mixed", 0, 1), ("lf", 0, 1), ("lr_bigcard", 0, 1), ("headquirk", 1, 1), ("hubs", 0, 1)])
 def test_generic_kernels_alone(golden, name, no_general, no_heavy, monkeypatch):
     """The layout heuristics send small test graphs to the tile and the wave-per-variable kernels;
     NSK_NO_GENERAL / NSK_NO_HEAVY (diagnostic switches read at graph creation) keep the variables
