@@ -245,17 +245,22 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     };
 
     c.color.assign(nvar, -1);
-    std::vector<int64_t> stamp(1, -1);
+    std::vector<int64_t> stamp(1, -1), load;
     int32_t ncolors = 0;
+    // greedy first fit in id order, then a balancing pass (below)
+    auto pick = [&](int64_t v) -> int32_t {
+        int32_t col = 0;
+        while (col < ncolors && stamp[col] == v) col++;
+        if (col == ncolors) { ncolors++; stamp.push_back(-1); load.push_back(0); }
+        load[col]++;
+        return col;
+    };
     for (int64_t v = 0; v < nvar; v++) {
         if (!sampled[v]) continue;
         for_each_read(v, [&](int64_t b) {
             if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
         });
-        int32_t col = 0;
-        while (col < ncolors && stamp[col] == v) col++;
-        if (col == ncolors) { ncolors++; stamp.push_back(-1); }
-        c.color[v] = col;
+        c.color[v] = pick(v);
     }
     // the greedy pass assumes reads are symmetric (true for compute_var_map output); verify, and
     // repair with explicit reverse-read lists when a raw index is asymmetric
@@ -277,6 +282,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             if (sampled[v]) for_each_read(v, [&](int64_t b) { if (b != v) readers[fill[b]++] = (int32_t)v; });
         std::fill(c.color.begin(), c.color.end(), -1);
         stamp.assign(1, -1);
+        load.clear();
         ncolors = 0;
         for (int64_t v = 0; v < nvar; v++) {
             if (!sampled[v]) continue;
@@ -287,11 +293,27 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 int32_t a = readers[j];
                 if (c.color[a] >= 0) stamp[c.color[a]] = v;
             }
-            int32_t col = 0;
-            while (col < ncolors && stamp[col] == v) col++;
-            if (col == ncolors) { ncolors++; stamp.push_back(-1); }
-            c.color[v] = col;
+            c.color[v] = pick(v);
         }
+    }
+
+    // balancing: first fit leaves a few huge classes and a tail of tiny ones, and every class costs
+    // a kernel's latency floor however few variables it holds.  Move variables, in id order, from
+    // their class to the least populated class none of their neighbours is in (reads are symmetric
+    // here -- the asymmetric repair above skips this pass).
+    if (!conflict && ncolors > 2 && !getenv("NSK_NO_BALANCE")) {
+        for (int pass = 0; pass < 2; pass++)
+            for (int64_t v = 0; v < nvar; v++) {
+                if (!sampled[v]) continue;
+                const int32_t cur = c.color[v];
+                for_each_read(v, [&](int64_t b) {
+                    if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
+                });
+                int32_t best = cur;
+                for (int32_t k = 0; k < ncolors; k++)
+                    if (k != cur && stamp[k] != v && load[k] + 1 < load[best]) best = k;
+                if (best != cur) { load[cur]--; load[best]++; c.color[v] = best; }
+            }
     }
 
     // ---- ghosts: variables outside the owned range read by a sampled variable -------------------
@@ -344,6 +366,9 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
     };
     const bool no_general = getenv("NSK_NO_GENERAL") != nullptr;
+    // longer lists go to the wave-per-variable kernel: a tile is walked by one wave, so its longest
+    // lane sets a serial chain of memory round trips and the longest tile the kernel's run time
+    const int64_t gen_max_entries = getenv("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(getenv("NSK_GEN_MAX_ENTRIES")))) : 12;
     auto general_words = [&](int64_t v, std::vector<uint32_t> *out) -> bool {
         const nsk_variable &var = d->variable[v];
         if (var.cardinality > 8 || var.cardinality < 2) return false;
@@ -396,7 +421,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 const uint32_t role = !positional ? 0u : (self_head ? 2u : 1u);
                 const uint32_t kslot = var.dataType == 0 ? 15u : (uint32_t)k;
                 nwords += 2 + (size_t)others;
-                if (nwords > 120 || ++nentries > 24) return false;
+                if (nwords > 120 || (int64_t)++nentries > gen_max_entries) return false;
                 if (out) {
                     out->push_back((uint32_t)fa.weightId);
                     out->push_back((uint32_t)code | ((uint32_t)others << 4) | (role << 7) |
@@ -481,11 +506,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             const int32_t k = c.color[v];
             if (k < 0 || fast[v] != 1 || classes[k][sig[v]].first >= min_class[k]) continue;
             if (shp[v] != 0 && shapes[k][shp[v]].first >= 64) continue;
-            if (!general_words(v, nullptr)) continue;
             if (shp[v] != 0) shapes[k][shp[v]].first--;
-            fast[v] = 2;
             nfast_of[k]--;
-            ngt_of[k]++;
+            if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
+            else { fast[v] = 0; ngen_of[k]++; }          // long lists: wave-per-variable / generic kernels
         }
         std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
         std::vector<std::vector<int64_t>> gen_bin_start;

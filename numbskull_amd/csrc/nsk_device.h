@@ -208,6 +208,14 @@ struct DevGraph {
 // symmetric boolean ones, so a factor's value for candidate k follows from three facts about
 // the OTHER members: all non-zero? any == 1? all equal (and to what)?
 // ------------------------------------------------------------------------------------------
+// 16-byte load of streamed-once data (adjacency tiles) with the non-temporal hint, so that it does
+// not evict the gathered arrays (values, weights) from the L2
+typedef unsigned int nsk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 stream_load(const uint4 *p) {
+    const nsk_u32x4 v = __builtin_nontemporal_load((const nsk_u32x4 *)p);
+    return uint4{v.x, v.y, v.z, v.w};
+}
+
 #define NSK_PAD_WORD 0xFFFFFFFFu
 // Wave-uniform, read-only data (tile descriptors, shared headers, weights) is read through the
 // constant address space so that it travels on the scalar path (s_load) instead of occupying 64
@@ -597,20 +605,58 @@ __device__ inline int wave_draw_sample(const DevGraph<VT> &g, int var_samp, uint
                                        const VT *val, double u) {
     const int card = NSK_INFO_CARD(info);
     const int step = NSK_INFO_DT1(info);
-    if (card == 2) {
+    if (card == 2 && !step) {
         double p0, p1;
-        if (step) {
-            p0 = wave_potential(g, var_samp, 0, slot0, val);
-            p1 = wave_potential(g, var_samp, 1, slot0 + 1, val);
-        } else {
-            wave_potential2(g, var_samp, slot0, val, p0, p1);
-        }
+        wave_potential2(g, var_samp, slot0, val, p0, p1);
         const double z0 = nsk_exp(p0);
         const double z1 = z0 + nsk_exp(p1);
         const double z = u * z1;
         return (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     }
-    // any cardinality: two passes, the second recomputes the identical running sums
+    if (card <= 64) {
+        // all (candidate, factor) pairs spread over the lanes, 64 pairs per round trip to memory:
+        // candidate-major, so that each candidate's terms are met -- and added -- in list order.
+        // Lane k keeps candidate k's potential, then its exp and its running sum Z[k].
+        const int lane = (int)(threadIdx.x & 63);
+        const int B = g.slot_off[slot0];
+        const int n0 = g.slot_off[slot0 + 1] - B;                     // dataType 0: the one list
+        const int P = step ? g.slot_off[slot0 + card] - B : n0 * card;
+        double myp = 0.0;
+        for (int base = 0; base < P; base += 64) {
+            const int x = base + lane;
+            int kk = 0;
+            double t = 0.0;
+            if (x < P) {
+                int at;
+                if (step) {                                           // pair x = entry B + x of slot kk
+                    at = B + x;
+                    for (int k = 1; k < card; k++) kk += (at >= g.slot_off[slot0 + k]) ? 1 : 0;
+                } else {
+                    kk = x / n0;
+                    at = B + (x - kk * n0);
+                }
+                const uint4 rec = g.f_rec[g.fidx[at]];
+                t = g.w[rec.z] * eval_factor(g, rec, g.m_rec, var_samp, kk, val);
+            }
+            const int n = min(64, P - base);
+            for (int i = 0; i < n; i++) {
+                const int ki = __builtin_amdgcn_readlane(kk, i);
+                const double ti = lane_value(t, i);
+                if (lane == ki) myp = myp + ti;
+            }
+        }
+        const double ek = nsk_exp(myp);
+        double acc = 0.0, myZ = 0.0;
+        for (int k = 0; k < card; k++) {
+            const double e = lane_value(ek, k);
+            acc = (k == 0) ? e : acc + e;
+            if (lane == k) myZ = acc;
+        }
+        const double z = u * acc;
+        const unsigned long long hit = __ballot(lane < card && myZ >= z);
+        return hit ? (int)__ffsll((long long)hit) - 1 : 0;
+    }
+    // larger domains: two passes, the second recomputes the identical running sums
     double acc = 0.0;
     for (int k = 0; k < card; k++) {
         const double ek = nsk_exp(wave_potential(g, var_samp, k, slot0 + step * k, val));

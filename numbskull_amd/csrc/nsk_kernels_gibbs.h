@@ -332,6 +332,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_shape_weights(const uint4
 #ifndef NSK_GEN_NULL
 #define NSK_GEN_NULL 0x7FFFFFFu
 #endif
+#define NSK_GEN_GROUP 2
 struct GenChain {
     bool allnz, prevall, any1, alleq, lastnz;
     int first;
@@ -340,68 +341,126 @@ struct GenChain {
     }
     // one member slot; `cat`: the function compares with dense_equal_to instead of 0 / 1
     __device__ __forceinline__ void member(bool F, bool cat, uint32_t word, int x) {
-        if ((word & NSK_GEN_NULL) == NSK_GEN_NULL) return;            // empty slot
+        const bool live = (word & NSK_GEN_NULL) != NSK_GEN_NULL;      // not an empty slot
         const int deo = (int)(word >> 27);
         const bool nz = cat ? (x == deo) : (x != 0);
         const bool one = cat ? (x == deo) : (x == 1);
-        alleq = F || (alleq && x == first);
-        first = F ? x : first;
-        prevall = allnz;
-        allnz = allnz && nz;
-        any1 = any1 || one;
-        lastnz = nz;
+        alleq = live ? (F || (alleq && x == first)) : alleq;          // selects, no divergent branch
+        first = (live && F) ? x : first;
+        prevall = live ? allnz : prevall;
+        allnz = live ? (allnz && nz) : allnz;
+        any1 = live ? (any1 || one) : any1;
+        lastnz = live ? nz : lastnz;
     }
-    // (c == cstar) ? A : B for the entry described by descriptor word d1
-    __device__ __forceinline__ void close(uint32_t d1, int &cstar, int &A, int &B) const {
-        const uint32_t code = d1 & 15u, role = (d1 >> 7) & 3u;
-        const bool nomember = ((d1 >> 4) & 7u) == 0u;
+    // (c == cstar) ? A : B for the entry described by descriptor word d1: one byte of the table below
+    __device__ __forceinline__ void close(uint32_t d1, const uint8_t *lut, int &cstar, int &A, int &B) const {
+        const uint32_t nomember = ((d1 >> 4) & 7u) == 0u ? 1u : 0u;
+        const uint32_t idx = (d1 & 15u) | ((((d1 >> 7) & 3u) == 1u ? 1u : 0u) << 4) | (nomember << 5) |
+                             ((allnz ? 1u : 0u) << 6) | ((prevall ? 1u : 0u) << 7) | ((any1 ? 1u : 0u) << 8) |
+                             ((alleq ? 1u : 0u) << 9) | ((lastnz ? 1u : 0u) << 10);
+        const uint32_t e = lut[idx];
+        A = (int)(e & 3u) - 1;
+        B = (int)((e >> 2) & 3u) - 1;
+        const uint32_t sel = e >> 4;                    // cstar: 0, 1, first member's value, own dense_equal_to
         const int sdeo = (int)((d1 >> 9) & 31u);
-        const bool body = role == 1u ? prevall : allnz;               // body members all true / matching
-        const bool hd = lastnz;                                       // role 1: the head is the last member
-        cstar = 0; A = 0; B = 0;
-        if (code == 1u) { B = allnz ? 1 : 0; }                                            // IMPLY_NATURAL
-        else if (code == 2u) { cstar = 1; A = 1; B = any1 ? 1 : -1; }                     // OR
-        else if (code == 3u) { A = -1; B = allnz ? 1 : -1; }                              // AND / ISTRUE
-        else if (code == 4u) { cstar = first; A = (nomember || alleq) ? 1 : -1; B = nomember ? 1 : -1; }   // EQUAL
-        else if (code == 5u) {                                                            // IMPLY_MLN
-            if (role == 1u) { A = 1; B = !body ? 1 : (hd ? 1 : 0); }
-            else { A = !allnz ? 1 : 0; B = 1; }
-        } else if (code == 6u) { cstar = sdeo; A = allnz ? 1 : 0; }                       // AND_CAT / EQUAL_CAT_CONST
-        else if (code == 7u) { cstar = sdeo; A = 1; B = any1 ? 1 : -1; }                  // OR_CAT
-        else if (code == 8u) {                                                            // IMPLY_NATURAL_CAT
-            cstar = sdeo;
-            if (role == 1u) { A = body ? (hd ? 1 : -1) : 0; }
-            else { A = allnz ? 1 : 0; B = allnz ? -1 : 0; }
-        } else if (code == 9u) {                                                          // IMPLY_MLN_CAT
-            cstar = sdeo;
-            if (role == 1u) { A = !body ? 1 : (hd ? 1 : 0); B = 1; }
-            else { A = 1; B = allnz ? 0 : 1; }
-        }
+        cstar = sel == 0u ? 0 : (sel == 1u ? 1 : (sel == 2u ? first : sdeo));
     }
 };
+
+// The restatement of eval_factor (inference.py:162-200, 232-295) as facts about the other members,
+// tabulated: index = code | own role is body << 4 | no other member << 5 | allnz << 6 | prevall << 7 |
+// any1 << 8 | alleq << 9 | lastnz << 10; entry = (A + 1) | (B + 1) << 2 | cstar selector << 4.
+// (A table instead of branches: the function code is per lane, and the 64-fold unrolled walk with
+// ten-way divergent branches per entry did not fit the instruction cache.)
+struct GenLut { uint8_t t[2048]; };
+constexpr uint8_t gen_lut_entry(uint32_t idx) {
+    const uint32_t code = idx & 15u;
+    const bool role1 = (idx >> 4) & 1u, nomember = (idx >> 5) & 1u, allnz = (idx >> 6) & 1u,
+               prevall = (idx >> 7) & 1u, any1 = (idx >> 8) & 1u, alleq = (idx >> 9) & 1u,
+               lastnz = (idx >> 10) & 1u;
+    const bool body = role1 ? prevall : allnz;          // body members all true / matching
+    const bool hd = lastnz;                             // own role body: the head is the last member
+    int sel = 0, A = 0, B = 0;
+    if (code == 1u) { B = allnz ? 1 : 0; }                                            // IMPLY_NATURAL
+    else if (code == 2u) { sel = 1; A = 1; B = any1 ? 1 : -1; }                       // OR
+    else if (code == 3u) { A = -1; B = allnz ? 1 : -1; }                              // AND / ISTRUE
+    else if (code == 4u) { sel = 2; A = (nomember || alleq) ? 1 : -1; B = nomember ? 1 : -1; }   // EQUAL
+    else if (code == 5u) {                                                            // IMPLY_MLN
+        if (role1) { A = 1; B = !body ? 1 : (hd ? 1 : 0); }
+        else { A = !allnz ? 1 : 0; B = 1; }
+    } else if (code == 6u) { sel = 3; A = allnz ? 1 : 0; }                            // AND_CAT / EQUAL_CAT_CONST
+    else if (code == 7u) { sel = 3; A = 1; B = any1 ? 1 : -1; }                       // OR_CAT
+    else if (code == 8u) {                                                            // IMPLY_NATURAL_CAT
+        sel = 3;
+        if (role1) { A = body ? (hd ? 1 : -1) : 0; }
+        else { A = allnz ? 1 : 0; B = allnz ? -1 : 0; }
+    } else if (code == 9u) {                                                          // IMPLY_MLN_CAT
+        sel = 3;
+        if (role1) { A = !body ? 1 : (hd ? 1 : 0); B = 1; }
+        else { A = 1; B = allnz ? 0 : 1; }
+    }
+    return (uint8_t)((A + 1) | ((B + 1) << 2) | (sel << 4));
+}
+constexpr GenLut make_gen_lut() {
+    GenLut l{};
+    for (uint32_t i = 0; i < 2048; i++) l.t[i] = gen_lut_entry(i);
+    return l;
+}
+__constant__ GenLut k_gen_lut = make_gen_lut();
+
+// block-wide copy of the table into LDS; every thread of the block must call it
+__device__ __forceinline__ void load_gen_lut(uint8_t *lds) {
+    for (int i = (int)threadIdx.x; i < 512; i += NSK_BLOCK)
+        ((uint32_t *)lds)[i] = ((const uint32_t *)k_gen_lut.t)[i];
+    __syncthreads();
+}
 
 // Walk a general tile over one (TWO = false) or two value arrays; on_entry(weight id, descriptor,
 // chain a, chain b) runs at every entry end -- wave-uniform control flow, so it may use wave
 // collectives.  The next 16-byte chunk is requested before the gathers of the current one.
-template <typename VT, bool TWO, typename FN>
+// WMODE: where an entry's weight comes from -- 0 gathered from g.w, 1 the tile's materialised weight
+// rows (wt = this lane's column), 2 not needed (0.0).  Weights are requested with the group's
+// member gathers, not when the entry ends.
+template <typename VT, bool TWO, int WMODE, bool NT, typename FN>
 __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va, const VT *vb,
-                                             const uint4 *sp, int len, uint32_t prog, FN &&on_entry) {
+                                             const uint4 *sp, int len, uint32_t prog, const double *wt,
+                                             FN &&on_entry) {
     const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
     if (len <= 0) return;
     GenChain a, b;
     a.open(); b.open();
     uint32_t wid = 0, d1 = 0;
-    uint4 q = sp[0];
-    for (int c = 0; c * 4 < len; c++) {
-        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-        if ((c + 1) * 4 < len) q = sp[(size_t)(c + 1) * 64];
-        uint32_t role[4];
+    double w = 0.0;
+    int entry = 0;                                 // wave-uniform
+    // NSK_GEN_GROUP chunks (16-byte loads) at a time: their stream loads, then all their gathers,
+    // are in flight together -- the walk of a long tile is a chain of dependent memory round trips
+    for (int c0 = 0; c0 * 4 < len; c0 += NSK_GEN_GROUP) {
+        uint4 q[NSK_GEN_GROUP];
 #pragma unroll
-        for (int i = 0; i < 4; i++) role[i] = rp[4 * c + i] & 0x3Fu;     // scalar; 0 = padding word
-        int xa[4], xb[4];
+        for (int j = 0; j < NSK_GEN_GROUP; j++)
+            q[j] = ((c0 + j) * 4 >= len) ? uint4{0u, 0u, 0u, 0u}                                // uniform guard
+                   : (NT ? stream_load(sp + (size_t)(c0 + j) * 64)   // NT: the tile is read once (inference)
+                         : sp[(size_t)(c0 + j) * 64]);
+        uint32_t wd[4 * NSK_GEN_GROUP], role[4 * NSK_GEN_GROUP];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int j = 0; j < NSK_GEN_GROUP; j++) {
+            wd[4 * j] = q[j].x; wd[4 * j + 1] = q[j].y; wd[4 * j + 2] = q[j].z; wd[4 * j + 3] = q[j].w;
+#pragma unroll
+            for (int i = 0; i < 4; i++)           // scalar; 0 = padding word or beyond the tile
+                role[4 * j + i] = ((c0 + j) * 4 + i < len) ? (rp[(c0 + j) * 4 + i] & 0x3Fu) : 0u;
+        }
+        int xa[4 * NSK_GEN_GROUP], xb[4 * NSK_GEN_GROUP];
+        double wv[NSK_GEN_GROUP * 2];              // at most one weight word per two words
+        int nwv = 0;
+#pragma unroll
+        for (int i = 0; i < 4 * NSK_GEN_GROUP; i++) {
             xa[i] = 0; xb[i] = 0;
+            if ((role[i] & 1u) && WMODE != 2) {
+                const double x = WMODE == 1 ? wt[(size_t)(entry++) * 64] : g.w[wd[i]];
+#pragma unroll
+                for (int j = 0; j < NSK_GEN_GROUP * 2; j++) if (j == nwv) wv[j] = x;
+                nwv++;
+            }
             if (role[i] & 16u) {
                 const uint32_t id = wd[i] & NSK_GEN_NULL;
                 const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
@@ -409,19 +468,26 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
                 if (TWO) xb[i] = (int)vb[at];
             }
         }
+        int iwv = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (role[i] & 1u) wid = wd[i];
-            else if (role[i] & 32u) {
+        for (int i = 0; i < 4 * NSK_GEN_GROUP; i++) {
+            if (role[i] & 1u) {
+                wid = wd[i];
+                if (WMODE != 2) {
+#pragma unroll
+                    for (int j = 0; j < NSK_GEN_GROUP * 2; j++) if (j == iwv) w = wv[j];
+                    iwv++;
+                }
+            } else if (role[i] & 32u) {
                 d1 = wd[i];
                 a.open();
                 if (TWO) b.open();
-                if (role[i] & 8u) on_entry(wid, d1, a, b);
+                if (role[i] & 8u) on_entry(wid, w, d1, a, b);
             } else if (role[i] & 16u) {
                 const bool F = (role[i] & 2u) != 0, cat = (d1 & 15u) >= 6u;
                 a.member(F, cat, wd[i], xa[i]);
                 if (TWO) b.member(F, cat, wd[i], xb[i]);
-                if (role[i] & 4u) on_entry(wid, d1, a, b);
+                if (role[i] & 4u) on_entry(wid, w, d1, a, b);
             }
         }
     }
@@ -473,8 +539,9 @@ struct GenPot {
 };
 
 template <typename VT, int MAXC>
-__device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const uint4 *sp, uint32_t tdw,
-                                                   uint32_t prog, uint32_t wrow, int p, bool valid, int sample_evidence,
+__device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const uint8_t *lut, const uint4 *sp,
+                                                   uint32_t tdw, uint32_t prog, uint32_t wrow, int p, bool valid,
+                                                   int sample_evidence,
                                                    int burnin, uint32_t k0, uint32_t k1, uint32_t s0,
                                                    uint32_t s1) {
     const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
@@ -482,23 +549,16 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
     const uint32_t info = valid ? g.p_info[p] : (2u << 9);
     GenPot<MAXC> pot;
     pot.clear();
-    if ((tdw >> 19) & 1u) {                    // materialised weight rows (large weight tables)
-        const double *wt = g.adj_wt + (size_t)wrow * 64 + (threadIdx.x & 63);
-        int entry = 0;                         // wave-uniform
-        general_walk<VT, false>(g, g.val, g.val, sp, len, prog,
-                                [&](uint32_t, uint32_t d1, const GenChain &a, const GenChain &) {
-                                    int cstar, A, B;
-                                    a.close(d1, cstar, A, B);
-                                    pot.add(maxcard, d1, wt[(size_t)(entry++) * 64], cstar, A, B);
-                                });
-    } else {
-        general_walk<VT, false>(g, g.val, g.val, sp, len, prog,
-                                [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &) {
-                                    int cstar, A, B;
-                                    a.close(d1, cstar, A, B);
-                                    pot.add(maxcard, d1, g.w[wid], cstar, A, B);
-                                });
-    }
+    auto on_entry = [&](uint32_t, double w, uint32_t d1, const GenChain &a, const GenChain &) {
+        int cstar, A, B;
+        a.close(d1, lut, cstar, A, B);
+        pot.add(maxcard, d1, w, cstar, A, B);
+    };
+    if ((tdw >> 19) & 1u)                      // materialised weight rows (large weight tables)
+        general_walk<VT, false, 1, true>(g, g.val, g.val, sp, len, prog,
+                                   g.adj_wt + (size_t)wrow * 64 + (threadIdx.x & 63), on_entry);
+    else
+        general_walk<VT, false, 0, true>(g, g.val, g.val, sp, len, prog, nullptr, on_entry);
     const int ev = NSK_INFO_EV(info);
     if (!valid || !(ev == 0 || sample_evidence)) return;
     const int card = NSK_INFO_CARD(info);
@@ -570,6 +630,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
                                                              int nblocks, int sample_evidence, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0,
                                                              uint32_t s1) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
+    load_gen_lut(lut);
     const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
     if (lb < 0) return;
     const int lane = (int)(threadIdx.x & 63);
@@ -581,8 +643,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
     const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + tile));
     const uint32_t tdx = tdp[0], tdz = tdp[2], tdw = tdp[3];
     const uint32_t wrow = *(const NSK_SCALAR uint32_t *)(g.tile_wrow + (wb_base + tile));
-    gibbs_tile_general<VT, MAXC>(g, g.adj + tdx + lane, tdw, tdz, wrow, p, valid, sample_evidence, burnin, k0, k1,
-                                 s0, s1);
+    gibbs_tile_general<VT, MAXC>(g, lut, g.adj + tdx + lane, tdw, tdz, wrow, p, valid, sample_evidence, burnin,
+                                 k0, k1, s0, s1);
 }
 
 // Homogeneous segments: runs of consecutive uniform tiles with one program, slot count, kind and
@@ -621,7 +683,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTabl
     const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
     uint4 q[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];
+    for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];     // (the non-temporal hint costs 10 % here)
     int x[4 * NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {

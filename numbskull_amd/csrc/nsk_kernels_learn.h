@@ -446,9 +446,9 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
 // entry is in one list only: variables whose own edges in one factor disagree on dense_equal_to
 // stay on the generic path).
 template <typename VT, int MAXC>
-__device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
-                                                   uint32_t tdw, uint32_t prog, int p, bool valid,
-                                                   const LearnParams &lp) {
+__device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const GradSink &sk, const uint8_t *lut,
+                                                   const uint4 *sp, uint32_t tdw, uint32_t prog, int p,
+                                                   bool valid, const LearnParams &lp) {
     const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
     const uint32_t info = valid ? g.p_info[p] : (2u << 9);
     const int v = valid ? g.p_vid[p] : 0;
@@ -457,22 +457,21 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
     GenPot<MAXC> pf, pe;
     pf.clear(); pe.clear();
     if (need_evid)
-        general_walk<VT, true>(g, g.val, g.val_evid, sp, len, prog,
-                               [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &b) {
-                                   int cstar, A, B;
-                                   const double w = g.w[wid];
-                                   a.close(d1, cstar, A, B);
-                                   pf.add(maxcard, d1, w, cstar, A, B);
-                                   b.close(d1, cstar, A, B);
-                                   pe.add(maxcard, d1, w, cstar, A, B);
-                               });
+        general_walk<VT, true, 0, false>(g, g.val, g.val_evid, sp, len, prog, nullptr,
+                                  [&](uint32_t, double w, uint32_t d1, const GenChain &a, const GenChain &b) {
+                                      int cstar, A, B;
+                                      a.close(d1, lut, cstar, A, B);
+                                      pf.add(maxcard, d1, w, cstar, A, B);
+                                      b.close(d1, lut, cstar, A, B);
+                                      pe.add(maxcard, d1, w, cstar, A, B);
+                                  });
     else
-        general_walk<VT, false>(g, g.val, g.val, sp, len, prog,
-                                [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &) {
-                                    int cstar, A, B;
-                                    a.close(d1, cstar, A, B);
-                                    pf.add(maxcard, d1, g.w[wid], cstar, A, B);
-                                });
+        general_walk<VT, false, 0, false>(g, g.val, g.val, sp, len, prog, nullptr,
+                                   [&](uint32_t, double w, uint32_t d1, const GenChain &a, const GenChain &) {
+                                       int cstar, A, B;
+                                       a.close(d1, lut, cstar, A, B);
+                                       pf.add(maxcard, d1, w, cstar, A, B);
+                                   });
     const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
     int evidence = valid ? (int)g.p_init[p] : 0;                                       // learning.py:61-62
     if (need_evid && ev != 1) evidence = pe.draw(maxcard, card, u53(r.z, r.w));        // 54-58
@@ -488,13 +487,13 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
         truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
     }
     if (__ballot(part) == 0) return;
-    general_walk<VT, true>(g, g.val, g.val_evid, sp, len, prog,
-                           [&](uint32_t wid, uint32_t d1, const GenChain &a, const GenChain &b) {
+    general_walk<VT, true, 2, false>(g, g.val, g.val_evid, sp, len, prog, nullptr,
+                           [&](uint32_t wid, double, uint32_t d1, const GenChain &a, const GenChain &b) {
                                const int ks = (int)((d1 >> 14) & 15u);
                                const bool mine = ks == 15 || ks == evidence || ks == proposal;
                                int cf, Af, Bf, ce, Ae, Be;
-                               a.close(d1, cf, Af, Bf);
-                               b.close(d1, ce, Ae, Be);
+                               a.close(d1, lut, cf, Af, Bf);
+                               b.close(d1, lut, ce, Ae, Be);
                                const long long diff = (long long)(proposal == cf ? Af : Bf) -
                                                       (long long)(evidence == ce ? Ae : Be);
                                const bool have = part && mine && !g.w_fixed[wid];      // 100-101
@@ -537,6 +536,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
                                                              int wb_base, int tile0, int ntiles,
                                                              LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
+    load_gen_lut(lut);
     const GradSink sk = open_sink<SMALLW>(g, smem);
     const int lane = (int)(threadIdx.x & 63);
     const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
         const uint32_t tdx = tdp[0], tdz = tdp[2], tdw = tdp[3];
         const int p = pbegin + tile * 64 + lane;
         const bool valid = p < pend && g.p_vid[p] >= 0;
-        learn_tile_general<VT, MAXC>(g, sk, g.adj + tdx + lane, tdw, tdz, p, valid, lp);
+        learn_tile_general<VT, MAXC>(g, sk, lut, g.adj + tdx + lane, tdw, tdz, p, valid, lp);
     }
     close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
 }
