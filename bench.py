@@ -92,8 +92,14 @@ def cpu_baseline(fg, learning, budget_s=20.0):
         run(extra)
         total_t += time.time() - t0
         total_n += extra
+    # one thread = the reference's own sequential scan (SURVEY.md section 8d asks for T = 1 too)
+    run1 = (lambda n: og.learn_hogwild(1, n, vv, ve, wv, 1e-7, 0.95, 2, 0.01, 1, False, 1)) \
+        if learning else (lambda n: og.gibbs_hogwild(1, n, vv, wv, cnt, 1, True, False))
+    t0 = time.time()
+    assert run1(1) == 0
+    single = nvar / (time.time() - t0)
     return {"value": nvar * total_n / total_t, "unit": "variable-updates/s", "cores": cores,
-            "kind": "port",
+            "kind": "port", "single_thread": single,
             "sample": "%d sweep(s) of the same %d-variable grid, %d Hogwild threads "
                       "(reference shard formula), %.1f s" % (total_n, nvar, cores, total_t)}
 

@@ -458,7 +458,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             nfast_of[c.color[v]]++;
             const nsk_variable &var = d->variable[v];
             const nsk_vtf &vt = d->vmap[var.vtf_offset];
-            uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence, h2 = h ^ 0x9e3779b97f4a7c15ull;
+            // (the evidence flag is multiplied in before the first word: a plain xor would cancel
+            // against the low bit of the first weight id / member count)
+            uint64_t h = (0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence) * 0x100000001b3ull;
+            uint64_t h2 = (h ^ 0x9e3779b97f4a7c15ull) * 0x100000001b3ull;
             int64_t nwords = 0;
             for (int64_t j = 0; j < vt.factor_index_length; j++) {
                 const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
@@ -863,6 +866,40 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             c.phase_rest_base[k + 1] = (int64_t)c.rest_tiles.size();
         }
         if (c.rest_tiles.empty()) c.rest_tiles.push_back(0);
+        if (getenv("NSK_VERBOSE")) {                 // layout report: tiles by kind, per colour
+            for (int32_t k = 0; k < ncolors; k++) {
+                int64_t kinds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
+                    const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                    kinds[td[2] == 0xFFFFFFFFu ? 8 : (td[3] >> 8) & 7u]++;
+                }
+                if (getenv("NSK_DEBUG_TILES"))
+                    for (int64_t b = 0, shown = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k] && shown < 3; b++) {
+                        const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                        if (td[2] != 0xFFFFFFFFu) continue;
+                        shown++;
+                        fprintf(stderr, "  per-lane tile %lld (gen tiles start %lld):", (long long)b, (long long)c.phase_gen_tile[k]);
+                        for (int64_t p = c.phase_start[k] + 64 * b; p < c.phase_start[k] + 64 * b + 64; p += 9) {
+                            const int64_t v = c.p_vid[p];
+                            if (v < 0) { fprintf(stderr, " pad"); continue; }
+                            std::vector<uint32_t> ww;
+                            lane_words(v, ww);
+                            fprintf(stderr, " v%lld f%d ev%d [", (long long)v, (int)fast[v], (int)d->variable[v].isEvidence);
+                            for (size_t j = 0; j < ww.size(); j += 1 + ((ww[j] >> 24) & 7u))
+                                fprintf(stderr, "%u:%u:%u ", ww[j] >> 27, (ww[j] >> 24) & 7u, ww[j] & 0xFFFFFFu);
+                            fprintf(stderr, "]");
+                        }
+                        fprintf(stderr, "\n");
+                    }
+                fprintf(stderr, "[nsk] colour %d: %lld positions, tiles uniform %lld pair %lld general %lld shape %lld "
+                                "per-lane %lld; generic %lld (hub-style %lld)\n", (int)k,
+                        (long long)(c.phase_start[k + 1] - c.phase_start[k]),
+                        (long long)kinds[0], (long long)(kinds[2] + kinds[3] + kinds[4]), (long long)kinds[6],
+                        (long long)kinds[7], (long long)kinds[8],
+                        (long long)(c.phase_start[k + 1] - c.phase_fast_end[k]),
+                        (long long)(c.phase_heavy_end[k] - c.phase_fast_end[k]));
+            }
+        }
         // pass 2: fill the tiles.  Padding: member slots read variable 0 (harmless) in uniform
         // tiles, 0xFFFFFFFF in tiles with per-lane headers.
         c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);
