@@ -159,16 +159,19 @@ def _small_graphs(golden):
         "gencat_vid": (_general_tile_graph(), True),
         # weight table beyond 4 MB: general tiles read materialised weight rows in inference
         "gencat_bigw": (_general_tile_graph(nweight=600000), True),
+        "gencat_i32": (_general_tile_graph(wide_values=True), True),
     }
 
 
-def _general_tile_graph(nweight=30):
+def _general_tile_graph(nweight=30, wide_values=False):
     from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar
     rng = np.random.default_rng(23)
     nvar, nfactor = 6000, 1700
     variable = np.zeros(nvar, Variable)
     card = rng.integers(2, 9, nvar)
     card[rng.random(nvar) < 0.03] = 30                 # too large for a general tile: generic path
+    if wide_values:
+        card[::997] = 200                              # values no longer fit int8: the int32 kernels
     variable["cardinality"] = card
     variable["dataType"] = rng.random(nvar) < 0.5
     variable["isEvidence"] = rng.random(nvar) < 0.5
@@ -286,7 +289,7 @@ def _big_cardinality_graph():
 
 GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
           "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat", "gencat_vid",
-          "gencat_bigw"]
+          "gencat_bigw", "gencat_i32"]
 
 
 @pytest.mark.parametrize("name", GRAPHS)
@@ -316,7 +319,7 @@ def test_chromatic_inference_equals_oracle(golden, name, sample_evidence):
 
 @pytest.mark.parametrize("name", ["mixed", "lf", "pairs", "grid32", "lr3000", "lr_bigcard",
                                   "headquirk", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat",
-                                  "gencat_vid"])
+                                  "gencat_vid", "gencat_i32"])
 @pytest.mark.parametrize("reg,trunc", [(0, 1), (1, 1), (1, 3), (2, 1)])
 @pytest.mark.parametrize("lne", [False, True])
 def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
@@ -372,6 +375,29 @@ def test_generic_kernels_alone(golden, name, no_general, no_heavy, monkeypatch):
     fg.inference(0, 3, True)
     for sweep in range(2, 5):
         assert og.gibbs_dev(order, ps, vv, wv, cnt, 5, sweep, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
+def test_general_tiles_at_scale():
+    """200 000-variable mixed LR graph: full tiles of every layout (up to 12 entries x 5 words),
+    both launches (binary / categorical), thousands of wave-per-variable leftovers."""
+    g = graphgen.mixed_lr_graph(200000, seed=11)
+    ns, fg = session(g, seed=9, head_by_vid=True)
+    info = fg.info()
+    assert info["nfast"] > 190000 and 0 < info["ngeneric"] < 10000
+    og = oracle_of(fg, True)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, cnt = og.initial_state()
+    fg.learn(0, 2, 0.001, 0.9, 2, 0.01, 1, learn_non_evidence=False)
+    step = 0.001
+    for sweep in range(2):
+        assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 9, sweep) == 0
+        step *= 0.9
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    assert np.array_equal(fg.weight_value[0], wv)
+    fg.inference(0, 3, True)
+    for sweep in range(2, 5):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 9, sweep, True) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
 
 
