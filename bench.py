@@ -137,6 +137,17 @@ def side_run(name, seed, steps, warmup):
             "avg_launch_us": ms.value * 1e3 / max(1, nl.value)}
 
 
+def dominant_kernel(workload, learning, info):
+    """Name of the kernel family the launch average is dominated by (profiles/*_kernel_stats.csv)."""
+    if not info["nfast"]:
+        return "k_learn_phase" if learning else "k_gibbs_phase"
+    if workload.startswith("lr"):
+        return "k_learn_general" if learning else "k_gibbs_general"
+    if workload.startswith("boolw"):
+        return "k_learn_fast+k_learn_general" if learning else "k_gibbs_fast+k_gibbs_general"
+    return "k_learn_fast" if learning else "k_gibbs_seg"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,8 +174,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # test hooks for a box with fewer GPUs than ranks: NSK_BENCH_ONE_DEVICE puts every rank on
+        # device 0, NSK_BENCH_BACKEND=gloo replaces RCCL (the library then falls back to the
+        # torch.distributed exchange loop); the driver's runs use neither
+        if os.environ.get("NSK_BENCH_ONE_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("NSK_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     rows, cols, learning = WORKLOADS[args.workload]
     g = build_graph(rows, cols, learning, name=args.workload)
@@ -230,7 +246,7 @@ def main():
         achieved = alg_per_launch / launch_s / 1e9
         traffic = None
         tp = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and world == 1:      # PMC bytes were collected for the one-GPU launch
             try:
                 traffic = json.load(open(tp)).get(args.workload)
             except Exception:
@@ -257,8 +273,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "actual_GBs": (traffic / launch_s / 1e9) if traffic else None,
                          "alg_bytes_per_update": alg_sweep * world / nvar,
-                         "kernel": ("k_learn_fast" if info["nfast"] else "k_learn_phase") if learning
-                         else ("k_gibbs_seg" if info["nfast"] else "k_gibbs_phase"),
+                         "kernel": dominant_kernel(args.workload, learning, info),
                          "stream_copy_GBs": copy_gbs,
                          "launches": nlaunch, "avg_launch_us": launch_s * 1e6},
         }
