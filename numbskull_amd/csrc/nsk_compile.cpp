@@ -368,6 +368,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const bool no_general = getenv("NSK_NO_GENERAL") != nullptr;
     // longer lists go to the wave-per-variable kernel: a tile is walked by one wave, so its longest
     // lane sets a serial chain of memory round trips and the longest tile the kernel's run time
+    const int64_t gen_block = getenv("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(getenv("NSK_GEN_BLOCK"))) : 262144;
     const int64_t gen_max_entries = getenv("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(getenv("NSK_GEN_MAX_ENTRIES")))) : 12;
     auto general_words = [&](int64_t v, std::vector<uint32_t> *out) -> bool {
         const nsk_variable &var = d->variable[v];
@@ -595,7 +596,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // largest first, and cut into tiles of 64 -- a tile's layout is the maximum over its lanes,
         // so neighbours in this order waste the least padding (SELL-C-sigma)
         {
-            std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (-key, vid)
+            std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (key, vid)
             for (int64_t v = 0; v < nvar; v++) {
                 if (c.color[v] < 0 || fast[v] != 2) continue;
                 general_words(v, &gw);
@@ -604,8 +605,12 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     ne++;
                     mo = std::max<int64_t>(mo, (gw[j + 1] >> 4) & 7u);
                 }
-                const int64_t catv = d->variable[v].cardinality > 2 ? 1 : 0;     // categorical tiles first
-                order[c.color[v]].push_back({-((catv << 20) + ne * 8 + mo), v});
+                // key: categorical lanes first (their tiles form a launch of their own), then blocks
+                // of gen_block consecutive ids (sigma of SELL-C-sigma: each XCD walks a contiguous
+                // run of tiles, so its L2 then sees one slice of the value array instead of all of
+                // it), largest layouts first inside a block
+                const int64_t catv = d->variable[v].cardinality > 2 ? 0 : 1;
+                order[c.color[v]].push_back({(catv << 50) | ((v / gen_block) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
             }
             for (int32_t k = 0; k < ncolors; k++) {
                 std::sort(order[k].begin(), order[k].end());
