@@ -297,6 +297,48 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
     }
 
+    // fewer classes: iterated greedy (Culberson) -- recolour first fit with the vertices taken class
+    // by class in a permuted class order; a class stays independent, so the count never grows, and
+    // a few passes typically drop one or two classes (LR graph: 9 -> 7).  Every class costs a
+    // kernel's latency floor, so this is sweep time.
+    if (!conflict && ncolors > 2 && !getenv("NSK_NO_RECOLOUR")) {
+        std::vector<int32_t> newc(nvar), seq;
+        seq.reserve((size_t)nvar);
+        for (int pass = 0; pass < 6; pass++) {
+            std::vector<int64_t> size((size_t)ncolors, 0);
+            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) size[c.color[v]]++;
+            std::vector<int32_t> cls((size_t)ncolors);
+            for (int32_t k = 0; k < ncolors; k++) cls[k] = k;
+            if (pass % 3 == 0) std::reverse(cls.begin(), cls.end());
+            else std::stable_sort(cls.begin(), cls.end(), [&](int32_t a, int32_t b) {
+                return pass % 3 == 1 ? size[a] > size[b] : size[a] < size[b]; });
+            std::vector<int64_t> at((size_t)ncolors + 1, 0);           // counting sort by class rank
+            std::vector<int32_t> rank((size_t)ncolors);
+            for (int32_t r = 0; r < ncolors; r++) rank[cls[r]] = r;
+            for (int32_t k = 0; k < ncolors; k++) at[rank[k] + 1] = size[k];
+            for (int32_t r = 0; r < ncolors; r++) at[r + 1] += at[r];
+            seq.assign((size_t)at[ncolors], 0);
+            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) seq[at[rank[c.color[v]]]++] = (int32_t)v;
+            std::fill(newc.begin(), newc.end(), -1);
+            std::vector<int64_t> st(1, -1);
+            int32_t nnew = 0;
+            for (int32_t v : seq) {
+                for_each_read(v, [&](int64_t b) {
+                    if (b != v && newc[b] >= 0) st[newc[b]] = v;
+                });
+                int32_t col = 0;
+                while (col < nnew && st[col] == v) col++;
+                if (col == nnew) { nnew++; st.push_back(-1); }
+                newc[v] = col;
+            }
+            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) c.color[v] = newc[v];
+            ncolors = nnew;
+        }
+        stamp.assign((size_t)ncolors, -1);
+        load.assign((size_t)ncolors, 0);
+        for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) load[c.color[v]]++;
+    }
+
     // balancing: first fit leaves a few huge classes and a tail of tiny ones, and every class costs
     // a kernel's latency floor however few variables it holds.  Move variables, in id order, from
     // their class to the least populated class none of their neighbours is in (reads are symmetric
