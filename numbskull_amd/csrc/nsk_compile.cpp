@@ -411,7 +411,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // longer lists go to the wave-per-variable kernel: a tile is walked by one wave, so its longest
     // lane sets a serial chain of memory round trips and the longest tile the kernel's run time
     const int64_t gen_block = getenv("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(getenv("NSK_GEN_BLOCK"))) : 262144;
-    const int64_t gen_max_entries = getenv("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(getenv("NSK_GEN_MAX_ENTRIES")))) : 12;
+    const int64_t gen_max_entries = getenv("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(getenv("NSK_GEN_MAX_ENTRIES")))) : 16;
     auto general_words = [&](int64_t v, std::vector<uint32_t> *out) -> bool {
         const nsk_variable &var = d->variable[v];
         if (var.cardinality > 8 || var.cardinality < 2) return false;
