@@ -188,6 +188,7 @@ static DevGraph<VT> view(nsk_graph *g) {
     d.prog_w = g->prog_w; d.adj_wt = g->adj_wt; d.tile_wrow = g->tile_wrow;
     d.part_G = g->part_G; d.part_K = g->part_K; d.part_T = g->part_T;
     d.nweight = (int32_t)g->c.nweight;
+    d.packed_grad = g->c.packed_grad ? 1 : 0;
     d.cnt_pos = g->cnt_pos;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
@@ -605,7 +606,8 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                         g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0);
                 } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation);
+                        g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation,
+                        (!SMALLW && g->c.packed_grad) ? 1 : 0);
                     refresh_prog_weights(g, true);
                 }
             }

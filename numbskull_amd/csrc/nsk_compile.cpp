@@ -1115,6 +1115,22 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 }
             }
     }
+    // integer gradients?  (p1 - p0) * featureValue is an integer of magnitude <= 2 when featureValue
+    // is -1, 0 or 1 and no function returns counts or logarithms; visits per weight and class are
+    // bounded by the weight's member edges
+    {
+        bool ok = true;
+        std::vector<int64_t> edges_of((size_t)nw, 0);
+        for (int64_t f = 0; f < nfac && ok; f++) {
+            const nsk_factor &fa = d->factor[f];
+            const int fn = fa.factorFunction;
+            if (!(fa.featureValue == 1.0 || fa.featureValue == 0.0 || fa.featureValue == -1.0)) ok = false;
+            if (fn == 7 || fn == 8 || fn == 30) ok = false;            // LINEAR, RATIO, UFO
+            if (fa.weightId >= 0 && fa.weightId < nw) edges_of[fa.weightId] += std::max<int64_t>(fa.arity, 1);
+        }
+        for (int64_t i = 0; i < nw && ok; i++) if (edges_of[i] >= ((int64_t)1 << 28)) ok = false;
+        c.packed_grad = ok && !getenv("NSK_NO_PACKED");
+    }
     c.alg_bytes_inference = bytes_inf;
     c.alg_bytes_learning = bytes_learn;
     return NSK_OK;

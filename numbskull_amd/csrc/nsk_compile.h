@@ -62,6 +62,7 @@ struct Compiled {
     std::vector<int64_t> phase_rest_base;   // [ncolors+1]
     // general tiles (kind 6) are the last tiles of a colour's tile range: first one, relative
     std::vector<int64_t> phase_gen_tile;    // [ncolors]
+    bool packed_grad = false;               // integer gradients, bounded visit counts (GradSink::packed)
     std::vector<int64_t> phase_gen_bin_tile;   // [ncolors] first of the all-binary general tiles (they come last)
     int64_t nfast = 0;
     // per position

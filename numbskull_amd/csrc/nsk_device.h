@@ -185,6 +185,7 @@ struct DevGraph {
     long long *part_G;          // [rows][nweight]
     uint32_t *part_K, *part_T;
     int32_t nweight;
+    int32_t packed_grad;        // integer gradients: visit counts ride in the low half of G (GradSink)
     // fast path: inlined adjacency streams (DESIGN.md "fast path") and a position-indexed tally
     const uint4 *adj;           // stream: chunk c of lane i of a tile at adj[off + 64*c + i]
     const uint4 *tiles;         // [nwb] {stream offset, words per lane, tile_hdr offset | PAD, entries}
@@ -689,6 +690,10 @@ struct GradSink {
     long long *G;       // fixed-point gradient sums (Q31.32: order-independent, hence deterministic)
     uint32_t *K;        // visits
     uint32_t *T;        // truncating visits (L1)
+    // packed: every gradient of the graph is an integer (featureValue in {-1,0,1}, no LINEAR / RATIO
+    // / UFO), so the 32 fraction bits of G are free and carry the visit count -- one 64-bit atomic
+    // per visit instead of two atomics (global accumulators only; nsk_compile.cpp decides)
+    bool packed;
 };
 
 // Add one (weight, gradient) visit per participating lane.  Must be called by all 64 lanes of the
@@ -707,15 +712,15 @@ __device__ __forceinline__ void accumulate_gradient(const GradSink &sk, bool hav
         const long long sum = wave_sum_i64(same ? gfix : 0LL);
         const int nt = __popcll(__ballot(same && trunc));
         if ((int)(threadIdx.x & 63) == leader) {
-            atomicAdd((unsigned long long *)&sk.G[lw], (unsigned long long)sum);
-            atomicAdd(&sk.K[lw], (uint32_t)nsame);
+            atomicAdd((unsigned long long *)&sk.G[lw], (unsigned long long)(sum + (sk.packed ? nsame : 0)));
+            if (!sk.packed) atomicAdd(&sk.K[lw], (uint32_t)nsame);
             if (nt) atomicAdd(&sk.T[lw], (uint32_t)nt);
         }
         have = have && !same;
     }
     if (have) {
-        atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)gfix);
-        atomicAdd(&sk.K[wid], 1u);
+        atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)(gfix + (sk.packed ? 1 : 0)));
+        if (!sk.packed) atomicAdd(&sk.K[wid], 1u);
         if (trunc) atomicAdd(&sk.T[wid], 1u);
     }
 }

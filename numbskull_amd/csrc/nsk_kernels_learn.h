@@ -33,6 +33,7 @@ __device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem)
     } else {
         sk.G = g.G; sk.K = g.K; sk.T = g.T;
     }
+    sk.packed = !SMALLW && g.packed_grad != 0;
     return sk;
 }
 
@@ -310,8 +311,8 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
             if ((threadIdx.x & 63) == 0) {
                 const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
                 const int wid = (int)(s & 0xFFFFFFu);
-                atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)dG);
-                atomicAdd(&sk.K[wid], nk);
+                atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
+                if (!sk.packed) atomicAdd(&sk.K[wid], nk);
                 if (nt) atomicAdd(&sk.T[wid], nt);
             }
         }
@@ -577,13 +578,23 @@ __device__ __forceinline__ double apply_update(double x, long long G, uint32_t k
 __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
                                                              uint32_t *T, int nweight, double step,
                                                              int regularization, double reg_param,
-                                                             double truncation) {
+                                                             double truncation, int packed) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= nweight) return;
-    const uint32_t k = K[i];
-    if (k == 0) return;
-    w[i] = apply_update(w[i], G[i], k, T[i], step, regularization, reg_param, truncation);
-    G[i] = 0; K[i] = 0; T[i] = 0;
+    long long gsum = G[i];
+    uint32_t k;
+    if (packed) {                       // visits in the low half, integer gradient sum in the high half
+        k = (uint32_t)((unsigned long long)gsum & 0xFFFFFFFFull);
+        gsum -= (long long)k;
+    } else {
+        k = K[i];
+    }
+    if (k == 0) return;                 // untouched in this class (packed: one 8-byte read)
+    const uint32_t t = regularization == 1 ? T[i] : 0u;     // only L1 ever counts truncations
+    w[i] = apply_update(w[i], gsum, k, t, step, regularization, reg_param, truncation);
+    G[i] = 0;
+    if (!packed) K[i] = 0;
+    if (regularization == 1) T[i] = 0;
 }
 
 // SMALLW flavour: one block per weight adds up the per-block rows, applies the update and rewrites

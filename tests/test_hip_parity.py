@@ -378,6 +378,27 @@ def test_generic_kernels_alone(golden, name, no_general, no_heavy, monkeypatch):
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
 
 
+@pytest.mark.parametrize("name", ["lr_manyw", "pairs_manyw", "boolw", "gencat_bigw"])
+@pytest.mark.parametrize("reg", [1, 2])
+def test_learning_with_unpacked_accumulators(golden, name, reg, monkeypatch):
+    """Graphs with integer gradients carry the visit count in the low half of the 64-bit gradient
+    accumulator (one atomic per visit); NSK_NO_PACKED keeps the separate counters that graphs with
+    fractional gradients use: same weights."""
+    monkeypatch.setenv("NSK_NO_PACKED", "1")
+    g, hbv = _small_graphs(golden)[name]
+    ns, fg = session(g, seed=5, head_by_vid=hbv)
+    og = oracle_of(fg, hbv)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, _ = og.initial_state()
+    fg.learn(0, 3, 0.01, 0.9, reg, 0.05, 2, learn_non_evidence=True)
+    step = 0.01
+    for sweep in range(3):
+        assert og.learn_dev(order, ps, vv, ve, wv, step, reg, 0.05, 2, True, 5, sweep) == 0
+        step *= 0.9
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    assert np.array_equal(fg.weight_value[0], wv)
+
+
 def test_general_tiles_at_scale():
     """200 000-variable mixed LR graph: full tiles of every layout (up to 12 entries x 5 words),
     both launches (binary / categorical), thousands of wave-per-variable leftovers."""
