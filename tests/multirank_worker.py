@@ -1,0 +1,88 @@
+"""Worker of tests/test_multirank_gpu.py: one of WORLD_SIZE processes (all on cuda:0, gloo
+rendezvous) running the real multi-rank host path -- FactorGraph with an owned range, ghost-need
+gathering, boundary planning, PartitionedSampler's per-sweep loop -- against the oracle's emulation
+of the partitioned semantics.  Exits non-zero on any mismatch."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from util import graphgen, oracle_of, phases_from_colors          # noqa: E402
+import numbskull_amd                                              # noqa: E402
+from numbskull_amd.distributed import PartitionedSampler, shard_range   # noqa: E402
+
+
+def graph(kind):
+    if kind == "grid":
+        rng = np.random.default_rng(3)
+        return graphgen.ising_grid(40, 30, weight=0.1, fixed=False, two_weights=True,
+                                   evidence=rng.integers(0, 2, 1200)), False
+    return graphgen.mixed_lr_graph(4000, seed=12, nweights=300), True     # general tiles, global atomics
+
+
+def main():
+    kind, learn, nsweeps = sys.argv[1], sys.argv[2] == "learn", 4
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g, hbv = graph(kind)
+    nvar = len(g[1])
+    handles = []
+    for r in range(world):                       # rank r's graph; the others only to emulate them
+        ns = numbskull_amd.NumbSkull(quiet=True, seed=31, head_by_vid=hbv)
+        w, v, f, fm, dm, edges = [x.copy() if isinstance(x, np.ndarray) else x for x in g]
+        ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=shard_range(r, world, nvar))
+        handles.append(ns.factorGraphs[0])
+    fg = handles[rank]
+    sampler = PartitionedSampler(fg, dist, torch, rank, world)       # native RCCL refuses one device
+    assert not sampler.native                                        # for two ranks: torch loop
+    oracles = []
+    for r in range(world):
+        color = handles[r].plan()[0] if r != rank else fg.colors()
+        og = oracle_of(handles[r], hbv)
+        oracles.append((og, phases_from_colors(color), og.initial_state()))
+    if learn:
+        sampler.learn(nsweeps, 0.01, 0.9, 2, 0.01, 1)
+    else:
+        sampler.gibbs(nsweeps, True, False)
+    torch.cuda.synchronize()
+    step = 0.01
+    for s in range(nsweeps):
+        starts = [st[2].copy() for _, _, st in oracles]
+        for og, (order, ps), (vv, ve, wv, cnt) in oracles:
+            if learn:
+                assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 31, s) == 0
+            else:
+                assert og.gibbs_dev(order, ps, vv, wv, cnt, 31, s, True) == 0
+        step *= 0.9
+        for r in range(world):                   # owners publish their boundary values
+            b = sampler.lists[r]
+            for q in range(world):
+                if q != r:
+                    oracles[q][2][0][b] = oracles[r][2][0][b]
+                    oracles[q][2][1][b] = oracles[r][2][1][b]
+        if learn:
+            total = sum(st[2] - s0 for (_, _, st), s0 in zip(oracles, starts))
+            for (_, _, st), s0 in zip(oracles, starts):
+                st[2][:] = s0 + total
+    vv, ve, wv, cnt = oracles[rank][2]
+    lo, hi = shard_range(rank, world, nvar)
+    got = sampler.val.cpu().numpy().astype(np.int64)
+    assert np.array_equal(got[lo:hi], vv[lo:hi]), "owned values differ"
+    for r in range(world):
+        if r != rank:
+            assert np.array_equal(got[sampler.lists[r]], vv[sampler.lists[r]]), "ghost values differ"
+    if learn:
+        gote = sampler.val_evid.cpu().numpy().astype(np.int64)
+        assert np.array_equal(gote[lo:hi], ve[lo:hi]), "evidence-chain values differ"
+        assert np.allclose(sampler.w.cpu().numpy(), wv, rtol=0, atol=1e-13), "weights differ"
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,29 @@
+"""Two real processes on one GPU (gloo rendezvous, both ranks on cuda:0): the multi-rank host path
+-- owned ranges, ghost needs gathered with torch.distributed, boundary planning, PartitionedSampler's
+per-sweep exchange through torch collectives on the library's own device buffers, weight-delta
+all-reduce -- against the oracle's emulation of the partitioned semantics.  (RCCL itself needs one
+device per rank: the 1-rank RCCL tests in test_hip_parity.py and the driver's 8-GPU run cover it.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("kind", ["grid", "lr"])
+@pytest.mark.parametrize("mode", ["gibbs", "learn"])
+def test_two_ranks_one_gpu(kind, mode):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(HERE, "multirank_worker.py"), kind, mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
