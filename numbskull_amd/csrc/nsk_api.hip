@@ -84,7 +84,7 @@ struct nsk_graph {
     uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr, *gstream = nullptr, *gs_off = nullptr;
     double *prog_w = nullptr, *adj_wt = nullptr;
     uint32_t *tile_wrow = nullptr;
-    uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr;
+    uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr, *learn_rest_tiles = nullptr;
     long long *part_G = nullptr;       // SMALLW: rows of per-block partial sums
     uint32_t *part_K = nullptr, *part_T = nullptr;
     bool smallw = false;
@@ -252,7 +252,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx); UP(gstream); UP(gs_off);
     UP(f_rec); UP(f_feat); UP(m_rec); UP(v_card); UP(v_pos);
-    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(tile_wrow);
+    UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
@@ -581,11 +581,30 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 rows += grid;
                 g->launches++;
             }
-            if (gt0 > ndyn) {           // uniform and shape tiles: inlined-adjacency learning kernel
-                const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (gt0 + 3) / 4);
+            for (const Compiled::SegLaunch &sl : g->c.learn_seg) {       // homogeneous segments
+                if (sl.phase != (int)ph) continue;
+                SegTable tab;
+                tab.n = sl.n;
+                for (int i = 0; i <= NSK_SEG_MAX; i++) tab.tile_start[i] = sl.tile_start[i];
+                for (int i = 0; i < NSK_SEG_MAX; i++) { tab.pos0[i] = sl.pos0[i]; tab.adj_off[i] = sl.adj_off[i]; tab.prog[i] = sl.prog[i]; }
+                const int grid = std::min(NSK_LEARN_SEG_BLOCKS, (tab.tile_start[tab.n] + 3) / 4);
+                lp.row_base = rows;
+#define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
+                if (sl.kind == 4) { if (sl.nch == 1) NSK_LSEG(4, 1); else NSK_LSEG(4, 2); }
+                else if (sl.kind == 2) { if (sl.nch == 1) NSK_LSEG(2, 1); else NSK_LSEG(2, 2); }
+                else if (sl.kind == 0) { if (sl.nch == 1) NSK_LSEG(0, 1); else NSK_LSEG(0, 2); }
+                else { if (sl.nch == 1) NSK_LSEG(3, 1); else NSK_LSEG(3, 2); }
+#undef NSK_LSEG
+                rows += grid;
+                g->launches++;
+            }
+            const int nlrest = (int)(g->c.phase_learn_rest_base[ph + 1] - g->c.phase_learn_rest_base[ph]);
+            if (nlrest > 0) {           // the other uniform and shape tiles: descriptor-driven kernel
+                const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (nlrest + 3) / 4);
                 lp.row_base = rows;
                 k_learn_fast<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, lp);
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], g->learn_rest_tiles + g->c.phase_learn_rest_base[ph],
+                    nlrest, lp);
                 rows += grid;
                 g->launches++;
             }

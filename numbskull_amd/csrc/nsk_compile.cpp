@@ -913,6 +913,41 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             c.phase_rest_base[k + 1] = (int64_t)c.rest_tiles.size();
         }
         if (c.rest_tiles.empty()) c.rest_tiles.push_back(0);
+        // learning launches: segments grouped by (kind, chunks) into tables of <= 8, the
+        // NSK_LEARN_SEG_LAUNCHES largest tables of a colour become launches, the tiles of the
+        // others join the colour's rest list
+        c.phase_learn_rest_base.assign((size_t)ncolors + 1, 0);
+        for (int32_t k = 0; k < ncolors; k++) {
+            std::vector<Compiled::SegLaunch> tabs;
+            for (int kind = 0; kind <= 4; kind++)
+                for (int nch = 1; nch <= 2; nch++) {
+                    Compiled::SegLaunch t;
+                    memset(&t, 0, sizeof(t));
+                    t.phase = k; t.kind = kind; t.nch = nch;
+                    for (const Compiled::Segment &sg : c.segments) {
+                        if (sg.phase != k || (int)(sg.kind == 1 ? 3 : sg.kind) != kind || (sg.nslots > 4 ? 2 : 1) != nch)
+                            continue;
+                        t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
+                        t.tile_start[t.n + 1] = t.tile_start[t.n] + sg.ntiles;
+                        if (++t.n == 8) { tabs.push_back(t); t.n = 0; t.tile_start[0] = 0; }
+                    }
+                    if (t.n) tabs.push_back(t);
+                }
+            std::stable_sort(tabs.begin(), tabs.end(), [](const Compiled::SegLaunch &a, const Compiled::SegLaunch &b) {
+                return a.tile_start[a.n] > b.tile_start[b.n]; });
+            std::vector<uint32_t> extra;
+            for (size_t i = 0; i < tabs.size(); i++) {
+                if (i < NSK_LEARN_SEG_LAUNCHES && !getenv("NSK_NO_LEARN_SEG")) { c.learn_seg.push_back(tabs[i]); continue; }
+                for (int j = 0; j < tabs[i].n; j++)
+                    for (int32_t t = 0; t < tabs[i].tile_start[j + 1] - tabs[i].tile_start[j]; t++)
+                        extra.push_back((uint32_t)((tabs[i].pos0[j] - c.phase_start[k]) / 64 + t));
+            }
+            for (int64_t i = c.phase_rest_base[k]; i < c.phase_rest_base[k + 1]; i++) extra.push_back(c.rest_tiles[i]);
+            std::sort(extra.begin(), extra.end());
+            c.learn_rest_tiles.insert(c.learn_rest_tiles.end(), extra.begin(), extra.end());
+            c.phase_learn_rest_base[k + 1] = (int64_t)c.learn_rest_tiles.size();
+        }
+        if (c.learn_rest_tiles.empty()) c.learn_rest_tiles.push_back(0);
         if (getenv("NSK_VERBOSE")) {                 // layout report: tiles by kind, per colour
             for (int32_t k = 0; k < ncolors; k++) {
                 int64_t kinds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

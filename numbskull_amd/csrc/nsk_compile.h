@@ -10,6 +10,7 @@
 
 #include "../../include/numbskull_amd.h"
 
+#define NSK_LEARN_SEG_LAUNCHES 4       // segment launches of the learning sweep per colour class
 #define NSK_GEN_NULL 0x7FFFFFFu     // member id of an empty slot in a general tile (kind 6)
 
 namespace nsk {
@@ -59,6 +60,13 @@ struct Compiled {
     struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev; };
     std::vector<Segment> segments;
     std::vector<uint32_t> rest_tiles;       // tile indices relative to the phase's first tile
+    // learning: the largest (kind, chunks) groups of a colour's segments run as segment launches of
+    // their own (at most NSK_LEARN_SEG_LAUNCHES per colour); every other non-general tile is on
+    // the colour's learn_rest list
+    struct SegLaunch { int32_t phase, kind, nch, n; int32_t tile_start[9]; int32_t pos0[8]; uint32_t adj_off[8], prog[8]; };
+    std::vector<SegLaunch> learn_seg;
+    std::vector<uint32_t> learn_rest_tiles;
+    std::vector<int64_t> phase_learn_rest_base;   // [ncolors+1]
     std::vector<int64_t> phase_rest_base;   // [ncolors+1]
     // general tiles (kind 6) are the last tiles of a colour's tile range: first one, relative
     std::vector<int64_t> phase_gen_tile;    // [ncolors]

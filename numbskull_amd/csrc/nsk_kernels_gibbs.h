@@ -21,8 +21,9 @@ namespace nsk {
 #define NSK_LEARN_GEN_BLOCKS 2048
 #define NSK_LEARN_HEAVY_BLOCKS 512
 #define NSK_LEARN_GENERAL_BLOCKS 2048
+#define NSK_LEARN_SEG_BLOCKS 2048      // per segment launch, at most 4 launches per colour (nsk_compile.h)
 #define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS + NSK_LEARN_HEAVY_BLOCKS + \
-                        NSK_LEARN_GENERAL_BLOCKS)
+                        NSK_LEARN_GENERAL_BLOCKS + 4 * NSK_LEARN_SEG_BLOCKS)
 
 // One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
 // gibbsthread's loop body (inference.py:20-33) for that variable.

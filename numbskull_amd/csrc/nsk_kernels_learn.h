@@ -502,11 +502,39 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
                            });
 }
 
-// Learning over the uniform tiles of a colour class (tiles with per-lane headers are left to
-// k_learn_phase in list mode).  Each wave takes a contiguous run of tiles.
+// Learning over the uniform and shape tiles of a colour class that are not in a segment launch
+// (tiles with per-lane headers are left to k_learn_phase in list mode).  Each wave takes a
+// contiguous run of the list.
+// Learning over homogeneous segments (runs of uniform tiles with one program; see k_gibbs_seg): the
+// tile kind and chunk count are template parameters, so the body is the one learn_tile variant the
+// segments need, with every loop bound known at compile time.
+template <typename VT, bool SMALLW, int KIND, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTable tab, LearnParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
+    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
+    const int ntiles = tab.tile_start[tab.n];
+    const int per = (ntiles + nwaves - 1) / nwaves;
+    const int t1 = min(ntiles, (wave0 + 1) * per);
+    for (int T = wave0 * per; T < t1; T++) {
+        int sidx = 0;
+#pragma unroll
+        for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+        const int t = T - tab.tile_start[sidx];
+        const int p = tab.pos0[sidx] + t * 64 + lane;
+        const bool valid = g.p_vid[p] >= 0;                  // -1: padding lane at a class end
+        const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+        learn_tile<VT, KIND>(g, sk, sp, 4 * NCH, tab.prog[sidx], p, valid, lp);
+    }
+    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+}
+
 template <typename VT, bool SMALLW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pbegin, int pend,
-                                                          int wb_base, int ntiles, LearnParams lp) {
+                                                          int wb_base, const uint32_t *list, int ntiles,
+                                                          LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GradSink sk = open_sink<SMALLW>(g, smem);
     const int lane = (int)(threadIdx.x & 63);
@@ -514,7 +542,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
     const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
     const int per = (ntiles + nwaves - 1) / nwaves;
     const int t1 = min(ntiles, (wave0 + 1) * per);
-    for (int t = wave0 * per; t < t1; t++) {
+    for (int i = wave0 * per; i < t1; i++) {
+        const int t = (int)__builtin_amdgcn_readfirstlane(list[i]);     // the colour's learn_rest list
         const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
         const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
         if (td.z == NSK_PAD_WORD) continue;                  // mixed per-lane headers: generic kernel's job
