@@ -145,7 +145,7 @@ def dominant_kernel(workload, learning, info):
         return "k_learn_general" if learning else "k_gibbs_general"
     if workload.startswith("boolw"):
         return "k_learn_fast+k_learn_general" if learning else "k_gibbs_fast+k_gibbs_general"
-    return "k_learn_fast" if learning else "k_gibbs_seg"
+    return "k_learn_seg" if learning else "k_gibbs_seg"
 
 
 def main():
