@@ -434,14 +434,23 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
     double w = 0.0;
     int entry = 0;                                 // wave-uniform
     // NSK_GEN_GROUP chunks (16-byte loads) at a time: their stream loads, then all their gathers,
-    // are in flight together -- the walk of a long tile is a chain of dependent memory round trips
-    for (int c0 = 0; c0 * 4 < len; c0 += NSK_GEN_GROUP) {
-        uint4 q[NSK_GEN_GROUP];
+    // are in flight together -- the walk of a long tile is a chain of dependent memory round trips.
+    // The next group's stream loads are issued before this group's gathers (double buffer), so the
+    // chain is one round trip per group instead of two.
+    auto load_group = [&](int c0, uint4 (&q)[NSK_GEN_GROUP]) {
 #pragma unroll
         for (int j = 0; j < NSK_GEN_GROUP; j++)
             q[j] = ((c0 + j) * 4 >= len) ? uint4{0u, 0u, 0u, 0u}                                // uniform guard
                    : (NT ? stream_load(sp + (size_t)(c0 + j) * 64)   // NT: the tile is read once (inference)
                          : sp[(size_t)(c0 + j) * 64]);
+    };
+    uint4 qn[NSK_GEN_GROUP];
+    load_group(0, qn);
+    for (int c0 = 0; c0 * 4 < len; c0 += NSK_GEN_GROUP) {
+        uint4 q[NSK_GEN_GROUP];
+#pragma unroll
+        for (int j = 0; j < NSK_GEN_GROUP; j++) q[j] = qn[j];
+        if ((c0 + NSK_GEN_GROUP) * 4 < len) load_group(c0 + NSK_GEN_GROUP, qn);
         uint32_t wd[4 * NSK_GEN_GROUP], role[4 * NSK_GEN_GROUP];
 #pragma unroll
         for (int j = 0; j < NSK_GEN_GROUP; j++) {
