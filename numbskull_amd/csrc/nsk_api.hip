@@ -426,11 +426,17 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 const int e = (int)g->c.phase_start[ph + 1];
                 const int he = (int)g->c.phase_heavy_end[ph];
                 ColourStreams cs(g, !g->no_overlap);
-                if (he > fe) {      // hubs: one wave per variable
-                    k_gibbs_heavy<VT><<<dim3((he - fe + 3) / 4), dim3(NSK_BLOCK), 0, cs.side(0)>>>(
-                        d, fe, he, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
-                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
-                    g->launches++;
+                {   // hubs (one wave per variable) + general tiles with categorical lanes: one launch
+                    const int gt0 = fe > fb ? (int)g->c.phase_gen_tile[ph] : 0;
+                    const int gtb = fe > fb ? (int)g->c.phase_gen_bin_tile[ph] : 0;
+                    const int nblocks = (gtb - gt0 + 3) / 4, hblocks = (he - fe + 3) / 4;
+                    if (nblocks + hblocks > 0) {
+                        k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, cs.side(0)>>>(
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks,
+                            sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                            (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                        g->launches++;
+                    }
                 }
                 if (e > he) {       // generic CSR kernel, one lane per variable
                     k_gibbs_phase<VT><<<dim3((e - he + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, cs.side(1)>>>(
@@ -444,17 +450,10 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const int gt0 = (int)g->c.phase_gen_tile[ph];
                     const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
                     const int gtb = (int)g->c.phase_gen_bin_tile[ph];
-                    if (gtb > gt0) {   // general tiles with categorical lanes
-                        const int nblocks = (gtb - gt0 + 3) / 4;
-                        k_gibbs_general<VT, 8><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, cs.side(2)>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, sample_evidence,
-                            burnin, K0, K1, S0, S1);
-                        g->launches++;
-                    }
                     if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
                         const int nblocks = (gt0 + ngt - gtb + 3) / 4;
                         k_gibbs_general<VT, 2><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks,
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, 0, 0, 0,
                             sample_evidence, burnin, K0, K1, S0, S1);
                         g->launches++;
                     }
@@ -547,13 +546,6 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
             const int he = (int)g->c.phase_heavy_end[ph];
             ColourStreams cs(g, !g->no_overlap);
-            if (he > fe) {              // hubs: one wave per variable
-                const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
-                lp.row_base = rows;
-                k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(0)>>>(d, fe, he, lp);
-                rows += grid;
-                g->launches++;
-            }
             if (e > he) {               // variables outside the fast path: generic kernel, range mode
                 const int nitems = (e - he + 63) / 64;
                 const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
@@ -565,10 +557,17 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             }
             const int gt0 = (int)g->c.phase_gen_tile[ph];
             const int gtb = (int)g->c.phase_gen_bin_tile[ph];
+            if (he > fe) {              // hubs: one wave per variable
+                const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
+                lp.row_base = rows;
+                k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(2)>>>(d, fe, he, lp);
+                rows += grid;
+                g->launches++;
+            }
             if (gtb > gt0) {            // general tiles with categorical lanes
                 const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (gtb - gt0 + 3) / 4);
                 lp.row_base = rows;
-                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(2)>>>(
+                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(0)>>>(
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, lp);
                 rows += grid;
                 g->launches++;

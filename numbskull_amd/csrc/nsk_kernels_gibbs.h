@@ -49,16 +49,13 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_WAVES) void k_gibbs_phase(De
     }
 }
 
-// Hubs (variables whose factor lists hold >= 128 entries): one WAVE per variable.  The lanes
-// evaluate the factors of a list 64 at a time and the terms are added in list order, so values are
-// bit-identical to the one-lane kernel; one lane draws and stores.
+// Hubs (long factor lists; every generic-path variable of a colour with few of them): one WAVE per
+// variable.  The lanes evaluate 64 (candidate, factor) pairs at a time and the terms are added in
+// list order, so values are bit-identical to the one-lane kernel; one lane draws and stores.  Runs
+// as the first blocks of the categorical general-tile launch (k_gibbs_general<VT, 8>).
 template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_heavy(DevGraph<VT> g, int pbegin, int pend,
-                                                           int sample_evidence, int burnin,
-                                                           uint32_t k0, uint32_t k1, uint32_t s0,
-                                                           uint32_t s1) {
-    const int p = pbegin + (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
-    if (p >= pend) return;                                // wave-uniform
+__device__ __forceinline__ void heavy_update(const DevGraph<VT> &g, int p, int sample_evidence, int burnin,
+                                             uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
     const uint32_t info = g.p_info[p];
     const int ev = NSK_INFO_EV(info);
     const int v = g.p_vid[p];
@@ -634,15 +631,23 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
 }
 
 // The general tiles of one colour class: tiles [tile0, tile0 + ntiles) of the colour, one wave each.
+// Blocks [0, hblocks) of the grid are hub blocks (one wave per position of [hb, he)), the rest walk
+// the tiles: one launch, so that a colour class needs one side stream less.
 template <typename VT, int MAXC>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int pbegin, int pend,
                                                              int wb_base, int tile0, int ntiles,
-                                                             int nblocks, int sample_evidence, int burnin,
+                                                             int nblocks, int hb, int he, int hblocks,
+                                                             int sample_evidence, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0,
                                                              uint32_t s1) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
     load_gen_lut(lut);
-    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
+    if ((int)blockIdx.x < hblocks) {                      // block-uniform
+        const int hp = hb + (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+        if (hp < he) heavy_update(g, hp, sample_evidence, burnin, k0, k1, s0, s1);
+        return;
+    }
+    const int lb = xcd_logical_block((int)blockIdx.x - hblocks, nblocks);
     if (lb < 0) return;
     const int lane = (int)(threadIdx.x & 63);
     const int t = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));

@@ -145,62 +145,66 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
 // gradient visits of list(evidence) and of the factors that are only in list(proposal) are spread
 // over the lanes (membership of a proposal-list factor in the evidence list: binary search, both
 // lists are sorted) and go through the same wave-aggregated accumulators.
+template <typename VT>
+__device__ __forceinline__ void learn_heavy_variable(const DevGraph<VT> &g, const GradSink &sk, int p,
+                                                     const LearnParams &lp) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int v = g.p_vid[p];
+    if (v < 0) return;
+    const uint32_t info = g.p_info[p];
+    const int ev = NSK_INFO_EV(info);
+    const int slot0 = g.p_slot[p];
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    int evidence;
+    if (ev != 1) evidence = wave_draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));
+    else evidence = (int)g.p_init[p];
+    const int proposal = wave_draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));
+    if (lane == 0) { g.val_evid[v] = (VT)evidence; g.val[v] = (VT)proposal; }
+    if (!(lp.learn_non_evidence || ev == 1)) return;
+    bool truncate = false;
+    if (lp.regularization == 1) {
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        truncate = u53(t.x, t.y) < lp.inv_trunc;
+    }
+    const int step = NSK_INFO_DT1(info);
+    const int a = g.slot_off[slot0 + step * evidence], ae = g.slot_off[slot0 + step * evidence + 1];
+    int b = 0, be = 0;
+    if (step && evidence != proposal) { b = g.slot_off[slot0 + proposal]; be = g.slot_off[slot0 + proposal + 1]; }
+    const int na = ae - a, nb = be - b;
+    for (int base = 0; base < na + nb; base += 64) {                 // wave-uniform trip count
+        const int i = base + lane;
+        bool have = false;
+        int wid = 0;
+        long long gfix = 0;
+        if (i < na + nb) {
+            const int fid = i < na ? g.fidx[a + i] : g.fidx[b + (i - na)];
+            bool dup = false;
+            if (i >= na) {                                           // already visited via list(evidence)?
+                int lo = a, hi = ae;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (g.fidx[mid] < fid) lo = mid + 1; else hi = mid; }
+                dup = lo < ae && g.fidx[lo] == fid;
+            }
+            const uint4 rec = g.f_rec[fid];
+            wid = (int)rec.z;
+            if (!dup && !g.w_fixed[wid]) {
+                const double p0 = eval_factor(g, rec, g.m_rec, v, evidence, g.val_evid);
+                const double p1 = eval_factor(g, rec, g.m_rec, v, proposal, g.val);
+                gfix = __double2ll_rn(((p1 - p0) * g.f_feat[fid]) * NSK_GRAD_SCALE);
+                have = true;
+            }
+        }
+        accumulate_gradient(sk, have, wid, gfix, truncate);
+    }
+}
+
 template <typename VT, bool SMALLW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_heavy(DevGraph<VT> g, int pbegin, int pend,
                                                            LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GradSink sk = open_sink<SMALLW>(g, smem);
-    const int lane = (int)(threadIdx.x & 63);
     const int wave0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
     const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
-    for (int p = pbegin + wave0; p < pend; p += nwaves) {
-        const int v = g.p_vid[p];
-        if (v < 0) continue;
-        const uint32_t info = g.p_info[p];
-        const int ev = NSK_INFO_EV(info);
-        const int slot0 = g.p_slot[p];
-        const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
-        int evidence;
-        if (ev != 1) evidence = wave_draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));
-        else evidence = (int)g.p_init[p];
-        const int proposal = wave_draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));
-        if (lane == 0) { g.val_evid[v] = (VT)evidence; g.val[v] = (VT)proposal; }
-        if (!(lp.learn_non_evidence || ev == 1)) continue;
-        bool truncate = false;
-        if (lp.regularization == 1) {
-            const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
-            truncate = u53(t.x, t.y) < lp.inv_trunc;
-        }
-        const int step = NSK_INFO_DT1(info);
-        const int a = g.slot_off[slot0 + step * evidence], ae = g.slot_off[slot0 + step * evidence + 1];
-        int b = 0, be = 0;
-        if (step && evidence != proposal) { b = g.slot_off[slot0 + proposal]; be = g.slot_off[slot0 + proposal + 1]; }
-        const int na = ae - a, nb = be - b;
-        for (int base = 0; base < na + nb; base += 64) {                 // wave-uniform trip count
-            const int i = base + lane;
-            bool have = false;
-            int wid = 0;
-            long long gfix = 0;
-            if (i < na + nb) {
-                const int fid = i < na ? g.fidx[a + i] : g.fidx[b + (i - na)];
-                bool dup = false;
-                if (i >= na) {                                           // already visited via list(evidence)?
-                    int lo = a, hi = ae;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (g.fidx[mid] < fid) lo = mid + 1; else hi = mid; }
-                    dup = lo < ae && g.fidx[lo] == fid;
-                }
-                const uint4 rec = g.f_rec[fid];
-                wid = (int)rec.z;
-                if (!dup && !g.w_fixed[wid]) {
-                    const double p0 = eval_factor(g, rec, g.m_rec, v, evidence, g.val_evid);
-                    const double p1 = eval_factor(g, rec, g.m_rec, v, proposal, g.val);
-                    gfix = __double2ll_rn(((p1 - p0) * g.f_feat[fid]) * NSK_GRAD_SCALE);
-                    have = true;
-                }
-            }
-            accumulate_gradient(sk, have, wid, gfix, truncate);
-        }
-    }
+    for (int p = pbegin + wave0; p < pend; p += nwaves) learn_heavy_variable<VT>(g, sk, p, lp);
     close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
 }
 
