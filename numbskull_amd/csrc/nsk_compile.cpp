@@ -614,7 +614,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             int bin = 0;
             while (work > 8 && bin < 39) { work = work * 3 / 4; bin++; }     // ~log_{4/3} bins
             work_bin[v] = (uint8_t)(40 - bin);                               // heavier variables first
-            // hubs: a whole wave works on one such variable (k_gibbs_heavy / k_learn_heavy)
+            // hubs: a whole wave works on one such variable (heavy_update in k_gibbs_general / k_learn_heavy)
             if (listlen >= NSK_HEAVY_LIST && !getenv("NSK_NO_HEAVY")) work_bin[v] = 0;
         }
         // a colour with few generic-path variables gives every one of them a wave: the one-lane
