@@ -429,7 +429,11 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 {   // hubs (one wave per variable) + general tiles with categorical lanes: one launch
                     const int gt0 = fe > fb ? (int)g->c.phase_gen_tile[ph] : 0;
                     const int gtb = fe > fb ? (int)g->c.phase_gen_bin_tile[ph] : 0;
-                    const int nblocks = (gtb - gt0 + 3) / 4, hblocks = (he - fe + 3) / 4;
+                    // without categorical tiles the hubs ride in the binary launch on the main stream
+                    // (no side stream, no fork / join events for this class)
+                    const bool hubs_with_binary = gtb == gt0 && fe > fb &&
+                        (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) > gtb;
+                    const int nblocks = (gtb - gt0 + 3) / 4, hblocks = hubs_with_binary ? 0 : (he - fe + 3) / 4;
                     if (nblocks + hblocks > 0) {
                         k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, cs.side(0)>>>(
                             d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks,
@@ -452,8 +456,9 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const int gtb = (int)g->c.phase_gen_bin_tile[ph];
                     if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
                         const int nblocks = (gt0 + ngt - gtb + 3) / 4;
-                        k_gibbs_general<VT, 2><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, 0, 0, 0,
+                        const int hbl = gtb == gt0 ? (he - fe + 3) / 4 : 0;     // see above
+                        k_gibbs_general<VT, 2><<<dim3(hbl + 8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, fe, he, hbl,
                             sample_evidence, burnin, K0, K1, S0, S1);
                         g->launches++;
                     }
