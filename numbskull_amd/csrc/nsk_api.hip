@@ -428,14 +428,19 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 ColourStreams cs(g, !g->no_overlap);
                 {   // hubs (one wave per variable) + general tiles with categorical lanes: one launch
                     const int gt0 = fe > fb ? (int)g->c.phase_gen_tile[ph] : 0;
-                    const int gtb = fe > fb ? (int)g->c.phase_gen_bin_tile[ph] : 0;
+                    int gtb = fe > fb ? (int)g->c.phase_gen_bin_tile[ph] : 0;
+                    // a class with categorical tiles walks ALL its general tiles in this launch, on
+                    // the main stream: the fork / join events of a side stream cost more (~20 us per
+                    // class) than the binary tiles lose by running the 8-candidate code
+                    const bool one_general = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
+                    if (one_general) gtb = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
                     // without categorical tiles the hubs ride in the binary launch on the main stream
                     // (no side stream, no fork / join events for this class)
                     const bool hubs_with_binary = gtb == gt0 && fe > fb &&
                         (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) > gtb;
                     const int nblocks = (gtb - gt0 + 3) / 4, hblocks = hubs_with_binary ? 0 : (he - fe + 3) / 4;
                     if (nblocks + hblocks > 0) {
-                        k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, cs.side(0)>>>(
+                        k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, one_general ? g->stream : cs.side(0)>>>(
                             d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks,
                             sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
                             (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
@@ -453,7 +458,8 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const uint32_t S0 = (uint32_t)g->sweep, S1 = (uint32_t)(g->sweep >> 32);
                     const int gt0 = (int)g->c.phase_gen_tile[ph];
                     const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
-                    const int gtb = (int)g->c.phase_gen_bin_tile[ph];
+                    int gtb = (int)g->c.phase_gen_bin_tile[ph];
+                    if (gtb > gt0 && !getenv("NSK_SPLIT_GENERAL")) gtb = gt0 + ngt;     // walked by the launch above
                     if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
                         const int nblocks = (gt0 + ngt - gtb + 3) / 4;
                         const int hbl = gtb == gt0 ? (he - fe + 3) / 4 : 0;     // see above

@@ -399,6 +399,21 @@ def test_learning_with_unpacked_accumulators(golden, name, reg, monkeypatch):
     assert np.array_equal(fg.weight_value[0], wv)
 
 
+def test_split_general_launches(golden, monkeypatch):
+    """NSK_SPLIT_GENERAL: binary and categorical general tiles in separate launches (the latter on a
+    side stream) instead of one launch of the 8-candidate kernel: same samples."""
+    monkeypatch.setenv("NSK_SPLIT_GENERAL", "1")
+    g, hbv = _small_graphs(golden)["gencat"]
+    ns, fg = session(g, seed=6, head_by_vid=hbv)
+    og = oracle_of(fg, hbv)
+    order, ps = phases_from_colors(fg.colors())
+    vv, _, wv, cnt = og.initial_state()
+    fg.inference(0, 4, True)
+    for sweep in range(4):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 6, sweep, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
 def test_general_tiles_at_scale():
     """200 000-variable mixed LR graph: full tiles of every layout (up to 12 entries x 5 words),
     both launches (binary / categorical), thousands of wave-per-variable leftovers."""
