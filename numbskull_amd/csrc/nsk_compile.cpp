@@ -557,6 +557,19 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
             else { fast[v] = 0; ngen_of[k]++; }          // long lists: wave-per-variable / generic kernels
         }
+        // a colour whose exact / shape classes are a sliver next to its general tiles gives them up:
+        // their few tiles would cost two or three extra launches per class and sweep
+        for (int32_t k = 0; k < ncolors && !no_general; k++) {
+            if (nfast_of[k] == 0 || nfast_of[k] * 20 >= ngt_of[k]) continue;
+            for (int64_t v = 0; v < nvar; v++) {
+                if (c.color[v] != k || fast[v] != 1) continue;
+                nfast_of[k]--;
+                if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
+                else { fast[v] = 0; ngen_of[k]++; }
+            }
+            classes[k].clear();
+            shapes[k].clear();
+        }
         std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
         std::vector<std::vector<int64_t>> gen_bin_start;
         std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors);
