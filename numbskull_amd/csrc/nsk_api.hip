@@ -575,15 +575,19 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 rows += grid;
                 g->launches++;
             }
+            // as in inference: a class with categorical tiles walks all its general tiles in one
+            // launch of the 8-candidate kernel on the main stream (+10 % over two concurrent launches)
+            const bool one_lg = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
             if (gtb > gt0) {            // general tiles with categorical lanes
-                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (gtb - gt0 + 3) / 4);
+                const int nt8 = one_lg ? ntiles - gt0 : gtb - gt0;
+                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4);
                 lp.row_base = rows;
-                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(0)>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, lp);
+                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, one_lg ? g->stream : cs.side(0)>>>(
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, lp);
                 rows += grid;
                 g->launches++;
             }
-            if (ntiles > gtb) {         // all-binary general tiles
+            if (ntiles > gtb && !one_lg) {   // all-binary general tiles
                 const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4);
                 lp.row_base = rows;
                 k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(

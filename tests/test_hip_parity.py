@@ -407,9 +407,15 @@ def test_split_general_launches(golden, monkeypatch):
     ns, fg = session(g, seed=6, head_by_vid=hbv)
     og = oracle_of(fg, hbv)
     order, ps = phases_from_colors(fg.colors())
-    vv, _, wv, cnt = og.initial_state()
+    vv, ve, wv, cnt = og.initial_state()
+    fg.learn(0, 2, 0.01, 0.9, 1, 0.05, 2, learn_non_evidence=True)
+    step = 0.01
+    for sweep in range(2):
+        assert og.learn_dev(order, ps, vv, ve, wv, step, 1, 0.05, 2, True, 6, sweep) == 0
+        step *= 0.9
+    assert np.array_equal(fg.var_value_evid[0], ve) and np.array_equal(fg.weight_value[0], wv)
     fg.inference(0, 4, True)
-    for sweep in range(4):
+    for sweep in range(2, 6):
         assert og.gibbs_dev(order, ps, vv, wv, cnt, 6, sweep, True) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
 
