@@ -568,7 +568,10 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             }
             const int gt0 = (int)g->c.phase_gen_tile[ph];
             const int gtb = (int)g->c.phase_gen_bin_tile[ph];
-            if (he > fe) {              // hubs: one wave per variable
+            // hubs ride as extra blocks of a general-tile launch when the class has one
+            const bool hubs_in_general = (gtb > gt0 || ntiles > gtb) && he > fe && !getenv("NSK_SPLIT_GENERAL");
+            const int hbl = hubs_in_general ? std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4) : 0;
+            if (he > fe && !hubs_in_general) {   // hubs: one wave per variable
                 const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
                 lp.row_base = rows;
                 k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(2)>>>(d, fe, he, lp);
@@ -580,18 +583,19 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const bool one_lg = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
             if (gtb > gt0) {            // general tiles with categorical lanes
                 const int nt8 = one_lg ? ntiles - gt0 : gtb - gt0;
-                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4);
+                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + hbl;
                 lp.row_base = rows;
                 k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, one_lg ? g->stream : cs.side(0)>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, lp);
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, fe, he, hbl, lp);
                 rows += grid;
                 g->launches++;
             }
             if (ntiles > gtb && !one_lg) {   // all-binary general tiles
-                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4);
+                const int hb2 = gtb > gt0 ? 0 : hbl;        // no categorical launch: the hubs come here
+                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + hb2;
                 lp.row_base = rows;
                 k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, lp);
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, fe, he, hb2, lp);
                 rows += grid;
                 g->launches++;
             }

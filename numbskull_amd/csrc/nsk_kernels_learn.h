@@ -568,14 +568,20 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
 template <typename VT, bool SMALLW, int MAXC>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int pbegin, int pend,
                                                              int wb_base, int tile0, int ntiles,
-                                                             LearnParams lp) {
+                                                             int hb, int he, int hblocks, LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
     load_gen_lut(lut);
     const GradSink sk = open_sink<SMALLW>(g, smem);
     const int lane = (int)(threadIdx.x & 63);
-    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
-    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
+    if ((int)blockIdx.x < hblocks) {                      // hub blocks: one wave per hub position, strided
+        const int hw0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+        for (int hp = hb + hw0; hp < he; hp += hblocks * (NSK_BLOCK / 64)) learn_heavy_variable<VT>(g, sk, hp, lp);
+        close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+        return;
+    }
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x - hblocks) * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
+    const int nwaves = (int)((gridDim.x - hblocks) * (NSK_BLOCK / 64));
     for (int t = wave0; t < ntiles; t += nwaves) {
         const int tile = tile0 + t;
         const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + tile));
