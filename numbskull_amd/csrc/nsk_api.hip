@@ -578,6 +578,11 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 rows += grid;
                 g->launches++;
             }
+            // a class with a lot of both general tiles and other tiles runs the two groups side by side
+            // (side stream 0); smaller ones are not worth the fork / join events
+            int other_tiles = (int)(g->c.phase_learn_rest_base[ph + 1] - g->c.phase_learn_rest_base[ph]);
+            for (const Compiled::SegLaunch &sl : g->c.learn_seg) if (sl.phase == (int)ph) other_tiles += sl.tile_start[sl.n];
+            const bool general_aside = ntiles - gt0 >= 2048 && other_tiles >= 2048 && !g->no_overlap;
             // as in inference: a class with categorical tiles walks all its general tiles in one
             // launch of the 8-candidate kernel on the main stream (+10 % over two concurrent launches)
             const bool one_lg = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
@@ -585,7 +590,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 const int nt8 = one_lg ? ntiles - gt0 : gtb - gt0;
                 const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + hbl;
                 lp.row_base = rows;
-                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, one_lg ? g->stream : cs.side(0)>>>(
+                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, (one_lg && !general_aside) ? g->stream : cs.side(0)>>>(
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, fe, he, hbl, lp);
                 rows += grid;
                 g->launches++;
@@ -594,7 +599,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 const int hb2 = gtb > gt0 ? 0 : hbl;        // no categorical launch: the hubs come here
                 const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + hb2;
                 lp.row_base = rows;
-                k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, general_aside ? cs.side(0) : g->stream>>>(
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, fe, he, hb2, lp);
                 rows += grid;
                 g->launches++;
