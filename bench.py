@@ -105,8 +105,9 @@ def cpu_baseline(fg, learning, budget_s=20.0):
 
 
 def side_run(name, seed, steps, warmup):
-    """Secondary measurement on one GPU (BASELINE configs[1]: the 1M-variable grid), reported
-    beside the headline line under "also"."""
+    """Secondary measurements on one GPU (BASELINE configs[1]: the 1M-variable grid; configs[2]'s
+    learning half: the 10M grid with two free weights), reported beside the headline line under
+    "also"."""
     import ctypes as C
     import io
     from contextlib import redirect_stdout
@@ -121,17 +122,23 @@ def side_run(name, seed, steps, warmup):
     fg = ns.factorGraphs[0]
     L, h = _lib.lib(), fg._engine()
     info = fg.info()
-    _lib.check(L.nsk_gibbs_sweeps(h, warmup, 1, 0))
+
+    def run(n):
+        if learning:                     # config #3 parameters: step 1e-7, L2 0.01
+            _lib.check(L.nsk_learn_sweeps(h, n, 1e-7, 1.0, 2, 0.01, 1, 0))
+        else:
+            _lib.check(L.nsk_gibbs_sweeps(h, n, 1, 0))
+    run(warmup)
     torch.cuda.synchronize()
     _lib.check(L.nsk_profile_begin(h))
     t0 = time.perf_counter()
-    _lib.check(L.nsk_gibbs_sweeps(h, steps, 1, 0))
+    run(steps)
     ms, nl = C.c_double(), C.c_int64()
     _lib.check(L.nsk_profile_end(h, C.byref(ms), C.byref(nl)))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fg.close()
-    alg = info["alg_bytes_inference"] * steps / (ms.value / 1e3) / 1e9
+    alg = info["alg_bytes_learning" if learning else "alg_bytes_inference"] * steps / (ms.value / 1e3) / 1e9
     return {"value": rows * cols * steps / dt, "unit": "variable-updates/s", "steps": steps,
             "ms_per_step": dt * 1e3 / steps, "roofline_frac": alg / HBM_PEAK_GBS,
             "avg_launch_us": ms.value * 1e3 / max(1, nl.value)}
@@ -280,7 +287,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fg, learning)
         if world == 1 and args.workload == "ising10m" and not args.no_extra:
-            out["also"] = {"ising1m": side_run("ising1m", args.seed, 1000, 100)}
+            out["also"] = {"ising1m": side_run("ising1m", args.seed, 1000, 100),
+                           "ising10m_learn": side_run("ising10m_learn", args.seed, 100, 10)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
