@@ -426,6 +426,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 const int e = (int)g->c.phase_start[ph + 1];
                 const int he = (int)g->c.phase_heavy_end[ph];
                 ColourStreams cs(g, !g->no_overlap);
+                bool rest_in_general = false;       // the colour's rest tiles were given to a general launch
                 {   // hubs (one wave per variable) + general tiles with categorical lanes: one launch
                     const int gt0 = fe > fb ? (int)g->c.phase_gen_tile[ph] : 0;
                     int gtb = fe > fb ? (int)g->c.phase_gen_bin_tile[ph] : 0;
@@ -439,9 +440,15 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const bool hubs_with_binary = gtb == gt0 && fe > fb &&
                         (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) > gtb;
                     const int nblocks = (gtb - gt0 + 3) / 4, hblocks = hubs_with_binary ? 0 : (he - fe + 3) / 4;
+                    // the colour's other tiles outside segments ride in the general launch too
+                    const int nrest_all = fe > fb ? (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]) : 0;
+                    const bool rest_here = one_general && nrest_all > 0;
+                    rest_in_general = rest_here;
+                    const int rblocks = rest_here ? (nrest_all + 3) / 4 : 0;
                     if (nblocks + hblocks > 0) {
-                        k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, one_general ? g->stream : cs.side(0)>>>(
+                        k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, one_general ? g->stream : cs.side(0)>>>(
                             d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks,
+                            g->rest_tiles + g->c.phase_rest_base[ph], rest_here ? nrest_all : 0,
                             sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
                             (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
                         g->launches++;
@@ -463,8 +470,12 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
                         const int nblocks = (gt0 + ngt - gtb + 3) / 4;
                         const int hbl = gtb == gt0 ? (he - fe + 3) / 4 : 0;     // see above
-                        k_gibbs_general<VT, 2><<<dim3(hbl + 8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        const int nrest_all = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
+                        rest_in_general = gtb == gt0 && nrest_all > 0 && !getenv("NSK_SPLIT_GENERAL");
+                        const int rblocks = rest_in_general ? (nrest_all + 3) / 4 : 0;
+                        k_gibbs_general<VT, 2><<<dim3(hbl + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, g->stream>>>(
                             d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, fe, he, hbl,
+                            g->rest_tiles + g->c.phase_rest_base[ph], rest_in_general ? nrest_all : 0,
                             sample_evidence, burnin, K0, K1, S0, S1);
                         g->launches++;
                     }
@@ -502,7 +513,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         }
                     }
                     const int nrest = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
-                    if (nrest > 0) {
+                    if (nrest > 0 && !rest_in_general) {
                         const int nblocks = (nrest + 3) / 4;
                         k_gibbs_fast<VT><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
                             d, fb, fe, (int)g->c.phase_wb_base[ph], nblocks,

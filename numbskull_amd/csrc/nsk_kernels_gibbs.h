@@ -579,6 +579,11 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
 }
 
 template <typename VT>
+__device__ __forceinline__ void fast_tile_update(const DevGraph<VT> &g, int pbegin, int pend, int wb_base,
+                                                 int wave, int sample_evidence, int burnin, uint32_t k0,
+                                                 uint32_t k1, uint32_t s0, uint32_t s1);
+
+template <typename VT>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pbegin, int pend,
                                                           int wb_base, int nblocks,
                                                           const uint32_t *tile_list, int nlist,
@@ -587,12 +592,20 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
                                                           uint32_t s1) {
     const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
     if (lb < 0) return;
-    const int lane = (int)(threadIdx.x & 63);
     int wave = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
     if (tile_list) {                                      // list mode: the tiles outside segments
         if (wave >= nlist) return;
         wave = (int)__builtin_amdgcn_readfirstlane(tile_list[wave]);
     }
+    fast_tile_update(g, pbegin, pend, wb_base, wave, sample_evidence, burnin, k0, k1, s0, s1);
+}
+
+// One uniform / shape / per-lane-header tile (tile index `wave` of the colour), one wave.
+template <typename VT>
+__device__ __forceinline__ void fast_tile_update(const DevGraph<VT> &g, int pbegin, int pend, int wb_base,
+                                                 int wave, int sample_evidence, int burnin, uint32_t k0,
+                                                 uint32_t k1, uint32_t s0, uint32_t s1) {
+    const int lane = (int)(threadIdx.x & 63);
     const int p = pbegin + wave * 64 + lane;
     if (pbegin + wave * 64 >= pend) return;               // whole wave beyond the range
     const int v0 = p < pend ? g.p_vid[p] : -1;            // -1 also marks padding positions
@@ -631,12 +644,14 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_fast(DevGraph<VT> g, int pb
 }
 
 // The general tiles of one colour class: tiles [tile0, tile0 + ntiles) of the colour, one wave each.
-// Blocks [0, hblocks) of the grid are hub blocks (one wave per position of [hb, he)), the rest walk
-// the tiles: one launch, so that a colour class needs one side stream less.
+// Blocks [0, hblocks) of the grid are hub blocks (one wave per position of [hb, he)), the next ones
+// walk the general tiles, the last ones the colour's other tiles outside segments (rest_list): one
+// launch per colour class instead of three.
 template <typename VT, int MAXC>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int pbegin, int pend,
                                                              int wb_base, int tile0, int ntiles,
                                                              int nblocks, int hb, int he, int hblocks,
+                                                             const uint32_t *rest_list, int nrest,
                                                              int sample_evidence, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0,
                                                              uint32_t s1) {
@@ -645,6 +660,15 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
     if ((int)blockIdx.x < hblocks) {                      // block-uniform
         const int hp = hb + (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
         if (hp < he) heavy_update(g, hp, sample_evidence, burnin, k0, k1, s0, s1);
+        return;
+    }
+    const int tblocks = 8 * ((nblocks + 7) / 8);
+    if ((int)blockIdx.x >= hblocks + tblocks) {           // the colour's uniform / shape tiles outside segments
+        const int i = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - hblocks - tblocks) * (NSK_BLOCK / 64) +
+                                                     (int)(threadIdx.x >> 6));
+        if (i < nrest)
+            fast_tile_update(g, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(rest_list[i]),
+                             sample_evidence, burnin, k0, k1, s0, s1);
         return;
     }
     const int lb = xcd_logical_block((int)blockIdx.x - hblocks, nblocks);
