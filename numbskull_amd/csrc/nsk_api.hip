@@ -589,9 +589,13 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 rows += grid;
                 g->launches++;
             }
+            // the colour's uniform / shape tiles outside segment launches ride in the general launch
+            const int nlrest = (int)(g->c.phase_learn_rest_base[ph + 1] - g->c.phase_learn_rest_base[ph]);
+            const bool rest_in_general = ntiles > gt0 && nlrest > 0 && !getenv("NSK_SPLIT_GENERAL");
+            const uint32_t *lrest = g->learn_rest_tiles + g->c.phase_learn_rest_base[ph];
             // a class with a lot of both general tiles and other tiles runs the two groups side by side
             // (side stream 0); smaller ones are not worth the fork / join events
-            int other_tiles = (int)(g->c.phase_learn_rest_base[ph + 1] - g->c.phase_learn_rest_base[ph]);
+            int other_tiles = rest_in_general ? 0 : nlrest;
             for (const Compiled::SegLaunch &sl : g->c.learn_seg) if (sl.phase == (int)ph) other_tiles += sl.tile_start[sl.n];
             const bool general_aside = ntiles - gt0 >= 2048 && other_tiles >= 2048 && !g->no_overlap;
             // as in inference: a class with categorical tiles walks all its general tiles in one
@@ -602,7 +606,8 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + hbl;
                 lp.row_base = rows;
                 k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, (one_lg && !general_aside) ? g->stream : cs.side(0)>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, fe, he, hbl, lp);
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, fe, he, hbl, lrest,
+                    (rest_in_general && one_lg) ? nlrest : 0, lp);
                 rows += grid;
                 g->launches++;
             }
@@ -611,7 +616,8 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + hb2;
                 lp.row_base = rows;
                 k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, general_aside ? cs.side(0) : g->stream>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, fe, he, hb2, lp);
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, fe, he, hb2, lrest,
+                    (rest_in_general && !(one_lg)) ? nlrest : 0, lp);
                 rows += grid;
                 g->launches++;
             }
@@ -632,8 +638,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 rows += grid;
                 g->launches++;
             }
-            const int nlrest = (int)(g->c.phase_learn_rest_base[ph + 1] - g->c.phase_learn_rest_base[ph]);
-            if (nlrest > 0) {           // the other uniform and shape tiles: descriptor-driven kernel
+            if (nlrest > 0 && !rest_in_general) {   // the other uniform and shape tiles: descriptor-driven kernel
                 const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (nlrest + 3) / 4);
                 lp.row_base = rows;
                 k_learn_fast<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(

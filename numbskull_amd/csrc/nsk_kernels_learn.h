@@ -506,6 +506,25 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
                            });
 }
 
+// One uniform / shape tile (tile t of the colour) of the learning sweep, descriptor-driven
+template <typename VT>
+__device__ __forceinline__ void learn_rest_tile(const DevGraph<VT> &g, const GradSink &sk, int pbegin, int pend,
+                                                int wb_base, int t, const LearnParams &lp) {
+    const int lane = (int)(threadIdx.x & 63);
+    const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
+    const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
+    if (td.z == NSK_PAD_WORD) return;                        // mixed per-lane headers: generic kernel's job
+    const int p = pbegin + t * 64 + lane;
+    const bool valid = p < pend && g.p_vid[p] >= 0;
+    const uint4 *sp = g.adj + td.x + lane;
+    const uint32_t kind = (td.w >> 8) & 7u;
+    if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp);
+    else if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+    else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+    else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+    else learn_tile<VT, 3>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
+}
+
 // Learning over the uniform and shape tiles of a colour class that are not in a segment launch
 // (tiles with per-lane headers are left to k_learn_phase in list mode).  Each wave takes a
 // contiguous run of the list.
@@ -546,21 +565,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
     const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
     const int per = (ntiles + nwaves - 1) / nwaves;
     const int t1 = min(ntiles, (wave0 + 1) * per);
-    for (int i = wave0 * per; i < t1; i++) {
-        const int t = (int)__builtin_amdgcn_readfirstlane(list[i]);     // the colour's learn_rest list
-        const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
-        const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
-        if (td.z == NSK_PAD_WORD) continue;                  // mixed per-lane headers: generic kernel's job
-        const int p = pbegin + t * 64 + lane;
-        const bool valid = p < pend && g.p_vid[p] >= 0;
-        const uint4 *sp = g.adj + td.x + lane;
-        const uint32_t kind = (td.w >> 8) & 7u;
-        if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp);
-        else if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
-        else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
-        else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
-        else learn_tile<VT, 3>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
-    }
+    for (int i = wave0 * per; i < t1; i++)
+        learn_rest_tile<VT>(g, sk, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(list[i]), lp);
+    (void)lane;
     close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
 }
 
@@ -568,7 +575,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
 template <typename VT, bool SMALLW, int MAXC>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int pbegin, int pend,
                                                              int wb_base, int tile0, int ntiles,
-                                                             int hb, int he, int hblocks, LearnParams lp) {
+                                                             int hb, int he, int hblocks,
+                                                             const uint32_t *rest_list, int nrest, LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
     load_gen_lut(lut);
@@ -590,6 +598,11 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
         const bool valid = p < pend && g.p_vid[p] >= 0;
         learn_tile_general<VT, MAXC>(g, sk, lut, g.adj + tdx + lane, tdw, tdz, p, valid, lp);
     }
+    // then the colour's uniform / shape tiles outside segment launches (a contiguous run per wave)
+    const int per = (nrest + nwaves - 1) / nwaves;
+    const int r1 = min(nrest, (wave0 + 1) * per);
+    for (int i = wave0 * per; i < r1; i++)
+        learn_rest_tile<VT>(g, sk, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(rest_list[i]), lp);
     close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
 }
 
