@@ -656,6 +656,8 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 g->launches++;
             }
             cs.join();
+            if (SMALLW && rows > NSK_LEARN_ROWS)             // cannot happen with the grid caps above
+                return fail(NSK_E_RANGE, "partial-sum rows exceeded");
             if (nw > 0) {
                 if (SMALLW) {
                     k_apply_weights_rows<<<dim3(nw), dim3(NSK_BLOCK), 0, g->stream>>>(
