@@ -111,6 +111,10 @@ typedef struct {
     double alg_bytes_inference;       /* algorithmic bytes per sweep       */
     double alg_bytes_learning;
     int64_t sweeps_done;
+    double layout_bytes_inference;    /* bytes one sweep must move in the compiled device layout  */
+    double layout_bytes_learning;     /*   (tile words, positions, distinct values, stores, tally) */
+    int64_t ztab_entries;             /* draw-table entries (0: no tabulated program)              */
+    double compile_seconds;           /* host time spent in the graph compiler                     */
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);

@@ -44,7 +44,9 @@ class GraphInfo(C.Structure):
                 ("value_bytes", C.c_int64), ("device_bytes", C.c_int64),
                 ("nfast", C.c_int64), ("ngeneric", C.c_int64),
                 ("alg_bytes_inference", C.c_double), ("alg_bytes_learning", C.c_double),
-                ("sweeps_done", C.c_int64)]
+                ("sweeps_done", C.c_int64), ("layout_bytes_inference", C.c_double),
+                ("layout_bytes_learning", C.c_double), ("ztab_entries", C.c_int64),
+                ("compile_seconds", C.c_double)]
 
 
 _lib = None

@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>      // types only: the library is bound at run time with dlopen
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,8 +20,7 @@
 #include "nsk_compile.h"
 #include "nsk_device.h"
 
-#include "nsk_kernels_gibbs.h"
-#include "nsk_kernels_learn.h"
+#include "nsk_internal.h"
 #include "nsk_kernels_misc.h"
 
 using namespace nsk;
@@ -30,11 +30,13 @@ using namespace nsk;
 // =============================================================================================
 static thread_local std::string g_err;
 
-static int fail(int code, const std::string &msg) {
+namespace nsk {
+int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
-namespace nsk { void set_error(const std::string &m) { g_err = m; } }
+void set_error(const std::string &m) { g_err = m; }
+}
 
 // RCCL entry points, bound at run time (nsk_comm_init)
 struct RcclApi {
@@ -50,67 +52,7 @@ static RcclApi g_rccl;
 
 
 
-#define HIPCHECK(expr)                                                                          \
-    do {                                                                                        \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-            return fail(NSK_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
-    } while (0)
 
-struct nsk_graph {
-    Compiled c;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    // the kernels of one colour class are independent: hubs and generic-path variables run on side
-    // streams next to the tile kernels (fork/join with events around every colour)
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    bool no_overlap = getenv("NSK_NO_OVERLAP") != nullptr;     // diagnostic: one stream
-    std::vector<void *> allocs;
-    int64_t device_bytes = 0;
-    // device arrays
-    int32_t *p_vid = nullptr, *p_slot = nullptr, *p_cnt = nullptr, *slot_off = nullptr, *fidx = nullptr;
-    uint32_t *p_info = nullptr, *f_rec = nullptr;
-    void *p_init = nullptr;
-    int32_t *m_rec = nullptr, *v_card = nullptr,
-            *v_pos = nullptr;
-    double *f_feat = nullptr, *w = nullptr, *logtab = nullptr;
-    uint8_t *w_fixed = nullptr;
-    void *val = nullptr, *val_evid = nullptr;
-    int32_t *cnt = nullptr;
-    uint8_t *cnt_pos = nullptr;
-    int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
-    uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr, *gstream = nullptr, *gs_off = nullptr;
-    double *prog_w = nullptr, *adj_wt = nullptr;
-    uint32_t *tile_wrow = nullptr;
-    uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr, *learn_rest_tiles = nullptr;
-    long long *part_G = nullptr;       // SMALLW: rows of per-block partial sums
-    uint32_t *part_K = nullptr, *part_T = nullptr;
-    bool smallw = false;
-    bool weights_dirty = true;      // prog_w must be rebuilt before the next fast-path launch
-    bool weights_exposed = false;
-    bool adj_wt_skip = false;       // learning reads weights directly: skip the shape-tile rows until the next inference   // the weight buffer was handed out: assume it changes between calls
-    // boundary exchange (multi-GPU)
-    int xworld = 0, xrank = 0;
-    int64_t xslot = 0, xnsend = 0, xnrecv = 0;
-    int32_t *x_send_vids = nullptr, *x_recv_vids = nullptr, *x_recv_slot = nullptr;
-    void *x_send = nullptr, *x_recv = nullptr, *x_send_evid = nullptr, *x_recv_evid = nullptr;
-    double *w_start = nullptr, *w_delta = nullptr;
-    // native RCCL
-    void *rccl_lib = nullptr, *rccl_comm = nullptr;
-    long long *cnt_total = nullptr, *G = nullptr;
-    uint32_t *K = nullptr, *T = nullptr;
-    MTState *mt_np = nullptr, *mt_py = nullptr;
-    // run state
-    uint64_t seed = 0, sweep = 0;
-    int scan = NSK_SCAN_CHROMATIC;
-    bool cnt_dirty = false;
-    int64_t sweeps_done = 0;
-    // profiling bracket
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int64_t launches = 0, launches_at_begin = 0;
-};
 
 template <typename T>
 static int dev_alloc(nsk_graph *g, T **ptr, size_t n) {
@@ -172,28 +114,6 @@ static void mt_seed_python(MTState &s, uint64_t seed) {     // random.seed(int):
     s.idx = 624;
 }
 
-template <typename VT>
-static DevGraph<VT> view(nsk_graph *g) {
-    DevGraph<VT> d;
-    d.p_vid = g->p_vid; d.p_info = g->p_info; d.p_slot = g->p_slot; d.p_cnt = g->p_cnt;
-    d.p_init = (const VT *)g->p_init;
-    d.slot_off = g->slot_off; d.fidx = g->fidx;
-    d.gstream = (const uint2 *)g->gstream; d.gs_off = g->gs_off;
-    d.f_rec = (const uint4 *)g->f_rec; d.f_feat = g->f_feat;
-    d.m_rec = (const int2 *)g->m_rec; d.v_card = g->v_card;
-    d.w = g->w; d.w_fixed = g->w_fixed; d.logtab = g->logtab;
-    d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
-    d.G = g->G; d.K = g->K; d.T = g->T;
-    d.adj = (const uint4 *)g->adj; d.tiles = (const uint4 *)g->tiles; d.tile_hdr = g->tile_hdr;
-    d.prog_w = g->prog_w; d.adj_wt = g->adj_wt; d.tile_wrow = g->tile_wrow;
-    d.part_G = g->part_G; d.part_K = g->part_K; d.part_T = g->part_T;
-    d.nweight = (int32_t)g->c.nweight;
-    d.packed_grad = g->c.packed_grad ? 1 : 0;
-    d.cnt_pos = g->cnt_pos;
-    d.nvar = (int32_t)g->c.nvar;
-    d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
-    return d;
-}
 
 extern "C" {
 
@@ -229,8 +149,11 @@ int nsk_graph_destroy(nsk_graph *g) {
 
 static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     std::string err;
+    const auto t_compile = std::chrono::steady_clock::now();
     int rc = compile_graph(desc, g->c, err);
     if (rc) return fail(rc, err);
+    g->compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_compile).count();
+    g->values_regular = g->chain_regular[0] = g->chain_regular[1] = g->c.values_regular;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -268,6 +191,12 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos); if (rc) return rc;
     rc = dev_alloc(g, &g->prog_w, 2 * c.tile_hdr.size()); if (rc) return rc;
     rc = dev_alloc(g, &g->adj_wt, (size_t)c.nwrows * 64); if (rc) return rc;
+    rc = dev_alloc(g, &g->ztab, (size_t)c.nztab); if (rc) return rc;
+    {
+        std::vector<ZProgDev> zp(c.zprogs.size());
+        for (size_t i = 0; i < zp.size(); i++) zp[i] = {c.zprogs[i].prog, c.zprogs[i].nslots, c.zprogs[i].off, 0u};
+        rc = dev_upload(g, &g->zprogs, zp); if (rc) return rc;
+    }
     g->smallw = c.nweight > 0 && c.nweight <= NSK_SMALLW;
     if (g->smallw) {
         const size_t cells = (size_t)NSK_LEARN_ROWS * (size_t)c.nweight;
@@ -344,22 +273,32 @@ int nsk_synchronize(nsk_graph *g) {
     return NSK_OK;
 }
 
+}  // extern "C"
+
 // the fast path reads weights through prog_w: rebuild it whenever weights may have changed (start
 // of every sweep call -- the host may have written the weight buffer -- and after every update)
-static void refresh_prog_weights(nsk_graph *g, bool force = false) {
+void nsk_refresh_ztab(nsk_graph *g) {
+    if (!g->c.zprogs.empty())
+        k_refresh_ztab<<<dim3((unsigned)g->c.zprogs.size()), dim3(NSK_BLOCK), 0, g->stream>>>(
+            g->zprogs, g->tile_hdr, g->prog_w, g->ztab);
+}
+
+void nsk_refresh_prog_weights(nsk_graph *g, bool force) {
     if (!force && !g->weights_dirty && !g->weights_exposed) return;
     g->weights_dirty = false;
     const int n = (int)g->c.tile_hdr.size();
-    if (n > 0 && g->c.nfast > 0 && g->c.nweight > 0)
+    if (n > 0 && g->c.nfast > 0 && g->c.nweight > 0) {
         k_refresh_prog_weights<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
             g->tile_hdr, g->w, g->prog_w, n);
+        nsk_refresh_ztab(g);
+    }
     const int nt = (int)(g->c.tiles.size() / 4) - 1;
     if (g->c.nwrows > 0 && nt > 0 && !g->adj_wt_skip)
         k_refresh_shape_weights<<<dim3((nt + 3) / 4), dim3(NSK_BLOCK), 0, g->stream>>>(
             (const uint4 *)g->tiles, (const uint4 *)g->adj, g->tile_hdr, g->tile_wrow, g->w, g->adj_wt, nt);
 }
 
-static int fold_position_tally(nsk_graph *g) {
+int nsk_fold_position_tally(nsk_graph *g) {
     const int np = (int)g->c.npos;
     if (np > 0 && g->c.nfast > 0 && g->pos_tally_sweeps > 0)
         k_fold_counts_pos<<<dim3((np + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
@@ -368,13 +307,15 @@ static int fold_position_tally(nsk_graph *g) {
     return NSK_OK;
 }
 
+extern "C" {
+
 static int fold_counts(nsk_graph *g) {
     if (!g->cnt_dirty) return NSK_OK;
     const int n = (int)g->c.ncount;
     if (n > 0)
         k_fold_counts<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
             g->cnt, g->cnt_total, n);
-    fold_position_tally(g);
+    nsk_fold_position_tally(g);
     HIPCHECK(hipGetLastError());
     g->cnt_dirty = false;
     return NSK_OK;
@@ -382,340 +323,10 @@ static int fold_counts(nsk_graph *g) {
 
 }  // extern "C"
 
-// Streams for the kernels of one colour: the tile kernels stay on the main stream; when there are
-// tile kernels to overlap with, hubs go to side stream 0, the generic kernel to side stream 1 and
-// the categorical general tiles to side stream 2.
-struct ColourStreams {
-    nsk_graph *g;
-    bool forked[3] = {false, false, false};
-    bool overlap;
-    bool recorded = false;
-    ColourStreams(nsk_graph *g_, bool overlap_) : g(g_), overlap(overlap_) {}
-    // side streams must be requested before anything of the colour is put on the main stream
-    hipStream_t side(int i) {
-        if (!overlap) return g->stream;
-        if (!recorded) { (void)hipEventRecord(g->ev_fork, g->stream); recorded = true; }
-        if (!forked[i]) { (void)hipStreamWaitEvent(g->side[i], g->ev_fork, 0); forked[i] = true; }
-        return g->side[i];
-    }
-    void join() {
-        for (int i = 0; i < 3; i++)
-            if (forked[i]) {
-                (void)hipEventRecord(g->ev_join[i], g->side[i]);
-                (void)hipStreamWaitEvent(g->stream, g->ev_join[i], 0);
-                forked[i] = false;
-            }
-    }
-};
 
-template <typename VT>
-static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
-    DevGraph<VT> d = view<VT>(g);
-    if (g->scan == NSK_SCAN_SEQUENTIAL) {
-        k_seq_gibbs<VT><<<dim3(1), dim3(64), 0, g->stream>>>(d, g->v_pos, g->mt_np, (int)nsweeps,
-                                                            sample_evidence, burnin);
-        HIPCHECK(hipGetLastError());
-        g->launches++;
-        g->sweep += (uint64_t)nsweeps;
-    } else {
-        const size_t nphase = g->c.phase_start.size() - 1;
-        refresh_prog_weights(g);
-        for (int64_t s = 0; s < nsweeps; s++) {
-            for (size_t ph = 0; ph < nphase; ph++) {
-                const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
-                const int e = (int)g->c.phase_start[ph + 1];
-                const int he = (int)g->c.phase_heavy_end[ph];
-                ColourStreams cs(g, !g->no_overlap);
-                bool rest_in_general = false;       // the colour's rest tiles were given to a general launch
-                {   // hubs (one wave per variable) + general tiles with categorical lanes: one launch
-                    const int gt0 = fe > fb ? (int)g->c.phase_gen_tile[ph] : 0;
-                    int gtb = fe > fb ? (int)g->c.phase_gen_bin_tile[ph] : 0;
-                    // a class with categorical tiles walks ALL its general tiles in this launch, on
-                    // the main stream: the fork / join events of a side stream cost more (~20 us per
-                    // class) than the binary tiles lose by running the 8-candidate code
-                    const bool one_general = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
-                    if (one_general) gtb = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
-                    // without categorical tiles the hubs ride in the binary launch on the main stream
-                    // (no side stream, no fork / join events for this class)
-                    const bool hubs_with_binary = gtb == gt0 && fe > fb &&
-                        (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) > gtb;
-                    const int nblocks = (gtb - gt0 + 3) / 4, hblocks = hubs_with_binary ? 0 : (he - fe + 3) / 4;
-                    // the colour's other tiles outside segments ride in the general launch too
-                    const int nrest_all = fe > fb ? (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]) : 0;
-                    const bool rest_here = one_general && nrest_all > 0;
-                    rest_in_general = rest_here;
-                    const int rblocks = rest_here ? (nrest_all + 3) / 4 : 0;
-                    if (nblocks + hblocks > 0) {
-                        k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, one_general ? g->stream : cs.side(0)>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks,
-                            g->rest_tiles + g->c.phase_rest_base[ph], rest_here ? nrest_all : 0,
-                            sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
-                            (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
-                        g->launches++;
-                    }
-                }
-                if (e > he) {       // generic CSR kernel, one lane per variable
-                    k_gibbs_phase<VT><<<dim3((e - he + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, cs.side(1)>>>(
-                        d, he, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
-                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
-                    g->launches++;
-                }
-                if (fe > fb) {      // inlined-adjacency kernels
-                    const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
-                    const uint32_t S0 = (uint32_t)g->sweep, S1 = (uint32_t)(g->sweep >> 32);
-                    const int gt0 = (int)g->c.phase_gen_tile[ph];
-                    const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
-                    int gtb = (int)g->c.phase_gen_bin_tile[ph];
-                    if (gtb > gt0 && !getenv("NSK_SPLIT_GENERAL")) gtb = gt0 + ngt;     // walked by the launch above
-                    if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
-                        const int nblocks = (gt0 + ngt - gtb + 3) / 4;
-                        const int hbl = gtb == gt0 ? (he - fe + 3) / 4 : 0;     // see above
-                        const int nrest_all = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
-                        rest_in_general = gtb == gt0 && nrest_all > 0 && !getenv("NSK_SPLIT_GENERAL");
-                        const int rblocks = rest_in_general ? (nrest_all + 3) / 4 : 0;
-                        k_gibbs_general<VT, 2><<<dim3(hbl + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, g->stream>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, fe, he, hbl,
-                            g->rest_tiles + g->c.phase_rest_base[ph], rest_in_general ? nrest_all : 0,
-                            sample_evidence, burnin, K0, K1, S0, S1);
-                        g->launches++;
-                    }
-                    // segments of this colour, batched by (kind, chunks) into table launches
-                    for (int kind = 0; kind <= 4; kind++) {
-                        if (kind == 1) continue;                 // IMPLY_NATURAL shares the AND step (3)
-                        for (int nch = 1; nch <= 2; nch++) {
-                            SegTable tab;
-                            tab.n = 0; tab.tile_start[0] = 0;
-                            auto flush = [&]() {
-                                if (tab.n == 0) return;
-                                const int nb = (tab.tile_start[tab.n] + 3) / 4;
-                                const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
-#define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
-                                if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
-                                else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
-                                else if (kind == 0) { if (nch == 1) NSK_SEG(0, 1); else NSK_SEG(0, 2); }
-                                else { if (nch == 1) NSK_SEG(3, 1); else NSK_SEG(3, 2); }
-#undef NSK_SEG
-                                g->launches++;
-                                tab.n = 0;
-                            };
-                            for (const Compiled::Segment &sg : g->c.segments) {
-                                if (sg.phase != (int)ph) continue;
-                                const int k3 = sg.kind == 1 ? 3 : (int)sg.kind;
-                                if (k3 != kind || (sg.nslots > 4 ? 2 : 1) != nch) continue;
-                                if (!(sg.ev == 0 || sample_evidence)) continue;      // inference.py:24
-                                tab.pos0[tab.n] = (int)sg.pos0;
-                                tab.adj_off[tab.n] = sg.adj_off;
-                                tab.prog[tab.n] = sg.prog;
-                                tab.tile_start[tab.n + 1] = tab.tile_start[tab.n] + sg.ntiles;
-                                if (++tab.n == NSK_SEG_MAX) flush();
-                            }
-                            flush();
-                        }
-                    }
-                    const int nrest = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
-                    if (nrest > 0 && !rest_in_general) {
-                        const int nblocks = (nrest + 3) / 4;
-                        k_gibbs_fast<VT><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], nblocks,
-                            g->rest_tiles + g->c.phase_rest_base[ph], nrest, sample_evidence, burnin,
-                            K0, K1, S0, S1);
-                        g->launches++;
-                    }
-                }
-                cs.join();
-            }
-            g->sweep++;
-            if (!burnin && ++g->pos_tally_sweeps == 255) fold_position_tally(g);   // uint8 tally is full
-        }
-        HIPCHECK(hipGetLastError());
-    }
-    if (!burnin) g->cnt_dirty = true;
-    g->sweeps_done += nsweeps;
-    return NSK_OK;
-}
-
-extern "C" int nsk_gibbs_sweeps(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
-    if (!g) return fail(NSK_E_INVALID, "null graph");
-    if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
-    if (nsweeps == 0) return NSK_OK;
-    HIPCHECK(hipSetDevice(g->device));
-    return g->c.vbytes == 1 ? gibbs_impl<int8_t>(g, nsweeps, sample_evidence, burnin)
-                            : gibbs_impl<int32_t>(g, nsweeps, sample_evidence, burnin);
-}
-
-template <typename VT, bool SMALLW>
-static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
-                           double reg_param, int64_t truncation, int learn_non_evidence) {
-    DevGraph<VT> d = view<VT>(g);
-    const size_t nphase = g->c.phase_start.size() - 1;
-    const int nw = (int)g->c.nweight;
-    const size_t shmem = SMALLW ? (size_t)nw * 16 : 0;
-    LearnParams lp;
-    lp.regularization = regularization;
-    lp.learn_non_evidence = learn_non_evidence;
-    lp.inv_trunc = 1.0 / (double)truncation;
-    lp.k0 = (uint32_t)g->seed; lp.k1 = (uint32_t)(g->seed >> 32);
-    g->adj_wt_skip = true;          // the learning kernels gather weights themselves
-    refresh_prog_weights(g);
-    for (int64_t s = 0; s < nsweeps; s++) {
-        lp.s0 = (uint32_t)g->sweep; lp.s1 = (uint32_t)(g->sweep >> 32);
-        for (size_t ph = 0; ph < nphase; ph++) {
-            const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
-            const int e = (int)g->c.phase_start[ph + 1];
-            if (e <= fb) continue;
-            int rows = 0;
-            const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
-            const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
-            const int he = (int)g->c.phase_heavy_end[ph];
-            ColourStreams cs(g, !g->no_overlap);
-            if (e > he) {               // variables outside the fast path: generic kernel, range mode
-                const int nitems = (e - he + 63) / 64;
-                const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
-                lp.row_base = rows;
-                k_learn_phase<VT, SMALLW, true><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(1)>>>(
-                    d, he, e, nullptr, nitems, lp);
-                rows += grid;
-                g->launches++;
-            }
-            const int gt0 = (int)g->c.phase_gen_tile[ph];
-            const int gtb = (int)g->c.phase_gen_bin_tile[ph];
-            // hubs ride as extra blocks of a general-tile launch when the class has one
-            const bool hubs_in_general = (gtb > gt0 || ntiles > gtb) && he > fe && !getenv("NSK_SPLIT_GENERAL");
-            const int hbl = hubs_in_general ? std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4) : 0;
-            if (he > fe && !hubs_in_general) {   // hubs: one wave per variable
-                const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
-                lp.row_base = rows;
-                k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(2)>>>(d, fe, he, lp);
-                rows += grid;
-                g->launches++;
-            }
-            // the colour's uniform / shape tiles outside segment launches ride in the general launch
-            const int nlrest = (int)(g->c.phase_learn_rest_base[ph + 1] - g->c.phase_learn_rest_base[ph]);
-            const bool rest_in_general = ntiles > gt0 && nlrest > 0 && !getenv("NSK_SPLIT_GENERAL");
-            const uint32_t *lrest = g->learn_rest_tiles + g->c.phase_learn_rest_base[ph];
-            // a class with a lot of both general tiles and other tiles runs the two groups side by side
-            // (side stream 0); smaller ones are not worth the fork / join events
-            int other_tiles = rest_in_general ? 0 : nlrest;
-            for (const Compiled::SegLaunch &sl : g->c.learn_seg) if (sl.phase == (int)ph) other_tiles += sl.tile_start[sl.n];
-            const bool general_aside = ntiles - gt0 >= 2048 && other_tiles >= 2048 && !g->no_overlap;
-            // as in inference: a class with categorical tiles walks all its general tiles in one
-            // launch of the 8-candidate kernel on the main stream (+10 % over two concurrent launches)
-            const bool one_lg = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
-            if (gtb > gt0) {            // general tiles with categorical lanes
-                const int nt8 = one_lg ? ntiles - gt0 : gtb - gt0;
-                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + hbl;
-                lp.row_base = rows;
-                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, (one_lg && !general_aside) ? g->stream : cs.side(0)>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, fe, he, hbl, lrest,
-                    (rest_in_general && one_lg) ? nlrest : 0, lp);
-                rows += grid;
-                g->launches++;
-            }
-            if (ntiles > gtb && !one_lg) {   // all-binary general tiles
-                const int hb2 = gtb > gt0 ? 0 : hbl;        // no categorical launch: the hubs come here
-                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + hb2;
-                lp.row_base = rows;
-                k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, general_aside ? cs.side(0) : g->stream>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, fe, he, hb2, lrest,
-                    (rest_in_general && !(one_lg)) ? nlrest : 0, lp);
-                rows += grid;
-                g->launches++;
-            }
-            for (const Compiled::SegLaunch &sl : g->c.learn_seg) {       // homogeneous segments
-                if (sl.phase != (int)ph) continue;
-                SegTable tab;
-                tab.n = sl.n;
-                for (int i = 0; i <= NSK_SEG_MAX; i++) tab.tile_start[i] = sl.tile_start[i];
-                for (int i = 0; i < NSK_SEG_MAX; i++) { tab.pos0[i] = sl.pos0[i]; tab.adj_off[i] = sl.adj_off[i]; tab.prog[i] = sl.prog[i]; }
-                const int grid = std::min(NSK_LEARN_SEG_BLOCKS, (tab.tile_start[tab.n] + 3) / 4);
-                lp.row_base = rows;
-#define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
-                if (sl.kind == 4) { if (sl.nch == 1) NSK_LSEG(4, 1); else NSK_LSEG(4, 2); }
-                else if (sl.kind == 2) { if (sl.nch == 1) NSK_LSEG(2, 1); else NSK_LSEG(2, 2); }
-                else if (sl.kind == 0) { if (sl.nch == 1) NSK_LSEG(0, 1); else NSK_LSEG(0, 2); }
-                else { if (sl.nch == 1) NSK_LSEG(3, 1); else NSK_LSEG(3, 2); }
-#undef NSK_LSEG
-                rows += grid;
-                g->launches++;
-            }
-            if (nlrest > 0 && !rest_in_general) {   // the other uniform and shape tiles: descriptor-driven kernel
-                const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (nlrest + 3) / 4);
-                lp.row_base = rows;
-                k_learn_fast<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
-                    d, fb, fe, (int)g->c.phase_wb_base[ph], g->learn_rest_tiles + g->c.phase_learn_rest_base[ph],
-                    nlrest, lp);
-                rows += grid;
-                g->launches++;
-            }
-            if (ndyn > 0) {             // tiles with per-lane headers: generic kernel, list mode
-                const int grid = std::min(NSK_LEARN_LIST_BLOCKS, (ndyn + 3) / 4);
-                lp.row_base = rows;
-                k_learn_phase<VT, SMALLW, false><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
-                    d, fb, fe, g->dyn_tiles + g->c.phase_dyn_base[ph], ndyn, lp);
-                rows += grid;
-                g->launches++;
-            }
-            cs.join();
-            if (SMALLW && rows > NSK_LEARN_ROWS)             // cannot happen with the grid caps above
-                return fail(NSK_E_RANGE, "partial-sum rows exceeded");
-            if (nw > 0) {
-                if (SMALLW) {
-                    k_apply_weights_rows<<<dim3(nw), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        g->w, g->part_G, g->part_K, g->part_T, rows, nw, step, regularization, reg_param,
-                        (double)truncation, g->tile_hdr, g->prog_w,
-                        g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0);
-                } else {
-                    k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation,
-                        (!SMALLW && g->c.packed_grad) ? 1 : 0);
-                    refresh_prog_weights(g, true);
-                }
-            }
-        }
-        g->sweep++;
-        step *= decay;                                   // factorgraph.py:206
-    }
-    g->adj_wt_skip = false;
-    g->weights_dirty = true;        // the next inference call rebuilds prog_w and the weight rows
-    HIPCHECK(hipGetLastError());
-    return NSK_OK;
-}
-
-template <typename VT>
-static int learn_impl(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
-                      double reg_param, int64_t truncation, int learn_non_evidence) {
-    if (g->scan == NSK_SCAN_SEQUENTIAL) {
-        DevGraph<VT> d = view<VT>(g);
-        k_seq_learn<VT><<<dim3(1), dim3(64), 0, g->stream>>>(d, g->v_pos, g->mt_np, g->mt_py, (int)nsweeps,
-                                                            step, decay, regularization, reg_param,
-                                                            (double)truncation, learn_non_evidence);
-        HIPCHECK(hipGetLastError());
-        g->launches++;
-        g->sweep += (uint64_t)nsweeps;
-    } else {
-        int rc = g->smallw ? learn_chromatic<VT, true>(g, nsweeps, step, decay, regularization, reg_param,
-                                                       truncation, learn_non_evidence)
-                           : learn_chromatic<VT, false>(g, nsweeps, step, decay, regularization, reg_param,
-                                                        truncation, learn_non_evidence);
-        if (rc) return rc;
-    }
-    g->sweeps_done += nsweeps;
-    return NSK_OK;
-}
 
 extern "C" {
 
-int nsk_learn_sweeps(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
-                     double reg_param, int64_t truncation, int learn_non_evidence) {
-    if (!g) return fail(NSK_E_INVALID, "null graph");
-    if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
-    if (regularization == 1 && truncation == 0) return fail(NSK_E_INVALID, "truncation must be non-zero (ZeroDivisionError in the reference)");
-    if (nsweeps == 0) return NSK_OK;
-    HIPCHECK(hipSetDevice(g->device));
-    return g->c.vbytes == 1
-               ? learn_impl<int8_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence)
-               : learn_impl<int32_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence);
-}
 
 int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_value_evid,
                      const double *weight_value, const int64_t *count) {
@@ -729,11 +340,15 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
     for (int k = 0; k < 2; k++) {
         if (!srcs[k]) continue;
         tmp.resize(nvar);
+        bool regular = true;
         for (size_t i = 0; i < nvar; i++) {
             if (srcs[k][i] < lo || srcs[k][i] > hi)
                 return fail(NSK_E_RANGE, "variable value does not fit the device value type");
             tmp[i] = (int32_t)srcs[k][i];
+            regular = regular && srcs[k][i] >= 0 && srcs[k][i] < (int64_t)g->c.v_card[i];
         }
+        g->chain_regular[k] = regular;
+        g->values_regular = g->chain_regular[0] && g->chain_regular[1];
         int rc = upload_values(g, dsts[k], tmp.data(), nvar);
         if (rc) return rc;
     }
@@ -797,6 +412,10 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->alg_bytes_inference = c.alg_bytes_inference;
     info->alg_bytes_learning = c.alg_bytes_learning;
     info->sweeps_done = 0;
+    info->layout_bytes_inference = c.layout_bytes_inference;
+    info->layout_bytes_learning = c.layout_bytes_learning;
+    info->ztab_entries = c.nztab;
+    info->compile_seconds = 0;
 }
 
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
@@ -804,6 +423,7 @@ int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
     fill_info(g->c, info);
     info->device_bytes = g->device_bytes;
     info->sweeps_done = g->sweeps_done;
+    info->compile_seconds = g->compile_seconds;
     return NSK_OK;
 }
 

@@ -84,6 +84,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             err = fmt("variable %lld: initialValue does not fit int32", v);
             return NSK_E_RANGE;
         }
+        // an evidence value is used as a value-slot / member index by the learning kernels
+        // (learning.py:61-62 with get_factor_id_range's vmap[vtf_offset + value]): the reference
+        // reads a neighbouring variable's lists or faults; here it is an error
+        if (var.dataType != 0 && var.isEvidence == 1 &&
+            (var.initialValue < 0 || var.initialValue >= var.cardinality)) {
+            err = fmt("variable %lld: evidence value %lld outside its domain [0, %lld)", v, var.initialValue,
+                      var.cardinality);
+            return NSK_E_INDEX;
+        }
+        if (var.initialValue < 0 || var.initialValue >= var.cardinality) c.values_regular = false;
         c.v_card[v] = (int32_t)var.cardinality;
         c.v_init[v] = (int32_t)var.initialValue;
         maxcard = std::max(maxcard, var.cardinality);
@@ -786,9 +796,13 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
                     continue;
                 }
+                bool binmem = true;                // every member the lanes read is a binary variable
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;                  // padding position
                     lane_words(c.p_vid[p], words);
+                    for (size_t j = 0; j < words.size(); j += 1 + ((words[j] >> 24) & 7u))
+                        for (uint32_t m = 1; m <= ((words[j] >> 24) & 7u); m++)
+                            if (d->variable[words[j + m]].cardinality != 2) binmem = false;
                     len = std::max<int64_t>(len, (int64_t)words.size());
                     headers_of(words, have0 ? hdrs : hdrs0);
                     if (have0 && hdrs != hdrs0) {
@@ -830,7 +844,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     for (uint32_t wdp : prog)
                         if (((wdp >> 24) & 7u) != kind || ((wdp >> 27) & 7u) != 3u) kind = 0;   // first+last, not ignored
                     td[2] = it->second;
-                    td[3] = (uint32_t)nslots | (kind << 8);
+                    // bit 11: draw-table candidate (padding slots read variable 0: masked off by nslots)
+                    td[3] = (uint32_t)nslots | (kind << 8) | ((binmem && !getenv("NSK_NO_ZTAB")) ? 1u << 11 : 0u);
                     len = nslots;
                 }
                 if (td[2] == 0xFFFFFFFFu && same_shape && len <= 16 && len > 0 && !getenv("NSK_NO_SHAPE")) {
@@ -881,6 +896,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         if (c.dyn_tiles.empty()) c.dyn_tiles.push_back(0);
         // homogeneous segments and the rest list
         const int64_t SEG_MIN = 1;
+        std::map<uint32_t, int64_t> ztab_of;                        // program -> first table entry
         c.phase_rest_base.assign((size_t)ncolors + 1, 0);
         for (int32_t k = 0; k < ncolors; k++) {
             const int64_t nt = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
@@ -917,6 +933,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     sg.phase = k; sg.pos0 = c.phase_start[k] + 64 * b; sg.ntiles = (int32_t)(e - b);
                     sg.adj_off = td[0]; sg.prog = td[2]; sg.nslots = td[3] & 0xFFu; sg.kind = (td[3] >> 8) & 7u;
                     sg.ev = ev;
+                    sg.ztab = -1;
+                    if ((td[3] >> 11) & 1u) {                      // draw table of the program (shared)
+                        auto zi = ztab_of.find(sg.prog);
+                        if (zi == ztab_of.end() && c.nztab + ((int64_t)1 << sg.nslots) <= ((int64_t)1 << 20)) {
+                            zi = ztab_of.emplace(sg.prog, c.nztab).first;
+                            c.zprogs.push_back({sg.prog, sg.nslots, (uint32_t)c.nztab, 0u});
+                            c.nztab += (int64_t)1 << sg.nslots;
+                        }
+                        if (zi != ztab_of.end()) sg.ztab = zi->second;
+                    }
                     c.segments.push_back(sg);
                 } else if (td[2] == 0xFFFFFFFFu || ((td[3] >> 8) & 7u) != 6u) {      // general tiles: own kernel
                     for (int64_t t = b; t < e; t++) c.rest_tiles.push_back((uint32_t)t);
@@ -932,15 +958,19 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         c.phase_learn_rest_base.assign((size_t)ncolors + 1, 0);
         for (int32_t k = 0; k < ncolors; k++) {
             std::vector<Compiled::SegLaunch> tabs;
+            for (int tab = 0; tab <= 1; tab++)
             for (int kind = 0; kind <= 4; kind++)
                 for (int nch = 1; nch <= 2; nch++) {
                     Compiled::SegLaunch t;
                     memset(&t, 0, sizeof(t));
-                    t.phase = k; t.kind = kind; t.nch = nch;
+                    t.phase = k; t.kind = kind; t.nch = nch; t.tab = tab;
                     for (const Compiled::Segment &sg : c.segments) {
-                        if (sg.phase != k || (int)(sg.kind == 1 ? 3 : sg.kind) != kind || (sg.nslots > 4 ? 2 : 1) != nch)
+                        if (sg.phase != k || (int)(sg.kind == 1 ? 3 : sg.kind) != kind || (sg.nslots > 4 ? 2 : 1) != nch ||
+                            (sg.ztab >= 0 ? 1 : 0) != tab)
                             continue;
                         t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
+                        t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
+                        t.zmask[t.n] = (1u << sg.nslots) - 1u;
                         t.tile_start[t.n + 1] = t.tile_start[t.n] + sg.ntiles;
                         if (++t.n == 8) { tabs.push_back(t); t.n = 0; t.tile_start[0] = 0; }
                     }
@@ -1063,6 +1093,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t s_i = 4, s_v = c.vbytes, s_c = 4;
     const bool big_w = nw * 8 > (4 << 20);
     double bytes_inf = 0, bytes_learn = 0;
+    double lay_inf = 0, lay_learn = 0;         // generic-path positions: the CSR model is their layout
+    std::vector<uint8_t> generic_pos((size_t)c.npos + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++)
+        for (int64_t p = c.phase_fast_end[k]; p < c.phase_start[k + 1]; p++) generic_pos[p] = 1;
     std::vector<int64_t> uni;
     int64_t si = 0, li = 0;
     for (int64_t p = 0; p < c.npos; p++) {
@@ -1101,6 +1135,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         bytes_inf += bi + 2 * s_c;
         bytes_learn += bi + bl + s_v;
+        if (generic_pos[p]) { lay_inf += bi + 2 * s_c; lay_learn += bi + bl + s_v; }
     }
     c.slot_off[si] = (int32_t)li;
 
@@ -1181,6 +1216,41 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     }
     c.alg_bytes_inference = bytes_inf;
     c.alg_bytes_learning = bytes_learn;
+    // ---- layout bytes: what one sweep must move in the compiled layout.  Tile words (padding
+    // included), position arrays, the distinct neighbour values a colour class reads, the stores and
+    // the tally read-modify-write; materialised weight rows / gathered weights when the table
+    // exceeds the L2; generic-path positions as in the CSR model above.
+    {
+        std::vector<int32_t> seen(nvar, -1);
+        for (int32_t k = 0; k < ncolors; k++) {
+            double words = 0, wrows = 0;
+            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
+                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                const uint32_t kind = td[2] == 0xFFFFFFFFu ? 8u : (td[3] >> 8) & 7u;
+                words += (double)td[1] * 64 * 4;
+                const bool seg_like = kind < 6u;                 // uniform tiles: p_vid + tally only
+                lay_inf += 64.0 * (4 + (seg_like ? 0 : 4));
+                lay_learn += 64.0 * (4 + 4 + s_v);               // p_vid, p_info, p_init
+                if (big_w && kind == 6u) wrows += (double)((td[3] & 0xFFu) / (2 + ((td[3] >> 16) & 7u))) * 64 * 8;
+                if (big_w && kind == 7u) wrows += (double)(td[3] & 0xFFu) * 64 * 8 / 2;   // ~ one header per two words
+            }
+            lay_inf += words + wrows;
+            lay_learn += words + 3 * wrows;            // weight gathers + one 16-byte atomic per visit
+            int64_t distinct = 0, nfastpos = 0, ncatpos = 0;
+            for (int64_t p = c.phase_start[k]; p < c.phase_fast_end[k]; p++) {
+                const int64_t v = c.p_vid[p];
+                if (v < 0) continue;
+                if (d->variable[v].cardinality == 2) nfastpos++; else ncatpos++;
+                for_each_read(v, [&](int64_t b) {
+                    if (b != v && seen[b] != k) { seen[b] = k; distinct++; }
+                });
+            }
+            lay_inf += (double)distinct * s_v + (double)(nfastpos + ncatpos) * s_v + 2.0 * nfastpos + 2.0 * s_c * ncatpos;
+            lay_learn += 2.0 * distinct * s_v + 2.0 * (nfastpos + ncatpos) * s_v;
+        }
+        c.layout_bytes_inference = lay_inf;
+        c.layout_bytes_learning = lay_learn;
+    }
     return NSK_OK;
 }
 

@@ -57,13 +57,22 @@ struct Compiled {
     // program, slot count, kind and evidence flag.  The inference sweep launches a straight-line
     // kernel per segment with the tile description in kernel arguments; the tiles outside any
     // segment (rest_tiles, per phase) go through the descriptor-driven kernel.
-    struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev; };
+    struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev;
+                     int64_t ztab; };      // ztab: first entry of the program's draw table, -1 = none
     std::vector<Segment> segments;
+    // Draw tables (DESIGN.md "draw tables"): a uniform program whose lanes read binary members only
+    // has 2^nslots possible neighbourhoods; per neighbourhood the draw threshold and the per-slot
+    // satisfied bits are tabulated by k_refresh_ztab whenever weights change.
+    struct ZProg { uint32_t prog, nslots, off, pad; };
+    std::vector<ZProg> zprogs;
+    int64_t nztab = 0;                      // entries (16 bytes each)
+    bool values_regular = true;             // every initial value lies in [0, cardinality)
     std::vector<uint32_t> rest_tiles;       // tile indices relative to the phase's first tile
     // learning: the largest (kind, chunks) groups of a colour's segments run as segment launches of
     // their own (at most NSK_LEARN_SEG_LAUNCHES per colour); every other non-general tile is on
     // the colour's learn_rest list
-    struct SegLaunch { int32_t phase, kind, nch, n; int32_t tile_start[9]; int32_t pos0[8]; uint32_t adj_off[8], prog[8]; };
+    struct SegLaunch { int32_t phase, kind, nch, n, tab; int32_t tile_start[9]; int32_t pos0[8];
+                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8]; };
     std::vector<SegLaunch> learn_seg;
     std::vector<uint32_t> learn_rest_tiles;
     std::vector<int64_t> phase_learn_rest_base;   // [ncolors+1]
@@ -98,6 +107,9 @@ struct Compiled {
     std::vector<int32_t> v_init;
     // algorithmic traffic, bytes per sweep over the sampled variables
     double alg_bytes_inference = 0, alg_bytes_learning = 0;
+    // bytes one sweep must move in THIS layout (tile words, position arrays, distinct values read
+    // per colour class, stores, tallies): what roofline fractions are computed from
+    double layout_bytes_inference = 0, layout_bytes_learning = 0;
 };
 
 // returns NSK_OK or an NSK_E_* code with `err` filled

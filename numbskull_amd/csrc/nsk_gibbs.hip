@@ -1,0 +1,152 @@
+// nsk_gibbs.hip -- inference sweep driver: replaces run_pool(gibbsthread) at
+// numbskull/factorgraph.py:141 (burn-in) and :163 (inference); kernels in nsk_kernels_gibbs.h.
+#include <algorithm>
+#include <cstdlib>
+
+#include "nsk_internal.h"
+#include "nsk_kernels_misc.h"
+
+using namespace nsk;
+
+template <typename VT>
+static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
+    DevGraph<VT> d = view<VT>(g);
+    if (g->scan == NSK_SCAN_SEQUENTIAL) {
+        k_seq_gibbs<VT><<<dim3(1), dim3(64), 0, g->stream>>>(d, g->v_pos, g->mt_np, (int)nsweeps,
+                                                            sample_evidence, burnin);
+        HIPCHECK(hipGetLastError());
+        g->launches++;
+        g->sweep += (uint64_t)nsweeps;
+    } else {
+        const size_t nphase = g->c.phase_start.size() - 1;
+        nsk_refresh_prog_weights(g);
+        for (int64_t s = 0; s < nsweeps; s++) {
+            for (size_t ph = 0; ph < nphase; ph++) {
+                const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
+                const int e = (int)g->c.phase_start[ph + 1];
+                const int he = (int)g->c.phase_heavy_end[ph];
+                ColourStreams cs(g, !g->no_overlap);
+                bool rest_in_general = false;       // the colour's rest tiles were given to a general launch
+                {   // hubs (one wave per variable) + general tiles with categorical lanes: one launch
+                    const int gt0 = fe > fb ? (int)g->c.phase_gen_tile[ph] : 0;
+                    int gtb = fe > fb ? (int)g->c.phase_gen_bin_tile[ph] : 0;
+                    // a class with categorical tiles walks ALL its general tiles in this launch, on
+                    // the main stream: the fork / join events of a side stream cost more (~20 us per
+                    // class) than the binary tiles lose by running the 8-candidate code
+                    const bool one_general = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
+                    if (one_general) gtb = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
+                    // without categorical tiles the hubs ride in the binary launch on the main stream
+                    // (no side stream, no fork / join events for this class)
+                    const bool hubs_with_binary = gtb == gt0 && fe > fb &&
+                        (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) > gtb;
+                    const int nblocks = (gtb - gt0 + 3) / 4, hblocks = hubs_with_binary ? 0 : (he - fe + 3) / 4;
+                    // the colour's other tiles outside segments ride in the general launch too
+                    const int nrest_all = fe > fb ? (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]) : 0;
+                    const bool rest_here = one_general && nrest_all > 0;
+                    rest_in_general = rest_here;
+                    const int rblocks = rest_here ? (nrest_all + 3) / 4 : 0;
+                    if (nblocks + hblocks > 0) {
+                        k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, one_general ? g->stream : cs.side(0)>>>(
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks,
+                            g->rest_tiles + g->c.phase_rest_base[ph], rest_here ? nrest_all : 0,
+                            sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                            (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                        g->launches++;
+                    }
+                }
+                if (e > he) {       // generic CSR kernel, one lane per variable
+                    k_gibbs_phase<VT><<<dim3((e - he + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, cs.side(1)>>>(
+                        d, he, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
+                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                    g->launches++;
+                }
+                if (fe > fb) {      // inlined-adjacency kernels
+                    const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
+                    const uint32_t S0 = (uint32_t)g->sweep, S1 = (uint32_t)(g->sweep >> 32);
+                    const int gt0 = (int)g->c.phase_gen_tile[ph];
+                    const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
+                    int gtb = (int)g->c.phase_gen_bin_tile[ph];
+                    if (gtb > gt0 && !getenv("NSK_SPLIT_GENERAL")) gtb = gt0 + ngt;     // walked by the launch above
+                    if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
+                        const int nblocks = (gt0 + ngt - gtb + 3) / 4;
+                        const int hbl = gtb == gt0 ? (he - fe + 3) / 4 : 0;     // see above
+                        const int nrest_all = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
+                        rest_in_general = gtb == gt0 && nrest_all > 0 && !getenv("NSK_SPLIT_GENERAL");
+                        const int rblocks = rest_in_general ? (nrest_all + 3) / 4 : 0;
+                        k_gibbs_general<VT, 2><<<dim3(hbl + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, g->stream>>>(
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, fe, he, hbl,
+                            g->rest_tiles + g->c.phase_rest_base[ph], rest_in_general ? nrest_all : 0,
+                            sample_evidence, burnin, K0, K1, S0, S1);
+                        g->launches++;
+                    }
+                    // segments of this colour, batched by (kind, chunks) into table launches
+                    // kind 8 = segments with draw tables (any function: the table encodes it)
+                    const bool use_tab = g->values_regular;
+                    for (int kind = 0; kind <= 8; kind++) {
+                        if (kind == 1 || (kind > 4 && kind < 8)) continue;   // IMPLY_NATURAL shares the AND step (3)
+                        for (int nch = 1; nch <= 2; nch++) {
+                            SegTable tab;
+                            tab.n = 0; tab.tile_start[0] = 0;
+                            auto flush = [&]() {
+                                if (tab.n == 0) return;
+                                const int nb = (tab.tile_start[tab.n] + 3) / 4;
+                                const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
+#define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
+                                if (kind == 8) {
+                                    if (nch == 1) k_gibbs_seg_tab<VT, 1><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1);
+                                    else k_gibbs_seg_tab<VT, 2><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1);
+                                }
+                                else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
+                                else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
+                                else if (kind == 0) { if (nch == 1) NSK_SEG(0, 1); else NSK_SEG(0, 2); }
+                                else { if (nch == 1) NSK_SEG(3, 1); else NSK_SEG(3, 2); }
+#undef NSK_SEG
+                                g->launches++;
+                                tab.n = 0;
+                            };
+                            for (const Compiled::Segment &sg : g->c.segments) {
+                                if (sg.phase != (int)ph) continue;
+                                const int k3 = (use_tab && sg.ztab >= 0) ? 8 : sg.kind == 1 ? 3 : (int)sg.kind;
+                                if (k3 != kind || (sg.nslots > 4 ? 2 : 1) != nch) continue;
+                                if (!(sg.ev == 0 || sample_evidence)) continue;      // inference.py:24
+                                tab.pos0[tab.n] = (int)sg.pos0;
+                                tab.adj_off[tab.n] = sg.adj_off;
+                                tab.prog[tab.n] = sg.prog;
+                                tab.zoff[tab.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
+                                tab.zmask[tab.n] = (1u << sg.nslots) - 1u;
+                                tab.tile_start[tab.n + 1] = tab.tile_start[tab.n] + sg.ntiles;
+                                if (++tab.n == NSK_SEG_MAX) flush();
+                            }
+                            flush();
+                        }
+                    }
+                    const int nrest = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
+                    if (nrest > 0 && !rest_in_general) {
+                        const int nblocks = (nrest + 3) / 4;
+                        k_gibbs_fast<VT><<<dim3(8 * ((nblocks + 7) / 8)), dim3(NSK_BLOCK), 0, g->stream>>>(
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], nblocks,
+                            g->rest_tiles + g->c.phase_rest_base[ph], nrest, sample_evidence, burnin,
+                            K0, K1, S0, S1);
+                        g->launches++;
+                    }
+                }
+                cs.join();
+            }
+            g->sweep++;
+            if (!burnin && ++g->pos_tally_sweeps == 255) nsk_fold_position_tally(g);   // uint8 tally is full
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    if (!burnin) g->cnt_dirty = true;
+    g->sweeps_done += nsweeps;
+    return NSK_OK;
+}
+
+extern "C" int nsk_gibbs_sweeps(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
+    if (nsweeps == 0) return NSK_OK;
+    HIPCHECK(hipSetDevice(g->device));
+    return g->c.vbytes == 1 ? gibbs_impl<int8_t>(g, nsweeps, sample_evidence, burnin)
+                            : gibbs_impl<int32_t>(g, nsweeps, sample_evidence, burnin);
+}

@@ -1,0 +1,142 @@
+// nsk_internal.h -- host-side state of a compiled graph handle, shared by the translation units of
+// the library (nsk_api.hip: C-ABI, state sync, exchange; nsk_gibbs.hip / nsk_learn.hip: the sweep
+// drivers of numbskull/factorgraph.py:141,163,202).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/numbskull_amd.h"
+#include "nsk_compile.h"
+#include "nsk_device.h"
+#include "nsk_kernels_gibbs.h"
+
+namespace nsk {
+int fail(int code, const std::string &msg);       // records nsk_last_error, returns code
+}
+
+#define HIPCHECK(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return nsk::fail(NSK_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+struct nsk_graph {
+    nsk::Compiled c;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // the kernels of one colour class are independent: hubs and generic-path variables run on side
+    // streams next to the tile kernels (fork/join with events around every colour)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    bool no_overlap = getenv("NSK_NO_OVERLAP") != nullptr;     // diagnostic: one stream
+    std::vector<void *> allocs;
+    int64_t device_bytes = 0;
+    // device arrays
+    int32_t *p_vid = nullptr, *p_slot = nullptr, *p_cnt = nullptr, *slot_off = nullptr, *fidx = nullptr;
+    uint32_t *p_info = nullptr, *f_rec = nullptr;
+    void *p_init = nullptr;
+    int32_t *m_rec = nullptr, *v_card = nullptr,
+            *v_pos = nullptr;
+    double *f_feat = nullptr, *w = nullptr, *logtab = nullptr;
+    uint8_t *w_fixed = nullptr;
+    void *val = nullptr, *val_evid = nullptr;
+    int32_t *cnt = nullptr;
+    uint8_t *cnt_pos = nullptr;
+    int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
+    uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr, *gstream = nullptr, *gs_off = nullptr;
+    double *prog_w = nullptr, *adj_wt = nullptr;
+    uint32_t *tile_wrow = nullptr;
+    uint4 *ztab = nullptr;              // draw tables (k_refresh_ztab)
+    nsk::ZProgDev *zprogs = nullptr;
+    bool values_regular = true;         // every value on the device lies in [0, cardinality): the
+                                        // table kernels index with the neighbours' low bits
+    bool chain_regular[2] = {true, true};   // ... per chain (var_value, var_value_evid)
+    double compile_seconds = 0;
+    uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr, *learn_rest_tiles = nullptr;
+    long long *part_G = nullptr;       // SMALLW: rows of per-block partial sums
+    uint32_t *part_K = nullptr, *part_T = nullptr;
+    bool smallw = false;
+    bool weights_dirty = true;      // prog_w must be rebuilt before the next fast-path launch
+    bool weights_exposed = false;
+    bool adj_wt_skip = false;       // learning reads weights directly: skip the shape-tile rows until the next inference   // the weight buffer was handed out: assume it changes between calls
+    // boundary exchange (multi-GPU)
+    int xworld = 0, xrank = 0;
+    int64_t xslot = 0, xnsend = 0, xnrecv = 0;
+    int32_t *x_send_vids = nullptr, *x_recv_vids = nullptr, *x_recv_slot = nullptr;
+    void *x_send = nullptr, *x_recv = nullptr, *x_send_evid = nullptr, *x_recv_evid = nullptr;
+    double *w_start = nullptr, *w_delta = nullptr;
+    // native RCCL
+    void *rccl_lib = nullptr, *rccl_comm = nullptr;
+    long long *cnt_total = nullptr, *G = nullptr;
+    uint32_t *K = nullptr, *T = nullptr;
+    nsk::MTState *mt_np = nullptr, *mt_py = nullptr;
+    // run state
+    uint64_t seed = 0, sweep = 0;
+    int scan = NSK_SCAN_CHROMATIC;
+    bool cnt_dirty = false;
+    int64_t sweeps_done = 0;
+    // profiling bracket
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t launches = 0, launches_at_begin = 0;
+};
+
+template <typename VT>
+static nsk::DevGraph<VT> view(nsk_graph *g) {
+    nsk::DevGraph<VT> d;
+    d.p_vid = g->p_vid; d.p_info = g->p_info; d.p_slot = g->p_slot; d.p_cnt = g->p_cnt;
+    d.p_init = (const VT *)g->p_init;
+    d.slot_off = g->slot_off; d.fidx = g->fidx;
+    d.gstream = (const uint2 *)g->gstream; d.gs_off = g->gs_off;
+    d.f_rec = (const uint4 *)g->f_rec; d.f_feat = g->f_feat;
+    d.m_rec = (const int2 *)g->m_rec; d.v_card = g->v_card;
+    d.w = g->w; d.w_fixed = g->w_fixed; d.logtab = g->logtab;
+    d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
+    d.G = g->G; d.K = g->K; d.T = g->T;
+    d.adj = (const uint4 *)g->adj; d.tiles = (const uint4 *)g->tiles; d.tile_hdr = g->tile_hdr;
+    d.prog_w = g->prog_w; d.adj_wt = g->adj_wt; d.tile_wrow = g->tile_wrow;
+    d.part_G = g->part_G; d.part_K = g->part_K; d.part_T = g->part_T;
+    d.nweight = (int32_t)g->c.nweight;
+    d.packed_grad = g->c.packed_grad ? 1 : 0;
+    d.cnt_pos = g->cnt_pos;
+    d.ztab = g->ztab;
+    d.nvar = (int32_t)g->c.nvar;
+    d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
+    return d;
+}
+
+// Streams for the kernels of one colour: the tile kernels stay on the main stream; when there are
+// tile kernels to overlap with, hubs go to side stream 0, the generic kernel to side stream 1 and
+// the categorical general tiles to side stream 2.
+struct ColourStreams {
+    nsk_graph *g;
+    bool forked[3] = {false, false, false};
+    bool overlap;
+    bool recorded = false;
+    ColourStreams(nsk_graph *g_, bool overlap_) : g(g_), overlap(overlap_) {}
+    // side streams must be requested before anything of the colour is put on the main stream
+    hipStream_t side(int i) {
+        if (!overlap) return g->stream;
+        if (!recorded) { (void)hipEventRecord(g->ev_fork, g->stream); recorded = true; }
+        if (!forked[i]) { (void)hipStreamWaitEvent(g->side[i], g->ev_fork, 0); forked[i] = true; }
+        return g->side[i];
+    }
+    void join() {
+        for (int i = 0; i < 3; i++)
+            if (forked[i]) {
+                (void)hipEventRecord(g->ev_join[i], g->side[i]);
+                (void)hipStreamWaitEvent(g->stream, g->ev_join[i], 0);
+                forked[i] = false;
+            }
+    }
+};
+
+// the fast path reads weights through prog_w (and the draw tables): rebuilt whenever weights may
+// have changed (nsk_api.hip)
+void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);
+void nsk_refresh_ztab(nsk_graph *g);
+int nsk_fold_position_tally(nsk_graph *g);

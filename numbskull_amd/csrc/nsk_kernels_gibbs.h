@@ -218,7 +218,7 @@ __device__ __forceinline__ void tile_potentials_uniform(const DevGraph<VT> &g, c
 // prog_w[2i], prog_w[2i+1] = weight * (value when satisfied, value when not) of program word i, or
 // (0, 0) when the slot does not close an entry.  The products are the reference's own
 // `weight * eval_factor` (inference.py:68-70), so adding them reproduces potential() exactly.
-__global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32_t *prog, const double *w,
+static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const uint32_t *prog, const double *w,
                                                                     double *prog_w, int n) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= n) return;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, con
 
 // adj_wt row e of a shape tile <- the weights its lanes' e-th headers name (run whenever weights
 // may have changed; the sweeps then read weights as coalesced rows instead of 64 random sectors)
-__global__ __launch_bounds__(NSK_BLOCK) void k_refresh_shape_weights(const uint4 *tiles, const uint4 *adj,
+static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_shape_weights(const uint4 *tiles, const uint4 *adj,
                                                                      const uint32_t *tile_hdr,
                                                                      const uint32_t *tile_wrow, const double *w,
                                                                      double *adj_wt, int ntiles) {
@@ -404,7 +404,7 @@ constexpr GenLut make_gen_lut() {
     for (uint32_t i = 0; i < 2048; i++) l.t[i] = gen_lut_entry(i);
     return l;
 }
-__constant__ GenLut k_gen_lut = make_gen_lut();
+static __constant__ GenLut k_gen_lut = make_gen_lut();
 
 // block-wide copy of the table into LDS; every thread of the block must call it
 __device__ __forceinline__ void load_gen_lut(uint8_t *lds) {
@@ -698,7 +698,115 @@ struct SegTable {
     int pos0[NSK_SEG_MAX];                // position of the segment's first lane
     uint32_t adj_off[NSK_SEG_MAX];        // stream offset (16-byte units) of its first tile
     uint32_t prog[NSK_SEG_MAX];           // slot program
+    uint32_t zoff[NSK_SEG_MAX];           // draw-table launches: first entry of the program's table,
+    uint32_t zmask[NSK_SEG_MAX];          //   (1 << member slots) - 1
 };
+
+// ---------------------------------------------------------------------------------------------
+// Draw tables.  For a uniform program whose lanes read binary members only, the potentials of the
+// two candidates -- hence z0 = exp(p0), z1 = z0 + exp(p1) -- depend on the <= 8 neighbour bits
+// alone.  draw_sample's decision (inference.py:49-52) is  value = 0  iff  z0 >= fl(u * z1)  (or the
+// second comparison fails, which needs a NaN);  u = k * 2^-53 is exact for the 53-bit integer k of
+// the generator, and fl(u * z1) is non-decreasing in k, so the k that give 0 are a prefix [0, K]:
+// K is found per neighbourhood by bisection over k WITH THE VERY SAME float64 OPERATIONS the
+// sampling kernels and the oracle use (slot_step sums, nsk_exp, u53's product), and the sweep
+// kernels compare integers.  Bit-identical to the exp-per-update path by construction (both are
+// tested against the oracle).  sat0 / sat1: bit j = slot j's entry is satisfied for candidate 0 / 1
+// (the learning kernels' gradient bits).
+// ---------------------------------------------------------------------------------------------
+struct ZProgDev { uint32_t prog, nslots, off, pad; };
+
+__device__ __forceinline__ int draw_from_z(double z0, double z1, unsigned long long k) {
+    const double u = u53((uint32_t)(k >> 26) << 5, (uint32_t)(k & 0x3FFFFFFull) << 6);
+    const double z = u * z1;
+    return (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
+}
+
+static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_ztab(const ZProgDev *zp, const uint32_t *tile_hdr,
+                                                            const double *prog_w, uint4 *ztab) {
+    const ZProgDev z = zp[blockIdx.x];
+    const uint32_t idx = threadIdx.x;
+    if (idx >= (1u << z.nslots)) return;
+    const uint32_t *pp = tile_hdr + z.prog;
+    const double *tw = prog_w + 2 * (size_t)z.prog;
+    double p0 = 0.0, p1 = 0.0;
+    uint32_t sat0 = 0, sat1 = 0;
+    SlotState st = {0, true, false, true};
+    for (uint32_t j = 0; j < z.nslots; j++) {
+        const uint32_t s = pp[j];
+        const int x = (int)((idx >> j) & 1u);
+        const bool F = (s >> 27) & 1u, ig = (s >> 29) & 1u;          // slot_step / slot_sat, spelled out
+        const uint32_t code = (s >> 24) & 7u;
+        const bool nz = ig || (x != 0), one = !ig && (x == 1);
+        st.alleq = F || (st.alleq && (x == st.first));
+        st.allnz = (F || st.allnz) && nz;
+        st.any1 = (!F && st.any1) || one;
+        st.first = F ? x : st.first;
+        const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
+        const bool b0 = (isEq && st.alleq && (ig || st.first == 0)) || (isOr && st.any1);
+        const bool b1 = (isEq && st.alleq && (ig || st.first == 1)) || (isAnd && st.allnz) || isOr;
+        const double thi = tw[2 * j], tlo = tw[2 * j + 1];
+        p0 = p0 + (b0 ? thi : tlo);
+        p1 = p1 + (b1 ? thi : tlo);
+        sat0 |= (b0 ? 1u : 0u) << j;
+        sat1 |= (b1 ? 1u : 0u) << j;
+    }
+    const double z0 = nsk_exp(p0);
+    const double z1 = z0 + nsk_exp(p1);
+    unsigned long long lo = 0, hi = (1ull << 53) - 1;           // draw(0) == 0 always (z = +0 or NaN)
+    if (draw_from_z(z0, z1, hi) == 0) lo = hi;
+    while (hi - lo > 1) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        if (draw_from_z(z0, z1, mid) == 0) lo = mid; else hi = mid;
+    }
+    ztab[z.off + idx] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), sat0 | (sat1 << 8), 0u};
+}
+
+// the generator's 53-bit integer: u53(a, b) == k * 2^-53 exactly
+__device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
+    return ((unsigned long long)(a >> 5) << 26) | (unsigned long long)(b >> 6);
+}
+
+// Homogeneous segments whose programs have draw tables: ids, byte gathers, bit pack, one 8-byte
+// table read, integer compare.  No float64 arithmetic.
+template <typename VT, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int nblocks,
+                                                             int burnin, uint32_t k0, uint32_t k1,
+                                                             uint32_t s0, uint32_t s1) {
+    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
+    if (lb < 0) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int T = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (T >= tab.tile_start[tab.n]) return;
+    int sidx = 0;
+#pragma unroll
+    for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+    const int t = T - tab.tile_start[sidx];
+    const int p = tab.pos0[sidx] + t * 64 + lane;
+    const int v = g.p_vid[p];                             // -1: padding lane at a class end
+    const uint8_t tally = burnin ? (uint8_t)0 : g.cnt_pos[p];
+    const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+    uint4 q[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];
+    uint32_t idx = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        idx |= ((uint32_t)g.val[q[c].x] & 1u) << (4 * c);
+        idx |= ((uint32_t)g.val[q[c].y] & 1u) << (4 * c + 1);
+        idx |= ((uint32_t)g.val[q[c].z] & 1u) << (4 * c + 2);
+        idx |= ((uint32_t)g.val[q[c].w] & 1u) << (4 * c + 3);
+    }
+    idx &= tab.zmask[sidx];
+    const uint2 e = *(const uint2 *)(g.ztab + tab.zoff[sidx] + idx);
+    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const unsigned long long K = ((unsigned long long)e.y << 32) | e.x;
+    const int nv = k53(rr.x, rr.y) > K ? 1 : 0;
+    if (v >= 0) {
+        g.val[v] = (VT)nv;
+        if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
+    }
+}
 
 template <typename VT, int KIND, int NCH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTable tab, int nblocks,

@@ -554,6 +554,89 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
     close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
 }
 
+// The same over segments whose programs have draw tables (k_refresh_ztab): both chains' draws are
+// integer compares against the tabulated thresholds, the per-slot satisfied bits come from the same
+// table entries.  learn_tile's gradient bookkeeping, no float64 arithmetic.
+template <typename VT, bool SMALLW, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, SegTable tab, LearnParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
+    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
+    const int ntiles = tab.tile_start[tab.n];
+    const int per = (ntiles + nwaves - 1) / nwaves;
+    const int t1 = min(ntiles, (wave0 + 1) * per);
+    for (int T = wave0 * per; T < t1; T++) {
+        int sidx = 0;
+#pragma unroll
+        for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+        const int t = T - tab.tile_start[sidx];
+        const int p = tab.pos0[sidx] + t * 64 + lane;
+        const int v0 = g.p_vid[p];                           // -1: padding lane at a class end
+        const bool valid = v0 >= 0;
+        const int v = valid ? v0 : 0;
+        const int ev = valid ? NSK_INFO_EV(g.p_info[p]) : 0;
+        const int init = valid ? (int)g.p_init[p] : 0;
+        const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+        const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + tab.prog[sidx]);
+        uint4 q[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];
+        uint32_t idf = 0, ide = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const uint32_t wd[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                idf |= ((uint32_t)g.val[wd[i]] & 1u) << (4 * c + i);
+                ide |= ((uint32_t)g.val_evid[wd[i]] & 1u) << (4 * c + i);
+            }
+        }
+        idf &= tab.zmask[sidx];
+        ide &= tab.zmask[sidx];
+        const uint4 ef = g.ztab[tab.zoff[sidx] + idf];
+        const uint4 ee = g.ztab[tab.zoff[sidx] + ide];
+        const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+        int evidence = init;                                                  // learning.py:61-62
+        if (ev != 1) evidence = k53(r.z, r.w) > (((unsigned long long)ee.y << 32) | ee.x) ? 1 : 0;   // 54-58
+        const int proposal = k53(r.x, r.y) > (((unsigned long long)ef.y << 32) | ef.x) ? 1 : 0;     // 66-70
+        if (valid) {
+            g.val_evid[v] = (VT)evidence;
+            g.val[v] = (VT)proposal;
+        }
+        const bool part = valid && (lp.learn_non_evidence || ev == 1);        // 71-72
+        bool truncate = false;
+        if (lp.regularization == 1) {                                         // 90
+            const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+            truncate = part && (u53(tt.x, tt.y) < lp.inv_trunc);
+        }
+        const unsigned long long pm = __ballot(part);
+        if (pm == 0) continue;
+        const uint32_t satf = proposal ? (ef.z >> 8) : ef.z, sate = evidence ? (ee.z >> 8) : ee.z;
+        const uint32_t nk = (uint32_t)__popcll(pm), nt = (uint32_t)__popcll(__ballot(truncate));
+#pragma unroll
+        for (int j = 0; j < 4 * NCH; j++) {
+            const uint32_t s = pp[j];
+            const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
+            if (closes && !fixed) {
+                const uint32_t code = (s >> 24) & 7u;
+                const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
+                const int nf = __popcll(__ballot(part && ((satf >> j) & 1u)));
+                const int ne = __popcll(__ballot(part && ((sate >> j) & 1u)));
+                if (lane == 0) {
+                    const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
+                    const int wid = (int)(s & 0xFFFFFFu);
+                    atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
+                    if (!sk.packed) atomicAdd(&sk.K[wid], nk);
+                    if (nt) atomicAdd(&sk.T[wid], nt);
+                }
+            }
+        }
+    }
+    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+}
+
 template <typename VT, bool SMALLW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pbegin, int pend,
                                                           int wb_base, const uint32_t *list, int ntiles,
@@ -627,7 +710,7 @@ __device__ __forceinline__ double apply_update(double x, long long G, uint32_t k
     return x;
 }
 
-__global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
+static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
                                                              uint32_t *T, int nweight, double step,
                                                              int regularization, double reg_param,
                                                              double truncation, int packed) {
@@ -651,7 +734,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long lon
 
 // SMALLW flavour: one block per weight adds up the per-block rows, applies the update and rewrites
 // the prog_w entries of the slot programs that use this weight (so no separate refresh launch).
-__global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights_rows(double *w, const long long *part_G,
+static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights_rows(double *w, const long long *part_G,
                                                                   const uint32_t *part_K, const uint32_t *part_T,
                                                                   int nrows, int nweight, double step,
                                                                   int regularization, double reg_param,

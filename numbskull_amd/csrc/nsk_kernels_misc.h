@@ -8,7 +8,7 @@
 namespace nsk {
 
 // int32 per-call tally deltas -> int64 master copy (the host-visible `count`)
-__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts(int32_t *delta, long long *total, int n) {
+static __global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts(int32_t *delta, long long *total, int n) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= n) return;
     total[i] += (long long)delta[i];
@@ -42,21 +42,21 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_exchange_unpack(VT *val, const in
 }
 
 // weight merge of the partitioned learning sweep: delta = w - start ... w = start + sum(delta)
-__global__ __launch_bounds__(NSK_BLOCK) void k_weight_delta(const double *w, const double *start, double *delta, int n) {
+static __global__ __launch_bounds__(NSK_BLOCK) void k_weight_delta(const double *w, const double *start, double *delta, int n) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i < n) delta[i] = w[i] - start[i];
 }
-__global__ __launch_bounds__(NSK_BLOCK) void k_weight_merge(double *w, const double *start, const double *delta, int n) {
+static __global__ __launch_bounds__(NSK_BLOCK) void k_weight_merge(double *w, const double *start, const double *delta, int n) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i < n) w[i] = start[i] + delta[i];
 }
 
-__global__ void k_selftest_exp(const double *x, double *y, long long n) {
+static __global__ void k_selftest_exp(const double *x, double *y, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = nsk_exp(x[i]);
 }
 
-__global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t s0, uint32_t s1,
+static __global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t s0, uint32_t s1,
                                   long long n, uint32_t *out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -65,7 +65,7 @@ __global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stream, uin
 }
 
 // position-indexed tally deltas of the fast path -> int64 master copy at cstart[vid]
-__global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(uint8_t *cnt_pos, const int32_t *p_cnt,
+static __global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(uint8_t *cnt_pos, const int32_t *p_cnt,
                                                                long long *total, int npos) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= npos) return;

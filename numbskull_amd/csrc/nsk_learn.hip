@@ -1,0 +1,190 @@
+// nsk_learn.hip -- learning sweep driver: replaces the epoch loop around run_pool(learnthread) at
+// numbskull/factorgraph.py:194-206; kernels in nsk_kernels_learn.h.
+#include <algorithm>
+#include <cstdlib>
+
+#include "nsk_internal.h"
+#include "nsk_kernels_learn.h"
+#include "nsk_kernels_misc.h"
+
+using namespace nsk;
+
+template <typename VT, bool SMALLW>
+static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                           double reg_param, int64_t truncation, int learn_non_evidence) {
+    DevGraph<VT> d = view<VT>(g);
+    const size_t nphase = g->c.phase_start.size() - 1;
+    const int nw = (int)g->c.nweight;
+    const size_t shmem = SMALLW ? (size_t)nw * 16 : 0;
+    LearnParams lp;
+    lp.regularization = regularization;
+    lp.learn_non_evidence = learn_non_evidence;
+    lp.inv_trunc = 1.0 / (double)truncation;
+    lp.k0 = (uint32_t)g->seed; lp.k1 = (uint32_t)(g->seed >> 32);
+    g->adj_wt_skip = true;          // the learning kernels gather weights themselves
+    nsk_refresh_prog_weights(g);
+    for (int64_t s = 0; s < nsweeps; s++) {
+        lp.s0 = (uint32_t)g->sweep; lp.s1 = (uint32_t)(g->sweep >> 32);
+        for (size_t ph = 0; ph < nphase; ph++) {
+            const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
+            const int e = (int)g->c.phase_start[ph + 1];
+            if (e <= fb) continue;
+            int rows = 0;
+            const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
+            const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
+            const int he = (int)g->c.phase_heavy_end[ph];
+            ColourStreams cs(g, !g->no_overlap);
+            if (e > he) {               // variables outside the fast path: generic kernel, range mode
+                const int nitems = (e - he + 63) / 64;
+                const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
+                lp.row_base = rows;
+                k_learn_phase<VT, SMALLW, true><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(1)>>>(
+                    d, he, e, nullptr, nitems, lp);
+                rows += grid;
+                g->launches++;
+            }
+            const int gt0 = (int)g->c.phase_gen_tile[ph];
+            const int gtb = (int)g->c.phase_gen_bin_tile[ph];
+            // hubs ride as extra blocks of a general-tile launch when the class has one
+            const bool hubs_in_general = (gtb > gt0 || ntiles > gtb) && he > fe && !getenv("NSK_SPLIT_GENERAL");
+            const int hbl = hubs_in_general ? std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4) : 0;
+            if (he > fe && !hubs_in_general) {   // hubs: one wave per variable
+                const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
+                lp.row_base = rows;
+                k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(2)>>>(d, fe, he, lp);
+                rows += grid;
+                g->launches++;
+            }
+            // the colour's uniform / shape tiles outside segment launches ride in the general launch
+            const int nlrest = (int)(g->c.phase_learn_rest_base[ph + 1] - g->c.phase_learn_rest_base[ph]);
+            const bool rest_in_general = ntiles > gt0 && nlrest > 0 && !getenv("NSK_SPLIT_GENERAL");
+            const uint32_t *lrest = g->learn_rest_tiles + g->c.phase_learn_rest_base[ph];
+            // a class with a lot of both general tiles and other tiles runs the two groups side by side
+            // (side stream 0); smaller ones are not worth the fork / join events
+            int other_tiles = rest_in_general ? 0 : nlrest;
+            for (const Compiled::SegLaunch &sl : g->c.learn_seg) if (sl.phase == (int)ph) other_tiles += sl.tile_start[sl.n];
+            const bool general_aside = ntiles - gt0 >= 2048 && other_tiles >= 2048 && !g->no_overlap;
+            // as in inference: a class with categorical tiles walks all its general tiles in one
+            // launch of the 8-candidate kernel on the main stream (+10 % over two concurrent launches)
+            const bool one_lg = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
+            if (gtb > gt0) {            // general tiles with categorical lanes
+                const int nt8 = one_lg ? ntiles - gt0 : gtb - gt0;
+                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + hbl;
+                lp.row_base = rows;
+                k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, (one_lg && !general_aside) ? g->stream : cs.side(0)>>>(
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, fe, he, hbl, lrest,
+                    (rest_in_general && one_lg) ? nlrest : 0, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (ntiles > gtb && !one_lg) {   // all-binary general tiles
+                const int hb2 = gtb > gt0 ? 0 : hbl;        // no categorical launch: the hubs come here
+                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + hb2;
+                lp.row_base = rows;
+                k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, general_aside ? cs.side(0) : g->stream>>>(
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, fe, he, hb2, lrest,
+                    (rest_in_general && !(one_lg)) ? nlrest : 0, lp);
+                rows += grid;
+                g->launches++;
+            }
+            for (const Compiled::SegLaunch &sl : g->c.learn_seg) {       // homogeneous segments
+                if (sl.phase != (int)ph) continue;
+                SegTable tab;
+                tab.n = sl.n;
+                for (int i = 0; i <= NSK_SEG_MAX; i++) tab.tile_start[i] = sl.tile_start[i];
+                for (int i = 0; i < NSK_SEG_MAX; i++) {
+                    tab.pos0[i] = sl.pos0[i]; tab.adj_off[i] = sl.adj_off[i]; tab.prog[i] = sl.prog[i];
+                    tab.zoff[i] = sl.zoff[i]; tab.zmask[i] = sl.zmask[i];
+                }
+                const int grid = std::min(NSK_LEARN_SEG_BLOCKS, (tab.tile_start[tab.n] + 3) / 4);
+                lp.row_base = rows;
+#define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
+                if (sl.tab && g->values_regular) {
+                    if (sl.nch == 1) k_learn_seg_tab<VT, SMALLW, 1><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp);
+                    else k_learn_seg_tab<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp);
+                }
+                else if (sl.kind == 4) { if (sl.nch == 1) NSK_LSEG(4, 1); else NSK_LSEG(4, 2); }
+                else if (sl.kind == 2) { if (sl.nch == 1) NSK_LSEG(2, 1); else NSK_LSEG(2, 2); }
+                else if (sl.kind == 0) { if (sl.nch == 1) NSK_LSEG(0, 1); else NSK_LSEG(0, 2); }
+                else { if (sl.nch == 1) NSK_LSEG(3, 1); else NSK_LSEG(3, 2); }
+#undef NSK_LSEG
+                rows += grid;
+                g->launches++;
+            }
+            if (nlrest > 0 && !rest_in_general) {   // the other uniform and shape tiles: descriptor-driven kernel
+                const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (nlrest + 3) / 4);
+                lp.row_base = rows;
+                k_learn_fast<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], g->learn_rest_tiles + g->c.phase_learn_rest_base[ph],
+                    nlrest, lp);
+                rows += grid;
+                g->launches++;
+            }
+            if (ndyn > 0) {             // tiles with per-lane headers: generic kernel, list mode
+                const int grid = std::min(NSK_LEARN_LIST_BLOCKS, (ndyn + 3) / 4);
+                lp.row_base = rows;
+                k_learn_phase<VT, SMALLW, false><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
+                    d, fb, fe, g->dyn_tiles + g->c.phase_dyn_base[ph], ndyn, lp);
+                rows += grid;
+                g->launches++;
+            }
+            cs.join();
+            if (SMALLW && rows > NSK_LEARN_ROWS)             // cannot happen with the grid caps above
+                return fail(NSK_E_RANGE, "partial-sum rows exceeded");
+            if (nw > 0) {
+                if (SMALLW) {
+                    k_apply_weights_rows<<<dim3(nw), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        g->w, g->part_G, g->part_K, g->part_T, rows, nw, step, regularization, reg_param,
+                        (double)truncation, g->tile_hdr, g->prog_w,
+                        g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0);
+                    if (g->c.nfast > 0) nsk_refresh_ztab(g);
+                } else {
+                    k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation,
+                        (!SMALLW && g->c.packed_grad) ? 1 : 0);
+                    nsk_refresh_prog_weights(g, true);
+                }
+            }
+        }
+        g->sweep++;
+        step *= decay;                                   // factorgraph.py:206
+    }
+    g->adj_wt_skip = false;
+    g->weights_dirty = true;        // the next inference call rebuilds prog_w and the weight rows
+    HIPCHECK(hipGetLastError());
+    return NSK_OK;
+}
+
+template <typename VT>
+static int learn_impl(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                      double reg_param, int64_t truncation, int learn_non_evidence) {
+    if (g->scan == NSK_SCAN_SEQUENTIAL) {
+        DevGraph<VT> d = view<VT>(g);
+        k_seq_learn<VT><<<dim3(1), dim3(64), 0, g->stream>>>(d, g->v_pos, g->mt_np, g->mt_py, (int)nsweeps,
+                                                            step, decay, regularization, reg_param,
+                                                            (double)truncation, learn_non_evidence);
+        HIPCHECK(hipGetLastError());
+        g->launches++;
+        g->sweep += (uint64_t)nsweeps;
+    } else {
+        int rc = g->smallw ? learn_chromatic<VT, true>(g, nsweeps, step, decay, regularization, reg_param,
+                                                       truncation, learn_non_evidence)
+                           : learn_chromatic<VT, false>(g, nsweeps, step, decay, regularization, reg_param,
+                                                        truncation, learn_non_evidence);
+        if (rc) return rc;
+    }
+    g->sweeps_done += nsweeps;
+    return NSK_OK;
+}
+
+extern "C" int nsk_learn_sweeps(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                     double reg_param, int64_t truncation, int learn_non_evidence) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
+    if (regularization == 1 && truncation == 0) return fail(NSK_E_INVALID, "truncation must be non-zero (ZeroDivisionError in the reference)");
+    if (nsweeps == 0) return NSK_OK;
+    HIPCHECK(hipSetDevice(g->device));
+    return g->c.vbytes == 1
+               ? learn_impl<int8_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence)
+               : learn_impl<int32_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence);
+}
