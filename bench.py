@@ -243,8 +243,9 @@ def main():
     copy_gbs = None
     if rank == 0:
         cg = C.c_double()
-        if L.nsk_selftest_stream(local_rank, 1 << 30, 16, 10, C.byref(cg)) == 0:
-            copy_gbs = cg.value           # achievable HBM copy rate on this GPU, same run
+        if L.nsk_selftest_stream(local_rank, 4 << 30, 64, 5, C.byref(cg)) == 0:
+            copy_gbs = cg.value           # achievable HBM copy rate on this GPU, same run (4 GiB,
+                                          # non-temporal 16-byte accesses, 4 loads in flight per lane)
     if rank == 0:
         alg_sweep = info["alg_bytes_learning"] if learning else info["alg_bytes_inference"]
         # roofline.achieved: the bytes one launch must move in the compiled device layout (tile

@@ -190,7 +190,8 @@ int nsk_selftest_exp(int device, const double *x, double *y, int64_t n);
 int nsk_selftest_philox(int device, uint64_t seed, uint64_t sweep, uint32_t stream, int64_t n,
                         uint32_t *out /* 4*n words, counter c0 = 0..n-1 */);
 
-/* Plain HBM stream-copy of `nbytes` (read + write) with `width`-byte accesses per lane (4 or 16):
+/* Plain HBM stream-copy of `nbytes` (read + write) with `width`-byte accesses per lane (4 or 16;
+ * 64 = four 16-byte non-temporal loads in flight per lane and non-temporal stores, the ceiling):
  * the achievable-bandwidth ceiling bench.py reports beside the sweep, and the calibration
  * workload for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters. */
 int nsk_selftest_stream(int device, int64_t nbytes, int width, int iters, double *gbytes_per_s);

@@ -520,7 +520,9 @@ int nsk_selftest_philox(int device, uint64_t seed, uint64_t sweep, uint32_t stre
 }
 
 int nsk_selftest_stream(int device, int64_t nbytes, int width, int iters, double *gbytes_per_s) {
-    if (nbytes < 4096 || (width != 4 && width != 16) || iters < 1 || !gbytes_per_s) return fail(NSK_E_INVALID, "bad argument");
+    // width 4 / 16: plain grid-stride copy (the counter-calibration workload); width 64: the
+    // bandwidth ceiling -- 4 x 16-byte non-temporal loads in flight per lane, non-temporal stores
+    if (nbytes < 4096 || (width != 4 && width != 16 && width != 64) || iters < 1 || !gbytes_per_s) return fail(NSK_E_INVALID, "bad argument");
     HIPCHECK(hipSetDevice(device));
     nbytes &= ~(int64_t)4095;
     void *a = nullptr, *b = nullptr;
@@ -530,12 +532,13 @@ int nsk_selftest_stream(int device, int64_t nbytes, int width, int iters, double
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
-    const long long n = nbytes / width;
+    const long long n = nbytes / (width == 64 ? 16 : width);
     const int grid = 256 * 8;
     for (int it = -1; it < iters; it++) {
         if (it == 0) HIPCHECK(hipEventRecord(e0, 0));
         if (width == 4) k_stream_copy<uint32_t><<<dim3(grid), dim3(NSK_BLOCK)>>>((const uint32_t *)a, (uint32_t *)b, n);
-        else k_stream_copy<uint4><<<dim3(grid), dim3(NSK_BLOCK)>>>((const uint4 *)a, (uint4 *)b, n);
+        else if (width == 16) k_stream_copy<uint4><<<dim3(grid), dim3(NSK_BLOCK)>>>((const uint4 *)a, (uint4 *)b, n);
+        else k_stream_copy_nt<4><<<dim3(grid * 2), dim3(NSK_BLOCK)>>>((const uint4 *)a, (uint4 *)b, n);
     }
     HIPCHECK(hipEventRecord(e1, 0));
     HIPCHECK(hipEventSynchronize(e1));

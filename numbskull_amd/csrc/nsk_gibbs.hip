@@ -93,8 +93,13 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
 #define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
                                 if (kind == 8) {
-                                    if (nch == 1) k_gibbs_seg_tab<VT, 1><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1);
-                                    else k_gibbs_seg_tab<VT, 2><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1);
+                                    static const int tpw = getenv("NSK_TPW") ? atoi(getenv("NSK_TPW")) : 2;
+                                    const int nbt = (tab.tile_start[tab.n] + 4 * tpw - 1) / (4 * tpw);
+                                    const dim3 gridt(8 * ((nbt + 7) / 8));
+#define NSK_SEGT(NCH, TPW) k_gibbs_seg_tab<VT, NCH, TPW><<<gridt, block, 0, g->stream>>>(d, tab, nbt, burnin, K0, K1, S0, S1)
+                                    if (nch == 1) { if (tpw == 1) NSK_SEGT(1, 1); else if (tpw == 2) NSK_SEGT(1, 2); else NSK_SEGT(1, 4); }
+                                    else { if (tpw == 1) NSK_SEGT(2, 1); else NSK_SEGT(2, 2); }
+#undef NSK_SEGT
                                 }
                                 else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
                                 else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }

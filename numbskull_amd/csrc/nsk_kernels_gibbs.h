@@ -768,43 +768,67 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
 }
 
 // Homogeneous segments whose programs have draw tables: ids, byte gathers, bit pack, one 8-byte
-// table read, integer compare.  No float64 arithmetic.
-template <typename VT, int NCH>
+// table read, integer compare.  No float64 arithmetic.  A wave walks TPW consecutive tiles of the
+// launch at once: all their loads are issued before the first dependent gather, which is what
+// keeps enough bytes in flight per SIMD (one tile per wave: 28.6 us per 10M-grid class at full
+// occupancy, two thirds of the wave-cycles waiting).
+template <typename VT, int NCH, int TPW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int nblocks,
                                                              int burnin, uint32_t k0, uint32_t k1,
                                                              uint32_t s0, uint32_t s1) {
     const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
     if (lb < 0) return;
     const int lane = (int)(threadIdx.x & 63);
-    const int T = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
-    if (T >= tab.tile_start[tab.n]) return;
-    int sidx = 0;
+    const int T0 = __builtin_amdgcn_readfirstlane((lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6)) * TPW);
+    const int ntiles = tab.tile_start[tab.n];
+    if (T0 >= ntiles) return;
+    int p[TPW], v[TPW];
+    uint8_t tally[TPW];
+    uint4 q[TPW][NCH];
+    uint32_t zoff[TPW], zmask[TPW];
+    bool live[TPW];
 #pragma unroll
-    for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
-    const int t = T - tab.tile_start[sidx];
-    const int p = tab.pos0[sidx] + t * 64 + lane;
-    const int v = g.p_vid[p];                             // -1: padding lane at a class end
-    const uint8_t tally = burnin ? (uint8_t)0 : g.cnt_pos[p];
-    const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
-    uint4 q[NCH];
+    for (int k = 0; k < TPW; k++) {
+        const int T = min(T0 + k, ntiles - 1);                // wave-uniform; a clamped tile is not stored
+        live[k] = T0 + k < ntiles;
+        int sidx = 0;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];
-    uint32_t idx = 0;
+        for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+        const int t = T - tab.tile_start[sidx];
+        p[k] = tab.pos0[sidx] + t * 64 + lane;
+        zoff[k] = tab.zoff[sidx]; zmask[k] = tab.zmask[sidx];
+        const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        idx |= ((uint32_t)g.val[q[c].x] & 1u) << (4 * c);
-        idx |= ((uint32_t)g.val[q[c].y] & 1u) << (4 * c + 1);
-        idx |= ((uint32_t)g.val[q[c].z] & 1u) << (4 * c + 2);
-        idx |= ((uint32_t)g.val[q[c].w] & 1u) << (4 * c + 3);
+        for (int c = 0; c < NCH; c++) q[k][c] = sp[c * 64];
+        v[k] = g.p_vid[p[k]];                                 // -1: padding lane at a class end
+        tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[p[k]];
     }
-    idx &= tab.zmask[sidx];
-    const uint2 e = *(const uint2 *)(g.ztab + tab.zoff[sidx] + idx);
-    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-    const unsigned long long K = ((unsigned long long)e.y << 32) | e.x;
-    const int nv = k53(rr.x, rr.y) > K ? 1 : 0;
-    if (v >= 0) {
-        g.val[v] = (VT)nv;
-        if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
+    uint32_t idx[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; k++) {
+        uint32_t x[4 * NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            x[4 * c] = (uint32_t)g.val[q[k][c].x]; x[4 * c + 1] = (uint32_t)g.val[q[k][c].y];
+            x[4 * c + 2] = (uint32_t)g.val[q[k][c].z]; x[4 * c + 3] = (uint32_t)g.val[q[k][c].w];
+        }
+        idx[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (x[j] & 1u) << j;
+        idx[k] &= zmask[k];
+    }
+    uint2 e[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; k++) e[k] = *(const uint2 *)(g.ztab + zoff[k] + idx[k]);
+#pragma unroll
+    for (int k = 0; k < TPW; k++) {
+        const u32x4 rr = philox4x32(k0, k1, (uint32_t)v[k], 0u, s0, s1);
+        const unsigned long long K = ((unsigned long long)e[k].y << 32) | e[k].x;
+        const int nv = k53(rr.x, rr.y) > K ? 1 : 0;
+        if (live[k] && v[k] >= 0) {
+            g.val[v[k]] = (VT)nv;
+            if (!burnin) g.cnt_pos[p[k]] = (uint8_t)(tally[k] + nv);
+        }
     }
 }
 

@@ -22,6 +22,23 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_stream_copy(const T *__restrict__
     for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// achievable-bandwidth ceiling: every lane moves UNR x 16 bytes per trip, all loads issued before
+// the stores, non-temporal both ways (the data is touched once)
+template <int UNR>
+__global__ __launch_bounds__(NSK_BLOCK) void k_stream_copy_nt(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                              long long n) {
+    const long long stride = (long long)gridDim.x * NSK_BLOCK;
+    long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x;
+    for (; i + (UNR - 1) * stride < n; i += UNR * stride) {
+        nsk_u32x4 v[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; k++) v[k] = __builtin_nontemporal_load((const nsk_u32x4 *)(src + i + k * stride));
+#pragma unroll
+        for (int k = 0; k < UNR; k++) __builtin_nontemporal_store(v[k], (nsk_u32x4 *)(dst + i + k * stride));
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
 // ---- boundary exchange ---------------------------------------------------------------------------
 template <typename VT>
 __global__ __launch_bounds__(NSK_BLOCK) void k_exchange_pack(const VT *val, const int32_t *send_vids,
