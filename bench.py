@@ -10,19 +10,25 @@ learning.py:12-125).  The default workload is the one BASELINE.json's metric is 
 factors, one fixed weight 0.1, inference only, inputs resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0): metric = variable-updates/sec over all GPUs, plus
-  roofline     algorithmic bytes per launch (106.9 B/update on the grid) /
-               average launch duration measured with HIP events on the library's stream
+  roofline     bytes one launch must move in the compiled device layout (nsk_compile.cpp "layout
+               bytes") / average launch duration measured with HIP events on the library's
+               stream; the SURVEY.md section 8d CSR-model figure rides along as
+               alg_bytes_per_update_csr
   cpu_baseline the CPU restatement of the reference algorithm (oracle/, Hogwild threads like the
-               reference's run_pool) timed on this node's host cores on a bounded sample.
+               reference's run_pool) timed on this node's host cores on a bounded sample
+  parity       invariants of the state after the timed region (tally bounds, mean marginal) and,
+               with the CPU baseline, the nearest-neighbour agreement statistic of both runs.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the grid is range-partitioned by
-variable id with the reference's shard formula and the owned value slices are all-gathered over
-RCCL after every sweep (numbskull_amd/distributed.py); total work is fixed => "strong" scaling.
+N > 1: one rank per GPU (torch.distributed.run; started by this script as a child process when
+it is not already running under it), the grid range-partitioned by variable id with the
+reference's shard formula, boundary values all-gathered over RCCL after every sweep
+(numbskull_amd/distributed.py); total work is fixed => "strong" scaling.
 """
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -41,10 +47,13 @@ WORKLOADS = {
     # (the shape of feature-weighted DeepDive graphs): exercises the per-lane-weight shape tiles
     "boolw4m": (2000, 2000, False),
     "boolw4m_learn": (2000, 2000, True),
-    # scaled-down BASELINE configs[4]: mixed-arity LR graph (25 % categorical variables, ISTRUE / OR /
-    # IMPLY_MLN / OR_CAT / IMPLY_MLN_CAT / AND_CAT factors, 10^5 weights), inference and learning
+    # BASELINE configs[4]: mixed-arity LR graph (25 % categorical variables, ISTRUE / OR /
+    # IMPLY_MLN / OR_CAT / IMPLY_MLN_CAT / AND_CAT factors), scaled down 10x and at full size
     "lr5m": (2500, 2000, False),
     "lr5m_learn": (2500, 2000, True),
+    "lr50m": (10000, 5000, False),
+    "lr50m_learn": (10000, 5000, True),
+    "ising64k": (256, 256, False),            # plumbing tests
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -60,8 +69,8 @@ def build_graph(rows, cols, learning, seed=20240602, name=None):
             g[1]["isEvidence"] = rng.random(len(g[1])) < 0.5
             g[1]["initialValue"] = rng.integers(0, 2, len(g[1]))
         return g
-    if name in ("lr5m", "lr5m_learn"):
-        return graphgen.mixed_lr_graph(rows * cols, seed=20240603)
+    if name is not None and name.startswith("lr"):
+        return graphgen.mixed_lr_graph(rows * cols, seed=20240603)     # 10^5 weights at 5M, 10^6 at 50M
     if not learning:
         return graphgen.ising_grid(rows, cols, weight=0.1, fixed=True)
     # learning variant: two free weights, every variable evidence;
@@ -72,8 +81,46 @@ def build_graph(rows, cols, learning, seed=20240602, name=None):
     return graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True, evidence=ev)
 
 
-def cpu_baseline(fg, learning, budget_s=20.0):
+def native_oracle():
+    """The CPU baseline is built ON THIS NODE with -O3 -march=native; the
+    portable build in oracle/ (made in the build container, -O2) is the fallback."""
+    from oracle import binding as orc
+    src = os.path.join(REPO, "oracle", "nsk_oracle.c")
+    out_dir = os.path.join(REPO, "oracle", "_native")
+    out = os.path.join(out_dir, "libnsk_oracle_native.so")
+    flags = "-O3 -march=native -ffp-contract=off"
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["gcc"] + flags.split() + ["-fPIC", "-std=c99", "-D_GNU_SOURCE", "-shared",
+                                                         "-o", out, src, "-lm", "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        orc.use_library(out)
+        return flags
+    except Exception:
+        return "-O2 -mfma -ffp-contract=off (portable build; native rebuild failed)"
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def grid_agreement(values, rows, cols):
+    """Fraction of grid edges whose two variables agree (the sufficient statistic of the EQUAL
+    pair model: its expectation is a function of the weight alone)."""
+    x = np.asarray(values).reshape(rows, cols)
+    same = int((x[1:, :] == x[:-1, :]).sum()) + int((x[:, 1:] == x[:, :-1]).sum())
+    return same / float((rows - 1) * cols + rows * (cols - 1))
+
+
+def cpu_baseline(fg, learning, budget_s=20.0, grid=None):
     """Oracle (CPU restatement of the reference algorithm) on this node's cores, bounded sample."""
+    flags = native_oracle()
     from oracle import binding as orc
     og = orc.Graph(fg.weight, fg.variable, fg.factor, fg.fmap, fg.vmap, fg.factor_index)
     nvar = len(fg.variable)
@@ -92,16 +139,46 @@ def cpu_baseline(fg, learning, budget_s=20.0):
         run(extra)
         total_t += time.time() - t0
         total_n += extra
+    agree = grid_agreement(vv, *grid) if grid and not learning else None
+    mean_marg = float(cnt.sum()) / (nvar * total_n) if not learning else None
     # one thread = the reference's own sequential scan (SURVEY.md section 8d asks for T = 1 too)
-    run1 = (lambda n: og.learn_hogwild(1, n, vv, ve, wv, 1e-7, 0.95, 2, 0.01, 1, False, 1)) \
-        if learning else (lambda n: og.gibbs_hogwild(1, n, vv, wv, cnt, 1, True, False))
+    vv1, ve1, wv1, cnt1 = og.initial_state()
+    run1 = (lambda n: og.learn_hogwild(1, n, vv1, ve1, wv1, 1e-7, 0.95, 2, 0.01, 1, False, 1)) \
+        if learning else (lambda n: og.gibbs_hogwild(1, n, vv1, wv1, cnt1, 1, True, False))
     t0 = time.time()
     assert run1(1) == 0
     single = nvar / (time.time() - t0)
     return {"value": nvar * total_n / total_t, "unit": "variable-updates/s", "cores": cores,
-            "kind": "port", "single_thread": single,
-            "sample": "%d sweep(s) of the same %d-variable grid, %d Hogwild threads "
-                      "(reference shard formula), %.1f s" % (total_n, nvar, cores, total_t)}
+            "kind": "port", "single_thread": single, "cflags": flags, "cpu": cpu_model(),
+            "sample": "%d sweep(s) of the same %d-variable graph, %d Hogwild threads "
+                      "(reference shard formula), %.1f s" % (total_n, nvar, cores, total_t),
+            "_agreement": agree, "_mean_marginal": mean_marg, "_sweeps": total_n}
+
+
+def state_checks(fg, info, tallied_sweeps, grid, learning):
+    """Cheap invariants of the device state after the timed region (downloaded once)."""
+    fg._pull(0, 0, values=True, weights=True, count=True)
+    own = fg.own_range if fg.own_range is not None else (0, len(fg.variable))
+    v = fg.var_value[0][own[0]:own[1]]
+    card = fg.variable["cardinality"][own[0]:own[1]]
+    out = {"values_in_domain": bool(((v >= 0) & (v < card)).all())}
+    if not learning:
+        cs = fg.cstart
+        cnt = fg.count[cs[own[0]]:cs[own[1]]]
+        out["tally_min"] = int(cnt.min()) if len(cnt) else 0
+        out["tally_max"] = int(cnt.max()) if len(cnt) else 0
+        out["tallied_sweeps"] = int(tallied_sweeps)
+        out["tally_in_bounds"] = bool(out["tally_min"] >= 0 and out["tally_max"] <= tallied_sweeps)
+        if grid:
+            out["mean_marginal"] = float(cnt.sum()) / max(1, len(cnt) * tallied_sweeps)
+            out["mean_marginal_ok"] = bool(abs(out["mean_marginal"] - 0.5) < 0.01)
+            if fg.own_range is None:
+                out["edge_agreement"] = grid_agreement(fg.var_value[0], *grid)
+    else:
+        w = fg.weight_value[0]
+        out["weights_finite"] = bool(np.isfinite(w).all())
+        out["weights"] = [float(x) for x in w[:4]]
+    return out
 
 
 def side_run(name, seed, steps, warmup):
@@ -137,11 +214,12 @@ def side_run(name, seed, steps, warmup):
     _lib.check(L.nsk_profile_end(h, C.byref(ms), C.byref(nl)))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    checks = state_checks(fg, info, warmup + steps, (rows, cols), learning)
     fg.close()
-    alg = info["layout_bytes_learning" if learning else "layout_bytes_inference"] * steps / (ms.value / 1e3) / 1e9
+    lay = info["layout_bytes_learning" if learning else "layout_bytes_inference"] * steps / (ms.value / 1e3) / 1e9
     return {"value": rows * cols * steps / dt, "unit": "variable-updates/s", "steps": steps,
-            "ms_per_step": dt * 1e3 / steps, "roofline_frac": alg / HBM_PEAK_GBS,
-            "avg_launch_us": ms.value * 1e3 / max(1, nl.value)}
+            "ms_per_step": dt * 1e3 / steps, "roofline_frac": lay / HBM_PEAK_GBS,
+            "avg_launch_us": ms.value * 1e3 / max(1, nl.value), "parity": checks}
 
 
 def dominant_kernel(workload, learning, info):
@@ -152,7 +230,66 @@ def dominant_kernel(workload, learning, info):
         return "k_learn_general" if learning else "k_gibbs_general"
     if workload.startswith("boolw"):
         return "k_learn_fast+k_learn_general" if learning else "k_gibbs_fast+k_gibbs_general"
+    if info["ztab_entries"]:
+        return "k_learn_seg_tab" if learning else "k_gibbs_seg_tab"
     return "k_learn_seg" if learning else "k_gibbs_seg"
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start it as a CHILD process (this
+    parent has not touched the GPU, and a process that has must never exec), relay its output and
+    exit with its code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stdout.write(proc.stdout)
+    sys.exit(proc.returncode)
+
+
+def dry_run(args, dist, rank, world, rows, cols, learning):
+    """NSK_BENCH_DRYRUN=1 (CPU test hook): everything of the N-rank launch that needs no GPU -- the
+    self-spawn, the rendezvous, the shard formula, the host-side plan of every rank's partition and
+    the boundary lists the ranks agree on -- then one JSON line with value 0."""
+    import io
+    from contextlib import redirect_stdout
+    import numbskull_amd
+    from numbskull_amd.distributed import shard_range, plan_boundaries, gather_needs
+    g = build_graph(rows, cols, learning, name=args.workload)
+    ns = numbskull_amd.NumbSkull(quiet=True, seed=args.seed)
+    own = shard_range(rank, world, rows * cols)
+    w, v, f, fm, dm, edges = g
+    with redirect_stdout(io.StringIO()):
+        ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=own if world > 1 else None)
+    fg = ns.factorGraphs[0]
+    color, info = fg.plan()
+    needs = fg.ghost_needs(host_only=True) if world > 1 else np.zeros(0, np.int32)
+    nb = int(len(needs))
+    sampled = int((color >= 0).sum())
+    if world > 1:
+        import torch
+        t = torch.tensor([sampled, nb], dtype=torch.int64)
+        dist.all_reduce(t)
+        sampled, nb = int(t[0]), int(t[1])
+        lists, slot = plan_boundaries(gather_needs(dist, torch, needs, world, "cpu"), world, rows * cols)
+        nb = int(sum(len(x) for x in lists))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "variable-updates/sec", "value": 0.0, "unit": "variable-updates/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "config": {"name": args.workload, "sampled_total": sampled, "boundary_total": nb,
+                                     "colors": info["ncolors"]}}))
 
 
 def main():
@@ -166,6 +303,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20240601)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)           # does not return
+
     import torch
     import numbskull_amd
     from numbskull_amd import _lib
@@ -175,8 +315,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -186,11 +325,17 @@ def main():
         # torch.distributed exchange loop); the driver's runs use neither
         if os.environ.get("NSK_BENCH_ONE_DEVICE"):
             local_rank = 0
-        torch.cuda.set_device(local_rank)
+        if not os.environ.get("NSK_BENCH_DRYRUN"):
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(os.environ.get("NSK_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     rows, cols, learning = WORKLOADS[args.workload]
+    is_grid = args.workload.startswith("ising")
+    if os.environ.get("NSK_BENCH_DRYRUN"):
+        return dry_run(args, dist, rank, world, rows, cols, learning)
+    t_gen = time.time()
     g = build_graph(rows, cols, learning, name=args.workload)
+    t_gen = time.time() - t_gen
     nvar = rows * cols
     ns = numbskull_amd.NumbSkull(quiet=True, device=local_rank, seed=args.seed,
                                  head_by_vid=args.workload.startswith("lr"))
@@ -198,10 +343,12 @@ def main():
     w, v, f, fm, dm, edges = g
     import io
     from contextlib import redirect_stdout
+    t_load = time.time()
     with redirect_stdout(io.StringIO()):
         ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=own if world > 1 else None)
     fg = ns.factorGraphs[0]
     L, h = _lib.lib(), fg._engine()
+    t_load = time.time() - t_load
     info = fg.info()
     sampler = PartitionedSampler(fg, dist, torch, rank, world) if world > 1 else None
     lr = (1e-7, 0.95, 2, 0.01, 1)       # step, decay, L2, reg_param, truncation (config #3)
@@ -240,6 +387,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # invariants of the state the timed sweeps left behind (every rank checks its own shard)
+    checks = state_checks(fg, info, args.warmup + args.steps, (rows, cols) if is_grid else None, learning)
+    ok_local = all(bool(x) for k, x in checks.items() if k.endswith("_ok") or k.endswith("_in_bounds")
+                   or k in ("values_in_domain", "weights_finite"))
+    if world > 1:
+        t = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        checks["all_ranks_ok"] = bool(t.item() > 0.5)
+        ok_local = checks["all_ranks_ok"]
+
     copy_gbs = None
     if rank == 0:
         cg = C.c_double()
@@ -258,18 +415,21 @@ def main():
         lay_per_launch = lay_sweep * args.steps / nlaunch
         launch_s = (ms_ev.value / 1e3) / nlaunch
         achieved = lay_per_launch / launch_s / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tp = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tp) and world == 1:      # PMC bytes were collected for the one-GPU launch
             try:
-                traffic = json.load(open(tp)).get(args.workload)
+                tj = json.load(open(tp))
+                traffic = tj.get(args.workload)
+                traffic_src = "profiles/traffic.json (%s)" % tj.get("_source", "rocprofv3 --pmc passes, not this run")
             except Exception:
                 traffic = None
         out = {
             "metric": "variable-updates/sec", "value": nvar * args.steps / dt,
             "unit": "variable-updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int64" if info["ztab_entries"] and is_grid else "f64",
             "data": "synthetic",
             "config": {"workload": ("%d boolean variables, %d ISTRUE/OR/EQUAL factors with one weight each, "
                                     "inference only, chromatic scan, seed %d" % (nvar, len(f), args.seed))
@@ -282,25 +442,46 @@ def main():
                        % (rows, cols, nvar, len(f), "learning (2 free weights, L2)"
                           if learning else "inference only, weight 0.1 fixed", args.seed),
                        "name": args.workload, "partition": "range by variable id, %d shard(s)" % world,
-                       "colors": info["ncolors"], "value_bytes": info["value_bytes"]},
+                       "colors": info["ncolors"], "value_bytes": info["value_bytes"],
+                       "generate_s": round(t_gen, 2), "load_and_compile_s": round(t_load, 2),
+                       "compile_s": round(info["compile_seconds"], 2),
+                       "device_bytes": info["device_bytes"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "actual_GBs": (traffic / launch_s / 1e9) if traffic else None,
+                         "traffic_source": traffic_src,
+                         "traffic_GBs": (traffic / launch_s / 1e9) if traffic else None,
                          "layout_bytes_per_update": lay_sweep * world / nvar,
                          "alg_bytes_per_update_csr": alg_sweep * world / nvar,
                          "csr_model_GBs": alg_sweep * args.steps / (ms_ev.value / 1e3) / 1e9,
                          "kernel": dominant_kernel(args.workload, learning, info),
                          "stream_copy_GBs": copy_gbs,
+                         "frac_of_stream_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "launches": nlaunch, "avg_launch_us": launch_s * 1e6},
+            "parity": checks,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(fg, learning)
+        if not args.no_cpu_baseline and world == 1 and nvar <= 12_000_000:
+            cb = cpu_baseline(fg, learning, grid=(rows, cols) if is_grid else None)
+            agree, mm = cb.pop("_agreement"), cb.pop("_mean_marginal")
+            cb.pop("_sweeps")
+            out["cpu_baseline"] = cb
+            if agree is not None and "edge_agreement" in checks:
+                # L3 statistic: both samplers target the same distribution,
+                # so the agreement fraction over the 2*10^7 grid edges must coincide (the standard
+                # error of one configuration's fraction is ~1e-4)
+                checks["edge_agreement_cpu"] = agree
+                checks["edge_agreement_diff"] = abs(agree - checks["edge_agreement"])
+                checks["edge_agreement_ok"] = bool(checks["edge_agreement_diff"] < 1e-3)
+                checks["mean_marginal_cpu"] = mm
+                ok_local = ok_local and checks["edge_agreement_ok"]
         if world == 1 and args.workload == "ising10m" and not args.no_extra:
             out["also"] = {"ising1m": side_run("ising1m", args.seed, 1000, 100),
                            "ising10m_learn": side_run("ising10m_learn", args.seed, 100, 10)}
+        checks["ok"] = bool(ok_local)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and not ok_local:
+        sys.exit(3)                  # a fast sweep with a broken state is not a result
 
 
 if __name__ == "__main__":

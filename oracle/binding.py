@@ -37,13 +37,22 @@ def build(force=False):
 
 
 _lib = None
+_override = None
+
+
+def use_library(path):
+    """Load the oracle from another shared object (bench.py builds a -march=native copy on the
+    node it times the CPU baseline on)."""
+    global _lib, _override
+    _override, _lib = path, None
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        if _override is None:
+            build()
+        _lib = C.CDLL(_override or _SO)
         _lib.orc_exp_det.restype = C.c_double
         _lib.orc_exp_det.argtypes = [C.c_double]
         _lib.orc_mt_res53.restype = C.c_double

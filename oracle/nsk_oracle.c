@@ -817,6 +817,14 @@ static int64_t max_list2(const orc_graph *g) {
     return 2 * m + 1;
 }
 
+/* per-thread scratch on cache lines of its own: Z is written at every update, and neighbouring
+ * 16-byte malloc chunks would make the Hogwild threads share lines */
+static void *hog_alloc(size_t bytes) {
+    void *p = NULL;
+    if (posix_memalign(&p, 128, (bytes + 127) / 128 * 128 + 128)) return NULL;
+    return p;
+}
+
 int orc_gibbs_hogwild(const orc_graph *g, int nthreads, int64_t nsweeps, const int64_t *cstart,
                       int64_t *count, int64_t *var_value, const double *weight_value,
                       int sample_evidence, int burnin, uint32_t seed) {
@@ -827,7 +835,7 @@ int orc_gibbs_hogwild(const orc_graph *g, int nthreads, int64_t nsweeps, const i
         args[t].cstart = cstart; args[t].count = count; args[t].var_value = var_value;
         args[t].weight_value = (double *)weight_value;
         args[t].sample_evidence = sample_evidence; args[t].burnin = burnin;
-        args[t].Z = (double *)malloc(sizeof(double) * (size_t)mc);
+        args[t].Z = (double *)hog_alloc(sizeof(double) * (size_t)mc);
         orc_mt_seed_numpy(&args[t].np_rng, seed + (uint32_t)t);
     }
     int rc = hog_run(args, nthreads, nsweeps, 1.0);
@@ -848,8 +856,8 @@ int orc_learn_hogwild(const orc_graph *g, int nthreads, int64_t nsweeps, double 
         args[t].weight_value = weight_value; args[t].learn_non_evidence = learn_non_evidence;
         args[t].regularization = regularization; args[t].step = step;
         args[t].reg_param = reg_param; args[t].truncation = truncation;
-        args[t].Z = (double *)malloc(sizeof(double) * (size_t)mc);
-        args[t].fids = (int64_t *)malloc(sizeof(int64_t) * (size_t)ml);
+        args[t].Z = (double *)hog_alloc(sizeof(double) * (size_t)mc);
+        args[t].fids = (int64_t *)hog_alloc(sizeof(int64_t) * (size_t)ml);
         orc_mt_seed_numpy(&args[t].np_rng, seed + (uint32_t)t);
         orc_mt_seed_python(&args[t].py_rng, (uint64_t)seed + (uint64_t)t);
     }

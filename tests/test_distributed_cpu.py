@@ -176,3 +176,26 @@ def test_plan_colours_every_kind_of_graph():
     # B_inf = 2 + 4 + degree*23 + 1 + 8 (106.9 B/update at degree 3.996)
     assert info["ncolors"] == 2
     assert abs(info["alg_bytes_inference"] / 2000 - (15 + 23 * degree)) < 1e-9
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` outside torch.distributed.run starts the ranks itself as a child
+    process, rendezvous over gloo, plans both partitions and prints ONE JSON line (dry run: the part
+    of the N-rank launch that needs no GPU)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NSK_BENCH_DRYRUN="1", NSK_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--workload", "ising64k",
+                        "--steps", "3", "--warmup", "1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True
+    assert out["config"]["sampled_total"] == 256 * 256
+    assert out["config"]["boundary_total"] == 2 * 256           # one grid row on each side of the cut
