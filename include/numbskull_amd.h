@@ -93,6 +93,12 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
  * sweep of any kind.  Sequential scan seeds MT19937 like np.random.seed(seed); random.seed(seed). */
 int nsk_set_seed(nsk_graph *g, uint64_t seed, uint64_t sweep0);
 int nsk_set_scan(nsk_graph *g, int scan);
+/* Chromatic learning applies sample_and_sgd's update (learning.py:110-125) once per colour class:
+ * a weight visited k times moves by step * (sum of its k gradients).  The reference updates per
+ * visit, which is stable for any k * step; the batch is not, so a weight with k * step > cap uses
+ * step = cap / k in that class (same fixed point).  Default 0.5; cap <= 0 switches clipping off.
+ * nsk_graph_info.learn_clipped counts the clipped updates. */
+int nsk_set_learn_cap(nsk_graph *g, double cap);
 
 /* Replaces run_pool(gibbsthread) at factorgraph.py:141 (burnin=1) and :163 (burnin=0):
  * `nsweeps` epochs of gibbsthread (inference.py:10-33) over the owned variables. */
@@ -115,6 +121,8 @@ typedef struct {
     double layout_bytes_learning;     /*   (tile words, positions, distinct values, stores, tally) */
     int64_t ztab_entries;             /* draw-table entries (0: no tabulated program)              */
     double compile_seconds;           /* host time spent in the graph compiler                     */
+    double learn_cap;                 /* nsk_set_learn_cap                                         */
+    int64_t learn_clipped;            /* weight updates whose step was clipped so far              */
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);

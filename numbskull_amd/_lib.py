@@ -21,7 +21,7 @@ BUF_VALUE, BUF_VALUE_EVID, BUF_WEIGHT, BUF_SEND, BUF_RECV, BUF_SEND_EVID, BUF_RE
 # every symbol include/numbskull_amd.h declares (tests/test_cabi.py checks the export list)
 SYMBOLS = (
     "nsk_graph_create", "nsk_graph_destroy", "nsk_state_upload", "nsk_state_download",
-    "nsk_set_seed", "nsk_set_scan", "nsk_gibbs_sweeps", "nsk_learn_sweeps", "nsk_graph_get_info",
+    "nsk_set_seed", "nsk_set_scan", "nsk_set_learn_cap", "nsk_gibbs_sweeps", "nsk_learn_sweeps", "nsk_graph_get_info",
     "nsk_graph_get_colors", "nsk_graph_plan", "nsk_graph_plan_needs", "nsk_profile_begin", "nsk_profile_end", "nsk_device_buffer",
     "nsk_set_stream", "nsk_synchronize", "nsk_ghost_needs", "nsk_exchange_setup", "nsk_exchange_pack",
     "nsk_exchange_unpack", "nsk_comm_unique_id", "nsk_comm_init", "nsk_gibbs_sweeps_exchange",
@@ -46,7 +46,8 @@ class GraphInfo(C.Structure):
                 ("alg_bytes_inference", C.c_double), ("alg_bytes_learning", C.c_double),
                 ("sweeps_done", C.c_int64), ("layout_bytes_inference", C.c_double),
                 ("layout_bytes_learning", C.c_double), ("ztab_entries", C.c_int64),
-                ("compile_seconds", C.c_double)]
+                ("compile_seconds", C.c_double), ("learn_cap", C.c_double),
+                ("learn_clipped", C.c_int64)]
 
 
 _lib = None
@@ -71,6 +72,7 @@ def lib():
                                        C.c_double, C.c_int64, C.c_int]
         L.nsk_set_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.nsk_set_scan.argtypes = [C.c_void_p, C.c_int]
+        L.nsk_set_learn_cap.argtypes = [C.c_void_p, C.c_double]
         L.nsk_state_upload.argtypes = [C.c_void_p] * 5
         L.nsk_state_download.argtypes = [C.c_void_p] * 5
         L.nsk_graph_create.argtypes = [C.POINTER(GraphDesc), C.POINTER(C.c_void_p)]

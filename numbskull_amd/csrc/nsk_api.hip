@@ -21,6 +21,7 @@
 #include "nsk_device.h"
 
 #include "nsk_internal.h"
+#include "nsk_kernels_learn.h"
 #include "nsk_kernels_misc.h"
 
 using namespace nsk;
@@ -199,15 +200,20 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     }
     g->smallw = c.nweight > 0 && c.nweight <= NSK_SMALLW;
     if (g->smallw) {
-        const size_t cells = (size_t)NSK_LEARN_ROWS * (size_t)c.nweight;
+        const size_t cells = (size_t)NSK_LEARN_BINS * (size_t)c.nweight;     // binned partial sums
         rc = dev_alloc(g, &g->part_G, cells); if (rc) return rc;
         rc = dev_alloc(g, &g->part_K, cells); if (rc) return rc;
         rc = dev_alloc(g, &g->part_T, cells); if (rc) return rc;
+        HIPCHECK(hipMemsetAsync(g->part_G, 0, cells * sizeof(long long), g->stream));
+        HIPCHECK(hipMemsetAsync(g->part_K, 0, cells * sizeof(uint32_t), g->stream));
+        HIPCHECK(hipMemsetAsync(g->part_T, 0, cells * sizeof(uint32_t), g->stream));
     }
     HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (c.npos ? c.npos : 1), g->stream));
     rc = dev_alloc(g, &g->G, (size_t)c.nweight); if (rc) return rc;
     rc = dev_alloc(g, &g->K, (size_t)c.nweight); if (rc) return rc;
     rc = dev_alloc(g, &g->T, (size_t)c.nweight); if (rc) return rc;
+    rc = dev_alloc(g, &g->clip_count, 1); if (rc) return rc;
+    HIPCHECK(hipMemsetAsync(g->clip_count, 0, sizeof(unsigned int), g->stream));
     rc = dev_alloc(g, &g->mt_np, 1); if (rc) return rc;
     rc = dev_alloc(g, &g->mt_py, 1); if (rc) return rc;
     HIPCHECK(hipMemsetAsync(g->cnt, 0, (c.ncount ? c.ncount : 1) * sizeof(int32_t), g->stream));
@@ -245,6 +251,13 @@ int nsk_set_seed(nsk_graph *g, uint64_t seed, uint64_t sweep0) {
     HIPCHECK(hipMemcpyAsync(g->mt_np, &a, sizeof(MTState), hipMemcpyHostToDevice, g->stream));
     HIPCHECK(hipMemcpyAsync(g->mt_py, &b, sizeof(MTState), hipMemcpyHostToDevice, g->stream));
     HIPCHECK(hipStreamSynchronize(g->stream));
+    return NSK_OK;
+}
+
+int nsk_set_learn_cap(nsk_graph *g, double cap) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (cap != cap) return fail(NSK_E_INVALID, "cap is NaN");
+    g->learn_cap = cap;
     return NSK_OK;
 }
 
@@ -416,6 +429,8 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->layout_bytes_learning = c.layout_bytes_learning;
     info->ztab_entries = c.nztab;
     info->compile_seconds = 0;
+    info->learn_cap = 0.5;
+    info->learn_clipped = 0;
 }
 
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
@@ -423,6 +438,13 @@ int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
     fill_info(g->c, info);
     info->device_bytes = g->device_bytes;
     info->sweeps_done = g->sweeps_done;
+    info->learn_cap = g->learn_cap;
+    if (g->clip_count) {
+        unsigned int n = 0;
+        (void)hipSetDevice(g->device);
+        (void)hipStreamSynchronize(g->stream);
+        if (hipMemcpy(&n, g->clip_count, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) info->learn_clipped = (int64_t)n;
+    }
     info->compile_seconds = g->compile_seconds;
     return NSK_OK;
 }

@@ -5,6 +5,7 @@
 #include "nsk_compile.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -65,6 +66,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     }
     c.own_begin = ob; c.own_end = oe;
     const bool head_by_vid = (d->flags & NSK_FLAG_HEAD_BY_VID) != 0;
+    const bool verbose = getenv("NSK_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nsk] compile %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
 
     // ---- variables ---------------------------------------------------------------------------
     c.v_card.resize(nvar); c.v_init.resize(nvar); c.cstart.resize(nvar + 1);
@@ -139,6 +148,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         c.m_rec[2 * l + 1] = (int32_t)std::max<int64_t>(std::min<int64_t>(deo, INT32_MAX), INT32_MIN);
     }
 
+    lap("records");
     // ---- which variables does this handle sample? -------------------------------------------
     std::vector<uint8_t> sampled(nvar, 0);
     for (int64_t v = ob; v < oe; v++) sampled[v] = d->variable[v].isEvidence != 4;   // inference.py:21-23
@@ -228,6 +238,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
         }
     }
+    lap("validate");
     c.logtab.resize((size_t)max_ratio_arity + 2);
     c.logtab[0] = 0.0;
     for (size_t k = 1; k < c.logtab.size(); k++) c.logtab[k] = std::log((double)k);   // math.log, inference.py:222
@@ -272,6 +283,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         });
         c.color[v] = pick(v);
     }
+    lap("greedy colouring");
     // the greedy pass assumes reads are symmetric (true for compute_var_map output); verify, and
     // repair with explicit reverse-read lists when a raw index is asymmetric
     bool conflict = false;
@@ -307,6 +319,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
     }
 
+    lap("symmetry check");
     // fewer classes: iterated greedy (Culberson) -- recolour first fit with the vertices taken class
     // by class in a permuted class order; a class stays independent, so the count never grows, and
     // a few passes typically drop one or two classes (LR graph: 9 -> 7).  Every class costs a
@@ -349,6 +362,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) load[c.color[v]]++;
     }
 
+    lap("iterated greedy");
     // balancing: first fit leaves a few huge classes and a tail of tiny ones, and every class costs
     // a kernel's latency floor however few variables it holds.  Move variables, in id order, from
     // their class to the least populated class none of their neighbours is in (reads are symmetric
@@ -368,6 +382,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
     }
 
+    lap("balancing");
     // ---- ghosts: variables outside the owned range read by a sampled variable -------------------
     if (ob > 0 || oe < nvar) {
         std::vector<uint8_t> need(nvar, 0);
@@ -376,6 +391,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int64_t v = 0; v < nvar; v++) if (need[v]) c.ghost_needs.push_back((int32_t)v);
     }
 
+    lap("ghosts");
     // ---- fast-path eligibility (DESIGN.md "fast path"): a binary dataType-0 variable whose every
     // factor is a symmetric boolean function it is a member of, with <= 6 other members and a
     // weight id below 2^24; and featureValue == 1 so that learning can use the same stream.
@@ -403,6 +419,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         fast[v] = ok;
     }
 
+    lap("fast eligibility");
     // ---- general tiles (kind 6): variables of cardinality <= 8 and any dataType whose factors are
     // boolean symmetric functions, IMPLY_MLN or the categorical *_CAT functions.  Stream words per
     // entry: W0 = weight id; W1 = code | others << 4 | own role << 7 (1 body, 2 head of a positional
@@ -488,6 +505,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     for (int64_t v = 0; v < nvar; v++)
         if (c.color[v] >= 0 && !fast[v] && !no_fast && !no_general && general_words(v, nullptr)) fast[v] = 2;
 
+    lap("general eligibility");
     // ---- positions: colour-major.  Inside a colour: the fast variables grouped by "shape class"
     // -- the sequence of (function, member count, weight id) of their factor lists plus their
     // evidence flag -- so that the 64 lanes of a tile share one slot program; every class with at
@@ -705,6 +723,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             c.nsampled++;
         }
     }
+    lap("positions");
     // ---- inlined adjacency streams of the fast variables, one column-major tile per 64 positions
     c.phase_wb_base.assign((size_t)ncolors + 1, 0);
     for (int32_t k = 0; k < ncolors; k++)
@@ -879,6 +898,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
             }
         }
+        lap("tile shapes (pass 1)");
         c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
         c.phase_gen_bin_tile.assign((size_t)ncolors, 0);
         for (int32_t k = 0; k < ncolors; k++) {
@@ -971,6 +991,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
                         t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
                         t.zmask[t.n] = (1u << sg.nslots) - 1u;
+                        t.ev[t.n] = sg.ev;
                         t.tile_start[t.n + 1] = t.tile_start[t.n] + sg.ntiles;
                         if (++t.n == 8) { tabs.push_back(t); t.n = 0; t.tile_start[0] = 0; }
                     }
@@ -1025,6 +1046,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         (long long)(c.phase_heavy_end[k] - c.phase_fast_end[k]));
             }
         }
+        lap("segments");
         // pass 2: fill the tiles.  Padding: member slots read variable 0 (harmless) in uniform
         // tiles, 0xFFFFFFFF in tiles with per-lane headers.
         c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);
@@ -1075,6 +1097,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
         }
     }
+    lap("tile fill (pass 2)");
     int64_t nslot = 0, nlist = 0;
     for (int64_t p = 0; p < c.npos; p++) {
         if (c.p_vid[p] < 0) continue;
@@ -1139,6 +1162,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     }
     c.slot_off[si] = (int32_t)li;
 
+    lap("slots + CSR bytes");
     // ---- inline generic stream: for the positions handled by the one-lane generic kernels, every
     // factor record of every slot copied in list order, members included, so that a lane reads its
     // update sequentially instead of chasing fidx -> factor -> fmap through three arrays
@@ -1198,6 +1222,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 }
             }
     }
+    lap("generic stream");
     // integer gradients?  (p1 - p0) * featureValue is an integer of magnitude <= 2 when featureValue
     // is -1, 0 or 1 and no function returns counts or logarithms; visits per weight and class are
     // bounded by the weight's member edges
@@ -1216,6 +1241,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     }
     c.alg_bytes_inference = bytes_inf;
     c.alg_bytes_learning = bytes_learn;
+    lap("packed-gradient check");
     // ---- layout bytes: what one sweep must move in the compiled layout.  Tile words (padding
     // included), position arrays, the distinct neighbour values a colour class reads, the stores and
     // the tally read-modify-write; materialised weight rows / gathered weights when the table
@@ -1251,6 +1277,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         c.layout_bytes_inference = lay_inf;
         c.layout_bytes_learning = lay_learn;
     }
+    lap("layout bytes");
     return NSK_OK;
 }
 

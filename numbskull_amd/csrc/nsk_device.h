@@ -181,8 +181,8 @@ struct DevGraph {
     long long *G;               // fixed-point gradient sum
     uint32_t *K;                // visits
     uint32_t *T;                // truncating visits (L1)
-    // learning accumulators, row-of-partials flavour (graphs with <= NSK_SMALLW weights)
-    long long *part_G;          // [rows][nweight]
+    // learning accumulators, binned flavour (graphs with <= NSK_SMALLW weights)
+    long long *part_G;          // [NSK_LEARN_BINS][nweight]
     uint32_t *part_K, *part_T;
     int32_t nweight;
     int32_t packed_grad;        // integer gradients: visit counts ride in the low half of G (GradSink)

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -58,7 +59,9 @@ struct nsk_graph {
     bool chain_regular[2] = {true, true};   // ... per chain (var_value, var_value_evid)
     double compile_seconds = 0;
     uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr, *learn_rest_tiles = nullptr;
-    long long *part_G = nullptr;       // SMALLW: rows of per-block partial sums
+    double learn_cap = 0.5;            // per-class cap on visits * step of one weight (nsk_set_learn_cap)
+    unsigned int *clip_count = nullptr;   // weight updates whose step was clipped (device counter)
+    long long *part_G = nullptr;       // SMALLW: NSK_LEARN_BINS bins of partial sums per weight
     uint32_t *part_K = nullptr, *part_T = nullptr;
     bool smallw = false;
     bool weights_dirty = true;      // prog_w must be rebuilt before the next fast-path launch
@@ -137,6 +140,19 @@ struct ColourStreams {
 
 // the fast path reads weights through prog_w (and the draw tables): rebuilt whenever weights may
 // have changed (nsk_api.hip)
+// Grid of a table-driven learning segment launch: one trip per wave (two tiles at once) unless the
+// block's flush of its LDS sums (a few atomics per weight) would rival its tile traffic
+static inline int nsk_learn_tab_grid(int ntiles, int nweight, bool smallw) {
+    const int blocks = (ntiles + 7) / 8;                            // 4 waves x 2 tiles
+    const int trips = smallw ? std::max(1, (nweight * 16 * 16 + 14847) / 14848) : 1;
+    return std::max(1, (blocks + trips - 1) / trips);
+}
+static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {
+    const int ntiles = sl.tile_start[sl.n];
+    if (sl.tab && use_tab) return nsk_learn_tab_grid(ntiles, nweight, smallw);
+    return std::min(NSK_LEARN_SEG_BLOCKS, (ntiles + 3) / 4);
+}
+
 void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);
 void nsk_refresh_ztab(nsk_graph *g);
 int nsk_fold_position_tally(nsk_graph *g);

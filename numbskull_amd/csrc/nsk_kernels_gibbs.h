@@ -15,15 +15,13 @@ namespace nsk {
 #ifndef NSK_GENERIC_LEARN_WAVES
 #define NSK_GENERIC_LEARN_WAVES 6
 #endif
-// persistent grids of the learning kernels (rows of the SMALLW partial-sum tables)
+// persistent grids of the learning kernels
 #define NSK_LEARN_FAST_BLOCKS 2048
 #define NSK_LEARN_LIST_BLOCKS 512
 #define NSK_LEARN_GEN_BLOCKS 2048
 #define NSK_LEARN_HEAVY_BLOCKS 512
 #define NSK_LEARN_GENERAL_BLOCKS 2048
 #define NSK_LEARN_SEG_BLOCKS 2048      // per segment launch, at most 4 launches per colour (nsk_compile.h)
-#define NSK_LEARN_ROWS (NSK_LEARN_FAST_BLOCKS + NSK_LEARN_LIST_BLOCKS + NSK_LEARN_GEN_BLOCKS + NSK_LEARN_HEAVY_BLOCKS + \
-                        NSK_LEARN_GENERAL_BLOCKS + 4 * NSK_LEARN_SEG_BLOCKS)
 
 // One colour class of one inference sweep: lane <-> variable at position pbegin + global lane id.
 // gibbsthread's loop body (inference.py:20-33) for that variable.
@@ -700,6 +698,7 @@ struct SegTable {
     uint32_t prog[NSK_SEG_MAX];           // slot program
     uint32_t zoff[NSK_SEG_MAX];           // draw-table launches: first entry of the program's table,
     uint32_t zmask[NSK_SEG_MAX];          //   (1 << member slots) - 1
+    int ev[NSK_SEG_MAX];                  // the segment's common isEvidence (learning launches)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -722,17 +721,15 @@ __device__ __forceinline__ int draw_from_z(double z0, double z1, unsigned long l
     return (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
 }
 
-static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_ztab(const ZProgDev *zp, const uint32_t *tile_hdr,
-                                                            const double *prog_w, uint4 *ztab) {
-    const ZProgDev z = zp[blockIdx.x];
-    const uint32_t idx = threadIdx.x;
-    if (idx >= (1u << z.nslots)) return;
-    const uint32_t *pp = tile_hdr + z.prog;
-    const double *tw = prog_w + 2 * (size_t)z.prog;
+// One table entry: the program's slot algebra for neighbourhood `idx` with the per-slot terms
+// delivered by term(j, thi, tlo); K by a galloping search around z0 / z1 * 2^53 (every probe is
+// the real decision function, so the result is exact however poor the guess).
+template <typename TERM>
+__device__ __forceinline__ uint4 ztab_entry(const uint32_t *pp, uint32_t nslots, uint32_t idx, TERM &&term) {
     double p0 = 0.0, p1 = 0.0;
     uint32_t sat0 = 0, sat1 = 0;
     SlotState st = {0, true, false, true};
-    for (uint32_t j = 0; j < z.nslots; j++) {
+    for (uint32_t j = 0; j < nslots; j++) {
         const uint32_t s = pp[j];
         const int x = (int)((idx >> j) & 1u);
         const bool F = (s >> 27) & 1u, ig = (s >> 29) & 1u;          // slot_step / slot_sat, spelled out
@@ -745,7 +742,8 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_ztab(const ZProgDe
         const bool isEq = code == 4u, isAnd = code == 3u || code == 1u, isOr = code == 2u;
         const bool b0 = (isEq && st.alleq && (ig || st.first == 0)) || (isOr && st.any1);
         const bool b1 = (isEq && st.alleq && (ig || st.first == 1)) || (isAnd && st.allnz) || isOr;
-        const double thi = tw[2 * j], tlo = tw[2 * j + 1];
+        double thi, tlo;
+        term(j, s, thi, tlo);
         p0 = p0 + (b0 ? thi : tlo);
         p1 = p1 + (b1 ? thi : tlo);
         sat0 |= (b0 ? 1u : 0u) << j;
@@ -753,13 +751,41 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_ztab(const ZProgDe
     }
     const double z0 = nsk_exp(p0);
     const double z1 = z0 + nsk_exp(p1);
-    unsigned long long lo = 0, hi = (1ull << 53) - 1;           // draw(0) == 0 always (z = +0 or NaN)
-    if (draw_from_z(z0, z1, hi) == 0) lo = hi;
-    while (hi - lo > 1) {
+    const unsigned long long top = (1ull << 53) - 1;
+    // invariant: draw(lo) == 0 (draw(0) == 0 always: z = +0 or NaN), draw(hi) == 1 or hi == top + 1
+    unsigned long long lo = 0, hi = top + 1;
+    const double guess = (z0 / z1) * 9007199254740992.0;
+    unsigned long long kg = (guess >= 0.0 && guess < 9007199254740992.0) ? (unsigned long long)guess : 0ull;
+    if (kg > top) kg = top;
+    if (draw_from_z(z0, z1, kg) == 0) {
+        lo = kg;
+        for (unsigned long long stp = 1; lo + stp <= top; stp <<= 1) {        // gallop up
+            if (draw_from_z(z0, z1, lo + stp) == 0) lo += stp; else { hi = lo + stp; break; }
+        }
+        if (hi == top + 1) { if (draw_from_z(z0, z1, top) == 0) lo = top; else hi = top; }
+    } else {
+        hi = kg;
+        for (unsigned long long stp = 1; ; stp <<= 1) {                        // gallop down
+            const unsigned long long probe = hi > stp ? hi - stp : 0ull;
+            if (draw_from_z(z0, z1, probe) == 0) { lo = probe; break; }
+            hi = probe;
+        }
+    }
+    while (lo < top && hi - lo > 1) {
         const unsigned long long mid = lo + ((hi - lo) >> 1);
         if (draw_from_z(z0, z1, mid) == 0) lo = mid; else hi = mid;
     }
-    ztab[z.off + idx] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), sat0 | (sat1 << 8), 0u};
+    return uint4{(uint32_t)lo, (uint32_t)(lo >> 32), sat0 | (sat1 << 8), 0u};
+}
+
+static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_ztab(const ZProgDev *zp, const uint32_t *tile_hdr,
+                                                            const double *prog_w, uint4 *ztab) {
+    const ZProgDev z = zp[blockIdx.x];
+    const uint32_t idx = threadIdx.x;
+    if (idx >= (1u << z.nslots)) return;
+    const double *tw = prog_w + 2 * (size_t)z.prog;
+    ztab[z.off + idx] = ztab_entry(tile_hdr + z.prog, z.nslots, idx,
+                                   [&](uint32_t j, uint32_t, double &thi, double &tlo) { thi = tw[2 * j]; tlo = tw[2 * j + 1]; });
 }
 
 // the generator's 53-bit integer: u53(a, b) == k * 2^-53 exactly

@@ -37,15 +37,22 @@ __device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem)
     return sk;
 }
 
+// SMALLW: a block's LDS sums go to one of NSK_LEARN_BINS bins per weight with plain global atomics
+// (integer sums: order-free); k_apply_bins adds the bins up.  Spreading the blocks over the bins
+// keeps the same-address atomic chains short (a few hundred per bin, hidden behind the launch),
+// and there is no per-block row to budget for.
+#define NSK_LEARN_BINS 64
 template <bool SMALLW, typename VT>
-__device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink &sk, int row) {
+__device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink &sk, int) {
     if (!SMALLW) return;
     __syncthreads();
     const int nw = g.nweight;
+    const size_t bin = (size_t)(blockIdx.x & (NSK_LEARN_BINS - 1)) * (size_t)nw;
     for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) {
-        g.part_G[(size_t)row * nw + i] = sk.G[i];
-        g.part_K[(size_t)row * nw + i] = sk.K[i];
-        g.part_T[(size_t)row * nw + i] = sk.T[i];
+        if (sk.K[i] == 0) continue;
+        atomicAdd((unsigned long long *)&g.part_G[bin + i], (unsigned long long)sk.G[i]);
+        atomicAdd(&g.part_K[bin + i], sk.K[i]);
+        if (sk.T[i]) atomicAdd(&g.part_T[bin + i], sk.T[i]);
     }
 }
 
@@ -556,8 +563,11 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
 
 // The same over segments whose programs have draw tables (k_refresh_ztab): both chains' draws are
 // integer compares against the tabulated thresholds, the per-slot satisfied bits come from the same
-// table entries.  learn_tile's gradient bookkeeping, no float64 arithmetic.
-template <typename VT, bool SMALLW, int NCH>
+// table entries.  learn_tile's gradient bookkeeping, no float64 arithmetic.  A wave walks TPW
+// consecutive tiles at once (all their loads in flight before the first dependent gather); the grid
+// is sized by the host so that a wave makes one trip when the partial-sum rows are cheap (few
+// weights) and several when a block's row flush would rival its tile traffic.
+template <typename VT, bool SMALLW, int NCH, int TPW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, SegTable tab, LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GradSink sk = open_sink<SMALLW>(g, smem);
@@ -565,71 +575,89 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
     const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
     const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
     const int ntiles = tab.tile_start[tab.n];
-    const int per = (ntiles + nwaves - 1) / nwaves;
-    const int t1 = min(ntiles, (wave0 + 1) * per);
-    for (int T = wave0 * per; T < t1; T++) {
-        int sidx = 0;
+    for (int T0 = wave0 * TPW; T0 < ntiles; T0 += nwaves * TPW) {
+        int p[TPW], v[TPW], ev[TPW], init[TPW];
+        bool valid[TPW];
+        uint4 q[TPW][NCH];
+        uint32_t zoff[TPW], zmask[TPW], prog[TPW];
 #pragma unroll
-        for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
-        const int t = T - tab.tile_start[sidx];
-        const int p = tab.pos0[sidx] + t * 64 + lane;
-        const int v0 = g.p_vid[p];                           // -1: padding lane at a class end
-        const bool valid = v0 >= 0;
-        const int v = valid ? v0 : 0;
-        const int ev = valid ? NSK_INFO_EV(g.p_info[p]) : 0;
-        const int init = valid ? (int)g.p_init[p] : 0;
-        const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
-        const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + tab.prog[sidx]);
-        uint4 q[NCH];
+        for (int k = 0; k < TPW; k++) {
+            const bool live = T0 + k < ntiles;                       // wave-uniform
+            const int T = min(T0 + k, ntiles - 1);
+            int sidx = 0;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) q[c] = sp[c * 64];
-        uint32_t idf = 0, ide = 0;
+            for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+            const int t = T - tab.tile_start[sidx];
+            p[k] = tab.pos0[sidx] + t * 64 + lane;
+            zoff[k] = tab.zoff[sidx]; zmask[k] = tab.zmask[sidx]; prog[k] = tab.prog[sidx];
+            const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const uint32_t wd[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+            for (int c = 0; c < NCH; c++) q[k][c] = sp[c * 64];
+            const int v0 = g.p_vid[p[k]];                            // -1: padding lane at a class end
+            valid[k] = live && v0 >= 0;
+            v[k] = v0 >= 0 ? v0 : 0;
+            ev[k] = tab.ev[sidx];                                    // uniform over a segment
+            init[k] = ev[k] == 1 ? (int)g.p_init[p[k]] : 0;
+        }
+        uint32_t idf[TPW], ide[TPW];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                idf |= ((uint32_t)g.val[wd[i]] & 1u) << (4 * c + i);
-                ide |= ((uint32_t)g.val_evid[wd[i]] & 1u) << (4 * c + i);
+        for (int k = 0; k < TPW; k++) {
+            uint32_t xf[4 * NCH], xe[4 * NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint32_t wd[4] = {q[k][c].x, q[k][c].y, q[k][c].z, q[k][c].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    xf[4 * c + i] = (uint32_t)g.val[wd[i]];
+                    xe[4 * c + i] = (uint32_t)g.val_evid[wd[i]];
+                }
             }
-        }
-        idf &= tab.zmask[sidx];
-        ide &= tab.zmask[sidx];
-        const uint4 ef = g.ztab[tab.zoff[sidx] + idf];
-        const uint4 ee = g.ztab[tab.zoff[sidx] + ide];
-        const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
-        int evidence = init;                                                  // learning.py:61-62
-        if (ev != 1) evidence = k53(r.z, r.w) > (((unsigned long long)ee.y << 32) | ee.x) ? 1 : 0;   // 54-58
-        const int proposal = k53(r.x, r.y) > (((unsigned long long)ef.y << 32) | ef.x) ? 1 : 0;     // 66-70
-        if (valid) {
-            g.val_evid[v] = (VT)evidence;
-            g.val[v] = (VT)proposal;
-        }
-        const bool part = valid && (lp.learn_non_evidence || ev == 1);        // 71-72
-        bool truncate = false;
-        if (lp.regularization == 1) {                                         // 90
-            const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
-            truncate = part && (u53(tt.x, tt.y) < lp.inv_trunc);
-        }
-        const unsigned long long pm = __ballot(part);
-        if (pm == 0) continue;
-        const uint32_t satf = proposal ? (ef.z >> 8) : ef.z, sate = evidence ? (ee.z >> 8) : ee.z;
-        const uint32_t nk = (uint32_t)__popcll(pm), nt = (uint32_t)__popcll(__ballot(truncate));
+            idf[k] = 0; ide[k] = 0;
 #pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) {
-            const uint32_t s = pp[j];
-            const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
-            if (closes && !fixed) {
-                const uint32_t code = (s >> 24) & 7u;
-                const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
-                const int nf = __popcll(__ballot(part && ((satf >> j) & 1u)));
-                const int ne = __popcll(__ballot(part && ((sate >> j) & 1u)));
-                if (lane == 0) {
-                    const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
-                    const int wid = (int)(s & 0xFFFFFFu);
-                    atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
-                    if (!sk.packed) atomicAdd(&sk.K[wid], nk);
-                    if (nt) atomicAdd(&sk.T[wid], nt);
+            for (int j = 0; j < 4 * NCH; j++) { idf[k] |= (xf[j] & 1u) << j; ide[k] |= (xe[j] & 1u) << j; }
+            idf[k] &= zmask[k];
+            ide[k] &= zmask[k];
+        }
+        uint4 ef[TPW], ee[TPW];
+#pragma unroll
+        for (int k = 0; k < TPW; k++) { ef[k] = g.ztab[zoff[k] + idf[k]]; ee[k] = g.ztab[zoff[k] + ide[k]]; }
+#pragma unroll
+        for (int k = 0; k < TPW; k++) {
+            const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog[k]);
+            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v[k], 0u, lp.s0, lp.s1);
+            int evidence = init[k];                                               // learning.py:61-62
+            if (ev[k] != 1) evidence = k53(r.z, r.w) > (((unsigned long long)ee[k].y << 32) | ee[k].x) ? 1 : 0;   // 54-58
+            const int proposal = k53(r.x, r.y) > (((unsigned long long)ef[k].y << 32) | ef[k].x) ? 1 : 0;         // 66-70
+            if (valid[k]) {
+                g.val_evid[v[k]] = (VT)evidence;
+                g.val[v[k]] = (VT)proposal;
+            }
+            const bool part = valid[k] && (lp.learn_non_evidence || ev[k] == 1);  // 71-72
+            bool truncate = false;
+            if (lp.regularization == 1) {                                         // 90
+                const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)v[k], 1u, lp.s0, lp.s1);
+                truncate = part && (u53(tt.x, tt.y) < lp.inv_trunc);
+            }
+            const unsigned long long pm = __ballot(part);
+            if (pm == 0) continue;
+            const uint32_t satf = proposal ? (ef[k].z >> 8) : ef[k].z, sate = evidence ? (ee[k].z >> 8) : ee[k].z;
+            const uint32_t nk = (uint32_t)__popcll(pm), nt = (uint32_t)__popcll(__ballot(truncate));
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) {
+                const uint32_t s = pp[j];
+                const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
+                if (closes && !fixed) {
+                    const uint32_t code = (s >> 24) & 7u;
+                    const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
+                    const int nf = __popcll(__ballot(part && ((satf >> j) & 1u)));
+                    const int ne = __popcll(__ballot(part && ((sate >> j) & 1u)));
+                    if (lane == 0) {
+                        const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
+                        const int wid = (int)(s & 0xFFFFFFu);
+                        atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
+                        if (!sk.packed) atomicAdd(&sk.K[wid], nk);
+                        if (nt) atomicAdd(&sk.T[wid], nt);
+                    }
                 }
             }
         }
@@ -691,9 +719,18 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
 
 // The weight update of learning.py:110-125 applied to a whole colour class at once
 // (DESIGN.md "device-mode learning" gives the closed forms; the oracle restates them).
+// cap: a weight visited k times in the class would move by k * step * (mean gradient); when
+// k * step exceeds `cap` the class uses step = cap / k for that weight (DESIGN.md "device-mode
+// learning": the per-visit rule of the reference has the same fixed point and is stable at any
+// k * step because every visit sees the weight the previous one left).  cap <= 0: no clipping.
 __device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
-                                               int regularization, double reg_param, double truncation) {
+                                               int regularization, double reg_param, double truncation,
+                                               double cap, unsigned int *clipped) {
     const double Gf = (double)G * (1.0 / 4294967296.0);
+    if (cap > 0.0 && (double)k * step > cap) {
+        step = cap / (double)k;
+        if (clipped) atomicAdd(clipped, 1u);
+    }
     if (regularization == 2) {
         const double a = 1.0 / (1.0 + reg_param * step);
         x = powi_det(a, (unsigned long long)k) * x;
@@ -713,7 +750,8 @@ __device__ __forceinline__ double apply_update(double x, long long G, uint32_t k
 static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
                                                              uint32_t *T, int nweight, double step,
                                                              int regularization, double reg_param,
-                                                             double truncation, int packed) {
+                                                             double truncation, int packed, double cap,
+                                                             unsigned int *clipped) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= nweight) return;
     long long gsum = G[i];
@@ -726,53 +764,66 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, l
     }
     if (k == 0) return;                 // untouched in this class (packed: one 8-byte read)
     const uint32_t t = regularization == 1 ? T[i] : 0u;     // only L1 ever counts truncations
-    w[i] = apply_update(w[i], gsum, k, t, step, regularization, reg_param, truncation);
+    w[i] = apply_update(w[i], gsum, k, t, step, regularization, reg_param, truncation, cap, clipped);
     G[i] = 0;
     if (!packed) K[i] = 0;
     if (regularization == 1) T[i] = 0;
 }
 
-// SMALLW flavour: one block per weight adds up the per-block rows, applies the update and rewrites
-// the prog_w entries of the slot programs that use this weight (so no separate refresh launch).
-static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights_rows(double *w, const long long *part_G,
-                                                                  const uint32_t *part_K, const uint32_t *part_T,
-                                                                  int nrows, int nweight, double step,
-                                                                  int regularization, double reg_param,
-                                                                  double truncation, const uint32_t *prog,
-                                                                  double *prog_w, int nprog) {
-    __shared__ long long red[3][NSK_BLOCK / 64];
-    __shared__ double wnew;
-    const int i = (int)blockIdx.x, tid = (int)threadIdx.x;
-    long long G = 0, K = 0, T = 0;
-    for (int r = tid; r < nrows; r += NSK_BLOCK) {
-        G += part_G[(size_t)r * nweight + i];
-        K += (long long)part_K[(size_t)r * nweight + i];
-        T += (long long)part_T[(size_t)r * nweight + i];
-    }
-    G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = G; red[1][tid >> 6] = K; red[2][tid >> 6] = T; }
-    __syncthreads();
-    if (tid == 0) {
-        G = 0; K = 0; T = 0;
-        for (int k = 0; k < NSK_BLOCK / 64; k++) { G += red[0][k]; K += red[1][k]; T += red[2][k]; }
-        double x = w[i];
-        if (K > 0) {
-            x = apply_update(x, G, (uint32_t)K, (uint32_t)T, step, regularization, reg_param, truncation);
-            w[i] = x;
+// SMALLW: one block adds up the bins of every weight (and clears them), applies the update,
+// rewrites prog_w and rebuilds the draw tables from the new weights (the same products prog_w
+// holds) -- one small launch per colour class.
+static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_bins(
+        double *w, long long *part_G, uint32_t *part_K, uint32_t *part_T, int nweight, double step,
+        int regularization, double reg_param, double truncation, const uint32_t *prog, double *prog_w,
+        int nprog, const ZProgDev *zp, int nzp, int nztab, uint4 *ztab, double cap, unsigned int *clipped) {
+    __shared__ double sw[NSK_SMALLW];
+    static_assert(NSK_LEARN_BINS == 64, "one bin per lane");
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    // wave k sums weights k, k + 4, ...: lane b reads (and clears) bin b, the wave adds the lanes up
+    for (int i = tid >> 6; i < nweight; i += NSK_BLOCK / 64) {
+        const size_t at = (size_t)lane * nweight + i;
+        long long G = part_G[at];
+        long long K = (long long)part_K[at], T = (long long)part_T[at];
+        if (K) { part_G[at] = 0; part_K[at] = 0; part_T[at] = 0; }
+        G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
+        if (lane == 0) {
+            double x = w[i];
+            if (K > 0) {
+                x = apply_update(x, G, (uint32_t)K, (uint32_t)T, step, regularization, reg_param, truncation, cap, clipped);
+                w[i] = x;
+            }
+            sw[i] = x;
         }
-        wnew = x;
     }
     __syncthreads();
-    const double x = wnew;
     for (int j = tid; j < nprog; j += NSK_BLOCK) {
         const uint32_t s = prog[j];
-        if ((s >> 31) || (int)(s & 0xFFFFFFu) != i) continue;
-        const uint32_t code = (s >> 24) & 7u;
+        if (s >> 31) continue;
+        const uint32_t code = (s >> 24) & 7u, wid = s & 0xFFFFFFu;
+        if ((int)wid >= nweight) continue;
         const bool last = (s >> 28) & 1u;
         const double hi = code == 0u ? 0.0 : 1.0;
         const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+        const double x = sw[wid];
         prog_w[2 * j] = last ? x * hi : 0.0;
         prog_w[2 * j + 1] = last ? x * lo : 0.0;
+    }
+    // all table entries of all programs, flattened over the threads
+    for (int e = tid; e < nztab; e += NSK_BLOCK) {
+        int z = 0;
+        while (z + 1 < nzp && (uint32_t)e >= zp[z + 1].off) z++;
+        const ZProgDev zz = zp[z];
+        ztab[e] = ztab_entry(prog + zz.prog, zz.nslots, (uint32_t)e - zz.off,
+                             [&](uint32_t, uint32_t s, double &thi, double &tlo) {
+                                 const uint32_t code = (s >> 24) & 7u;
+                                 const bool last = (s >> 28) & 1u;
+                                 const double hi = code == 0u ? 0.0 : 1.0;
+                                 const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+                                 const double x = sw[s & 0xFFFFFFu];
+                                 thi = last ? x * hi : 0.0;
+                                 tlo = last ? x * lo : 0.0;
+                             });
     }
 }
 

@@ -94,14 +94,14 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 for (int i = 0; i <= NSK_SEG_MAX; i++) tab.tile_start[i] = sl.tile_start[i];
                 for (int i = 0; i < NSK_SEG_MAX; i++) {
                     tab.pos0[i] = sl.pos0[i]; tab.adj_off[i] = sl.adj_off[i]; tab.prog[i] = sl.prog[i];
-                    tab.zoff[i] = sl.zoff[i]; tab.zmask[i] = sl.zmask[i];
+                    tab.zoff[i] = sl.zoff[i]; tab.zmask[i] = sl.zmask[i]; tab.ev[i] = sl.ev[i];
                 }
-                const int grid = std::min(NSK_LEARN_SEG_BLOCKS, (tab.tile_start[tab.n] + 3) / 4);
+                const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
                 lp.row_base = rows;
 #define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
                 if (sl.tab && g->values_regular) {
-                    if (sl.nch == 1) k_learn_seg_tab<VT, SMALLW, 1><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp);
-                    else k_learn_seg_tab<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp);
+                    if (sl.nch == 1) k_learn_seg_tab<VT, SMALLW, 1, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp);
+                    else k_learn_seg_tab<VT, SMALLW, 2, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp);
                 }
                 else if (sl.kind == 4) { if (sl.nch == 1) NSK_LSEG(4, 1); else NSK_LSEG(4, 2); }
                 else if (sl.kind == 2) { if (sl.nch == 1) NSK_LSEG(2, 1); else NSK_LSEG(2, 2); }
@@ -129,19 +129,20 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 g->launches++;
             }
             cs.join();
-            if (SMALLW && rows > NSK_LEARN_ROWS)             // cannot happen with the grid caps above
-                return fail(NSK_E_RANGE, "partial-sum rows exceeded");
             if (nw > 0) {
                 if (SMALLW) {
-                    k_apply_weights_rows<<<dim3(nw), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        g->w, g->part_G, g->part_K, g->part_T, rows, nw, step, regularization, reg_param,
+                    const bool tabs_here = g->c.nfast > 0 && g->c.nztab <= 2048;
+                    k_apply_bins<<<dim3(1), dim3(NSK_BLOCK), 0, g->stream>>>(
+                        g->w, g->part_G, g->part_K, g->part_T, nw, step, regularization, reg_param,
                         (double)truncation, g->tile_hdr, g->prog_w,
-                        g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0);
-                    if (g->c.nfast > 0) nsk_refresh_ztab(g);
+                        g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0, g->zprogs,
+                        tabs_here ? (int)g->c.zprogs.size() : 0, tabs_here ? (int)g->c.nztab : 0, g->ztab,
+                        g->learn_cap, g->clip_count);
+                    if (g->c.nfast > 0 && !tabs_here) nsk_refresh_ztab(g);       // big tables: own launch
                 } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
                         g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation,
-                        (!SMALLW && g->c.packed_grad) ? 1 : 0);
+                        (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count);
                     nsk_refresh_prog_weights(g, true);
                 }
             }

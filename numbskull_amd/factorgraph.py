@@ -31,7 +31,7 @@ class FactorGraph(object):
 
     def __init__(self, weight, variable, factor, fmap, vmap, factor_index, var_copies,
                  weight_copies, fid, workers, *, device=0, seed=0, scan="chromatic",
-                 head_by_vid=False, own_range=None):
+                 head_by_vid=False, own_range=None, learn_cap=0.5):
         self.weight, self.variable, self.factor = weight, variable, factor
         self.fmap, self.vmap, self.factor_index = fmap, vmap, factor_index
 
@@ -66,6 +66,7 @@ class FactorGraph(object):
         self.device = int(device)
         self.seed = int(seed)
         self.scan = scan
+        self.learn_cap = float(learn_cap)
         self.head_by_vid = bool(head_by_vid)
         self.own_range = own_range
         self._handle = None
@@ -129,6 +130,7 @@ class FactorGraph(object):
         _lib.check(L.nsk_set_seed(h, self.seed, 0))
         scan = {"chromatic": _lib.SCAN_CHROMATIC, "sequential": _lib.SCAN_SEQUENTIAL}[self.scan]
         _lib.check(L.nsk_set_scan(h, scan))
+        _lib.check(L.nsk_set_learn_cap(h, self.learn_cap))
         return h
 
     def close(self):

@@ -83,6 +83,8 @@ engine_arguments = [
     _opt(('--seed',), 'seed', 0, int, 'SEED', 'sampler seed (Philox key / MT19937 seed)'),
     _opt(('--scan',), 'scan', 'chromatic', str, 'SCAN',
          '"chromatic" (parallel colour classes) or "sequential" (reference trajectory, slow)'),
+    _opt(('--learn_cap',), 'learn_cap', 0.5, float, 'LEARN_CAP',
+         'chromatic learning: cap on (visits of a weight in one colour class) x stepsize; 0 = off'),
 ]
 engine_flags = [
     _flag(('--head_by_vid',), 'head_by_vid', False,
@@ -108,7 +110,7 @@ class NumbSkull(object):
                    weight_copies, **extra):
         fg = FactorGraph(weight, variable, factor, fmap, vmap, factor_index, var_copies,
                          weight_copies, len(self.factorGraphs), self.nthreads,
-                         device=self.device, seed=self.seed, scan=self.scan,
+                         device=self.device, seed=self.seed, scan=self.scan, learn_cap=self.learn_cap,
                          head_by_vid=self.head_by_vid, **extra)
         self.factorGraphs.append(fg)
         return fg

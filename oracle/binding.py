@@ -164,14 +164,14 @@ class Graph:
             int(burnin), C.c_uint64(seed), C.c_uint64(sweep))
 
     def learn_dev(self, order, phase_start, var_value, var_value_evid, weight_value, step,
-                  regularization, reg_param, truncation, learn_non_evidence, seed, sweep):
+                  regularization, reg_param, truncation, learn_non_evidence, seed, sweep, cap=0.5):
         order = np.ascontiguousarray(order, np.int64)
         phase_start = np.ascontiguousarray(phase_start, np.int64)
         return lib().orc_learn_sweep_dev(
             C.byref(self.g), _p(order), _p(phase_start), C.c_int64(len(phase_start) - 1),
             C.c_double(step), int(regularization), C.c_double(reg_param), C.c_int64(truncation),
             _p(var_value), _p(var_value_evid), _p(weight_value), int(learn_non_evidence),
-            C.c_uint64(seed), C.c_uint64(sweep))
+            C.c_uint64(seed), C.c_uint64(sweep), C.c_double(cap))
 
     # ---- CPU baseline (Hogwild threads) ----
     def gibbs_hogwild(self, nthreads, nsweeps, var_value, weight_value, count, seed,

@@ -618,7 +618,7 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
                         int64_t nphase, double step, int regularization, double reg_param,
                         int64_t truncation, int64_t *var_value, int64_t *var_value_evid,
                         double *weight_value, int learn_non_evidence, uint64_t seed,
-                        uint64_t sweep) {
+                        uint64_t sweep, double cap) {
     double *Z = (double *)malloc(sizeof(double) * (size_t)max_card(g));
     int64_t *G = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
     int64_t *K = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
@@ -673,18 +673,22 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             if (K[w] == 0) continue;
             double Gf = (double)G[w] * (1.0 / 4294967296.0);
             double x = weight_value[w];
+            /* device-mode step cap: K visits at `step` move the weight by K * step * mean gradient;
+             * beyond `cap` the class uses cap / K (DESIGN.md "device-mode learning") */
+            double st = step;
+            if (cap > 0.0 && (double)K[w] * step > cap) st = cap / (double)K[w];
             if (regularization == 2) {
-                double a = 1.0 / (1.0 + reg_param * step);
+                double a = 1.0 / (1.0 + reg_param * st);
                 x = powi_det(a, (uint64_t)K[w]) * x;
-                x = x - step * Gf;
+                x = x - st * Gf;
             } else if (regularization == 1) {
-                x = x - step * Gf;
+                x = x - st * Gf;
                 if (T[w] > 0) {
-                    double l1 = (reg_param * step * (double)truncation) * (double)T[w];
+                    double l1 = (reg_param * st * (double)truncation) * (double)T[w];
                     x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
                 }
             } else {
-                x = x - step * Gf;
+                x = x - st * Gf;
             }
             weight_value[w] = x;
             G[w] = 0; K[w] = 0; T[w] = 0;

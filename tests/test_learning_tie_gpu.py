@@ -1,0 +1,96 @@
+"""Chromatic ("device-mode") learning tied to the reference's own per-visit SGD.
+
+scan="sequential" reproduces sample_and_sgd (learning.py:46-125) visit by visit -- bit-exact
+against reference traces in test_hip_parity.py.  The production scan updates each weight once per
+colour class (batch of k visits, step clipped to learn_cap / k when k * step exceeds the cap).
+Both rules have the same fixed point; these tests run the SAME graph with IDENTICAL
+hyper-parameters (the reference's CLI defaults: stepsize 0.01, decay 0.95, L2 0.01) under both
+scans and require the learned weights to agree, and check the planted-weight recovery.
+"""
+
+import numpy as np
+import pytest
+
+from numbskull_amd import graphgen
+from util import session
+
+pytestmark = pytest.mark.gpu
+
+DEFAULTS = dict(step=0.01, decay=0.95, reg=2, reg_param=0.01)     # numbskull.py:18-149
+
+
+def planted_grid(rows, cols, w, seed, sweeps=300):
+    """An evidence configuration sampled (by the library's own sampler) at planted weights."""
+    g = graphgen.ising_grid(rows, cols, weight=0.0, fixed=True, two_weights=True)
+    g[0]["initialValue"] = w
+    ns, fg = session(g, seed=seed)
+    fg.inference(sweeps, 0, True)
+    return fg.var_value[0].copy()
+
+
+def learn(g, scan, epochs, seed=5, **kw):
+    ns, fg = session(g, seed=seed, scan=scan, **kw)
+    fg.learn(0, epochs, DEFAULTS["step"], DEFAULTS["decay"], DEFAULTS["reg"], DEFAULTS["reg_param"], 1)
+    return fg.weight_value[0].copy(), fg
+
+
+@pytest.mark.parametrize("shape", [(32, 32), (64, 64)])
+def test_two_weight_grid_chromatic_matches_sequential_at_reference_defaults(shape):
+    rows, cols = shape
+    ev = planted_grid(rows, cols, (0.3, 0.15), seed=3)
+    g = graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True, evidence=ev)
+    w_seq, _ = learn(g, "sequential", 150)
+    w_chr, fg = learn(g, "chromatic", 150)
+    assert np.isfinite(w_chr).all()
+    assert fg.info()["learn_clipped"] > 0           # k * step = 10..41 here: the cap was active
+    assert np.abs(w_chr - w_seq).max() <= 0.02, (w_chr, w_seq)
+
+
+def test_pairs_model_chromatic_matches_sequential():
+    g = graphgen.ising_pairs(2000, 1.0, 1.0, 0.5, seed=7)
+    w_seq, _ = learn(g, "sequential", 150)
+    w_chr, _ = learn(g, "chromatic", 150)
+    assert np.abs(w_chr - w_seq).max() <= 0.02, (w_chr, w_seq)
+
+
+def test_lf_graph_chromatic_matches_sequential():
+    g = graphgen.lf_graph(0.0, [1.5, 1.0, 0.5], 2000, seed=3)
+    w_seq, _ = learn(g, "sequential", 150)
+    w_chr, _ = learn(g, "chromatic", 150)
+    assert np.abs(w_chr - w_seq).max() <= 0.03, (w_chr, w_seq)
+
+
+def test_reference_default_stepsize_recovers_planted_weights_1000x1000():
+    """The reference's default -s 0.01 on the 1000x1000 two-weight grid: one colour class visits a
+    weight 10^6 times (k * step = 10^4); with the step cap the run converges to the planted
+    weights instead of diverging."""
+    ev = planted_grid(1000, 1000, (0.3, 0.2), seed=11, sweeps=200)
+    g = graphgen.ising_grid(1000, 1000, weight=0.0, fixed=False, two_weights=True, evidence=ev)
+    w, fg = learn(g, "chromatic", 60)
+    assert np.isfinite(w).all()
+    assert abs(w[0] - 0.3) < 0.01 and abs(w[1] - 0.2) < 0.01, w
+
+
+def test_cap_off_reproduces_plain_batch_rule_and_diverges_where_expected():
+    """learn_cap=0 is the unclipped batch rule (what round 1 shipped): same weights as the cap when
+    k * step is small, runaway weights at the reference defaults on a shared-weight grid."""
+    ev = planted_grid(32, 32, (0.3, 0.15), seed=3)
+    g = graphgen.ising_grid(32, 32, weight=0.0, fixed=False, two_weights=True, evidence=ev)
+    ns, a = session(g, seed=5, learn_cap=0.0)
+    ns, b = session(g, seed=5)
+    a.learn(0, 20, 1e-4, 0.95, 2, 0.01, 1)          # k * step = 0.1: below the cap
+    b.learn(0, 20, 1e-4, 0.95, 2, 0.01, 1)
+    assert np.array_equal(a.weight_value, b.weight_value)
+    ns, c = session(g, seed=5, learn_cap=0.0)
+    c.learn(0, 30, 0.01, 1.0, 2, 0.01, 1)
+    assert np.abs(c.weight_value[0]).max() > 2.0     # oscillates far from (0.3, 0.15)
+
+
+def test_planted_pair_weights_tight():
+    """ising.cpp:202-318 scenario (known-answer 2) with enough pairs for the
+    estimate itself to be tight: weights (1, 1, 0.5) planted."""
+    g = graphgen.ising_pairs(40000, 1.0, 1.0, 0.5, seed=7)
+    ns, fg = session(g, seed=7)
+    fg.learn(0, 300, 0.01, 0.98, 2, 1e-4, 1)
+    w = fg.weight_value[0]
+    assert abs(w[0] - 1.0) < 0.05 and abs(w[1] - 1.0) < 0.05 and abs(w[2] - 0.5) < 0.05, w
