@@ -148,6 +148,21 @@ int nsk_graph_destroy(nsk_graph *g) {
     return NSK_OK;
 }
 
+// upload the generic-path arrays (once)
+int nsk_ensure_generic(nsk_graph *g) {
+    if (g->generic_uploaded) return NSK_OK;
+    Compiled &c = g->c;
+    int rc;
+    HIPCHECK(hipSetDevice(g->device));
+#define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
+    UP(p_slot); UP(slot_off); UP(fidx); UP(gstream); UP(gs_off);
+    UP(f_rec); UP(f_feat); UP(m_rec); UP(v_card); UP(v_pos);
+#undef UP
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    g->generic_uploaded = true;
+    return NSK_OK;
+}
+
 static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     std::string err;
     const auto t_compile = std::chrono::steady_clock::now();
@@ -174,8 +189,16 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     HIPCHECK(hipEventCreate(&g->ev1));
     Compiled &c = g->c;
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
-    UP(p_vid); UP(p_info); UP(p_slot); UP(p_cnt); UP(slot_off); UP(fidx); UP(gstream); UP(gs_off);
-    UP(f_rec); UP(f_feat); UP(m_rec); UP(v_card); UP(v_pos);
+    UP(p_vid); UP(p_info); UP(p_cnt);
+    // the CSR-style arrays serve the generic kernels, the hub waves, the per-lane-header tiles and
+    // the sequential validation scan only: a graph that lives entirely in tiles (the Ising grids:
+    // 1.4 GB of them at 10M variables) uploads them when the sequential scan is first selected
+    {
+        bool generic_needed = c.phase_dyn_base.size() > 0 && c.phase_dyn_base.back() > 0;
+        for (size_t k = 0; k + 1 < c.phase_start.size(); k++)
+            if (c.phase_start[k + 1] > c.phase_fast_end[k]) generic_needed = true;
+        if (generic_needed || getenv("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
+    }
     UP(w_fixed); UP(logtab); UP(adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
@@ -266,6 +289,7 @@ int nsk_set_scan(nsk_graph *g, int scan) {
     if (scan != NSK_SCAN_CHROMATIC && scan != NSK_SCAN_SEQUENTIAL) return fail(NSK_E_INVALID, "unknown scan order");
     if (scan == NSK_SCAN_SEQUENTIAL && (g->c.own_begin != 0 || g->c.own_end != g->c.nvar))
         return fail(NSK_E_INVALID, "sequential scan needs the whole graph on one handle");
+    if (scan == NSK_SCAN_SEQUENTIAL) { int rc = nsk_ensure_generic(g); if (rc) return rc; }
     g->scan = scan;
     return NSK_OK;
 }

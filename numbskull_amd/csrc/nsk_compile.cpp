@@ -10,8 +10,31 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace nsk {
+
+// Static block partition of [0, n) over the compile threads (NSK_COMPILE_THREADS, default: the
+// hardware's, at most 64).  Every use writes disjoint outputs per index, so results do not depend
+// on the thread count.
+static int compile_threads() {
+    static const int n = [] {
+        const char *e = getenv("NSK_COMPILE_THREADS");
+        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(64, t));
+    }();
+    return n;
+}
+template <typename F>
+static void parallel_for(int64_t n, F &&body) {            // body(begin, end, thread index)
+    const int T = (int)std::min<int64_t>(compile_threads(), std::max<int64_t>(1, n / 4096));
+    if (T <= 1) { body((int64_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)T);
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] { body(n * t / T, n * (t + 1) / T, t); });
+    for (auto &x : th) x.join();
+}
 
 // a variable whose factor lists hold at least this many entries in total is sampled by a whole wave
 static const int64_t NSK_HEAVY_LIST = 32;
@@ -128,25 +151,30 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
 
     // ---- factors and edges: narrow copies; validated lazily for factors that are reachable ----
     c.f_rec.assign((size_t)nfac * 4 + 4, 0); c.f_feat.resize(nfac);
-    for (int64_t f = 0; f < nfac; f++) {
+    for (int64_t f = 0; f < nfac; f++)
+        if (d->factor[f].arity >= ((int64_t)1 << 24)) {
+            err = fmt("factor %lld: arity %lld too large", f, d->factor[f].arity);
+            return NSK_E_RANGE;
+        }
+    parallel_for(nfac, [&](int64_t fb0, int64_t fb1, int) {
+    for (int64_t f = fb0; f < fb1; f++) {
         const nsk_factor &fa = d->factor[f];
         int64_t ar = fa.arity;
         if (ar < 0) ar = 0;
-        if (ar >= ((int64_t)1 << 24)) {
-            err = fmt("factor %lld: arity %lld too large", f, fa.arity);
-            return NSK_E_RANGE;
-        }
         c.f_rec[4 * f] = ((uint32_t)ar << 8) | (uint32_t)((fa.factorFunction + 1) & 0xff);
         c.f_rec[4 * f + 1] = (uint32_t)(int32_t)std::max<int64_t>(std::min<int64_t>(fa.ftv_offset, LIM - 2), -1);
         c.f_rec[4 * f + 2] = (uint32_t)(int32_t)std::max<int64_t>(std::min<int64_t>(fa.weightId, LIM - 2), -1);
         c.f_feat[f] = fa.featureValue;
     }
+    });
     c.m_rec.assign((size_t)nedge * 2 + 2, 0);
-    for (int64_t l = 0; l < nedge; l++) {
+    parallel_for(nedge, [&](int64_t lb0, int64_t lb1, int) {
+    for (int64_t l = lb0; l < lb1; l++) {
         int64_t vid = d->fmap[l].vid, deo = d->fmap[l].dense_equal_to;
         c.m_rec[2 * l] = (vid < 0 || vid >= nvar) ? -1 : (int32_t)vid;
         c.m_rec[2 * l + 1] = (int32_t)std::max<int64_t>(std::min<int64_t>(deo, INT32_MAX), INT32_MIN);
     }
+    });
 
     lap("records");
     // ---- which variables does this handle sample? -------------------------------------------
@@ -245,7 +273,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
 
     // ---- colouring: no two variables of a colour may read each other ---------------------------
     // reads(v) = members of every factor in v's lists (+ the literal head index variable)
-    auto for_each_read = [&](int64_t v, auto &&fn_) {
+    auto for_each_read_slow = [&](int64_t v, auto &&fn_) {
         const nsk_variable &var = d->variable[v];
         const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
         for (int64_t k = 0; k < nslots; k++) {
@@ -265,6 +293,43 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
     };
 
+    // compact read lists: reads of v, sorted and unique, self excluded, as int32 -- built once, in
+    // parallel, from the packed records; every colouring pass below walks these 4-byte lists
+    // instead of chasing vmap -> factor_index -> factor -> fmap again
+    std::vector<int64_t> rd_off((size_t)nvar + 1, 0);
+    std::vector<int32_t> rd_len((size_t)nvar, 0);
+    std::vector<int32_t> rd;
+    bool use_rd = true;
+    {
+        parallel_for(nvar, [&](int64_t b0, int64_t b1, int) {
+            for (int64_t v = b0; v < b1; v++) {
+                if (!sampled[v]) continue;
+                int64_t n = 0;
+                for_each_read_slow(v, [&](int64_t b) { if (b != v) n++; });
+                rd_off[v + 1] = n;
+            }
+        });
+        for (int64_t v = 0; v < nvar; v++) rd_off[v + 1] += rd_off[v];
+        // (factors with a huge arity make the lists quadratic: beyond 2^32 entries walk the records)
+        use_rd = rd_off[nvar] < ((int64_t)1 << 32);
+        rd.resize(use_rd ? (size_t)rd_off[nvar] : 0);
+        if (use_rd) parallel_for(nvar, [&](int64_t b0, int64_t b1, int) {
+            for (int64_t v = b0; v < b1; v++) {
+                if (!sampled[v]) continue;
+                int32_t *out = rd.data() + rd_off[v];
+                int64_t n = 0;
+                for_each_read_slow(v, [&](int64_t b) { if (b != v) out[n++] = (int32_t)b; });
+                std::sort(out, out + n);
+                rd_len[v] = (int32_t)(std::unique(out, out + n) - out);
+            }
+        });
+    }
+    auto for_each_read = [&](int64_t v, auto &&fn_) {
+        if (!use_rd) { for_each_read_slow(v, fn_); return; }
+        const int32_t *p = rd.data() + rd_off[v];
+        for (int32_t j = 0, n = rd_len[v]; j < n; j++) fn_((int64_t)p[j]);
+    };
+    lap("read lists");
     c.color.assign(nvar, -1);
     std::vector<int64_t> stamp(1, -1), load;
     int32_t ncolors = 0;
@@ -398,7 +463,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     std::vector<uint8_t> fast(nvar, 0);
     auto fast_function = [](int fn) { return fn == -1 || (fn >= 0 && fn <= 4); };
     const bool no_fast = getenv("NSK_NO_FAST") != nullptr;      // diagnostic: everything on the generic path
-    for (int64_t v = 0; v < nvar; v++) {
+    parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
+    for (int64_t v = vb0; v < vb1; v++) {
         if (c.color[v] < 0 || no_fast) continue;
         const nsk_variable &var = d->variable[v];
         if (var.cardinality != 2 || var.dataType != 0) continue;
@@ -418,6 +484,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         fast[v] = ok;
     }
+    });
 
     lap("fast eligibility");
     // ---- general tiles (kind 6): variables of cardinality <= 8 and any dataType whose factors are
@@ -502,8 +569,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         return true;
     };
-    for (int64_t v = 0; v < nvar; v++)
-        if (c.color[v] >= 0 && !fast[v] && !no_fast && !no_general && general_words(v, nullptr)) fast[v] = 2;
+    parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
+        for (int64_t v = vb0; v < vb1; v++)
+            if (c.color[v] >= 0 && !fast[v] && !no_fast && !no_general && general_words(v, nullptr)) fast[v] = 2;
+    });
 
     lap("general eligibility");
     // ---- positions: colour-major.  Inside a colour: the fast variables grouped by "shape class"
@@ -524,9 +593,13 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0), ngt_of((size_t)ncolors, 0);
         for (int64_t v = 0; v < nvar; v++) {
             if (c.color[v] < 0) continue;
-            if (fast[v] == 2) { ngt_of[c.color[v]]++; continue; }
-            if (!fast[v]) { ngen_of[c.color[v]]++; continue; }
-            nfast_of[c.color[v]]++;
+            if (fast[v] == 2) ngt_of[c.color[v]]++;
+            else if (!fast[v]) ngen_of[c.color[v]]++;
+            else nfast_of[c.color[v]]++;
+        }
+        parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
+        for (int64_t v = vb0; v < vb1; v++) {
+            if (c.color[v] < 0 || fast[v] != 1) continue;
             const nsk_variable &var = d->variable[v];
             const nsk_vtf &vt = d->vmap[var.vtf_offset];
             // (the evidence flag is multiplied in before the first word: a plain xor would cancel
@@ -550,6 +623,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             sig[v] = h | 1;
             shp[v] = nwords <= 16 ? (h2 | 1) : 0;
         }
+        });
         typedef std::map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
         std::vector<ClassMap> classes((size_t)ncolors), shapes((size_t)ncolors);
         for (int64_t v = 0; v < nvar; v++) {
@@ -680,14 +754,23 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // so neighbours in this order waste the least padding (SELL-C-sigma)
         {
             std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (key, vid)
+            std::vector<uint8_t> g_ne(nvar, 0), g_mo(nvar, 0);      // entries / widest entry of a general lane
+            parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
+                std::vector<uint32_t> w;
+                for (int64_t v = vb0; v < vb1; v++) {
+                    if (c.color[v] < 0 || fast[v] != 2) continue;
+                    general_words(v, &w);
+                    int64_t ne = 0, mo = 0;
+                    for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) {
+                        ne++;
+                        mo = std::max<int64_t>(mo, (w[j + 1] >> 4) & 7u);
+                    }
+                    g_ne[v] = (uint8_t)ne; g_mo[v] = (uint8_t)mo;
+                }
+            });
             for (int64_t v = 0; v < nvar; v++) {
                 if (c.color[v] < 0 || fast[v] != 2) continue;
-                general_words(v, &gw);
-                int64_t ne = 0, mo = 0;
-                for (size_t j = 0; j < gw.size(); j += 2 + ((gw[j + 1] >> 4) & 7u)) {
-                    ne++;
-                    mo = std::max<int64_t>(mo, (gw[j + 1] >> 4) & 7u);
-                }
+                const int64_t ne = g_ne[v], mo = g_mo[v];
                 // key: categorical lanes first (their tiles form a launch of their own), then blocks
                 // of gen_block consecutive ids (sigma of SELL-C-sigma: each XCD walks a contiguous
                 // run of tiles, so its L2 then sees one slice of the value array instead of all of
@@ -695,8 +778,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 const int64_t catv = d->variable[v].cardinality > 2 ? 0 : 1;
                 order[c.color[v]].push_back({(catv << 50) | ((v / gen_block) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
             }
+            {
+                std::vector<std::thread> sorters;             // one colour per thread (few colours only)
+                for (int32_t k = 0; k < ncolors; k++) {
+                    if (ncolors <= 64 && compile_threads() > 1)
+                        sorters.emplace_back([&, k] { std::sort(order[k].begin(), order[k].end()); });
+                    else std::sort(order[k].begin(), order[k].end());
+                }
+                for (auto &t : sorters) t.join();
+            }
             for (int32_t k = 0; k < ncolors; k++) {
-                std::sort(order[k].begin(), order[k].end());
                 for (auto &o : order[k]) {
                     const int64_t p = gt_at[k]++;
                     c.p_vid[p] = (int32_t)o.second;
@@ -754,24 +845,35 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             for (size_t j = 0; j < w.size(); j += 1 + ((w[j] >> 24) & 7u)) h.push_back(w[j]);
         };
         // pass 1: shape of every tile.  Uniform tile = all its lanes have the same header sequence.
-        std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
-        std::vector<uint32_t> words, hdrs, hdrs0, prog;
-        uint64_t total4 = 0;                      // stream size in 16-byte units
-        for (int32_t k = 0; k < ncolors; k++) {
-            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
+        // Phase A (parallel over tiles): classify the tile and reduce its program to a short key;
+        // phase B (sequential): pool the programs, assign stream offsets and weight rows.
+        struct TileShape {
+            uint8_t cls;            // 0 per-lane headers, 1 general, 2 uniform, 3 shape
+            uint8_t nkey;
+            int32_t len;            // words per lane before rounding to chunks
+            uint32_t flags;         // td[3]
+            uint32_t nrows;         // materialised weight rows the tile needs
+            uint32_t key[16];       // uniform / shape: the program words; general: {E, M}
+        };
+        std::vector<TileShape> shapes_of((size_t)nwb);
+        std::vector<int32_t> tile_colour((size_t)nwb);
+        for (int32_t k = 0; k < ncolors; k++)
+            for (int64_t t = c.phase_wb_base[k]; t < c.phase_wb_base[k + 1]; t++) tile_colour[t] = k;
+        const bool no_shape = getenv("NSK_NO_SHAPE") != nullptr, no_ztab = getenv("NSK_NO_ZTAB") != nullptr;
+        parallel_for(nwb, [&](int64_t tb0, int64_t tb1, int) {
+            std::vector<uint32_t> words, hdrs, hdrs0;
+            for (int64_t t = tb0; t < tb1; t++) {
+                const int32_t k = tile_colour[t];
+                const int64_t b = t - c.phase_wb_base[k];
                 const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
-                uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
-                int64_t len = 0;
-                bool uniform = true, shape_tile = false;
-                (void)shape_tile;
-                bool have0 = false, same_shape = true;
+                TileShape &ts = shapes_of[t];
+                memset(&ts, 0, sizeof(ts));
                 bool gen_tile = false;                             // general tile (kind 6)
                 for (int64_t p = p0; p < p1 && !gen_tile; p++)
                     if (c.p_vid[p] >= 0 && fast[c.p_vid[p]] == 2) gen_tile = true;
                 if (gen_tile) {
                     // layout shared by the 64 lanes: E entries of 2 + M words, E and M the maxima over
-                    // the lanes.  Role program: 1 weight word | 32 descriptor word (8: no member
-                    // slots) | 16 member slot | 2 first slot | 4 last slot
+                    // the lanes
                     uint32_t E = 0, M = 0, maxcard = 2;
                     for (int64_t p = p0; p < p1; p++) {
                         if (c.p_vid[p] < 0) continue;
@@ -784,37 +886,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         E = std::max(E, ne);
                         maxcard = std::max(maxcard, (uint32_t)d->variable[c.p_vid[p]].cardinality);
                     }
-                    prog.clear();
-                    for (uint32_t e = 0; e < E; e++) {
-                        prog.push_back(1u | 0x80000000u);
-                        prog.push_back(32u | (M == 0 ? 8u : 0u) | 0x80000000u);
-                        for (uint32_t m = 0; m < M; m++)
-                            prog.push_back(16u | (m == 0 ? 2u : 0u) | (m + 1 == M ? 4u : 0u) | 0x80000000u);
-                    }
-                    auto it = hdr_pool.find(prog);
-                    if (it == hdr_pool.end()) {
-                        it = hdr_pool.emplace(prog, (uint32_t)c.tile_hdr.size()).first;
-                        c.tile_hdr.insert(c.tile_hdr.end(), prog.begin(), prog.end());
-                        c.tile_hdr.resize((c.tile_hdr.size() + 7) / 8 * 8, 0u);
-                    }
-                    len = (int64_t)E * (2 + M);
-                    td[2] = it->second;
-                    td[3] = (uint32_t)len | (6u << 8) | (maxcard << 12) | (M << 16);
-                    if (nw * 8 > (4 << 20) && E > 0) {
-                        // a weight table beyond the L2: inference reads materialised weight rows (one
-                        // coalesced row per entry, refreshed when weights change) like the shape tiles
-                        td[3] |= 1u << 19;
-                        c.tile_wrow[c.phase_wb_base[k] + b] = (uint32_t)c.nwrows;
-                        c.nwrows += (int64_t)E;
-                        if (c.nwrows >= ((int64_t)1 << 31)) { err = "weight stream too large"; return NSK_E_RANGE; }
-                    }
-                    len = (len + 3) / 4 * 4;
-                    td[0] = (uint32_t)total4;
-                    td[1] = (uint32_t)len;
-                    total4 += (uint64_t)(len / 4) * 64;
-                    if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
+                    ts.cls = 1; ts.nkey = 2; ts.key[0] = E; ts.key[1] = M;
+                    ts.len = (int32_t)(E * (2 + M));
+                    ts.flags = (uint32_t)ts.len | (6u << 8) | (maxcard << 12) | (M << 16);
+                    if (nw * 8 > (4 << 20) && E > 0) { ts.flags |= 1u << 19; ts.nrows = E; }
                     continue;
                 }
+                int64_t len = 0;
+                bool uniform = true, have0 = false, same_shape = true;
                 bool binmem = true;                // every member the lanes read is a binary variable
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;                  // padding position
@@ -833,23 +912,80 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     have0 = true;
                 }
                 if (!have0) { hdrs0.clear(); uniform = false; same_shape = false; }
-                td[2] = 0xFFFFFFFFu;
                 // slot program of a uniform tile: one word per member slot (an entry without other
                 // members still gets one, ignored, slot):
                 //   weightId | code << 24 | first << 27 | last << 28 | ignore << 29 | weight fixed << 30
                 //   code: 0 NOOP, 1 IMPLY_NATURAL, 2 OR, 3 AND/ISTRUE, 4 EQUAL
                 int64_t nslots = 0;
                 for (uint32_t h : hdrs0) nslots += std::max<int64_t>(1, (h >> 24) & 7u);
+                ts.cls = 0; ts.len = (int32_t)len;
                 if (uniform && nslots <= 8 && p1 > p0) {
-                    prog.clear();
+                    uint32_t n = 0;
                     for (uint32_t h : hdrs0) {
                         const int fn = (int)(h >> 27) - 1;
                         const uint32_t code = fn == 3 ? 4u : (fn == 2 || fn == 4) ? 3u : fn == 1 ? 2u : fn == 0 ? 1u : 0u;
                         const uint32_t no = (h >> 24) & 7u, wid = h & 0xFFFFFFu;
                         for (uint32_t m = 0; m < std::max(1u, no); m++)
-                            prog.push_back(wid | (code << 24) | ((m == 0 ? 1u : 0u) << 27) |
-                                           ((m + 1 >= no ? 1u : 0u) << 28) | ((no == 0 ? 1u : 0u) << 29) |
-                                           ((c.w_fixed[wid] ? 1u : 0u) << 30));
+                            ts.key[n++] = wid | (code << 24) | ((m == 0 ? 1u : 0u) << 27) |
+                                          ((m + 1 >= no ? 1u : 0u) << 28) | ((no == 0 ? 1u : 0u) << 29) |
+                                          ((c.w_fixed[wid] ? 1u : 0u) << 30);
+                    }
+                    ts.nkey = (uint8_t)n;
+                    // kind: every entry has exactly one other member and the same function code ->
+                    // the kernel runs a specialised, table-free step (code in bits 8..10)
+                    uint32_t kind = n == 0 ? 0u : (ts.key[0] >> 24) & 7u;
+                    for (uint32_t j = 0; j < n; j++)
+                        if (((ts.key[j] >> 24) & 7u) != kind || ((ts.key[j] >> 27) & 7u) != 3u) kind = 0;   // first+last, not ignored
+                    // bit 11: draw-table candidate (padding slots read variable 0: masked off by nslots)
+                    ts.cls = 2;
+                    ts.flags = (uint32_t)nslots | (kind << 8) | ((binmem && !no_ztab) ? 1u << 11 : 0u);
+                    ts.len = (int32_t)nslots;
+                } else if (same_shape && len <= 16 && len > 0 && !no_shape) {
+                    // shape tile: per-lane headers (own function and weight) but one word layout for the
+                    // 64 lanes.  Role program, one word per stream word: 1 header | 8 header of an
+                    // entry without other members | 16 member | 2 first member | 4 last member; kind 7.
+                    uint32_t n = 0;
+                    for (uint32_t h : hdrs0) {
+                        const uint32_t no = (h >> 24) & 7u;
+                        ts.key[n++] = 1u | (no == 0 ? 8u : 0u) | 0x80000000u;   // bit 31 marks role words
+                        for (uint32_t m = 0; m < no; m++)
+                            ts.key[n++] = 16u | (m == 0 ? 2u : 0u) | (m + 1 == no ? 4u : 0u) | 0x80000000u;
+                    }
+                    ts.nkey = (uint8_t)n;
+                    ts.cls = 3;
+                    ts.flags = (uint32_t)len | (7u << 8);
+                    ts.nrows = (uint32_t)hdrs0.size();
+                }
+            }
+        });
+        std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
+        std::vector<uint32_t> words, prog;
+        uint64_t total4 = 0;                      // stream size in 16-byte units
+        const TileShape *last_ts = nullptr;
+        uint32_t last_prog = 0;
+        for (int64_t t = 0; t < nwb; t++) {
+            const TileShape &ts = shapes_of[t];
+            uint32_t *td = &c.tiles[4 * t];
+            int64_t len = ts.len;
+            td[2] = 0xFFFFFFFFu;
+            if (ts.cls != 0) {
+                if (last_ts && last_ts->cls == ts.cls && last_ts->nkey == ts.nkey &&
+                    !memcmp(last_ts->key, ts.key, sizeof(uint32_t) * ts.nkey)) {
+                    td[2] = last_prog;                              // same program as the previous tile
+                } else {
+                    prog.clear();
+                    if (ts.cls == 1) {
+                        // role program: 1 weight word | 32 descriptor word (8: no member slots) | 16 member
+                        // slot | 2 first slot | 4 last slot
+                        const uint32_t E = ts.key[0], M = ts.key[1];
+                        for (uint32_t e = 0; e < E; e++) {
+                            prog.push_back(1u | 0x80000000u);
+                            prog.push_back(32u | (M == 0 ? 8u : 0u) | 0x80000000u);
+                            for (uint32_t m = 0; m < M; m++)
+                                prog.push_back(16u | (m == 0 ? 2u : 0u) | (m + 1 == M ? 4u : 0u) | 0x80000000u);
+                        }
+                    } else {
+                        prog.assign(ts.key, ts.key + ts.nkey);
                     }
                     auto it = hdr_pool.find(prog);
                     if (it == hdr_pool.end()) {
@@ -857,46 +993,23 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         c.tile_hdr.insert(c.tile_hdr.end(), prog.begin(), prog.end());
                         c.tile_hdr.resize((c.tile_hdr.size() + 7) / 8 * 8, 0u);   // pad: NOOP, weight 0
                     }
-                    // kind: every entry has exactly one other member and the same function code ->
-                    // the kernel runs a specialised, table-free step (code in bits 8..10)
-                    uint32_t kind = prog.empty() ? 0u : (prog[0] >> 24) & 7u;
-                    for (uint32_t wdp : prog)
-                        if (((wdp >> 24) & 7u) != kind || ((wdp >> 27) & 7u) != 3u) kind = 0;   // first+last, not ignored
                     td[2] = it->second;
-                    // bit 11: draw-table candidate (padding slots read variable 0: masked off by nslots)
-                    td[3] = (uint32_t)nslots | (kind << 8) | ((binmem && !getenv("NSK_NO_ZTAB")) ? 1u << 11 : 0u);
-                    len = nslots;
+                    last_ts = &ts; last_prog = td[2];
                 }
-                if (td[2] == 0xFFFFFFFFu && same_shape && len <= 16 && len > 0 && !getenv("NSK_NO_SHAPE")) {
-                    // shape tile: per-lane headers (own function and weight) but one word layout for the
-                    // 64 lanes.  Role program, one word per stream word: 1 header | 8 header of an
-                    // entry without other members | 16 member | 2 first member | 4 last member; kind 7.
-                    prog.clear();
-                    for (uint32_t h : hdrs0) {
-                        const uint32_t no = (h >> 24) & 7u;
-                        prog.push_back(1u | (no == 0 ? 8u : 0u) | 0x80000000u);   // bit 31 marks role words
-                        for (uint32_t m = 0; m < no; m++)
-                            prog.push_back(16u | (m == 0 ? 2u : 0u) | (m + 1 == no ? 4u : 0u) | 0x80000000u);
-                    }
-                    auto it = hdr_pool.find(prog);
-                    if (it == hdr_pool.end()) {
-                        it = hdr_pool.emplace(prog, (uint32_t)c.tile_hdr.size()).first;
-                        c.tile_hdr.insert(c.tile_hdr.end(), prog.begin(), prog.end());
-                        c.tile_hdr.resize((c.tile_hdr.size() + 7) / 8 * 8, 0u);
-                    }
-                    td[2] = it->second;
-                    td[3] = (uint32_t)len | (7u << 8);
-                    shape_tile = true;
-                    c.tile_wrow[c.phase_wb_base[k] + b] = (uint32_t)c.nwrows;
-                    c.nwrows += (int64_t)hdrs0.size();
+                td[3] = ts.flags;
+                if (ts.nrows) {
+                    // a weight table beyond the L2 (general tiles) / per-lane weights (shape tiles):
+                    // inference reads materialised weight rows, one coalesced row per entry
+                    c.tile_wrow[t] = (uint32_t)c.nwrows;
+                    c.nwrows += (int64_t)ts.nrows;
                     if (c.nwrows >= ((int64_t)1 << 31)) { err = "weight stream too large"; return NSK_E_RANGE; }
                 }
-                len = (len + 3) / 4 * 4;
-                td[0] = (uint32_t)total4;
-                td[1] = (uint32_t)len;
-                total4 += (uint64_t)(len / 4) * 64;
-                if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
             }
+            len = (len + 3) / 4 * 4;
+            td[0] = (uint32_t)total4;
+            td[1] = (uint32_t)len;
+            total4 += (uint64_t)(len / 4) * 64;
+            if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
         }
         lap("tile shapes (pass 1)");
         c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
@@ -1050,10 +1163,15 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // pass 2: fill the tiles.  Padding: member slots read variable 0 (harmless) in uniform
         // tiles, 0xFFFFFFFF in tiles with per-lane headers.
         c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);
-        for (int32_t k = 0; k < ncolors; k++) {
-            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
+        std::vector<int64_t> nfast_part((size_t)compile_threads() + 1, 0);
+        parallel_for(nwb, [&](int64_t tb0, int64_t tb1, int tix) {
+            std::vector<uint32_t> words;
+            int64_t nfast_here = 0;
+            for (int64_t t = tb0; t < tb1; t++) {
+                const int32_t k = tile_colour[t];
+                const int64_t b = t - c.phase_wb_base[k];
                 const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
-                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                const uint32_t *td = &c.tiles[4 * t];
                 const uint64_t base = (uint64_t)td[0] * 4;
                 const bool uniform = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u;
                 const bool general = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 6u;
@@ -1081,7 +1199,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                             put(14u << 14);
                             for (uint32_t m = 0; m < M; m++) put(NSK_GEN_NULL);
                         }
-                        c.nfast++;
+                        nfast_here++;
                         continue;
                     }
                     lane_words(c.p_vid[p], words);
@@ -1092,20 +1210,29 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         for (uint32_t m = 1; m <= nother; m++) put(words[j + m]);
                         j += 1 + nother;
                     }
-                    c.nfast++;
+                    nfast_here++;
                 }
             }
-        }
+            nfast_part[tix] = nfast_here;
+        });
+        for (int64_t x : nfast_part) c.nfast += x;
     }
     lap("tile fill (pass 2)");
-    int64_t nslot = 0, nlist = 0;
-    for (int64_t p = 0; p < c.npos; p++) {
-        if (c.p_vid[p] < 0) continue;
-        const nsk_variable &var = d->variable[c.p_vid[p]];
-        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-        for (int64_t k = 0; k < nslots; k++) nlist += d->vmap[var.vtf_offset + k].factor_index_length;
-        nslot += nslots;
-    }
+    // per position: first slot and first list entry (exclusive prefix sums of the per-position counts)
+    std::vector<int64_t> pos_si((size_t)c.npos + 1, 0), pos_li((size_t)c.npos + 1, 0);
+    parallel_for(c.npos, [&](int64_t pb0, int64_t pb1, int) {
+        for (int64_t p = pb0; p < pb1; p++) {
+            if (c.p_vid[p] < 0) continue;
+            const nsk_variable &var = d->variable[c.p_vid[p]];
+            const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+            int64_t nl = 0;
+            for (int64_t k = 0; k < nslots; k++) nl += d->vmap[var.vtf_offset + k].factor_index_length;
+            pos_si[p + 1] = nslots;
+            pos_li[p + 1] = nl;
+        }
+    });
+    for (int64_t p = 0; p < c.npos; p++) { pos_si[p + 1] += pos_si[p]; pos_li[p + 1] += pos_li[p]; }
+    const int64_t nslot = pos_si[c.npos], nlist = pos_li[c.npos];
     if (nslot >= LIM - 1 || nlist >= LIM - 1) {
         err = "inverted index too large for 32-bit device indices";
         return NSK_E_RANGE;
@@ -1115,52 +1242,63 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     c.fidx.resize(nlist);
     const int64_t s_i = 4, s_v = c.vbytes, s_c = 4;
     const bool big_w = nw * 8 > (4 << 20);
-    double bytes_inf = 0, bytes_learn = 0;
-    double lay_inf = 0, lay_learn = 0;         // generic-path positions: the CSR model is their layout
     std::vector<uint8_t> generic_pos((size_t)c.npos + 1, 0);
     for (int32_t k = 0; k < ncolors; k++)
         for (int64_t p = c.phase_fast_end[k]; p < c.phase_start[k + 1]; p++) generic_pos[p] = 1;
-    std::vector<int64_t> uni;
-    int64_t si = 0, li = 0;
-    for (int64_t p = 0; p < c.npos; p++) {
-        const int64_t v = c.p_vid[p];
-        if (v < 0) { c.p_slot[p] = (int32_t)si; continue; }      // padding position
-        const nsk_variable &var = d->variable[v];
-        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-        c.p_info[p] = ((uint32_t)var.cardinality << 9) | ((var.dataType != 0) ? 0x100u : 0u) |
-                      (uint32_t)(uint8_t)var.isEvidence;
-        c.p_slot[p] = (int32_t)si;
-        c.p_cnt[p] = (int32_t)c.cstart[v];
-        c.p_init[p] = c.v_init[v];
-        uni.clear();
-        for (int64_t k = 0; k < nslots; k++) {
-            const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
-            c.slot_off[si++] = (int32_t)li;
-            for (int64_t j = 0; j < vt.factor_index_length; j++) {
-                const int64_t f = d->factor_index[vt.factor_index_offset + j];
-                c.fidx[li++] = (int32_t)f;
-                uni.push_back(f);
+    // (all byte counts are integers far below 2^53: the partial sums add up exactly in any order)
+    std::vector<double> part_bytes((size_t)(compile_threads() + 1) * 4, 0.0);
+    parallel_for(c.npos, [&](int64_t pb0, int64_t pb1, int tix) {
+        std::vector<int64_t> uni;
+        double bytes_inf = 0, bytes_learn = 0, lay_inf = 0, lay_learn = 0;
+        for (int64_t p = pb0; p < pb1; p++) {
+            const int64_t v = c.p_vid[p];
+            int64_t si = pos_si[p], li = pos_li[p];
+            if (v < 0) { c.p_slot[p] = (int32_t)si; continue; }      // padding position
+            const nsk_variable &var = d->variable[v];
+            const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+            c.p_info[p] = ((uint32_t)var.cardinality << 9) | ((var.dataType != 0) ? 0x100u : 0u) |
+                          (uint32_t)(uint8_t)var.isEvidence;
+            c.p_slot[p] = (int32_t)si;
+            c.p_cnt[p] = (int32_t)c.cstart[v];
+            c.p_init[p] = c.v_init[v];
+            uni.clear();
+            for (int64_t k = 0; k < nslots; k++) {
+                const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+                c.slot_off[si++] = (int32_t)li;
+                for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                    const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                    c.fidx[li++] = (int32_t)f;
+                    uni.push_back(f);
+                }
             }
+            if (nslots > 1) {
+                std::sort(uni.begin(), uni.end());
+                uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+            }
+            // algorithmic bytes of this update, SURVEY.md section 8(d)
+            double bi = 2 + s_i + s_v, bl = 0;
+            for (int64_t f : uni) {
+                const nsk_factor &fa = d->factor[f];
+                const double ar = (double)std::max<int64_t>(fa.arity, 0);
+                bi += s_i + 10 + ar * s_i + (is_cat_function(fa.factorFunction) ? ar * s_i : 0) +
+                      (ar - 1) * s_v + (big_w ? 8 : 0);
+                bl += (ar - 1) * s_v + 8 + 1 +
+                      ((big_w && fa.weightId >= 0 && fa.weightId < nw && !c.w_fixed[fa.weightId]) ? 16 : 0);
+            }
+            bytes_inf += bi + 2 * s_c;
+            bytes_learn += bi + bl + s_v;
+            if (generic_pos[p]) { lay_inf += bi + 2 * s_c; lay_learn += bi + bl + s_v; }
         }
-        if (nslots > 1) {
-            std::sort(uni.begin(), uni.end());
-            uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
-        }
-        // algorithmic bytes of this update, SURVEY.md section 8(d)
-        double bi = 2 + s_i + s_v, bl = 0;
-        for (int64_t f : uni) {
-            const nsk_factor &fa = d->factor[f];
-            const double ar = (double)std::max<int64_t>(fa.arity, 0);
-            bi += s_i + 10 + ar * s_i + (is_cat_function(fa.factorFunction) ? ar * s_i : 0) +
-                  (ar - 1) * s_v + (big_w ? 8 : 0);
-            bl += (ar - 1) * s_v + 8 + 1 +
-                  ((big_w && fa.weightId >= 0 && fa.weightId < nw && !c.w_fixed[fa.weightId]) ? 16 : 0);
-        }
-        bytes_inf += bi + 2 * s_c;
-        bytes_learn += bi + bl + s_v;
-        if (generic_pos[p]) { lay_inf += bi + 2 * s_c; lay_learn += bi + bl + s_v; }
+        part_bytes[4 * tix] = bytes_inf; part_bytes[4 * tix + 1] = bytes_learn;
+        part_bytes[4 * tix + 2] = lay_inf; part_bytes[4 * tix + 3] = lay_learn;
+    });
+    double bytes_inf = 0, bytes_learn = 0;
+    double lay_inf = 0, lay_learn = 0;         // generic-path positions: the CSR model is their layout
+    for (size_t t = 0; t * 4 < part_bytes.size(); t++) {
+        bytes_inf += part_bytes[4 * t]; bytes_learn += part_bytes[4 * t + 1];
+        lay_inf += part_bytes[4 * t + 2]; lay_learn += part_bytes[4 * t + 3];
     }
-    c.slot_off[si] = (int32_t)li;
+    c.slot_off[nslot] = (int32_t)nlist;
 
     lap("slots + CSR bytes");
     // ---- inline generic stream: for the positions handled by the one-lane generic kernels, every

@@ -59,6 +59,7 @@ struct nsk_graph {
     bool chain_regular[2] = {true, true};   // ... per chain (var_value, var_value_evid)
     double compile_seconds = 0;
     uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr, *learn_rest_tiles = nullptr;
+    bool generic_uploaded = false;     // CSR-style arrays of the generic kernels are on the device
     double learn_cap = 0.5;            // per-class cap on visits * step of one weight (nsk_set_learn_cap)
     unsigned int *clip_count = nullptr;   // weight updates whose step was clipped (device counter)
     long long *part_G = nullptr;       // SMALLW: NSK_LEARN_BINS bins of partial sums per weight
@@ -153,6 +154,7 @@ static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nwe
     return std::min(NSK_LEARN_SEG_BLOCKS, (ntiles + 3) / 4);
 }
 
+extern "C" int nsk_ensure_generic(nsk_graph *g);       // internal (not in the public header)
 void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);
 void nsk_refresh_ztab(nsk_graph *g);
 int nsk_fold_position_tally(nsk_graph *g);

@@ -1,0 +1,58 @@
+"""BASELINE configs[4] at its stated size: the 50M-variable mixed-arity LR graph (SURVEY.md section
+8d config #5: 75 % boolean / 25 % categorical variables, ISTRUE / OR / IMPLY_MLN / OR_CAT /
+IMPLY_MLN_CAT / AND_CAT factors, 10^6 weights) on ONE GPU, against the CPU oracle's device mode on
+the FULL graph: one burn-in and one tallied inference sweep (values and tallies bit-exact,
+inference.py:10-33, 232-295) and one learning epoch (weights and both chains bit-exact,
+learning.py:46-125), plus determinism and tally bounds.
+
+Needs ~100 GB of host memory for the reference-layout arrays (int64 records, numbskulltypes.py);
+skipped on smaller hosts.
+"""
+
+import numpy as np
+import psutil
+import pytest
+
+from numbskull_amd import graphgen
+from util import session, oracle_of, phases_from_colors
+
+pytestmark = pytest.mark.gpu
+
+NVAR = 50_000_000
+
+
+@pytest.fixture(scope="module")
+def lr50m():
+    if psutil.virtual_memory().available < 110 * 2 ** 30:
+        pytest.skip("needs ~110 GB of free host memory")
+    return graphgen.mixed_lr_graph(NVAR, seed=20240603)
+
+
+def test_config5_inference_and_learning_bit_exact_vs_oracle(lr50m):
+    ns, fg = session(lr50m, seed=20240603, head_by_vid=True)
+    info = fg.info()
+    assert info["nowned"] == NVAR and info["value_bytes"] == 1
+    assert info["ngeneric"] < NVAR // 100                 # the tiles carry the graph
+    assert 5 <= info["ncolors"] <= 12
+    og = oracle_of(fg, head_by_vid=True)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, cnt = og.initial_state()
+
+    fg.inference(1, 1, True)
+    og.gibbs_dev(order, ps, vv, wv, cnt, 20240603, 0, True, burnin=True)
+    og.gibbs_dev(order, ps, vv, wv, cnt, 20240603, 1, True)
+    assert np.array_equal(fg.var_value[0], vv), "values differ from the oracle on the 50M graph"
+    assert np.array_equal(fg.count, cnt), "tallies differ from the oracle on the 50M graph"
+    assert fg.count.min() >= 0 and fg.count.max() <= 1
+
+    fg.learn(0, 1, 1e-3, 0.95, 2, 0.01, 1)
+    og.learn_dev(order, ps, vv, ve, wv, 1e-3, 2, 0.01, 1, False, 20240603, 2)
+    assert np.array_equal(fg.weight_value[0], wv)
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    assert np.isfinite(fg.weight_value[0]).all()
+
+    # determinism: a second handle with the same seed repeats the trajectory
+    ns2, fg2 = session(lr50m, seed=20240603, head_by_vid=True)
+    fg2.inference(1, 1, True)
+    fg2.learn(0, 1, 1e-3, 0.95, 2, 0.01, 1)
+    assert np.array_equal(fg2.var_value, fg.var_value) and np.array_equal(fg2.weight_value, fg.weight_value)
