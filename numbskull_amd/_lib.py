@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnumbskull_amd.so")
+LIB_PATH = os.environ.get("NSK_LIB") or os.path.join(_HERE, "libnumbskull_amd.so")   # NSK_LIB: ablation builds (tools/)
 
 OK, E_INVALID, E_FACTOR_FUNC, E_INDEX, E_DEVICE, E_RANGE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 FLAG_HEAD_BY_VID = 1

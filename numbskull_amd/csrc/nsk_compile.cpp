@@ -1085,46 +1085,6 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             c.phase_rest_base[k + 1] = (int64_t)c.rest_tiles.size();
         }
         if (c.rest_tiles.empty()) c.rest_tiles.push_back(0);
-        // learning launches: segments grouped by (kind, chunks) into tables of <= 8, the
-        // NSK_LEARN_SEG_LAUNCHES largest tables of a colour become launches, the tiles of the
-        // others join the colour's rest list
-        c.phase_learn_rest_base.assign((size_t)ncolors + 1, 0);
-        for (int32_t k = 0; k < ncolors; k++) {
-            std::vector<Compiled::SegLaunch> tabs;
-            for (int tab = 0; tab <= 1; tab++)
-            for (int kind = 0; kind <= 4; kind++)
-                for (int nch = 1; nch <= 2; nch++) {
-                    Compiled::SegLaunch t;
-                    memset(&t, 0, sizeof(t));
-                    t.phase = k; t.kind = kind; t.nch = nch; t.tab = tab;
-                    for (const Compiled::Segment &sg : c.segments) {
-                        if (sg.phase != k || (int)(sg.kind == 1 ? 3 : sg.kind) != kind || (sg.nslots > 4 ? 2 : 1) != nch ||
-                            (sg.ztab >= 0 ? 1 : 0) != tab)
-                            continue;
-                        t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
-                        t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
-                        t.zmask[t.n] = (1u << sg.nslots) - 1u;
-                        t.ev[t.n] = sg.ev;
-                        t.tile_start[t.n + 1] = t.tile_start[t.n] + sg.ntiles;
-                        if (++t.n == 8) { tabs.push_back(t); t.n = 0; t.tile_start[0] = 0; }
-                    }
-                    if (t.n) tabs.push_back(t);
-                }
-            std::stable_sort(tabs.begin(), tabs.end(), [](const Compiled::SegLaunch &a, const Compiled::SegLaunch &b) {
-                return a.tile_start[a.n] > b.tile_start[b.n]; });
-            std::vector<uint32_t> extra;
-            for (size_t i = 0; i < tabs.size(); i++) {
-                if (i < NSK_LEARN_SEG_LAUNCHES && !getenv("NSK_NO_LEARN_SEG")) { c.learn_seg.push_back(tabs[i]); continue; }
-                for (int j = 0; j < tabs[i].n; j++)
-                    for (int32_t t = 0; t < tabs[i].tile_start[j + 1] - tabs[i].tile_start[j]; t++)
-                        extra.push_back((uint32_t)((tabs[i].pos0[j] - c.phase_start[k]) / 64 + t));
-            }
-            for (int64_t i = c.phase_rest_base[k]; i < c.phase_rest_base[k + 1]; i++) extra.push_back(c.rest_tiles[i]);
-            std::sort(extra.begin(), extra.end());
-            c.learn_rest_tiles.insert(c.learn_rest_tiles.end(), extra.begin(), extra.end());
-            c.phase_learn_rest_base[k + 1] = (int64_t)c.learn_rest_tiles.size();
-        }
-        if (c.learn_rest_tiles.empty()) c.learn_rest_tiles.push_back(0);
         if (getenv("NSK_VERBOSE")) {                 // layout report: tiles by kind, per colour
             for (int32_t k = 0; k < ncolors; k++) {
                 int64_t kinds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1218,6 +1178,94 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int64_t x : nfast_part) c.nfast += x;
     }
     lap("tile fill (pass 2)");
+    // ---- compact twin of the table segments' streams: member ids as int16 deltas from the lane's
+    // own variable id (8 bytes per lane instead of 16 for <= 4 slots), for segments whose every
+    // delta fits.  The table kernels read this stream; the 32-bit stream stays for the kernels that
+    // run when the draw tables cannot be used (values outside their domains on the device).
+    {
+        uint64_t units = 0;                               // 8-byte units
+        const bool no_d16 = getenv("NSK_NO_D16") != nullptr;
+        for (Compiled::Segment &sg : c.segments) {
+            sg.d16 = -1;
+            if (sg.ztab < 0 || no_d16) continue;
+            const int nch = sg.nslots > 4 ? 2 : 1;
+            bool fits = true;
+            for (int64_t t = 0; t < sg.ntiles && fits; t++)
+                for (int64_t i = 0; i < 64 && fits; i++) {
+                    const int64_t v = c.p_vid[sg.pos0 + 64 * t + i];
+                    if (v < 0) continue;
+                    for (uint32_t j = 0; j < sg.nslots; j++) {
+                        const int64_t id = c.adj[((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4 + 256 * (j / 4) + 4 * i + (j % 4)];
+                        if (id - v < -32768 || id - v > 32767) { fits = false; break; }
+                    }
+                }
+            if (!fits) continue;
+            sg.d16 = (int64_t)units;
+            units += (uint64_t)sg.ntiles * 64 * nch;
+        }
+        if (units >= ((uint64_t)1 << 31)) { err = "compact stream too large"; return NSK_E_RANGE; }
+        c.adj16.assign((size_t)units * 2 + 2, 0u);
+        for (const Compiled::Segment &sg : c.segments) {
+            if (sg.d16 < 0) continue;
+            const int nch = sg.nslots > 4 ? 2 : 1;
+            parallel_for(sg.ntiles, [&](int64_t tb0, int64_t tb1, int) {
+                for (int64_t t = tb0; t < tb1; t++)
+                    for (int64_t i = 0; i < 64; i++) {
+                        const int64_t v = c.p_vid[sg.pos0 + 64 * t + i];
+                        if (v < 0) continue;
+                        uint16_t *out = (uint16_t *)&c.adj16[((uint64_t)sg.d16 + ((uint64_t)t * 64 + i) * nch) * 2];
+                        for (uint32_t j = 0; j < sg.nslots; j++) {
+                            const int64_t id = c.adj[((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4 + 256 * (j / 4) + 4 * i + (j % 4)];
+                            out[j] = (uint16_t)(int16_t)(id - v);
+                        }
+                    }
+            });
+        }
+    }
+    lap("compact streams");
+    {
+    // learning launches: segments grouped by (kind, chunks) into tables of <= 8, the
+    // NSK_LEARN_SEG_LAUNCHES largest tables of a colour become launches, the tiles of the
+    // others join the colour's rest list
+    c.phase_learn_rest_base.assign((size_t)ncolors + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++) {
+        std::vector<Compiled::SegLaunch> tabs;
+        for (int tab = 0; tab <= 2; tab++)                  // 0 no draw table, 1 table, 2 table + compact stream
+        for (int kind = 0; kind <= 4; kind++)
+            for (int nch = 1; nch <= 2; nch++) {
+                Compiled::SegLaunch t;
+                memset(&t, 0, sizeof(t));
+                t.phase = k; t.kind = kind; t.nch = nch; t.tab = tab > 0; t.d16 = tab == 2;
+                for (const Compiled::Segment &sg : c.segments) {
+                    if (sg.phase != k || (int)(sg.kind == 1 ? 3 : sg.kind) != kind || (sg.nslots > 4 ? 2 : 1) != nch ||
+                        (sg.ztab < 0 ? 0 : sg.d16 < 0 ? 1 : 2) != tab)
+                        continue;
+                    t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
+                    t.d16off[t.n] = sg.d16 >= 0 ? (uint32_t)sg.d16 : 0u;
+                    t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
+                    t.zmask[t.n] = (1u << sg.nslots) - 1u;
+                    t.ev[t.n] = sg.ev;
+                    t.tile_start[t.n + 1] = t.tile_start[t.n] + sg.ntiles;
+                    if (++t.n == 8) { tabs.push_back(t); t.n = 0; t.tile_start[0] = 0; }
+                }
+                if (t.n) tabs.push_back(t);
+            }
+        std::stable_sort(tabs.begin(), tabs.end(), [](const Compiled::SegLaunch &a, const Compiled::SegLaunch &b) {
+            return a.tile_start[a.n] > b.tile_start[b.n]; });
+        std::vector<uint32_t> extra;
+        for (size_t i = 0; i < tabs.size(); i++) {
+            if (i < NSK_LEARN_SEG_LAUNCHES && !getenv("NSK_NO_LEARN_SEG")) { c.learn_seg.push_back(tabs[i]); continue; }
+            for (int j = 0; j < tabs[i].n; j++)
+                for (int32_t t = 0; t < tabs[i].tile_start[j + 1] - tabs[i].tile_start[j]; t++)
+                    extra.push_back((uint32_t)((tabs[i].pos0[j] - c.phase_start[k]) / 64 + t));
+        }
+        for (int64_t i = c.phase_rest_base[k]; i < c.phase_rest_base[k + 1]; i++) extra.push_back(c.rest_tiles[i]);
+        std::sort(extra.begin(), extra.end());
+        c.learn_rest_tiles.insert(c.learn_rest_tiles.end(), extra.begin(), extra.end());
+        c.phase_learn_rest_base[k + 1] = (int64_t)c.learn_rest_tiles.size();
+    }
+    if (c.learn_rest_tiles.empty()) c.learn_rest_tiles.push_back(0);
+    }
     // per position: first slot and first list entry (exclusive prefix sums of the per-position counts)
     std::vector<int64_t> pos_si((size_t)c.npos + 1, 0), pos_li((size_t)c.npos + 1, 0);
     parallel_for(c.npos, [&](int64_t pb0, int64_t pb1, int) {
@@ -1412,6 +1460,12 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             lay_inf += (double)distinct * s_v + (double)(nfastpos + ncatpos) * s_v + 2.0 * nfastpos + 2.0 * s_c * ncatpos;
             lay_learn += 2.0 * distinct * s_v + 2.0 * (nfastpos + ncatpos) * s_v;
         }
+        for (const Compiled::Segment &sg : c.segments)      // table segments read the compact stream
+            if (sg.d16 >= 0) {
+                const double saved = (double)sg.ntiles * 64 * 8 * (sg.nslots > 4 ? 2 : 1);
+                lay_inf -= saved;
+                lay_learn -= saved;
+            }
         c.layout_bytes_inference = lay_inf;
         c.layout_bytes_learning = lay_learn;
     }

@@ -44,6 +44,7 @@ struct Compiled {
     std::vector<uint32_t> tile_wrow;       // [nwb]
     int64_t nwrows = 0;
     std::vector<uint32_t> adj;             // inlined adjacency words (DESIGN.md "fast path")
+    std::vector<uint32_t> adj16;           // compact twin of the table segments' streams: int16 deltas
     // A tile whose 64 lanes share one header sequence (same function, member count and weight per
     // entry) with at most 8 member slots is "uniform": its stream holds member words only and its
     // per-slot program (weight id, function code, first/last/ignore flags; nsk_compile.cpp) is kept
@@ -58,7 +59,8 @@ struct Compiled {
     // kernel per segment with the tile description in kernel arguments; the tiles outside any
     // segment (rest_tiles, per phase) go through the descriptor-driven kernel.
     struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev;
-                     int64_t ztab; };      // ztab: first entry of the program's draw table, -1 = none
+                     int64_t ztab;         // first entry of the program's draw table, -1 = none
+                     int64_t d16; };       // first 8-byte unit of the compact (int16 delta) stream, -1 = none
     std::vector<Segment> segments;
     // Draw tables (DESIGN.md "draw tables"): a uniform program whose lanes read binary members only
     // has 2^nslots possible neighbourhoods; per neighbourhood the draw threshold and the per-slot
@@ -71,8 +73,8 @@ struct Compiled {
     // learning: the largest (kind, chunks) groups of a colour's segments run as segment launches of
     // their own (at most NSK_LEARN_SEG_LAUNCHES per colour); every other non-general tile is on
     // the colour's learn_rest list
-    struct SegLaunch { int32_t phase, kind, nch, n, tab; int32_t tile_start[9]; int32_t pos0[8];
-                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8]; int32_t ev[8]; };
+    struct SegLaunch { int32_t phase, kind, nch, n, tab, d16; int32_t tile_start[9]; int32_t pos0[8];
+                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], d16off[8]; int32_t ev[8]; };
     std::vector<SegLaunch> learn_seg;
     std::vector<uint32_t> learn_rest_tiles;
     std::vector<int64_t> phase_learn_rest_base;   // [ncolors+1]

@@ -197,6 +197,8 @@ struct DevGraph {
                                 //  refreshed by k_refresh_prog_weights whenever weights change
     uint8_t *cnt_pos;           // [npos] tally delta of binary fast-path variables, by position
                                 //        (folded into the int64 master copy every 255 sweeps)
+    const uint2 *adj16;         // compact streams of table segments: member ids as int16 deltas from
+                                //  the lane's own variable id, 4 per 8-byte unit
     const uint4 *ztab;          // draw tables of the uniform programs whose members are all binary:
                                 //  entry (program, neighbourhood bits) = {K lo, K hi, sat0 | sat1 << 8, 0}
                                 //  (k_refresh_ztab; DESIGN.md "draw tables")

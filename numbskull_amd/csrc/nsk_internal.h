@@ -53,6 +53,7 @@ struct nsk_graph {
     double *prog_w = nullptr, *adj_wt = nullptr;
     uint32_t *tile_wrow = nullptr;
     uint4 *ztab = nullptr;              // draw tables (k_refresh_ztab)
+    uint32_t *adj16 = nullptr;          // compact streams of table segments
     nsk::ZProgDev *zprogs = nullptr;
     bool values_regular = true;         // every value on the device lies in [0, cardinality): the
                                         // table kernels index with the neighbours' low bits
@@ -108,6 +109,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.packed_grad = g->c.packed_grad ? 1 : 0;
     d.cnt_pos = g->cnt_pos;
     d.ztab = g->ztab;
+    d.adj16 = (const uint2 *)g->adj16;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
     return d;

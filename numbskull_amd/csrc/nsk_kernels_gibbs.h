@@ -354,7 +354,11 @@ struct GenChain {
         const uint32_t idx = (d1 & 15u) | ((((d1 >> 7) & 3u) == 1u ? 1u : 0u) << 4) | (nomember << 5) |
                              ((allnz ? 1u : 0u) << 6) | ((prevall ? 1u : 0u) << 7) | ((any1 ? 1u : 0u) << 8) |
                              ((alleq ? 1u : 0u) << 9) | ((lastnz ? 1u : 0u) << 10);
+#ifdef NSK_ABL_NOLUT
+        const uint32_t e = idx & 0x3Fu;
+#else
         const uint32_t e = lut[idx];
+#endif
         A = (int)(e & 3u) - 1;
         B = (int)((e >> 2) & 3u) - 1;
         const uint32_t sel = e >> 4;                    // cstar: 0, 1, first member's value, own dense_equal_to
@@ -461,7 +465,11 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
         for (int i = 0; i < 4 * NSK_GEN_GROUP; i++) {
             xa[i] = 0; xb[i] = 0;
             if ((role[i] & 1u) && WMODE != 2) {
+#ifdef NSK_ABL_NOGATHER
+                const double x = 1.0; entry++;
+#else
                 const double x = WMODE == 1 ? wt[(size_t)(entry++) * 64] : g.w[wd[i]];
+#endif
 #pragma unroll
                 for (int j = 0; j < NSK_GEN_GROUP * 2; j++) if (j == nwv) wv[j] = x;
                 nwv++;
@@ -469,8 +477,12 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
             if (role[i] & 16u) {
                 const uint32_t id = wd[i] & NSK_GEN_NULL;
                 const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
+#ifdef NSK_ABL_NOGATHER
+                xa[i] = (int)(at & 1u); if (TWO) xb[i] = (int)(at & 1u);
+#else
                 xa[i] = (int)va[at];
                 if (TWO) xb[i] = (int)vb[at];
+#endif
             }
         }
         int iwv = 0;
@@ -559,16 +571,26 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
         a.close(d1, lut, cstar, A, B);
         pot.add(maxcard, d1, w, cstar, A, B);
     };
+#ifdef NSK_ABL_NOWALK
+    if (len < 0)
+#else
     if ((tdw >> 19) & 1u)                      // materialised weight rows (large weight tables)
+#endif
         general_walk<VT, false, 1, true>(g, g.val, g.val, sp, len, prog,
                                    g.adj_wt + (size_t)wrow * 64 + (threadIdx.x & 63), on_entry);
+#ifndef NSK_ABL_NOWALK
     else
         general_walk<VT, false, 0, true>(g, g.val, g.val, sp, len, prog, nullptr, on_entry);
+#endif
     const int ev = NSK_INFO_EV(info);
     if (!valid || !(ev == 0 || sample_evidence)) return;
     const int card = NSK_INFO_CARD(info);
+#ifdef NSK_ABL_NODRAW
+    const int nv = pot.p[0] > pot.p[1] ? 0 : 1;
+#else
     const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
     const int nv = pot.draw(maxcard, card, u53(rr.x, rr.y));
+#endif
     g.val[v] = (VT)nv;
     if (!burnin) {
         if (card == 2) g.cnt_pos[p] = (uint8_t)(g.cnt_pos[p] + nv);
@@ -699,7 +721,24 @@ struct SegTable {
     uint32_t zoff[NSK_SEG_MAX];           // draw-table launches: first entry of the program's table,
     uint32_t zmask[NSK_SEG_MAX];          //   (1 << member slots) - 1
     int ev[NSK_SEG_MAX];                  // the segment's common isEvidence (learning launches)
+    uint32_t d16off[NSK_SEG_MAX];         // compact-stream launches: first 8-byte unit of the segment
 };
+
+// member ids of one lane from the compact stream: the lane's 4 * NCH int16 deltas (2 * NCH raw
+// words, loaded early) added to its own variable id
+template <int NCH>
+__device__ __forceinline__ void d16_load(const uint2 *base, int lane_unit, uint32_t (&w)[2 * NCH]) {
+    if (NCH == 1) { const uint2 q = base[lane_unit]; w[0] = q.x; w[1] = q.y; }
+    else { const uint4 q = ((const uint4 *)base)[lane_unit]; w[0] = q.x; w[1] = q.y; w[2 * NCH - 2] = q.z; w[2 * NCH - 1] = q.w; }
+}
+template <int NCH>
+__device__ __forceinline__ void d16_ids(const uint32_t (&w)[2 * NCH], int vb, uint32_t (&id)[4 * NCH]) {
+#pragma unroll
+    for (int j = 0; j < 2 * NCH; j++) {
+        id[2 * j] = (uint32_t)(vb + (int)(int16_t)(w[j] & 0xFFFFu));
+        id[2 * j + 1] = (uint32_t)(vb + ((int)w[j] >> 16));
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Draw tables.  For a uniform program whose lanes read binary members only, the potentials of the
@@ -798,7 +837,7 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
 // launch at once: all their loads are issued before the first dependent gather, which is what
 // keeps enough bytes in flight per SIMD (one tile per wave: 28.6 us per 10M-grid class at full
 // occupancy, two thirds of the wave-cycles waiting).
-template <typename VT, int NCH, int TPW>
+template <typename VT, int NCH, int TPW, bool D16>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int nblocks,
                                                              int burnin, uint32_t k0, uint32_t k1,
                                                              uint32_t s0, uint32_t s1) {
@@ -810,9 +849,10 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     if (T0 >= ntiles) return;
     int p[TPW], v[TPW];
     uint8_t tally[TPW];
-    uint4 q[TPW][NCH];
+    uint32_t id[TPW][4 * NCH];
     uint32_t zoff[TPW], zmask[TPW];
     bool live[TPW];
+    uint32_t w16[TPW][2 * NCH];
 #pragma unroll
     for (int k = 0; k < TPW; k++) {
         const int T = min(T0 + k, ntiles - 1);                // wave-uniform; a clamped tile is not stored
@@ -823,21 +863,29 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
         const int t = T - tab.tile_start[sidx];
         p[k] = tab.pos0[sidx] + t * 64 + lane;
         zoff[k] = tab.zoff[sidx]; zmask[k] = tab.zmask[sidx];
-        const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+        if (D16) {
+            d16_load<NCH>(g.adj16 + tab.d16off[sidx] + (size_t)t * (64 * NCH), lane, w16[k]);
+        } else {
+            const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) q[k][c] = sp[c * 64];
+            for (int c = 0; c < NCH; c++) {
+                const uint4 q = sp[c * 64];
+                id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+            }
+        }
         v[k] = g.p_vid[p[k]];                                 // -1: padding lane at a class end
         tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[p[k]];
+    }
+    if (D16) {
+#pragma unroll
+        for (int k = 0; k < TPW; k++) d16_ids<NCH>(w16[k], max(v[k], 0), id[k]);
     }
     uint32_t idx[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; k++) {
         uint32_t x[4 * NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            x[4 * c] = (uint32_t)g.val[q[k][c].x]; x[4 * c + 1] = (uint32_t)g.val[q[k][c].y];
-            x[4 * c + 2] = (uint32_t)g.val[q[k][c].z]; x[4 * c + 3] = (uint32_t)g.val[q[k][c].w];
-        }
+        for (int j = 0; j < 4 * NCH; j++) x[j] = (uint32_t)g.val[id[k][j]];
         idx[k] = 0;
 #pragma unroll
         for (int j = 0; j < 4 * NCH; j++) idx[k] |= (x[j] & 1u) << j;

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
 // consecutive tiles at once (all their loads in flight before the first dependent gather); the grid
 // is sized by the host so that a wave makes one trip when the partial-sum rows are cheap (few
 // weights) and several when a block's row flush would rival its tile traffic.
-template <typename VT, bool SMALLW, int NCH, int TPW>
+template <typename VT, bool SMALLW, int NCH, int TPW, bool D16>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, SegTable tab, LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GradSink sk = open_sink<SMALLW>(g, smem);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
     for (int T0 = wave0 * TPW; T0 < ntiles; T0 += nwaves * TPW) {
         int p[TPW], v[TPW], ev[TPW], init[TPW];
         bool valid[TPW];
-        uint4 q[TPW][NCH];
+        uint32_t id[TPW][4 * NCH], w16[TPW][2 * NCH];
         uint32_t zoff[TPW], zmask[TPW], prog[TPW];
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
@@ -590,27 +590,34 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             const int t = T - tab.tile_start[sidx];
             p[k] = tab.pos0[sidx] + t * 64 + lane;
             zoff[k] = tab.zoff[sidx]; zmask[k] = tab.zmask[sidx]; prog[k] = tab.prog[sidx];
-            const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+            if (D16) {
+                d16_load<NCH>(g.adj16 + tab.d16off[sidx] + (size_t)t * (64 * NCH), lane, w16[k]);
+            } else {
+                const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) q[k][c] = sp[c * 64];
+                for (int c = 0; c < NCH; c++) {
+                    const uint4 q = sp[c * 64];
+                    id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+                }
+            }
             const int v0 = g.p_vid[p[k]];                            // -1: padding lane at a class end
             valid[k] = live && v0 >= 0;
             v[k] = v0 >= 0 ? v0 : 0;
             ev[k] = tab.ev[sidx];                                    // uniform over a segment
             init[k] = ev[k] == 1 ? (int)g.p_init[p[k]] : 0;
         }
+        if (D16) {
+#pragma unroll
+            for (int k = 0; k < TPW; k++) d16_ids<NCH>(w16[k], v[k], id[k]);
+        }
         uint32_t idf[TPW], ide[TPW];
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             uint32_t xf[4 * NCH], xe[4 * NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const uint32_t wd[4] = {q[k][c].x, q[k][c].y, q[k][c].z, q[k][c].w};
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    xf[4 * c + i] = (uint32_t)g.val[wd[i]];
-                    xe[4 * c + i] = (uint32_t)g.val_evid[wd[i]];
-                }
+            for (int j = 0; j < 4 * NCH; j++) {
+                xf[j] = (uint32_t)g.val[id[k][j]];
+                xe[j] = (uint32_t)g.val_evid[id[k][j]];
             }
             idf[k] = 0; ide[k] = 0;
 #pragma unroll

@@ -94,14 +94,16 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 for (int i = 0; i <= NSK_SEG_MAX; i++) tab.tile_start[i] = sl.tile_start[i];
                 for (int i = 0; i < NSK_SEG_MAX; i++) {
                     tab.pos0[i] = sl.pos0[i]; tab.adj_off[i] = sl.adj_off[i]; tab.prog[i] = sl.prog[i];
-                    tab.zoff[i] = sl.zoff[i]; tab.zmask[i] = sl.zmask[i]; tab.ev[i] = sl.ev[i];
+                    tab.zoff[i] = sl.zoff[i]; tab.zmask[i] = sl.zmask[i]; tab.ev[i] = sl.ev[i]; tab.d16off[i] = sl.d16off[i];
                 }
                 const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
                 lp.row_base = rows;
 #define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
                 if (sl.tab && g->values_regular) {
-                    if (sl.nch == 1) k_learn_seg_tab<VT, SMALLW, 1, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp);
-                    else k_learn_seg_tab<VT, SMALLW, 2, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp);
+#define NSK_LTAB(NCH, D16) k_learn_seg_tab<VT, SMALLW, NCH, 2, D16><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
+                    if (sl.d16) { if (sl.nch == 1) NSK_LTAB(1, true); else NSK_LTAB(2, true); }
+                    else { if (sl.nch == 1) NSK_LTAB(1, false); else NSK_LTAB(2, false); }
+#undef NSK_LTAB
                 }
                 else if (sl.kind == 4) { if (sl.nch == 1) NSK_LSEG(4, 1); else NSK_LSEG(4, 2); }
                 else if (sl.kind == 2) { if (sl.nch == 1) NSK_LSEG(2, 1); else NSK_LSEG(2, 2); }
