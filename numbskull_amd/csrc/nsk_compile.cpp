@@ -886,6 +886,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         E = std::max(E, ne);
                         maxcard = std::max(maxcard, (uint32_t)d->variable[c.p_vid[p]].cardinality);
                     }
+                    // the walk is specialised on M and eats whole 16-byte chunks: E is a multiple of
+                    // the entries per super-group (general_walk_m, nsk_kernels_gibbs.h)
+                    const uint32_t EG = ((2 + M) % 4 == 0) ? 1u : ((2 + M) % 2 == 0) ? 2u : 4u;
+                    E = (E + EG - 1) / EG * EG;
                     ts.cls = 1; ts.nkey = 2; ts.key[0] = E; ts.key[1] = M;
                     ts.len = (int32_t)(E * (2 + M));
                     ts.flags = (uint32_t)ts.len | (6u << 8) | (maxcard << 12) | (M << 16);

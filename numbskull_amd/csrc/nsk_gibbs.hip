@@ -154,6 +154,12 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
     return NSK_OK;
 }
 
+#ifdef NSK_ABL_TIMING
+extern "C" int nsk_debug_dump(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk::nsk_dbg), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+
 extern "C" int nsk_gibbs_sweeps(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");

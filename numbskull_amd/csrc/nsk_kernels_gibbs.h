@@ -329,6 +329,9 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_shape_weights(cons
 #define NSK_GEN_NULL 0x7FFFFFFu
 #endif
 #define NSK_GEN_GROUP 2
+#ifndef NSK_GEN_AHEAD_MAX
+#define NSK_GEN_AHEAD_MAX 3
+#endif
 struct GenChain {
     bool allnz, prevall, any1, alleq, lastnz;
     int first;
@@ -415,14 +418,80 @@ __device__ __forceinline__ void load_gen_lut(uint8_t *lds) {
     __syncthreads();
 }
 
-// Walk a general tile over one (TWO = false) or two value arrays; on_entry(weight id, descriptor,
-// chain a, chain b) runs at every entry end -- wave-uniform control flow, so it may use wave
-// collectives.  The next 16-byte chunk is requested before the gathers of the current one.
+// Walk a general tile over one (TWO = false) or two value arrays; on_entry(weight id, weight,
+// descriptor, chain a, chain b) runs at every entry end, in list order -- wave-uniform control flow,
+// so it may use wave collectives.
 // WMODE: where an entry's weight comes from -- 0 gathered from g.w, 1 the tile's materialised weight
-// rows (wt = this lane's column), 2 not needed (0.0).  Weights are requested with the group's
-// member gathers, not when the entry ends.
+// rows (wt = this lane's column), 2 not needed (0.0).
+// The tile's layout is E entries of (weight word, descriptor word, M member slots) with E and M
+// shared by the 64 lanes (nsk_compile.cpp), so the walk is specialised on M and straight-line per
+// entry: a "super-group" of EG entries covers a whole number CG of 16-byte chunks (E is padded to a
+// multiple of EG by the compiler).  Per super-group: the chunks arrive (the next super-group's are
+// requested first), then every weight and member gather is issued, then the entries are closed.
+// (The first general kernels decoded a per-word role program with scalar branches: 53 VALU + 38
+// SALU instructions per stream word, which made the launch instruction-issue bound.)
+template <typename VT, bool TWO, int WMODE, bool NT, int M, typename FN>
+__device__ __forceinline__ void general_walk_m(const DevGraph<VT> &g, const VT *va, const VT *vb,
+                                               const uint4 *sp, int E, const double *wt, FN &&on_entry) {
+    constexpr int W = 2 + M;
+    constexpr int EG = (W % 4 == 0) ? 1 : (W % 2 == 0) ? 2 : 4;      // entries per super-group
+    constexpr int CG = W * EG / 4;                                    // 16-byte chunks per super-group
+    auto load_sg = [&](int e0, uint4 (&q)[CG]) {
+#pragma unroll
+        for (int j = 0; j < CG; j++) {
+            const uint4 *at = sp + (size_t)((e0 / EG) * CG + j) * 64;
+            q[j] = NT ? stream_load(at) : *at;                        // NT: the tile is read once (inference)
+        }
+    };
+    // (the next super-group is requested ahead only while that costs few registers: at CG >= 5 the
+    // second buffer would push the kernel from 4 to 3 waves per SIMD)
+    constexpr bool AHEAD = CG <= NSK_GEN_AHEAD_MAX;
+    uint4 qn[CG];
+    if (AHEAD && E > 0) load_sg(0, qn);
+    for (int e0 = 0; e0 < E; e0 += EG) {
+        if (!AHEAD) load_sg(e0, qn);
+        uint32_t wd[W * EG];
+#pragma unroll
+        for (int j = 0; j < CG; j++) {
+            wd[4 * j] = qn[j].x; wd[4 * j + 1] = qn[j].y; wd[4 * j + 2] = qn[j].z; wd[4 * j + 3] = qn[j].w;
+        }
+        if (AHEAD && e0 + EG < E) load_sg(e0 + EG, qn);
+        double wv[EG];
+        int xa[EG * (M > 0 ? M : 1)], xb[EG * (M > 0 ? M : 1)];
+#pragma unroll
+        for (int j = 0; j < EG; j++) {
+            wv[j] = WMODE == 0 ? g.w[wd[j * W]] : (WMODE == 1 ? wt[(size_t)(e0 + j) * 64] : 0.0);
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t id = wd[j * W + 2 + m] & NSK_GEN_NULL;
+                const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
+                xa[j * M + m] = (int)va[at];
+                xb[j * M + m] = TWO ? (int)vb[at] : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < EG; j++) {
+            const uint32_t d1 = wd[j * W + 1];
+            const bool cat = (d1 & 15u) >= 6u;
+            GenChain a, b;
+            a.open();
+            if (TWO) b.open();
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                a.member(m == 0, cat, wd[j * W + 2 + m], xa[j * M + m]);
+                if (TWO) b.member(m == 0, cat, wd[j * W + 2 + m], xb[j * M + m]);
+            }
+            on_entry(wd[j * W], wv[j], d1, a, b);
+        }
+    }
+}
+
+// Entries with more than 3 other members (factors of arity >= 5 over small-domain variables) are
+// rare; their tiles take the role-program walk: one scalar role word per stream word (tile_hdr)
+// drives the same chain updates.  Keeping them out of the specialised walk keeps its register
+// count at the M <= 3 instantiations'.
 template <typename VT, bool TWO, int WMODE, bool NT, typename FN>
-__device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va, const VT *vb,
+__device__ __forceinline__ void general_walk_roles(const DevGraph<VT> &g, const VT *va, const VT *vb,
                                              const uint4 *sp, int len, uint32_t prog, const double *wt,
                                              FN &&on_entry) {
     const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
@@ -465,11 +534,7 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
         for (int i = 0; i < 4 * NSK_GEN_GROUP; i++) {
             xa[i] = 0; xb[i] = 0;
             if ((role[i] & 1u) && WMODE != 2) {
-#ifdef NSK_ABL_NOGATHER
-                const double x = 1.0; entry++;
-#else
                 const double x = WMODE == 1 ? wt[(size_t)(entry++) * 64] : g.w[wd[i]];
-#endif
 #pragma unroll
                 for (int j = 0; j < NSK_GEN_GROUP * 2; j++) if (j == nwv) wv[j] = x;
                 nwv++;
@@ -477,12 +542,8 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
             if (role[i] & 16u) {
                 const uint32_t id = wd[i] & NSK_GEN_NULL;
                 const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
-#ifdef NSK_ABL_NOGATHER
-                xa[i] = (int)(at & 1u); if (TWO) xb[i] = (int)(at & 1u);
-#else
                 xa[i] = (int)va[at];
                 if (TWO) xb[i] = (int)vb[at];
-#endif
             }
         }
         int iwv = 0;
@@ -507,6 +568,23 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
                 if (role[i] & 4u) on_entry(wid, w, d1, a, b);
             }
         }
+    }
+}
+
+
+// `len` = E * (2 + M) words, M = member slots per entry (tile descriptor bits 16..18)
+template <typename VT, bool TWO, int WMODE, bool NT, typename FN>
+__device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va, const VT *vb,
+                                             const uint4 *sp, int len, int M, uint32_t prog, const double *wt,
+                                             FN &&on_entry) {
+    if (len <= 0) return;
+    const int E = len / (2 + M);
+    switch (M) {                                                       // wave-uniform
+    case 0: general_walk_m<VT, TWO, WMODE, NT, 0>(g, va, vb, sp, E, wt, on_entry); break;
+    case 1: general_walk_m<VT, TWO, WMODE, NT, 1>(g, va, vb, sp, E, wt, on_entry); break;
+    case 2: general_walk_m<VT, TWO, WMODE, NT, 2>(g, va, vb, sp, E, wt, on_entry); break;
+    case 3: general_walk_m<VT, TWO, WMODE, NT, 3>(g, va, vb, sp, E, wt, on_entry); break;
+    default: general_walk_roles<VT, TWO, WMODE, NT>(g, va, vb, sp, len, prog, wt, on_entry); break;
     }
 }
 
@@ -555,6 +633,11 @@ struct GenPot {
     }
 };
 
+#ifdef NSK_ABL_TIMING
+// instrumented build (tools/build_ablations.sh TIMING): per general tile {start, after walk, end, len}
+static __device__ unsigned long long nsk_dbg[4 * 65536];
+#endif
+
 template <typename VT, int MAXC>
 __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const uint8_t *lut, const uint4 *sp,
                                                    uint32_t tdw, uint32_t prog, uint32_t wrow, int p, bool valid,
@@ -562,6 +645,9 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
                                                    int burnin, uint32_t k0, uint32_t k1, uint32_t s0,
                                                    uint32_t s1) {
     const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
+#ifdef NSK_ABL_TIMING
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int v = valid ? g.p_vid[p] : 0;
     const uint32_t info = valid ? g.p_info[p] : (2u << 9);
     GenPot<MAXC> pot;
@@ -576,13 +662,16 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
 #else
     if ((tdw >> 19) & 1u)                      // materialised weight rows (large weight tables)
 #endif
-        general_walk<VT, false, 1, true>(g, g.val, g.val, sp, len, prog,
+        general_walk<VT, false, 1, true>(g, g.val, g.val, sp, len, (int)((tdw >> 16) & 7u), prog,
                                    g.adj_wt + (size_t)wrow * 64 + (threadIdx.x & 63), on_entry);
 #ifndef NSK_ABL_NOWALK
     else
-        general_walk<VT, false, 0, true>(g, g.val, g.val, sp, len, prog, nullptr, on_entry);
+        general_walk<VT, false, 0, true>(g, g.val, g.val, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr, on_entry);
 #endif
     const int ev = NSK_INFO_EV(info);
+#ifdef NSK_ABL_TIMING
+    const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime() + (unsigned long long)(pot.p[0] == 12345.678 ? 1 : 0);
+#endif
     if (!valid || !(ev == 0 || sample_evidence)) return;
     const int card = NSK_INFO_CARD(info);
 #ifdef NSK_ABL_NODRAW
@@ -596,6 +685,16 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
         if (card == 2) g.cnt_pos[p] = (uint8_t)(g.cnt_pos[p] + nv);
         else g.cnt[g.p_cnt[p] + nv] += 1;
     }
+#ifdef NSK_ABL_TIMING
+    {
+        const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
+        const int slot = (p / 64) & 65535;
+        if ((threadIdx.x & 63) == 0) {
+            nsk_dbg[4 * slot] = dbg_t0; nsk_dbg[4 * slot + 1] = dbg_t1; nsk_dbg[4 * slot + 2] = dbg_t2;
+            nsk_dbg[4 * slot + 3] = (unsigned long long)len | ((unsigned long long)blockIdx.x << 32);
+        }
+    }
+#endif
 }
 
 template <typename VT>
@@ -679,7 +778,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
     load_gen_lut(lut);
     if ((int)blockIdx.x < hblocks) {                      // block-uniform
         const int hp = hb + (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+#ifndef NSK_ABL_NOHUB
         if (hp < he) heavy_update(g, hp, sample_evidence, burnin, k0, k1, s0, s1);
+#endif
         return;
     }
     const int tblocks = 8 * ((nblocks + 7) / 8);

@@ -469,7 +469,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
     GenPot<MAXC> pf, pe;
     pf.clear(); pe.clear();
     if (need_evid)
-        general_walk<VT, true, 0, false>(g, g.val, g.val_evid, sp, len, prog, nullptr,
+        general_walk<VT, true, 0, false>(g, g.val, g.val_evid, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr,
                                   [&](uint32_t, double w, uint32_t d1, const GenChain &a, const GenChain &b) {
                                       int cstar, A, B;
                                       a.close(d1, lut, cstar, A, B);
@@ -478,7 +478,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
                                       pe.add(maxcard, d1, w, cstar, A, B);
                                   });
     else
-        general_walk<VT, false, 0, false>(g, g.val, g.val, sp, len, prog, nullptr,
+        general_walk<VT, false, 0, false>(g, g.val, g.val, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr,
                                    [&](uint32_t, double w, uint32_t d1, const GenChain &a, const GenChain &) {
                                        int cstar, A, B;
                                        a.close(d1, lut, cstar, A, B);
@@ -499,7 +499,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
         truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
     }
     if (__ballot(part) == 0) return;
-    general_walk<VT, true, 2, false>(g, g.val, g.val_evid, sp, len, prog, nullptr,
+    general_walk<VT, true, 2, false>(g, g.val, g.val_evid, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr,
                            [&](uint32_t wid, double, uint32_t d1, const GenChain &a, const GenChain &b) {
                                const int ks = (int)((d1 >> 14) & 15u);
                                const bool mine = ks == 15 || ks == evidence || ks == proposal;

@@ -6,11 +6,11 @@ set -e
 cd "$(dirname "$0")/../numbskull_amd/csrc"
 mkdir -p ../variants build
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
-for v in NODRAW NOGATHER NOLUT NOWALK "$@"; do
+for v in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS -DNSK_ABL_$v -c -o build/nsk_gibbs_$v.o nsk_gibbs.hip &
 done
 wait
-for v in NODRAW NOGATHER NOLUT NOWALK "$@"; do
+for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../variants/libnsk_$v.so build/nsk_api.o build/nsk_gibbs_$v.o build/nsk_learn.o build/nsk_compile.o build/nsk_host.o
 done
 ls -la ../variants

@@ -1,0 +1,32 @@
+"""Per-tile timeline of one general-tile launch (instrumented build: tools/build_ablations.sh TIMING,
+run with NSK_LIB=numbskull_amd/variants/libnsk_TIMING.so)."""
+import ctypes as C, io, sys, os
+from contextlib import redirect_stdout
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import numbskull_amd
+from numbskull_amd import graphgen, _lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+g = graphgen.mixed_lr_graph(n, seed=20240603)
+ns = numbskull_amd.NumbSkull(quiet=True, seed=1, head_by_vid=True)
+with redirect_stdout(io.StringIO()):
+    ns.loadFactorGraph(*g[:5], int(g[5]))
+fg = ns.factorGraphs[0]
+L, h = _lib.lib(), fg._engine()
+_lib.check(L.nsk_gibbs_sweeps(h, 5, 1, 0))
+torch.cuda.synchronize()
+buf = np.zeros(4 * 65536, np.uint64)
+raw = C.CDLL(_lib.LIB_PATH)
+raw.nsk_debug_dump(C.c_void_p(buf.ctypes.data), C.c_int(len(buf)))
+b = buf.reshape(-1, 4)
+b = b[b[:, 0] > 0]
+t0, t1, t2 = b[:, 0].astype(np.int64), b[:, 1].astype(np.int64), b[:, 2].astype(np.int64)
+ln = (b[:, 3] & 0xFFFFFFFF).astype(np.int64)
+print("tiles recorded", len(b), "(last launches of the sweep; memtime ticks)")
+walk, draw = t1 - t0, t2 - t1
+for name, x in (("walk", walk), ("draw+store", draw), ("total", t2 - t0)):
+    print("%-11s mean %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f" % (name, x.mean(), np.median(x), np.percentile(x, 90), x.max()))
+for lo, hi in ((0, 16), (16, 32), (32, 48), (48, 64), (64, 96), (96, 256)):
+    m = (ln >= lo) & (ln < hi)
+    if m.any():
+        print("len %3d-%3d: %6d tiles, walk mean %8.0f ticks, per word %6.1f" % (lo, hi, m.sum(), walk[m].mean(), (walk[m] / np.maximum(ln[m], 1)).mean()))
