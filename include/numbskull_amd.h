@@ -52,6 +52,9 @@ typedef struct { int64_t value; int64_t factor_index_offset;
                                    var_value[fmap[l].vid] instead of the reference's literal
                                    var_value[l] (inference.py:243,277,292)                        */
 
+#define NSK_FLAG_PARTITION 2    /* [own_begin, own_end) is this handle's shard even when it is empty;
+                                   without the flag own_begin == own_end == 0 means "the whole graph" */
+
 /* scan orders (nsk_set_scan) */
 #define NSK_SCAN_CHROMATIC 0    /* colour classes in parallel, Philox uniforms (default)          */
 #define NSK_SCAN_SEQUENTIAL 1   /* one lane, variable-id order, MT19937: the reference's own
@@ -126,6 +129,11 @@ typedef struct {
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);
+/* Internal numbering: the device keeps values in the order of its compiled layout (a sampled
+ * variable at its position, the others after them).  iid[v] (nvar entries, may be NULL) = index of
+ * variable v in the NSK_BUF_VALUE / NSK_BUF_VALUE_EVID buffers, *nid = their length in elements.
+ * nsk_state_upload / nsk_state_download and the exchange lists take the caller's variable ids. */
+int nsk_graph_get_layout(nsk_graph *g, int32_t *iid, int64_t *nid);
 
 /* Host-only planning (no GPU touched): validate + colour the graph exactly as nsk_graph_create
  * would and report the colours / sizes.  `color` (nvar entries, may be NULL) gets -1 for variables
@@ -140,8 +148,8 @@ int nsk_profile_begin(nsk_graph *g);
 int nsk_profile_end(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches);
 
 /* Multi-GPU plumbing: raw device addresses of the value arrays (element size = value_bytes,
- * indexed by variable id) so the host can all-gather owned slices with RCCL, and the stream the
- * library launches on. */
+ * indexed by INTERNAL id, see nsk_graph_get_layout), of the weights and of the boundary staging
+ * buffers, and the stream the library launches on. */
 #define NSK_BUF_VALUE 0
 #define NSK_BUF_VALUE_EVID 1
 #define NSK_BUF_WEIGHT 2

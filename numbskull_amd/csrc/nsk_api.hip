@@ -156,8 +156,10 @@ int nsk_ensure_generic(nsk_graph *g) {
     HIPCHECK(hipSetDevice(g->device));
 #define UP(name) do { rc = dev_upload(g, &g->name, c.name); if (rc) return rc; } while (0)
     UP(p_slot); UP(slot_off); UP(fidx); UP(gstream); UP(gs_off);
-    UP(f_rec); UP(f_feat); UP(m_rec); UP(v_card); UP(v_pos);
+    UP(f_rec); UP(f_feat); UP(m_rec); UP(v_pos);
 #undef UP
+    rc = dev_upload(g, &g->v_card, c.v_card_i); if (rc) return rc;
+    if (c.literal_heads) { rc = dev_upload(g, &g->iid_of_vid, c.iid); if (rc) return rc; }
     HIPCHECK(hipStreamSynchronize(g->stream));
     g->generic_uploaded = true;
     return NSK_OK;
@@ -202,20 +204,25 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     UP(w_fixed); UP(logtab); UP(adj); UP(adj16); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
-    const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes;
+    const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes, nid = (size_t)c.nid;
     uint8_t *tmp = nullptr;
     rc = dev_alloc(g, &tmp, npos * vb); if (rc) return rc; g->p_init = tmp;
-    rc = dev_alloc(g, &tmp, nvar * vb); if (rc) return rc; g->val = tmp;
-    rc = dev_alloc(g, &tmp, nvar * vb); if (rc) return rc; g->val_evid = tmp;
+    rc = dev_alloc(g, &tmp, nid * vb); if (rc) return rc; g->val = tmp;
+    rc = dev_alloc(g, &tmp, nid * vb); if (rc) return rc; g->val_evid = tmp;
     rc = upload_values(g, g->p_init, c.p_init.data(), npos); if (rc) return rc;
-    rc = upload_values(g, g->val, c.v_init.data(), nvar); if (rc) return rc;
-    rc = upload_values(g, g->val_evid, c.v_init.data(), nvar); if (rc) return rc;
+    {   // values live at internal ids (padding positions hold 0 and are never read as a variable)
+        std::vector<int32_t> init_i(nid, 0);
+        for (size_t v = 0; v < nvar; v++) init_i[c.iid[v]] = c.v_init[v];
+        rc = upload_values(g, g->val, init_i.data(), nid); if (rc) return rc;
+        rc = upload_values(g, g->val_evid, init_i.data(), nid); if (rc) return rc;
+    }
     rc = dev_alloc(g, &g->cnt, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_total, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos); if (rc) return rc;
     rc = dev_alloc(g, &g->prog_w, 2 * c.tile_hdr.size()); if (rc) return rc;
     rc = dev_alloc(g, &g->adj_wt, (size_t)c.nwrows * 64); if (rc) return rc;
     rc = dev_alloc(g, &g->ztab, (size_t)c.nztab); if (rc) return rc;
+    rc = dev_alloc(g, &g->sink, 1024); if (rc) return rc;
     {
         std::vector<ZProgDev> zp(c.zprogs.size());
         for (size_t i = 0; i < zp.size(); i++) zp[i] = {c.zprogs[i].prog, c.zprogs[i].nslots, c.zprogs[i].off, 0u};
@@ -376,17 +383,22 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
     std::vector<int32_t> tmp;
     for (int k = 0; k < 2; k++) {
         if (!srcs[k]) continue;
-        tmp.resize(nvar);
+        tmp.assign((size_t)g->c.nid, 0);
         bool regular = true;
         for (size_t i = 0; i < nvar; i++) {
             if (srcs[k][i] < lo || srcs[k][i] > hi)
                 return fail(NSK_E_RANGE, "variable value does not fit the device value type");
-            tmp[i] = (int32_t)srcs[k][i];
+            tmp[g->c.iid[i]] = (int32_t)srcs[k][i];                 // caller's order -> internal order
             regular = regular && srcs[k][i] >= 0 && srcs[k][i] < (int64_t)g->c.v_card[i];
         }
+        // UFO (inference.py:398-405) uses the first member's value as an index into the factor's
+        // member list: the reference reads a neighbouring factor's edge (or faults); refuse
+        if (!regular && g->c.has_ufo)
+            return fail(NSK_E_RANGE, "a variable value lies outside its domain on a graph with UFO factors "
+                                     "(the value indexes the factor's member list)");
         g->chain_regular[k] = regular;
         g->values_regular = g->chain_regular[0] && g->chain_regular[1];
-        int rc = upload_values(g, dsts[k], tmp.data(), nvar);
+        int rc = upload_values(g, dsts[k], tmp.data(), (size_t)g->c.nid);
         if (rc) return rc;
     }
     if (weight_value && g->c.nweight) {
@@ -405,17 +417,18 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
 }
 
 static int download_values(nsk_graph *g, const void *src, int64_t *dst) {
-    const size_t nvar = (size_t)g->c.nvar;
+    const size_t nvar = (size_t)g->c.nvar, nid = (size_t)g->c.nid;
+    const int32_t *iid = g->c.iid.data();                      // internal order -> caller's order
     if (g->c.vbytes == 1) {
-        std::vector<int8_t> tmp(nvar);
-        if (nvar) HIPCHECK(hipMemcpyAsync(tmp.data(), src, nvar, hipMemcpyDeviceToHost, g->stream));
+        std::vector<int8_t> tmp(nid);
+        if (nid) HIPCHECK(hipMemcpyAsync(tmp.data(), src, nid, hipMemcpyDeviceToHost, g->stream));
         HIPCHECK(hipStreamSynchronize(g->stream));
-        for (size_t i = 0; i < nvar; i++) dst[i] = tmp[i];
+        for (size_t i = 0; i < nvar; i++) dst[i] = tmp[iid[i]];
     } else {
-        std::vector<int32_t> tmp(nvar);
-        if (nvar) HIPCHECK(hipMemcpyAsync(tmp.data(), src, nvar * 4, hipMemcpyDeviceToHost, g->stream));
+        std::vector<int32_t> tmp(nid);
+        if (nid) HIPCHECK(hipMemcpyAsync(tmp.data(), src, nid * 4, hipMemcpyDeviceToHost, g->stream));
         HIPCHECK(hipStreamSynchronize(g->stream));
-        for (size_t i = 0; i < nvar; i++) dst[i] = tmp[i];
+        for (size_t i = 0; i < nvar; i++) dst[i] = tmp[iid[i]];
     }
     return NSK_OK;
 }
@@ -495,6 +508,13 @@ int nsk_graph_plan_needs(const nsk_graph_desc *desc, int64_t *count, int32_t *vi
     return NSK_OK;
 }
 
+int nsk_graph_get_layout(nsk_graph *g, int32_t *iid, int64_t *nid) {
+    if (!g) return fail(NSK_E_INVALID, "null argument");
+    if (iid && g->c.nvar) memcpy(iid, g->c.iid.data(), (size_t)g->c.nvar * sizeof(int32_t));
+    if (nid) *nid = g->c.nid;
+    return NSK_OK;
+}
+
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color) {
     if (!g || !color) return fail(NSK_E_INVALID, "null argument");
     if (g->c.nvar) memcpy(color, g->c.color.data(), (size_t)g->c.nvar * sizeof(int32_t));
@@ -524,8 +544,8 @@ int nsk_profile_end(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches) 
 int nsk_device_buffer(nsk_graph *g, int which, void **ptr, int64_t *nbytes) {
     if (!g || !ptr) return fail(NSK_E_INVALID, "null argument");
     switch (which) {
-    case NSK_BUF_VALUE: *ptr = g->val; if (nbytes) *nbytes = g->c.nvar * g->c.vbytes; return NSK_OK;
-    case NSK_BUF_VALUE_EVID: *ptr = g->val_evid; if (nbytes) *nbytes = g->c.nvar * g->c.vbytes; return NSK_OK;
+    case NSK_BUF_VALUE: *ptr = g->val; if (nbytes) *nbytes = g->c.nid * g->c.vbytes; return NSK_OK;
+    case NSK_BUF_VALUE_EVID: *ptr = g->val_evid; if (nbytes) *nbytes = g->c.nid * g->c.vbytes; return NSK_OK;
     case NSK_BUF_WEIGHT: *ptr = g->w; if (nbytes) *nbytes = g->c.nweight * 8; g->weights_exposed = true; return NSK_OK;
     case NSK_BUF_SEND: *ptr = g->x_send; if (nbytes) *nbytes = g->xslot * g->c.vbytes; return NSK_OK;
     case NSK_BUF_RECV: *ptr = g->x_recv; if (nbytes) *nbytes = g->xslot * g->c.vbytes * g->xworld; return NSK_OK;
@@ -622,6 +642,8 @@ int nsk_exchange_setup(nsk_graph *g, int world, int rank, const int32_t *send_vi
     }
     g->xworld = world; g->xrank = rank; g->xslot = slot; g->xnsend = nsend; g->xnrecv = nrecv;
     std::vector<int32_t> sv(send_vids, send_vids + nsend), rv(recv_vids, recv_vids + nrecv);
+    for (auto &x : sv) x = g->c.iid[x];                        // the kernels address values by internal id
+    for (auto &x : rv) x = g->c.iid[x];
     int rc;
     if ((rc = dev_upload(g, &g->x_send_vids, sv))) return rc;
     if ((rc = dev_upload(g, &g->x_recv_vids, rv))) return rc;

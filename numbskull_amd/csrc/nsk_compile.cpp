@@ -81,8 +81,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         return NSK_E_INVALID;
     }
     c.nvar = nvar; c.nfactor = nfac; c.nedge = nedge; c.nweight = nw; c.flags = d->flags;
+    // NSK_FLAG_PARTITION: the owned range is taken literally -- (0, 0) is an EMPTY shard (what the
+    // reference's shard formula yields for rank 0 when nvar < ranks).  Without the flag the handle
+    // samples the whole graph; a non-zero range given without the flag is honoured too (round-1 ABI).
     int64_t ob = d->own_begin, oe = d->own_end;
-    if (ob == 0 && oe == 0) oe = nvar;
+    if (!(d->flags & NSK_FLAG_PARTITION) && ob == 0 && oe == 0) oe = nvar;
     if (ob < 0 || oe > nvar || ob > oe) {
         err = "owned range outside [0, nvar]";
         return NSK_E_INVALID;
@@ -225,6 +228,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 return NSK_E_INDEX;
             }
         }
+        if (fn == 30) c.has_ufo = true;
         if (fn == 30) {   // UFO reads member (value of first member) - 1
             int64_t reach = s + d->variable[d->fmap[s].vid].cardinality - 2;
             if (reach >= nedge) { err = fmt("factor %lld: UFO member index beyond fmap", f); return NSK_E_INDEX; }
@@ -234,6 +238,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     return NSK_E_INDEX;
                 }
         }
+        if (literal_head_function(fn) && !head_by_vid) c.literal_heads = true;
         if (literal_head_function(fn) && !head_by_vid && e - 1 >= nvar) {
             err = fmt("factor %lld: the reference reads var_value[%lld] for the head of function %lld "
                       "(inference.py:243,277,292), outside the variable array; pass NSK_FLAG_HEAD_BY_VID "
@@ -501,7 +506,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         default: return -1;
         }
     };
-    const bool no_general = getenv("NSK_NO_GENERAL") != nullptr;
+    // (general-tile member words keep the id in 27 bits: positions include padding, so stay well below)
+    const bool no_general = getenv("NSK_NO_GENERAL") != nullptr || nvar >= (int64_t)100000000;
     // longer lists go to the wave-per-variable kernel: a tile is walked by one wave, so its longest
     // lane sets a serial chain of memory round trips and the longest tile the kernel's run time
     const int64_t gen_block = getenv("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(getenv("NSK_GEN_BLOCK"))) : 262144;
@@ -813,6 +819,25 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             c.v_pos[v] = (int32_t)p;
             c.nsampled++;
         }
+    }
+    // ---- internal ids: a positioned variable's id is its position; the others (ghosts, isEvidence
+    // == 4 -- read but never sampled here) follow.  Every variable id stored for the device from
+    // here on is internal (m_rec, tiles, gstream, v_card): values are kept in this order, so the
+    // stores of a colour class are contiguous and its gathers run through the other classes' ranges
+    // in step with the lanes (DESIGN.md "internal numbering").
+    c.iid.assign(nvar, -1);
+    {
+        int64_t next = c.npos;
+        for (int64_t v = 0; v < nvar; v++) c.iid[v] = c.v_pos[v] >= 0 ? c.v_pos[v] : (int32_t)next++;
+        c.nid = next;
+        if (c.nid >= LIM - 1) { err = "too many internal ids"; return NSK_E_RANGE; }
+        parallel_for(nedge, [&](int64_t lb0, int64_t lb1, int) {
+            for (int64_t l = lb0; l < lb1; l++)
+                if (c.m_rec[2 * l] >= 0) c.m_rec[2 * l] = c.iid[c.m_rec[2 * l]];
+        });
+        std::vector<int32_t> card_i((size_t)c.nid, 2);
+        for (int64_t v = 0; v < nvar; v++) card_i[c.iid[v]] = c.v_card[v];
+        c.v_card_i.swap(card_i);
     }
     lap("positions");
     // ---- inlined adjacency streams of the fast variables, one column-major tile per 64 positions
@@ -1154,7 +1179,9 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         uint32_t ne = 0;
                         for (size_t j = 0; j < words.size(); ne++) {
                             const uint32_t no = (words[j + 1] >> 4) & 7u;
-                            for (uint32_t m = 0; m < 2 + no; m++) put(words[j + m]);
+                            put(words[j]); put(words[j + 1]);
+                            for (uint32_t m = 2; m < 2 + no; m++)        // member: internal id | deo << 27
+                                put((uint32_t)c.iid[words[j + m] & NSK_GEN_NULL] | (words[j + m] & ~NSK_GEN_NULL));
                             for (uint32_t m = no; m < M; m++) put(NSK_GEN_NULL);
                             j += 2 + no;
                         }
@@ -1171,7 +1198,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         const uint32_t nother = (words[j] >> 24) & 7u;
                         if (!uniform) put(words[j]);
                         else if (nother == 0) put(0u);            // the ignored slot of a member-less entry
-                        for (uint32_t m = 1; m <= nother; m++) put(words[j + m]);
+                        for (uint32_t m = 1; m <= nother; m++) put((uint32_t)c.iid[words[j + m]]);
                         j += 1 + nother;
                     }
                     nfast_here++;
@@ -1182,29 +1209,43 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int64_t x : nfast_part) c.nfast += x;
     }
     lap("tile fill (pass 2)");
-    // ---- compact twin of the table segments' streams: member ids as int16 deltas from the lane's
-    // own variable id (8 bytes per lane instead of 16 for <= 4 slots), for segments whose every
-    // delta fits.  The table kernels read this stream; the 32-bit stream stays for the kernels that
-    // run when the draw tables cannot be used (values outside their domains on the device).
+    // ---- compact twin of the table segments' streams: member positions as int16 deltas from the
+    // lane's own position plus one base offset per segment (8 bytes per lane instead of 16 for <= 4
+    // slots), for segments whose every delta fits -- on a grid every neighbour of a class lives in
+    // the other class's range at a fixed offset +- a row.  The table kernels read this stream; the
+    // 32-bit stream stays for the kernels that run when the draw tables cannot be used (values
+    // outside their domains on the device).  Ignored slots (member-less entries) repeat the lane's
+    // first real member (their value never matters) or point at the lane itself.
     {
         uint64_t units = 0;                               // 8-byte units
         const bool no_d16 = getenv("NSK_NO_D16") != nullptr;
+        auto word_at = [&](const Compiled::Segment &sg, int nch, int64_t t, int64_t i, uint32_t j) -> int64_t {
+            return (int64_t)c.adj[((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4 + 256 * (j / 4) + 4 * i + (j % 4)];
+        };
         for (Compiled::Segment &sg : c.segments) {
-            sg.d16 = -1;
+            sg.d16 = -1; sg.d16base = 0;
             if (sg.ztab < 0 || no_d16) continue;
             const int nch = sg.nslots > 4 ? 2 : 1;
-            bool fits = true;
+            const uint32_t *pw = &c.tile_hdr[sg.prog];
+            bool fits = true, have_base = false;
+            int64_t base = 0;
             for (int64_t t = 0; t < sg.ntiles && fits; t++)
                 for (int64_t i = 0; i < 64 && fits; i++) {
-                    const int64_t v = c.p_vid[sg.pos0 + 64 * t + i];
-                    if (v < 0) continue;
+                    const int64_t pp = sg.pos0 + 64 * t + i;
+                    // (every lane, padding ones too, must be able to name SOME valid position)
+                    if (have_base && (pp + base < -32767 || pp + base > c.nid - 1 + 32767)) { fits = false; break; }
+                    if (c.p_vid[pp] < 0) continue;
                     for (uint32_t j = 0; j < sg.nslots; j++) {
-                        const int64_t id = c.adj[((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4 + 256 * (j / 4) + 4 * i + (j % 4)];
-                        if (id - v < -32768 || id - v > 32767) { fits = false; break; }
+                        if ((pw[j] >> 29) & 1u) continue;                    // ignored slot
+                        const int64_t id = word_at(sg, nch, t, i, j);
+                        if (!have_base) { base = id - pp; have_base = true; }
+                        const int64_t dl = id - (pp + base);
+                        if (dl < -32768 || dl > 32767) { fits = false; break; }
                     }
                 }
-            if (!fits) continue;
+            if (!fits || base < INT32_MIN || base > INT32_MAX) continue;
             sg.d16 = (int64_t)units;
+            sg.d16base = (int32_t)base;
             units += (uint64_t)sg.ntiles * 64 * nch;
         }
         if (units >= ((uint64_t)1 << 31)) { err = "compact stream too large"; return NSK_E_RANGE; }
@@ -1212,15 +1253,24 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (const Compiled::Segment &sg : c.segments) {
             if (sg.d16 < 0) continue;
             const int nch = sg.nslots > 4 ? 2 : 1;
+            const uint32_t *pw = &c.tile_hdr[sg.prog];
             parallel_for(sg.ntiles, [&](int64_t tb0, int64_t tb1, int) {
                 for (int64_t t = tb0; t < tb1; t++)
                     for (int64_t i = 0; i < 64; i++) {
-                        const int64_t v = c.p_vid[sg.pos0 + 64 * t + i];
-                        if (v < 0) continue;
+                        const int64_t pp = sg.pos0 + 64 * t + i;
                         uint16_t *out = (uint16_t *)&c.adj16[((uint64_t)sg.d16 + ((uint64_t)t * 64 + i) * nch) * 2];
-                        for (uint32_t j = 0; j < sg.nslots; j++) {
-                            const int64_t id = c.adj[((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4 + 256 * (j / 4) + 4 * i + (j % 4)];
-                            out[j] = (uint16_t)(int16_t)(id - v);
+                        // default (padding lanes and slots, ignored slots): the lane's first real
+                        // member, else the valid position nearest to own position + base
+                        const int64_t near = std::min<int64_t>(std::max<int64_t>(pp + sg.d16base, 0), c.nid - 1);
+                        int64_t dflt = near - (pp + sg.d16base);
+                        if (c.p_vid[pp] >= 0)
+                            for (uint32_t j = 0; j < sg.nslots; j++)
+                                if (!((pw[j] >> 29) & 1u)) { dflt = word_at(sg, nch, t, i, j) - (pp + sg.d16base); break; }
+                        for (uint32_t j = 0; j < (uint32_t)(4 * nch); j++) {
+                            int64_t dl = dflt;
+                            if (c.p_vid[pp] >= 0 && j < sg.nslots && !((pw[j] >> 29) & 1u))
+                                dl = word_at(sg, nch, t, i, j) - (pp + sg.d16base);
+                            out[j] = (uint16_t)(int16_t)dl;
                         }
                     }
             });
@@ -1234,18 +1284,27 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     c.phase_learn_rest_base.assign((size_t)ncolors + 1, 0);
     for (int32_t k = 0; k < ncolors; k++) {
         std::vector<Compiled::SegLaunch> tabs;
-        for (int tab = 0; tab <= 2; tab++)                  // 0 no draw table, 1 table, 2 table + compact stream
+        for (int tab = 0; tab <= 1; tab++)                  // 0 no draw table, 1 table (compact stream or not)
         for (int kind = 0; kind <= 4; kind++)
             for (int nch = 1; nch <= 2; nch++) {
                 Compiled::SegLaunch t;
                 memset(&t, 0, sizeof(t));
-                t.phase = k; t.kind = kind; t.nch = nch; t.tab = tab > 0; t.d16 = tab == 2;
+                t.phase = k; t.kind = tab ? 8 : kind; t.nch = nch; t.tab = tab; t.d16 = 0;
+                std::vector<const Compiled::Segment *> mine;       // largest first (seg_of_tile's first probe)
                 for (const Compiled::Segment &sg : c.segments) {
-                    if (sg.phase != k || (int)(sg.kind == 1 ? 3 : sg.kind) != kind || (sg.nslots > 4 ? 2 : 1) != nch ||
-                        (sg.ztab < 0 ? 0 : sg.d16 < 0 ? 1 : 2) != tab)
+                    // table segments of any function share a launch (the table encodes the function)
+                    if (sg.phase != k || (sg.nslots > 4 ? 2 : 1) != nch || (sg.ztab < 0 ? 0 : 1) != tab ||
+                        (tab ? kind != 0 : (int)(sg.kind == 1 ? 3 : sg.kind) != kind))
                         continue;
+                    mine.push_back(&sg);
+                }
+                std::stable_sort(mine.begin(), mine.end(), [](const Compiled::Segment *a, const Compiled::Segment *b) {
+                    return a->ntiles > b->ntiles; });
+                for (const Compiled::Segment *sgp : mine) {
+                    const Compiled::Segment &sg = *sgp;
                     t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
-                    t.d16off[t.n] = sg.d16 >= 0 ? (uint32_t)sg.d16 : 0u;
+                    t.d16off[t.n] = sg.d16 >= 0 ? (uint32_t)sg.d16 : 0xFFFFFFFFu;
+                    t.d16base[t.n] = sg.d16base;
                     t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
                     t.zmask[t.n] = (1u << sg.nslots) - 1u;
                     t.ev[t.n] = sg.ev;
@@ -1428,6 +1487,19 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         for (int64_t i = 0; i < nw && ok; i++) if (edges_of[i] >= ((int64_t)1 << 28)) ok = false;
         c.packed_grad = ok && !getenv("NSK_NO_PACKED");
+        // Q31.32 range: a class's gradient sum for weight w is at most sum over its factors of
+        // |featureValue| * (largest |value difference| of the function) * (member edges)
+        std::vector<double> gbound((size_t)nw, 0.0);
+        for (int64_t f = 0; f < nfac; f++) {
+            const nsk_factor &fa = d->factor[f];
+            if (fa.weightId < 0 || fa.weightId >= nw) continue;
+            const double ar = (double)std::max<int64_t>(fa.arity, 1);
+            const int fn = fa.factorFunction;
+            const double span = fn == 7 ? ar : fn == 8 ? std::log(ar + 1.0) : fn == 30 ? 1e6 : 2.0;
+            gbound[fa.weightId] += std::fabs(fa.featureValue) * span * ar;
+        }
+        c.grad_bound = 0.0;
+        for (int64_t i = 0; i < nw; i++) c.grad_bound = std::max(c.grad_bound, gbound[i]);
     }
     c.alg_bytes_inference = bytes_inf;
     c.alg_bytes_learning = bytes_learn;

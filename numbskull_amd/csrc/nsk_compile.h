@@ -60,7 +60,8 @@ struct Compiled {
     // segment (rest_tiles, per phase) go through the descriptor-driven kernel.
     struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev;
                      int64_t ztab;         // first entry of the program's draw table, -1 = none
-                     int64_t d16; };       // first 8-byte unit of the compact (int16 delta) stream, -1 = none
+                     int64_t d16;          // first 8-byte unit of the compact (int16 delta) stream, -1 = none
+                     int32_t d16base; };   // member position = own position + d16base + delta
     std::vector<Segment> segments;
     // Draw tables (DESIGN.md "draw tables"): a uniform program whose lanes read binary members only
     // has 2^nslots possible neighbourhoods; per neighbourhood the draw threshold and the per-slot
@@ -69,12 +70,14 @@ struct Compiled {
     std::vector<ZProg> zprogs;
     int64_t nztab = 0;                      // entries (16 bytes each)
     bool values_regular = true;             // every initial value lies in [0, cardinality)
+    bool has_ufo = false;                   // a reachable factor is UFO: values index its member list
+    double grad_bound = 0.0;                // bound on |gradient sum| of one weight in one colour class
     std::vector<uint32_t> rest_tiles;       // tile indices relative to the phase's first tile
     // learning: the largest (kind, chunks) groups of a colour's segments run as segment launches of
     // their own (at most NSK_LEARN_SEG_LAUNCHES per colour); every other non-general tile is on
     // the colour's learn_rest list
     struct SegLaunch { int32_t phase, kind, nch, n, tab, d16; int32_t tile_start[9]; int32_t pos0[8];
-                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], d16off[8]; int32_t ev[8]; };
+                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], d16off[8]; int32_t ev[8], d16base[8]; };
     std::vector<SegLaunch> learn_seg;
     std::vector<uint32_t> learn_rest_tiles;
     std::vector<int64_t> phase_learn_rest_base;   // [ncolors+1]
@@ -98,6 +101,10 @@ struct Compiled {
     std::vector<double> f_feat;
     std::vector<int32_t> m_rec;         // [2*nedge] {variable id, dense_equal_to}
     std::vector<int32_t> v_card, v_pos;
+    // internal numbering: iid[v] = position of a sampled variable, npos.. for the others; nid ids
+    std::vector<int32_t> iid, v_card_i;
+    int64_t nid = 0;
+    bool literal_heads = false;         // a reachable factor reads its head at the literal edge index
     std::vector<int64_t> cstart;        // [nvar+1]
     // weights
     std::vector<double> w_init;

@@ -149,11 +149,16 @@ __device__ inline double mt_res53(MTState *s) {
 template <typename VT>
 struct DevGraph {
     // per position (owned variables in colour-major order)
-    const int32_t *p_vid;       // variable id
+    const int32_t *p_vid;       // the caller's variable id (-1: padding position)
     const uint32_t *p_info;     // cardinality / dataType / isEvidence
     const int32_t *p_slot;      // first slot of the variable in slot_off
     const int32_t *p_cnt;       // cstart[vid]: base index into the tally
     const VT *p_init;           // initialValue (evidence value of the evidence chain)
+    // Variables are renumbered internally: a sampled variable's internal id IS its position, the
+    // variables this handle reads but does not sample (ghosts, isEvidence == 4) follow.  Every id in
+    // the arrays below and in the tiles is internal; val / val_evid / v_card are indexed by it, so a
+    // class's own stores are contiguous and its neighbour gathers walk the other classes' value
+    // ranges in step with the lanes.  p_vid keeps the caller's id for the counter-based generator.
     // inverted index, compacted and laid out in position order
     const int32_t *slot_off;    // [nslot+1] offsets into fidx
     const int32_t *fidx;        // sorted-unique factor ids per (variable, value) slot
@@ -197,11 +202,14 @@ struct DevGraph {
                                 //  refreshed by k_refresh_prog_weights whenever weights change
     uint8_t *cnt_pos;           // [npos] tally delta of binary fast-path variables, by position
                                 //        (folded into the int64 master copy every 255 sweeps)
+    uint8_t *sink;              // 1 KiB scratch: where padding lanes store (branch-free epilogues)
     const uint2 *adj16;         // compact streams of table segments: member ids as int16 deltas from
                                 //  the lane's own variable id, 4 per 8-byte unit
     const uint4 *ztab;          // draw tables of the uniform programs whose members are all binary:
                                 //  entry (program, neighbourhood bits) = {K lo, K hi, sat0 | sat1 << 8, 0}
                                 //  (k_refresh_ztab; DESIGN.md "draw tables")
+    const int32_t *iid_of_vid;  // variable id -> internal id (position; ghosts after the positions): the
+                                //  literal head lookup of the generic path needs it (uploaded only then)
     int32_t nvar;
     int32_t head_by_vid;
 };
@@ -305,7 +313,7 @@ __device__ __forceinline__ int head_member(const DevGraph<VT> &g, const int2 *mb
     const int2 m = mb[l];
     deo = m.y;
     if (m.x == var_samp) return value;
-    return (int)val[g.head_by_vid ? m.x : l];
+    return (int)val[g.head_by_vid ? m.x : g.iid_of_vid[l]];          // values live at internal ids
 }
 
 // eval_factor (inference.py:149-413).  nsk_graph_create rejects unknown function ids and

@@ -2,6 +2,7 @@
 // numbskull/factorgraph.py:141 (burn-in) and :163 (inference); kernels in nsk_kernels_gibbs.h.
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "nsk_internal.h"
 #include "nsk_kernels_misc.h"
@@ -82,8 +83,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     // segments of this colour, batched by (kind, chunks) into table launches
                     // kind 8 = segments with draw tables (any function: the table encodes it)
                     const bool use_tab = g->values_regular;
-                    // kind 9 = the same reading the compact (int16 delta) stream
-                    for (int kind = 0; kind <= 9; kind++) {
+                    for (int kind = 0; kind <= 8; kind++) {
                         if (kind == 1 || (kind > 4 && kind < 8)) continue;   // IMPLY_NATURAL shares the AND step (3)
                         for (int nch = 1; nch <= 2; nch++) {
                             SegTable tab;
@@ -97,14 +97,9 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                     static const int tpw = getenv("NSK_TPW") ? atoi(getenv("NSK_TPW")) : 2;
                                     const int nbt = (tab.tile_start[tab.n] + 4 * tpw - 1) / (4 * tpw);
                                     const dim3 gridt(8 * ((nbt + 7) / 8));
-#define NSK_SEGT(NCH, TPW, D16) k_gibbs_seg_tab<VT, NCH, TPW, D16><<<gridt, block, 0, g->stream>>>(d, tab, nbt, burnin, K0, K1, S0, S1)
-                                    if (kind == 9) {
-                                        if (nch == 1) { if (tpw == 1) NSK_SEGT(1, 1, true); else if (tpw == 2) NSK_SEGT(1, 2, true); else NSK_SEGT(1, 4, true); }
-                                        else { if (tpw == 1) NSK_SEGT(2, 1, true); else NSK_SEGT(2, 2, true); }
-                                    } else {
-                                        if (nch == 1) { if (tpw == 1) NSK_SEGT(1, 1, false); else NSK_SEGT(1, 2, false); }
-                                        else { if (tpw == 1) NSK_SEGT(2, 1, false); else NSK_SEGT(2, 2, false); }
-                                    }
+#define NSK_SEGT(NCH, TPW) k_gibbs_seg_tab<VT, NCH, TPW><<<gridt, block, 0, g->stream>>>(d, tab, nbt, burnin, K0, K1, S0, S1)
+                                    if (nch == 1) { if (tpw == 1) NSK_SEGT(1, 1); else if (tpw == 2) NSK_SEGT(1, 2); else NSK_SEGT(1, 4); }
+                                    else { if (tpw == 1) NSK_SEGT(2, 1); else NSK_SEGT(2, 2); }
 #undef NSK_SEGT
                                 }
                                 else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
@@ -115,17 +110,27 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 g->launches++;
                                 tab.n = 0;
                             };
+                            // largest segments first: the kernels find a tile's segment with a scan
+                            // whose first probe is the table's first entry
+                            std::vector<const Compiled::Segment *> mine;
                             for (const Compiled::Segment &sg : g->c.segments) {
                                 if (sg.phase != (int)ph) continue;
-                                const int k3 = (use_tab && sg.ztab >= 0) ? (sg.d16 >= 0 ? 9 : 8) : sg.kind == 1 ? 3 : (int)sg.kind;
+                                const int k3 = (use_tab && sg.ztab >= 0) ? 8 : sg.kind == 1 ? 3 : (int)sg.kind;
                                 if (k3 != kind || (sg.nslots > 4 ? 2 : 1) != nch) continue;
                                 if (!(sg.ev == 0 || sample_evidence)) continue;      // inference.py:24
+                                mine.push_back(&sg);
+                            }
+                            std::stable_sort(mine.begin(), mine.end(), [](const Compiled::Segment *a, const Compiled::Segment *b) {
+                                return a->ntiles > b->ntiles; });
+                            for (const Compiled::Segment *sgp : mine) {
+                                const Compiled::Segment &sg = *sgp;
                                 tab.pos0[tab.n] = (int)sg.pos0;
                                 tab.adj_off[tab.n] = sg.adj_off;
                                 tab.prog[tab.n] = sg.prog;
                                 tab.zoff[tab.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
                                 tab.zmask[tab.n] = (1u << sg.nslots) - 1u;
-                                tab.d16off[tab.n] = sg.d16 >= 0 ? (uint32_t)sg.d16 : 0u;
+                                tab.d16off[tab.n] = sg.d16 >= 0 ? (uint32_t)sg.d16 : NSK_NO_D16_STREAM;
+                                tab.d16base[tab.n] = sg.d16base;
                                 tab.tile_start[tab.n + 1] = tab.tile_start[tab.n] + sg.ntiles;
                                 if (++tab.n == NSK_SEG_MAX) flush();
                             }

@@ -41,6 +41,7 @@ struct nsk_graph {
     int32_t *p_vid = nullptr, *p_slot = nullptr, *p_cnt = nullptr, *slot_off = nullptr, *fidx = nullptr;
     uint32_t *p_info = nullptr, *f_rec = nullptr;
     void *p_init = nullptr;
+    int32_t *iid_of_vid = nullptr;
     int32_t *m_rec = nullptr, *v_card = nullptr,
             *v_pos = nullptr;
     double *f_feat = nullptr, *w = nullptr, *logtab = nullptr;
@@ -54,6 +55,7 @@ struct nsk_graph {
     uint32_t *tile_wrow = nullptr;
     uint4 *ztab = nullptr;              // draw tables (k_refresh_ztab)
     uint32_t *adj16 = nullptr;          // compact streams of table segments
+    uint8_t *sink = nullptr;            // scratch line for padding lanes' stores
     nsk::ZProgDev *zprogs = nullptr;
     bool values_regular = true;         // every value on the device lies in [0, cardinality): the
                                         // table kernels index with the neighbours' low bits
@@ -98,7 +100,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.slot_off = g->slot_off; d.fidx = g->fidx;
     d.gstream = (const uint2 *)g->gstream; d.gs_off = g->gs_off;
     d.f_rec = (const uint4 *)g->f_rec; d.f_feat = g->f_feat;
-    d.m_rec = (const int2 *)g->m_rec; d.v_card = g->v_card;
+    d.m_rec = (const int2 *)g->m_rec; d.v_card = g->v_card; d.iid_of_vid = g->iid_of_vid;
     d.w = g->w; d.w_fixed = g->w_fixed; d.logtab = g->logtab;
     d.val = (VT *)g->val; d.val_evid = (VT *)g->val_evid; d.cnt = g->cnt;
     d.G = g->G; d.K = g->K; d.T = g->T;
@@ -109,6 +111,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.packed_grad = g->c.packed_grad ? 1 : 0;
     d.cnt_pos = g->cnt_pos;
     d.ztab = g->ztab;
+    d.sink = g->sink;
     d.adj16 = (const uint2 *)g->adj16;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_WAVES) void k_gibbs_phase(De
     const int v = g.p_vid[p];
     if (v < 0) return;
     const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-    const int nv = draw_sample<VT, true>(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));   // inline stream
-    g.val[v] = (VT)nv;
+    const int nv = draw_sample<VT, true>(g, p, info, g.p_slot[p], g.val, u53(r.x, r.y));   // inline stream
+    g.val[p] = (VT)nv;                                  // values live at the variable's position
     if (!burnin) {                                      // inference.py:29-33
         const int base = g.p_cnt[p];
         if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
@@ -59,9 +59,9 @@ __device__ __forceinline__ void heavy_update(const DevGraph<VT> &g, int p, int s
     const int v = g.p_vid[p];
     if (v < 0 || !(ev == 0 || sample_evidence)) return;
     const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-    const int nv = wave_draw_sample(g, v, info, g.p_slot[p], g.val, u53(r.x, r.y));
+    const int nv = wave_draw_sample(g, p, info, g.p_slot[p], g.val, u53(r.x, r.y));
     if ((threadIdx.x & 63) == 0) {
-        g.val[v] = (VT)nv;
+        g.val[p] = (VT)nv;
         if (!burnin) {
             const int base = g.p_cnt[p];
             if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
@@ -680,7 +680,7 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
     const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
     const int nv = pot.draw(maxcard, card, u53(rr.x, rr.y));
 #endif
-    g.val[v] = (VT)nv;
+    g.val[p] = (VT)nv;
     if (!burnin) {
         if (card == 2) g.cnt_pos[p] = (uint8_t)(g.cnt_pos[p] + nv);
         else g.cnt[g.p_cnt[p] + nv] += 1;
@@ -758,7 +758,7 @@ __device__ __forceinline__ void fast_tile_update(const DevGraph<VT> &g, int pbeg
     const double z1 = z0 + nsk_exp(p1);
     const double z = u53(rr.x, rr.y) * z1;
     const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
-    g.val[v] = (VT)nv;
+    g.val[p] = (VT)nv;
     if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
 }
 
@@ -813,6 +813,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
 // kernel fetches per tile comes from the kernel-argument table here, and the body is straight
 // line: ids, 16-byte member loads, byte gathers, compares, draw, store.
 #define NSK_SEG_MAX 8
+#define NSK_NO_D16_STREAM 0xFFFFFFFFu      // SegTable.d16off of a segment without a compact stream
 struct SegTable {
     int n;
     int tile_start[NSK_SEG_MAX + 1];      // first tile of each segment in this launch's numbering
@@ -822,11 +823,21 @@ struct SegTable {
     uint32_t zoff[NSK_SEG_MAX];           // draw-table launches: first entry of the program's table,
     uint32_t zmask[NSK_SEG_MAX];          //   (1 << member slots) - 1
     int ev[NSK_SEG_MAX];                  // the segment's common isEvidence (learning launches)
-    uint32_t d16off[NSK_SEG_MAX];         // compact-stream launches: first 8-byte unit of the segment
+    uint32_t d16off[NSK_SEG_MAX];         // compact-stream launches: first 8-byte unit of the segment,
+    int d16base[NSK_SEG_MAX];             //   member position = own position + d16base + int16 delta
 };
 
-// member ids of one lane from the compact stream: the lane's 4 * NCH int16 deltas (2 * NCH raw
-// words, loaded early) added to its own variable id
+// segment of launch-tile T (wave-uniform): the first segment is the common case, the others are
+// found by a short scalar scan
+__device__ __forceinline__ int seg_of_tile(const SegTable &tab, int T) {
+    int sidx = 0;
+    if (T >= tab.tile_start[1])
+        for (int i = 1; i < tab.n && T >= tab.tile_start[i]; i++) sidx = i;
+    return sidx;
+}
+
+// member positions of one lane from the compact stream: the lane's 4 * NCH int16 deltas (2 * NCH
+// raw words, loaded early) added to its own position + the segment's base offset
 template <int NCH>
 __device__ __forceinline__ void d16_load(const uint2 *base, int lane_unit, uint32_t (&w)[2 * NCH]) {
     if (NCH == 1) { const uint2 q = base[lane_unit]; w[0] = q.x; w[1] = q.y; }
@@ -938,7 +949,7 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
 // launch at once: all their loads are issued before the first dependent gather, which is what
 // keeps enough bytes in flight per SIMD (one tile per wave: 28.6 us per 10M-grid class at full
 // occupancy, two thirds of the wave-cycles waiting).
-template <typename VT, int NCH, int TPW, bool D16>
+template <typename VT, int NCH, int TPW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int nblocks,
                                                              int burnin, uint32_t k0, uint32_t k1,
                                                              uint32_t s0, uint32_t s1) {
@@ -954,17 +965,20 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     uint32_t zoff[TPW], zmask[TPW];
     bool live[TPW];
     uint32_t w16[TPW][2 * NCH];
+    int dbase[TPW];
+    bool u16[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; k++) {
         const int T = min(T0 + k, ntiles - 1);                // wave-uniform; a clamped tile is not stored
         live[k] = T0 + k < ntiles;
-        int sidx = 0;
-#pragma unroll
-        for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+        const int sidx = seg_of_tile(tab, T);
         const int t = T - tab.tile_start[sidx];
         p[k] = tab.pos0[sidx] + t * 64 + lane;
         zoff[k] = tab.zoff[sidx]; zmask[k] = tab.zmask[sidx];
-        if (D16) {
+        // a segment with a compact stream reads int16 deltas, the others 32-bit ids (wave-uniform)
+        u16[k] = tab.d16off[sidx] != NSK_NO_D16_STREAM;
+        dbase[k] = tab.d16base[sidx];
+        if (u16[k]) {
             d16_load<NCH>(g.adj16 + tab.d16off[sidx] + (size_t)t * (64 * NCH), lane, w16[k]);
         } else {
             const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
@@ -977,10 +991,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
         v[k] = g.p_vid[p[k]];                                 // -1: padding lane at a class end
         tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[p[k]];
     }
-    if (D16) {
 #pragma unroll
-        for (int k = 0; k < TPW; k++) d16_ids<NCH>(w16[k], max(v[k], 0), id[k]);
-    }
+    for (int k = 0; k < TPW; k++)
+        if (u16[k]) d16_ids<NCH>(w16[k], p[k] + dbase[k], id[k]);
     uint32_t idx[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; k++) {
@@ -997,12 +1010,22 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     for (int k = 0; k < TPW; k++) e[k] = *(const uint2 *)(g.ztab + zoff[k] + idx[k]);
 #pragma unroll
     for (int k = 0; k < TPW; k++) {
+#ifdef NSK_ABL_NOPHILOX
+        const u32x4 rr = {(uint32_t)v[k] * 2654435761u ^ s0, (uint32_t)v[k] * 40503u + k0, 0u, 0u};
+#else
         const u32x4 rr = philox4x32(k0, k1, (uint32_t)v[k], 0u, s0, s1);
+#endif
         const unsigned long long K = ((unsigned long long)e[k].y << 32) | e[k].x;
         const int nv = k53(rr.x, rr.y) > K ? 1 : 0;
-        if (live[k] && v[k] >= 0) {
-            g.val[v[k]] = (VT)nv;
-            if (!burnin) g.cnt_pos[p[k]] = (uint8_t)(tally[k] + nv);
+        // padding lanes (and the clamped tile past the end) store to a scratch line instead of
+        // branching: a branch here lets the compiler sink this tile's gathers and table read into
+        // it, behind the other tile's -- two more dependent round trips per wave
+        const bool ok = live[k] && v[k] >= 0;
+        VT *dst = ok ? g.val + p[k] : (VT *)g.sink + lane;
+        *dst = (VT)nv;
+        if (!burnin) {
+            uint8_t *td = ok ? g.cnt_pos + p[k] : g.sink + 256 + lane;
+            *td = (uint8_t)(tally[k] + nv);
         }
     }
 }
@@ -1050,7 +1073,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTabl
     const double z = u53(rr.x, rr.y) * z1;
     const int nv = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     if (v >= 0) {
-        g.val[v] = (VT)nv;
+        g.val[p] = (VT)nv;
         if (!burnin) g.cnt_pos[p] = (uint8_t)(tally + nv);
     }
 }

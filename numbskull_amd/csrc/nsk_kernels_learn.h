@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
     for (int item = wave0; item < nitems; item += nwaves) {
         const int p = (list ? (int)list[item] : pbegin + 64 * item) + lane;
         bool more = false, truncate = false;
-        int v = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
+        int v = 0, self = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
         const uint2 *ra = nullptr, *rb = nullptr;        // INL: cursors into the inline records
         if (p < pend && g.p_vid[p] >= 0) {
             const uint32_t info = g.p_info[p];
@@ -79,11 +79,12 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
             const int slot0 = g.p_slot[p];
             v = g.p_vid[p];
             const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
-            if (ev != 1) evidence = draw_sample<VT, INL>(g, v, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
+            if (ev != 1) evidence = draw_sample<VT, INL>(g, p, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
             else evidence = (int)g.p_init[p];                                                            // 61-62
-            g.val_evid[v] = (VT)evidence;
-            proposal = draw_sample<VT, INL>(g, v, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
-            g.val[v] = (VT)proposal;
+            g.val_evid[p] = (VT)evidence;
+            proposal = draw_sample<VT, INL>(g, p, info, slot0, g.val, u53(r.x, r.y));                      // 66-70
+            g.val[p] = (VT)proposal;
+            self = p;
             if (lp.learn_non_evidence || ev == 1) {                                               // 71-72
                 if (lp.regularization == 1) {                                                     // 90
                     const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
                 more = (a < ae) || (b < be);
                 wid = (int)rec.z;
                 if (!g.w_fixed[wid]) {                                                            // 100-101
-                    const double p0 = eval_factor(g, rec, mb, v, evidence, g.val_evid);
-                    const double p1 = eval_factor(g, rec, mb, v, proposal, g.val);
+                    const double p0 = eval_factor(g, rec, mb, self, evidence, g.val_evid);
+                    const double p1 = eval_factor(g, rec, mb, self, proposal, g.val);
                     const double gradient = (p1 - p0) * feat;                                     // 109
                     gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
                     have = true;
@@ -163,10 +164,10 @@ __device__ __forceinline__ void learn_heavy_variable(const DevGraph<VT> &g, cons
     const int slot0 = g.p_slot[p];
     const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
     int evidence;
-    if (ev != 1) evidence = wave_draw_sample(g, v, info, slot0, g.val_evid, u53(r.z, r.w));
+    if (ev != 1) evidence = wave_draw_sample(g, p, info, slot0, g.val_evid, u53(r.z, r.w));
     else evidence = (int)g.p_init[p];
-    const int proposal = wave_draw_sample(g, v, info, slot0, g.val, u53(r.x, r.y));
-    if (lane == 0) { g.val_evid[v] = (VT)evidence; g.val[v] = (VT)proposal; }
+    const int proposal = wave_draw_sample(g, p, info, slot0, g.val, u53(r.x, r.y));
+    if (lane == 0) { g.val_evid[p] = (VT)evidence; g.val[p] = (VT)proposal; }
     if (!(lp.learn_non_evidence || ev == 1)) return;
     bool truncate = false;
     if (lp.regularization == 1) {
@@ -194,8 +195,8 @@ __device__ __forceinline__ void learn_heavy_variable(const DevGraph<VT> &g, cons
             const uint4 rec = g.f_rec[fid];
             wid = (int)rec.z;
             if (!dup && !g.w_fixed[wid]) {
-                const double p0 = eval_factor(g, rec, g.m_rec, v, evidence, g.val_evid);
-                const double p1 = eval_factor(g, rec, g.m_rec, v, proposal, g.val);
+                const double p0 = eval_factor(g, rec, g.m_rec, p, evidence, g.val_evid);
+                const double p1 = eval_factor(g, rec, g.m_rec, p, proposal, g.val);
                 gfix = __double2ll_rn(((p1 - p0) * g.f_feat[fid]) * NSK_GRAD_SCALE);
                 have = true;
             }
@@ -297,8 +298,8 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
     const double z = u53(r.x, r.y) * z1;
     const int proposal = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     if (valid) {
-        g.val_evid[v] = (VT)evidence;
-        g.val[v] = (VT)proposal;
+        g.val_evid[p] = (VT)evidence;
+        g.val[p] = (VT)proposal;
     }
     const bool part = valid && (lp.learn_non_evidence || ev == 1);        // 71-72
     bool truncate = false;
@@ -416,8 +417,8 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
     const double z = u53(r.x, r.y) * z1;
     const int proposal = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     if (valid) {
-        g.val_evid[v] = (VT)evidence;
-        g.val[v] = (VT)proposal;
+        g.val_evid[p] = (VT)evidence;
+        g.val[p] = (VT)proposal;
     }
     const bool part = valid && (lp.learn_non_evidence || ev == 1);
     bool truncate = false;
@@ -489,8 +490,8 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
     if (need_evid && ev != 1) evidence = pe.draw(maxcard, card, u53(r.z, r.w));        // 54-58
     const int proposal = pf.draw(maxcard, card, u53(r.x, r.y));                        // 66-70
     if (valid) {
-        g.val_evid[v] = (VT)evidence;
-        g.val[v] = (VT)proposal;
+        g.val_evid[p] = (VT)evidence;
+        g.val[p] = (VT)proposal;
     }
     const bool part = valid && (lp.learn_non_evidence || ev == 1);                     // 71-72
     bool truncate = false;
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
 // consecutive tiles at once (all their loads in flight before the first dependent gather); the grid
 // is sized by the host so that a wave makes one trip when the partial-sum rows are cheap (few
 // weights) and several when a block's row flush would rival its tile traffic.
-template <typename VT, bool SMALLW, int NCH, int TPW, bool D16>
+template <typename VT, bool SMALLW, int NCH, int TPW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, SegTable tab, LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GradSink sk = open_sink<SMALLW>(g, smem);
@@ -579,18 +580,20 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
         int p[TPW], v[TPW], ev[TPW], init[TPW];
         bool valid[TPW];
         uint32_t id[TPW][4 * NCH], w16[TPW][2 * NCH];
+        int dbase[TPW];
+        bool u16[TPW];
         uint32_t zoff[TPW], zmask[TPW], prog[TPW];
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             const bool live = T0 + k < ntiles;                       // wave-uniform
             const int T = min(T0 + k, ntiles - 1);
-            int sidx = 0;
-#pragma unroll
-            for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
+            const int sidx = seg_of_tile(tab, T);
             const int t = T - tab.tile_start[sidx];
             p[k] = tab.pos0[sidx] + t * 64 + lane;
             zoff[k] = tab.zoff[sidx]; zmask[k] = tab.zmask[sidx]; prog[k] = tab.prog[sidx];
-            if (D16) {
+            u16[k] = tab.d16off[sidx] != NSK_NO_D16_STREAM;           // wave-uniform
+            dbase[k] = tab.d16base[sidx];
+            if (u16[k]) {
                 d16_load<NCH>(g.adj16 + tab.d16off[sidx] + (size_t)t * (64 * NCH), lane, w16[k]);
             } else {
                 const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
@@ -606,10 +609,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             ev[k] = tab.ev[sidx];                                    // uniform over a segment
             init[k] = ev[k] == 1 ? (int)g.p_init[p[k]] : 0;
         }
-        if (D16) {
 #pragma unroll
-            for (int k = 0; k < TPW; k++) d16_ids<NCH>(w16[k], v[k], id[k]);
-        }
+        for (int k = 0; k < TPW; k++)
+            if (u16[k]) d16_ids<NCH>(w16[k], p[k] + dbase[k], id[k]);
         uint32_t idf[TPW], ide[TPW];
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
@@ -636,8 +638,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             if (ev[k] != 1) evidence = k53(r.z, r.w) > (((unsigned long long)ee[k].y << 32) | ee[k].x) ? 1 : 0;   // 54-58
             const int proposal = k53(r.x, r.y) > (((unsigned long long)ef[k].y << 32) | ef[k].x) ? 1 : 0;         // 66-70
             if (valid[k]) {
-                g.val_evid[v[k]] = (VT)evidence;
-                g.val[v[k]] = (VT)proposal;
+                g.val_evid[p[k]] = (VT)evidence;
+                g.val[p[k]] = (VT)proposal;
             }
             const bool part = valid[k] && (lp.learn_non_evidence || ev[k] == 1);  // 71-72
             bool truncate = false;

@@ -107,8 +107,8 @@ __global__ void k_seq_gibbs(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rn
             // the reference fills Z first and draws its uniform afterwards; draw_sample only needs
             // u at the very end, and nothing else consumes the stream in between
             const double u = mt_res53(np_rng);
-            const int nv = draw_sample(g, v, info, g.p_slot[p], g.val, u);
-            g.val[v] = (VT)nv;
+            const int nv = draw_sample(g, p, info, g.p_slot[p], g.val, u);
+            g.val[p] = (VT)nv;
             if (!burnin) {
                 const int base = g.p_cnt[p];
                 if (NSK_INFO_CARD(info) == 2) g.cnt[base] += nv;
@@ -131,11 +131,11 @@ __global__ void k_seq_learn(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rn
             const int ev = NSK_INFO_EV(info);
             const int slot0 = g.p_slot[p];
             int evidence;
-            if (ev != 1) evidence = draw_sample(g, v, info, slot0, g.val_evid, mt_res53(np_rng));
+            if (ev != 1) evidence = draw_sample(g, p, info, slot0, g.val_evid, mt_res53(np_rng));
             else evidence = (int)g.p_init[p];
-            g.val_evid[v] = (VT)evidence;
-            const int proposal = draw_sample(g, v, info, slot0, g.val, mt_res53(np_rng));
-            g.val[v] = (VT)proposal;
+            g.val_evid[p] = (VT)evidence;
+            const int proposal = draw_sample(g, p, info, slot0, g.val, mt_res53(np_rng));
+            g.val[p] = (VT)proposal;
             if (!learn_non_evidence && ev != 1) continue;
             const int st = NSK_INFO_DT1(info);
             int a = g.slot_off[slot0 + st * evidence], ae = g.slot_off[slot0 + st * evidence + 1];
@@ -155,8 +155,8 @@ __global__ void k_seq_learn(DevGraph<VT> g, const int32_t *v_pos, MTState *np_rn
                 const uint4 rec = g.f_rec[fid];
                 const int wid = (int)rec.z;
                 if (g.w_fixed[wid]) continue;
-                const double p0 = eval_factor(g, rec, g.m_rec, v, evidence, g.val_evid);
-                const double p1 = eval_factor(g, rec, g.m_rec, v, proposal, g.val);
+                const double p0 = eval_factor(g, rec, g.m_rec, p, evidence, g.val_evid);
+                const double p1 = eval_factor(g, rec, g.m_rec, p, proposal, g.val);
                 const double gradient = (p1 - p0) * g.f_feat[fid];
                 double w = g.w[wid];
                 if (regularization == 2) {

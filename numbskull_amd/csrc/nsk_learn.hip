@@ -94,17 +94,18 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 for (int i = 0; i <= NSK_SEG_MAX; i++) tab.tile_start[i] = sl.tile_start[i];
                 for (int i = 0; i < NSK_SEG_MAX; i++) {
                     tab.pos0[i] = sl.pos0[i]; tab.adj_off[i] = sl.adj_off[i]; tab.prog[i] = sl.prog[i];
-                    tab.zoff[i] = sl.zoff[i]; tab.zmask[i] = sl.zmask[i]; tab.ev[i] = sl.ev[i]; tab.d16off[i] = sl.d16off[i];
+                    tab.zoff[i] = sl.zoff[i]; tab.zmask[i] = sl.zmask[i]; tab.ev[i] = sl.ev[i]; tab.d16off[i] = sl.d16off[i]; tab.d16base[i] = sl.d16base[i];
                 }
                 const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
                 lp.row_base = rows;
 #define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
                 if (sl.tab && g->values_regular) {
-#define NSK_LTAB(NCH, D16) k_learn_seg_tab<VT, SMALLW, NCH, 2, D16><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
-                    if (sl.d16) { if (sl.nch == 1) NSK_LTAB(1, true); else NSK_LTAB(2, true); }
-                    else { if (sl.nch == 1) NSK_LTAB(1, false); else NSK_LTAB(2, false); }
+#define NSK_LTAB(NCH) k_learn_seg_tab<VT, SMALLW, NCH, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
+                    if (sl.nch == 1) NSK_LTAB(1); else NSK_LTAB(2);
 #undef NSK_LTAB
                 }
+                else if (sl.tab) { if (sl.nch == 1) NSK_LSEG(0, 1); else NSK_LSEG(0, 2); }   // tables unusable: the
+                                                                       // generic slot algebra serves every function
                 else if (sl.kind == 4) { if (sl.nch == 1) NSK_LSEG(4, 1); else NSK_LSEG(4, 2); }
                 else if (sl.kind == 2) { if (sl.nch == 1) NSK_LSEG(2, 1); else NSK_LSEG(2, 2); }
                 else if (sl.kind == 0) { if (sl.nch == 1) NSK_LSEG(0, 1); else NSK_LSEG(0, 2); }
@@ -186,6 +187,11 @@ extern "C" int nsk_learn_sweeps(nsk_graph *g, int64_t nsweeps, double step, doub
     if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
     if (regularization == 1 && truncation == 0) return fail(NSK_E_INVALID, "truncation must be non-zero (ZeroDivisionError in the reference)");
     if (nsweeps == 0) return NSK_OK;
+    // chromatic learning sums a class's gradients as Q31.32 fixed point (order-free, deterministic)
+    if (g->scan == NSK_SCAN_CHROMATIC && g->c.grad_bound >= 1073741824.0)
+        return fail(NSK_E_RANGE, "the gradient sum of one weight in one colour class can exceed the Q31.32 "
+                                 "accumulator (|featureValue| x visits >= 2^30); rescale featureValue or "
+                                 "use the sequential scan");
     HIPCHECK(hipSetDevice(g->device));
     return g->c.vbytes == 1
                ? learn_impl<int8_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence)

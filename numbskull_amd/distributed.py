@@ -101,13 +101,28 @@ class PartitionedSampler(object):
         self.typestr = {1: "|i1", 4: "<i4"}[info["value_bytes"]]
         self.dev = "cuda:%d" % fg.device
         _lib.check(self.L.nsk_set_stream(h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
-        self.val = self._wrap(_lib.BUF_VALUE, self.nvar, self.typestr)
-        self.val_evid = self._wrap(_lib.BUF_VALUE_EVID, self.nvar, self.typestr)
+        # the library keeps values in its own (layout) order: index tensor = internal id of every
+        # variable; ``val`` / ``val_evid`` below are by-variable-id copies gathered through it
+        iid = np.zeros(self.nvar, np.int32)
+        nid = C.c_int64()
+        _lib.check(self.L.nsk_graph_get_layout(h, _lib.ptr(iid), C.byref(nid)))
+        self.iid = torch.as_tensor(iid.astype(np.int64), device=self.dev)
+        self.val_raw = self._wrap(_lib.BUF_VALUE, nid.value, self.typestr)
+        self.val_evid_raw = self._wrap(_lib.BUF_VALUE_EVID, nid.value, self.typestr)
         self.w = self._wrap(_lib.BUF_WEIGHT, fg.weight.shape[0], "<f8")
         self.native = False
         self.lists, self.slot = None, 0
         if world > 1:
             self.setup_exchange(native)
+
+    @property
+    def val(self):
+        """var_value by variable id (a copy gathered from the device buffer's internal order)."""
+        return self.val_raw[self.iid] if self.nvar else self.val_raw
+
+    @property
+    def val_evid(self):
+        return self.val_evid_raw[self.iid] if self.nvar else self.val_evid_raw
 
     def _wrap(self, which, nelem, ts):
         p, nb = C.c_void_p(), C.c_int64()

@@ -6,8 +6,12 @@ smoke scripts, code that patches ``var_value`` / ``weight_value`` between epochs
 What changed is what happens below ``burnIn`` / ``inference`` / ``learn``: the reference fans
 ``gibbsthread`` / ``learnthread`` out over a thread pool (run_pool, factorgraph.py:13-24, called
 at :141, :163, :202); here those three call sites go through the C-ABI to HIP kernels on the
-MI355X.  Host arrays are uploaded when a call starts and downloaded when it returns, so in-place
-edits between calls are honoured exactly like in the reference.
+MI355X.  The STATE arrays -- ``var_value``, ``var_value_evid``, ``weight_value``, ``count`` -- are
+uploaded when a call starts and downloaded when it returns, so in-place edits of them between
+calls are honoured exactly like in the reference.  The STRUCTURE (``variable`` incl. isEvidence /
+initialValue of evidence, ``weight['isFixed']``, ``factor``, ``fmap``, ``vmap``,
+``factor_index``) is compiled into the device layout once, at the first call; after editing it in
+place call ``invalidate()`` so that the next call recompiles.
 """
 
 import ctypes as C
@@ -87,7 +91,8 @@ class FactorGraph(object):
         desc = _lib.GraphDesc(len(w), len(v), len(f), len(fm), len(vm), len(fi),
                               w.ctypes.data, v.ctypes.data, f.ctypes.data, fm.ctypes.data,
                               vm.ctypes.data, fi.ctypes.data,
-                              _lib.FLAG_HEAD_BY_VID if self.head_by_vid else 0, self.device,
+                              (_lib.FLAG_HEAD_BY_VID if self.head_by_vid else 0) |
+                              (_lib.FLAG_PARTITION if self.own_range is not None else 0), self.device,
                               int(ob), int(oe))
         return desc, (arrays, fi)
 
@@ -137,6 +142,12 @@ class FactorGraph(object):
         if self._handle is not None:
             _lib.lib().nsk_graph_destroy(self._handle)
             self._handle = None
+
+    def invalidate(self):
+        """Drop the compiled device graph: the next burnIn / inference / learn call recompiles it
+        from the current contents of the structural arrays (the reference reads them on every
+        sweep, e.g. after its master marks ownership with isEvidence == 4)."""
+        self.close()
 
     def __del__(self):
         try:

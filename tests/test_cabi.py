@@ -219,3 +219,43 @@ def test_bad_graphs_are_rejected_with_reference_like_errors():
     ns, fg = session(tuple(g))
     with pytest.raises(IndexError):
         fg.plan()
+
+
+def test_evidence_value_outside_domain_is_rejected():
+    """An evidence value of a dataType-1 variable selects its factor list (learning.py:61-62 with
+    get_factor_id_range): outside [0, cardinality) the reference reads another variable's lists;
+    the graph compiler refuses (IndexError)."""
+    g = list(_graph_from_spec(3, [(14, [0, 1])], card=np.array([3, 3, 2])))
+    g[1] = g[1].copy()
+    g[1]["dataType"][:2] = 1
+    ns, fg = session(tuple(g))
+    fg.plan()                                                        # fine as it stands
+    g[1]["isEvidence"][0] = 1
+    g[1]["initialValue"][0] = 5
+    ns, fg = session(tuple(g))
+    with pytest.raises(IndexError):
+        fg.plan()
+
+
+def test_empty_shard_is_empty_and_unflagged_zero_range_is_the_whole_graph():
+    """shard_range(0, world, nvar) is (0, 0) when nvar < world: with own_range given that is an EMPTY
+    shard (NSK_FLAG_PARTITION), not the whole graph."""
+    from numbskull_amd import graphgen
+    from numbskull_amd.distributed import shard_range
+    g = graphgen.ising_grid(1, 3, weight=0.2)
+    assert shard_range(0, 8, 3) == (0, 0)
+    ns = numbskull_amd.NumbSkull(quiet=True)
+    ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in g[:5]], int(g[5]),
+                       own_range=shard_range(0, 8, 3))
+    color, info = ns.factorGraphs[0].plan()
+    assert info["nowned"] == 0 and (color < 0).all()
+    ns, fg = session(g)
+    color, info = fg.plan()
+    assert info["nowned"] == 3
+    owned = 0
+    for r in range(8):                                               # every variable has exactly one owner
+        ns = numbskull_amd.NumbSkull(quiet=True)
+        ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in g[:5]], int(g[5]),
+                           own_range=shard_range(r, 8, 3))
+        owned += ns.factorGraphs[0].plan()[1]["nowned"]
+    assert owned == 3

@@ -3,7 +3,8 @@
 # PMC passes for HBM traffic, each counter set in its own run (MI355X_MICROARCH.md, HBM section).
 # Raw output goes to gpurun_out/prof/; tools/summarize_profile.py condenses it into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof
+WL=${1:-ising10m}
+OUT=$R/gpurun_out/prof_$WL
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 WL=${1:-ising10m}
@@ -16,6 +17,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal_write -- python3 $R/tools/calib_stream.py > $OUT/calib_write.log 2>&1
 python3 $R/tools/summarize_profile.py $OUT $WL > $OUT/summary.txt 2>&1
 # keep the merge small: drop anything big
-find $OUT -type f -size +8M -delete
-ls -laR $OUT | head -80
+find $OUT -type f -size +4M -delete
+
 cat $OUT/summary.txt
