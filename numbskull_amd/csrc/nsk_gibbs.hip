@@ -2,6 +2,7 @@
 // numbskull/factorgraph.py:141 (burn-in) and :163 (inference); kernels in nsk_kernels_gibbs.h.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "nsk_internal.h"
@@ -87,15 +88,16 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         if (kind == 1 || (kind > 4 && kind < 8)) continue;   // IMPLY_NATURAL shares the AND step (3)
                         for (int nch = 1; nch <= 2; nch++) {
                             SegTable tab;
-                            tab.n = 0; tab.tile_start[0] = 0;
+                            memset(&tab, 0, sizeof(tab));
                             auto flush = [&]() {
                                 if (tab.n == 0) return;
-                                const int nb = (tab.tile_start[tab.n] + 3) / 4;
+                                for (int i = tab.n; i < NSK_SEG_MAX; i++) tab.e[i].tile_start = tab.ntiles;
+                                const int nb = (tab.ntiles + 3) / 4;
                                 const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
 #define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
                                 if (kind >= 8) {
                                     static const int tpw = getenv("NSK_TPW") ? atoi(getenv("NSK_TPW")) : 2;
-                                    const int nbt = (tab.tile_start[tab.n] + 4 * tpw - 1) / (4 * tpw);
+                                    const int nbt = (tab.ntiles + 4 * tpw - 1) / (4 * tpw);
                                     const dim3 gridt(8 * ((nbt + 7) / 8));
 #define NSK_SEGT(NCH, TPW) k_gibbs_seg_tab<VT, NCH, TPW><<<gridt, block, 0, g->stream>>>(d, tab, nbt, burnin, K0, K1, S0, S1)
                                     if (nch == 1) { if (tpw == 1) NSK_SEGT(1, 1); else if (tpw == 2) NSK_SEGT(1, 2); else NSK_SEGT(1, 4); }
@@ -108,7 +110,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 else { if (nch == 1) NSK_SEG(3, 1); else NSK_SEG(3, 2); }
 #undef NSK_SEG
                                 g->launches++;
-                                tab.n = 0;
+                                memset(&tab, 0, sizeof(tab));
                             };
                             // largest segments first: the kernels find a tile's segment with a scan
                             // whose first probe is the table's first entry
@@ -124,14 +126,16 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 return a->ntiles > b->ntiles; });
                             for (const Compiled::Segment *sgp : mine) {
                                 const Compiled::Segment &sg = *sgp;
-                                tab.pos0[tab.n] = (int)sg.pos0;
-                                tab.adj_off[tab.n] = sg.adj_off;
-                                tab.prog[tab.n] = sg.prog;
-                                tab.zoff[tab.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
-                                tab.zmask[tab.n] = (1u << sg.nslots) - 1u;
-                                tab.d16off[tab.n] = sg.d16 >= 0 ? (uint32_t)sg.d16 : NSK_NO_D16_STREAM;
-                                tab.d16base[tab.n] = sg.d16base;
-                                tab.tile_start[tab.n + 1] = tab.tile_start[tab.n] + sg.ntiles;
+                                SegEntry &en = tab.e[tab.n];
+                                en.tile_start = tab.ntiles;
+                                en.pos0 = (int)sg.pos0;
+                                en.adj_off = sg.adj_off;
+                                en.prog = sg.prog;
+                                en.zoff = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
+                                en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8);
+                                en.d16off = sg.d16 >= 0 ? (uint32_t)sg.d16 : NSK_NO_D16_STREAM;
+                                en.d16base = sg.d16base;
+                                tab.ntiles += sg.ntiles;
                                 if (++tab.n == NSK_SEG_MAX) flush();
                             }
                             flush();

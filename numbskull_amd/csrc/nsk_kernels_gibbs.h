@@ -814,25 +814,27 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
 // line: ids, 16-byte member loads, byte gathers, compares, draw, store.
 #define NSK_SEG_MAX 8
 #define NSK_NO_D16_STREAM 0xFFFFFFFFu      // SegTable.d16off of a segment without a compact stream
+struct SegEntry {                         // 32 bytes: one scalar load per tile
+    int tile_start;                       // first tile of the segment in this launch's numbering
+    int pos0;                             // position of the segment's first lane
+    uint32_t adj_off;                     // stream offset (16-byte units) of its first tile
+    uint32_t prog;                        // slot program
+    uint32_t zoff;                        // draw-table launches: first entry of the program's table
+    uint32_t zmask_ev;                    // (1 << member slots) - 1 | (uint8) common isEvidence << 8
+    uint32_t d16off;                      // first 8-byte unit of the compact stream, NSK_NO_D16_STREAM: none
+    int d16base;                          // member position = own position + d16base + int16 delta
+};
 struct SegTable {
-    int n;
-    int tile_start[NSK_SEG_MAX + 1];      // first tile of each segment in this launch's numbering
-    int pos0[NSK_SEG_MAX];                // position of the segment's first lane
-    uint32_t adj_off[NSK_SEG_MAX];        // stream offset (16-byte units) of its first tile
-    uint32_t prog[NSK_SEG_MAX];           // slot program
-    uint32_t zoff[NSK_SEG_MAX];           // draw-table launches: first entry of the program's table,
-    uint32_t zmask[NSK_SEG_MAX];          //   (1 << member slots) - 1
-    int ev[NSK_SEG_MAX];                  // the segment's common isEvidence (learning launches)
-    uint32_t d16off[NSK_SEG_MAX];         // compact-stream launches: first 8-byte unit of the segment,
-    int d16base[NSK_SEG_MAX];             //   member position = own position + d16base + int16 delta
+    int n, ntiles;                        // segments, tiles of the launch; e[i].tile_start = ntiles for i >= n
+    SegEntry e[NSK_SEG_MAX];
 };
 
 // segment of launch-tile T (wave-uniform): the first segment is the common case, the others are
 // found by a short scalar scan
 __device__ __forceinline__ int seg_of_tile(const SegTable &tab, int T) {
     int sidx = 0;
-    if (T >= tab.tile_start[1])
-        for (int i = 1; i < tab.n && T >= tab.tile_start[i]; i++) sidx = i;
+    if (T >= tab.e[1].tile_start)                           // (= ntiles when the launch has one segment)
+        for (int i = 1; i < tab.n && T >= tab.e[i].tile_start; i++) sidx = i;
     return sidx;
 }
 
@@ -957,7 +959,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     if (lb < 0) return;
     const int lane = (int)(threadIdx.x & 63);
     const int T0 = __builtin_amdgcn_readfirstlane((lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6)) * TPW);
-    const int ntiles = tab.tile_start[tab.n];
+    const int ntiles = tab.ntiles;
     if (T0 >= ntiles) return;
     int p[TPW], v[TPW];
     uint8_t tally[TPW];
@@ -972,16 +974,17 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
         const int T = min(T0 + k, ntiles - 1);                // wave-uniform; a clamped tile is not stored
         live[k] = T0 + k < ntiles;
         const int sidx = seg_of_tile(tab, T);
-        const int t = T - tab.tile_start[sidx];
-        p[k] = tab.pos0[sidx] + t * 64 + lane;
-        zoff[k] = tab.zoff[sidx]; zmask[k] = tab.zmask[sidx];
+        const SegEntry en = tab.e[sidx];                      // one 32-byte scalar load
+        const int t = T - en.tile_start;
+        p[k] = en.pos0 + t * 64 + lane;
+        zoff[k] = en.zoff; zmask[k] = (en.zmask_ev & 0xFFu);
         // a segment with a compact stream reads int16 deltas, the others 32-bit ids (wave-uniform)
-        u16[k] = tab.d16off[sidx] != NSK_NO_D16_STREAM;
-        dbase[k] = tab.d16base[sidx];
+        u16[k] = en.d16off != NSK_NO_D16_STREAM;
+        dbase[k] = en.d16base;
         if (u16[k]) {
-            d16_load<NCH>(g.adj16 + tab.d16off[sidx] + (size_t)t * (64 * NCH), lane, w16[k]);
+            d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16[k]);
         } else {
-            const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+            const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 const uint4 q = sp[c * 64];
@@ -1038,16 +1041,17 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTabl
     if (lb < 0) return;
     const int lane = (int)(threadIdx.x & 63);
     const int T = __builtin_amdgcn_readfirstlane(lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
-    if (T >= tab.tile_start[tab.n]) return;
+    if (T >= tab.ntiles) return;
     int sidx = 0;
 #pragma unroll
-    for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
-    const int t = T - tab.tile_start[sidx];
-    const uint32_t prog = tab.prog[sidx];
-    const int p = tab.pos0[sidx] + t * 64 + lane;
+    for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.e[i].tile_start) ? 1 : 0;
+    const SegEntry en = tab.e[sidx];
+    const int t = T - en.tile_start;
+    const uint32_t prog = en.prog;
+    const int p = en.pos0 + t * 64 + lane;
     const int v = g.p_vid[p];                             // -1: padding lane at a class end
     const uint8_t tally = burnin ? (uint8_t)0 : g.cnt_pos[p];
-    const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+    const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
     const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
     const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
     uint4 q[NCH];

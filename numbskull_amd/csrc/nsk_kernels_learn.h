@@ -546,18 +546,19 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
     const int lane = (int)(threadIdx.x & 63);
     const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
     const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
-    const int ntiles = tab.tile_start[tab.n];
+    const int ntiles = tab.ntiles;
     const int per = (ntiles + nwaves - 1) / nwaves;
     const int t1 = min(ntiles, (wave0 + 1) * per);
     for (int T = wave0 * per; T < t1; T++) {
         int sidx = 0;
 #pragma unroll
-        for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.tile_start[i]) ? 1 : 0;
-        const int t = T - tab.tile_start[sidx];
-        const int p = tab.pos0[sidx] + t * 64 + lane;
+        for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.e[i].tile_start) ? 1 : 0;
+    const SegEntry en = tab.e[sidx];
+        const int t = T - en.tile_start;
+        const int p = en.pos0 + t * 64 + lane;
         const bool valid = g.p_vid[p] >= 0;                  // -1: padding lane at a class end
-        const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
-        learn_tile<VT, KIND>(g, sk, sp, 4 * NCH, tab.prog[sidx], p, valid, lp);
+        const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+        learn_tile<VT, KIND>(g, sk, sp, 4 * NCH, en.prog, p, valid, lp);
     }
     close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
 }
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
     const int lane = (int)(threadIdx.x & 63);
     const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
     const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
-    const int ntiles = tab.tile_start[tab.n];
+    const int ntiles = tab.ntiles;
     for (int T0 = wave0 * TPW; T0 < ntiles; T0 += nwaves * TPW) {
         int p[TPW], v[TPW], ev[TPW], init[TPW];
         bool valid[TPW];
@@ -588,15 +589,16 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             const bool live = T0 + k < ntiles;                       // wave-uniform
             const int T = min(T0 + k, ntiles - 1);
             const int sidx = seg_of_tile(tab, T);
-            const int t = T - tab.tile_start[sidx];
-            p[k] = tab.pos0[sidx] + t * 64 + lane;
-            zoff[k] = tab.zoff[sidx]; zmask[k] = tab.zmask[sidx]; prog[k] = tab.prog[sidx];
-            u16[k] = tab.d16off[sidx] != NSK_NO_D16_STREAM;           // wave-uniform
-            dbase[k] = tab.d16base[sidx];
+        const SegEntry en = tab.e[sidx];                      // one 32-byte scalar load
+            const int t = T - en.tile_start;
+            p[k] = en.pos0 + t * 64 + lane;
+            zoff[k] = en.zoff; zmask[k] = (en.zmask_ev & 0xFFu); prog[k] = en.prog;
+            u16[k] = en.d16off != NSK_NO_D16_STREAM;           // wave-uniform
+            dbase[k] = en.d16base;
             if (u16[k]) {
-                d16_load<NCH>(g.adj16 + tab.d16off[sidx] + (size_t)t * (64 * NCH), lane, w16[k]);
+                d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16[k]);
             } else {
-                const uint4 *sp = g.adj + tab.adj_off[sidx] + (size_t)t * (64 * NCH) + lane;
+                const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     const uint4 q = sp[c * 64];
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             const int v0 = g.p_vid[p[k]];                            // -1: padding lane at a class end
             valid[k] = live && v0 >= 0;
             v[k] = v0 >= 0 ? v0 : 0;
-            ev[k] = tab.ev[sidx];                                    // uniform over a segment
+            ev[k] = ((int)(int8_t)(en.zmask_ev >> 8));                                    // uniform over a segment
             init[k] = ev[k] == 1 ? (int)g.p_init[p[k]] : 0;
         }
 #pragma unroll

@@ -2,6 +2,7 @@
 // numbskull/factorgraph.py:194-206; kernels in nsk_kernels_learn.h.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "nsk_internal.h"
 #include "nsk_kernels_learn.h"
@@ -90,11 +91,16 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             for (const Compiled::SegLaunch &sl : g->c.learn_seg) {       // homogeneous segments
                 if (sl.phase != (int)ph) continue;
                 SegTable tab;
+                memset(&tab, 0, sizeof(tab));
                 tab.n = sl.n;
-                for (int i = 0; i <= NSK_SEG_MAX; i++) tab.tile_start[i] = sl.tile_start[i];
+                tab.ntiles = sl.tile_start[sl.n];
                 for (int i = 0; i < NSK_SEG_MAX; i++) {
-                    tab.pos0[i] = sl.pos0[i]; tab.adj_off[i] = sl.adj_off[i]; tab.prog[i] = sl.prog[i];
-                    tab.zoff[i] = sl.zoff[i]; tab.zmask[i] = sl.zmask[i]; tab.ev[i] = sl.ev[i]; tab.d16off[i] = sl.d16off[i]; tab.d16base[i] = sl.d16base[i];
+                    SegEntry &en = tab.e[i];
+                    en.tile_start = i < sl.n ? sl.tile_start[i] : tab.ntiles;
+                    en.pos0 = sl.pos0[i]; en.adj_off = sl.adj_off[i]; en.prog = sl.prog[i];
+                    en.zoff = sl.zoff[i];
+                    en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
+                    en.d16off = sl.d16off[i]; en.d16base = sl.d16base[i];
                 }
                 const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
                 lp.row_base = rows;

@@ -949,3 +949,30 @@ def test_marginals_within_1e_3_of_exact_after_burn_in():
     want = np.array([exact[i][1] for i in range(n1)])
     assert np.max(np.abs(got - want)) < 1e-3, (got, want)
     assert abs(want[0] - 0.5) > 0.05           # the bias makes the check non-trivial
+
+
+def test_compact_delta_streams_are_bit_exact(monkeypatch):
+    """NSK_D16=1 builds the int16-delta twin of the table segments' streams (member positions as
+    deltas from the lane's own position); the sweep must not change by a bit."""
+    monkeypatch.setenv("NSK_D16", "1")
+    rng = np.random.default_rng(5)
+    for learn in (False, True):
+        g = graphgen.ising_grid(96, 200, weight=0.3, fixed=not learn, two_weights=learn,
+                                evidence=rng.integers(0, 2, 96 * 200) if learn else None)
+        ns, fg = session(g, seed=21)
+        og = oracle_of(fg)
+        order, ps = phases_from_colors(fg.colors())
+        vv, ve, wv, cnt = og.initial_state()
+        if learn:
+            fg.learn(0, 3, 1e-3, 0.95, 2, 0.01, 1)
+            step = 1e-3
+            for s in range(3):
+                og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 21, s)
+                step *= 0.95
+            assert np.array_equal(fg.weight_value[0], wv) and np.array_equal(fg.var_value_evid[0], ve)
+        else:
+            fg.inference(1, 4, True)
+            for s in range(5):
+                og.gibbs_dev(order, ps, vv, wv, cnt, 21, s, True, burnin=s < 1)
+            assert np.array_equal(fg.count, cnt)
+        assert np.array_equal(fg.var_value[0], vv)

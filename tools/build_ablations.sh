@@ -1,16 +1,17 @@
 #!/bin/bash
-# Builds ablated variants of the library (general-tile inference kernel with one stage removed) into
-# numbskull_amd/variants/ for timing experiments on the GPU box (NSK_LIB=... python bench.py ...).
+# Builds ablated variants of the library (a sweep kernel with one stage removed, or instrumented)
+# into numbskull_amd/variants/ for timing experiments on the GPU box (NSK_LIB=... python bench.py).
 # The variants compute wrong samples by construction; they exist to price the stages.
+# usage: tools/build_ablations.sh NAME[+NAME...] ...   (each NAME defines NSK_ABL_<NAME>)
 set -e
 cd "$(dirname "$0")/../numbskull_amd/csrc"
 mkdir -p ../variants build
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
 for v in "$@"; do
-  /opt/rocm/bin/hipcc $FLAGS -DNSK_ABL_$v -c -o build/nsk_gibbs_$v.o nsk_gibbs.hip &
+  defs=""; for d in ${v//+/ }; do defs="$defs -DNSK_ABL_$d"; done
+  /opt/rocm/bin/hipcc $FLAGS $defs -c -o build/nsk_gibbs_$v.o nsk_gibbs.hip &
 done
 wait
 for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../variants/libnsk_$v.so build/nsk_api.o build/nsk_gibbs_$v.o build/nsk_learn.o build/nsk_compile.o build/nsk_host.o
 done
-ls -la ../variants
