@@ -239,18 +239,22 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
         HIPCHECK(hipMemsetAsync(g->part_T, 0, cells * sizeof(uint32_t), g->stream));
     }
     HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (c.npos ? c.npos : 1), g->stream));
-    rc = dev_alloc(g, &g->G, (size_t)c.nweight); if (rc) return rc;
-    rc = dev_alloc(g, &g->K, (size_t)c.nweight); if (rc) return rc;
-    rc = dev_alloc(g, &g->T, (size_t)c.nweight); if (rc) return rc;
+    // global learning accumulators: one private copy per XCD (nsk_device.h sink_add); graphs with few
+    // weights accumulate in LDS and never touch them
+    g->acc_copies = (!g->smallw && c.nweight <= (1 << 21)) ? NSK_XCDS : 1;
+    const size_t nacc = (size_t)g->acc_copies * (size_t)(c.nweight ? c.nweight : 1);
+    rc = dev_alloc(g, &g->G, nacc); if (rc) return rc;
+    rc = dev_alloc(g, &g->K, nacc); if (rc) return rc;
+    rc = dev_alloc(g, &g->T, nacc); if (rc) return rc;
     rc = dev_alloc(g, &g->clip_count, 1); if (rc) return rc;
     HIPCHECK(hipMemsetAsync(g->clip_count, 0, sizeof(unsigned int), g->stream));
     rc = dev_alloc(g, &g->mt_np, 1); if (rc) return rc;
     rc = dev_alloc(g, &g->mt_py, 1); if (rc) return rc;
     HIPCHECK(hipMemsetAsync(g->cnt, 0, (c.ncount ? c.ncount : 1) * sizeof(int32_t), g->stream));
     HIPCHECK(hipMemsetAsync(g->cnt_total, 0, (c.ncount ? c.ncount : 1) * sizeof(long long), g->stream));
-    HIPCHECK(hipMemsetAsync(g->G, 0, (c.nweight ? c.nweight : 1) * sizeof(long long), g->stream));
-    HIPCHECK(hipMemsetAsync(g->K, 0, (c.nweight ? c.nweight : 1) * sizeof(uint32_t), g->stream));
-    HIPCHECK(hipMemsetAsync(g->T, 0, (c.nweight ? c.nweight : 1) * sizeof(uint32_t), g->stream));
+    HIPCHECK(hipMemsetAsync(g->G, 0, nacc * sizeof(long long), g->stream));
+    HIPCHECK(hipMemsetAsync(g->K, 0, nacc * sizeof(uint32_t), g->stream));
+    HIPCHECK(hipMemsetAsync(g->T, 0, nacc * sizeof(uint32_t), g->stream));
     HIPCHECK(hipStreamSynchronize(g->stream));
     return nsk_set_seed(g, 0, 0);
 }

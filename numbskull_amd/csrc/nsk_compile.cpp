@@ -397,7 +397,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     if (!conflict && ncolors > 2 && !getenv("NSK_NO_RECOLOUR")) {
         std::vector<int32_t> newc(nvar), seq;
         seq.reserve((size_t)nvar);
-        for (int pass = 0; pass < 6; pass++) {
+        const int npass = getenv("NSK_RECOLOUR_PASSES") ? atoi(getenv("NSK_RECOLOUR_PASSES")) : 6;
+        for (int pass = 0; pass < npass; pass++) {
             std::vector<int64_t> size((size_t)ncolors, 0);
             for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) size[c.color[v]]++;
             std::vector<int32_t> cls((size_t)ncolors);

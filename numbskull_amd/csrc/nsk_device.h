@@ -40,6 +40,7 @@ enum : int {
 #define NSK_ZLOCAL 16      // cardinalities up to this keep their running sums in registers/scratch
 #define NSK_GRAD_SCALE 4294967296.0   // gradients accumulate as Q31.32 fixed point (order-free)
 #define NSK_SMALLW 256      // graphs with at most this many weights accumulate per block in LDS
+#define NSK_XCDS 8          // accelerator dies of the MI355X: private copies of the global accumulators
 
 // ------------------------------------------------------------------------------------------
 // deterministic exp -- same operation sequence as oracle/nsk_oracle.c:orc_exp_det
@@ -182,7 +183,8 @@ struct DevGraph {
     VT *val;                    // var_value[0]
     VT *val_evid;               // var_value_evid[0]
     int32_t *cnt;               // tally delta since the last fold into the int64 master copy
-    // learning accumulators (per weight), global flavour
+    // learning accumulators (per weight), global flavour: NSK_XCDS private copies, one per XCD
+    // (copy x at [x * nweight, (x + 1) * nweight)); k_apply_weights adds them up
     long long *G;               // fixed-point gradient sum
     uint32_t *K;                // visits
     uint32_t *T;                // truncating visits (L1)
@@ -190,6 +192,7 @@ struct DevGraph {
     long long *part_G;          // [NSK_LEARN_BINS][nweight]
     uint32_t *part_K, *part_T;
     int32_t nweight;
+    int32_t acc_copies;         // copies of G / K / T: NSK_XCDS (one per XCD) or 1
     int32_t packed_grad;        // integer gradients: visit counts ride in the low half of G (GradSink)
     // fast path: inlined adjacency streams (DESIGN.md "fast path") and a position-indexed tally
     const uint4 *adj;           // stream: chunk c of lane i of a tile at adj[off + 64*c + i]
@@ -707,7 +710,25 @@ struct GradSink {
     // / UFO), so the 32 fraction bits of G are free and carry the visit count -- one 64-bit atomic
     // per visit instead of two atomics (global accumulators only; nsk_compile.cpp decides)
     bool packed;
+    bool local;         // LDS tables or an XCD-private copy: workgroup-scope adds (sink_add)
 };
+
+// The accumulators of a sink live in LDS (SMALLW) or in the XCD-private copy of the global tables
+// (open_sink): either way nothing outside the issuing XCD touches them during the launch, so the
+// adds are workgroup-scope atomics -- they execute in LDS / in the XCD's own L2.  (Agent-scope
+// atomics are carried out on the memory side of the fabric because the eight L2s are not coherent
+// with each other: the 3.75 million of a 5M-variable LR class cost 130 us of a 300 us launch.)
+// `local`: the table is private to this XCD (or in LDS).  Very large weight tables keep ONE global
+// copy (eight would cost more to add up after every class than the atomics save) and use
+// agent-scope adds.
+__device__ __forceinline__ void sink_add(bool local, unsigned long long *p, unsigned long long v) {
+    if (local) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sink_add(bool local, uint32_t *p, uint32_t v) {
+    if (local) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Add one (weight, gradient) visit per participating lane.  Must be called by all 64 lanes of the
 // wave (converged); `have` marks participating lanes.  Lanes sharing the leader's weight id are
@@ -725,16 +746,16 @@ __device__ __forceinline__ void accumulate_gradient(const GradSink &sk, bool hav
         const long long sum = wave_sum_i64(same ? gfix : 0LL);
         const int nt = __popcll(__ballot(same && trunc));
         if ((int)(threadIdx.x & 63) == leader) {
-            atomicAdd((unsigned long long *)&sk.G[lw], (unsigned long long)(sum + (sk.packed ? nsame : 0)));
-            if (!sk.packed) atomicAdd(&sk.K[lw], (uint32_t)nsame);
-            if (nt) atomicAdd(&sk.T[lw], (uint32_t)nt);
+            sink_add(sk.local, (unsigned long long *)&sk.G[lw], (unsigned long long)(sum + (sk.packed ? nsame : 0)));
+            if (!sk.packed) sink_add(sk.local, &sk.K[lw], (uint32_t)nsame);
+            if (nt) sink_add(sk.local, &sk.T[lw], (uint32_t)nt);
         }
         have = have && !same;
     }
     if (have) {
-        atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)(gfix + (sk.packed ? 1 : 0)));
-        if (!sk.packed) atomicAdd(&sk.K[wid], 1u);
-        if (trunc) atomicAdd(&sk.T[wid], 1u);
+        sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(gfix + (sk.packed ? 1 : 0)));
+        if (!sk.packed) sink_add(sk.local, &sk.K[wid], 1u);
+        if (trunc) sink_add(sk.local, &sk.T[wid], 1u);
     }
 }
 

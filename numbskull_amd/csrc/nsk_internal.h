@@ -62,6 +62,7 @@ struct nsk_graph {
     bool chain_regular[2] = {true, true};   // ... per chain (var_value, var_value_evid)
     double compile_seconds = 0;
     uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr, *learn_rest_tiles = nullptr;
+    int acc_copies = 1;                // copies of the global learning accumulators (one per XCD, or 1)
     bool generic_uploaded = false;     // CSR-style arrays of the generic kernels are on the device
     double learn_cap = 0.5;            // per-class cap on visits * step of one weight (nsk_set_learn_cap)
     unsigned int *clip_count = nullptr;   // weight updates whose step was clipped (device counter)
@@ -109,6 +110,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.part_G = g->part_G; d.part_K = g->part_K; d.part_T = g->part_T;
     d.nweight = (int32_t)g->c.nweight;
     d.packed_grad = g->c.packed_grad ? 1 : 0;
+    d.acc_copies = g->acc_copies;
     d.cnt_pos = g->cnt_pos;
     d.ztab = g->ztab;
     d.sink = g->sink;

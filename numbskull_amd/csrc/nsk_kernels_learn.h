@@ -31,8 +31,13 @@ __device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem)
         for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) { sk.G[i] = 0; sk.K[i] = 0; sk.T[i] = 0; }
         __syncthreads();
     } else {
-        sk.G = g.G; sk.K = g.K; sk.T = g.T;
+        // this XCD's private copy (HW_REG_XCC_ID, bits 3:0): the adds then stay in its own L2
+        const uint32_t xcc = g.acc_copies > 1
+            ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (NSK_XCDS - 1)) : 0u;
+        const size_t off = (size_t)xcc * (size_t)g.nweight;
+        sk.G = g.G + off; sk.K = g.K + off; sk.T = g.T + off;
     }
+    sk.local = SMALLW || g.acc_copies > 1;
     sk.packed = !SMALLW && g.packed_grad != 0;
     return sk;
 }
@@ -323,9 +328,9 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
             if ((threadIdx.x & 63) == 0) {
                 const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
                 const int wid = (int)(s & 0xFFFFFFu);
-                atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
-                if (!sk.packed) atomicAdd(&sk.K[wid], nk);
-                if (nt) atomicAdd(&sk.T[wid], nt);
+                sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
+                if (!sk.packed) sink_add(sk.local, &sk.K[wid], nk);
+                if (nt) sink_add(sk.local, &sk.T[wid], nt);
             }
         }
     }
@@ -499,6 +504,9 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
         const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
         truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
     }
+#ifdef NSK_ABL_NOPASS2
+    if (lp.k0 != 0xDEADBEEFu) return;
+#endif
     if (__ballot(part) == 0) return;
     general_walk<VT, true, 2, false>(g, g.val, g.val_evid, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr,
                            [&](uint32_t wid, double, uint32_t d1, const GenChain &a, const GenChain &b) {
@@ -510,7 +518,11 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
                                const long long diff = (long long)(proposal == cf ? Af : Bf) -
                                                       (long long)(evidence == ce ? Ae : Be);
                                const bool have = part && mine && !g.w_fixed[wid];      // 100-101
+#ifdef NSK_ABL_NOATOMIC
+                               if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
+#else
                                accumulate_gradient(sk, have, (int)wid, diff * 4294967296ll, truncate);
+#endif
                            });
 }
 
@@ -665,9 +677,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
                     if (lane == 0) {
                         const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
                         const int wid = (int)(s & 0xFFFFFFu);
-                        atomicAdd((unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
-                        if (!sk.packed) atomicAdd(&sk.K[wid], nk);
-                        if (nt) atomicAdd(&sk.T[wid], nt);
+                        sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
+                        if (!sk.packed) sink_add(sk.local, &sk.K[wid], nk);
+                        if (nt) sink_add(sk.local, &sk.T[wid], nt);
                     }
                 }
             }
@@ -762,23 +774,33 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, l
                                                              uint32_t *T, int nweight, double step,
                                                              int regularization, double reg_param,
                                                              double truncation, int packed, double cap,
-                                                             unsigned int *clipped) {
+                                                             unsigned int *clipped, int copies) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= nweight) return;
-    long long gsum = G[i];
-    uint32_t k;
-    if (packed) {                       // visits in the low half, integer gradient sum in the high half
-        k = (uint32_t)((unsigned long long)gsum & 0xFFFFFFFFull);
-        gsum -= (long long)k;
-    } else {
-        k = K[i];
+    long long gsum = 0;
+    unsigned long long k = 0, t = 0;
+    for (int x = 0; x < copies; x++) {                  // the XCDs' private copies (cleared as they are read)
+        const size_t at = (size_t)x * nweight + i;
+        long long gx = G[at];
+        if (packed) {                   // visits in the low half, integer gradient sum in the high half
+            const unsigned long long kx = (unsigned long long)gx & 0xFFFFFFFFull;
+            if (gx) G[at] = 0;
+            gx -= (long long)kx;
+            k += kx;
+        } else {
+            const uint32_t kx = K[at];
+            if (kx) { G[at] = 0; K[at] = 0; }
+            k += kx;
+        }
+        gsum += gx;
+        if (regularization == 1) {      // only L1 ever counts truncations
+            const uint32_t tx = T[at];
+            if (tx) T[at] = 0;
+            t += tx;
+        }
     }
-    if (k == 0) return;                 // untouched in this class (packed: one 8-byte read)
-    const uint32_t t = regularization == 1 ? T[i] : 0u;     // only L1 ever counts truncations
-    w[i] = apply_update(w[i], gsum, k, t, step, regularization, reg_param, truncation, cap, clipped);
-    G[i] = 0;
-    if (!packed) K[i] = 0;
-    if (regularization == 1) T[i] = 0;
+    if (k == 0) return;                 // untouched in this class
+    w[i] = apply_update(w[i], gsum, (uint32_t)k, (uint32_t)t, step, regularization, reg_param, truncation, cap, clipped);
 }
 
 // SMALLW: one block adds up the bins of every weight (and clears them), applies the update,

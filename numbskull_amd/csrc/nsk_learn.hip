@@ -151,7 +151,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
                         g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation,
-                        (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count);
+                        (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies);
                     nsk_refresh_prog_weights(g, true);
                 }
             }

@@ -7,11 +7,14 @@ set -e
 cd "$(dirname "$0")/../numbskull_amd/csrc"
 mkdir -p ../variants build
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
+# NSK_ABL_TU=learn builds the variants of the learning translation unit instead of the inference one
+TU=${NSK_ABL_TU:-gibbs}
 for v in "$@"; do
   defs=""; for d in ${v//+/ }; do defs="$defs -DNSK_ABL_$d"; done
-  /opt/rocm/bin/hipcc $FLAGS $defs -c -o build/nsk_gibbs_$v.o nsk_gibbs.hip &
+  /opt/rocm/bin/hipcc $FLAGS $defs -c -o build/nsk_${TU}_$v.o nsk_$TU.hip &
 done
 wait
 for v in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../variants/libnsk_$v.so build/nsk_api.o build/nsk_gibbs_$v.o build/nsk_learn.o build/nsk_compile.o build/nsk_host.o
+  if [ "$TU" = learn ]; then objs="build/nsk_gibbs.o build/nsk_learn_$v.o"; else objs="build/nsk_gibbs_$v.o build/nsk_learn.o"; fi
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../variants/libnsk_$v.so build/nsk_api.o $objs build/nsk_compile.o build/nsk_host.o
 done

@@ -30,3 +30,20 @@ for lo, hi in ((0, 16), (16, 32), (32, 48), (48, 64), (64, 96), (96, 256)):
     m = (ln >= lo) & (ln < hi)
     if m.any():
         print("len %3d-%3d: %6d tiles, walk mean %8.0f ticks, per word %6.1f" % (lo, hi, m.sum(), walk[m].mean(), (walk[m] / np.maximum(ln[m], 1)).mean()))
+
+# ---- timeline per launch: tiles of one launch share a time window; launches are separated by gaps
+order = np.argsort(t0)
+ts, te = t0[order], t2[order]
+cuts = [0] + [i for i in range(1, len(ts)) if ts[i] - ts[:i].max() > 20000 and ts[i] > te[:i].max()] + [len(ts)]
+print("launch windows (ticks): start-to-end span, tiles, mean concurrency, time with < 1/4 of peak concurrency")
+for a, b in zip(cuts[:-1], cuts[1:]):
+    if b - a < 100:
+        continue
+    s, e = ts[a:b], te[a:b]
+    span = e.max() - s.min()
+    grid = np.linspace(s.min(), e.max(), 400)
+    conc = np.array([((s <= g) & (e > g)).sum() for g in grid])
+    low = (conc < conc.max() / 4).mean()
+    first_end = e.min() - s.min()
+    print("  span %7d  tiles %6d  peak conc %5d  mean conc %7.1f  low-occupancy time %4.0f%%  last start at %4.0f%%  first tile done at %4.0f%%"
+          % (span, b - a, conc.max(), conc.mean(), 100 * low, 100 * (s.max() - s.min()) / span, 100 * first_end / span))
