@@ -44,6 +44,11 @@ struct Compiled {
     std::vector<uint32_t> tile_wrow;       // [nwb]
     int64_t nwrows = 0;
     std::vector<uint32_t> adj;             // inlined adjacency words (DESIGN.md "fast path")
+    // entry-parallel hub streams: per hub position {offset, entries, M | cardinality << 8, 0} (entries == 0:
+    // the hub takes the generic walk) and the lane-per-entry word rows
+    std::vector<uint32_t> hub_desc, hub_adj;
+    std::vector<int64_t> phase_hub_base;    // [ncolors+1] first descriptor of each colour's hub range
+    int64_t nhub_ep = 0;
     std::vector<uint32_t> adj16;           // compact twin of the table segments' streams: int16 deltas
     // A tile whose 64 lanes share one header sequence (same function, member count and weight per
     // entry) with at most 8 member slots is "uniform": its stream holds member words only and its

@@ -205,6 +205,8 @@ struct DevGraph {
                                 //  refreshed by k_refresh_prog_weights whenever weights change
     uint8_t *cnt_pos;           // [npos] tally delta of binary fast-path variables, by position
                                 //        (folded into the int64 master copy every 255 sweeps)
+    const uint4 *hub_desc;      // [npos] entry-parallel hubs: {offset into hub_adj, entries, M | card << 8, 0};
+    const uint32_t *hub_adj;    //  entries == 0: generic hub walk.  Rows of 64 words, one entry per lane
     uint8_t *sink;              // 1 KiB scratch: where padding lanes store (branch-free epilogues)
     const uint2 *adj16;         // compact streams of table segments: member ids as int16 deltas from
                                 //  the lane's own variable id, 4 per 8-byte unit

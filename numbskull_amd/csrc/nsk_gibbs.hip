@@ -49,7 +49,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const int rblocks = rest_here ? (nrest_all + 3) / 4 : 0;
                     if (nblocks + hblocks > 0) {
                         k_gibbs_general<VT, 8><<<dim3(hblocks + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, one_general ? g->stream : cs.side(0)>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks,
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks, (int)g->c.phase_hub_base[ph],
                             g->rest_tiles + g->c.phase_rest_base[ph], rest_here ? nrest_all : 0,
                             sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
                             (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
@@ -76,7 +76,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         rest_in_general = gtb == gt0 && nrest_all > 0 && !getenv("NSK_SPLIT_GENERAL");
                         const int rblocks = rest_in_general ? (nrest_all + 3) / 4 : 0;
                         k_gibbs_general<VT, 2><<<dim3(hbl + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, g->stream>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, fe, he, hbl,
+                            d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, fe, he, hbl, (int)g->c.phase_hub_base[ph],
                             g->rest_tiles + g->c.phase_rest_base[ph], rest_in_general ? nrest_all : 0,
                             sample_evidence, burnin, K0, K1, S0, S1);
                         g->launches++;

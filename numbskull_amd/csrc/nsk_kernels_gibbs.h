@@ -633,6 +633,104 @@ struct GenPot {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Entry-parallel hubs (nsk_compile.cpp "entry-parallel hub streams"): one wave per hub, one LANE
+// per list entry.  Every lane evaluates its entry exactly like a general tile does (chain facts,
+// gen_lut_entry), then the entries' terms are added IN LIST ORDER into the candidates' potentials:
+// lane c keeps candidate c's sum and step i adds entry i's term (broadcast with readlane) -- the
+// same sequence of float64 additions as potential() (inference.py:55-71).
+// ---------------------------------------------------------------------------------------------
+struct HubEntry { uint32_t wid, d1; int cstar, A, B; double w; };
+
+// lane's entry of round r under the value array `val`: loads, gathers, closes
+template <typename VT>
+__device__ __forceinline__ void hub_entry(const DevGraph<VT> &g, const uint8_t *lut, const uint32_t *base,
+                                          int rows, int r, int M, const VT *val, bool want_w, HubEntry &en) {
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t *row = base + (size_t)(r * rows) * 64 + lane;
+    en.wid = row[0];
+    en.d1 = row[64];
+    uint32_t mw[6];
+    int x[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) {                       // M is wave-uniform
+        mw[m] = m < M ? row[(2 + m) * 64] : NSK_GEN_NULL;
+        const uint32_t id = mw[m] & NSK_GEN_NULL;
+        x[m] = (m < M && id != NSK_GEN_NULL) ? (int)val[id] : 0;
+    }
+    en.w = want_w ? g.w[en.wid] : 0.0;
+    const bool cat = (en.d1 & 15u) >= 6u;
+    GenChain a;
+    a.open();
+#pragma unroll
+    for (int m = 0; m < 6; m++)
+        if (m < M) a.member(m == 0, cat, mw[m], x[m]);
+    a.close(en.d1, lut, en.cstar, en.A, en.B);
+}
+
+// candidate `lane`'s potential of the hub over `val` (every lane returns its own candidate's sum)
+template <typename VT>
+__device__ __forceinline__ double hub_potentials(const DevGraph<VT> &g, const uint8_t *lut, const uint4 hd,
+                                                 const VT *val) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int n = (int)hd.y, M = (int)(hd.z & 0xFFu), rows = 2 + M;
+    const uint32_t *base = g.hub_adj + hd.x;
+    double pc = 0.0;
+    for (int r = 0; r * 64 < n; r++) {
+        HubEntry en;
+        hub_entry(g, lut, base, rows, r, M, val, true, en);
+        const double tA = en.w * (double)en.A, tB = en.w * (double)en.B;
+        const int ks = (int)((en.d1 >> 14) & 15u);
+        const int nlive = min(64, n - r * 64);
+        for (int i = 0; i < nlive; i++) {               // list order
+            const int s_cstar = __builtin_amdgcn_readlane(en.cstar, i);
+            const int s_ks = __builtin_amdgcn_readlane(ks, i);
+            const double s_tA = lane_value(tA, i), s_tB = lane_value(tB, i);
+            const bool on = s_ks == 15 || s_ks == lane;
+            const double t = on ? (lane == s_cstar ? s_tA : s_tB) : 0.0;       // +0.0 leaves the sum unchanged
+            pc = pc + t;
+        }
+    }
+    return pc;
+}
+
+// draw_sample (inference.py:36-52) from per-lane candidate potentials; every lane returns the value
+__device__ __forceinline__ int hub_draw(double pc, int card, double u) {
+    const int lane = (int)(threadIdx.x & 63);
+    const double ek = nsk_exp(pc);
+    double acc = 0.0, myZ = 0.0;
+    for (int k = 0; k < card; k++) {
+        const double e = lane_value(ek, k);
+        acc = (k == 0) ? e : acc + e;
+        if (lane == k) myZ = acc;
+    }
+    const double z = u * acc;
+    const unsigned long long hit = __ballot(lane < card && myZ >= z);
+    return hit ? (int)__ffsll((long long)hit) - 1 : 0;
+}
+
+template <typename VT>
+__device__ __forceinline__ void heavy_update_ep(const DevGraph<VT> &g, const uint8_t *lut, int p, const uint4 hd,
+                                                int sample_evidence, int burnin, uint32_t k0, uint32_t k1,
+                                                uint32_t s0, uint32_t s1) {
+    const uint32_t info = g.p_info[p];
+    const int ev = NSK_INFO_EV(info);
+    const int v = g.p_vid[p];
+    if (v < 0 || !(ev == 0 || sample_evidence)) return;
+    const int card = NSK_INFO_CARD(info);
+    const double pc = hub_potentials(g, lut, hd, g.val);
+    const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const int nv = hub_draw(pc, card, u53(r.x, r.y));
+    if ((threadIdx.x & 63) == 0) {
+        g.val[p] = (VT)nv;
+        if (!burnin) {
+            const int base = g.p_cnt[p];
+            if (card == 2) g.cnt[base] += nv;
+            else g.cnt[base + nv] += 1;
+        }
+    }
+}
+
 #ifdef NSK_ABL_TIMING
 // instrumented build (tools/build_ablations.sh TIMING): per general tile {start, after walk, end, len}
 static __device__ unsigned long long nsk_dbg[4 * 65536];
@@ -769,7 +867,7 @@ __device__ __forceinline__ void fast_tile_update(const DevGraph<VT> &g, int pbeg
 template <typename VT, int MAXC>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int pbegin, int pend,
                                                              int wb_base, int tile0, int ntiles,
-                                                             int nblocks, int hb, int he, int hblocks,
+                                                             int nblocks, int hb, int he, int hblocks, int hub0,
                                                              const uint32_t *rest_list, int nrest,
                                                              int sample_evidence, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0,
@@ -779,7 +877,22 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
     if ((int)blockIdx.x < hblocks) {                      // block-uniform
         const int hp = hb + (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
 #ifndef NSK_ABL_NOHUB
-        if (hp < he) heavy_update(g, hp, sample_evidence, burnin, k0, k1, s0, s1);
+        if (hp < he) {
+            const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + hub0 + (hp - hb));
+            const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
+#ifdef NSK_ABL_TIMING
+            const unsigned long long hub_t0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (hd.y) heavy_update_ep(g, lut, hp, hd, sample_evidence, burnin, k0, k1, s0, s1);
+            else heavy_update(g, hp, sample_evidence, burnin, k0, k1, s0, s1);
+#ifdef NSK_ABL_TIMING
+            if ((threadIdx.x & 63) == 0) {
+                const int slot = 60000 + ((hub0 + hp - hb) & 4095);
+                nsk_dbg[4 * slot] = hub_t0; nsk_dbg[4 * slot + 1] = hub_t0; nsk_dbg[4 * slot + 2] = __builtin_amdgcn_s_memtime();
+                nsk_dbg[4 * slot + 3] = 1000ull + hd.y;
+            }
+#endif
+        }
 #endif
         return;
     }

@@ -16,7 +16,8 @@ struct LearnParams {
     int regularization, learn_non_evidence;
     double inv_trunc;
     uint32_t k0, k1, s0, s1;
-    int row_base;               // first row of this launch in the partial-sum tables (SMALLW)
+    int row_base;               // (unused: partial sums are binned)
+    int hub0;                   // first hub descriptor of the colour class
 };
 
 // per-block accumulation tables in LDS (SMALLW) or the global accumulators
@@ -210,14 +211,65 @@ __device__ __forceinline__ void learn_heavy_variable(const DevGraph<VT> &g, cons
     }
 }
 
+// Learning for an entry-parallel hub (heavy_update_ep's twin): both chains' potentials with one lane
+// per entry, the draws, then a second pass over the entries for the gradient visits -- the union of
+// list(evidence) and list(proposal) is "entries owned by every candidate, by the evidence value or by
+// the proposal" (learning.py:76-95), each lane hands its entry to the wave-aggregated accumulators.
+template <typename VT>
+__device__ __forceinline__ void learn_heavy_variable_ep(const DevGraph<VT> &g, const GradSink &sk, const uint8_t *lut,
+                                                        int p, const uint4 hd, const LearnParams &lp) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int v = g.p_vid[p];
+    if (v < 0) return;
+    const uint32_t info = g.p_info[p];
+    const int ev = NSK_INFO_EV(info), card = NSK_INFO_CARD(info);
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    int evidence;
+    if (ev != 1) evidence = hub_draw(hub_potentials(g, lut, hd, g.val_evid), card, u53(r.z, r.w));   // 54-58
+    else evidence = (int)g.p_init[p];                                                             // 61-62
+    const int proposal = hub_draw(hub_potentials(g, lut, hd, g.val), card, u53(r.x, r.y));            // 66-70
+    if (lane == 0) { g.val_evid[p] = (VT)evidence; g.val[p] = (VT)proposal; }
+    if (!(lp.learn_non_evidence || ev == 1)) return;                                               // 71-72
+    bool truncate = false;
+    if (lp.regularization == 1) {                                                                  // 90
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        truncate = u53(t.x, t.y) < lp.inv_trunc;
+    }
+    const int n = (int)hd.y, M = (int)(hd.z & 0xFFu), rows = 2 + M;
+    const uint32_t *base = g.hub_adj + hd.x;
+    for (int rr = 0; rr * 64 < n; rr++) {
+        HubEntry ef, ee;
+        hub_entry(g, lut, base, rows, rr, M, g.val, false, ef);
+        hub_entry(g, lut, base, rows, rr, M, g.val_evid, false, ee);
+        const int ks = (int)((ef.d1 >> 14) & 15u);
+        const bool mine = ks == 15 || ks == evidence || ks == proposal;
+        const long long diff = (long long)(proposal == ef.cstar ? ef.A : ef.B) -
+                               (long long)(evidence == ee.cstar ? ee.A : ee.B);
+        const bool have = rr * 64 + lane < n && mine && !g.w_fixed[ef.wid];                        // 100-101
+        accumulate_gradient(sk, have, (int)ef.wid, diff * 4294967296ll, truncate);
+    }
+}
+
+// a hub position: entry-parallel when the graph compiler built its lane-per-entry stream
+template <typename VT>
+__device__ __forceinline__ void learn_hub(const DevGraph<VT> &g, const GradSink &sk, const uint8_t *lut, int p,
+                                          int hubdesc, const LearnParams &lp) {
+    const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + hubdesc);
+    const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
+    if (hd.y) learn_heavy_variable_ep<VT>(g, sk, lut, p, hd, lp);
+    else learn_heavy_variable<VT>(g, sk, p, lp);
+}
+
 template <typename VT, bool SMALLW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_heavy(DevGraph<VT> g, int pbegin, int pend,
                                                            LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
+    load_gen_lut(lut);
     const GradSink sk = open_sink<SMALLW>(g, smem);
     const int wave0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
     const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
-    for (int p = pbegin + wave0; p < pend; p += nwaves) learn_heavy_variable<VT>(g, sk, p, lp);
+    for (int p = pbegin + wave0; p < pend; p += nwaves) learn_hub<VT>(g, sk, lut, p, lp.hub0 + (p - pbegin), lp);
     close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
 }
 
@@ -718,7 +770,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
     const int lane = (int)(threadIdx.x & 63);
     if ((int)blockIdx.x < hblocks) {                      // hub blocks: one wave per hub position, strided
         const int hw0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
-        for (int hp = hb + hw0; hp < he; hp += hblocks * (NSK_BLOCK / 64)) learn_heavy_variable<VT>(g, sk, hp, lp);
+        for (int hp = hb + hw0; hp < he; hp += hblocks * (NSK_BLOCK / 64)) learn_hub<VT>(g, sk, lut, hp, lp.hub0 + (hp - hb), lp);
         close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
         return;
     }

@@ -30,6 +30,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
             const int e = (int)g->c.phase_start[ph + 1];
             if (e <= fb) continue;
+            lp.hub0 = (int)g->c.phase_hub_base[ph];
             int rows = 0;
             const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);

@@ -19,6 +19,15 @@ buf = np.zeros(4 * 65536, np.uint64)
 raw = C.CDLL(_lib.LIB_PATH)
 raw.nsk_debug_dump(C.c_void_p(buf.ctypes.data), C.c_int(len(buf)))
 b = buf.reshape(-1, 4)
+hub = b[60000:64096]
+hub = hub[hub[:, 0] > 0]
+if len(hub):
+    dur = (hub[:, 2] - hub[:, 0]).astype(np.int64)
+    ep = hub[:, 3] > 1000
+    print("hub waves recorded %d (entry-parallel %d): duration ticks mean %.0f p50 %.0f p90 %.0f max %.0f; generic-walk mean %.0f, entry-parallel mean %.0f"
+          % (len(hub), ep.sum(), dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max(),
+             dur[~ep].mean() if (~ep).any() else 0, dur[ep].mean() if ep.any() else 0))
+b = b[:60000]
 b = b[b[:, 0] > 0]
 t0, t1, t2 = b[:, 0].astype(np.int64), b[:, 1].astype(np.int64), b[:, 2].astype(np.int64)
 ln = (b[:, 3] & 0xFFFFFFFF).astype(np.int64)
