@@ -92,9 +92,11 @@ __device__ __forceinline__ u32x4 philox4x32(uint32_t k0, uint32_t k1, uint32_t c
     for (int round = 0; round < 10; round++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        // (three-input xor as ONE v_bitop3_b32, truth table 0x96: the rounds are half of the table
+        // kernels' vector instructions)
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
         uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
         uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u;
