@@ -95,7 +95,14 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 const int nb = (tab.ntiles + 3) / 4;
                                 const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
 #define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
-                                if (kind >= 8) {
+                                static const int persist = getenv("NSK_PERSIST") ? atoi(getenv("NSK_PERSIST")) : 0;
+                                if (kind >= 8 && persist > 0 && tab.ntiles >= 8 * 1024) {
+                                    // resident grid: `persist` blocks per CU (8 = full occupancy)
+                                    const dim3 gridp(256 * persist);
+                                    if (nch == 1) k_gibbs_seg_tab_p<VT, 1><<<gridp, block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
+                                    else k_gibbs_seg_tab_p<VT, 2><<<gridp, block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
+                                }
+                                else if (kind >= 8) {
                                     static const int tpw = getenv("NSK_TPW") ? atoi(getenv("NSK_TPW")) : 2;
                                     const int nbt = (tab.ntiles + 4 * tpw - 1) / (4 * tpw);
                                     const dim3 gridt(8 * ((nbt + 7) / 8));

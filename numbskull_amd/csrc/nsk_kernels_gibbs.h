@@ -1146,6 +1146,125 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     }
 }
 
+#ifdef NSK_ABL_PAIR
+// EXPERIMENT (timing only, wrong stream): two consecutive tiles per trip sharing ONE Philox call
+// keyed by the first tile's lane position (words 0-1 / 2-3), no p_vid load.
+template <typename VT, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab_p(DevGraph<VT> g, SegTable tab, int burnin,
+                                                               uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int ntiles = tab.ntiles;
+    const int npairs = (ntiles + 1) >> 1;
+    const int per = (npairs + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7);
+    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);
+    const int pend = min(npairs, (xcd + 1) * per);
+    for (int P = xcd * per + wx; P < pend; P += wpx) {
+        int p[2];
+        uint32_t id[2][4 * NCH];
+        uint32_t zoff[2], zmask[2];
+        uint8_t tally[2];
+        bool live[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int T = min(2 * P + k, ntiles - 1);
+            live[k] = 2 * P + k < ntiles;
+            const int sidx = seg_of_tile(tab, T);
+            const SegEntry en = tab.e[sidx];
+            const int t = T - en.tile_start;
+            p[k] = en.pos0 + t * 64 + lane;
+            zoff[k] = en.zoff; zmask[k] = en.zmask_ev & 0xFFu;
+            const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint4 q = sp[c * 64];
+                id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+            }
+            tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[p[k]];
+        }
+        uint32_t idx[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            idx[k] = 0;
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) idx[k] |= ((uint32_t)g.val[id[k][j]] & 1u) << j;
+            idx[k] &= zmask[k];
+        }
+        uint2 e[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) e[k] = *(const uint2 *)(g.ztab + zoff[k] + idx[k]);
+        const u32x4 rr = philox4x32(k0, k1, (uint32_t)p[0], 0u, s0, s1);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned long long K = ((unsigned long long)e[k].y << 32) | e[k].x;
+            const int nv = (k == 0 ? k53(rr.x, rr.y) : k53(rr.z, rr.w)) > K ? 1 : 0;
+            VT *dst = live[k] ? g.val + p[k] : (VT *)g.sink + lane;
+            *dst = (VT)nv;
+            if (!burnin) {
+                uint8_t *td = live[k] ? g.cnt_pos + p[k] : g.sink + 256 + lane;
+                *td = (uint8_t)(tally[k] + nv);
+            }
+        }
+    }
+}
+#else
+// Persistent flavour of k_gibbs_seg_tab: a resident grid (8 waves per SIMD) whose waves loop over
+// tiles, so the per-wave set-up -- kernel-argument loads, the Philox key schedule, base pointers --
+// is paid once per wave instead of once per tile pair.  XCD x walks the x-th eighth of the tiles
+// (same locality as xcd_logical_block).  The table kernels are bound by instruction issue
+// (DESIGN.md section 4): this variant exists to cut scalar instructions per tile.
+template <typename VT, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab_p(DevGraph<VT> g, SegTable tab, int burnin,
+                                                               uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int ntiles = tab.ntiles;
+    const int per = (ntiles + 7) >> 3;                                  // tiles per XCD
+    const int xcd = (int)(blockIdx.x & 7);
+    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
+    const int tend = min(ntiles, (xcd + 1) * per);
+    for (int T = xcd * per + wx; T < tend; T += wpx) {
+        const int sidx = seg_of_tile(tab, T);
+        const SegEntry en = tab.e[sidx];
+        const int t = T - en.tile_start;
+        const int p = en.pos0 + t * 64 + lane;
+        uint32_t id[4 * NCH];
+        const bool u16 = en.d16off != NSK_NO_D16_STREAM;
+        uint32_t w16[2 * NCH];
+        if (u16) {
+            d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16);
+        } else {
+            const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint4 q = sp[c * 64];
+                id[4 * c] = q.x; id[4 * c + 1] = q.y; id[4 * c + 2] = q.z; id[4 * c + 3] = q.w;
+            }
+        }
+        const int v = g.p_vid[p];                             // -1: padding lane at a class end
+        const uint8_t tally = burnin ? (uint8_t)0 : g.cnt_pos[p];
+        if (u16) d16_ids<NCH>(w16, p + en.d16base, id);
+        uint32_t idx = 0;
+#pragma unroll
+        for (int j = 0; j < 4 * NCH; j++) idx |= ((uint32_t)g.val[id[j]] & 1u) << j;
+        idx &= en.zmask_ev & 0xFFu;
+        const uint2 e = *(const uint2 *)(g.ztab + en.zoff + idx);
+        const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+        const unsigned long long K = ((unsigned long long)e.y << 32) | e.x;
+        const int nv = k53(rr.x, rr.y) > K ? 1 : 0;
+        const bool ok = v >= 0;
+        VT *dst = ok ? g.val + p : (VT *)g.sink + lane;
+        *dst = (VT)nv;
+        if (!burnin) {
+            uint8_t *td = ok ? g.cnt_pos + p : g.sink + 256 + lane;
+            *td = (uint8_t)(tally + nv);
+        }
+    }
+}
+
+#endif
+
 template <typename VT, int KIND, int NCH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTable tab, int nblocks,
                                                          int burnin, uint32_t k0, uint32_t k1,
