@@ -198,7 +198,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     {
         bool generic_needed = c.phase_dyn_base.size() > 0 && c.phase_dyn_base.back() > 0;
         for (size_t k = 0; k + 1 < c.phase_start.size(); k++)
-            if (c.phase_start[k + 1] > c.phase_fast_end[k]) generic_needed = true;
+            if (c.phase_end[k] > c.phase_fast_end[k]) generic_needed = true;
         if (generic_needed || getenv("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
     }
     UP(w_fixed); UP(logtab); UP(adj); UP(adj16); UP(hub_desc); UP(hub_adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
@@ -350,7 +350,7 @@ int nsk_fold_position_tally(nsk_graph *g) {
     const int np = (int)g->c.npos;
     if (np > 0 && g->c.nfast > 0 && g->pos_tally_sweeps > 0)
         k_fold_counts_pos<<<dim3((np + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-            g->cnt_pos, g->p_cnt, g->cnt_total, np);
+            g->cnt_pos, g->p_cnt, g->p_vid, g->cnt_total, np);
     g->pos_tally_sweeps = 0;
     return NSK_OK;
 }

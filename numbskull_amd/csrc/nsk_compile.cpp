@@ -590,6 +590,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // p_vid = -1); smaller classes share a tail in id order; then the generic-path variables.
     // Order inside a class: variable id.
     c.phase_start.assign((size_t)ncolors + 1, 0);
+    c.phase_end.assign((size_t)ncolors, 0);
     c.phase_fast_end.assign((size_t)ncolors, 0);
     c.phase_gen_tile.assign((size_t)ncolors, 0);
     c.v_pos.assign(nvar, -1);
@@ -685,7 +686,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors);
         int64_t pos = 0;
         for (int32_t k = 0; k < ncolors; k++) {
-            c.phase_start[k] = pos;
+            pos = (pos + 127) / 128 * 128;      // tiles sit on multiples of 64, tile pairs on multiples of
+            c.phase_start[k] = pos;             // 128: a lane's position & 63 is its lane (generator ids)
             int64_t nbig = 0;
             for (int level = 0; level < 2; level++) {
                 ClassMap &cm = level == 0 ? classes[k] : shapes[k];
@@ -711,6 +713,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             c.phase_fast_end[k] = pos;
             next_gen[k] = pos;
             pos += ngen_of[k];
+            c.phase_end[k] = pos;               // (the next colour starts at the next multiple of 128)
         }
         c.phase_start[ncolors] = pos;
         c.npos = pos;
@@ -1616,6 +1619,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 lay_inf -= saved;
                 lay_learn -= saved;
             }
+        for (const Compiled::Segment &sg : c.segments)      // the inference table kernel keys its generator
+            if (sg.ztab >= 0) lay_inf -= (double)sg.ntiles * 64 * 4;   // by position: no p_vid read
         c.layout_bytes_inference = lay_inf;
         c.layout_bytes_learning = lay_learn;
     }

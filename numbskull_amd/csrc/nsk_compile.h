@@ -25,7 +25,8 @@ struct Compiled {
     int64_t own_begin = 0, own_end = 0;
     // colouring
     std::vector<int32_t> color;         // [nvar], -1 = not sampled by this handle
-    std::vector<int64_t> phase_start;   // [ncolors+1] positions
+    std::vector<int64_t> phase_start;   // [ncolors+1] positions (every colour starts on a multiple of 128)
+    std::vector<int64_t> phase_end;     // [ncolors] end of the colour's positions (<= phase_start[k+1])
     // Inside a phase the "fast" variables (binary, symmetric boolean factors: inlined adjacency
     // streams) come first, the rest (generic CSR kernel) after: [phase_start, phase_fast_end) fast.
     std::vector<int64_t> phase_fast_end;   // [ncolors]

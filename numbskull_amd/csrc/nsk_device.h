@@ -105,6 +105,18 @@ __device__ __forceinline__ u32x4 philox4x32(uint32_t k0, uint32_t k1, uint32_t c
     return u32x4{c0, c1, c2, c3};
 }
 
+// Generator ids.  A variable's id q is its position in the compiled layout.
+// Inference sweeps: ids q and q + 64 with equal q >> 7 -- the same lane of two consecutive tiles --
+// share ONE Philox block: counter ((q >> 7) * 64 + (q & 63), 0, sweep), words 0-1 for the lower id
+// and 2-3 for the upper one; a kernel that holds both in one lane computes the block once, any other
+// computes it per variable.  Learning sweeps need two uniforms per variable and use counter
+// (q, stream, sweep) directly.
+__device__ __forceinline__ uint32_t inf_block(uint32_t q) { return ((q >> 7) << 6) | (q & 63u); }
+__device__ __forceinline__ uint2 inf_words(uint32_t k0, uint32_t k1, uint32_t q, uint32_t s0, uint32_t s1) {
+    const u32x4 r = philox4x32(k0, k1, inf_block(q), 0u, s0, s1);
+    return ((q >> 6) & 1u) ? uint2{r.z, r.w} : uint2{r.x, r.y};
+}
+
 // 53-bit uniform in [0,1) from two 32-bit words: the genrand_res53 construction that
 // np.random.rand() / random.random() use (inference.py:50, learning.py:90)
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {

@@ -25,7 +25,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
         for (int64_t s = 0; s < nsweeps; s++) {
             for (size_t ph = 0; ph < nphase; ph++) {
                 const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
-                const int e = (int)g->c.phase_start[ph + 1];
+                const int e = (int)g->c.phase_end[ph];
                 const int he = (int)g->c.phase_heavy_end[ph];
                 ColourStreams cs(g, !g->no_overlap);
                 bool rest_in_general = false;       // the colour's rest tiles were given to a general launch
@@ -95,21 +95,12 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 const int nb = (tab.ntiles + 3) / 4;
                                 const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
 #define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
-                                static const int persist = getenv("NSK_PERSIST") ? atoi(getenv("NSK_PERSIST")) : 0;
-                                if (kind >= 8 && persist > 0 && tab.ntiles >= 8 * 1024) {
-                                    // resident grid: `persist` blocks per CU (8 = full occupancy)
-                                    const dim3 gridp(256 * persist);
-                                    if (nch == 1) k_gibbs_seg_tab_p<VT, 1><<<gridp, block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
-                                    else k_gibbs_seg_tab_p<VT, 2><<<gridp, block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
-                                }
-                                else if (kind >= 8) {
-                                    static const int tpw = getenv("NSK_TPW") ? atoi(getenv("NSK_TPW")) : 2;
-                                    const int nbt = (tab.ntiles + 4 * tpw - 1) / (4 * tpw);
-                                    const dim3 gridt(8 * ((nbt + 7) / 8));
-#define NSK_SEGT(NCH, TPW) k_gibbs_seg_tab<VT, NCH, TPW><<<gridt, block, 0, g->stream>>>(d, tab, nbt, burnin, K0, K1, S0, S1)
-                                    if (nch == 1) { if (tpw == 1) NSK_SEGT(1, 1); else if (tpw == 2) NSK_SEGT(1, 2); else NSK_SEGT(1, 4); }
-                                    else { if (tpw == 1) NSK_SEGT(2, 1); else NSK_SEGT(2, 2); }
-#undef NSK_SEGT
+                                if (kind >= 8) {
+                                    // resident grid over tile pairs: at most 8 blocks per CU
+                                    const int npairs = tab.ntiles / 2;
+                                    const int nbp = std::min(2048, 8 * ((((npairs + 3) / 4) + 7) / 8));
+                                    if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
+                                    else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
                                 }
                                 else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
                                 else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
@@ -134,6 +125,11 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                             for (const Compiled::Segment *sgp : mine) {
                                 const Compiled::Segment &sg = *sgp;
                                 SegEntry &en = tab.e[tab.n];
+                                // table launches number their tiles virtually: a segment starts on a pair
+                                // boundary (positions 128 m), with one dead tile in front when needed
+                                const int lead = kind >= 8 ? (int)((sg.pos0 / 64) & 1) : 0;
+                                const int vtiles = kind >= 8 ? ((sg.ntiles + lead + 1) & ~1) : sg.ntiles;
+                                en.ntiles_lead = (uint32_t)sg.ntiles | ((uint32_t)lead << 30);
                                 en.tile_start = tab.ntiles;
                                 en.pos0 = (int)sg.pos0;
                                 en.adj_off = sg.adj_off;
@@ -142,7 +138,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8);
                                 en.d16off = sg.d16 >= 0 ? (uint32_t)sg.d16 : NSK_NO_D16_STREAM;
                                 en.d16base = sg.d16base;
-                                tab.ntiles += sg.ntiles;
+                                tab.ntiles += vtiles;
                                 if (++tab.n == NSK_SEG_MAX) flush();
                             }
                             flush();

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_WAVES) void k_gibbs_phase(De
     if (!(ev == 0 || sample_evidence)) return;          // inference.py:24 (ev == 4 never gets a position)
     const int v = g.p_vid[p];
     if (v < 0) return;
-    const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const uint2 r = inf_words(k0, k1, (uint32_t)p, s0, s1);
     const int nv = draw_sample<VT, true>(g, p, info, g.p_slot[p], g.val, u53(r.x, r.y));   // inline stream
     g.val[p] = (VT)nv;                                  // values live at the variable's position
     if (!burnin) {                                      // inference.py:29-33
@@ -58,7 +58,7 @@ __device__ __forceinline__ void heavy_update(const DevGraph<VT> &g, int p, int s
     const int ev = NSK_INFO_EV(info);
     const int v = g.p_vid[p];
     if (v < 0 || !(ev == 0 || sample_evidence)) return;
-    const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const uint2 r = inf_words(k0, k1, (uint32_t)p, s0, s1);
     const int nv = wave_draw_sample(g, p, info, g.p_slot[p], g.val, u53(r.x, r.y));
     if ((threadIdx.x & 63) == 0) {
         g.val[p] = (VT)nv;
@@ -719,7 +719,7 @@ __device__ __forceinline__ void heavy_update_ep(const DevGraph<VT> &g, const uin
     if (v < 0 || !(ev == 0 || sample_evidence)) return;
     const int card = NSK_INFO_CARD(info);
     const double pc = hub_potentials(g, lut, hd, g.val);
-    const u32x4 r = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const uint2 r = inf_words(k0, k1, (uint32_t)p, s0, s1);
     const int nv = hub_draw(pc, card, u53(r.x, r.y));
     if ((threadIdx.x & 63) == 0) {
         g.val[p] = (VT)nv;
@@ -775,7 +775,7 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
 #ifdef NSK_ABL_NODRAW
     const int nv = pot.p[0] > pot.p[1] ? 0 : 1;
 #else
-    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const uint2 rr = inf_words(k0, k1, (uint32_t)p, s0, s1);
     const int nv = pot.draw(maxcard, card, u53(rr.x, rr.y));
 #endif
     g.val[p] = (VT)nv;
@@ -851,7 +851,7 @@ __device__ __forceinline__ void fast_tile_update(const DevGraph<VT> &g, int pbeg
     if (!valid) return;
     const int ev = NSK_INFO_EV(info);
     if (!(ev == 0 || sample_evidence)) return;
-    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const uint2 rr = inf_words(k0, k1, (uint32_t)p, s0, s1);
     const double z0 = nsk_exp(p0);
     const double z1 = z0 + nsk_exp(p1);
     const double z = u53(rr.x, rr.y) * z1;
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
 // line: ids, 16-byte member loads, byte gathers, compares, draw, store.
 #define NSK_SEG_MAX 8
 #define NSK_NO_D16_STREAM 0xFFFFFFFFu      // SegTable.d16off of a segment without a compact stream
-struct SegEntry {                         // 32 bytes: one scalar load per tile
+struct SegEntry {                         // 48 bytes: two scalar loads per tile (pair)
     int tile_start;                       // first tile of the segment in this launch's numbering
     int pos0;                             // position of the segment's first lane
     uint32_t adj_off;                     // stream offset (16-byte units) of its first tile
@@ -936,6 +936,9 @@ struct SegEntry {                         // 32 bytes: one scalar load per tile
     uint32_t zmask_ev;                    // (1 << member slots) - 1 | (uint8) common isEvidence << 8
     uint32_t d16off;                      // first 8-byte unit of the compact stream, NSK_NO_D16_STREAM: none
     int d16base;                          // member position = own position + d16base + int16 delta
+    uint32_t ntiles_lead;                 // table launches: tiles of the segment | lead << 30 (one dead
+                                          //   virtual tile in front: the segment starts on an upper half)
+    uint32_t pad_[3];
 };
 struct SegTable {
     int n, ntiles;                        // segments, tiles of the launch; e[i].tile_start = ntiles for i >= n
@@ -1060,128 +1063,56 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
 }
 
 // Homogeneous segments whose programs have draw tables: ids, byte gathers, bit pack, one 8-byte
-// table read, integer compare.  No float64 arithmetic.  A wave walks TPW consecutive tiles of the
-// launch at once: all their loads are issued before the first dependent gather, which is what
-// keeps enough bytes in flight per SIMD (one tile per wave: 28.6 us per 10M-grid class at full
-// occupancy, two thirds of the wave-cycles waiting).
-template <typename VT, int NCH, int TPW>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int nblocks,
-                                                             int burnin, uint32_t k0, uint32_t k1,
-                                                             uint32_t s0, uint32_t s1) {
-    const int lb = xcd_logical_block((int)blockIdx.x, nblocks);
-    if (lb < 0) return;
-    const int lane = (int)(threadIdx.x & 63);
-    const int T0 = __builtin_amdgcn_readfirstlane((lb * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6)) * TPW);
-    const int ntiles = tab.ntiles;
-    if (T0 >= ntiles) return;
-    int p[TPW], v[TPW];
-    uint8_t tally[TPW];
-    uint32_t id[TPW][4 * NCH];
-    uint32_t zoff[TPW], zmask[TPW];
-    bool live[TPW];
-    uint32_t w16[TPW][2 * NCH];
-    int dbase[TPW];
-    bool u16[TPW];
-#pragma unroll
-    for (int k = 0; k < TPW; k++) {
-        const int T = min(T0 + k, ntiles - 1);                // wave-uniform; a clamped tile is not stored
-        live[k] = T0 + k < ntiles;
-        const int sidx = seg_of_tile(tab, T);
-        const SegEntry en = tab.e[sidx];                      // one 32-byte scalar load
-        const int t = T - en.tile_start;
-        p[k] = en.pos0 + t * 64 + lane;
-        zoff[k] = en.zoff; zmask[k] = (en.zmask_ev & 0xFFu);
-        // a segment with a compact stream reads int16 deltas, the others 32-bit ids (wave-uniform)
-        u16[k] = en.d16off != NSK_NO_D16_STREAM;
-        dbase[k] = en.d16base;
-        if (u16[k]) {
-            d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16[k]);
-        } else {
-            const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const uint4 q = sp[c * 64];
-                id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
-            }
-        }
-        v[k] = g.p_vid[p[k]];                                 // -1: padding lane at a class end
-        tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[p[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < TPW; k++)
-        if (u16[k]) d16_ids<NCH>(w16[k], p[k] + dbase[k], id[k]);
-    uint32_t idx[TPW];
-#pragma unroll
-    for (int k = 0; k < TPW; k++) {
-        uint32_t x[4 * NCH];
-#pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) x[j] = (uint32_t)g.val[id[k][j]];
-        idx[k] = 0;
-#pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (x[j] & 1u) << j;
-        idx[k] &= zmask[k];
-    }
-    uint2 e[TPW];
-#pragma unroll
-    for (int k = 0; k < TPW; k++) e[k] = *(const uint2 *)(g.ztab + zoff[k] + idx[k]);
-#pragma unroll
-    for (int k = 0; k < TPW; k++) {
-#ifdef NSK_ABL_NOPHILOX
-        const u32x4 rr = {(uint32_t)v[k] * 2654435761u ^ s0, (uint32_t)v[k] * 40503u + k0, 0u, 0u};
-#else
-        const u32x4 rr = philox4x32(k0, k1, (uint32_t)v[k], 0u, s0, s1);
-#endif
-        const unsigned long long K = ((unsigned long long)e[k].y << 32) | e[k].x;
-        const int nv = k53(rr.x, rr.y) > K ? 1 : 0;
-        // padding lanes (and the clamped tile past the end) store to a scratch line instead of
-        // branching: a branch here lets the compiler sink this tile's gathers and table read into
-        // it, behind the other tile's -- two more dependent round trips per wave
-        const bool ok = live[k] && v[k] >= 0;
-        VT *dst = ok ? g.val + p[k] : (VT *)g.sink + lane;
-        *dst = (VT)nv;
-        if (!burnin) {
-            uint8_t *td = ok ? g.cnt_pos + p[k] : g.sink + 256 + lane;
-            *td = (uint8_t)(tally[k] + nv);
-        }
-    }
-}
-
-#ifdef NSK_ABL_PAIR
-// EXPERIMENT (timing only, wrong stream): two consecutive tiles per trip sharing ONE Philox call
-// keyed by the first tile's lane position (words 0-1 / 2-3), no p_vid load.
+// table read, integer compare.  No float64 arithmetic, no p_vid.
+// * Resident grid (8 waves per SIMD): the waves loop over tile PAIRS, so the per-wave set-up --
+//   kernel-argument loads, the Philox key schedule, base pointers -- is paid once per wave, and XCD x
+//   walks the x-th eighth of the pairs (same locality as xcd_logical_block).
+// * A pair is two tiles at positions 128 m .. 128 m + 127: lane l holds generator ids q and q + 64,
+//   which share one Philox block (nsk_device.h inf_block) -- ONE Philox evaluation per lane serves two
+//   updates.  The host numbers a launch's tiles "virtually": every segment starts on a pair boundary
+//   (lead = 1 inserts a dead tile in front when its first tile is the upper half of a pair).
+// * Padding lanes (class ends) sample like any other lane into their own, never-read, position; the
+//   tally fold skips them.
+// The kernel is bound by instruction issue; these three points took a 10M-grid
+// class from 23.7 to 16.3 us.
 template <typename VT, int NCH>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab_p(DevGraph<VT> g, SegTable tab, int burnin,
-                                                               uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
+                                                             uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
     const int lane = (int)(threadIdx.x & 63);
-    const int ntiles = tab.ntiles;
-    const int npairs = (ntiles + 1) >> 1;
-    const int per = (npairs + 7) >> 3;
+    const int npairs = tab.ntiles >> 1;                                 // virtual tiles: always even
+    const int per = (npairs + 7) >> 3;                                  // pairs per XCD
     const int xcd = (int)(blockIdx.x & 7);
     const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
-    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);
+    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
     const int pend = min(npairs, (xcd + 1) * per);
     for (int P = xcd * per + wx; P < pend; P += wpx) {
-        int p[2];
-        uint32_t id[2][4 * NCH];
-        uint32_t zoff[2], zmask[2];
-        uint8_t tally[2];
+        const int sidx = seg_of_tile(tab, 2 * P);
+        const SegEntry en = tab.e[sidx];
+        const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu), lead = (int)(en.ntiles_lead >> 30);
+        const int t0 = 2 * P - en.tile_start - lead;                    // segment tile of the lower half
+        const bool u16 = en.d16off != NSK_NO_D16_STREAM;
         bool live[2];
+        int p[2];
+        uint8_t tally[2];
+        uint32_t id[2][4 * NCH], w16[2][2 * NCH];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const int T = min(2 * P + k, ntiles - 1);
-            live[k] = 2 * P + k < ntiles;
-            const int sidx = seg_of_tile(tab, T);
-            const SegEntry en = tab.e[sidx];
-            const int t = T - en.tile_start;
-            p[k] = en.pos0 + t * 64 + lane;
-            zoff[k] = en.zoff; zmask[k] = en.zmask_ev & 0xFFu;
-            const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+            live[k] = t0 + k >= 0 && t0 + k < nt;                       // wave-uniform
+            const int t = live[k] ? t0 + k : (t0 + k < 0 ? 0 : nt - 1);
+            p[k] = en.pos0 + (t0 + k) * 64 + lane;                      // the GENERATOR id keeps the pair's geometry
+            const int pl = en.pos0 + t * 64 + lane;                     // (a dead tile reads a real one's data)
+            if (u16) {
+                d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16[k]);
+            } else {
+                const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const uint4 q = sp[c * 64];
-                id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+                for (int c = 0; c < NCH; c++) {
+                    const uint4 q = sp[c * 64];
+                    id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+                }
             }
-            tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[p[k]];
+            tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl];
+            if (u16) d16_ids<NCH>(w16[k], pl + en.d16base, id[k]);
         }
         uint32_t idx[2];
 #pragma unroll
@@ -1189,17 +1120,18 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab_p(DevGraph<VT> g, S
             idx[k] = 0;
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) idx[k] |= ((uint32_t)g.val[id[k][j]] & 1u) << j;
-            idx[k] &= zmask[k];
+            idx[k] &= en.zmask_ev & 0xFFu;
         }
         uint2 e[2];
 #pragma unroll
-        for (int k = 0; k < 2; k++) e[k] = *(const uint2 *)(g.ztab + zoff[k] + idx[k]);
-        const u32x4 rr = philox4x32(k0, k1, (uint32_t)p[0], 0u, s0, s1);
+        for (int k = 0; k < 2; k++) e[k] = *(const uint2 *)(g.ztab + en.zoff + idx[k]);
+        // p[0] is a multiple-of-128 block's lower half, p[1] = p[0] + 64 its upper half: one block
+        const u32x4 rr = philox4x32(k0, k1, inf_block((uint32_t)p[0]), 0u, s0, s1);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const unsigned long long K = ((unsigned long long)e[k].y << 32) | e[k].x;
             const int nv = (k == 0 ? k53(rr.x, rr.y) : k53(rr.z, rr.w)) > K ? 1 : 0;
-            VT *dst = live[k] ? g.val + p[k] : (VT *)g.sink + lane;
+            VT *dst = live[k] ? g.val + p[k] : (VT *)g.sink + lane;     // (no branch: see seg_of_tile's note)
             *dst = (VT)nv;
             if (!burnin) {
                 uint8_t *td = live[k] ? g.cnt_pos + p[k] : g.sink + 256 + lane;
@@ -1208,62 +1140,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab_p(DevGraph<VT> g, S
         }
     }
 }
-#else
-// Persistent flavour of k_gibbs_seg_tab: a resident grid (8 waves per SIMD) whose waves loop over
-// tiles, so the per-wave set-up -- kernel-argument loads, the Philox key schedule, base pointers --
-// is paid once per wave instead of once per tile pair.  XCD x walks the x-th eighth of the tiles
-// (same locality as xcd_logical_block).  The table kernels are bound by instruction issue
-// (DESIGN.md section 4): this variant exists to cut scalar instructions per tile.
-template <typename VT, int NCH>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab_p(DevGraph<VT> g, SegTable tab, int burnin,
-                                                               uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
-    const int lane = (int)(threadIdx.x & 63);
-    const int ntiles = tab.ntiles;
-    const int per = (ntiles + 7) >> 3;                                  // tiles per XCD
-    const int xcd = (int)(blockIdx.x & 7);
-    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
-    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
-    const int tend = min(ntiles, (xcd + 1) * per);
-    for (int T = xcd * per + wx; T < tend; T += wpx) {
-        const int sidx = seg_of_tile(tab, T);
-        const SegEntry en = tab.e[sidx];
-        const int t = T - en.tile_start;
-        const int p = en.pos0 + t * 64 + lane;
-        uint32_t id[4 * NCH];
-        const bool u16 = en.d16off != NSK_NO_D16_STREAM;
-        uint32_t w16[2 * NCH];
-        if (u16) {
-            d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16);
-        } else {
-            const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const uint4 q = sp[c * 64];
-                id[4 * c] = q.x; id[4 * c + 1] = q.y; id[4 * c + 2] = q.z; id[4 * c + 3] = q.w;
-            }
-        }
-        const int v = g.p_vid[p];                             // -1: padding lane at a class end
-        const uint8_t tally = burnin ? (uint8_t)0 : g.cnt_pos[p];
-        if (u16) d16_ids<NCH>(w16, p + en.d16base, id);
-        uint32_t idx = 0;
-#pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) idx |= ((uint32_t)g.val[id[j]] & 1u) << j;
-        idx &= en.zmask_ev & 0xFFu;
-        const uint2 e = *(const uint2 *)(g.ztab + en.zoff + idx);
-        const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
-        const unsigned long long K = ((unsigned long long)e.y << 32) | e.x;
-        const int nv = k53(rr.x, rr.y) > K ? 1 : 0;
-        const bool ok = v >= 0;
-        VT *dst = ok ? g.val + p : (VT *)g.sink + lane;
-        *dst = (VT)nv;
-        if (!burnin) {
-            uint8_t *td = ok ? g.cnt_pos + p : g.sink + 256 + lane;
-            *td = (uint8_t)(tally + nv);
-        }
-    }
-}
-
-#endif
 
 template <typename VT, int KIND, int NCH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTable tab, int nblocks,
@@ -1303,7 +1179,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTabl
         if (KIND) pair_step<KIND>(thi, tlo, x[j], p0, p1);
         else slot_step(st, pp[j], thi, tlo, x[j], p0, p1);
     }
-    const u32x4 rr = philox4x32(k0, k1, (uint32_t)v, 0u, s0, s1);
+    const uint2 rr = inf_words(k0, k1, (uint32_t)p, s0, s1);
     const double z0 = nsk_exp(p0);
     const double z1 = z0 + nsk_exp(p1);
     const double z = u53(rr.x, rr.y) * z1;

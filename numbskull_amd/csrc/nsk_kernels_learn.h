@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
             const int ev = NSK_INFO_EV(info);
             const int slot0 = g.p_slot[p];
             v = g.p_vid[p];
-            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
             if (ev != 1) evidence = draw_sample<VT, INL>(g, p, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
             else evidence = (int)g.p_init[p];                                                            // 61-62
             g.val_evid[p] = (VT)evidence;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
             self = p;
             if (lp.learn_non_evidence || ev == 1) {                                               // 71-72
                 if (lp.regularization == 1) {                                                     // 90
-                    const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+                    const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
                     truncate = u53(t.x, t.y) < lp.inv_trunc;
                 }
                 const int step = NSK_INFO_DT1(info);
@@ -168,7 +168,7 @@ __device__ __forceinline__ void learn_heavy_variable(const DevGraph<VT> &g, cons
     const uint32_t info = g.p_info[p];
     const int ev = NSK_INFO_EV(info);
     const int slot0 = g.p_slot[p];
-    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
     int evidence;
     if (ev != 1) evidence = wave_draw_sample(g, p, info, slot0, g.val_evid, u53(r.z, r.w));
     else evidence = (int)g.p_init[p];
@@ -177,7 +177,7 @@ __device__ __forceinline__ void learn_heavy_variable(const DevGraph<VT> &g, cons
     if (!(lp.learn_non_evidence || ev == 1)) return;
     bool truncate = false;
     if (lp.regularization == 1) {
-        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
         truncate = u53(t.x, t.y) < lp.inv_trunc;
     }
     const int step = NSK_INFO_DT1(info);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void learn_heavy_variable_ep(const DevGraph<VT> &g, c
     if (v < 0) return;
     const uint32_t info = g.p_info[p];
     const int ev = NSK_INFO_EV(info), card = NSK_INFO_CARD(info);
-    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
     int evidence;
     if (ev != 1) evidence = hub_draw(hub_potentials(g, lut, hd, g.val_evid), card, u53(r.z, r.w));   // 54-58
     else evidence = (int)g.p_init[p];                                                             // 61-62
@@ -232,7 +232,7 @@ __device__ __forceinline__ void learn_heavy_variable_ep(const DevGraph<VT> &g, c
     if (!(lp.learn_non_evidence || ev == 1)) return;                                               // 71-72
     bool truncate = false;
     if (lp.regularization == 1) {                                                                  // 90
-        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
         truncate = u53(t.x, t.y) < lp.inv_trunc;
     }
     const int n = (int)hd.y, M = (int)(hd.z & 0xFFu), rows = 2 + M;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
             }
         }
     }
-    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
     int evidence = init;                                                  // learning.py:61-62
     if (need_evid && ev != 1) {                                           // 54-58
         const double z0 = nsk_exp(q0), z1 = z0 + nsk_exp(q1);
@@ -361,7 +361,7 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
     const bool part = valid && (lp.learn_non_evidence || ev == 1);        // 71-72
     bool truncate = false;
     if (lp.regularization == 1) {                                         // 90
-        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
         truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
     }
     const unsigned long long pm = __ballot(part);
@@ -463,7 +463,7 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
             }
         }
     }
-    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
     int evidence = init;
     if (need_evid && ev != 1) {
         const double z0 = nsk_exp(q0), z1 = z0 + nsk_exp(q1);
@@ -480,7 +480,7 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
     const bool part = valid && (lp.learn_non_evidence || ev == 1);
     bool truncate = false;
     if (lp.regularization == 1) {
-        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
         truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
     }
     if (__ballot(part) == 0) return;
@@ -542,7 +542,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
                                        a.close(d1, lut, cstar, A, B);
                                        pf.add(maxcard, d1, w, cstar, A, B);
                                    });
-    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v, 0u, lp.s0, lp.s1);
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
     int evidence = valid ? (int)g.p_init[p] : 0;                                       // learning.py:61-62
     if (need_evid && ev != 1) evidence = pe.draw(maxcard, card, u53(r.z, r.w));        // 54-58
     const int proposal = pf.draw(maxcard, card, u53(r.x, r.y));                        // 66-70
@@ -553,7 +553,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
     const bool part = valid && (lp.learn_non_evidence || ev == 1);                     // 71-72
     bool truncate = false;
     if (lp.regularization == 1) {
-        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)v, 1u, lp.s0, lp.s1);
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
         truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
     }
 #ifdef NSK_ABL_NOPASS2
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog[k]);
-            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)v[k], 0u, lp.s0, lp.s1);
+            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p[k], 0u, lp.s0, lp.s1);
             int evidence = init[k];                                               // learning.py:61-62
             if (ev[k] != 1) evidence = k53(r.z, r.w) > (((unsigned long long)ee[k].y << 32) | ee[k].x) ? 1 : 0;   // 54-58
             const int proposal = k53(r.x, r.y) > (((unsigned long long)ef[k].y << 32) | ef[k].x) ? 1 : 0;         // 66-70
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             const bool part = valid[k] && (lp.learn_non_evidence || ev[k] == 1);  // 71-72
             bool truncate = false;
             if (lp.regularization == 1) {                                         // 90
-                const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)v[k], 1u, lp.s0, lp.s1);
+                const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)p[k], 1u, lp.s0, lp.s1);
                 truncate = part && (u53(tt.x, tt.y) < lp.inv_trunc);
             }
             const unsigned long long pm = __ballot(part);

@@ -83,12 +83,12 @@ static __global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stre
 
 // position-indexed tally deltas of the fast path -> int64 master copy at cstart[vid]
 static __global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(uint8_t *cnt_pos, const int32_t *p_cnt,
-                                                               long long *total, int npos) {
+                                                               const int32_t *p_vid, long long *total, int npos) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= npos) return;
     const int d = cnt_pos[i];
     if (d) {
-        total[p_cnt[i]] += (long long)d;
+        if (p_vid[i] >= 0) total[p_cnt[i]] += (long long)d;      // (padding lanes of the table kernels tally too)
         cnt_pos[i] = 0;
     }
 }

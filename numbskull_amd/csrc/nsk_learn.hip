@@ -28,7 +28,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
         lp.s0 = (uint32_t)g->sweep; lp.s1 = (uint32_t)(g->sweep >> 32);
         for (size_t ph = 0; ph < nphase; ph++) {
             const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
-            const int e = (int)g->c.phase_start[ph + 1];
+            const int e = (int)g->c.phase_end[ph];
             if (e <= fb) continue;
             lp.hub0 = (int)g->c.phase_hub_base[ph];
             int rows = 0;

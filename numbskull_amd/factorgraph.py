@@ -165,6 +165,14 @@ class FactorGraph(object):
         _lib.check(_lib.lib().nsk_graph_get_info(self._engine(), C.byref(inf)))
         return {k: getattr(inf, k) for k, _ in inf._fields_}
 
+    def layout(self):
+        """Internal id of every variable (its index in the device's value arrays; for a sampled
+        variable its position in the compiled layout = its generator id in the chromatic scan)."""
+        iid = np.zeros(self.variable.shape[0], np.int32)
+        nid = C.c_int64()
+        _lib.check(_lib.lib().nsk_graph_get_layout(self._engine(), _lib.ptr(iid), C.byref(nid)))
+        return iid.astype(np.int64)
+
     def colors(self):
         out = np.zeros(self.variable.shape[0], np.int32)
         _lib.check(_lib.lib().nsk_graph_get_colors(self._engine(), _lib.ptr(out)))

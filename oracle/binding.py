@@ -21,7 +21,7 @@ class _Graph(C.Structure):
                 ("nedge", C.c_int64), ("nvtf", C.c_int64),
                 ("weight", C.c_void_p), ("variable", C.c_void_p), ("factor", C.c_void_p),
                 ("fmap", C.c_void_p), ("vmap", C.c_void_p), ("factor_index", C.c_void_p),
-                ("head_by_vid", C.c_int)]
+                ("head_by_vid", C.c_int), ("rng_id", C.c_void_p)]
 
 
 class _MT(C.Structure):
@@ -108,13 +108,24 @@ class Graph:
         self.g = _Graph(len(self.variable), len(self.factor), len(self.weight), len(self.fmap),
                         len(self.vmap), self.weight.ctypes.data, self.variable.ctypes.data,
                         self.factor.ctypes.data, self.fmap.ctypes.data, self.vmap.ctypes.data,
-                        self.factor_index.ctypes.data, int(bool(head_by_vid)))
+                        self.factor_index.ctypes.data, int(bool(head_by_vid)), None)
+        self.rng_id = None
         card = self.variable["cardinality"]
         self.cstart = np.zeros(len(card) + 1, np.int64)
         self.cstart[1:] = np.where(card == 2, 1, card)
         np.cumsum(self.cstart, out=self.cstart)
         self.maxcard = int(card.max()) if len(card) else 1
         self.maxlist = int(self.vmap["factor_index_length"].max()) if len(self.vmap) else 0
+
+    def set_rng_ids(self, ids):
+        """Device mode: the generator id of every variable = its position in the library's layout
+        (FactorGraph.layout()); None = the variable id."""
+        if ids is None:
+            self.rng_id, self.g.rng_id = None, None
+        else:
+            self.rng_id = np.ascontiguousarray(ids, np.int64)
+            assert len(self.rng_id) == len(self.variable)
+            self.g.rng_id = self.rng_id.ctypes.data
 
     # ---- state helpers (factorgraph.py:41-53) ----
     def initial_state(self):

@@ -568,11 +568,19 @@ int orc_gibbs_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             const orc_variable *var = &g->variable[v];
             if (var->isEvidence == 4) continue;
             if (!(var->isEvidence == 0 || sample_evidence)) continue;
+            /* device-mode generator of the inference sweep: the variable's
+             * generator id q is its position in the library's layout (g->rng_id; identity when
+             * absent); ids q and q + 64 with equal q >> 7 share ONE Philox block -- counter
+             * ((q >> 7) * 64 + (q & 63), 0, sweep), words 0-1 for the lower id, 2-3 for the upper */
             uint32_t r[4];
-            orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)v, 0u,
+            const uint64_t q = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
+            orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32),
+                           (uint32_t)(((q >> 7) << 6) | (q & 63u)), 0u,
                            (uint32_t)sweep, (uint32_t)(sweep >> 32), r);
+            const int half = (int)((q >> 6) & 1u);
             int64_t nv;
-            rc = draw_sample(g, v, Z, var_value, weight_value, orc_u53(r[0], r[1]), 1, &nv);
+            rc = draw_sample(g, v, Z, var_value, weight_value,
+                             half ? orc_u53(r[2], r[3]) : orc_u53(r[0], r[1]), 1, &nv);
             if (rc) break;
             var_value[v] = nv;
             if (!burnin) {
@@ -629,8 +637,11 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             int64_t v = order[i];
             const orc_variable *var = &g->variable[v];
             if (var->isEvidence == 4) continue;
+            /* learning sweep: one block per variable, counter (q, stream, sweep); stream 0 words 0-1
+             * free chain, 2-3 evidence chain; stream 1 words 0-1 the truncation coin */
             uint32_t r[4];
-            orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)v, 0u,
+            const uint64_t q = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
+            orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)q, 0u,
                            (uint32_t)sweep, (uint32_t)(sweep >> 32), r);
             int64_t evidence, proposal;
             if (var->isEvidence != 1) {
@@ -648,7 +659,7 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             int truncate = 0;
             if (regularization == 1) {
                 uint32_t t[4];
-                orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)v, 1u,
+                orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)q, 1u,
                                (uint32_t)sweep, (uint32_t)(sweep >> 32), t);
                 truncate = orc_u53(t[0], t[1]) < 1.0 / (double)truncation;
             }

@@ -31,10 +31,15 @@ def session(g, **kw):
     return ns, ns.factorGraphs[0]
 
 
-def oracle_of(fg, head_by_vid=False):
-    """Oracle view of the arrays a product FactorGraph holds."""
-    return orc.Graph(fg.weight, fg.variable, fg.factor, fg.fmap, fg.vmap, fg.factor_index,
-                     head_by_vid=head_by_vid)
+def oracle_of(fg, head_by_vid=False, layout=True):
+    """Oracle view of the arrays a product FactorGraph holds.  Device mode keys its generator by
+    the variables' positions in the library's compiled layout: on a GPU box
+    the oracle is handed that layout (``layout=False`` for host-only uses)."""
+    og = orc.Graph(fg.weight, fg.variable, fg.factor, fg.fmap, fg.vmap, fg.factor_index,
+                   head_by_vid=head_by_vid)
+    if layout and numbskull_amd._lib.device_count() > 0:
+        og.set_rng_ids(fg.layout())
+    return og
 
 
 def phases_from_colors(color):
