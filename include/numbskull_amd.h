@@ -91,9 +91,14 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
 int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid,
                        double *weight_value, int64_t *count);
 
-/* RNG: chromatic scan draws from Philox4x32-10 keyed by `seed` with counter
- * (variable id, stream, sweep index); the sweep index starts at `sweep0` and advances by one per
- * sweep of any kind.  Sequential scan seeds MT19937 like np.random.seed(seed); random.seed(seed). */
+/* RNG: the chromatic scan draws from Philox4x32-10 keyed by `seed`.  A variable's generator id is
+ * its position in the compiled layout (nsk_graph_get_layout), so samples are a function of the seed
+ * AND the layout the library chose (device, flags and diagnostic switches being equal, a graph
+ * always compiles to the same layout).  Learning sweeps: counter (id, stream, sweep index);
+ * inference sweeps: ids q and q + 64 with equal q >> 7 share one block, counter
+ * ((q >> 7) * 64 + (q & 63), 0, sweep index), words 0-1 / 2-3.  The sweep index starts at `sweep0`
+ * and advances by one per sweep of any kind.  Sequential scan seeds MT19937 like
+ * np.random.seed(seed); random.seed(seed). */
 int nsk_set_seed(nsk_graph *g, uint64_t seed, uint64_t sweep0);
 int nsk_set_scan(nsk_graph *g, int scan);
 /* Chromatic learning applies sample_and_sgd's update (learning.py:110-125) once per colour class:
