@@ -206,6 +206,15 @@ int nsk_parse_factors(const uint8_t *data, int64_t nbytes, int64_t nfactor, int6
                       nsk_factor *factor, nsk_ftv *fmap, const uint8_t *domain_mask,
                       const nsk_variable *variable, int64_t nvar, const nsk_vtf *vmap);
 
+/* dataloading.load_domains (dataloading.py:159-187) on the raw bytes of graph.domains: marks
+ * domain_mask, fills vmap[vtf_offset ..].value and re-maps initialValue exactly as the reference. */
+int nsk_parse_domains(const uint8_t *data, int64_t nbytes, uint8_t *domain_mask, int64_t nvar,
+                      nsk_variable *variable, nsk_vtf *vmap, int64_t nvtf);
+/* FactorGraph.dump_probabilities (factorgraph.py:216-229): the "<vid> <value> <prob>" text file. */
+int nsk_write_probabilities(const char *path, int64_t nvar, const nsk_variable *variable,
+                            const nsk_vtf *vmap, const int64_t *cstart, const int64_t *count,
+                            double epochs);
+
 /* Self-test hooks: run the device exp / Philox on caller data (parity tests vs the oracle). */
 int nsk_selftest_exp(int device, const double *x, double *y, int64_t n);
 int nsk_selftest_philox(int device, uint64_t seed, uint64_t sweep, uint32_t stream, int64_t n,

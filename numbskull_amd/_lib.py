@@ -26,7 +26,7 @@ SYMBOLS = (
     "nsk_graph_get_colors", "nsk_graph_get_layout", "nsk_graph_plan", "nsk_graph_plan_needs", "nsk_profile_begin", "nsk_profile_end", "nsk_device_buffer",
     "nsk_set_stream", "nsk_synchronize", "nsk_ghost_needs", "nsk_exchange_setup", "nsk_exchange_pack",
     "nsk_exchange_unpack", "nsk_comm_unique_id", "nsk_comm_init", "nsk_gibbs_sweeps_exchange",
-    "nsk_learn_sweeps_exchange", "nsk_compute_var_map", "nsk_parse_factors",
+    "nsk_learn_sweeps_exchange", "nsk_compute_var_map", "nsk_parse_factors", "nsk_parse_domains", "nsk_write_probabilities",
     "nsk_selftest_exp", "nsk_selftest_philox", "nsk_selftest_stream", "nsk_device_count", "nsk_last_error", "nsk_version",
 )
 
@@ -104,6 +104,10 @@ def lib():
                                           C.c_void_p, C.c_void_p, C.c_int64]
         L.nsk_parse_factors.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.nsk_parse_domains.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_int64]
+        L.nsk_write_probabilities.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_double]
         L.nsk_device_count.argtypes = [C.POINTER(C.c_int)]
         L.nsk_selftest_exp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
         L.nsk_selftest_stream.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]

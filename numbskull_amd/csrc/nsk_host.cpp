@@ -2,12 +2,15 @@
 //
 //   nsk_compute_var_map  <-  numbskull/dataloading.py:16-81  compute_var_map
 //   nsk_parse_factors    <-  numbskull/dataloading.py:196-235 load_factors
+//   nsk_parse_domains    <-  numbskull/dataloading.py:159-187 load_domains
+//   nsk_write_probabilities <- numbskull/factorgraph.py:216-229 dump_probabilities
 //
 // These run once per graph load (not per sweep) and need no GPU.  They reproduce the reference's
 // output arrays exactly, including the quirks a caller can observe: offsets are not compacted
 // after de-duplication, slot lengths count the edges of skipped factors, and slices are clipped
 // to the factor_index array like numpy slices are.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -127,5 +130,59 @@ extern "C" int nsk_parse_factors(const uint8_t *data, int64_t nbytes, int64_t nf
         memcpy(&factor[i].featureValue, &fv, 8);
         index += 16;
     }
+    return NSK_OK;
+}
+
+
+// graph.domains (dataloading.py:159-187): blocks of (variable id, cardinality, cardinality values),
+// all big-endian int64.  Marks the variable, stores its domain in vmap[vtf_offset ..].value and
+// rewrites its initialValue as a dense index -- the reference rewrites it EVERY time a domain value
+// matches the CURRENT initialValue while scanning j = 0 .. cardinality-1, so a later match can re-map
+// an earlier result; restated as coded.
+extern "C" int nsk_parse_domains(const uint8_t *data, int64_t nbytes, uint8_t *domain_mask, int64_t nvar,
+                                 nsk_variable *variable, nsk_vtf *vmap, int64_t nvtf) {
+    int64_t i = 0;
+    while (i + 16 <= nbytes) {
+        const int64_t vid = (int64_t)be64(data + i), card = (int64_t)be64(data + i + 8);
+        i += 16;
+        if (vid < 0 || vid >= nvar) { nsk::set_error("graph.domains: variable id outside the variables"); return NSK_E_INDEX; }
+        if (card < 0 || i + 8 * card > nbytes) { nsk::set_error("graph.domains truncated"); return NSK_E_INDEX; }
+        const int64_t off = variable[vid].vtf_offset;
+        if (off < 0 || off + card > nvtf) { nsk::set_error("graph.domains: domain outside vmap"); return NSK_E_INDEX; }
+        domain_mask[vid] = 1;
+        int64_t init = variable[vid].initialValue;
+        for (int64_t j = 0; j < card; j++) {
+            const int64_t val = (int64_t)be64(data + i + 8 * j);
+            vmap[off + j].value = val;
+            if (val == init) init = j;
+        }
+        variable[vid].initialValue = init;
+        i += 8 * card;
+    }
+    if (i != nbytes) { nsk::set_error("graph.domains: trailing bytes"); return NSK_E_INDEX; }
+    return NSK_OK;
+}
+
+// dump_probabilities (factorgraph.py:216-229): "<vid> <value> <prob %.3f>" lines; a binary variable
+// prints the probability of value 1, any other one line per domain value (vmap.value).
+extern "C" int nsk_write_probabilities(const char *path, int64_t nvar, const nsk_variable *variable,
+                                       const nsk_vtf *vmap, const int64_t *cstart, const int64_t *count,
+                                       double epochs) {
+    FILE *f = fopen(path, "w");
+    if (!f) { nsk::set_error(std::string("cannot open ") + path); return NSK_E_INVALID; }
+    std::vector<char> buf(1 << 20);
+    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    for (int64_t i = 0; i < nvar; i++) {
+        if (variable[i].cardinality == 2) {
+            fprintf(f, "%lld %d %.3f\n", (long long)i, 1, (double)count[cstart[i]] / epochs);
+            continue;
+        }
+        for (int64_t k = 0; k < variable[i].cardinality; k++)
+            fprintf(f, "%lld %lld %.3f\n", (long long)i, (long long)vmap[variable[i].vtf_offset + k].value,
+                    (double)count[cstart[i] + k] / epochs);
+    }
+    const int bad = ferror(f);
+    fclose(f);
+    if (bad) { nsk::set_error("write error"); return NSK_E_INVALID; }
     return NSK_OK;
 }

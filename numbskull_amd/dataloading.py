@@ -67,23 +67,13 @@ def load_variables(data, nvariables, variables):
 def load_domains(data, domain_mask, vmap, variables):
     """graph.domains: (vid, cardinality, values...) blocks; marks the variable, stores its sorted
     domain in ``vmap.value`` and rewrites its initialValue as a dense index
-    (dataloading.py:159-187)."""
-    words = np.frombuffer(data, ">i8").astype(np.int64)
-    i = 0
-    while i < len(words):
-        vid, card = int(words[i]), int(words[i + 1])
-        vals = words[i + 2:i + 2 + card]
-        i += 2 + card
-        domain_mask[vid] = True
-        off = int(variables[vid]["vtf_offset"])
-        vmap["value"][off:off + card] = vals
-        # the reference rewrites initialValue every time a domain value matches the CURRENT
-        # initialValue while scanning j = 0..card-1 (a later match can re-map an earlier result)
-        init = int(variables[vid]["initialValue"])
-        for j in range(card):
-            if int(vals[j]) == init:
-                init = j
-        variables[vid]["initialValue"] = init
+    (dataloading.py:159-187; parsed natively, nsk_parse_domains)."""
+    raw = np.frombuffer(data, np.uint8)
+    dm = domain_mask.view(np.uint8) if domain_mask.dtype == np.bool_ else domain_mask
+    if not (dm.flags.c_contiguous and variables.flags.c_contiguous and vmap.flags.c_contiguous):
+        raise ValueError("load_domains needs contiguous arrays (they are filled in place)")
+    _lib.check(_lib.lib().nsk_parse_domains(_lib.ptr(raw), len(raw), _lib.ptr(dm), len(variables),
+                                            _lib.ptr(variables), _lib.ptr(vmap), len(vmap)))
     print("LOADED DOMAINS")
 
 

@@ -329,19 +329,11 @@ class FactorGraph(object):
 
     def dump_probabilities(self, fout, epochs):
         """<vid, value, prob> text file (factorgraph.py:216-229): binary variables print the
-        probability of value 1, others one line per domain value."""
+        probability of value 1, others one line per domain value (written natively,
+        nsk_write_probabilities)."""
         epochs = epochs or 1
-        card = self.variable["cardinality"]
-        with open(fout, 'w') as out:
-            if np.all(card == 2):
-                prob = self.count[self.cstart[:-1]] / float(epochs)
-                out.write("".join('%d %d %.3f\n' % (i, 1, p) for i, p in enumerate(prob)))
-                return
-            for i, v in enumerate(self.variable):
-                if v["cardinality"] == 2:
-                    out.write('%d %d %.3f\n' % (i, 1, float(self.count[self.cstart[i]]) / epochs))
-                    continue
-                for k in range(v["cardinality"]):
-                    prob = float(self.count[self.cstart[i] + k]) / epochs
-                    out.write('%d %d %.3f\n' % (i, self.vmap[v["vtf_offset"] + k]["value"], prob))
+        v, vm = _lib.as_c(self.variable), _lib.as_c(self.vmap)
+        cs, cnt = _lib.as_c(self.cstart, np.int64), _lib.as_c(self.count, np.int64)
+        _lib.check(_lib.lib().nsk_write_probabilities(str(fout).encode(), len(v), _lib.ptr(v), _lib.ptr(vm),
+                                                      _lib.ptr(cs), _lib.ptr(cnt), float(epochs)))
 

@@ -259,3 +259,27 @@ def test_empty_shard_is_empty_and_unflagged_zero_range_is_the_whole_graph():
                            own_range=shard_range(r, 8, 3))
         owned += ns.factorGraphs[0].plan()[1]["nowned"]
     assert owned == 3
+
+
+def test_write_probabilities_matches_the_reference_format(tmp_path):
+    """nsk_write_probabilities == FactorGraph.dump_probabilities (factorgraph.py:216-229): binary
+    variables one line with value 1, others one line per domain value taken from vmap.value."""
+    g = _graph_from_spec(4, [(14, [0, 1]), (4, [2]), (3, [2, 3])], card=np.array([3, 4, 2, 2]))
+    g = list(g)
+    g[1] = g[1].copy()
+    g[1]["dataType"][:2] = 1
+    ns, fg = session(tuple(g))
+    rng = np.random.default_rng(1)
+    fg.count[:] = rng.integers(0, 7, len(fg.count))
+    fg.vmap["value"][:] = np.arange(len(fg.vmap))[::-1] * 3
+    out = tmp_path / "p.txt"
+    fg.dump_probabilities(str(out), 7)
+    want = []
+    for i, v in enumerate(fg.variable):
+        if v["cardinality"] == 2:
+            want.append('%d %d %.3f\n' % (i, 1, float(fg.count[fg.cstart[i]]) / 7))
+        else:
+            for k in range(v["cardinality"]):
+                want.append('%d %d %.3f\n' % (i, fg.vmap[v["vtf_offset"] + k]["value"],
+                                              float(fg.count[fg.cstart[i] + k]) / 7))
+    assert out.read_text() == "".join(want)
