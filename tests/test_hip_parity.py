@@ -976,3 +976,39 @@ def test_compact_delta_streams_are_bit_exact(monkeypatch):
                 og.gibbs_dev(order, ps, vv, wv, cnt, 21, s, True, burnin=s < 1)
             assert np.array_equal(fg.count, cnt)
         assert np.array_equal(fg.var_value[0], vv)
+
+
+@pytest.mark.parametrize("learn", [False, True])
+def test_values_outside_their_domain_take_the_exp_path(learn):
+    """A caller may write any int into var_value (the reference computes with whatever is there).
+    The draw-table kernels index with the neighbours' low bit, so an upload with a value outside
+    [0, cardinality) switches the handle to the exp-per-update kernels until the next regular
+    upload; either way the sweep equals the oracle's."""
+    rng = np.random.default_rng(9)
+    g = graphgen.ising_grid(40, 64, weight=0.25, fixed=not learn, two_weights=learn,
+                            evidence=rng.integers(0, 2, 40 * 64) if learn else None)
+    ns, fg = session(g, seed=17)
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, cnt = og.initial_state()
+    bad = rng.choice(40 * 64, 50, replace=False)
+    for arr in (fg.var_value[0], vv) + ((fg.var_value_evid[0], ve) if learn else ()):
+        arr[bad] = 2                                       # not a value of a binary variable
+    if learn:
+        fg.learn(0, 2, 1e-3, 0.9, 2, 0.01, 1)
+        step = 1e-3
+        for s in range(2):
+            og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 17, s)
+            step *= 0.9
+        assert np.array_equal(fg.weight_value[0], wv) and np.array_equal(fg.var_value_evid[0], ve)
+    else:
+        fg.inference(0, 3, True)
+        for s in range(3):
+            og.gibbs_dev(order, ps, vv, wv, cnt, 17, s, True)
+        assert np.array_equal(fg.count, cnt)
+    assert np.array_equal(fg.var_value[0], vv)
+    # a regular upload re-enables the tables: one more sweep, still equal
+    if not learn:
+        fg.inference(0, 1, True)
+        og.gibbs_dev(order, ps, vv, wv, cnt, 17, 3, True)
+        assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
