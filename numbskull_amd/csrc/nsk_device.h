@@ -716,8 +716,9 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
 
 // Where a block sends its (weight, gradient) visits.  Graphs with few weights (every factor of an
 // Ising grid shares one or two) would serialise millions of same-address global atomics, so their
-// blocks accumulate in LDS tables and write one row of partial sums each (k_apply_weights_rows
-// adds the rows up); graphs with many weights use the global accumulators directly.
+// blocks accumulate in LDS tables and add them to one of NSK_LEARN_BINS binned partial sums when
+// they finish (k_apply_bins adds the bins up); graphs with many weights use the global
+// accumulators -- one private copy per XCD -- directly.
 struct GradSink {
     long long *G;       // fixed-point gradient sums (Q31.32: order-independent, hence deterministic)
     uint32_t *K;        // visits

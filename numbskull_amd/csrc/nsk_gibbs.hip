@@ -35,7 +35,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     // a class with categorical tiles walks ALL its general tiles in this launch, on
                     // the main stream: the fork / join events of a side stream cost more (~20 us per
                     // class) than the binary tiles lose by running the 8-candidate code
-                    const bool one_general = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
+                    const bool one_general = gtb > gt0;
                     if (one_general) gtb = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
                     // without categorical tiles the hubs ride in the binary launch on the main stream
                     // (no side stream, no fork / join events for this class)
@@ -68,12 +68,12 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const int gt0 = (int)g->c.phase_gen_tile[ph];
                     const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
                     int gtb = (int)g->c.phase_gen_bin_tile[ph];
-                    if (gtb > gt0 && !getenv("NSK_SPLIT_GENERAL")) gtb = gt0 + ngt;     // walked by the launch above
+                    if (gtb > gt0) gtb = gt0 + ngt;     // walked by the launch above
                     if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
                         const int nblocks = (gt0 + ngt - gtb + 3) / 4;
                         const int hbl = gtb == gt0 ? (he - fe + 3) / 4 : 0;     // see above
                         const int nrest_all = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
-                        rest_in_general = gtb == gt0 && nrest_all > 0 && !getenv("NSK_SPLIT_GENERAL");
+                        rest_in_general = gtb == gt0 && nrest_all > 0;
                         const int rblocks = rest_in_general ? (nrest_all + 3) / 4 : 0;
                         k_gibbs_general<VT, 2><<<dim3(hbl + 8 * ((nblocks + 7) / 8) + rblocks), dim3(NSK_BLOCK), 0, g->stream>>>(
                             d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, gt0 + ngt - gtb, nblocks, fe, he, hbl, (int)g->c.phase_hub_base[ph],

@@ -746,7 +746,6 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
 #ifdef NSK_ABL_TIMING
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    const int v = valid ? g.p_vid[p] : 0;
     const uint32_t info = valid ? g.p_info[p] : (2u << 9);
     GenPot<MAXC> pot;
     pot.clear();
@@ -827,7 +826,6 @@ __device__ __forceinline__ void fast_tile_update(const DevGraph<VT> &g, int pbeg
     if (pbegin + wave * 64 >= pend) return;               // whole wave beyond the range
     const int v0 = p < pend ? g.p_vid[p] : -1;            // -1 also marks padding positions
     const bool valid = v0 >= 0;
-    const int v = valid ? v0 : 0;
     const uint32_t info = valid ? g.p_info[p] : 0u;
     const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + wave));
     const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};

@@ -16,7 +16,6 @@ struct LearnParams {
     int regularization, learn_non_evidence;
     double inv_trunc;
     uint32_t k0, k1, s0, s1;
-    int row_base;               // (unused: partial sums are binned)
     int hub0;                   // first hub descriptor of the colour class
 };
 
@@ -49,7 +48,7 @@ __device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem)
 // and there is no per-block row to budget for.
 #define NSK_LEARN_BINS 64
 template <bool SMALLW, typename VT>
-__device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink &sk, int) {
+__device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink &sk) {
     if (!SMALLW) return;
     __syncthreads();
     const int nw = g.nweight;
@@ -77,13 +76,12 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
     for (int item = wave0; item < nitems; item += nwaves) {
         const int p = (list ? (int)list[item] : pbegin + 64 * item) + lane;
         bool more = false, truncate = false;
-        int v = 0, self = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
+        int self = 0, evidence = 0, proposal = 0, a = 0, ae = 0, b = 0, be = 0;
         const uint2 *ra = nullptr, *rb = nullptr;        // INL: cursors into the inline records
         if (p < pend && g.p_vid[p] >= 0) {
             const uint32_t info = g.p_info[p];
             const int ev = NSK_INFO_EV(info);
             const int slot0 = g.p_slot[p];
-            v = g.p_vid[p];
             const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
             if (ev != 1) evidence = draw_sample<VT, INL>(g, p, info, slot0, g.val_evid, u53(r.z, r.w));   // 54-58
             else evidence = (int)g.p_init[p];                                                            // 61-62
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
             accumulate_gradient(sk, have, wid, gfix, truncate);
         }
     }
-    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+    close_sink<SMALLW>(g, sk);
 }
 
 // Learning for hubs: one wave per variable.  Draws use the wave-cooperative potentials; the
@@ -270,7 +268,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_heavy(DevGraph<VT> g, int p
     const int wave0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
     const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
     for (int p = pbegin + wave0; p < pend; p += nwaves) learn_hub<VT>(g, sk, lut, p, lp.hub0 + (p - pbegin), lp);
-    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+    close_sink<SMALLW>(g, sk);
 }
 
 // "satisfied" bits of one slot for the sampled variable at 0 / at 1; the generic flavour keeps
@@ -307,7 +305,6 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
     const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
     const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
     const uint32_t info = valid ? g.p_info[p] : 0u;
-    const int v = valid ? g.p_vid[p] : 0;
     const int ev = NSK_INFO_EV(info);
     const int init = valid ? (int)g.p_init[p] : 0;
     const bool need_evid = __ballot(valid && ev != 1) != 0;          // wave-uniform
@@ -399,7 +396,6 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
                                                  const LearnParams &lp) {
     const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
     const uint32_t info = valid ? g.p_info[p] : 0u;
-    const int v = valid ? g.p_vid[p] : 0;
     const int ev = NSK_INFO_EV(info);
     const int init = valid ? (int)g.p_init[p] : 0;
     const bool need_evid = __ballot(valid && ev != 1) != 0;
@@ -521,7 +517,6 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
                                                    bool valid, const LearnParams &lp) {
     const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
     const uint32_t info = valid ? g.p_info[p] : (2u << 9);
-    const int v = valid ? g.p_vid[p] : 0;
     const int ev = NSK_INFO_EV(info), card = NSK_INFO_CARD(info);
     const bool need_evid = __ballot(valid && ev != 1) != 0;
     GenPot<MAXC> pf, pe;
@@ -624,7 +619,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
         const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
         learn_tile<VT, KIND>(g, sk, sp, 4 * NCH, en.prog, p, valid, lp);
     }
-    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+    close_sink<SMALLW>(g, sk);
 }
 
 // The same over segments whose programs have draw tables (k_refresh_ztab): both chains' draws are
@@ -653,7 +648,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             const bool live = T0 + k < ntiles;                       // wave-uniform
             const int T = min(T0 + k, ntiles - 1);
             const int sidx = seg_of_tile(tab, T);
-        const SegEntry en = tab.e[sidx];                      // one 32-byte scalar load
+            const SegEntry en = tab.e[sidx];                     // one 48-byte scalar load
             const int t = T - en.tile_start;
             p[k] = en.pos0 + t * 64 + lane;
             zoff[k] = en.zoff; zmask[k] = (en.zmask_ev & 0xFFu); prog[k] = en.prog;
@@ -737,7 +732,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             }
         }
     }
-    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+    close_sink<SMALLW>(g, sk);
 }
 
 template <typename VT, bool SMALLW>
@@ -754,7 +749,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pb
     for (int i = wave0 * per; i < t1; i++)
         learn_rest_tile<VT>(g, sk, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(list[i]), lp);
     (void)lane;
-    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+    close_sink<SMALLW>(g, sk);
 }
 
 // Learning over the general tiles [tile0, tile0 + ntiles) of a colour class
@@ -771,7 +766,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
     if ((int)blockIdx.x < hblocks) {                      // hub blocks: one wave per hub position, strided
         const int hw0 = (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
         for (int hp = hb + hw0; hp < he; hp += hblocks * (NSK_BLOCK / 64)) learn_hub<VT>(g, sk, lut, hp, lp.hub0 + (hp - hb), lp);
-        close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+        close_sink<SMALLW>(g, sk);
         return;
     }
     const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x - hblocks) * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
@@ -789,7 +784,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
     const int r1 = min(nrest, (wave0 + 1) * per);
     for (int i = wave0 * per; i < r1; i++)
         learn_rest_tile<VT>(g, sk, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(rest_list[i]), lp);
-    close_sink<SMALLW>(g, sk, lp.row_base + (int)blockIdx.x);
+    close_sink<SMALLW>(g, sk);
 }
 
 // The weight update of learning.py:110-125 applied to a whole colour class at once

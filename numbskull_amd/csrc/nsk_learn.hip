@@ -31,7 +31,6 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const int e = (int)g->c.phase_end[ph];
             if (e <= fb) continue;
             lp.hub0 = (int)g->c.phase_hub_base[ph];
-            int rows = 0;
             const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
             const int he = (int)g->c.phase_heavy_end[ph];
@@ -39,27 +38,23 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             if (e > he) {               // variables outside the fast path: generic kernel, range mode
                 const int nitems = (e - he + 63) / 64;
                 const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
-                lp.row_base = rows;
                 k_learn_phase<VT, SMALLW, true><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(1)>>>(
                     d, he, e, nullptr, nitems, lp);
-                rows += grid;
                 g->launches++;
             }
             const int gt0 = (int)g->c.phase_gen_tile[ph];
             const int gtb = (int)g->c.phase_gen_bin_tile[ph];
             // hubs ride as extra blocks of a general-tile launch when the class has one
-            const bool hubs_in_general = (gtb > gt0 || ntiles > gtb) && he > fe && !getenv("NSK_SPLIT_GENERAL");
+            const bool hubs_in_general = (gtb > gt0 || ntiles > gtb) && he > fe;
             const int hbl = hubs_in_general ? std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4) : 0;
             if (he > fe && !hubs_in_general) {   // hubs: one wave per variable
                 const int grid = std::min(NSK_LEARN_HEAVY_BLOCKS, (he - fe + 3) / 4);
-                lp.row_base = rows;
                 k_learn_heavy<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, cs.side(2)>>>(d, fe, he, lp);
-                rows += grid;
                 g->launches++;
             }
             // the colour's uniform / shape tiles outside segment launches ride in the general launch
             const int nlrest = (int)(g->c.phase_learn_rest_base[ph + 1] - g->c.phase_learn_rest_base[ph]);
-            const bool rest_in_general = ntiles > gt0 && nlrest > 0 && !getenv("NSK_SPLIT_GENERAL");
+            const bool rest_in_general = ntiles > gt0 && nlrest > 0;
             const uint32_t *lrest = g->learn_rest_tiles + g->c.phase_learn_rest_base[ph];
             // a class with a lot of both general tiles and other tiles runs the two groups side by side
             // (side stream 0); smaller ones are not worth the fork / join events
@@ -68,25 +63,21 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const bool general_aside = ntiles - gt0 >= 2048 && other_tiles >= 2048 && !g->no_overlap;
             // as in inference: a class with categorical tiles walks all its general tiles in one
             // launch of the 8-candidate kernel on the main stream (+10 % over two concurrent launches)
-            const bool one_lg = gtb > gt0 && !getenv("NSK_SPLIT_GENERAL");
+            const bool one_lg = gtb > gt0;
             if (gtb > gt0) {            // general tiles with categorical lanes
                 const int nt8 = one_lg ? ntiles - gt0 : gtb - gt0;
                 const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + hbl;
-                lp.row_base = rows;
                 k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, (one_lg && !general_aside) ? g->stream : cs.side(0)>>>(
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, fe, he, hbl, lrest,
                     (rest_in_general && one_lg) ? nlrest : 0, lp);
-                rows += grid;
                 g->launches++;
             }
             if (ntiles > gtb && !one_lg) {   // all-binary general tiles
                 const int hb2 = gtb > gt0 ? 0 : hbl;        // no categorical launch: the hubs come here
                 const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + hb2;
-                lp.row_base = rows;
                 k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, general_aside ? cs.side(0) : g->stream>>>(
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, fe, he, hb2, lrest,
                     (rest_in_general && !(one_lg)) ? nlrest : 0, lp);
-                rows += grid;
                 g->launches++;
             }
             for (const Compiled::SegLaunch &sl : g->c.learn_seg) {       // homogeneous segments
@@ -104,7 +95,6 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                     en.d16off = sl.d16off[i]; en.d16base = sl.d16base[i];
                 }
                 const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
-                lp.row_base = rows;
 #define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
                 if (sl.tab && g->values_regular) {
 #define NSK_LTAB(NCH) k_learn_seg_tab<VT, SMALLW, NCH, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
@@ -118,24 +108,19 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 else if (sl.kind == 0) { if (sl.nch == 1) NSK_LSEG(0, 1); else NSK_LSEG(0, 2); }
                 else { if (sl.nch == 1) NSK_LSEG(3, 1); else NSK_LSEG(3, 2); }
 #undef NSK_LSEG
-                rows += grid;
                 g->launches++;
             }
             if (nlrest > 0 && !rest_in_general) {   // the other uniform and shape tiles: descriptor-driven kernel
                 const int grid = std::min(NSK_LEARN_FAST_BLOCKS, (nlrest + 3) / 4);
-                lp.row_base = rows;
                 k_learn_fast<VT, SMALLW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
                     d, fb, fe, (int)g->c.phase_wb_base[ph], g->learn_rest_tiles + g->c.phase_learn_rest_base[ph],
                     nlrest, lp);
-                rows += grid;
                 g->launches++;
             }
             if (ndyn > 0) {             // tiles with per-lane headers: generic kernel, list mode
                 const int grid = std::min(NSK_LEARN_LIST_BLOCKS, (ndyn + 3) / 4);
-                lp.row_base = rows;
                 k_learn_phase<VT, SMALLW, false><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(
                     d, fb, fe, g->dyn_tiles + g->c.phase_dyn_base[ph], ndyn, lp);
-                rows += grid;
                 g->launches++;
             }
             cs.join();
