@@ -1441,14 +1441,15 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int64_t p = pb0; p < pb1; p++) {
             const int64_t v = c.p_vid[p];
             int64_t si = pos_si[p], li = pos_li[p];
-            if (v < 0) { c.p_slot[p] = (int32_t)si; continue; }      // padding position
+            if (v < 0) { c.p_slot[p] = (int32_t)si; c.p_init[p] = -1; continue; }      // padding position (-1: the learning
+                                                                                   // table kernel's validity test)
             const nsk_variable &var = d->variable[v];
             const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
             c.p_info[p] = ((uint32_t)var.cardinality << 9) | ((var.dataType != 0) ? 0x100u : 0u) |
                           (uint32_t)(uint8_t)var.isEvidence;
             c.p_slot[p] = (int32_t)si;
             c.p_cnt[p] = (int32_t)c.cstart[v];
-            c.p_init[p] = c.v_init[v];
+            c.p_init[p] = var.isEvidence == 1 ? c.v_init[v] : 0;         // read by the evidence chain only (learning.py:61-62)
             uni.clear();
             for (int64_t k = 0; k < nslots; k++) {
                 const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
@@ -1613,14 +1614,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             lay_inf += (double)distinct * s_v + (double)(nfastpos + ncatpos) * s_v + 2.0 * nfastpos + 2.0 * s_c * ncatpos;
             lay_learn += 2.0 * distinct * s_v + 2.0 * (nfastpos + ncatpos) * s_v;
         }
-        for (const Compiled::Segment &sg : c.segments)      // table segments read the compact stream
-            if (sg.d16 >= 0) {
-                const double saved = (double)sg.ntiles * 64 * 8 * (sg.nslots > 4 ? 2 : 1);
-                lay_inf -= saved;
-                lay_learn -= saved;
+        for (const Compiled::Segment &sg : c.segments)      // inference over table segments reads the compact
+            if (sg.d16 >= 0)                                 // stream when there is one
+                lay_inf -= (double)sg.ntiles * 64 * 8 * (sg.nslots > 4 ? 2 : 1);
+        for (const Compiled::Segment &sg : c.segments)      // the table kernels key their generators by
+            if (sg.ztab >= 0) {                              // position: no p_vid read; learning: no p_info either
+                lay_inf -= (double)sg.ntiles * 64 * 4;
+                lay_learn -= (double)sg.ntiles * 64 * 8;
             }
-        for (const Compiled::Segment &sg : c.segments)      // the inference table kernel keys its generator
-            if (sg.ztab >= 0) lay_inf -= (double)sg.ntiles * 64 * 4;   // by position: no p_vid read
         c.layout_bytes_inference = lay_inf;
         c.layout_bytes_learning = lay_learn;
     }

@@ -151,15 +151,15 @@ struct ColourStreams {
 
 // the fast path reads weights through prog_w (and the draw tables): rebuilt whenever weights may
 // have changed (nsk_api.hip)
-// Grid of a table-driven learning segment launch: one trip per wave (two tiles at once) unless the
-// block's flush of its LDS sums (a few atomics per weight) would rival its tile traffic
+// Grid of a table-driven learning segment launch: resident -- the waves loop over their XCD's trips
+// with the next trip's loads in flight (k_learn_seg_tab) -- and smaller when a block's flush of its
+// LDS sums (a few atomics per weight) would rival its tile traffic
 static inline int nsk_learn_tab_grid(int ntiles, int nweight, bool smallw) {
     const int blocks = (ntiles + 7) / 8;                            // 4 waves x 2 tiles
     const int trips = smallw ? std::max(1, (nweight * 16 * 16 + 14847) / 14848) : 1;
-    // bounded grid: beyond it the waves loop (measured on the 10M grid: 4096 blocks 46 us, 2048 49 us,
-    // unbounded 49 us per class)
-    static const int cap = getenv("NSK_LEARN_GRID_CAP") ? atoi(getenv("NSK_LEARN_GRID_CAP")) : 4096;
-    return std::max(1, std::min(cap, (blocks + trips - 1) / trips));
+    // (measured on the 10M grid, per class: 1792 blocks 33.6 us, 2048 32.5 us, 3584 34.2 us, 4096 34.7 us)
+    static const int cap = getenv("NSK_LEARN_GRID_CAP") ? atoi(getenv("NSK_LEARN_GRID_CAP")) : 2048;
+    return 8 * ((std::max(1, std::min(cap, (blocks + trips - 1) / trips)) + 7) / 8);     // whole rounds of XCDs
 }
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {
     const int ntiles = sl.tile_start[sl.n];

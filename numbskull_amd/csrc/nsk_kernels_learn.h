@@ -622,116 +622,289 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
     close_sink<SMALLW>(g, sk);
 }
 
+// The weight update of learning.py:110-125 applied to a whole colour class at once
+// (DESIGN.md "device-mode learning" gives the closed forms; the oracle restates them).
+// cap: a weight visited k times in the class would move by k * step * (mean gradient); when
+// k * step exceeds `cap` the class uses step = cap / k for that weight (DESIGN.md "device-mode
+// learning": the per-visit rule of the reference has the same fixed point and is stable at any
+// k * step because every visit sees the weight the previous one left).  cap <= 0: no clipping.
+__device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
+                                               int regularization, double reg_param, double truncation,
+                                               double cap, unsigned int *clipped) {
+    const double Gf = (double)G * (1.0 / 4294967296.0);
+    if (cap > 0.0 && (double)k * step > cap) {
+        step = cap / (double)k;
+        if (clipped) atomicAdd(clipped, 1u);
+    }
+    if (regularization == 2) {
+        const double a = 1.0 / (1.0 + reg_param * step);
+        x = powi_det(a, (unsigned long long)k) * x;
+        x = x - step * Gf;
+    } else if (regularization == 1) {
+        x = x - step * Gf;
+        if (t > 0) {
+            const double l1 = (reg_param * step * truncation) * (double)t;
+            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
+        }
+    } else {
+        x = x - step * Gf;
+    }
+    return x;
+}
+
+// SMALLW: one block adds up the bins of every weight (and clears them), applies the update,
+// rewrites prog_w and rebuilds the draw tables from the new weights (the same products prog_w
+// holds) -- one small launch per colour class.  (Running it as the tail of the class's learning
+// launch -- last block to finish, found with a ticket counter -- was tried: 2048 same-address
+// agent-scope atomics serialise at ~0.125 us each, 262 us per class instead of 33.)
+#define NSK_APPLY_STAGE_WORDS 2048
+#define NSK_APPLY_STAGE_PROGS 64
+struct ApplyArgs {
+    double *w;
+    long long *part_G;
+    uint32_t *part_K, *part_T;
+    int nweight;
+    double step;
+    int regularization;
+    double reg_param, truncation;
+    const uint32_t *prog;
+    double *prog_w;
+    int nprog;
+    const ZProgDev *zp;
+    int nzp, nztab;
+    uint4 *ztab;
+    double cap;
+    unsigned int *clipped;
+};
+
+// every thread of the launch's ONE block calls it
+__device__ __forceinline__ void apply_bins_block(const ApplyArgs &aa) {
+    __shared__ double sw[NSK_SMALLW];
+    // the slot programs and table descriptors are staged in LDS while the bins arrive: the later
+    // phases would otherwise start with chains of dependent global loads (this is a pure latency
+    // chain on the critical path between two colour classes)
+    __shared__ uint32_t sprog[NSK_APPLY_STAGE_WORDS];
+    __shared__ ZProgDev szp[NSK_APPLY_STAGE_PROGS];
+    static_assert(NSK_LEARN_BINS == 64, "one bin per lane");
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int nweight = aa.nweight, nprog = aa.nprog, nzp = aa.nzp, nztab = aa.nztab;
+    const uint32_t *prog = aa.prog;
+    const ZProgDev *zp = aa.zp;
+    const bool staged = nprog <= NSK_APPLY_STAGE_WORDS && nzp <= NSK_APPLY_STAGE_PROGS;
+    if (staged) {
+        for (int j = tid; j < nprog; j += NSK_BLOCK) sprog[j] = prog[j];
+        for (int z = tid; z < nzp; z += NSK_BLOCK) szp[z] = zp[z];
+        prog = sprog;
+        zp = szp;
+    }
+    // wave k sums weights k, k + 4, ...: lane b reads (and clears) bin b, the wave adds the lanes up
+    for (int i = tid >> 6; i < nweight; i += NSK_BLOCK / 64) {
+        const size_t at = (size_t)lane * nweight + i;
+        long long G = aa.part_G[at];
+        long long K = (long long)aa.part_K[at], T = (long long)aa.part_T[at];
+        if (K) { aa.part_G[at] = 0; aa.part_K[at] = 0; aa.part_T[at] = 0; }
+        G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
+        if (lane == 0) {
+            double x = aa.w[i];
+            if (K > 0) {
+                x = apply_update(x, G, (uint32_t)K, (uint32_t)T, aa.step, aa.regularization, aa.reg_param,
+                                 aa.truncation, aa.cap, aa.clipped);
+                aa.w[i] = x;
+            }
+            sw[i] = x;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < nprog; j += NSK_BLOCK) {
+        const uint32_t s = prog[j];
+        if (s >> 31) continue;
+        const uint32_t code = (s >> 24) & 7u, wid = s & 0xFFFFFFu;
+        if ((int)wid >= nweight) continue;
+        const bool last = (s >> 28) & 1u;
+        const double hi = code == 0u ? 0.0 : 1.0;
+        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+        const double x = sw[wid];
+        aa.prog_w[2 * j] = last ? x * hi : 0.0;
+        aa.prog_w[2 * j + 1] = last ? x * lo : 0.0;
+    }
+    // all table entries of all programs, flattened over the threads
+    for (int e = tid; e < nztab; e += NSK_BLOCK) {
+        int z = 0;
+        while (z + 1 < nzp && (uint32_t)e >= zp[z + 1].off) z++;
+        const ZProgDev zz = zp[z];
+        aa.ztab[e] = ztab_entry(prog + zz.prog, zz.nslots, (uint32_t)e - zz.off,
+                                [&](uint32_t, uint32_t s, double &thi, double &tlo) {
+                                    const uint32_t code = (s >> 24) & 7u;
+                                    const bool last = (s >> 28) & 1u;
+                                    const double hi = code == 0u ? 0.0 : 1.0;
+                                    const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
+                                    const double x = sw[s & 0xFFFFFFu];
+                                    thi = last ? x * hi : 0.0;
+                                    tlo = last ? x * lo : 0.0;
+                                });
+    }
+}
+
+static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_bins(ApplyArgs aa) { apply_bins_block(aa); }
+
 // The same over segments whose programs have draw tables (k_refresh_ztab): both chains' draws are
 // integer compares against the tabulated thresholds, the per-slot satisfied bits come from the same
-// table entries.  learn_tile's gradient bookkeeping, no float64 arithmetic.  A wave walks TPW
-// consecutive tiles at once (all their loads in flight before the first dependent gather); the grid
-// is sized by the host so that a wave makes one trip when the partial-sum rows are cheap (few
-// weights) and several when a block's row flush would rival its tile traffic.
+// table entries.  learn_tile's gradient bookkeeping, no float64 arithmetic.
+//
+// A "trip" is TPW consecutive tiles of one segment; the host numbers a launch's tiles virtually so
+// that every segment is a whole number of trips (the dead tiles at a segment's end re-read its last
+// tile and take no part).  The grid is resident (k_gibbs_seg_tab's XCD-contiguous ranges) and each
+// wave runs a two-stage pipeline: the NEXT trip's member ids and evidence values are requested
+// right after this trip's table entries, so the stream's HBM latency overlaps the draw, the stores
+// and the gradient bookkeeping -- the wave is a chain of dependent round trips (ids -> member
+// values -> table entries) and the ablations showed that chain, not instruction issue or bytes,
+// bounding the launch.  No p_vid read: p_init is -1 at padding positions (nsk_compile.cpp).
+// (Measured on the 10M grid, per class with the update launch: strided one-trip-per-visit grid 43 us,
+// this kernel 32.5 us; requesting two trips ahead 35.3 us, forcing 8 waves per SIMD -- the kernel
+// sits at 7 for its scalar registers -- 33.9 us.)
+template <int NCH, int TPW>
+struct LearnTrip {                       // what a trip needs from memory before its gathers
+    uint32_t id[TPW][4 * NCH];
+    int init[TPW];
+};
+struct LearnTripInfo {                   // wave-uniform
+    int pos, nt, t0, ev;
+    uint32_t prog, zoff, zmask;
+};
+
 template <typename VT, bool SMALLW, int NCH, int TPW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, SegTable tab, LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GradSink sk = open_sink<SMALLW>(g, smem);
     const int lane = (int)(threadIdx.x & 63);
-    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
-    const int nwaves = (int)(gridDim.x * (NSK_BLOCK / 64));
-    const int ntiles = tab.ntiles;
-    for (int T0 = wave0 * TPW; T0 < ntiles; T0 += nwaves * TPW) {
-        int p[TPW], v[TPW], ev[TPW], init[TPW];
-        bool valid[TPW];
-        uint32_t id[TPW][4 * NCH], w16[TPW][2 * NCH];
-        int dbase[TPW];
-        bool u16[TPW];
-        uint32_t zoff[TPW], zmask[TPW], prog[TPW];
+    const int ntrips = tab.ntiles / TPW;
+    const int per = (ntrips + 7) >> 3;                                  // trips per XCD
+    const int xcd = (int)(blockIdx.x & 7);
+    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD (grid: multiple of 8)
+    const int pend = min(ntrips, (xcd + 1) * per);
+    // The wave keeps its gradient counts in scalar registers while the trips it walks share a slot
+    // program: acc[j] = (satisfied under the proposal) - (satisfied under the evidence) of slot j's
+    // factor summed over lanes and tiles, accK / accT the participating / truncating lanes.  They
+    // reach the sink when the program changes and at the end -- the sums are integers, so the
+    // grouping does not change them.
+    uint32_t cur_prog = 0xFFFFFFFFu;
+    int acc[4 * NCH];
+    uint32_t accK = 0u, accT = 0u;
 #pragma unroll
-        for (int k = 0; k < TPW; k++) {
-            const bool live = T0 + k < ntiles;                       // wave-uniform
-            const int T = min(T0 + k, ntiles - 1);
-            const int sidx = seg_of_tile(tab, T);
-            const SegEntry en = tab.e[sidx];                     // one 48-byte scalar load
-            const int t = T - en.tile_start;
-            p[k] = en.pos0 + t * 64 + lane;
-            zoff[k] = en.zoff; zmask[k] = (en.zmask_ev & 0xFFu); prog[k] = en.prog;
-            u16[k] = en.d16off != NSK_NO_D16_STREAM;           // wave-uniform
-            dbase[k] = en.d16base;
-            if (u16[k]) {
-                d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16[k]);
-            } else {
-                const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+    for (int j = 0; j < 4 * NCH; j++) acc[j] = 0;
+    auto flush = [&]() {
+        if (cur_prog != 0xFFFFFFFFu && accK != 0u) {
+            const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + cur_prog);
 #pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    const uint4 q = sp[c * 64];
-                    id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+            for (int j = 0; j < 4 * NCH; j++) {
+                const uint32_t s = pp[j];
+                const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
+                if (closes && !fixed && lane == 0) {
+                    const uint32_t code = (s >> 24) & 7u;
+                    const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
+                    const long long dG = (span * (long long)acc[j]) << 32;                   // Q31.32
+                    const int wid = (int)(s & 0xFFFFFFu);
+                    sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)accK : 0)));
+                    if (!sk.packed) sink_add(sk.local, &sk.K[wid], accK);
+                    if (accT) sink_add(sk.local, &sk.T[wid], accT);
                 }
             }
-            const int v0 = g.p_vid[p[k]];                            // -1: padding lane at a class end
-            valid[k] = live && v0 >= 0;
-            v[k] = v0 >= 0 ? v0 : 0;
-            ev[k] = ((int)(int8_t)(en.zmask_ev >> 8));                                    // uniform over a segment
-            init[k] = ev[k] == 1 ? (int)g.p_init[p[k]] : 0;
         }
 #pragma unroll
-        for (int k = 0; k < TPW; k++)
-            if (u16[k]) d16_ids<NCH>(w16[k], p[k] + dbase[k], id[k]);
+        for (int j = 0; j < 4 * NCH; j++) acc[j] = 0;
+        accK = 0u; accT = 0u;
+    };
+    // the segment of the last located trip stays in scalar registers: most launches have one
+    int c_lo = 0, c_hi = 0, c_pos = 0, c_nt = 1;
+    uint32_t c_adj = 0u, c_prog = 0u, c_zoff = 0u, c_zmask_ev = 0u;
+    auto issue = [&](int P, LearnTrip<NCH, TPW> &r, LearnTripInfo &ti) {
+        const int T0 = P * TPW;
+        if (T0 < c_lo || T0 >= c_hi) {                                  // wave-uniform, rare
+            const int sidx = seg_of_tile(tab, T0);
+            c_lo = tab.e[sidx].tile_start;
+            c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
+            c_pos = tab.e[sidx].pos0; c_adj = tab.e[sidx].adj_off; c_prog = tab.e[sidx].prog;
+            c_zoff = tab.e[sidx].zoff; c_zmask_ev = tab.e[sidx].zmask_ev;
+            c_nt = (int)(tab.e[sidx].ntiles_lead & 0x3FFFFFFFu);
+        }
+        ti.pos = c_pos; ti.nt = c_nt; ti.t0 = T0 - c_lo; ti.prog = c_prog; ti.zoff = c_zoff;
+        ti.zmask = c_zmask_ev & 0xFFu; ti.ev = (int)(int8_t)(c_zmask_ev >> 8);
+#pragma unroll
+        for (int k = 0; k < TPW; k++) {
+            const int t = min(ti.t0 + k, c_nt - 1);                    // a dead tile re-reads the last one
+            const uint4 *sp = g.adj + c_adj + (size_t)t * (64 * NCH) + lane;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint4 q = sp[c * 64];
+                r.id[k][4 * c] = q.x; r.id[k][4 * c + 1] = q.y; r.id[k][4 * c + 2] = q.z; r.id[k][4 * c + 3] = q.w;
+            }
+            r.init[k] = (int)g.p_init[c_pos + t * 64 + lane];          // -1: padding lane at a class end
+        }
+    };
+    LearnTrip<NCH, TPW> rn;
+    LearnTripInfo in;
+    int P = xcd * per + wx;
+    if (P < pend) issue(P, rn, in);
+    for (; P < pend; P += wpx) {
+        const LearnTrip<NCH, TPW> r = rn;
+        const LearnTripInfo ti = in;
         uint32_t idf[TPW], ide[TPW];
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             uint32_t xf[4 * NCH], xe[4 * NCH];
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
-                xf[j] = (uint32_t)g.val[id[k][j]];
-                xe[j] = (uint32_t)g.val_evid[id[k][j]];
+                xf[j] = (uint32_t)g.val[r.id[k][j]];
+                xe[j] = (uint32_t)g.val_evid[r.id[k][j]];
             }
             idf[k] = 0; ide[k] = 0;
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) { idf[k] |= (xf[j] & 1u) << j; ide[k] |= (xe[j] & 1u) << j; }
-            idf[k] &= zmask[k];
-            ide[k] &= zmask[k];
+            idf[k] &= ti.zmask;
+            ide[k] &= ti.zmask;
         }
         uint4 ef[TPW], ee[TPW];
 #pragma unroll
-        for (int k = 0; k < TPW; k++) { ef[k] = g.ztab[zoff[k] + idf[k]]; ee[k] = g.ztab[zoff[k] + ide[k]]; }
+        for (int k = 0; k < TPW; k++) { ef[k] = g.ztab[ti.zoff + idf[k]]; ee[k] = g.ztab[ti.zoff + ide[k]]; }
+        // the next trip's requests go out behind the table loads (vmcnt counts in order: waiting
+        // for the entries then leaves these in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        if (P + wpx < pend) issue(P + wpx, rn, in);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ti.prog != cur_prog) { flush(); cur_prog = ti.prog; }             // uniform, rare
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
-            const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog[k]);
-            const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p[k], 0u, lp.s0, lp.s1);
-            int evidence = init[k];                                               // learning.py:61-62
-            if (ev[k] != 1) evidence = k53(r.z, r.w) > (((unsigned long long)ee[k].y << 32) | ee[k].x) ? 1 : 0;   // 54-58
-            const int proposal = k53(r.x, r.y) > (((unsigned long long)ef[k].y << 32) | ef[k].x) ? 1 : 0;         // 66-70
-            if (valid[k]) {
-                g.val_evid[p[k]] = (VT)evidence;
-                g.val[p[k]] = (VT)proposal;
+            const bool valid = ti.t0 + k < ti.nt && r.init[k] >= 0;
+            const int p = ti.pos + (ti.t0 + k) * 64 + lane;
+#ifdef NSK_ABL_NOPHILOX
+            const uint32_t hq = (uint32_t)p * 2654435761u ^ lp.s0;
+            const u32x4 rr = {hq, hq * 40503u, hq ^ 0x9E3779B9u, hq * 7u};
+#else
+            const u32x4 rr = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
+#endif
+            int evidence = r.init[k];                                             // learning.py:61-62
+            if (ti.ev != 1) evidence = k53(rr.z, rr.w) > (((unsigned long long)ee[k].y << 32) | ee[k].x) ? 1 : 0;   // 54-58
+            const int proposal = k53(rr.x, rr.y) > (((unsigned long long)ef[k].y << 32) | ef[k].x) ? 1 : 0;         // 66-70
+            if (valid) {
+                g.val_evid[p] = (VT)evidence;
+                g.val[p] = (VT)proposal;
             }
-            const bool part = valid[k] && (lp.learn_non_evidence || ev[k] == 1);  // 71-72
-            bool truncate = false;
+            const bool part = valid && (lp.learn_non_evidence || ti.ev == 1);     // 71-72
             if (lp.regularization == 1) {                                         // 90
-                const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)p[k], 1u, lp.s0, lp.s1);
-                truncate = part && (u53(tt.x, tt.y) < lp.inv_trunc);
+                const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
+                accT += (uint32_t)__popcll(__ballot(part && (u53(tt.x, tt.y) < lp.inv_trunc)));
             }
-            const unsigned long long pm = __ballot(part);
-            if (pm == 0) continue;
-            const uint32_t satf = proposal ? (ef[k].z >> 8) : ef[k].z, sate = evidence ? (ee[k].z >> 8) : ee[k].z;
-            const uint32_t nk = (uint32_t)__popcll(pm), nt = (uint32_t)__popcll(__ballot(truncate));
+            accK += (uint32_t)__popcll(__ballot(part));
+            // the slots' satisfied bits of the two chains, zero for lanes that do not take part
+            const uint32_t satf = part ? (proposal ? (ef[k].z >> 8) : ef[k].z) : 0u;
+            const uint32_t sate = part ? (evidence ? (ee[k].z >> 8) : ee[k].z) : 0u;
 #pragma unroll
-            for (int j = 0; j < 4 * NCH; j++) {
-                const uint32_t s = pp[j];
-                const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
-                if (closes && !fixed) {
-                    const uint32_t code = (s >> 24) & 7u;
-                    const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
-                    const int nf = __popcll(__ballot(part && ((satf >> j) & 1u)));
-                    const int ne = __popcll(__ballot(part && ((sate >> j) & 1u)));
-                    if (lane == 0) {
-                        const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
-                        const int wid = (int)(s & 0xFFFFFFu);
-                        sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
-                        if (!sk.packed) sink_add(sk.local, &sk.K[wid], nk);
-                        if (nt) sink_add(sk.local, &sk.T[wid], nt);
-                    }
-                }
-            }
+            for (int j = 0; j < 4 * NCH; j++)
+                acc[j] += __popcll(__ballot((satf >> j) & 1u)) - __popcll(__ballot((sate >> j) & 1u));
         }
     }
+    flush();
     close_sink<SMALLW>(g, sk);
 }
 
@@ -787,35 +960,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
     close_sink<SMALLW>(g, sk);
 }
 
-// The weight update of learning.py:110-125 applied to a whole colour class at once
-// (DESIGN.md "device-mode learning" gives the closed forms; the oracle restates them).
-// cap: a weight visited k times in the class would move by k * step * (mean gradient); when
-// k * step exceeds `cap` the class uses step = cap / k for that weight (DESIGN.md "device-mode
-// learning": the per-visit rule of the reference has the same fixed point and is stable at any
-// k * step because every visit sees the weight the previous one left).  cap <= 0: no clipping.
-__device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
-                                               int regularization, double reg_param, double truncation,
-                                               double cap, unsigned int *clipped) {
-    const double Gf = (double)G * (1.0 / 4294967296.0);
-    if (cap > 0.0 && (double)k * step > cap) {
-        step = cap / (double)k;
-        if (clipped) atomicAdd(clipped, 1u);
-    }
-    if (regularization == 2) {
-        const double a = 1.0 / (1.0 + reg_param * step);
-        x = powi_det(a, (unsigned long long)k) * x;
-        x = x - step * Gf;
-    } else if (regularization == 1) {
-        x = x - step * Gf;
-        if (t > 0) {
-            const double l1 = (reg_param * step * truncation) * (double)t;
-            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
-        }
-    } else {
-        x = x - step * Gf;
-    }
-    return x;
-}
 
 static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
                                                              uint32_t *T, int nweight, double step,
@@ -848,63 +992,6 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, l
     }
     if (k == 0) return;                 // untouched in this class
     w[i] = apply_update(w[i], gsum, (uint32_t)k, (uint32_t)t, step, regularization, reg_param, truncation, cap, clipped);
-}
-
-// SMALLW: one block adds up the bins of every weight (and clears them), applies the update,
-// rewrites prog_w and rebuilds the draw tables from the new weights (the same products prog_w
-// holds) -- one small launch per colour class.
-static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_bins(
-        double *w, long long *part_G, uint32_t *part_K, uint32_t *part_T, int nweight, double step,
-        int regularization, double reg_param, double truncation, const uint32_t *prog, double *prog_w,
-        int nprog, const ZProgDev *zp, int nzp, int nztab, uint4 *ztab, double cap, unsigned int *clipped) {
-    __shared__ double sw[NSK_SMALLW];
-    static_assert(NSK_LEARN_BINS == 64, "one bin per lane");
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    // wave k sums weights k, k + 4, ...: lane b reads (and clears) bin b, the wave adds the lanes up
-    for (int i = tid >> 6; i < nweight; i += NSK_BLOCK / 64) {
-        const size_t at = (size_t)lane * nweight + i;
-        long long G = part_G[at];
-        long long K = (long long)part_K[at], T = (long long)part_T[at];
-        if (K) { part_G[at] = 0; part_K[at] = 0; part_T[at] = 0; }
-        G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
-        if (lane == 0) {
-            double x = w[i];
-            if (K > 0) {
-                x = apply_update(x, G, (uint32_t)K, (uint32_t)T, step, regularization, reg_param, truncation, cap, clipped);
-                w[i] = x;
-            }
-            sw[i] = x;
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < nprog; j += NSK_BLOCK) {
-        const uint32_t s = prog[j];
-        if (s >> 31) continue;
-        const uint32_t code = (s >> 24) & 7u, wid = s & 0xFFFFFFu;
-        if ((int)wid >= nweight) continue;
-        const bool last = (s >> 28) & 1u;
-        const double hi = code == 0u ? 0.0 : 1.0;
-        const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
-        const double x = sw[wid];
-        prog_w[2 * j] = last ? x * hi : 0.0;
-        prog_w[2 * j + 1] = last ? x * lo : 0.0;
-    }
-    // all table entries of all programs, flattened over the threads
-    for (int e = tid; e < nztab; e += NSK_BLOCK) {
-        int z = 0;
-        while (z + 1 < nzp && (uint32_t)e >= zp[z + 1].off) z++;
-        const ZProgDev zz = zp[z];
-        ztab[e] = ztab_entry(prog + zz.prog, zz.nslots, (uint32_t)e - zz.off,
-                             [&](uint32_t, uint32_t s, double &thi, double &tlo) {
-                                 const uint32_t code = (s >> 24) & 7u;
-                                 const bool last = (s >> 28) & 1u;
-                                 const double hi = code == 0u ? 0.0 : 1.0;
-                                 const double lo = (code == 0u || code == 1u) ? 0.0 : -1.0;
-                                 const double x = sw[s & 0xFFFFFFu];
-                                 thi = last ? x * hi : 0.0;
-                                 tlo = last ? x * lo : 0.0;
-                             });
-    }
 }
 
 }  // namespace nsk

@@ -10,6 +10,9 @@
 
 using namespace nsk;
 
+#define NSK_LEARN_TPW 2          // tiles per trip of the learning table kernel (1: 41.6 us, 2: 41.6 us, 4: 46.7 us
+                                 // per 10M-grid class before the kernel was pipelined)
+
 template <typename VT, bool SMALLW>
 static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
                            double reg_param, int64_t truncation, int learn_non_evidence) {
@@ -35,6 +38,16 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
             const int he = (int)g->c.phase_heavy_end[ph];
             ColourStreams cs(g, !g->no_overlap);
+            // the weight update of the class (SMALLW): arguments of k_apply_bins
+            const bool tabs_here = g->c.nfast > 0 && g->c.nztab <= 2048;
+            ApplyArgs aa;
+            memset(&aa, 0, sizeof(aa));
+            aa.w = g->w; aa.part_G = g->part_G; aa.part_K = g->part_K; aa.part_T = g->part_T;
+            aa.nweight = nw; aa.step = step; aa.regularization = regularization; aa.reg_param = reg_param;
+            aa.truncation = (double)truncation; aa.prog = g->tile_hdr; aa.prog_w = g->prog_w;
+            aa.nprog = g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0; aa.zp = g->zprogs;
+            aa.nzp = tabs_here ? (int)g->c.zprogs.size() : 0; aa.nztab = tabs_here ? (int)g->c.nztab : 0;
+            aa.ztab = g->ztab; aa.cap = g->learn_cap; aa.clipped = g->clip_count;
             if (e > he) {               // variables outside the fast path: generic kernel, range mode
                 const int nitems = (e - he + 63) / 64;
                 const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
@@ -82,22 +95,28 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             }
             for (const Compiled::SegLaunch &sl : g->c.learn_seg) {       // homogeneous segments
                 if (sl.phase != (int)ph) continue;
+                const bool use_tab = sl.tab && g->values_regular;
                 SegTable tab;
                 memset(&tab, 0, sizeof(tab));
                 tab.n = sl.n;
-                tab.ntiles = sl.tile_start[sl.n];
+                // table launches number their tiles virtually: every segment is padded to whole trips
+                int vt = 0;
                 for (int i = 0; i < NSK_SEG_MAX; i++) {
                     SegEntry &en = tab.e[i];
-                    en.tile_start = i < sl.n ? sl.tile_start[i] : tab.ntiles;
+                    const int nt_i = i < sl.n ? sl.tile_start[i + 1] - sl.tile_start[i] : 0;
+                    en.tile_start = use_tab ? vt : (i < sl.n ? sl.tile_start[i] : sl.tile_start[sl.n]);
+                    vt += (nt_i + NSK_LEARN_TPW - 1) / NSK_LEARN_TPW * NSK_LEARN_TPW;
+                    en.ntiles_lead = (uint32_t)nt_i;
                     en.pos0 = sl.pos0[i]; en.adj_off = sl.adj_off[i]; en.prog = sl.prog[i];
                     en.zoff = sl.zoff[i];
                     en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
                     en.d16off = sl.d16off[i]; en.d16base = sl.d16base[i];
                 }
+                tab.ntiles = use_tab ? vt : sl.tile_start[sl.n];
                 const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
 #define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
-                if (sl.tab && g->values_regular) {
-#define NSK_LTAB(NCH) k_learn_seg_tab<VT, SMALLW, NCH, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
+                if (use_tab) {
+#define NSK_LTAB(NCH) k_learn_seg_tab<VT, SMALLW, NCH, NSK_LEARN_TPW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
                     if (sl.nch == 1) NSK_LTAB(1); else NSK_LTAB(2);
 #undef NSK_LTAB
                 }
@@ -126,13 +145,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             cs.join();
             if (nw > 0) {
                 if (SMALLW) {
-                    const bool tabs_here = g->c.nfast > 0 && g->c.nztab <= 2048;
-                    k_apply_bins<<<dim3(1), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        g->w, g->part_G, g->part_K, g->part_T, nw, step, regularization, reg_param,
-                        (double)truncation, g->tile_hdr, g->prog_w,
-                        g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0, g->zprogs,
-                        tabs_here ? (int)g->c.zprogs.size() : 0, tabs_here ? (int)g->c.nztab : 0, g->ztab,
-                        g->learn_cap, g->clip_count);
+                    k_apply_bins<<<dim3(1), dim3(NSK_BLOCK), 0, g->stream>>>(aa);
                     if (g->c.nfast > 0 && !tabs_here) nsk_refresh_ztab(g);       // big tables: own launch
                 } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
