@@ -1072,7 +1072,9 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
 // * Padding lanes (class ends) sample like any other lane into their own, never-read, position; the
 //   tally fold skips them.
 // The kernel is bound by instruction issue; these three points took a 10M-grid
-// class from 23.7 to 16.3 us.
+// class from 23.7 to 16.3 us.  (Requesting the next pair's stream words behind this pair's table
+// loads, as k_learn_seg_tab does, was measured here too: 10M grid 17.0 -> 19.7 us per class, 1M grid
+// 4.1 -> 3.8 us -- not kept.)
 template <typename VT, int NCH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
