@@ -1366,7 +1366,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             for (int nch = 1; nch <= 2; nch++) {
                 Compiled::SegLaunch t;
                 memset(&t, 0, sizeof(t));
-                t.phase = k; t.kind = tab ? 8 : kind; t.nch = nch; t.tab = tab; t.d16 = 0;
+                t.phase = k; t.kind = tab ? 8 : kind; t.nch = nch; t.tab = tab;
                 std::vector<const Compiled::Segment *> mine;       // largest first (seg_of_tile's first probe)
                 for (const Compiled::Segment &sg : c.segments) {
                     // table segments of any function share a launch (the table encodes the function)

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
         int sidx = 0;
 #pragma unroll
         for (int i = 1; i < NSK_SEG_MAX; i++) sidx += (i < tab.n && T >= tab.e[i].tile_start) ? 1 : 0;
-    const SegEntry en = tab.e[sidx];
+        const SegEntry en = tab.e[sidx];
         const int t = T - en.tile_start;
         const int p = en.pos0 + t * 64 + lane;
         const bool valid = g.p_vid[p] >= 0;                  // -1: padding lane at a class end

@@ -5,4 +5,3 @@ for v in full NOATOMIC NOPASS2; do
   echo -n "lr5m_learn variant=$v "
   NSK_LIB=$lib python bench.py --workload lr5m_learn --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3e updates/s  %.1f us/launch' % (d['value'], d['roofline']['avg_launch_us']))"
 done
-for t in 1 2 4; do echo -n "ising1m TPW=$t "; NSK_TPW=$t python bench.py --workload ising1m --steps 2000 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3e updates/s  %.2f us/launch' % (d['value'], d['roofline']['avg_launch_us']))"; done
