@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/../numbskull_amd/csrc"
 mkdir -p ../variants build
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function ${NSK_ABL_EXTRA:-}"
 # NSK_ABL_TU=learn builds the variants of the learning translation unit instead of the inference one
 TU=${NSK_ABL_TU:-gibbs}
 for v in "$@"; do
