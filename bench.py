@@ -54,8 +54,17 @@ WORKLOADS = {
     "lr50m": (10000, 5000, False),
     "lr50m_learn": (10000, 5000, True),
     "ising64k": (256, 256, False),            # plumbing tests
+    # 4x / 10x the metric config: the streams of one sweep (0.8 / 2 GB) no longer fit the 256 MiB
+    # Infinity Cache, so the rate is HBM's
+    "ising40m": (5000, 8000, False),
+    "ising100m": (10000, 10000, False),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+# 256 MiB Infinity Cache (memory-side): a sweep whose streams fit in it is served partly from there
+# from the second sweep on, and FETCH_SIZE counts those hits as fetches (MI355X_MICROARCH.md).  The
+# 10M grid's sweep moves 200 MB, so its fraction of the HBM peak is an upper bound on what HBM
+# itself delivered; `also.ising40m` (800 MB per sweep) is the same kernel beyond the cache.
+INFINITY_CACHE_BYTES = 256 << 20
 
 
 def build_graph(rows, cols, learning, seed=20240602, name=None):
@@ -217,8 +226,10 @@ def side_run(name, seed, steps, warmup):
     checks = state_checks(fg, info, warmup + steps, (rows, cols), learning)
     fg.close()
     lay = info["layout_bytes_learning" if learning else "layout_bytes_inference"] * steps / (ms.value / 1e3) / 1e9
+    lay_sweep = info["layout_bytes_learning" if learning else "layout_bytes_inference"]
     return {"value": rows * cols * steps / dt, "unit": "variable-updates/s", "steps": steps,
             "ms_per_step": dt * 1e3 / steps, "roofline_frac": lay / HBM_PEAK_GBS,
+            "sweep_stream_bytes": lay_sweep, "stream_fits_infinity_cache": bool(lay_sweep < INFINITY_CACHE_BYTES),
             "avg_launch_us": ms.value * 1e3 / max(1, nl.value), "parity": checks}
 
 
@@ -451,6 +462,8 @@ def main():
                          "traffic_source": traffic_src,
                          "traffic_GBs": (traffic / launch_s / 1e9) if traffic else None,
                          "layout_bytes_per_update": lay_sweep * world / nvar,
+                         "sweep_stream_bytes": lay_sweep,
+                         "stream_fits_infinity_cache": bool(lay_sweep < INFINITY_CACHE_BYTES),
                          "alg_bytes_per_update_csr": alg_sweep * world / nvar,
                          "csr_model_GBs": alg_sweep * args.steps / (ms_ev.value / 1e3) / 1e9,
                          "kernel": dominant_kernel(args.workload, learning, info),
@@ -475,7 +488,8 @@ def main():
                 ok_local = ok_local and checks["edge_agreement_ok"]
         if world == 1 and args.workload == "ising10m" and not args.no_extra:
             out["also"] = {"ising1m": side_run("ising1m", args.seed, 1000, 100),
-                           "ising10m_learn": side_run("ising10m_learn", args.seed, 100, 10)}
+                           "ising10m_learn": side_run("ising10m_learn", args.seed, 100, 10),
+                           "ising40m": side_run("ising40m", args.seed, 50, 5)}
         checks["ok"] = bool(ok_local)
         print(json.dumps(out))
     if world > 1:
