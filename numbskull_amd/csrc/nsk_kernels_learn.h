@@ -944,7 +944,16 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
     }
     const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x - hblocks) * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
     const int nwaves = (int)((gridDim.x - hblocks) * (NSK_BLOCK / 64));
-    for (int t = wave0; t < ntiles; t += nwaves) {
+    // XCD x (= blockIdx & 7: the hardware deals blocks to XCDs round-robin) walks the x-th eighth of the
+    // tiles, so the member values a tile reads -- mostly positions near its own in every colour's
+    // range -- stay in one XCD's L2
+    const int xcd = (int)(blockIdx.x & 7);
+    const int first = hblocks + ((xcd - (hblocks & 7) + 8) & 7);          // first tile block on this XCD
+    const int nbx = first < (int)gridDim.x ? ((int)gridDim.x - 1 - first) / 8 + 1 : 0;
+    const int wx = __builtin_amdgcn_readfirstlane((((int)blockIdx.x - first) >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    const int per8 = (ntiles + 7) >> 3;
+    const int tend = min(ntiles, (xcd + 1) * per8);
+    for (int t = xcd * per8 + wx; t < tend; t += nbx * (NSK_BLOCK / 64)) {
         const int tile = tile0 + t;
         const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + tile));
         const uint32_t tdx = tdp[0], tdz = tdp[2], tdw = tdp[3];

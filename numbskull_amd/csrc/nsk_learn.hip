@@ -79,7 +79,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const bool one_lg = gtb > gt0;
             if (gtb > gt0) {            // general tiles with categorical lanes
                 const int nt8 = one_lg ? ntiles - gt0 : gtb - gt0;
-                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + hbl;
+                const int grid = 8 * ((std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + 7) / 8) + hbl;   // whole rounds of XCDs
                 k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, (one_lg && !general_aside) ? g->stream : cs.side(0)>>>(
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, nt8, fe, he, hbl, lrest,
                     (rest_in_general && one_lg) ? nlrest : 0, lp);
@@ -87,7 +87,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             }
             if (ntiles > gtb && !one_lg) {   // all-binary general tiles
                 const int hb2 = gtb > gt0 ? 0 : hbl;        // no categorical launch: the hubs come here
-                const int grid = std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + hb2;
+                const int grid = 8 * ((std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + 7) / 8) + hb2;
                 k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, general_aside ? cs.side(0) : g->stream>>>(
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gtb, ntiles - gtb, fe, he, hb2, lrest,
                     (rest_in_general && !(one_lg)) ? nlrest : 0, lp);
