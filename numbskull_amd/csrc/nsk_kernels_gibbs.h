@@ -588,6 +588,35 @@ __device__ __forceinline__ void general_walk(const DevGraph<VT> &g, const VT *va
     }
 }
 
+// The (weight id, descriptor) words of a general tile's entries, in list order, without member
+// gathers: fn(entry index, weight id, descriptor).  M <= 3 only (the layouts of general_walk_m).
+template <int M, typename FN>
+__device__ __forceinline__ void general_walk_ids_m(const uint4 *sp, int E, FN &&fn) {
+    constexpr int W = 2 + M;
+    constexpr int EG = (W % 4 == 0) ? 1 : (W % 2 == 0) ? 2 : 4;
+    constexpr int CG = W * EG / 4;
+    for (int e0 = 0; e0 < E; e0 += EG) {
+        uint32_t wd[W * EG];
+#pragma unroll
+        for (int j = 0; j < CG; j++) {
+            const uint4 q = sp[(size_t)((e0 / EG) * CG + j) * 64];
+            wd[4 * j] = q.x; wd[4 * j + 1] = q.y; wd[4 * j + 2] = q.z; wd[4 * j + 3] = q.w;
+        }
+#pragma unroll
+        for (int j = 0; j < EG; j++) fn(e0 + j, wd[j * W], wd[j * W + 1]);
+    }
+}
+template <typename FN>
+__device__ __forceinline__ void general_walk_ids(const uint4 *sp, int len, int M, FN &&fn) {
+    const int E = len / (2 + M);
+    switch (M) {                                                       // wave-uniform
+    case 0: general_walk_ids_m<0>(sp, E, fn); break;
+    case 1: general_walk_ids_m<1>(sp, E, fn); break;
+    case 2: general_walk_ids_m<2>(sp, E, fn); break;
+    default: general_walk_ids_m<3>(sp, E, fn); break;
+    }
+}
+
 // potentials of the candidates 0..MAXC-1 of one general tile: p[c] accumulates, in list order, the
 // rounded products weight * value exactly like potential() (inference.py:55-71).  MAXC = 2 serves
 // the tiles whose lanes are all binary (the compiler sorts those behind the categorical ones).

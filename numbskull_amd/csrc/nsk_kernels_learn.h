@@ -511,26 +511,43 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
 // evidence or the proposal value -- the union of the two factor lists of learning.py:76-95 (an
 // entry is in one list only: variables whose own edges in one factor disagree on dense_equal_to
 // stay on the generic path).
+// `facts`: this wave's LDS array of NSK_LEARN_FACTS x 64 uint16.  When pass 1 walks both chains it
+// leaves every entry's closed facts there -- (cstar clamped to 15, A + 1, B + 1) per chain, 8 bits
+// each -- and pass 2 only re-reads the entries' weight ids and descriptors from the stream: no
+// second round of member gathers, chain updates and table look-ups.
+#define NSK_LEARN_FACTS 32
+__device__ __forceinline__ uint32_t pack_facts(int cstar, int A, int B) {
+    return (uint32_t)(cstar > 15 ? 15 : cstar) | ((uint32_t)(A + 1) << 4) | ((uint32_t)(B + 1) << 6);
+}
 template <typename VT, int MAXC>
 __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const GradSink &sk, const uint8_t *lut,
                                                    const uint4 *sp, uint32_t tdw, uint32_t prog, int p,
-                                                   bool valid, const LearnParams &lp) {
+                                                   bool valid, const LearnParams &lp, uint16_t *facts) {
     const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
     const uint32_t info = valid ? g.p_info[p] : (2u << 9);
     const int ev = NSK_INFO_EV(info), card = NSK_INFO_CARD(info);
     const bool need_evid = __ballot(valid && ev != 1) != 0;
+    const int Mslots = (int)((tdw >> 16) & 7u);
+    const int lane = (int)(threadIdx.x & 63);
+    // pass 2 from the saved facts: both chains walked in pass 1, a layout general_walk_ids knows, and room
+    const bool saved = need_evid && Mslots <= 3 && len / (2 + Mslots) <= NSK_LEARN_FACTS;    // wave-uniform
     GenPot<MAXC> pf, pe;
     pf.clear(); pe.clear();
-    if (need_evid)
-        general_walk<VT, true, 0, false>(g, g.val, g.val_evid, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr,
+    if (need_evid) {
+        int ei = 0;                                                      // wave-uniform entry counter
+        general_walk<VT, true, 0, false>(g, g.val, g.val_evid, sp, len, Mslots, prog, nullptr,
                                   [&](uint32_t, double w, uint32_t d1, const GenChain &a, const GenChain &b) {
                                       int cstar, A, B;
                                       a.close(d1, lut, cstar, A, B);
                                       pf.add(maxcard, d1, w, cstar, A, B);
+                                      uint32_t fx = pack_facts(cstar, A, B);
                                       b.close(d1, lut, cstar, A, B);
                                       pe.add(maxcard, d1, w, cstar, A, B);
+                                      fx |= pack_facts(cstar, A, B) << 8;
+                                      if (saved) facts[ei * 64 + lane] = (uint16_t)fx;
+                                      ei++;
                                   });
-    else
+    } else
         general_walk<VT, false, 0, false>(g, g.val, g.val, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr,
                                    [&](uint32_t, double w, uint32_t d1, const GenChain &a, const GenChain &) {
                                        int cstar, A, B;
@@ -555,6 +572,19 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
     if (lp.k0 != 0xDEADBEEFu) return;
 #endif
     if (__ballot(part) == 0) return;
+    if (saved) {
+        general_walk_ids(sp, len, Mslots, [&](int e, uint32_t wid, uint32_t d1) {
+            const int ks = (int)((d1 >> 14) & 15u);
+            const bool mine = ks == 15 || ks == evidence || ks == proposal;
+            const uint32_t fx = facts[e * 64 + lane];
+            const int cf = (int)(fx & 15u), Af = (int)((fx >> 4) & 3u) - 1, Bf = (int)((fx >> 6) & 3u) - 1;
+            const int ce = (int)((fx >> 8) & 15u), Ae = (int)((fx >> 12) & 3u) - 1, Be = (int)((fx >> 14) & 3u) - 1;
+            const long long diff = (long long)(proposal == cf ? Af : Bf) - (long long)(evidence == ce ? Ae : Be);
+            const bool have = part && mine && !g.w_fixed[wid];          // 100-101
+            accumulate_gradient(sk, have, (int)wid, diff * 4294967296ll, truncate);
+        });
+        return;
+    }
     general_walk<VT, true, 2, false>(g, g.val, g.val_evid, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr,
                            [&](uint32_t wid, double, uint32_t d1, const GenChain &a, const GenChain &b) {
                                const int ks = (int)((d1 >> 14) & 15u);
@@ -933,6 +963,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
                                                              const uint32_t *rest_list, int nrest, LearnParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
+    __shared__ uint16_t gfacts[NSK_BLOCK / 64][NSK_LEARN_FACTS * 64];     // learn_tile_general: one array per wave
     load_gen_lut(lut);
     const GradSink sk = open_sink<SMALLW>(g, smem);
     const int lane = (int)(threadIdx.x & 63);
@@ -959,7 +990,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
         const uint32_t tdx = tdp[0], tdz = tdp[2], tdw = tdp[3];
         const int p = pbegin + tile * 64 + lane;
         const bool valid = p < pend && g.p_vid[p] >= 0;
-        learn_tile_general<VT, MAXC>(g, sk, lut, g.adj + tdx + lane, tdw, tdz, p, valid, lp);
+        learn_tile_general<VT, MAXC>(g, sk, lut, g.adj + tdx + lane, tdw, tdz, p, valid, lp, gfacts[threadIdx.x >> 6]);
     }
     // then the colour's uniform / shape tiles outside segment launches (a contiguous run per wave)
     const int per = (nrest + nwaves - 1) / nwaves;
