@@ -581,7 +581,11 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
             const int ce = (int)((fx >> 8) & 15u), Ae = (int)((fx >> 12) & 3u) - 1, Be = (int)((fx >> 14) & 3u) - 1;
             const long long diff = (long long)(proposal == cf ? Af : Bf) - (long long)(evidence == ce ? Ae : Be);
             const bool have = part && mine && !g.w_fixed[wid];          // 100-101
+#ifdef NSK_ABL_NOATOMIC
+            if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
+#else
             accumulate_gradient(sk, have, (int)wid, diff * 4294967296ll, truncate);
+#endif
         });
         return;
     }
