@@ -158,7 +158,8 @@ static inline int nsk_learn_tab_grid(int ntiles, int nweight, bool smallw) {
     const int blocks = (ntiles + 7) / 8;                            // 4 waves x 2 tiles
     const int trips = smallw ? std::max(1, (nweight * 16 * 16 + 14847) / 14848) : 1;
     // (measured on the 10M grid, per class: 1792 blocks 33.6 us, 2048 32.5 us, 3584 34.2 us, 4096 34.7 us)
-    static const int cap = getenv("NSK_LEARN_GRID_CAP") ? atoi(getenv("NSK_LEARN_GRID_CAP")) : 2048;
+    const char *cap_env = getenv("NSK_LEARN_GRID_CAP");              // (diagnostic; read per launch so that tests can set it)
+    const int cap = cap_env ? atoi(cap_env) : 2048;
     return 8 * ((std::max(1, std::min(cap, (blocks + trips - 1) / trips)) + 7) / 8);     // whole rounds of XCDs
 }
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {

@@ -399,25 +399,32 @@ def test_learning_with_unpacked_accumulators(golden, name, reg, monkeypatch):
     assert np.array_equal(fg.weight_value[0], wv)
 
 
-def test_split_general_launches(golden, monkeypatch):
-    """NSK_SPLIT_GENERAL: binary and categorical general tiles in separate launches (the latter on a
-    side stream) instead of one launch of the 8-candidate kernel: same samples."""
-    monkeypatch.setenv("NSK_SPLIT_GENERAL", "1")
-    g, hbv = _small_graphs(golden)["gencat"]
-    ns, fg = session(g, seed=6, head_by_vid=hbv)
-    og = oracle_of(fg, hbv)
+@pytest.mark.parametrize("evidence", ["all", "half"])
+def test_learning_table_kernel_with_a_tiny_resident_grid(monkeypatch, evidence):
+    """k_learn_seg_tab's waves walk several trips each -- across segment boundaries, with the
+    gradient counts carried in scalar registers until the slot program changes -- when the grid
+    is smaller than the work: NSK_LEARN_GRID_CAP=8 forces that on a 128x128 grid (interior and
+    border segments, with and without the evidence chain's own draw): same samples and weights as
+    the oracle."""
+    from numbskull_amd import graphgen
+    monkeypatch.setenv("NSK_LEARN_GRID_CAP", "8")
+    rng = np.random.Generator(np.random.PCG64(11))
+    ev = rng.integers(0, 2, 128 * 128)
+    g = graphgen.ising_grid(128, 128, weight=0.0, fixed=False, two_weights=True, evidence=ev)
+    if evidence == "half":
+        g[1]["isEvidence"] = rng.random(128 * 128) < 0.5
+    ns, fg = session(g, seed=9)
+    assert fg.info()["ztab_entries"] > 0
+    og = oracle_of(fg, False)
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, cnt = og.initial_state()
-    fg.learn(0, 2, 0.01, 0.9, 1, 0.05, 2, learn_non_evidence=True)
-    step = 0.01
-    for sweep in range(2):
-        assert og.learn_dev(order, ps, vv, ve, wv, step, 1, 0.05, 2, True, 6, sweep) == 0
+    fg.learn(0, 3, 0.001, 0.9, 2, 0.01, 1, learn_non_evidence=(evidence == "half"))
+    step = 0.001
+    for sweep in range(3):
+        assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, evidence == "half", 9, sweep) == 0
         step *= 0.9
-    assert np.array_equal(fg.var_value_evid[0], ve) and np.array_equal(fg.weight_value[0], wv)
-    fg.inference(0, 4, True)
-    for sweep in range(2, 6):
-        assert og.gibbs_dev(order, ps, vv, wv, cnt, 6, sweep, True) == 0
-    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    assert np.array_equal(fg.weight_value[0], wv)
 
 
 def test_general_tiles_at_scale():
