@@ -212,8 +212,8 @@ int nsk_parse_domains(const uint8_t *data, int64_t nbytes, uint8_t *domain_mask,
                       nsk_variable *variable, nsk_vtf *vmap, int64_t nvtf);
 /* FactorGraph.dump_probabilities (factorgraph.py:216-229): the "<vid> <value> <prob>" text file. */
 int nsk_write_probabilities(const char *path, int64_t nvar, const nsk_variable *variable,
-                            const nsk_vtf *vmap, const int64_t *cstart, const int64_t *count,
-                            double epochs);
+                            const nsk_vtf *vmap, int64_t nvtf, const int64_t *cstart,
+                            const int64_t *count, int64_t ncount, double epochs);
 
 /* Self-test hooks: run the device exp / Philox on caller data (parity tests vs the oracle). */
 int nsk_selftest_exp(int device, const double *x, double *y, int64_t n);

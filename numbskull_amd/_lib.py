@@ -106,8 +106,8 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.nsk_parse_domains.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                         C.c_void_p, C.c_int64]
-        L.nsk_write_probabilities.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                              C.c_void_p, C.c_double]
+        L.nsk_write_probabilities.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_void_p, C.c_int64, C.c_double]
         L.nsk_device_count.argtypes = [C.POINTER(C.c_int)]
         L.nsk_selftest_exp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
         L.nsk_selftest_stream.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]

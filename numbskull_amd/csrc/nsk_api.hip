@@ -172,6 +172,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     if (rc) return fail(rc, err);
     g->compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_compile).count();
     g->values_regular = g->chain_regular[0] = g->chain_regular[1] = g->c.values_regular;
+    g->rng_tag = (uint32_t)g->c.own_begin;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -199,7 +200,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
         bool generic_needed = c.phase_dyn_base.size() > 0 && c.phase_dyn_base.back() > 0;
         for (size_t k = 0; k + 1 < c.phase_start.size(); k++)
             if (c.phase_end[k] > c.phase_fast_end[k]) generic_needed = true;
-        if (generic_needed || getenv("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
+        if (generic_needed || nsk::diag_env("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
     }
     UP(w_fixed); UP(logtab); UP(adj); UP(adj16); UP(hub_desc); UP(hub_adj); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
@@ -384,23 +385,29 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
     const int64_t lo = g->c.vbytes == 1 ? -128 : INT32_MIN, hi = g->c.vbytes == 1 ? 127 : INT32_MAX;
     const int64_t *srcs[2] = {var_value, var_value_evid};
     void *dsts[2] = {g->val, g->val_evid};
+    // validate BOTH chains before anything is copied: an error must leave the device state as it was
+    bool regular[2] = {g->chain_regular[0], g->chain_regular[1]};
+    for (int k = 0; k < 2; k++) {
+        if (!srcs[k]) continue;
+        bool reg = true;
+        for (size_t i = 0; i < nvar; i++) {
+            if (srcs[k][i] < lo || srcs[k][i] > hi)
+                return fail(NSK_E_RANGE, "variable value does not fit the device value type");
+            reg = reg && srcs[k][i] >= 0 && srcs[k][i] < (int64_t)g->c.v_card[i];
+        }
+        // UFO (inference.py:398-405) uses the first member's value as an index into the factor's
+        // member list: the reference reads a neighbouring factor's edge (or faults); refuse
+        if (!reg && g->c.has_ufo)
+            return fail(NSK_E_RANGE, "a variable value lies outside its domain on a graph with UFO factors "
+                                     "(the value indexes the factor's member list)");
+        regular[k] = reg;
+    }
     std::vector<int32_t> tmp;
     for (int k = 0; k < 2; k++) {
         if (!srcs[k]) continue;
         tmp.assign((size_t)g->c.nid, 0);
-        bool regular = true;
-        for (size_t i = 0; i < nvar; i++) {
-            if (srcs[k][i] < lo || srcs[k][i] > hi)
-                return fail(NSK_E_RANGE, "variable value does not fit the device value type");
-            tmp[g->c.iid[i]] = (int32_t)srcs[k][i];                 // caller's order -> internal order
-            regular = regular && srcs[k][i] >= 0 && srcs[k][i] < (int64_t)g->c.v_card[i];
-        }
-        // UFO (inference.py:398-405) uses the first member's value as an index into the factor's
-        // member list: the reference reads a neighbouring factor's edge (or faults); refuse
-        if (!regular && g->c.has_ufo)
-            return fail(NSK_E_RANGE, "a variable value lies outside its domain on a graph with UFO factors "
-                                     "(the value indexes the factor's member list)");
-        g->chain_regular[k] = regular;
+        for (size_t i = 0; i < nvar; i++) tmp[g->c.iid[i]] = (int32_t)srcs[k][i];   // caller's order -> internal order
+        g->chain_regular[k] = regular[k];
         g->values_regular = g->chain_regular[0] && g->chain_regular[1];
         int rc = upload_values(g, dsts[k], tmp.data(), (size_t)g->c.nid);
         if (rc) return rc;

@@ -394,10 +394,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // by class in a permuted class order; a class stays independent, so the count never grows, and
     // a few passes typically drop one or two classes (LR graph: 9 -> 7).  Every class costs a
     // kernel's latency floor, so this is sweep time.
-    if (!conflict && ncolors > 2 && !getenv("NSK_NO_RECOLOUR")) {
+    if (!conflict && ncolors > 2 && !diag_env("NSK_NO_RECOLOUR")) {
         std::vector<int32_t> newc(nvar), seq;
         seq.reserve((size_t)nvar);
-        const int npass = getenv("NSK_RECOLOUR_PASSES") ? atoi(getenv("NSK_RECOLOUR_PASSES")) : 6;
+        const int npass = diag_env("NSK_RECOLOUR_PASSES") ? atoi(diag_env("NSK_RECOLOUR_PASSES")) : 6;
         for (int pass = 0; pass < npass; pass++) {
             std::vector<int64_t> size((size_t)ncolors, 0);
             for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) size[c.color[v]]++;
@@ -438,7 +438,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // a kernel's latency floor however few variables it holds.  Move variables, in id order, from
     // their class to the least populated class none of their neighbours is in (reads are symmetric
     // here -- the asymmetric repair above skips this pass).
-    if (!conflict && ncolors > 2 && !getenv("NSK_NO_BALANCE")) {
+    if (!conflict && ncolors > 2 && !diag_env("NSK_NO_BALANCE")) {
         for (int pass = 0; pass < 2; pass++)
             for (int64_t v = 0; v < nvar; v++) {
                 if (!sampled[v]) continue;
@@ -468,7 +468,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // weight id below 2^24; and featureValue == 1 so that learning can use the same stream.
     std::vector<uint8_t> fast(nvar, 0);
     auto fast_function = [](int fn) { return fn == -1 || (fn >= 0 && fn <= 4); };
-    const bool no_fast = getenv("NSK_NO_FAST") != nullptr;      // diagnostic: everything on the generic path
+    const bool no_fast = diag_env("NSK_NO_FAST") != nullptr;      // diagnostic: everything on the generic path
     parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
     for (int64_t v = vb0; v < vb1; v++) {
         if (c.color[v] < 0 || no_fast) continue;
@@ -508,11 +508,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
     };
     // (general-tile member words keep the id in 27 bits: positions include padding, so stay well below)
-    const bool no_general = getenv("NSK_NO_GENERAL") != nullptr || nvar >= (int64_t)100000000;
+    const bool no_general = diag_env("NSK_NO_GENERAL") != nullptr || nvar >= (int64_t)100000000;
     // longer lists go to the wave-per-variable kernel: a tile is walked by one wave, so its longest
     // lane sets a serial chain of memory round trips and the longest tile the kernel's run time
-    const int64_t gen_block = getenv("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(getenv("NSK_GEN_BLOCK"))) : 262144;
-    const int64_t gen_max_entries = getenv("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(getenv("NSK_GEN_MAX_ENTRIES")))) : 16;
+    const int64_t gen_block = diag_env("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(diag_env("NSK_GEN_BLOCK"))) : 262144;
+    const int64_t gen_max_entries = diag_env("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(diag_env("NSK_GEN_MAX_ENTRIES")))) : 16;
     // (hub = true lifts the per-lane size caps: the entry-parallel hub kernels take up to 256 entries)
     auto general_words = [&](int64_t v, std::vector<uint32_t> *out, bool hub = false) -> bool {
         const nsk_variable &var = d->variable[v];
@@ -741,11 +741,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             while (work > 8 && bin < 39) { work = work * 3 / 4; bin++; }     // ~log_{4/3} bins
             work_bin[v] = (uint8_t)(40 - bin);                               // heavier variables first
             // hubs: a whole wave works on one such variable (heavy_update in k_gibbs_general / k_learn_heavy)
-            if (listlen >= NSK_HEAVY_LIST && !getenv("NSK_NO_HEAVY")) work_bin[v] = 0;
+            if (listlen >= NSK_HEAVY_LIST && !diag_env("NSK_NO_HEAVY")) work_bin[v] = 0;
         }
         // a colour with few generic-path variables gives every one of them a wave: the one-lane
         // kernel's run time is the latency of its longest serial walk however few lanes are busy
-        if (!getenv("NSK_NO_HEAVY"))
+        if (!diag_env("NSK_NO_HEAVY"))
             for (int64_t v = 0; v < nvar; v++)
                 if (c.color[v] >= 0 && !fast[v] && ngen_of[c.color[v]] <= NSK_FEW_GENERIC) work_bin[v] = 0;
         {
@@ -889,7 +889,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         std::vector<int32_t> tile_colour((size_t)nwb);
         for (int32_t k = 0; k < ncolors; k++)
             for (int64_t t = c.phase_wb_base[k]; t < c.phase_wb_base[k + 1]; t++) tile_colour[t] = k;
-        const bool no_shape = getenv("NSK_NO_SHAPE") != nullptr, no_ztab = getenv("NSK_NO_ZTAB") != nullptr;
+        const bool no_shape = diag_env("NSK_NO_SHAPE") != nullptr, no_ztab = diag_env("NSK_NO_ZTAB") != nullptr;
         parallel_for(nwb, [&](int64_t tb0, int64_t tb1, int) {
             std::vector<uint32_t> words, hdrs, hdrs0;
             for (int64_t t = tb0; t < tb1; t++) {
@@ -1226,7 +1226,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // opt-in (NSK_D16=1): on the 10M grid the compact stream cuts the launch's HBM traffic from
         // 130 MB to 90 MB at the same 24 us -- the table kernel is bound by instruction issue, not by
         // bandwidth -- so by default the second copy is not built
-        const bool no_d16 = getenv("NSK_D16") == nullptr;
+        const bool no_d16 = diag_env("NSK_D16") == nullptr;
         auto word_at = [&](const Compiled::Segment &sg, int nch, int64_t t, int64_t i, uint32_t j) -> int64_t {
             return (int64_t)c.adj[((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4 + 256 * (j / 4) + 4 * i + (j % 4)];
         };
@@ -1294,7 +1294,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         c.phase_hub_base[k + 1] = c.phase_hub_base[k] + (c.phase_heavy_end[k] - c.phase_fast_end[k]);
     c.hub_desc.assign((size_t)(c.phase_hub_base[ncolors] + 1) * 4, 0u);
     std::vector<int32_t> hub_colour;
-    if (!getenv("NSK_NO_HUB_EP") && !no_general) {
+    if (!diag_env("NSK_NO_HUB_EP") && !no_general) {
         std::vector<int64_t> hubs;
         for (int32_t k = 0; k < ncolors; k++)
             for (int64_t p = c.phase_fast_end[k]; p < c.phase_heavy_end[k]; p++)
@@ -1394,7 +1394,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             return a.tile_start[a.n] > b.tile_start[b.n]; });
         std::vector<uint32_t> extra;
         for (size_t i = 0; i < tabs.size(); i++) {
-            if (i < NSK_LEARN_SEG_LAUNCHES && !getenv("NSK_NO_LEARN_SEG")) { c.learn_seg.push_back(tabs[i]); continue; }
+            if (i < NSK_LEARN_SEG_LAUNCHES && !diag_env("NSK_NO_LEARN_SEG")) { c.learn_seg.push_back(tabs[i]); continue; }
             for (int j = 0; j < tabs[i].n; j++)
                 for (int32_t t = 0; t < tabs[i].tile_start[j + 1] - tabs[i].tile_start[j]; t++)
                     extra.push_back((uint32_t)((tabs[i].pos0[j] - c.phase_start[k]) / 64 + t));
@@ -1564,7 +1564,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             if (fa.weightId >= 0 && fa.weightId < nw) edges_of[fa.weightId] += std::max<int64_t>(fa.arity, 1);
         }
         for (int64_t i = 0; i < nw && ok; i++) if (edges_of[i] >= ((int64_t)1 << 28)) ok = false;
-        c.packed_grad = ok && !getenv("NSK_NO_PACKED");
+        c.packed_grad = ok && !diag_env("NSK_NO_PACKED");
         // Q31.32 range: a class's gradient sum for weight w is at most sum over its factors of
         // |featureValue| * (largest |value difference| of the function) * (member edges)
         std::vector<double> gbound((size_t)nw, 0.0);

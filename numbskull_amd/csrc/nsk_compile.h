@@ -3,6 +3,7 @@
 #pragma once
 
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <map>
 #include <string>
@@ -14,6 +15,15 @@
 #define NSK_GEN_NULL 0x7FFFFFFu     // member id of an empty slot in a general tile (kind 6)
 
 namespace nsk {
+
+// Diagnostic switches (INTEGRATION.md "Diagnostic switches") change which layout / kernel family a
+// graph compiles to -- and therefore its sample stream.  A product library must not pick those up
+// from an inherited environment: they are read only when NSK_DIAG=1 is set as well.
+inline const char *diag_env(const char *name) {
+    const char *on = getenv("NSK_DIAG");
+    if (!on || on[0] != '1') return nullptr;
+    return getenv(name);
+}
 
 struct Compiled {
     // sizes

@@ -52,19 +52,19 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                             d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, gtb - gt0, nblocks, fe, he, hblocks, (int)g->c.phase_hub_base[ph],
                             g->rest_tiles + g->c.phase_rest_base[ph], rest_here ? nrest_all : 0,
                             sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
-                            (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                            (uint32_t)g->sweep, nsk_sweep_hi(g));
                         g->launches++;
                     }
                 }
                 if (e > he) {       // generic CSR kernel, one lane per variable
                     k_gibbs_phase<VT><<<dim3((e - he + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, cs.side(1)>>>(
                         d, he, e, sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32),
-                        (uint32_t)g->sweep, (uint32_t)(g->sweep >> 32));
+                        (uint32_t)g->sweep, nsk_sweep_hi(g));
                     g->launches++;
                 }
                 if (fe > fb) {      // inlined-adjacency kernels
                     const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
-                    const uint32_t S0 = (uint32_t)g->sweep, S1 = (uint32_t)(g->sweep >> 32);
+                    const uint32_t S0 = (uint32_t)g->sweep, S1 = nsk_sweep_hi(g);
                     const int gt0 = (int)g->c.phase_gen_tile[ph];
                     const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
                     int gtb = (int)g->c.phase_gen_bin_tile[ph];

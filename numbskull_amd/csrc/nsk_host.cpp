@@ -166,8 +166,20 @@ extern "C" int nsk_parse_domains(const uint8_t *data, int64_t nbytes, uint8_t *d
 // dump_probabilities (factorgraph.py:216-229): "<vid> <value> <prob %.3f>" lines; a binary variable
 // prints the probability of value 1, any other one line per domain value (vmap.value).
 extern "C" int nsk_write_probabilities(const char *path, int64_t nvar, const nsk_variable *variable,
-                                       const nsk_vtf *vmap, const int64_t *cstart, const int64_t *count,
-                                       double epochs) {
+                                       const nsk_vtf *vmap, int64_t nvtf, const int64_t *cstart,
+                                       const int64_t *count, int64_t ncount, double epochs) {
+    // validate before anything is written: a malformed variable array must not index past vmap / count
+    for (int64_t i = 0; i < nvar; i++) {
+        const int64_t card = variable[i].cardinality, span = card == 2 ? 1 : card;
+        if (card < 1 || cstart[i] < 0 || cstart[i] + span > ncount) {
+            nsk::set_error("dump_probabilities: tally slots of a variable lie outside count");
+            return NSK_E_INDEX;
+        }
+        if (card != 2 && (variable[i].vtf_offset < 0 || variable[i].vtf_offset + card > nvtf)) {
+            nsk::set_error("dump_probabilities: domain of a variable lies outside vmap");
+            return NSK_E_INDEX;
+        }
+    }
     FILE *f = fopen(path, "w");
     if (!f) { nsk::set_error(std::string("cannot open ") + path); return NSK_E_INVALID; }
     std::vector<char> buf(1 << 20);

@@ -35,7 +35,7 @@ struct nsk_graph {
     // streams next to the tile kernels (fork/join with events around every colour)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    bool no_overlap = getenv("NSK_NO_OVERLAP") != nullptr;     // diagnostic: one stream
+    bool no_overlap = nsk::diag_env("NSK_NO_OVERLAP") != nullptr;     // diagnostic: one stream
     std::vector<void *> allocs;
     int64_t device_bytes = 0;
     // device arrays
@@ -87,6 +87,11 @@ struct nsk_graph {
     nsk::MTState *mt_np = nullptr, *mt_py = nullptr;
     // run state
     uint64_t seed = 0, sweep = 0;
+    // Generator ids are positions in THIS handle's layout, so two shards of one graph would draw
+    // the same uniforms at equal positions: Philox counter word 3 is the sweep index's high half
+    // XOR this tag -- the first variable id the handle owns (disjoint shards => distinct tags;
+    // 0 for a handle that owns the whole graph).
+    uint32_t rng_tag = 0;
     int scan = NSK_SCAN_CHROMATIC;
     bool cnt_dirty = false;
     int64_t sweeps_done = 0;
@@ -94,6 +99,9 @@ struct nsk_graph {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t launches = 0, launches_at_begin = 0;
 };
+
+// Philox counter word 3 of every sweep kernel (see rng_tag)
+static inline uint32_t nsk_sweep_hi(const nsk_graph *g) { return (uint32_t)(g->sweep >> 32) ^ g->rng_tag; }
 
 template <typename VT>
 static nsk::DevGraph<VT> view(nsk_graph *g) {
@@ -158,7 +166,7 @@ static inline int nsk_learn_tab_grid(int ntiles, int nweight, bool smallw) {
     const int blocks = (ntiles + 7) / 8;                            // 4 waves x 2 tiles
     const int trips = smallw ? std::max(1, (nweight * 16 * 16 + 14847) / 14848) : 1;
     // (measured on the 10M grid, per class: 1792 blocks 33.6 us, 2048 32.5 us, 3584 34.2 us, 4096 34.7 us)
-    const char *cap_env = getenv("NSK_LEARN_GRID_CAP");              // (diagnostic; read per launch so that tests can set it)
+    const char *cap_env = nsk::diag_env("NSK_LEARN_GRID_CAP");              // (diagnostic; read per launch so that tests can set it)
     const int cap = cap_env ? atoi(cap_env) : 2048;
     return 8 * ((std::max(1, std::min(cap, (blocks + trips - 1) / trips)) + 7) / 8);     // whole rounds of XCDs
 }

@@ -28,7 +28,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
     g->adj_wt_skip = true;          // the learning kernels gather weights themselves
     nsk_refresh_prog_weights(g);
     for (int64_t s = 0; s < nsweeps; s++) {
-        lp.s0 = (uint32_t)g->sweep; lp.s1 = (uint32_t)(g->sweep >> 32);
+        lp.s0 = (uint32_t)g->sweep; lp.s1 = nsk_sweep_hi(g);
         for (size_t ph = 0; ph < nphase; ph++) {
             const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
             const int e = (int)g->c.phase_end[ph];

@@ -16,6 +16,7 @@ place call ``invalidate()`` so that the next call recompiles.
 
 import ctypes as C
 import sys
+import warnings
 
 import numpy as np
 
@@ -75,6 +76,7 @@ class FactorGraph(object):
         self.own_range = own_range
         self._handle = None
         self._keep = None
+        self._clipped_seen = 0
 
     # ------------------------------------------------------------------ device handle
     def _descriptor(self):
@@ -142,6 +144,7 @@ class FactorGraph(object):
         if self._handle is not None:
             _lib.lib().nsk_graph_destroy(self._handle)
             self._handle = None
+            self._clipped_seen = 0
 
     def invalidate(self):
         """Drop the compiled device graph: the next burnIn / inference / learn call recompiles it
@@ -318,6 +321,22 @@ class FactorGraph(object):
                 self.learning_epoch_time = timer.interval / epochs
                 self.learning_total_time += timer.interval
             self._pull(var_copy, weight_copy, count=False)
+            # Chromatic learning applies the SGD rule once per colour class and caps visits * step
+            # of a weight at `learn_cap` (a weight tied to many factors then moves more slowly per
+            # epoch than under the reference's per-visit rule, learning.py:110-125; same fixed
+            # point).  Say so instead of leaving it to a counter nobody reads.
+            clipped = self.info()["learn_clipped"]
+            if self.scan == "chromatic" and clipped > self._clipped_seen:
+                msg = ("numbskull_amd: %d weight update(s) used a step below stepsize because one "
+                       "colour class visits the weight more than learn_cap / stepsize = %g times "
+                       "(learn_cap=%g; pass learn_cap=0 for the uncapped batch rule, or "
+                       "scan='sequential' for the reference's per-visit trajectory)"
+                       % (clipped - self._clipped_seen, self.learn_cap / max(stepsize, 1e-300),
+                          self.learn_cap))
+                warnings.warn(msg, RuntimeWarning, stacklevel=2)
+                if diagnostics:
+                    print(msg)
+            self._clipped_seen = clipped
         if diagnostics:
             print("FACTOR " + str(self.fid) + ": DONE WITH LEARNING")
 
@@ -335,5 +354,6 @@ class FactorGraph(object):
         v, vm = _lib.as_c(self.variable), _lib.as_c(self.vmap)
         cs, cnt = _lib.as_c(self.cstart, np.int64), _lib.as_c(self.count, np.int64)
         _lib.check(_lib.lib().nsk_write_probabilities(str(fout).encode(), len(v), _lib.ptr(v), _lib.ptr(vm),
-                                                      _lib.ptr(cs), _lib.ptr(cnt), float(epochs)))
+                                                      len(vm), _lib.ptr(cs), _lib.ptr(cnt), len(cnt),
+                                                      float(epochs)))
 

@@ -21,7 +21,7 @@ class _Graph(C.Structure):
                 ("nedge", C.c_int64), ("nvtf", C.c_int64),
                 ("weight", C.c_void_p), ("variable", C.c_void_p), ("factor", C.c_void_p),
                 ("fmap", C.c_void_p), ("vmap", C.c_void_p), ("factor_index", C.c_void_p),
-                ("head_by_vid", C.c_int), ("rng_id", C.c_void_p)]
+                ("head_by_vid", C.c_int), ("rng_id", C.c_void_p), ("rng_tag", C.c_uint32)]
 
 
 class _MT(C.Structure):
@@ -108,7 +108,7 @@ class Graph:
         self.g = _Graph(len(self.variable), len(self.factor), len(self.weight), len(self.fmap),
                         len(self.vmap), self.weight.ctypes.data, self.variable.ctypes.data,
                         self.factor.ctypes.data, self.fmap.ctypes.data, self.vmap.ctypes.data,
-                        self.factor_index.ctypes.data, int(bool(head_by_vid)), None)
+                        self.factor_index.ctypes.data, int(bool(head_by_vid)), None, 0)
         self.rng_id = None
         card = self.variable["cardinality"]
         self.cstart = np.zeros(len(card) + 1, np.int64)
@@ -126,6 +126,11 @@ class Graph:
             self.rng_id = np.ascontiguousarray(ids, np.int64)
             assert len(self.rng_id) == len(self.variable)
             self.g.rng_id = self.rng_id.ctypes.data
+
+    def set_rng_tag(self, tag):
+        """Device mode: the shard tag of the emulated handle (its first owned variable id; 0 for a
+        handle that owns the whole graph) -- XORed into Philox counter word 3."""
+        self.g.rng_tag = int(tag) & 0xFFFFFFFF
 
     # ---- state helpers (factorgraph.py:41-53) ----
     def initial_state(self):
@@ -183,6 +188,16 @@ class Graph:
             C.c_double(step), int(regularization), C.c_double(reg_param), C.c_int64(truncation),
             _p(var_value), _p(var_value_evid), _p(weight_value), int(learn_non_evidence),
             C.c_uint64(seed), C.c_uint64(sweep), C.c_double(cap))
+
+    def check_coloring(self, color):
+        """(-1, -1) when no sampled variable reads a variable of its own colour, else such a pair."""
+        color = np.ascontiguousarray(color, np.int32)
+        assert len(color) == len(self.variable)
+        other = C.c_int64(-1)
+        f = lib().orc_check_coloring
+        f.restype = C.c_int64
+        v = f(C.byref(self.g), _p(color), C.byref(other))
+        return int(v), int(other.value)
 
     # ---- CPU baseline (Hogwild threads) ----
     def gibbs_hogwild(self, nthreads, nsweeps, var_value, weight_value, count, seed,

@@ -545,6 +545,48 @@ int orc_learn_shard_ref(const orc_graph *g, int64_t shardID, int64_t nshards, do
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Checker of a chromatic colouring (test infrastructure for the device mode): a colour class is
+ * sampled in parallel, so no sampled variable may READ another variable of its own colour.
+ * reads(v) = the members of every factor in v's lists -- as eval_factor walks them: the arity,
+ * the fixed member positions of the data-programming functions (inference.py:301-393), UFO's
+ * value-indexed member (398-405) -- plus, with the literal head lookup (243, 277, 292), the
+ * variable whose id equals the head's absolute edge index.  Returns -1 when the colouring is
+ * valid, else the id of a variable that reads a same-coloured one (*other = that one).
+ * ---------------------------------------------------------------------------------------- */
+int64_t orc_check_coloring(const orc_graph *g, const int32_t *color, int64_t *other) {
+    for (int64_t v = 0; v < g->nvar; v++) {
+        if (color[v] < 0) continue;
+        const orc_variable *var = &g->variable[v];
+        const int64_t nslots = var->dataType == 0 ? 1 : var->cardinality;
+        for (int64_t k = 0; k < nslots; k++) {
+            const orc_vtf *vt = &g->vmap[var->vtf_offset + k];
+            for (int64_t j = 0; j < vt->factor_index_length; j++) {
+                const orc_factor *fa = &g->factor[g->factor_index[vt->factor_index_offset + j]];
+                const int fn = fa->factorFunction;
+                if (fn == -1) continue;
+                int64_t need = (fn == 21 || fn == 22 || fn == 25 || fn == 26) ? 2
+                             : (fn == 23 || fn == 24) ? 3 : (fn >= 18 && fn <= 20) ? 1 : 0;
+                int64_t s = fa->ftv_offset, e = s + (fa->arity > need ? fa->arity : need);
+                if (fn == 30 && s >= 0 && s < g->nedge) {
+                    int64_t r = s + g->variable[g->fmap[s].vid].cardinality - 1;
+                    if (r > e) e = r;
+                }
+                if (e > g->nedge) e = g->nedge;
+                for (int64_t l = s; l < e; l++) {
+                    const int64_t b = g->fmap[l].vid;
+                    if (b != v && b >= 0 && b < g->nvar && color[b] == color[v]) { if (other) *other = b; return v; }
+                }
+                if ((fn == 13 || fn == 16 || fn == 17) && !g->head_by_vid) {
+                    const int64_t b = s + fa->arity - 1;
+                    if (b != v && b >= 0 && b < g->nvar && color[b] == color[v]) { if (other) *other = b; return v; }
+                }
+            }
+        }
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Device mode: Philox uniforms keyed (seed; vid, stream, sweep), orc_exp_det,
  * phases = colour classes, weights frozen inside a phase and updated at its end from
  * order-independent fixed-point gradient sums.
@@ -576,7 +618,7 @@ int orc_gibbs_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             const uint64_t q = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
             orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32),
                            (uint32_t)(((q >> 7) << 6) | (q & 63u)), 0u,
-                           (uint32_t)sweep, (uint32_t)(sweep >> 32), r);
+                           (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
             const int half = (int)((q >> 6) & 1u);
             int64_t nv;
             rc = draw_sample(g, v, Z, var_value, weight_value,
@@ -642,7 +684,7 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             uint32_t r[4];
             const uint64_t q = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
             orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)q, 0u,
-                           (uint32_t)sweep, (uint32_t)(sweep >> 32), r);
+                           (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
             int64_t evidence, proposal;
             if (var->isEvidence != 1) {
                 rc = draw_sample(g, v, Z, var_value_evid, weight_value, orc_u53(r[2], r[3]), 1,
@@ -660,7 +702,7 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             if (regularization == 1) {
                 uint32_t t[4];
                 orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)q, 1u,
-                               (uint32_t)sweep, (uint32_t)(sweep >> 32), t);
+                               (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, t);
                 truncate = orc_u53(t[0], t[1]) < 1.0 / (double)truncation;
             }
             /* union of the two sorted-unique factor lists, each factor visited once */

@@ -283,3 +283,22 @@ def test_write_probabilities_matches_the_reference_format(tmp_path):
                 want.append('%d %d %.3f\n' % (i, fg.vmap[v["vtf_offset"] + k]["value"],
                                               float(fg.count[fg.cstart[i] + k]) / 7))
     assert out.read_text() == "".join(want)
+
+
+def test_write_probabilities_refuses_a_malformed_variable_array(tmp_path):
+    """A vtf_offset / tally slot beyond the arrays handed in is NSK_E_INDEX (IndexError), checked
+    before anything is written -- the reference would raise IndexError from numpy."""
+    g = _graph_from_spec(3, [(14, [0, 1]), (4, [2])], card=np.array([3, 2, 2]))
+    g = list(g)
+    g[1] = g[1].copy()
+    g[1]["dataType"][:1] = 1
+    ns, fg = session(tuple(g))
+    out = tmp_path / "p.txt"
+    fg.variable["vtf_offset"][0] = len(fg.vmap) - 1            # 3 domain values do not fit behind it
+    with pytest.raises(IndexError):
+        fg.dump_probabilities(str(out), 1)
+    assert not out.exists()
+    fg.variable["vtf_offset"][0] = 0
+    fg.cstart[2] = len(fg.count) + 5
+    with pytest.raises(IndexError):
+        fg.dump_probabilities(str(out), 1)

@@ -356,8 +356,10 @@ def test_generic_kernels_alone(golden, name, no_general, no_heavy, monkeypatch):
     NSK_NO_GENERAL / NSK_NO_HEAVY (diagnostic switches read at graph creation) keep the variables
     on the wave-per-variable / the one-lane generic kernels instead: same results."""
     if no_general:
+        monkeypatch.setenv("NSK_DIAG", "1")
         monkeypatch.setenv("NSK_NO_GENERAL", "1")
     if no_heavy:
+        monkeypatch.setenv("NSK_DIAG", "1")
         monkeypatch.setenv("NSK_NO_HEAVY", "1")
     g, hbv = _small_graphs(golden)[name]
     ns, fg = session(g, seed=5, head_by_vid=hbv)
@@ -384,6 +386,7 @@ def test_learning_with_unpacked_accumulators(golden, name, reg, monkeypatch):
     """Graphs with integer gradients carry the visit count in the low half of the 64-bit gradient
     accumulator (one atomic per visit); NSK_NO_PACKED keeps the separate counters that graphs with
     fractional gradients use: same weights."""
+    monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv("NSK_NO_PACKED", "1")
     g, hbv = _small_graphs(golden)[name]
     ns, fg = session(g, seed=5, head_by_vid=hbv)
@@ -407,6 +410,7 @@ def test_learning_table_kernel_with_a_tiny_resident_grid(monkeypatch, evidence):
     border segments, with and without the evidence chain's own draw): same samples and weights as
     the oracle."""
     from numbskull_amd import graphgen
+    monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv("NSK_LEARN_GRID_CAP", "8")
     rng = np.random.Generator(np.random.PCG64(11))
     ev = rng.integers(0, 2, 128 * 128)
@@ -732,6 +736,44 @@ def test_two_partitions_on_one_gpu_match_emulation(learn):
             assert np.allclose(parts[r].w.cpu().numpy(), wv, rtol=0, atol=1e-15)
 
 
+@pytest.mark.parametrize("learn", [False, True])
+def test_shards_draw_from_disjoint_generator_streams(learn):
+    """Generator ids are positions in a handle's own layout, so position q exists in every shard:
+    the shard tag in the Philox counter (the first owned variable id, nsk_internal.h rng_tag) must
+    keep their uniforms apart.  4096 uncoupled fair coins (ISTRUE, weight 0) cut into two shards:
+    with a shared counter the coin at position q of shard 0 would equal the coin at position q of
+    shard 1 in every sweep; with disjoint streams they agree half of the time."""
+    from test_cabi import _graph_from_spec
+    from numbskull_amd.distributed import shard_range
+    nvar = 4096
+    g = _graph_from_spec(nvar, [(4, [i]) for i in range(nvar)], weights=(0.0,))
+    if learn:
+        g[0]["isFixed"][:] = True                      # learning sweeps, weights untouched
+    vals, pos = [], []
+    for r in range(2):
+        ns = numbskull_amd.NumbSkull(quiet=True, seed=77)
+        ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in g[:5]], int(g[5]),
+                           own_range=shard_range(r, 2, nvar))
+        fg = ns.factorGraphs[0]
+        lo, hi = shard_range(r, 2, nvar)
+        rows = []
+        for s in range(8):
+            if learn:
+                fg.learn(0, 1, 0.01, 1.0, 0, 0.0, 1, learn_non_evidence=True)
+            else:
+                fg.inference(0, 1, True)
+            rows.append(fg.var_value[0][lo:hi].copy())
+        ids = fg.layout()[lo:hi]
+        order = np.argsort(ids)                        # both shards listed by position in their layout
+        pos.append(ids[order])
+        vals.append(np.array(rows)[:, order])
+    assert np.array_equal(pos[0], pos[1])              # same positions (same generator ids) in both shards
+    agree = float((vals[0] == vals[1]).mean())
+    assert 0.45 < agree < 0.55, agree                  # 32768 pairs of fair coins: sigma = 0.0028
+    for v in vals:
+        assert 0.45 < float(v.mean()) < 0.55
+
+
 def test_native_rccl_loop_single_rank():
     """nsk_comm_init + nsk_gibbs_sweeps_exchange / nsk_learn_sweeps_exchange with a 1-rank
     communicator: the native loop (sweep, pack, ncclAllGather, unpack, ncclAllReduce of weight
@@ -961,6 +1003,7 @@ def test_marginals_within_1e_3_of_exact_after_burn_in():
 def test_compact_delta_streams_are_bit_exact(monkeypatch):
     """NSK_D16=1 builds the int16-delta twin of the table segments' streams (member positions as
     deltas from the lane's own position); the sweep must not change by a bit."""
+    monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv("NSK_D16", "1")
     rng = np.random.default_rng(5)
     for learn in (False, True):

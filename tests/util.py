@@ -34,12 +34,30 @@ def session(g, **kw):
 def oracle_of(fg, head_by_vid=False, layout=True):
     """Oracle view of the arrays a product FactorGraph holds.  Device mode keys its generator by
     the variables' positions in the library's compiled layout: on a GPU box
-    the oracle is handed that layout (``layout=False`` for host-only uses)."""
+    the oracle is handed that layout (``layout=False`` for host-only uses) -- after checking, for
+    EVERY graph the parity tests touch, what bit-equality with the oracle cannot show by itself:
+    that the generator ids of the sampled variables are distinct (two variables sharing a Philox
+    counter would still "equal the oracle") and that the colouring the library chose is valid."""
     og = orc.Graph(fg.weight, fg.variable, fg.factor, fg.fmap, fg.vmap, fg.factor_index,
                    head_by_vid=head_by_vid)
     if layout and numbskull_amd._lib.device_count() > 0:
-        og.set_rng_ids(fg.layout())
+        ids, color = fg.layout(), fg.colors()
+        check_layout(ids, color)
+        bad = og.check_coloring(color)
+        assert bad == (-1, -1), ("variable reads a variable of its own colour", bad)
+        og.set_rng_ids(ids)
+        og.set_rng_tag(fg.own_range[0] if fg.own_range is not None else 0)
     return og
+
+
+def check_layout(ids, color):
+    """Generator ids (= internal ids) must be injective: over the sampled variables (their Philox
+    counters) and over all variables (their slots in the device's value arrays)."""
+    ids = np.asarray(ids, np.int64)
+    assert len(ids) == 0 or (ids.min() >= 0 and np.bincount(ids).max() == 1), \
+        "two variables share an internal id"
+    sampled = ids[np.asarray(color) >= 0]
+    assert len(np.unique(sampled)) == len(sampled), "two sampled variables share a generator id"
 
 
 def phases_from_colors(color):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Degree-skew micro-benchmark: 200 hub variables, each tied to 5000 leaves by EQUAL factors
 (1M leaves with ISTRUE priors).  Compares the wave-per-variable hub kernels with the one-lane
-generic kernel:  python tools/hub_bench.py ; NSK_NO_HEAVY=1 python tools/hub_bench.py
+generic kernel:  python tools/hub_bench.py ; NSK_DIAG=1 NSK_NO_HEAVY=1 python tools/hub_bench.py
 Round-1 measurement on one MI355X: 0.42 ms/sweep vs 9.9 ms/sweep."""
 import sys, time, io, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
