@@ -514,9 +514,29 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t gen_block = diag_env("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(diag_env("NSK_GEN_BLOCK"))) : 262144;
     const int64_t gen_max_entries = diag_env("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(diag_env("NSK_GEN_MAX_ENTRIES")))) : 16;
     // (hub = true lifts the per-lane size caps: the entry-parallel hub kernels take up to 256 entries)
-    auto general_words = [&](int64_t v, std::vector<uint32_t> *out, bool hub = false) -> bool {
+    //
+    // The variable may occur SEVERAL times in one factor (the config-#5 generator draws the other
+    // members from [v - 1024, v + 1024], v included): as body member and head of a positional
+    // function, or with different dense_equal_to values.  With x = the candidate value c at every
+    // own edge, eval_factor still reduces to (c == cstar) ? A : B:
+    //   * positional function, own body edges (all with dense_equal_to db) AND own head (dh) -> role 3:
+    //     the head test is the constant (db == dh) [IMPLY_MLN: true -- the head is only reached with
+    //     every body member, the variable included, non-zero], the body test is over the other members;
+    //   * own edges whose dense_equal_to disagree: the variable cannot match all of them -- AND_CAT /
+    //     EQUAL_CAT_CONST and IMPLY_NATURAL_CAT (own body edges) are constant 0, IMPLY_MLN_CAT (own
+    //     body edges) constant 1, OR_CAT over a binary variable with both values named constant 1
+    //     (codes 10 / 11; no member words); OR_CAT naming two of more than two values is not of the
+    //     one-cstar form and keeps the variable on the generic path.
+    // A dataType-1 variable finds such a factor in the list of EVERY dense_equal_to its own edges
+    // name (dataloading.py:34-38); the learning sweep visits a factor once per variable
+    // (learning.py:76-95), so the entry in the list of the larger value names the smaller one as its
+    // `partner` (descriptor bits 19-22) and is skipped when the partner's list is selected too.
+    auto general_words = [&](int64_t v, std::vector<uint32_t> *out, bool hub = false, size_t hub_cap = 0) -> bool {
         const nsk_variable &var = d->variable[v];
         if (var.cardinality > 8 || var.cardinality < 2) return false;
+        // (an evidence value outside the domain is kept off the tiles: their saved facts hold the
+        // variable's own values in 4 bits)
+        if (var.initialValue < 0 || var.initialValue >= var.cardinality) return false;
         const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
         size_t nwords = 0, nentries = 0;
         if (out) out->clear();
@@ -524,53 +544,80 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
             for (int64_t j = 0; j < vt.factor_index_length; j++) {
                 const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
-                const int code = general_code(fa.factorFunction);
+                int code = general_code(fa.factorFunction);
                 if (code < 0 || fa.featureValue != 1.0 || fa.arity > 64) return false;
                 const bool positional = code == 5 || code == 8 || code == 9;
                 const bool cat = code >= 6;
                 const int64_t s = fa.ftv_offset, e = s + fa.arity;
-                int64_t others = 0, self_deo = -1, self_body = 0, self_head = 0;
+                int64_t others = 0, self_body = 0, self_head = 0;
+                int64_t body_deo = -1, head_deo = -1;      // dense_equal_to of the own body edges / own head
+                bool body_deo_mixed = false;
+                int64_t own_deo[2] = {-1, -1};             // distinct dense_equal_to of all own edges
+                int n_own_deo = 0;
                 uint32_t mem[8];
-                if (code == 0 && var.dataType != 0) {         // NOOP: only "one list per factor" matters
-                    for (int64_t l = s; l < e; l++) {
-                        if (d->fmap[l].vid != v) continue;
-                        if (self_deo >= 0 && self_deo != d->fmap[l].dense_equal_to) return false;
-                        self_deo = d->fmap[l].dense_equal_to;
-                    }
-                }
-                if (code != 0) {
-                    for (int64_t l = s; l < e; l++) {
-                        const int64_t vid = d->fmap[l].vid, deo = d->fmap[l].dense_equal_to;
-                        if (vid == v) {
-                            // repeated own edges: fine while they agree on dense_equal_to where it
-                            // matters (categorical functions; dataType 1, whose lists are keyed by it)
-                            if (cat || var.dataType != 0) {
-                                if (cat && (deo < 0 || deo > 31)) return false;
-                                if (self_deo >= 0 && self_deo != deo) return false;
-                                self_deo = deo;
+                const bool keyed = cat || var.dataType != 0;      // own dense_equal_to matters
+                for (int64_t l = s; l < e; l++) {
+                    const int64_t vid = d->fmap[l].vid, deo = d->fmap[l].dense_equal_to;
+                    if (vid == v) {
+                        if (keyed) {
+                            if (cat && (deo < 0 || deo > 31)) return false;
+                            if (n_own_deo == 0 || (own_deo[0] != deo && (n_own_deo < 2 || own_deo[1] != deo))) {
+                                if (n_own_deo == 2) return false;          // three different own values: generic path
+                                own_deo[n_own_deo++] = deo;
                             }
-                            if (l == e - 1) self_head++; else self_body++;
-                        } else {
-                            if (others >= 6) return false;
-                            int64_t rd = vid;                                  // index the value is read at
-                            if (positional && l == e - 1 && !head_by_vid) rd = l;   // inference.py:243,277,292
-                            if (rd >= (int64_t)NSK_GEN_NULL) return false;
-                            int64_t dd = cat ? deo : 0;
-                            if (dd < 0 || dd > 31) return false;
-                            mem[others++] = (uint32_t)rd | ((uint32_t)dd << 27);
                         }
+                        if (code == 0) continue;
+                        if (positional && l == e - 1) { self_head++; head_deo = deo; }
+                        else {
+                            self_body++;
+                            if (body_deo >= 0 && body_deo != deo) body_deo_mixed = true;
+                            body_deo = deo;
+                        }
+                    } else if (code != 0) {
+                        if (others >= 6) return false;
+                        int64_t rd = vid;                                  // index the value is read at
+                        if (positional && l == e - 1 && !head_by_vid) rd = l;   // inference.py:243,277,292
+                        if (rd >= (int64_t)NSK_GEN_NULL) return false;
+                        int64_t dd = cat ? deo : 0;
+                        if (dd < 0 || dd > 31) return false;
+                        mem[others++] = (uint32_t)rd | ((uint32_t)dd << 27);
                     }
-                    if (self_body + self_head == 0) return false;
-                    if (positional && self_body > 0 && self_head > 0) return false;
                 }
-                const uint32_t role = !positional ? 0u : (self_head ? 2u : 1u);
+                if (code != 0 && self_body + self_head == 0) return false;
+                // a non-categorical function over a dataType-1 variable whose own edges disagree:
+                // rare and not of the tile form (the lists are keyed by values the function ignores)
+                if (!cat && var.dataType != 0 && n_own_deo > 1 && code != 0) return false;
+                if (code == 0 && var.dataType != 0 && n_own_deo > 1) return false;
+                uint32_t role = 0, hbit = 0;
+                int64_t self_deo = keyed && n_own_deo > 0 ? own_deo[0] : -1;
+                if (code != 0 && positional) {
+                    if (self_body > 0 && cat && body_deo_mixed) {            // the body can never match
+                        code = code == 9 ? 11 : 10;
+                        others = 0;
+                    } else if (self_body > 0 && self_head > 0) {
+                        role = 3; self_deo = body_deo;
+                        hbit = cat ? (body_deo == head_deo ? 1u : 0u) : 1u;
+                    } else if (self_body > 0) { role = 1; self_deo = body_deo; }
+                    else { role = 2; self_deo = head_deo; }
+                } else if (code != 0 && cat && n_own_deo > 1) {             // AND_CAT / EQUAL_CAT_CONST / OR_CAT
+                    if (code == 6) { code = 10; others = 0; }
+                    else if (var.cardinality == 2) { code = 11; others = 0; }     // own edges name 0 and 1
+                    else return false;
+                }
+                uint32_t partner = 0;                       // bit 19: has one; bits 20-22: its value
+                if (var.dataType != 0 && n_own_deo > 1) {
+                    const int64_t lo = std::min(own_deo[0], own_deo[1]), hi = std::max(own_deo[0], own_deo[1]);
+                    if (lo < 0 || hi > 7) return false;
+                    if (k == hi) partner = 1u | ((uint32_t)lo << 1);
+                }
                 const uint32_t kslot = var.dataType == 0 ? 15u : (uint32_t)k;
                 nwords += 2 + (size_t)others;
-                if (hub ? (++nentries > 256) : (nwords > 120 || (int64_t)++nentries > gen_max_entries)) return false;
+                if (hub ? (++nentries > (hub_cap ? hub_cap : 256)) : (nwords > 120 || (int64_t)++nentries > gen_max_entries)) return false;
                 if (out) {
                     out->push_back((uint32_t)fa.weightId);
                     out->push_back((uint32_t)code | ((uint32_t)others << 4) | (role << 7) |
-                                   ((uint32_t)(cat && self_deo > 0 ? self_deo : 0) << 9) | (kslot << 14));
+                                   ((uint32_t)(cat && self_deo > 0 ? self_deo : 0) << 9) | (kslot << 14) |
+                                   (hbit << 18) | (partner << 19));
                     for (int64_t m = 0; m < others; m++) out->push_back(mem[m]);
                 }
             }
@@ -779,6 +826,18 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     g_ne[v] = (uint8_t)ne; g_mo[v] = (uint8_t)mo;
                 }
             });
+            // entry-parallel groups (nsk_compile.h ep_desc) serve a colour whose general variables all
+            // have entries of at most 3 other members and at most 16 entries (ordinal: 5 bits, LDS slots)
+            c.phase_ep.assign((size_t)ncolors, 0);
+            c.phase_ep_emax.assign((size_t)ncolors, 0);
+            if (!diag_env("NSK_NO_EP") && nw < ((int64_t)1 << 27)) {
+                for (int32_t k = 0; k < ncolors; k++) c.phase_ep[k] = ngt_of[k] > 0 ? 1 : 0;
+                for (int64_t v = 0; v < nvar; v++) {
+                    if (c.color[v] < 0 || fast[v] != 2) continue;
+                    if (g_mo[v] > 3 || g_ne[v] > 16) c.phase_ep[c.color[v]] = 0;
+                    c.phase_ep_emax[c.color[v]] = std::max<int32_t>(c.phase_ep_emax[c.color[v]], g_ne[v]);
+                }
+            }
             for (int64_t v = 0; v < nvar; v++) {
                 if (c.color[v] < 0 || fast[v] != 2) continue;
                 const int64_t ne = g_ne[v], mo = g_mo[v];
@@ -920,6 +979,12 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     // the entries per super-group (general_walk_m, nsk_kernels_gibbs.h)
                     const uint32_t EG = ((2 + M) % 4 == 0) ? 1u : ((2 + M) % 2 == 0) ? 2u : 4u;
                     E = (E + EG - 1) / EG * EG;
+                    if (c.phase_ep[k]) {            // entry-parallel group layout: no per-tile stream
+                        ts.cls = 1; ts.nkey = 2; ts.key[0] = 0; ts.key[1] = M;
+                        ts.len = 0;
+                        ts.flags = (6u << 8) | (maxcard << 12) | (M << 16);
+                        continue;
+                    }
                     ts.cls = 1; ts.nkey = 2; ts.key[0] = E; ts.key[1] = M;
                     ts.len = (int32_t)(E * (2 + M));
                     ts.flags = (uint32_t)ts.len | (6u << 8) | (maxcard << 12) | (M << 16);
@@ -1178,6 +1243,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         c.adj[base + 256 * (out / 4) + 4 * (uint64_t)(p - p0) + (out % 4)] = word;
                         out++;
                     };
+                    if (general && c.phase_ep[k]) { nfast_here++; continue; }     // laid out by groups, below
                     if (general) {               // entries padded to M member slots, then E entries
                         general_words(c.p_vid[p], &words);
                         const uint32_t M = (td[3] >> 16) & 7u, E = (td[3] & 0xFFu) / (2 + M);
@@ -1214,6 +1280,104 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int64_t x : nfast_part) c.nfast += x;
     }
     lap("tile fill (pass 2)");
+    // ---- entry-parallel groups (nsk_compile.h ep_desc): the general tiles of an EP colour, four at a
+    // time, as rows of 64 list entries sorted by their member count
+    c.phase_ep_base.assign((size_t)ncolors + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++) {
+        const int64_t ngt = (c.phase_wb_base[k + 1] - c.phase_wb_base[k]) - c.phase_gen_tile[k];
+        c.phase_ep_base[k + 1] = c.phase_ep_base[k] + (c.phase_ep[k] ? (ngt + 3) / 4 : 0);
+    }
+    {
+        const int64_t ngroups = c.phase_ep_base[ncolors];
+        c.ep_desc.assign((size_t)ngroups * 4 + 4, 0u);
+        std::vector<int32_t> group_colour((size_t)ngroups);
+        for (int32_t k = 0; k < ncolors; k++)
+            for (int64_t gi = c.phase_ep_base[k]; gi < c.phase_ep_base[k + 1]; gi++) group_colour[gi] = k;
+        auto group_range = [&](int64_t gi, int64_t &p0, int64_t &p1) {
+            const int32_t k = group_colour[gi];
+            p0 = c.phase_start[k] + 64 * (c.phase_gen_tile[k] + 4 * (gi - c.phase_ep_base[k]));
+            p1 = std::min(p0 + 256, c.phase_fast_end[k]);
+        };
+        std::vector<uint64_t> subrows((size_t)ngroups + 1, 0);
+        // row classes: member count M = 0..3 of the entries with ordinal < 8 ("base", classes 0-3),
+        // then the same for ordinals 8..15 ("overflow", classes 4-7): the kernels hold 8 list positions
+        // per variable in LDS and take a group with longer lists in two passes
+        auto row_class = [](uint32_t m, uint32_t ordinal) { return m + (ordinal >= 8 ? 4u : 0u); };
+        parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass A: rows per class
+            std::vector<uint32_t> w;
+            for (int64_t gi = g0; gi < g1; gi++) {
+                int64_t p0, p1;
+                group_range(gi, p0, p1);
+                uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, emax = 0, maxcard = 2;
+                for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;
+                    general_words(c.p_vid[p], &w);
+                    uint32_t ne = 0;
+                    for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) { cnt[row_class((w[j + 1] >> 4) & 7u, ne)]++; ne++; }
+                    emax = std::max(emax, ne);
+                    maxcard = std::max(maxcard, (uint32_t)d->variable[c.p_vid[p]].cardinality);
+                }
+                uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
+                uint64_t sr = 0;
+                gd[1] = 0; gd[3] = 0;
+                for (uint32_t cl = 0; cl < 8; cl++) {
+                    const uint32_t rows = (cnt[cl] + 63) / 64;
+                    gd[cl < 4 ? 1 : 3] |= rows << (8 * (cl & 3u));
+                    sr += (uint64_t)rows * (2 + (cl & 3u));
+                }
+                gd[2] = emax | (maxcard << 8);
+                subrows[gi + 1] = sr;
+            }
+        });
+        for (int64_t gi = 0; gi < ngroups; gi++) subrows[gi + 1] += subrows[gi];
+        if (subrows[ngroups] * 64 >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
+        c.ep_adj.assign((size_t)subrows[ngroups] * 64 + 64, 0u);
+        parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass B: fill
+            std::vector<uint32_t> w;
+            for (int64_t gi = g0; gi < g1; gi++) {
+                int64_t p0, p1;
+                group_range(gi, p0, p1);
+                uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
+                gd[0] = (uint32_t)subrows[gi];
+                uint64_t base[8], at[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first sub-row / entries placed, per class
+                uint64_t sr = subrows[gi];
+                for (uint32_t cl = 0; cl < 8; cl++) {
+                    const uint32_t m = cl & 3u;
+                    base[cl] = sr;
+                    const uint32_t rows = (gd[cl < 4 ? 1 : 3] >> (8 * m)) & 255u;
+                    // padding entries of the last row: owned by no candidate, empty member slots
+                    for (uint64_t r = 0; r < rows; r++)
+                        for (uint32_t e = 0; e < 64; e++) {
+                            uint32_t *row = &c.ep_adj[(sr + r * (2 + m)) * 64];
+                            row[2 * e] = 0u; row[2 * e + 1] = 14u << 14;
+                            for (uint32_t mm = 0; mm < m; mm++) row[(2 + mm) * 64 + e] = NSK_GEN_NULL;
+                        }
+                    sr += (uint64_t)rows * (2 + m);
+                }
+                for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;
+                    general_words(c.p_vid[p], &w);
+                    uint32_t ordinal = 0;
+                    for (size_t j = 0; j < w.size(); ordinal++) {
+                        const uint32_t m = (w[j + 1] >> 4) & 7u, cl = row_class(m, ordinal);
+                        const uint64_t r = at[cl] / 64, e = at[cl] % 64;
+                        at[cl]++;
+                        uint32_t *row = &c.ep_adj[(base[cl] + r * (2 + m)) * 64];
+                        const uint32_t wid = w[j];
+                        row[2 * e] = wid | (ordinal << 27);
+                        row[2 * e + 1] = w[j + 1] | ((uint32_t)(p - p0) << 23) | (c.w_fixed[wid] ? 0x80000000u : 0u);
+                        for (uint32_t mm = 0; mm < m; mm++)
+                            row[(2 + mm) * 64 + e] = (uint32_t)c.iid[w[j + 2 + mm] & NSK_GEN_NULL] | (w[j + 2 + mm] & ~NSK_GEN_NULL);
+                        j += 2 + m;
+                    }
+                }
+            }
+        });
+        if (verbose && ngroups)
+            fprintf(stderr, "[nsk] entry-parallel groups %lld, stream %.1f MB\n", (long long)ngroups,
+                    (double)subrows[ngroups] * 256 / 1e6);
+    }
+    lap("entry-parallel groups");
     // ---- compact twin of the table segments' streams: member positions as int16 deltas from the
     // lane's own position plus one base offset per segment (8 bytes per lane instead of 16 for <= 4
     // slots), for segments whose every delta fits -- on a grid every neighbour of a class lives in
@@ -1293,6 +1457,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     for (int32_t k = 0; k < ncolors; k++)
         c.phase_hub_base[k + 1] = c.phase_hub_base[k] + (c.phase_heavy_end[k] - c.phase_fast_end[k]);
     c.hub_desc.assign((size_t)(c.phase_hub_base[ncolors] + 1) * 4, 0u);
+    c.phase_bighub_base.assign((size_t)ncolors + 1, 0);
     std::vector<int32_t> hub_colour;
     if (!diag_env("NSK_NO_HUB_EP") && !no_general) {
         std::vector<int64_t> hubs;
@@ -1303,7 +1468,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         parallel_for((int64_t)hubs.size(), [&](int64_t b0, int64_t b1, int) {
             std::vector<uint32_t> w;
             for (int64_t h = b0; h < b1; h++) {
-                if (!general_words(c.p_vid[hubs[h]], &w, true)) continue;
+                // (a colour laid out as entry-parallel groups has the block-per-hub kernels for long lists)
+                if (!general_words(c.p_vid[hubs[h]], &w, true, c.phase_ep[hub_colour[h]] ? 16384 : 256)) continue;
                 uint32_t ne = 0, mo = 0;
                 for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) { ne++; mo = std::max(mo, (w[j + 1] >> 4) & 7u); }
                 nent[h] = ne; mh[h] = mo;
@@ -1324,7 +1490,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     if (!nent[h]) continue;
                     const int64_t p = hubs[h];
                     const nsk_variable &var = d->variable[c.p_vid[p]];
-                    general_words(c.p_vid[p], &w, true);
+                    general_words(c.p_vid[p], &w, true, 16384);
                     const uint32_t rows = 2 + mh[h], rounds = (nent[h] + 63) / 64;
                     uint32_t *base = &c.hub_adj[off[h]];
                     for (uint32_t r = 0; r < rounds; r++)              // padding entries: owned by no candidate
@@ -1344,15 +1510,25 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     }
                     const int32_t hk = hub_colour[h];
                     uint32_t *hd = &c.hub_desc[(size_t)(c.phase_hub_base[hk] + (p - c.phase_fast_end[hk])) * 4];
-                    hd[0] = (uint32_t)off[h]; hd[1] = nent[h]; hd[2] = mh[h] | ((uint32_t)var.cardinality << 8); hd[3] = 0;
+                    // hd[3] = 1: a long list, evaluated by a whole workgroup (k_gibbs_ep / k_learn_ep)
+                    hd[0] = (uint32_t)off[h]; hd[1] = nent[h]; hd[2] = mh[h] | ((uint32_t)var.cardinality << 8);
+                    hd[3] = (c.phase_ep[hk] && nent[h] > 128) ? 1u : 0u;
                 }
             });
+            for (size_t h = 0; h < hubs.size(); h++) {          // (hubs are listed colour by colour)
+                const int32_t hk = hub_colour[h];
+                if (!c.hub_desc[(size_t)(c.phase_hub_base[hk] + (hubs[h] - c.phase_fast_end[hk])) * 4 + 3]) continue;
+                c.bighub_pos.push_back((uint32_t)hubs[h]);
+                c.phase_bighub_base[hk + 1]++;
+            }
             c.nhub_ep = 0;
             for (size_t h = 0; h < hubs.size(); h++) if (nent[h]) c.nhub_ep++;
             if (verbose) fprintf(stderr, "[nsk] hubs %zu, entry-parallel %lld, stream %.1f MB\n", hubs.size(),
                                  (long long)c.nhub_ep, (double)total * 4 / 1e6);
         }
     }
+    for (int32_t k = 0; k < ncolors; k++) c.phase_bighub_base[k + 1] += c.phase_bighub_base[k];
+    if (c.bighub_pos.empty()) c.bighub_pos.push_back(0);
     lap("compact streams");
     {
     // learning launches: segments grouped by (kind, chunks) into tables of <= 8, the
@@ -1600,6 +1776,19 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 if (big_w && kind == 6u) wrows += (double)((td[3] & 0xFFu) / (2 + ((td[3] >> 16) & 7u))) * 64 * 8;
                 if (big_w && kind == 7u) wrows += (double)(td[3] & 0xFFu) * 64 * 8 / 2;   // ~ one header per two words
             }
+            if (c.phase_ep[k])                         // entry-parallel groups: their rows instead of tile words;
+                for (int64_t gi = c.phase_ep_base[k]; gi < c.phase_ep_base[k + 1]; gi++) {
+                    const uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
+                    double sr = 0;
+                    double rows = 0;
+                    for (uint32_t m = 0; m < 4; m++) {
+                        const double r = (double)((gd[1] >> (8 * m)) & 255u) + (double)((gd[3] >> (8 * m)) & 255u);
+                        sr += r * (2 + m);
+                        rows += r;
+                    }
+                    words += sr * 256;
+                    if (big_w) wrows += rows * 64 * 8;                 // one gathered weight per entry
+                }
             lay_inf += words + wrows;
             lay_learn += words + 3 * wrows;            // weight gathers + one 16-byte atomic per visit
             int64_t distinct = 0, nfastpos = 0, ncatpos = 0;

@@ -59,6 +59,9 @@ struct Compiled {
     // the hub takes the generic walk) and the lane-per-entry word rows
     std::vector<uint32_t> hub_desc, hub_adj;
     std::vector<int64_t> phase_hub_base;    // [ncolors+1] first descriptor of each colour's hub range
+    // hubs with long lists in entry-parallel colours: positions, colour by colour (hub_desc[..][3] = 1)
+    std::vector<uint32_t> bighub_pos;
+    std::vector<int64_t> phase_bighub_base; // [ncolors+1]
     int64_t nhub_ep = 0;
     std::vector<uint32_t> adj16;           // compact twin of the table segments' streams: int16 deltas
     // A tile whose 64 lanes share one header sequence (same function, member count and weight per
@@ -102,6 +105,20 @@ struct Compiled {
     std::vector<int64_t> phase_gen_tile;    // [ncolors]
     bool packed_grad = false;               // integer gradients, bounded visit counts (GradSink::packed)
     std::vector<int64_t> phase_gen_bin_tile;   // [ncolors] first of the all-binary general tiles (they come last)
+    // Entry-parallel layout of a colour's general tiles (DESIGN.md "entry-parallel groups"): a GROUP is
+    // four consecutive general tiles (256 positions = one workgroup).  Its list entries -- the very
+    // words of the general tiles plus `ordinal << 27` in the weight word (position in the variable's
+    // list order) and `position in the group << 23 | weight fixed << 31` in the descriptor word -- are
+    // sorted into 8 classes (member count M = 0..3 of the entries with ordinal < 8, then the same for
+    // ordinals 8..15) and cut into ROWS of 64 entries, one entry per lane: a row is (2 + M) sub-rows
+    // of 64 words in ep_adj -- the (weight, descriptor) pairs interleaved in the first two, then one
+    // sub-row per member slot.  No padding to the widest lane of a tile.
+    // ep_desc[group] = {first sub-row, rows of classes 0-3 (8 bits each), most entries of a variable |
+    // largest cardinality << 8, rows of classes 4-7}.
+    std::vector<uint32_t> ep_desc, ep_adj;
+    std::vector<int64_t> phase_ep_base;        // [ncolors+1] first group of each colour
+    std::vector<uint8_t> phase_ep;             // [ncolors] 1: the colour's general tiles are laid out as groups
+    std::vector<int32_t> phase_ep_emax;        // [ncolors] most entries of one of its variables
     int64_t nfast = 0;
     // per position
     std::vector<int32_t> p_vid, p_slot, p_cnt;

@@ -227,6 +227,9 @@ struct DevGraph {
     const uint4 *ztab;          // draw tables of the uniform programs whose members are all binary:
                                 //  entry (program, neighbourhood bits) = {K lo, K hi, sat0 | sat1 << 8, 0}
                                 //  (k_refresh_ztab; DESIGN.md "draw tables")
+    const uint32_t *bighub_pos; // positions of the hubs a whole workgroup evaluates (hub_desc[..].w = 1)
+    const uint4 *ep_desc;       // entry-parallel groups of general tiles (nsk_compile.h ep_desc): one per
+    const uint32_t *ep_adj;     //  256 positions; ep_adj: sub-rows of 64 words
     const int32_t *iid_of_vid;  // variable id -> internal id (position; ghosts after the positions): the
                                 //  literal head lookup of the generic path needs it (uploaded only then)
     int32_t nvar;

@@ -29,7 +29,29 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 const int he = (int)g->c.phase_heavy_end[ph];
                 ColourStreams cs(g, !g->no_overlap);
                 bool rest_in_general = false;       // the colour's rest tiles were given to a general launch
-                {   // hubs (one wave per variable) + general tiles with categorical lanes: one launch
+                const bool ep = fe > fb && g->c.phase_ep[ph];
+                if (ep) {   // entry-parallel groups: hubs, the colour's general tiles and its rest tiles in one launch
+                    const int gt0 = (int)g->c.phase_gen_tile[ph];
+                    const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
+                    const int ngroups = (int)(g->c.phase_ep_base[ph + 1] - g->c.phase_ep_base[ph]);
+                    const int nbh = (int)(g->c.phase_bighub_base[ph + 1] - g->c.phase_bighub_base[ph]);   // a block per long-list hub
+                    const int hblocks = nbh + (he - fe + 3) / 4;
+                    const int nrest_all = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
+                    rest_in_general = nrest_all > 0;
+                    const int rblocks = (nrest_all + 3) / 4;
+                    // resident grid: 7 workgroups per CU (22 KB of LDS each), whole rounds of XCDs
+                    const int gblocks = 8 * ((std::min(ngroups, 256 * 7) + 7) / 8);
+                    const dim3 grid(hblocks + gblocks + rblocks);
+                    const size_t smem = 0;
+#define NSK_EP_ARGS d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, ngt, ngroups, (int)g->c.phase_ep_base[ph], gblocks, fe, he, hblocks, \
+                    (int)g->c.phase_hub_base[ph], nbh, (int)g->c.phase_bighub_base[ph], g->rest_tiles + g->c.phase_rest_base[ph], nrest_all, sample_evidence, burnin, \
+                    (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep, nsk_sweep_hi(g)
+                    if (g->c.phase_gen_bin_tile[ph] > gt0) k_gibbs_ep<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
+                    else k_gibbs_ep<VT, 2><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
+#undef NSK_EP_ARGS
+                    g->launches++;
+                }
+                if (!ep) {   // hubs (one wave per variable) + general tiles with categorical lanes: one launch
                     const int gt0 = fe > fb ? (int)g->c.phase_gen_tile[ph] : 0;
                     int gtb = fe > fb ? (int)g->c.phase_gen_bin_tile[ph] : 0;
                     // a class with categorical tiles walks ALL its general tiles in this launch, on
@@ -69,7 +91,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const int ngt = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]) - gt0;
                     int gtb = (int)g->c.phase_gen_bin_tile[ph];
                     if (gtb > gt0) gtb = gt0 + ngt;     // walked by the launch above
-                    if (gt0 + ngt > gtb) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
+                    if (gt0 + ngt > gtb && !ep) {   // all-binary general tiles (IMPLY_MLN, mixed tails)
                         const int nblocks = (gt0 + ngt - gtb + 3) / 4;
                         const int hbl = gtb == gt0 ? (he - fe + 3) / 4 : 0;     // see above
                         const int nrest_all = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);

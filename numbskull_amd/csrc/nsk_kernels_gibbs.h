@@ -354,9 +354,14 @@ struct GenChain {
     // (c == cstar) ? A : B for the entry described by descriptor word d1: one byte of the table below
     __device__ __forceinline__ void close(uint32_t d1, const uint8_t *lut, int &cstar, int &A, int &B) const {
         const uint32_t nomember = ((d1 >> 4) & 7u) == 0u ? 1u : 0u;
-        const uint32_t idx = (d1 & 15u) | ((((d1 >> 7) & 3u) == 1u ? 1u : 0u) << 4) | (nomember << 5) |
-                             ((allnz ? 1u : 0u) << 6) | ((prevall ? 1u : 0u) << 7) | ((any1 ? 1u : 0u) << 8) |
-                             ((alleq ? 1u : 0u) << 9) | ((lastnz ? 1u : 0u) << 10);
+        // own role (bits 7-8): 1 body, 2 head, 3 body AND head of a positional function -- then every
+        // other member is a body member (body test = allnz) and the head test is the constant in bit 18
+        // (nsk_compile.cpp general_words)
+        const bool both = ((d1 >> 7) & 3u) == 3u;
+        const bool pv = both ? allnz : prevall, ln = both ? ((d1 >> 18) & 1u) != 0u : lastnz;
+        const uint32_t idx = (d1 & 15u) | (((d1 >> 7) & 1u) << 4) | (nomember << 5) |
+                             ((allnz ? 1u : 0u) << 6) | ((pv ? 1u : 0u) << 7) | ((any1 ? 1u : 0u) << 8) |
+                             ((alleq ? 1u : 0u) << 9) | ((ln ? 1u : 0u) << 10);
 #ifdef NSK_ABL_NOLUT
         const uint32_t e = idx & 0x3Fu;
 #else
@@ -401,8 +406,8 @@ constexpr uint8_t gen_lut_entry(uint32_t idx) {
         sel = 3;
         if (role1) { A = !body ? 1 : (hd ? 1 : 0); B = 1; }
         else { A = 1; B = allnz ? 0 : 1; }
-    }
-    return (uint8_t)((A + 1) | ((B + 1) << 2) | (sel << 4));
+    } else if (code == 11u) { A = 1; B = 1; }           // constant 1 (code 10: constant 0) -- a variable
+    return (uint8_t)((A + 1) | ((B + 1) << 2) | (sel << 4));   // whose own edges in the factor disagree
 }
 constexpr GenLut make_gen_lut() {
     GenLut l{};
@@ -410,6 +415,18 @@ constexpr GenLut make_gen_lut() {
     return l;
 }
 static __constant__ GenLut k_gen_lut = make_gen_lut();
+
+// Learning: is the entry with descriptor d1 among the factors sample_and_sgd visits for this variable
+// (learning.py:76-95: the sorted-unique union of the lists of the evidence and the proposal value)?
+// dataType 0: always (one list).  dataType 1: when its list is selected -- except that a factor the
+// variable's own edges put into TWO lists is visited through the smaller value's entry when both are
+// selected (descriptor bit 19: has such a partner, bits 20-22: the partner's value).
+__device__ __forceinline__ bool entry_visited(uint32_t d1, int evidence, int proposal) {
+    const int ks = (int)((d1 >> 14) & 15u);
+    const int partner = (int)((d1 >> 20) & 7u);
+    const bool dup = ((d1 >> 19) & 1u) != 0u && (partner == evidence || partner == proposal);
+    return ks == 15 || ((ks == evidence || ks == proposal) && !dup);
+}
 
 // block-wide copy of the table into LDS; every thread of the block must call it
 __device__ __forceinline__ void load_gen_lut(uint8_t *lds) {
@@ -628,7 +645,10 @@ struct GenPot {
         for (int c = 0; c < MAXC; c++) p[c] = 0.0;
     }
     __device__ __forceinline__ void add(int maxcard, uint32_t d1, double w, int cstar, int A, int B) {
-        const int ks = (int)((d1 >> 14) & 15u);       // candidate owning the entry; 15 = all (dataType 0)
+        add_ks(maxcard, (int)((d1 >> 14) & 15u), w, cstar, A, B);
+    }
+    // ks: candidate owning the entry; 15 = all (dataType 0); 14 = none (padding)
+    __device__ __forceinline__ void add_ks(int maxcard, int ks, double w, int cstar, int A, int B) {
         const double tA = w * (double)A, tB = w * (double)B;
 #pragma unroll
         for (int c = 0; c < MAXC; c++) {
@@ -945,6 +965,323 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
     const uint32_t wrow = *(const NSK_SCALAR uint32_t *)(g.tile_wrow + (wb_base + tile));
     gibbs_tile_general<VT, MAXC>(g, lut, g.adj + tdx + lane, tdw, tdz, wrow, p, valid, sample_evidence, burnin,
                                  k0, k1, s0, s1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Entry-parallel groups (nsk_compile.h ep_desc; DESIGN.md "entry-parallel groups").  A general tile
+// walked by one lane per VARIABLE is a chain of dependent memory round trips -- stream words, member
+// gathers, next entries -- as long as its longest lane and padded to its widest lane.  Here a
+// workgroup owns 256 positions and alternates two phases:
+//   1. one lane per LIST ENTRY: the entries of the 256 variables, sorted by member count, are rows of
+//      64; a lane loads its entry's words (coalesced), gathers the weight and the <= 3 member values,
+//      closes the chain facts exactly like a general tile (GenChain, gen_lut_entry) and leaves
+//      (weight, owner candidate, cstar, A, B) in the LDS slot [position in the list][variable].
+//      No lane waits for a previous entry; the next row's words are requested before this row's gathers.
+//   2. one lane per VARIABLE: adds its entries' terms IN LIST ORDER from LDS -- the same float64
+//      additions as potential() (inference.py:55-71) -- then draws and stores.
+// LDS holds 8 list positions per variable (22 KB per workgroup: 7 workgroups per CU); a group whose
+// variables have up to 16 entries takes two passes (its entries 8..15 are rows of their own).  The
+// grid is resident: a workgroup walks the groups of its XCD's eighth of the colour.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int nsk_u32x2 __attribute__((ext_vector_type(2)));
+#define NSK_EP_WID(w0) ((w0) & 0x7FFFFFFu)
+#define NSK_EP_SLOT(w0, d1) ((((w0) >> 27) & 7u) * 256u + (((d1) >> 23) & 255u))
+#define NSK_EP_LIST 8                      // list positions per variable held in LDS
+
+struct EpRow { uint32_t w0, d1, m[3]; };
+
+// sub-rows of the rows of one pass: classes M = 0..3 with the row counts of `rowsw` (8 bits each)
+__device__ __forceinline__ int ep_pass_subrows(uint32_t rowsw) {
+    return (int)(rowsw & 255u) * 2 + (int)((rowsw >> 8) & 255u) * 3 + (int)((rowsw >> 16) & 255u) * 4 + (int)(rowsw >> 24) * 5;
+}
+__device__ __forceinline__ int ep_pass_rows(uint32_t rowsw) {
+    return (int)(rowsw & 255u) + (int)((rowsw >> 8) & 255u) + (int)((rowsw >> 16) & 255u) + (int)(rowsw >> 24);
+}
+
+// words of row r (wave-uniform) of a pass; M = its member count
+template <bool NT, bool MEMBERS>
+__device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, uint32_t rowsw, int r, EpRow &q, int &M) {
+    const int n0 = (int)(rowsw & 255u), n1 = (int)((rowsw >> 8) & 255u), n2 = (int)((rowsw >> 16) & 255u);
+    const int c1 = n0 + n1, c2 = c1 + n2;
+    int sub;
+    if (r < n0) { M = 0; sub = r * 2; }
+    else if (r < c1) { M = 1; sub = n0 * 2 + (r - n0) * 3; }
+    else if (r < c2) { M = 2; sub = n0 * 2 + n1 * 3 + (r - c1) * 4; }
+    else { M = 3; sub = n0 * 2 + n1 * 3 + n2 * 4 + (r - c2) * 5; }
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t *row = adj + (size_t)(sub0 + (uint32_t)sub) * 64;
+    const nsk_u32x2 h = NT ? __builtin_nontemporal_load((const nsk_u32x2 *)row + lane) : *((const nsk_u32x2 *)row + lane);
+    q.w0 = h.x; q.d1 = h.y;
+    q.m[0] = NSK_GEN_NULL; q.m[1] = NSK_GEN_NULL; q.m[2] = NSK_GEN_NULL;
+    if (MEMBERS) {
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+            if (M > m) q.m[m] = NT ? __builtin_nontemporal_load(row + (2 + m) * 64 + lane) : row[(2 + m) * 64 + lane];
+    }
+}
+
+// The rows of one pass that belong to this wave (dealt round-robin over the four waves):
+// fn(weight word, descriptor, chain over va, chain over vb, weight).  MEMBERS = false: only the
+// (weight word, descriptor) pairs are read (the gradient pass of learning).
+template <typename VT, bool TWO, bool WANT_W, bool NT, bool MEMBERS, typename FN>
+__device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, const VT *vb, uint32_t sub0,
+                                        uint32_t rowsw, FN &&fn) {
+    const int wave = (int)(threadIdx.x >> 6);
+    const int total = ep_pass_rows(rowsw);
+    if (wave >= total) return;
+    EpRow cur, nxt;
+    int Mc, Mn = 0;
+    ep_load_row<NT, MEMBERS>(g.ep_adj, sub0, rowsw, wave, cur, Mc);
+    for (int r = wave; r < total; r += 4) {
+        if (r + 4 < total) ep_load_row<NT, MEMBERS>(g.ep_adj, sub0, rowsw, r + 4, nxt, Mn);
+#ifdef NSK_ABL_EPNOW
+        const double w = WANT_W ? __longlong_as_double(0x3FB0000000000000ll | (long long)cur.w0) : 0.0;
+#else
+        const double w = WANT_W ? g.w[NSK_EP_WID(cur.w0)] : 0.0;
+#endif
+        int xa[3] = {0, 0, 0}, xb[3] = {0, 0, 0};
+        if (MEMBERS) {
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+                if (Mc > m) {                                       // wave-uniform
+                    const uint32_t id = cur.m[m] & NSK_GEN_NULL;
+                    const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
+#ifdef NSK_ABL_EPNOVAL
+                    xa[m] = (int)(at & 1u);
+                    if (TWO) xb[m] = (int)((at >> 1) & 1u);
+#else
+                    xa[m] = (int)va[at];
+                    if (TWO) xb[m] = (int)vb[at];
+#endif
+                }
+        }
+        const bool cat = (cur.d1 & 15u) >= 6u;
+        GenChain a, b;
+        a.open();
+        if (TWO) b.open();
+        if (MEMBERS) {
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+                if (Mc > m) {
+                    a.member(m == 0, cat, cur.m[m], xa[m]);
+                    if (TWO) b.member(m == 0, cat, cur.m[m], xb[m]);
+                }
+        }
+        fn(cur.w0, cur.d1, a, b, w);
+        cur = nxt; Mc = Mn;
+    }
+}
+
+// (cstar, A, B) of a closed entry in 8 bits; a cstar no candidate of a general variable (< 8) can
+// equal is stored as 15
+__device__ __forceinline__ uint32_t ep_facts(int cstar, int A, int B) {
+    return ((uint32_t)cstar > 15u ? 15u : (uint32_t)cstar) | ((uint32_t)(A + 1) << 4) | ((uint32_t)(B + 1) << 6);
+}
+
+// the groups of a resident launch that this workgroup walks: XCD x (= blockIdx & 7, how the hardware
+// deals workgroups; for speed only) takes the x-th eighth of the groups
+struct EpWalk { int gi, gend, step; };
+__device__ __forceinline__ EpWalk ep_walk(int ngroups, int hblocks, int gblocks) {
+    const int xcd = (int)(blockIdx.x & 7);
+    const int firstb = hblocks + ((xcd - (hblocks & 7) + 8) & 7);        // first group block on this XCD
+    const int nbx = firstb < hblocks + gblocks ? (hblocks + gblocks - 1 - firstb) / 8 + 1 : 0;
+    const int per8 = (ngroups + 7) >> 3;
+    EpWalk wk;
+    wk.gi = xcd * per8 + (((int)blockIdx.x - firstb) >> 3);
+    wk.gend = min(ngroups, (xcd + 1) * per8);
+    wk.step = nbx;
+    return wk;
+}
+
+// A hub with a long list, evaluated by a whole workgroup: the four waves evaluate its entries 64 at a
+// time (hub_entry, as heavy_update_ep does) into LDS, 2048 entries per round, then wave 0 adds the
+// terms IN LIST ORDER -- lane c keeps candidate c's sum and every lane reads the same entry (an LDS
+// broadcast) -- the same float64 additions as potential() (inference.py:55-71).  One wave on such a
+// list is a chain of hundreds of dependent steps that outlasts the rest of the colour class.
+// fsz: bytes of one facts word (2: owner | facts << 4; 4: the learning kernels' two-chain word).
+template <typename VT>
+__device__ __forceinline__ double block_hub_potentials(const DevGraph<VT> &g, const uint8_t *lut, const uint4 hd,
+                                                       const VT *val, double *ws, uint16_t *fs) {
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int n = (int)hd.y, M = (int)(hd.z & 0xFFu), rows = 2 + M;
+    const uint32_t *base = g.hub_adj + hd.x;
+    double pc = 0.0;
+    for (int c0 = 0; c0 < n; c0 += NSK_EP_LIST * 256) {
+        const int cn = min(NSK_EP_LIST * 256, n - c0);
+        __syncthreads();                                   // (wave 0 is done with the previous round)
+        for (int r = wave; r * 64 < cn; r += NSK_BLOCK / 64) {
+            HubEntry en;
+            hub_entry(g, lut, base, rows, c0 / 64 + r, M, val, true, en);
+            ws[r * 64 + lane] = en.w;
+            fs[r * 64 + lane] = (uint16_t)(((en.d1 >> 14) & 15u) | (ep_facts(en.cstar, en.A, en.B) << 4));
+        }
+        __syncthreads();
+        if (wave == 0)
+            for (int i = 0; i < cn; i++) {                 // list order
+                const uint32_t f = fs[i];
+                const double w = ws[i];
+                const int ks = (int)(f & 15u), cstar = (int)((f >> 4) & 15u);
+                const double tA = w * (double)((int)((f >> 8) & 3u) - 1), tB = w * (double)((int)((f >> 10) & 3u) - 1);
+                const bool on = ks == 15 || ks == lane;
+                const double t = on ? (lane == cstar ? tA : tB) : 0.0;       // +0.0 leaves the sum unchanged
+                pc = pc + t;
+            }
+    }
+    return pc;                                             // meaningful in wave 0
+}
+
+template <typename VT>
+__device__ __forceinline__ void block_hub_update(const DevGraph<VT> &g, const uint8_t *lut, int p, const uint4 hd,
+                                                 double *ws, uint16_t *fs, int sample_evidence, int burnin,
+                                                 uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+    const uint32_t info = g.p_info[p];
+    const int ev = NSK_INFO_EV(info);
+    if (g.p_vid[p] < 0 || !(ev == 0 || sample_evidence)) return;             // (block-uniform)
+    const int card = NSK_INFO_CARD(info);
+    const double pc = block_hub_potentials(g, lut, hd, g.val, ws, fs);
+    if ((threadIdx.x >> 6) != 0) return;
+    const uint2 r = inf_words(k0, k1, (uint32_t)p, s0, s1);
+    const int nv = hub_draw(pc, card, u53(r.x, r.y));
+    if ((threadIdx.x & 63) == 0) {
+        g.val[p] = (VT)nv;
+        if (!burnin) {
+            const int base = g.p_cnt[p];
+            if (card == 2) g.cnt[base] += nv;
+            else g.cnt[base + nv] += 1;
+        }
+    }
+}
+
+template <typename VT, int MAXC>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
+                                                        int tile0, int ntiles, int ngroups, int group0, int gblocks,
+                                                        int hb, int he, int hblocks, int hub0, int nbh, int bh0,
+                                                        const uint32_t *rest_list, int nrest,
+                                                        int sample_evidence, int burnin,
+                                                        uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+    __shared__ __attribute__((aligned(16))) double ws[NSK_EP_LIST * 256];
+    __shared__ __attribute__((aligned(16))) uint16_t fs[NSK_EP_LIST * 256];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
+    load_gen_lut(lut);
+    // blocks [0, nbh): one long-list hub each; [nbh, hblocks): one wave per hub position; then the
+    // resident group blocks; then the colour's rest tiles
+    if ((int)blockIdx.x < nbh) {
+#ifndef NSK_ABL_NOHUB
+        const int hp = (int)__builtin_amdgcn_readfirstlane(g.bighub_pos[bh0 + (int)blockIdx.x]);
+        const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + hub0 + (hp - hb));
+        const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
+        block_hub_update(g, lut, hp, hd, ws, fs, sample_evidence, burnin, k0, k1, s0, s1);
+#endif
+        return;
+    }
+    if ((int)blockIdx.x < hblocks) {                      // hub blocks: as in k_gibbs_general
+        const int hp = hb + (int)((blockIdx.x - nbh) * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+#ifndef NSK_ABL_NOHUB
+        if (hp < he && !*(const NSK_SCALAR uint32_t *)((const uint32_t *)(g.hub_desc + hub0 + (hp - hb)) + 3)) {
+            const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + hub0 + (hp - hb));
+            const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
+#ifdef NSK_ABL_TIMING
+            const unsigned long long hub_t0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (hd.y) heavy_update_ep(g, lut, hp, hd, sample_evidence, burnin, k0, k1, s0, s1);
+            else heavy_update(g, hp, sample_evidence, burnin, k0, k1, s0, s1);
+#ifdef NSK_ABL_TIMING
+            if ((threadIdx.x & 63) == 0) {
+                const int slot = 60000 + ((hub0 + hp - hb) & 4095);
+                nsk_dbg[4 * slot] = hub_t0; nsk_dbg[4 * slot + 1] = hub_t0; nsk_dbg[4 * slot + 2] = __builtin_amdgcn_s_memtime();
+                nsk_dbg[4 * slot + 3] = 1000ull + hd.y + ((unsigned long long)(g.slot_off[g.p_slot[hp] + 1] - g.slot_off[g.p_slot[hp]]) << 32);
+            }
+#endif
+        }
+#endif
+        return;
+    }
+    if ((int)blockIdx.x >= hblocks + gblocks) {           // the colour's uniform / shape tiles outside segments
+        const int i = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - hblocks - gblocks) * (NSK_BLOCK / 64) +
+                                                     (int)(threadIdx.x >> 6));
+        if (i < nrest)
+            fast_tile_update(g, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(rest_list[i]),
+                             sample_evidence, burnin, k0, k1, s0, s1);
+        return;
+    }
+    const EpWalk wk = ep_walk(ngroups, hblocks, gblocks);
+    for (int gi = wk.gi; gi < wk.gend; gi += wk.step) {
+        const NSK_SCALAR uint32_t *gdp = (const NSK_SCALAR uint32_t *)(g.ep_desc + group0 + gi);
+        const uint32_t gsub = gdp[0], grows0 = gdp[1], gmax = gdp[2], grows1 = gdp[3];
+        const int ne = (int)(gmax & 255u);
+#ifdef NSK_ABL_TIMING
+        const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+        unsigned long long dbg_t1 = dbg_t0;
+#endif
+        // this lane's variable (phase 2): requested now, needed after the entries
+        const int tile = tile0 + 4 * gi + (int)(threadIdx.x >> 6);
+        const bool tile_ok = tile < tile0 + ntiles;                       // wave-uniform
+        const int p = pbegin + tile * 64 + (int)(threadIdx.x & 63);
+        const bool valid = tile_ok && p < pend && g.p_vid[p] >= 0;
+        const uint32_t info = valid ? g.p_info[p] : (2u << 9);
+        const uint32_t tdw = tile_ok ? *(const NSK_SCALAR uint32_t *)((const uint32_t *)(g.tiles + (wb_base + tile)) + 3) : 0u;
+        const int maxcard = (int)((tdw >> 12) & 15u);
+        GenPot<MAXC> pot;
+        pot.clear();
+        uint32_t sub = gsub;
+        for (int pass = 0; pass * NSK_EP_LIST < ne; pass++) {
+            const uint32_t rowsw = pass ? grows1 : grows0;
+            __syncthreads();                               // (the previous sums have been read)
+            for (int i = (int)threadIdx.x; i < NSK_EP_LIST * 128; i += NSK_BLOCK)      // slots no entry writes:
+                ((uint32_t *)fs)[i] = 14u | (14u << 16);                                   // owned by no candidate
+            __syncthreads();
+#ifndef NSK_ABL_EPNOP1
+            ep_pass<VT, false, true, true, true>(g, g.val, g.val, sub, rowsw,
+                [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &, double w) {
+                    int cstar, A, B;
+                    a.close(d1, lut, cstar, A, B);
+                    const uint32_t ks = (d1 >> 14) & 15u;
+                    if (ks != 14u) {
+                        const uint32_t slot = NSK_EP_SLOT(w0, d1);
+                        ws[slot] = w;
+                        fs[slot] = (uint16_t)(ks | (ep_facts(cstar, A, B) << 4));
+                    }
+                });
+#endif
+#ifdef NSK_ABL_TIMING
+            if (pass == 0) dbg_t1 = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads();
+#ifndef NSK_ABL_EPNOP2
+            const int nacc = min(NSK_EP_LIST, ne - pass * NSK_EP_LIST);
+            if (tile_ok)
+                for (int o = 0; o < nacc; o++) {
+                    const uint32_t f = fs[o * 256 + (int)threadIdx.x];
+                    const double w = ws[o * 256 + (int)threadIdx.x];
+                    pot.add_ks(maxcard, (int)(f & 15u), w, (int)((f >> 4) & 15u), (int)((f >> 8) & 3u) - 1, (int)((f >> 10) & 3u) - 1);
+                }
+#endif
+            sub += (uint32_t)ep_pass_subrows(rowsw);
+        }
+        const int ev = NSK_INFO_EV(info);
+        if (valid && (ev == 0 || sample_evidence)) {
+            const int card = NSK_INFO_CARD(info);
+#ifdef NSK_ABL_NODRAW
+            const int nv = pot.p[0] > pot.p[1] ? 0 : 1;
+#else
+            const uint2 rr = inf_words(k0, k1, (uint32_t)p, s0, s1);
+            const int nv = pot.draw(maxcard, card, u53(rr.x, rr.y));
+#endif
+            g.val[p] = (VT)nv;
+            if (!burnin) {
+                if (card == 2) g.cnt_pos[p] = (uint8_t)(g.cnt_pos[p] + nv);
+                else g.cnt[g.p_cnt[p] + nv] += 1;
+            }
+        }
+#ifdef NSK_ABL_TIMING
+        if (threadIdx.x == 0) {          // per group: {start, first pass's entries done (wave 0), end, entries}
+            const int slot = gi & 32767;
+            nsk_dbg[4 * slot] = dbg_t0; nsk_dbg[4 * slot + 1] = dbg_t1;
+            nsk_dbg[4 * slot + 2] = __builtin_amdgcn_s_memtime() + (unsigned long long)(pot.p[0] == 12345.678 ? 1 : 0);
+            nsk_dbg[4 * slot + 3] = (unsigned long long)ne;
+        }
+#endif
+    }
 }
 
 // Homogeneous segments: runs of consecutive uniform tiles with one program, slot count, kind and

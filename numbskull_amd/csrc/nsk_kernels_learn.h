@@ -239,8 +239,7 @@ __device__ __forceinline__ void learn_heavy_variable_ep(const DevGraph<VT> &g, c
         HubEntry ef, ee;
         hub_entry(g, lut, base, rows, rr, M, g.val, false, ef);
         hub_entry(g, lut, base, rows, rr, M, g.val_evid, false, ee);
-        const int ks = (int)((ef.d1 >> 14) & 15u);
-        const bool mine = ks == 15 || ks == evidence || ks == proposal;
+        const bool mine = entry_visited(ef.d1, evidence, proposal);
         const long long diff = (long long)(proposal == ef.cstar ? ef.A : ef.B) -
                                (long long)(evidence == ee.cstar ? ee.A : ee.B);
         const bool have = rr * 64 + lane < n && mine && !g.w_fixed[ef.wid];                        // 100-101
@@ -254,6 +253,7 @@ __device__ __forceinline__ void learn_hub(const DevGraph<VT> &g, const GradSink 
                                           int hubdesc, const LearnParams &lp) {
     const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + hubdesc);
     const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
+    if (hd.w) return;                                      // a long list: a whole workgroup's (block_hub_learn)
     if (hd.y) learn_heavy_variable_ep<VT>(g, sk, lut, p, hd, lp);
     else learn_heavy_variable<VT>(g, sk, p, lp);
 }
@@ -574,8 +574,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
     if (__ballot(part) == 0) return;
     if (saved) {
         general_walk_ids(sp, len, Mslots, [&](int e, uint32_t wid, uint32_t d1) {
-            const int ks = (int)((d1 >> 14) & 15u);
-            const bool mine = ks == 15 || ks == evidence || ks == proposal;
+            const bool mine = entry_visited(d1, evidence, proposal);
             const uint32_t fx = facts[e * 64 + lane];
             const int cf = (int)(fx & 15u), Af = (int)((fx >> 4) & 3u) - 1, Bf = (int)((fx >> 6) & 3u) - 1;
             const int ce = (int)((fx >> 8) & 15u), Ae = (int)((fx >> 12) & 3u) - 1, Be = (int)((fx >> 14) & 3u) - 1;
@@ -591,8 +590,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
     }
     general_walk<VT, true, 2, false>(g, g.val, g.val_evid, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr,
                            [&](uint32_t wid, double, uint32_t d1, const GenChain &a, const GenChain &b) {
-                               const int ks = (int)((d1 >> 14) & 15u);
-                               const bool mine = ks == 15 || ks == evidence || ks == proposal;
+                               const bool mine = entry_visited(d1, evidence, proposal);
                                int cf, Af, Bf, ce, Ae, Be;
                                a.close(d1, lut, cf, Af, Bf);
                                b.close(d1, lut, ce, Ae, Be);
@@ -1001,6 +999,200 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_general(DevGraph<VT> g, int
     const int r1 = min(nrest, (wave0 + 1) * per);
     for (int i = wave0 * per; i < r1; i++)
         learn_rest_tile<VT>(g, sk, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(rest_list[i]), lp);
+    close_sink<SMALLW>(g, sk);
+}
+
+
+// A long-list hub in the learning sweep, by a whole workgroup (block_hub_potentials): both chains'
+// potentials with the ordered sums in wave 0, the draws, then the gradient pass over the entries
+// spread over the four waves (as learn_heavy_variable_ep does with one).
+template <typename VT>
+__device__ __forceinline__ void block_hub_learn(const DevGraph<VT> &g, const GradSink &sk, const uint8_t *lut, int p,
+                                                const uint4 hd, double *ws, uint16_t *fs, uint16_t *sel,
+                                                const LearnParams &lp) {
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    if (g.p_vid[p] < 0) return;                                                    // (block-uniform)
+    const uint32_t info = g.p_info[p];
+    const int ev = NSK_INFO_EV(info), card = NSK_INFO_CARD(info);
+    const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
+    double pce = 0.0;
+    if (ev != 1) pce = block_hub_potentials(g, lut, hd, g.val_evid, ws, fs);         // 54-58
+    const double pcf = block_hub_potentials(g, lut, hd, g.val, ws, fs);              // 66-70
+    if (wave == 0) {
+        const int evidence = ev != 1 ? hub_draw(pce, card, u53(r.z, r.w)) : (int)g.p_init[p];   // 61-62
+        const int proposal = hub_draw(pcf, card, u53(r.x, r.y));
+        if (lane == 0) {
+            g.val_evid[p] = (VT)evidence; g.val[p] = (VT)proposal;
+            sel[0] = (uint16_t)evidence; sel[1] = (uint16_t)proposal;
+        }
+    }
+    __syncthreads();
+    if (!(lp.learn_non_evidence || ev == 1)) return;                               // 71-72
+    const int evidence = (int)(int16_t)sel[0], proposal = (int)(int16_t)sel[1];
+    bool truncate = false;
+    if (lp.regularization == 1) {                                                  // 90
+        const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
+        truncate = u53(t.x, t.y) < lp.inv_trunc;
+    }
+    const int n = (int)hd.y, M = (int)(hd.z & 0xFFu), rows = 2 + M;
+    const uint32_t *base = g.hub_adj + hd.x;
+    for (int rr = wave; rr * 64 < n; rr += NSK_BLOCK / 64) {
+        HubEntry ef, ee;
+        hub_entry(g, lut, base, rows, rr, M, g.val, false, ef);
+        hub_entry(g, lut, base, rows, rr, M, g.val_evid, false, ee);
+        const bool mine = entry_visited(ef.d1, evidence, proposal);
+        const long long diff = (long long)(proposal == ef.cstar ? ef.A : ef.B) -
+                               (long long)(evidence == ee.cstar ? ee.A : ee.B);
+        const bool have = rr * 64 + lane < n && mine && !g.w_fixed[ef.wid];                        // 100-101
+        accumulate_gradient(sk, have, (int)ef.wid, diff * 4294967296ll, truncate);
+    }
+}
+
+// Learning over the entry-parallel groups of a colour class (k_gibbs_ep's layout, passes and phases):
+//   1. one lane per list entry, BOTH chains: (weight, owner, free-chain facts, evidence-chain facts)
+//      into the LDS slot [position in the list][variable];
+//   2. one lane per variable: free-chain and evidence-chain potentials in list order -> proposal and
+//      evidence (learning.py:54-70), stores, and (evidence, proposal, takes part, truncation coin)
+//      into LDS;
+//   3. one lane per list entry again: the entry's gradient value(proposal | free chain) -
+//      value(evidence | evidence chain) from the saved facts, for the entries sample_and_sgd visits
+//      (entry_visited), into the wave-aggregated accumulators.
+// A group with more than 8 entries per variable takes two passes of (1, 2); phase 3 then runs over the
+// second pass's entries (their facts are in LDS) and, after redoing phase 1 for them, over the first's.
+// Dynamic LDS: the SMALLW accumulators only.
+template <typename VT, bool SMALLW, int MAXC>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
+                                                        int tile0, int ntiles, int ngroups, int group0, int gblocks,
+                                                        int hb, int he, int hblocks, int nbh, int bh0,
+                                                        const uint32_t *rest_list, int nrest, LearnParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) double ws[NSK_EP_LIST * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t fs[NSK_EP_LIST * 256];
+    __shared__ uint16_t sel[256];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
+    load_gen_lut(lut);
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    if ((int)blockIdx.x < nbh) {                          // one long-list hub per block
+        const int hp = (int)__builtin_amdgcn_readfirstlane(g.bighub_pos[bh0 + (int)blockIdx.x]);
+        const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + lp.hub0 + (hp - hb));
+        const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
+        block_hub_learn<VT>(g, sk, lut, hp, hd, ws, (uint16_t *)fs, sel, lp);
+        close_sink<SMALLW>(g, sk);
+        return;
+    }
+    if ((int)blockIdx.x < hblocks) {                      // hub blocks: one wave per hub position, strided
+        const int hw0 = (int)((blockIdx.x - nbh) * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
+        for (int hp = hb + hw0; hp < he; hp += (hblocks - nbh) * (NSK_BLOCK / 64)) learn_hub<VT>(g, sk, lut, hp, lp.hub0 + (hp - hb), lp);
+        close_sink<SMALLW>(g, sk);
+        return;
+    }
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x - hblocks) * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
+    const int nwaves = gblocks * (NSK_BLOCK / 64);
+    // phase 1 of one pass: both chains' facts and the weight into the slots
+    auto entries = [&](uint32_t sub, uint32_t rowsw) {
+        for (int i = (int)threadIdx.x; i < NSK_EP_LIST * 256; i += NSK_BLOCK) fs[i] = 14u;      // owned by no candidate
+        __syncthreads();
+        ep_pass<VT, true, true, false, true>(g, g.val, g.val_evid, sub, rowsw,
+            [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &b, double w) {
+                int cstar, A, B;
+                a.close(d1, lut, cstar, A, B);
+                uint32_t fx = ep_facts(cstar, A, B) << 4;
+                b.close(d1, lut, cstar, A, B);
+                fx |= ep_facts(cstar, A, B) << 12;
+                const uint32_t ks = (d1 >> 14) & 15u;
+                if (ks != 14u) {
+                    const uint32_t slot = NSK_EP_SLOT(w0, d1);
+                    ws[slot] = w;
+                    fs[slot] = ks | fx;
+                }
+            });
+        __syncthreads();
+    };
+    // phase 3 of one pass: gradients of its entries from the facts in the slots
+    auto gradients = [&](uint32_t sub, uint32_t rowsw) {
+        ep_pass<VT, false, false, false, false>(g, g.val, g.val, sub, rowsw,
+            [&](uint32_t w0, uint32_t d1, const GenChain &, const GenChain &, double) {
+                const uint32_t sv = sel[(d1 >> 23) & 255u];
+                const int evidence = (int)(sv & 15u), proposal = (int)((sv >> 4) & 15u);
+                const uint32_t f = fs[NSK_EP_SLOT(w0, d1)];
+                const int cf = (int)((f >> 4) & 15u), Af = (int)((f >> 8) & 3u) - 1, Bf = (int)((f >> 10) & 3u) - 1;
+                const int ce = (int)((f >> 12) & 15u), Ae = (int)((f >> 16) & 3u) - 1, Be = (int)((f >> 18) & 3u) - 1;
+                const long long diff = (long long)(proposal == cf ? Af : Bf) - (long long)(evidence == ce ? Ae : Be);
+                const bool have = (sv & 256u) && ((d1 >> 14) & 15u) != 14u && entry_visited(d1, evidence, proposal) &&
+                                  !(d1 >> 31);                                              // 100-101
+                accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * 4294967296ll, (sv & 512u) != 0u);
+            });
+    };
+    if ((int)blockIdx.x < hblocks + gblocks) {
+        const EpWalk wk = ep_walk(ngroups, hblocks, gblocks);
+        for (int gi = wk.gi; gi < wk.gend; gi += wk.step) {
+            const NSK_SCALAR uint32_t *gdp = (const NSK_SCALAR uint32_t *)(g.ep_desc + group0 + gi);
+            const uint32_t gsub = gdp[0], grows0 = gdp[1], gmax = gdp[2], grows1 = gdp[3];
+            const int ne = (int)(gmax & 255u);
+            const int tile = tile0 + 4 * gi + (int)(threadIdx.x >> 6);
+            const bool tile_ok = tile < tile0 + ntiles;                           // wave-uniform
+            const int p = pbegin + tile * 64 + (int)(threadIdx.x & 63);
+            const bool valid = tile_ok && p < pend && g.p_vid[p] >= 0;
+            const uint32_t info = valid ? g.p_info[p] : (2u << 9);
+            const uint32_t tdw = tile_ok ? *(const NSK_SCALAR uint32_t *)((const uint32_t *)(g.tiles + (wb_base + tile)) + 3) : 0u;
+            const int maxcard = (int)((tdw >> 12) & 15u);
+            const int ev = NSK_INFO_EV(info), card = NSK_INFO_CARD(info);
+            const bool need_evid = __ballot(valid && ev != 1) != 0;               // wave-uniform
+            GenPot<MAXC> pf, pe;
+            pf.clear(); pe.clear();
+            uint32_t sub = gsub;
+            const bool two = ne > NSK_EP_LIST;
+            for (int pass = 0; pass * NSK_EP_LIST < ne; pass++) {
+                const uint32_t rowsw = pass ? grows1 : grows0;
+                __syncthreads();                           // (the previous group / pass is done with the slots)
+                entries(sub, rowsw);
+                const int nacc = min(NSK_EP_LIST, ne - pass * NSK_EP_LIST);
+                if (tile_ok)
+                    for (int o = 0; o < nacc; o++) {
+                        const uint32_t f = fs[o * 256 + (int)threadIdx.x];
+                        const double w = ws[o * 256 + (int)threadIdx.x];
+                        pf.add_ks(maxcard, (int)(f & 15u), w, (int)((f >> 4) & 15u), (int)((f >> 8) & 3u) - 1, (int)((f >> 10) & 3u) - 1);
+                        if (need_evid)
+                            pe.add_ks(maxcard, (int)(f & 15u), w, (int)((f >> 12) & 15u), (int)((f >> 16) & 3u) - 1, (int)((f >> 18) & 3u) - 1);
+                    }
+                if (pass == 0 && two) sub += (uint32_t)ep_pass_subrows(rowsw);
+            }
+            uint32_t mysel = 0;
+            if (tile_ok) {
+                const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
+                const int proposal = pf.draw(maxcard, card, u53(r.x, r.y));                    // 66-70
+                int evidence = valid ? (int)g.p_init[p] : 0;                                   // 61-62
+                if (need_evid && ev != 1) evidence = pe.draw(maxcard, card, u53(r.z, r.w));    // 54-58
+                if (valid) {
+                    g.val_evid[p] = (VT)evidence;
+                    g.val[p] = (VT)proposal;
+                }
+                const bool part = valid && (lp.learn_non_evidence || ev == 1);                 // 71-72
+                bool truncate = false;
+                if (lp.regularization == 1) {                                                  // 90
+                    const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
+                    truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
+                }
+                mysel = ((uint32_t)evidence & 15u) | (((uint32_t)proposal & 15u) << 4) | (part ? 256u : 0u) | (truncate ? 512u : 0u);
+            }
+            sel[threadIdx.x] = (uint16_t)mysel;
+            __syncthreads();
+            gradients(sub, two ? grows1 : grows0);         // the last pass's facts are in the slots
+            if (two) {                                     // the first pass's entries: their facts again, then their gradients
+                __syncthreads();
+                entries(gsub, grows0);
+                gradients(gsub, grows0);
+            }
+        }
+    }
+    // then the colour's uniform / shape tiles outside segment launches (a contiguous run per wave of the
+    // group and rest blocks)
+    const int nw_all = (int)((gridDim.x - hblocks) * (NSK_BLOCK / 64));
+    const int per = (nrest + nw_all - 1) / nw_all;
+    const int r1 = min(nrest, (wave0 + 1) * per);
+    for (int i = wave0 * per; i < r1; i++)
+        learn_rest_tile<VT>(g, sk, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(rest_list[i]), lp);
+    (void)nwaves;
     close_sink<SMALLW>(g, sk);
 }
 

@@ -77,7 +77,24 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             // as in inference: a class with categorical tiles walks all its general tiles in one
             // launch of the 8-candidate kernel on the main stream (+10 % over two concurrent launches)
             const bool one_lg = gtb > gt0;
-            if (gtb > gt0) {            // general tiles with categorical lanes
+            const bool ep = fe > fb && g->c.phase_ep[ph] && ntiles > gt0;
+            if (ep) {                   // entry-parallel groups: hubs, the general tiles and the rest tiles
+                const int ngroups = (int)(g->c.phase_ep_base[ph + 1] - g->c.phase_ep_base[ph]);
+                // resident grid: the static LDS (26.5 KB) + the SMALLW tables bound the workgroups per CU
+                const int per_cu = std::max(1, std::min(8, (int)((size_t)(160 << 10) / (27136 + shmem + 256))));
+                const int gblocks = 8 * ((std::min(256 * per_cu, ngroups) + 7) / 8);
+                const int nbh = (int)(g->c.phase_bighub_base[ph + 1] - g->c.phase_bighub_base[ph]);   // a block per long-list hub
+                const int hbl_ep = nbh + hbl;
+                const int grid = gblocks + hbl_ep;
+                hipStream_t st = general_aside ? cs.side(0) : g->stream;
+#define NSK_LEP(MAXC) k_learn_ep<VT, SMALLW, MAXC><<<dim3(grid), dim3(NSK_BLOCK), shmem, st>>>( \
+                    d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, ntiles - gt0, ngroups, (int)g->c.phase_ep_base[ph], gblocks, \
+                    fe, he, hbl_ep, nbh, (int)g->c.phase_bighub_base[ph], lrest, rest_in_general ? nlrest : 0, lp)
+                if (one_lg) NSK_LEP(8); else NSK_LEP(2);
+#undef NSK_LEP
+                g->launches++;
+            }
+            if (gtb > gt0 && !ep) {            // general tiles with categorical lanes
                 const int nt8 = one_lg ? ntiles - gt0 : gtb - gt0;
                 const int grid = 8 * ((std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (nt8 + 3) / 4) + 7) / 8) + hbl;   // whole rounds of XCDs
                 k_learn_general<VT, SMALLW, 8><<<dim3(grid), dim3(NSK_BLOCK), shmem, (one_lg && !general_aside) ? g->stream : cs.side(0)>>>(
@@ -85,7 +102,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                     (rest_in_general && one_lg) ? nlrest : 0, lp);
                 g->launches++;
             }
-            if (ntiles > gtb && !one_lg) {   // all-binary general tiles
+            if (ntiles > gtb && !one_lg && !ep) {   // all-binary general tiles
                 const int hb2 = gtb > gt0 ? 0 : hbl;        // no categorical launch: the hubs come here
                 const int grid = 8 * ((std::min(NSK_LEARN_GENERAL_BLOCKS / 2, (ntiles - gtb + 3) / 4) + 7) / 8) + hb2;
                 k_learn_general<VT, SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, general_aside ? cs.side(0) : g->stream>>>(

@@ -147,6 +147,10 @@ def _small_graphs(golden):
         "lr3000": (graphgen.mixed_lr_graph(3000, seed=5, nweights=40), True),
         # > 256 weights: gradients go through global atomics instead of per-block LDS tables
         "lr_manyw": (graphgen.mixed_lr_graph(3000, seed=6, nweights=1500), True),
+        # other members drawn from [v - 2, v + 2]: a fifth of them is the variable itself -- body
+        # member AND head of IMPLY_MLN / IMPLY_MLN_CAT, own edges with different dense_equal_to --
+        # the two-role entries of the general tiles (nsk_compile.cpp general_words)
+        "lr_selfdup": (graphgen.mixed_lr_graph(3000, seed=8, nweights=40, window=2), True),
         "pairs_manyw": (_pairs_many_weights(), False),
         # one weight per factor: tiles share a word layout but not weights (shape tiles)
         "boolw": (_boolw(), False),
@@ -289,7 +293,7 @@ def _big_cardinality_graph():
 
 GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
           "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat", "gencat_vid",
-          "gencat_bigw", "gencat_i32"]
+          "gencat_bigw", "gencat_i32", "lr_selfdup"]
 
 
 @pytest.mark.parametrize("name", GRAPHS)
@@ -319,7 +323,7 @@ def test_chromatic_inference_equals_oracle(golden, name, sample_evidence):
 
 @pytest.mark.parametrize("name", ["mixed", "lf", "pairs", "grid32", "lr3000", "lr_bigcard",
                                   "headquirk", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat",
-                                  "gencat_vid", "gencat_i32"])
+                                  "gencat_vid", "gencat_i32", "lr_selfdup"])
 @pytest.mark.parametrize("reg,trunc", [(0, 1), (1, 1), (1, 3), (2, 1)])
 @pytest.mark.parametrize("lne", [False, True])
 def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
@@ -452,6 +456,22 @@ def test_general_tiles_at_scale():
     for sweep in range(2, 5):
         assert og.gibbs_dev(order, ps, vv, wv, cnt, 9, sweep, True) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
+def test_self_duplicate_members_stay_on_the_tiles(golden):
+    """A variable that is body member and head of one of its own factors, or whose own edges carry
+    different dense_equal_to values, is a general-tile lane (two-role entries), not a wave-per-variable
+    straggler: on the window-2 LR graph a third of the variables are of that kind."""
+    g, hbv = _small_graphs(golden)["lr_selfdup"]
+    w, v, f, fm = g[0], g[1], g[2], g[3]
+    fac_of_edge = np.repeat(np.arange(len(f)), f["arity"])
+    head = fm["vid"][f["ftv_offset"] + f["arity"] - 1]
+    is_head_edge = np.arange(len(fm)) == (f["ftv_offset"] + f["arity"] - 1)[fac_of_edge]
+    selfdup = np.unique(fm["vid"][(fm["vid"] == head[fac_of_edge]) & ~is_head_edge])
+    assert len(selfdup) > 500
+    ns, fg = session(g, seed=1, head_by_vid=hbv)
+    info = fg.info()
+    assert info["ngeneric"] < 200, info            # (OR_CAT naming two of > 2 values stays generic)
 
 
 def test_fast_and_generic_paths_are_both_exercised(golden):
