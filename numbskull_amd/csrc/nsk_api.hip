@@ -202,7 +202,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
             if (c.phase_end[k] > c.phase_fast_end[k]) generic_needed = true;
         if (generic_needed || nsk::diag_env("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
     }
-    UP(w_fixed); UP(logtab); UP(adj); UP(adj16); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
+    UP(w_fixed); UP(logtab); UP(adj); UP(adj16); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes, nid = (size_t)c.nid;
@@ -223,6 +223,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &g->prog_w, 2 * c.tile_hdr.size()); if (rc) return rc;
     rc = dev_alloc(g, &g->adj_wt, (size_t)c.nwrows * 64); if (rc) return rc;
     rc = dev_alloc(g, &g->ztab, (size_t)c.nztab); if (rc) return rc;
+    rc = dev_alloc(g, &g->ep_wt, (size_t)(c.ep_wrow.empty() ? 0 : c.ep_wrow.back()) * 64); if (rc) return rc;
     rc = dev_alloc(g, &g->sink, 1024); if (rc) return rc;
     {
         std::vector<ZProgDev> zp(c.zprogs.size());
@@ -341,6 +342,10 @@ void nsk_refresh_prog_weights(nsk_graph *g, bool force) {
             g->tile_hdr, g->w, g->prog_w, n);
         nsk_refresh_ztab(g);
     }
+    const int neg = (int)g->c.ep_wrow.size() - 1;
+    if (neg > 0 && !g->adj_wt_skip)          // materialised weights of the entry-parallel groups (inference)
+        k_refresh_ep_weights<<<dim3((unsigned)neg), dim3(NSK_BLOCK), 0, g->stream>>>(
+            (const uint4 *)g->ep_desc, g->ep_adj, g->ep_wrow, g->w, g->ep_wt);
     const int nt = (int)(g->c.tiles.size() / 4) - 1;
     if (g->c.nwrows > 0 && nt > 0 && !g->adj_wt_skip)
         k_refresh_shape_weights<<<dim3((nt + 3) / 4), dim3(NSK_BLOCK), 0, g->stream>>>(

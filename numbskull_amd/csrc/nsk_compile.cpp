@@ -512,6 +512,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // longer lists go to the wave-per-variable kernel: a tile is walked by one wave, so its longest
     // lane sets a serial chain of memory round trips and the longest tile the kernel's run time
     const int64_t gen_block = diag_env("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(diag_env("NSK_GEN_BLOCK"))) : 262144;
+    const int64_t ep_block = diag_env("NSK_EP_BLOCK") ? std::max<int64_t>(64, atoll(diag_env("NSK_EP_BLOCK"))) : 1024;
     const int64_t gen_max_entries = diag_env("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(diag_env("NSK_GEN_MAX_ENTRIES")))) : 16;
     // (hub = true lifts the per-lane size caps: the entry-parallel hub kernels take up to 256 entries)
     //
@@ -846,7 +847,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 // run of tiles, so its L2 then sees one slice of the value array instead of all of
                 // it), largest layouts first inside a block
                 const int64_t catv = d->variable[v].cardinality > 2 ? 0 : 1;
-                order[c.color[v]].push_back({(catv << 50) | ((v / gen_block) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
+                // (entry-parallel groups carry no padding to the widest lane, so their colours are cut
+                // into small id blocks: a group's member values then share cache lines)
+                // into small id blocks: a group's member values then share cache lines), with the
+                // variables of more than 8 entries -- two LDS passes per group -- in front of the others
+                const bool epk = c.phase_ep[c.color[v]] != 0;
+                const int64_t gb = epk ? ep_block : gen_block;
+                const int64_t small = (epk && ne <= 8) ? 1 : 0;
+                order[c.color[v]].push_back({(small << 51) | (catv << 50) | ((v / gb) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
             }
             {
                 std::vector<std::thread> sorters;             // one colour per thread (few colours only)
@@ -1290,6 +1298,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     {
         const int64_t ngroups = c.phase_ep_base[ncolors];
         c.ep_desc.assign((size_t)ngroups * 4 + 4, 0u);
+        c.ep_wrow.assign((size_t)ngroups + 1, 0u);
         std::vector<int32_t> group_colour((size_t)ngroups);
         for (int32_t k = 0; k < ncolors; k++)
             for (int64_t gi = c.phase_ep_base[k]; gi < c.phase_ep_base[k + 1]; gi++) group_colour[gi] = k;
@@ -1327,8 +1336,16 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 }
                 gd[2] = emax | (maxcard << 8);
                 subrows[gi + 1] = sr;
+                uint32_t nrows = 0;
+                for (uint32_t cl = 0; cl < 8; cl++) nrows += (cnt[cl] + 63) / 64;
+                c.ep_wrow[gi + 1] = nrows;
             }
         });
+        for (int64_t gi = 0; gi < ngroups; gi++) {
+            const uint64_t next = (uint64_t)c.ep_wrow[gi] + c.ep_wrow[gi + 1];
+            if (next >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
+            c.ep_wrow[gi + 1] = (uint32_t)next;
+        }
         for (int64_t gi = 0; gi < ngroups; gi++) subrows[gi + 1] += subrows[gi];
         if (subrows[ngroups] * 64 >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
         c.ep_adj.assign((size_t)subrows[ngroups] * 64 + 64, 0u);
@@ -1765,7 +1782,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     {
         std::vector<int32_t> seen(nvar, -1);
         for (int32_t k = 0; k < ncolors; k++) {
-            double words = 0, wrows = 0;
+            double words = 0, wrows = 0, ep_wt_bytes = 0;
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
                 const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
                 const uint32_t kind = td[2] == 0xFFFFFFFFu ? 8u : (td[3] >> 8) & 7u;
@@ -1787,9 +1804,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         rows += r;
                     }
                     words += sr * 256;
-                    if (big_w) wrows += rows * 64 * 8;                 // one gathered weight per entry
+                    ep_wt_bytes += rows * 64 * 8;                      // inference: the materialised weight of every entry
+                    if (big_w) wrows += rows * 64 * 8;                 // learning: one gathered weight per entry
                 }
-            lay_inf += words + wrows;
+            lay_inf += words + (c.phase_ep[k] ? ep_wt_bytes : wrows);
             lay_learn += words + 3 * wrows;            // weight gathers + one 16-byte atomic per visit
             int64_t distinct = 0, nfastpos = 0, ncatpos = 0;
             for (int64_t p = c.phase_start[k]; p < c.phase_fast_end[k]; p++) {

@@ -115,7 +115,10 @@ struct Compiled {
     // sub-row per member slot.  No padding to the widest lane of a tile.
     // ep_desc[group] = {first sub-row, rows of classes 0-3 (8 bits each), most entries of a variable |
     // largest cardinality << 8, rows of classes 4-7}.
-    std::vector<uint32_t> ep_desc, ep_adj;
+    // ep_wrow[group] = first row of the group in the materialised weight rows (one double per entry
+    // slot, row-major: the inference kernels read an entry's weight next to its words; refreshed
+    // whenever weights change); ep_wrow[ngroups] = rows in total
+    std::vector<uint32_t> ep_desc, ep_adj, ep_wrow;
     std::vector<int64_t> phase_ep_base;        // [ncolors+1] first group of each colour
     std::vector<uint8_t> phase_ep;             // [ncolors] 1: the colour's general tiles are laid out as groups
     std::vector<int32_t> phase_ep_emax;        // [ncolors] most entries of one of its variables

@@ -230,6 +230,8 @@ struct DevGraph {
     const uint32_t *bighub_pos; // positions of the hubs a whole workgroup evaluates (hub_desc[..].w = 1)
     const uint4 *ep_desc;       // entry-parallel groups of general tiles (nsk_compile.h ep_desc): one per
     const uint32_t *ep_adj;     //  256 positions; ep_adj: sub-rows of 64 words
+    const uint32_t *ep_wrow;    // [groups + 1] first row of a group in ep_wt
+    double *ep_wt;              // materialised weights of the groups' entries: row r, lane i at ep_wt[64 r + i]
     const int32_t *iid_of_vid;  // variable id -> internal id (position; ghosts after the positions): the
                                 //  literal head lookup of the generic path needs it (uploaded only then)
     int32_t nvar;

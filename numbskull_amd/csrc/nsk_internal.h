@@ -59,7 +59,8 @@ struct nsk_graph {
     uint8_t *sink = nullptr;            // scratch line for padding lanes' stores
     uint32_t *hub_desc = nullptr, *hub_adj = nullptr;   // entry-parallel hub streams
     uint32_t *ep_desc = nullptr, *ep_adj = nullptr;     // entry-parallel groups of general tiles
-    uint32_t *bighub_pos = nullptr;
+    uint32_t *bighub_pos = nullptr, *ep_wrow = nullptr;
+    double *ep_wt = nullptr;
     nsk::ZProgDev *zprogs = nullptr;
     bool values_regular = true;         // every value on the device lies in [0, cardinality): the
                                         // table kernels index with the neighbours' low bits
@@ -128,6 +129,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.sink = g->sink;
     d.hub_desc = (const uint4 *)g->hub_desc; d.hub_adj = g->hub_adj;
     d.ep_desc = (const uint4 *)g->ep_desc; d.ep_adj = g->ep_adj; d.bighub_pos = g->bighub_pos;
+    d.ep_wrow = g->ep_wrow; d.ep_wt = g->ep_wt;
     d.adj16 = (const uint2 *)g->adj16;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;

@@ -1000,7 +1000,8 @@ __device__ __forceinline__ int ep_pass_rows(uint32_t rowsw) {
 
 // words of row r (wave-uniform) of a pass; M = its member count
 template <bool NT, bool MEMBERS>
-__device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, uint32_t rowsw, int r, EpRow &q, int &M) {
+__device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, uint32_t rowsw, int r, EpRow &q, int &M,
+                                            const double *wt, double &w) {
     const int n0 = (int)(rowsw & 255u), n1 = (int)((rowsw >> 8) & 255u), n2 = (int)((rowsw >> 16) & 255u);
     const int c1 = n0 + n1, c2 = c1 + n2;
     int sub;
@@ -1012,6 +1013,7 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
     const uint32_t *row = adj + (size_t)(sub0 + (uint32_t)sub) * 64;
     const nsk_u32x2 h = NT ? __builtin_nontemporal_load((const nsk_u32x2 *)row + lane) : *((const nsk_u32x2 *)row + lane);
     q.w0 = h.x; q.d1 = h.y;
+    if (wt) w = __builtin_nontemporal_load(wt + (size_t)r * 64 + lane);     // the entry's materialised weight
     q.m[0] = NSK_GEN_NULL; q.m[1] = NSK_GEN_NULL; q.m[2] = NSK_GEN_NULL;
     if (MEMBERS) {
 #pragma unroll
@@ -1023,52 +1025,103 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
 // The rows of one pass that belong to this wave (dealt round-robin over the four waves):
 // fn(weight word, descriptor, chain over va, chain over vb, weight).  MEMBERS = false: only the
 // (weight word, descriptor) pairs are read (the gradient pass of learning).
-template <typename VT, bool TWO, bool WANT_W, bool NT, bool MEMBERS, typename FN>
+// WMODE: the entry's weight -- 0 not needed, 1 gathered from g.w (learning: weights change with every
+// class), 2 read from the materialised rows `wt` (first row of this pass; inference).
+// A wave takes U of its rows per step: their words were requested during the previous step,
+// their gathers are issued together and waited for once.
+// (measured on the 5M LR graph, per class: inference U = 1 58.5 us, 2 63.8, 3 64.9 -- the single-chain walk
+// keeps 6 waves per SIMD; learning, whose rows carry two chains, U = 1 159.8, 2 149.4, 3 164.2)
+template <typename VT, bool TWO, int WMODE, bool NT, bool MEMBERS, int U, typename FN>
 __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, const VT *vb, uint32_t sub0,
-                                        uint32_t rowsw, FN &&fn) {
+                                        uint32_t rowsw, const double *wt, FN &&fn) {
     const int wave = (int)(threadIdx.x >> 6);
     const int total = ep_pass_rows(rowsw);
     if (wave >= total) return;
-    EpRow cur, nxt;
-    int Mc, Mn = 0;
-    ep_load_row<NT, MEMBERS>(g.ep_adj, sub0, rowsw, wave, cur, Mc);
-    for (int r = wave; r < total; r += 4) {
-        if (r + 4 < total) ep_load_row<NT, MEMBERS>(g.ep_adj, sub0, rowsw, r + 4, nxt, Mn);
+    EpRow cur[U], nxt[U];
+    int Mc[U], Mn[U];
+    double wc[U], wn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        Mc[u] = 0; Mn[u] = 0; wc[u] = 0.0; wn[u] = 0.0;
+        if (wave + 4 * u < total) ep_load_row<NT, MEMBERS>(g.ep_adj, sub0, rowsw, wave + 4 * u, cur[u], Mc[u], WMODE == 2 ? wt : nullptr, wc[u]);
+    }
+    for (int r = wave; r < total; r += 4 * U) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (r + 4 * (U + u) < total)
+                ep_load_row<NT, MEMBERS>(g.ep_adj, sub0, rowsw, r + 4 * (U + u), nxt[u], Mn[u], WMODE == 2 ? wt : nullptr, wn[u]);
+        double w[U];
+        int xa[U][3], xb[U][3];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            w[u] = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; m++) { xa[u][m] = 0; xb[u][m] = 0; }
+            if (r + 4 * u >= total) continue;                       // wave-uniform
 #ifdef NSK_ABL_EPNOW
-        const double w = WANT_W ? __longlong_as_double(0x3FB0000000000000ll | (long long)cur.w0) : 0.0;
+            w[u] = WMODE ? __longlong_as_double(0x3FB0000000000000ll | (long long)cur[u].w0) : 0.0;
 #else
-        const double w = WANT_W ? g.w[NSK_EP_WID(cur.w0)] : 0.0;
+            w[u] = WMODE == 1 ? g.w[NSK_EP_WID(cur[u].w0)] : (WMODE == 2 ? wc[u] : 0.0);
 #endif
-        int xa[3] = {0, 0, 0}, xb[3] = {0, 0, 0};
-        if (MEMBERS) {
+            if (MEMBERS) {
 #pragma unroll
-            for (int m = 0; m < 3; m++)
-                if (Mc > m) {                                       // wave-uniform
-                    const uint32_t id = cur.m[m] & NSK_GEN_NULL;
-                    const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
+                for (int m = 0; m < 3; m++)
+                    if (Mc[u] > m) {                                // wave-uniform
+                        const uint32_t id = cur[u].m[m] & NSK_GEN_NULL;
+                        const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
 #ifdef NSK_ABL_EPNOVAL
-                    xa[m] = (int)(at & 1u);
-                    if (TWO) xb[m] = (int)((at >> 1) & 1u);
+                        xa[u][m] = (int)(at & 1u);
+                        if (TWO) xb[u][m] = (int)((at >> 1) & 1u);
 #else
-                    xa[m] = (int)va[at];
-                    if (TWO) xb[m] = (int)vb[at];
+                        xa[u][m] = (int)va[at];
+                        if (TWO) xb[u][m] = (int)vb[at];
 #endif
-                }
+                    }
+            }
         }
-        const bool cat = (cur.d1 & 15u) >= 6u;
-        GenChain a, b;
-        a.open();
-        if (TWO) b.open();
-        if (MEMBERS) {
 #pragma unroll
-            for (int m = 0; m < 3; m++)
-                if (Mc > m) {
-                    a.member(m == 0, cat, cur.m[m], xa[m]);
-                    if (TWO) b.member(m == 0, cat, cur.m[m], xb[m]);
-                }
+        for (int u = 0; u < U; u++) {
+            if (r + 4 * u >= total) continue;
+            const bool cat = (cur[u].d1 & 15u) >= 6u;
+            GenChain a, b;
+            a.open();
+            if (TWO) b.open();
+            if (MEMBERS) {
+#pragma unroll
+                for (int m = 0; m < 3; m++)
+                    if (Mc[u] > m) {
+                        a.member(m == 0, cat, cur[u].m[m], xa[u][m]);
+                        if (TWO) b.member(m == 0, cat, cur[u].m[m], xb[u][m]);
+                    }
+            }
+            fn(cur[u].w0, cur[u].d1, a, b, w[u]);
         }
-        fn(cur.w0, cur.d1, a, b, w);
-        cur = nxt; Mc = Mn;
+#pragma unroll
+        for (int u = 0; u < U; u++) { cur[u] = nxt[u]; Mc[u] = Mn[u]; wc[u] = wn[u]; }
+    }
+}
+
+// ep_wt row <- the weights its entries name (run whenever weights may have changed, before an
+// inference call): one workgroup per group, its rows dealt to the waves
+static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_ep_weights(const uint4 *ep_desc, const uint32_t *ep_adj,
+                                                                  const uint32_t *ep_wrow, const double *w,
+                                                                  double *ep_wt) {
+    const uint4 gd = ep_desc[blockIdx.x];
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t sub = gd.x;
+    int row = (int)ep_wrow[blockIdx.x];
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t rowsw = pass ? gd.w : gd.y;
+        const int total = ep_pass_rows(rowsw);
+        for (int r = (int)(threadIdx.x >> 6); r < total; r += NSK_BLOCK / 64) {
+            EpRow q;
+            int M;
+            double unused = 0.0;
+            ep_load_row<false, false>(ep_adj, sub, rowsw, r, q, M, nullptr, unused);
+            ep_wt[(size_t)(row + r) * 64 + lane] = w[NSK_EP_WID(q.w0)];
+        }
+        sub += (uint32_t)ep_pass_subrows(rowsw);
+        row += total;
     }
 }
 
@@ -1078,27 +1131,29 @@ __device__ __forceinline__ uint32_t ep_facts(int cstar, int A, int B) {
     return ((uint32_t)cstar > 15u ? 15u : (uint32_t)cstar) | ((uint32_t)(A + 1) << 4) | ((uint32_t)(B + 1) << 6);
 }
 
-// the groups of a resident launch that this workgroup walks: XCD x (= blockIdx & 7, how the hardware
-// deals workgroups; for speed only) takes the x-th eighth of the groups
-struct EpWalk { int gi, gend, step; };
+// The groups of a resident launch that this workgroup walks.  Groups are dealt to the XCDs (XCD =
+// blockIdx & 7, how the hardware deals workgroups; for speed only) in chunks of 16 consecutive groups,
+// round-robin: neighbouring groups read the same value lines (one L2), and every XCD gets its share
+// of every region of the colour (the long-list groups come first).  `li` counts a workgroup's XCD-local
+// groups; ep_group() maps it to the group or -1.
+#define NSK_EP_CHUNK 16
+struct EpWalk { int li, lend, step, xcd; };
 __device__ __forceinline__ EpWalk ep_walk(int ngroups, int hblocks, int gblocks) {
     const int xcd = (int)(blockIdx.x & 7);
     const int firstb = hblocks + ((xcd - (hblocks & 7) + 8) & 7);        // first group block on this XCD
     const int nbx = firstb < hblocks + gblocks ? (hblocks + gblocks - 1 - firstb) / 8 + 1 : 0;
-    const int per8 = (ngroups + 7) >> 3;
     EpWalk wk;
-    wk.gi = xcd * per8 + (((int)blockIdx.x - firstb) >> 3);
-    wk.gend = min(ngroups, (xcd + 1) * per8);
+    wk.xcd = xcd;
+    wk.li = ((int)blockIdx.x - firstb) >> 3;
+    wk.lend = ((ngroups + 8 * NSK_EP_CHUNK - 1) / (8 * NSK_EP_CHUNK)) * NSK_EP_CHUNK;
     wk.step = nbx;
     return wk;
 }
+__device__ __forceinline__ int ep_group(const EpWalk &wk, int li, int ngroups) {
+    const int gi = ((li / NSK_EP_CHUNK) * 8 + wk.xcd) * NSK_EP_CHUNK + (li % NSK_EP_CHUNK);
+    return gi < ngroups ? gi : -1;
+}
 
-// A hub with a long list, evaluated by a whole workgroup: the four waves evaluate its entries 64 at a
-// time (hub_entry, as heavy_update_ep does) into LDS, 2048 entries per round, then wave 0 adds the
-// terms IN LIST ORDER -- lane c keeps candidate c's sum and every lane reads the same entry (an LDS
-// broadcast) -- the same float64 additions as potential() (inference.py:55-71).  One wave on such a
-// list is a chain of hundreds of dependent steps that outlasts the rest of the colour class.
-// fsz: bytes of one facts word (2: owner | facts << 4; 4: the learning kernels' two-chain word).
 template <typename VT>
 __device__ __forceinline__ double block_hub_potentials(const DevGraph<VT> &g, const uint8_t *lut, const uint4 hd,
                                                        const VT *val, double *ws, uint16_t *fs) {
@@ -1205,7 +1260,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(DevGraph<VT> g, int pbeg
         return;
     }
     const EpWalk wk = ep_walk(ngroups, hblocks, gblocks);
-    for (int gi = wk.gi; gi < wk.gend; gi += wk.step) {
+    for (int li = wk.li; li < wk.lend; li += wk.step) {
+        const int gi = ep_group(wk, li, ngroups);
+        if (gi < 0) continue;
         const NSK_SCALAR uint32_t *gdp = (const NSK_SCALAR uint32_t *)(g.ep_desc + group0 + gi);
         const uint32_t gsub = gdp[0], grows0 = gdp[1], gmax = gdp[2], grows1 = gdp[3];
         const int ne = (int)(gmax & 255u);
@@ -1223,7 +1280,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(DevGraph<VT> g, int pbeg
         const int maxcard = (int)((tdw >> 12) & 15u);
         GenPot<MAXC> pot;
         pot.clear();
-        uint32_t sub = gsub;
+        uint32_t sub = gsub, wrow = *(const NSK_SCALAR uint32_t *)(g.ep_wrow + group0 + gi);
         for (int pass = 0; pass * NSK_EP_LIST < ne; pass++) {
             const uint32_t rowsw = pass ? grows1 : grows0;
             __syncthreads();                               // (the previous sums have been read)
@@ -1231,7 +1288,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(DevGraph<VT> g, int pbeg
                 ((uint32_t *)fs)[i] = 14u | (14u << 16);                                   // owned by no candidate
             __syncthreads();
 #ifndef NSK_ABL_EPNOP1
-            ep_pass<VT, false, true, true, true>(g, g.val, g.val, sub, rowsw,
+            ep_pass<VT, false, 2, true, true, 1>(g, g.val, g.val, sub, rowsw, g.ep_wt + (size_t)wrow * 64,
                 [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &, double w) {
                     int cstar, A, B;
                     a.close(d1, lut, cstar, A, B);
@@ -1257,6 +1314,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(DevGraph<VT> g, int pbeg
                 }
 #endif
             sub += (uint32_t)ep_pass_subrows(rowsw);
+            wrow += (uint32_t)ep_pass_rows(rowsw);
         }
         const int ev = NSK_INFO_EV(info);
         if (valid && (ev == 0 || sample_evidence)) {

@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbeg
     auto entries = [&](uint32_t sub, uint32_t rowsw) {
         for (int i = (int)threadIdx.x; i < NSK_EP_LIST * 256; i += NSK_BLOCK) fs[i] = 14u;      // owned by no candidate
         __syncthreads();
-        ep_pass<VT, true, true, false, true>(g, g.val, g.val_evid, sub, rowsw,
+        ep_pass<VT, true, 1, false, true, 2>(g, g.val, g.val_evid, sub, rowsw, nullptr,
             [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &b, double w) {
                 int cstar, A, B;
                 a.close(d1, lut, cstar, A, B);
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbeg
     };
     // phase 3 of one pass: gradients of its entries from the facts in the slots
     auto gradients = [&](uint32_t sub, uint32_t rowsw) {
-        ep_pass<VT, false, false, false, false>(g, g.val, g.val, sub, rowsw,
+        ep_pass<VT, false, 0, false, false, 2>(g, g.val, g.val, sub, rowsw, nullptr,
             [&](uint32_t w0, uint32_t d1, const GenChain &, const GenChain &, double) {
                 const uint32_t sv = sel[(d1 >> 23) & 255u];
                 const int evidence = (int)(sv & 15u), proposal = (int)((sv >> 4) & 15u);
@@ -1120,12 +1120,18 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbeg
                 const long long diff = (long long)(proposal == cf ? Af : Bf) - (long long)(evidence == ce ? Ae : Be);
                 const bool have = (sv & 256u) && ((d1 >> 14) & 15u) != 14u && entry_visited(d1, evidence, proposal) &&
                                   !(d1 >> 31);                                              // 100-101
+#ifdef NSK_ABL_NOATOMIC
+                if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
+#else
                 accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * 4294967296ll, (sv & 512u) != 0u);
+#endif
             });
     };
     if ((int)blockIdx.x < hblocks + gblocks) {
         const EpWalk wk = ep_walk(ngroups, hblocks, gblocks);
-        for (int gi = wk.gi; gi < wk.gend; gi += wk.step) {
+        for (int li = wk.li; li < wk.lend; li += wk.step) {
+            const int gi = ep_group(wk, li, ngroups);
+            if (gi < 0) continue;
             const NSK_SCALAR uint32_t *gdp = (const NSK_SCALAR uint32_t *)(g.ep_desc + group0 + gi);
             const uint32_t gsub = gdp[0], grows0 = gdp[1], gmax = gdp[2], grows1 = gdp[3];
             const int ne = (int)(gmax & 255u);
@@ -1177,6 +1183,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbeg
             }
             sel[threadIdx.x] = (uint16_t)mysel;
             __syncthreads();
+#ifdef NSK_ABL_EPNOP3
+            if (lp.k0 != 0xDEADBEEFu) continue;
+#endif
             gradients(sub, two ? grows1 : grows0);         // the last pass's facts are in the slots
             if (two) {                                     // the first pass's entries: their facts again, then their gradients
                 __syncthreads();
