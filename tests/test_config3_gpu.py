@@ -73,3 +73,27 @@ def test_config3_learning_bit_exact_vs_oracle():
     assert np.array_equal(fg.var_value[0], vv)
     assert np.array_equal(fg.var_value_evid[0], ve)
     assert np.isfinite(fg.weight_value[0]).all()
+
+
+def test_config3_planted_weights_are_recovered():
+    """Config #3 end to end: the 2500x4000 grid sampled for 200 sweeps at planted
+    weights (0.3 vertical, 0.3 horizontal), then learned from that configuration as evidence with the
+    config's own hyper-parameters (step 1e-7, decay 0.95, L2 0.01, 50 epochs) -- every (variable,
+    factor) visit is one SGD step of sample_and_sgd (learning.py:96-125), 10^7 visits per weight and
+    colour class, so the per-class step cap (visits x step = 1 > 0.5) is active.  The weights come back
+    within 0.01."""
+    import warnings
+    g = graphgen.ising_grid(ROWS, COLS, weight=0.3, fixed=True, two_weights=True)
+    g[0]["initialValue"] = (0.3, 0.3)
+    ns, fg = session(g, seed=20240602)
+    fg.inference(0, 200, True)
+    x = fg.var_value[0].copy()
+    fg.close()
+    g2 = graphgen.ising_grid(ROWS, COLS, weight=0.0, fixed=False, two_weights=True, evidence=x)
+    ns2, fg2 = session(g2, seed=20240603)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        fg2.learn(0, 50, 1e-7, 0.95, 2, 0.01, 1)
+    w = fg2.weight_value[0]
+    assert fg2.info()["learn_clipped"] > 0 and any("learn_cap" in str(c.message) for c in caught)
+    assert abs(w[0] - 0.3) < 0.01 and abs(w[1] - 0.3) < 0.01, w
