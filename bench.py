@@ -315,12 +315,18 @@ def dry_run(args, dist, rank, world, rows, cols, learning):
     g = build_graph(rows, cols, learning, name=args.workload)
     ns = numbskull_amd.NumbSkull(quiet=True, seed=args.seed)
     own = shard_range(rank, world, rows * cols)
+    if world > 1:
+        from numbskull_amd import graphgen
+        g, gids, own_local = graphgen.extract_shard(g, own[0], own[1])
     w, v, f, fm, dm, edges = g
     with redirect_stdout(io.StringIO()):
-        ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=own if world > 1 else None)
+        if world > 1:
+            ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=own_local, global_ids=gids)
+        else:
+            ns.loadFactorGraph(w, v, f, fm, dm, int(edges))
     fg = ns.factorGraphs[0]
     color, info = fg.plan()
-    needs = fg.ghost_needs(host_only=True) if world > 1 else np.zeros(0, np.int32)
+    needs = gids[fg.ghost_needs(host_only=True)].astype(np.int32) if world > 1 else np.zeros(0, np.int32)
     nb = int(len(needs))
     sampled = int((color >= 0).sum())
     if world > 1:
@@ -387,17 +393,28 @@ def main():
     ns = numbskull_amd.NumbSkull(quiet=True, device=local_rank, seed=args.seed,
                                  head_by_vid=args.workload.startswith("lr"))
     own = shard_range(rank, world, nvar)
-    w, v, f, fm, dm, edges = g
     import io
     from contextlib import redirect_stdout
     t_load = time.time()
-    with redirect_stdout(io.StringIO()):
-        ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=own if world > 1 else None)
+    nfactor_total, nweight_total = len(g[2]), len(g[0])
+    if world > 1:
+        # every rank keeps only its shard -- owned variables, the ghosts they read, the factors that
+        # touch them (graphgen.extract_shard; the reference's minions load their partition only,
+        # salt/src/numbskull_minion.py:185) -- and drops the generated whole graph
+        from numbskull_amd import graphgen
+        g, gids, own_local = graphgen.extract_shard(g, own[0], own[1])
+        w, v, f, fm, dm, edges = g
+        with redirect_stdout(io.StringIO()):
+            ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=own_local, global_ids=gids)
+    else:
+        w, v, f, fm, dm, edges = g
+        with redirect_stdout(io.StringIO()):
+            ns.loadFactorGraph(w, v, f, fm, dm, int(edges))
     fg = ns.factorGraphs[0]
     L, h = _lib.lib(), fg._engine()
     t_load = time.time() - t_load
     info = fg.info()
-    sampler = PartitionedSampler(fg, dist, torch, rank, world) if world > 1 else None
+    sampler = PartitionedSampler(fg, dist, torch, rank, world, nvar_global=nvar) if world > 1 else None
     lr = (1e-7, 0.95, 2, 0.01, 1)       # step, decay, L2, reg_param, truncation (config #3)
     if args.workload.startswith("lr") or args.workload.startswith("boolw"):
         lr = (1e-3, 0.95, 2, 0.01, 1)
@@ -452,6 +469,11 @@ def main():
         checks["all_ranks_ok"] = bool(t.item() > 0.5)
         ok_local = checks["all_ranks_ok"]
 
+    phases = None
+    if world > 1 and not learning:      # per-phase timings of one shard's sweep (diagnostic; burn-in sweeps)
+        phases = sampler.phase_timings(20)
+        phases["exchange_path"] = "peer-to-peer writes + flags" if sampler.p2p else (
+            "native RCCL all-gather" if sampler.native else "torch.distributed all-gather")
     copy_gbs = None
     if rank == 0:
         cg = C.c_double()
@@ -490,16 +512,17 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": ("%d boolean variables, %d ISTRUE/OR/EQUAL factors with one weight each, "
-                                    "inference only, chromatic scan, seed %d" % (nvar, len(f), args.seed))
+                                    "inference only, chromatic scan, seed %d" % (nvar, nfactor_total, args.seed))
                        if args.workload.startswith("boolw4m") else
                        ("mixed-arity LR graph: %d variables (25%% categorical), %d factors, %d weights, %s"
-                        % (nvar, len(f), len(w), "learning" if learning else "inference"))
+                        % (nvar, nfactor_total, nweight_total, "learning" if learning else "inference"))
                        if args.workload.startswith("lr") else
                        "%dx%d Ising grid (%d binary variables, %d EQUAL factors), %s, "
                        "chromatic scan, seed %d"
-                       % (rows, cols, nvar, len(f), "learning (2 free weights, L2)"
+                       % (rows, cols, nvar, nfactor_total, "learning (2 free weights, L2)"
                           if learning else "inference only, weight 0.1 fixed", args.seed),
-                       "name": args.workload, "partition": "range by variable id, %d shard(s)" % world,
+                       "name": args.workload, "partition": "range by variable id, %d shard(s)%s" % (
+                           world, ", shard-local graphs (%d of %d variables held by rank 0)" % (len(v), nvar) if world > 1 else ""),
                        "colors": info["ncolors"], "value_bytes": info["value_bytes"],
                        "generate_s": round(t_gen, 2), "load_and_compile_s": round(t_load, 2),
                        "compile_s": round(info["compile_seconds"], 2),
@@ -519,6 +542,8 @@ def main():
                          "launches": nlaunch, "avg_launch_us": launch_s * 1e6},
             "parity": checks,
         }
+        if phases is not None:
+            out["phases_us"] = phases      # rank 0's shard: sweep kernels / exchange, each with its launch latency
         if learning:
             out["learn_clipped"] = fg.info()["learn_clipped"]
             out["learn_hyper"] = {"step": lr[0], "regularization": lr[2], "reg_param": lr[3],

@@ -100,6 +100,13 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
  * and advances by one per sweep of any kind.  Sequential scan seeds MT19937 like
  * np.random.seed(seed); random.seed(seed). */
 int nsk_set_seed(nsk_graph *g, uint64_t seed, uint64_t sweep0);
+/* Shards of one graph must not share generator streams although their generator ids (layout
+ * positions) coincide: Philox counter word 3 is the sweep index's high half XOR a shard tag.  The
+ * tag defaults to own_begin (distinct for disjoint shards of one variable array); a handle built
+ * from a shard-local graph (own variables + ghosts, renumbered) passes the GLOBAL id of its first
+ * owned variable here, which also makes it sample exactly what the whole-graph handle with that
+ * own_range samples. */
+int nsk_set_rng_tag(nsk_graph *g, uint32_t tag);
 int nsk_set_scan(nsk_graph *g, int scan);
 /* Chromatic learning applies sample_and_sgd's update (learning.py:110-125) once per colour class:
  * a weight visited k times moves by step * (sum of its k gradients).  The reference updates per
@@ -172,7 +179,9 @@ int nsk_set_stream(nsk_graph *g, void *hip_stream);
  *                       variables read (vids == NULL: query the count)
  *   nsk_exchange_setup  send_vids: the owned variables some other rank reads, in the order every
  *                       rank agreed on; recv_vids / recv_off: the same lists of all `world` ranks,
- *                       concatenated; slot: elements reserved per rank in the gathered buffer
+ *                       concatenated (-1: a variable this handle does not hold -- a shard-local graph
+ *                       keeps only the ghosts it reads -- is skipped); slot: elements reserved per
+ *                       rank in the gathered buffer
  *   nsk_exchange_pack   SEND[i] = value[send_vids[i]]          (which = NSK_BUF_VALUE[_EVID])
  *   nsk_exchange_unpack value[recv_vids[j]] = RECV[src*slot + j - recv_off[src]] for every src != rank
  * The all-gather of SEND into RECV is done by the caller (torch.distributed) or by the native loop
@@ -194,6 +203,23 @@ int nsk_learn_sweeps_exchange(nsk_graph *g, int64_t nsweeps, double step, double
                               int regularization, double reg_param, int64_t truncation,
                               int learn_non_evidence);
 int nsk_synchronize(nsk_graph *g);
+
+/* Peer-to-peer boundary exchange on one node (after nsk_exchange_setup): instead of pack ->
+ * ncclAllGather -> unpack, a rank writes its boundary values straight into buffers of its peers
+ * (device memory they expose with hipIpc; over xGMI between GPUs) and raises a flag there; a rank
+ * waits for the flags of the ranks it reads from and scatters their values -- no collective, no
+ * host round trip per sweep (the reference's per-epoch owner -> replica copy,
+ * salt/src/numbskull_master.py:165-224).
+ *   nsk_p2p_export  allocates this rank's buffers; handles128 receives two 64-byte hipIpc handles
+ *   nsk_p2p_import  all_handles: the world x 128 bytes of every rank, gathered by the caller;
+ *                   readers: world flags, readers[q] != 0 iff rank q reads boundary values of this rank
+ *   nsk_gibbs_sweeps_p2p  `nsweeps` x (sweep, push to peers, wait + unpack) on the library's stream;
+ *                   NSK_E_DEVICE when a peer's flag does not arrive within ~2 s
+ *   nsk_p2p_exchange  one exchange of the current boundary values alone (set-up self-test) */
+int nsk_p2p_export(nsk_graph *g, void *handles128);
+int nsk_p2p_import(nsk_graph *g, const void *all_handles, const int32_t *readers);
+int nsk_gibbs_sweeps_p2p(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin);
+int nsk_p2p_exchange(nsk_graph *g);
 
 /* ---- host-side index build and file parsing (no GPU needed) ---- */
 /* dataloading.compute_var_map (dataloading.py:16-81), native and O(edges). */

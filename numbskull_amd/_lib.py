@@ -22,11 +22,11 @@ BUF_VALUE, BUF_VALUE_EVID, BUF_WEIGHT, BUF_SEND, BUF_RECV, BUF_SEND_EVID, BUF_RE
 # every symbol include/numbskull_amd.h declares (tests/test_cabi.py checks the export list)
 SYMBOLS = (
     "nsk_graph_create", "nsk_graph_destroy", "nsk_state_upload", "nsk_state_download",
-    "nsk_set_seed", "nsk_set_scan", "nsk_set_learn_cap", "nsk_gibbs_sweeps", "nsk_learn_sweeps", "nsk_graph_get_info",
+    "nsk_set_seed", "nsk_set_rng_tag", "nsk_set_scan", "nsk_set_learn_cap", "nsk_gibbs_sweeps", "nsk_learn_sweeps", "nsk_graph_get_info",
     "nsk_graph_get_colors", "nsk_graph_get_layout", "nsk_graph_plan", "nsk_graph_plan_needs", "nsk_profile_begin", "nsk_profile_end", "nsk_device_buffer",
     "nsk_set_stream", "nsk_synchronize", "nsk_ghost_needs", "nsk_exchange_setup", "nsk_exchange_pack",
     "nsk_exchange_unpack", "nsk_comm_unique_id", "nsk_comm_init", "nsk_gibbs_sweeps_exchange",
-    "nsk_learn_sweeps_exchange", "nsk_compute_var_map", "nsk_parse_factors", "nsk_parse_domains", "nsk_write_probabilities",
+    "nsk_learn_sweeps_exchange", "nsk_p2p_export", "nsk_p2p_import", "nsk_gibbs_sweeps_p2p", "nsk_p2p_exchange", "nsk_compute_var_map", "nsk_parse_factors", "nsk_parse_domains", "nsk_write_probabilities",
     "nsk_selftest_exp", "nsk_selftest_philox", "nsk_selftest_stream", "nsk_device_count", "nsk_last_error", "nsk_version",
 )
 
@@ -72,6 +72,7 @@ def lib():
         L.nsk_learn_sweeps.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int,
                                        C.c_double, C.c_int64, C.c_int]
         L.nsk_set_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.nsk_set_rng_tag.argtypes = [C.c_void_p, C.c_uint32]
         L.nsk_set_scan.argtypes = [C.c_void_p, C.c_int]
         L.nsk_set_learn_cap.argtypes = [C.c_void_p, C.c_double]
         L.nsk_state_upload.argtypes = [C.c_void_p] * 5
@@ -99,6 +100,10 @@ def lib():
         L.nsk_gibbs_sweeps_exchange.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.nsk_learn_sweeps_exchange.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int,
                                                 C.c_double, C.c_int64, C.c_int]
+        L.nsk_p2p_export.argtypes = [C.c_void_p, C.c_void_p]
+        L.nsk_p2p_import.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nsk_gibbs_sweeps_p2p.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.nsk_p2p_exchange.argtypes = [C.c_void_p]
         L.nsk_compute_var_map.argtypes = [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int64]

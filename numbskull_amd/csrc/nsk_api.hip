@@ -290,6 +290,12 @@ int nsk_set_seed(nsk_graph *g, uint64_t seed, uint64_t sweep0) {
     return NSK_OK;
 }
 
+int nsk_set_rng_tag(nsk_graph *g, uint32_t tag) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    g->rng_tag = tag;
+    return NSK_OK;
+}
+
 int nsk_set_learn_cap(nsk_graph *g, double cap) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (cap != cap) return fail(NSK_E_INVALID, "cap is NaN");
@@ -652,14 +658,14 @@ int nsk_exchange_setup(nsk_graph *g, int world, int rank, const int32_t *send_vi
     for (int src = 0; src < world; src++) {
         if (recv_off[src + 1] - recv_off[src] > slot) return fail(NSK_E_INVALID, "slot smaller than a rank's list");
         for (int64_t j = recv_off[src]; j < recv_off[src + 1]; j++) {
-            if (recv_vids[j] < 0 || recv_vids[j] >= g->c.nvar) return fail(NSK_E_INDEX, "receive list out of range");
-            rslot[j] = src == rank ? -1 : (int32_t)(src * slot + (j - recv_off[src]));
+            if (recv_vids[j] < -1 || recv_vids[j] >= g->c.nvar) return fail(NSK_E_INDEX, "receive list out of range");
+            rslot[j] = (src == rank || recv_vids[j] < 0) ? -1 : (int32_t)(src * slot + (j - recv_off[src]));
         }
     }
     g->xworld = world; g->xrank = rank; g->xslot = slot; g->xnsend = nsend; g->xnrecv = nrecv;
     std::vector<int32_t> sv(send_vids, send_vids + nsend), rv(recv_vids, recv_vids + nrecv);
     for (auto &x : sv) x = g->c.iid[x];                        // the kernels address values by internal id
-    for (auto &x : rv) x = g->c.iid[x];
+    for (auto &x : rv) x = x < 0 ? 0 : g->c.iid[x];          // (skipped entries: slot -1, never written)
     int rc;
     if ((rc = dev_upload(g, &g->x_send_vids, sv))) return rc;
     if ((rc = dev_upload(g, &g->x_recv_vids, rv))) return rc;
@@ -712,6 +718,110 @@ static int exchange_step(nsk_graph *g, int which, bool pack) {
 
 int nsk_exchange_pack(nsk_graph *g, int which) { return exchange_step(g, which, true); }
 int nsk_exchange_unpack(nsk_graph *g, int which) { return exchange_step(g, which, false); }
+
+// ---- peer-to-peer exchange ------------------------------------------------------------------------
+int nsk_p2p_export(nsk_graph *g, void *handles128) {
+    if (!g || !handles128) return fail(NSK_E_INVALID, "null argument");
+    if (g->xworld == 0) return fail(NSK_E_INVALID, "nsk_exchange_setup has not been called");
+    if (g->xworld > 16) return fail(NSK_E_INVALID, "peer-to-peer exchange serves at most 16 ranks (one node)");
+    HIPCHECK(hipSetDevice(g->device));
+    const size_t vb = (size_t)g->c.vbytes;
+    const size_t rbytes = std::max<size_t>(2 * (size_t)g->xworld * (size_t)g->xslot * vb, 256);
+    const size_t fbytes = 2 * (size_t)g->xworld * sizeof(unsigned int);
+    if (!g->p2p_recv) {
+        // fine-grained: a peer's stores and this rank's polling loads are coherent while kernels run
+        HIPCHECK(hipExtMallocWithFlags(&g->p2p_recv, rbytes, hipDeviceMallocFinegrained));
+        HIPCHECK(hipExtMallocWithFlags((void **)&g->p2p_flags, fbytes + 64, hipDeviceMallocFinegrained));
+        g->allocs.push_back(g->p2p_recv);
+        g->allocs.push_back(g->p2p_flags);
+        g->device_bytes += (int64_t)(rbytes + fbytes);
+        int rc = dev_alloc(g, &g->p2p_err, 1);
+        if (rc) return rc;
+        HIPCHECK(hipMemsetAsync(g->p2p_recv, 0, rbytes, g->stream));
+        HIPCHECK(hipMemsetAsync(g->p2p_flags, 0, fbytes + 64, g->stream));
+        HIPCHECK(hipMemsetAsync(g->p2p_err, 0, sizeof(unsigned int), g->stream));
+        HIPCHECK(hipStreamSynchronize(g->stream));
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h[2];
+    HIPCHECK(hipIpcGetMemHandle(&h[0], g->p2p_recv));
+    HIPCHECK(hipIpcGetMemHandle(&h[1], g->p2p_flags));
+    memcpy(handles128, h, 128);
+    return NSK_OK;
+}
+
+int nsk_p2p_import(nsk_graph *g, const void *all_handles, const int32_t *readers) {
+    if (!g || !all_handles || !readers) return fail(NSK_E_INVALID, "null argument");
+    if (!g->p2p_recv) return fail(NSK_E_INVALID, "nsk_p2p_export first");
+    HIPCHECK(hipSetDevice(g->device));
+    g->p2p_peer_mask = 0; g->p2p_src_mask = 0;
+    for (int q = 0; q < g->xworld; q++) {
+        if (q == g->xrank) { g->p2p_peer_recv[q] = g->p2p_recv; g->p2p_peer_flags[q] = g->p2p_flags; continue; }
+        hipIpcMemHandle_t h[2];
+        memcpy(h, (const char *)all_handles + (size_t)q * 128, 128);
+        HIPCHECK(hipIpcOpenMemHandle(&g->p2p_peer_recv[q], h[0], hipIpcMemLazyEnablePeerAccess));
+        HIPCHECK(hipIpcOpenMemHandle(&g->p2p_peer_flags[q], h[1], hipIpcMemLazyEnablePeerAccess));
+        if (readers[q]) g->p2p_peer_mask |= 1u << q;
+    }
+    // the ranks this one reads from: those with a live entry in its receive lists
+    std::vector<int32_t> rslot((size_t)g->xnrecv);
+    if (g->xnrecv) HIPCHECK(hipMemcpy(rslot.data(), g->x_recv_slot, (size_t)g->xnrecv * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int32_t sl : rslot) if (sl >= 0) g->p2p_src_mask |= 1u << (unsigned)(sl / std::max<int64_t>(g->xslot, 1));
+    g->p2p_tag = 0;
+    g->p2p_ready = true;
+    return NSK_OK;
+}
+
+}  // extern "C"
+
+template <typename VT>
+static int p2p_exchange(nsk_graph *g) {
+    P2PPeers peers;
+    for (int q = 0; q < 16; q++) { peers.recv[q] = g->p2p_peer_recv[q]; peers.flags[q] = (unsigned int *)g->p2p_peer_flags[q]; }
+    const unsigned int tag = ++g->p2p_tag;
+    if (g->p2p_peer_mask)
+        k_p2p_push<VT><<<dim3(1), dim3(1024), 0, g->stream>>>((const VT *)g->val, g->x_send_vids, (int)g->xnsend, peers,
+                                                              g->xworld, g->xrank, g->xslot, g->p2p_peer_mask, tag);
+    const int n = (int)g->xnrecv;
+    if (g->p2p_src_mask && n > 0)
+        k_p2p_wait_unpack<VT><<<dim3(std::min(64, (n + NSK_BLOCK - 1) / NSK_BLOCK)), dim3(NSK_BLOCK), 0, g->stream>>>(
+            (VT *)g->val, g->x_recv_vids, g->x_recv_slot, (const VT *)g->p2p_recv, g->p2p_flags, n, g->xworld,
+            g->xslot, g->p2p_src_mask, tag, g->p2p_err);
+    HIPCHECK(hipGetLastError());
+    return NSK_OK;
+}
+
+extern "C" {
+
+static int p2p_check(nsk_graph *g);
+
+int nsk_p2p_exchange(nsk_graph *g) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_export / nsk_p2p_import first");
+    HIPCHECK(hipSetDevice(g->device));
+    int rc = g->c.vbytes == 1 ? p2p_exchange<int8_t>(g) : p2p_exchange<int32_t>(g);
+    return rc ? rc : p2p_check(g);
+}
+
+int nsk_gibbs_sweeps_p2p(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_export / nsk_p2p_import first");
+    for (int64_t s = 0; s < nsweeps; s++) {
+        int rc = nsk_gibbs_sweeps(g, 1, sample_evidence, burnin);
+        if (rc) return rc;
+        rc = g->c.vbytes == 1 ? p2p_exchange<int8_t>(g) : p2p_exchange<int32_t>(g);
+        if (rc) return rc;
+    }
+    return p2p_check(g);
+}
+
+static int p2p_check(nsk_graph *g) {
+    unsigned int err = 0;
+    HIPCHECK(hipMemcpyAsync(&err, g->p2p_err, sizeof(err), hipMemcpyDeviceToHost, g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    if (err) return fail(NSK_E_DEVICE, "peer-to-peer exchange: a peer's boundary values did not arrive (timeout)");
+    return NSK_OK;
+}
 
 // ---- native RCCL loop -----------------------------------------------------------------------------
 static int load_rccl(const char *path) {

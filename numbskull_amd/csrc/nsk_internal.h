@@ -83,6 +83,13 @@ struct nsk_graph {
     int32_t *x_send_vids = nullptr, *x_recv_vids = nullptr, *x_recv_slot = nullptr;
     void *x_send = nullptr, *x_recv = nullptr, *x_send_evid = nullptr, *x_recv_evid = nullptr;
     double *w_start = nullptr, *w_delta = nullptr;
+    // peer-to-peer exchange (nsk_p2p_*): fine-grained double-buffered gathered buffer + flags, the peers'
+    // mappings of theirs, the exchange counter
+    void *p2p_recv = nullptr;
+    unsigned int *p2p_flags = nullptr, *p2p_err = nullptr;
+    void *p2p_peer_recv[16] = {nullptr}, *p2p_peer_flags[16] = {nullptr};
+    unsigned int p2p_peer_mask = 0, p2p_src_mask = 0, p2p_tag = 0;
+    bool p2p_ready = false;
     // native RCCL
     void *rccl_lib = nullptr, *rccl_comm = nullptr;
     long long *cnt_total = nullptr, *G = nullptr;

@@ -58,6 +58,64 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_exchange_unpack(VT *val, const in
     if (sl >= 0) val[recv_vids[j]] = recvbuf[sl];
 }
 
+// ---- peer-to-peer boundary exchange (one node: xGMI / same device) ---------------------------------
+// Every rank owns a double-buffered gathered buffer recv[2][world * slot] and flags[2][world] in
+// fine-grained device memory that its peers have mapped (hipIpc).  After a sweep a rank WRITES its
+// boundary values straight into the peers' buffers (slot block `me` of parity tag & 1), fences to
+// system scope and stores the exchange tag into its flag at every peer; a rank then waits for the
+// tags of the ranks it reads from and scatters their blocks into its value array.  No collective, no
+// host in the loop.  Two parities suffice: a peer can run at most one exchange ahead (it needs this
+// rank's next boundary before the one after).
+struct P2PPeers { void *recv[16]; unsigned int *flags[16]; };       // (one node: at most 16 ranks)
+
+template <typename VT>
+__global__ __launch_bounds__(1024) void k_p2p_push(const VT *val, const int32_t *send_vids, int nsend, P2PPeers peers,
+                                                   int world, int me, int64_t slot, unsigned int peer_mask,
+                                                   unsigned int tag) {
+    const size_t base = ((size_t)(tag & 1u) * (size_t)world + (size_t)me) * (size_t)slot;
+    for (int q = 0; q < world; q++) {
+        if (!((peer_mask >> q) & 1u)) continue;
+        VT *dst = (VT *)peers.recv[q] + base;
+        for (int i = (int)threadIdx.x; i < nsend; i += (int)blockDim.x) dst[i] = val[send_vids[i]];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x < (unsigned)world && ((peer_mask >> threadIdx.x) & 1u))
+        __hip_atomic_store(peers.flags[threadIdx.x] + (size_t)(tag & 1u) * (size_t)world + (size_t)me, tag,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// waits (bounded: ~2 s of the 100 MHz wall clock, then *err = 1) for the tags of the ranks in
+// src_mask, then unpacks like k_exchange_unpack from the parity's buffer
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_wait_unpack(VT *val, const int32_t *recv_vids, const int32_t *recv_slot,
+                                                               const VT *recv2, unsigned int *flags, int n, int world,
+                                                               int64_t slot, unsigned int src_mask, unsigned int tag,
+                                                               unsigned int *err) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        ok = 1;
+        const unsigned long long t0 = wall_clock64();
+        for (int q = 0; q < world; q++) {
+            if (!((src_mask >> q) & 1u)) continue;
+            const unsigned int *f = flags + (size_t)(tag & 1u) * (size_t)world + (size_t)q;
+            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+                if (wall_clock64() - t0 > 200000000ull) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (!ok) *err = 1u;
+    }
+    __syncthreads();
+    if (!ok) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const VT *rb = recv2 + (size_t)(tag & 1u) * (size_t)world * (size_t)slot;
+    for (int j = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x); j < n; j += (int)(gridDim.x * NSK_BLOCK)) {
+        const int sl = recv_slot[j];
+        if (sl >= 0) val[recv_vids[j]] = __builtin_nontemporal_load(rb + sl);
+    }
+}
+
 // weight merge of the partitioned learning sweep: delta = w - start ... w = start + sum(delta)
 static __global__ __launch_bounds__(NSK_BLOCK) void k_weight_delta(const double *w, const double *start, double *delta, int n) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);

@@ -15,7 +15,11 @@ therefore one sweep old inside a sweep, exactly the reference's distributed sema
 learning the evidence-chain values are exchanged too and the weight deltas of the epoch are summed
 with an all-reduce.
 
-Two drivers for the per-sweep loop:
+Drivers for the per-sweep loop:
+  * peer-to-peer (opt-in, NSK_P2P=1, inference sweeps): every rank writes its boundary values straight
+    into buffers of its peers (device memory mapped with hipIpc; xGMI between GPUs) and raises a flag
+    there; a rank waits for the flags of the ranks it reads from and scatters their values
+    (nsk_gibbs_sweeps_p2p) -- no collective, no host round trip per sweep;
   * native (default on GPUs): the whole loop -- sweep kernels, pack, ncclAllGather, unpack -- is
     enqueued from C++ on one stream (nsk_gibbs_sweeps_exchange), the communicator being created
     from a ncclUniqueId that rank 0 makes and ``torch.distributed`` broadcasts;
@@ -89,7 +93,7 @@ class PartitionedSampler(object):
     torch's current stream, so sweeps and collectives are ordered by the stream.
     """
 
-    def __init__(self, fg, dist, torch, rank, world, native=True):
+    def __init__(self, fg, dist, torch, rank, world, native=True, nvar_global=None, p2p=None):
         from . import _lib
         self.fg, self.dist, self.torch, self.rank, self.world = fg, dist, torch, rank, world
         self.L = _lib.lib()
@@ -97,6 +101,10 @@ class PartitionedSampler(object):
         h = fg._engine()
         self.h = h
         self.nvar = fg.variable.shape[0]
+        # a shard-local graph (graphgen.extract_shard) holds its own variables and the ghosts it reads
+        # under local ids: boundaries are planned in GLOBAL ids and translated for the library
+        self.gids = fg.global_ids
+        self.nvar_global = int(nvar_global) if nvar_global is not None else self.nvar
         info = fg.info()
         self.typestr = {1: "|i1", 4: "<i4"}[info["value_bytes"]]
         self.dev = "cuda:%d" % fg.device
@@ -111,9 +119,16 @@ class PartitionedSampler(object):
         self.val_evid_raw = self._wrap(_lib.BUF_VALUE_EVID, nid.value, self.typestr)
         self.w = self._wrap(_lib.BUF_WEIGHT, fg.weight.shape[0], "<f8")
         self.native = False
+        self.p2p = False
         self.lists, self.slot = None, 0
+        self.all_needs = None
         if world > 1:
             self.setup_exchange(native)
+            # peer-to-peer exchange for the inference sweeps (NSK_P2P=0 or p2p=False: off).  Set-up ends
+            # with a self-test -- two real exchanges, one per buffer parity -- and every rank must pass
+            # or none uses it (the collective loop stays as the fallback)
+            if p2p if p2p is not None else os.environ.get("NSK_P2P", "1") != "0":
+                self.p2p = self._init_p2p()
 
     @property
     def val(self):
@@ -135,8 +150,9 @@ class PartitionedSampler(object):
         """Hand the agreed boundary lists to the library and wrap its staging buffers."""
         _lib = self._lib
         self.lists, self.slot = lists, int(slot)
-        send = np.ascontiguousarray(lists[self.rank], np.int32)
-        recv = np.ascontiguousarray(np.concatenate(lists + [np.empty(0, np.int32)]), np.int32)
+        send = np.ascontiguousarray(self._local(lists[self.rank]), np.int32)
+        assert (send >= 0).all(), "a boundary list names a variable this shard does not hold"
+        recv = np.ascontiguousarray(self._local(np.concatenate(lists + [np.empty(0, np.int32)])), np.int32)
         off = np.zeros(self.world + 1, np.int64)
         np.cumsum([len(b) for b in lists], out=off[1:])
         _lib.check(self.L.nsk_exchange_setup(self.h, self.world, self.rank, _lib.ptr(send), len(send),
@@ -146,10 +162,23 @@ class PartitionedSampler(object):
         self.send_evid = self._wrap(_lib.BUF_SEND_EVID, self.slot, self.typestr)
         self.recv_evid = self._wrap(_lib.BUF_RECV_EVID, self.slot * self.world, self.typestr)
 
-    def setup_exchange(self, native=True):
+    def _local(self, ids):
+        """Global variable ids -> this handle's ids (-1: not held here); identity for a whole-graph handle."""
+        ids = np.asarray(ids, np.int64)
+        if self.gids is None:
+            return ids
+        at = np.minimum(np.searchsorted(self.gids, ids), len(self.gids) - 1) if len(self.gids) else np.zeros(len(ids), np.int64)
+        return np.where(len(self.gids) and self.gids[at] == ids, at, -1) if len(ids) else ids
+
+    def global_needs(self):
+        """Sorted GLOBAL ids of the variables this shard reads but does not own."""
         needs = self.fg.ghost_needs()
-        lists, slot = plan_boundaries(gather_needs(self.dist, self.torch, needs, self.world, self.dev),
-                                      self.world, self.nvar)
+        return needs if self.gids is None else self.gids[needs].astype(np.int32)
+
+    def setup_exchange(self, native=True):
+        needs = self.global_needs()
+        self.all_needs = gather_needs(self.dist, self.torch, needs, self.world, self.dev)
+        lists, slot = plan_boundaries(self.all_needs, self.world, self.nvar_global)
         self.install_boundaries(lists, slot)
         if native:
             self.native = self._init_native()
@@ -176,6 +205,36 @@ class PartitionedSampler(object):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # native only if it works everywhere
         return bool(flag.item())
 
+    def _init_p2p(self):
+        """hipIpc handles of every rank's gathered buffer and flags, all-gathered with
+        torch.distributed; each rank maps its peers' (nsk_p2p_import)."""
+        torch, dist = self.torch, self.dist
+        mine = (C.c_uint8 * 128)()
+        ok = int(self.L.nsk_p2p_export(self.h, mine) == 0)
+        t = torch.tensor(list(bytes(mine)) + [ok], dtype=torch.uint8, device=self.dev)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(outs, t)
+        raw = [bytes(o.cpu().numpy().tolist()) for o in outs]
+        if not all(r[128] == 1 for r in raw):
+            return False
+        table = (C.c_uint8 * (128 * self.world)).from_buffer_copy(b"".join(r[:128] for r in raw))
+        mine_ids = np.asarray(self.lists[self.rank], np.int64)
+        readers = np.array([int(q != self.rank and len(np.intersect1d(self.all_needs[q], mine_ids)) > 0)
+                            for q in range(self.world)], np.int32)
+        rc = self.L.nsk_p2p_import(self.h, table, self._lib.ptr(readers))
+        flag = torch.tensor([int(rc == 0)], dtype=torch.int32, device=self.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not bool(flag.item()):
+            return False
+        # self-test: the boundary values are still the initial ones every rank already holds, so two
+        # exchanges change nothing -- but they run the very kernels, mappings and flags of the sweep loop
+        rc = 0
+        for _ in range(2):
+            rc = rc or self.L.nsk_p2p_exchange(self.h)
+        flag = torch.tensor([int(rc == 0)], dtype=torch.int32, device=self.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
     # ------------------------------------------------------------------ per-sweep loops
     def _exchange(self, which, send, recv):
         self._lib.check(self.L.nsk_exchange_pack(self.h, which))
@@ -187,12 +246,47 @@ class PartitionedSampler(object):
         _lib = self._lib
         if self.world == 1:
             _lib.check(self.L.nsk_gibbs_sweeps(self.h, nsweeps, int(sample_evidence), int(burnin)))
+        elif self.p2p:
+            _lib.check(self.L.nsk_gibbs_sweeps_p2p(self.h, nsweeps, int(sample_evidence), int(burnin)))
         elif self.native:
             _lib.check(self.L.nsk_gibbs_sweeps_exchange(self.h, nsweeps, int(sample_evidence), int(burnin)))
         else:
             for _ in range(nsweeps):
                 _lib.check(self.L.nsk_gibbs_sweeps(self.h, 1, int(sample_evidence), int(burnin)))
                 self._exchange(_lib.BUF_VALUE, self.send, self.recv)
+
+    def phase_timings(self, nsweeps=20, sample_evidence=True):
+        """Diagnostic: mean microseconds of the phases of one inference sweep of this shard, each
+        bracketed by HIP events on the library's stream and issued on its own (so every figure
+        carries one launch latency): the sweep kernels, then the exchange -- peer-to-peer push +
+        wait/unpack, or pack / collective / unpack."""
+        _lib, L, h = self._lib, self.L, self.h
+        ms, nl = C.c_double(), C.c_int64()
+
+        def timed(fn):
+            _lib.check(L.nsk_profile_begin(h))
+            fn()
+            _lib.check(L.nsk_profile_end(h, C.byref(ms), C.byref(nl)))
+            return ms.value * 1e3
+        out = {"sweep": 0.0}
+        for _ in range(nsweeps):
+            out["sweep"] += timed(lambda: _lib.check(L.nsk_gibbs_sweeps(h, 1, int(sample_evidence), 1)))
+            if self.world == 1:
+                continue
+            if self.p2p:
+                out["p2p_exchange"] = out.get("p2p_exchange", 0.0) + timed(lambda: _lib.check(L.nsk_p2p_exchange(h)))
+            else:
+                out["pack"] = out.get("pack", 0.0) + timed(lambda: _lib.check(L.nsk_exchange_pack(h, _lib.BUF_VALUE)))
+                t0 = self.torch.cuda.Event(enable_timing=True)
+                t1 = self.torch.cuda.Event(enable_timing=True)
+                t0.record()
+                if self.slot > 0:
+                    self.dist.all_gather_into_tensor(self.recv, self.send)
+                t1.record()
+                t1.synchronize()
+                out["all_gather"] = out.get("all_gather", 0.0) + t0.elapsed_time(t1) * 1e3
+                out["unpack"] = out.get("unpack", 0.0) + timed(lambda: _lib.check(L.nsk_exchange_unpack(h, _lib.BUF_VALUE)))
+        return {k: v / nsweeps for k, v in out.items()}
 
     def learn(self, nsweeps, step, decay, regularization, reg_param, truncation,
               learn_non_evidence=False):

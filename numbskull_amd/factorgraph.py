@@ -36,7 +36,7 @@ class FactorGraph(object):
 
     def __init__(self, weight, variable, factor, fmap, vmap, factor_index, var_copies,
                  weight_copies, fid, workers, *, device=0, seed=0, scan="chromatic",
-                 head_by_vid=False, own_range=None, learn_cap=0.5):
+                 head_by_vid=False, own_range=None, learn_cap=0.5, global_ids=None):
         self.weight, self.variable, self.factor = weight, variable, factor
         self.fmap, self.vmap, self.factor_index = fmap, vmap, factor_index
 
@@ -74,6 +74,9 @@ class FactorGraph(object):
         self.learn_cap = float(learn_cap)
         self.head_by_vid = bool(head_by_vid)
         self.own_range = own_range
+        # shard-local graph (graphgen.extract_shard): global id of every local variable; the shard's
+        # generator streams are tagged with the GLOBAL id of its first owned variable
+        self.global_ids = None if global_ids is None else np.ascontiguousarray(global_ids, np.int64)
         self._handle = None
         self._keep = None
         self._clipped_seen = 0
@@ -135,6 +138,10 @@ class FactorGraph(object):
         self._handle = h
         self._keep = keep
         _lib.check(L.nsk_set_seed(h, self.seed, 0))
+        if self.global_ids is not None and self.own_range is not None and len(self.global_ids):
+            lo = int(self.own_range[0])
+            tag = int(self.global_ids[lo]) if lo < len(self.global_ids) else int(self.global_ids[-1]) + 1
+            _lib.check(L.nsk_set_rng_tag(h, tag & 0xFFFFFFFF))
         scan = {"chromatic": _lib.SCAN_CHROMATIC, "sequential": _lib.SCAN_SEQUENTIAL}[self.scan]
         _lib.check(L.nsk_set_scan(h, scan))
         _lib.check(L.nsk_set_learn_cap(h, self.learn_cap))

@@ -277,6 +277,41 @@ _V_DISK = np.dtype([("variableId", ">i8"), ("isEvidence", "u1"), ("initialValue"
 assert _W_DISK.itemsize == 17 and _V_DISK.itemsize == 27
 
 
+def extract_shard(g, lo, hi):
+    """The part of a graph the shard that owns variables ``[lo, hi)`` needs -- what the reference's
+    minions load (salt/src/numbskull_minion.py:185): the owned variables, the variables outside the
+    range their factors touch (kept as ghosts, ``isEvidence = 4``: read, never sampled,
+    inference.py:21-23) and every factor with an owned member, all renumbered locally in ascending
+    global order (so factor lists keep their order and a shard samples exactly what it samples when
+    it is handed the whole graph with ``own_range``).  Weights keep their ids.
+
+    Returns ``(weight, variable, factor, fmap, domain_mask, edges), global_ids, (l0, l1)``:
+    ``global_ids[i]`` = the global id of local variable ``i``; ``[l0, l1)`` = the owned variables'
+    local ids.  Factors whose head is looked up at its literal edge index (IMPLY_MLN & co. without
+    ``head_by_vid``, inference.py:243) do not survive renumbering: use ``head_by_vid``.
+    """
+    weight, variable, factor, fmap, domain_mask, edges = g
+    vid = fmap["vid"]
+    arity = factor["arity"].astype(np.int64)
+    nfactor = len(factor)
+    fac_of_edge = np.repeat(np.arange(nfactor, dtype=np.int64), arity)
+    owned_edge = (vid >= lo) & (vid < hi)
+    keep_f = np.zeros(nfactor, np.bool_)
+    keep_f[fac_of_edge[owned_edge]] = True
+    keep_e = keep_f[fac_of_edge]
+    gids = np.unique(np.concatenate([np.arange(lo, hi, dtype=np.int64), vid[keep_e]]))
+    lvar = variable[gids].copy()
+    ghost = (gids < lo) | (gids >= hi)
+    lvar["isEvidence"][ghost] = 4
+    lfac = factor[keep_f].copy()
+    lar = lfac["arity"].astype(np.int64)
+    lfac["ftv_offset"] = np.cumsum(lar) - lar
+    lfm = fmap[keep_e].copy()
+    lfm["vid"] = np.searchsorted(gids, lfm["vid"])
+    l0, l1 = int(np.searchsorted(gids, lo)), int(np.searchsorted(gids, hi))
+    return (weight, lvar, lfac, lfm, np.ascontiguousarray(domain_mask[gids]), int(lar.sum())), gids, (l0, l1)
+
+
 def write_graph(directory, weight, variable, factor, fmap, domains=None):
     """Write ``graph.{meta,weights,variables,factors[,domains]}`` in the format the
     reference reads (dataloading.py:103-237) and ising/ising.cpp:88-130 writes.

@@ -122,7 +122,8 @@ class NumbSkull(object):
                         weight_copies)
 
     def loadFactorGraph(self, weight, variable, factor, fmap, domain_mask, edges, var_copies=1,
-                        weight_copies=1, factors_to_skip=np.empty(0, np.int64), own_range=None):
+                        weight_copies=1, factors_to_skip=np.empty(0, np.int64), own_range=None,
+                        global_ids=None):
         """In-memory graph (numbskull.py:192-243).  ``factors_to_skip`` must be sorted."""
         for arr, dt in ((weight, Weight), (variable, Variable), (factor, Factor),
                         (fmap, FactorToVar)):
@@ -137,6 +138,8 @@ class NumbSkull(object):
         dataloading.compute_var_map(variable, factor, fmap, vmap, factor_index, domain_mask,
                                     factors_to_skip)
         extra = {} if own_range is None else {"own_range": own_range}
+        if global_ids is not None:
+            extra["global_ids"] = global_ids
         self._new_graph(weight, variable, factor, fmap, vmap, factor_index, var_copies,
                         weight_copies, **extra)
 

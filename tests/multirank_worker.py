@@ -25,20 +25,30 @@ def graph(kind):
 
 def main():
     kind, learn, nsweeps = sys.argv[1], sys.argv[2] == "learn", 4
+    local = len(sys.argv) > 3 and sys.argv[3] == "local"      # every rank holds only its shard (+ ghosts)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g, hbv = graph(kind)
     nvar = len(g[1])
-    handles = []
+    handles, gids = [], []
     for r in range(world):                       # rank r's graph; the others only to emulate them
         ns = numbskull_amd.NumbSkull(quiet=True, seed=31, head_by_vid=hbv)
-        w, v, f, fm, dm, edges = [x.copy() if isinstance(x, np.ndarray) else x for x in g]
-        ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=shard_range(r, world, nvar))
+        if local:
+            sg, ids, own = graphgen.extract_shard(g, *shard_range(r, world, nvar))
+            ns.loadFactorGraph(*sg[:5], int(sg[5]), own_range=own, global_ids=ids)
+            assert len(ids) < nvar                                   # the shard is a part of the graph
+        else:
+            w, v, f, fm, dm, edges = [x.copy() if isinstance(x, np.ndarray) else x for x in g]
+            ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=shard_range(r, world, nvar))
+            ids = np.arange(nvar, dtype=np.int64)
         handles.append(ns.factorGraphs[0])
+        gids.append(ids)
     fg = handles[rank]
-    sampler = PartitionedSampler(fg, dist, torch, rank, world)       # native RCCL refuses one device
+    p2p = len(sys.argv) > 3 and sys.argv[3] == "p2p"      # boundary values written into the peer's memory (hipIpc)
+    sampler = PartitionedSampler(fg, dist, torch, rank, world, nvar_global=nvar, p2p=p2p)   # native RCCL refuses one device
     assert not sampler.native                                        # for two ranks: torch loop
+    assert sampler.p2p == p2p, "peer-to-peer exchange could not be set up"
     oracles = []
     for r in range(world):
         color = handles[r].plan()[0] if r != rank else fg.colors()
@@ -49,6 +59,12 @@ def main():
     else:
         sampler.gibbs(nsweeps, True, False)
     torch.cuda.synchronize()
+
+    def loc(r, ids):                             # global ids -> rank r's ids (all present)
+        at = np.searchsorted(gids[r], ids)
+        assert np.array_equal(gids[r][at], ids)
+        return at
+
     step = 0.01
     for s in range(nsweeps):
         starts = [st[2].copy() for _, _, st in oracles]
@@ -59,22 +75,24 @@ def main():
                 assert og.gibbs_dev(order, ps, vv, wv, cnt, 31, s, True) == 0
         step *= 0.9
         for r in range(world):                   # owners publish their boundary values
-            b = sampler.lists[r]
             for q in range(world):
                 if q != r:
-                    oracles[q][2][0][b] = oracles[r][2][0][b]
-                    oracles[q][2][1][b] = oracles[r][2][1][b]
+                    b = np.intersect1d(sampler.lists[r], gids[q])    # what q holds of r's boundary
+                    oracles[q][2][0][loc(q, b)] = oracles[r][2][0][loc(r, b)]
+                    oracles[q][2][1][loc(q, b)] = oracles[r][2][1][loc(r, b)]
         if learn:
             total = sum(st[2] - s0 for (_, _, st), s0 in zip(oracles, starts))
             for (_, _, st), s0 in zip(oracles, starts):
                 st[2][:] = s0 + total
     vv, ve, wv, cnt = oracles[rank][2]
-    lo, hi = shard_range(rank, world, nvar)
+    lo, hi = fg.own_range
     got = sampler.val.cpu().numpy().astype(np.int64)
     assert np.array_equal(got[lo:hi], vv[lo:hi]), "owned values differ"
+    needs = sampler.global_needs()
     for r in range(world):
         if r != rank:
-            assert np.array_equal(got[sampler.lists[r]], vv[sampler.lists[r]]), "ghost values differ"
+            b = np.intersect1d(sampler.lists[r], needs)
+            assert np.array_equal(got[loc(rank, b)], vv[loc(rank, b)]), "ghost values differ"
     if learn:
         gote = sampler.val_evid.cpu().numpy().astype(np.int64)
         assert np.array_equal(gote[lo:hi], ve[lo:hi]), "evidence-chain values differ"

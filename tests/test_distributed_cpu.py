@@ -199,3 +199,34 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["dry_run"] is True
     assert out["config"]["sampled_total"] == 256 * 256
     assert out["config"]["boundary_total"] == 2 * 256           # one grid row on each side of the cut
+
+
+def test_shard_local_graph_plans_like_the_whole_graph():
+    """graphgen.extract_shard: a rank that holds only its shard (owned variables, the ghosts they read
+    flagged isEvidence 4, the factors that touch them, renumbered in ascending global order -- what
+    the reference's minions load, salt/src/numbskull_minion.py:185) colours its variables and lists
+    its ghost needs exactly like a handle that is given the whole graph with own_range."""
+    import numbskull_amd
+    from numbskull_amd import graphgen
+    from numbskull_amd.distributed import shard_range
+    for g, hbv in ((graphgen.ising_grid(40, 30, weight=0.3), False),
+                   (graphgen.mixed_lr_graph(4000, seed=12, nweights=300), True)):
+        nvar = len(g[1])
+        total = 0
+        for r in range(3):
+            lo, hi = shard_range(r, 3, nvar)
+            ns = numbskull_amd.NumbSkull(quiet=True, seed=1, head_by_vid=hbv)
+            ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in g[:5]], int(g[5]),
+                               own_range=(lo, hi))
+            whole = ns.factorGraphs[0]
+            sg, gids, (l0, l1) = graphgen.extract_shard(g, lo, hi)
+            assert len(gids) < nvar and np.array_equal(gids[l0:l1], np.arange(lo, hi))
+            assert (sg[1]["isEvidence"][:l0] == 4).all() and (sg[1]["isEvidence"][l1:] == 4).all()
+            ns2 = numbskull_amd.NumbSkull(quiet=True, seed=1, head_by_vid=hbv)
+            ns2.loadFactorGraph(*sg[:5], int(sg[5]), own_range=(l0, l1), global_ids=gids)
+            part = ns2.factorGraphs[0]
+            cw, cl = whole.plan()[0], part.plan()[0]
+            assert np.array_equal(cw[lo:hi], cl[l0:l1]) and (cl[:l0] == -1).all() and (cl[l1:] == -1).all()
+            assert np.array_equal(whole.ghost_needs(host_only=True), gids[part.ghost_needs(host_only=True)])
+            total += len(sg[2])
+        assert total < 2 * len(g[2])                      # factors are shared by at most the shards they touch

@@ -16,14 +16,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("kind", ["grid", "lr"])
 @pytest.mark.parametrize("mode", ["gibbs", "learn"])
-def test_two_ranks_one_gpu(kind, mode):
+@pytest.mark.parametrize("layout", ["whole", "local", "p2p"])
+def test_two_ranks_one_gpu(kind, mode, layout):
+    """layout "local": every rank holds only its shard of the graph -- owned variables, the ghosts
+    they read, the factors that touch them (graphgen.extract_shard; what the reference's minions
+    load, salt/src/numbskull_minion.py:185) -- and boundaries are planned in global ids.
+    layout "p2p": the inference sweeps exchange boundaries by peer writes into hipIpc-mapped buffers with
+    flags (nsk_gibbs_sweeps_p2p) instead of a collective; learning keeps the collective path."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(HERE, "multirank_worker.py"), kind, mode]
+           os.path.join(HERE, "multirank_worker.py"), kind, mode, layout]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

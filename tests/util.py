@@ -46,7 +46,10 @@ def oracle_of(fg, head_by_vid=False, layout=True):
         bad = og.check_coloring(color)
         assert bad == (-1, -1), ("variable reads a variable of its own colour", bad)
         og.set_rng_ids(ids)
-        og.set_rng_tag(fg.own_range[0] if fg.own_range is not None else 0)
+        tag = fg.own_range[0] if fg.own_range is not None else 0
+        if fg.global_ids is not None and fg.own_range is not None and len(fg.global_ids):     # shard-local graph
+            tag = int(fg.global_ids[tag]) if tag < len(fg.global_ids) else int(fg.global_ids[-1]) + 1
+        og.set_rng_tag(tag)
     return og
 
 
