@@ -138,6 +138,8 @@ typedef struct {
     double compile_seconds;           /* host time spent in the graph compiler                     */
     double learn_cap;                 /* nsk_set_learn_cap                                         */
     int64_t learn_clipped;            /* weight updates whose step was clipped so far              */
+    int64_t grad_shift;               /* gradient sums are Q(31+s).(32-s) fixed point: s (0 unless one
+                                         weight's sum in one colour class could reach 2^30)        */
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);

@@ -1465,6 +1465,44 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             });
         }
     }
+    // ---- implicit adjacency of table segments (nsk_compile.h seg_aff)
+    {
+        uint64_t ntile4 = 0;
+        const bool no_aff = diag_env("NSK_NO_AFFINE") != nullptr;
+        for (Compiled::Segment &sg : c.segments) {
+            sg.aff = -1;
+            if (sg.ztab < 0 || no_aff) continue;
+            sg.aff = (int64_t)ntile4;
+            ntile4 += (uint64_t)sg.ntiles * (sg.nslots > 4 ? 2 : 1);
+        }
+        if (ntile4 >= ((uint64_t)1 << 30)) { err = "implicit adjacency table too large"; return NSK_E_RANGE; }
+        c.seg_aff.assign((size_t)ntile4 * 4 + 4, 0xFFFFFFFFu);
+        for (const Compiled::Segment &sg : c.segments) {
+            if (sg.aff < 0) continue;
+            const int nch = sg.nslots > 4 ? 2 : 1;
+            parallel_for(sg.ntiles, [&](int64_t tb0, int64_t tb1, int) {
+                for (int64_t t = tb0; t < tb1; t++) {
+                    const uint64_t wbase = ((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4;
+                    int64_t first = -1;                         // first live lane
+                    for (int64_t i = 0; i < 64 && first < 0; i++) if (c.p_vid[sg.pos0 + 64 * t + i] >= 0) first = i;
+                    if (first < 0) continue;
+                    bool ok = true;
+                    uint32_t base[8];
+                    for (uint32_t j = 0; j < (uint32_t)(4 * nch) && ok; j++) {
+                        const uint64_t wj = wbase + 256 * (j / 4) + (j % 4);
+                        const int64_t b0 = (int64_t)c.adj[wj + 4 * first] - first;
+                        if (b0 < 0 || b0 + 63 >= c.nid) { ok = false; break; }       // every lane reads a valid id
+                        for (int64_t i = 0; i < 64 && ok; i++)
+                            if (c.p_vid[sg.pos0 + 64 * t + i] >= 0 && (int64_t)c.adj[wj + 4 * i] != b0 + i) ok = false;
+                        base[j] = (uint32_t)b0;
+                    }
+                    if (!ok || base[0] == 0xFFFFFFFFu) continue;
+                    for (int cidx = 0; cidx < nch; cidx++)
+                        for (int q = 0; q < 4; q++) c.seg_aff[((size_t)sg.aff + (size_t)t * nch + cidx) * 4 + q] = base[4 * cidx + q];
+                }
+            });
+        }
+    }
     // ---- entry-parallel hub streams: a hub (a long-list variable sampled by a whole wave) whose
     // factors are all of the general-tile kind gets its entries laid out one per LANE -- word j of
     // entry e of round r at hub_adj[off + (r * (2 + M) + j) * 64 + e] -- so that one coalesced row
@@ -1771,6 +1809,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         c.grad_bound = 0.0;
         for (int64_t i = 0; i < nw; i++) c.grad_bound = std::max(c.grad_bound, gbound[i]);
+        // Q31.32 holds sums below 2^31; a larger bound trades fraction bits for range (the reference
+        // sums float64 gradients, learning.py:109): Q(31+s).(32-s), gradients below 2^-(33-s) vanish
+        c.grad_shift = 0;
+        while (c.grad_shift < 32 && c.grad_bound >= 1073741824.0 * std::ldexp(1.0, c.grad_shift)) c.grad_shift++;
+        if (c.grad_shift > 0) c.packed_grad = false;       // the fraction bits are no longer free for visit counts
     }
     c.alg_bytes_inference = bytes_inf;
     c.alg_bytes_learning = bytes_learn;
@@ -1824,6 +1867,12 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (const Compiled::Segment &sg : c.segments)      // inference over table segments reads the compact
             if (sg.d16 >= 0)                                 // stream when there is one
                 lay_inf -= (double)sg.ntiles * 64 * 8 * (sg.nslots > 4 ? 2 : 1);
+        for (const Compiled::Segment &sg : c.segments) {    // inference over table segments: a tile with implicit
+            if (sg.aff < 0 || sg.d16 >= 0) continue;         // adjacency reads 16 bytes per chunk, not 64 x 16
+            const int nch = sg.nslots > 4 ? 2 : 1;
+            for (int64_t t = 0; t < sg.ntiles; t++)
+                if (c.seg_aff[((size_t)sg.aff + (size_t)t * nch) * 4] != 0xFFFFFFFFu) lay_inf -= (double)nch * (64 * 16 - 16);
+        }
         for (const Compiled::Segment &sg : c.segments)      // the table kernels key their generators by
             if (sg.ztab >= 0) {                              // position: no p_vid read; learning: no p_info either
                 lay_inf -= (double)sg.ntiles * 64 * 4;

@@ -80,8 +80,15 @@ struct Compiled {
     struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev;
                      int64_t ztab;         // first entry of the program's draw table, -1 = none
                      int64_t d16;          // first 8-byte unit of the compact (int16 delta) stream, -1 = none
-                     int32_t d16base; };   // member position = own position + d16base + delta
+                     int32_t d16base;      // member position = own position + d16base + delta
+                     int64_t aff; };       // first entry of the segment's tiles in seg_aff (-1: none)
     std::vector<Segment> segments;
+    // Implicit adjacency of table segments: a tile whose every member slot holds position
+    // (base of the slot) + lane -- the interior of a grid, where a class's neighbours are runs of the
+    // other class -- needs no stream: seg_aff holds one uint4 of slot bases per tile and 16-byte chunk
+    // (x = 0xFFFFFFFF: the tile is not of that form and reads its stream).  The member gathers of such
+    // a tile are contiguous 64-byte reads.
+    std::vector<uint32_t> seg_aff;
     // Draw tables (DESIGN.md "draw tables"): a uniform program whose lanes read binary members only
     // has 2^nslots possible neighbourhoods; per neighbourhood the draw threshold and the per-slot
     // satisfied bits are tabulated by k_refresh_ztab whenever weights change.
@@ -91,6 +98,8 @@ struct Compiled {
     bool values_regular = true;             // every initial value lies in [0, cardinality)
     bool has_ufo = false;                   // a reachable factor is UFO: values index its member list
     double grad_bound = 0.0;                // bound on |gradient sum| of one weight in one colour class
+    int grad_shift = 0;                     // gradients accumulate as Q(31+s).(32-s) fixed point: s > 0 when
+                                            // the bound reaches 2^30 (Q31.32 would overflow)
     std::vector<uint32_t> rest_tiles;       // tile indices relative to the phase's first tile
     // learning: the largest (kind, chunks) groups of a colour's segments run as segment launches of
     // their own (at most NSK_LEARN_SEG_LAUNCHES per colour); every other non-general tile is on

@@ -208,6 +208,10 @@ struct DevGraph {
     int32_t nweight;
     int32_t acc_copies;         // copies of G / K / T: NSK_XCDS (one per XCD) or 1
     int32_t packed_grad;        // integer gradients: visit counts ride in the low half of G (GradSink)
+    // gradients accumulate as fixed point Q(31+s).(32-s): s = 0 unless the bound on one weight's
+    // gradient sum in one class would overflow Q31.32 (nsk_compile.cpp grad_shift)
+    long long grad_mul;         // 2^(32-s)
+    double grad_inv;            // 2^-(32-s)
     // fast path: inlined adjacency streams (DESIGN.md "fast path") and a position-indexed tally
     const uint4 *adj;           // stream: chunk c of lane i of a tile at adj[off + 64*c + i]
     const uint4 *tiles;         // [nwb] {stream offset, words per lane, tile_hdr offset | PAD, entries}
@@ -224,6 +228,7 @@ struct DevGraph {
     uint8_t *sink;              // 1 KiB scratch: where padding lanes store (branch-free epilogues)
     const uint2 *adj16;         // compact streams of table segments: member ids as int16 deltas from
                                 //  the lane's own variable id, 4 per 8-byte unit
+    const uint4 *seg_aff;       // implicit adjacency of table segments: slot bases per tile (nsk_compile.h)
     const uint4 *ztab;          // draw tables of the uniform programs whose members are all binary:
                                 //  entry (program, neighbourhood bits) = {K lo, K hi, sat0 | sat1 << 8, 0}
                                 //  (k_refresh_ztab; DESIGN.md "draw tables")

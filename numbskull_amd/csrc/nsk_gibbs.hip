@@ -22,6 +22,65 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
     } else {
         const size_t nphase = g->c.phase_start.size() - 1;
         nsk_refresh_prog_weights(g);
+        // The segment launches of every colour, prepared once per call (a small graph's sweep is two
+        // 4 us kernels: rebuilding the tables per sweep made the host the bottleneck): segments batched
+        // by (kind, chunks) into tables of <= NSK_SEG_MAX; kind 8 = segments with draw tables (any
+        // function: the table encodes it)
+        typedef NskSegPlan SegPlan;
+        std::vector<std::vector<SegPlan>> &seg_plans = g->seg_plans;
+        const int plans_key = (sample_evidence ? 1 : 0) | (g->values_regular ? 2 : 0);
+        if (g->seg_plans_key != plans_key) {
+            g->seg_plans_key = plans_key;
+            seg_plans.assign(nphase, std::vector<SegPlan>());
+            const bool use_tab = g->values_regular;
+            for (size_t ph = 0; ph < nphase; ph++)
+                for (int kind = 0; kind <= 8; kind++) {
+                    if (kind == 1 || (kind > 4 && kind < 8)) continue;   // IMPLY_NATURAL shares the AND step (3)
+                    for (int nch = 1; nch <= 2; nch++) {
+                        SegTable tab;
+                        memset(&tab, 0, sizeof(tab));
+                        auto flush = [&]() {
+                            if (tab.n == 0) return;
+                            for (int i = tab.n; i < NSK_SEG_MAX; i++) tab.e[i].tile_start = tab.ntiles;
+                            seg_plans[ph].push_back(SegPlan{kind, nch, tab});
+                            memset(&tab, 0, sizeof(tab));
+                        };
+                        // largest segments first: the kernels find a tile's segment with a scan
+                        // whose first probe is the table's first entry
+                        std::vector<const Compiled::Segment *> mine;
+                        for (const Compiled::Segment &sg : g->c.segments) {
+                            if (sg.phase != (int)ph) continue;
+                            const int k3 = (use_tab && sg.ztab >= 0) ? 8 : sg.kind == 1 ? 3 : (int)sg.kind;
+                            if (k3 != kind || (sg.nslots > 4 ? 2 : 1) != nch) continue;
+                            if (!(sg.ev == 0 || sample_evidence)) continue;      // inference.py:24
+                            mine.push_back(&sg);
+                        }
+                        std::stable_sort(mine.begin(), mine.end(), [](const Compiled::Segment *a, const Compiled::Segment *b) {
+                            return a->ntiles > b->ntiles; });
+                        for (const Compiled::Segment *sgp : mine) {
+                            const Compiled::Segment &sg = *sgp;
+                            SegEntry &en = tab.e[tab.n];
+                            // table launches number their tiles virtually: a segment starts on a pair
+                            // boundary (positions 128 m), with one dead tile in front when needed
+                            const int lead = kind >= 8 ? (int)((sg.pos0 / 64) & 1) : 0;
+                            const int vtiles = kind >= 8 ? ((sg.ntiles + lead + 1) & ~1) : sg.ntiles;
+                            en.ntiles_lead = (uint32_t)sg.ntiles | ((uint32_t)lead << 30);
+                            en.tile_start = tab.ntiles;
+                            en.pos0 = (int)sg.pos0;
+                            en.adj_off = sg.adj_off;
+                            en.prog = sg.prog;
+                            en.zoff = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
+                            en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8);
+                            en.d16off = sg.d16 >= 0 ? (uint32_t)sg.d16 : NSK_NO_D16_STREAM;
+                            en.d16base = sg.d16base;
+                            en.aff_off = (kind >= 8 && sg.aff >= 0) ? (uint32_t)sg.aff : NSK_NO_D16_STREAM;
+                            tab.ntiles += vtiles;
+                            if (++tab.n == NSK_SEG_MAX) flush();
+                        }
+                        flush();
+                    }
+                }
+        }
         for (int64_t s = 0; s < nsweeps; s++) {
             for (size_t ph = 0; ph < nphase; ph++) {
                 const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
@@ -103,68 +162,26 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                             sample_evidence, burnin, K0, K1, S0, S1);
                         g->launches++;
                     }
-                    // segments of this colour, batched by (kind, chunks) into table launches
-                    // kind 8 = segments with draw tables (any function: the table encodes it)
-                    const bool use_tab = g->values_regular;
-                    for (int kind = 0; kind <= 8; kind++) {
-                        if (kind == 1 || (kind > 4 && kind < 8)) continue;   // IMPLY_NATURAL shares the AND step (3)
-                        for (int nch = 1; nch <= 2; nch++) {
-                            SegTable tab;
-                            memset(&tab, 0, sizeof(tab));
-                            auto flush = [&]() {
-                                if (tab.n == 0) return;
-                                for (int i = tab.n; i < NSK_SEG_MAX; i++) tab.e[i].tile_start = tab.ntiles;
-                                const int nb = (tab.ntiles + 3) / 4;
-                                const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
+                    // segments of this colour: the launches prepared before the sweep loop
+                    for (const SegPlan &pl : seg_plans[ph]) {
+                        const SegTable &tab = pl.tab;
+                        const int kind = pl.kind, nch = pl.nch;
+                        const int nb = (tab.ntiles + 3) / 4;
+                        const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
 #define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
-                                if (kind >= 8) {
-                                    // resident grid over tile pairs: at most 8 blocks per CU
-                                    const int npairs = tab.ntiles / 2;
-                                    const int nbp = std::min(2048, 8 * ((((npairs + 3) / 4) + 7) / 8));
-                                    if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
-                                    else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
-                                }
-                                else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
-                                else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
-                                else if (kind == 0) { if (nch == 1) NSK_SEG(0, 1); else NSK_SEG(0, 2); }
-                                else { if (nch == 1) NSK_SEG(3, 1); else NSK_SEG(3, 2); }
-#undef NSK_SEG
-                                g->launches++;
-                                memset(&tab, 0, sizeof(tab));
-                            };
-                            // largest segments first: the kernels find a tile's segment with a scan
-                            // whose first probe is the table's first entry
-                            std::vector<const Compiled::Segment *> mine;
-                            for (const Compiled::Segment &sg : g->c.segments) {
-                                if (sg.phase != (int)ph) continue;
-                                const int k3 = (use_tab && sg.ztab >= 0) ? 8 : sg.kind == 1 ? 3 : (int)sg.kind;
-                                if (k3 != kind || (sg.nslots > 4 ? 2 : 1) != nch) continue;
-                                if (!(sg.ev == 0 || sample_evidence)) continue;      // inference.py:24
-                                mine.push_back(&sg);
-                            }
-                            std::stable_sort(mine.begin(), mine.end(), [](const Compiled::Segment *a, const Compiled::Segment *b) {
-                                return a->ntiles > b->ntiles; });
-                            for (const Compiled::Segment *sgp : mine) {
-                                const Compiled::Segment &sg = *sgp;
-                                SegEntry &en = tab.e[tab.n];
-                                // table launches number their tiles virtually: a segment starts on a pair
-                                // boundary (positions 128 m), with one dead tile in front when needed
-                                const int lead = kind >= 8 ? (int)((sg.pos0 / 64) & 1) : 0;
-                                const int vtiles = kind >= 8 ? ((sg.ntiles + lead + 1) & ~1) : sg.ntiles;
-                                en.ntiles_lead = (uint32_t)sg.ntiles | ((uint32_t)lead << 30);
-                                en.tile_start = tab.ntiles;
-                                en.pos0 = (int)sg.pos0;
-                                en.adj_off = sg.adj_off;
-                                en.prog = sg.prog;
-                                en.zoff = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
-                                en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8);
-                                en.d16off = sg.d16 >= 0 ? (uint32_t)sg.d16 : NSK_NO_D16_STREAM;
-                                en.d16base = sg.d16base;
-                                tab.ntiles += vtiles;
-                                if (++tab.n == NSK_SEG_MAX) flush();
-                            }
-                            flush();
+                        if (kind >= 8) {
+                            // resident grid over tile pairs: at most 8 blocks per CU
+                            const int npairs = tab.ntiles / 2;
+                            const int nbp = std::min(2048, 8 * ((((npairs + 3) / 4) + 7) / 8));
+                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
+                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
                         }
+                        else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
+                        else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
+                        else if (kind == 0) { if (nch == 1) NSK_SEG(0, 1); else NSK_SEG(0, 2); }
+                        else { if (nch == 1) NSK_SEG(3, 1); else NSK_SEG(3, 2); }
+#undef NSK_SEG
+                        g->launches++;
                     }
                     const int nrest = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
                     if (nrest > 0 && !rest_in_general) {

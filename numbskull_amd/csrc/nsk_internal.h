@@ -26,8 +26,14 @@ int fail(int code, const std::string &msg);       // records nsk_last_error, ret
             return nsk::fail(NSK_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));  \
     } while (0)
 
+struct NskSegPlan { int kind, nch; nsk::SegTable tab; };       // one prepared segment launch (nsk_gibbs.hip)
+
 struct nsk_graph {
     nsk::Compiled c;
+    // the inference sweep's segment launches per colour, kept across calls (the N-rank loops sweep one
+    // epoch per call); key = sample_evidence | draw tables usable << 1
+    std::vector<std::vector<NskSegPlan>> seg_plans;
+    int seg_plans_key = -1;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -56,6 +62,7 @@ struct nsk_graph {
     uint32_t *tile_wrow = nullptr;
     uint4 *ztab = nullptr;              // draw tables (k_refresh_ztab)
     uint32_t *adj16 = nullptr;          // compact streams of table segments
+    uint32_t *seg_aff = nullptr;        // implicit adjacency of table segments
     uint8_t *sink = nullptr;            // scratch line for padding lanes' stores
     uint32_t *hub_desc = nullptr, *hub_adj = nullptr;   // entry-parallel hub streams
     uint32_t *ep_desc = nullptr, *ep_adj = nullptr;     // entry-parallel groups of general tiles
@@ -130,6 +137,8 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.part_G = g->part_G; d.part_K = g->part_K; d.part_T = g->part_T;
     d.nweight = (int32_t)g->c.nweight;
     d.packed_grad = g->c.packed_grad ? 1 : 0;
+    d.grad_mul = 1ll << (32 - g->c.grad_shift);
+    d.grad_inv = 1.0 / (double)d.grad_mul;
     d.acc_copies = g->acc_copies;
     d.cnt_pos = g->cnt_pos;
     d.ztab = g->ztab;
@@ -138,6 +147,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.ep_desc = (const uint4 *)g->ep_desc; d.ep_adj = g->ep_adj; d.bighub_pos = g->bighub_pos;
     d.ep_wrow = g->ep_wrow; d.ep_wt = g->ep_wt;
     d.adj16 = (const uint2 *)g->adj16;
+    d.seg_aff = (const uint4 *)g->seg_aff;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
     return d;

@@ -1360,7 +1360,8 @@ struct SegEntry {                         // 48 bytes: two scalar loads per tile
     int d16base;                          // member position = own position + d16base + int16 delta
     uint32_t ntiles_lead;                 // table launches: tiles of the segment | lead << 30 (one dead
                                           //   virtual tile in front: the segment starts on an upper half)
-    uint32_t pad_[3];
+    uint32_t aff_off;                     // first entry of the segment's tiles in seg_aff, NSK_NO_D16_STREAM: none
+    uint32_t pad_[2];
 };
 struct SegTable {
     int n, ntiles;                        // segments, tiles of the launch; e[i].tile_start = ntiles for i >= n
@@ -1528,11 +1529,24 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
             if (u16) {
                 d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16[k]);
             } else {
-                const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+                // implicit adjacency: the tile's slot bases by scalar loads, member = base + lane
+                uint32_t ab[4 * NCH];
+                ab[0] = NSK_NO_D16_STREAM;
+                if (en.aff_off != NSK_NO_D16_STREAM) {
+                    const NSK_SCALAR uint32_t *ap = (const NSK_SCALAR uint32_t *)(g.seg_aff + en.aff_off + (size_t)t * NCH);
 #pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    const uint4 q = sp[c * 64];
-                    id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+                    for (int j = 0; j < 4 * NCH; j++) ab[j] = ap[j];
+                }
+                if (ab[0] != NSK_NO_D16_STREAM) {               // wave-uniform
+#pragma unroll
+                    for (int j = 0; j < 4 * NCH; j++) id[k][j] = ab[j] + (uint32_t)lane;
+                } else {
+                    const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) {
+                        const uint4 q = sp[c * 64];
+                        id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+                    }
                 }
             }
             tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl];

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NSK_BLOCK, NSK_GENERIC_LEARN_WAVES) void k_learn_ph
                     const double p0 = eval_factor(g, rec, mb, self, evidence, g.val_evid);
                     const double p1 = eval_factor(g, rec, mb, self, proposal, g.val);
                     const double gradient = (p1 - p0) * feat;                                     // 109
-                    gfix = __double2ll_rn(gradient * NSK_GRAD_SCALE);
+                    gfix = __double2ll_rn(gradient * (double)g.grad_mul);
                     have = true;
                 }
             }
@@ -201,7 +201,7 @@ __device__ __forceinline__ void learn_heavy_variable(const DevGraph<VT> &g, cons
             if (!dup && !g.w_fixed[wid]) {
                 const double p0 = eval_factor(g, rec, g.m_rec, p, evidence, g.val_evid);
                 const double p1 = eval_factor(g, rec, g.m_rec, p, proposal, g.val);
-                gfix = __double2ll_rn(((p1 - p0) * g.f_feat[fid]) * NSK_GRAD_SCALE);
+                gfix = __double2ll_rn(((p1 - p0) * g.f_feat[fid]) * (double)g.grad_mul);
                 have = true;
             }
         }
@@ -243,7 +243,7 @@ __device__ __forceinline__ void learn_heavy_variable_ep(const DevGraph<VT> &g, c
         const long long diff = (long long)(proposal == ef.cstar ? ef.A : ef.B) -
                                (long long)(evidence == ee.cstar ? ee.A : ee.B);
         const bool have = rr * 64 + lane < n && mine && !g.w_fixed[ef.wid];                        // 100-101
-        accumulate_gradient(sk, have, (int)ef.wid, diff * 4294967296ll, truncate);
+        accumulate_gradient(sk, have, (int)ef.wid, diff * g.grad_mul, truncate);
     }
 }
 
@@ -375,7 +375,7 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
             const int nf = __popcll(__ballot(part && ((satf >> j) & 1u)));
             const int ne = __popcll(__ballot(part && ((sate >> j) & 1u)));
             if ((threadIdx.x & 63) == 0) {
-                const long long dG = (span * (long long)(nf - ne)) << 32;            // Q31.32
+                const long long dG = (span * (long long)(nf - ne)) * g.grad_mul;     // Q31.32
                 const int wid = (int)(s & 0xFFFFFFu);
                 sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)nk : 0)));
                 if (!sk.packed) sink_add(sk.local, &sk.K[wid], nk);
@@ -498,7 +498,7 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
                 const long long span = cd == 0u ? 0 : (cd == 1u ? 1 : 2);          // hi - lo
                 const bool have = part && !g.w_fixed[wid];
                 const long long diff = (long long)((satf >> e2) & 1u) - (long long)((sate >> e2) & 1u);
-                accumulate_gradient(sk, have, wid, (span * diff) << 32, truncate);
+                accumulate_gradient(sk, have, wid, (span * diff) * g.grad_mul, truncate);
             }
         }
     }
@@ -583,7 +583,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
 #ifdef NSK_ABL_NOATOMIC
             if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
 #else
-            accumulate_gradient(sk, have, (int)wid, diff * 4294967296ll, truncate);
+            accumulate_gradient(sk, have, (int)wid, diff * g.grad_mul, truncate);
 #endif
         });
         return;
@@ -600,7 +600,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
 #ifdef NSK_ABL_NOATOMIC
                                if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
 #else
-                               accumulate_gradient(sk, have, (int)wid, diff * 4294967296ll, truncate);
+                               accumulate_gradient(sk, have, (int)wid, diff * g.grad_mul, truncate);
 #endif
                            });
 }
@@ -662,8 +662,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
 // k * step because every visit sees the weight the previous one left).  cap <= 0: no clipping.
 __device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
                                                int regularization, double reg_param, double truncation,
-                                               double cap, unsigned int *clipped) {
-    const double Gf = (double)G * (1.0 / 4294967296.0);
+                                               double cap, unsigned int *clipped, double grad_inv) {
+    const double Gf = (double)G * grad_inv;
     if (cap > 0.0 && (double)k * step > cap) {
         step = cap / (double)k;
         if (clipped) atomicAdd(clipped, 1u);
@@ -707,6 +707,7 @@ struct ApplyArgs {
     uint4 *ztab;
     double cap;
     unsigned int *clipped;
+    double grad_inv;            // 2^-(fraction bits of the gradient sums)
 };
 
 // every thread of the launch's ONE block calls it
@@ -740,7 +741,7 @@ __device__ __forceinline__ void apply_bins_block(const ApplyArgs &aa) {
             double x = aa.w[i];
             if (K > 0) {
                 x = apply_update(x, G, (uint32_t)K, (uint32_t)T, aa.step, aa.regularization, aa.reg_param,
-                                 aa.truncation, aa.cap, aa.clipped);
+                                 aa.truncation, aa.cap, aa.clipped, aa.grad_inv);
                 aa.w[i] = x;
             }
             sw[i] = x;
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
                 if (closes && !fixed && lane == 0) {
                     const uint32_t code = (s >> 24) & 7u;
                     const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
-                    const long long dG = (span * (long long)acc[j]) << 32;                   // Q31.32
+                    const long long dG = (span * (long long)acc[j]) * g.grad_mul;            // Q31.32
                     const int wid = (int)(s & 0xFFFFFFu);
                     sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)accK : 0)));
                     if (!sk.packed) sink_add(sk.local, &sk.K[wid], accK);
@@ -1044,7 +1045,7 @@ __device__ __forceinline__ void block_hub_learn(const DevGraph<VT> &g, const Gra
         const long long diff = (long long)(proposal == ef.cstar ? ef.A : ef.B) -
                                (long long)(evidence == ee.cstar ? ee.A : ee.B);
         const bool have = rr * 64 + lane < n && mine && !g.w_fixed[ef.wid];                        // 100-101
-        accumulate_gradient(sk, have, (int)ef.wid, diff * 4294967296ll, truncate);
+        accumulate_gradient(sk, have, (int)ef.wid, diff * g.grad_mul, truncate);
     }
 }
 
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbeg
 #ifdef NSK_ABL_NOATOMIC
                 if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
 #else
-                accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * 4294967296ll, (sv & 512u) != 0u);
+                accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * g.grad_mul, (sv & 512u) != 0u);
 #endif
             });
     };
@@ -1210,7 +1211,7 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, l
                                                              uint32_t *T, int nweight, double step,
                                                              int regularization, double reg_param,
                                                              double truncation, int packed, double cap,
-                                                             unsigned int *clipped, int copies) {
+                                                             unsigned int *clipped, int copies, double grad_inv) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= nweight) return;
     long long gsum = 0;
@@ -1236,7 +1237,7 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, l
         }
     }
     if (k == 0) return;                 // untouched in this class
-    w[i] = apply_update(w[i], gsum, (uint32_t)k, (uint32_t)t, step, regularization, reg_param, truncation, cap, clipped);
+    w[i] = apply_update(w[i], gsum, (uint32_t)k, (uint32_t)t, step, regularization, reg_param, truncation, cap, clipped, grad_inv);
 }
 
 }  // namespace nsk

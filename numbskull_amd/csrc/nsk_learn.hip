@@ -47,7 +47,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             aa.truncation = (double)truncation; aa.prog = g->tile_hdr; aa.prog_w = g->prog_w;
             aa.nprog = g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0; aa.zp = g->zprogs;
             aa.nzp = tabs_here ? (int)g->c.zprogs.size() : 0; aa.nztab = tabs_here ? (int)g->c.nztab : 0;
-            aa.ztab = g->ztab; aa.cap = g->learn_cap; aa.clipped = g->clip_count;
+            aa.ztab = g->ztab; aa.cap = g->learn_cap; aa.clipped = g->clip_count; aa.grad_inv = d.grad_inv;
             if (e > he) {               // variables outside the fast path: generic kernel, range mode
                 const int nitems = (e - he + 63) / 64;
                 const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
@@ -128,6 +128,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                     en.zoff = sl.zoff[i];
                     en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
                     en.d16off = sl.d16off[i]; en.d16base = sl.d16base[i];
+                    en.aff_off = NSK_NO_D16_STREAM;          // (the learning table kernel reads the stream)
                 }
                 tab.ntiles = use_tab ? vt : sl.tile_start[sl.n];
                 const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
@@ -167,7 +168,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
                         g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation,
-                        (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies);
+                        (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies, d.grad_inv);
                     nsk_refresh_prog_weights(g, true);
                 }
             }
@@ -209,10 +210,11 @@ extern "C" int nsk_learn_sweeps(nsk_graph *g, int64_t nsweeps, double step, doub
     if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
     if (regularization == 1 && truncation == 0) return fail(NSK_E_INVALID, "truncation must be non-zero (ZeroDivisionError in the reference)");
     if (nsweeps == 0) return NSK_OK;
-    // chromatic learning sums a class's gradients as Q31.32 fixed point (order-free, deterministic)
-    if (g->scan == NSK_SCAN_CHROMATIC && g->c.grad_bound >= 1073741824.0)
-        return fail(NSK_E_RANGE, "the gradient sum of one weight in one colour class can exceed the Q31.32 "
-                                 "accumulator (|featureValue| x visits >= 2^30); rescale featureValue or "
+    // chromatic learning sums a class's gradients as fixed point (order-free, deterministic): Q31.32, or
+    // Q(31+s).(32-s) when the bound on one weight's sum reaches 2^30 (nsk_compile.cpp grad_shift)
+    if (g->scan == NSK_SCAN_CHROMATIC && g->c.grad_bound >= 1073741824.0 * 4294967296.0)
+        return fail(NSK_E_RANGE, "the gradient sum of one weight in one colour class can exceed a 63-bit integer "
+                                 "accumulator (|featureValue| x visits >= 2^62); rescale featureValue or "
                                  "use the sequential scan");
     HIPCHECK(hipSetDevice(g->device));
     return g->c.vbytes == 1

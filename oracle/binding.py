@@ -21,7 +21,8 @@ class _Graph(C.Structure):
                 ("nedge", C.c_int64), ("nvtf", C.c_int64),
                 ("weight", C.c_void_p), ("variable", C.c_void_p), ("factor", C.c_void_p),
                 ("fmap", C.c_void_p), ("vmap", C.c_void_p), ("factor_index", C.c_void_p),
-                ("head_by_vid", C.c_int), ("rng_id", C.c_void_p), ("rng_tag", C.c_uint32)]
+                ("head_by_vid", C.c_int), ("rng_id", C.c_void_p), ("grad_shift", C.c_int),
+                ("rng_tag", C.c_uint32)]
 
 
 class _MT(C.Structure):
@@ -108,7 +109,7 @@ class Graph:
         self.g = _Graph(len(self.variable), len(self.factor), len(self.weight), len(self.fmap),
                         len(self.vmap), self.weight.ctypes.data, self.variable.ctypes.data,
                         self.factor.ctypes.data, self.fmap.ctypes.data, self.vmap.ctypes.data,
-                        self.factor_index.ctypes.data, int(bool(head_by_vid)), None, 0)
+                        self.factor_index.ctypes.data, int(bool(head_by_vid)), None, 0, 0)
         self.rng_id = None
         card = self.variable["cardinality"]
         self.cstart = np.zeros(len(card) + 1, np.int64)
@@ -126,6 +127,11 @@ class Graph:
             self.rng_id = np.ascontiguousarray(ids, np.int64)
             assert len(self.rng_id) == len(self.variable)
             self.g.rng_id = self.rng_id.ctypes.data
+
+    def set_grad_shift(self, s):
+        """Device-mode learning: fraction bits traded for range in the fixed-point gradient sums
+        (nsk_graph_info.grad_shift)."""
+        self.g.grad_shift = int(s)
 
     def set_rng_tag(self, tag):
         """Device mode: the shard tag of the emulated handle (its first owned variable id; 0 for a

@@ -658,7 +658,7 @@ static int accumulate_visit(const orc_graph *g, int64_t fid, int64_t v, int64_t 
     rc = orc_eval_factor(g, fid, v, proposal, var_value, &p1);
     if (rc) return rc;
     double gradient = (p1 - p0) * g->factor[fid].featureValue;
-    G[wid] += (int64_t)llrint(gradient * 4294967296.0);
+    G[wid] += (int64_t)llrint(gradient * ldexp(1.0, 32 - g->grad_shift));
     K[wid] += 1;
     if (truncate) T[wid] += 1;
     return ORC_OK;
@@ -724,7 +724,7 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
         /* end of phase: apply the batch to every touched weight */
         for (int64_t w = 0; w < g->nweight; w++) {
             if (K[w] == 0) continue;
-            double Gf = (double)G[w] * (1.0 / 4294967296.0);
+            double Gf = (double)G[w] * ldexp(1.0, g->grad_shift - 32);
             double x = weight_value[w];
             /* device-mode step cap: K visits at `step` move the weight by K * step * mean gradient;
              * beyond `cap` the class uses cap / K (DESIGN.md "device-mode learning") */

@@ -794,6 +794,34 @@ def test_shards_draw_from_disjoint_generator_streams(learn):
         assert 0.45 < float(v.mean()) < 0.55
 
 
+@pytest.mark.parametrize("reg", [0, 2])
+def test_large_feature_values_widen_the_gradient_accumulator(reg):
+    """featureValue 1000 on one weight shared by 319 200 factors: the bound on the weight's gradient
+    sum in one colour class (|featureValue| x span x arity x factors = 1.3e9) exceeds Q31.32, which
+    round 2 refused (NSK_E_RANGE).  The sums now trade fraction bits for range -- Q(31+s).(32-s),
+    nsk_graph_info.grad_shift -- stay integer (order-free, deterministic) and the oracle mirrors the
+    scale: weights bit-exact.  The reference accumulates in float64 (learning.py:109)."""
+    rng = np.random.default_rng(4)
+    g = list(graphgen.ising_grid(400, 400, weight=0.0, fixed=False, evidence=rng.integers(0, 2, 160000)))
+    fac = g[2].copy()
+    fac["featureValue"] = 1000.0
+    g[2] = fac
+    ns, fg = session(tuple(g), seed=3)
+    info = fg.info()
+    assert info["grad_shift"] >= 1
+    fg.learn(0, 3, 1e-9, 0.9, reg, 0.01, 1)
+    og = oracle_of(fg)
+    assert og.g.grad_shift == info["grad_shift"]
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, _ = og.initial_state()
+    step = 1e-9
+    for s in range(3):
+        assert og.learn_dev(order, ps, vv, ve, wv, step, reg, 0.01, 1, False, 3, s) == 0
+        step *= 0.9
+    assert np.array_equal(fg.weight_value[0], wv), (fg.weight_value[0], wv)
+    assert np.array_equal(fg.var_value[0], vv) and wv[0] != 0.0
+
+
 def test_native_rccl_loop_single_rank():
     """nsk_comm_init + nsk_gibbs_sweeps_exchange / nsk_learn_sweeps_exchange with a 1-rank
     communicator: the native loop (sweep, pack, ncclAllGather, unpack, ncclAllReduce of weight
