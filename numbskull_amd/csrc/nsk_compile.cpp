@@ -1613,6 +1613,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
                     t.d16off[t.n] = sg.d16 >= 0 ? (uint32_t)sg.d16 : 0xFFFFFFFFu;
                     t.d16base[t.n] = sg.d16base;
+                    t.aff[t.n] = sg.aff >= 0 ? (uint32_t)sg.aff : 0xFFFFFFFFu;
                     t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
                     t.zmask[t.n] = (1u << sg.nslots) - 1u;
                     t.ev[t.n] = sg.ev;
@@ -1868,10 +1869,13 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             if (sg.d16 >= 0)                                 // stream when there is one
                 lay_inf -= (double)sg.ntiles * 64 * 8 * (sg.nslots > 4 ? 2 : 1);
         for (const Compiled::Segment &sg : c.segments) {    // inference over table segments: a tile with implicit
-            if (sg.aff < 0 || sg.d16 >= 0) continue;         // adjacency reads 16 bytes per chunk, not 64 x 16
+            if (sg.aff < 0) continue;                        // adjacency reads 16 bytes per chunk, not 64 x 16
             const int nch = sg.nslots > 4 ? 2 : 1;
             for (int64_t t = 0; t < sg.ntiles; t++)
-                if (c.seg_aff[((size_t)sg.aff + (size_t)t * nch) * 4] != 0xFFFFFFFFu) lay_inf -= (double)nch * (64 * 16 - 16);
+                if (c.seg_aff[((size_t)sg.aff + (size_t)t * nch) * 4] != 0xFFFFFFFFu) {
+                    if (sg.d16 < 0) lay_inf -= (double)nch * (64 * 16 - 16);     // (a compact stream is read instead)
+                    lay_learn -= (double)nch * (64 * 16 - 16);
+                }
         }
         for (const Compiled::Segment &sg : c.segments)      // the table kernels key their generators by
             if (sg.ztab >= 0) {                              // position: no p_vid read; learning: no p_info either

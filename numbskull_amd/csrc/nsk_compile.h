@@ -105,7 +105,7 @@ struct Compiled {
     // their own (at most NSK_LEARN_SEG_LAUNCHES per colour); every other non-general tile is on
     // the colour's learn_rest list
     struct SegLaunch { int32_t phase, kind, nch, n, tab; int32_t tile_start[9]; int32_t pos0[8];
-                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], d16off[8]; int32_t ev[8], d16base[8]; };
+                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], d16off[8], aff[8]; int32_t ev[8], d16base[8]; };
     std::vector<SegLaunch> learn_seg;
     std::vector<uint32_t> learn_rest_tiles;
     std::vector<int64_t> phase_learn_rest_base;   // [ncolors+1]

@@ -1157,29 +1157,40 @@ __device__ __forceinline__ int ep_group(const EpWalk &wk, int li, int ngroups) {
 template <typename VT>
 __device__ __forceinline__ double block_hub_potentials(const DevGraph<VT> &g, const uint8_t *lut, const uint4 hd,
                                                        const VT *val, double *ws, uint16_t *fs) {
+    // LDS per round of NSK_HUB_CHUNK entries: the two possible terms of an entry (weight x A, weight x B:
+    // the products potential() forms) in ws[0 .. CHUNK) / ws[CHUNK .. 2 CHUNK), owner | cstar << 4 in fs
+    constexpr int CHUNK = NSK_EP_LIST * 128;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int n = (int)hd.y, M = (int)(hd.z & 0xFFu), rows = 2 + M;
     const uint32_t *base = g.hub_adj + hd.x;
     double pc = 0.0;
-    for (int c0 = 0; c0 < n; c0 += NSK_EP_LIST * 256) {
-        const int cn = min(NSK_EP_LIST * 256, n - c0);
+    for (int c0 = 0; c0 < n; c0 += CHUNK) {
+        const int cn = min(CHUNK, n - c0);
         __syncthreads();                                   // (wave 0 is done with the previous round)
         for (int r = wave; r * 64 < cn; r += NSK_BLOCK / 64) {
             HubEntry en;
             hub_entry(g, lut, base, rows, c0 / 64 + r, M, val, true, en);
-            ws[r * 64 + lane] = en.w;
-            fs[r * 64 + lane] = (uint16_t)(((en.d1 >> 14) & 15u) | (ep_facts(en.cstar, en.A, en.B) << 4));
+            ws[r * 64 + lane] = en.w * (double)en.A;
+            ws[CHUNK + r * 64 + lane] = en.w * (double)en.B;
+            fs[r * 64 + lane] = (uint16_t)(((en.d1 >> 14) & 15u) | (((uint32_t)en.cstar > 15u ? 15u : (uint32_t)en.cstar) << 4));
         }
         __syncthreads();
         if (wave == 0)
-            for (int i = 0; i < cn; i++) {                 // list order
-                const uint32_t f = fs[i];
-                const double w = ws[i];
-                const int ks = (int)(f & 15u), cstar = (int)((f >> 4) & 15u);
-                const double tA = w * (double)((int)((f >> 8) & 3u) - 1), tB = w * (double)((int)((f >> 10) & 3u) - 1);
-                const bool on = ks == 15 || ks == lane;
-                const double t = on ? (lane == cstar ? tA : tB) : 0.0;       // +0.0 leaves the sum unchanged
-                pc = pc + t;
+            for (int i0 = 0; i0 < cn; i0 += 16) {          // list order; 16 entries' LDS reads in flight at a time
+                double tA[16], tB[16];
+                uint32_t f[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) {             // (entries past cn: the round's padding, owner 14, or
+                    const int i = min(i0 + j, cn - 1);     //  a repeat that is masked below)
+                    tA[j] = ws[i]; tB[j] = ws[CHUNK + i]; f[j] = fs[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int ks = (int)(f[j] & 15u), cstar = (int)((f[j] >> 4) & 15u);
+                    const bool on = i0 + j < cn && (ks == 15 || ks == lane);
+                    const double t = on ? (lane == cstar ? tA[j] : tB[j]) : 0.0;     // +0.0 leaves the sum unchanged
+                    pc = pc + t;
+                }
             }
     }
     return pc;                                             // meaningful in wave 0

@@ -850,7 +850,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
     };
     // the segment of the last located trip stays in scalar registers: most launches have one
     int c_lo = 0, c_hi = 0, c_pos = 0, c_nt = 1;
-    uint32_t c_adj = 0u, c_prog = 0u, c_zoff = 0u, c_zmask_ev = 0u;
+    uint32_t c_adj = 0u, c_prog = 0u, c_zoff = 0u, c_zmask_ev = 0u, c_aff = NSK_NO_D16_STREAM;
     auto issue = [&](int P, LearnTrip<NCH, TPW> &r, LearnTripInfo &ti) {
         const int T0 = P * TPW;
         if (T0 < c_lo || T0 >= c_hi) {                                  // wave-uniform, rare
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             c_lo = tab.e[sidx].tile_start;
             c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
             c_pos = tab.e[sidx].pos0; c_adj = tab.e[sidx].adj_off; c_prog = tab.e[sidx].prog;
-            c_zoff = tab.e[sidx].zoff; c_zmask_ev = tab.e[sidx].zmask_ev;
+            c_zoff = tab.e[sidx].zoff; c_zmask_ev = tab.e[sidx].zmask_ev; c_aff = tab.e[sidx].aff_off;
             c_nt = (int)(tab.e[sidx].ntiles_lead & 0x3FFFFFFFu);
         }
         ti.pos = c_pos; ti.nt = c_nt; ti.t0 = T0 - c_lo; ti.prog = c_prog; ti.zoff = c_zoff;
@@ -866,11 +866,24 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             const int t = min(ti.t0 + k, c_nt - 1);                    // a dead tile re-reads the last one
-            const uint4 *sp = g.adj + c_adj + (size_t)t * (64 * NCH) + lane;
+            // implicit adjacency (nsk_compile.h seg_aff): slot bases by scalar loads, member = base + lane
+            uint32_t ab[4 * NCH];
+            ab[0] = NSK_NO_D16_STREAM;
+            if (c_aff != NSK_NO_D16_STREAM) {
+                const NSK_SCALAR uint32_t *ap = (const NSK_SCALAR uint32_t *)(g.seg_aff + c_aff + (size_t)t * NCH);
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const uint4 q = sp[c * 64];
-                r.id[k][4 * c] = q.x; r.id[k][4 * c + 1] = q.y; r.id[k][4 * c + 2] = q.z; r.id[k][4 * c + 3] = q.w;
+                for (int j = 0; j < 4 * NCH; j++) ab[j] = ap[j];
+            }
+            if (ab[0] != NSK_NO_D16_STREAM) {                           // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4 * NCH; j++) r.id[k][j] = ab[j] + (uint32_t)lane;
+            } else {
+                const uint4 *sp = g.adj + c_adj + (size_t)t * (64 * NCH) + lane;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const uint4 q = sp[c * 64];
+                    r.id[k][4 * c] = q.x; r.id[k][4 * c + 1] = q.y; r.id[k][4 * c + 2] = q.z; r.id[k][4 * c + 3] = q.w;
+                }
             }
             r.init[k] = (int)g.p_init[c_pos + t * 64 + lane];          // -1: padding lane at a class end
         }

@@ -128,7 +128,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                     en.zoff = sl.zoff[i];
                     en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
                     en.d16off = sl.d16off[i]; en.d16base = sl.d16base[i];
-                    en.aff_off = NSK_NO_D16_STREAM;          // (the learning table kernel reads the stream)
+                    en.aff_off = use_tab ? sl.aff[i] : NSK_NO_D16_STREAM;     // implicit adjacency (table kernel)
                 }
                 tab.ntiles = use_tab ? vt : sl.tile_start[sl.n];
                 const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
