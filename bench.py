@@ -273,10 +273,8 @@ def dominant_kernel(workload, learning, info):
     """Name of the kernel family the launch average is dominated by (profiles/*_kernel_stats.csv)."""
     if not info["nfast"]:
         return "k_learn_phase" if learning else "k_gibbs_phase"
-    if workload.startswith("lr"):
-        return "k_learn_general" if learning else "k_gibbs_general"
-    if workload.startswith("boolw"):
-        return "k_learn_fast+k_learn_general" if learning else "k_gibbs_fast+k_gibbs_general"
+    if workload.startswith("lr") or workload.startswith("boolw"):
+        return "k_learn_ep" if learning else "k_gibbs_ep"          # entry-parallel groups (+ hubs, rest tiles)
     if info["ztab_entries"]:
         return "k_learn_seg_tab" if learning else "k_gibbs_seg_tab"
     return "k_learn_seg" if learning else "k_gibbs_seg"

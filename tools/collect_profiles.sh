@@ -8,8 +8,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 OUT=$R/gpurun_out/profiles_r3
 rm -rf $OUT; mkdir -p $OUT
 git_head=$(cat $R/.git_head 2>/dev/null || echo unknown)
-python bench.py > $OUT/r3_default_bench.json 2> $OUT/r3_default_bench.err
-echo "default bench rc $?"
 TRAFFIC=$OUT/traffic_parts; mkdir -p $TRAFFIC
 for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
   bash tools/profile_gpu.sh $WL > /dev/null 2>&1
@@ -17,25 +15,33 @@ for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_lea
   cp $P/summary.txt $OUT/r3_${WL}_summary.txt 2>/dev/null
   cp $P/summary.json $OUT/r3_${WL}_summary.json 2>/dev/null
   f=$(find $P/trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/r3_${WL}_kernel_stats.csv
-  grep -h '"metric"' $P/bench_trace.log > $OUT/r3_${WL}_bench.json
   cp $P/traffic_$WL.json $TRAFFIC/ 2>/dev/null
   echo "profiled $WL: $(grep -h 'dominant kernel' $P/summary.txt)"
+done
+# the HBM-traffic table first (bench.py prints it as roofline.traffic), then every bench line with it
+python - <<PY
+import json, glob, os
+out = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh (tools/profile_gpu.sh per workload), "
+                  "corrected with the known-byte stream-copy calibration of the same run; all workloads collected in the same "
+                  "gpurun call as the bench lines (commit: profiles/r3_COMMIT.txt); separate passes from the bench run"}
+for f in sorted(glob.glob("$TRAFFIC/traffic_*.json")):
+    out.update(json.load(open(f)))
+json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
+json.dump(out, open("$R/profiles/traffic.json", "w"), indent=1)
+print(json.dumps(out)[:600])
+PY
+python bench.py > $OUT/r3_default_bench.json 2> $OUT/r3_default_bench.err
+echo "default bench rc $?"
+for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
+  [ $WL = ising10m ] && continue        # (the default line)
+  python bench.py --workload $WL --steps 100 --warmup 10 --no-extra > $OUT/r3_${WL}_bench.json 2> /dev/null
+  echo "bench $WL rc $?"
 done
 for WL in ${NSK_PROFILE_BENCH_ONLY:-ising40m lr50m lr50m_learn}; do
   python bench.py --workload $WL --steps 10 --warmup 3 --no-extra > $OUT/r3_${WL}_bench.json 2> $OUT/r3_${WL}_bench.err
   echo "bench $WL rc $?"
 done
 NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/r3_two_ranks_one_device_bench.json 2>/dev/null
-python - <<PY
-import json, glob, os
-out = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh (tools/profile_gpu.sh per workload), "
-                  "corrected with the known-byte stream-copy calibration of the same run; all workloads collected in one "
-                  "gpurun call at the commit named in profiles/README.md; separate from the bench run"}
-for f in sorted(glob.glob("$TRAFFIC/traffic_*.json")):
-    out.update(json.load(open(f)))
-json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
-print(json.dumps(out)[:600])
-PY
 cp gpurun_out/config4_shards_*.json $OUT/ 2>/dev/null
 find $OUT -type f -size +2M -delete
 ls $OUT

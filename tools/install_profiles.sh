@@ -9,5 +9,6 @@ for f in profiles/r3_*; do [ -e "$f" ] && rm -f "$f"; done
 cp gpurun_out/profiles_r3/r3_* profiles/
 cp gpurun_out/profiles_r3/traffic.json profiles/traffic.json
 for f in gpurun_out/profiles_r3/config4_shards_*.json; do [ -e "$f" ] && cp "$f" profiles/r3_$(basename $f); done
+cp gpurun_out/profiles_r3_commit.txt profiles/r3_COMMIT.txt
 rm -f profiles/*.err
 ls profiles
