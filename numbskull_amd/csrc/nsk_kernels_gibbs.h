@@ -1511,9 +1511,13 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
 // class from 23.7 to 16.3 us.  (Requesting the next pair's stream words behind this pair's table
 // loads, as k_learn_seg_tab does, was measured here too: 10M grid 17.0 -> 19.7 us per class, 1M grid
 // 4.1 -> 3.8 us -- not kept.)
+#ifndef NSK_TAB_PP
+#define NSK_TAB_PP 1          // tile pairs a wave takes per step (10M grid, per class: 1 pair 14.7 us, 2 15.6, 3 16.8)
+#endif
 template <typename VT, int NCH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+    constexpr int PP = NSK_TAB_PP;
     const int lane = (int)(threadIdx.x & 63);
     const int npairs = tab.ntiles >> 1;                                 // virtual tiles: always even
     const int per = (npairs + 7) >> 3;                                  // pairs per XCD
@@ -1521,70 +1525,102 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
     const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
     const int pend = min(npairs, (xcd + 1) * per);
-    for (int P = xcd * per + wx; P < pend; P += wpx) {
-        const int sidx = seg_of_tile(tab, 2 * P);
-        const SegEntry en = tab.e[sidx];
-        const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu), lead = (int)(en.ntiles_lead >> 30);
-        const int t0 = 2 * P - en.tile_start - lead;                    // segment tile of the lower half
-        const bool u16 = en.d16off != NSK_NO_D16_STREAM;
-        bool live[2];
-        int p[2];
-        uint8_t tally[2];
-        uint32_t id[2][4 * NCH], w16[2][2 * NCH];
+    // the segment of the last located pair stays in scalar registers: most launches have one
+    int c_lo = 0, c_hi = -1;
+    SegEntry en = tab.e[0];
+    for (int P0 = xcd * per + wx; P0 < pend; P0 += PP * wpx) {
+        bool live[PP][2], on[PP];
+        int p[PP][2], pl[PP][2];
+        uint8_t tally[PP][2];
+        uint32_t id[PP][2][4 * NCH], zoff[PP], zmask[PP];
+        // stage 1: per pair the segment entry (cached), the slot bases (scalar loads) or stream words
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            live[k] = t0 + k >= 0 && t0 + k < nt;                       // wave-uniform
-            const int t = live[k] ? t0 + k : (t0 + k < 0 ? 0 : nt - 1);
-            p[k] = en.pos0 + (t0 + k) * 64 + lane;                      // the GENERATOR id keeps the pair's geometry
-            const int pl = en.pos0 + t * 64 + lane;                     // (a dead tile reads a real one's data)
-            if (u16) {
-                d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16[k]);
-            } else {
-                // implicit adjacency: the tile's slot bases by scalar loads, member = base + lane
-                uint32_t ab[4 * NCH];
-                ab[0] = NSK_NO_D16_STREAM;
-                if (en.aff_off != NSK_NO_D16_STREAM) {
-                    const NSK_SCALAR uint32_t *ap = (const NSK_SCALAR uint32_t *)(g.seg_aff + en.aff_off + (size_t)t * NCH);
+        for (int q = 0; q < PP; q++) {
+            const int P = P0 + q * wpx;
+            on[q] = P < pend;                                           // wave-uniform
+            const int Pc = on[q] ? P : P0;                              // (a dead pair repeats the first one's loads)
+            if (2 * Pc < c_lo || 2 * Pc >= c_hi) {                      // wave-uniform, rare
+                const int sidx = seg_of_tile(tab, 2 * Pc);
+                en = tab.e[sidx];
+                c_lo = en.tile_start;
+                c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
+            }
+            const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu), lead = (int)(en.ntiles_lead >> 30);
+            const int t0 = 2 * Pc - en.tile_start - lead;               // segment tile of the lower half
+            const bool u16 = en.d16off != NSK_NO_D16_STREAM;
+            const bool haff = !u16 && en.aff_off != NSK_NO_D16_STREAM;  // implicit adjacency (nsk_compile.h seg_aff)
+            zoff[q] = en.zoff; zmask[q] = en.zmask_ev & 0xFFu;
+            int tt[2];
+            uint32_t ab[2][4 * NCH];
 #pragma unroll
-                    for (int j = 0; j < 4 * NCH; j++) ab[j] = ap[j];
+            for (int k = 0; k < 2; k++) {
+                live[q][k] = on[q] && t0 + k >= 0 && t0 + k < nt;       // wave-uniform
+                tt[k] = (t0 + k >= 0 && t0 + k < nt) ? t0 + k : (t0 + k < 0 ? 0 : nt - 1);
+                p[q][k] = en.pos0 + (t0 + k) * 64 + lane;               // the GENERATOR id keeps the pair's geometry
+                pl[q][k] = en.pos0 + tt[k] * 64 + lane;                 // (a dead tile reads a real one's data)
+                ab[k][0] = NSK_NO_D16_STREAM;
+            }
+            if (haff) {                // both tiles' slot bases: scalar loads, issued together
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const NSK_SCALAR uint32_t *ap = (const NSK_SCALAR uint32_t *)(g.seg_aff + en.aff_off + (size_t)tt[k] * NCH);
+#pragma unroll
+                    for (int j = 0; j < 4 * NCH; j++) ab[k][j] = ap[j];
                 }
-                if (ab[0] != NSK_NO_D16_STREAM) {               // wave-uniform
+            }
 #pragma unroll
-                    for (int j = 0; j < 4 * NCH; j++) id[k][j] = ab[j] + (uint32_t)lane;
+            for (int k = 0; k < 2; k++) tally[q][k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[q][k]];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int t = tt[k];
+                if (u16) {
+                    uint32_t w16[2 * NCH];
+                    d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16);
+                    d16_ids<NCH>(w16, pl[q][k] + en.d16base, id[q][k]);
+                } else if (ab[k][0] != NSK_NO_D16_STREAM) {             // wave-uniform: member = base + lane
+#pragma unroll
+                    for (int j = 0; j < 4 * NCH; j++) id[q][k][j] = ab[k][j] + (uint32_t)lane;
                 } else {
                     const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
-                        const uint4 q = sp[c * 64];
-                        id[k][4 * c] = q.x; id[k][4 * c + 1] = q.y; id[k][4 * c + 2] = q.z; id[k][4 * c + 3] = q.w;
+                        const uint4 w = sp[c * 64];
+                        id[q][k][4 * c] = w.x; id[q][k][4 * c + 1] = w.y; id[q][k][4 * c + 2] = w.z; id[q][k][4 * c + 3] = w.w;
                     }
                 }
             }
-            tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl];
-            if (u16) d16_ids<NCH>(w16[k], pl + en.d16base, id[k]);
         }
-        uint32_t idx[2];
+        // stage 2: member values -> neighbourhood bits -> table entries
+        uint2 e[PP][2];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            idx[k] = 0;
+        for (int q = 0; q < PP; q++) {
+            uint32_t idx[2];
 #pragma unroll
-            for (int j = 0; j < 4 * NCH; j++) idx[k] |= ((uint32_t)g.val[id[k][j]] & 1u) << j;
-            idx[k] &= en.zmask_ev & 0xFFu;
+            for (int k = 0; k < 2; k++) {
+                idx[k] = 0;
+#pragma unroll
+                for (int j = 0; j < 4 * NCH; j++) idx[k] |= ((uint32_t)g.val[id[q][k][j]] & 1u) << j;
+                idx[k] &= zmask[q];
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) e[q][k] = *(const uint2 *)(g.ztab + zoff[q] + idx[k]);
         }
-        uint2 e[2];
+        // stage 3: draws and stores
 #pragma unroll
-        for (int k = 0; k < 2; k++) e[k] = *(const uint2 *)(g.ztab + en.zoff + idx[k]);
-        // p[0] is a multiple-of-128 block's lower half, p[1] = p[0] + 64 its upper half: one block
-        const u32x4 rr = philox4x32(k0, k1, inf_block((uint32_t)p[0]), 0u, s0, s1);
+        for (int q = 0; q < PP; q++) {
+            if (!on[q]) continue;
+            // p[0] is a multiple-of-128 block's lower half, p[1] = p[0] + 64 its upper half: one block
+            const u32x4 rr = philox4x32(k0, k1, inf_block((uint32_t)p[q][0]), 0u, s0, s1);
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const unsigned long long K = ((unsigned long long)e[k].y << 32) | e[k].x;
-            const int nv = (k == 0 ? k53(rr.x, rr.y) : k53(rr.z, rr.w)) > K ? 1 : 0;
-            VT *dst = live[k] ? g.val + p[k] : (VT *)g.sink + lane;     // (no branch: see seg_of_tile's note)
-            *dst = (VT)nv;
-            if (!burnin) {
-                uint8_t *td = live[k] ? g.cnt_pos + p[k] : g.sink + 256 + lane;
-                *td = (uint8_t)(tally[k] + nv);
+            for (int k = 0; k < 2; k++) {
+                const unsigned long long K = ((unsigned long long)e[q][k].y << 32) | e[q][k].x;
+                const int nv = (k == 0 ? k53(rr.x, rr.y) : k53(rr.z, rr.w)) > K ? 1 : 0;
+                VT *dst = live[q][k] ? g.val + p[q][k] : (VT *)g.sink + lane;     // (no branch: see seg_of_tile's note)
+                *dst = (VT)nv;
+                if (!burnin) {
+                    uint8_t *td = live[q][k] ? g.cnt_pos + p[q][k] : g.sink + 256 + lane;
+                    *td = (uint8_t)(tally[q][k] + nv);
+                }
             }
         }
     }
