@@ -202,7 +202,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
             if (c.phase_end[k] > c.phase_fast_end[k]) generic_needed = true;
         if (generic_needed || nsk::diag_env("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
     }
-    UP(w_fixed); UP(logtab); UP(adj); UP(adj16); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
+    UP(w_fixed); UP(logtab); UP(adj); UP(adj16); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes, nid = (size_t)c.nid;

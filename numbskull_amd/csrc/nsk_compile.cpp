@@ -1390,6 +1390,26 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 }
             }
         });
+        // structural visit counts (nsk_compile.h ep_kstat): global accumulators only (graphs with few
+        // weights accumulate in LDS tables, where an update costs nothing)
+        if (ngroups > 0 && nw > 256 && (int64_t)ncolors * nw * 2 <= ((int64_t)1 << 26) && !diag_env("NSK_NO_KSTAT")) {
+            c.ep_kstat.assign((size_t)ncolors * 2 * (size_t)nw, 0u);
+            std::vector<uint32_t> w;
+            for (int64_t gi = 0; gi < ngroups; gi++) {
+                int64_t p0, p1;
+                group_range(gi, p0, p1);
+                const int32_t k = group_colour[gi];
+                for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;
+                    const nsk_variable &var = d->variable[c.p_vid[p]];
+                    if (var.dataType != 0) continue;
+                    general_words(c.p_vid[p], &w);
+                    const size_t o = var.isEvidence == 1 ? 0 : 1;
+                    for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u))
+                        if (!c.w_fixed[w[j]]) c.ep_kstat[((size_t)k * 2 + o) * (size_t)nw + w[j]]++;
+                }
+            }
+        }
         if (verbose && ngroups)
             fprintf(stderr, "[nsk] entry-parallel groups %lld, stream %.1f MB\n", (long long)ngroups,
                     (double)subrows[ngroups] * 256 / 1e6);

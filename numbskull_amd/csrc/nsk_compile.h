@@ -128,6 +128,14 @@ struct Compiled {
     // slot, row-major: the inference kernels read an entry's weight next to its words; refreshed
     // whenever weights change); ep_wrow[ngroups] = rows in total
     std::vector<uint32_t> ep_desc, ep_adj, ep_wrow;
+    // Structural visit counts of the entry-parallel groups (learning): an entry of a dataType-0 variable
+    // is visited by sample_and_sgd in EVERY sweep its variable takes part in (learning.py:76-95: one
+    // list), so its contribution to the visit count K of its weight in its colour class is known here:
+    // ep_kstat[(2 k + o) * nweight + w] = entries of colour k with weight w (not fixed) whose variable
+    // is evidence (o = 0: takes part always) / is not (o = 1: only with learn_non_evidence).  The
+    // gradient pass then skips the accumulator update of such an entry when its gradient is 0 -- the
+    // common case -- and the weight update adds the structural count.  Empty: not used.
+    std::vector<uint32_t> ep_kstat;
     std::vector<int64_t> phase_ep_base;        // [ncolors+1] first group of each colour
     std::vector<uint8_t> phase_ep;             // [ncolors] 1: the colour's general tiles are laid out as groups
     std::vector<int32_t> phase_ep_emax;        // [ncolors] most entries of one of its variables

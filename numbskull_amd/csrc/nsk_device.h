@@ -236,6 +236,7 @@ struct DevGraph {
     const uint4 *ep_desc;       // entry-parallel groups of general tiles (nsk_compile.h ep_desc): one per
     const uint32_t *ep_adj;     //  256 positions; ep_adj: sub-rows of 64 words
     const uint32_t *ep_wrow;    // [groups + 1] first row of a group in ep_wt
+    const uint32_t *ep_kstat;   // structural visit counts (nsk_compile.h ep_kstat) or null
     double *ep_wt;              // materialised weights of the groups' entries: row r, lane i at ep_wt[64 r + i]
     const int32_t *iid_of_vid;  // variable id -> internal id (position; ghosts after the positions): the
                                 //  literal head lookup of the generic path needs it (uploaded only then)
@@ -760,8 +761,10 @@ __device__ __forceinline__ void sink_add(bool local, uint32_t *p, uint32_t v) {
 // Add one (weight, gradient) visit per participating lane.  Must be called by all 64 lanes of the
 // wave (converged); `have` marks participating lanes.  Lanes sharing the leader's weight id are
 // reduced in registers first.
+// `count`: the lane's visit adds to the visit count K (false: the visit is counted structurally by the
+// weight update, nsk_compile.h ep_kstat -- only its gradient is added).
 __device__ __forceinline__ void accumulate_gradient(const GradSink &sk, bool have, int wid,
-                                                    long long gfix, bool trunc) {
+                                                    long long gfix, bool trunc, bool count = true) {
     const unsigned long long mask = __ballot(have);
     if (mask == 0) return;
     const int leader = __ffsll((long long)mask) - 1;
@@ -772,16 +775,17 @@ __device__ __forceinline__ void accumulate_gradient(const GradSink &sk, bool hav
     if (nsame >= 4) {
         const long long sum = wave_sum_i64(same ? gfix : 0LL);
         const int nt = __popcll(__ballot(same && trunc));
+        const int nc = __popcll(__ballot(same && count));
         if ((int)(threadIdx.x & 63) == leader) {
-            sink_add(sk.local, (unsigned long long *)&sk.G[lw], (unsigned long long)(sum + (sk.packed ? nsame : 0)));
-            if (!sk.packed) sink_add(sk.local, &sk.K[lw], (uint32_t)nsame);
+            sink_add(sk.local, (unsigned long long *)&sk.G[lw], (unsigned long long)(sum + (sk.packed ? nc : 0)));
+            if (!sk.packed && nc) sink_add(sk.local, &sk.K[lw], (uint32_t)nc);
             if (nt) sink_add(sk.local, &sk.T[lw], (uint32_t)nt);
         }
         have = have && !same;
     }
     if (have) {
-        sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(gfix + (sk.packed ? 1 : 0)));
-        if (!sk.packed) sink_add(sk.local, &sk.K[wid], 1u);
+        sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(gfix + ((sk.packed && count) ? 1 : 0)));
+        if (!sk.packed && count) sink_add(sk.local, &sk.K[wid], 1u);
         if (trunc) sink_add(sk.local, &sk.T[wid], 1u);
     }
 }

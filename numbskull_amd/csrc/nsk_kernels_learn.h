@@ -17,6 +17,8 @@ struct LearnParams {
     double inv_trunc;
     uint32_t k0, k1, s0, s1;
     int hub0;                   // first hub descriptor of the colour class
+    int kstat;                  // the weight update adds the structural visit counts (nsk_compile.h ep_kstat):
+                                // entries of dataType-0 variables with a zero gradient skip the accumulators
 };
 
 // per-block accumulation tables in LDS (SMALLW) or the global accumulators
@@ -1132,12 +1134,15 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbeg
                 const int cf = (int)((f >> 4) & 15u), Af = (int)((f >> 8) & 3u) - 1, Bf = (int)((f >> 10) & 3u) - 1;
                 const int ce = (int)((f >> 12) & 15u), Ae = (int)((f >> 16) & 3u) - 1, Be = (int)((f >> 18) & 3u) - 1;
                 const long long diff = (long long)(proposal == cf ? Af : Bf) - (long long)(evidence == ce ? Ae : Be);
+                // (a dataType-0 entry's visit is counted structurally: with a zero gradient -- the common
+                // case -- it has nothing to add)
+                const bool counted = lp.kstat && ((d1 >> 14) & 15u) == 15u;
                 const bool have = (sv & 256u) && ((d1 >> 14) & 15u) != 14u && entry_visited(d1, evidence, proposal) &&
-                                  !(d1 >> 31);                                              // 100-101
+                                  !(d1 >> 31) && !(counted && diff == 0);                    // 100-101
 #ifdef NSK_ABL_NOATOMIC
                 if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
 #else
-                accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * g.grad_mul, (sv & 512u) != 0u);
+                accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * g.grad_mul, (sv & 512u) != 0u, !counted);
 #endif
             });
     };
@@ -1224,11 +1229,14 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, l
                                                              uint32_t *T, int nweight, double step,
                                                              int regularization, double reg_param,
                                                              double truncation, int packed, double cap,
-                                                             unsigned int *clipped, int copies, double grad_inv) {
+                                                             unsigned int *clipped, int copies, double grad_inv,
+                                                             const uint32_t *kstat_ev, const uint32_t *kstat_other) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
     if (i >= nweight) return;
     long long gsum = 0;
-    unsigned long long k = 0, t = 0;
+    // structural visit counts of the class (nsk_compile.h ep_kstat): visits the kernels did not count
+    unsigned long long k = (kstat_ev ? (unsigned long long)kstat_ev[i] : 0ull) +
+                           (kstat_other ? (unsigned long long)kstat_other[i] : 0ull), t = 0;
     for (int x = 0; x < copies; x++) {                  // the XCDs' private copies (cleared as they are read)
         const size_t at = (size_t)x * nweight + i;
         long long gx = G[at];
@@ -1239,7 +1247,7 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, l
             k += kx;
         } else {
             const uint32_t kx = K[at];
-            if (kx) { G[at] = 0; K[at] = 0; }
+            if (kx || gx) { G[at] = 0; K[at] = 0; }          // (a structurally counted visit adds to G only)
             k += kx;
         }
         gsum += gx;

@@ -25,6 +25,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
     lp.learn_non_evidence = learn_non_evidence;
     lp.inv_trunc = 1.0 / (double)truncation;
     lp.k0 = (uint32_t)g->seed; lp.k1 = (uint32_t)(g->seed >> 32);
+    lp.kstat = 0;
     g->adj_wt_skip = true;          // the learning kernels gather weights themselves
     nsk_refresh_prog_weights(g);
     for (int64_t s = 0; s < nsweeps; s++) {
@@ -78,6 +79,11 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             // launch of the 8-candidate kernel on the main stream (+10 % over two concurrent launches)
             const bool one_lg = gtb > gt0;
             const bool ep = fe > fb && g->c.phase_ep[ph] && ntiles > gt0;
+            // structural visit counts: the entry-parallel launch skips zero-gradient visits of dataType-0
+            // variables and the weight update adds their counts (not with L1: its truncation coins are
+            // counted per visit)
+            const bool kstat_here = ep && !SMALLW && d.ep_kstat != nullptr && regularization != 1;
+            lp.kstat = kstat_here ? 1 : 0;
             if (ep) {                   // entry-parallel groups: hubs, the general tiles and the rest tiles
                 const int ngroups = (int)(g->c.phase_ep_base[ph + 1] - g->c.phase_ep_base[ph]);
                 // resident grid: the static LDS (26.5 KB) + the SMALLW tables bound the workgroups per CU
@@ -168,7 +174,9 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
                         g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation,
-                        (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies, d.grad_inv);
+                        (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies, d.grad_inv,
+                        kstat_here ? d.ep_kstat + (size_t)(2 * ph) * (size_t)nw : nullptr,
+                        (kstat_here && learn_non_evidence) ? d.ep_kstat + (size_t)(2 * ph + 1) * (size_t)nw : nullptr);
                     nsk_refresh_prog_weights(g, true);
                 }
             }
