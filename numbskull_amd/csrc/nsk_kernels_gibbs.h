@@ -1599,7 +1599,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
             for (int k = 0; k < 2; k++) {
                 idx[k] = 0;
 #pragma unroll
-                for (int j = 0; j < 4 * NCH; j++) idx[k] |= ((uint32_t)g.val[id[q][k][j]] & 1u) << j;
+                // (the table kernels run only while every value on the device lies in its domain --
+                // values_regular -- and their members are binary: a value IS its bit)
+                for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[q][k][j]] << j;
                 idx[k] &= zmask[q];
             }
 #pragma unroll

@@ -10,8 +10,10 @@
 
 using namespace nsk;
 
+#ifndef NSK_LEARN_TPW
 #define NSK_LEARN_TPW 2          // tiles per trip of the learning table kernel (1: 41.6 us, 2: 41.6 us, 4: 46.7 us
                                  // per 10M-grid class before the kernel was pipelined)
+#endif
 
 template <typename VT, bool SMALLW>
 static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,

@@ -302,3 +302,19 @@ def test_write_probabilities_refuses_a_malformed_variable_array(tmp_path):
     fg.cstart[2] = len(fg.count) + 5
     with pytest.raises(IndexError):
         fg.dump_probabilities(str(out), 1)
+
+
+def test_diagnostic_switches_need_nsk_diag(monkeypatch):
+    """Layout switches (NSK_NO_FAST & co.) change which kernels a graph compiles to -- and therefore its
+    sample stream -- so an inherited environment variable alone must not do that: they are read only
+    together with NSK_DIAG=1."""
+    from numbskull_amd import graphgen
+    g = graphgen.ising_grid(16, 16, weight=0.2)
+    monkeypatch.delenv("NSK_DIAG", raising=False)
+    monkeypatch.delenv("NSK_NO_FAST", raising=False)
+    base = session(g)[1].plan()[1]
+    assert base["nfast"] == 256
+    monkeypatch.setenv("NSK_NO_FAST", "1")
+    assert session(g)[1].plan()[1]["nfast"] == 256          # ignored without NSK_DIAG
+    monkeypatch.setenv("NSK_DIAG", "1")
+    assert session(g)[1].plan()[1]["nfast"] == 0            # honoured with it
