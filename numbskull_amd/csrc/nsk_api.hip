@@ -135,6 +135,7 @@ int nsk_graph_destroy(nsk_graph *g) {
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     for (void *p : g->allocs) (void)hipFree(p);
+    if (g->sweep_graph) (void)hipGraphExecDestroy(g->sweep_graph);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)g->rccl_comm);
@@ -249,6 +250,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &g->K, nacc); if (rc) return rc;
     rc = dev_alloc(g, &g->T, nacc); if (rc) return rc;
     rc = dev_alloc(g, &g->clip_count, 1); if (rc) return rc;
+    rc = dev_alloc(g, &g->d_counters, 2); if (rc) return rc;
     HIPCHECK(hipMemsetAsync(g->clip_count, 0, sizeof(unsigned int), g->stream));
     rc = dev_alloc(g, &g->mt_np, 1); if (rc) return rc;
     rc = dev_alloc(g, &g->mt_py, 1); if (rc) return rc;
@@ -776,20 +778,24 @@ int nsk_p2p_import(nsk_graph *g, const void *all_handles, const int32_t *readers
 }  // extern "C"
 
 template <typename VT>
-static int p2p_exchange(nsk_graph *g) {
+static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off) {
     P2PPeers peers;
     for (int q = 0; q < 16; q++) { peers.recv[q] = g->p2p_peer_recv[q]; peers.flags[q] = (unsigned int *)g->p2p_peer_flags[q]; }
-    const unsigned int tag = ++g->p2p_tag;
+    const unsigned int tag = tag_base ? tag_off : ++g->p2p_tag;
     if (g->p2p_peer_mask)
         k_p2p_push<VT><<<dim3(1), dim3(1024), 0, g->stream>>>((const VT *)g->val, g->x_send_vids, (int)g->xnsend, peers,
-                                                              g->xworld, g->xrank, g->xslot, g->p2p_peer_mask, tag);
+                                                              g->xworld, g->xrank, g->xslot, g->p2p_peer_mask, tag, tag_base);
     const int n = (int)g->xnrecv;
     if (g->p2p_src_mask && n > 0)
         k_p2p_wait_unpack<VT><<<dim3(std::min(64, (n + NSK_BLOCK - 1) / NSK_BLOCK)), dim3(NSK_BLOCK), 0, g->stream>>>(
             (VT *)g->val, g->x_recv_vids, g->x_recv_slot, (const VT *)g->p2p_recv, g->p2p_flags, n, g->xworld,
-            g->xslot, g->p2p_src_mask, tag, g->p2p_err);
+            g->xslot, g->p2p_src_mask, tag, g->p2p_err, tag_base);
     HIPCHECK(hipGetLastError());
     return NSK_OK;
+}
+
+int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off) {
+    return g->c.vbytes == 1 ? p2p_exchange<int8_t>(g, tag_base, tag_off) : p2p_exchange<int32_t>(g, tag_base, tag_off);
 }
 
 extern "C" {
@@ -800,20 +806,17 @@ int nsk_p2p_exchange(nsk_graph *g) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_export / nsk_p2p_import first");
     HIPCHECK(hipSetDevice(g->device));
-    int rc = g->c.vbytes == 1 ? p2p_exchange<int8_t>(g) : p2p_exchange<int32_t>(g);
+    int rc = nsk_p2p_enqueue(g, nullptr, 0);
     return rc ? rc : p2p_check(g);
 }
 
 int nsk_gibbs_sweeps_p2p(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_export / nsk_p2p_import first");
-    for (int64_t s = 0; s < nsweeps; s++) {
-        int rc = nsk_gibbs_sweeps(g, 1, sample_evidence, burnin);
-        if (rc) return rc;
-        rc = g->c.vbytes == 1 ? p2p_exchange<int8_t>(g) : p2p_exchange<int32_t>(g);
-        if (rc) return rc;
-    }
-    return p2p_check(g);
+    if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
+    HIPCHECK(hipSetDevice(g->device));
+    int rc = nsk_gibbs_run(g, nsweeps, sample_evidence, burnin, true);
+    return rc ? rc : p2p_check(g);
 }
 
 static int p2p_check(nsk_graph *g) {

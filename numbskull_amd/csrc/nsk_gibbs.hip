@@ -173,8 +173,8 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                             // resident grid over tile pairs: at most 8 blocks per CU
                             const int npairs = tab.ntiles / 2;
                             const int nbp = std::min(2048, 8 * ((((npairs + 3) / 4) + 7) / 8));
-                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
-                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1);
+                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, 0u);
+                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, 0u);
                         }
                         else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
                         else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
@@ -211,11 +211,117 @@ extern "C" int nsk_debug_dump(unsigned long long *out, int n) {
 }
 #endif
 
+static int gibbs_eager(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
+    return g->c.vbytes == 1 ? gibbs_impl<int8_t>(g, nsweeps, sample_evidence, burnin)
+                            : gibbs_impl<int32_t>(g, nsweeps, sample_evidence, burnin);
+}
+
+// ---- captured sweep sequences (hipGraph) -------------------------------------------------------------
+// A handle whose inference sweep consists of table launches only (grids and their shards: two ~4 us
+// kernels per sweep, plus two exchange kernels in an N-rank run) is bound by launches, not by kernels.
+// NSK_GRAPH_SWEEPS sweeps -- class launches, peer-to-peer push and wait/unpack -- are captured once into
+// a hipGraph whose kernels read the sweep index (and the exchange tag) from device memory + a per-node
+// offset, so the same executable graph serves every replay; a one-thread kernel at its end advances the
+// counters.  The uint8 position tally is folded between replays when it would overflow.
+static bool graph_eligible(const nsk_graph *g) {
+    if (g->scan != NSK_SCAN_CHROMATIC || !g->values_regular || nsk::diag_env("NSK_NO_GRAPH")) return false;
+    const nsk::Compiled &c = g->c;
+    const size_t nphase = c.phase_start.size() - 1;
+    if (nphase == 0) return false;
+    for (size_t ph = 0; ph < nphase; ph++) {
+        const int64_t ntiles = c.phase_wb_base[ph + 1] - c.phase_wb_base[ph];
+        if (c.phase_end[ph] > c.phase_fast_end[ph]) return false;                    // generic-path variables / hubs
+        if (ntiles > c.phase_gen_tile[ph]) return false;                             // general tiles
+        if (c.phase_rest_base[ph + 1] > c.phase_rest_base[ph]) return false;         // tiles outside segments
+    }
+    for (const nsk::Compiled::Segment &sg : c.segments) if (sg.ztab < 0) return false;
+    return true;
+}
+
+template <typename VT>
+static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, int key) {
+    if (g->sweep_graph) { (void)hipGraphExecDestroy(g->sweep_graph); g->sweep_graph = nullptr; }
+    g->sweep_graph_key = -1;
+    // the segment plans (kept in the handle) are built by an eager sweep-free call path: make sure they exist
+    DevGraph<VT> d = view<VT>(g);
+    const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
+    hipGraph_t graph = nullptr;
+    HIPCHECK(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+    int launches = 0;
+    for (int i = 0; i < NSK_GRAPH_SWEEPS; i++) {
+        for (size_t ph = 0; ph < g->seg_plans.size(); ph++)
+            for (const NskSegPlan &pl : g->seg_plans[ph]) {
+                const int npairs = pl.tab.ntiles / 2;
+                const int nbp = std::min(2048, 8 * ((((npairs + 3) / 4) + 7) / 8));
+                if (pl.nch == 1)
+                    k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, K0, K1, 0u, 0u,
+                                                                                         g->d_counters, (uint32_t)i, g->rng_tag);
+                else
+                    k_gibbs_seg_tab<VT, 2><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, K0, K1, 0u, 0u,
+                                                                                         g->d_counters, (uint32_t)i, g->rng_tag);
+                launches++;
+            }
+        if (p2p) {
+            int rc = nsk_p2p_enqueue(g, g->d_counters, (unsigned int)(i + 1));
+            if (rc) { (void)hipStreamEndCapture(g->stream, &graph); if (graph) (void)hipGraphDestroy(graph); return rc; }
+        }
+    }
+    k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, NSK_GRAPH_SWEEPS, p2p ? NSK_GRAPH_SWEEPS : 0, 0);
+    hipError_t e = hipStreamEndCapture(g->stream, &graph);
+    if (e != hipSuccess || !graph) return nsk::fail(NSK_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(&g->sweep_graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { g->sweep_graph = nullptr; return nsk::fail(NSK_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    g->sweep_graph_key = key;
+    g->sweep_graph_launches = launches;
+    (void)sample_evidence;
+    return NSK_OK;
+}
+
+int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p) {
+    int64_t left = nsweeps;
+    if (left >= NSK_GRAPH_SWEEPS && graph_eligible(g)) {
+        // the plans of this (sample_evidence, tables) combination: one eager sweep builds / refreshes them
+        int rc = gibbs_eager(g, 1, sample_evidence, burnin);
+        if (rc) return rc;
+        if (p2p && (rc = nsk_p2p_enqueue(g, nullptr, 0))) return rc;
+        left--;
+        bool all_tab = true;
+        for (const auto &v : g->seg_plans) for (const NskSegPlan &pl : v) all_tab = all_tab && pl.kind >= 8;
+        const int key = g->seg_plans_key | (burnin ? 4 : 0) | (p2p ? 8 : 0);
+        if (all_tab && left >= NSK_GRAPH_SWEEPS) {
+            if (g->sweep_graph_key != key) {
+                rc = g->c.vbytes == 1 ? graph_build<int8_t>(g, sample_evidence, burnin, p2p, key)
+                                      : graph_build<int32_t>(g, sample_evidence, burnin, p2p, key);
+                if (rc) return rc;
+            }
+            k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, g->sweep, g->p2p_tag, 1);
+            while (left >= NSK_GRAPH_SWEEPS) {
+                if (!burnin && g->pos_tally_sweeps + NSK_GRAPH_SWEEPS > 255) nsk_fold_position_tally(g);   // uint8 tally
+                HIPCHECK(hipGraphLaunch(g->sweep_graph, g->stream));
+                g->sweep += NSK_GRAPH_SWEEPS;
+                if (p2p) g->p2p_tag += NSK_GRAPH_SWEEPS;
+                if (!burnin) { g->pos_tally_sweeps += NSK_GRAPH_SWEEPS; g->cnt_dirty = true; }
+                g->sweeps_done += NSK_GRAPH_SWEEPS;
+                g->launches += g->sweep_graph_launches;
+                left -= NSK_GRAPH_SWEEPS;
+            }
+            HIPCHECK(hipGetLastError());
+        }
+    }
+    for (; left > 0; left--) {              // the rest eagerly (one sweep at a time when exchanging)
+        int rc = gibbs_eager(g, p2p ? 1 : left, sample_evidence, burnin);
+        if (rc) return rc;
+        if (!p2p) break;
+        if ((rc = nsk_p2p_enqueue(g, nullptr, 0))) return rc;
+    }
+    return NSK_OK;
+}
+
 extern "C" int nsk_gibbs_sweeps(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
     if (nsweeps == 0) return NSK_OK;
     HIPCHECK(hipSetDevice(g->device));
-    return g->c.vbytes == 1 ? gibbs_impl<int8_t>(g, nsweeps, sample_evidence, burnin)
-                            : gibbs_impl<int32_t>(g, nsweeps, sample_evidence, burnin);
+    return nsk_gibbs_run(g, nsweeps, sample_evidence, burnin, false);
 }

@@ -34,6 +34,11 @@ struct nsk_graph {
     // epoch per call); key = sample_evidence | draw tables usable << 1
     std::vector<std::vector<NskSegPlan>> seg_plans;
     int seg_plans_key = -1;
+    // captured sweep sequence (hipGraph): NSK_GRAPH_SWEEPS inference sweeps of a handle whose sweep is
+    // table launches only (+ the peer-to-peer exchange), replayed with the sweep index in device memory
+    hipGraphExec_t sweep_graph = nullptr;
+    int sweep_graph_key = -1, sweep_graph_launches = 0;
+    unsigned long long *d_counters = nullptr;      // [0] sweep index, [1] exchange tag
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -200,6 +205,11 @@ static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nwe
 }
 
 extern "C" int nsk_ensure_generic(nsk_graph *g);       // internal (not in the public header)
+#define NSK_GRAPH_SWEEPS 16
+// one peer-to-peer exchange on the library's stream; tag_base != null: a captured launch whose tag is
+// the device counter + tag_off (nsk_api.hip)
+int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off);
+int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p);   // nsk_gibbs.hip
 void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);
 void nsk_refresh_ztab(nsk_graph *g);
 int nsk_fold_position_tally(nsk_graph *g);

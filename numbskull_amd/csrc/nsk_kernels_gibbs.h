@@ -1516,8 +1516,15 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
 #endif
 template <typename VT, int NCH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
-                                                             uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+                                                             uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
+                                                             const unsigned long long *sweep_base, uint32_t sweep_off,
+                                                             uint32_t rng_tag) {
     constexpr int PP = NSK_TAB_PP;
+    if (sweep_base) {             // a captured launch (hipGraph): the sweep index lives in device memory
+        const unsigned long long sw = *(const NSK_SCALAR unsigned long long *)sweep_base + sweep_off;
+        s0 = (uint32_t)sw;
+        s1 = (uint32_t)(sw >> 32) ^ rng_tag;
+    }
     const int lane = (int)(threadIdx.x & 63);
     const int npairs = tab.ntiles >> 1;                                 // virtual tiles: always even
     const int per = (npairs + 7) >> 3;                                  // pairs per XCD

@@ -71,7 +71,8 @@ struct P2PPeers { void *recv[16]; unsigned int *flags[16]; };       // (one node
 template <typename VT>
 __global__ __launch_bounds__(1024) void k_p2p_push(const VT *val, const int32_t *send_vids, int nsend, P2PPeers peers,
                                                    int world, int me, int64_t slot, unsigned int peer_mask,
-                                                   unsigned int tag) {
+                                                   unsigned int tag, const unsigned long long *tag_base) {
+    if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
     const size_t base = ((size_t)(tag & 1u) * (size_t)world + (size_t)me) * (size_t)slot;
     for (int q = 0; q < world; q++) {
         if (!((peer_mask >> q) & 1u)) continue;
@@ -91,7 +92,8 @@ template <typename VT>
 __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_wait_unpack(VT *val, const int32_t *recv_vids, const int32_t *recv_slot,
                                                                const VT *recv2, unsigned int *flags, int n, int world,
                                                                int64_t slot, unsigned int src_mask, unsigned int tag,
-                                                               unsigned int *err) {
+                                                               unsigned int *err, const unsigned long long *tag_base) {
+    if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
     __shared__ int ok;
     if (threadIdx.x == 0) {
         ok = 1;
@@ -114,6 +116,12 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_wait_unpack(VT *val, const in
         const int sl = recv_slot[j];
         if (sl >= 0) val[recv_vids[j]] = __builtin_nontemporal_load(rb + sl);
     }
+}
+
+// counters of captured sweep sequences (hipGraph): [0] sweep index, [1] peer-to-peer exchange tag
+static __global__ void k_graph_counters(unsigned long long *c, unsigned long long sweep, unsigned long long tag, int set) {
+    if (set) { c[0] = sweep; c[1] = tag; }
+    else { c[0] += sweep; c[1] += tag; }
 }
 
 // weight merge of the partitioned learning sweep: delta = w - start ... w = start + sum(delta)

@@ -25,6 +25,8 @@ def graph(kind):
 
 def main():
     kind, learn, nsweeps = sys.argv[1], sys.argv[2] == "learn", 4
+    if len(sys.argv) > 3 and sys.argv[3] == "p2p" and not learn:
+        nsweeps = 37                              # long enough for captured sweep sequences (grids)
     local = len(sys.argv) > 3 and sys.argv[3] == "local"      # every rank holds only its shard (+ ghosts)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)

@@ -822,6 +822,27 @@ def test_large_feature_values_widen_the_gradient_accumulator(reg):
     assert np.array_equal(fg.var_value[0], vv) and wv[0] != 0.0
 
 
+@pytest.mark.parametrize("burn", [0, 37])
+def test_captured_sweep_sequences_equal_the_oracle(burn):
+    """A handle whose sweep is table launches only replays NSK_GRAPH_SWEEPS = 16 sweeps per hipGraph
+    launch (sweep index in device memory + a per-node offset, nsk_gibbs.hip): 16-sweep replays, the
+    eager remainder, the position-tally fold between replays (300 tallied sweeps) and a burn-in graph
+    must leave values and tallies exactly where the oracle's sweep-by-sweep run leaves them."""
+    g = graphgen.ising_grid(48, 40, weight=0.3)
+    ns, fg = session(g, seed=9)
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, _, wv, cnt = og.initial_state()
+    fg.inference(burn, 300, True)
+    for s in range(burn + 300):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 9, s, True, burnin=s < burn) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+    fg.inference(0, 21, True)                       # a second call continues the sweep index
+    for s in range(burn + 300, burn + 321):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 9, s, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
 def test_native_rccl_loop_single_rank():
     """nsk_comm_init + nsk_gibbs_sweeps_exchange / nsk_learn_sweeps_exchange with a 1-rank
     communicator: the native loop (sweep, pack, ncclAllGather, unpack, ncclAllReduce of weight
