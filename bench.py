@@ -412,6 +412,10 @@ def main():
     L, h = _lib.lib(), fg._engine()
     t_load = time.time() - t_load
     info = fg.info()
+    if world > 1:
+        # the library is pointed at torch's current stream: a stream of its own, so that the sweep
+        # sequences can be captured into hipGraphs (the legacy default stream cannot be captured)
+        torch.cuda.set_stream(torch.cuda.Stream())
     sampler = PartitionedSampler(fg, dist, torch, rank, world, nvar_global=nvar) if world > 1 else None
     lr = (1e-7, 0.95, 2, 0.01, 1)       # step, decay, L2, reg_param, truncation (config #3)
     if args.workload.startswith("lr") or args.workload.startswith("boolw"):

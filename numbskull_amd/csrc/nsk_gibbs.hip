@@ -246,6 +246,9 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
     DevGraph<VT> d = view<VT>(g);
     const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
     hipGraph_t graph = nullptr;
+    // (the legacy default stream cannot be captured: a caller that pointed the library at it -- torch's
+    // current stream in a process without its own streams -- keeps the eager loop)
+    if (g->stream == nullptr) return nsk::fail(NSK_E_DEVICE, "the default stream cannot be captured");
     HIPCHECK(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
     int launches = 0;
     for (int i = 0; i < NSK_GRAPH_SWEEPS; i++) {
@@ -290,13 +293,17 @@ int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin
         for (const auto &v : g->seg_plans) for (const NskSegPlan &pl : v) all_tab = all_tab && pl.kind >= 8;
         const int key = g->seg_plans_key | (burnin ? 4 : 0) | (p2p ? 8 : 0);
         if (all_tab && left >= NSK_GRAPH_SWEEPS) {
-            if (g->sweep_graph_key != key) {
+            if (g->sweep_graph_key != key && !g->sweep_graph_off) {
                 rc = g->c.vbytes == 1 ? graph_build<int8_t>(g, sample_evidence, burnin, p2p, key)
                                       : graph_build<int32_t>(g, sample_evidence, burnin, p2p, key);
-                if (rc) return rc;
+                if (rc) {                   // capture is an optimisation: without it the eager loop runs
+                    g->sweep_graph_off = true;
+                    (void)hipGetLastError();
+                }
             }
-            k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, g->sweep, g->p2p_tag, 1);
-            while (left >= NSK_GRAPH_SWEEPS) {
+            if (g->sweep_graph_key == key && !g->sweep_graph_off)
+                k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, g->sweep, g->p2p_tag, 1);
+            while (left >= NSK_GRAPH_SWEEPS && g->sweep_graph_key == key && !g->sweep_graph_off) {
                 if (!burnin && g->pos_tally_sweeps + NSK_GRAPH_SWEEPS > 255) nsk_fold_position_tally(g);   // uint8 tally
                 HIPCHECK(hipGraphLaunch(g->sweep_graph, g->stream));
                 g->sweep += NSK_GRAPH_SWEEPS;

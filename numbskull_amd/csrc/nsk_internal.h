@@ -38,6 +38,7 @@ struct nsk_graph {
     // table launches only (+ the peer-to-peer exchange), replayed with the sweep index in device memory
     hipGraphExec_t sweep_graph = nullptr;
     int sweep_graph_key = -1, sweep_graph_launches = 0;
+    bool sweep_graph_off = false;                  // capture failed once (e.g. the legacy default stream): eager from then on
     unsigned long long *d_counters = nullptr;      // [0] sweep index, [1] exchange tag
     int device = 0;
     hipStream_t stream = nullptr;

@@ -48,6 +48,8 @@ def main():
         gids.append(ids)
     fg = handles[rank]
     p2p = len(sys.argv) > 3 and sys.argv[3] == "p2p"      # boundary values written into the peer's memory (hipIpc)
+    if p2p:                                               # a stream of its own: sweep sequences can be captured
+        torch.cuda.set_stream(torch.cuda.Stream())        # (the legacy default stream cannot)
     sampler = PartitionedSampler(fg, dist, torch, rank, world, nvar_global=nvar, p2p=p2p)   # native RCCL refuses one device
     assert not sampler.native                                        # for two ranks: torch loop
     assert sampler.p2p == p2p, "peer-to-peer exchange could not be set up"
