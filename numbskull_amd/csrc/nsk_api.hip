@@ -245,6 +245,14 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     // global learning accumulators: one private copy per XCD (nsk_device.h sink_add); graphs with few
     // weights accumulate in LDS and never touch them
     g->acc_copies = (!g->smallw && c.nweight <= (1 << 21)) ? NSK_XCDS : 1;
+    {   // the XCD-private copies rely on global atomics executing in the issuing XCD's own L2 and on
+        // HW_REG_XCC_ID (nsk_device.h sink_add): true on gfx942 / gfx950, so any other architecture (or
+        // NSK_DIAG=1 NSK_ONE_ACC=1) keeps ONE copy updated with agent-scope atomics
+        hipDeviceProp_t prop;
+        const bool known = hipGetDeviceProperties(&prop, g->device) == hipSuccess &&
+                           (strstr(prop.gcnArchName, "gfx950") || strstr(prop.gcnArchName, "gfx942"));
+        if (!known || nsk::diag_env("NSK_ONE_ACC")) g->acc_copies = 1;
+    }
     const size_t nacc = (size_t)g->acc_copies * (size_t)(c.nweight ? c.nweight : 1);
     rc = dev_alloc(g, &g->G, nacc); if (rc) return rc;
     rc = dev_alloc(g, &g->K, nacc); if (rc) return rc;

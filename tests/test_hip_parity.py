@@ -384,6 +384,28 @@ def test_generic_kernels_alone(golden, name, no_general, no_heavy, monkeypatch):
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
 
 
+@pytest.mark.parametrize("switch", ["NSK_ONE_ACC", "NSK_NO_KSTAT"])
+@pytest.mark.parametrize("name", ["lr_manyw", "gencat_bigw"])
+def test_learning_accumulator_fallbacks(golden, name, switch, monkeypatch):
+    """NSK_ONE_ACC: one copy of the global gradient accumulators updated with agent-scope atomics -- what
+    an architecture other than gfx942 / gfx950 gets instead of the XCD-private copies; NSK_NO_KSTAT:
+    every visit goes through the accumulators instead of the structural visit counts.  Same weights."""
+    monkeypatch.setenv("NSK_DIAG", "1")
+    monkeypatch.setenv(switch, "1")
+    g, hbv = _small_graphs(golden)[name]
+    ns, fg = session(g, seed=5, head_by_vid=hbv)
+    og = oracle_of(fg, hbv)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, _ = og.initial_state()
+    fg.learn(0, 3, 0.01, 0.9, 2, 0.05, 1, learn_non_evidence=True)
+    step = 0.01
+    for sweep in range(3):
+        assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.05, 1, True, 5, sweep) == 0
+        step *= 0.9
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    assert np.array_equal(fg.weight_value[0], wv)
+
+
 @pytest.mark.parametrize("name", ["lr_manyw", "pairs_manyw", "boolw", "gencat_bigw"])
 @pytest.mark.parametrize("reg", [1, 2])
 def test_learning_with_unpacked_accumulators(golden, name, reg, monkeypatch):
