@@ -164,10 +164,16 @@ def _small_graphs(golden):
         # weight table beyond 4 MB: general tiles read materialised weight rows in inference
         "gencat_bigw": (_general_tile_graph(nweight=600000), True),
         "gencat_i32": (_general_tile_graph(wide_values=True), True),
+        # arity <= 4: every entry has at most 3 other members, so these colours are laid out as
+        # entry-parallel groups (k_gibbs_ep / k_learn_ep) -- all twelve general-tile functions, repeated
+        # members, both head lookups, int8 and int32 values
+        "gencat4": (_general_tile_graph(maxarity=4), False),
+        "gencat4_vid": (_general_tile_graph(maxarity=4), True),
+        "gencat4_i32": (_general_tile_graph(wide_values=True, maxarity=4), True),
     }
 
 
-def _general_tile_graph(nweight=30, wide_values=False):
+def _general_tile_graph(nweight=30, wide_values=False, maxarity=5):
     from numbskull_amd.numbskulltypes import Weight, Variable, Factor, FactorToVar
     rng = np.random.default_rng(23)
     nvar, nfactor = 6000, 1700
@@ -181,7 +187,7 @@ def _general_tile_graph(nweight=30, wide_values=False):
     variable["isEvidence"] = rng.random(nvar) < 0.5
     variable["initialValue"] = (rng.random(nvar) * card).astype(np.int64)
     funcs = np.array([-1, 0, 1, 2, 3, 4, 12, 13, 14, 15, 16, 17])
-    arity = rng.integers(1, 6, nfactor)
+    arity = rng.integers(1, maxarity + 1, nfactor)
     off = np.cumsum(arity) - arity
     nedge = int(arity.sum())
     assert nedge < nvar                                # literal head lookup reads var_value[edge index]
@@ -293,7 +299,7 @@ def _big_cardinality_graph():
 
 GRAPHS = ["grid4x5", "grid32", "mixed", "lf", "headquirk", "headquirk_vid", "pairs", "grid57x33",
           "lr3000", "lr_bigcard", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat", "gencat_vid",
-          "gencat_bigw", "gencat_i32", "lr_selfdup"]
+          "gencat_bigw", "gencat_i32", "lr_selfdup", "gencat4", "gencat4_vid", "gencat4_i32"]
 
 
 @pytest.mark.parametrize("name", GRAPHS)
@@ -323,7 +329,8 @@ def test_chromatic_inference_equals_oracle(golden, name, sample_evidence):
 
 @pytest.mark.parametrize("name", ["mixed", "lf", "pairs", "grid32", "lr3000", "lr_bigcard",
                                   "headquirk", "lr_manyw", "pairs_manyw", "boolw", "hubs", "gencat",
-                                  "gencat_vid", "gencat_i32", "lr_selfdup"])
+                                  "gencat_vid", "gencat_i32", "lr_selfdup", "gencat4", "gencat4_vid",
+                                  "gencat4_i32"])
 @pytest.mark.parametrize("reg,trunc", [(0, 1), (1, 1), (1, 3), (2, 1)])
 @pytest.mark.parametrize("lne", [False, True])
 def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
