@@ -572,7 +572,10 @@ def main():
             # the headline sweep's 200 MB of streams fit the 256 MiB Infinity Cache; the same kernel
             # on the 40M grid (800 MB per sweep) is served by HBM alone
             out["roofline"]["frac_hbm_only"] = out["also"]["ising40m"]["roofline_frac"]
-            out["roofline"]["frac_is"] = "memory-system bandwidth (HBM + Infinity Cache) as a fraction of the HBM peak"
+            out["roofline"]["frac_is"] = ("bytes the compiled layout moves per launch / launch time / HBM peak.  With implicit "
+                                          "adjacency the table kernel reads no per-lane stream (4.8 B/update instead of round 2's "
+                                          "20.0): it is bound by its chain of dependent steps, not by HBM, so this fraction fell "
+                                          "while updates/s rose; csr_model_GBs prices the same sweep in SURVEY 8(d)'s CSR layout")
         checks["ok"] = bool(ok_local)
         print(json.dumps(out))
     if world > 1:
