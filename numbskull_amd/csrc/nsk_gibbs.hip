@@ -228,6 +228,9 @@ static bool graph_eligible(const nsk_graph *g) {
     const nsk::Compiled &c = g->c;
     const size_t nphase = c.phase_start.size() - 1;
     if (nphase == 0) return false;
+    // launches set the pace only while the class kernels are short: beyond a few million variables per
+    // handle (10M grid: 14.5 us per class) a replay saves nothing and its launch latency shows in short runs
+    if (c.nsampled > 3000000) return false;
     for (size_t ph = 0; ph < nphase; ph++) {
         const int64_t ntiles = c.phase_wb_base[ph + 1] - c.phase_wb_base[ph];
         if (c.phase_end[ph] > c.phase_fast_end[ph]) return false;                    // generic-path variables / hubs
