@@ -252,6 +252,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
         const bool known = hipGetDeviceProperties(&prop, g->device) == hipSuccess &&
                            (strstr(prop.gcnArchName, "gfx950") || strstr(prop.gcnArchName, "gfx942"));
         if (!known || nsk::diag_env("NSK_ONE_ACC")) g->acc_copies = 1;
+        g->bins_xcd = (known && !nsk::diag_env("NSK_ONE_ACC")) ? 1 : 0;
     }
     const size_t nacc = (size_t)g->acc_copies * (size_t)(c.nweight ? c.nweight : 1);
     rc = dev_alloc(g, &g->G, nacc); if (rc) return rc;

@@ -207,6 +207,7 @@ struct DevGraph {
     uint32_t *part_K, *part_T;
     int32_t nweight;
     int32_t acc_copies;         // copies of G / K / T: NSK_XCDS (one per XCD) or 1
+    int32_t bins_xcd;           // the SMALLW bins are dealt to XCDs (8 each): a block adds to its own XCD's bins in that L2
     int32_t packed_grad;        // integer gradients: visit counts ride in the low half of G (GradSink)
     // gradients accumulate as fixed point Q(31+s).(32-s): s = 0 unless the bound on one weight's
     // gradient sum in one class would overflow Q31.32 (nsk_compile.cpp grad_shift)

@@ -172,7 +172,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         if (kind >= 8) {
                             // resident grid over tile pairs: at most 8 blocks per CU
                             const int npairs = tab.ntiles / 2;
-                            const int nbp = std::min(2048, 8 * ((((npairs + 3) / 4) + 7) / 8));
+                            const int nbp = nsk_tab_grid(npairs);
                             if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, 0u);
                             else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, 0u);
                         }
@@ -258,7 +258,7 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
         for (size_t ph = 0; ph < g->seg_plans.size(); ph++)
             for (const NskSegPlan &pl : g->seg_plans[ph]) {
                 const int npairs = pl.tab.ntiles / 2;
-                const int nbp = std::min(2048, 8 * ((((npairs + 3) / 4) + 7) / 8));
+                const int nbp = nsk_tab_grid(npairs);
                 if (pl.nch == 1)
                     k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, K0, K1, 0u, 0u,
                                                                                          g->d_counters, (uint32_t)i, g->rng_tag);

@@ -81,6 +81,7 @@ struct nsk_graph {
     double compile_seconds = 0;
     uint32_t *dyn_tiles = nullptr, *rest_tiles = nullptr, *learn_rest_tiles = nullptr;
     int acc_copies = 1;                // copies of the global learning accumulators (one per XCD, or 1)
+    int bins_xcd = 0;                  // SMALLW bins private to XCDs (close_sink)
     bool generic_uploaded = false;     // CSR-style arrays of the generic kernels are on the device
     double learn_cap = 0.5;            // per-class cap on visits * step of one weight (nsk_set_learn_cap)
     unsigned int *clip_count = nullptr;   // weight updates whose step was clipped (device counter)
@@ -146,6 +147,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.grad_mul = 1ll << (32 - g->c.grad_shift);
     d.grad_inv = 1.0 / (double)d.grad_mul;
     d.acc_copies = g->acc_copies;
+    d.bins_xcd = g->bins_xcd;
     d.cnt_pos = g->cnt_pos;
     d.ztab = g->ztab;
     d.sink = g->sink;
@@ -194,10 +196,24 @@ struct ColourStreams {
 static inline int nsk_learn_tab_grid(int ntiles, int nweight, bool smallw) {
     const int blocks = (ntiles + 7) / 8;                            // 4 waves x 2 tiles
     const int trips = smallw ? std::max(1, (nweight * 16 * 16 + 14847) / 14848) : 1;
-    // (measured on the 10M grid, per class: 1792 blocks 33.6 us, 2048 32.5 us, 3584 34.2 us, 4096 34.7 us)
+    // Six blocks per CU.  The kernel holds 7 waves per SIMD (112 scalar registers), so 2048 blocks are
+    // not all resident, and whole blocks per CU beat fractions (measured on the 10M grid, per class with
+    // the update launch: 1024 blocks 31.2 us, 1280 30.1, 1408 31.1, 1536 29.6, 1664 31.2, 1792 32.2,
+    // 1920 32.5, 2048 31.4, 3072 31.3, 4096 31.7; the 1M grid is indifferent: 14.1-14.3)
     const char *cap_env = nsk::diag_env("NSK_LEARN_GRID_CAP");              // (diagnostic; read per launch so that tests can set it)
-    const int cap = cap_env ? atoi(cap_env) : 2048;
+    const int cap = cap_env ? atoi(cap_env) : 1536;
     return 8 * ((std::max(1, std::min(cap, (blocks + trips - 1) / trips)) + 7) / 8);     // whole rounds of XCDs
+}
+// Grid of a table-driven inference segment launch (k_gibbs_seg_tab): one block per four tile pairs
+// while that is at most 8 blocks per CU (every wave makes one trip), else a resident grid of 7 blocks
+// per CU, whole rounds of XCDs.  Measured per class (NSK_TAB_GRID_CAP, two passes on one box): 10M grid
+// 1024 blocks 15.8 us, 1280 15.0, 1536 14.7, 1792 14.3, 2048 15.0; 40M grid 1280 49.7, 1536 48.2,
+// 1792 47.1, 2048 53.0; the 1M grid needs 1954 blocks and is best left alone (4.13 against 4.20 us).
+static inline int nsk_tab_grid(int npairs) {
+    const int need = std::max(8, 8 * ((((npairs + 3) / 4) + 7) / 8));
+    const char *cap_env = nsk::diag_env("NSK_TAB_GRID_CAP");                // (diagnostic)
+    if (cap_env) return std::max(8, std::min(atoi(cap_env) & ~7, need));
+    return need <= 2048 ? need : 1792;
 }
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {
     const int ntiles = sl.tile_start[sl.n];

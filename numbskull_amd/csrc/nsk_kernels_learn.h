@@ -44,22 +44,29 @@ __device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem)
     return sk;
 }
 
-// SMALLW: a block's LDS sums go to one of NSK_LEARN_BINS bins per weight with plain global atomics
+// SMALLW: a block's LDS sums go to one of NSK_LEARN_BINS bins per weight with global atomics
 // (integer sums: order-free); k_apply_bins adds the bins up.  Spreading the blocks over the bins
-// keeps the same-address atomic chains short (a few hundred per bin, hidden behind the launch),
-// and there is no per-block row to budget for.
+// keeps the same-address atomic chains short, and there is no per-block row to budget for.
+// bins_xcd (gfx942 / gfx950, as the XCD-private accumulators of open_sink): the bins are dealt to
+// the XCDs, eight each, and a block adds to the bins of the XCD it runs on (HW_REG_XCC_ID) with
+// workgroup-scope atomics, which execute in that XCD's L2.  Agent-scope adds are carried out on the
+// memory side of the fabric, and the 32 same-address adds of a resident grid's blocks -- all
+// finishing together -- were a 3.6 us tail of the 25 us table launch (10M grid, LNOSINK ablation).
 #define NSK_LEARN_BINS 64
 template <bool SMALLW, typename VT>
 __device__ __forceinline__ void close_sink(const DevGraph<VT> &g, const GradSink &sk) {
     if (!SMALLW) return;
     __syncthreads();
     const int nw = g.nweight;
-    const size_t bin = (size_t)(blockIdx.x & (NSK_LEARN_BINS - 1)) * (size_t)nw;
+    const bool own = g.bins_xcd != 0;
+    const uint32_t xcc = own ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (NSK_XCDS - 1)) : 0u;
+    static_assert(NSK_LEARN_BINS == 8 * NSK_XCDS, "eight bins per XCD");
+    const size_t bin = (size_t)(own ? 8u * xcc + ((blockIdx.x >> 3) & 7u) : (blockIdx.x & (NSK_LEARN_BINS - 1))) * (size_t)nw;
     for (int i = (int)threadIdx.x; i < nw; i += NSK_BLOCK) {
         if (sk.K[i] == 0) continue;
-        atomicAdd((unsigned long long *)&g.part_G[bin + i], (unsigned long long)sk.G[i]);
-        atomicAdd(&g.part_K[bin + i], sk.K[i]);
-        if (sk.T[i]) atomicAdd(&g.part_T[bin + i], sk.T[i]);
+        sink_add(own, (unsigned long long *)&g.part_G[bin + i], (unsigned long long)sk.G[i]);
+        sink_add(own, &g.part_K[bin + i], sk.K[i]);
+        if (sk.T[i]) sink_add(own, &g.part_T[bin + i], sk.T[i]);
     }
 }
 
@@ -829,7 +836,11 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
     for (int j = 0; j < 4 * NCH; j++) acc[j] = 0;
     auto flush = [&]() {
+#ifdef NSK_ABL_LNOSINK
+        if (cur_prog != 0xFFFFFFFFu && accK == 0xFFFFFFF1u) {
+#else
         if (cur_prog != 0xFFFFFFFFu && accK != 0u) {
+#endif
             const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + cur_prog);
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
@@ -865,20 +876,30 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
         }
         ti.pos = c_pos; ti.nt = c_nt; ti.t0 = T0 - c_lo; ti.prog = c_prog; ti.zoff = c_zoff;
         ti.zmask = c_zmask_ev & 0xFFu; ti.ev = (int)(int8_t)(c_zmask_ev >> 8);
+        // implicit adjacency (nsk_compile.h seg_aff): slot bases by scalar loads, member = base + lane;
+        // the bases of all the trip's tiles are requested before the first is looked at
+        uint32_t ab[TPW][4 * NCH];
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             const int t = min(ti.t0 + k, c_nt - 1);                    // a dead tile re-reads the last one
-            // implicit adjacency (nsk_compile.h seg_aff): slot bases by scalar loads, member = base + lane
-            uint32_t ab[4 * NCH];
-            ab[0] = NSK_NO_D16_STREAM;
+            ab[k][0] = NSK_NO_D16_STREAM;
             if (c_aff != NSK_NO_D16_STREAM) {
                 const NSK_SCALAR uint32_t *ap = (const NSK_SCALAR uint32_t *)(g.seg_aff + c_aff + (size_t)t * NCH);
 #pragma unroll
-                for (int j = 0; j < 4 * NCH; j++) ab[j] = ap[j];
+                for (int j = 0; j < 4 * NCH; j++) ab[k][j] = ap[j];
             }
-            if (ab[0] != NSK_NO_D16_STREAM) {                           // wave-uniform
+#ifdef NSK_ABL_LNOINIT
+            r.init[k] = 1;
+#else
+            r.init[k] = (int)g.p_init[c_pos + t * 64 + lane];          // -1: padding lane at a class end
+#endif
+        }
 #pragma unroll
-                for (int j = 0; j < 4 * NCH; j++) r.id[k][j] = ab[j] + (uint32_t)lane;
+        for (int k = 0; k < TPW; k++) {
+            const int t = min(ti.t0 + k, c_nt - 1);
+            if (ab[k][0] != NSK_NO_D16_STREAM) {                        // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4 * NCH; j++) r.id[k][j] = ab[k][j] + (uint32_t)lane;
             } else {
                 const uint4 *sp = g.adj + c_adj + (size_t)t * (64 * NCH) + lane;
 #pragma unroll
@@ -887,7 +908,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
                     r.id[k][4 * c] = q.x; r.id[k][4 * c + 1] = q.y; r.id[k][4 * c + 2] = q.z; r.id[k][4 * c + 3] = q.w;
                 }
             }
-            r.init[k] = (int)g.p_init[c_pos + t * 64 + lane];          // -1: padding lane at a class end
         }
     };
     LearnTrip<NCH, TPW> rn;
@@ -909,7 +929,11 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
                 xf[j] = (uint32_t)(uint8_t)g.val[r.id[k][j]];
+#ifdef NSK_ABL_LNOEV
+                xe[j] = xf[j];
+#else
                 xe[j] = (uint32_t)(uint8_t)g.val_evid[r.id[k][j]];
+#endif
             }
             idf[k] = 0; ide[k] = 0;
 #pragma unroll
@@ -919,7 +943,11 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
         }
         uint4 ef[TPW], ee[TPW];
 #pragma unroll
+#ifdef NSK_ABL_LNOEV
+        for (int k = 0; k < TPW; k++) { ef[k] = g.ztab[ti.zoff + idf[k]]; ee[k] = ef[k]; }
+#else
         for (int k = 0; k < TPW; k++) { ef[k] = g.ztab[ti.zoff + idf[k]]; ee[k] = g.ztab[ti.zoff + ide[k]]; }
+#endif
         // the next trip's requests go out behind the table loads (vmcnt counts in order: waiting
         // for the entries then leaves these in flight)
 #ifdef NSK_LEARN_PREFETCH
@@ -942,7 +970,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             if (ti.ev != 1) evidence = k53(rr.z, rr.w) > (((unsigned long long)ee[k].y << 32) | ee[k].x) ? 1 : 0;   // 54-58
             const int proposal = k53(rr.x, rr.y) > (((unsigned long long)ef[k].y << 32) | ef[k].x) ? 1 : 0;         // 66-70
             if (valid) {
+#ifndef NSK_ABL_LNOEVST
                 g.val_evid[p] = (VT)evidence;
+#endif
                 g.val[p] = (VT)proposal;
             }
             const bool part = valid && (lp.learn_non_evidence || ti.ev == 1);     // 71-72
@@ -954,12 +984,19 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             // the slots' satisfied bits of the two chains, zero for lanes that do not take part
             const uint32_t satf = part ? (proposal ? (ef[k].z >> 8) : ef[k].z) : 0u;
             const uint32_t sate = part ? (evidence ? (ee[k].z >> 8) : ee[k].z) : 0u;
+#if defined(NSK_ABL_LNOBALLOT)
+            acc[0] += __popcll(__ballot((satf ^ sate) & 1u));
+#else
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++)
                 acc[j] += __popcll(__ballot((satf >> j) & 1u)) - __popcll(__ballot((sate >> j) & 1u));
+#endif
         }
     }
     flush();
+#ifdef NSK_ABL_LNOSINK
+    if (accK == 0xFFFFFFF1u)
+#endif
     close_sink<SMALLW>(g, sk);
 }
 

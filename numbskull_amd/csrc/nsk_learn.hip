@@ -171,7 +171,9 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             cs.join();
             if (nw > 0) {
                 if (SMALLW) {
+#ifndef NSK_ABL_NOAPPLY
                     k_apply_bins<<<dim3(1), dim3(NSK_BLOCK), 0, g->stream>>>(aa);
+#endif
                     if (g->c.nfast > 0 && !tabs_here) nsk_refresh_ztab(g);       // big tables: own launch
                 } else {
                     k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(

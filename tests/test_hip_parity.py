@@ -435,16 +435,20 @@ def test_learning_with_unpacked_accumulators(golden, name, reg, monkeypatch):
     assert np.array_equal(fg.weight_value[0], wv)
 
 
+@pytest.mark.parametrize("bins", ["xcd", "agent"])
 @pytest.mark.parametrize("evidence", ["all", "half"])
-def test_learning_table_kernel_with_a_tiny_resident_grid(monkeypatch, evidence):
+def test_learning_table_kernel_with_a_tiny_resident_grid(monkeypatch, evidence, bins):
     """k_learn_seg_tab's waves walk several trips each -- across segment boundaries, with the
     gradient counts carried in scalar registers until the slot program changes -- when the grid
     is smaller than the work: NSK_LEARN_GRID_CAP=8 forces that on a 128x128 grid (interior and
     border segments, with and without the evidence chain's own draw): same samples and weights as
-    the oracle."""
+    the oracle.  bins: the blocks' partial sums go to bins of their own XCD (workgroup-scope adds in
+    that L2, the gfx950 path) or, with NSK_ONE_ACC, to bins shared across XCDs (agent-scope adds)."""
     from numbskull_amd import graphgen
     monkeypatch.setenv("NSK_DIAG", "1")
-    monkeypatch.setenv("NSK_LEARN_GRID_CAP", "8")
+    monkeypatch.setenv("NSK_LEARN_GRID_CAP", "8" if bins == "xcd" else "64")
+    if bins == "agent":
+        monkeypatch.setenv("NSK_ONE_ACC", "1")
     rng = np.random.Generator(np.random.PCG64(11))
     ev = rng.integers(0, 2, 128 * 128)
     g = graphgen.ising_grid(128, 128, weight=0.0, fixed=False, two_weights=True, evidence=ev)
@@ -462,6 +466,29 @@ def test_learning_table_kernel_with_a_tiny_resident_grid(monkeypatch, evidence):
         step *= 0.9
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.array_equal(fg.weight_value[0], wv)
+
+
+@pytest.mark.parametrize("cap", ["8", "24"])
+def test_inference_table_kernel_with_a_tiny_resident_grid(monkeypatch, cap):
+    """k_gibbs_seg_tab's waves walk several tile pairs each, across segment boundaries, when the
+    grid is smaller than the work (what the 7-blocks-per-CU grid does on the 10M / 40M grids):
+    NSK_TAB_GRID_CAP forces that on a 128x128 grid with an evidence border -- values and tallies
+    as the oracle's, eager launches and the captured sweep sequence alike (17 + 3 sweeps)."""
+    from numbskull_amd import graphgen
+    monkeypatch.setenv("NSK_DIAG", "1")
+    monkeypatch.setenv("NSK_TAB_GRID_CAP", cap)
+    g = graphgen.ising_grid(128, 128, weight=0.2)
+    rng = np.random.Generator(np.random.PCG64(5))
+    g[1]["isEvidence"] = rng.random(128 * 128) < 0.1
+    ns, fg = session(g, seed=21)
+    assert fg.info()["ztab_entries"] > 0
+    og = oracle_of(fg, False)
+    order, ps = phases_from_colors(fg.colors())
+    vv, _, wv, cnt = og.initial_state()
+    fg.inference(3, 17, False)
+    for s in range(20):
+        og.gibbs_dev(order, ps, vv, wv, cnt, 21, s, False, burnin=s < 3)
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
 
 
 def test_general_tiles_at_scale():
