@@ -4,6 +4,9 @@
 # set in its own run, calibrated on a known-byte stream copy of the same run) for the workloads listed,
 # the bench lines of the large configurations, and the HBM-traffic table bench.py reads.  Output:
 # gpurun_out/profiles_r3/ (tools/install_profiles.sh copies it into profiles/).
+# NSK_PROFILE_PARTIAL=1 with NSK_PROFILE_WORKLOADS / NSK_PROFILE_BENCH_ONLY: only those workloads (a change
+# that touches some kernel families only); the traffic table keeps the other workloads' entries and
+# install_profiles.sh replaces only the files collected.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 OUT=$R/gpurun_out/profiles_r3
 rm -rf $OUT; mkdir -p $OUT
@@ -24,6 +27,9 @@ import json, glob, os
 out = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh (tools/profile_gpu.sh per workload), "
                   "corrected with the known-byte stream-copy calibration of the same run; all workloads collected in the same "
                   "gpurun call as the bench lines (commit: profiles/r3_COMMIT.txt); separate passes from the bench run"}
+if os.environ.get("NSK_PROFILE_PARTIAL") and os.path.exists("$R/profiles/traffic.json"):
+    prev = json.load(open("$R/profiles/traffic.json"))
+    out.update({k: v for k, v in prev.items() if not k.startswith("_")})
 for f in sorted(glob.glob("$TRAFFIC/traffic_*.json")):
     out.update(json.load(open(f)))
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
