@@ -99,7 +99,9 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     rest_in_general = nrest_all > 0;
                     const int rblocks = (nrest_all + 3) / 4;
                     // resident grid: 7 workgroups per CU (22 KB of LDS each), whole rounds of XCDs
-                    const int gblocks = 8 * ((std::min(ngroups, 256 * 7) + 7) / 8);
+                    const char *pcu_env = nsk::diag_env("NSK_EP_PER_CU");        // (diagnostic: workgroups per CU)
+                    const int pcu = pcu_env ? std::max(1, std::min(7, atoi(pcu_env))) : 7;
+                    const int gblocks = 8 * ((std::min(ngroups, 256 * pcu) + 7) / 8);
                     const dim3 grid(hblocks + gblocks + rblocks);
                     const size_t smem = 0;
 #define NSK_EP_ARGS d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, ngt, ngroups, (int)g->c.phase_ep_base[ph], gblocks, fe, he, hblocks, \

@@ -89,7 +89,8 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             if (ep) {                   // entry-parallel groups: hubs, the general tiles and the rest tiles
                 const int ngroups = (int)(g->c.phase_ep_base[ph + 1] - g->c.phase_ep_base[ph]);
                 // resident grid: the static LDS (26.5 KB) + the SMALLW tables bound the workgroups per CU
-                const int per_cu = std::max(1, std::min(8, (int)((size_t)(160 << 10) / (27136 + shmem + 256))));
+                const char *pcu_env = nsk::diag_env("NSK_EP_PER_CU");            // (diagnostic: workgroups per CU)
+                const int per_cu = std::max(1, std::min(pcu_env ? atoi(pcu_env) : 8, (int)((size_t)(160 << 10) / (27136 + shmem + 256))));
                 const int gblocks = 8 * ((std::min(256 * per_cu, ngroups) + 7) / 8);
                 const int nbh = (int)(g->c.phase_bighub_base[ph + 1] - g->c.phase_bighub_base[ph]);   // a block per long-list hub
                 const int hbl_ep = nbh + hbl;
