@@ -141,6 +141,11 @@ typedef struct {
     int64_t learn_clipped;            /* weight updates whose step was clipped so far              */
     int64_t grad_shift;               /* gradient sums are Q(31+s).(32-s) fixed point: s (0 unless one
                                          weight's sum in one colour class could reach 2^30)        */
+    int64_t acc_copies;               /* copies of the global learning accumulators: 8 (one per XCD, after
+                                         the device passed the self-test of nsk_graph_create), 1 for a
+                                         graph that accumulates in LDS or a device that failed it; +16
+                                         when the LDS path's bins are private to XCDs; 0 from
+                                         nsk_graph_plan (no device)                                */
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);

@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +75,43 @@ static int dev_upload(nsk_graph *g, T **ptr, const std::vector<T> &h) {
     if (rc) return rc;
     if (!h.empty()) HIPCHECK(hipMemcpyAsync(*ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, g->stream));
     return NSK_OK;
+}
+
+// May this device keep XCD-private accumulators (workgroup-scope atomics in the issuing XCD's L2,
+// private copies picked by HW_REG_XCC_ID)?  gfx942 / gfx950 by architecture name AND a self-test, run
+// once per device and process: 2048 x 256 threads add to the slot of their XCD (k_xcd_selftest); the
+// slots, read back after the kernel boundary, must add up to the number of threads, with ids < 8.
+static bool xcd_private_ok(nsk_graph *g) {
+    static std::mutex mu;
+    static std::map<int, bool> verdict;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = verdict.find(g->device);
+    if (it != verdict.end()) return it->second;
+    bool ok = false;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, g->device) == hipSuccess &&
+        (strstr(prop.gcnArchName, "gfx950") || strstr(prop.gcnArchName, "gfx942"))) {
+        unsigned int *d = nullptr, h[17];
+        const unsigned int nblocks = 2048, nthreads = 256;
+        if (hipMalloc((void **)&d, sizeof(h)) == hipSuccess) {
+            bool ran = hipMemsetAsync(d, 0, sizeof(h), g->stream) == hipSuccess;
+            if (ran) {
+                k_xcd_selftest<<<dim3(nblocks), dim3(nthreads), 0, g->stream>>>(d);
+                ran = hipGetLastError() == hipSuccess &&
+                      hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, g->stream) == hipSuccess &&
+                      hipStreamSynchronize(g->stream) == hipSuccess;
+            }
+            if (ran) {
+                unsigned long long sum = 0;
+                for (int i = 0; i < 16; i++) sum += h[i];
+                ok = sum == (unsigned long long)nblocks * nthreads && h[16] != 0u && (h[16] >> NSK_XCDS) == 0u;
+            }
+            (void)hipFree(d);
+        }
+        if (!ok && getenv("NSK_VERBOSE")) fprintf(stderr, "[nsk] XCD-private accumulators: self-test failed, one shared copy\n");
+    }
+    verdict[g->device] = ok;
+    return ok;
 }
 
 // narrow int32 host values to the device value type (int8 / int32) and upload
@@ -246,11 +285,10 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     // weights accumulate in LDS and never touch them
     g->acc_copies = (!g->smallw && c.nweight <= (1 << 21)) ? NSK_XCDS : 1;
     {   // the XCD-private copies rely on global atomics executing in the issuing XCD's own L2 and on
-        // HW_REG_XCC_ID (nsk_device.h sink_add): true on gfx942 / gfx950, so any other architecture (or
-        // NSK_DIAG=1 NSK_ONE_ACC=1) keeps ONE copy updated with agent-scope atomics
-        hipDeviceProp_t prop;
-        const bool known = hipGetDeviceProperties(&prop, g->device) == hipSuccess &&
-                           (strstr(prop.gcnArchName, "gfx950") || strstr(prop.gcnArchName, "gfx942"));
+        // HW_REG_XCC_ID (nsk_device.h sink_add): true on gfx942 / gfx950 -- and checked once per device by
+        // xcd_private_ok -- so any other architecture, a failed check (or NSK_DIAG=1 NSK_ONE_ACC=1) keeps
+        // ONE copy updated with agent-scope atomics
+        const bool known = xcd_private_ok(g);
         if (!known || nsk::diag_env("NSK_ONE_ACC")) g->acc_copies = 1;
         g->bins_xcd = (known && !nsk::diag_env("NSK_ONE_ACC")) ? 1 : 0;
     }
@@ -502,6 +540,7 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->learn_cap = 0.5;
     info->learn_clipped = 0;
     info->grad_shift = c.grad_shift;
+    info->acc_copies = 0;
 }
 
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
@@ -517,6 +556,7 @@ int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
         if (hipMemcpy(&n, g->clip_count, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) info->learn_clipped = (int64_t)n;
     }
     info->compile_seconds = g->compile_seconds;
+    info->acc_copies = g->acc_copies + (g->bins_xcd ? 16 : 0);
     return NSK_OK;
 }
 

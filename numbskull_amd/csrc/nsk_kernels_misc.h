@@ -124,6 +124,17 @@ static __global__ void k_graph_counters(unsigned long long *c, unsigned long lon
     else { c[0] += sweep; c[1] += tag; }
 }
 
+// Self-test of the XCD-private accumulators (nsk_api.hip, once per device): every thread adds 1 to the
+// slot of the XCD it runs on (HW_REG_XCC_ID) with a workgroup-scope atomic -- the add executes in that
+// XCD's L2 -- and marks the id it saw.  The slots must add up to the number of threads: if two dies
+// with incoherent L2s reported one id, or the adds did not reach memory at the kernel boundary, counts
+// would be lost.  out[0..15]: slots, out[16]: mask of ids seen.
+static __global__ void k_xcd_selftest(unsigned int *out) {
+    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;
+    (void)__hip_atomic_fetch_add(&out[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_or(&out[16], 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // weight merge of the partitioned learning sweep: delta = w - start ... w = start + sum(delta)
 static __global__ __launch_bounds__(NSK_BLOCK) void k_weight_delta(const double *w, const double *start, double *delta, int n) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);

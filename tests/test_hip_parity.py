@@ -397,10 +397,18 @@ def test_learning_accumulator_fallbacks(golden, name, switch, monkeypatch):
     """NSK_ONE_ACC: one copy of the global gradient accumulators updated with agent-scope atomics -- what
     an architecture other than gfx942 / gfx950 gets instead of the XCD-private copies; NSK_NO_KSTAT:
     every visit goes through the accumulators instead of the structural visit counts.  Same weights."""
+    g, hbv = _small_graphs(golden)[name]
+    if switch == "NSK_ONE_ACC":
+        # the product configuration on an MI355X: the device passed nsk_graph_create's self-test of the
+        # XCD-private accumulators (k_xcd_selftest), so a many-weight graph keeps 8 copies
+        ns0, fg0 = session(g, seed=5, head_by_vid=hbv)
+        assert fg0.info()["acc_copies"] & 15 == 8
+        fg0.close()
     monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv(switch, "1")
-    g, hbv = _small_graphs(golden)[name]
     ns, fg = session(g, seed=5, head_by_vid=hbv)
+    if switch == "NSK_ONE_ACC":
+        assert fg.info()["acc_copies"] == 1
     og = oracle_of(fg, hbv)
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, _ = og.initial_state()
@@ -456,6 +464,7 @@ def test_learning_table_kernel_with_a_tiny_resident_grid(monkeypatch, evidence, 
         g[1]["isEvidence"] = rng.random(128 * 128) < 0.5
     ns, fg = session(g, seed=9)
     assert fg.info()["ztab_entries"] > 0
+    assert fg.info()["acc_copies"] == (17 if bins == "xcd" else 1)     # LDS sums; bins private to XCDs or not
     og = oracle_of(fg, False)
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, cnt = og.initial_state()
