@@ -54,6 +54,7 @@ WORKLOADS = {
     "lr50m": (10000, 5000, False),
     "lr50m_learn": (10000, 5000, True),
     "ising64k": (256, 256, False),            # plumbing tests
+    "lr300k_learn": (600, 500, True),
     # 4x / 10x the metric config: the streams of one sweep (0.8 / 2 GB) no longer fit the 256 MiB
     # Infinity Cache, so the rate is HBM's
     "ising40m": (5000, 8000, False),
@@ -88,6 +89,27 @@ def build_graph(rows, cols, learning, seed=20240602, name=None):
     rng = np.random.Generator(np.random.PCG64(seed))
     ev = rng.integers(0, 2, rows * cols)
     return graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True, evidence=ev)
+
+
+def build_shard(rows, cols, learning, name, lo, hi):
+    """Rank-local graph of an N-rank run: (graph, global_ids, own_local, nfactor_total, nweight_total,
+    seconds).  The LR workloads generate the shard alone (graphgen.mixed_lr_shard: 4 bytes per variable
+    of the whole graph + this rank's factors -- the reference's minions load only their partition,
+    salt/src/numbskull_minion.py:185); the grids are cut out of the generated graph."""
+    from numbskull_amd import graphgen
+    t0 = time.time()
+    if name.startswith("lr"):
+        g, gids, own_local = graphgen.mixed_lr_shard(rows * cols, lo, hi, seed=20240603)
+        return g, gids, own_local, None, len(g[0]), time.time() - t0
+    whole = build_graph(rows, cols, learning, name=name)
+    nf, nw = len(whole[2]), len(whole[0])
+    g, gids, own_local = graphgen.extract_shard(whole, lo, hi)
+    return g, gids, own_local, nf, nw, time.time() - t0
+
+
+def peak_rss_gb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2.0 ** 20
 
 
 def native_oracle():
@@ -310,12 +332,12 @@ def dry_run(args, dist, rank, world, rows, cols, learning):
     from contextlib import redirect_stdout
     import numbskull_amd
     from numbskull_amd.distributed import shard_range, plan_boundaries, gather_needs
-    g = build_graph(rows, cols, learning, name=args.workload)
-    ns = numbskull_amd.NumbSkull(quiet=True, seed=args.seed)
+    ns = numbskull_amd.NumbSkull(quiet=True, seed=args.seed, head_by_vid=args.workload.startswith("lr"))
     own = shard_range(rank, world, rows * cols)
     if world > 1:
-        from numbskull_amd import graphgen
-        g, gids, own_local = graphgen.extract_shard(g, own[0], own[1])
+        g, gids, own_local, _, _, _ = build_shard(rows, cols, learning, args.workload, own[0], own[1])
+    else:
+        g = build_graph(rows, cols, learning, name=args.workload)
     w, v, f, fm, dm, edges = g
     with redirect_stdout(io.StringIO()):
         if world > 1:
@@ -327,11 +349,15 @@ def dry_run(args, dist, rank, world, rows, cols, learning):
     needs = gids[fg.ghost_needs(host_only=True)].astype(np.int32) if world > 1 else np.zeros(0, np.int32)
     nb = int(len(needs))
     sampled = int((color >= 0).sum())
+    rss = peak_rss_gb()
     if world > 1:
         import torch
         t = torch.tensor([sampled, nb], dtype=torch.int64)
         dist.all_reduce(t)
         sampled, nb = int(t[0]), int(t[1])
+        t = torch.tensor([rss], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rss = float(t[0])
         lists, slot = plan_boundaries(gather_needs(dist, torch, needs, world, "cpu"), world, rows * cols)
         nb = int(sum(len(x) for x in lists))
         dist.barrier()
@@ -340,7 +366,8 @@ def dry_run(args, dist, rank, world, rows, cols, learning):
         print(json.dumps({"metric": "variable-updates/sec", "value": 0.0, "unit": "variable-updates/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
                           "config": {"name": args.workload, "sampled_total": sampled, "boundary_total": nb,
-                                     "colors": info["ncolors"]}}))
+                                     "colors": info["ncolors"], "variables_held_by_rank0": int(len(v)),
+                                     "peak_rss_gb_max_over_ranks": round(rss, 2)}}))
 
 
 def main():
@@ -384,28 +411,30 @@ def main():
     is_grid = args.workload.startswith("ising")
     if os.environ.get("NSK_BENCH_DRYRUN"):
         return dry_run(args, dist, rank, world, rows, cols, learning)
-    t_gen = time.time()
-    g = build_graph(rows, cols, learning, name=args.workload)
-    t_gen = time.time() - t_gen
     nvar = rows * cols
     ns = numbskull_amd.NumbSkull(quiet=True, device=local_rank, seed=args.seed,
                                  head_by_vid=args.workload.startswith("lr"))
     own = shard_range(rank, world, nvar)
     import io
     from contextlib import redirect_stdout
-    t_load = time.time()
-    nfactor_total, nweight_total = len(g[2]), len(g[0])
     if world > 1:
-        # every rank keeps only its shard -- owned variables, the ghosts they read, the factors that
-        # touch them (graphgen.extract_shard; the reference's minions load their partition only,
-        # salt/src/numbskull_minion.py:185) -- and drops the generated whole graph
-        from numbskull_amd import graphgen
-        g, gids, own_local = graphgen.extract_shard(g, own[0], own[1])
+        # every rank holds only its shard -- owned variables, the ghosts they read, the factors that
+        # touch them (the reference's minions load their partition only, salt/src/numbskull_minion.py:185);
+        # the LR workloads never materialise the whole graph (graphgen.mixed_lr_shard)
+        g, gids, own_local, nfactor_total, nweight_total, t_gen = build_shard(rows, cols, learning, args.workload, own[0], own[1])
         w, v, f, fm, dm, edges = g
+        if nfactor_total is None:                   # (factors with members in several shards are held by each of them)
+            nfactor_total = -1
+        t_load = time.time()
         with redirect_stdout(io.StringIO()):
             ns.loadFactorGraph(w, v, f, fm, dm, int(edges), own_range=own_local, global_ids=gids)
     else:
+        t_gen = time.time()
+        g = build_graph(rows, cols, learning, name=args.workload)
+        t_gen = time.time() - t_gen
+        nfactor_total, nweight_total = len(g[2]), len(g[0])
         w, v, f, fm, dm, edges = g
+        t_load = time.time()
         with redirect_stdout(io.StringIO()):
             ns.loadFactorGraph(w, v, f, fm, dm, int(edges))
     fg = ns.factorGraphs[0]
@@ -449,6 +478,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         blocks = [(float(t[i].item()), b[1], b[2]) for i, b in enumerate(blocks)]
     dt, ms_ev_v, launches_v = median_block(blocks)
+    if sampler is not None:
+        sampler.check()                  # a peer-to-peer exchange that timed out fails the run here
 
     class _V(object):       # (keeps the names the report below uses)
         def __init__(self, v):

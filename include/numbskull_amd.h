@@ -166,6 +166,10 @@ int nsk_graph_plan_needs(const nsk_graph_desc *desc, int64_t *count, int32_t *vi
  * between begin and end (bench.py's roofline leg). */
 int nsk_profile_begin(nsk_graph *g);
 int nsk_profile_end(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches);
+/* the same bracket without blocking at its end: nsk_profile_mark records the closing event,
+ * nsk_profile_read waits for it (handles whose streams wait for each other are marked first, read later) */
+int nsk_profile_mark(nsk_graph *g);
+int nsk_profile_read(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches);
 
 /* Multi-GPU plumbing: raw device addresses of the value arrays (element size = value_bytes,
  * indexed by INTERNAL id, see nsk_graph_get_layout), of the weights and of the boundary staging
@@ -212,22 +216,39 @@ int nsk_learn_sweeps_exchange(nsk_graph *g, int64_t nsweeps, double step, double
                               int learn_non_evidence);
 int nsk_synchronize(nsk_graph *g);
 
-/* Peer-to-peer boundary exchange on one node (after nsk_exchange_setup): instead of pack ->
- * ncclAllGather -> unpack, a rank writes its boundary values straight into buffers of its peers
- * (device memory they expose with hipIpc; over xGMI between GPUs) and raises a flag there; a rank
- * waits for the flags of the ranks it reads from and scatters their values -- no collective, no
- * host round trip per sweep (the reference's per-epoch owner -> replica copy,
- * salt/src/numbskull_master.py:165-224).
- *   nsk_p2p_export  allocates this rank's buffers; handles128 receives two 64-byte hipIpc handles
- *   nsk_p2p_import  all_handles: the world x 128 bytes of every rank, gathered by the caller;
- *                   readers: world flags, readers[q] != 0 iff rank q reads boundary values of this rank
- *   nsk_gibbs_sweeps_p2p  `nsweeps` x (sweep, push to peers, wait + unpack) on the library's stream;
- *                   NSK_E_DEVICE when a peer's flag does not arrive within ~2 s
- *   nsk_p2p_exchange  one exchange of the current boundary values alone (set-up self-test) */
-int nsk_p2p_export(nsk_graph *g, void *handles128);
-int nsk_p2p_import(nsk_graph *g, const void *all_handles, const int32_t *readers);
+/* Peer-to-peer boundary exchange on one node: instead of pack -> ncclAllGather -> unpack, a rank writes
+ * the boundary values each peer reads straight into that peer's buffer (device memory the peer exposes
+ * with hipIpc; over xGMI between GPUs) and raises a flag there; a rank waits for the flags of its peers
+ * and scatters their values -- no collective, no host round trip per sweep (the reference's per-epoch
+ * owner -> replica copy, salt/src/numbskull_master.py:165-224).  Learning epochs send both chains and the
+ * epoch's weight deltas the same way and merge them as w = w_start + (d_0 + d_1 + ...) in rank order on
+ * every rank (the master's rule, numbskull_master.py:223-224; minions' deltas numbskull_minion.py:260-280).
+ *   nsk_p2p_setup   PAIRWISE lists: send_vids[send_off[q] .. send_off[q+1]) = the owned variables rank q
+ *                   reads, recv_vids[recv_off[q] ..) = the variables this handle reads from rank q, both in
+ *                   the order the two sides agreed on (ascending global id); peer_base[q] = where this
+ *                   rank's segment starts in q's receive list, peer_total[q] = length of q's receive list
+ *   nsk_p2p_export  allocates this rank's buffer; handle64 (may be NULL) receives its hipIpc handle, *base
+ *                   (may be NULL) its device address
+ *   nsk_p2p_import  all_handles: world x 64 bytes, gathered by the caller (one process per rank)
+ *   nsk_p2p_import_local  bases[q] = device address of rank q's buffer, for ranks that live in ONE process
+ *                   (several handles on one device, or one process driving several GPUs with peer access)
+ *   nsk_gibbs_sweeps_p2p / nsk_learn_sweeps_p2p  `nsweeps` x (sweep, push to peers, wait + unpack [+ weight
+ *                   merge]) enqueued on the library's stream; asynchronous like nsk_gibbs_sweeps
+ *   nsk_p2p_exchange  one exchange alone (learn != 0: both chains + weight deltas); part 0 = all of it,
+ *                   1 = the pushes, 2 = flags + wait + unpack (set-up self-test, phase timings)
+ *   nsk_p2p_check   synchronises and returns NSK_E_DEVICE when a peer's flag did not arrive within
+ *                   NSK_P2P_TIMEOUT_S seconds (default 30) in any exchange since the last check */
+int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, const int64_t *send_off,
+                  const int32_t *recv_vids, const int64_t *recv_off, const int64_t *peer_base,
+                  const int64_t *peer_total);
+int nsk_p2p_export(nsk_graph *g, void *handle64, void **base);
+int nsk_p2p_import(nsk_graph *g, const void *all_handles);
+int nsk_p2p_import_local(nsk_graph *g, void *const *bases);
 int nsk_gibbs_sweeps_p2p(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin);
-int nsk_p2p_exchange(nsk_graph *g);
+int nsk_learn_sweeps_p2p(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                         double reg_param, int64_t truncation, int learn_non_evidence);
+int nsk_p2p_exchange(nsk_graph *g, int learn, int part);
+int nsk_p2p_check(nsk_graph *g);
 
 /* ---- host-side index build and file parsing (no GPU needed) ---- */
 /* dataloading.compute_var_map (dataloading.py:16-81), native and O(edges). */

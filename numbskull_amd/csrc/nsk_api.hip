@@ -173,6 +173,8 @@ int nsk_graph_destroy(nsk_graph *g) {
     if (!g) return NSK_OK;
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (int q = 0; q < 16; q++)           // peers' allocations mapped with hipIpc
+        if (g->p2p_peer_ipc[q] && g->p2p_peer_base[q]) (void)hipIpcCloseMemHandle(g->p2p_peer_base[q]);
     for (void *p : g->allocs) (void)hipFree(p);
     if (g->sweep_graph) (void)hipGraphExecDestroy(g->sweep_graph);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
@@ -297,7 +299,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &g->K, nacc); if (rc) return rc;
     rc = dev_alloc(g, &g->T, nacc); if (rc) return rc;
     rc = dev_alloc(g, &g->clip_count, 1); if (rc) return rc;
-    rc = dev_alloc(g, &g->d_counters, 2); if (rc) return rc;
+    rc = dev_alloc(g, &g->d_counters, 4); if (rc) return rc;
     HIPCHECK(hipMemsetAsync(g->clip_count, 0, sizeof(unsigned int), g->stream));
     rc = dev_alloc(g, &g->mt_np, 1); if (rc) return rc;
     rc = dev_alloc(g, &g->mt_py, 1); if (rc) return rc;
@@ -615,6 +617,24 @@ int nsk_profile_end(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches) 
     return NSK_OK;
 }
 
+int nsk_profile_mark(nsk_graph *g) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    HIPCHECK(hipEventRecord(g->ev1, g->stream));
+    return NSK_OK;
+}
+
+int nsk_profile_read(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    HIPCHECK(hipSetDevice(g->device));
+    HIPCHECK(hipEventSynchronize(g->ev1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    if (elapsed_ms) *elapsed_ms = (double)ms;
+    if (kernel_launches) *kernel_launches = g->launches - g->launches_at_begin;
+    return NSK_OK;
+}
+
 int nsk_device_buffer(nsk_graph *g, int which, void **ptr, int64_t *nbytes) {
     if (!g || !ptr) return fail(NSK_E_INVALID, "null argument");
     switch (which) {
@@ -730,13 +750,20 @@ int nsk_exchange_setup(nsk_graph *g, int world, int rank, const int32_t *send_vi
     if ((rc = dev_alloc(g, &t, (size_t)slot * vb * world))) return rc; g->x_recv_evid = t;
     HIPCHECK(hipMemsetAsync(g->x_send, 0, (size_t)(slot ? slot : 1) * vb, g->stream));
     HIPCHECK(hipMemsetAsync(g->x_send_evid, 0, (size_t)(slot ? slot : 1) * vb, g->stream));
-    if ((rc = dev_alloc(g, &g->w_start, (size_t)g->c.nweight))) return rc;
-    if ((rc = dev_alloc(g, &g->w_delta, (size_t)g->c.nweight))) return rc;
+    if (!g->w_start) {
+        if ((rc = dev_alloc(g, &g->w_start, (size_t)g->c.nweight))) return rc;
+        if ((rc = dev_alloc(g, &g->w_delta, (size_t)g->c.nweight))) return rc;
+    }
     HIPCHECK(hipStreamSynchronize(g->stream));
     return NSK_OK;
 }
 
 }  // extern "C"
+
+void nsk_drop_sweep_graph(nsk_graph *g) {
+    if (g->sweep_graph) { (void)hipGraphExecDestroy(g->sweep_graph); g->sweep_graph = nullptr; }
+    g->sweep_graph_key = -1;
+}
 
 template <typename VT>
 static int exchange_kernels(nsk_graph *g, int which, bool pack) {
@@ -772,107 +799,249 @@ int nsk_exchange_pack(nsk_graph *g, int which) { return exchange_step(g, which, 
 int nsk_exchange_unpack(nsk_graph *g, int which) { return exchange_step(g, which, false); }
 
 // ---- peer-to-peer exchange ------------------------------------------------------------------------
-int nsk_p2p_export(nsk_graph *g, void *handles128) {
-    if (!g || !handles128) return fail(NSK_E_INVALID, "null argument");
-    if (g->xworld == 0) return fail(NSK_E_INVALID, "nsk_exchange_setup has not been called");
-    if (g->xworld > 16) return fail(NSK_E_INVALID, "peer-to-peer exchange serves at most 16 ranks (one node)");
+int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, const int64_t *send_off,
+                  const int32_t *recv_vids, const int64_t *recv_off, const int64_t *peer_base,
+                  const int64_t *peer_total) {
+    if (!g || world < 1 || world > 16 || rank < 0 || rank >= world || !send_off || !recv_off || !peer_base || !peer_total)
+        return fail(NSK_E_INVALID, "bad peer-to-peer description (at most 16 ranks: one node)");
     HIPCHECK(hipSetDevice(g->device));
-    const size_t vb = (size_t)g->c.vbytes;
-    const size_t rbytes = std::max<size_t>(2 * (size_t)g->xworld * (size_t)g->xslot * vb, 256);
-    const size_t fbytes = 2 * (size_t)g->xworld * sizeof(unsigned int);
-    if (!g->p2p_recv) {
-        // fine-grained: a peer's stores and this rank's polling loads are coherent while kernels run
-        HIPCHECK(hipExtMallocWithFlags(&g->p2p_recv, rbytes, hipDeviceMallocFinegrained));
-        HIPCHECK(hipExtMallocWithFlags((void **)&g->p2p_flags, fbytes + 64, hipDeviceMallocFinegrained));
-        g->allocs.push_back(g->p2p_recv);
-        g->allocs.push_back(g->p2p_flags);
-        g->device_bytes += (int64_t)(rbytes + fbytes);
-        int rc = dev_alloc(g, &g->p2p_err, 1);
-        if (rc) return rc;
-        HIPCHECK(hipMemsetAsync(g->p2p_recv, 0, rbytes, g->stream));
-        HIPCHECK(hipMemsetAsync(g->p2p_flags, 0, fbytes + 64, g->stream));
-        HIPCHECK(hipMemsetAsync(g->p2p_err, 0, sizeof(unsigned int), g->stream));
-        HIPCHECK(hipStreamSynchronize(g->stream));
+    const int64_t nsend = send_off[world], nrecv = recv_off[world];
+    if (send_off[0] != 0 || recv_off[0] != 0 || nsend < 0 || nrecv < 0) return fail(NSK_E_INVALID, "bad list offsets");
+    for (int q = 0; q < world; q++) {
+        if (send_off[q + 1] < send_off[q] || recv_off[q + 1] < recv_off[q]) return fail(NSK_E_INVALID, "bad list offsets");
+        const int64_t seg = send_off[q + 1] - send_off[q];
+        if (peer_base[q] < 0 || peer_base[q] + seg > peer_total[q]) return fail(NSK_E_INVALID, "a send segment does not fit its reader's buffer");
     }
-    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
-    hipIpcMemHandle_t h[2];
-    HIPCHECK(hipIpcGetMemHandle(&h[0], g->p2p_recv));
-    HIPCHECK(hipIpcGetMemHandle(&h[1], g->p2p_flags));
-    memcpy(handles128, h, 128);
+    if (send_off[rank + 1] != send_off[rank] || recv_off[rank + 1] != recv_off[rank])
+        return fail(NSK_E_INVALID, "a rank does not exchange with itself");
+    if (peer_total[rank] != nrecv) return fail(NSK_E_INVALID, "peer_total[rank] must be this rank's receive total");
+    std::vector<int32_t> sv((size_t)nsend), rv((size_t)nrecv);
+    for (int64_t i = 0; i < nsend; i++) {
+        if (send_vids[i] < g->c.own_begin || send_vids[i] >= g->c.own_end)
+            return fail(NSK_E_INDEX, "send list names a variable this handle does not own");
+        sv[(size_t)i] = g->c.iid[send_vids[i]];               // the kernels address values by internal id
+    }
+    for (int64_t j = 0; j < nrecv; j++) {
+        if (recv_vids[j] < 0 || recv_vids[j] >= g->c.nvar || (recv_vids[j] >= g->c.own_begin && recv_vids[j] < g->c.own_end))
+            return fail(NSK_E_INDEX, "receive list names a variable this handle owns or does not hold");
+        rv[(size_t)j] = g->c.iid[recv_vids[j]];
+    }
+    nsk_drop_sweep_graph(g);
+    g->p2p_ready = false;
+    g->pworld = world; g->prank = rank; g->p_nsend = nsend; g->p_nrecv = nrecv;
+    g->p_soff.assign(send_off, send_off + world + 1);
+    g->p_dbase.assign(peer_base, peer_base + world);
+    g->p_dtotal.assign(peer_total, peer_total + world);
+    g->p2p_peer_mask = 0;
+    for (int q = 0; q < world; q++)             // symmetric: q is a peer when either side reads from the other
+        if (q != rank && (send_off[q + 1] > send_off[q] || recv_off[q + 1] > recv_off[q])) g->p2p_peer_mask |= 1u << q;
+    int rc;
+    if ((rc = dev_upload(g, &g->p_send_iid, sv))) return rc;
+    if ((rc = dev_upload(g, &g->p_recv_iid, rv))) return rc;
+    if (!g->w_start) {
+        if ((rc = dev_alloc(g, &g->w_start, (size_t)g->c.nweight))) return rc;
+        if ((rc = dev_alloc(g, &g->w_delta, (size_t)g->c.nweight))) return rc;
+    }
+    if (!g->p2p_err) {
+        if ((rc = dev_alloc(g, &g->p2p_err, 2))) return rc;          // [0] time-out mark, [1] the push kernel's ticket
+        HIPCHECK(hipMemsetAsync(g->p2p_err, 0, 2 * sizeof(unsigned int), g->stream));
+    }
+    if (const char *t = getenv("NSK_P2P_TIMEOUT_S")) {
+        const double sec = atof(t);
+        if (sec > 0) g->p2p_timeout_ticks = (unsigned long long)(sec * 1e8);
+    }
+    HIPCHECK(hipStreamSynchronize(g->stream));
     return NSK_OK;
 }
 
-int nsk_p2p_import(nsk_graph *g, const void *all_handles, const int32_t *readers) {
-    if (!g || !all_handles || !readers) return fail(NSK_E_INVALID, "null argument");
-    if (!g->p2p_recv) return fail(NSK_E_INVALID, "nsk_p2p_export first");
-    HIPCHECK(hipSetDevice(g->device));
-    g->p2p_peer_mask = 0; g->p2p_src_mask = 0;
-    for (int q = 0; q < g->xworld; q++) {
-        if (q == g->xrank) { g->p2p_peer_recv[q] = g->p2p_recv; g->p2p_peer_flags[q] = g->p2p_flags; continue; }
-        hipIpcMemHandle_t h[2];
-        memcpy(h, (const char *)all_handles + (size_t)q * 128, 128);
-        HIPCHECK(hipIpcOpenMemHandle(&g->p2p_peer_recv[q], h[0], hipIpcMemLazyEnablePeerAccess));
-        HIPCHECK(hipIpcOpenMemHandle(&g->p2p_peer_flags[q], h[1], hipIpcMemLazyEnablePeerAccess));
-        if (readers[q]) g->p2p_peer_mask |= 1u << q;
+static void p2p_close_peers(nsk_graph *g) {
+    for (int q = 0; q < 16; q++) {
+        if (g->p2p_peer_ipc[q] && g->p2p_peer_base[q]) (void)hipIpcCloseMemHandle(g->p2p_peer_base[q]);
+        g->p2p_peer_base[q] = nullptr;
+        g->p2p_peer_ipc[q] = false;
     }
-    // the ranks this one reads from: those with a live entry in its receive lists
-    std::vector<int32_t> rslot((size_t)g->xnrecv);
-    if (g->xnrecv) HIPCHECK(hipMemcpy(rslot.data(), g->x_recv_slot, (size_t)g->xnrecv * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (int32_t sl : rslot) if (sl >= 0) g->p2p_src_mask |= 1u << (unsigned)(sl / std::max<int64_t>(g->xslot, 1));
+}
+
+int nsk_p2p_export(nsk_graph *g, void *handle64, void **base) {
+    if (!g) return fail(NSK_E_INVALID, "null argument");
+    if (g->pworld == 0) return fail(NSK_E_INVALID, "nsk_p2p_setup has not been called");
+    HIPCHECK(hipSetDevice(g->device));
+    const size_t vb = (size_t)g->c.vbytes, nw = (size_t)g->c.nweight;
+    const size_t bytes = nsk_p2p_wbuf_off(g->pworld, (size_t)g->p_nrecv, vb) + 2 * (size_t)g->pworld * nw * sizeof(double) + 256;
+    if (g->p2p_base && g->p2p_bytes < bytes) {          // a later set-up with longer lists: a new allocation
+        HIPCHECK(hipStreamSynchronize(g->stream));
+        g->allocs.erase(std::remove(g->allocs.begin(), g->allocs.end(), g->p2p_base), g->allocs.end());
+        (void)hipFree(g->p2p_base);
+        g->device_bytes -= (int64_t)g->p2p_bytes;
+        g->p2p_base = nullptr;
+    }
+    if (!g->p2p_base) {
+        // fine-grained: a peer's stores and this rank's polling loads are coherent while kernels run
+        HIPCHECK(hipExtMallocWithFlags(&g->p2p_base, bytes, hipDeviceMallocFinegrained));
+        g->allocs.push_back(g->p2p_base);
+        g->p2p_bytes = bytes;
+        g->device_bytes += (int64_t)bytes;
+    }
+    HIPCHECK(hipMemsetAsync(g->p2p_base, 0, g->p2p_bytes, g->stream));
+    HIPCHECK(hipMemsetAsync(g->p2p_err, 0, 2 * sizeof(unsigned int), g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    g->p2p_tag = 0;
+    g->p2p_ready = false;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (handle64) {
+        hipIpcMemHandle_t h;
+        HIPCHECK(hipIpcGetMemHandle(&h, g->p2p_base));
+        memcpy(handle64, &h, 64);
+    }
+    if (base) *base = g->p2p_base;
+    return NSK_OK;
+}
+
+static int p2p_finish_import(nsk_graph *g) {
+    if (g->c.nweight)       // the weights every rank starts the next learning epoch from
+        HIPCHECK(hipMemcpyAsync(g->w_start, g->w, (size_t)g->c.nweight * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    nsk_drop_sweep_graph(g);
     g->p2p_tag = 0;
     g->p2p_ready = true;
     return NSK_OK;
 }
 
+int nsk_p2p_import(nsk_graph *g, const void *all_handles) {
+    if (!g || !all_handles) return fail(NSK_E_INVALID, "null argument");
+    if (!g->p2p_base) return fail(NSK_E_INVALID, "nsk_p2p_export first");
+    HIPCHECK(hipSetDevice(g->device));
+    p2p_close_peers(g);
+    for (int q = 0; q < g->pworld; q++) {
+        if (q == g->prank) { g->p2p_peer_base[q] = g->p2p_base; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)all_handles + (size_t)q * 64, 64);
+        HIPCHECK(hipIpcOpenMemHandle(&g->p2p_peer_base[q], h, hipIpcMemLazyEnablePeerAccess));
+        g->p2p_peer_ipc[q] = true;
+    }
+    return p2p_finish_import(g);
+}
+
+int nsk_p2p_import_local(nsk_graph *g, void *const *bases) {
+    if (!g || !bases) return fail(NSK_E_INVALID, "null argument");
+    if (!g->p2p_base) return fail(NSK_E_INVALID, "nsk_p2p_export first");
+    HIPCHECK(hipSetDevice(g->device));
+    p2p_close_peers(g);
+    for (int q = 0; q < g->pworld; q++) {
+        if (q != g->prank && !bases[q]) return fail(NSK_E_INVALID, "null peer allocation");
+        g->p2p_peer_base[q] = q == g->prank ? g->p2p_base : bases[q];
+    }
+    return p2p_finish_import(g);
+}
+
 }  // extern "C"
 
 template <typename VT>
-static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off) {
-    P2PPeers peers;
-    for (int q = 0; q < 16; q++) { peers.recv[q] = g->p2p_peer_recv[q]; peers.flags[q] = (unsigned int *)g->p2p_peer_flags[q]; }
-    const unsigned int tag = tag_base ? tag_off : ++g->p2p_tag;
-    if (g->p2p_peer_mask)
-        k_p2p_push<VT><<<dim3(1), dim3(1024), 0, g->stream>>>((const VT *)g->val, g->x_send_vids, (int)g->xnsend, peers,
-                                                              g->xworld, g->xrank, g->xslot, g->p2p_peer_mask, tag, tag_base);
-    const int n = (int)g->xnrecv;
-    if (g->p2p_src_mask && n > 0)
-        k_p2p_wait_unpack<VT><<<dim3(std::min(64, (n + NSK_BLOCK - 1) / NSK_BLOCK)), dim3(NSK_BLOCK), 0, g->stream>>>(
-            (VT *)g->val, g->x_recv_vids, g->x_recv_slot, (const VT *)g->p2p_recv, g->p2p_flags, n, g->xworld,
-            g->xslot, g->p2p_src_mask, tag, g->p2p_err, tag_base);
+static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off, bool learn, int part) {
+    const int world = g->pworld, me = g->prank;
+    const size_t vb = (size_t)g->c.vbytes;
+    const int nw = (int)g->c.nweight;
+    if (part != 2 && !tag_base) ++g->p2p_tag;
+    const unsigned int tag = tag_base ? tag_off : g->p2p_tag;
+    // a learning epoch's weight deltas go to every rank, so every rank is a peer of every other
+    const unsigned int mask = (learn && nw > 0 && world > 1) ? (((1u << world) - 1u) & ~(1u << me)) : g->p2p_peer_mask;
+    if (part != 2) {
+        if (learn && nw > 0) {                  // first: the flags go up behind it
+            P2PWeights pw;
+            memset(&pw, 0, sizeof(pw));
+            for (int q = 0; q < world; q++)
+                pw.wbuf[q] = (double *)((char *)g->p2p_peer_base[q] + nsk_p2p_wbuf_off(world, (size_t)g->p_dtotal[q], vb));
+            const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
+            k_p2p_push_dw<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, pw, world, me, nw, tag);
+        }
+        if (mask) {
+            P2PPlan pl;
+            memset(&pl, 0, sizeof(pl));
+            for (int q = 0; q < world; q++) {
+                pl.base[q] = g->p2p_peer_base[q];
+                pl.soff[q] = (unsigned long long)g->p_soff[q];
+                pl.dbase[q] = (unsigned long long)g->p_dbase[q];
+                pl.dtotal[q] = (unsigned long long)g->p_dtotal[q];
+            }
+            for (int q = world; q <= 16; q++) pl.soff[q] = (unsigned long long)g->p_nsend;
+            // at most 64 blocks (grid-stride): the closing ticket adds must not queue up
+            const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (g->p_nsend + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK)));
+            k_p2p_push<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const VT *)g->val, learn ? (const VT *)g->val_evid : nullptr,
+                                                                       g->p_send_iid, (long long)g->p_nsend, pl, world, me, mask,
+                                                                       g->p2p_err + 1, tag, tag_base);
+        }
+    }
+    if (part != 1) {
+        if (mask) {
+            const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (g->p_nrecv + NSK_BLOCK - 1) / NSK_BLOCK));
+            k_p2p_wait_unpack<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
+                (VT *)g->val, learn ? (VT *)g->val_evid : nullptr, g->p_recv_iid, (long long)g->p_nrecv, g->p2p_base, world,
+                mask, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks);
+        }
+        if (learn && nw > 0) {
+            const double *wb = (const double *)((const char *)g->p2p_base + nsk_p2p_wbuf_off(world, (size_t)g->p_nrecv, vb));
+            const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
+            k_p2p_merge_w<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, wb, world, nw, tag);
+            g->weights_dirty = true;
+        }
+    }
     HIPCHECK(hipGetLastError());
     return NSK_OK;
 }
 
-int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off) {
-    return g->c.vbytes == 1 ? p2p_exchange<int8_t>(g, tag_base, tag_off) : p2p_exchange<int32_t>(g, tag_base, tag_off);
+int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off, bool learn, int part) {
+    return g->c.vbytes == 1 ? p2p_exchange<int8_t>(g, tag_base, tag_off, learn, part)
+                            : p2p_exchange<int32_t>(g, tag_base, tag_off, learn, part);
 }
 
 extern "C" {
 
-static int p2p_check(nsk_graph *g);
-
-int nsk_p2p_exchange(nsk_graph *g) {
+int nsk_p2p_check(nsk_graph *g) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
-    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_export / nsk_p2p_import first");
+    if (!g->p2p_err) return NSK_OK;
     HIPCHECK(hipSetDevice(g->device));
-    int rc = nsk_p2p_enqueue(g, nullptr, 0);
-    return rc ? rc : p2p_check(g);
+    unsigned int err = 0;
+    HIPCHECK(hipMemcpyAsync(&err, g->p2p_err, sizeof(err), hipMemcpyDeviceToHost, g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    if (err) {
+        HIPCHECK(hipMemsetAsync(g->p2p_err, 0, sizeof(unsigned int), g->stream));      // reported once
+        return fail(NSK_E_DEVICE, "peer-to-peer exchange: a peer's boundary values did not arrive within "
+                                  "NSK_P2P_TIMEOUT_S; the ghost values of this handle are incomplete");
+    }
+    return NSK_OK;
+}
+
+int nsk_p2p_exchange(nsk_graph *g, int learn, int part) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
+    if (part < 0 || part > 2) return fail(NSK_E_INVALID, "bad part");
+    HIPCHECK(hipSetDevice(g->device));
+    return nsk_p2p_enqueue(g, nullptr, 0, learn != 0, part);
 }
 
 int nsk_gibbs_sweeps_p2p(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
-    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_export / nsk_p2p_import first");
+    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
     if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
     HIPCHECK(hipSetDevice(g->device));
-    int rc = nsk_gibbs_run(g, nsweeps, sample_evidence, burnin, true);
-    return rc ? rc : p2p_check(g);
+    return nsk_gibbs_run(g, nsweeps, sample_evidence, burnin, true);
 }
 
-static int p2p_check(nsk_graph *g) {
-    unsigned int err = 0;
-    HIPCHECK(hipMemcpyAsync(&err, g->p2p_err, sizeof(err), hipMemcpyDeviceToHost, g->stream));
-    HIPCHECK(hipStreamSynchronize(g->stream));
-    if (err) return fail(NSK_E_DEVICE, "peer-to-peer exchange: a peer's boundary values did not arrive (timeout)");
+int nsk_learn_sweeps_p2p(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                         double reg_param, int64_t truncation, int learn_non_evidence) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
+    if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
+    HIPCHECK(hipSetDevice(g->device));
+    const int nw = (int)g->c.nweight;
+    // the caller may have written the weight buffer since the last epoch: this call starts from what is there
+    if (nw && nsweeps) HIPCHECK(hipMemcpyAsync(g->w_start, g->w, (size_t)nw * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+    for (int64_t s = 0; s < nsweeps; s++) {
+        int rc = nsk_learn_sweeps(g, 1, step, 1.0, regularization, reg_param, truncation, learn_non_evidence);
+        if (rc) return rc;
+        if ((rc = nsk_p2p_enqueue(g, nullptr, 0, true, 0))) return rc;     // values of both chains + weight deltas; w_start = merged w
+        step *= decay;
+    }
     return NSK_OK;
 }
 

@@ -175,8 +175,8 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                             // resident grid over tile pairs: at most 8 blocks per CU
                             const int npairs = tab.ntiles / 2;
                             const int nbp = nsk_tab_grid(npairs);
-                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, 0u);
-                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, 0u);
+                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
+                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
                         }
                         else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
                         else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
@@ -249,7 +249,6 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
     g->sweep_graph_key = -1;
     // the segment plans (kept in the handle) are built by an eager sweep-free call path: make sure they exist
     DevGraph<VT> d = view<VT>(g);
-    const uint32_t K0 = (uint32_t)g->seed, K1 = (uint32_t)(g->seed >> 32);
     hipGraph_t graph = nullptr;
     // (the legacy default stream cannot be captured: a caller that pointed the library at it -- torch's
     // current stream in a process without its own streams -- keeps the eager loop)
@@ -262,11 +261,11 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
                 const int npairs = pl.tab.ntiles / 2;
                 const int nbp = nsk_tab_grid(npairs);
                 if (pl.nch == 1)
-                    k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, K0, K1, 0u, 0u,
-                                                                                         g->d_counters, (uint32_t)i, g->rng_tag);
+                    k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
+                                                                                         g->d_counters, (uint32_t)i);
                 else
-                    k_gibbs_seg_tab<VT, 2><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, K0, K1, 0u, 0u,
-                                                                                         g->d_counters, (uint32_t)i, g->rng_tag);
+                    k_gibbs_seg_tab<VT, 2><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
+                                                                                         g->d_counters, (uint32_t)i);
                 launches++;
             }
         if (p2p) {
@@ -274,7 +273,7 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
             if (rc) { (void)hipStreamEndCapture(g->stream, &graph); if (graph) (void)hipGraphDestroy(graph); return rc; }
         }
     }
-    k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, NSK_GRAPH_SWEEPS, p2p ? NSK_GRAPH_SWEEPS : 0, 0);
+    k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, NSK_GRAPH_SWEEPS, p2p ? NSK_GRAPH_SWEEPS : 0, 0, 0ull, 0ull);
     hipError_t e = hipStreamEndCapture(g->stream, &graph);
     if (e != hipSuccess || !graph) return nsk::fail(NSK_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     e = hipGraphInstantiate(&g->sweep_graph, graph, nullptr, nullptr, 0);
@@ -307,7 +306,7 @@ int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin
                 }
             }
             if (g->sweep_graph_key == key && !g->sweep_graph_off)
-                k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, g->sweep, g->p2p_tag, 1);
+                k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, g->sweep, g->p2p_tag, 1, g->seed, g->rng_tag);
             while (left >= NSK_GRAPH_SWEEPS && g->sweep_graph_key == key && !g->sweep_graph_off) {
                 if (!burnin && g->pos_tally_sweeps + NSK_GRAPH_SWEEPS > 255) nsk_fold_position_tally(g);   // uint8 tally
                 HIPCHECK(hipGraphLaunch(g->sweep_graph, g->stream));

@@ -39,7 +39,7 @@ struct nsk_graph {
     hipGraphExec_t sweep_graph = nullptr;
     int sweep_graph_key = -1, sweep_graph_launches = 0;
     bool sweep_graph_off = false;                  // capture failed once (e.g. the legacy default stream): eager from then on
-    unsigned long long *d_counters = nullptr;      // [0] sweep index, [1] exchange tag
+    unsigned long long *d_counters = nullptr;      // [0] sweep index, [1] exchange tag, [2] Philox key, [3] shard tag
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -97,12 +97,20 @@ struct nsk_graph {
     int32_t *x_send_vids = nullptr, *x_recv_vids = nullptr, *x_recv_slot = nullptr;
     void *x_send = nullptr, *x_recv = nullptr, *x_send_evid = nullptr, *x_recv_evid = nullptr;
     double *w_start = nullptr, *w_delta = nullptr;
-    // peer-to-peer exchange (nsk_p2p_*): fine-grained double-buffered gathered buffer + flags, the peers'
-    // mappings of theirs, the exchange counter
-    void *p2p_recv = nullptr;
-    unsigned int *p2p_flags = nullptr, *p2p_err = nullptr;
-    void *p2p_peer_recv[16] = {nullptr}, *p2p_peer_flags[16] = {nullptr};
-    unsigned int p2p_peer_mask = 0, p2p_src_mask = 0, p2p_tag = 0;
+    // peer-to-peer exchange (nsk_p2p_*): pairwise boundary lists, ONE fine-grained allocation per rank
+    // (flags | received values of both chains, two parities | weight deltas; nsk_kernels_misc.h), the
+    // peers' mappings of theirs, the exchange counter
+    int pworld = 0, prank = 0;
+    int64_t p_nsend = 0, p_nrecv = 0;
+    std::vector<int64_t> p_soff, p_dbase, p_dtotal;
+    int32_t *p_send_iid = nullptr, *p_recv_iid = nullptr;
+    void *p2p_base = nullptr;
+    size_t p2p_bytes = 0;
+    unsigned int *p2p_err = nullptr;
+    void *p2p_peer_base[16] = {nullptr};
+    bool p2p_peer_ipc[16] = {false};                // mapped with hipIpcOpenMemHandle (closed at destroy / re-import)
+    unsigned int p2p_peer_mask = 0, p2p_tag = 0;
+    unsigned long long p2p_timeout_ticks = 3000000000ull;      // 30 s of the 100 MHz wall clock (NSK_P2P_TIMEOUT_S)
     bool p2p_ready = false;
     // native RCCL
     void *rccl_lib = nullptr, *rccl_comm = nullptr;
@@ -224,8 +232,10 @@ static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nwe
 extern "C" int nsk_ensure_generic(nsk_graph *g);       // internal (not in the public header)
 #define NSK_GRAPH_SWEEPS 16
 // one peer-to-peer exchange on the library's stream; tag_base != null: a captured launch whose tag is
-// the device counter + tag_off (nsk_api.hip)
-int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off);
+// the device counter + tag_off; learn: both chains + the weight deltas; part 0 = all of it, 1 = the
+// pushes only, 2 = flags + wait + unpack (+ weight merge) only (nsk_api.hip)
+int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off, bool learn = false, int part = 0);
+void nsk_drop_sweep_graph(nsk_graph *g);            // the captured sweep sequence bakes exchange pointers: drop it when they change
 int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p);   // nsk_gibbs.hip
 void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);
 void nsk_refresh_ztab(nsk_graph *g);

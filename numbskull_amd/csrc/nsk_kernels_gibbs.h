@@ -1517,13 +1517,15 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
 template <typename VT, int NCH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
-                                                             const unsigned long long *sweep_base, uint32_t sweep_off,
-                                                             uint32_t rng_tag) {
+                                                             const unsigned long long *sweep_base, uint32_t sweep_off) {
     constexpr int PP = NSK_TAB_PP;
-    if (sweep_base) {             // a captured launch (hipGraph): the sweep index lives in device memory
-        const unsigned long long sw = *(const NSK_SCALAR unsigned long long *)sweep_base + sweep_off;
+    if (sweep_base) {             // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
+        const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
+        const unsigned long long sw = cb[0] + sweep_off, key = cb[2];
         s0 = (uint32_t)sw;
-        s1 = (uint32_t)(sw >> 32) ^ rng_tag;
+        s1 = (uint32_t)(sw >> 32) ^ (uint32_t)cb[3];
+        k0 = (uint32_t)key;
+        k1 = (uint32_t)(key >> 32);
     }
     const int lane = (int)(threadIdx.x & 63);
     const int npairs = tab.ntiles >> 1;                                 // virtual tiles: always even

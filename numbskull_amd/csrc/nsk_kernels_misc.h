@@ -58,51 +58,113 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_exchange_unpack(VT *val, const in
     if (sl >= 0) val[recv_vids[j]] = recvbuf[sl];
 }
 
-// ---- peer-to-peer boundary exchange (one node: xGMI / same device) ---------------------------------
-// Every rank owns a double-buffered gathered buffer recv[2][world * slot] and flags[2][world] in
-// fine-grained device memory that its peers have mapped (hipIpc).  After a sweep a rank WRITES its
-// boundary values straight into the peers' buffers (slot block `me` of parity tag & 1), fences to
-// system scope and stores the exchange tag into its flag at every peer; a rank then waits for the
-// tags of the ranks it reads from and scatters their blocks into its value array.  No collective, no
-// host in the loop.  Two parities suffice: a peer can run at most one exchange ahead (it needs this
-// rank's next boundary before the one after).
-struct P2PPeers { void *recv[16]; unsigned int *flags[16]; };       // (one node: at most 16 ranks)
-
-template <typename VT>
-__global__ __launch_bounds__(1024) void k_p2p_push(const VT *val, const int32_t *send_vids, int nsend, P2PPeers peers,
-                                                   int world, int me, int64_t slot, unsigned int peer_mask,
-                                                   unsigned int tag, const unsigned long long *tag_base) {
-    if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
-    const size_t base = ((size_t)(tag & 1u) * (size_t)world + (size_t)me) * (size_t)slot;
-    for (int q = 0; q < world; q++) {
-        if (!((peer_mask >> q) & 1u)) continue;
-        VT *dst = (VT *)peers.recv[q] + base;
-        for (int i = (int)threadIdx.x; i < nsend; i += (int)blockDim.x) dst[i] = val[send_vids[i]];
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x < (unsigned)world && ((peer_mask >> threadIdx.x) & 1u))
-        __hip_atomic_store(peers.flags[threadIdx.x] + (size_t)(tag & 1u) * (size_t)world + (size_t)me, tag,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// ---- peer-to-peer boundary exchange (one node: xGMI between GPUs / one device shared by ranks) ------
+// Every rank owns ONE fine-grained allocation its peers have mapped (hipIpc, or plain pointers when the
+// ranks live in one process):
+//     flags[2][world]                     tag of the last exchange rank q completed towards this rank
+//     recv[2][2][nrecv]                   per parity, per chain (var_value, var_value_evid): the values this
+//                                         rank reads from others, segment of source q at roff[q]
+//     wbuf[2][world][nweight]             per parity: every rank's weight deltas of a learning epoch
+// Boundary lists are PAIRWISE: rank s sends rank d exactly the variables d reads from s (ascending global
+// id on both sides), so nothing travels that its receiver does not read.  After a sweep a rank WRITES its
+// boundary values (k_p2p_push: a grid of workgroups over the concatenated per-reader lists) -- and, after
+// a learning epoch, its weight deltas first (k_p2p_push_dw) -- straight into the peers' buffers; the last
+// block of k_p2p_push raises this rank's flag at every peer; k_p2p_wait_unpack waits for the peers' flags
+// and scatters their values.  No collective, no host in the loop.  Peers are symmetric (q is a peer when either side reads from the other), so two ranks that
+// exchange anything wait for each other in every exchange and a peer runs at most one exchange ahead:
+// two parities suffice.
+struct P2PPlan {                        // (one node: at most 16 ranks)
+    void *base[16];                     // peer q's allocation
+    unsigned long long soff[17];        // this rank's send list = concatenation over q of what q reads: [soff[q], soff[q+1])
+    unsigned long long dbase[16];       // where this rank's segment starts inside q's per-chain block
+    unsigned long long dtotal[16];      // elements of q's per-chain block (q's receive total)
+};
+#define NSK_P2P_ALIGN 256ull
+__host__ __device__ inline size_t nsk_p2p_recv_off(int world) {           // byte offset of recv[] in an allocation
+    return ((size_t)(2 * world) * sizeof(unsigned int) + NSK_P2P_ALIGN - 1) / NSK_P2P_ALIGN * NSK_P2P_ALIGN;
+}
+__host__ __device__ inline size_t nsk_p2p_wbuf_off(int world, size_t nrecv, size_t vbytes) {
+    return nsk_p2p_recv_off(world) + (4 * nrecv * vbytes + NSK_P2P_ALIGN - 1) / NSK_P2P_ALIGN * NSK_P2P_ALIGN;
 }
 
-// waits (bounded: ~2 s of the 100 MHz wall clock, then *err = 1) for the tags of the ranks in
-// src_mask, then unpacks like k_exchange_unpack from the parity's buffer
 template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_wait_unpack(VT *val, const int32_t *recv_vids, const int32_t *recv_slot,
-                                                               const VT *recv2, unsigned int *flags, int n, int world,
-                                                               int64_t slot, unsigned int src_mask, unsigned int tag,
-                                                               unsigned int *err, const unsigned long long *tag_base) {
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push(const VT *val, const VT *val_evid, const int32_t *send_iid,
+                                                        long long nsend, P2PPlan pl, int world, int me,
+                                                        unsigned int peer_mask, unsigned int *ticket, unsigned int tag,
+                                                        const unsigned long long *tag_base) {
     if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
+    const size_t par = tag & 1u;
+    const size_t roff = nsk_p2p_recv_off(world);
+    for (long long k = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; k < nsend; k += (long long)gridDim.x * NSK_BLOCK) {
+        int q = 0;
+        while (q + 1 < world && (unsigned long long)k >= pl.soff[q + 1]) q++;
+        const size_t tot = (size_t)pl.dtotal[q];
+        VT *dst = (VT *)((char *)pl.base[q] + roff) + par * 2 * tot + (size_t)pl.dbase[q] + (size_t)((unsigned long long)k - pl.soff[q]);
+        const int id = send_iid[k];
+        dst[0] = val[id];
+        if (val_evid) dst[tot] = val_evid[id];
+    }
+    // the last block to finish raises this rank's flag at every peer (a handful of blocks: the ticket adds
+    // do not queue up); everything this rank pushed in this exchange -- earlier kernels on the stream
+    // included -- is then visible to a peer that has seen the flag
+    __threadfence_system();
+    __syncthreads();
+    __shared__ unsigned int last;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    if (threadIdx.x < (unsigned)world && ((peer_mask >> threadIdx.x) & 1u))
+        __hip_atomic_store((unsigned int *)pl.base[threadIdx.x] + par * (size_t)world + (size_t)me, tag, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// weight deltas of a learning epoch (w - w_start) into block `me` of every rank's wbuf, this rank's included
+struct P2PWeights { double *wbuf[16]; };
+static __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push_dw(const double *w, const double *w_start, P2PWeights pw,
+                                                                  int world, int me, int nw, unsigned int tag) {
+    const size_t blk = ((size_t)(tag & 1u) * (size_t)world + (size_t)me) * (size_t)nw;
+    for (int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x); i < nw; i += (int)(gridDim.x * NSK_BLOCK)) {
+        const double d = w[i] - w_start[i];
+        for (int q = 0; q < world; q++) pw.wbuf[q][blk + (size_t)i] = d;
+    }
+}
+
+// w = w_start + (d_0 + d_1 + ... ) in rank order -- the master's merge rule (numbskull_master.py:223-224),
+// the same additions on every rank -- and w_start = w for the next epoch
+static __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_merge_w(double *w, double *w_start, const double *wbuf, int world,
+                                                                  int nw, unsigned int tag) {
+    const double *b = wbuf + (size_t)(tag & 1u) * (size_t)world * (size_t)nw;
+    for (int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x); i < nw; i += (int)(gridDim.x * NSK_BLOCK)) {
+        double t = __builtin_nontemporal_load(b + i);
+        for (int q = 1; q < world; q++) t += __builtin_nontemporal_load(b + (size_t)q * (size_t)nw + i);
+        const double x = w_start[i] + t;
+        w[i] = x;
+        w_start[i] = x;
+    }
+}
+
+// waits (bounded: timeout_ticks of the 100 MHz wall clock, then *err = 1) for the tags of the peers, then
+// scatters the received values of one or both chains
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_wait_unpack(VT *val, VT *val_evid, const int32_t *recv_iid, long long nrecv,
+                                                               const void *mine, int world, unsigned int peer_mask,
+                                                               unsigned int tag, unsigned int *err,
+                                                               const unsigned long long *tag_base,
+                                                               unsigned long long timeout_ticks) {
+    if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
+    const size_t par = tag & 1u;
     __shared__ int ok;
     if (threadIdx.x == 0) {
         ok = 1;
         const unsigned long long t0 = wall_clock64();
-        for (int q = 0; q < world; q++) {
-            if (!((src_mask >> q) & 1u)) continue;
-            const unsigned int *f = flags + (size_t)(tag & 1u) * (size_t)world + (size_t)q;
+        const unsigned int *flags = (const unsigned int *)mine;
+        for (int q = 0; q < world && ok; q++) {
+            if (!((peer_mask >> q) & 1u)) continue;
+            const unsigned int *f = flags + par * (size_t)world + (size_t)q;
             while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
-                if (wall_clock64() - t0 > 200000000ull) { ok = 0; break; }
+                if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
         }
@@ -110,17 +172,20 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_wait_unpack(VT *val, const in
     }
     __syncthreads();
     if (!ok) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const VT *rb = recv2 + (size_t)(tag & 1u) * (size_t)world * (size_t)slot;
-    for (int j = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x); j < n; j += (int)(gridDim.x * NSK_BLOCK)) {
-        const int sl = recv_slot[j];
-        if (sl >= 0) val[recv_vids[j]] = __builtin_nontemporal_load(rb + sl);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the payload was written by another agent
+    const VT *rb = (const VT *)((const char *)mine + nsk_p2p_recv_off(world)) + par * 2 * (size_t)nrecv;
+    for (long long j = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; j < nrecv; j += (long long)gridDim.x * NSK_BLOCK) {
+        const int id = recv_iid[j];
+        val[id] = __builtin_nontemporal_load(rb + j);
+        if (val_evid) val_evid[id] = __builtin_nontemporal_load(rb + (size_t)nrecv + j);
     }
 }
 
 // counters of captured sweep sequences (hipGraph): [0] sweep index, [1] peer-to-peer exchange tag
-static __global__ void k_graph_counters(unsigned long long *c, unsigned long long sweep, unsigned long long tag, int set) {
-    if (set) { c[0] = sweep; c[1] = tag; }
+// [2] the Philox key (seed), [3] the shard tag: a replay after nsk_set_seed / nsk_set_rng_tag draws from the new stream
+static __global__ void k_graph_counters(unsigned long long *c, unsigned long long sweep, unsigned long long tag, int set,
+                                        unsigned long long seed, unsigned long long rng_tag) {
+    if (set) { c[0] = sweep; c[1] = tag; c[2] = seed; c[3] = rng_tag; }
     else { c[0] += sweep; c[1] += tag; }
 }
 

@@ -16,15 +16,20 @@ learning the evidence-chain values are exchanged too and the weight deltas of th
 with an all-reduce.
 
 Drivers for the per-sweep loop:
-  * peer-to-peer (opt-in, NSK_P2P=1, inference sweeps): every rank writes its boundary values straight
-    into buffers of its peers (device memory mapped with hipIpc; xGMI between GPUs) and raises a flag
-    there; a rank waits for the flags of the ranks it reads from and scatters their values
-    (nsk_gibbs_sweeps_p2p) -- no collective, no host round trip per sweep;
-  * native (default on GPUs): the whole loop -- sweep kernels, pack, ncclAllGather, unpack -- is
-    enqueued from C++ on one stream (nsk_gibbs_sweeps_exchange), the communicator being created
-    from a ncclUniqueId that rank 0 makes and ``torch.distributed`` broadcasts;
+  * peer-to-peer (default on GPUs when its set-up self-test passes on every rank; NSK_P2P=0 or
+    ``p2p=False`` switches it off): boundary lists are PAIRWISE (rank s sends rank d exactly what d reads
+    from s); every rank writes its boundary values -- in learning also the evidence-chain values and the
+    epoch's weight deltas -- straight into buffers of its peers (device memory mapped with hipIpc; xGMI
+    between GPUs) and raises a flag there; a rank waits for the flags of its peers and scatters their
+    values (nsk_gibbs_sweeps_p2p / nsk_learn_sweeps_p2p) -- no collective, no host round trip per sweep.
+    A peer whose flag does not arrive within NSK_P2P_TIMEOUT_S (default 30 s) is reported by
+    ``check()``.  Exercised with several ranks sharing ONE device only (tests/); across devices it
+    relies on hipIpc peer mappings and system-scope flags over xGMI;
+  * native: the whole loop -- sweep kernels, pack, ncclAllGather, unpack (+ ncclAllReduce of the weight
+    deltas) -- is enqueued from C++ on one stream (nsk_*_sweeps_exchange), the communicator being
+    created from a ncclUniqueId that rank 0 makes and ``torch.distributed`` broadcasts;
   * torch: ``torch.distributed.all_gather_into_tensor`` on the library's staging buffers wrapped
-    as tensors; used by the CPU (gloo) tests and as the fallback.
+    as tensors; used by the CPU (gloo) tests and as the last fallback.
 """
 
 import ctypes as C
@@ -52,6 +57,18 @@ def plan_boundaries(needs_per_rank, world, nvar):
         lists.append(allneed[(allneed >= lo) & (allneed < hi)].astype(np.int32))
     slot = max([len(b) for b in lists] + [0])
     return lists, slot
+
+
+def plan_pairs(needs_per_rank, world, nvar):
+    """Pairwise boundary lists: ``pairs[s][d]`` = sorted ids owned by ``s`` that rank ``d`` reads."""
+    bounds = np.array([shard_range(r, world, nvar)[0] for r in range(world)] + [nvar], np.int64)
+    pairs = [[None] * world for _ in range(world)]
+    for d in range(world):
+        need = np.asarray(needs_per_rank[d], np.int64)
+        cut = np.searchsorted(need, bounds)
+        for s_ in range(world):
+            pairs[s_][d] = need[cut[s_]:cut[s_ + 1]] if s_ != d else need[:0]
+    return pairs
 
 
 def gather_needs(dist, torch, needs, world, device):
@@ -124,9 +141,9 @@ class PartitionedSampler(object):
         self.all_needs = None
         if world > 1:
             self.setup_exchange(native)
-            # peer-to-peer exchange for the inference sweeps (NSK_P2P=0 or p2p=False: off).  Set-up ends
-            # with a self-test -- two real exchanges, one per buffer parity -- and every rank must pass
-            # or none uses it (the collective loop stays as the fallback)
+            # peer-to-peer exchange for inference and learning sweeps (NSK_P2P=0 or p2p=False: off).  Set-up
+            # ends with a self-test -- two real exchanges, one per buffer parity -- and every rank must
+            # pass or none uses it (the collective loop stays as the fallback)
             if p2p if p2p is not None else os.environ.get("NSK_P2P", "1") != "0":
                 self.p2p = self._init_p2p()
 
@@ -205,35 +222,64 @@ class PartitionedSampler(object):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # native only if it works everywhere
         return bool(flag.item())
 
+    def p2p_lists(self):
+        """Arguments of nsk_p2p_setup for this rank, from the gathered need lists: what every peer reads
+        from this rank, what this rank reads from every peer (local ids), and where this rank's segment
+        lies in every peer's receive list."""
+        pairs = plan_pairs(self.all_needs, self.world, self.nvar_global)
+        me, W = self.rank, self.world
+        send = [self._local(pairs[me][q]) for q in range(W)]
+        recv = [self._local(pairs[q][me]) for q in range(W)]
+        soff, roff = np.zeros(W + 1, np.int64), np.zeros(W + 1, np.int64)
+        np.cumsum([len(x) for x in send], out=soff[1:])
+        np.cumsum([len(x) for x in recv], out=roff[1:])
+        base = np.array([sum(len(pairs[s_][q]) for s_ in range(me)) for q in range(W)], np.int64)
+        total = np.array([sum(len(pairs[s_][q]) for s_ in range(W)) for q in range(W)], np.int64)
+        cat = lambda xs: np.ascontiguousarray(np.concatenate(xs + [np.empty(0, np.int64)]), np.int32)
+        return cat(send), soff, cat(recv), roff, base, total
+
+    def p2p_setup(self):
+        _lib = self._lib
+        send, soff, recv, roff, base, total = self.p2p_lists()
+        assert (send >= 0).all() and (recv >= 0).all(), "a boundary list names a variable this shard does not hold"
+        return self.L.nsk_p2p_setup(self.h, self.world, self.rank, _lib.ptr(send), _lib.ptr(soff), _lib.ptr(recv),
+                                    _lib.ptr(roff), _lib.ptr(base), _lib.ptr(total))
+
     def _init_p2p(self):
-        """hipIpc handles of every rank's gathered buffer and flags, all-gathered with
+        """Pairwise lists to the library, then the hipIpc handle of every rank's buffer, all-gathered with
         torch.distributed; each rank maps its peers' (nsk_p2p_import)."""
         torch, dist = self.torch, self.dist
-        mine = (C.c_uint8 * 128)()
-        ok = int(self.L.nsk_p2p_export(self.h, mine) == 0)
+
+        def agreed(ok):
+            flag = torch.tensor([int(bool(ok))], dtype=torch.int32, device=self.dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+        if not agreed(self.p2p_setup() == 0):
+            return False
+        mine = (C.c_uint8 * 64)()
+        ok = int(self.L.nsk_p2p_export(self.h, mine, None) == 0)
         t = torch.tensor(list(bytes(mine)) + [ok], dtype=torch.uint8, device=self.dev)
         outs = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(outs, t)
         raw = [bytes(o.cpu().numpy().tolist()) for o in outs]
-        if not all(r[128] == 1 for r in raw):
+        if not all(r[64] == 1 for r in raw):
             return False
-        table = (C.c_uint8 * (128 * self.world)).from_buffer_copy(b"".join(r[:128] for r in raw))
-        mine_ids = np.asarray(self.lists[self.rank], np.int64)
-        readers = np.array([int(q != self.rank and len(np.intersect1d(self.all_needs[q], mine_ids)) > 0)
-                            for q in range(self.world)], np.int32)
-        rc = self.L.nsk_p2p_import(self.h, table, self._lib.ptr(readers))
-        flag = torch.tensor([int(rc == 0)], dtype=torch.int32, device=self.dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if not bool(flag.item()):
+        table = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(r[:64] for r in raw))
+        if not agreed(self.L.nsk_p2p_import(self.h, table) == 0):
             return False
-        # self-test: the boundary values are still the initial ones every rank already holds, so two
-        # exchanges change nothing -- but they run the very kernels, mappings and flags of the sweep loop
+        # self-test: the boundary values are still the initial ones every rank already holds and the
+        # weight deltas are zero, so two learning-mode exchanges change nothing -- but they run the very
+        # kernels, mappings and flags of the sweep loops, one exchange per buffer parity
         rc = 0
         for _ in range(2):
-            rc = rc or self.L.nsk_p2p_exchange(self.h)
-        flag = torch.tensor([int(rc == 0)], dtype=torch.int32, device=self.dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(flag.item())
+            rc = rc or self.L.nsk_p2p_exchange(self.h, 1, 0)
+        rc = rc or self.L.nsk_p2p_check(self.h)
+        return agreed(rc == 0)
+
+    def check(self):
+        """Raise if a peer-to-peer exchange since the last check timed out (synchronises the stream)."""
+        if self.p2p:
+            self._lib.check(self.L.nsk_p2p_check(self.h))
 
     # ------------------------------------------------------------------ per-sweep loops
     def _exchange(self, which, send, recv):
@@ -274,7 +320,7 @@ class PartitionedSampler(object):
             if self.world == 1:
                 continue
             if self.p2p:
-                out["p2p_exchange"] = out.get("p2p_exchange", 0.0) + timed(lambda: _lib.check(L.nsk_p2p_exchange(h)))
+                out["p2p_exchange"] = out.get("p2p_exchange", 0.0) + timed(lambda: _lib.check(L.nsk_p2p_exchange(h, 0, 0)))
             else:
                 out["pack"] = out.get("pack", 0.0) + timed(lambda: _lib.check(L.nsk_exchange_pack(h, _lib.BUF_VALUE)))
                 t0 = self.torch.cuda.Event(enable_timing=True)
@@ -294,6 +340,8 @@ class PartitionedSampler(object):
         args = (int(regularization), float(reg_param), int(truncation), int(learn_non_evidence))
         if self.world == 1:
             _lib.check(self.L.nsk_learn_sweeps(self.h, nsweeps, float(step), float(decay), *args))
+        elif self.p2p:
+            _lib.check(self.L.nsk_learn_sweeps_p2p(self.h, nsweeps, float(step), float(decay), *args))
         elif self.native:
             _lib.check(self.L.nsk_learn_sweeps_exchange(self.h, nsweeps, float(step), float(decay), *args))
         else:

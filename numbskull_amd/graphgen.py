@@ -168,8 +168,76 @@ def lf_graph(prior, accuracy, copies, seed=0):
     return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
 
 
+LR_BLOCK = 65536     # ids per generator block of mixed_lr_graph: every block draws from streams of its own
+
+
+def _lr_variables(nvar, seed, cat_frac, evidence_frac, block):
+    """Compact per-variable attributes of the WHOLE graph (4 bytes per variable): every id block has a
+    stream of its own, so any rank reproduces them without the factors."""
+    card = np.empty(nvar, np.uint8)
+    ev = np.empty(nvar, np.bool_)
+    init = np.empty(nvar, np.uint8)
+    nf_of = np.empty(nvar, np.uint8)
+    for b, v0 in enumerate(range(0, nvar, block)):
+        n = min(block, nvar - v0)
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), 0, b])))
+        is_cat = rng.random(n) < cat_frac
+        c = np.where(is_cat, rng.integers(3, 9, n), 2)
+        e = rng.random(n) < evidence_frac
+        card[v0:v0 + n] = c
+        ev[v0:v0 + n] = e
+        init[v0:v0 + n] = np.where(e, (rng.random(n) * c).astype(np.int64), 0)
+        nf_of[v0:v0 + n] = 1 + np.minimum(rng.poisson(2.0, n), 15)
+    return card, ev, init, nf_of
+
+
+def _lr_factor_block(seed, b, v0, nf_of_b, card, nvar, nweights, window, global_frac):
+    """Factors headed by the variables of id block ``b`` (global member ids), from the block's own stream."""
+    rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), 1, b])))
+    n = len(nf_of_b)
+    nfactor = int(nf_of_b.sum(dtype=np.int64))
+    head = np.repeat(np.arange(v0, v0 + n, dtype=np.int64), nf_of_b)
+    arity = rng.choice(np.array([1, 2, 3, 4]), size=nfactor, p=[.4, .3, .2, .1]).astype(np.int64)
+    off = np.cumsum(arity) - arity
+    nedge = int(arity.sum())
+    fac_of_edge = np.repeat(np.arange(nfactor, dtype=np.int64), arity)
+    pos = np.arange(nedge, dtype=np.int64) - off[fac_of_edge]
+    is_head = pos == arity[fac_of_edge] - 1
+    h = head[fac_of_edge]
+    local = np.clip(h + rng.integers(-window, window + 1, nedge), 0, nvar - 1)
+    glob = rng.integers(0, nvar, nedge)
+    other = np.where(rng.random(nedge) < global_frac, glob, local)
+    vid = np.where(is_head, h, other)
+    cv = card[vid].astype(np.int64)
+    deo = (rng.random(nedge) * cv).astype(np.int64)
+    any_cat = np.add.reduceat((cv > 2).astype(np.int32), off) > 0
+    r = rng.random(nfactor)
+    func = np.where(arity == 1, FUNC_ISTRUE, np.where(r < 0.5, 1, 13))          # OR / IMPLY_MLN
+    func_cat = np.where(r < 1 / 3, 14, np.where(r < 2 / 3, 17, 12))             # OR_CAT/IMPLY_MLN_CAT/AND_CAT
+    func = np.where(any_cat, func_cat, func)
+    wid = np.minimum((nweights * rng.random(nfactor) ** 2).astype(np.int64), nweights - 1)
+    return func, wid, arity, off, vid, deo
+
+
+def _lr_records(func, wid, arity, vid, deo):
+    factor = np.zeros(len(func), Factor)
+    factor["factorFunction"] = func
+    factor["weightId"] = wid
+    factor["featureValue"] = 1.0
+    factor["arity"] = arity
+    factor["ftv_offset"] = np.cumsum(arity) - arity
+    fmap = np.zeros(len(vid), FactorToVar)
+    fmap["vid"] = vid
+    fmap["dense_equal_to"] = deo
+    return factor, fmap
+
+
+def _lr_nweights(nvar, nweights):
+    return max(1, min(10 ** 6, nvar // 50)) if nweights is None else int(nweights)
+
+
 def mixed_lr_graph(nvar, seed=20240603, nweights=None, window=1024, global_frac=0.01,
-                   evidence_frac=0.5, cat_frac=0.25):
+                   evidence_frac=0.5, cat_frac=0.25, block=LR_BLOCK):
     """Mixed-arity logistic-regression-style graph (benchmark config #5).
 
     75 % boolean / 25 % categorical (dataType 1, cardinality 3..8) variables, half of them
@@ -180,54 +248,57 @@ def mixed_lr_graph(nvar, seed=20240603, nweights=None, window=1024, global_frac=
     uniform over each member's domain.  ``weightId = floor(nweights*u^2)``, all free,
     initial 0.  IMPLY_MLN* need the library's ``head_by_vid`` lookup (the reference's
     literal head indexing is out of range on such graphs, inference.py:243).
+
+    The generator is keyed per id block (``block`` ids: PCG64 streams seeded (seed, 0, b) for the
+    block's variables and (seed, 1, b) for the factors they head), so a rank of an N-rank run can
+    produce its shard alone (``mixed_lr_shard``) -- the reference's minions load only their partition
+    (salt/src/numbskull_minion.py:185).
     """
-    rng = np.random.Generator(np.random.PCG64(seed))
     nvar = int(nvar)
-    if nweights is None:
-        nweights = max(1, min(10 ** 6, nvar // 50))
-    is_cat = rng.random(nvar) < cat_frac
-    card = np.where(is_cat, rng.integers(3, 9, nvar), 2).astype(np.int64)
+    nweights = _lr_nweights(nvar, nweights)
+    card, ev, init, nf_of = _lr_variables(nvar, seed, cat_frac, evidence_frac, block)
     variable = np.zeros(nvar, Variable)
-    variable["dataType"] = is_cat
+    variable["dataType"] = card > 2
     variable["cardinality"] = card
-    ev = rng.random(nvar) < evidence_frac
     variable["isEvidence"] = ev
-    variable["initialValue"] = np.where(ev, (rng.random(nvar) * card).astype(np.int64), 0)
-
-    nf_of = 1 + np.minimum(rng.poisson(2.0, nvar), 15)
-    nfactor = int(nf_of.sum())
-    head = np.repeat(np.arange(nvar, dtype=np.int64), nf_of)
-    arity = rng.choice(np.array([1, 2, 3, 4]), size=nfactor, p=[.4, .3, .2, .1]).astype(np.int64)
-    off = np.cumsum(arity) - arity
-    nedge = int(arity.sum())
-
-    fmap = np.zeros(nedge, FactorToVar)
-    fac_of_edge = np.repeat(np.arange(nfactor, dtype=np.int64), arity)
-    pos = np.arange(nedge, dtype=np.int64) - off[fac_of_edge]
-    is_head = pos == arity[fac_of_edge] - 1
-    h = head[fac_of_edge]
-    local = np.clip(h + rng.integers(-window, window + 1, nedge), 0, nvar - 1)
-    glob = rng.integers(0, nvar, nedge)
-    other = np.where(rng.random(nedge) < global_frac, glob, local)
-    vid = np.where(is_head, h, other)
-    fmap["vid"] = vid
-    fmap["dense_equal_to"] = (rng.random(nedge) * card[vid]).astype(np.int64)
-
-    any_cat = np.zeros(nfactor, np.bool_)
-    np.logical_or.at(any_cat, fac_of_edge, is_cat[vid])
-    r = rng.random(nfactor)
-    func = np.where(arity == 1, FUNC_ISTRUE, np.where(r < 0.5, 1, 13))          # OR / IMPLY_MLN
-    func_cat = np.where(r < 1 / 3, 14, np.where(r < 2 / 3, 17, 12))             # OR_CAT/IMPLY_MLN_CAT/AND_CAT
-    func = np.where(any_cat, func_cat, func)
-    factor = np.zeros(nfactor, Factor)
-    factor["factorFunction"] = func
-    factor["weightId"] = np.minimum((nweights * rng.random(nfactor) ** 2).astype(np.int64),
-                                    nweights - 1)
-    factor["featureValue"] = 1.0
-    factor["arity"] = arity
-    factor["ftv_offset"] = off
+    variable["initialValue"] = init
+    parts = [_lr_factor_block(seed, b, v0, nf_of[v0:v0 + block], card, nvar, nweights, window, global_frac)
+             for b, v0 in enumerate(range(0, nvar, block))]
+    cat = lambda i: np.concatenate([p_[i] for p_ in parts]) if parts else np.zeros(0, np.int64)
+    factor, fmap = _lr_records(cat(0), cat(1), cat(2), cat(4), cat(5))
     wrec = np.zeros(nweights, Weight)
-    return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), nedge
+    return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), len(fmap)
+
+
+def mixed_lr_shard(nvar, lo, hi, seed=20240603, nweights=None, window=1024, global_frac=0.01,
+                   evidence_frac=0.5, cat_frac=0.25, block=LR_BLOCK):
+    """``extract_shard(mixed_lr_graph(nvar, ...), lo, hi)`` without ever holding the whole graph: the
+    compact attributes of all variables (4 bytes each), then the factor blocks one at a time, keeping
+    the factors with a member in ``[lo, hi)``.  Same return value as ``extract_shard``."""
+    nvar, lo, hi = int(nvar), int(lo), int(hi)
+    nweights = _lr_nweights(nvar, nweights)
+    card, ev, init, nf_of = _lr_variables(nvar, seed, cat_frac, evidence_frac, block)
+    kept = []
+    for b, v0 in enumerate(range(0, nvar, block)):
+        func, wid, arity, off, vid, deo = _lr_factor_block(seed, b, v0, nf_of[v0:v0 + block], card, nvar,
+                                                           nweights, window, global_frac)
+        keep_f = np.add.reduceat(((vid >= lo) & (vid < hi)).astype(np.int32), off) > 0
+        if not keep_f.any():
+            continue
+        keep_e = np.repeat(keep_f, arity)
+        kept.append((func[keep_f], wid[keep_f], arity[keep_f], vid[keep_e], deo[keep_e]))
+    cat = lambda i: np.concatenate([k[i] for k in kept]) if kept else np.zeros(0, np.int64)
+    vid = cat(3)
+    gids = np.unique(np.concatenate([np.arange(lo, hi, dtype=np.int64), vid]))
+    lvar = np.zeros(len(gids), Variable)
+    lvar["dataType"] = card[gids] > 2
+    lvar["cardinality"] = card[gids]
+    lvar["isEvidence"] = ev[gids]
+    lvar["initialValue"] = init[gids]
+    lvar["isEvidence"][(gids < lo) | (gids >= hi)] = 4
+    factor, fmap = _lr_records(cat(0), cat(1), cat(2), np.searchsorted(gids, vid), cat(4))
+    l0, l1 = int(np.searchsorted(gids, lo)), int(np.searchsorted(gids, hi))
+    return (np.zeros(nweights, Weight), lvar, factor, fmap, np.zeros(len(gids), np.bool_), len(fmap)), gids, (l0, l1)
 
 
 def boolean_weighted_graph(nvar, seed=0, window=64, factors_per_var=2.0, max_arity=3):

@@ -25,9 +25,9 @@ def graph(kind):
 
 def main():
     kind, learn, nsweeps = sys.argv[1], sys.argv[2] == "learn", 4
-    if len(sys.argv) > 3 and sys.argv[3] == "p2p" and not learn:
+    if len(sys.argv) > 3 and sys.argv[3].startswith("p2p") and not learn:
         nsweeps = 37                              # long enough for captured sweep sequences (grids)
-    local = len(sys.argv) > 3 and sys.argv[3] == "local"      # every rank holds only its shard (+ ghosts)
+    local = len(sys.argv) > 3 and sys.argv[3] in ("local", "p2plocal")   # every rank holds only its shard (+ ghosts)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,7 +47,7 @@ def main():
         handles.append(ns.factorGraphs[0])
         gids.append(ids)
     fg = handles[rank]
-    p2p = len(sys.argv) > 3 and sys.argv[3] == "p2p"      # boundary values written into the peer's memory (hipIpc)
+    p2p = len(sys.argv) > 3 and sys.argv[3].startswith("p2p")   # boundary values (learning: both chains + weight deltas) written into the peer's memory (hipIpc)
     if p2p:                                               # a stream of its own: sweep sequences can be captured
         torch.cuda.set_stream(torch.cuda.Stream())        # (the legacy default stream cannot)
     sampler = PartitionedSampler(fg, dist, torch, rank, world, nvar_global=nvar, p2p=p2p)   # native RCCL refuses one device
@@ -62,6 +62,7 @@ def main():
         sampler.learn(nsweeps, 0.01, 0.9, 2, 0.01, 1)
     else:
         sampler.gibbs(nsweeps, True, False)
+    sampler.check()                              # a peer-to-peer exchange that timed out raises here
     torch.cuda.synchronize()
 
     def loc(r, ids):                             # global ids -> rank r's ids (all present)

@@ -1,0 +1,219 @@
+"""BASELINE configs[4] ("config #5") as BASELINE states it -- the mixed-arity LR graph range-partitioned
+into EIGHT shards, learning included -- on one device: every shard is generated alone
+(graphgen.mixed_lr_shard: own variables, the ghosts they read, the factors that touch them; what the
+reference's minions load, salt/src/numbskull_minion.py:185), compiled into a handle of its own, and the
+eight handles exchange boundaries through the REAL peer-to-peer path -- pairwise send lists, k_p2p_push
+into the peers' buffers, flags, wait/unpack, in learning both chains and the epoch's weight deltas
+(nsk_gibbs_sweeps_p2p / nsk_learn_sweeps_p2p; the peers' buffers are handed over as plain pointers,
+nsk_p2p_import_local, since the ranks live in one process).  Owned values, ghosts, tallies, both chains and
+the merged weights must equal the oracle's emulation of the partitioned run bit for bit
+(numbskull_master.py:165-224 semantics: ghost values are one sweep old; w = w_start + sum of deltas,
+:223-224).  The same harness runs the 10M grid of config #4 through the peer-to-peer path.
+
+Per-shard phase timings (HIP events) go to gpurun_out/config5_shards_*.json (profiles/r4_*)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import psutil
+import pytest
+
+from numbskull_amd import _lib, graphgen
+from util import oracle_of, phases_from_colors
+import numbskull_amd
+
+pytestmark = pytest.mark.gpu
+WORLD = 8
+LR_SEED = 20240603
+
+
+def make_parts(kind, nvar, learn, seed):
+    """One handle + PartitionedSampler per shard, every one on a stream of its own."""
+    import torch
+    from numbskull_amd.distributed import PartitionedSampler, shard_range
+    parts, streams = [], []
+    grid = None
+    if kind == "grid":
+        rng = np.random.Generator(np.random.PCG64(20240602))
+        rows, cols = nvar
+        nvar = rows * cols
+        grid = (graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True,
+                                    evidence=rng.integers(0, 2, nvar)) if learn
+                else graphgen.ising_grid(rows, cols, weight=0.1))
+    for r in range(WORLD):
+        lo, hi = shard_range(r, WORLD, nvar)
+        if kind == "grid":
+            sg, gids, own = graphgen.extract_shard(grid, lo, hi)
+        else:
+            sg, gids, own = graphgen.mixed_lr_shard(nvar, lo, hi, seed=LR_SEED)
+        ns = numbskull_amd.NumbSkull(quiet=True, seed=seed, head_by_vid=kind != "grid")
+        ns.loadFactorGraph(*sg[:5], int(sg[5]), own_range=own, global_ids=gids)
+        fg = ns.factorGraphs[0]
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            ps = PartitionedSampler(fg, None, torch, r, 1, nvar_global=nvar)
+        ps.world = WORLD
+        assert fg.info()["nowned"] == hi - lo
+        parts.append(ps)
+        streams.append(st)
+    return parts, streams, nvar
+
+
+def wire_p2p(parts):
+    """What PartitionedSampler._init_p2p does across processes, for handles that share one."""
+    L = _lib.lib()
+    needs = [p.global_needs() for p in parts]
+    bases = (C.c_void_p * WORLD)()
+    for p in parts:
+        p.all_needs = needs
+        _lib.check(p.p2p_setup())
+        b = C.c_void_p()
+        _lib.check(L.nsk_p2p_export(p.h, None, C.byref(b)))
+        bases[p.rank] = b.value
+    for p in parts:
+        _lib.check(L.nsk_p2p_import_local(p.h, bases))
+        p.p2p = True
+    return needs
+
+
+def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
+    import torch
+    from numbskull_amd.distributed import shard_range, plan_pairs
+    seed = 20240601
+    parts, streams, nvar = make_parts(kind, size, learn, seed)
+    hbv = kind != "grid"
+    oracles = []
+    for p in parts:
+        og = oracle_of(p.fg, head_by_vid=hbv)           # checks the layout and the colouring of every shard
+        oracles.append((og, phases_from_colors(p.fg.colors()), og.initial_state()))
+    needs = wire_p2p(parts)
+    pairs = plan_pairs(needs, WORLD, nvar)
+    L = _lib.lib()
+    # what nsk_gibbs_sweeps_p2p / nsk_learn_sweeps_p2p enqueue per sweep -- the sweep's kernels, the pushes
+    # (nsk_p2p_exchange part 1), then flags-wait + unpack (+ weight merge; part 2) -- issued breadth-first
+    # over the eight handles: they share one process, hence a few hardware queues, and a rank's spinning
+    # wait kernel must not sit in front of a peer's push in the same queue (ranks of a real run are
+    # processes with queues of their own: tests/test_multirank_gpu.py runs those loops as they are)
+    step, decay = hyper[0], hyper[1]
+    st = step
+    for s in range(nsweeps):
+        for p in parts:
+            if learn:
+                _lib.check(L.nsk_learn_sweeps(p.h, 1, st, 1.0, hyper[2], hyper[3], hyper[4], 0))
+            else:
+                _lib.check(L.nsk_gibbs_sweeps(p.h, 1, 1, 0))
+            _lib.check(L.nsk_p2p_exchange(p.h, int(learn), 1))
+        for p in parts:
+            _lib.check(L.nsk_p2p_exchange(p.h, int(learn), 2))
+        st *= decay
+    for p in parts:
+        p.check()
+    torch.cuda.synchronize()
+
+    def loc(r, ids):
+        at = np.searchsorted(parts[r].gids, ids)
+        assert np.array_equal(parts[r].gids[at], ids)
+        return at
+
+    for s in range(nsweeps):
+        starts = [st[2].copy() for _, _, st in oracles]
+        for og, (order, ps_), (vv, ve, wv, cnt) in oracles:
+            if learn:
+                assert og.learn_dev(order, ps_, vv, ve, wv, step, hyper[2], hyper[3], hyper[4], False, seed, s) == 0
+            else:
+                assert og.gibbs_dev(order, ps_, vv, wv, cnt, seed, s, True) == 0
+        step *= decay
+        for r in range(WORLD):                   # owners publish what each peer reads of them
+            for q in range(WORLD):
+                if q != r and len(pairs[r][q]):
+                    b = pairs[r][q]
+                    oracles[q][2][0][loc(q, b)] = oracles[r][2][0][loc(r, b)]
+                    oracles[q][2][1][loc(q, b)] = oracles[r][2][1][loc(r, b)]
+        if learn:                                # w = w_start + (d_0 + d_1 + ...), numbskull_master.py:223-224
+            total = sum(st[2] - s0 for (_, _, st), s0 in zip(oracles, starts))
+            for (_, _, st), s0 in zip(oracles, starts):
+                st[2][:] = s0 + total
+    nghost = 0
+    for r, p in enumerate(parts):
+        vv, ve, wv, cnt = oracles[r][2]
+        lo, hi = p.fg.own_range
+        got = p.val.cpu().numpy().astype(np.int64)
+        assert np.array_equal(got[lo:hi], vv[lo:hi]), ("owned values differ", r)
+        gh = loc(r, np.asarray(needs[r], np.int64))
+        nghost += len(gh)
+        assert np.array_equal(got[gh], vv[gh]), ("ghost values differ", r)
+        if learn:
+            gote = p.val_evid.cpu().numpy().astype(np.int64)
+            assert np.array_equal(gote[lo:hi], ve[lo:hi]), ("evidence-chain values differ", r)
+            assert np.array_equal(gote[gh], ve[gh]), ("evidence-chain ghosts differ", r)
+            assert np.array_equal(p.w.cpu().numpy(), wv), ("merged weights differ", r)
+        else:
+            p.fg._pull(0, 0)
+            cs = p.fg.cstart
+            assert np.array_equal(p.fg.count[cs[lo]:cs[hi]], cnt[cs[lo]:cs[hi]]), ("tallies differ", r)
+    if learn:
+        w0 = parts[0].w.cpu().numpy()
+        assert all(np.array_equal(p.w.cpu().numpy(), w0) for p in parts), "ranks disagree on the merged weights"
+        assert np.isfinite(w0).all() and np.abs(w0).max() > 0
+
+    # phase timings per shard: the sweep kernels alone, then all pushes, then all flag/wait/unpack
+    # (+ weight merge) kernels -- each rank's bracket on its own stream, marked first, read afterwards
+    timing = {"sweep_us": [], "push_us": [], "wait_unpack_us": []}
+    ms, nl = C.c_double(), C.c_int64()
+    for _ in range(3):
+        row = []
+        for p in parts:
+            _lib.check(L.nsk_profile_begin(p.h))
+            if learn:
+                _lib.check(L.nsk_learn_sweeps(p.h, 1, 1e-4, 1.0, hyper[2], hyper[3], hyper[4], 0))
+            else:
+                _lib.check(L.nsk_gibbs_sweeps(p.h, 1, 1, 1))
+            _lib.check(L.nsk_profile_end(p.h, C.byref(ms), C.byref(nl)))
+            row.append(ms.value * 1e3)
+        timing["sweep_us"].append(row)
+        for part, key in ((1, "push_us"), (2, "wait_unpack_us")):
+            for p in parts:
+                _lib.check(L.nsk_profile_begin(p.h))
+                _lib.check(L.nsk_p2p_exchange(p.h, int(learn), part))
+                _lib.check(L.nsk_profile_mark(p.h))
+            row = []
+            for p in parts:
+                _lib.check(L.nsk_profile_read(p.h, C.byref(ms), C.byref(nl)))
+                row.append(ms.value * 1e3)
+            timing[key].append(row)
+    for p in parts:
+        p.check()
+    sends = [int(sum(len(pairs[r][q]) for q in range(WORLD))) for r in range(WORLD)]
+    owned = [p.fg.own_range[1] - p.fg.own_range[0] for p in parts]
+    out = {"config": "%s in 8 range shards, all on one MI355X, %s, peer-to-peer exchange" % (tag, "learning" if learn else "inference"),
+           "owned_per_rank": owned, "values_sent_per_rank": sends, "ghosts_per_rank": [len(n) for n in needs],
+           "exchange_fraction": float(np.mean([np.mean(a) + np.mean(b) for a, b in zip(timing["push_us"][1:], timing["wait_unpack_us"][1:])])
+                                      / np.mean([np.mean(a) for a in timing["sweep_us"][1:]])),
+           "per_shard_us": {k: {"mean": float(np.mean(v[1:])), "max": float(np.max(v[1:]))} for k, v in timing.items()},
+           "note": "one shard's kernels alone on the device (HIP events on the shard's stream); the push / wait brackets of "
+                   "the eight shards overlap on the device; first repetition excluded"}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/config5_shards_%s_%s.json" % (tag.split()[0], "learn" if learn else "inference"), "w") as f:
+        json.dump(out, f, indent=1)
+    for p in parts:
+        p.fg.close()
+    return out
+
+
+@pytest.mark.parametrize("learn", [False, True])
+def test_lr5m_eight_shards_p2p_match_emulation(learn):
+    out = run_case("lr", 5_000_000, learn, "lr5m (5M-variable LR graph)")
+    assert sum(out["ghosts_per_rank"]) > 0
+
+
+@pytest.mark.parametrize("learn", [False, True])
+def test_grid10m_eight_shards_p2p_match_emulation(learn):
+    run_case("grid", (2500, 4000), learn, "ising10m (2500x4000 grid)", hyper=(1e-7, 0.95, 2, 0.01, 1))
+
+
+def test_lr50m_eight_shards_learning_p2p():
+    """Config #5 at its stated size, 8-way: one learning epoch after one inference sweep per shard."""
+    if psutil.virtual_memory().available < 110 * 2 ** 30:
+        pytest.skip("needs ~110 GB of free host memory")
+    run_case("lr", 50_000_000, True, "lr50m (50M-variable LR graph)", nsweeps=2)

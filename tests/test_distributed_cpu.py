@@ -201,6 +201,67 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out["config"]["boundary_total"] == 2 * 256           # one grid row on each side of the cut
 
 
+def test_bench_dry_run_generates_lr_shards_alone():
+    """The LR workloads of an N-rank run never materialise the whole graph: every rank generates its
+    shard (graphgen.mixed_lr_shard) and the dry run reports the largest peak RSS over the ranks."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NSK_BENCH_DRYRUN="1", NSK_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--workload", "lr300k_learn",
+                        "--steps", "3", "--warmup", "1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True
+    assert out["config"]["sampled_total"] == 300000
+    assert 150000 < out["config"]["variables_held_by_rank0"] < 170000      # its half + the ghosts it reads
+    assert 0 < out["config"]["peak_rss_gb_max_over_ranks"] < 8
+
+
+def test_lr_shard_generator_equals_the_cut_of_the_whole_graph():
+    """graphgen.mixed_lr_shard(nvar, lo, hi) == graphgen.extract_shard(graphgen.mixed_lr_graph(nvar), lo, hi),
+    array for array, for shards at both ends, in the middle, across generator blocks, and an empty one."""
+    from numbskull_amd import graphgen
+    nvar = 40000
+    g = graphgen.mixed_lr_graph(nvar, seed=5, block=4096)
+    assert (g[3]["vid"] == 0).sum() > 100 and (g[3]["vid"] == nvar - 1).sum() > 100      # the clipped windows' hubs
+    for lo, hi in ((0, 5000), (5000, 10000), (35000, 40000), (4090, 4100), (77, 77)):
+        a, gids, own = graphgen.mixed_lr_shard(nvar, lo, hi, seed=5, block=4096)
+        b, gids2, own2 = graphgen.extract_shard(g, lo, hi)
+        assert np.array_equal(gids, gids2) and own == own2 and a[5] == b[5]
+        for x, y in zip(a[:5], b[:5]):
+            assert x.dtype == y.dtype and np.array_equal(x, y)
+    # a different block size is a different graph (the streams are keyed per block), the same one is not
+    assert not np.array_equal(graphgen.mixed_lr_graph(nvar, seed=5, block=8192)[3], g[3])
+    assert np.array_equal(graphgen.mixed_lr_graph(nvar, seed=5, block=4096)[3], g[3])
+
+
+def test_pairwise_boundary_lists():
+    """distributed.plan_pairs: rank s sends rank d exactly what d reads from s; the peer-to-peer set-up
+    arguments of every rank are mutually consistent (segment bases and totals)."""
+    from numbskull_amd.distributed import plan_pairs, shard_range
+    world, nvar = 4, 1000
+    rng = np.random.default_rng(1)
+    needs = []
+    for r in range(world):
+        lo, hi = shard_range(r, world, nvar)
+        cand = np.setdiff1d(np.arange(nvar), np.arange(lo, hi))
+        needs.append(np.sort(rng.choice(cand, 60, replace=False)).astype(np.int32))
+    needs[2] = needs[2][(needs[2] < 250)]                # rank 2 reads from rank 0 only
+    pairs = plan_pairs(needs, world, nvar)
+    for d in range(world):
+        assert len(pairs[d][d]) == 0
+        assert np.array_equal(np.concatenate([pairs[s][d] for s in range(world)]), needs[d])
+        for s_ in range(world):
+            lo, hi = shard_range(s_, world, nvar)
+            assert ((pairs[s_][d] >= lo) & (pairs[s_][d] < hi)).all()
+    assert all(len(pairs[s_][2]) == 0 for s_ in (1, 3))
+
+
 def test_shard_local_graph_plans_like_the_whole_graph():
     """graphgen.extract_shard: a rank that holds only its shard (owned variables, the ghosts they read
     flagged isEvidence 4, the factors that touch them, renumbered in ascending global order -- what

@@ -908,6 +908,32 @@ def test_captured_sweep_sequences_equal_the_oracle(burn):
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
 
 
+def test_captured_sweep_sequences_follow_a_reseed():
+    """The captured sequence reads the Philox key and the shard tag from device memory like the sweep
+    index: after set_seed the replays draw from the NEW stream (a graph captured under the old seed
+    used to keep it while the eager remainder switched)."""
+    g = graphgen.ising_grid(48, 40, weight=0.3)
+    ns, fg = session(g, seed=9)
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, _, wv, cnt = og.initial_state()
+    fg.inference(0, 40, True)                       # captures under seed 9
+    for s in range(40):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 9, s, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+    fg.set_seed(77, 5)
+    fg.inference(0, 40, True)                       # replays + remainder under seed 77 from sweep 5
+    for s in range(5, 45):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 77, s, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+    _lib.check(_lib.lib().nsk_set_rng_tag(fg._engine(), 12345))
+    og.set_rng_tag(12345)
+    fg.inference(0, 40, True)
+    for s in range(45, 85):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 77, s, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
 def test_native_rccl_loop_single_rank():
     """nsk_comm_init + nsk_gibbs_sweeps_exchange / nsk_learn_sweeps_exchange with a 1-rank
     communicator: the native loop (sweep, pack, ncclAllGather, unpack, ncclAllReduce of weight

@@ -16,13 +16,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("kind", ["grid", "lr"])
 @pytest.mark.parametrize("mode", ["gibbs", "learn"])
-@pytest.mark.parametrize("layout", ["whole", "local", "p2p"])
+@pytest.mark.parametrize("layout", ["whole", "local", "p2p", "p2plocal"])
 def test_two_ranks_one_gpu(kind, mode, layout):
     """layout "local": every rank holds only its shard of the graph -- owned variables, the ghosts
     they read, the factors that touch them (graphgen.extract_shard; what the reference's minions
     load, salt/src/numbskull_minion.py:185) -- and boundaries are planned in global ids.
-    layout "p2p": the inference sweeps exchange boundaries by peer writes into hipIpc-mapped buffers with
-    flags (nsk_gibbs_sweeps_p2p) instead of a collective; learning keeps the collective path."""
+    layout "p2p": the sweeps exchange boundaries by peer writes into hipIpc-mapped buffers with flags
+    (nsk_gibbs_sweeps_p2p; learning: both chains and the epoch's weight deltas, nsk_learn_sweeps_p2p)
+    instead of collectives; "p2plocal": the same on shard-local graphs (what bench.py --gpus N runs)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
