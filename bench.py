@@ -55,16 +55,17 @@ WORKLOADS = {
     "lr50m_learn": (10000, 5000, True),
     "ising64k": (256, 256, False),            # plumbing tests
     "lr300k_learn": (600, 500, True),
-    # 4x / 10x the metric config: the streams of one sweep (0.8 / 2 GB) no longer fit the 256 MiB
-    # Infinity Cache, so the rate is HBM's
+    # 4x / 10x the metric config.  With implicit adjacency a sweep of the 40M grid moves ~190 MB (it was
+    # 800 MB in round 2) and fits the 256 MiB Infinity Cache again; the 100M grid (~450 MB per sweep) is
+    # the one beyond it
     "ising40m": (5000, 8000, False),
     "ising100m": (10000, 10000, False),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 # 256 MiB Infinity Cache (memory-side): a sweep whose streams fit in it is served partly from there
 # from the second sweep on, and FETCH_SIZE counts those hits as fetches (MI355X_MICROARCH.md).  The
-# 10M grid's sweep moves 200 MB, so its fraction of the HBM peak is an upper bound on what HBM
-# itself delivered; `also.ising40m` (800 MB per sweep) is the same kernel beyond the cache.
+# 10M grid's sweep moves ~48 MB and the 40M grid's ~190 MB: both fit, so their fractions of the HBM peak
+# are upper bounds on what HBM itself delivered (`stream_fits_infinity_cache` says so per workload).
 INFINITY_CACHE_BYTES = 256 << 20
 
 
@@ -178,13 +179,15 @@ def cpu_baseline(fg, learning, budget_s=20.0, grid=None, head_by_vid=False, lr=(
     vv1, ve1, wv1, cnt1 = og.initial_state()
     run1 = (lambda n: og.learn_hogwild(1, n, vv1, ve1, wv1, lr[0], lr[1], lr[2], lr[3], lr[4], False, 1)) \
         if learning else (lambda n: og.gibbs_hogwild(1, n, vv1, wv1, cnt1, 1, True, False))
-    single = None
+    single = None               # None in the line = not measured (skipped for graphs beyond 12M variables)
     if nvar <= 12_000_000:      # (a one-thread sweep of the 50M graph alone would take the whole budget)
         t0 = time.time()
         assert run1(1) == 0
         single = nvar / (time.time() - t0)
     return {"value": nvar * total_n / total_t, "unit": "variable-updates/s", "cores": cores,
-            "kind": "port", "single_thread": single, "cflags": flags, "cpu": cpu_model(),
+            "kind": "port", "single_thread": single,
+            "single_thread_note": None if single is not None else "skipped: one sweep of this graph on one thread exceeds the sample budget",
+            "cflags": flags, "cpu": cpu_model(),
             "sample": "%d sweep(s) of the same %d-variable graph, %d Hogwild threads "
                       "(reference shard formula), %.1f s" % (total_n, nvar, cores, total_t),
             "_agreement": agree, "_mean_marginal": mean_marg, "_sweeps": total_n}
@@ -288,6 +291,40 @@ def side_run(name, seed, steps, warmup):
            "avg_launch_us": ms * 1e3 / max(1, nl), "parity": checks}
     if learning:
         out["learn_clipped"] = clipped   # weight updates whose step the per-class cap shrank
+    return out
+
+
+def roofline_bound(kernel):
+    """What binds the dominant kernel (from the stage ablations and PMC passes under
+    profiles/): the draw-table kernels read almost no stream and are bound by instruction issue along a
+    chain of dependent steps; the entry-parallel kernels by the latency of their dependent gathers at the
+    occupancy their registers allow (no unit saturated); the CSR / exp-per-update kernels by HBM."""
+    if kernel.endswith("_seg_tab"):
+        return "issue"
+    if kernel.endswith("_ep"):
+        return "latency"
+    return "hbm"
+
+
+def issue_side(workload, launch_s):
+    """Issue-side figures of the dominant kernel from the rocprofv3 --pmc SQ pass of the same workload
+    (profiles/issue.json, written by tools/collect_profiles.sh): vector instructions per launch, the
+    fraction of the chip's vector issue slots they fill over THIS run's launch time (1024 SIMDs, a wave64
+    vector instruction occupies its SIMD for 4 cycles at 2.4 GHz: an upper bound on the rate), and the
+    shares of wave-cycles with an instruction in flight / waiting."""
+    tp = os.path.join(REPO, "profiles", "issue.json")
+    if not os.path.exists(tp):
+        return None
+    try:
+        rec = json.load(open(tp)).get(workload)
+    except Exception:
+        return None
+    if not rec:
+        return None
+    out = dict(rec)
+    if rec.get("valu_insts_per_launch") and launch_s > 0:
+        out["valu_issue_frac"] = rec["valu_insts_per_launch"] * 4.0 / (1024 * launch_s * 2.4e9)
+    out["source"] = "profiles/issue.json (rocprofv3 --pmc SQ_* pass, not this run)"
     return out
 
 
@@ -490,12 +527,15 @@ def main():
     checks = state_checks(fg, info, args.steps * REPEATS, (rows, cols) if is_grid else None, learning)
     # hard invariants decide the exit code; the statistical ones (mean marginal, agreement with the
     # CPU chain) are always reported but only count once the chain has been burnt in (>= 10 warm-up
-    # sweeps): a 2-sweep warm-up of a profiling pass still sits in the transient from the all-zero state
+    # sweeps): a 2-sweep warm-up of a profiling pass still sits in the transient from the all-zero
+    # state -- the line then says parity.statistics = "skipped (warm-up < 10 sweeps)" instead of passing
+    # them silently
     burnt_in = args.warmup >= 10
     ok_local = all(bool(x) for k, x in checks.items()
                    if k.endswith("_in_bounds") or k in ("values_in_domain", "weights_finite")
                    or (burnt_in and k.endswith("_ok")))
     checks["statistics_count"] = burnt_in
+    checks["statistics"] = "counted" if burnt_in else "skipped (warm-up < 10 sweeps)"
     if world > 1:
         t = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -560,8 +600,13 @@ def main():
                        "generate_s": round(t_gen, 2), "load_and_compile_s": round(t_load, 2),
                        "compile_s": round(info["compile_seconds"], 2),
                        "device_bytes": info["device_bytes"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": roofline_bound(dominant_kernel(args.workload, learning, info)),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # launch time / the time the launch's bytes (PMC traffic when collected, else the
+                         # layout bytes) would take at the HBM peak: 1 = at the memory floor
+                         "time_over_memory_floor": launch_s / ((traffic or lay_per_launch) / (HBM_PEAK_GBS * 1e9)),
+                         "issue": issue_side(args.workload, launch_s),
                          "traffic_source": traffic_src,
                          "traffic_GBs": (traffic / launch_s / 1e9) if traffic else None,
                          "layout_bytes_per_update": lay_sweep * world / nvar,
@@ -600,13 +645,13 @@ def main():
             out["also"] = {"ising1m": side_run("ising1m", args.seed, 400, 100),
                            "ising10m_learn": side_run("ising10m_learn", args.seed, 40, 10),
                            "ising40m": side_run("ising40m", args.seed, 20, 5)}
-            # the headline sweep's 200 MB of streams fit the 256 MiB Infinity Cache; the same kernel
-            # on the 40M grid (800 MB per sweep) is served by HBM alone
-            out["roofline"]["frac_hbm_only"] = out["also"]["ising40m"]["roofline_frac"]
             out["roofline"]["frac_is"] = ("bytes the compiled layout moves per launch / launch time / HBM peak.  With implicit "
                                           "adjacency the table kernel reads no per-lane stream (4.8 B/update instead of round 2's "
-                                          "20.0): it is bound by its chain of dependent steps, not by HBM, so this fraction fell "
-                                          "while updates/s rose; csr_model_GBs prices the same sweep in SURVEY 8(d)'s CSR layout")
+                                          "20.0): it is bound by instruction issue along its chain of dependent steps (bound = "
+                                          "'issue'; roofline.issue, time_over_memory_floor), not by HBM, so this fraction fell "
+                                          "while updates/s rose; csr_model_GBs prices the same sweep in SURVEY 8(d)'s CSR layout. "
+                                          "Both grids' sweeps fit the Infinity Cache (stream_fits_infinity_cache); the 100M grid "
+                                          "(--workload ising100m) is the one beyond it")
         checks["ok"] = bool(ok_local)
         print(json.dumps(out))
     if world > 1:

@@ -115,6 +115,13 @@ int nsk_set_scan(nsk_graph *g, int scan);
  * step = cap / k in that class (same fixed point).  Default 0.5; cap <= 0 switches clipping off.
  * nsk_graph_info.learn_clipped counts the clipped updates. */
 int nsk_set_learn_cap(nsk_graph *g, double cap);
+/* Chromatic learning, one-class lag (default on): the weight update of colour class c runs on a second
+ * stream beside the sampling of class c + 1, which therefore sees the weights as of the end of class
+ * c - 1 -- milder than the staleness of the reference's own Hogwild threads and of its distributed merge
+ * (one epoch, salt/src/numbskull_master.py:223-224).  The pipeline is drained at the end of every
+ * nsk_learn_sweeps call (the weights it leaves include every update).  lag = 0: every class waits for the
+ * previous class's update.  Same fixed point either way; the oracle's device mode mirrors both. */
+int nsk_set_learn_lag(nsk_graph *g, int lag);
 
 /* Replaces run_pool(gibbsthread) at factorgraph.py:141 (burnin=1) and :163 (burnin=0):
  * `nsweeps` epochs of gibbsthread (inference.py:10-33) over the owned variables. */
@@ -154,6 +161,13 @@ int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */)
  * variable v in the NSK_BUF_VALUE / NSK_BUF_VALUE_EVID buffers, *nid = their length in elements.
  * nsk_state_upload / nsk_state_download and the exchange lists take the caller's variable ids. */
 int nsk_graph_get_layout(nsk_graph *g, int32_t *iid, int64_t *nid);
+/* The chromatic scan's generator of every variable (nvar entries; -1: not sampled by this handle): bits
+ * 0-39 the generator id (= the position in the compiled layout), bit 40 set when the variable's INFERENCE
+ * draws come from the quad scheme -- positions inside segments with draw tables: ids q, q + 64, q + 128,
+ * q + 192 with equal q >> 8 share two Philox blocks, counter ((q >> 8) * 64 + (q & 63), stream, sweep),
+ * stream 2 word (q >> 6) & 3 = the draw's high word, stream 3 the same word its low word -- instead of
+ * the pair scheme described at nsk_set_seed.  What a checker needs to reproduce the samples. */
+int nsk_graph_get_generators(nsk_graph *g, int64_t *gen);
 
 /* Host-only planning (no GPU touched): validate + colour the graph exactly as nsk_graph_create
  * would and report the colours / sizes.  `color` (nvar entries, may be NULL) gets -1 for variables

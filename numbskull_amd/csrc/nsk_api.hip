@@ -176,6 +176,7 @@ int nsk_graph_destroy(nsk_graph *g) {
     for (int q = 0; q < 16; q++)           // peers' allocations mapped with hipIpc
         if (g->p2p_peer_ipc[q] && g->p2p_peer_base[q]) (void)hipIpcCloseMemHandle(g->p2p_peer_base[q]);
     for (void *p : g->allocs) (void)hipFree(p);
+    for (int k = 0; k < 2; k++) if (g->xfer_host[k]) (void)hipHostFree(g->xfer_host[k]);
     if (g->sweep_graph) (void)hipGraphExecDestroy(g->sweep_graph);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -244,7 +245,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
             if (c.phase_end[k] > c.phase_fast_end[k]) generic_needed = true;
         if (generic_needed || nsk::diag_env("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
     }
-    UP(w_fixed); UP(logtab); UP(adj); UP(adj16); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
+    UP(w_fixed); UP(logtab); UP(adj); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes, nid = (size_t)c.nid;
@@ -354,6 +355,12 @@ int nsk_set_learn_cap(nsk_graph *g, double cap) {
     return NSK_OK;
 }
 
+int nsk_set_learn_lag(nsk_graph *g, int lag) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    g->learn_lag = lag != 0;
+    return NSK_OK;
+}
+
 int nsk_set_scan(nsk_graph *g, int scan) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (scan != NSK_SCAN_CHROMATIC && scan != NSK_SCAN_SEQUENTIAL) return fail(NSK_E_INVALID, "unknown scan order");
@@ -384,10 +391,38 @@ int nsk_synchronize(nsk_graph *g) {
 
 // the fast path reads weights through prog_w: rebuild it whenever weights may have changed (start
 // of every sweep call -- the host may have written the weight buffer -- and after every update)
-void nsk_refresh_ztab(nsk_graph *g) {
+void nsk_refresh_ztab(nsk_graph *g, int set, hipStream_t st) {
     if (!g->c.zprogs.empty())
-        k_refresh_ztab<<<dim3((unsigned)g->c.zprogs.size()), dim3(NSK_BLOCK), 0, g->stream>>>(
-            g->zprogs, g->tile_hdr, g->prog_w, g->ztab);
+        k_refresh_ztab<<<dim3((unsigned)g->c.zprogs.size()), dim3(NSK_BLOCK), 0, st ? st : g->stream>>>(
+            g->zprogs, g->tile_hdr, set ? g->prog_w1 : g->prog_w, set ? g->ztab1 : g->ztab);
+}
+
+int nsk_ensure_lag_sets(nsk_graph *g) {
+    if (g->G1) return NSK_OK;
+    const Compiled &c = g->c;
+    int rc;
+    HIPCHECK(hipSetDevice(g->device));
+    if ((rc = dev_alloc(g, &g->w1, (size_t)c.nweight))) return rc;
+    if ((rc = dev_alloc(g, &g->prog_w1, 2 * c.tile_hdr.size()))) return rc;
+    if ((rc = dev_alloc(g, &g->ztab1, (size_t)c.nztab))) return rc;
+    if (g->smallw) {
+        const size_t cells = (size_t)NSK_LEARN_BINS * (size_t)c.nweight;
+        if ((rc = dev_alloc(g, &g->part_G1, cells))) return rc;
+        if ((rc = dev_alloc(g, &g->part_K1, cells))) return rc;
+        if ((rc = dev_alloc(g, &g->part_T1, cells))) return rc;
+        HIPCHECK(hipMemsetAsync(g->part_G1, 0, cells * sizeof(long long), g->stream));
+        HIPCHECK(hipMemsetAsync(g->part_K1, 0, cells * sizeof(uint32_t), g->stream));
+        HIPCHECK(hipMemsetAsync(g->part_T1, 0, cells * sizeof(uint32_t), g->stream));
+    }
+    const size_t nacc = (size_t)g->acc_copies * (size_t)(c.nweight ? c.nweight : 1);
+    if ((rc = dev_alloc(g, &g->G1, nacc))) return rc;
+    if ((rc = dev_alloc(g, &g->K1, nacc))) return rc;
+    if ((rc = dev_alloc(g, &g->T1, nacc))) return rc;
+    HIPCHECK(hipMemsetAsync(g->G1, 0, nacc * sizeof(long long), g->stream));
+    HIPCHECK(hipMemsetAsync(g->K1, 0, nacc * sizeof(uint32_t), g->stream));
+    HIPCHECK(hipMemsetAsync(g->T1, 0, nacc * sizeof(uint32_t), g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    return NSK_OK;
 }
 
 void nsk_refresh_prog_weights(nsk_graph *g, bool force) {
@@ -436,6 +471,41 @@ static int fold_counts(nsk_graph *g) {
 
 
 
+static int xfer_ensure(nsk_graph *g) {
+    if (g->xfer_dev) return NSK_OK;
+    const size_t bytes = (size_t)std::max<int64_t>(g->c.nvar, 1) * (size_t)g->c.vbytes;
+    for (int k = 0; k < 2; k++) HIPCHECK(hipHostMalloc(&g->xfer_host[k], bytes, hipHostMallocDefault));
+    uint8_t *t = nullptr;
+    int rc = dev_alloc(g, &t, bytes);
+    if (rc) return rc;
+    g->xfer_dev = t;
+    if (g->iid_of_vid) { g->xfer_iid = g->iid_of_vid; return NSK_OK; }
+    return dev_upload(g, &g->xfer_iid, g->c.iid);
+}
+
+// validate the caller's int64 values and narrow them to the device value type, in the caller's order
+// (host threads over index blocks); bad: 0 fine, 1 a value does not fit the value type; *regular: every
+// value lies in [0, cardinality)
+template <typename VT>
+static void narrow_values(const nsk_graph *g, const int64_t *src, VT *dst, int *bad, bool *regular) {
+    const int64_t lo = sizeof(VT) == 1 ? -128 : INT32_MIN, hi = sizeof(VT) == 1 ? 127 : INT32_MAX;
+    const int32_t *card = g->c.v_card.data();
+    std::vector<int> tbad((size_t)nsk::compile_threads(), 0), tirr((size_t)nsk::compile_threads(), 0);
+    nsk::parallel_for(g->c.nvar, [&](int64_t b0, int64_t b1, int t) {
+        int bd = 0, ir = 0;
+        for (int64_t i = b0; i < b1; i++) {
+            const int64_t x = src[i];
+            bd |= (x < lo || x > hi) ? 1 : 0;
+            ir |= (x < 0 || x >= (int64_t)card[i]) ? 1 : 0;
+            dst[i] = (VT)x;
+        }
+        tbad[(size_t)t] = bd; tirr[(size_t)t] = ir;
+    });
+    *bad = 0; *regular = true;
+    for (int x : tbad) *bad |= x;
+    for (int x : tirr) if (x) *regular = false;
+}
+
 extern "C" {
 
 
@@ -443,36 +513,38 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
                      const double *weight_value, const int64_t *count) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     HIPCHECK(hipSetDevice(g->device));
-    const size_t nvar = (size_t)g->c.nvar;
-    const int64_t lo = g->c.vbytes == 1 ? -128 : INT32_MIN, hi = g->c.vbytes == 1 ? 127 : INT32_MAX;
+    const int64_t nvar = g->c.nvar;
+    const size_t vb = (size_t)g->c.vbytes;
     const int64_t *srcs[2] = {var_value, var_value_evid};
     void *dsts[2] = {g->val, g->val_evid};
-    // validate BOTH chains before anything is copied: an error must leave the device state as it was
-    bool regular[2] = {g->chain_regular[0], g->chain_regular[1]};
-    for (int k = 0; k < 2; k++) {
-        if (!srcs[k]) continue;
-        bool reg = true;
-        for (size_t i = 0; i < nvar; i++) {
-            if (srcs[k][i] < lo || srcs[k][i] > hi)
-                return fail(NSK_E_RANGE, "variable value does not fit the device value type");
-            reg = reg && srcs[k][i] >= 0 && srcs[k][i] < (int64_t)g->c.v_card[i];
-        }
-        // UFO (inference.py:398-405) uses the first member's value as an index into the factor's
-        // member list: the reference reads a neighbouring factor's edge (or faults); refuse
-        if (!reg && g->c.has_ufo)
-            return fail(NSK_E_RANGE, "a variable value lies outside its domain on a graph with UFO factors "
-                                     "(the value indexes the factor's member list)");
-        regular[k] = reg;
-    }
-    std::vector<int32_t> tmp;
-    for (int k = 0; k < 2; k++) {
-        if (!srcs[k]) continue;
-        tmp.assign((size_t)g->c.nid, 0);
-        for (size_t i = 0; i < nvar; i++) tmp[g->c.iid[i]] = (int32_t)srcs[k][i];   // caller's order -> internal order
-        g->chain_regular[k] = regular[k];
-        g->values_regular = g->chain_regular[0] && g->chain_regular[1];
-        int rc = upload_values(g, dsts[k], tmp.data(), (size_t)g->c.nid);
+    if ((var_value || var_value_evid) && nvar) {
+        int rc = xfer_ensure(g);
         if (rc) return rc;
+        // validate BOTH chains before anything is copied: an error must leave the device state as it was
+        bool regular[2] = {g->chain_regular[0], g->chain_regular[1]};
+        for (int k = 0; k < 2; k++) {
+            if (!srcs[k]) continue;
+            int bad = 0;
+            bool reg = true;
+            if (vb == 1) narrow_values<int8_t>(g, srcs[k], (int8_t *)g->xfer_host[k], &bad, &reg);
+            else narrow_values<int32_t>(g, srcs[k], (int32_t *)g->xfer_host[k], &bad, &reg);
+            if (bad) return fail(NSK_E_RANGE, "variable value does not fit the device value type");
+            // UFO (inference.py:398-405) uses the first member's value as an index into the factor's
+            // member list: the reference reads a neighbouring factor's edge (or faults); refuse
+            if (!reg && g->c.has_ufo)
+                return fail(NSK_E_RANGE, "a variable value lies outside its domain on a graph with UFO factors "
+                                         "(the value indexes the factor's member list)");
+            regular[k] = reg;
+        }
+        const int nb = (int)std::min<int64_t>(4096, (nvar + NSK_BLOCK - 1) / NSK_BLOCK);
+        for (int k = 0; k < 2; k++) {
+            if (!srcs[k]) continue;
+            g->chain_regular[k] = regular[k];
+            g->values_regular = g->chain_regular[0] && g->chain_regular[1];
+            HIPCHECK(hipMemcpyAsync(g->xfer_dev, g->xfer_host[k], (size_t)nvar * vb, hipMemcpyHostToDevice, g->stream));
+            if (vb == 1) k_state_scatter<int8_t><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((int8_t *)dsts[k], g->xfer_iid, (const int8_t *)g->xfer_dev, nvar);
+            else k_state_scatter<int32_t><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((int32_t *)dsts[k], g->xfer_iid, (const int32_t *)g->xfer_dev, nvar);
+        }
     }
     if (weight_value && g->c.nweight) {
         HIPCHECK(hipMemcpyAsync(g->w, weight_value, (size_t)g->c.nweight * sizeof(double), hipMemcpyHostToDevice, g->stream));
@@ -489,20 +561,24 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
     return NSK_OK;
 }
 
-static int download_values(nsk_graph *g, const void *src, int64_t *dst) {
-    const size_t nvar = (size_t)g->c.nvar, nid = (size_t)g->c.nid;
-    const int32_t *iid = g->c.iid.data();                      // internal order -> caller's order
-    if (g->c.vbytes == 1) {
-        std::vector<int8_t> tmp(nid);
-        if (nid) HIPCHECK(hipMemcpyAsync(tmp.data(), src, nid, hipMemcpyDeviceToHost, g->stream));
-        HIPCHECK(hipStreamSynchronize(g->stream));
-        for (size_t i = 0; i < nvar; i++) dst[i] = tmp[iid[i]];
-    } else {
-        std::vector<int32_t> tmp(nid);
-        if (nid) HIPCHECK(hipMemcpyAsync(tmp.data(), src, nid * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHECK(hipStreamSynchronize(g->stream));
-        for (size_t i = 0; i < nvar; i++) dst[i] = tmp[iid[i]];
-    }
+// device values of one chain -> the caller's int64 array: gather into the caller's order on the device, one
+// narrow copy over PCIe, widened by the host threads
+static int download_values(nsk_graph *g, const void *src, int64_t *dst, int k) {
+    const int64_t nvar = g->c.nvar;
+    if (!nvar) return NSK_OK;
+    int rc = xfer_ensure(g);
+    if (rc) return rc;
+    const size_t vb = (size_t)g->c.vbytes;
+    const int nb = (int)std::min<int64_t>(4096, (nvar + NSK_BLOCK - 1) / NSK_BLOCK);
+    if (vb == 1) k_state_gather<int8_t><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const int8_t *)src, g->xfer_iid, (int8_t *)g->xfer_dev, nvar);
+    else k_state_gather<int32_t><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const int32_t *)src, g->xfer_iid, (int32_t *)g->xfer_dev, nvar);
+    HIPCHECK(hipMemcpyAsync(g->xfer_host[k], g->xfer_dev, (size_t)nvar * vb, hipMemcpyDeviceToHost, g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    const void *h = g->xfer_host[k];
+    nsk::parallel_for(nvar, [&](int64_t b0, int64_t b1, int) {
+        if (vb == 1) for (int64_t i = b0; i < b1; i++) dst[i] = ((const int8_t *)h)[i];
+        else for (int64_t i = b0; i < b1; i++) dst[i] = ((const int32_t *)h)[i];
+    });
     return NSK_OK;
 }
 
@@ -511,8 +587,8 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
     if (!g) return fail(NSK_E_INVALID, "null graph");
     HIPCHECK(hipSetDevice(g->device));
     int rc;
-    if (var_value && (rc = download_values(g, g->val, var_value))) return rc;
-    if (var_value_evid && (rc = download_values(g, g->val_evid, var_value_evid))) return rc;
+    if (var_value && (rc = download_values(g, g->val, var_value, 0))) return rc;
+    if (var_value_evid && (rc = download_values(g, g->val_evid, var_value_evid, 1))) return rc;
     if (weight_value && g->c.nweight)
         HIPCHECK(hipMemcpyAsync(weight_value, g->w, (size_t)g->c.nweight * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     if (count) {
@@ -588,6 +664,20 @@ int nsk_graph_get_layout(nsk_graph *g, int32_t *iid, int64_t *nid) {
     if (!g) return fail(NSK_E_INVALID, "null argument");
     if (iid && g->c.nvar) memcpy(iid, g->c.iid.data(), (size_t)g->c.nvar * sizeof(int32_t));
     if (nid) *nid = g->c.nid;
+    return NSK_OK;
+}
+
+int nsk_graph_get_generators(nsk_graph *g, int64_t *gen) {
+    if (!g || !gen) return fail(NSK_E_INVALID, "null argument");
+    const Compiled &c = g->c;
+    std::vector<uint8_t> quad((size_t)c.npos, 0);
+    for (const Compiled::Segment &sg : c.segments)
+        if (sg.ztab >= 0)
+            for (int64_t p = sg.pos0; p < sg.pos0 + (int64_t)sg.ntiles * 64 && p < c.npos; p++) quad[(size_t)p] = 1;
+    for (int64_t v = 0; v < c.nvar; v++) {
+        const int64_t p = c.color[v] >= 0 ? (int64_t)c.iid[v] : -1;
+        gen[v] = p < 0 ? -1 : (p | ((p < c.npos && quad[(size_t)p]) ? (1ll << 40) : 0ll));
+    }
     return NSK_OK;
 }
 

@@ -14,27 +14,6 @@
 
 namespace nsk {
 
-// Static block partition of [0, n) over the compile threads (NSK_COMPILE_THREADS, default: the
-// hardware's, at most 64).  Every use writes disjoint outputs per index, so results do not depend
-// on the thread count.
-static int compile_threads() {
-    static const int n = [] {
-        const char *e = getenv("NSK_COMPILE_THREADS");
-        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-        return std::max(1, std::min(64, t));
-    }();
-    return n;
-}
-template <typename F>
-static void parallel_for(int64_t n, F &&body) {            // body(begin, end, thread index)
-    const int T = (int)std::min<int64_t>(compile_threads(), std::max<int64_t>(1, n / 4096));
-    if (T <= 1) { body((int64_t)0, n, 0); return; }
-    std::vector<std::thread> th;
-    th.reserve((size_t)T);
-    for (int t = 0; t < T; t++)
-        th.emplace_back([&, t] { body(n * t / T, n * (t + 1) / T, t); });
-    for (auto &x : th) x.join();
-}
 
 // a variable whose factor lists hold at least this many entries in total is sampled by a whole wave
 static const int64_t NSK_HEAVY_LIST = 32;
@@ -1415,76 +1394,6 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     (double)subrows[ngroups] * 256 / 1e6);
     }
     lap("entry-parallel groups");
-    // ---- compact twin of the table segments' streams: member positions as int16 deltas from the
-    // lane's own position plus one base offset per segment (8 bytes per lane instead of 16 for <= 4
-    // slots), for segments whose every delta fits -- on a grid every neighbour of a class lives in
-    // the other class's range at a fixed offset +- a row.  The table kernels read this stream; the
-    // 32-bit stream stays for the kernels that run when the draw tables cannot be used (values
-    // outside their domains on the device).  Ignored slots (member-less entries) repeat the lane's
-    // first real member (their value never matters) or point at the lane itself.
-    {
-        uint64_t units = 0;                               // 8-byte units
-        // opt-in (NSK_D16=1): on the 10M grid the compact stream cuts the launch's HBM traffic from
-        // 130 MB to 90 MB at the same 24 us -- the table kernel is bound by instruction issue, not by
-        // bandwidth -- so by default the second copy is not built
-        const bool no_d16 = diag_env("NSK_D16") == nullptr;
-        auto word_at = [&](const Compiled::Segment &sg, int nch, int64_t t, int64_t i, uint32_t j) -> int64_t {
-            return (int64_t)c.adj[((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4 + 256 * (j / 4) + 4 * i + (j % 4)];
-        };
-        for (Compiled::Segment &sg : c.segments) {
-            sg.d16 = -1; sg.d16base = 0;
-            if (sg.ztab < 0 || no_d16) continue;
-            const int nch = sg.nslots > 4 ? 2 : 1;
-            const uint32_t *pw = &c.tile_hdr[sg.prog];
-            bool fits = true, have_base = false;
-            int64_t base = 0;
-            for (int64_t t = 0; t < sg.ntiles && fits; t++)
-                for (int64_t i = 0; i < 64 && fits; i++) {
-                    const int64_t pp = sg.pos0 + 64 * t + i;
-                    // (every lane, padding ones too, must be able to name SOME valid position)
-                    if (have_base && (pp + base < -32767 || pp + base > c.nid - 1 + 32767)) { fits = false; break; }
-                    if (c.p_vid[pp] < 0) continue;
-                    for (uint32_t j = 0; j < sg.nslots; j++) {
-                        if ((pw[j] >> 29) & 1u) continue;                    // ignored slot
-                        const int64_t id = word_at(sg, nch, t, i, j);
-                        if (!have_base) { base = id - pp; have_base = true; }
-                        const int64_t dl = id - (pp + base);
-                        if (dl < -32768 || dl > 32767) { fits = false; break; }
-                    }
-                }
-            if (!fits || base < INT32_MIN || base > INT32_MAX) continue;
-            sg.d16 = (int64_t)units;
-            sg.d16base = (int32_t)base;
-            units += (uint64_t)sg.ntiles * 64 * nch;
-        }
-        if (units >= ((uint64_t)1 << 31)) { err = "compact stream too large"; return NSK_E_RANGE; }
-        c.adj16.assign((size_t)units * 2 + 2, 0u);
-        for (const Compiled::Segment &sg : c.segments) {
-            if (sg.d16 < 0) continue;
-            const int nch = sg.nslots > 4 ? 2 : 1;
-            const uint32_t *pw = &c.tile_hdr[sg.prog];
-            parallel_for(sg.ntiles, [&](int64_t tb0, int64_t tb1, int) {
-                for (int64_t t = tb0; t < tb1; t++)
-                    for (int64_t i = 0; i < 64; i++) {
-                        const int64_t pp = sg.pos0 + 64 * t + i;
-                        uint16_t *out = (uint16_t *)&c.adj16[((uint64_t)sg.d16 + ((uint64_t)t * 64 + i) * nch) * 2];
-                        // default (padding lanes and slots, ignored slots): the lane's first real
-                        // member, else the valid position nearest to own position + base
-                        const int64_t near = std::min<int64_t>(std::max<int64_t>(pp + sg.d16base, 0), c.nid - 1);
-                        int64_t dflt = near - (pp + sg.d16base);
-                        if (c.p_vid[pp] >= 0)
-                            for (uint32_t j = 0; j < sg.nslots; j++)
-                                if (!((pw[j] >> 29) & 1u)) { dflt = word_at(sg, nch, t, i, j) - (pp + sg.d16base); break; }
-                        for (uint32_t j = 0; j < (uint32_t)(4 * nch); j++) {
-                            int64_t dl = dflt;
-                            if (c.p_vid[pp] >= 0 && j < sg.nslots && !((pw[j] >> 29) & 1u))
-                                dl = word_at(sg, nch, t, i, j) - (pp + sg.d16base);
-                            out[j] = (uint16_t)(int16_t)dl;
-                        }
-                    }
-            });
-        }
-    }
     // ---- implicit adjacency of table segments (nsk_compile.h seg_aff)
     {
         uint64_t ntile4 = 0;
@@ -1631,8 +1540,6 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 for (const Compiled::Segment *sgp : mine) {
                     const Compiled::Segment &sg = *sgp;
                     t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
-                    t.d16off[t.n] = sg.d16 >= 0 ? (uint32_t)sg.d16 : 0xFFFFFFFFu;
-                    t.d16base[t.n] = sg.d16base;
                     t.aff[t.n] = sg.aff >= 0 ? (uint32_t)sg.aff : 0xFFFFFFFFu;
                     t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
                     t.zmask[t.n] = (1u << sg.nslots) - 1u;
@@ -1885,15 +1792,12 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             lay_inf += (double)distinct * s_v + (double)(nfastpos + ncatpos) * s_v + 2.0 * nfastpos + 2.0 * s_c * ncatpos;
             lay_learn += 2.0 * distinct * s_v + 2.0 * (nfastpos + ncatpos) * s_v;
         }
-        for (const Compiled::Segment &sg : c.segments)      // inference over table segments reads the compact
-            if (sg.d16 >= 0)                                 // stream when there is one
-                lay_inf -= (double)sg.ntiles * 64 * 8 * (sg.nslots > 4 ? 2 : 1);
         for (const Compiled::Segment &sg : c.segments) {    // inference over table segments: a tile with implicit
             if (sg.aff < 0) continue;                        // adjacency reads 16 bytes per chunk, not 64 x 16
             const int nch = sg.nslots > 4 ? 2 : 1;
             for (int64_t t = 0; t < sg.ntiles; t++)
                 if (c.seg_aff[((size_t)sg.aff + (size_t)t * nch) * 4] != 0xFFFFFFFFu) {
-                    if (sg.d16 < 0) lay_inf -= (double)nch * (64 * 16 - 16);     // (a compact stream is read instead)
+                    lay_inf -= (double)nch * (64 * 16 - 16);
                     lay_learn -= (double)nch * (64 * 16 - 16);
                 }
         }

@@ -5,8 +5,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/numbskull_amd.h"
@@ -15,6 +17,27 @@
 #define NSK_GEN_NULL 0x7FFFFFFu     // member id of an empty slot in a general tile (kind 6)
 
 namespace nsk {
+
+// Static block partition of [0, n) over the host threads (NSK_COMPILE_THREADS, default: the hardware's, at
+// most 64).  Every use writes disjoint outputs per index, so results do not depend on the thread count.
+static inline int compile_threads() {
+    static const int n = [] {
+        const char *e = getenv("NSK_COMPILE_THREADS");
+        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(64, t));
+    }();
+    return n;
+}
+template <typename F>
+static void parallel_for(int64_t n, F &&body) {            // body(begin, end, thread index)
+    const int T = (int)std::min<int64_t>(compile_threads(), std::max<int64_t>(1, n / 4096));
+    if (T <= 1) { body((int64_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)T);
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] { body(n * t / T, n * (t + 1) / T, t); });
+    for (auto &x : th) x.join();
+}
 
 // Diagnostic switches (INTEGRATION.md "Diagnostic switches") change which layout / kernel family a
 // graph compiles to -- and therefore its sample stream.  A product library must not pick those up
@@ -63,7 +86,6 @@ struct Compiled {
     std::vector<uint32_t> bighub_pos;
     std::vector<int64_t> phase_bighub_base; // [ncolors+1]
     int64_t nhub_ep = 0;
-    std::vector<uint32_t> adj16;           // compact twin of the table segments' streams: int16 deltas
     // A tile whose 64 lanes share one header sequence (same function, member count and weight per
     // entry) with at most 8 member slots is "uniform": its stream holds member words only and its
     // per-slot program (weight id, function code, first/last/ignore flags; nsk_compile.cpp) is kept
@@ -79,8 +101,6 @@ struct Compiled {
     // segment (rest_tiles, per phase) go through the descriptor-driven kernel.
     struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev;
                      int64_t ztab;         // first entry of the program's draw table, -1 = none
-                     int64_t d16;          // first 8-byte unit of the compact (int16 delta) stream, -1 = none
-                     int32_t d16base;      // member position = own position + d16base + delta
                      int64_t aff; };       // first entry of the segment's tiles in seg_aff (-1: none)
     std::vector<Segment> segments;
     // Implicit adjacency of table segments: a tile whose every member slot holds position
@@ -105,7 +125,7 @@ struct Compiled {
     // their own (at most NSK_LEARN_SEG_LAUNCHES per colour); every other non-general tile is on
     // the colour's learn_rest list
     struct SegLaunch { int32_t phase, kind, nch, n, tab; int32_t tile_start[9]; int32_t pos0[8];
-                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], d16off[8], aff[8]; int32_t ev[8], d16base[8]; };
+                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], aff[8]; int32_t ev[8]; };
     std::vector<SegLaunch> learn_seg;
     std::vector<uint32_t> learn_rest_tiles;
     std::vector<int64_t> phase_learn_rest_base;   // [ncolors+1]

@@ -116,6 +116,23 @@ __device__ __forceinline__ uint2 inf_words(uint32_t k0, uint32_t k1, uint32_t q,
     const u32x4 r = philox4x32(k0, k1, inf_block(q), 0u, s0, s1);
     return ((q >> 6) & 1u) ? uint2{r.z, r.w} : uint2{r.x, r.y};
 }
+// Positions inside segments with draw tables use the QUAD scheme instead: ids q, q + 64, q + 128, q + 192
+// with equal q >> 8 -- the same lane of four consecutive tiles -- share TWO blocks, counter
+// ((q >> 8) * 64 + (q & 63), stream, sweep): stream 2 ("A") word (q >> 6) & 3 is the variable's HIGH word a,
+// stream 3 ("B") the same word its LOW word b; the 53-bit integer of the draw is (a >> 5) << 26 | b >> 6 as
+// ever.  The table kernel compares a >> 5 with the threshold's top 27 bits first -- one block per lane
+// decides four updates -- and evaluates block B only on a tie (probability 2^-27 per update); the
+// decision is the 53-bit one by construction.  Kernels that need the uniform itself compute both.
+__device__ __forceinline__ uint32_t quad_block(uint32_t q) { return ((q >> 8) << 6) | (q & 63u); }
+__device__ __forceinline__ uint32_t word_of(const u32x4 &r, uint32_t j) {
+    return j == 0u ? r.x : (j == 1u ? r.y : (j == 2u ? r.z : r.w));
+}
+__device__ __forceinline__ uint2 inf_words_quad(uint32_t k0, uint32_t k1, uint32_t q, uint32_t s0, uint32_t s1) {
+    const u32x4 a = philox4x32(k0, k1, quad_block(q), 2u, s0, s1);
+    const u32x4 b = philox4x32(k0, k1, quad_block(q), 3u, s0, s1);
+    const uint32_t j = (q >> 6) & 3u;
+    return uint2{word_of(a, j), word_of(b, j)};
+}
 
 // 53-bit uniform in [0,1) from two 32-bit words: the genrand_res53 construction that
 // np.random.rand() / random.random() use (inference.py:50, learning.py:90)
@@ -227,11 +244,9 @@ struct DevGraph {
     const uint4 *hub_desc;      // [npos] entry-parallel hubs: {offset into hub_adj, entries, M | card << 8, 0};
     const uint32_t *hub_adj;    //  entries == 0: generic hub walk.  Rows of 64 words, one entry per lane
     uint8_t *sink;              // 1 KiB scratch: where padding lanes store (branch-free epilogues)
-    const uint2 *adj16;         // compact streams of table segments: member ids as int16 deltas from
-                                //  the lane's own variable id, 4 per 8-byte unit
     const uint4 *seg_aff;       // implicit adjacency of table segments: slot bases per tile (nsk_compile.h)
     const uint4 *ztab;          // draw tables of the uniform programs whose members are all binary:
-                                //  entry (program, neighbourhood bits) = {K lo, K hi, sat0 | sat1 << 8, 0}
+                                //  entry (program, neighbourhood bits) = {K >> 26, K & (2^26 - 1), sat0 | sat1 << 8, 0}
                                 //  (k_refresh_ztab; DESIGN.md "draw tables")
     const uint32_t *bighub_pos; // positions of the hubs a whole workgroup evaluates (hub_desc[..].w = 1)
     const uint4 *ep_desc;       // entry-parallel groups of general tiles (nsk_compile.h ep_desc): one per

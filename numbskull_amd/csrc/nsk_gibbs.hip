@@ -60,20 +60,20 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         for (const Compiled::Segment *sgp : mine) {
                             const Compiled::Segment &sg = *sgp;
                             SegEntry &en = tab.e[tab.n];
-                            // table launches number their tiles virtually: a segment starts on a pair
-                            // boundary (positions 128 m), with one dead tile in front when needed
-                            const int lead = kind >= 8 ? (int)((sg.pos0 / 64) & 1) : 0;
-                            const int vtiles = kind >= 8 ? ((sg.ntiles + lead + 1) & ~1) : sg.ntiles;
+                            // table launches number their tiles virtually: a segment starts on a quad
+                            // boundary (positions 256 m), with up to three dead tiles in front
+                            const int lead = kind >= 8 ? (int)((sg.pos0 / 64) & 3) : 0;
+                            const int vtiles = kind >= 8 ? ((sg.ntiles + lead + 3) & ~3) : sg.ntiles;
                             en.ntiles_lead = (uint32_t)sg.ntiles | ((uint32_t)lead << 30);
                             en.tile_start = tab.ntiles;
                             en.pos0 = (int)sg.pos0;
                             en.adj_off = sg.adj_off;
                             en.prog = sg.prog;
                             en.zoff = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
-                            en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8);
-                            en.d16off = sg.d16 >= 0 ? (uint32_t)sg.d16 : NSK_NO_D16_STREAM;
-                            en.d16base = sg.d16base;
-                            en.aff_off = (kind >= 8 && sg.aff >= 0) ? (uint32_t)sg.aff : NSK_NO_D16_STREAM;
+                            // (bit 16: the positions of a segment with a draw table draw from the quad
+                            // scheme whichever kernel samples them, nsk_device.h quad_block)
+                            en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8) | (sg.ztab >= 0 ? 1u << 16 : 0u);
+                            en.aff_off = (kind >= 8 && sg.aff >= 0) ? (uint32_t)sg.aff : NSK_NO_STREAM;
                             tab.ntiles += vtiles;
                             if (++tab.n == NSK_SEG_MAX) flush();
                         }
@@ -98,16 +98,20 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const int nrest_all = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
                     rest_in_general = nrest_all > 0;
                     const int rblocks = (nrest_all + 3) / 4;
-                    // resident grid: 7 workgroups per CU (22 KB of LDS each), whole rounds of XCDs
+                    // grid: 7 workgroups per CU, whole rounds of XCDs.  Only 4 (categorical kernel: 101 vector
+                    // registers) or 5 of them are resident; the others start as those end, which deals the
+                    // groups' uneven costs out dynamically -- per class on the 5M LR graph (NSK_EP_PER_CU):
+                    // 3 workgroups per CU 68.4 us, 4 58.6, 5 65.6, 6 66.8, 7 58.3
+                    const bool cat8 = g->c.phase_gen_bin_tile[ph] > gt0;
                     const char *pcu_env = nsk::diag_env("NSK_EP_PER_CU");        // (diagnostic: workgroups per CU)
-                    const int pcu = pcu_env ? std::max(1, std::min(7, atoi(pcu_env))) : 7;
+                    const int pcu = pcu_env ? std::max(1, std::min(32, atoi(pcu_env))) : 7;
                     const int gblocks = 8 * ((std::min(ngroups, 256 * pcu) + 7) / 8);
                     const dim3 grid(hblocks + gblocks + rblocks);
                     const size_t smem = 0;
 #define NSK_EP_ARGS d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, ngt, ngroups, (int)g->c.phase_ep_base[ph], gblocks, fe, he, hblocks, \
                     (int)g->c.phase_hub_base[ph], nbh, (int)g->c.phase_bighub_base[ph], g->rest_tiles + g->c.phase_rest_base[ph], nrest_all, sample_evidence, burnin, \
                     (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep, nsk_sweep_hi(g)
-                    if (g->c.phase_gen_bin_tile[ph] > gt0) k_gibbs_ep<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
+                    if (cat8) k_gibbs_ep<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
                     else k_gibbs_ep<VT, 2><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
 #undef NSK_EP_ARGS
                     g->launches++;
@@ -172,11 +176,11 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
 #define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
                         if (kind >= 8) {
-                            // resident grid over tile pairs: at most 8 blocks per CU
-                            const int npairs = tab.ntiles / 2;
-                            const int nbp = nsk_tab_grid(npairs);
-                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
-                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
+                            // a wave per tile pair while that fits 8 blocks per CU, else a resident grid over quads
+                            int split;
+                            const int nbp = nsk_tab_grid(tab.ntiles, &split);
+                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, split);
+                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, split);
                         }
                         else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
                         else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
@@ -258,14 +262,14 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
     for (int i = 0; i < NSK_GRAPH_SWEEPS; i++) {
         for (size_t ph = 0; ph < g->seg_plans.size(); ph++)
             for (const NskSegPlan &pl : g->seg_plans[ph]) {
-                const int npairs = pl.tab.ntiles / 2;
-                const int nbp = nsk_tab_grid(npairs);
+                int split;
+                const int nbp = nsk_tab_grid(pl.tab.ntiles, &split);
                 if (pl.nch == 1)
                     k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
-                                                                                         g->d_counters, (uint32_t)i);
+                                                                                         g->d_counters, (uint32_t)i, split);
                 else
                     k_gibbs_seg_tab<VT, 2><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
-                                                                                         g->d_counters, (uint32_t)i);
+                                                                                         g->d_counters, (uint32_t)i, split);
                 launches++;
             }
         if (p2p) {

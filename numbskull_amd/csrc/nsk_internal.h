@@ -67,7 +67,6 @@ struct nsk_graph {
     double *prog_w = nullptr, *adj_wt = nullptr;
     uint32_t *tile_wrow = nullptr;
     uint4 *ztab = nullptr;              // draw tables (k_refresh_ztab)
-    uint32_t *adj16 = nullptr;          // compact streams of table segments
     uint32_t *seg_aff = nullptr;        // implicit adjacency of table segments
     uint8_t *sink = nullptr;            // scratch line for padding lanes' stores
     uint32_t *hub_desc = nullptr, *hub_adj = nullptr;   // entry-parallel hub streams
@@ -88,6 +87,20 @@ struct nsk_graph {
     long long *part_G = nullptr;       // SMALLW: NSK_LEARN_BINS bins of partial sums per weight
     uint32_t *part_K = nullptr, *part_T = nullptr;
     bool smallw = false;
+    // One-class-lagged learning (nsk_set_learn_lag, default on): class c samples with the weights as of
+    // the end of class c - 2 while the update of class c - 1 runs beside it (block 0 of the class's table
+    // launch) or behind it; weights, slot-program terms, draw tables and accumulators exist twice (set 0 =
+    // the arrays above) and the classes alternate between them.
+    bool learn_lag = true;
+    double *w1 = nullptr, *prog_w1 = nullptr;
+    uint4 *ztab1 = nullptr;
+    long long *G1 = nullptr, *part_G1 = nullptr;
+    uint32_t *K1 = nullptr, *T1 = nullptr, *part_K1 = nullptr, *part_T1 = nullptr;
+    // state transfer (nsk_state_upload / nsk_state_download): values cross PCIe narrowed (1 or 4 bytes) in the
+    // caller's order through pinned staging buffers; the permutation to layout order runs on the device
+    void *xfer_host[2] = {nullptr, nullptr};       // pinned, nvar * vbytes each (one per chain)
+    void *xfer_dev = nullptr;                      // nvar * vbytes
+    int32_t *xfer_iid = nullptr;                   // internal id of every variable
     bool weights_dirty = true;      // prog_w must be rebuilt before the next fast-path launch
     bool weights_exposed = false;
     bool adj_wt_skip = false;       // learning reads weights directly: skip the shape-tile rows until the next inference   // the weight buffer was handed out: assume it changes between calls
@@ -163,11 +176,28 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.ep_desc = (const uint4 *)g->ep_desc; d.ep_adj = g->ep_adj; d.bighub_pos = g->bighub_pos;
     d.ep_wrow = g->ep_wrow; d.ep_wt = g->ep_wt;
     d.ep_kstat = g->c.ep_kstat.empty() ? nullptr : g->ep_kstat;
-    d.adj16 = (const uint2 *)g->adj16;
     d.seg_aff = (const uint4 *)g->seg_aff;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
     return d;
+}
+
+// Workgroups of `kernel` (256 threads, `smem` bytes of dynamic LDS) that are RESIDENT per CU: the size of a
+// resident grid whose blocks loop over their share of the work (a block beyond it starts when another
+// ends: a tail round as long as the first).  The occupancy API accounts for vector registers and LDS but
+// admits one block too many when a kernel holds 97-112 scalar registers (MI355X_MICROARCH.md: blocks per
+// CU = min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) -- 6 at the 104-106 every sweep kernel here uses), hence
+// the cap.  Cached per kernel.
+template <typename K>
+static int nsk_blocks_per_cu(K kernel, size_t smem) {
+    static std::vector<std::pair<const void *, int>> cache;
+    const void *key = (const void *)kernel;
+    for (auto &e : cache) if (e.first == key) return e.second;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NSK_BLOCK, smem) != hipSuccess || n < 1) n = 4;
+    n = std::min(n, 6);
+    cache.push_back({key, n});
+    return n;
 }
 
 // Streams for the kernels of one colour: the tile kernels stay on the main stream; when there are
@@ -209,19 +239,29 @@ static inline int nsk_learn_tab_grid(int ntiles, int nweight, bool smallw) {
     // the update launch: 1024 blocks 31.2 us, 1280 30.1, 1408 31.1, 1536 29.6, 1664 31.2, 1792 32.2,
     // 1920 32.5, 2048 31.4, 3072 31.3, 4096 31.7; the 1M grid is indifferent: 14.1-14.3)
     const char *cap_env = nsk::diag_env("NSK_LEARN_GRID_CAP");              // (diagnostic; read per launch so that tests can set it)
-    const int cap = cap_env ? atoi(cap_env) : 1536;
+    // (SMALLW launches carry 8 service blocks in front, k_learn_seg_tab: they count towards the six per CU)
+    const int cap = cap_env ? atoi(cap_env) : (smallw ? 1528 : 1536);
     return 8 * ((std::max(1, std::min(cap, (blocks + trips - 1) / trips)) + 7) / 8);     // whole rounds of XCDs
 }
-// Grid of a table-driven inference segment launch (k_gibbs_seg_tab): one block per four tile pairs
-// while that is at most 8 blocks per CU (every wave makes one trip), else a resident grid of 7 blocks
-// per CU, whole rounds of XCDs.  Measured per class (NSK_TAB_GRID_CAP, two passes on one box): 10M grid
-// 1024 blocks 15.8 us, 1280 15.0, 1536 14.7, 1792 14.3, 2048 15.0; 40M grid 1280 49.7, 1536 48.2,
-// 1792 47.1, 2048 53.0; the 1M grid needs 1954 blocks and is best left alone (4.13 against 4.20 us).
-static inline int nsk_tab_grid(int npairs) {
+// Grid of a table-driven inference segment launch (k_gibbs_seg_tab) over `vtiles` virtual tiles (a multiple
+// of 4): one wave per tile PAIR (split = 1; both waves of a quad evaluate its Philox block) while that is
+// at most 8 blocks per CU -- a small launch is one wave lifetime long and the shorter wave wins --, else a
+// resident grid of 7 blocks per CU, whole rounds of XCDs, whose waves loop over QUADS (split = 0: one block
+// per lane decides four updates).  Measured per class in round 3 (pairs, NSK_TAB_GRID_CAP, two passes on one
+// box): 10M grid 1024 blocks 15.8 us, 1280 15.0, 1536 14.7, 1792 14.3, 2048 15.0; 40M grid 1280 49.7, 1536
+// 48.2, 1792 47.1, 2048 53.0; the 1M grid needs 1954 blocks and is best left alone (4.13 against 4.20 us).
+static inline int nsk_tab_grid(int vtiles, int *split) {
+    const int npairs = vtiles / 2, nquads = vtiles / 4;
     const int need = std::max(8, 8 * ((((npairs + 3) / 4) + 7) / 8));
-    const char *cap_env = nsk::diag_env("NSK_TAB_GRID_CAP");                // (diagnostic)
-    if (cap_env) return std::max(8, std::min(atoi(cap_env) & ~7, need));
-    return need <= 2048 ? need : 1792;
+    const char *cap_env = nsk::diag_env("NSK_TAB_GRID_CAP");                // (diagnostic; negative: quads at |cap| blocks)
+    if (cap_env) {
+        const int cap = atoi(cap_env);
+        *split = cap > 0 && need <= 2048 ? 1 : 0;
+        const int needq = std::max(8, 8 * ((((nquads + 3) / 4) + 7) / 8));
+        return *split ? std::max(8, std::min(cap & ~7, need)) : std::max(8, std::min(std::abs(cap) & ~7, needq));
+    }
+    *split = need <= 2048 ? 1 : 0;
+    return *split ? need : 1536;        // 6 blocks per CU are resident (106 scalar registers: nsk_blocks_per_cu)
 }
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {
     const int ntiles = sl.tile_start[sl.n];
@@ -230,6 +270,7 @@ static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nwe
 }
 
 extern "C" int nsk_ensure_generic(nsk_graph *g);       // internal (not in the public header)
+int nsk_ensure_lag_sets(nsk_graph *g);                 // second set of weights / tables / accumulators (nsk_api.hip)
 #define NSK_GRAPH_SWEEPS 16
 // one peer-to-peer exchange on the library's stream; tag_base != null: a captured launch whose tag is
 // the device counter + tag_off; learn: both chains + the weight deltas; part 0 = all of it, 1 = the
@@ -238,5 +279,5 @@ int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned i
 void nsk_drop_sweep_graph(nsk_graph *g);            // the captured sweep sequence bakes exchange pointers: drop it when they change
 int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p);   // nsk_gibbs.hip
 void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);
-void nsk_refresh_ztab(nsk_graph *g);
+void nsk_refresh_ztab(nsk_graph *g, int set = 0, hipStream_t st = nullptr);
 int nsk_fold_position_tally(nsk_graph *g);

@@ -1359,20 +1359,18 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(DevGraph<VT> g, int pbeg
 // kernel fetches per tile comes from the kernel-argument table here, and the body is straight
 // line: ids, 16-byte member loads, byte gathers, compares, draw, store.
 #define NSK_SEG_MAX 8
-#define NSK_NO_D16_STREAM 0xFFFFFFFFu      // SegTable.d16off of a segment without a compact stream
+#define NSK_NO_STREAM 0xFFFFFFFFu          // SegEntry.aff_off of a segment without implicit adjacency
 struct SegEntry {                         // 48 bytes: two scalar loads per tile (pair)
     int tile_start;                       // first tile of the segment in this launch's numbering
     int pos0;                             // position of the segment's first lane
     uint32_t adj_off;                     // stream offset (16-byte units) of its first tile
     uint32_t prog;                        // slot program
     uint32_t zoff;                        // draw-table launches: first entry of the program's table
-    uint32_t zmask_ev;                    // (1 << member slots) - 1 | (uint8) common isEvidence << 8
-    uint32_t d16off;                      // first 8-byte unit of the compact stream, NSK_NO_D16_STREAM: none
-    int d16base;                          // member position = own position + d16base + int16 delta
-    uint32_t ntiles_lead;                 // table launches: tiles of the segment | lead << 30 (one dead
-                                          //   virtual tile in front: the segment starts on an upper half)
-    uint32_t aff_off;                     // first entry of the segment's tiles in seg_aff, NSK_NO_D16_STREAM: none
-    uint32_t pad_[2];
+    uint32_t zmask_ev;                    // (1 << member slots) - 1 | (uint8) common isEvidence << 8 | quad generator scheme << 16
+    uint32_t ntiles_lead;                 // table launches: tiles of the segment | lead << 30 (dead virtual
+                                          //   tiles in front: the segment does not start a quad)
+    uint32_t aff_off;                     // first entry of the segment's tiles in seg_aff, NSK_NO_STREAM: none
+    uint32_t pad_[4];
 };
 struct SegTable {
     int n, ntiles;                        // segments, tiles of the launch; e[i].tile_start = ntiles for i >= n
@@ -1386,22 +1384,6 @@ __device__ __forceinline__ int seg_of_tile(const SegTable &tab, int T) {
     if (T >= tab.e[1].tile_start)                           // (= ntiles when the launch has one segment)
         for (int i = 1; i < tab.n && T >= tab.e[i].tile_start; i++) sidx = i;
     return sidx;
-}
-
-// member positions of one lane from the compact stream: the lane's 4 * NCH int16 deltas (2 * NCH
-// raw words, loaded early) added to its own position + the segment's base offset
-template <int NCH>
-__device__ __forceinline__ void d16_load(const uint2 *base, int lane_unit, uint32_t (&w)[2 * NCH]) {
-    if (NCH == 1) { const uint2 q = base[lane_unit]; w[0] = q.x; w[1] = q.y; }
-    else { const uint4 q = ((const uint4 *)base)[lane_unit]; w[0] = q.x; w[1] = q.y; w[2 * NCH - 2] = q.z; w[2 * NCH - 1] = q.w; }
-}
-template <int NCH>
-__device__ __forceinline__ void d16_ids(const uint32_t (&w)[2 * NCH], int vb, uint32_t (&id)[4 * NCH]) {
-#pragma unroll
-    for (int j = 0; j < 2 * NCH; j++) {
-        id[2 * j] = (uint32_t)(vb + (int)(int16_t)(w[j] & 0xFFFFu));
-        id[2 * j + 1] = (uint32_t)(vb + ((int)w[j] >> 16));
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1478,7 +1460,8 @@ __device__ __forceinline__ uint4 ztab_entry(const uint32_t *pp, uint32_t nslots,
         const unsigned long long mid = lo + ((hi - lo) >> 1);
         if (draw_from_z(z0, z1, mid) == 0) lo = mid; else hi = mid;
     }
-    return uint4{(uint32_t)lo, (uint32_t)(lo >> 32), sat0 | (sat1 << 8), 0u};
+    // entry: the threshold's top 27 bits, its low 26 bits, the satisfied bits
+    return uint4{(uint32_t)(lo >> 26), (uint32_t)(lo & 0x3FFFFFFull), sat0 | (sat1 << 8), 0u};
 }
 
 static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_ztab(const ZProgDev *zp, const uint32_t *tile_hdr,
@@ -1496,29 +1479,36 @@ __device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) {
     return ((unsigned long long)(a >> 5) << 26) | (unsigned long long)(b >> 6);
 }
 
+// the 53-bit threshold of a table entry
+__device__ __forceinline__ unsigned long long ztab_K(const uint4 &e) { return ((unsigned long long)e.x << 26) | (unsigned long long)e.y; }
+
 // Homogeneous segments whose programs have draw tables: ids, byte gathers, bit pack, one 8-byte
 // table read, integer compare.  No float64 arithmetic, no p_vid.
-// * Resident grid (8 waves per SIMD): the waves loop over tile PAIRS, so the per-wave set-up --
+// * Resident grid (8 waves per SIMD): the waves loop over their work units, so the per-wave set-up --
 //   kernel-argument loads, the Philox key schedule, base pointers -- is paid once per wave, and XCD x
-//   walks the x-th eighth of the pairs (same locality as xcd_logical_block).
-// * A pair is two tiles at positions 128 m .. 128 m + 127: lane l holds generator ids q and q + 64,
-//   which share one Philox block (nsk_device.h inf_block) -- ONE Philox evaluation per lane serves two
-//   updates.  The host numbers a launch's tiles "virtually": every segment starts on a pair boundary
-//   (lead = 1 inserts a dead tile in front when its first tile is the upper half of a pair).
+//   walks the x-th eighth of the units (same locality as xcd_logical_block).
+// * A QUAD is four tiles at positions 256 m .. 256 m + 255: lane l holds generator ids q, q + 64, q + 128,
+//   q + 192, whose high words are the four words of ONE Philox block (nsk_device.h quad_block) -- one
+//   Philox evaluation per lane decides four updates by comparing the top 27 bits with the tabulated
+//   threshold's; the low words (a second block) are computed only when some lane ties (2^-27 per update).
+//   The host numbers a launch's tiles "virtually": every segment starts on a quad boundary (lead = 1..3
+//   dead tiles in front when its first tile is not the first of a quad).
+//   A work unit is a quad (split = 0: big launches) or one of its two tile pairs (split = 1: launches
+//   small enough that every pair gets a wave of its own; the block is then evaluated by both waves).
 // * Padding lanes (class ends) sample like any other lane into their own, never-read, position; the
 //   tally fold skips them.
-// The kernel is bound by instruction issue; these three points took a 10M-grid
-// class from 23.7 to 16.3 us.  (Requesting the next pair's stream words behind this pair's table
-// loads, as k_learn_seg_tab does, was measured here too: 10M grid 17.0 -> 19.7 us per class, 1M grid
-// 4.1 -> 3.8 us -- not kept.)
-#ifndef NSK_TAB_PP
-#define NSK_TAB_PP 1          // tile pairs a wave takes per step (10M grid, per class: 1 pair 14.7 us, 2 15.6, 3 16.8)
+// Round 2/3: instruction issue bounds the kernel, 63 of its 107 vector instructions
+// per tile pair were the Philox rounds.
+#ifdef NSK_ABL_TABWPE8      // (experiment: at most 96 scalar registers, so that 7 blocks per CU are resident)
+#define NSK_TAB_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define NSK_TAB_ATTR
 #endif
 template <typename VT, int NCH>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
+__global__ __launch_bounds__(NSK_BLOCK) NSK_TAB_ATTR void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
-                                                             const unsigned long long *sweep_base, uint32_t sweep_off) {
-    constexpr int PP = NSK_TAB_PP;
+                                                             const unsigned long long *sweep_base, uint32_t sweep_off,
+                                                             int split) {
     if (sweep_base) {             // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
         const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
         const unsigned long long sw = cb[0] + sweep_off, key = cb[2];
@@ -1528,46 +1518,45 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
         k1 = (uint32_t)(key >> 32);
     }
     const int lane = (int)(threadIdx.x & 63);
-    const int npairs = tab.ntiles >> 1;                                 // virtual tiles: always even
-    const int per = (npairs + 7) >> 3;                                  // pairs per XCD
+    const int nunits = split ? (tab.ntiles >> 1) : (tab.ntiles >> 2);  // virtual tiles: a multiple of 4
+    const int per = (nunits + 7) >> 3;                                  // units per XCD
     const int xcd = (int)(blockIdx.x & 7);
     const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
     const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
-    const int pend = min(npairs, (xcd + 1) * per);
-    // the segment of the last located pair stays in scalar registers: most launches have one
+    const int uend = min(nunits, (xcd + 1) * per);
+    // the segment of the last located quad stays in scalar registers: most launches have one
     int c_lo = 0, c_hi = -1;
     SegEntry en = tab.e[0];
-    for (int P0 = xcd * per + wx; P0 < pend; P0 += PP * wpx) {
-        bool live[PP][2], on[PP];
-        int p[PP][2], pl[PP][2];
-        uint8_t tally[PP][2];
-        uint32_t id[PP][2][4 * NCH], zoff[PP], zmask[PP];
-        // stage 1: per pair the segment entry (cached), the slot bases (scalar loads) or stream words
-#pragma unroll
-        for (int q = 0; q < PP; q++) {
-            const int P = P0 + q * wpx;
-            on[q] = P < pend;                                           // wave-uniform
-            const int Pc = on[q] ? P : P0;                              // (a dead pair repeats the first one's loads)
-            if (2 * Pc < c_lo || 2 * Pc >= c_hi) {                      // wave-uniform, rare
-                const int sidx = seg_of_tile(tab, 2 * Pc);
-                en = tab.e[sidx];
-                c_lo = en.tile_start;
-                c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
-            }
-            const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu), lead = (int)(en.ntiles_lead >> 30);
-            const int t0 = 2 * Pc - en.tile_start - lead;               // segment tile of the lower half
-            const bool u16 = en.d16off != NSK_NO_D16_STREAM;
-            const bool haff = !u16 && en.aff_off != NSK_NO_D16_STREAM;  // implicit adjacency (nsk_compile.h seg_aff)
-            zoff[q] = en.zoff; zmask[q] = en.zmask_ev & 0xFFu;
-            int tt[2];
-            uint32_t ab[2][4 * NCH];
+    for (int U = xcd * per + wx; U < uend; U += wpx) {
+        const int Q = split ? (U >> 1) : U;
+        if (4 * Q < c_lo || 4 * Q >= c_hi) {                            // wave-uniform, rare
+            const int sidx = seg_of_tile(tab, 4 * Q);
+            en = tab.e[sidx];
+            c_lo = en.tile_start;
+            c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
+        }
+        const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu), lead = (int)(en.ntiles_lead >> 30);
+        const int t0q = 4 * Q - en.tile_start - lead;                   // segment tile of the quad's first tile
+        const bool haff = en.aff_off != NSK_NO_STREAM;              // implicit adjacency (nsk_compile.h seg_aff)
+        const uint32_t zoff = en.zoff, zmask = en.zmask_ev & 0xFFu;
+        // the quad's block: en.pos0 - 64 lead is a multiple of 256, so (pos >> 8, lane) names it
+        const uint32_t qb = quad_block((uint32_t)(en.pos0 + t0q * 64 + lane));
+        const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
+        u32x4 rb = {0u, 0u, 0u, 0u};
+        bool have_b = false;
+        auto half = [&](const int h, const uint32_t a0, const uint32_t a1) {
+            bool live[2];
+            int p[2], pl[2], tt[2];
+            uint8_t tally[2];
+            uint32_t id[2][4 * NCH], ab[2][4 * NCH];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                live[q][k] = on[q] && t0 + k >= 0 && t0 + k < nt;       // wave-uniform
-                tt[k] = (t0 + k >= 0 && t0 + k < nt) ? t0 + k : (t0 + k < 0 ? 0 : nt - 1);
-                p[q][k] = en.pos0 + (t0 + k) * 64 + lane;               // the GENERATOR id keeps the pair's geometry
-                pl[q][k] = en.pos0 + tt[k] * 64 + lane;                 // (a dead tile reads a real one's data)
-                ab[k][0] = NSK_NO_D16_STREAM;
+                const int t = t0q + 2 * h + k;
+                live[k] = t >= 0 && t < nt;                             // wave-uniform
+                tt[k] = live[k] ? t : (t < 0 ? 0 : nt - 1);             // (a dead tile reads a real one's data)
+                p[k] = en.pos0 + t * 64 + lane;
+                pl[k] = en.pos0 + tt[k] * 64 + lane;
+                ab[k][0] = NSK_NO_STREAM;
             }
             if (haff) {                // both tiles' slot bases: scalar loads, issued together
 #pragma unroll
@@ -1578,61 +1567,57 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 2; k++) tally[q][k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[q][k]];
+            for (int k = 0; k < 2; k++) tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[k]];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const int t = tt[k];
-                if (u16) {
-                    uint32_t w16[2 * NCH];
-                    d16_load<NCH>(g.adj16 + en.d16off + (size_t)t * (64 * NCH), lane, w16);
-                    d16_ids<NCH>(w16, pl[q][k] + en.d16base, id[q][k]);
-                } else if (ab[k][0] != NSK_NO_D16_STREAM) {             // wave-uniform: member = base + lane
+                if (ab[k][0] != NSK_NO_STREAM) {                    // wave-uniform: member = base + lane
 #pragma unroll
-                    for (int j = 0; j < 4 * NCH; j++) id[q][k][j] = ab[k][j] + (uint32_t)lane;
+                    for (int j = 0; j < 4 * NCH; j++) id[k][j] = ab[k][j] + (uint32_t)lane;
                 } else {
-                    const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+                    const uint4 *sp = g.adj + en.adj_off + (size_t)tt[k] * (64 * NCH) + lane;
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
                         const uint4 w = sp[c * 64];
-                        id[q][k][4 * c] = w.x; id[q][k][4 * c + 1] = w.y; id[q][k][4 * c + 2] = w.z; id[q][k][4 * c + 3] = w.w;
+                        id[k][4 * c] = w.x; id[k][4 * c + 1] = w.y; id[k][4 * c + 2] = w.z; id[k][4 * c + 3] = w.w;
                     }
                 }
             }
-        }
-        // stage 2: member values -> neighbourhood bits -> table entries
-        uint2 e[PP][2];
-#pragma unroll
-        for (int q = 0; q < PP; q++) {
-            uint32_t idx[2];
+            // member values -> neighbourhood bits -> table entries (the table kernels run only while every
+            // value on the device lies in its domain -- values_regular -- and their members are binary: a
+            // value IS its bit)
+            uint2 e[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                idx[k] = 0;
+                uint32_t idx = 0;
 #pragma unroll
-                // (the table kernels run only while every value on the device lies in its domain --
-                // values_regular -- and their members are binary: a value IS its bit)
-                for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[q][k][j]] << j;
-                idx[k] &= zmask[q];
+                for (int j = 0; j < 4 * NCH; j++) idx |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
+                e[k] = *(const uint2 *)(g.ztab + zoff + (idx & zmask));
+            }
+            // draws: the high 27 bits decide unless they tie with the threshold's
+            const uint32_t hi0 = a0 >> 5, hi1 = a1 >> 5;
+            int nv[2] = {hi0 > e[0].x ? 1 : 0, hi1 > e[1].x ? 1 : 0};
+            if (__builtin_expect(__any((hi0 == e[0].x) | (hi1 == e[1].x)), 0)) {
+                if (!have_b) { rb = philox4x32(k0, k1, qb, 3u, s0, s1); have_b = true; }
+                const uint32_t b0 = h ? rb.z : rb.x, b1 = h ? rb.w : rb.y;
+                if (hi0 == e[0].x) nv[0] = (b0 >> 6) > e[0].y ? 1 : 0;
+                if (hi1 == e[1].x) nv[1] = (b1 >> 6) > e[1].y ? 1 : 0;
             }
 #pragma unroll
-            for (int k = 0; k < 2; k++) e[q][k] = *(const uint2 *)(g.ztab + zoff[q] + idx[k]);
-        }
-        // stage 3: draws and stores
-#pragma unroll
-        for (int q = 0; q < PP; q++) {
-            if (!on[q]) continue;
-            // p[0] is a multiple-of-128 block's lower half, p[1] = p[0] + 64 its upper half: one block
-            const u32x4 rr = philox4x32(k0, k1, inf_block((uint32_t)p[q][0]), 0u, s0, s1);
-#pragma unroll
             for (int k = 0; k < 2; k++) {
-                const unsigned long long K = ((unsigned long long)e[q][k].y << 32) | e[q][k].x;
-                const int nv = (k == 0 ? k53(rr.x, rr.y) : k53(rr.z, rr.w)) > K ? 1 : 0;
-                VT *dst = live[q][k] ? g.val + p[q][k] : (VT *)g.sink + lane;     // (no branch: see seg_of_tile's note)
-                *dst = (VT)nv;
+                VT *dst = live[k] ? g.val + p[k] : (VT *)g.sink + lane;             // (no branch: see seg_of_tile's note)
+                *dst = (VT)nv[k];
                 if (!burnin) {
-                    uint8_t *td = live[q][k] ? g.cnt_pos + p[q][k] : g.sink + 256 + lane;
-                    *td = (uint8_t)(tally[q][k] + nv);
+                    uint8_t *td = live[k] ? g.cnt_pos + p[k] : g.sink + 256 + lane;
+                    *td = (uint8_t)(tally[k] + nv[k]);
                 }
             }
+        };
+        if (split) {
+            const int h = U & 1;                                        // wave-uniform
+            half(h, h ? ra.z : ra.x, h ? ra.w : ra.y);
+        } else {
+            half(0, ra.x, ra.y);
+            half(1, ra.z, ra.w);
         }
     }
 }
@@ -1675,7 +1660,10 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTabl
         if (KIND) pair_step<KIND>(thi, tlo, x[j], p0, p1);
         else slot_step(st, pp[j], thi, tlo, x[j], p0, p1);
     }
-    const uint2 rr = inf_words(k0, k1, (uint32_t)p, s0, s1);
+    // a segment with a draw table keeps its positions' quad scheme when the exp path runs instead of the
+    // table kernel (a value outside its domain has been uploaded): wave-uniform
+    const uint2 rr = ((en.zmask_ev >> 16) & 1u) ? inf_words_quad(k0, k1, (uint32_t)p, s0, s1)
+                                                : inf_words(k0, k1, (uint32_t)p, s0, s1);
     const double z0 = nsk_exp(p0);
     const double z1 = z0 + nsk_exp(p1);
     const double z = u53(rr.x, rr.y) * z1;

@@ -701,7 +701,8 @@ __device__ __forceinline__ double apply_update(double x, long long G, uint32_t k
 #define NSK_APPLY_STAGE_WORDS 2048
 #define NSK_APPLY_STAGE_PROGS 64
 struct ApplyArgs {
-    double *w;
+    double *w;                  // weights after the update (every weight is written)
+    const double *w_in;         // weights before it (another array under the one-class lag, nsk_set_learn_lag)
     long long *part_G;
     uint32_t *part_K, *part_T;
     int nweight;
@@ -747,12 +748,11 @@ __device__ __forceinline__ void apply_bins_block(const ApplyArgs &aa) {
         if (K) { aa.part_G[at] = 0; aa.part_K[at] = 0; aa.part_T[at] = 0; }
         G = wave_sum_i64(G); K = wave_sum_i64(K); T = wave_sum_i64(T);
         if (lane == 0) {
-            double x = aa.w[i];
-            if (K > 0) {
+            double x = aa.w_in[i];
+            if (K > 0)
                 x = apply_update(x, G, (uint32_t)K, (uint32_t)T, aa.step, aa.regularization, aa.reg_param,
                                  aa.truncation, aa.cap, aa.clipped, aa.grad_inv);
-                aa.w[i] = x;
-            }
+            aa.w[i] = x;
             sw[i] = x;
         }
     }
@@ -814,16 +814,30 @@ struct LearnTripInfo {                   // wave-uniform
     uint32_t prog, zoff, zmask;
 };
 
+// SMALLW launches carry NSK_SERVICE_BLOCKS extra blocks in front (one round of XCDs, so the tile blocks keep
+// their XCDs): block 0 applies the weight update of the PREVIOUS colour class (`prev`; nweight = 0: none)
+// while the other blocks sample this class -- under the one-class lag (nsk_set_learn_lag) nobody in this
+// launch reads what it writes (the other weight set, that class's bins), and the next launch starts behind
+// the kernel boundary.  The update is a 6 us single-block latency chain (bins -> update -> table
+// thresholds) that three in-order fusions could not hide; here it is off the critical
+// path by definition.
+#define NSK_SERVICE_BLOCKS 8
 template <typename VT, bool SMALLW, int NCH, int TPW>
-__global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, SegTable tab, LearnParams lp) {
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, SegTable tab, LearnParams lp, ApplyArgs prev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (SMALLW && blockIdx.x < NSK_SERVICE_BLOCKS) {                   // (block-uniform)
+        if (blockIdx.x == 0 && prev.nweight > 0) apply_bins_block(prev);
+        return;
+    }
+    const int bid = (int)blockIdx.x - (SMALLW ? NSK_SERVICE_BLOCKS : 0);
+    const int gdim = (int)gridDim.x - (SMALLW ? NSK_SERVICE_BLOCKS : 0);
     const GradSink sk = open_sink<SMALLW>(g, smem);
     const int lane = (int)(threadIdx.x & 63);
     const int ntrips = tab.ntiles / TPW;
     const int per = (ntrips + 7) >> 3;                                  // trips per XCD
-    const int xcd = (int)(blockIdx.x & 7);
-    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
-    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD (grid: multiple of 8)
+    const int xcd = bid & 7;
+    const int wx = __builtin_amdgcn_readfirstlane((bid >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    const int wpx = (gdim >> 3) * (NSK_BLOCK / 64);                     // waves per XCD (grid: multiple of 8)
     const int pend = min(ntrips, (xcd + 1) * per);
     // The wave keeps its gradient counts in scalar registers while the trips it walks share a slot
     // program: acc[j] = (satisfied under the proposal) - (satisfied under the evidence) of slot j's
@@ -863,7 +877,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
     };
     // the segment of the last located trip stays in scalar registers: most launches have one
     int c_lo = 0, c_hi = 0, c_pos = 0, c_nt = 1;
-    uint32_t c_adj = 0u, c_prog = 0u, c_zoff = 0u, c_zmask_ev = 0u, c_aff = NSK_NO_D16_STREAM;
+    uint32_t c_adj = 0u, c_prog = 0u, c_zoff = 0u, c_zmask_ev = 0u, c_aff = NSK_NO_STREAM;
     auto issue = [&](int P, LearnTrip<NCH, TPW> &r, LearnTripInfo &ti) {
         const int T0 = P * TPW;
         if (T0 < c_lo || T0 >= c_hi) {                                  // wave-uniform, rare
@@ -882,8 +896,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             const int t = min(ti.t0 + k, c_nt - 1);                    // a dead tile re-reads the last one
-            ab[k][0] = NSK_NO_D16_STREAM;
-            if (c_aff != NSK_NO_D16_STREAM) {
+            ab[k][0] = NSK_NO_STREAM;
+            if (c_aff != NSK_NO_STREAM) {
                 const NSK_SCALAR uint32_t *ap = (const NSK_SCALAR uint32_t *)(g.seg_aff + c_aff + (size_t)t * NCH);
 #pragma unroll
                 for (int j = 0; j < 4 * NCH; j++) ab[k][j] = ap[j];
@@ -897,7 +911,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             const int t = min(ti.t0 + k, c_nt - 1);
-            if (ab[k][0] != NSK_NO_D16_STREAM) {                        // wave-uniform
+            if (ab[k][0] != NSK_NO_STREAM) {                        // wave-uniform
 #pragma unroll
                 for (int j = 0; j < 4 * NCH; j++) r.id[k][j] = ab[k][j] + (uint32_t)lane;
             } else {
@@ -967,8 +981,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             const u32x4 rr = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
 #endif
             int evidence = r.init[k];                                             // learning.py:61-62
-            if (ti.ev != 1) evidence = k53(rr.z, rr.w) > (((unsigned long long)ee[k].y << 32) | ee[k].x) ? 1 : 0;   // 54-58
-            const int proposal = k53(rr.x, rr.y) > (((unsigned long long)ef[k].y << 32) | ef[k].x) ? 1 : 0;         // 66-70
+            if (ti.ev != 1) evidence = k53(rr.z, rr.w) > ztab_K(ee[k]) ? 1 : 0;   // 54-58
+            const int proposal = k53(rr.x, rr.y) > ztab_K(ef[k]) ? 1 : 0;         // 66-70
             if (valid) {
 #ifndef NSK_ABL_LNOEVST
                 g.val_evid[p] = (VT)evidence;
@@ -1269,7 +1283,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbeg
 }
 
 
-static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, long long *G, uint32_t *K,
+static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, const double *w_in, long long *G, uint32_t *K,
                                                              uint32_t *T, int nweight, double step,
                                                              int regularization, double reg_param,
                                                              double truncation, int packed, double cap,
@@ -1301,8 +1315,11 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, l
             t += tx;
         }
     }
-    if (k == 0) return;                 // untouched in this class
-    w[i] = apply_update(w[i], gsum, (uint32_t)k, (uint32_t)t, step, regularization, reg_param, truncation, cap, clipped, grad_inv);
+    if (k == 0) {                       // untouched in this class
+        if (w != w_in) w[i] = w_in[i];
+        return;
+    }
+    w[i] = apply_update(w_in[i], gsum, (uint32_t)k, (uint32_t)t, step, regularization, reg_param, truncation, cap, clipped, grad_inv);
 }
 
 }  // namespace nsk

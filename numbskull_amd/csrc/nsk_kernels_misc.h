@@ -39,6 +39,18 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_stream_copy_nt(const uint4 *__res
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// ---- state transfer: caller's order (variable id) <-> internal order (layout position) -----------------
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_state_scatter(VT *val, const int32_t *iid, const VT *by_vid, long long nvar) {
+    for (long long v = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; v < nvar; v += (long long)gridDim.x * NSK_BLOCK)
+        val[iid[v]] = by_vid[v];
+}
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_state_gather(const VT *val, const int32_t *iid, VT *by_vid, long long nvar) {
+    for (long long v = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; v < nvar; v += (long long)gridDim.x * NSK_BLOCK)
+        by_vid[v] = val[iid[v]];
+}
+
 // ---- boundary exchange ---------------------------------------------------------------------------
 template <typename VT>
 __global__ __launch_bounds__(NSK_BLOCK) void k_exchange_pack(const VT *val, const int32_t *send_vids,

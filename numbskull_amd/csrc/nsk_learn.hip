@@ -15,10 +15,19 @@ using namespace nsk;
                                  // per 10M-grid class before the kernel was pipelined)
 #endif
 
+// the fast-path refresh after a weight update of the large-table path, for one weight set on one stream
+static void refresh_after_update(nsk_graph *g, int set, hipStream_t st) {
+    const int n = (int)g->c.tile_hdr.size();
+    if (n > 0 && g->c.nfast > 0 && g->c.nweight > 0) {
+        k_refresh_prog_weights<<<dim3((n + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, st>>>(
+            g->tile_hdr, set ? g->w1 : g->w, set ? g->prog_w1 : g->prog_w, n);
+        nsk_refresh_ztab(g, set, st);
+    }
+}
+
 template <typename VT, bool SMALLW>
 static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
                            double reg_param, int64_t truncation, int learn_non_evidence) {
-    DevGraph<VT> d = view<VT>(g);
     const size_t nphase = g->c.phase_start.size() - 1;
     const int nw = (int)g->c.nweight;
     const size_t shmem = SMALLW ? (size_t)nw * 16 : 0;
@@ -30,12 +39,64 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
     lp.kstat = 0;
     g->adj_wt_skip = true;          // the learning kernels gather weights themselves
     nsk_refresh_prog_weights(g);
+    // One-class lag (nsk_set_learn_lag): class c of this call samples from weight set c & 1 -- the weights
+    // as of the end of class c - 2 -- and adds into accumulator set c & 1; its update U(c) reads the weights
+    // of set (c + 1) & 1 (end of class c - 1) and writes set c & 1, and is enqueued BEHIND class c + 1,
+    // which does not read it: fused into that class's table launch when there is one (block 0 of
+    // k_learn_seg_tab, beside the sampling), else as a launch of its own after the class.  Both sets start
+    // from the call's weights.  (A second stream with events around every class cost more than the update:
+    // 34 against 28.5 us per 10M-grid class.)
+    const bool lag = g->learn_lag && nw > 0;
+    DevGraph<VT> dv[2];
+    dv[0] = view<VT>(g);
+    dv[1] = dv[0];
+    if (lag) {
+        int rc = nsk_ensure_lag_sets(g);
+        if (rc) return rc;
+        dv[1].w = g->w1; dv[1].prog_w = g->prog_w1; dv[1].ztab = g->ztab1;
+        dv[1].G = g->G1; dv[1].K = g->K1; dv[1].T = g->T1;
+        dv[1].part_G = g->part_G1; dv[1].part_K = g->part_K1; dv[1].part_T = g->part_T1;
+        HIPCHECK(hipMemcpyAsync(g->w1, g->w, (size_t)nw * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+        if (!g->c.tile_hdr.empty())
+            HIPCHECK(hipMemcpyAsync(g->prog_w1, g->prog_w, 2 * g->c.tile_hdr.size() * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+        if (g->c.nztab)
+            HIPCHECK(hipMemcpyAsync(g->ztab1, g->ztab, (size_t)g->c.nztab * sizeof(uint4), hipMemcpyDeviceToDevice, g->stream));
+    }
+    int64_t cls = 0;                // classes launched in this call
+    struct Pending {                // the update of the previous class, not yet enqueued
+        bool valid = false;
+        int set = 0;
+        bool tabs_here = false, kstat = false;
+        size_t ph = 0;
+        double step = 0.0;
+        ApplyArgs aa;
+    } pend;
+    auto launch_update = [&](const Pending &u) {      // as launches of their own on the main stream
+        const DevGraph<VT> &du = dv[u.set];
+        if (SMALLW) {
+#ifndef NSK_ABL_NOAPPLY
+            k_apply_bins<<<dim3(1), dim3(NSK_BLOCK), 0, g->stream>>>(u.aa);
+#endif
+            if (g->c.nfast > 0 && !u.tabs_here) nsk_refresh_ztab(g, u.set, g->stream);   // big tables: own launch
+        } else {
+            k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                du.w, u.aa.w_in, du.G, du.K, du.T, nw, u.step, regularization, reg_param, (double)truncation,
+                (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies, du.grad_inv,
+                u.kstat ? du.ep_kstat + (size_t)(2 * u.ph) * (size_t)nw : nullptr,
+                (u.kstat && learn_non_evidence) ? du.ep_kstat + (size_t)(2 * u.ph + 1) * (size_t)nw : nullptr);
+            refresh_after_update(g, u.set, g->stream);
+        }
+    };
+    ApplyArgs no_update;
+    memset(&no_update, 0, sizeof(no_update));
     for (int64_t s = 0; s < nsweeps; s++) {
         lp.s0 = (uint32_t)g->sweep; lp.s1 = nsk_sweep_hi(g);
         for (size_t ph = 0; ph < nphase; ph++) {
             const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
             const int e = (int)g->c.phase_end[ph];
             if (e <= fb) continue;
+            const int set = lag ? (int)(cls & 1) : 0;
+            const DevGraph<VT> &d = dv[set];
             lp.hub0 = (int)g->c.phase_hub_base[ph];
             const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
@@ -45,12 +106,13 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const bool tabs_here = g->c.nfast > 0 && g->c.nztab <= 2048;
             ApplyArgs aa;
             memset(&aa, 0, sizeof(aa));
-            aa.w = g->w; aa.part_G = g->part_G; aa.part_K = g->part_K; aa.part_T = g->part_T;
+            aa.w = d.w; aa.w_in = lag ? dv[set ^ 1].w : d.w;
+            aa.part_G = d.part_G; aa.part_K = d.part_K; aa.part_T = d.part_T;
             aa.nweight = nw; aa.step = step; aa.regularization = regularization; aa.reg_param = reg_param;
-            aa.truncation = (double)truncation; aa.prog = g->tile_hdr; aa.prog_w = g->prog_w;
+            aa.truncation = (double)truncation; aa.prog = g->tile_hdr; aa.prog_w = const_cast<double *>(d.prog_w);
             aa.nprog = g->c.nfast > 0 ? (int)g->c.tile_hdr.size() : 0; aa.zp = g->zprogs;
             aa.nzp = tabs_here ? (int)g->c.zprogs.size() : 0; aa.nztab = tabs_here ? (int)g->c.nztab : 0;
-            aa.ztab = g->ztab; aa.cap = g->learn_cap; aa.clipped = g->clip_count; aa.grad_inv = d.grad_inv;
+            aa.ztab = const_cast<uint4 *>(d.ztab); aa.cap = g->learn_cap; aa.clipped = g->clip_count; aa.grad_inv = d.grad_inv;
             if (e > he) {               // variables outside the fast path: generic kernel, range mode
                 const int nitems = (e - he + 63) / 64;
                 const int grid = std::min(NSK_LEARN_GEN_BLOCKS, (nitems + 3) / 4);
@@ -88,9 +150,11 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             lp.kstat = kstat_here ? 1 : 0;
             if (ep) {                   // entry-parallel groups: hubs, the general tiles and the rest tiles
                 const int ngroups = (int)(g->c.phase_ep_base[ph + 1] - g->c.phase_ep_base[ph]);
-                // resident grid: the static LDS (26.5 KB) + the SMALLW tables bound the workgroups per CU
+                // grid: 7 workgroups per CU (3 or 4 are resident -- 153 / 111 vector registers --, the others
+                // start as those end: dynamic dealing of uneven groups).  Per class on the 5M LR graph
+                // (NSK_EP_PER_CU): 3 workgroups per CU 142.4 us, 4 149.2, 5 139.5, 6 135.4, 7 134.2
                 const char *pcu_env = nsk::diag_env("NSK_EP_PER_CU");            // (diagnostic: workgroups per CU)
-                const int per_cu = std::max(1, std::min(pcu_env ? atoi(pcu_env) : 8, (int)((size_t)(160 << 10) / (27136 + shmem + 256))));
+                const int per_cu = pcu_env ? std::max(1, std::min(32, atoi(pcu_env))) : 7;
                 const int gblocks = 8 * ((std::min(256 * per_cu, ngroups) + 7) / 8);
                 const int nbh = (int)(g->c.phase_bighub_base[ph + 1] - g->c.phase_bighub_base[ph]);   // a block per long-list hub
                 const int hbl_ep = nbh + hbl;
@@ -136,16 +200,20 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                     en.pos0 = sl.pos0[i]; en.adj_off = sl.adj_off[i]; en.prog = sl.prog[i];
                     en.zoff = sl.zoff[i];
                     en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
-                    en.d16off = sl.d16off[i]; en.d16base = sl.d16base[i];
-                    en.aff_off = use_tab ? sl.aff[i] : NSK_NO_D16_STREAM;     // implicit adjacency (table kernel)
+                    en.aff_off = use_tab ? sl.aff[i] : NSK_NO_STREAM;         // implicit adjacency (table kernel)
                 }
                 tab.ntiles = use_tab ? vt : sl.tile_start[sl.n];
                 const int grid = nsk_learn_seg_grid(sl, nw, SMALLW, g->values_regular);
 #define NSK_LSEG(KIND, NCH) k_learn_seg<VT, SMALLW, KIND, NCH><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
                 if (use_tab) {
-#define NSK_LTAB(NCH) k_learn_seg_tab<VT, SMALLW, NCH, NSK_LEARN_TPW><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp)
+                    // the previous class's update rides in this launch (block 0 of the service blocks in front)
+                    const bool fuse = SMALLW && pend.valid && pend.tabs_here;
+                    const ApplyArgs &prev = fuse ? pend.aa : no_update;
+                    const int gridx = grid + (SMALLW ? NSK_SERVICE_BLOCKS : 0);
+#define NSK_LTAB(NCH) k_learn_seg_tab<VT, SMALLW, NCH, NSK_LEARN_TPW><<<dim3(gridx), dim3(NSK_BLOCK), shmem, g->stream>>>(d, tab, lp, prev)
                     if (sl.nch == 1) NSK_LTAB(1); else NSK_LTAB(2);
 #undef NSK_LTAB
+                    if (fuse) pend.valid = false;
                 }
                 else if (sl.tab) { if (sl.nch == 1) NSK_LSEG(0, 1); else NSK_LSEG(0, 2); }   // tables unusable: the
                                                                        // generic slot algebra serves every function
@@ -171,24 +239,20 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             }
             cs.join();
             if (nw > 0) {
-                if (SMALLW) {
-#ifndef NSK_ABL_NOAPPLY
-                    k_apply_bins<<<dim3(1), dim3(NSK_BLOCK), 0, g->stream>>>(aa);
-#endif
-                    if (g->c.nfast > 0 && !tabs_here) nsk_refresh_ztab(g);       // big tables: own launch
-                } else {
-                    k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                        g->w, g->G, g->K, g->T, nw, step, regularization, reg_param, (double)truncation,
-                        (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies, d.grad_inv,
-                        kstat_here ? d.ep_kstat + (size_t)(2 * ph) * (size_t)nw : nullptr,
-                        (kstat_here && learn_non_evidence) ? d.ep_kstat + (size_t)(2 * ph + 1) * (size_t)nw : nullptr);
-                    nsk_refresh_prog_weights(g, true);
-                }
+                if (pend.valid) { launch_update(pend); pend.valid = false; }     // the previous class's, not fused above
+                Pending u;
+                u.valid = true; u.set = set; u.tabs_here = tabs_here; u.kstat = kstat_here; u.ph = ph; u.step = step; u.aa = aa;
+                if (lag) pend = u;              // behind the next class
+                else launch_update(u);
             }
+            cls++;
         }
         g->sweep++;
         step *= decay;                                   // factorgraph.py:206
     }
+    if (pend.valid) { launch_update(pend); pend.valid = false; }
+    if (lag && cls > 0 && ((cls - 1) & 1))          // the call leaves the weights, every update applied, in set 0
+        HIPCHECK(hipMemcpyAsync(g->w, g->w1, (size_t)nw * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
     g->adj_wt_skip = false;
     g->weights_dirty = true;        // the next inference call rebuilds prog_w and the weight rows
     HIPCHECK(hipGetLastError());

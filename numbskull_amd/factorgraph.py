@@ -31,12 +31,14 @@ class FactorGraph(object):
     ``device`` (HIP ordinal), ``seed`` (Philox key / MT19937 seed), ``scan`` ("chromatic" or
     "sequential"), ``head_by_vid`` (intended head lookup for IMPLY_MLN-type factors instead of
     the literal inference.py:243 indexing), ``own_range`` ((begin, end) variable ids sampled by
-    this handle when the graph is range-partitioned over several GPUs).
+    this handle when the graph is range-partitioned over several GPUs), ``learn_cap`` / ``learn_lag``
+    (chromatic learning: cap on visits x stepsize per weight and colour class; the weight update of a
+    class overlapped with the next class's sampling, nsk_set_learn_lag).
     """
 
     def __init__(self, weight, variable, factor, fmap, vmap, factor_index, var_copies,
                  weight_copies, fid, workers, *, device=0, seed=0, scan="chromatic",
-                 head_by_vid=False, own_range=None, learn_cap=0.5, global_ids=None):
+                 head_by_vid=False, own_range=None, learn_cap=0.5, global_ids=None, learn_lag=True):
         self.weight, self.variable, self.factor = weight, variable, factor
         self.fmap, self.vmap, self.factor_index = fmap, vmap, factor_index
 
@@ -72,6 +74,7 @@ class FactorGraph(object):
         self.seed = int(seed)
         self.scan = scan
         self.learn_cap = float(learn_cap)
+        self.learn_lag = bool(learn_lag)
         self.head_by_vid = bool(head_by_vid)
         self.own_range = own_range
         # shard-local graph (graphgen.extract_shard): global id of every local variable; the shard's
@@ -145,6 +148,7 @@ class FactorGraph(object):
         scan = {"chromatic": _lib.SCAN_CHROMATIC, "sequential": _lib.SCAN_SEQUENTIAL}[self.scan]
         _lib.check(L.nsk_set_scan(h, scan))
         _lib.check(L.nsk_set_learn_cap(h, self.learn_cap))
+        _lib.check(L.nsk_set_learn_lag(h, int(self.learn_lag)))
         return h
 
     def close(self):
@@ -182,6 +186,13 @@ class FactorGraph(object):
         nid = C.c_int64()
         _lib.check(_lib.lib().nsk_graph_get_layout(self._engine(), _lib.ptr(iid), C.byref(nid)))
         return iid.astype(np.int64)
+
+    def generators(self):
+        """The chromatic scan's generator of every variable (nsk_graph_get_generators): position in the
+        compiled layout | quad-scheme flag << 40; -1 for variables this handle does not sample."""
+        out = np.zeros(self.variable.shape[0], np.int64)
+        _lib.check(_lib.lib().nsk_graph_get_generators(self._engine(), _lib.ptr(out)))
+        return out
 
     def colors(self):
         out = np.zeros(self.variable.shape[0], np.int32)

@@ -89,6 +89,9 @@ engine_arguments = [
 engine_flags = [
     _flag(('--head_by_vid',), 'head_by_vid', False,
           'IMPLY_MLN-type factors read their head through fmap[l].vid'),
+    _flag(('--no_learn_lag',), 'no_learn_lag', False,
+          'chromatic learning: every colour class waits for the previous class\'s weight update '
+          '(default: the update overlaps the next class, which sees weights one class older)'),
 ]
 
 
@@ -111,6 +114,7 @@ class NumbSkull(object):
         fg = FactorGraph(weight, variable, factor, fmap, vmap, factor_index, var_copies,
                          weight_copies, len(self.factorGraphs), self.nthreads,
                          device=self.device, seed=self.seed, scan=self.scan, learn_cap=self.learn_cap,
+                         learn_lag=not self.no_learn_lag,
                          head_by_vid=self.head_by_vid, **extra)
         self.factorGraphs.append(fg)
         return fg

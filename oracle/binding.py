@@ -186,14 +186,33 @@ class Graph:
             int(burnin), C.c_uint64(seed), C.c_uint64(sweep))
 
     def learn_dev(self, order, phase_start, var_value, var_value_evid, weight_value, step,
-                  regularization, reg_param, truncation, learn_non_evidence, seed, sweep, cap=0.5):
+                  regularization, reg_param, truncation, learn_non_evidence, seed, sweep, cap=0.5, lag=None):
+        """One learning sweep in device mode.  ``lag``: the device's one-class lag (nsk_set_learn_lag,
+        its default) -- a float64 array the caller sets to ``weight_value.copy()`` at the start of every
+        device call (a call drains the pipeline) and hands to every sweep of that call; None = every
+        class sees the previous class's update."""
+        assert lag is None or (lag.dtype == np.float64 and lag.flags.c_contiguous and len(lag) == len(weight_value))
         order = np.ascontiguousarray(order, np.int64)
         phase_start = np.ascontiguousarray(phase_start, np.int64)
         return lib().orc_learn_sweep_dev(
             C.byref(self.g), _p(order), _p(phase_start), C.c_int64(len(phase_start) - 1),
             C.c_double(step), int(regularization), C.c_double(reg_param), C.c_int64(truncation),
             _p(var_value), _p(var_value_evid), _p(weight_value), int(learn_non_evidence),
-            C.c_uint64(seed), C.c_uint64(sweep), C.c_double(cap))
+            C.c_uint64(seed), C.c_uint64(sweep), C.c_double(cap), _p(lag))
+
+    def learn_call(self, order, phase_start, var_value, var_value_evid, weight_value, nsweeps, step, decay,
+                   regularization, reg_param, truncation, learn_non_evidence, seed, sweep0, cap=0.5, lag=True):
+        """What ONE nsk_learn_sweeps call does: ``nsweeps`` epochs from sweep index ``sweep0``, step *= decay
+        after each (factorgraph.py:206), the one-class lag pipeline (``lag``; the device's default) started
+        from the call's weights and drained into them at its end."""
+        lagw = np.ascontiguousarray(weight_value, np.float64).copy() if lag else None
+        for s in range(nsweeps):
+            rc = self.learn_dev(order, phase_start, var_value, var_value_evid, weight_value, step, regularization,
+                                reg_param, truncation, learn_non_evidence, seed, sweep0 + s, cap, lagw)
+            if rc:
+                return rc
+            step *= decay
+        return 0
 
     def check_coloring(self, color):
         """(-1, -1) when no sampled variable reads a variable of its own colour, else such a pair."""

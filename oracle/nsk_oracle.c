@@ -611,18 +611,34 @@ int orc_gibbs_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             if (var->isEvidence == 4) continue;
             if (!(var->isEvidence == 0 || sample_evidence)) continue;
             /* device-mode generator of the inference sweep: the variable's
-             * generator id q is its position in the library's layout (g->rng_id; identity when
-             * absent); ids q and q + 64 with equal q >> 7 share ONE Philox block -- counter
-             * ((q >> 7) * 64 + (q & 63), 0, sweep), words 0-1 for the lower id, 2-3 for the upper */
-            uint32_t r[4];
-            const uint64_t q = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
-            orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32),
-                           (uint32_t)(((q >> 7) << 6) | (q & 63u)), 0u,
-                           (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
-            const int half = (int)((q >> 6) & 1u);
+             * generator id q is its position in the library's layout (bits 0-39 of g->rng_id; identity
+             * when absent).  Pair scheme (bit 40 clear): ids q and q + 64 with equal q >> 7 share ONE
+             * Philox block -- counter ((q >> 7) * 64 + (q & 63), 0, sweep), words 0-1 for the lower id,
+             * 2-3 for the upper.  Quad scheme (bit 40 set: positions inside segments with draw tables):
+             * ids q, q + 64, q + 128, q + 192 with equal q >> 8 share TWO blocks -- counter
+             * ((q >> 8) * 64 + (q & 63), stream, sweep), stream 2 word (q >> 6) & 3 = the high word,
+             * stream 3 the same word = the low word */
+            uint32_t r[4], a, b;
+            const uint64_t gid = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
+            const uint64_t q = gid & 0xFFFFFFFFFFull;
+            if ((gid >> 40) & 1u) {
+                const uint32_t c0 = (uint32_t)(((q >> 8) << 6) | (q & 63u)), j = (uint32_t)((q >> 6) & 3u);
+                orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c0, 2u,
+                               (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
+                a = r[j];
+                orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c0, 3u,
+                               (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
+                b = r[j];
+            } else {
+                orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32),
+                               (uint32_t)(((q >> 7) << 6) | (q & 63u)), 0u,
+                               (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
+                const int half = (int)((q >> 6) & 1u);
+                a = half ? r[2] : r[0];
+                b = half ? r[3] : r[1];
+            }
             int64_t nv;
-            rc = draw_sample(g, v, Z, var_value, weight_value,
-                             half ? orc_u53(r[2], r[3]) : orc_u53(r[0], r[1]), 1, &nv);
+            rc = draw_sample(g, v, Z, var_value, weight_value, orc_u53(a, b), 1, &nv);
             if (rc) break;
             var_value[v] = nv;
             if (!burnin) {
@@ -668,13 +684,19 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
                         int64_t nphase, double step, int regularization, double reg_param,
                         int64_t truncation, int64_t *var_value, int64_t *var_value_evid,
                         double *weight_value, int learn_non_evidence, uint64_t seed,
-                        uint64_t sweep, double cap) {
+                        uint64_t sweep, double cap, double *weight_lag) {
+    /* weight_lag != NULL: the device's one-class lag (nsk_set_learn_lag) -- a class samples with the
+     * weights as of the end of the class before the previous one (weight_lag), its update moves
+     * weight_value on from the previous class's result; the caller sets weight_lag = weight_value at the
+     * start of every device call and carries it from sweep to sweep inside one */
+    const double *weight_samp = weight_lag ? weight_lag : weight_value;
     double *Z = (double *)malloc(sizeof(double) * (size_t)max_card(g));
     int64_t *G = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
     int64_t *K = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
     int64_t *T = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
     int rc = ORC_OK;
     for (int64_t p = 0; p < nphase && !rc; p++) {
+        if (phase_start[p] == phase_start[p + 1]) continue;     /* (an empty class is no class: no update, no lag step) */
         for (int64_t i = phase_start[p]; i < phase_start[p + 1] && !rc; i++) {
             int64_t v = order[i];
             const orc_variable *var = &g->variable[v];
@@ -682,19 +704,19 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             /* learning sweep: one block per variable, counter (q, stream, sweep); stream 0 words 0-1
              * free chain, 2-3 evidence chain; stream 1 words 0-1 the truncation coin */
             uint32_t r[4];
-            const uint64_t q = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
+            const uint64_t q = (g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v) & 0xFFFFFFFFFFull;
             orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)q, 0u,
                            (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
             int64_t evidence, proposal;
             if (var->isEvidence != 1) {
-                rc = draw_sample(g, v, Z, var_value_evid, weight_value, orc_u53(r[2], r[3]), 1,
+                rc = draw_sample(g, v, Z, var_value_evid, weight_samp, orc_u53(r[2], r[3]), 1,
                                  &evidence);
                 if (rc) break;
             } else {
                 evidence = var->initialValue;
             }
             var_value_evid[v] = evidence;
-            rc = draw_sample(g, v, Z, var_value, weight_value, orc_u53(r[0], r[1]), 1, &proposal);
+            rc = draw_sample(g, v, Z, var_value, weight_samp, orc_u53(r[0], r[1]), 1, &proposal);
             if (rc) break;
             var_value[v] = proposal;
             if (!learn_non_evidence && var->isEvidence != 1) continue;
@@ -723,9 +745,13 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
         if (rc) break;
         /* end of phase: apply the batch to every touched weight */
         for (int64_t w = 0; w < g->nweight; w++) {
-            if (K[w] == 0) continue;
+            if (K[w] == 0) {
+                if (weight_lag) weight_lag[w] = weight_value[w];
+                continue;
+            }
             double Gf = (double)G[w] * ldexp(1.0, g->grad_shift - 32);
             double x = weight_value[w];
+            if (weight_lag) weight_lag[w] = x;
             /* device-mode step cap: K visits at `step` move the weight by K * step * mean gradient;
              * beyond `cap` the class uses cap / K (DESIGN.md "device-mode learning") */
             double st = step;

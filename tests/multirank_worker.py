@@ -75,7 +75,7 @@ def main():
         starts = [st[2].copy() for _, _, st in oracles]
         for og, (order, ps), (vv, ve, wv, cnt) in oracles:
             if learn:
-                assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 31, s) == 0
+                assert og.learn_call(order, ps, vv, ve, wv, 1, step, 1.0, 2, 0.01, 1, False, 31, s) == 0
             else:
                 assert og.gibbs_dev(order, ps, vv, wv, cnt, 31, s, True) == 0
         step *= 0.9

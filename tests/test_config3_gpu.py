@@ -65,10 +65,7 @@ def test_config3_learning_bit_exact_vs_oracle():
     og = oracle_of(fg)
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, _ = og.initial_state()
-    step = 1e-7
-    for s in range(2):
-        og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 11, s)
-        step *= 0.95
+    assert og.learn_call(order, ps, vv, ve, wv, 2, 1e-7, 0.95, 2, 0.01, 1, False, 11, 0) == 0
     assert np.array_equal(fg.weight_value[0], wv), (fg.weight_value[0], wv)
     assert np.array_equal(fg.var_value[0], vv)
     assert np.array_equal(fg.var_value_evid[0], ve)

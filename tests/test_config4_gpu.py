@@ -73,7 +73,7 @@ def test_config4_eight_shards_match_emulation(learn):
         timing["sweep_us"].append(t_sweep)
         for og, (order, ps_), (vv, ve, wv, cnt) in oracles:
             if learn:
-                assert og.learn_dev(order, ps_, vv, ve, wv, step, 2, 0.01, 1, False, seed, s) == 0
+                assert og.learn_call(order, ps_, vv, ve, wv, 1, step, 1.0, 2, 0.01, 1, False, seed, s) == 0
             else:
                 assert og.gibbs_dev(order, ps_, vv, wv, cnt, seed, s, True) == 0
         step *= 0.95

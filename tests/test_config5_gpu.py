@@ -46,7 +46,7 @@ def test_config5_inference_and_learning_bit_exact_vs_oracle(lr50m):
     assert fg.count.min() >= 0 and fg.count.max() <= 1
 
     fg.learn(0, 1, 1e-3, 0.95, 2, 0.01, 1)
-    og.learn_dev(order, ps, vv, ve, wv, 1e-3, 2, 0.01, 1, False, 20240603, 2)
+    assert og.learn_call(order, ps, vv, ve, wv, 1, 1e-3, 0.95, 2, 0.01, 1, False, 20240603, 2) == 0
     assert np.array_equal(fg.weight_value[0], wv)
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.isfinite(fg.weight_value[0]).all()

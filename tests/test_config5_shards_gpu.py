@@ -120,7 +120,7 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
         starts = [st[2].copy() for _, _, st in oracles]
         for og, (order, ps_), (vv, ve, wv, cnt) in oracles:
             if learn:
-                assert og.learn_dev(order, ps_, vv, ve, wv, step, hyper[2], hyper[3], hyper[4], False, seed, s) == 0
+                assert og.learn_call(order, ps_, vv, ve, wv, 1, step, 1.0, hyper[2], hyper[3], hyper[4], False, seed, s) == 0
             else:
                 assert og.gibbs_dev(order, ps_, vv, wv, cnt, seed, s, True) == 0
         step *= decay

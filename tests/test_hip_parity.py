@@ -348,8 +348,8 @@ def test_chromatic_learning_equals_oracle(golden, name, reg, trunc, lne):
     step, decay, sweep = 0.01, 0.9, 0
     for chunk in (1, 3):
         fg.learn(0, chunk, step, decay, reg, 0.05, trunc, learn_non_evidence=lne)
+        assert og.learn_call(order, ps, vv, ve, wv, chunk, step, decay, reg, 0.05, trunc, lne, 5, sweep) == 0
         for _ in range(chunk):
-            assert og.learn_dev(order, ps, vv, ve, wv, step, reg, 0.05, trunc, lne, 5, sweep) == 0
             step *= decay
             sweep += 1
         assert np.array_equal(fg.var_value[0], vv), name
@@ -379,10 +379,7 @@ def test_generic_kernels_alone(golden, name, no_general, no_heavy, monkeypatch):
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, cnt = og.initial_state()
     fg.learn(0, 2, 0.01, 0.9, 2, 0.05, 1, learn_non_evidence=True)
-    step = 0.01
-    for sweep in range(2):
-        assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.05, 1, True, 5, sweep) == 0
-        step *= 0.9
+    assert og.learn_call(order, ps, vv, ve, wv, 2, 0.01, 0.9, 2, 0.05, 1, True, 5, 0) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.array_equal(fg.weight_value[0], wv)
     fg.inference(0, 3, True)
@@ -413,10 +410,7 @@ def test_learning_accumulator_fallbacks(golden, name, switch, monkeypatch):
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, _ = og.initial_state()
     fg.learn(0, 3, 0.01, 0.9, 2, 0.05, 1, learn_non_evidence=True)
-    step = 0.01
-    for sweep in range(3):
-        assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.05, 1, True, 5, sweep) == 0
-        step *= 0.9
+    assert og.learn_call(order, ps, vv, ve, wv, 3, 0.01, 0.9, 2, 0.05, 1, True, 5, 0) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.array_equal(fg.weight_value[0], wv)
 
@@ -435,10 +429,7 @@ def test_learning_with_unpacked_accumulators(golden, name, reg, monkeypatch):
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, _ = og.initial_state()
     fg.learn(0, 3, 0.01, 0.9, reg, 0.05, 2, learn_non_evidence=True)
-    step = 0.01
-    for sweep in range(3):
-        assert og.learn_dev(order, ps, vv, ve, wv, step, reg, 0.05, 2, True, 5, sweep) == 0
-        step *= 0.9
+    assert og.learn_call(order, ps, vv, ve, wv, 3, 0.01, 0.9, reg, 0.05, 2, True, 5, 0) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.array_equal(fg.weight_value[0], wv)
 
@@ -469,10 +460,7 @@ def test_learning_table_kernel_with_a_tiny_resident_grid(monkeypatch, evidence, 
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, cnt = og.initial_state()
     fg.learn(0, 3, 0.001, 0.9, 2, 0.01, 1, learn_non_evidence=(evidence == "half"))
-    step = 0.001
-    for sweep in range(3):
-        assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, evidence == "half", 9, sweep) == 0
-        step *= 0.9
+    assert og.learn_call(order, ps, vv, ve, wv, 3, 0.001, 0.9, 2, 0.01, 1, evidence == "half", 9, 0) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.array_equal(fg.weight_value[0], wv)
 
@@ -511,10 +499,7 @@ def test_general_tiles_at_scale():
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, cnt = og.initial_state()
     fg.learn(0, 2, 0.001, 0.9, 2, 0.01, 1, learn_non_evidence=False)
-    step = 0.001
-    for sweep in range(2):
-        assert og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 9, sweep) == 0
-        step *= 0.9
+    assert og.learn_call(order, ps, vv, ve, wv, 2, 0.001, 0.9, 2, 0.01, 1, False, 9, 0) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.array_equal(fg.weight_value[0], wv)
     fg.inference(0, 3, True)
@@ -561,10 +546,7 @@ def test_learning_then_inference_continue_from_state(golden):
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, cnt = og.initial_state()
     fg.learn(0, 2, 0.02, 0.95, 2, 0.01, 1)
-    step = 0.02
-    for s in range(2):
-        og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 9, s)
-        step *= 0.95
+    assert og.learn_call(order, ps, vv, ve, wv, 2, 0.02, 0.95, 2, 0.01, 1, False, 9, 0) == 0
     # patch state on the host, as numbskull_master.py:213-224 does between epochs
     fg.var_value[0][::2] = 0
     fg.weight_value[0][0] += 0.5
@@ -780,7 +762,7 @@ def test_two_partitions_on_one_gpu_match_emulation(learn):
                 _lib.check(L.nsk_gibbs_sweeps(p.h, 1, 1, 0))
         for og, (order, ps), (vv, ve, wv, cnt), _ in oracles:
             if learn:
-                og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 31, s)
+                og.learn_call(order, ps, vv, ve, wv, 1, step, 1.0, 2, 0.01, 1, False, 31, s)
             else:
                 og.gibbs_dev(order, ps, vv, wv, cnt, 31, s, True)
         step *= 0.9
@@ -879,10 +861,7 @@ def test_large_feature_values_widen_the_gradient_accumulator(reg):
     assert og.g.grad_shift == info["grad_shift"]
     order, ps = phases_from_colors(fg.colors())
     vv, ve, wv, _ = og.initial_state()
-    step = 1e-9
-    for s in range(3):
-        assert og.learn_dev(order, ps, vv, ve, wv, step, reg, 0.01, 1, False, 3, s) == 0
-        step *= 0.9
+    assert og.learn_call(order, ps, vv, ve, wv, 3, 1e-9, 0.9, reg, 0.01, 1, False, 3, 0) == 0
     assert np.array_equal(fg.weight_value[0], wv), (fg.weight_value[0], wv)
     assert np.array_equal(fg.var_value[0], vv) and wv[0] != 0.0
 
@@ -934,6 +913,29 @@ def test_captured_sweep_sequences_follow_a_reseed():
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
 
 
+@pytest.mark.parametrize("name", ["grid32", "mixed", "lr_manyw"])
+def test_learning_without_the_one_class_lag(golden, name):
+    """learn_lag=False (nsk_set_learn_lag 0): every colour class waits for the previous class's weight
+    update -- round 3's rule -- and equals the oracle's device mode without a lag array; with the lag
+    (the default) the same graph learns different, equally valid weights."""
+    g, hbv = _small_graphs(golden)[name]
+    if name == "grid32":
+        rng = np.random.default_rng(1)
+        g = graphgen.ising_grid(32, 32, weight=0.2, fixed=False, two_weights=True, evidence=rng.integers(0, 2, 32 * 32))
+    out = {}
+    for lag in (False, True):
+        ns, fg = session(g, seed=5, head_by_vid=hbv, no_learn_lag=not lag)
+        og = oracle_of(fg, hbv)
+        order, ps = phases_from_colors(fg.colors())
+        vv, ve, wv, _ = og.initial_state()
+        fg.learn(0, 4, 0.01, 0.9, 2, 0.05, 1, learn_non_evidence=True)
+        assert og.learn_call(order, ps, vv, ve, wv, 4, 0.01, 0.9, 2, 0.05, 1, True, 5, 0, lag=lag) == 0
+        assert np.array_equal(fg.weight_value[0], wv) and np.array_equal(fg.var_value[0], vv)
+        assert np.array_equal(fg.var_value_evid[0], ve)
+        out[lag] = wv.copy()
+    assert name != "grid32" or not np.array_equal(out[False], out[True])
+
+
 def test_native_rccl_loop_single_rank():
     """nsk_comm_init + nsk_gibbs_sweeps_exchange / nsk_learn_sweeps_exchange with a 1-rank
     communicator: the native loop (sweep, pack, ncclAllGather, unpack, ncclAllReduce of weight
@@ -954,7 +956,8 @@ def test_native_rccl_loop_single_rank():
     torch.cuda.synchronize()
     ns2, fg2 = session(g, seed=17)
     fg2.inference(0, 3, True)
-    fg2.learn(0, 2, 1e-3, 0.9, 2, 0.01, 1)
+    fg2.learn(0, 1, 1e-3, 0.9, 2, 0.01, 1)          # (the exchange loop is one nsk_learn_sweeps call per epoch:
+    fg2.learn(0, 1, 1e-3 * 0.9, 0.9, 2, 0.01, 1)    #  the one-class lag pipeline drains at every epoch's merge)
     assert np.array_equal(ps.val.cpu().numpy().astype(np.int64), fg2.var_value[0])
     assert np.array_equal(ps.val_evid.cpu().numpy().astype(np.int64), fg2.var_value_evid[0])
     assert np.allclose(ps.w.cpu().numpy(), fg2.weight_value[0], rtol=0, atol=1e-15)
@@ -1027,10 +1030,7 @@ def test_edge_case_graphs_run_and_match_oracle():
             og.gibbs_dev(order, ps, vv, wv, cnt, 13, 1 + s, True)
         assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
         fg.learn(0, 3, 0.05, 0.9, 1, 0.02, 2, learn_non_evidence=True)
-        step = 0.05
-        for s in range(3):
-            og.learn_dev(order, ps, vv, ve, wv, step, 1, 0.02, 2, True, 13, 7 + s)
-            step *= 0.9
+        assert og.learn_call(order, ps, vv, ve, wv, 3, 0.05, 0.9, 1, 0.02, 2, True, 13, 7) == 0
         assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.weight_value[0], wv)
     # isolated variables are fair coins
     ns, fg = session(_graph_from_spec(2000, []), seed=3)
@@ -1100,10 +1100,7 @@ def test_every_factor_function_on_device(scan):
             assert og.gibbs_dev(order, ps, vv, wv, cnt, 41, s, True, burnin=s < 2) == 0
         assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
         fg.learn(0, 10, 0.02, 0.9, 1, 0.05, 2, learn_non_evidence=True)
-        step = 0.02
-        for s in range(10):
-            assert og.learn_dev(order, ps, vv, ve, wv, step, 1, 0.05, 2, True, 41, 22 + s) == 0
-            step *= 0.9
+        assert og.learn_call(order, ps, vv, ve, wv, 10, 0.02, 0.9, 1, 0.05, 2, True, 41, 22) == 0
     else:
         np_rng, py_rng = orc.MT(41, "numpy"), orc.MT(41, "python")
         fg.inference(2, 20, True)
@@ -1160,34 +1157,6 @@ def test_marginals_within_1e_3_of_exact_after_burn_in():
     assert abs(want[0] - 0.5) > 0.05           # the bias makes the check non-trivial
 
 
-def test_compact_delta_streams_are_bit_exact(monkeypatch):
-    """NSK_D16=1 builds the int16-delta twin of the table segments' streams (member positions as
-    deltas from the lane's own position); the sweep must not change by a bit."""
-    monkeypatch.setenv("NSK_DIAG", "1")
-    monkeypatch.setenv("NSK_D16", "1")
-    rng = np.random.default_rng(5)
-    for learn in (False, True):
-        g = graphgen.ising_grid(96, 200, weight=0.3, fixed=not learn, two_weights=learn,
-                                evidence=rng.integers(0, 2, 96 * 200) if learn else None)
-        ns, fg = session(g, seed=21)
-        og = oracle_of(fg)
-        order, ps = phases_from_colors(fg.colors())
-        vv, ve, wv, cnt = og.initial_state()
-        if learn:
-            fg.learn(0, 3, 1e-3, 0.95, 2, 0.01, 1)
-            step = 1e-3
-            for s in range(3):
-                og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 21, s)
-                step *= 0.95
-            assert np.array_equal(fg.weight_value[0], wv) and np.array_equal(fg.var_value_evid[0], ve)
-        else:
-            fg.inference(1, 4, True)
-            for s in range(5):
-                og.gibbs_dev(order, ps, vv, wv, cnt, 21, s, True, burnin=s < 1)
-            assert np.array_equal(fg.count, cnt)
-        assert np.array_equal(fg.var_value[0], vv)
-
-
 @pytest.mark.parametrize("learn", [False, True])
 def test_values_outside_their_domain_take_the_exp_path(learn):
     """A caller may write any int into var_value (the reference computes with whatever is there).
@@ -1206,10 +1175,7 @@ def test_values_outside_their_domain_take_the_exp_path(learn):
         arr[bad] = 2                                       # not a value of a binary variable
     if learn:
         fg.learn(0, 2, 1e-3, 0.9, 2, 0.01, 1)
-        step = 1e-3
-        for s in range(2):
-            og.learn_dev(order, ps, vv, ve, wv, step, 2, 0.01, 1, False, 17, s)
-            step *= 0.9
+        assert og.learn_call(order, ps, vv, ve, wv, 2, 1e-3, 0.9, 2, 0.01, 1, False, 17, 0) == 0
         assert np.array_equal(fg.weight_value[0], wv) and np.array_equal(fg.var_value_evid[0], ve)
     else:
         fg.inference(0, 3, True)

@@ -32,5 +32,9 @@ def test_two_ranks_one_gpu(kind, mode, layout):
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(HERE, "multirank_worker.py"), kind, mode, layout]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:                      # the workers' full output, for the session log
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/multirank_%s_%s_%s.log" % (kind, mode, layout), "w") as f:
+            f.write(r.stdout + "\n----- stderr -----\n" + r.stderr)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

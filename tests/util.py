@@ -45,7 +45,10 @@ def oracle_of(fg, head_by_vid=False, layout=True):
         check_layout(ids, color)
         bad = og.check_coloring(color)
         assert bad == (-1, -1), ("variable reads a variable of its own colour", bad)
-        og.set_rng_ids(ids)
+        gen = fg.generators()
+        sampled = np.asarray(color) >= 0
+        assert np.array_equal(gen[sampled] & 0xFFFFFFFFFF, np.asarray(ids)[sampled]) and (gen[~sampled] == -1).all()
+        og.set_rng_ids(np.where(sampled, gen, ids))
         tag = fg.own_range[0] if fg.own_range is not None else 0
         if fg.global_ids is not None and fg.own_range is not None and len(fg.global_ids):     # shard-local graph
             tag = int(fg.global_ids[tag]) if tag < len(fg.global_ids) else int(fg.global_ids[-1]) + 1

@@ -1,24 +1,25 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun): regenerates EVERY profiles/r3_* artefact at the current HEAD in one go --
+# Runs ON THE GPU BOX (gpurun): regenerates EVERY profiles/${RT}_* artefact at the current HEAD in one go --
 # the default bench line, kernel-trace stats + PMC passes (FETCH_SIZE, WRITE_SIZE, L2, SQ; each counter
 # set in its own run, calibrated on a known-byte stream copy of the same run) for the workloads listed,
 # the bench lines of the large configurations, and the HBM-traffic table bench.py reads.  Output:
-# gpurun_out/profiles_r3/ (tools/install_profiles.sh copies it into profiles/).
+# gpurun_out/profiles_$RT/ (tools/install_profiles.sh copies it into profiles/).
 # NSK_PROFILE_PARTIAL=1 with NSK_PROFILE_WORKLOADS / NSK_PROFILE_BENCH_ONLY: only those workloads (a change
 # that touches some kernel families only); the traffic table keeps the other workloads' entries and
 # install_profiles.sh replaces only the files collected.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-OUT=$R/gpurun_out/profiles_r3
+RT=${NSK_ROUND_TAG:-r4}
+OUT=$R/gpurun_out/profiles_$RT
 rm -rf $OUT; mkdir -p $OUT
 git_head=$(cat $R/.git_head 2>/dev/null || echo unknown)
 TRAFFIC=$OUT/traffic_parts; mkdir -p $TRAFFIC
 for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
   bash tools/profile_gpu.sh $WL > /dev/null 2>&1
   P=$R/gpurun_out/prof_$WL
-  cp $P/summary.txt $OUT/r3_${WL}_summary.txt 2>/dev/null
-  cp $P/summary.json $OUT/r3_${WL}_summary.json 2>/dev/null
-  f=$(find $P/trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/r3_${WL}_kernel_stats.csv
-  cp $P/traffic_$WL.json $TRAFFIC/ 2>/dev/null
+  cp $P/summary.txt $OUT/${RT}_${WL}_summary.txt 2>/dev/null
+  cp $P/summary.json $OUT/${RT}_${WL}_summary.json 2>/dev/null
+  f=$(find $P/trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/${RT}_${WL}_kernel_stats.csv
+  cp $P/traffic_$WL.json $P/issue_$WL.json $TRAFFIC/ 2>/dev/null
   echo "profiled $WL: $(grep -h 'dominant kernel' $P/summary.txt)"
 done
 # the HBM-traffic table first (bench.py prints it as roofline.traffic), then every bench line with it
@@ -26,7 +27,7 @@ python - <<PY
 import json, glob, os
 out = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh (tools/profile_gpu.sh per workload), "
                   "corrected with the known-byte stream-copy calibration of the same run; all workloads collected in the same "
-                  "gpurun call as the bench lines (commit: profiles/r3_COMMIT.txt); separate passes from the bench run"}
+                  "gpurun call as the bench lines (commit: profiles/${RT}_COMMIT.txt); separate passes from the bench run"}
 if os.environ.get("NSK_PROFILE_PARTIAL") and os.path.exists("$R/profiles/traffic.json"):
     prev = json.load(open("$R/profiles/traffic.json"))
     out.update({k: v for k, v in prev.items() if not k.startswith("_")})
@@ -35,19 +36,28 @@ for f in sorted(glob.glob("$TRAFFIC/traffic_*.json")):
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
 json.dump(out, open("$R/profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out)[:600])
+iss = {"_source": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD pass of "
+                  "tools/profile_gpu.sh per workload: means per launch of the dominant kernel"}
+if os.environ.get("NSK_PROFILE_PARTIAL") and os.path.exists("$R/profiles/issue.json"):
+    prev = json.load(open("$R/profiles/issue.json"))
+    iss.update({k: v for k, v in prev.items() if not k.startswith("_")})
+for f in sorted(glob.glob("$TRAFFIC/issue_*.json")):
+    iss.update(json.load(open(f)))
+json.dump(iss, open("$OUT/issue.json", "w"), indent=1)
+json.dump(iss, open("$R/profiles/issue.json", "w"), indent=1)
 PY
-python bench.py > $OUT/r3_default_bench.json 2> $OUT/r3_default_bench.err
+python bench.py > $OUT/${RT}_default_bench.json 2> $OUT/${RT}_default_bench.err
 echo "default bench rc $?"
 for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
   [ $WL = ising10m ] && continue        # (the default line)
-  python bench.py --workload $WL --steps 100 --warmup 10 --no-extra > $OUT/r3_${WL}_bench.json 2> /dev/null
+  python bench.py --workload $WL --steps 100 --warmup 10 --no-extra > $OUT/${RT}_${WL}_bench.json 2> /dev/null
   echo "bench $WL rc $?"
 done
 for WL in ${NSK_PROFILE_BENCH_ONLY:-ising40m lr50m lr50m_learn}; do
-  python bench.py --workload $WL --steps 10 --warmup 3 --no-extra > $OUT/r3_${WL}_bench.json 2> $OUT/r3_${WL}_bench.err
+  python bench.py --workload $WL --steps 10 --warmup 3 --no-extra > $OUT/${RT}_${WL}_bench.json 2> $OUT/${RT}_${WL}_bench.err
   echo "bench $WL rc $?"
 done
-NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/r3_two_ranks_one_device_bench.json 2>/dev/null
-cp gpurun_out/config4_shards_*.json $OUT/ 2>/dev/null
+NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_bench.json 2>/dev/null
+cp gpurun_out/config4_shards_*.json gpurun_out/config5_shards_*.json $OUT/ 2>/dev/null
 find $OUT -type f -size +2M -delete
 ls $OUT

@@ -1,16 +1,18 @@
 #!/bin/bash
-# Run HERE after `gpurun -- bash tools/collect_profiles.sh`: profiles/r2_* go to profiles/history/, the
-# freshly collected r3 set (gpurun_out/profiles_r3/) becomes profiles/.
+# Run HERE after `git rev-parse HEAD > gpurun_out/profiles_r4_commit.txt; gpurun -- bash tools/collect_profiles.sh`:
+# earlier rounds' files go to profiles/history/, the freshly collected set (gpurun_out/profiles_$RT/) becomes profiles/.
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p profiles/history
-for f in profiles/r2_*; do [ -e "$f" ] && git mv -f "$f" profiles/history/ 2>/dev/null || true; done
+RT=${NSK_ROUND_TAG:-r4}
+for f in profiles/r2_* profiles/r3_*; do [ -e "$f" ] && git mv -f "$f" profiles/history/ 2>/dev/null || true; done
 # (NSK_PROFILE_PARTIAL=1: a partial collection replaces only the files it produced)
-[ -z "$NSK_PROFILE_PARTIAL" ] && for f in profiles/r3_*; do [ -e "$f" ] && rm -f "$f"; done
-cp gpurun_out/profiles_r3/r3_* profiles/
-cp gpurun_out/profiles_r3/traffic.json profiles/traffic.json
-for f in gpurun_out/profiles_r3/config4_shards_*.json; do [ -e "$f" ] && cp "$f" profiles/r3_$(basename $f); done
-if [ -z "$NSK_PROFILE_PARTIAL" ]; then cp gpurun_out/profiles_r3_commit.txt profiles/r3_COMMIT.txt
-else cat gpurun_out/profiles_r3_commit.txt >> profiles/r3_COMMIT.txt; fi
+[ -z "$NSK_PROFILE_PARTIAL" ] && for f in profiles/${RT}_*; do [ -e "$f" ] && rm -f "$f"; done
+cp gpurun_out/profiles_$RT/${RT}_* profiles/
+cp gpurun_out/profiles_$RT/traffic.json profiles/traffic.json
+cp gpurun_out/profiles_$RT/issue.json profiles/issue.json
+for f in gpurun_out/profiles_$RT/config4_shards_*.json gpurun_out/profiles_$RT/config5_shards_*.json; do [ -e "$f" ] && cp "$f" profiles/${RT}_$(basename $f); done
+if [ -z "$NSK_PROFILE_PARTIAL" ]; then cp gpurun_out/profiles_${RT}_commit.txt profiles/${RT}_COMMIT.txt
+else cat gpurun_out/profiles_${RT}_commit.txt >> profiles/${RT}_COMMIT.txt; fi
 rm -f profiles/*.err
 ls profiles

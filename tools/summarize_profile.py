@@ -90,6 +90,24 @@ for kr in summary["kernels"]:
         if k[:36] == kr["name"][:36] and "hbm_bytes_per_launch" in c and kr["total_ns"] > best:
             dom, best = c["hbm_bytes_per_launch"], kr["total_ns"]
             summary["dominant_kernel"] = kr["name"]
+# issue-side figures of the dominant kernel (bench.py prints them as roofline.issue)
+domk = None
+for kr in sorted(summary["kernels"], key=lambda k: -k["total_ns"]):
+    if "k_gibbs" in kr["name"] or "k_learn" in kr["name"]:
+        domk = kr
+        break
+if domk is not None:
+    for k, c in summary["pmc"].items():
+        if k[:36] == domk["name"][:36] and "SQ_INSTS_VALU" in c:
+            wc = c.get("SQ_WAVE_CYCLES") or float("nan")
+            issue = {"kernel": domk["name"], "avg_launch_us_profiled": domk["avg_ns"] / 1e3,
+                     "valu_insts_per_launch": c["SQ_INSTS_VALU"], "waves_per_launch": c.get("SQ_WAVES"),
+                     "active_inst_any_frac_of_wave_cycles": c.get("SQ_ACTIVE_INST_ANY", float("nan")) / wc,
+                     "wait_any_frac_of_wave_cycles": c.get("SQ_WAIT_ANY", float("nan")) / wc,
+                     "vmem_rd_insts_per_launch": c.get("SQ_INSTS_VMEM_RD")}
+            json.dump({wl: issue}, open(os.path.join(out, "issue_%s.json" % wl), "w"))
+            print("issue side:", issue)
+            break
 if dom is not None:
     json.dump({wl: dom}, open(os.path.join(out, "traffic_%s.json" % wl), "w"))
     json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
