@@ -377,7 +377,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         std::vector<int32_t> newc(nvar), seq;
         seq.reserve((size_t)nvar);
         const int npass = diag_env("NSK_RECOLOUR_PASSES") ? atoi(diag_env("NSK_RECOLOUR_PASSES")) : 6;
-        for (int pass = 0; pass < npass; pass++) {
+        int stale = 0;                                   // passes in a row that dropped no class
+        for (int pass = 0; pass < npass && stale < 2; pass++) {       // (each pass is a serial walk of the graph)
             std::vector<int64_t> size((size_t)ncolors, 0);
             for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) size[c.color[v]]++;
             std::vector<int32_t> cls((size_t)ncolors);
@@ -405,6 +406,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 newc[v] = col;
             }
             for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) c.color[v] = newc[v];
+            stale = nnew < ncolors ? 0 : stale + 1;
             ncolors = nnew;
         }
         stamp.assign((size_t)ncolors, -1);
@@ -1043,7 +1045,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     ts.nrows = (uint32_t)hdrs0.size();
                 }
             }
-        });
+        }, 64);
         std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
         std::vector<uint32_t> words, prog;
         uint64_t total4 = 0;                      // stream size in 16-byte units
@@ -1205,6 +1207,33 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         (long long)(c.phase_heavy_end[k] - c.phase_fast_end[k]));
             }
         }
+        if (const char *dv = diag_env("NSK_DEBUG_VAR")) {       // (diagnostic: where a variable landed)
+            for (const char *q = dv; *q;) {
+                const int64_t v = atoll(q);
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+                if (v < 0 || v >= nvar || c.color[v] < 0) continue;
+                const int64_t p = c.iid[v];
+                const int32_t k = c.color[v];
+                const int64_t b = (p - c.phase_start[k]) / 64;
+                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                fprintf(stderr, "[nsk] var %lld: colour %d position %lld tile %lld td {%u, %u, %u, %#x} kind %u slots %u",
+                        (long long)v, (int)k, (long long)p, (long long)b, td[0], td[1], td[2], td[3], (td[3] >> 8) & 7u, td[3] & 0xFFu);
+                for (const Compiled::Segment &sg : c.segments)
+                    if (p >= sg.pos0 && p < sg.pos0 + 64 * (int64_t)sg.ntiles)
+                        fprintf(stderr, " | segment pos0 %lld ntiles %d prog %u nslots %u kind %u ev %d ztab %lld", (long long)sg.pos0,
+                                sg.ntiles, sg.prog, sg.nslots, sg.kind, sg.ev, (long long)sg.ztab);
+                if (td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u) {
+                    fprintf(stderr, " | program:");
+                    for (uint32_t j = 0; j < 8; j++) {
+                        const uint32_t w_ = c.tile_hdr[td[2] + j];
+                        fprintf(stderr, " [w%u c%u F%u cl%u ig%u fx%u]", w_ & 0xFFFFFFu, (w_ >> 24) & 7u, (w_ >> 27) & 1u, (w_ >> 28) & 1u,
+                                (w_ >> 29) & 1u, (w_ >> 30) & 1u);
+                    }
+                }
+                fprintf(stderr, "\n");
+            }
+        }
         lap("segments");
         // pass 2: fill the tiles.  Padding: member slots read variable 0 (harmless) in uniform
         // tiles, 0xFFFFFFFF in tiles with per-lane headers.
@@ -1263,7 +1292,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 }
             }
             nfast_part[tix] = nfast_here;
-        });
+        }, 64);
         for (int64_t x : nfast_part) c.nfast += x;
     }
     lap("tile fill (pass 2)");
@@ -1319,7 +1348,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 for (uint32_t cl = 0; cl < 8; cl++) nrows += (cnt[cl] + 63) / 64;
                 c.ep_wrow[gi + 1] = nrows;
             }
-        });
+        }, 8);                                      // (a group is 256 variables' worth of work)
         for (int64_t gi = 0; gi < ngroups; gi++) {
             const uint64_t next = (uint64_t)c.ep_wrow[gi] + c.ep_wrow[gi + 1];
             if (next >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
@@ -1328,6 +1357,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int64_t gi = 0; gi < ngroups; gi++) subrows[gi + 1] += subrows[gi];
         if (subrows[ngroups] * 64 >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
         c.ep_adj.assign((size_t)subrows[ngroups] * 64 + 64, 0u);
+        // structural visit counts (nsk_compile.h ep_kstat): global accumulators only (graphs with few
+        // weights accumulate in LDS tables, where an update costs nothing); counted in pass B (atomic
+        // increments: a weight's entries are spread over the groups, contention is negligible)
+        const bool want_kstat = ngroups > 0 && nw > 256 && (int64_t)ncolors * nw * 2 <= ((int64_t)1 << 26) && !diag_env("NSK_NO_KSTAT");
+        if (want_kstat) c.ep_kstat.assign((size_t)ncolors * 2 * (size_t)nw, 0u);
         parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass B: fill
             std::vector<uint32_t> w;
             for (int64_t gi = g0; gi < g1; gi++) {
@@ -1350,9 +1384,17 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         }
                     sr += (uint64_t)rows * (2 + m);
                 }
+                const int32_t gk = group_colour[gi];
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;
                     general_words(c.p_vid[p], &w);
+                    const nsk_variable &var = d->variable[c.p_vid[p]];
+                    if (want_kstat && var.dataType == 0) {
+                        const size_t o = var.isEvidence == 1 ? 0 : 1;
+                        for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u))
+                            if (!c.w_fixed[w[j]])
+                                __atomic_fetch_add(&c.ep_kstat[((size_t)gk * 2 + o) * (size_t)nw + w[j]], 1u, __ATOMIC_RELAXED);
+                    }
                     uint32_t ordinal = 0;
                     for (size_t j = 0; j < w.size(); ordinal++) {
                         const uint32_t m = (w[j + 1] >> 4) & 7u, cl = row_class(m, ordinal);
@@ -1368,27 +1410,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     }
                 }
             }
-        });
-        // structural visit counts (nsk_compile.h ep_kstat): global accumulators only (graphs with few
-        // weights accumulate in LDS tables, where an update costs nothing)
-        if (ngroups > 0 && nw > 256 && (int64_t)ncolors * nw * 2 <= ((int64_t)1 << 26) && !diag_env("NSK_NO_KSTAT")) {
-            c.ep_kstat.assign((size_t)ncolors * 2 * (size_t)nw, 0u);
-            std::vector<uint32_t> w;
-            for (int64_t gi = 0; gi < ngroups; gi++) {
-                int64_t p0, p1;
-                group_range(gi, p0, p1);
-                const int32_t k = group_colour[gi];
-                for (int64_t p = p0; p < p1; p++) {
-                    if (c.p_vid[p] < 0) continue;
-                    const nsk_variable &var = d->variable[c.p_vid[p]];
-                    if (var.dataType != 0) continue;
-                    general_words(c.p_vid[p], &w);
-                    const size_t o = var.isEvidence == 1 ? 0 : 1;
-                    for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u))
-                        if (!c.w_fixed[w[j]]) c.ep_kstat[((size_t)k * 2 + o) * (size_t)nw + w[j]]++;
-                }
-            }
-        }
+        }, 8);
         if (verbose && ngroups)
             fprintf(stderr, "[nsk] entry-parallel groups %lld, stream %.1f MB\n", (long long)ngroups,
                     (double)subrows[ngroups] * 256 / 1e6);
@@ -1429,7 +1451,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     for (int cidx = 0; cidx < nch; cidx++)
                         for (int q = 0; q < 4; q++) c.seg_aff[((size_t)sg.aff + (size_t)t * nch + cidx) * 4 + q] = base[4 * cidx + q];
                 }
-            });
+            }, 64);
         }
     }
     // ---- entry-parallel hub streams: a hub (a long-list variable sampled by a whole wave) whose
@@ -1458,7 +1480,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) { ne++; mo = std::max(mo, (w[j + 1] >> 4) & 7u); }
                 nent[h] = ne; mh[h] = mo;
             }
-        });
+        }, 4);
         uint64_t total = 0;
         std::vector<uint64_t> off(hubs.size(), 0);
         for (size_t h = 0; h < hubs.size(); h++) {
@@ -1498,7 +1520,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     hd[0] = (uint32_t)off[h]; hd[1] = nent[h]; hd[2] = mh[h] | ((uint32_t)var.cardinality << 8);
                     hd[3] = (c.phase_ep[hk] && nent[h] > 128) ? 1u : 0u;
                 }
-            });
+            }, 4);
             for (size_t h = 0; h < hubs.size(); h++) {          // (hubs are listed colour by colour)
                 const int32_t hk = hub_colour[h];
                 if (!c.hub_desc[(size_t)(c.phase_hub_base[hk] + (hubs[h] - c.phase_fast_end[hk])) * 4 + 3]) continue;

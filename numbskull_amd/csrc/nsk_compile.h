@@ -29,8 +29,8 @@ static inline int compile_threads() {
     return n;
 }
 template <typename F>
-static void parallel_for(int64_t n, F &&body) {            // body(begin, end, thread index)
-    const int T = (int)std::min<int64_t>(compile_threads(), std::max<int64_t>(1, n / 4096));
+static void parallel_for(int64_t n, F &&body, int64_t grain = 4096) {    // body(begin, end, thread index); >= grain items per thread
+    const int T = (int)std::min<int64_t>(compile_threads(), std::max<int64_t>(1, n / grain));
     if (T <= 1) { body((int64_t)0, n, 0); return; }
     std::vector<std::thread> th;
     th.reserve((size_t)T);

@@ -176,11 +176,10 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         const dim3 grid(8 * ((nb + 7) / 8)), block(NSK_BLOCK);
 #define NSK_SEG(KIND, NCH) k_gibbs_seg<VT, KIND, NCH><<<grid, block, 0, g->stream>>>(d, tab, nb, burnin, K0, K1, S0, S1)
                         if (kind >= 8) {
-                            // a wave per tile pair while that fits 8 blocks per CU, else a resident grid over quads
-                            int split;
-                            const int nbp = nsk_tab_grid(tab.ntiles, &split);
-                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, split);
-                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, split);
+                            // a wave per tile pair while that fits the resident grid, else its waves loop over quads
+                            const int nbp = nsk_tab_grid(tab.ntiles);
+                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
+                            else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
                         }
                         else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
                         else if (kind == 2) { if (nch == 1) NSK_SEG(2, 1); else NSK_SEG(2, 2); }
@@ -262,14 +261,13 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
     for (int i = 0; i < NSK_GRAPH_SWEEPS; i++) {
         for (size_t ph = 0; ph < g->seg_plans.size(); ph++)
             for (const NskSegPlan &pl : g->seg_plans[ph]) {
-                int split;
-                const int nbp = nsk_tab_grid(pl.tab.ntiles, &split);
+                const int nbp = nsk_tab_grid(pl.tab.ntiles);
                 if (pl.nch == 1)
                     k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
-                                                                                         g->d_counters, (uint32_t)i, split);
+                                                                                         g->d_counters, (uint32_t)i);
                 else
                     k_gibbs_seg_tab<VT, 2><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
-                                                                                         g->d_counters, (uint32_t)i, split);
+                                                                                         g->d_counters, (uint32_t)i);
                 launches++;
             }
         if (p2p) {

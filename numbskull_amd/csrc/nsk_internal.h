@@ -244,24 +244,17 @@ static inline int nsk_learn_tab_grid(int ntiles, int nweight, bool smallw) {
     return 8 * ((std::max(1, std::min(cap, (blocks + trips - 1) / trips)) + 7) / 8);     // whole rounds of XCDs
 }
 // Grid of a table-driven inference segment launch (k_gibbs_seg_tab) over `vtiles` virtual tiles (a multiple
-// of 4): one wave per tile PAIR (split = 1; both waves of a quad evaluate its Philox block) while that is
-// at most 8 blocks per CU -- a small launch is one wave lifetime long and the shorter wave wins --, else a
-// resident grid of 7 blocks per CU, whole rounds of XCDs, whose waves loop over QUADS (split = 0: one block
-// per lane decides four updates).  Measured per class in round 3 (pairs, NSK_TAB_GRID_CAP, two passes on one
-// box): 10M grid 1024 blocks 15.8 us, 1280 15.0, 1536 14.7, 1792 14.3, 2048 15.0; 40M grid 1280 49.7, 1536
-// 48.2, 1792 47.1, 2048 53.0; the 1M grid needs 1954 blocks and is best left alone (4.13 against 4.20 us).
-static inline int nsk_tab_grid(int vtiles, int *split) {
-    const int npairs = vtiles / 2, nquads = vtiles / 4;
+// of 4): one wave per tile PAIR while that fits the resident grid, else the resident grid -- 6 blocks per CU
+// (106 scalar registers, nsk_blocks_per_cu), whole rounds of XCDs -- whose waves loop over QUADS (the kernel
+// deals whole rounds of quads, then pairs).  A grid beyond the resident one runs a tail round as long as
+// the first: per 10M-grid class 1024 blocks 15.2 us, 1280 14.3, 1536 12.7, 1632 16.2, 1792 14.1, 2048 14.3
+// (NSK_TAB_GRID_CAP); the 1M grid (1954 blocks of pairs) is indifferent (4.2 us).
+static inline int nsk_tab_grid(int vtiles) {
+    const int npairs = vtiles / 2;
     const int need = std::max(8, 8 * ((((npairs + 3) / 4) + 7) / 8));
-    const char *cap_env = nsk::diag_env("NSK_TAB_GRID_CAP");                // (diagnostic; negative: quads at |cap| blocks)
-    if (cap_env) {
-        const int cap = atoi(cap_env);
-        *split = cap > 0 && need <= 2048 ? 1 : 0;
-        const int needq = std::max(8, 8 * ((((nquads + 3) / 4) + 7) / 8));
-        return *split ? std::max(8, std::min(cap & ~7, need)) : std::max(8, std::min(std::abs(cap) & ~7, needq));
-    }
-    *split = need <= 2048 ? 1 : 0;
-    return *split ? need : 1536;        // 6 blocks per CU are resident (106 scalar registers: nsk_blocks_per_cu)
+    const char *cap_env = nsk::diag_env("NSK_TAB_GRID_CAP");                // (diagnostic)
+    const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : (need <= 2048 ? 2048 : 1536);
+    return std::min(cap, need);
 }
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {
     const int ntiles = sl.tile_start[sl.n];

@@ -998,6 +998,27 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             // the slots' satisfied bits of the two chains, zero for lanes that do not take part
             const uint32_t satf = part ? (proposal ? (ef[k].z >> 8) : ef[k].z) : 0u;
             const uint32_t sate = part ? (evidence ? (ee[k].z >> 8) : ee[k].z) : 0u;
+#ifdef NSK_ABL_LCHECK       // (debug build: the table's satisfied bits against the slot algebra, lane by lane)
+            if (part) {
+                const uint32_t *pq = g.tile_hdr + ti.prog;
+                SlotState sf = {0, true, false, true}, se = {0, true, false, true};
+                uint32_t B0 = 0, B1 = 0, C0 = 0, C1 = 0;
+                int ns = 0;
+                for (int j = 0; j < 4 * NCH; j++) if ((ti.zmask >> j) & 1u) ns = j + 1;
+                for (int j = 0; j < ns; j++) {
+                    bool b0, b1, c0, c1;
+                    slot_sat(sf, pq[j], (int)(uint8_t)g.val[r.id[k][j]], b0, b1);
+                    slot_sat(se, pq[j], (int)(uint8_t)g.val_evid[r.id[k][j]], c0, c1);
+                    B0 |= (b0 ? 1u : 0u) << j; B1 |= (b1 ? 1u : 0u) << j; C0 |= (c0 ? 1u : 0u) << j; C1 |= (c1 ? 1u : 0u) << j;
+                }
+                const uint32_t m = ti.zmask;
+                const uint32_t wf = (proposal ? B1 : B0) & m, we = (evidence ? C1 : C0) & m;
+                if ((satf & m) != wf || (sate & m) != we || ti.prog == 56u)
+                    printf("LCHECK sweep %u p %d prog %u zmask %#x idf %#x ide %#x ef.z %#x ee.z %#x prop %d evid %d satf %#x want %#x sate %#x want %#x init %d ev %d%s\n",
+                           lp.s0, p, ti.prog, m, idf[k], ide[k], ef[k].z, ee[k].z, proposal, evidence, satf & m, wf, sate & m, we, r.init[k], ti.ev,
+                           ((satf & m) != wf || (sate & m) != we) ? " MISMATCH" : "");
+            }
+#endif
 #if defined(NSK_ABL_LNOBALLOT)
             acc[0] += __popcll(__ballot((satf ^ sate) & 1u));
 #else

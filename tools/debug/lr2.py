@@ -12,6 +12,13 @@ lag = int(os.environ.get("LAG", "1"))
 world = int(os.environ.get("WORLD", "2"))
 g = graphgen.mixed_lr_graph(4000, seed=12, nweights=300)
 nvar = len(g[1])
+if os.environ.get("REMAP"):        # every factor of weight 131 gets a weight of its own: which one goes wrong?
+    from numbskull_amd.numbskulltypes import Weight
+    idx = np.nonzero(g[2]["weightId"] == 131)[0]
+    fac = g[2].copy()
+    fac["weightId"][idx] = 300 + np.arange(len(idx))
+    g = (np.zeros(300 + len(idx), Weight), g[1], fac) + tuple(g[3:])
+    print("remapped factors", list(idx))
 L = _lib.lib()
 hs, ogs = [], []
 for r in range(world):
