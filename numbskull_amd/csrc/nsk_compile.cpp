@@ -164,32 +164,35 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     for (int64_t v = ob; v < oe; v++) sampled[v] = d->variable[v].isEvidence != 4;   // inference.py:21-23
 
     // ---- validate every factor reachable from a sampled variable ------------------------------
+    // Two parallel phases over index blocks: (1) every sampled variable's lists -- bounds, factor ids -- mark
+    // the factors they reach; (2) every reached factor is checked.  Each thread keeps the first error of its
+    // block (lowest variable / factor index); the lowest block's error is reported, list errors first, so
+    // the message does not depend on the thread count.
     std::vector<uint8_t> checked(nfac, 0);
     int64_t max_ratio_arity = 0;
-    auto check_factor = [&](int64_t f) -> int {
-        if (checked[f]) return NSK_OK;
-        checked[f] = 1;
+    struct Issue { int rc = NSK_OK; std::string msg; bool ufo = false, literal = false; int64_t ratio = 0; };
+    auto check_factor = [&](int64_t f, Issue &is) -> int {
         const nsk_factor &fa = d->factor[f];
         const int fn = fa.factorFunction;
         if (!known_function(fn)) {
-            err = fmt("Factor function %lld (used in factor %lld) is not implemented.", fn, f);
+            is.msg = fmt("Factor function %lld (used in factor %lld) is not implemented.", fn, f);
             return NSK_E_FACTOR_FUNC;
         }
         if (fa.weightId < 0 || fa.weightId >= nw) {      // potential() reads it even for NOOP
-            err = fmt("factor %lld: weightId %lld outside weights", f, fa.weightId);
+            is.msg = fmt("factor %lld: weightId %lld outside weights", f, fa.weightId);
             return NSK_E_INDEX;
         }
         if (fn == -1) return NSK_OK;
         const int64_t s = fa.ftv_offset, e = fa.ftv_offset + fa.arity;
         if (fa.arity < 0 || s < 0 || e > nedge) {
-            err = fmt("factor %lld: members [%lld, %lld) outside fmap", f, s, e);
+            is.msg = fmt("factor %lld: members [%lld, %lld) outside fmap", f, s, e);
             return NSK_E_INDEX;
         }
         int64_t need = 0;       // member positions the function reads regardless of arity
         switch (fn) {
         case 3: need = 1; break;
         case 0: case 7: case 8: case 9: case 13: case 16: case 17:
-            if (fa.arity < 1) { err = fmt("factor %lld: function %lld needs arity >= 1", f, fn); return NSK_E_INDEX; }
+            if (fa.arity < 1) { is.msg = fmt("factor %lld: function %lld needs arity >= 1", f, fn); return NSK_E_INDEX; }
             break;
         case 18: case 19: case 20: case 30: need = 1; break;
         case 21: case 22: case 25: case 26: need = 2; break;
@@ -198,56 +201,75 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         const int64_t last = std::max(e, s + need);
         if (s + need > nedge) {
-            err = fmt("factor %lld: function %lld reads member %lld beyond fmap", f, fn, s + need - 1);
+            is.msg = fmt("factor %lld: function %lld reads member %lld beyond fmap", f, fn, s + need - 1);
             return NSK_E_INDEX;
         }
         for (int64_t l = s; l < last; l++) {
             if (d->fmap[l].vid < 0 || d->fmap[l].vid >= nvar) {
-                err = fmt("factor %lld: member variable %lld outside variables", f, d->fmap[l].vid);
+                is.msg = fmt("factor %lld: member variable %lld outside variables", f, d->fmap[l].vid);
                 return NSK_E_INDEX;
             }
         }
-        if (fn == 30) c.has_ufo = true;
+        if (fn == 30) is.ufo = true;
         if (fn == 30) {   // UFO reads member (value of first member) - 1
             int64_t reach = s + d->variable[d->fmap[s].vid].cardinality - 2;
-            if (reach >= nedge) { err = fmt("factor %lld: UFO member index beyond fmap", f); return NSK_E_INDEX; }
+            if (reach >= nedge) { is.msg = fmt("factor %lld: UFO member index beyond fmap", f); return NSK_E_INDEX; }
             for (int64_t l = s; l <= reach; l++)
                 if (d->fmap[l].vid < 0 || d->fmap[l].vid >= nvar) {
-                    err = fmt("factor %lld: member variable outside variables", f);
+                    is.msg = fmt("factor %lld: member variable outside variables", f);
                     return NSK_E_INDEX;
                 }
         }
-        if (literal_head_function(fn) && !head_by_vid) c.literal_heads = true;
+        if (literal_head_function(fn) && !head_by_vid) is.literal = true;
         if (literal_head_function(fn) && !head_by_vid && e - 1 >= nvar) {
-            err = fmt("factor %lld: the reference reads var_value[%lld] for the head of function %lld "
-                      "(inference.py:243,277,292), outside the variable array; pass NSK_FLAG_HEAD_BY_VID "
-                      "for the fmap[l].vid lookup", f, e - 1, fn);
+            is.msg = fmt("factor %lld: the reference reads var_value[%lld] for the head of function %lld "
+                         "(inference.py:243,277,292), outside the variable array; pass NSK_FLAG_HEAD_BY_VID "
+                         "for the fmap[l].vid lookup", f, e - 1, fn);
             return NSK_E_INDEX;
         }
-        if (fn == 8) max_ratio_arity = std::max(max_ratio_arity, fa.arity);
+        if (fn == 8) is.ratio = std::max(is.ratio, fa.arity);
         return NSK_OK;
     };
-
-    for (int64_t v = 0; v < nvar; v++) {
-        if (!sampled[v]) continue;
-        const nsk_variable &var = d->variable[v];
-        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-        for (int64_t k = 0; k < nslots; k++) {
-            const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
-            if (vt.factor_index_length < 0 || vt.factor_index_offset < 0 ||
-                vt.factor_index_offset + vt.factor_index_length > nfi) {
-                err = fmt("variable %lld: factor list outside factor_index", v);
-                return NSK_E_INDEX;
-            }
-            for (int64_t j = 0; j < vt.factor_index_length; j++) {
-                const int64_t f = d->factor_index[vt.factor_index_offset + j];
-                if (f < 0 || f >= nfac) {
-                    err = fmt("variable %lld: factor id %lld outside factors", v, f);
-                    return NSK_E_INDEX;
+    {
+        std::vector<Issue> issues((size_t)compile_threads());
+        parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int t) {
+            Issue &is = issues[(size_t)t];
+            for (int64_t v = vb0; v < vb1 && !is.rc; v++) {
+                if (!sampled[v]) continue;
+                const nsk_variable &var = d->variable[v];
+                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+                for (int64_t k = 0; k < nslots && !is.rc; k++) {
+                    const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+                    if (vt.factor_index_length < 0 || vt.factor_index_offset < 0 ||
+                        vt.factor_index_offset + vt.factor_index_length > nfi) {
+                        is.msg = fmt("variable %lld: factor list outside factor_index", v);
+                        is.rc = NSK_E_INDEX;
+                        break;
+                    }
+                    for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                        const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                        if (f < 0 || f >= nfac) {
+                            is.msg = fmt("variable %lld: factor id %lld outside factors", v, f);
+                            is.rc = NSK_E_INDEX;
+                            break;
+                        }
+                        checked[f] = 1;                   // (several threads may store the same 1)
+                    }
                 }
-                int rc = check_factor(f);
-                if (rc) return rc;
             }
+        });
+        for (const Issue &is : issues) if (is.rc) { err = is.msg; return is.rc; }      // blocks are in index order
+        for (Issue &is : issues) is = Issue();
+        parallel_for(nfac, [&](int64_t fb0, int64_t fb1, int t) {
+            Issue &is = issues[(size_t)t];
+            for (int64_t f = fb0; f < fb1 && !is.rc; f++)
+                if (checked[f]) is.rc = check_factor(f, is);
+        });
+        for (const Issue &is : issues) {
+            if (is.rc) { err = is.msg; return is.rc; }
+            c.has_ufo = c.has_ufo || is.ufo;
+            c.literal_heads = c.literal_heads || is.literal;
+            max_ratio_arity = std::max(max_ratio_arity, is.ratio);
         }
     }
     lap("validate");
@@ -882,6 +904,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     {
         int64_t next = c.npos;
         for (int64_t v = 0; v < nvar; v++) c.iid[v] = c.v_pos[v] >= 0 ? c.v_pos[v] : (int32_t)next++;
+        // one more id that belongs to no variable and always holds 0: where the ignored member slots and the
+        // padding of uniform tiles point.  The draw-table kernels take a member's value as its bit (values
+        // are regular, members binary), so such a slot must not read a categorical variable's value --
+        // position 0 may hold one (a 2 there set the NEXT slot's bit: wrong table entry, wrong gradient).
+        c.zero_id = next++;
         c.nid = next;
         if (c.nid >= LIM - 1) { err = "too many internal ids"; return NSK_E_RANGE; }
         parallel_for(nedge, [&](int64_t lb0, int64_t lb1, int) {
@@ -1024,7 +1051,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     uint32_t kind = n == 0 ? 0u : (ts.key[0] >> 24) & 7u;
                     for (uint32_t j = 0; j < n; j++)
                         if (((ts.key[j] >> 24) & 7u) != kind || ((ts.key[j] >> 27) & 7u) != 3u) kind = 0;   // first+last, not ignored
-                    // bit 11: draw-table candidate (padding slots read variable 0: masked off by nslots)
+                    // bit 11: draw-table candidate (padding slots read the always-zero id and are masked off by nslots)
                     ts.cls = 2;
                     ts.flags = (uint32_t)nslots | (kind << 8) | ((binmem && !no_ztab) ? 1u << 11 : 0u);
                     ts.len = (int32_t)nslots;
@@ -1235,7 +1262,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
         }
         lap("segments");
-        // pass 2: fill the tiles.  Padding: member slots read variable 0 (harmless) in uniform
+        // pass 2: fill the tiles.  Padding: member slots read the always-zero id (c.zero_id) in uniform
         // tiles, 0xFFFFFFFF in tiles with per-lane headers.
         c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);
         std::vector<int64_t> nfast_part((size_t)compile_threads() + 1, 0);
@@ -1250,8 +1277,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 const uint64_t base = (uint64_t)td[0] * 4;
                 const bool uniform = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u;
                 const bool general = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 6u;
-                if (td[2] != 0xFFFFFFFFu)       // uniform and shape tiles: padding reads variable / weight 0
-                    for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = 0;
+                if (td[2] != 0xFFFFFFFFu) {     // padding: uniform tiles read the always-zero id, shape tiles variable / weight 0
+                    const uint32_t padw = uniform ? (uint32_t)c.zero_id : 0u;
+                    for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = padw;
+                }
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;
                     size_t out = 0;
@@ -1284,7 +1313,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     for (size_t j = 0; j < words.size();) {
                         const uint32_t nother = (words[j] >> 24) & 7u;
                         if (!uniform) put(words[j]);
-                        else if (nother == 0) put(0u);            // the ignored slot of a member-less entry
+                        else if (nother == 0) put((uint32_t)c.zero_id);      // the ignored slot of a member-less entry
                         for (uint32_t m = 1; m <= nother; m++) put((uint32_t)c.iid[words[j + m]]);
                         j += 1 + nother;
                     }
@@ -1349,6 +1378,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 c.ep_wrow[gi + 1] = nrows;
             }
         }, 8);                                      // (a group is 256 variables' worth of work)
+        lap("entry-parallel groups: rows");
         for (int64_t gi = 0; gi < ngroups; gi++) {
             const uint64_t next = (uint64_t)c.ep_wrow[gi] + c.ep_wrow[gi + 1];
             if (next >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
@@ -1362,6 +1392,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // increments: a weight's entries are spread over the groups, contention is negligible)
         const bool want_kstat = ngroups > 0 && nw > 256 && (int64_t)ncolors * nw * 2 <= ((int64_t)1 << 26) && !diag_env("NSK_NO_KSTAT");
         if (want_kstat) c.ep_kstat.assign((size_t)ncolors * 2 * (size_t)nw, 0u);
+        lap("entry-parallel groups: allocation");
         parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass B: fill
             std::vector<uint32_t> w;
             for (int64_t gi = g0; gi < g1; gi++) {

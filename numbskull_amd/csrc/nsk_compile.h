@@ -175,8 +175,9 @@ struct Compiled {
     std::vector<int32_t> m_rec;         // [2*nedge] {variable id, dense_equal_to}
     std::vector<int32_t> v_card, v_pos;
     // internal numbering: iid[v] = position of a sampled variable, npos.. for the others; nid ids
+    // (+ one id past them that belongs to no variable and always holds 0: zero_id)
     std::vector<int32_t> iid, v_card_i;
-    int64_t nid = 0;
+    int64_t nid = 0, zero_id = 0;
     bool literal_heads = false;         // a reachable factor reads its head at the literal edge index
     std::vector<int64_t> cstart;        // [nvar+1]
     // weights

@@ -1013,6 +1013,11 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
                 }
                 const uint32_t m = ti.zmask;
                 const uint32_t wf = (proposal ? B1 : B0) & m, we = (evidence ? C1 : C0) & m;
+                if ((satf & m) != wf || (sate & m) != we)
+                    printf("LCHECKIDS p %d ids %u %u %u %u %u %u %u %u now %d %d %d %d %d %d %d %d\n", p,
+                           r.id[k][0], r.id[k][1], r.id[k][2], r.id[k][3], r.id[k][(4 * NCH) - 4], r.id[k][(4 * NCH) - 3], r.id[k][(4 * NCH) - 2], r.id[k][(4 * NCH) - 1],
+                           (int)g.val[r.id[k][0]], (int)g.val[r.id[k][1]], (int)g.val[r.id[k][2]], (int)g.val[r.id[k][3]],
+                           (int)g.val[r.id[k][(4 * NCH) - 4]], (int)g.val[r.id[k][(4 * NCH) - 3]], (int)g.val[r.id[k][(4 * NCH) - 2]], (int)g.val[r.id[k][(4 * NCH) - 1]]);
                 if ((satf & m) != wf || (sate & m) != we || ti.prog == 56u)
                     printf("LCHECK sweep %u p %d prog %u zmask %#x idf %#x ide %#x ef.z %#x ee.z %#x prop %d evid %d satf %#x want %#x sate %#x want %#x init %d ev %d%s\n",
                            lp.s0, p, ti.prog, m, idf[k], ide[k], ef[k].z, ee[k].z, proposal, evidence, satf & m, wf, sate & m, we, r.init[k], ti.ev,

@@ -30,6 +30,12 @@ for r in range(world):
     hs.append(fg)
     ogs.append((og, phases_from_colors(fg.colors()), og.initial_state()))
     print("rank", r, fg.info())
+    if r == 0:
+        lay, col = fg.layout(), fg.colors()
+        inv = {int(lay[v]): v for v in range(nvar)}
+        import json
+        json.dump({"inv": {str(k): int(v) for k, v in inv.items()}, "col": [int(x) for x in col],
+                   "ev": [int(x) for x in g[1]["isEvidence"]]}, open("gpurun_out/lr2_layout.json", "w"))
 step = 0.01
 for s in range(4):
     starts = [st[2].copy() for _, _, st in ogs]
