@@ -1804,7 +1804,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // the tally read-modify-write; materialised weight rows / gathered weights when the table
     // exceeds the L2; generic-path positions as in the CSR model above.
     {
-        std::vector<int32_t> seen(nvar, -1);
+        std::vector<uint64_t> seen((size_t)(nvar + 63) / 64);           // bit b: the class reads variable b
         for (int32_t k = 0; k < ncolors; k++) {
             double words = 0, wrows = 0, ep_wt_bytes = 0;
             for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
@@ -1834,13 +1834,25 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             lay_inf += words + (c.phase_ep[k] ? ep_wt_bytes : wrows);
             lay_learn += words + 3 * wrows;            // weight gathers + one 16-byte atomic per visit
             int64_t distinct = 0, nfastpos = 0, ncatpos = 0;
-            for (int64_t p = c.phase_start[k]; p < c.phase_fast_end[k]; p++) {
-                const int64_t v = c.p_vid[p];
-                if (v < 0) continue;
-                if (d->variable[v].cardinality == 2) nfastpos++; else ncatpos++;
-                for_each_read(v, [&](int64_t b) {
-                    if (b != v && seen[b] != k) { seen[b] = k; distinct++; }
+            std::fill(seen.begin(), seen.end(), 0ull);
+            {   // the class's positions over the host threads; a neighbour counts for the thread that sets its bit
+                const int64_t pa = c.phase_start[k], pb = c.phase_fast_end[k];
+                std::vector<int64_t> part((size_t)compile_threads() * 3, 0);
+                parallel_for(pb - pa, [&](int64_t b0, int64_t b1, int t) {
+                    int64_t dn = 0, nf = 0, nc = 0;
+                    for (int64_t p = pa + b0; p < pa + b1; p++) {
+                        const int64_t v = c.p_vid[p];
+                        if (v < 0) continue;
+                        if (d->variable[v].cardinality == 2) nf++; else nc++;
+                        for_each_read(v, [&](int64_t b) {
+                            if (b == v) return;
+                            const uint64_t bit = 1ull << (b & 63);
+                            if (!(__atomic_fetch_or(&seen[(size_t)b >> 6], bit, __ATOMIC_RELAXED) & bit)) dn++;
+                        });
+                    }
+                    part[(size_t)t * 3] = dn; part[(size_t)t * 3 + 1] = nf; part[(size_t)t * 3 + 2] = nc;
                 });
+                for (size_t t = 0; t < part.size(); t += 3) { distinct += part[t]; nfastpos += part[t + 1]; ncatpos += part[t + 2]; }
             }
             lay_inf += (double)distinct * s_v + (double)(nfastpos + ncatpos) * s_v + 2.0 * nfastpos + 2.0 * s_c * ncatpos;
             lay_learn += 2.0 * distinct * s_v + 2.0 * (nfastpos + ncatpos) * s_v;

@@ -1218,8 +1218,13 @@ __device__ __forceinline__ void block_hub_update(const DevGraph<VT> &g, const ui
     }
 }
 
+#ifdef NSK_EP_WPE_G      // (experiment: cap the vector registers so that this many waves per SIMD are resident)
+#define NSK_EP_ATTR_G __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_G, NSK_EP_WPE_G)))
+#else
+#define NSK_EP_ATTR_G
+#endif
 template <typename VT, int MAXC>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
+__global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_G void k_gibbs_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
                                                         int tile0, int ntiles, int ngroups, int group0, int gblocks,
                                                         int hb, int he, int hblocks, int hub0, int nbh, int bh0,
                                                         const uint32_t *rest_list, int nrest,

@@ -1160,8 +1160,13 @@ __device__ __forceinline__ void block_hub_learn(const DevGraph<VT> &g, const Gra
 // A group with more than 8 entries per variable takes two passes of (1, 2); phase 3 then runs over the
 // second pass's entries (their facts are in LDS) and, after redoing phase 1 for them, over the first's.
 // Dynamic LDS: the SMALLW accumulators only.
+#ifdef NSK_EP_WPE_L
+#define NSK_EP_ATTR_L __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_L, NSK_EP_WPE_L)))
+#else
+#define NSK_EP_ATTR_L
+#endif
 template <typename VT, bool SMALLW, int MAXC>
-__global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
+__global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
                                                         int tile0, int ntiles, int ngroups, int group0, int gblocks,
                                                         int hb, int he, int hblocks, int nbh, int bh0,
                                                         const uint32_t *rest_list, int nrest, LearnParams lp) {
