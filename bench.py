@@ -543,8 +543,9 @@ def main():
         ok_local = checks["all_ranks_ok"]
 
     phases = None
-    if world > 1 and not learning:      # per-phase timings of one shard's sweep (diagnostic; burn-in sweeps)
-        phases = sampler.phase_timings(20)
+    if world > 1 and (not learning or sampler.p2p):      # per-phase timings of one shard's sweep (diagnostic)
+        phases = sampler.phase_timings(20, learn=(lr[0], lr[2], lr[3], lr[4]) if learning else None)
+        sampler.check()
         phases["exchange_path"] = "peer-to-peer writes + flags" if sampler.p2p else (
             "native RCCL all-gather" if sampler.native else "torch.distributed all-gather")
     copy_gbs = None

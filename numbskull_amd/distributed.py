@@ -301,12 +301,15 @@ class PartitionedSampler(object):
                 _lib.check(self.L.nsk_gibbs_sweeps(self.h, 1, int(sample_evidence), int(burnin)))
                 self._exchange(_lib.BUF_VALUE, self.send, self.recv)
 
-    def phase_timings(self, nsweeps=20, sample_evidence=True):
-        """Diagnostic: mean microseconds of the phases of one inference sweep of this shard, each
-        bracketed by HIP events on the library's stream and issued on its own (so every figure
-        carries one launch latency): the sweep kernels, then the exchange -- peer-to-peer push +
-        wait/unpack, or pack / collective / unpack."""
+    def phase_timings(self, nsweeps=20, sample_evidence=True, learn=None):
+        """Diagnostic: mean microseconds of the phases of one sweep of this shard, each bracketed by
+        HIP events on the library's stream and issued on its own (so every figure carries one launch
+        latency): the sweep kernels, then the exchange -- peer-to-peer push + wait/unpack (learning:
+        both chains + weight deltas + merge), or pack / collective / unpack.  ``learn``: (step,
+        regularization, reg_param, truncation) for learning sweeps (peer-to-peer path only)."""
         _lib, L, h = self._lib, self.L, self.h
+        if learn is not None and not self.p2p:
+            return {}
         ms, nl = C.c_double(), C.c_int64()
 
         def timed(fn):
@@ -316,11 +319,16 @@ class PartitionedSampler(object):
             return ms.value * 1e3
         out = {"sweep": 0.0}
         for _ in range(nsweeps):
-            out["sweep"] += timed(lambda: _lib.check(L.nsk_gibbs_sweeps(h, 1, int(sample_evidence), 1)))
+            if learn is not None:
+                out["sweep"] += timed(lambda: _lib.check(L.nsk_learn_sweeps(h, 1, float(learn[0]), 1.0, int(learn[1]),
+                                                                                float(learn[2]), int(learn[3]), 0)))
+            else:
+                out["sweep"] += timed(lambda: _lib.check(L.nsk_gibbs_sweeps(h, 1, int(sample_evidence), 1)))
             if self.world == 1:
                 continue
             if self.p2p:
-                out["p2p_exchange"] = out.get("p2p_exchange", 0.0) + timed(lambda: _lib.check(L.nsk_p2p_exchange(h, 0, 0)))
+                out["p2p_exchange"] = out.get("p2p_exchange", 0.0) + timed(
+                    lambda: _lib.check(L.nsk_p2p_exchange(h, int(learn is not None), 0)))
             else:
                 out["pack"] = out.get("pack", 0.0) + timed(lambda: _lib.check(L.nsk_exchange_pack(h, _lib.BUF_VALUE)))
                 t0 = self.torch.cuda.Event(enable_timing=True)

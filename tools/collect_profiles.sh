@@ -22,6 +22,15 @@ for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_lea
   cp $P/traffic_$WL.json $P/issue_$WL.json $TRAFFIC/ 2>/dev/null
   echo "profiled $WL: $(grep -h 'dominant kernel' $P/summary.txt)"
 done
+# config #5 at size: kernel stats and HBM traffic only (minutes per run)
+for WL in ${NSK_PROFILE_LIGHT_WORKLOADS:-lr50m lr50m_learn}; do
+  NSK_PROFILE_LIGHT=1 NSK_PROFILE_STEPS=10 bash tools/profile_gpu.sh $WL > /dev/null 2>&1
+  P=$R/gpurun_out/prof_$WL
+  cp $P/summary.txt $OUT/${RT}_${WL}_summary.txt 2>/dev/null
+  f=$(find $P/trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/${RT}_${WL}_kernel_stats.csv
+  cp $P/traffic_$WL.json $TRAFFIC/ 2>/dev/null
+  echo "profiled (light) $WL: $(grep -h 'dominant kernel' $P/summary.txt)"
+done
 # the HBM-traffic table first (bench.py prints it as roofline.traffic), then every bench line with it
 python - <<PY
 import json, glob, os
@@ -53,11 +62,13 @@ for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_lea
   python bench.py --workload $WL --steps 100 --warmup 10 --no-extra > $OUT/${RT}_${WL}_bench.json 2> /dev/null
   echo "bench $WL rc $?"
 done
-for WL in ${NSK_PROFILE_BENCH_ONLY:-ising40m lr50m lr50m_learn}; do
-  python bench.py --workload $WL --steps 10 --warmup 3 --no-extra > $OUT/${RT}_${WL}_bench.json 2> $OUT/${RT}_${WL}_bench.err
+for WL in ${NSK_PROFILE_BENCH_ONLY:-ising40m ising100m lr50m lr50m_learn}; do
+  NSK_VERBOSE=1 python bench.py --workload $WL --steps 10 --warmup 3 --no-extra > $OUT/${RT}_${WL}_bench.json 2> $OUT/${RT}_${WL}_bench.err
+  grep "compile " $OUT/${RT}_${WL}_bench.err > $OUT/${RT}_${WL}_compile_laps.txt
   echo "bench $WL rc $?"
 done
 NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_bench.json 2>/dev/null
+NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload lr5m_learn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_lr5m_learn_bench.json 2>/dev/null
 cp gpurun_out/config4_shards_*.json gpurun_out/config5_shards_*.json $OUT/ 2>/dev/null
 find $OUT -type f -size +2M -delete
 ls $OUT
