@@ -1593,10 +1593,9 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
 }
 
 // The quads of an XCD's eighth are dealt to its waves in whole rounds -- a wave's trip is a quad --; what is
-// left after the last whole round (fewer quads than waves) is dealt in PARTS, several waves to a quad (each
-// evaluates the quad's block): single tiles when every tile then has a wave of its own -- the closing trip
-// of a big launch is a quarter as long --, else tile pairs; a launch with fewer quads than waves (small
-// grids: one wave lifetime long) runs entirely in pairs.
+// left after the last whole round (fewer quads than waves) is dealt as tile PAIRS, two waves to a quad (each
+// evaluates the quad's block): the closing trip of a launch is then half as long, and a launch with fewer
+// quads than waves (small grids: one wave lifetime long) runs entirely in pairs.
 template <typename VT, int NCH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
                                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
@@ -1616,22 +1615,19 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
     const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
     const int q0 = min(nquads, xcd * per), q1 = min(nquads, (xcd + 1) * per);
-    const int qr = q0 + ((q1 - q0) / wpx) * wpx;                        // first quad of the remainder
-    // the remainder's quads are cut into single tiles when every tile then gets a wave of its own (the
-    // closing trip of a big launch is a quarter as long), else into pairs
-    const int cut = 4 * (q1 - qr) <= wpx ? 4 : 2;                       // parts per quad (wave-uniform)
+    const int qr = q0 + ((q1 - q0) / wpx) * wpx;                        // first quad dealt as pairs
     // the segment of the last located quad stays in scalar registers: most launches have one
     int c_lo = 0, c_hi = -1;
     SegEntry en = tab.e[0];
-    // units: quads [q0, qr) one per trip, then the parts of quads [qr, q1)
+    // units: quads [q0, qr) one per trip, then the pairs of quads [qr, q1)
     for (int U = wx; ; U += wpx) {
-        int Q, part = -1;
+        int Q, h = -1;
         if (q0 + U < qr) Q = q0 + U;
         else {
-            const int u = U - (qr - q0);                                // part unit of the remainder
-            if (u >= cut * (q1 - qr)) break;
-            Q = qr + u / cut;
-            part = u % cut;
+            const int u = U - (qr - q0);                                // pair unit of the remainder
+            if (u >= 2 * (q1 - qr)) break;
+            Q = qr + (u >> 1);
+            h = u & 1;
         }
         if (4 * Q < c_lo || 4 * Q >= c_hi) {                            // wave-uniform, rare
             const int sidx = seg_of_tile(tab, 4 * Q);
@@ -1646,10 +1642,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
         const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
         u32x4 rb = {0u, 0u, 0u, 0u};
         bool have_b = false;
-        if (part >= 0 && cut == 4) {                                    // wave-uniform
-            tab_tiles<VT, NCH, 1>(g, en, t0q + part, part, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
-        } else if (part >= 0) {
-            tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * part, 2 * part, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+        if (h >= 0) {                                                   // wave-uniform
+            tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
         } else if (NSK_TAB_BATCH == 4) {
             tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
         } else {
