@@ -358,11 +358,17 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // the greedy pass assumes reads are symmetric (true for compute_var_map output); verify, and
     // repair with explicit reverse-read lists when a raw index is asymmetric
     bool conflict = false;
-    for (int64_t v = 0; v < nvar && !conflict; v++) {
-        if (!sampled[v]) continue;
-        for_each_read(v, [&](int64_t b) {
-            if (b != v && c.color[b] == c.color[v]) conflict = true;
+    {
+        std::vector<uint8_t> bad((size_t)compile_threads(), 0);
+        parallel_for(nvar, [&](int64_t b0, int64_t b1, int t) {
+            for (int64_t v = b0; v < b1 && !bad[(size_t)t]; v++) {
+                if (!sampled[v]) continue;
+                for_each_read(v, [&](int64_t b) {
+                    if (b != v && c.color[b] == c.color[v]) bad[(size_t)t] = 1;
+                });
+            }
         });
+        for (uint8_t x : bad) conflict = conflict || x;
     }
     if (conflict) {
         std::vector<int64_t> rcount(nvar + 1, 0);
@@ -416,16 +422,29 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             seq.assign((size_t)at[ncolors], 0);
             for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) seq[at[rank[c.color[v]]]++] = (int32_t)v;
             std::fill(newc.begin(), newc.end(), -1);
-            std::vector<int64_t> st(1, -1);
+            // The vertices of one old class are not adjacent, so first fit gives each of them the same
+            // colour whether they are taken one after the other or all at once: class by class, the
+            // class's vertices over the host threads (each reads only colours of earlier classes).
             int32_t nnew = 0;
-            for (int32_t v : seq) {
-                for_each_read(v, [&](int64_t b) {
-                    if (b != v && newc[b] >= 0) st[newc[b]] = v;
+            for (int32_t r = 0; r < ncolors; r++) {
+                const int64_t a0 = r ? at[r - 1] : 0, a1 = at[r];       // (at[] now holds the classes' ends in seq)
+                std::vector<int32_t> tmax((size_t)compile_threads(), -1);
+                parallel_for(a1 - a0, [&](int64_t b0, int64_t b1, int t) {
+                    std::vector<int64_t> st((size_t)ncolors + 1, -1);
+                    int32_t mx = -1;
+                    for (int64_t i = a0 + b0; i < a0 + b1; i++) {
+                        const int32_t v = seq[(size_t)i];
+                        for_each_read(v, [&](int64_t b) {
+                            if (b != v && newc[b] >= 0) st[newc[b]] = v;
+                        });
+                        int32_t col = 0;
+                        while (st[col] == v) col++;                  // (at most ncolors colours are in use)
+                        newc[v] = col;
+                        mx = std::max(mx, col);
+                    }
+                    tmax[(size_t)t] = mx;
                 });
-                int32_t col = 0;
-                while (col < nnew && st[col] == v) col++;
-                if (col == nnew) { nnew++; st.push_back(-1); }
-                newc[v] = col;
+                for (int32_t m : tmax) nnew = std::max(nnew, m + 1);
             }
             for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) c.color[v] = newc[v];
             stale = nnew < ncolors ? 0 : stale + 1;

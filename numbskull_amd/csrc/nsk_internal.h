@@ -101,6 +101,9 @@ struct nsk_graph {
     void *xfer_host[2] = {nullptr, nullptr};       // pinned, nvar * vbytes each (one per chain)
     void *xfer_dev = nullptr;                      // nvar * vbytes
     int32_t *xfer_iid = nullptr;                   // internal id of every variable
+    void *cnt_host = nullptr;                      // pinned, ncount * 4: the tally crosses PCIe as int32 when it fits
+    int32_t *cnt_dev32 = nullptr;
+    unsigned int *cnt_wide = nullptr;
     bool weights_dirty = true;      // prog_w must be rebuilt before the next fast-path launch
     bool weights_exposed = false;
     bool adj_wt_skip = false;       // learning reads weights directly: skip the shape-tile rows until the next inference   // the weight buffer was handed out: assume it changes between calls

@@ -51,6 +51,15 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_state_gather(const VT *val, const
         by_vid[v] = val[iid[v]];
 }
 
+// the int64 tally narrowed to int32 for the trip over PCIe (flag: some count does not fit)
+static __global__ __launch_bounds__(NSK_BLOCK) void k_count_narrow(const long long *total, int32_t *out, long long n, unsigned int *wide) {
+    for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * NSK_BLOCK) {
+        const long long x = total[i];
+        if (x < INT32_MIN || x > INT32_MAX) *wide = 1u;
+        out[i] = (int32_t)x;
+    }
+}
+
 // ---- boundary exchange ---------------------------------------------------------------------------
 template <typename VT>
 __global__ __launch_bounds__(NSK_BLOCK) void k_exchange_pack(const VT *val, const int32_t *send_vids,
