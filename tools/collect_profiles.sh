@@ -69,6 +69,11 @@ for WL in ${NSK_PROFILE_BENCH_ONLY:-ising40m ising100m lr50m lr50m_learn}; do
 done
 NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_bench.json 2>/dev/null
 NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload lr5m_learn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_lr5m_learn_bench.json 2>/dev/null
+# the 8-shard runs on one device (per-shard phase timings): config #4 through pack / unpack, configs #4 and #5
+# through the peer-to-peer kernels (the 50M graph included when the host has the memory)
+rm -f gpurun_out/config4_shards_*.json gpurun_out/config5_shards_*.json
+timeout 2400 python -m pytest tests/test_config5_shards_gpu.py tests/test_config4_gpu.py -m gpu -q > $OUT/${RT}_shards_tests.log 2>&1
+echo "shard tests rc $? $(tail -1 $OUT/${RT}_shards_tests.log)"
 cp gpurun_out/config4_shards_*.json gpurun_out/config5_shards_*.json $OUT/ 2>/dev/null
 find $OUT -type f -size +2M -delete
 ls $OUT
