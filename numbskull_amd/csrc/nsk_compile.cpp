@@ -861,29 +861,32 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     c.phase_ep_emax[c.color[v]] = std::max<int32_t>(c.phase_ep_emax[c.color[v]], g_ne[v]);
                 }
             }
-            for (int64_t v = 0; v < nvar; v++) {
-                if (c.color[v] < 0 || fast[v] != 2) continue;
-                const int64_t ne = g_ne[v], mo = g_mo[v];
-                // key: categorical lanes first (their tiles form a launch of their own), then blocks
-                // of gen_block consecutive ids (sigma of SELL-C-sigma: each XCD walks a contiguous
-                // run of tiles, so its L2 then sees one slice of the value array instead of all of
-                // it), largest layouts first inside a block
-                const int64_t catv = d->variable[v].cardinality > 2 ? 0 : 1;
-                // (entry-parallel groups carry no padding to the widest lane, so their colours are cut
-                // into small id blocks: a group's member values then share cache lines)
-                // into small id blocks: a group's member values then share cache lines), with the
-                // variables of more than 8 entries -- two LDS passes per group -- in front of the others
-                const bool epk = c.phase_ep[c.color[v]] != 0;
+            // key: categorical lanes first (their tiles form a launch of their own), then blocks
+            // of gen_block consecutive ids (sigma of SELL-C-sigma: each XCD walks a contiguous
+            // run of tiles, so its L2 then sees one slice of the value array instead of all of
+            // it), largest layouts first inside a block.  Entry-parallel groups carry no padding to the
+            // widest lane, so their colours are cut into small id blocks -- a group's member values then
+            // share cache lines --, with the variables of more than 8 entries (two LDS passes per group)
+            // in front of the others.  One colour per thread: collect its variables, sort them.
+            auto collect = [&](int32_t k) {
+                std::vector<std::pair<int64_t, int64_t>> &ord = order[(size_t)k];
+                ord.reserve((size_t)ngt_of[k]);
+                const bool epk = c.phase_ep[k] != 0;
                 const int64_t gb = epk ? ep_block : gen_block;
-                const int64_t small = (epk && ne <= 8) ? 1 : 0;
-                order[c.color[v]].push_back({(small << 51) | (catv << 50) | ((v / gb) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
-            }
+                for (int64_t v = 0; v < nvar; v++) {
+                    if (c.color[v] != k || fast[v] != 2) continue;
+                    const int64_t ne = g_ne[v], mo = g_mo[v];
+                    const int64_t catv = d->variable[v].cardinality > 2 ? 0 : 1;
+                    const int64_t small = (epk && ne <= 8) ? 1 : 0;
+                    ord.push_back({(small << 51) | (catv << 50) | ((v / gb) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
+                }
+                std::sort(ord.begin(), ord.end());
+            };
             {
-                std::vector<std::thread> sorters;             // one colour per thread (few colours only)
+                std::vector<std::thread> sorters;             // (few colours only)
                 for (int32_t k = 0; k < ncolors; k++) {
-                    if (ncolors <= 64 && compile_threads() > 1)
-                        sorters.emplace_back([&, k] { std::sort(order[k].begin(), order[k].end()); });
-                    else std::sort(order[k].begin(), order[k].end());
+                    if (ncolors <= 64 && compile_threads() > 1) sorters.emplace_back([&, k] { collect(k); });
+                    else collect(k);
                 }
                 for (auto &t : sorters) t.join();
             }

@@ -185,24 +185,6 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     return d;
 }
 
-// Workgroups of `kernel` (256 threads, `smem` bytes of dynamic LDS) that are RESIDENT per CU: the size of a
-// resident grid whose blocks loop over their share of the work (a block beyond it starts when another
-// ends: a tail round as long as the first).  The occupancy API accounts for vector registers and LDS but
-// admits one block too many when a kernel holds 97-112 scalar registers (MI355X_MICROARCH.md: blocks per
-// CU = min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) -- 6 at the 104-106 every sweep kernel here uses), hence
-// the cap.  Cached per kernel.
-template <typename K>
-static int nsk_blocks_per_cu(K kernel, size_t smem) {
-    static std::vector<std::pair<const void *, int>> cache;
-    const void *key = (const void *)kernel;
-    for (auto &e : cache) if (e.first == key) return e.second;
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NSK_BLOCK, smem) != hipSuccess || n < 1) n = 4;
-    n = std::min(n, 6);
-    cache.push_back({key, n});
-    return n;
-}
-
 // Streams for the kernels of one colour: the tile kernels stay on the main stream; when there are
 // tile kernels to overlap with, hubs go to side stream 0, the generic kernel to side stream 1 and
 // the categorical general tiles to side stream 2.
@@ -247,9 +229,11 @@ static inline int nsk_learn_tab_grid(int ntiles, int nweight, bool smallw) {
     return 8 * ((std::max(1, std::min(cap, (blocks + trips - 1) / trips)) + 7) / 8);     // whole rounds of XCDs
 }
 // Grid of a table-driven inference segment launch (k_gibbs_seg_tab) over `vtiles` virtual tiles (a multiple
-// of 4): one wave per tile PAIR while that fits the resident grid, else the resident grid -- 6 blocks per CU
-// (106 scalar registers, nsk_blocks_per_cu), whole rounds of XCDs -- whose waves loop over QUADS (the kernel
-// deals whole rounds of quads, then pairs).  A grid beyond the resident one runs a tail round as long as
+// of 4): one wave per tile PAIR while that fits the resident grid, else the resident grid -- 6 blocks per CU,
+// whole rounds of XCDs -- whose waves loop over QUADS (the kernel deals whole rounds of quads, then pairs).
+// Six, not the seven the compiler's occupancy and the occupancy API report: the kernel holds 106 scalar
+// registers and the hardware admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) blocks of 256 threads per CU
+// (MI355X_MICROARCH.md); capping the registers for a seventh or eighth block was slower.  A grid beyond the resident one runs a tail round as long as
 // the first: per 10M-grid class 1024 blocks 15.2 us, 1280 14.3, 1536 12.7, 1632 16.2, 1792 14.1, 2048 14.3
 // (NSK_TAB_GRID_CAP); the 1M grid (1954 blocks of pairs) is indifferent (4.2 us).
 static inline int nsk_tab_grid(int vtiles) {
@@ -257,7 +241,7 @@ static inline int nsk_tab_grid(int vtiles) {
     const int need = std::max(8, 8 * ((((npairs + 3) / 4) + 7) / 8));
     const char *cap_env = nsk::diag_env("NSK_TAB_GRID_CAP");                // (diagnostic)
     const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : (need <= 2048 ? 2048 : 1536);
-    return std::min(cap, need);
+    return std::min(cap, need);        // (a launch that needs fewer blocks than 2048 runs in pairs: one trip per wave)
 }
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {
     const int ntiles = sl.tile_start[sl.n];

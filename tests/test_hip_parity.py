@@ -803,6 +803,91 @@ def test_two_partitions_on_one_gpu_match_emulation(learn):
             assert np.allclose(parts[r].w.cpu().numpy(), wv, rtol=0, atol=1e-15)
 
 
+def test_table_segments_do_not_read_position_zero():
+    """The draw-table kernels take a member's value as its neighbourhood bit.  The ignored slot of a
+    member-less entry (ISTRUE) and the padding of a uniform tile used to read "variable 0": with a
+    categorical variable at internal id 0 holding 2 they set the NEXT slot's bit -- a wrong table entry and
+    wrong satisfied bits (one weight off by 2 * step per epoch on this very graph: the first shard of the
+    two-rank LR test).  They read an always-zero id now."""
+    from numbskull_amd.distributed import shard_range
+    g = graphgen.mixed_lr_graph(4000, seed=12, nweights=300)
+    ns = numbskull_amd.NumbSkull(quiet=True, seed=31, head_by_vid=True)
+    ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in g[:5]], int(g[5]),
+                       own_range=shard_range(0, 2, 4000))
+    fg = ns.factorGraphs[0]
+    info = fg.info()
+    assert info["ztab_entries"] > 0                        # table segments with several slots
+    lay = fg.layout()
+    v0 = int(np.nonzero(lay == 0)[0][0])                   # the variable at internal id 0 is categorical
+    assert fg.variable[v0]["cardinality"] > 2
+    og = oracle_of(fg, True)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, cnt = og.initial_state()
+    fg.learn(0, 5, 0.01, 0.9, 2, 0.01, 1)
+    assert og.learn_call(order, ps, vv, ve, wv, 5, 0.01, 0.9, 2, 0.01, 1, False, 31, 0) == 0
+    lo, hi = shard_range(0, 2, 4000)
+    assert np.array_equal(fg.weight_value[0], wv)
+    assert np.array_equal(fg.var_value[0][lo:hi], vv[lo:hi]) and np.array_equal(fg.var_value_evid[0][lo:hi], ve[lo:hi])
+    fg.inference(0, 6, True)
+    for s in range(5, 11):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 31, s, True) == 0
+    cs = fg.cstart
+    assert np.array_equal(fg.var_value[0][lo:hi], vv[lo:hi]) and np.array_equal(fg.count[cs[lo]:cs[hi]], cnt[cs[lo]:cs[hi]])
+
+
+def test_peer_to_peer_timeout_is_reported_once(monkeypatch):
+    """A peer whose flag never arrives: the wait kernel gives up after NSK_P2P_TIMEOUT_S, nsk_p2p_check
+    reports it (RuntimeError) and clears the mark, so the handle is usable again; set-up errors are
+    refused up front."""
+    import ctypes as C
+    import torch
+    from numbskull_amd.distributed import PartitionedSampler, shard_range
+    monkeypatch.setenv("NSK_P2P_TIMEOUT_S", "0.5")
+    g = graphgen.ising_grid(16, 16, weight=0.2)
+    L = _lib.lib()
+    parts = []
+    for r in range(2):
+        ns = numbskull_amd.NumbSkull(quiet=True, seed=3)
+        ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in g[:5]], int(g[5]),
+                           own_range=shard_range(r, 2, 256))
+        with torch.cuda.stream(torch.cuda.Stream()):
+            ps = PartitionedSampler(ns.factorGraphs[0], None, torch, r, 1, nvar_global=256)
+        ps.world = 2
+        parts.append(ps)
+    with pytest.raises(ValueError):                        # nothing set up yet
+        _lib.check(L.nsk_p2p_exchange(parts[0].h, 0, 0))
+    needs = [p.global_needs() for p in parts]
+    bases = (C.c_void_p * 2)()
+    for p in parts:
+        p.all_needs = needs
+        _lib.check(p.p2p_setup())
+        b = C.c_void_p()
+        _lib.check(L.nsk_p2p_export(p.h, None, C.byref(b)))
+        bases[p.rank] = b.value
+    for p in parts:
+        _lib.check(L.nsk_p2p_import_local(p.h, bases))
+        p.p2p = True
+    # rank 0 exchanges alone: rank 1 never pushes
+    _lib.check(L.nsk_p2p_exchange(parts[0].h, 0, 0))
+    with pytest.raises(RuntimeError):
+        parts[0].check()
+    parts[0].check()                                       # reported once
+    # rank 1 catches up (its push carries tag 1), then both exchange properly
+    _lib.check(L.nsk_p2p_exchange(parts[1].h, 0, 0))
+    parts[1].check()
+    for part in (1, 2):
+        for p in parts:
+            _lib.check(L.nsk_p2p_exchange(p.h, 0, part))
+    for p in parts:
+        p.check()
+    send = np.zeros(3, np.int32)
+    off = np.array([0, 0, 3], np.int64)
+    zero = np.zeros(3, np.int64)
+    with pytest.raises((ValueError, IndexError)):          # a send list naming variables the handle does not own
+        _lib.check(L.nsk_p2p_setup(parts[0].h, 2, 0, _lib.ptr(np.array([200, 201, 202], np.int32)), _lib.ptr(off),
+                                   _lib.ptr(send), _lib.ptr(np.array([0, 0, 0], np.int64)), _lib.ptr(zero), _lib.ptr(np.array([0, 3, 0], np.int64))))
+
+
 @pytest.mark.parametrize("learn", [False, True])
 def test_shards_draw_from_disjoint_generator_streams(learn):
     """Generator ids are positions in a handle's own layout, so position q exists in every shard:
