@@ -96,7 +96,8 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
  * AND the layout the library chose (device, flags and diagnostic switches being equal, a graph
  * always compiles to the same layout).  Learning sweeps: counter (id, stream, sweep index);
  * inference sweeps: ids q and q + 64 with equal q >> 7 share one block, counter
- * ((q >> 7) * 64 + (q & 63), 0, sweep index), words 0-1 / 2-3.  The sweep index starts at `sweep0`
+ * ((q >> 7) * 64 + (q & 63), 0, sweep index), words 0-1 / 2-3 (pair scheme), except inside segments with
+ * draw tables, where four ids share two blocks (quad scheme, nsk_graph_get_generators).  The sweep index starts at `sweep0`
  * and advances by one per sweep of any kind; its high half (counter word 3) is XORed with the
  * handle's shard tag (nsk_set_rng_tag; 0 for a handle that owns the whole graph).  Sequential scan seeds MT19937 like
  * np.random.seed(seed); random.seed(seed). */

@@ -111,7 +111,10 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
 #define NSK_EP_ARGS d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, ngt, ngroups, (int)g->c.phase_ep_base[ph], gblocks, fe, he, hblocks, \
                     (int)g->c.phase_hub_base[ph], nbh, (int)g->c.phase_bighub_base[ph], g->rest_tiles + g->c.phase_rest_base[ph], nrest_all, sample_evidence, burnin, \
                     (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep, nsk_sweep_hi(g)
-                    if (cat8) k_gibbs_ep<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
+                    // (value array within the L2s: the register-capped twin with a fifth wave per SIMD)
+                    const bool in_l2 = (size_t)g->c.nid * (size_t)g->c.vbytes <= ((size_t)24 << 20);
+                    if (cat8 && in_l2) k_gibbs_ep_w5<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
+                    else if (cat8) k_gibbs_ep<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
                     else k_gibbs_ep<VT, 2><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
 #undef NSK_EP_ARGS
                     g->launches++;
@@ -228,14 +231,16 @@ static int gibbs_eager(nsk_graph *g, int64_t nsweeps, int sample_evidence, int b
 // a hipGraph whose kernels read the sweep index (and the exchange tag) from device memory + a per-node
 // offset, so the same executable graph serves every replay; a one-thread kernel at its end advances the
 // counters.  The uint8 position tally is folded between replays when it would overflow.
-static bool graph_eligible(const nsk_graph *g) {
+static bool graph_eligible(const nsk_graph *g, bool p2p) {
     if (g->scan != NSK_SCAN_CHROMATIC || !g->values_regular || nsk::diag_env("NSK_NO_GRAPH")) return false;
     const nsk::Compiled &c = g->c;
     const size_t nphase = c.phase_start.size() - 1;
     if (nphase == 0) return false;
     // launches set the pace only while the class kernels are short: beyond a few million variables per
-    // handle (10M grid: 14.5 us per class) a replay saves nothing and its launch latency shows in short runs
-    if (c.nsampled > 3000000) return false;
+    // handle (10M grid: 12 us per class) a replay saves nothing and its launch latency shows in short runs.
+    // A handle that exchanges peer to peer adds two tiny kernels per sweep: its sequences are captured up
+    // to twice the size (the two shards of the 10M grid)
+    if (c.nsampled > (p2p ? 6000000 : 3000000)) return false;
     for (size_t ph = 0; ph < nphase; ph++) {
         const int64_t ntiles = c.phase_wb_base[ph + 1] - c.phase_wb_base[ph];
         if (c.phase_end[ph] > c.phase_fast_end[ph]) return false;                    // generic-path variables / hubs
@@ -289,7 +294,7 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
 
 int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p) {
     int64_t left = nsweeps;
-    if (left >= NSK_GRAPH_SWEEPS && graph_eligible(g)) {
+    if (left >= NSK_GRAPH_SWEEPS && graph_eligible(g, p2p)) {
         // the plans of this (sample_evidence, tables) combination: one eager sweep builds / refreshes them
         int rc = gibbs_eager(g, 1, sample_evidence, burnin);
         if (rc) return rc;

@@ -1218,18 +1218,13 @@ __device__ __forceinline__ void block_hub_update(const DevGraph<VT> &g, const ui
     }
 }
 
-#ifdef NSK_EP_WPE_G      // (experiment: cap the vector registers so that this many waves per SIMD are resident)
-#define NSK_EP_ATTR_G __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_G, NSK_EP_WPE_G)))
-#else
-#define NSK_EP_ATTR_G
-#endif
 template <typename VT, int MAXC>
-__global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_G void k_gibbs_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
-                                                        int tile0, int ntiles, int ngroups, int group0, int gblocks,
-                                                        int hb, int he, int hblocks, int hub0, int nbh, int bh0,
-                                                        const uint32_t *rest_list, int nrest,
-                                                        int sample_evidence, int burnin,
-                                                        uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+__device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin, int pend, int wb_base,
+                                              int tile0, int ntiles, int ngroups, int group0, int gblocks,
+                                              int hb, int he, int hblocks, int hub0, int nbh, int bh0,
+                                              const uint32_t *rest_list, int nrest,
+                                              int sample_evidence, int burnin,
+                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
     __shared__ __attribute__((aligned(16))) double ws[NSK_EP_LIST * 256];
     __shared__ __attribute__((aligned(16))) uint16_t fs[NSK_EP_LIST * 256];
     __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
@@ -1357,6 +1352,24 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_G void k_gibbs_ep(DevGraph<V
 #endif
     }
 }
+
+#define NSK_EP_PARAMS DevGraph<VT> g, int pbegin, int pend, int wb_base, int tile0, int ntiles, int ngroups, int group0, int gblocks, \
+                      int hb, int he, int hblocks, int hub0, int nbh, int bh0, const uint32_t *rest_list, int nrest, \
+                      int sample_evidence, int burnin, uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1
+#define NSK_EP_FORWARD g, pbegin, pend, wb_base, tile0, ntiles, ngroups, group0, gblocks, hb, he, hblocks, hub0, nbh, bh0, rest_list, nrest, \
+                       sample_evidence, burnin, k0, k1, s0, s1
+template <typename VT, int MAXC>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(NSK_EP_PARAMS) { gibbs_ep_body<VT, MAXC>(NSK_EP_FORWARD); }
+// The same with the vector registers capped at 96 (5 waves per SIMD instead of the categorical kernel's 4): for
+// graphs whose value array stays in the L2s the gathers are L2 hits and a fifth wave hides more of their
+// latency (5M LR graph: 55.4 -> 51.2 us per class); beyond them it is slower (50M LR graph: 472 -> 485 us) --
+// the launch picks by the size of the value array.
+template <typename VT, int MAXC>
+__global__ __launch_bounds__(NSK_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_gibbs_ep_w5(NSK_EP_PARAMS) {
+    gibbs_ep_body<VT, MAXC>(NSK_EP_FORWARD);
+}
+#undef NSK_EP_PARAMS
+#undef NSK_EP_FORWARD
 
 // Homogeneous segments: runs of consecutive uniform tiles with one program, slot count, kind and
 // evidence flag (the shape-class layout of nsk_compile.cpp makes whole classes such runs).  Up to

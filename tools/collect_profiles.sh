@@ -7,12 +7,16 @@
 # NSK_PROFILE_PARTIAL=1 with NSK_PROFILE_WORKLOADS / NSK_PROFILE_BENCH_ONLY: only those workloads (a change
 # that touches some kernel families only); the traffic table keeps the other workloads' entries and
 # install_profiles.sh replaces only the files collected.
+# NSK_PROFILE_STAGE=profile: the rocprofv3 passes and the two tables only; =bench: the bench lines, the two-rank
+# lines and the 8-shard runs only (they read profiles/traffic.json / issue.json as installed from a profile
+# stage: a gpurun call is limited to an hour and the whole collection takes longer); default: both.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 RT=${NSK_ROUND_TAG:-r4}
+STAGE=${NSK_PROFILE_STAGE:-all}
 OUT=$R/gpurun_out/profiles_$RT
 rm -rf $OUT; mkdir -p $OUT
-git_head=$(cat $R/.git_head 2>/dev/null || echo unknown)
 TRAFFIC=$OUT/traffic_parts; mkdir -p $TRAFFIC
+if [ $STAGE != bench ]; then
 for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
   bash tools/profile_gpu.sh $WL > /dev/null 2>&1
   P=$R/gpurun_out/prof_$WL
@@ -55,6 +59,8 @@ for f in sorted(glob.glob("$TRAFFIC/issue_*.json")):
 json.dump(iss, open("$OUT/issue.json", "w"), indent=1)
 json.dump(iss, open("$R/profiles/issue.json", "w"), indent=1)
 PY
+fi
+[ $STAGE = profile ] && { ls $OUT; exit 0; }
 python bench.py > $OUT/${RT}_default_bench.json 2> $OUT/${RT}_default_bench.err
 echo "default bench rc $?"
 for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
