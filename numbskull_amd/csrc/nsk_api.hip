@@ -1059,6 +1059,24 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
     const unsigned int tag = tag_base ? tag_off : g->p2p_tag;
     // a learning epoch's weight deltas go to every rank, so every rank is a peer of every other
     const unsigned int mask = (learn && nw > 0 && world > 1) ? (((1u << world) - 1u) & ~(1u << me)) : g->p2p_peer_mask;
+    P2PPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    for (int q = 0; q < world; q++) {
+        plan.base[q] = g->p2p_peer_base[q];
+        plan.soff[q] = (unsigned long long)g->p_soff[q];
+        plan.dbase[q] = (unsigned long long)g->p_dbase[q];
+        plan.dtotal[q] = (unsigned long long)g->p_dtotal[q];
+    }
+    for (int q = world; q <= 16; q++) plan.soff[q] = (unsigned long long)g->p_nsend;
+    if (part == 0 && mask && !learn) {          // the inference loops: push, flags, wait and unpack in one launch
+        const int64_t work = std::max(g->p_nsend, g->p_nrecv);
+        const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (work + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK)));
+        k_p2p_exchange<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
+            (VT *)g->val, (VT *)g->val_evid, 0, g->p_send_iid, (long long)g->p_nsend, plan, g->p_recv_iid, (long long)g->p_nrecv,
+            g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks);
+        HIPCHECK(hipGetLastError());
+        return NSK_OK;
+    }
     if (part != 2) {
         if (learn && nw > 0) {                  // first: the flags go up behind it
             P2PWeights pw;
@@ -1069,15 +1087,7 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
             k_p2p_push_dw<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, pw, world, me, nw, tag);
         }
         if (mask) {
-            P2PPlan pl;
-            memset(&pl, 0, sizeof(pl));
-            for (int q = 0; q < world; q++) {
-                pl.base[q] = g->p2p_peer_base[q];
-                pl.soff[q] = (unsigned long long)g->p_soff[q];
-                pl.dbase[q] = (unsigned long long)g->p_dbase[q];
-                pl.dtotal[q] = (unsigned long long)g->p_dtotal[q];
-            }
-            for (int q = world; q <= 16; q++) pl.soff[q] = (unsigned long long)g->p_nsend;
+            const P2PPlan &pl = plan;
             // at most 64 blocks (grid-stride): the closing ticket adds must not queue up
             const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (g->p_nsend + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK)));
             k_p2p_push<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const VT *)g->val, learn ? (const VT *)g->val_evid : nullptr,

@@ -141,6 +141,66 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push(const VT *val, const VT 
                            __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// One exchange in ONE launch (what the sweep loops enqueue): every block pushes its share, the last one to
+// finish raises the flags, then every block goes on to wait for the peers' flags and unpacks its share --
+// the wait depends on the peers' pushes only, so no block waits for another block of this launch.  A shard
+// of the metric config is a few 4 us kernels per sweep: one kernel less per sweep is worth having.
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_exchange(VT *val, VT *val_evid, int both, const int32_t *send_iid, long long nsend,
+                                                            P2PPlan pl, const int32_t *recv_iid, long long nrecv, const void *mine,
+                                                            int world, int me, unsigned int peer_mask, unsigned int *ticket,
+                                                            unsigned int tag, unsigned int *err, const unsigned long long *tag_base,
+                                                            unsigned long long timeout_ticks) {
+    if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
+    const size_t par = tag & 1u;
+    const size_t roff = nsk_p2p_recv_off(world);
+    for (long long k = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; k < nsend; k += (long long)gridDim.x * NSK_BLOCK) {
+        int q = 0;
+        while (q + 1 < world && (unsigned long long)k >= pl.soff[q + 1]) q++;
+        const size_t tot = (size_t)pl.dtotal[q];
+        VT *dst = (VT *)((char *)pl.base[q] + roff) + par * 2 * tot + (size_t)pl.dbase[q] + (size_t)((unsigned long long)k - pl.soff[q]);
+        const int id = send_iid[k];
+        dst[0] = val[id];
+        if (both) dst[tot] = val_evid[id];
+    }
+    __threadfence_system();
+    __syncthreads();
+    __shared__ unsigned int last;
+    __shared__ int ok;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last) {
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        if (threadIdx.x < (unsigned)world && ((peer_mask >> threadIdx.x) & 1u))
+            __hip_atomic_store((unsigned int *)pl.base[threadIdx.x] + par * (size_t)world + (size_t)me, tag, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) {
+        ok = 1;
+        const unsigned long long t0 = wall_clock64();
+        const unsigned int *flags = (const unsigned int *)mine;
+        for (int q = 0; q < world && ok; q++) {
+            if (!((peer_mask >> q) & 1u)) continue;
+            const unsigned int *f = flags + par * (size_t)world + (size_t)q;
+            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+                if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (!ok) *err = 1u;
+    }
+    __syncthreads();
+    if (!ok) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the payload was written by another agent
+    const VT *rb = (const VT *)((const char *)mine + roff) + par * 2 * (size_t)nrecv;
+    for (long long j = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; j < nrecv; j += (long long)gridDim.x * NSK_BLOCK) {
+        const int id = recv_iid[j];
+        val[id] = __builtin_nontemporal_load(rb + j);
+        if (both) val_evid[id] = __builtin_nontemporal_load(rb + (size_t)nrecv + j);
+    }
+}
+
 // weight deltas of a learning epoch (w - w_start) into block `me` of every rank's wbuf, this rank's included
 struct P2PWeights { double *wbuf[16]; };
 static __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push_dw(const double *w, const double *w_start, P2PWeights pw,
