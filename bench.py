@@ -301,7 +301,7 @@ def roofline_bound(kernel):
     occupancy their registers allow (no unit saturated); the CSR / exp-per-update kernels by HBM."""
     if kernel.endswith("_seg_tab"):
         return "issue"
-    if kernel.endswith("_ep"):
+    if kernel.endswith("_ep") or kernel.endswith("_ep_w5"):
         return "latency"
     return "hbm"
 
@@ -333,7 +333,11 @@ def dominant_kernel(workload, learning, info):
     if not info["nfast"]:
         return "k_learn_phase" if learning else "k_gibbs_phase"
     if workload.startswith("lr") or workload.startswith("boolw"):
-        return "k_learn_ep" if learning else "k_gibbs_ep"          # entry-parallel groups (+ hubs, rest tiles)
+        if learning:
+            return "k_learn_ep"                                    # entry-parallel groups (+ hubs, rest tiles)
+        # categorical graphs whose value array stays in the L2s run the register-capped twin (nsk_gibbs.hip)
+        small = info["nvar"] * info["value_bytes"] <= (24 << 20)
+        return "k_gibbs_ep_w5" if workload.startswith("lr") and small else "k_gibbs_ep"
     if info["ztab_entries"]:
         return "k_learn_seg_tab" if learning else "k_gibbs_seg_tab"
     return "k_learn_seg" if learning else "k_gibbs_seg"

@@ -1068,30 +1068,38 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
         plan.dtotal[q] = (unsigned long long)g->p_dtotal[q];
     }
     for (int q = world; q <= 16; q++) plan.soff[q] = (unsigned long long)g->p_nsend;
-    if (part == 0 && mask && !learn) {          // the inference loops: push, flags, wait and unpack in one launch
+    auto push_dw = [&]() {                      // a learning epoch's weight deltas, before the flags go up
+        P2PWeights pw;
+        memset(&pw, 0, sizeof(pw));
+        for (int q = 0; q < world; q++)
+            pw.wbuf[q] = (double *)((char *)g->p2p_peer_base[q] + nsk_p2p_wbuf_off(world, (size_t)g->p_dtotal[q], vb));
+        const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
+        k_p2p_push_dw<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, pw, world, me, nw, tag);
+    };
+    auto merge_w = [&]() {
+        const double *wb = (const double *)((const char *)g->p2p_base + nsk_p2p_wbuf_off(world, (size_t)g->p_nrecv, vb));
+        const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
+        k_p2p_merge_w<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, wb, world, nw, tag);
+        g->weights_dirty = true;
+    };
+    if (part == 0 && mask) {                    // the sweep loops: push, flags, wait and unpack in one launch
+        if (learn && nw > 0) push_dw();
         const int64_t work = std::max(g->p_nsend, g->p_nrecv);
         const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (work + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK)));
         k_p2p_exchange<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
-            (VT *)g->val, (VT *)g->val_evid, 0, g->p_send_iid, (long long)g->p_nsend, plan, g->p_recv_iid, (long long)g->p_nrecv,
-            g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks);
+            (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->p_send_iid, (long long)g->p_nsend, plan, g->p_recv_iid,
+            (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks);
+        if (learn && nw > 0) merge_w();
         HIPCHECK(hipGetLastError());
         return NSK_OK;
     }
-    if (part != 2) {
-        if (learn && nw > 0) {                  // first: the flags go up behind it
-            P2PWeights pw;
-            memset(&pw, 0, sizeof(pw));
-            for (int q = 0; q < world; q++)
-                pw.wbuf[q] = (double *)((char *)g->p2p_peer_base[q] + nsk_p2p_wbuf_off(world, (size_t)g->p_dtotal[q], vb));
-            const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
-            k_p2p_push_dw<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, pw, world, me, nw, tag);
-        }
+    if (part != 2) {                            // (the parts on their own: tests with several handles in one process, phase timings)
+        if (learn && nw > 0) push_dw();
         if (mask) {
-            const P2PPlan &pl = plan;
             // at most 64 blocks (grid-stride): the closing ticket adds must not queue up
             const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (g->p_nsend + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK)));
             k_p2p_push<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const VT *)g->val, learn ? (const VT *)g->val_evid : nullptr,
-                                                                       g->p_send_iid, (long long)g->p_nsend, pl, world, me, mask,
+                                                                       g->p_send_iid, (long long)g->p_nsend, plan, world, me, mask,
                                                                        g->p2p_err + 1, tag, tag_base);
         }
     }
@@ -1102,12 +1110,7 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
                 (VT *)g->val, learn ? (VT *)g->val_evid : nullptr, g->p_recv_iid, (long long)g->p_nrecv, g->p2p_base, world,
                 mask, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks);
         }
-        if (learn && nw > 0) {
-            const double *wb = (const double *)((const char *)g->p2p_base + nsk_p2p_wbuf_off(world, (size_t)g->p_nrecv, vb));
-            const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
-            k_p2p_merge_w<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, wb, world, nw, tag);
-            g->weights_dirty = true;
-        }
+        if (learn && nw > 0) merge_w();
     }
     HIPCHECK(hipGetLastError());
     return NSK_OK;
