@@ -120,8 +120,11 @@ int nsk_set_learn_cap(nsk_graph *g, double cap);
  * stream beside the sampling of class c + 1, which therefore sees the weights as of the end of class
  * c - 1 -- milder than the staleness of the reference's own Hogwild threads and of its distributed merge
  * (one epoch, salt/src/numbskull_master.py:223-224).  The pipeline is drained at the end of every
- * nsk_learn_sweeps call (the weights it leaves include every update).  lag = 0: every class waits for the
- * previous class's update.  Same fixed point either way; the oracle's device mode mirrors both. */
+ * nsk_learn_sweeps call (the weights it leaves include every update).  It applies to handles with at most
+ * 256 weights (they accumulate in LDS and the update rides in the next class's launch: the grids); with a
+ * larger weight table the update is a launch of its own either way and every class waits for it
+ * (nsk_graph_info.learn_lag says which).  lag = 0: every class waits for the previous class's update.  Same
+ * fixed point either way; the oracle's device mode mirrors both. */
 int nsk_set_learn_lag(nsk_graph *g, int lag);
 
 /* Replaces run_pool(gibbsthread) at factorgraph.py:141 (burnin=1) and :163 (burnin=0):
@@ -154,6 +157,13 @@ typedef struct {
                                          graph that accumulates in LDS or a device that failed it; +16
                                          when the LDS path's bins are private to XCDs; 0 from
                                          nsk_graph_plan (no device)                                */
+    int64_t learn_lag;                /* 1: learning sweeps of this handle run with the one-class lag
+                                         (nsk_set_learn_lag on AND at most 256 weights: the update then
+                                         rides in the next class's launch); 0: every class waits for the
+                                         previous class's update                                    */
+    int64_t direct_weights;           /* weights with a single factor that the learning kernels update in
+                                         place at their one visit per class (no accumulator, no update
+                                         launch for them); 0: none                                 */
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);

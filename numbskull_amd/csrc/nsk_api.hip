@@ -249,6 +249,10 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     UP(w_fixed); UP(logtab); UP(adj); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
+    if (c.ndirect > 0) {
+        rc = dev_upload(g, &g->w_direct, c.w_direct); if (rc) return rc;
+        rc = dev_upload(g, &g->multi_wids, c.multi_wids); if (rc) return rc;
+    }
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes, nid = (size_t)c.nid;
     uint8_t *tmp = nullptr;
     rc = dev_alloc(g, &tmp, npos * vb); if (rc) return rc; g->p_init = tmp;
@@ -643,6 +647,8 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->learn_clipped = 0;
     info->grad_shift = c.grad_shift;
     info->acc_copies = 0;
+    info->learn_lag = (c.nweight > 0 && c.nweight <= NSK_SMALLW) ? 1 : 0;
+    info->direct_weights = c.ndirect;
 }
 
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
@@ -659,6 +665,7 @@ int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
     }
     info->compile_seconds = g->compile_seconds;
     info->acc_copies = g->acc_copies + (g->bins_xcd ? 16 : 0);
+    info->learn_lag = (g->learn_lag && g->smallw) ? 1 : 0;
     return NSK_OK;
 }
 

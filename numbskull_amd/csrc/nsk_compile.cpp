@@ -1150,6 +1150,33 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         lap("tile shapes (pass 1)");
         c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
+        // ---- direct weights (nsk_compile.h w_direct)
+        c.w_direct.clear(); c.multi_wids.clear(); c.ndirect = 0;
+        if (nw > 256 && !diag_env("NSK_NO_DIRECT")) {
+            std::vector<uint8_t> nfac_of((size_t)nw, 0);                 // factors per weight, saturating at 2
+            for (int64_t f = 0; f < nfac; f++) {
+                const int64_t wid = d->factor[f].weightId;
+                if (wid >= 0 && wid < nw && nfac_of[(size_t)wid] < 2) nfac_of[(size_t)wid]++;
+            }
+            for (int64_t t = 0; t < nwb; t++) {                          // weights named by uniform tiles' programs
+                const uint32_t *td = &c.tiles[4 * t];
+                if (td[2] == 0xFFFFFFFFu || ((td[3] >> 8) & 7u) >= 6u) continue;
+                for (uint32_t j = 0; j < (td[3] & 0xFFu); j++) {
+                    const uint32_t wid = c.tile_hdr[td[2] + j] & 0xFFFFFFu;
+                    if ((int64_t)wid < nw) nfac_of[wid] = 2;
+                }
+            }
+            int64_t nd = 0;
+            for (int64_t w = 0; w < nw; w++) nd += (nfac_of[(size_t)w] == 1 && !c.w_fixed[(size_t)w]) ? 1 : 0;
+            if (2 * nd >= nw) {
+                c.w_direct.assign((size_t)(nw + 31) / 32, 0u);
+                for (int64_t w = 0; w < nw; w++) {
+                    if (nfac_of[(size_t)w] == 1 && !c.w_fixed[(size_t)w]) c.w_direct[(size_t)w >> 5] |= 1u << (w & 31);
+                    else c.multi_wids.push_back((int32_t)w);
+                }
+                c.ndirect = nd;
+            }
+        }
         c.phase_gen_bin_tile.assign((size_t)ncolors, 0);
         for (int32_t k = 0; k < ncolors; k++) {
             int64_t t = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
@@ -1412,7 +1439,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // structural visit counts (nsk_compile.h ep_kstat): global accumulators only (graphs with few
         // weights accumulate in LDS tables, where an update costs nothing); counted in pass B (atomic
         // increments: a weight's entries are spread over the groups, contention is negligible)
-        const bool want_kstat = ngroups > 0 && nw > 256 && (int64_t)ncolors * nw * 2 <= ((int64_t)1 << 26) && !diag_env("NSK_NO_KSTAT");
+        const bool want_kstat = ngroups > 0 && nw > 256 && (int64_t)ncolors * nw * 2 <= ((int64_t)1 << 26) && !diag_env("NSK_NO_KSTAT") &&
+                                c.ndirect == 0;      // (direct weights are updated at their visit: every visit must reach the kernel)
         if (want_kstat) c.ep_kstat.assign((size_t)ncolors * 2 * (size_t)nw, 0u);
         lap("entry-parallel groups: allocation");
         parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass B: fill

@@ -183,6 +183,15 @@ struct Compiled {
     // weights
     std::vector<double> w_init;
     std::vector<uint8_t> w_fixed;
+    // Weights with ONE factor ("direct"): the members of a factor sit in different colour classes, so such a
+    // weight has at most one visit per class and the learning kernels apply its update in place at that
+    // visit -- no accumulator, no pass of the update launch over it.  Enabled when at least half of the
+    // weights qualify (one weight per factor: feature-weighted graphs); bit w of w_direct; multi_wids = the
+    // other weights, the only ones the update launch then walks.  Weights that a uniform tile's program
+    // names stay with the accumulators (those kernels sum per tile, not per visit).
+    std::vector<uint32_t> w_direct;
+    std::vector<int32_t> multi_wids;
+    int64_t ndirect = 0;
     std::vector<double> logtab;
     // multi-GPU: variables outside the owned range that the sampled variables read (sorted)
     std::vector<int32_t> ghost_needs;

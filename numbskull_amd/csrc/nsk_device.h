@@ -230,6 +230,12 @@ struct DevGraph {
     // gradient sum in one class would overflow Q31.32 (nsk_compile.cpp grad_shift)
     long long grad_mul;         // 2^(32-s)
     double grad_inv;            // 2^-(32-s)
+    // direct weights (nsk_compile.h w_direct): bit w set = weight w has one factor, hence at most one visit per
+    // colour class, and the kernel applies its update at that visit with the class's parameters below
+    const uint32_t *w_direct;   // null: none
+    double upd_step, upd_reg_param, upd_truncation, upd_cap;
+    int32_t upd_regularization;
+    unsigned int *upd_clipped;
     // fast path: inlined adjacency streams (DESIGN.md "fast path") and a position-indexed tally
     const uint4 *adj;           // stream: chunk c of lane i of a tile at adj[off + 64*c + i]
     const uint4 *tiles;         // [nwb] {stream offset, words per lane, tile_hdr offset | PAD, entries}
@@ -755,6 +761,12 @@ struct GradSink {
     // per visit instead of two atomics (global accumulators only; nsk_compile.cpp decides)
     bool packed;
     bool local;         // LDS tables or an XCD-private copy: workgroup-scope adds (sink_add)
+    // direct weights (DevGraph::w_direct): updated in place at their one visit of the class
+    const uint32_t *w_direct;
+    double *w;
+    double step, reg_param, truncation, cap, grad_inv;
+    int regularization;
+    unsigned int *clipped;
 };
 
 // The accumulators of a sink live in LDS (SMALLW) or in the XCD-private copy of the global tables
@@ -774,6 +786,47 @@ __device__ __forceinline__ void sink_add(bool local, uint32_t *p, uint32_t v) {
     else (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// a^k by binary exponentiation: the operation sequence of oracle powi_det
+__device__ __forceinline__ double powi_det(double a, unsigned long long k) {
+    double r = 1.0, b = a;
+    while (k) {
+        if (k & 1) r *= b;
+        k >>= 1;
+        if (k) b *= b;
+    }
+    return r;
+}
+
+// The weight update of learning.py:110-125 applied to a whole colour class at once
+// (DESIGN.md "device-mode learning" gives the closed forms; the oracle restates them).
+// cap: a weight visited k times in the class would move by k * step * (mean gradient); when
+// k * step exceeds `cap` the class uses step = cap / k for that weight (DESIGN.md "device-mode
+// learning": the per-visit rule of the reference has the same fixed point and is stable at any
+// k * step because every visit sees the weight the previous one left).  cap <= 0: no clipping.
+__device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
+                                               int regularization, double reg_param, double truncation,
+                                               double cap, unsigned int *clipped, double grad_inv) {
+    const double Gf = (double)G * grad_inv;
+    if (cap > 0.0 && (double)k * step > cap) {
+        step = cap / (double)k;
+        if (clipped) atomicAdd(clipped, 1u);
+    }
+    if (regularization == 2) {
+        const double a = 1.0 / (1.0 + reg_param * step);
+        x = powi_det(a, (unsigned long long)k) * x;
+        x = x - step * Gf;
+    } else if (regularization == 1) {
+        x = x - step * Gf;
+        if (t > 0) {
+            const double l1 = (reg_param * step * truncation) * (double)t;
+            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
+        }
+    } else {
+        x = x - step * Gf;
+    }
+    return x;
+}
+
 // Add one (weight, gradient) visit per participating lane.  Must be called by all 64 lanes of the
 // wave (converged); `have` marks participating lanes.  Lanes sharing the leader's weight id are
 // reduced in registers first.
@@ -781,6 +834,13 @@ __device__ __forceinline__ void sink_add(bool local, uint32_t *p, uint32_t v) {
 // weight update, nsk_compile.h ep_kstat -- only its gradient is added).
 __device__ __forceinline__ void accumulate_gradient(const GradSink &sk, bool have, int wid,
                                                     long long gfix, bool trunc, bool count = true) {
+    if (sk.w_direct) {          // a weight with one factor: this is its only visit of the class -- update it here
+        const bool dir = have && ((sk.w_direct[(uint32_t)wid >> 5] >> ((uint32_t)wid & 31u)) & 1u);
+        if (dir)
+            sk.w[wid] = apply_update(sk.w[wid], gfix, 1u, trunc ? 1u : 0u, sk.step, sk.regularization, sk.reg_param,
+                                     sk.truncation, sk.cap, sk.clipped, sk.grad_inv);
+        have = have && !dir;
+    }
     const unsigned long long mask = __ballot(have);
     if (mask == 0) return;
     const int leader = __ffsll((long long)mask) - 1;
@@ -804,17 +864,6 @@ __device__ __forceinline__ void accumulate_gradient(const GradSink &sk, bool hav
         if (!sk.packed && count) sink_add(sk.local, &sk.K[wid], 1u);
         if (trunc) sink_add(sk.local, &sk.T[wid], 1u);
     }
-}
-
-// a^k by binary exponentiation: the operation sequence of oracle powi_det
-__device__ __forceinline__ double powi_det(double a, unsigned long long k) {
-    double r = 1.0, b = a;
-    while (k) {
-        if (k & 1) r *= b;
-        k >>= 1;
-        if (k) b *= b;
-    }
-    return r;
 }
 
 }  // namespace nsk

@@ -59,6 +59,8 @@ struct nsk_graph {
             *v_pos = nullptr;
     double *f_feat = nullptr, *w = nullptr, *logtab = nullptr;
     uint8_t *w_fixed = nullptr;
+    uint32_t *w_direct = nullptr;      // bit per weight: updated in place by the learning kernels (nsk_compile.h)
+    int32_t *multi_wids = nullptr;     // the other weights: what k_apply_weights walks then
     void *val = nullptr, *val_evid = nullptr;
     int32_t *cnt = nullptr;
     uint8_t *cnt_pos = nullptr;
@@ -180,6 +182,9 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.ep_wrow = g->ep_wrow; d.ep_wt = g->ep_wt;
     d.ep_kstat = g->c.ep_kstat.empty() ? nullptr : g->ep_kstat;
     d.seg_aff = (const uint4 *)g->seg_aff;
+    d.w_direct = g->c.ndirect > 0 ? g->w_direct : nullptr;
+    d.upd_step = 0.0; d.upd_reg_param = 0.0; d.upd_truncation = 1.0; d.upd_cap = 0.0; d.upd_regularization = 0;
+    d.upd_clipped = g->clip_count;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;
     return d;

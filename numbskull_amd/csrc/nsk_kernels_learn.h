@@ -41,6 +41,10 @@ __device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem)
     }
     sk.local = SMALLW || g.acc_copies > 1;
     sk.packed = !SMALLW && g.packed_grad != 0;
+    sk.w_direct = SMALLW ? nullptr : g.w_direct;
+    sk.w = g.w;
+    sk.step = g.upd_step; sk.reg_param = g.upd_reg_param; sk.truncation = g.upd_truncation; sk.cap = g.upd_cap;
+    sk.grad_inv = g.grad_inv; sk.regularization = g.upd_regularization; sk.clipped = g.upd_clipped;
     return sk;
 }
 
@@ -661,36 +665,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
         learn_tile<VT, KIND>(g, sk, sp, 4 * NCH, en.prog, p, valid, lp);
     }
     close_sink<SMALLW>(g, sk);
-}
-
-// The weight update of learning.py:110-125 applied to a whole colour class at once
-// (DESIGN.md "device-mode learning" gives the closed forms; the oracle restates them).
-// cap: a weight visited k times in the class would move by k * step * (mean gradient); when
-// k * step exceeds `cap` the class uses step = cap / k for that weight (DESIGN.md "device-mode
-// learning": the per-visit rule of the reference has the same fixed point and is stable at any
-// k * step because every visit sees the weight the previous one left).  cap <= 0: no clipping.
-__device__ __forceinline__ double apply_update(double x, long long G, uint32_t k, uint32_t t, double step,
-                                               int regularization, double reg_param, double truncation,
-                                               double cap, unsigned int *clipped, double grad_inv) {
-    const double Gf = (double)G * grad_inv;
-    if (cap > 0.0 && (double)k * step > cap) {
-        step = cap / (double)k;
-        if (clipped) atomicAdd(clipped, 1u);
-    }
-    if (regularization == 2) {
-        const double a = 1.0 / (1.0 + reg_param * step);
-        x = powi_det(a, (unsigned long long)k) * x;
-        x = x - step * Gf;
-    } else if (regularization == 1) {
-        x = x - step * Gf;
-        if (t > 0) {
-            const double l1 = (reg_param * step * truncation) * (double)t;
-            x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
-        }
-    } else {
-        x = x - step * Gf;
-    }
-    return x;
 }
 
 // SMALLW: one block adds up the bins of every weight (and clears them), applies the update,
@@ -1319,9 +1293,12 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, c
                                                              int regularization, double reg_param,
                                                              double truncation, int packed, double cap,
                                                              unsigned int *clipped, int copies, double grad_inv,
-                                                             const uint32_t *kstat_ev, const uint32_t *kstat_other) {
-    const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
-    if (i >= nweight) return;
+                                                             const uint32_t *kstat_ev, const uint32_t *kstat_other,
+                                                             const int32_t *widx, int nidx) {
+    // widx: the weights to walk (the ones that are not updated in place, nsk_compile.h multi_wids); null: all
+    const int at_ = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (at_ >= (widx ? nidx : nweight)) return;
+    const int i = widx ? widx[at_] : at_;
     long long gsum = 0;
     // structural visit counts of the class (nsk_compile.h ep_kstat): visits the kernels did not count
     unsigned long long k = (kstat_ev ? (unsigned long long)kstat_ev[i] : 0ull) +

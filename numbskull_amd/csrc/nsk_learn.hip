@@ -46,7 +46,10 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
     // k_learn_seg_tab, beside the sampling), else as a launch of its own after the class.  Both sets start
     // from the call's weights.  (A second stream with events around every class cost more than the update:
     // 34 against 28.5 us per 10M-grid class.)
-    const bool lag = g->learn_lag && nw > 0;
+    // (only handles that accumulate in LDS -- at most NSK_SMALLW weights: the grids -- run lagged: there the
+    // update rides in the next class's launch; with a large weight table it is a launch of its own either
+    // way, and the in-kernel updates of single-factor weights below want one weight set)
+    const bool lag = g->learn_lag && nw > 0 && SMALLW;
     DevGraph<VT> dv[2];
     dv[0] = view<VT>(g);
     dv[1] = dv[0];
@@ -79,12 +82,18 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
 #endif
             if (g->c.nfast > 0 && !u.tabs_here) nsk_refresh_ztab(g, u.set, g->stream);   // big tables: own launch
         } else {
-            k_apply_weights<<<dim3((nw + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
-                du.w, u.aa.w_in, du.G, du.K, du.T, nw, u.step, regularization, reg_param, (double)truncation,
-                (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies, du.grad_inv,
-                u.kstat ? du.ep_kstat + (size_t)(2 * u.ph) * (size_t)nw : nullptr,
-                (u.kstat && learn_non_evidence) ? du.ep_kstat + (size_t)(2 * u.ph + 1) * (size_t)nw : nullptr);
-            refresh_after_update(g, u.set, g->stream);
+            // (with direct weights only the others are walked -- none at all when every weight has one factor)
+            const bool direct = g->c.ndirect > 0;
+            const int nwalk = direct ? (int)g->c.multi_wids.size() : nw;
+            if (nwalk > 0) {
+                k_apply_weights<<<dim3((nwalk + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
+                    du.w, u.aa.w_in, du.G, du.K, du.T, nw, u.step, regularization, reg_param, (double)truncation,
+                    (!SMALLW && g->c.packed_grad) ? 1 : 0, g->learn_cap, g->clip_count, g->acc_copies, du.grad_inv,
+                    u.kstat ? du.ep_kstat + (size_t)(2 * u.ph) * (size_t)nw : nullptr,
+                    (u.kstat && learn_non_evidence) ? du.ep_kstat + (size_t)(2 * u.ph + 1) * (size_t)nw : nullptr,
+                    direct ? g->multi_wids : nullptr, nwalk);
+                refresh_after_update(g, u.set, g->stream);
+            }
         }
     };
     ApplyArgs no_update;
@@ -96,7 +105,10 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             const int e = (int)g->c.phase_end[ph];
             if (e <= fb) continue;
             const int set = lag ? (int)(cls & 1) : 0;
-            const DevGraph<VT> &d = dv[set];
+            DevGraph<VT> d = dv[set];
+            // the parameters of this class's update, for the weights the kernels update in place (w_direct)
+            d.upd_step = step; d.upd_regularization = regularization; d.upd_reg_param = reg_param;
+            d.upd_truncation = (double)truncation; d.upd_cap = g->learn_cap;
             lp.hub0 = (int)g->c.phase_hub_base[ph];
             const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);

@@ -111,6 +111,7 @@ class Graph:
                         self.factor.ctypes.data, self.fmap.ctypes.data, self.vmap.ctypes.data,
                         self.factor_index.ctypes.data, int(bool(head_by_vid)), None, 0, 0)
         self.rng_id = None
+        self.device_lag = None          # nsk_graph_info.learn_lag of the handle this oracle shadows (tests/util.oracle_of)
         card = self.variable["cardinality"]
         self.cstart = np.zeros(len(card) + 1, np.int64)
         self.cstart[1:] = np.where(card == 2, 1, card)
@@ -201,10 +202,13 @@ class Graph:
             C.c_uint64(seed), C.c_uint64(sweep), C.c_double(cap), _p(lag))
 
     def learn_call(self, order, phase_start, var_value, var_value_evid, weight_value, nsweeps, step, decay,
-                   regularization, reg_param, truncation, learn_non_evidence, seed, sweep0, cap=0.5, lag=True):
+                   regularization, reg_param, truncation, learn_non_evidence, seed, sweep0, cap=0.5, lag=None):
         """What ONE nsk_learn_sweeps call does: ``nsweeps`` epochs from sweep index ``sweep0``, step *= decay
-        after each (factorgraph.py:206), the one-class lag pipeline (``lag``; the device's default) started
-        from the call's weights and drained into them at its end."""
+        after each (factorgraph.py:206), the one-class lag pipeline (``lag``) started from the call's weights
+        and drained into them at its end.  ``lag=None``: the device's default -- lagged iff the graph has at
+        most 256 weights (nsk_graph_info.learn_lag; ``self.device_lag`` when oracle_of set it)."""
+        if lag is None:
+            lag = self.device_lag if self.device_lag is not None else len(weight_value) <= 256
         lagw = np.ascontiguousarray(weight_value, np.float64).copy() if lag else None
         for s in range(nsweeps):
             rc = self.learn_dev(order, phase_start, var_value, var_value_evid, weight_value, step, regularization,

@@ -803,6 +803,47 @@ def test_two_partitions_on_one_gpu_match_emulation(learn):
             assert np.allclose(parts[r].w.cpu().numpy(), wv, rtol=0, atol=1e-15)
 
 
+@pytest.mark.parametrize("reg", [0, 1, 2])
+@pytest.mark.parametrize("shared", [False, True])
+def test_weights_with_one_factor_are_updated_in_place(reg, shared):
+    """One weight per factor (feature-weighted graphs): the members of a factor lie in different colour
+    classes, so such a weight has at most one visit per class and the learning kernels apply its update at
+    that visit -- no accumulator, no pass of the update launch over it (nsk_graph_info.direct_weights).  Same
+    arithmetic as the per-class rule with K = 1: weights, both chains bit-exact vs the oracle; with `shared`
+    a third of the factors are tied to 50 common weights (those keep the accumulators)."""
+    g = list(graphgen.boolean_weighted_graph(3000, seed=4))
+    rng = np.random.Generator(np.random.PCG64(8))
+    w = g[0].copy()
+    w["isFixed"] = False
+    w["initialValue"] = 0.0
+    w["isFixed"][::17] = True                              # a few fixed ones stay out of it
+    g[0] = w
+    v = g[1].copy()
+    v["isEvidence"] = rng.random(len(v)) < 0.5
+    v["initialValue"] = rng.integers(0, 2, len(v))
+    g[1] = v
+    if shared:
+        f = g[2].copy()
+        pick = rng.random(len(f)) < 0.33
+        f["weightId"][pick] = rng.integers(0, 50, int(pick.sum()))
+        g[2] = f
+    ns, fg = session(tuple(g), seed=6)
+    info = fg.info()
+    assert info["direct_weights"] > len(w) // 2 and info["learn_lag"] == 0
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, cnt = og.initial_state()
+    fg.learn(0, 4, 0.02, 0.9, reg, 0.05, 2, learn_non_evidence=True)
+    assert og.learn_call(order, ps, vv, ve, wv, 4, 0.02, 0.9, reg, 0.05, 2, True, 6, 0) == 0
+    assert np.array_equal(fg.weight_value[0], wv)
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    assert np.abs(wv).max() > 0 and (wv[::17] == 0).all()
+    fg.inference(0, 3, True)                               # the weights the kernels left are the ones inference reads
+    for s in range(4, 7):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 6, s, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
 def test_table_segments_do_not_read_position_zero():
     """The draw-table kernels take a member's value as its neighbourhood bit.  The ignored slot of a
     member-less entry (ISTRUE) and the padding of a uniform tile used to read "variable 0": with a
@@ -1014,7 +1055,8 @@ def test_learning_without_the_one_class_lag(golden, name):
         order, ps = phases_from_colors(fg.colors())
         vv, ve, wv, _ = og.initial_state()
         fg.learn(0, 4, 0.01, 0.9, 2, 0.05, 1, learn_non_evidence=True)
-        assert og.learn_call(order, ps, vv, ve, wv, 4, 0.01, 0.9, 2, 0.05, 1, True, 5, 0, lag=lag) == 0
+        assert fg.info()["learn_lag"] == int(lag and len(wv) <= 256)      # (large weight tables never lag)
+        assert og.learn_call(order, ps, vv, ve, wv, 4, 0.01, 0.9, 2, 0.05, 1, True, 5, 0, lag=lag and len(wv) <= 256) == 0
         assert np.array_equal(fg.weight_value[0], wv) and np.array_equal(fg.var_value[0], vv)
         assert np.array_equal(fg.var_value_evid[0], ve)
         out[lag] = wv.copy()

@@ -53,7 +53,9 @@ def oracle_of(fg, head_by_vid=False, layout=True):
         if fg.global_ids is not None and fg.own_range is not None and len(fg.global_ids):     # shard-local graph
             tag = int(fg.global_ids[tag]) if tag < len(fg.global_ids) else int(fg.global_ids[-1]) + 1
         og.set_rng_tag(tag)
-        og.set_grad_shift(fg.info()["grad_shift"])
+        info = fg.info()
+        og.set_grad_shift(info["grad_shift"])
+        og.device_lag = bool(info["learn_lag"])
     return og
 
 
