@@ -1176,6 +1176,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 }
                 c.ndirect = nd;
             }
+            if (verbose) fprintf(stderr, "[nsk] weights with one factor %lld of %lld: %s\n", (long long)nd, (long long)nw,
+                                 c.ndirect ? "updated in place" : "too few, accumulators for all");
         }
         c.phase_gen_bin_tile.assign((size_t)ncolors, 0);
         for (int32_t k = 0; k < ncolors; k++) {

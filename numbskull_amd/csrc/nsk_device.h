@@ -234,6 +234,8 @@ struct DevGraph {
     // colour class, and the kernel applies its update at that visit with the class's parameters below
     const uint32_t *w_direct;   // null: none
     double upd_step, upd_reg_param, upd_truncation, upd_cap;
+    double upd_a1;              // 1 / (1 + reg_param * step): the L2 factor of a single visit (the same division the
+                                //  update launch and the oracle perform, done once on the host)
     int32_t upd_regularization;
     unsigned int *upd_clipped;
     // fast path: inlined adjacency streams (DESIGN.md "fast path") and a position-indexed tally
@@ -764,7 +766,7 @@ struct GradSink {
     // direct weights (DevGraph::w_direct): updated in place at their one visit of the class
     const uint32_t *w_direct;
     double *w;
-    double step, reg_param, truncation, cap, grad_inv;
+    double step, reg_param, truncation, cap, grad_inv, a1;
     int regularization;
     unsigned int *clipped;
 };
@@ -833,12 +835,31 @@ __device__ __forceinline__ double apply_update(double x, long long G, uint32_t k
 // `count`: the lane's visit adds to the visit count K (false: the visit is counted structurally by the
 // weight update, nsk_compile.h ep_kstat -- only its gradient is added).
 __device__ __forceinline__ void accumulate_gradient(const GradSink &sk, bool have, int wid,
-                                                    long long gfix, bool trunc, bool count = true) {
+                                                    long long gfix, bool trunc, bool count = true,
+                                                    bool have_w = false, double wval = 0.0) {
+    // have_w: the caller still holds the weight's value (`wval`: gathered for the potentials, unchanged since)
     if (sk.w_direct) {          // a weight with one factor: this is its only visit of the class -- update it here
         const bool dir = have && ((sk.w_direct[(uint32_t)wid >> 5] >> ((uint32_t)wid & 31u)) & 1u);
-        if (dir)
-            sk.w[wid] = apply_update(sk.w[wid], gfix, 1u, trunc ? 1u : 0u, sk.step, sk.regularization, sk.reg_param,
-                                     sk.truncation, sk.cap, sk.clipped, sk.grad_inv);
+        if (dir) {
+            double x = have_w ? wval : sk.w[wid];
+            if (sk.cap > 0.0 && sk.step > sk.cap) {         // (a step beyond the cap: the general rule, counts the clip)
+                x = apply_update(x, gfix, 1u, trunc ? 1u : 0u, sk.step, sk.regularization, sk.reg_param,
+                                 sk.truncation, sk.cap, sk.clipped, sk.grad_inv);
+            } else {                                        // apply_update with k = 1, its division hoisted (a1)
+                const double Gf = (double)gfix * sk.grad_inv;
+                if (sk.regularization == 2) {
+                    x = sk.a1 * x;                          // powi_det(a, 1) * x = (1.0 * a) * x
+                    x = x - sk.step * Gf;
+                } else {
+                    x = x - sk.step * Gf;
+                    if (sk.regularization == 1 && trunc) {
+                        const double l1 = (sk.reg_param * sk.step * sk.truncation) * 1.0;
+                        x = (x > 0) ? fmax(0.0, x - l1) : fmin(0.0, x + l1);
+                    }
+                }
+            }
+            sk.w[wid] = x;
+        }
         have = have && !dir;
     }
     const unsigned long long mask = __ballot(have);

@@ -183,7 +183,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.ep_kstat = g->c.ep_kstat.empty() ? nullptr : g->ep_kstat;
     d.seg_aff = (const uint4 *)g->seg_aff;
     d.w_direct = g->c.ndirect > 0 ? g->w_direct : nullptr;
-    d.upd_step = 0.0; d.upd_reg_param = 0.0; d.upd_truncation = 1.0; d.upd_cap = 0.0; d.upd_regularization = 0;
+    d.upd_step = 0.0; d.upd_reg_param = 0.0; d.upd_truncation = 1.0; d.upd_cap = 0.0; d.upd_regularization = 0; d.upd_a1 = 1.0;
     d.upd_clipped = g->clip_count;
     d.nvar = (int32_t)g->c.nvar;
     d.head_by_vid = (g->c.flags & NSK_FLAG_HEAD_BY_VID) ? 1 : 0;

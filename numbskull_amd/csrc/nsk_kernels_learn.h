@@ -44,7 +44,7 @@ __device__ __forceinline__ GradSink open_sink(const DevGraph<VT> &g, char *smem)
     sk.w_direct = SMALLW ? nullptr : g.w_direct;
     sk.w = g.w;
     sk.step = g.upd_step; sk.reg_param = g.upd_reg_param; sk.truncation = g.upd_truncation; sk.cap = g.upd_cap;
-    sk.grad_inv = g.grad_inv; sk.regularization = g.upd_regularization; sk.clipped = g.upd_clipped;
+    sk.grad_inv = g.grad_inv; sk.regularization = g.upd_regularization; sk.clipped = g.upd_clipped; sk.a1 = g.upd_a1;
     return sk;
 }
 
@@ -1205,7 +1205,9 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
 #ifdef NSK_ABL_NOATOMIC
                 if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
 #else
-                accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * g.grad_mul, (sv & 512u) != 0u, !counted);
+                // (the entry's weight is still in its LDS slot from phase 1: a weight updated in place needs no reload)
+                accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * g.grad_mul, (sv & 512u) != 0u, !counted,
+                                    sk.w_direct != nullptr, sk.w_direct ? ws[NSK_EP_SLOT(w0, d1)] : 0.0);
 #endif
             });
     };

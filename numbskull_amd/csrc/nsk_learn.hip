@@ -109,6 +109,7 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             // the parameters of this class's update, for the weights the kernels update in place (w_direct)
             d.upd_step = step; d.upd_regularization = regularization; d.upd_reg_param = reg_param;
             d.upd_truncation = (double)truncation; d.upd_cap = g->learn_cap;
+            d.upd_a1 = 1.0 / (1.0 + reg_param * step);
             lp.hub0 = (int)g->c.phase_hub_base[ph];
             const int ntiles = (int)(g->c.phase_wb_base[ph + 1] - g->c.phase_wb_base[ph]);
             const int ndyn = (int)(g->c.phase_dyn_base[ph + 1] - g->c.phase_dyn_base[ph]);
