@@ -163,11 +163,12 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
             lp.kstat = kstat_here ? 1 : 0;
             if (ep) {                   // entry-parallel groups: hubs, the general tiles and the rest tiles
                 const int ngroups = (int)(g->c.phase_ep_base[ph + 1] - g->c.phase_ep_base[ph]);
-                // grid: 7 workgroups per CU (3 or 4 are resident -- 153 / 111 vector registers --, the others
-                // start as those end: dynamic dealing of uneven groups).  Per class on the 5M LR graph
-                // (NSK_EP_PER_CU): 3 workgroups per CU 142.4 us, 4 149.2, 5 139.5, 6 135.4, 7 134.2
+                // grid: 10 workgroups per CU (3 or 4 are resident -- 153 / 111 vector registers --, the others
+                // start as those end: dynamic dealing of uneven groups).  Per class (NSK_EP_PER_CU), 5M LR graph:
+                // 3 workgroups per CU 142.4 us, 4 149.2, 5 139.5, 6 135.4, 7 134.2, 8 132.9, 10 134.7, 16 135.6;
+                // 50M LR graph: 4 1362 us, 7 1247, 10 1189
                 const char *pcu_env = nsk::diag_env("NSK_EP_PER_CU");            // (diagnostic: workgroups per CU)
-                const int per_cu = pcu_env ? std::max(1, std::min(32, atoi(pcu_env))) : 7;
+                const int per_cu = pcu_env ? std::max(1, std::min(32, atoi(pcu_env))) : 10;
                 const int gblocks = 8 * ((std::min(256 * per_cu, ngroups) + 7) / 8);
                 const int nbh = (int)(g->c.phase_bighub_base[ph + 1] - g->c.phase_bighub_base[ph]);   // a block per long-list hub
                 const int hbl_ep = nbh + hbl;
