@@ -63,7 +63,7 @@ fi
 [ $STAGE = profile ] && { ls $OUT; exit 0; }
 python bench.py > $OUT/${RT}_default_bench.json 2> $OUT/${RT}_default_bench.err
 echo "default bench rc $?"
-for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
+for WL in ${NSK_PROFILE_BENCH_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
   [ $WL = ising10m ] && continue        # (the default line)
   python bench.py --workload $WL --steps 100 --warmup 10 --no-extra > $OUT/${RT}_${WL}_bench.json 2> /dev/null
   echo "bench $WL rc $?"
