@@ -180,6 +180,14 @@ int nsk_graph_get_layout(nsk_graph *g, int32_t *iid, int64_t *nid);
  * the pair scheme described at nsk_set_seed.  What a checker needs to reproduce the samples. */
 int nsk_graph_get_generators(nsk_graph *g, int64_t *gen);
 
+/* Weight slots: where the device table (NSK_BUF_WEIGHT) keeps each weight, slot[w] for the caller's id w
+ * (nweight entries).  The identity except on whole-graph handles that update single-factor weights in place
+ * (nsk_graph_info.direct_weights): there those weights are numbered among themselves in the order the layout
+ * first meets them, so that the entries a workgroup walks read and update neighbouring slots.
+ * nsk_state_upload / nsk_state_download always speak the caller's ids.  Returns 1 when some slot differs
+ * from its id, 0 for the identity, < 0 on error. */
+int nsk_graph_get_weight_slots(nsk_graph *g, int64_t *slot);
+
 /* Host-only planning (no GPU touched): validate + colour the graph exactly as nsk_graph_create
  * would and report the colours / sizes.  `color` (nvar entries, may be NULL) gets -1 for variables
  * this handle does not sample. */

@@ -23,7 +23,7 @@ BUF_VALUE, BUF_VALUE_EVID, BUF_WEIGHT, BUF_SEND, BUF_RECV, BUF_SEND_EVID, BUF_RE
 SYMBOLS = (
     "nsk_graph_create", "nsk_graph_destroy", "nsk_state_upload", "nsk_state_download",
     "nsk_set_seed", "nsk_set_rng_tag", "nsk_set_scan", "nsk_set_learn_cap", "nsk_set_learn_lag", "nsk_gibbs_sweeps", "nsk_learn_sweeps", "nsk_graph_get_info",
-    "nsk_graph_get_colors", "nsk_graph_get_layout", "nsk_graph_get_generators", "nsk_graph_plan", "nsk_graph_plan_needs", "nsk_profile_begin", "nsk_profile_end", "nsk_device_buffer",
+    "nsk_graph_get_colors", "nsk_graph_get_layout", "nsk_graph_get_generators", "nsk_graph_get_weight_slots", "nsk_graph_plan", "nsk_graph_plan_needs", "nsk_profile_begin", "nsk_profile_end", "nsk_device_buffer",
     "nsk_set_stream", "nsk_synchronize", "nsk_ghost_needs", "nsk_exchange_setup", "nsk_exchange_pack",
     "nsk_exchange_unpack", "nsk_comm_unique_id", "nsk_comm_init", "nsk_gibbs_sweeps_exchange",
     "nsk_learn_sweeps_exchange", "nsk_p2p_setup", "nsk_p2p_export", "nsk_p2p_import", "nsk_p2p_import_local",
@@ -89,6 +89,7 @@ def lib():
         L.nsk_graph_get_colors.argtypes = [C.c_void_p, C.c_void_p]
         L.nsk_graph_get_layout.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.nsk_graph_get_generators.argtypes = [C.c_void_p, C.c_void_p]
+        L.nsk_graph_get_weight_slots.argtypes = [C.c_void_p, C.c_void_p]
         L.nsk_graph_plan.argtypes = [C.POINTER(GraphDesc), C.c_void_p, C.POINTER(GraphInfo)]
         L.nsk_graph_plan_needs.argtypes = [C.POINTER(GraphDesc), C.POINTER(C.c_int64), C.c_void_p]
         L.nsk_profile_begin.argtypes = [C.c_void_p]

@@ -554,7 +554,16 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
         }
     }
     if (weight_value && g->c.nweight) {
-        HIPCHECK(hipMemcpyAsync(g->w, weight_value, (size_t)g->c.nweight * sizeof(double), hipMemcpyHostToDevice, g->stream));
+        const double *src = weight_value;
+        if (!g->c.wuser.empty()) {      // the device table is in slot order (nsk_compile.h wmap)
+            g->w_stage.resize((size_t)g->c.nweight);
+            const int32_t *wuser = g->c.wuser.data();
+            double *st = g->w_stage.data();
+            nsk::parallel_for(g->c.nweight, [&](int64_t b0, int64_t b1, int) { for (int64_t i = b0; i < b1; i++) st[i] = weight_value[wuser[i]]; });
+            src = st;
+        }
+        HIPCHECK(hipMemcpyAsync(g->w, src, (size_t)g->c.nweight * sizeof(double), hipMemcpyHostToDevice, g->stream));
+        if (src != weight_value) HIPCHECK(hipStreamSynchronize(g->stream));
         g->weights_dirty = true;
     }
     if (count && g->c.ncount) {
@@ -596,8 +605,18 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
     int rc;
     if (var_value && (rc = download_values(g, g->val, var_value, 0))) return rc;
     if (var_value_evid && (rc = download_values(g, g->val_evid, var_value_evid, 1))) return rc;
-    if (weight_value && g->c.nweight)
-        HIPCHECK(hipMemcpyAsync(weight_value, g->w, (size_t)g->c.nweight * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    if (weight_value && g->c.nweight) {
+        if (!g->c.wuser.empty()) {      // slot order on the device, the caller's order in `weight_value`
+            g->w_stage.resize((size_t)g->c.nweight);
+            HIPCHECK(hipMemcpyAsync(g->w_stage.data(), g->w, (size_t)g->c.nweight * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+            HIPCHECK(hipStreamSynchronize(g->stream));
+            const int32_t *wmap = g->c.wmap.data();
+            const double *st = g->w_stage.data();
+            nsk::parallel_for(g->c.nweight, [&](int64_t b0, int64_t b1, int) { for (int64_t i = b0; i < b1; i++) weight_value[i] = st[wmap[i]]; });
+        } else {
+            HIPCHECK(hipMemcpyAsync(weight_value, g->w, (size_t)g->c.nweight * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+        }
+    }
     if (count) {
         if ((rc = fold_counts(g))) return rc;
         const int64_t nc = g->c.ncount;
@@ -710,6 +729,13 @@ int nsk_graph_get_generators(nsk_graph *g, int64_t *gen) {
         gen[v] = p < 0 ? -1 : (p | ((p < c.npos && quad[(size_t)p]) ? (1ll << 40) : 0ll));
     }
     return NSK_OK;
+}
+
+int nsk_graph_get_weight_slots(nsk_graph *g, int64_t *slot) {
+    if (!g || (!slot && g->c.nweight)) return fail(NSK_E_INVALID, "null argument");
+    const Compiled &c = g->c;
+    for (int64_t w = 0; w < c.nweight; w++) slot[w] = c.wmap.empty() ? w : (int64_t)c.wmap[(size_t)w];
+    return c.wmap.empty() ? 0 : 1;
 }
 
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color) {

@@ -554,6 +554,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // name (dataloading.py:34-38); the learning sweep visits a factor once per variable
     // (learning.py:76-95), so the entry in the list of the larger value names the smaller one as its
     // `partner` (descriptor bits 19-22) and is skipped when the partner's list is selected too.
+    // the weight's slot in the device table (nsk_compile.h wmap; the caller's id until the numbering exists:
+    // eligibility and the shapes of pass 1 never look at a direct weight's id)
+    auto slot_of_weight = [&](int64_t wid) -> uint32_t {
+        return (c.wmap.empty() || wid < 0 || wid >= nw) ? (uint32_t)wid : (uint32_t)c.wmap[(size_t)wid];
+    };
     auto general_words = [&](int64_t v, std::vector<uint32_t> *out, bool hub = false, size_t hub_cap = 0) -> bool {
         const nsk_variable &var = d->variable[v];
         if (var.cardinality > 8 || var.cardinality < 2) return false;
@@ -637,7 +642,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 nwords += 2 + (size_t)others;
                 if (hub ? (++nentries > (hub_cap ? hub_cap : 256)) : (nwords > 120 || (int64_t)++nentries > gen_max_entries)) return false;
                 if (out) {
-                    out->push_back((uint32_t)fa.weightId);
+                    out->push_back(slot_of_weight(fa.weightId));
                     out->push_back((uint32_t)code | ((uint32_t)others << 4) | (role << 7) |
                                    ((uint32_t)(cat && self_deo > 0 ? self_deo : 0) << 9) | (kslot << 14) |
                                    (hbit << 18) | (partner << 19));
@@ -964,7 +969,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 if (fa.factorFunction != -1)
                     for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++)
                         if (d->fmap[l].vid != v) { out.push_back((uint32_t)d->fmap[l].vid); others++; }
-                out[at] = ((uint32_t)(fa.factorFunction + 1) << 27) | (others << 24) | (uint32_t)fa.weightId;
+                out[at] = ((uint32_t)(fa.factorFunction + 1) << 27) | (others << 24) | slot_of_weight(fa.weightId);
             }
         };
         auto headers_of = [&](const std::vector<uint32_t> &w, std::vector<uint32_t> &h) {
@@ -1178,6 +1183,49 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
             if (verbose) fprintf(stderr, "[nsk] weights with one factor %lld of %lld: %s\n", (long long)nd, (long long)nw,
                                  c.ndirect ? "updated in place" : "too few, accumulators for all");
+        }
+        // ---- internal numbering of the direct weights (nsk_compile.h wmap): the order in which the layout's
+        // positions, each walking its lists, first meet them; a weight no position names keeps the tail.  A
+        // handle that samples a range of a larger graph keeps the caller's numbering: the ranks of a
+        // distributed run add their weight tables element by element.
+        c.wmap.clear(); c.wuser.clear();
+        if (c.ndirect && ob == 0 && oe == nvar && !(d->flags & NSK_FLAG_PARTITION) && !diag_env("NSK_NO_WORDER")) {
+            auto is_direct = [&](int64_t w) { return (c.w_direct[(size_t)w >> 5] >> (w & 31)) & 1u; };
+            std::vector<uint32_t> seen((size_t)(nw + 31) / 32, 0u);
+            // (bands of 2^24 ids are numbered separately: a slot then has the bits of the id it replaces, and the
+            // 24-bit weight field of the uniform-tile words holds whatever held before)
+            std::vector<std::vector<int32_t>> order((size_t)((nw - 1) >> 24) + 1);
+            for (int64_t p = 0; p < (int64_t)c.p_vid.size(); p++) {
+                const int64_t v = c.p_vid[p];
+                if (v < 0) continue;
+                const nsk_variable &var = d->variable[v];
+                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+                for (int64_t k = 0; k < nslots; k++) {
+                    const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+                    for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                        const int64_t w = d->factor[d->factor_index[vt.factor_index_offset + j]].weightId;
+                        if (w < 0 || w >= nw || !is_direct(w) || ((seen[(size_t)w >> 5] >> (w & 31)) & 1u)) continue;
+                        seen[(size_t)w >> 5] |= 1u << (w & 31);
+                        order[(size_t)w >> 24].push_back((int32_t)w);
+                    }
+                }
+            }
+            for (int64_t w = 0; w < nw; w++)
+                if (is_direct(w) && !((seen[(size_t)w >> 5] >> (w & 31)) & 1u)) order[(size_t)w >> 24].push_back((int32_t)w);
+            c.wmap.resize((size_t)nw); c.wuser.resize((size_t)nw);
+            std::vector<size_t> taken(order.size(), 0);
+            for (int64_t w = 0; w < nw; w++) {
+                if (!is_direct(w)) { c.wmap[(size_t)w] = (int32_t)w; c.wuser[(size_t)w] = (int32_t)w; continue; }
+                const int32_t met = order[(size_t)w >> 24][taken[(size_t)w >> 24]++];
+                c.wmap[(size_t)met] = (int32_t)w;               // the k-th weight of the band met takes its k-th direct slot
+                c.wuser[(size_t)w] = met;
+            }
+            for (int64_t w = 0; w < nw; w++) c.w_init[(size_t)w] = d->weight[c.wuser[(size_t)w]].initialValue;
+            for (int64_t f = 0; f < nfac; f++) {
+                const int64_t w = d->factor[f].weightId;
+                if (w >= 0 && w < nw) c.f_rec[4 * f + 2] = (uint32_t)c.wmap[(size_t)w];
+            }
+            lap("weight numbering");
         }
         c.phase_gen_bin_tile.assign((size_t)ncolors, 0);
         for (int32_t k = 0; k < ncolors; k++) {

@@ -192,6 +192,13 @@ struct Compiled {
     std::vector<uint32_t> w_direct;
     std::vector<int32_t> multi_wids;
     int64_t ndirect = 0;
+    // Internal numbering of the direct weights (whole-graph handles): with one weight per factor the table
+    // is far larger than the caches and a variable's weights, numbered by the caller's factor order, sit
+    // one per cache line.  The direct weights are renumbered AMONG THEMSELVES (their id set is kept: w_direct,
+    // w_fixed, multi_wids and every program naming another weight stay as they are) in the order the layout
+    // first meets them, so the entries of a group read and update neighbouring slots.  wmap: caller's id ->
+    // slot in the device table (w_init is in slot order), wuser: the inverse; empty = identity.
+    std::vector<int32_t> wmap, wuser;
     std::vector<double> logtab;
     // multi-GPU: variables outside the owned range that the sampled variables read (sorted)
     std::vector<int32_t> ghost_needs;

@@ -108,6 +108,7 @@ struct nsk_graph {
     unsigned int *cnt_wide = nullptr;
     bool weights_dirty = true;      // prog_w must be rebuilt before the next fast-path launch
     bool weights_exposed = false;
+    std::vector<double> w_stage;        // host staging of weight transfers when the table is in slot order (wmap)
     bool adj_wt_skip = false;       // learning reads weights directly: skip the shape-tile rows until the next inference   // the weight buffer was handed out: assume it changes between calls
     // boundary exchange (multi-GPU)
     int xworld = 0, xrank = 0;

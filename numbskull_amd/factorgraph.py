@@ -194,6 +194,15 @@ class FactorGraph(object):
         _lib.check(_lib.lib().nsk_graph_get_generators(self._engine(), _lib.ptr(out)))
         return out
 
+    def weight_slots(self):
+        """Slot of every weight in the device table (nsk_graph_get_weight_slots); the identity unless the
+        handle renumbered its single-factor weights."""
+        out = np.zeros(self.weight.shape[0], np.int64)
+        rc = _lib.lib().nsk_graph_get_weight_slots(self._engine(), _lib.ptr(out))
+        if rc < 0:
+            _lib.check(rc)
+        return out
+
     def colors(self):
         out = np.zeros(self.variable.shape[0], np.int32)
         _lib.check(_lib.lib().nsk_graph_get_colors(self._engine(), _lib.ptr(out)))

@@ -842,6 +842,27 @@ def test_weights_with_one_factor_are_updated_in_place(reg, shared):
     for s in range(4, 7):
         assert og.gibbs_dev(order, ps, vv, wv, cnt, 6, s, True) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+    # the device table keeps these weights in the order the layout meets them (nsk_graph_get_weight_slots):
+    # a permutation of the single-factor weights among themselves, invisible through upload / download
+    slots = fg.weight_slots()
+    assert np.array_equal(np.sort(slots), np.arange(len(w))) and (slots != np.arange(len(w))).any()
+    moved = np.nonzero(slots != np.arange(len(w)))[0]
+    assert not w["isFixed"][moved].any() and not w["isFixed"][slots[moved]].any()
+    nfac_of = np.bincount(fg.factor["weightId"], minlength=len(w))
+    assert (nfac_of[moved] == 1).all() and (nfac_of[slots[moved]] == 1).all()
+    wv += rng.normal(0, 0.2, len(wv))                      # every weight distinct: the upload must place each one
+    fg.weight_value[0][:] = wv
+    fg.learn(0, 2, 0.02, 0.9, reg, 0.05, 2, learn_non_evidence=True)
+    assert og.learn_call(order, ps, vv, ve, wv, 2, 0.02, 0.9, reg, 0.05, 2, True, 6, 7) == 0
+    assert np.array_equal(fg.weight_value[0], wv)
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+
+
+def test_weight_slots_are_the_identity_on_shared_weights():
+    """Graphs whose weights are shared by many factors keep the caller's numbering."""
+    ns, fg = session(graphgen.mixed_lr_graph(3000, seed=5, nweights=400), seed=2, head_by_vid=True)
+    assert fg.info()["direct_weights"] == 0
+    assert np.array_equal(fg.weight_slots(), np.arange(400))
 
 
 def test_table_segments_do_not_read_position_zero():
