@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <unordered_map>
 
 namespace nsk {
 
@@ -708,41 +709,44 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             shp[v] = nwords <= 16 ? (h2 | 1) : 0;
         }
         });
-        typedef std::map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
+        // (hash maps: with one weight per factor every variable is a class of its own -- millions of keys;
+        //  nothing below depends on their iteration order.  The colours are independent: one thread each.)
+        typedef std::unordered_map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
         std::vector<ClassMap> classes((size_t)ncolors), shapes((size_t)ncolors);
-        for (int64_t v = 0; v < nvar; v++) {
-            const int32_t k = c.color[v];
-            if (k < 0 || fast[v] != 1) continue;
-            auto &e = classes[k][sig[v]];
-            if (e.first++ == 0) e.second = v;
-        }
         // a class gets tiles of its own when it fills at least one (64 members) -- or whatever its
         // size when the colour has only a few small classes (then padding them costs nothing
         // and no tile is left with mixed programs, e.g. the corner cells of a grid)
         std::vector<int64_t> min_class((size_t)ncolors, 64);
-        for (int32_t k = 0; k < ncolors; k++) {
+        parallel_for(ncolors, [&](int64_t kb0, int64_t kb1, int) {
+        for (int32_t k = (int32_t)kb0; k < (int32_t)kb1; k++) {
+            ClassMap &cls = classes[k], &shs = shapes[k];
+            cls.reserve((size_t)nfast_of[k]);
+            for (int64_t v = 0; v < nvar; v++) {
+                if (c.color[v] != k || fast[v] != 1) continue;
+                auto &e = cls[sig[v]];
+                if (e.first++ == 0) e.second = v;
+            }
             int64_t nsmall = 0;
-            for (auto &kv : classes[k]) if (kv.second.first < 64) nsmall++;
+            for (auto &kv : cls) if (kv.second.first < 64) nsmall++;
             if (nsmall <= 16) min_class[k] = 1;
+            // variables outside the big exact classes are grouped by shape
+            for (int64_t v = 0; v < nvar; v++) {
+                if (c.color[v] != k || fast[v] != 1 || shp[v] == 0 || cls[sig[v]].first >= min_class[k]) continue;
+                auto &e = shs[shp[v]];
+                if (e.first++ == 0) e.second = v;
+            }
+            // what neither an exact nor a shape class can take would end in mixed tiles with per-lane
+            // parsing: the general tiles' sorted layout serves those variables better
+            for (int64_t v = 0; v < nvar && !no_general; v++) {
+                if (c.color[v] != k || fast[v] != 1 || cls[sig[v]].first >= min_class[k]) continue;
+                if (shp[v] != 0 && shs[shp[v]].first >= 64) continue;
+                if (shp[v] != 0) shs[shp[v]].first--;
+                nfast_of[k]--;
+                if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
+                else { fast[v] = 0; ngen_of[k]++; }          // long lists: wave-per-variable / generic kernels
+            }
         }
-        // variables outside the big exact classes are grouped by shape
-        for (int64_t v = 0; v < nvar; v++) {
-            const int32_t k = c.color[v];
-            if (k < 0 || fast[v] != 1 || shp[v] == 0 || classes[k][sig[v]].first >= min_class[k]) continue;
-            auto &e = shapes[k][shp[v]];
-            if (e.first++ == 0) e.second = v;
-        }
-        // what neither an exact nor a shape class can take would end in mixed tiles with per-lane
-        // parsing: the general tiles' sorted layout serves those variables better
-        for (int64_t v = 0; v < nvar && !no_general; v++) {
-            const int32_t k = c.color[v];
-            if (k < 0 || fast[v] != 1 || classes[k][sig[v]].first >= min_class[k]) continue;
-            if (shp[v] != 0 && shapes[k][shp[v]].first >= 64) continue;
-            if (shp[v] != 0) shapes[k][shp[v]].first--;
-            nfast_of[k]--;
-            if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
-            else { fast[v] = 0; ngen_of[k]++; }          // long lists: wave-per-variable / generic kernels
-        }
+        }, 1);
         // a colour whose exact / shape classes are a sliver next to its general tiles gives them up:
         // their few tiles would cost two or three extra launches per class and sweep
         for (int32_t k = 0; k < ncolors && !no_general; k++) {
