@@ -20,6 +20,14 @@ namespace nsk {
 static const int64_t NSK_HEAVY_LIST = 32;
 // ... and so is every generic-path variable of a colour class that has at most this many of them
 static const int64_t NSK_FEW_GENERIC = 32768;
+// stream words per lane of a shape tile at most (role program in TileShape::key, 32 words).  A lane walks its
+// words chunk by chunk, every chunk a load and then its gathers: longer lists belong to the entry-parallel
+// groups.  Measured on the 4M-variable weighted boolean graph (tools/sessions/r4_s24.sh, r4_s25.sh; learning /
+// inference, updates/s): 16 words 3.68e9 / 1.28e10, 20 words 2.93e9 / 1.18e10, 24 words 1.72e9 / 1.11e10,
+// 32 words 2.2e8 / 5.3e9.
+static const int64_t NSK_SHAPE_WORDS = 16;
+// a member slot of a shape tile that a lane does not have (its entry has fewer members than the tile's layout)
+static const uint32_t NSK_SHAPE_NULL = 0xFFFFFFFFu;
 
 bool known_function(int fn) {
     switch (fn) {
@@ -670,11 +678,28 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     c.phase_fast_end.assign((size_t)ncolors, 0);
     c.phase_gen_tile.assign((size_t)ncolors, 0);
     c.v_pos.assign(nvar, -1);
+    const int64_t shape_words = diag_env("NSK_SHAPE_MAX_WORDS") ? std::max<int64_t>(4, std::min<int64_t>(32, atoll(diag_env("NSK_SHAPE_MAX_WORDS")))) : NSK_SHAPE_WORDS;
+    // [shape_at[k], shape_end[k]): the positions of colour k's shape classes (tile shapes, pass 1)
+    std::vector<int64_t> shape_at((size_t)ncolors, 0), shape_end((size_t)ncolors, 0);
     {
         // sig: exact program (function, member count, weight id per entry, evidence flag);
         // shp: shape only (member count per entry, evidence flag), 0 when the stream would exceed
         //      16 words.  General-tile variables are not classed: they are sorted (below).
-        std::vector<uint64_t> sig(nvar, 0), shp(nvar, 0);
+        // pshp: the shape with every entry's member count rounded up to even ("padded" shape): variables whose
+        //      exact shape is rare share tiles with near shapes, the missing member slots filled with null
+        //      words (NSK_SHAPE_NULL) -- with individual weights and lists of 7+ entries the exact shapes
+        //      (2^(entries-1) of them on the weighted boolean graph) no longer fill tiles
+        std::vector<uint64_t> sig(nvar, 0), shp(nvar, 0), pshp(nvar, 0);
+        // Shape classes are formed per id range ("part") of the graph: the lanes of a shape tile then come from
+        // one part, and the values and weights they gather -- mostly those of id neighbours -- from a
+        // correspondingly narrow stretch of every colour's positions (the kernels hand an XCD a contiguous
+        // eighth of the colour's tiles, so one L2 serves those gathers).  One class over the whole id range
+        // put 64 unrelated variables into a tile: the learning sweep of the 4M-variable weighted boolean
+        // graph missed the L2 11 times per variable.  Parts of >= 2^19 ids keep the leftovers (< 64 members
+        // of a shape in a part, general tiles) few.
+        const bool no_pshape = diag_env("NSK_NO_PAD_SHAPE") != nullptr || diag_env("NSK_NO_SHAPE") != nullptr;
+        const int64_t shape_parts = diag_env("NSK_SHAPE_PARTS") ? std::max<int64_t>(1, atoll(diag_env("NSK_SHAPE_PARTS")))
+                                                                : std::max<int64_t>(1, std::min<int64_t>(64, (nvar + (1 << 19) - 1) >> 19));
         std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0), ngt_of((size_t)ncolors, 0);
         for (int64_t v = 0; v < nvar; v++) {
             if (c.color[v] < 0) continue;
@@ -690,8 +715,9 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             // (the evidence flag is multiplied in before the first word: a plain xor would cancel
             // against the low bit of the first weight id / member count)
             uint64_t h = (0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence) * 0x100000001b3ull;
-            uint64_t h2 = (h ^ 0x9e3779b97f4a7c15ull) * 0x100000001b3ull;
-            int64_t nwords = 0;
+            uint64_t h2 = (h ^ 0x9e3779b97f4a7c15ull ^ ((uint64_t)(v * shape_parts / std::max<int64_t>(nvar, 1)) << 40)) * 0x100000001b3ull;
+            uint64_t h3 = (h2 ^ 0xd6e8feb86659fd93ull) * 0x100000001b3ull;
+            int64_t nwords = 0, pwords = 0;
             for (int64_t j = 0; j < vt.factor_index_length; j++) {
                 const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
                 uint64_t others = 0;
@@ -703,23 +729,28 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 h ^= h >> 29;
                 h2 = (h2 ^ (others + 1)) * 0x100000001b3ull;
                 h2 ^= h2 >> 31;
+                const uint64_t padded = (others + 1) & ~(uint64_t)1;
+                h3 = (h3 ^ (padded + 1)) * 0x100000001b3ull;
+                h3 ^= h3 >> 31;
                 nwords += 1 + (int64_t)others;
+                pwords += 1 + (int64_t)padded;
             }
             sig[v] = h | 1;
-            shp[v] = nwords <= 16 ? (h2 | 1) : 0;
+            shp[v] = nwords <= shape_words ? (h2 | 1) : 0;
+            pshp[v] = (pwords <= shape_words && !no_pshape) ? (h3 | 1) : 0;
         }
         });
         // (hash maps: with one weight per factor every variable is a class of its own -- millions of keys;
         //  nothing below depends on their iteration order.  The colours are independent: one thread each.)
         typedef std::unordered_map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
-        std::vector<ClassMap> classes((size_t)ncolors), shapes((size_t)ncolors);
+        std::vector<ClassMap> classes((size_t)ncolors), shapes((size_t)ncolors), pshapes((size_t)ncolors);
         // a class gets tiles of its own when it fills at least one (64 members) -- or whatever its
         // size when the colour has only a few small classes (then padding them costs nothing
         // and no tile is left with mixed programs, e.g. the corner cells of a grid)
         std::vector<int64_t> min_class((size_t)ncolors, 64);
         parallel_for(ncolors, [&](int64_t kb0, int64_t kb1, int) {
         for (int32_t k = (int32_t)kb0; k < (int32_t)kb1; k++) {
-            ClassMap &cls = classes[k], &shs = shapes[k];
+            ClassMap &cls = classes[k], &shs = shapes[k], &pss = pshapes[k];
             cls.reserve((size_t)nfast_of[k]);
             for (int64_t v = 0; v < nvar; v++) {
                 if (c.color[v] != k || fast[v] != 1) continue;
@@ -735,12 +766,21 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 auto &e = shs[shp[v]];
                 if (e.first++ == 0) e.second = v;
             }
+            // ... and the ones whose exact shape fills no tile by padded shape
+            for (int64_t v = 0; v < nvar; v++) {
+                if (c.color[v] != k || fast[v] != 1 || pshp[v] == 0 || cls[sig[v]].first >= min_class[k]) continue;
+                if (shp[v] != 0 && shs[shp[v]].first >= 64) continue;
+                auto &e = pss[pshp[v]];
+                if (e.first++ == 0) e.second = v;
+            }
             // what neither an exact nor a shape class can take would end in mixed tiles with per-lane
             // parsing: the general tiles' sorted layout serves those variables better
             for (int64_t v = 0; v < nvar && !no_general; v++) {
                 if (c.color[v] != k || fast[v] != 1 || cls[sig[v]].first >= min_class[k]) continue;
                 if (shp[v] != 0 && shs[shp[v]].first >= 64) continue;
+                if (pshp[v] != 0 && pss[pshp[v]].first >= 64) continue;
                 if (shp[v] != 0) shs[shp[v]].first--;
+                if (pshp[v] != 0) pss[pshp[v]].first--;
                 nfast_of[k]--;
                 if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
                 else { fast[v] = 0; ngen_of[k]++; }          // long lists: wave-per-variable / generic kernels
@@ -759,30 +799,33 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
             classes[k].clear();
             shapes[k].clear();
+            pshapes[k].clear();
         }
         std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
         std::vector<std::vector<int64_t>> gen_bin_start;
-        std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors);
+        std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors), start3((size_t)ncolors);
         int64_t pos = 0;
         for (int32_t k = 0; k < ncolors; k++) {
             pos = (pos + 127) / 128 * 128;      // tiles sit on multiples of 64, tile pairs on multiples of
             c.phase_start[k] = pos;             // 128: a lane's position & 63 is its lane (generator ids)
             int64_t nbig = 0;
-            for (int level = 0; level < 2; level++) {
-                ClassMap &cm = level == 0 ? classes[k] : shapes[k];
+            for (int level = 0; level < 3; level++) {
+                if (level == 1) shape_at[k] = pos;
+                ClassMap &cm = level == 0 ? classes[k] : level == 1 ? shapes[k] : pshapes[k];
                 std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, key)
                 const int64_t need = level == 0 ? min_class[k] : 64;
                 for (auto &kv : cm)
                     if (kv.second.first >= need) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
                 std::sort(big.begin(), big.end());
                 for (auto &bc : big) {
-                    (level == 0 ? start[k] : start2[k])[bc.second] = pos;
+                    (level == 0 ? start[k] : level == 1 ? start2[k] : start3[k])[bc.second] = pos;
                     pos += cm[bc.second].first;
                     pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
                 }
                 cm.clear();
             }
             tail_at[k] = pos;
+            shape_end[k] = pos;
             pos += nfast_of[k] - nbig;
             pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
             gt_at[k] = pos;                                                     // general tiles
@@ -918,7 +961,11 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 if (it != start[k].end()) p = it->second++;
                 else {
                     auto it2 = shp[v] ? start2[k].find(shp[v]) : start2[k].end();
-                    p = (it2 != start2[k].end()) ? it2->second++ : tail_at[k]++;
+                    if (it2 != start2[k].end()) p = it2->second++;
+                    else {
+                        auto it3 = pshp[v] ? start3[k].find(pshp[v]) : start3[k].end();
+                        p = (it3 != start3[k].end()) ? it3->second++ : tail_at[k]++;
+                    }
                 }
             }
             c.p_vid[p] = (int32_t)v;
@@ -989,7 +1036,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             int32_t len;            // words per lane before rounding to chunks
             uint32_t flags;         // td[3]
             uint32_t nrows;         // materialised weight rows the tile needs
-            uint32_t key[16];       // uniform / shape: the program words; general: {E, M}
+            uint32_t key[32];       // uniform / shape: the program words (NSK_SHAPE_WORDS); general: {E, M}
         };
         std::vector<TileShape> shapes_of((size_t)nwb);
         std::vector<int32_t> tile_colour((size_t)nwb);
@@ -1041,6 +1088,12 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 int64_t len = 0;
                 bool uniform = true, have0 = false, same_shape = true;
                 bool binmem = true;                // every member the lanes read is a binary variable
+                // same shape: the lanes have the same number of entries and agree on which entries have members
+                // at all; an entry's member slots are the most any lane has there (lanes with fewer leave null
+                // words, NSK_SHAPE_NULL).  The classes of the position stage keep that padding small: exact
+                // shapes first, member counts rounded up to even for the rest.
+                uint32_t slots[32];
+                size_t nent = 0;
                 for (int64_t p = p0; p < p1; p++) {
                     if (c.p_vid[p] < 0) continue;                  // padding position
                     lane_words(c.p_vid[p], words);
@@ -1052,12 +1105,23 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     if (have0 && hdrs != hdrs0) {
                         uniform = false;
                         if (hdrs.size() != hdrs0.size()) same_shape = false;
-                        else for (size_t j = 0; j < hdrs.size(); j++)
-                            if (((hdrs[j] ^ hdrs0[j]) >> 24) & 7u) same_shape = false;
+                    }
+                    {
+                        const std::vector<uint32_t> &hh = have0 ? hdrs : hdrs0;
+                        if (!have0) { nent = std::min<size_t>(hh.size(), 32); if (hh.size() > 32) same_shape = false; }
+                        for (size_t j = 0; j < nent && j < hh.size() && same_shape; j++) {
+                            const uint32_t no = (hh[j] >> 24) & 7u;
+                            if (!have0) slots[j] = no;
+                            else if ((no == 0) != (slots[j] == 0)) same_shape = false;
+                            else slots[j] = std::max(slots[j], no);
+                        }
                     }
                     have0 = true;
                 }
                 if (!have0) { hdrs0.clear(); uniform = false; same_shape = false; }
+                // (the last tile of a shape class, left with one or two lanes, is no uniform tile: a segment
+                //  launch of its own per such tile costs more than the shape walk of its lanes)
+                if (p0 >= shape_at[k] && p0 < shape_end[k] && same_shape) uniform = false;
                 // slot program of a uniform tile: one word per member slot (an entry without other
                 // members still gets one, ignored, slot):
                 //   weightId | code << 24 | first << 27 | last << 28 | ignore << 29 | weight fixed << 30
@@ -1086,19 +1150,24 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                     ts.cls = 2;
                     ts.flags = (uint32_t)nslots | (kind << 8) | ((binmem && !no_ztab) ? 1u << 11 : 0u);
                     ts.len = (int32_t)nslots;
-                } else if (same_shape && len <= 16 && len > 0 && !no_shape) {
+                } else if (same_shape && len > 0 && !no_shape && [&] {
+                               int64_t pl = 0;
+                               for (size_t j = 0; j < nent; j++) pl += 1 + (int64_t)slots[j];
+                               len = pl;                                   // (the padded length from here on)
+                               return pl <= shape_words; }()) {
                     // shape tile: per-lane headers (own function and weight) but one word layout for the
                     // 64 lanes.  Role program, one word per stream word: 1 header | 8 header of an
                     // entry without other members | 16 member | 2 first member | 4 last member; kind 7.
                     uint32_t n = 0;
-                    for (uint32_t h : hdrs0) {
-                        const uint32_t no = (h >> 24) & 7u;
+                    for (size_t e = 0; e < nent; e++) {
+                        const uint32_t no = slots[e];
                         ts.key[n++] = 1u | (no == 0 ? 8u : 0u) | 0x80000000u;   // bit 31 marks role words
                         for (uint32_t m = 0; m < no; m++)
                             ts.key[n++] = 16u | (m == 0 ? 2u : 0u) | (m + 1 == no ? 4u : 0u) | 0x80000000u;
                     }
                     ts.nkey = (uint8_t)n;
                     ts.cls = 3;
+                    ts.len = (int32_t)len;
                     ts.flags = (uint32_t)len | (7u << 8);
                     ts.nrows = (uint32_t)hdrs0.size();
                 }
@@ -1380,6 +1449,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 const uint64_t base = (uint64_t)td[0] * 4;
                 const bool uniform = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u;
                 const bool general = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 6u;
+                const bool shape = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 7u;
                 if (td[2] != 0xFFFFFFFFu) {     // padding: uniform tiles read the always-zero id, shape tiles variable / weight 0
                     const uint32_t padw = uniform ? (uint32_t)c.zero_id : 0u;
                     for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = padw;
@@ -1418,6 +1488,9 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                         if (!uniform) put(words[j]);
                         else if (nother == 0) put((uint32_t)c.zero_id);      // the ignored slot of a member-less entry
                         for (uint32_t m = 1; m <= nother; m++) put((uint32_t)c.iid[words[j + m]]);
+                        // shape tile: the member slots of the tile's layout that this lane's entry lacks
+                        while (shape && out < (size_t)td[1] && (c.tile_hdr[td[2] + out] & 0x80000010u) == 0x80000010u)
+                            put(NSK_SHAPE_NULL);
                         j += 1 + nother;
                     }
                     nfast_here++;

@@ -231,6 +231,7 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_prog_weights(const
     prog_w[2 * i + 1] = last ? wt * lo : 0.0;
 }
 
+#define NSK_SHAPE_NULL 0xFFFFFFFFu      // member slot of a shape tile that the lane's entry lacks (nsk_compile.cpp)
 // Shape tile: every lane has its own factor functions and weights (per-lane header words in the
 // stream) but all 64 lanes share the word layout -- which words are headers, which are members,
 // where entries start and end -- so the walk is driven by a scalar role program and only the
@@ -269,7 +270,7 @@ __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, con
         for (int i = 0; i < 4; i++) {                                    // one load per word
             wv[i] = 0.0; xv[i] = 0;
             if (role[i] & 1u) wv[i] = wt[(size_t)(e2++) * 64];           // coalesced: materialised weight
-            else if (role[i] & 16u) xv[i] = (int)val[wd[i]];
+            else if ((role[i] & 16u) && wd[i] != NSK_SHAPE_NULL) xv[i] = (int)val[wd[i]];
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -280,7 +281,9 @@ __device__ __forceinline__ void tile_potentials_shape(const DevGraph<VT> &g, con
                 first = 0; allnz = true; any1 = false; alleq = true;
                 if (role[i] & 8u) finish(true);
             } else if (role[i] & 16u) {                                  // member
-                const int x = xv[i];
+                // (a slot this lane's entry does not have -- never its first -- repeats the first member's value:
+                //  neutral for "all equal", "all non-zero" and "any is 1")
+                const int x = wd[i] == NSK_SHAPE_NULL ? first : xv[i];
                 const bool F = (role[i] & 2u) != 0;
                 alleq = F || (alleq && (x == first));
                 allnz = (F || allnz) && (x != 0);

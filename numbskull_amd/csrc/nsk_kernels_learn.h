@@ -406,7 +406,9 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
 template <typename VT>
 __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
                                                  int len, uint32_t prog, int p, bool valid,
-                                                 const LearnParams &lp) {
+                                                 const LearnParams &lp, double *wsave = nullptr) {
+    // wsave: LDS, 8 x NSK_BLOCK doubles or null -- pass 1 leaves the weights of a lane's first 8 entries at
+    // [entry][thread], so pass 2 updates a single-factor weight in place without gathering it again
     const NSK_SCALAR uint32_t *rp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
     const uint32_t info = valid ? g.p_info[p] : 0u;
     const int ev = NSK_INFO_EV(info);
@@ -451,7 +453,7 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
         for (int i = 0; i < 4; i++) {
             wv[i] = 0.0; xv[i] = 0; xe[i] = 0;
             if (role[i] & 1u) wv[i] = g.w[wd[i] & 0xFFFFFFu];
-            else if (role[i] & 16u) { xv[i] = (int)g.val[wd[i]]; xe[i] = (int)g.val_evid[wd[i]]; }
+            else if ((role[i] & 16u) && wd[i] != NSK_SHAPE_NULL) { xv[i] = (int)g.val[wd[i]]; xe[i] = (int)g.val_evid[wd[i]]; }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -459,11 +461,13 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
                 entry++;
                 code = (0x343210u >> (4u * (wd[i] >> 27))) & 0xFu;
                 w = wv[i];
+                if (wsave && entry < 8) wsave[entry * NSK_BLOCK + (int)threadIdx.x] = w;
                 ff = 0; fe = 0; nzf = true; onef = false; eqf = true; nze = true; onee = false; eqe = true;
                 if (role[i] & 8u) close(true);
             } else if (role[i] & 16u) {
                 const bool F = (role[i] & 2u) != 0;
-                const int x = xv[i], y = xe[i];
+                const bool nul = wd[i] == NSK_SHAPE_NULL;         // a slot the lane's entry lacks: the first member again
+                const int x = nul ? ff : xv[i], y = nul ? fe : xe[i];
                 eqf = F || (eqf && (x == ff)); nzf = (F || nzf) && (x != 0); onef = (!F && onef) || (x == 1);
                 ff = F ? x : ff;
                 eqe = F || (eqe && (y == fe)); nze = (F || nze) && (y != 0); onee = (!F && onee) || (y == 1);
@@ -509,9 +513,13 @@ __device__ __forceinline__ void learn_tile_shape(const DevGraph<VT> &g, const Gr
                 const int wid = (int)(wd[i] & 0xFFFFFFu);
                 const uint32_t cd = (0x343210u >> (4u * (wd[i] >> 27))) & 0xFu;
                 const long long span = cd == 0u ? 0 : (cd == 1u ? 1 : 2);          // hi - lo
-                const bool have = part && !g.w_fixed[wid];
+                // (a weight that is updated in place is never a fixed one: its flag is not even looked up)
+                const bool dir = part && sk.w_direct && ((sk.w_direct[(uint32_t)wid >> 5] >> ((uint32_t)wid & 31u)) & 1u);
+                const bool have = part && (dir || !g.w_fixed[wid]);
                 const long long diff = (long long)((satf >> e2) & 1u) - (long long)((sate >> e2) & 1u);
-                accumulate_gradient(sk, have, wid, (span * diff) * g.grad_mul, truncate);
+                const bool saved = wsave != nullptr && e2 < 8;
+                accumulate_gradient(sk, have, wid, (span * diff) * g.grad_mul, truncate, true, saved,
+                                    saved ? wsave[e2 * NSK_BLOCK + (int)threadIdx.x] : 0.0);
             }
         }
     }
@@ -621,7 +629,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
 // One uniform / shape tile (tile t of the colour) of the learning sweep, descriptor-driven
 template <typename VT>
 __device__ __forceinline__ void learn_rest_tile(const DevGraph<VT> &g, const GradSink &sk, int pbegin, int pend,
-                                                int wb_base, int t, const LearnParams &lp) {
+                                                int wb_base, int t, const LearnParams &lp, double *wsave = nullptr) {
     const int lane = (int)(threadIdx.x & 63);
     const NSK_SCALAR uint32_t *tdp = (const NSK_SCALAR uint32_t *)(g.tiles + (wb_base + t));
     const struct { uint32_t x, y, z, w; } td = {tdp[0], tdp[1], tdp[2], tdp[3]};
@@ -630,7 +638,7 @@ __device__ __forceinline__ void learn_rest_tile(const DevGraph<VT> &g, const Gra
     const bool valid = p < pend && g.p_vid[p] >= 0;
     const uint4 *sp = g.adj + td.x + lane;
     const uint32_t kind = (td.w >> 8) & 7u;
-    if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp);
+    if (kind == 7u) learn_tile_shape<VT>(g, sk, sp, (int)(td.w & 0xFFu), td.z, p, valid, lp, wsave);
     else if (kind == 4u) learn_tile<VT, 4>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
     else if (kind == 0u) learn_tile<VT, 0>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
     else if (kind == 2u) learn_tile<VT, 2>(g, sk, sp, (int)td.y, td.z, p, valid, lp);
@@ -1280,11 +1288,31 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
     }
     // then the colour's uniform / shape tiles outside segment launches (a contiguous run per wave of the
     // group and rest blocks)
-    const int nw_all = (int)((gridDim.x - hblocks) * (NSK_BLOCK / 64));
-    const int per = (nrest + nw_all - 1) / nw_all;
-    const int r1 = min(nrest, (wave0 + 1) * per);
-    for (int i = wave0 * per; i < r1; i++)
-        learn_rest_tile<VT>(g, sk, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(rest_list[i]), lp);
+    // XCD x (= blockIdx & 7: how the hardware deals workgroups; for speed only) takes the x-th eighth of the
+    // list, a contiguous run per wave: the list is in position order and shape classes are formed per id
+    // range (nsk_compile.cpp "shape_parts"), so the values and weights an XCD's tiles gather lie in a
+    // correspondingly narrow stretch of every colour -- one L2's worth
+    const int nb_all = (int)gridDim.x - hblocks;
+    int r0, r1;
+    if (nb_all >= 8) {
+        const int xcd = (int)(blockIdx.x & 7);
+        const int first = hblocks + ((xcd - (hblocks & 7) + 8) & 7);          // first such block on this XCD
+        const int nwx = (((int)gridDim.x - 1 - first) / 8 + 1) * (NSK_BLOCK / 64);
+        const int wx = __builtin_amdgcn_readfirstlane((((int)blockIdx.x - first) >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+        const int per8 = (nrest + 7) >> 3;
+        const int t0 = min(nrest, xcd * per8), tend = min(nrest, t0 + per8);
+        const int per = (tend - t0 + nwx - 1) / nwx;
+        r0 = min(tend, t0 + wx * per);
+        r1 = min(tend, r0 + per);
+    } else {
+        const int nw_all = nb_all * (NSK_BLOCK / 64);
+        const int per = (nrest + nw_all - 1) / nw_all;
+        r0 = min(nrest, wave0 * per);
+        r1 = min(nrest, r0 + per);
+    }
+    __syncthreads();                                       // (the last group's gradient pass is done with `ws`)
+    for (int i = r0; i < r1; i++)
+        learn_rest_tile<VT>(g, sk, pbegin, pend, wb_base, (int)__builtin_amdgcn_readfirstlane(rest_list[i]), lp, ws);
     (void)nwaves;
     close_sink<SMALLW>(g, sk);
 }

@@ -858,6 +858,46 @@ def test_weights_with_one_factor_are_updated_in_place(reg, shared):
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
 
 
+@pytest.mark.parametrize("parts", [1, 5])
+def test_shape_classes_per_id_range(parts, monkeypatch):
+    """Shape classes are formed per id range of the graph (large graphs: ranges of >= 2^19 ids); forced on a
+    small graph here.  Inference and learning stay bit-exact vs the oracle on the resulting layout, and the
+    ranges put more variables into general tiles (the leftovers of every shape in every range)."""
+    monkeypatch.setenv("NSK_DIAG", "1")
+    monkeypatch.setenv("NSK_SHAPE_PARTS", str(parts))
+    g = list(graphgen.boolean_weighted_graph(40000, seed=14))
+    rng = np.random.Generator(np.random.PCG64(3))
+    w = g[0].copy()
+    w["isFixed"] = False
+    w["initialValue"] = rng.normal(0, 0.2, len(w))
+    g[0] = w
+    v = g[1].copy()
+    v["isEvidence"] = rng.random(len(v)) < 0.5
+    v["initialValue"] = rng.integers(0, 2, len(v))
+    g[1] = v
+    ns, fg = session(tuple(g), seed=12)
+    lay, col = fg.layout(), fg.colors()
+    if parts > 1:       # a shape tile's 64 lanes come from one fifth of the ids (where whole classes were laid out)
+        vids = np.nonzero(col >= 0)[0]
+        tile = lay[vids] // 64
+        lo = np.full(int(tile.max()) + 1, len(v)); hi = np.full(int(tile.max()) + 1, -1)
+        np.minimum.at(lo, tile, vids); np.maximum.at(hi, tile, vids)
+        used = hi >= 0
+        assert np.median((hi - lo)[used]) <= len(v) // parts
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(col)
+    vv, ve, wv, cnt = og.initial_state()
+    fg.learn(0, 3, 0.02, 0.9, 2, 0.05, 1, learn_non_evidence=True)
+    assert og.learn_call(order, ps, vv, ve, wv, 3, 0.02, 0.9, 2, 0.05, 1, True, 12, 0) == 0
+    assert np.array_equal(fg.weight_value[0], wv)
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    fg.inference(1, 3, True)
+    assert og.gibbs_dev(order, ps, vv, wv, cnt, 12, 3, True, burnin=True) == 0
+    for s_ in range(4, 7):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 12, s_, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
 def test_weight_slots_are_the_identity_on_shared_weights():
     """Graphs whose weights are shared by many factors keep the caller's numbering."""
     ns, fg = session(graphgen.mixed_lr_graph(3000, seed=5, nweights=400), seed=2, head_by_vid=True)
