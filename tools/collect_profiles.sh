@@ -78,8 +78,15 @@ NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --workloa
 # the 8-shard runs on one device (per-shard phase timings): config #4 through pack / unpack, configs #4 and #5
 # through the peer-to-peer kernels (the 50M graph included when the host has the memory)
 rm -f gpurun_out/config4_shards_*.json gpurun_out/config5_shards_*.json
+if [ -n "$NSK_PROFILE_FULL_TESTS" ]; then      # the whole GPU suite (it contains the 8-shard runs) in the same call
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/${RT}_gpu_tests.log 2>&1
+  echo "gpu tests rc $? $(tail -1 $OUT/${RT}_gpu_tests.log)"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${RT}_smoke.log 2>&1
+  echo "smoke rc $? $(tail -1 $OUT/${RT}_smoke.log)"
+else
 timeout 2400 python -m pytest tests/test_config5_shards_gpu.py tests/test_config4_gpu.py -m gpu -q > $OUT/${RT}_shards_tests.log 2>&1
 echo "shard tests rc $? $(tail -1 $OUT/${RT}_shards_tests.log)"
+fi
 cp gpurun_out/config4_shards_*.json gpurun_out/config5_shards_*.json $OUT/ 2>/dev/null
 find $OUT -type f -size +2M -delete
 ls $OUT
