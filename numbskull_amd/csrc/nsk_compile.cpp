@@ -695,11 +695,12 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // correspondingly narrow stretch of every colour's positions (the kernels hand an XCD a contiguous
         // eighth of the colour's tiles, so one L2 serves those gathers).  One class over the whole id range
         // put 64 unrelated variables into a tile: the learning sweep of the 4M-variable weighted boolean
-        // graph missed the L2 11 times per variable.  Parts of >= 2^19 ids keep the leftovers (< 64 members
-        // of a shape in a part, general tiles) few.
+        // graph missed the L2 11 times per variable.  Parts of >= 2^18 ids keep the leftovers (< 64 members
+        // of a shape in a part, general tiles) few: that graph's learning sweep, 8 / 16 / 32 parts: 3.71 / 4.07 /
+        // 4.06e9 updates/s (tools/sessions/r4_s26.sh).
         const bool no_pshape = diag_env("NSK_NO_PAD_SHAPE") != nullptr || diag_env("NSK_NO_SHAPE") != nullptr;
         const int64_t shape_parts = diag_env("NSK_SHAPE_PARTS") ? std::max<int64_t>(1, atoll(diag_env("NSK_SHAPE_PARTS")))
-                                                                : std::max<int64_t>(1, std::min<int64_t>(64, (nvar + (1 << 19) - 1) >> 19));
+                                                                : std::max<int64_t>(1, std::min<int64_t>(64, (nvar + (1 << 18) - 1) >> 18));
         std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0), ngt_of((size_t)ncolors, 0);
         for (int64_t v = 0; v < nvar; v++) {
             if (c.color[v] < 0) continue;

@@ -168,11 +168,19 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
                 // 3 workgroups per CU 142.4 us, 4 149.2, 5 139.5, 6 135.4, 7 134.2, 8 132.9, 10 134.7, 16 135.6;
                 // 50M LR graph: 4 1362 us, 7 1247, 10 1189
                 const char *pcu_env = nsk::diag_env("NSK_EP_PER_CU");            // (diagnostic: workgroups per CU)
-                const int per_cu = pcu_env ? std::max(1, std::min(32, atoi(pcu_env))) : 10;
+                // -- and at 5M, twice each (tools/sessions/r4_s26.sh): 10 per CU 4.95 / 4.97e9 updates/s, 7 per CU
+                // 5.04 / 5.06e9.  Hence 10 when a workgroup walks four groups or more, 7 otherwise (the shards
+                // of an 8-rank run of the 50M graph are of the second kind).
+                const int per_cu = pcu_env ? std::max(1, std::min(32, atoi(pcu_env))) : (ngroups >= 4 * 2560 ? 10 : 7);
                 const int gblocks = 8 * ((std::min(256 * per_cu, ngroups) + 7) / 8);
                 const int nbh = (int)(g->c.phase_bighub_base[ph + 1] - g->c.phase_bighub_base[ph]);   // a block per long-list hub
                 const int hbl_ep = nbh + hbl;
-                const int grid = gblocks + hbl_ep;
+                // the colour's rest tiles (shape tiles: graphs with individual weights) are walked by all of these
+                // workgroups, one wave per tile: when the groups alone bring too few, more workgroups (they skip the
+                // group walk) -- the weighted boolean graph has 750 groups and 7 000 rest tiles per colour
+                const int nrest_here = rest_in_general ? nlrest : 0;
+                const int rblocks = std::max(0, 8 * ((std::min(2560, (nrest_here + 3) / 4) + 7) / 8) - gblocks);
+                const int grid = gblocks + rblocks + hbl_ep;
                 hipStream_t st = general_aside ? cs.side(0) : g->stream;
 #define NSK_LEP(MAXC) k_learn_ep<VT, SMALLW, MAXC><<<dim3(grid), dim3(NSK_BLOCK), shmem, st>>>( \
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, ntiles - gt0, ngroups, (int)g->c.phase_ep_base[ph], gblocks, \
