@@ -9,8 +9,8 @@ for f in profiles/r2_* profiles/r3_*; do [ -e "$f" ] && git mv -f "$f" profiles/
 # (NSK_PROFILE_PARTIAL=1: a partial collection replaces only the files it produced)
 [ -z "$NSK_PROFILE_PARTIAL" ] && for f in profiles/${RT}_*; do [ -e "$f" ] && rm -f "$f"; done
 cp gpurun_out/profiles_$RT/${RT}_* profiles/
-cp gpurun_out/profiles_$RT/traffic.json profiles/traffic.json
-cp gpurun_out/profiles_$RT/issue.json profiles/issue.json
+[ -e gpurun_out/profiles_$RT/traffic.json ] && cp gpurun_out/profiles_$RT/traffic.json profiles/traffic.json
+[ -e gpurun_out/profiles_$RT/issue.json ] && cp gpurun_out/profiles_$RT/issue.json profiles/issue.json
 for f in gpurun_out/profiles_$RT/config4_shards_*.json gpurun_out/profiles_$RT/config5_shards_*.json; do [ -e "$f" ] && cp "$f" profiles/${RT}_$(basename $f); done
 if [ -z "$NSK_PROFILE_PARTIAL" ]; then cp gpurun_out/profiles_${RT}_commit.txt profiles/${RT}_COMMIT.txt
 else cat gpurun_out/profiles_${RT}_commit.txt >> profiles/${RT}_COMMIT.txt; fi
