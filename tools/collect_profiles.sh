@@ -61,8 +61,10 @@ json.dump(iss, open("$R/profiles/issue.json", "w"), indent=1)
 PY
 fi
 [ $STAGE = profile ] && { ls $OUT; exit 0; }
+if [ -z "$NSK_PROFILE_SKIP_DEFAULT" ]; then      # (a partial collection of one kernel family skips the default and two-rank lines)
 python bench.py > $OUT/${RT}_default_bench.json 2> $OUT/${RT}_default_bench.err
 echo "default bench rc $?"
+fi
 for WL in ${NSK_PROFILE_BENCH_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
   [ $WL = ising10m ] && continue        # (the default line)
   python bench.py --workload $WL --steps 100 --warmup 10 --no-extra > $OUT/${RT}_${WL}_bench.json 2> /dev/null
@@ -73,8 +75,8 @@ for WL in ${NSK_PROFILE_BENCH_ONLY:-ising40m ising100m lr50m lr50m_learn}; do
   grep "compile " $OUT/${RT}_${WL}_bench.err > $OUT/${RT}_${WL}_compile_laps.txt
   echo "bench $WL rc $?"
 done
-NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_bench.json 2>/dev/null
-NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload lr5m_learn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_lr5m_learn_bench.json 2>/dev/null
+[ -z "$NSK_PROFILE_SKIP_DEFAULT" ] && NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_bench.json 2>/dev/null
+[ -z "$NSK_PROFILE_SKIP_DEFAULT" ] && NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload lr5m_learn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_lr5m_learn_bench.json 2>/dev/null
 # the 8-shard runs on one device (per-shard phase timings): config #4 through pack / unpack, configs #4 and #5
 # through the peer-to-peer kernels (the 50M graph included when the host has the memory)
 rm -f gpurun_out/config4_shards_*.json gpurun_out/config5_shards_*.json
