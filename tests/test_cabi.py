@@ -5,6 +5,7 @@ product never reaches into oracle/."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -318,3 +319,39 @@ def test_diagnostic_switches_need_nsk_diag(monkeypatch):
     assert session(g)[1].plan()[1]["nfast"] == 256          # ignored without NSK_DIAG
     monkeypatch.setenv("NSK_DIAG", "1")
     assert session(g)[1].plan()[1]["nfast"] == 0            # honoured with it
+
+
+_PLAN_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.util import session
+from numbskull_amd import graphgen
+out = {}
+for name, g, kw in (("boolw", graphgen.boolean_weighted_graph(60000, seed=9), {}),
+                    ("lr", graphgen.mixed_lr_graph(60000, seed=4, nweights=700), {"head_by_vid": True}),
+                    ("grid", graphgen.ising_grid(150, 220, weight=0.1), {})):
+    if name == "boolw":
+        g[0]["isFixed"] = False
+    color, info = session(g, **kw)[1].plan()
+    out[name] = [hashlib.sha256(np.ascontiguousarray(color).tobytes()).hexdigest(), info]
+print(json.dumps(out, sort_keys=True))
+"""
+
+
+def test_graph_compiler_is_independent_of_the_thread_count():
+    """compile_graph runs its stages over host threads (static index blocks, one thread per colour for the
+    class maps, class-by-class recolouring): colours, the path split and every byte count of the plan must not
+    depend on how many there are.  (The thread count is read once per process: two subprocesses.)"""
+    import json
+    import subprocess
+    outs = []
+    for threads in ("1", "7"):
+        env = dict(os.environ, NSK_COMPILE_THREADS=threads)
+        env.pop("NSK_DIAG", None)
+        r = subprocess.run([sys.executable, "-c", _PLAN_SCRIPT, REPO], env=env, capture_output=True, text=True,
+                           timeout=600, cwd=REPO)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert outs[0]["boolw"][1]["direct_weights"] > 0 and outs[0]["lr"][1]["ncolors"] >= 2
