@@ -397,9 +397,10 @@ def test_learning_accumulator_fallbacks(golden, name, switch, monkeypatch):
     g, hbv = _small_graphs(golden)[name]
     if switch == "NSK_ONE_ACC":
         # the product configuration on an MI355X: the device passed nsk_graph_create's self-test of the
-        # XCD-private accumulators (k_xcd_selftest), so a many-weight graph keeps 8 copies
+        # XCD-private accumulators (k_xcd_selftest), so a many-weight graph keeps 8 copies -- while a copy
+        # fits its XCD's L2 (up to 2^18 weights); a larger table has one copy in the product as well
         ns0, fg0 = session(g, seed=5, head_by_vid=hbv)
-        assert fg0.info()["acc_copies"] & 15 == 8
+        assert fg0.info()["acc_copies"] & 15 == (8 if len(g[0]) <= 1 << 18 else 1)
         fg0.close()
     monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv(switch, "1")
