@@ -26,6 +26,12 @@ static const int64_t NSK_FEW_GENERIC = 32768;
 // inference, updates/s): 16 words 3.68e9 / 1.28e10, 20 words 2.93e9 / 1.18e10, 24 words 1.72e9 / 1.11e10,
 // 32 words 2.2e8 / 5.3e9.
 static const int64_t NSK_SHAPE_WORDS = 16;
+// ... and the same limit for variables the entry-parallel groups can take.  Once the single-factor weights had
+// slots in layout order (nsk_compile.h wmap) the groups overtook the shape tiles at every list length; same
+// graph, every rest tile with a wave of its own (tools/sessions/r4_s31.sh .. r4_s33.sh), learning / inference:
+// 20 words 4.20e9 / 1.20e10, 16 words 4.78e9 / 1.30e10, 12 words 5.25e9 / 1.56e10, 10 words 5.61e9 / 1.60e10,
+// 8 words 6.13e9 / 1.60e10, 6 words 6.35e9 / 1.59e10, 4 words 6.56e9 / 1.60e10.
+static const int64_t NSK_SHAPE_WORDS_EP = 4;
 // a member slot of a shape tile that a lane does not have (its entry has fewer members than the tile's layout)
 static const uint32_t NSK_SHAPE_NULL = 0xFFFFFFFFu;
 
@@ -679,6 +685,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     c.phase_gen_tile.assign((size_t)ncolors, 0);
     c.v_pos.assign(nvar, -1);
     const int64_t shape_words = diag_env("NSK_SHAPE_MAX_WORDS") ? std::max<int64_t>(4, std::min<int64_t>(32, atoll(diag_env("NSK_SHAPE_MAX_WORDS")))) : NSK_SHAPE_WORDS;
+    const int64_t shape_words_ep = diag_env("NSK_SHAPE_MAX_WORDS") ? shape_words : NSK_SHAPE_WORDS_EP;
     // [shape_at[k], shape_end[k]): the positions of colour k's shape classes (tile shapes, pass 1)
     std::vector<int64_t> shape_at((size_t)ncolors, 0), shape_end((size_t)ncolors, 0);
     {
@@ -719,6 +726,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             uint64_t h2 = (h ^ 0x9e3779b97f4a7c15ull ^ ((uint64_t)(v * shape_parts / std::max<int64_t>(nvar, 1)) << 40)) * 0x100000001b3ull;
             uint64_t h3 = (h2 ^ 0xd6e8feb86659fd93ull) * 0x100000001b3ull;
             int64_t nwords = 0, pwords = 0;
+            uint64_t maxo = 0;
             for (int64_t j = 0; j < vt.factor_index_length; j++) {
                 const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
                 uint64_t others = 0;
@@ -731,14 +739,18 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 h2 = (h2 ^ (others + 1)) * 0x100000001b3ull;
                 h2 ^= h2 >> 31;
                 const uint64_t padded = (others + 1) & ~(uint64_t)1;
+                maxo = std::max(maxo, others);
                 h3 = (h3 ^ (padded + 1)) * 0x100000001b3ull;
                 h3 ^= h3 >> 31;
                 nwords += 1 + (int64_t)others;
                 pwords += 1 + (int64_t)padded;
             }
             sig[v] = h | 1;
-            shp[v] = nwords <= shape_words ? (h2 | 1) : 0;
-            pshp[v] = (pwords <= shape_words && !no_pshape) ? (h3 | 1) : 0;
+            // (a variable the entry-parallel groups can take -- <= 3 other members per entry, <= 16 entries -- joins a
+            //  shape class only with a list of a few words, shape_words_ep)
+            const int64_t lim = (maxo <= 3 && vt.factor_index_length <= 16) ? shape_words_ep : shape_words;
+            shp[v] = nwords <= lim ? (h2 | 1) : 0;
+            pshp[v] = (pwords <= lim && !no_pshape) ? (h3 | 1) : 0;
         }
         });
         // (hash maps: with one weight per factor every variable is a class of its own -- millions of keys;
