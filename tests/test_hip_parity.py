@@ -866,6 +866,8 @@ def test_shape_classes_per_id_range(parts, monkeypatch):
     ranges put more variables into general tiles (the leftovers of every shape in every range)."""
     monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv("NSK_SHAPE_PARTS", str(parts))
+    if parts > 1:       # ... with shape tiles of up to 16 words for every variable (the product keeps lists of
+        monkeypatch.setenv("NSK_SHAPE_MAX_WORDS", "16")     # more than 4 words for the entry-parallel groups)
     g = list(graphgen.boolean_weighted_graph(40000, seed=14))
     rng = np.random.Generator(np.random.PCG64(3))
     w = g[0].copy()
