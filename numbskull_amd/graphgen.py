@@ -270,6 +270,44 @@ def mixed_lr_graph(nvar, seed=20240603, nweights=None, window=1024, global_frac=
     return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), len(fmap)
 
 
+def _lr_shard_from(kept, card, ev, init, lo, hi, nweights):
+    """The shard's arrays from the kept (func, wid, arity, vid, deo) pieces of the factor blocks."""
+    cat = lambda i: np.concatenate([k[i] for k in kept]) if kept else np.zeros(0, np.int64)
+    vid = cat(3)
+    gids = np.unique(np.concatenate([np.arange(lo, hi, dtype=np.int64), vid]))
+    lvar = np.zeros(len(gids), Variable)
+    lvar["dataType"] = card[gids] > 2
+    lvar["cardinality"] = card[gids]
+    lvar["isEvidence"] = ev[gids]
+    lvar["initialValue"] = init[gids]
+    lvar["isEvidence"][(gids < lo) | (gids >= hi)] = 4
+    factor, fmap = _lr_records(cat(0), cat(1), cat(2), np.searchsorted(gids, vid), cat(4))
+    l0, l1 = int(np.searchsorted(gids, lo)), int(np.searchsorted(gids, hi))
+    return (np.zeros(nweights, Weight), lvar, factor, fmap, np.zeros(len(gids), np.bool_), len(fmap)), gids, (l0, l1)
+
+
+def mixed_lr_shards(nvar, ranges, seed=20240603, nweights=None, window=1024, global_frac=0.01,
+                    evidence_frac=0.5, cat_frac=0.25, block=LR_BLOCK):
+    """``[mixed_lr_shard(nvar, lo, hi, ...) for lo, hi in ranges]`` in ONE pass over the factor blocks: for a
+    process that holds several shards at once (the 8-handles-on-one-device tests).  A rank of a real run calls
+    ``mixed_lr_shard`` for its own range."""
+    nvar = int(nvar)
+    ranges = [(int(lo), int(hi)) for lo, hi in ranges]
+    nweights = _lr_nweights(nvar, nweights)
+    card, ev, init, nf_of = _lr_variables(nvar, seed, cat_frac, evidence_frac, block)
+    kept = [[] for _ in ranges]
+    for b, v0 in enumerate(range(0, nvar, block)):
+        func, wid, arity, off, vid, deo = _lr_factor_block(seed, b, v0, nf_of[v0:v0 + block], card, nvar,
+                                                           nweights, window, global_frac)
+        for r, (lo, hi) in enumerate(ranges):
+            keep_f = np.add.reduceat(((vid >= lo) & (vid < hi)).astype(np.int32), off) > 0
+            if not keep_f.any():
+                continue
+            keep_e = np.repeat(keep_f, arity)
+            kept[r].append((func[keep_f], wid[keep_f], arity[keep_f], vid[keep_e], deo[keep_e]))
+    return [_lr_shard_from(kept[r], card, ev, init, lo, hi, nweights) for r, (lo, hi) in enumerate(ranges)]
+
+
 def mixed_lr_shard(nvar, lo, hi, seed=20240603, nweights=None, window=1024, global_frac=0.01,
                    evidence_frac=0.5, cat_frac=0.25, block=LR_BLOCK):
     """``extract_shard(mixed_lr_graph(nvar, ...), lo, hi)`` without ever holding the whole graph: the
@@ -287,18 +325,7 @@ def mixed_lr_shard(nvar, lo, hi, seed=20240603, nweights=None, window=1024, glob
             continue
         keep_e = np.repeat(keep_f, arity)
         kept.append((func[keep_f], wid[keep_f], arity[keep_f], vid[keep_e], deo[keep_e]))
-    cat = lambda i: np.concatenate([k[i] for k in kept]) if kept else np.zeros(0, np.int64)
-    vid = cat(3)
-    gids = np.unique(np.concatenate([np.arange(lo, hi, dtype=np.int64), vid]))
-    lvar = np.zeros(len(gids), Variable)
-    lvar["dataType"] = card[gids] > 2
-    lvar["cardinality"] = card[gids]
-    lvar["isEvidence"] = ev[gids]
-    lvar["initialValue"] = init[gids]
-    lvar["isEvidence"][(gids < lo) | (gids >= hi)] = 4
-    factor, fmap = _lr_records(cat(0), cat(1), cat(2), np.searchsorted(gids, vid), cat(4))
-    l0, l1 = int(np.searchsorted(gids, lo)), int(np.searchsorted(gids, hi))
-    return (np.zeros(nweights, Weight), lvar, factor, fmap, np.zeros(len(gids), np.bool_), len(fmap)), gids, (l0, l1)
+    return _lr_shard_from(kept, card, ev, init, lo, hi, nweights)
 
 
 def boolean_weighted_graph(nvar, seed=0, window=64, factors_per_var=2.0, max_arity=3):

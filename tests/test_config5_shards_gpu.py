@@ -41,12 +41,17 @@ def make_parts(kind, nvar, learn, seed):
         grid = (graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True,
                                     evidence=rng.integers(0, 2, nvar)) if learn
                 else graphgen.ising_grid(rows, cols, weight=0.1))
+    shards = None
+    if kind != "grid":      # all eight in one pass over the generator's blocks (a rank of a real run calls
+        shards = graphgen.mixed_lr_shards(nvar, [shard_range(r, WORLD, nvar) for r in range(WORLD)],      # mixed_lr_shard)
+                                          seed=LR_SEED)
     for r in range(WORLD):
         lo, hi = shard_range(r, WORLD, nvar)
         if kind == "grid":
             sg, gids, own = graphgen.extract_shard(grid, lo, hi)
         else:
-            sg, gids, own = graphgen.mixed_lr_shard(nvar, lo, hi, seed=LR_SEED)
+            sg, gids, own = shards[r]
+            shards[r] = None
         ns = numbskull_amd.NumbSkull(quiet=True, seed=seed, head_by_vid=kind != "grid")
         ns.loadFactorGraph(*sg[:5], int(sg[5]), own_range=own, global_ids=gids)
         fg = ns.factorGraphs[0]

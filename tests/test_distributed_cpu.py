@@ -235,6 +235,13 @@ def test_lr_shard_generator_equals_the_cut_of_the_whole_graph():
         assert np.array_equal(gids, gids2) and own == own2 and a[5] == b[5]
         for x, y in zip(a[:5], b[:5]):
             assert x.dtype == y.dtype and np.array_equal(x, y)
+    # several shards in one pass over the blocks (a process that holds them all: the 8-handle tests)
+    ranges = ((0, 5000), (5000, 10000), (35000, 40000), (4090, 4100), (77, 77))
+    for (lo, hi), (a, gids, own) in zip(ranges, graphgen.mixed_lr_shards(nvar, ranges, seed=5, block=4096)):
+        b, gids2, own2 = graphgen.mixed_lr_shard(nvar, lo, hi, seed=5, block=4096)
+        assert np.array_equal(gids, gids2) and own == own2 and a[5] == b[5]
+        for x, y in zip(a[:5], b[:5]):
+            assert x.dtype == y.dtype and np.array_equal(x, y)
     # a different block size is a different graph (the streams are keyed per block), the same one is not
     assert not np.array_equal(graphgen.mixed_lr_graph(nvar, seed=5, block=8192)[3], g[3])
     assert np.array_equal(graphgen.mixed_lr_graph(nvar, seed=5, block=4096)[3], g[3])
