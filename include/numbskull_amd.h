@@ -205,8 +205,9 @@ int nsk_profile_mark(nsk_graph *g);
 int nsk_profile_read(nsk_graph *g, double *elapsed_ms, int64_t *kernel_launches);
 
 /* Multi-GPU plumbing: raw device addresses of the value arrays (element size = value_bytes,
- * indexed by INTERNAL id, see nsk_graph_get_layout), of the weights and of the boundary staging
- * buffers, and the stream the library launches on. */
+ * indexed by INTERNAL id, see nsk_graph_get_layout), of the weights (float64, indexed by weight SLOT: the
+ * caller's id except where nsk_graph_get_weight_slots says otherwise -- never on a handle that samples a
+ * range of a larger graph) and of the boundary staging buffers, and the stream the library launches on. */
 #define NSK_BUF_VALUE 0
 #define NSK_BUF_VALUE_EVID 1
 #define NSK_BUF_WEIGHT 2
