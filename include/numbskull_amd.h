@@ -164,6 +164,11 @@ typedef struct {
     int64_t direct_weights;           /* weights with a single factor that the learning kernels update in
                                          place at their one visit per class (no accumulator, no update
                                          launch for them); 0: none                                 */
+    int64_t layout_hash;              /* with NSK_LAYOUT_HASH=1 in the environment: a 64-bit hash of every
+                                         array of the compiled layout (colours, positions, tile and group
+                                         streams, programs, weight slots ...) -- what a check that two builds /
+                                         thread counts / library versions compile a graph alike compares;
+                                         0 otherwise (hashing the layout of a 50M-variable graph takes seconds) */
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);

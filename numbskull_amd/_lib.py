@@ -50,7 +50,8 @@ class GraphInfo(C.Structure):
                 ("layout_bytes_learning", C.c_double), ("ztab_entries", C.c_int64),
                 ("compile_seconds", C.c_double), ("learn_cap", C.c_double),
                 ("learn_clipped", C.c_int64), ("grad_shift", C.c_int64),
-                ("acc_copies", C.c_int64), ("learn_lag", C.c_int64), ("direct_weights", C.c_int64)]
+                ("acc_copies", C.c_int64), ("learn_lag", C.c_int64), ("direct_weights", C.c_int64),
+                ("layout_hash", C.c_int64)]
 
 
 _lib = None

@@ -651,6 +651,34 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
     return NSK_OK;
 }
 
+// 64-bit hash of the compiled layout (nsk_graph_info.layout_hash): FNV-1a over 8-byte words, one lane per array,
+// the lanes folded in a fixed order
+#define hash_array(v) hash_bytes((v).data(), (v).size() * sizeof((v)[0]))
+static uint64_t hash_bytes(const void *data, size_t n) {
+    const unsigned char *p = (const unsigned char *)data;
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; }
+    for (; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h;
+}
+static int64_t layout_hash(const Compiled &c) {
+    const uint64_t parts[] = {
+        hash_array(c.color), hash_array(c.phase_start), hash_array(c.phase_end), hash_array(c.phase_fast_end),
+        hash_array(c.phase_wb_base), hash_array(c.tiles), hash_array(c.tile_wrow), hash_array(c.adj),
+        hash_array(c.hub_desc), hash_array(c.hub_adj), hash_array(c.phase_hub_base), hash_array(c.bighub_pos),
+        hash_array(c.tile_hdr), hash_array(c.dyn_tiles), hash_array(c.seg_aff), hash_array(c.rest_tiles),
+        hash_array(c.learn_rest_tiles), hash_array(c.phase_gen_tile), hash_array(c.ep_desc), hash_array(c.ep_adj),
+        hash_array(c.ep_wrow), hash_array(c.ep_kstat), hash_array(c.phase_ep_base), hash_array(c.phase_ep),
+        hash_array(c.p_vid), hash_array(c.p_slot), hash_array(c.p_cnt), hash_array(c.p_info), hash_array(c.p_init),
+        hash_array(c.slot_off), hash_array(c.fidx), hash_array(c.gstream), hash_array(c.gs_off), hash_array(c.f_rec),
+        hash_array(c.m_rec), hash_array(c.iid), hash_array(c.w_init), hash_array(c.w_fixed), hash_array(c.w_direct),
+        hash_array(c.multi_wids), hash_array(c.wmap), hash_array(c.ghost_needs)};
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (uint64_t x : parts) { h = (h ^ x) * 0x100000001b3ull; h ^= h >> 31; }
+    return (int64_t)(h >> 1);             // non-negative
+}
+
 static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->nvar = c.nvar;
     info->nowned = c.nsampled;
@@ -672,6 +700,7 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->acc_copies = 0;
     info->learn_lag = (c.nweight > 0 && c.nweight <= NSK_SMALLW) ? 1 : 0;
     info->direct_weights = c.ndirect;
+    info->layout_hash = getenv("NSK_LAYOUT_HASH") ? layout_hash(c) : 0;
 }
 
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {

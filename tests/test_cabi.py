@@ -341,13 +341,13 @@ print(json.dumps(out, sort_keys=True))
 
 def test_graph_compiler_is_independent_of_the_thread_count():
     """compile_graph runs its stages over host threads (static index blocks, one thread per colour for the
-    class maps, class-by-class recolouring): colours, the path split and every byte count of the plan must not
-    depend on how many there are.  (The thread count is read once per process: two subprocesses.)"""
+    class maps, class-by-class recolouring): colours, the path split, every byte count of the plan and the hash
+    of every array of the compiled layout (nsk_graph_info.layout_hash) must not depend on how many there are.  (The thread count is read once per process: two subprocesses.)"""
     import json
     import subprocess
     outs = []
     for threads in ("1", "7"):
-        env = dict(os.environ, NSK_COMPILE_THREADS=threads)
+        env = dict(os.environ, NSK_COMPILE_THREADS=threads, NSK_LAYOUT_HASH="1")
         env.pop("NSK_DIAG", None)
         r = subprocess.run([sys.executable, "-c", _PLAN_SCRIPT, REPO], env=env, capture_output=True, text=True,
                            timeout=600, cwd=REPO)
@@ -355,3 +355,5 @@ def test_graph_compiler_is_independent_of_the_thread_count():
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1]
     assert outs[0]["boolw"][1]["direct_weights"] > 0 and outs[0]["lr"][1]["ncolors"] >= 2
+    assert all(outs[0][k][1]["layout_hash"] != 0 for k in outs[0])        # every array of the layout, hashed
+    assert len({outs[0][k][1]["layout_hash"] for k in outs[0]}) == 3
