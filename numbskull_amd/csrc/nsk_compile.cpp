@@ -56,6 +56,124 @@ static std::string fmt(const char *f, long long a = 0, long long b = 0, long lon
     return std::string(buf);
 }
 
+// Direct weights (nsk_compile.h w_direct): the weights with one factor, when at least half of all weights are of
+// that kind.  nwb = number of tiles (weights a uniform tile's program names stay with the accumulators).
+static void find_direct_weights(const nsk_graph_desc *d, Compiled &c, int64_t nwb, bool verbose) {
+    const int64_t nw = c.nweight, nfac = c.nfactor;
+    c.w_direct.clear(); c.multi_wids.clear(); c.ndirect = 0;
+    if (nw > 256 && !diag_env("NSK_NO_DIRECT")) {
+        std::vector<uint8_t> nfac_of((size_t)nw, 0);                 // factors per weight, saturating at 2
+        for (int64_t f = 0; f < nfac; f++) {
+            const int64_t wid = d->factor[f].weightId;
+            if (wid >= 0 && wid < nw && nfac_of[(size_t)wid] < 2) nfac_of[(size_t)wid]++;
+        }
+        for (int64_t t = 0; t < nwb; t++) {                          // weights named by uniform tiles' programs
+            const uint32_t *td = &c.tiles[4 * t];
+            if (td[2] == 0xFFFFFFFFu || ((td[3] >> 8) & 7u) >= 6u) continue;
+            for (uint32_t j = 0; j < (td[3] & 0xFFu); j++) {
+                const uint32_t wid = c.tile_hdr[td[2] + j] & 0xFFFFFFu;
+                if ((int64_t)wid < nw) nfac_of[wid] = 2;
+            }
+        }
+        int64_t nd = 0;
+        for (int64_t w = 0; w < nw; w++) nd += (nfac_of[(size_t)w] == 1 && !c.w_fixed[(size_t)w]) ? 1 : 0;
+        if (2 * nd >= nw) {
+            c.w_direct.assign((size_t)(nw + 31) / 32, 0u);
+            for (int64_t w = 0; w < nw; w++) {
+                if (nfac_of[(size_t)w] == 1 && !c.w_fixed[(size_t)w]) c.w_direct[(size_t)w >> 5] |= 1u << (w & 31);
+                else c.multi_wids.push_back((int32_t)w);
+            }
+            c.ndirect = nd;
+        }
+        if (verbose) fprintf(stderr, "[nsk] weights with one factor %lld of %lld: %s\n", (long long)nd, (long long)nw,
+                             c.ndirect ? "updated in place" : "too few, accumulators for all");
+    }
+}
+
+// Internal numbering of the direct weights (nsk_compile.h wmap): the order in which the layout's positions, each
+// walking its lists, first meet them; a weight no position names keeps the tail.  Returns false (and leaves the
+// caller's numbering) on a handle that samples a range of a larger graph: the ranks of a distributed run add their
+// weight tables element by element.
+static bool number_direct_weights(const nsk_graph_desc *d, Compiled &c) {
+    const int64_t nw = c.nweight, nvar = c.nvar, nfac = c.nfactor;
+    c.wmap.clear(); c.wuser.clear();
+    if (!(c.ndirect && c.own_begin == 0 && c.own_end == nvar && !(d->flags & NSK_FLAG_PARTITION) && !diag_env("NSK_NO_WORDER")))
+        return false;
+    auto is_direct = [&](int64_t w) { return (c.w_direct[(size_t)w >> 5] >> (w & 31)) & 1u; };
+    std::vector<uint32_t> seen((size_t)(nw + 31) / 32, 0u);
+    // (bands of 2^24 ids are numbered separately: a slot then has the bits of the id it replaces, and the
+    // 24-bit weight field of the uniform-tile words holds whatever held before)
+    std::vector<std::vector<int32_t>> order((size_t)((nw - 1) >> 24) + 1);
+    for (int64_t p = 0; p < (int64_t)c.p_vid.size(); p++) {
+        const int64_t v = c.p_vid[p];
+        if (v < 0) continue;
+        const nsk_variable &var = d->variable[v];
+        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+        for (int64_t k = 0; k < nslots; k++) {
+            const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+            for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                const int64_t w = d->factor[d->factor_index[vt.factor_index_offset + j]].weightId;
+                if (w < 0 || w >= nw || !is_direct(w) || ((seen[(size_t)w >> 5] >> (w & 31)) & 1u)) continue;
+                seen[(size_t)w >> 5] |= 1u << (w & 31);
+                order[(size_t)w >> 24].push_back((int32_t)w);
+            }
+        }
+    }
+    for (int64_t w = 0; w < nw; w++)
+        if (is_direct(w) && !((seen[(size_t)w >> 5] >> (w & 31)) & 1u)) order[(size_t)w >> 24].push_back((int32_t)w);
+    c.wmap.resize((size_t)nw); c.wuser.resize((size_t)nw);
+    std::vector<size_t> taken(order.size(), 0);
+    for (int64_t w = 0; w < nw; w++) {
+        if (!is_direct(w)) { c.wmap[(size_t)w] = (int32_t)w; c.wuser[(size_t)w] = (int32_t)w; continue; }
+        const int32_t met = order[(size_t)w >> 24][taken[(size_t)w >> 24]++];
+        c.wmap[(size_t)met] = (int32_t)w;               // the k-th weight of the band met takes its k-th direct slot
+        c.wuser[(size_t)w] = met;
+    }
+    for (int64_t w = 0; w < nw; w++) c.w_init[(size_t)w] = d->weight[c.wuser[(size_t)w]].initialValue;
+    for (int64_t f = 0; f < nfac; f++) {
+        const int64_t w = d->factor[f].weightId;
+        if (w >= 0 && w < nw) c.f_rec[4 * f + 2] = (uint32_t)c.wmap[(size_t)w];
+    }
+    return true;
+}
+
+// Gradient format of the learning accumulators.  Integer gradients?  (p1 - p0) * featureValue is an integer of
+// magnitude <= 2 when featureValue is -1, 0 or 1 and no function returns counts or logarithms; visits per weight and
+// class are bounded by the weight's member edges: the 32 fraction bits of G then carry the visit count (packed_grad).
+// And the fixed-point range (grad_bound, grad_shift).
+static void choose_gradient_format(const nsk_graph_desc *d, Compiled &c) {
+    const int64_t nw = c.nweight, nfac = c.nfactor;
+    bool ok = true;
+    std::vector<int64_t> edges_of((size_t)nw, 0);
+    for (int64_t f = 0; f < nfac && ok; f++) {
+        const nsk_factor &fa = d->factor[f];
+        const int fn = fa.factorFunction;
+        if (!(fa.featureValue == 1.0 || fa.featureValue == 0.0 || fa.featureValue == -1.0)) ok = false;
+        if (fn == 7 || fn == 8 || fn == 30) ok = false;            // LINEAR, RATIO, UFO
+        if (fa.weightId >= 0 && fa.weightId < nw) edges_of[fa.weightId] += std::max<int64_t>(fa.arity, 1);
+    }
+    for (int64_t i = 0; i < nw && ok; i++) if (edges_of[i] >= ((int64_t)1 << 28)) ok = false;
+    c.packed_grad = ok && !diag_env("NSK_NO_PACKED");
+    // Q31.32 range: a class's gradient sum for weight w is at most sum over its factors of
+    // |featureValue| * (largest |value difference| of the function) * (member edges)
+    std::vector<double> gbound((size_t)nw, 0.0);
+    for (int64_t f = 0; f < nfac; f++) {
+        const nsk_factor &fa = d->factor[f];
+        if (fa.weightId < 0 || fa.weightId >= nw) continue;
+        const double ar = (double)std::max<int64_t>(fa.arity, 1);
+        const int fn = fa.factorFunction;
+        const double span = fn == 7 ? ar : fn == 8 ? std::log(ar + 1.0) : fn == 30 ? 1e6 : 2.0;
+        gbound[fa.weightId] += std::fabs(fa.featureValue) * span * ar;
+    }
+    c.grad_bound = 0.0;
+    for (int64_t i = 0; i < nw; i++) c.grad_bound = std::max(c.grad_bound, gbound[i]);
+    // Q31.32 holds sums below 2^31; a larger bound trades fraction bits for range (the reference
+    // sums float64 gradients, learning.py:109): Q(31+s).(32-s), gradients below 2^-(33-s) vanish
+    c.grad_shift = 0;
+    while (c.grad_shift < 32 && c.grad_bound >= 1073741824.0 * std::ldexp(1.0, c.grad_shift)) c.grad_shift++;
+    if (c.grad_shift > 0) c.packed_grad = false;       // the fraction bits are no longer free for visit counts
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1241,78 +1359,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         }
         lap("tile shapes (pass 1)");
         c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
-        // ---- direct weights (nsk_compile.h w_direct)
-        c.w_direct.clear(); c.multi_wids.clear(); c.ndirect = 0;
-        if (nw > 256 && !diag_env("NSK_NO_DIRECT")) {
-            std::vector<uint8_t> nfac_of((size_t)nw, 0);                 // factors per weight, saturating at 2
-            for (int64_t f = 0; f < nfac; f++) {
-                const int64_t wid = d->factor[f].weightId;
-                if (wid >= 0 && wid < nw && nfac_of[(size_t)wid] < 2) nfac_of[(size_t)wid]++;
-            }
-            for (int64_t t = 0; t < nwb; t++) {                          // weights named by uniform tiles' programs
-                const uint32_t *td = &c.tiles[4 * t];
-                if (td[2] == 0xFFFFFFFFu || ((td[3] >> 8) & 7u) >= 6u) continue;
-                for (uint32_t j = 0; j < (td[3] & 0xFFu); j++) {
-                    const uint32_t wid = c.tile_hdr[td[2] + j] & 0xFFFFFFu;
-                    if ((int64_t)wid < nw) nfac_of[wid] = 2;
-                }
-            }
-            int64_t nd = 0;
-            for (int64_t w = 0; w < nw; w++) nd += (nfac_of[(size_t)w] == 1 && !c.w_fixed[(size_t)w]) ? 1 : 0;
-            if (2 * nd >= nw) {
-                c.w_direct.assign((size_t)(nw + 31) / 32, 0u);
-                for (int64_t w = 0; w < nw; w++) {
-                    if (nfac_of[(size_t)w] == 1 && !c.w_fixed[(size_t)w]) c.w_direct[(size_t)w >> 5] |= 1u << (w & 31);
-                    else c.multi_wids.push_back((int32_t)w);
-                }
-                c.ndirect = nd;
-            }
-            if (verbose) fprintf(stderr, "[nsk] weights with one factor %lld of %lld: %s\n", (long long)nd, (long long)nw,
-                                 c.ndirect ? "updated in place" : "too few, accumulators for all");
-        }
-        // ---- internal numbering of the direct weights (nsk_compile.h wmap): the order in which the layout's
-        // positions, each walking its lists, first meet them; a weight no position names keeps the tail.  A
-        // handle that samples a range of a larger graph keeps the caller's numbering: the ranks of a
-        // distributed run add their weight tables element by element.
-        c.wmap.clear(); c.wuser.clear();
-        if (c.ndirect && ob == 0 && oe == nvar && !(d->flags & NSK_FLAG_PARTITION) && !diag_env("NSK_NO_WORDER")) {
-            auto is_direct = [&](int64_t w) { return (c.w_direct[(size_t)w >> 5] >> (w & 31)) & 1u; };
-            std::vector<uint32_t> seen((size_t)(nw + 31) / 32, 0u);
-            // (bands of 2^24 ids are numbered separately: a slot then has the bits of the id it replaces, and the
-            // 24-bit weight field of the uniform-tile words holds whatever held before)
-            std::vector<std::vector<int32_t>> order((size_t)((nw - 1) >> 24) + 1);
-            for (int64_t p = 0; p < (int64_t)c.p_vid.size(); p++) {
-                const int64_t v = c.p_vid[p];
-                if (v < 0) continue;
-                const nsk_variable &var = d->variable[v];
-                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-                for (int64_t k = 0; k < nslots; k++) {
-                    const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
-                    for (int64_t j = 0; j < vt.factor_index_length; j++) {
-                        const int64_t w = d->factor[d->factor_index[vt.factor_index_offset + j]].weightId;
-                        if (w < 0 || w >= nw || !is_direct(w) || ((seen[(size_t)w >> 5] >> (w & 31)) & 1u)) continue;
-                        seen[(size_t)w >> 5] |= 1u << (w & 31);
-                        order[(size_t)w >> 24].push_back((int32_t)w);
-                    }
-                }
-            }
-            for (int64_t w = 0; w < nw; w++)
-                if (is_direct(w) && !((seen[(size_t)w >> 5] >> (w & 31)) & 1u)) order[(size_t)w >> 24].push_back((int32_t)w);
-            c.wmap.resize((size_t)nw); c.wuser.resize((size_t)nw);
-            std::vector<size_t> taken(order.size(), 0);
-            for (int64_t w = 0; w < nw; w++) {
-                if (!is_direct(w)) { c.wmap[(size_t)w] = (int32_t)w; c.wuser[(size_t)w] = (int32_t)w; continue; }
-                const int32_t met = order[(size_t)w >> 24][taken[(size_t)w >> 24]++];
-                c.wmap[(size_t)met] = (int32_t)w;               // the k-th weight of the band met takes its k-th direct slot
-                c.wuser[(size_t)w] = met;
-            }
-            for (int64_t w = 0; w < nw; w++) c.w_init[(size_t)w] = d->weight[c.wuser[(size_t)w]].initialValue;
-            for (int64_t f = 0; f < nfac; f++) {
-                const int64_t w = d->factor[f].weightId;
-                if (w >= 0 && w < nw) c.f_rec[4 * f + 2] = (uint32_t)c.wmap[(size_t)w];
-            }
-            lap("weight numbering");
-        }
+        find_direct_weights(d, c, nwb, verbose);
+        if (number_direct_weights(d, c)) lap("weight numbering");
         c.phase_gen_bin_tile.assign((size_t)ncolors, 0);
         for (int32_t k = 0; k < ncolors; k++) {
             int64_t t = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
@@ -1952,40 +2000,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
             }
     }
     lap("generic stream");
-    // integer gradients?  (p1 - p0) * featureValue is an integer of magnitude <= 2 when featureValue
-    // is -1, 0 or 1 and no function returns counts or logarithms; visits per weight and class are
-    // bounded by the weight's member edges
-    {
-        bool ok = true;
-        std::vector<int64_t> edges_of((size_t)nw, 0);
-        for (int64_t f = 0; f < nfac && ok; f++) {
-            const nsk_factor &fa = d->factor[f];
-            const int fn = fa.factorFunction;
-            if (!(fa.featureValue == 1.0 || fa.featureValue == 0.0 || fa.featureValue == -1.0)) ok = false;
-            if (fn == 7 || fn == 8 || fn == 30) ok = false;            // LINEAR, RATIO, UFO
-            if (fa.weightId >= 0 && fa.weightId < nw) edges_of[fa.weightId] += std::max<int64_t>(fa.arity, 1);
-        }
-        for (int64_t i = 0; i < nw && ok; i++) if (edges_of[i] >= ((int64_t)1 << 28)) ok = false;
-        c.packed_grad = ok && !diag_env("NSK_NO_PACKED");
-        // Q31.32 range: a class's gradient sum for weight w is at most sum over its factors of
-        // |featureValue| * (largest |value difference| of the function) * (member edges)
-        std::vector<double> gbound((size_t)nw, 0.0);
-        for (int64_t f = 0; f < nfac; f++) {
-            const nsk_factor &fa = d->factor[f];
-            if (fa.weightId < 0 || fa.weightId >= nw) continue;
-            const double ar = (double)std::max<int64_t>(fa.arity, 1);
-            const int fn = fa.factorFunction;
-            const double span = fn == 7 ? ar : fn == 8 ? std::log(ar + 1.0) : fn == 30 ? 1e6 : 2.0;
-            gbound[fa.weightId] += std::fabs(fa.featureValue) * span * ar;
-        }
-        c.grad_bound = 0.0;
-        for (int64_t i = 0; i < nw; i++) c.grad_bound = std::max(c.grad_bound, gbound[i]);
-        // Q31.32 holds sums below 2^31; a larger bound trades fraction bits for range (the reference
-        // sums float64 gradients, learning.py:109): Q(31+s).(32-s), gradients below 2^-(33-s) vanish
-        c.grad_shift = 0;
-        while (c.grad_shift < 32 && c.grad_bound >= 1073741824.0 * std::ldexp(1.0, c.grad_shift)) c.grad_shift++;
-        if (c.grad_shift > 0) c.packed_grad = false;       // the fraction bits are no longer free for visit counts
-    }
+    choose_gradient_format(d, c);
     c.alg_bytes_inference = bytes_inf;
     c.alg_bytes_learning = bytes_learn;
     lap("packed-gradient check");
