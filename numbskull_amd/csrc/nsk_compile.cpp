@@ -174,6 +174,125 @@ static void choose_gradient_format(const nsk_graph_desc *d, Compiled &c) {
     if (c.grad_shift > 0) c.packed_grad = false;       // the fraction bits are no longer free for visit counts
 }
 
+// Validation of every factor reachable from a sampled variable (errors as the reference raises them: SURVEY.md
+// section 8b); sets c.has_ufo / c.literal_heads, returns the largest arity of a RATIO factor in max_ratio_arity.
+static int validate_reachable(const nsk_graph_desc *d, Compiled &c, const std::vector<uint8_t> &sampled, bool head_by_vid,
+                              int64_t &max_ratio_arity_out, std::string &err) {
+    const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
+    const int64_t nfi = d->nfactor_index;
+    // ---- validate every factor reachable from a sampled variable ------------------------------
+    // Two parallel phases over index blocks: (1) every sampled variable's lists -- bounds, factor ids -- mark
+    // the factors they reach; (2) every reached factor is checked.  Each thread keeps the first error of its
+    // block (lowest variable / factor index); the lowest block's error is reported, list errors first, so
+    // the message does not depend on the thread count.
+    std::vector<uint8_t> checked(nfac, 0);
+    int64_t max_ratio_arity = 0;
+    struct Issue { int rc = NSK_OK; std::string msg; bool ufo = false, literal = false; int64_t ratio = 0; };
+    auto check_factor = [&](int64_t f, Issue &is) -> int {
+        const nsk_factor &fa = d->factor[f];
+        const int fn = fa.factorFunction;
+        if (!known_function(fn)) {
+            is.msg = fmt("Factor function %lld (used in factor %lld) is not implemented.", fn, f);
+            return NSK_E_FACTOR_FUNC;
+        }
+        if (fa.weightId < 0 || fa.weightId >= nw) {      // potential() reads it even for NOOP
+            is.msg = fmt("factor %lld: weightId %lld outside weights", f, fa.weightId);
+            return NSK_E_INDEX;
+        }
+        if (fn == -1) return NSK_OK;
+        const int64_t s = fa.ftv_offset, e = fa.ftv_offset + fa.arity;
+        if (fa.arity < 0 || s < 0 || e > nedge) {
+            is.msg = fmt("factor %lld: members [%lld, %lld) outside fmap", f, s, e);
+            return NSK_E_INDEX;
+        }
+        int64_t need = 0;       // member positions the function reads regardless of arity
+        switch (fn) {
+        case 3: need = 1; break;
+        case 0: case 7: case 8: case 9: case 13: case 16: case 17:
+            if (fa.arity < 1) { is.msg = fmt("factor %lld: function %lld needs arity >= 1", f, fn); return NSK_E_INDEX; }
+            break;
+        case 18: case 19: case 20: case 30: need = 1; break;
+        case 21: case 22: case 25: case 26: need = 2; break;
+        case 23: case 24: need = 3; break;
+        default: break;
+        }
+        const int64_t last = std::max(e, s + need);
+        if (s + need > nedge) {
+            is.msg = fmt("factor %lld: function %lld reads member %lld beyond fmap", f, fn, s + need - 1);
+            return NSK_E_INDEX;
+        }
+        for (int64_t l = s; l < last; l++) {
+            if (d->fmap[l].vid < 0 || d->fmap[l].vid >= nvar) {
+                is.msg = fmt("factor %lld: member variable %lld outside variables", f, d->fmap[l].vid);
+                return NSK_E_INDEX;
+            }
+        }
+        if (fn == 30) is.ufo = true;
+        if (fn == 30) {   // UFO reads member (value of first member) - 1
+            int64_t reach = s + d->variable[d->fmap[s].vid].cardinality - 2;
+            if (reach >= nedge) { is.msg = fmt("factor %lld: UFO member index beyond fmap", f); return NSK_E_INDEX; }
+            for (int64_t l = s; l <= reach; l++)
+                if (d->fmap[l].vid < 0 || d->fmap[l].vid >= nvar) {
+                    is.msg = fmt("factor %lld: member variable outside variables", f);
+                    return NSK_E_INDEX;
+                }
+        }
+        if (literal_head_function(fn) && !head_by_vid) is.literal = true;
+        if (literal_head_function(fn) && !head_by_vid && e - 1 >= nvar) {
+            is.msg = fmt("factor %lld: the reference reads var_value[%lld] for the head of function %lld "
+                         "(inference.py:243,277,292), outside the variable array; pass NSK_FLAG_HEAD_BY_VID "
+                         "for the fmap[l].vid lookup", f, e - 1, fn);
+            return NSK_E_INDEX;
+        }
+        if (fn == 8) is.ratio = std::max(is.ratio, fa.arity);
+        return NSK_OK;
+    };
+    {
+        std::vector<Issue> issues((size_t)compile_threads());
+        parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int t) {
+            Issue &is = issues[(size_t)t];
+            for (int64_t v = vb0; v < vb1 && !is.rc; v++) {
+                if (!sampled[v]) continue;
+                const nsk_variable &var = d->variable[v];
+                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+                for (int64_t k = 0; k < nslots && !is.rc; k++) {
+                    const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+                    if (vt.factor_index_length < 0 || vt.factor_index_offset < 0 ||
+                        vt.factor_index_offset + vt.factor_index_length > nfi) {
+                        is.msg = fmt("variable %lld: factor list outside factor_index", v);
+                        is.rc = NSK_E_INDEX;
+                        break;
+                    }
+                    for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                        const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                        if (f < 0 || f >= nfac) {
+                            is.msg = fmt("variable %lld: factor id %lld outside factors", v, f);
+                            is.rc = NSK_E_INDEX;
+                            break;
+                        }
+                        checked[f] = 1;                   // (several threads may store the same 1)
+                    }
+                }
+            }
+        });
+        for (const Issue &is : issues) if (is.rc) { err = is.msg; return is.rc; }      // blocks are in index order
+        for (Issue &is : issues) is = Issue();
+        parallel_for(nfac, [&](int64_t fb0, int64_t fb1, int t) {
+            Issue &is = issues[(size_t)t];
+            for (int64_t f = fb0; f < fb1 && !is.rc; f++)
+                if (checked[f]) is.rc = check_factor(f, is);
+        });
+        for (const Issue &is : issues) {
+            if (is.rc) { err = is.msg; return is.rc; }
+            c.has_ufo = c.has_ufo || is.ufo;
+            c.literal_heads = c.literal_heads || is.literal;
+            max_ratio_arity = std::max(max_ratio_arity, is.ratio);
+        }
+    }
+    max_ratio_arity_out = max_ratio_arity;
+    return NSK_OK;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -296,115 +415,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     std::vector<uint8_t> sampled(nvar, 0);
     for (int64_t v = ob; v < oe; v++) sampled[v] = d->variable[v].isEvidence != 4;   // inference.py:21-23
 
-    // ---- validate every factor reachable from a sampled variable ------------------------------
-    // Two parallel phases over index blocks: (1) every sampled variable's lists -- bounds, factor ids -- mark
-    // the factors they reach; (2) every reached factor is checked.  Each thread keeps the first error of its
-    // block (lowest variable / factor index); the lowest block's error is reported, list errors first, so
-    // the message does not depend on the thread count.
-    std::vector<uint8_t> checked(nfac, 0);
     int64_t max_ratio_arity = 0;
-    struct Issue { int rc = NSK_OK; std::string msg; bool ufo = false, literal = false; int64_t ratio = 0; };
-    auto check_factor = [&](int64_t f, Issue &is) -> int {
-        const nsk_factor &fa = d->factor[f];
-        const int fn = fa.factorFunction;
-        if (!known_function(fn)) {
-            is.msg = fmt("Factor function %lld (used in factor %lld) is not implemented.", fn, f);
-            return NSK_E_FACTOR_FUNC;
-        }
-        if (fa.weightId < 0 || fa.weightId >= nw) {      // potential() reads it even for NOOP
-            is.msg = fmt("factor %lld: weightId %lld outside weights", f, fa.weightId);
-            return NSK_E_INDEX;
-        }
-        if (fn == -1) return NSK_OK;
-        const int64_t s = fa.ftv_offset, e = fa.ftv_offset + fa.arity;
-        if (fa.arity < 0 || s < 0 || e > nedge) {
-            is.msg = fmt("factor %lld: members [%lld, %lld) outside fmap", f, s, e);
-            return NSK_E_INDEX;
-        }
-        int64_t need = 0;       // member positions the function reads regardless of arity
-        switch (fn) {
-        case 3: need = 1; break;
-        case 0: case 7: case 8: case 9: case 13: case 16: case 17:
-            if (fa.arity < 1) { is.msg = fmt("factor %lld: function %lld needs arity >= 1", f, fn); return NSK_E_INDEX; }
-            break;
-        case 18: case 19: case 20: case 30: need = 1; break;
-        case 21: case 22: case 25: case 26: need = 2; break;
-        case 23: case 24: need = 3; break;
-        default: break;
-        }
-        const int64_t last = std::max(e, s + need);
-        if (s + need > nedge) {
-            is.msg = fmt("factor %lld: function %lld reads member %lld beyond fmap", f, fn, s + need - 1);
-            return NSK_E_INDEX;
-        }
-        for (int64_t l = s; l < last; l++) {
-            if (d->fmap[l].vid < 0 || d->fmap[l].vid >= nvar) {
-                is.msg = fmt("factor %lld: member variable %lld outside variables", f, d->fmap[l].vid);
-                return NSK_E_INDEX;
-            }
-        }
-        if (fn == 30) is.ufo = true;
-        if (fn == 30) {   // UFO reads member (value of first member) - 1
-            int64_t reach = s + d->variable[d->fmap[s].vid].cardinality - 2;
-            if (reach >= nedge) { is.msg = fmt("factor %lld: UFO member index beyond fmap", f); return NSK_E_INDEX; }
-            for (int64_t l = s; l <= reach; l++)
-                if (d->fmap[l].vid < 0 || d->fmap[l].vid >= nvar) {
-                    is.msg = fmt("factor %lld: member variable outside variables", f);
-                    return NSK_E_INDEX;
-                }
-        }
-        if (literal_head_function(fn) && !head_by_vid) is.literal = true;
-        if (literal_head_function(fn) && !head_by_vid && e - 1 >= nvar) {
-            is.msg = fmt("factor %lld: the reference reads var_value[%lld] for the head of function %lld "
-                         "(inference.py:243,277,292), outside the variable array; pass NSK_FLAG_HEAD_BY_VID "
-                         "for the fmap[l].vid lookup", f, e - 1, fn);
-            return NSK_E_INDEX;
-        }
-        if (fn == 8) is.ratio = std::max(is.ratio, fa.arity);
-        return NSK_OK;
-    };
-    {
-        std::vector<Issue> issues((size_t)compile_threads());
-        parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int t) {
-            Issue &is = issues[(size_t)t];
-            for (int64_t v = vb0; v < vb1 && !is.rc; v++) {
-                if (!sampled[v]) continue;
-                const nsk_variable &var = d->variable[v];
-                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-                for (int64_t k = 0; k < nslots && !is.rc; k++) {
-                    const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
-                    if (vt.factor_index_length < 0 || vt.factor_index_offset < 0 ||
-                        vt.factor_index_offset + vt.factor_index_length > nfi) {
-                        is.msg = fmt("variable %lld: factor list outside factor_index", v);
-                        is.rc = NSK_E_INDEX;
-                        break;
-                    }
-                    for (int64_t j = 0; j < vt.factor_index_length; j++) {
-                        const int64_t f = d->factor_index[vt.factor_index_offset + j];
-                        if (f < 0 || f >= nfac) {
-                            is.msg = fmt("variable %lld: factor id %lld outside factors", v, f);
-                            is.rc = NSK_E_INDEX;
-                            break;
-                        }
-                        checked[f] = 1;                   // (several threads may store the same 1)
-                    }
-                }
-            }
-        });
-        for (const Issue &is : issues) if (is.rc) { err = is.msg; return is.rc; }      // blocks are in index order
-        for (Issue &is : issues) is = Issue();
-        parallel_for(nfac, [&](int64_t fb0, int64_t fb1, int t) {
-            Issue &is = issues[(size_t)t];
-            for (int64_t f = fb0; f < fb1 && !is.rc; f++)
-                if (checked[f]) is.rc = check_factor(f, is);
-        });
-        for (const Issue &is : issues) {
-            if (is.rc) { err = is.msg; return is.rc; }
-            c.has_ufo = c.has_ufo || is.ufo;
-            c.literal_heads = c.literal_heads || is.literal;
-            max_ratio_arity = std::max(max_ratio_arity, is.ratio);
-        }
-    }
+    if (int vrc = validate_reachable(d, c, sampled, head_by_vid, max_ratio_arity, err)) return vrc;
     lap("validate");
     c.logtab.resize((size_t)max_ratio_arity + 2);
     c.logtab[0] = 0.0;
