@@ -293,6 +293,154 @@ static int validate_reachable(const nsk_graph_desc *d, Compiled &c, const std::v
     return NSK_OK;
 }
 
+// Colouring of the sampled variables: no two variables of a colour may read each other.  Greedy first fit in id
+// order, a symmetry check of the reads (repaired with reverse lists when a raw index is asymmetric), iterated greedy
+// (class by class, the classes of a pass over the host threads) and a balancing pass.  for_each_read(v, fn) calls
+// fn(b) for every variable b that v reads; lap(name) closes a timed stage.  Returns the number of colours.
+template <typename ReadFn, typename LapFn>
+static int32_t colour_sampled(Compiled &c, const std::vector<uint8_t> &sampled, ReadFn &&for_each_read, LapFn &&lap) {
+    const int64_t nvar = c.nvar;
+    c.color.assign(nvar, -1);
+    std::vector<int64_t> stamp(1, -1), load;
+    int32_t ncolors = 0;
+    // greedy first fit in id order, then a balancing pass (below)
+    auto pick = [&](int64_t v) -> int32_t {
+        int32_t col = 0;
+        while (col < ncolors && stamp[col] == v) col++;
+        if (col == ncolors) { ncolors++; stamp.push_back(-1); load.push_back(0); }
+        load[col]++;
+        return col;
+    };
+    for (int64_t v = 0; v < nvar; v++) {
+        if (!sampled[v]) continue;
+        for_each_read(v, [&](int64_t b) {
+            if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
+        });
+        c.color[v] = pick(v);
+    }
+    lap("greedy colouring");
+    // the greedy pass assumes reads are symmetric (true for compute_var_map output); verify, and
+    // repair with explicit reverse-read lists when a raw index is asymmetric
+    bool conflict = false;
+    {
+        std::vector<uint8_t> bad((size_t)compile_threads(), 0);
+        parallel_for(nvar, [&](int64_t b0, int64_t b1, int t) {
+            for (int64_t v = b0; v < b1 && !bad[(size_t)t]; v++) {
+                if (!sampled[v]) continue;
+                for_each_read(v, [&](int64_t b) {
+                    if (b != v && c.color[b] == c.color[v]) bad[(size_t)t] = 1;
+                });
+            }
+        });
+        for (uint8_t x : bad) conflict = conflict || x;
+    }
+    if (conflict) {
+        std::vector<int64_t> rcount(nvar + 1, 0);
+        for (int64_t v = 0; v < nvar; v++)
+            if (sampled[v]) for_each_read(v, [&](int64_t b) { if (b != v) rcount[b + 1]++; });
+        for (int64_t v = 0; v < nvar; v++) rcount[v + 1] += rcount[v];
+        std::vector<int32_t> readers((size_t)rcount[nvar]);
+        std::vector<int64_t> fill(rcount.begin(), rcount.end() - 1);
+        for (int64_t v = 0; v < nvar; v++)
+            if (sampled[v]) for_each_read(v, [&](int64_t b) { if (b != v) readers[fill[b]++] = (int32_t)v; });
+        std::fill(c.color.begin(), c.color.end(), -1);
+        stamp.assign(1, -1);
+        load.clear();
+        ncolors = 0;
+        for (int64_t v = 0; v < nvar; v++) {
+            if (!sampled[v]) continue;
+            for_each_read(v, [&](int64_t b) {
+                if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
+            });
+            for (int64_t j = rcount[v]; j < rcount[v + 1]; j++) {
+                int32_t a = readers[j];
+                if (c.color[a] >= 0) stamp[c.color[a]] = v;
+            }
+            c.color[v] = pick(v);
+        }
+    }
+
+    lap("symmetry check");
+    // fewer classes: iterated greedy (Culberson) -- recolour first fit with the vertices taken class
+    // by class in a permuted class order; a class stays independent, so the count never grows, and
+    // a few passes typically drop one or two classes (LR graph: 9 -> 7).  Every class costs a
+    // kernel's latency floor, so this is sweep time.
+    if (!conflict && ncolors > 2 && !diag_env("NSK_NO_RECOLOUR")) {
+        std::vector<int32_t> newc(nvar), seq;
+        seq.reserve((size_t)nvar);
+        const int npass = diag_env("NSK_RECOLOUR_PASSES") ? atoi(diag_env("NSK_RECOLOUR_PASSES")) : 6;
+        int stale = 0;                                   // passes in a row that dropped no class
+        for (int pass = 0; pass < npass && stale < 2; pass++) {       // (each pass is a serial walk of the graph)
+            std::vector<int64_t> size((size_t)ncolors, 0);
+            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) size[c.color[v]]++;
+            std::vector<int32_t> cls((size_t)ncolors);
+            for (int32_t k = 0; k < ncolors; k++) cls[k] = k;
+            if (pass % 3 == 0) std::reverse(cls.begin(), cls.end());
+            else std::stable_sort(cls.begin(), cls.end(), [&](int32_t a, int32_t b) {
+                return pass % 3 == 1 ? size[a] > size[b] : size[a] < size[b]; });
+            std::vector<int64_t> at((size_t)ncolors + 1, 0);           // counting sort by class rank
+            std::vector<int32_t> rank((size_t)ncolors);
+            for (int32_t r = 0; r < ncolors; r++) rank[cls[r]] = r;
+            for (int32_t k = 0; k < ncolors; k++) at[rank[k] + 1] = size[k];
+            for (int32_t r = 0; r < ncolors; r++) at[r + 1] += at[r];
+            seq.assign((size_t)at[ncolors], 0);
+            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) seq[at[rank[c.color[v]]]++] = (int32_t)v;
+            std::fill(newc.begin(), newc.end(), -1);
+            // The vertices of one old class are not adjacent, so first fit gives each of them the same
+            // colour whether they are taken one after the other or all at once: class by class, the
+            // class's vertices over the host threads (each reads only colours of earlier classes).
+            int32_t nnew = 0;
+            for (int32_t r = 0; r < ncolors; r++) {
+                const int64_t a0 = r ? at[r - 1] : 0, a1 = at[r];       // (at[] now holds the classes' ends in seq)
+                std::vector<int32_t> tmax((size_t)compile_threads(), -1);
+                parallel_for(a1 - a0, [&](int64_t b0, int64_t b1, int t) {
+                    std::vector<int64_t> st((size_t)ncolors + 1, -1);
+                    int32_t mx = -1;
+                    for (int64_t i = a0 + b0; i < a0 + b1; i++) {
+                        const int32_t v = seq[(size_t)i];
+                        for_each_read(v, [&](int64_t b) {
+                            if (b != v && newc[b] >= 0) st[newc[b]] = v;
+                        });
+                        int32_t col = 0;
+                        while (st[col] == v) col++;                  // (at most ncolors colours are in use)
+                        newc[v] = col;
+                        mx = std::max(mx, col);
+                    }
+                    tmax[(size_t)t] = mx;
+                });
+                for (int32_t m : tmax) nnew = std::max(nnew, m + 1);
+            }
+            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) c.color[v] = newc[v];
+            stale = nnew < ncolors ? 0 : stale + 1;
+            ncolors = nnew;
+        }
+        stamp.assign((size_t)ncolors, -1);
+        load.assign((size_t)ncolors, 0);
+        for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) load[c.color[v]]++;
+    }
+
+    lap("iterated greedy");
+    // balancing: first fit leaves a few huge classes and a tail of tiny ones, and every class costs
+    // a kernel's latency floor however few variables it holds.  Move variables, in id order, from
+    // their class to the least populated class none of their neighbours is in (reads are symmetric
+    // here -- the asymmetric repair above skips this pass).
+    if (!conflict && ncolors > 2 && !diag_env("NSK_NO_BALANCE")) {
+        for (int pass = 0; pass < 2; pass++)
+            for (int64_t v = 0; v < nvar; v++) {
+                if (!sampled[v]) continue;
+                const int32_t cur = c.color[v];
+                for_each_read(v, [&](int64_t b) {
+                    if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
+                });
+                int32_t best = cur;
+                for (int32_t k = 0; k < ncolors; k++)
+                    if (k != cur && stamp[k] != v && load[k] + 1 < load[best]) best = k;
+                if (best != cur) { load[cur]--; load[best]++; c.color[v] = best; }
+            }
+    }
+    return ncolors;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -481,145 +629,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int32_t j = 0, n = rd_len[v]; j < n; j++) fn_((int64_t)p[j]);
     };
     lap("read lists");
-    c.color.assign(nvar, -1);
-    std::vector<int64_t> stamp(1, -1), load;
-    int32_t ncolors = 0;
-    // greedy first fit in id order, then a balancing pass (below)
-    auto pick = [&](int64_t v) -> int32_t {
-        int32_t col = 0;
-        while (col < ncolors && stamp[col] == v) col++;
-        if (col == ncolors) { ncolors++; stamp.push_back(-1); load.push_back(0); }
-        load[col]++;
-        return col;
-    };
-    for (int64_t v = 0; v < nvar; v++) {
-        if (!sampled[v]) continue;
-        for_each_read(v, [&](int64_t b) {
-            if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
-        });
-        c.color[v] = pick(v);
-    }
-    lap("greedy colouring");
-    // the greedy pass assumes reads are symmetric (true for compute_var_map output); verify, and
-    // repair with explicit reverse-read lists when a raw index is asymmetric
-    bool conflict = false;
-    {
-        std::vector<uint8_t> bad((size_t)compile_threads(), 0);
-        parallel_for(nvar, [&](int64_t b0, int64_t b1, int t) {
-            for (int64_t v = b0; v < b1 && !bad[(size_t)t]; v++) {
-                if (!sampled[v]) continue;
-                for_each_read(v, [&](int64_t b) {
-                    if (b != v && c.color[b] == c.color[v]) bad[(size_t)t] = 1;
-                });
-            }
-        });
-        for (uint8_t x : bad) conflict = conflict || x;
-    }
-    if (conflict) {
-        std::vector<int64_t> rcount(nvar + 1, 0);
-        for (int64_t v = 0; v < nvar; v++)
-            if (sampled[v]) for_each_read(v, [&](int64_t b) { if (b != v) rcount[b + 1]++; });
-        for (int64_t v = 0; v < nvar; v++) rcount[v + 1] += rcount[v];
-        std::vector<int32_t> readers((size_t)rcount[nvar]);
-        std::vector<int64_t> fill(rcount.begin(), rcount.end() - 1);
-        for (int64_t v = 0; v < nvar; v++)
-            if (sampled[v]) for_each_read(v, [&](int64_t b) { if (b != v) readers[fill[b]++] = (int32_t)v; });
-        std::fill(c.color.begin(), c.color.end(), -1);
-        stamp.assign(1, -1);
-        load.clear();
-        ncolors = 0;
-        for (int64_t v = 0; v < nvar; v++) {
-            if (!sampled[v]) continue;
-            for_each_read(v, [&](int64_t b) {
-                if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
-            });
-            for (int64_t j = rcount[v]; j < rcount[v + 1]; j++) {
-                int32_t a = readers[j];
-                if (c.color[a] >= 0) stamp[c.color[a]] = v;
-            }
-            c.color[v] = pick(v);
-        }
-    }
-
-    lap("symmetry check");
-    // fewer classes: iterated greedy (Culberson) -- recolour first fit with the vertices taken class
-    // by class in a permuted class order; a class stays independent, so the count never grows, and
-    // a few passes typically drop one or two classes (LR graph: 9 -> 7).  Every class costs a
-    // kernel's latency floor, so this is sweep time.
-    if (!conflict && ncolors > 2 && !diag_env("NSK_NO_RECOLOUR")) {
-        std::vector<int32_t> newc(nvar), seq;
-        seq.reserve((size_t)nvar);
-        const int npass = diag_env("NSK_RECOLOUR_PASSES") ? atoi(diag_env("NSK_RECOLOUR_PASSES")) : 6;
-        int stale = 0;                                   // passes in a row that dropped no class
-        for (int pass = 0; pass < npass && stale < 2; pass++) {       // (each pass is a serial walk of the graph)
-            std::vector<int64_t> size((size_t)ncolors, 0);
-            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) size[c.color[v]]++;
-            std::vector<int32_t> cls((size_t)ncolors);
-            for (int32_t k = 0; k < ncolors; k++) cls[k] = k;
-            if (pass % 3 == 0) std::reverse(cls.begin(), cls.end());
-            else std::stable_sort(cls.begin(), cls.end(), [&](int32_t a, int32_t b) {
-                return pass % 3 == 1 ? size[a] > size[b] : size[a] < size[b]; });
-            std::vector<int64_t> at((size_t)ncolors + 1, 0);           // counting sort by class rank
-            std::vector<int32_t> rank((size_t)ncolors);
-            for (int32_t r = 0; r < ncolors; r++) rank[cls[r]] = r;
-            for (int32_t k = 0; k < ncolors; k++) at[rank[k] + 1] = size[k];
-            for (int32_t r = 0; r < ncolors; r++) at[r + 1] += at[r];
-            seq.assign((size_t)at[ncolors], 0);
-            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) seq[at[rank[c.color[v]]]++] = (int32_t)v;
-            std::fill(newc.begin(), newc.end(), -1);
-            // The vertices of one old class are not adjacent, so first fit gives each of them the same
-            // colour whether they are taken one after the other or all at once: class by class, the
-            // class's vertices over the host threads (each reads only colours of earlier classes).
-            int32_t nnew = 0;
-            for (int32_t r = 0; r < ncolors; r++) {
-                const int64_t a0 = r ? at[r - 1] : 0, a1 = at[r];       // (at[] now holds the classes' ends in seq)
-                std::vector<int32_t> tmax((size_t)compile_threads(), -1);
-                parallel_for(a1 - a0, [&](int64_t b0, int64_t b1, int t) {
-                    std::vector<int64_t> st((size_t)ncolors + 1, -1);
-                    int32_t mx = -1;
-                    for (int64_t i = a0 + b0; i < a0 + b1; i++) {
-                        const int32_t v = seq[(size_t)i];
-                        for_each_read(v, [&](int64_t b) {
-                            if (b != v && newc[b] >= 0) st[newc[b]] = v;
-                        });
-                        int32_t col = 0;
-                        while (st[col] == v) col++;                  // (at most ncolors colours are in use)
-                        newc[v] = col;
-                        mx = std::max(mx, col);
-                    }
-                    tmax[(size_t)t] = mx;
-                });
-                for (int32_t m : tmax) nnew = std::max(nnew, m + 1);
-            }
-            for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) c.color[v] = newc[v];
-            stale = nnew < ncolors ? 0 : stale + 1;
-            ncolors = nnew;
-        }
-        stamp.assign((size_t)ncolors, -1);
-        load.assign((size_t)ncolors, 0);
-        for (int64_t v = 0; v < nvar; v++) if (c.color[v] >= 0) load[c.color[v]]++;
-    }
-
-    lap("iterated greedy");
-    // balancing: first fit leaves a few huge classes and a tail of tiny ones, and every class costs
-    // a kernel's latency floor however few variables it holds.  Move variables, in id order, from
-    // their class to the least populated class none of their neighbours is in (reads are symmetric
-    // here -- the asymmetric repair above skips this pass).
-    if (!conflict && ncolors > 2 && !diag_env("NSK_NO_BALANCE")) {
-        for (int pass = 0; pass < 2; pass++)
-            for (int64_t v = 0; v < nvar; v++) {
-                if (!sampled[v]) continue;
-                const int32_t cur = c.color[v];
-                for_each_read(v, [&](int64_t b) {
-                    if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
-                });
-                int32_t best = cur;
-                for (int32_t k = 0; k < ncolors; k++)
-                    if (k != cur && stamp[k] != v && load[k] + 1 < load[best]) best = k;
-                if (best != cur) { load[cur]--; load[best]++; c.color[v] = best; }
-            }
-    }
-
+    int32_t ncolors = colour_sampled(c, sampled, for_each_read, lap);
     lap("balancing");
     // ---- ghosts: variables outside the owned range read by a sampled variable -------------------
     if (ob > 0 || oe < nvar) {
