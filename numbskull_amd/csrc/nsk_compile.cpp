@@ -441,6 +441,139 @@ static int32_t colour_sampled(Compiled &c, const std::vector<uint8_t> &sampled, 
     return ncolors;
 }
 
+// Entry-parallel groups (nsk_compile.h ep_desc): the general tiles of an EP colour, four at a time, as rows of 64
+// list entries sorted by their member count.  general_words(v, &out) is the compiler's per-variable entry list;
+// lap(name) closes a timed stage.
+template <typename WordsFn, typename LapFn>
+static int build_ep_groups(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, WordsFn &&general_words, LapFn &&lap,
+                           bool verbose, std::string &err) {
+    const int64_t nw = c.nweight;
+    (void)d; (void)nw;
+    // ---- entry-parallel groups (nsk_compile.h ep_desc): the general tiles of an EP colour, four at a
+    // time, as rows of 64 list entries sorted by their member count
+    c.phase_ep_base.assign((size_t)ncolors + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++) {
+        const int64_t ngt = (c.phase_wb_base[k + 1] - c.phase_wb_base[k]) - c.phase_gen_tile[k];
+        c.phase_ep_base[k + 1] = c.phase_ep_base[k] + (c.phase_ep[k] ? (ngt + 3) / 4 : 0);
+    }
+    {
+        const int64_t ngroups = c.phase_ep_base[ncolors];
+        c.ep_desc.assign((size_t)ngroups * 4 + 4, 0u);
+        c.ep_wrow.assign((size_t)ngroups + 1, 0u);
+        std::vector<int32_t> group_colour((size_t)ngroups);
+        for (int32_t k = 0; k < ncolors; k++)
+            for (int64_t gi = c.phase_ep_base[k]; gi < c.phase_ep_base[k + 1]; gi++) group_colour[gi] = k;
+        auto group_range = [&](int64_t gi, int64_t &p0, int64_t &p1) {
+            const int32_t k = group_colour[gi];
+            p0 = c.phase_start[k] + 64 * (c.phase_gen_tile[k] + 4 * (gi - c.phase_ep_base[k]));
+            p1 = std::min(p0 + 256, c.phase_fast_end[k]);
+        };
+        std::vector<uint64_t> subrows((size_t)ngroups + 1, 0);
+        // row classes: member count M = 0..3 of the entries with ordinal < 8 ("base", classes 0-3),
+        // then the same for ordinals 8..15 ("overflow", classes 4-7): the kernels hold 8 list positions
+        // per variable in LDS and take a group with longer lists in two passes
+        auto row_class = [](uint32_t m, uint32_t ordinal) { return m + (ordinal >= 8 ? 4u : 0u); };
+        parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass A: rows per class
+            std::vector<uint32_t> w;
+            for (int64_t gi = g0; gi < g1; gi++) {
+                int64_t p0, p1;
+                group_range(gi, p0, p1);
+                uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, emax = 0, maxcard = 2;
+                for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;
+                    general_words(c.p_vid[p], &w);
+                    uint32_t ne = 0;
+                    for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) { cnt[row_class((w[j + 1] >> 4) & 7u, ne)]++; ne++; }
+                    emax = std::max(emax, ne);
+                    maxcard = std::max(maxcard, (uint32_t)d->variable[c.p_vid[p]].cardinality);
+                }
+                uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
+                uint64_t sr = 0;
+                gd[1] = 0; gd[3] = 0;
+                for (uint32_t cl = 0; cl < 8; cl++) {
+                    const uint32_t rows = (cnt[cl] + 63) / 64;
+                    gd[cl < 4 ? 1 : 3] |= rows << (8 * (cl & 3u));
+                    sr += (uint64_t)rows * (2 + (cl & 3u));
+                }
+                gd[2] = emax | (maxcard << 8);
+                subrows[gi + 1] = sr;
+                uint32_t nrows = 0;
+                for (uint32_t cl = 0; cl < 8; cl++) nrows += (cnt[cl] + 63) / 64;
+                c.ep_wrow[gi + 1] = nrows;
+            }
+        }, 8);                                      // (a group is 256 variables' worth of work)
+        lap("entry-parallel groups: rows");
+        for (int64_t gi = 0; gi < ngroups; gi++) {
+            const uint64_t next = (uint64_t)c.ep_wrow[gi] + c.ep_wrow[gi + 1];
+            if (next >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
+            c.ep_wrow[gi + 1] = (uint32_t)next;
+        }
+        for (int64_t gi = 0; gi < ngroups; gi++) subrows[gi + 1] += subrows[gi];
+        if (subrows[ngroups] * 64 >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
+        c.ep_adj.assign((size_t)subrows[ngroups] * 64 + 64, 0u);
+        // structural visit counts (nsk_compile.h ep_kstat): global accumulators only (graphs with few
+        // weights accumulate in LDS tables, where an update costs nothing); counted in pass B (atomic
+        // increments: a weight's entries are spread over the groups, contention is negligible)
+        const bool want_kstat = ngroups > 0 && nw > 256 && (int64_t)ncolors * nw * 2 <= ((int64_t)1 << 26) && !diag_env("NSK_NO_KSTAT") &&
+                                c.ndirect == 0;      // (direct weights are updated at their visit: every visit must reach the kernel)
+        if (want_kstat) c.ep_kstat.assign((size_t)ncolors * 2 * (size_t)nw, 0u);
+        lap("entry-parallel groups: allocation");
+        parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass B: fill
+            std::vector<uint32_t> w;
+            for (int64_t gi = g0; gi < g1; gi++) {
+                int64_t p0, p1;
+                group_range(gi, p0, p1);
+                uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
+                gd[0] = (uint32_t)subrows[gi];
+                uint64_t base[8], at[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first sub-row / entries placed, per class
+                uint64_t sr = subrows[gi];
+                for (uint32_t cl = 0; cl < 8; cl++) {
+                    const uint32_t m = cl & 3u;
+                    base[cl] = sr;
+                    const uint32_t rows = (gd[cl < 4 ? 1 : 3] >> (8 * m)) & 255u;
+                    // padding entries of the last row: owned by no candidate, empty member slots
+                    for (uint64_t r = 0; r < rows; r++)
+                        for (uint32_t e = 0; e < 64; e++) {
+                            uint32_t *row = &c.ep_adj[(sr + r * (2 + m)) * 64];
+                            row[2 * e] = 0u; row[2 * e + 1] = 14u << 14;
+                            for (uint32_t mm = 0; mm < m; mm++) row[(2 + mm) * 64 + e] = NSK_GEN_NULL;
+                        }
+                    sr += (uint64_t)rows * (2 + m);
+                }
+                const int32_t gk = group_colour[gi];
+                for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;
+                    general_words(c.p_vid[p], &w);
+                    const nsk_variable &var = d->variable[c.p_vid[p]];
+                    if (want_kstat && var.dataType == 0) {
+                        const size_t o = var.isEvidence == 1 ? 0 : 1;
+                        for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u))
+                            if (!c.w_fixed[w[j]])
+                                __atomic_fetch_add(&c.ep_kstat[((size_t)gk * 2 + o) * (size_t)nw + w[j]], 1u, __ATOMIC_RELAXED);
+                    }
+                    uint32_t ordinal = 0;
+                    for (size_t j = 0; j < w.size(); ordinal++) {
+                        const uint32_t m = (w[j + 1] >> 4) & 7u, cl = row_class(m, ordinal);
+                        const uint64_t r = at[cl] / 64, e = at[cl] % 64;
+                        at[cl]++;
+                        uint32_t *row = &c.ep_adj[(base[cl] + r * (2 + m)) * 64];
+                        const uint32_t wid = w[j];
+                        row[2 * e] = wid | (ordinal << 27);
+                        row[2 * e + 1] = w[j + 1] | ((uint32_t)(p - p0) << 23) | (c.w_fixed[wid] ? 0x80000000u : 0u);
+                        for (uint32_t mm = 0; mm < m; mm++)
+                            row[(2 + mm) * 64 + e] = (uint32_t)c.iid[w[j + 2 + mm] & NSK_GEN_NULL] | (w[j + 2 + mm] & ~NSK_GEN_NULL);
+                        j += 2 + m;
+                    }
+                }
+            }
+        }, 8);
+        if (verbose && ngroups)
+            fprintf(stderr, "[nsk] entry-parallel groups %lld, stream %.1f MB\n", (long long)ngroups,
+                    (double)subrows[ngroups] * 256 / 1e6);
+    }
+    return NSK_OK;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1584,128 +1717,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         for (int64_t x : nfast_part) c.nfast += x;
     }
     lap("tile fill (pass 2)");
-    // ---- entry-parallel groups (nsk_compile.h ep_desc): the general tiles of an EP colour, four at a
-    // time, as rows of 64 list entries sorted by their member count
-    c.phase_ep_base.assign((size_t)ncolors + 1, 0);
-    for (int32_t k = 0; k < ncolors; k++) {
-        const int64_t ngt = (c.phase_wb_base[k + 1] - c.phase_wb_base[k]) - c.phase_gen_tile[k];
-        c.phase_ep_base[k + 1] = c.phase_ep_base[k] + (c.phase_ep[k] ? (ngt + 3) / 4 : 0);
-    }
-    {
-        const int64_t ngroups = c.phase_ep_base[ncolors];
-        c.ep_desc.assign((size_t)ngroups * 4 + 4, 0u);
-        c.ep_wrow.assign((size_t)ngroups + 1, 0u);
-        std::vector<int32_t> group_colour((size_t)ngroups);
-        for (int32_t k = 0; k < ncolors; k++)
-            for (int64_t gi = c.phase_ep_base[k]; gi < c.phase_ep_base[k + 1]; gi++) group_colour[gi] = k;
-        auto group_range = [&](int64_t gi, int64_t &p0, int64_t &p1) {
-            const int32_t k = group_colour[gi];
-            p0 = c.phase_start[k] + 64 * (c.phase_gen_tile[k] + 4 * (gi - c.phase_ep_base[k]));
-            p1 = std::min(p0 + 256, c.phase_fast_end[k]);
-        };
-        std::vector<uint64_t> subrows((size_t)ngroups + 1, 0);
-        // row classes: member count M = 0..3 of the entries with ordinal < 8 ("base", classes 0-3),
-        // then the same for ordinals 8..15 ("overflow", classes 4-7): the kernels hold 8 list positions
-        // per variable in LDS and take a group with longer lists in two passes
-        auto row_class = [](uint32_t m, uint32_t ordinal) { return m + (ordinal >= 8 ? 4u : 0u); };
-        parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass A: rows per class
-            std::vector<uint32_t> w;
-            for (int64_t gi = g0; gi < g1; gi++) {
-                int64_t p0, p1;
-                group_range(gi, p0, p1);
-                uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, emax = 0, maxcard = 2;
-                for (int64_t p = p0; p < p1; p++) {
-                    if (c.p_vid[p] < 0) continue;
-                    general_words(c.p_vid[p], &w);
-                    uint32_t ne = 0;
-                    for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) { cnt[row_class((w[j + 1] >> 4) & 7u, ne)]++; ne++; }
-                    emax = std::max(emax, ne);
-                    maxcard = std::max(maxcard, (uint32_t)d->variable[c.p_vid[p]].cardinality);
-                }
-                uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
-                uint64_t sr = 0;
-                gd[1] = 0; gd[3] = 0;
-                for (uint32_t cl = 0; cl < 8; cl++) {
-                    const uint32_t rows = (cnt[cl] + 63) / 64;
-                    gd[cl < 4 ? 1 : 3] |= rows << (8 * (cl & 3u));
-                    sr += (uint64_t)rows * (2 + (cl & 3u));
-                }
-                gd[2] = emax | (maxcard << 8);
-                subrows[gi + 1] = sr;
-                uint32_t nrows = 0;
-                for (uint32_t cl = 0; cl < 8; cl++) nrows += (cnt[cl] + 63) / 64;
-                c.ep_wrow[gi + 1] = nrows;
-            }
-        }, 8);                                      // (a group is 256 variables' worth of work)
-        lap("entry-parallel groups: rows");
-        for (int64_t gi = 0; gi < ngroups; gi++) {
-            const uint64_t next = (uint64_t)c.ep_wrow[gi] + c.ep_wrow[gi + 1];
-            if (next >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
-            c.ep_wrow[gi + 1] = (uint32_t)next;
-        }
-        for (int64_t gi = 0; gi < ngroups; gi++) subrows[gi + 1] += subrows[gi];
-        if (subrows[ngroups] * 64 >= ((uint64_t)1 << 31)) { err = "entry-parallel stream too large"; return NSK_E_RANGE; }
-        c.ep_adj.assign((size_t)subrows[ngroups] * 64 + 64, 0u);
-        // structural visit counts (nsk_compile.h ep_kstat): global accumulators only (graphs with few
-        // weights accumulate in LDS tables, where an update costs nothing); counted in pass B (atomic
-        // increments: a weight's entries are spread over the groups, contention is negligible)
-        const bool want_kstat = ngroups > 0 && nw > 256 && (int64_t)ncolors * nw * 2 <= ((int64_t)1 << 26) && !diag_env("NSK_NO_KSTAT") &&
-                                c.ndirect == 0;      // (direct weights are updated at their visit: every visit must reach the kernel)
-        if (want_kstat) c.ep_kstat.assign((size_t)ncolors * 2 * (size_t)nw, 0u);
-        lap("entry-parallel groups: allocation");
-        parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {          // pass B: fill
-            std::vector<uint32_t> w;
-            for (int64_t gi = g0; gi < g1; gi++) {
-                int64_t p0, p1;
-                group_range(gi, p0, p1);
-                uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
-                gd[0] = (uint32_t)subrows[gi];
-                uint64_t base[8], at[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first sub-row / entries placed, per class
-                uint64_t sr = subrows[gi];
-                for (uint32_t cl = 0; cl < 8; cl++) {
-                    const uint32_t m = cl & 3u;
-                    base[cl] = sr;
-                    const uint32_t rows = (gd[cl < 4 ? 1 : 3] >> (8 * m)) & 255u;
-                    // padding entries of the last row: owned by no candidate, empty member slots
-                    for (uint64_t r = 0; r < rows; r++)
-                        for (uint32_t e = 0; e < 64; e++) {
-                            uint32_t *row = &c.ep_adj[(sr + r * (2 + m)) * 64];
-                            row[2 * e] = 0u; row[2 * e + 1] = 14u << 14;
-                            for (uint32_t mm = 0; mm < m; mm++) row[(2 + mm) * 64 + e] = NSK_GEN_NULL;
-                        }
-                    sr += (uint64_t)rows * (2 + m);
-                }
-                const int32_t gk = group_colour[gi];
-                for (int64_t p = p0; p < p1; p++) {
-                    if (c.p_vid[p] < 0) continue;
-                    general_words(c.p_vid[p], &w);
-                    const nsk_variable &var = d->variable[c.p_vid[p]];
-                    if (want_kstat && var.dataType == 0) {
-                        const size_t o = var.isEvidence == 1 ? 0 : 1;
-                        for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u))
-                            if (!c.w_fixed[w[j]])
-                                __atomic_fetch_add(&c.ep_kstat[((size_t)gk * 2 + o) * (size_t)nw + w[j]], 1u, __ATOMIC_RELAXED);
-                    }
-                    uint32_t ordinal = 0;
-                    for (size_t j = 0; j < w.size(); ordinal++) {
-                        const uint32_t m = (w[j + 1] >> 4) & 7u, cl = row_class(m, ordinal);
-                        const uint64_t r = at[cl] / 64, e = at[cl] % 64;
-                        at[cl]++;
-                        uint32_t *row = &c.ep_adj[(base[cl] + r * (2 + m)) * 64];
-                        const uint32_t wid = w[j];
-                        row[2 * e] = wid | (ordinal << 27);
-                        row[2 * e + 1] = w[j + 1] | ((uint32_t)(p - p0) << 23) | (c.w_fixed[wid] ? 0x80000000u : 0u);
-                        for (uint32_t mm = 0; mm < m; mm++)
-                            row[(2 + mm) * 64 + e] = (uint32_t)c.iid[w[j + 2 + mm] & NSK_GEN_NULL] | (w[j + 2 + mm] & ~NSK_GEN_NULL);
-                        j += 2 + m;
-                    }
-                }
-            }
-        }, 8);
-        if (verbose && ngroups)
-            fprintf(stderr, "[nsk] entry-parallel groups %lld, stream %.1f MB\n", (long long)ngroups,
-                    (double)subrows[ngroups] * 256 / 1e6);
-    }
+    if (int erc = build_ep_groups(d, c, ncolors, general_words, lap, verbose, err)) return erc;
     lap("entry-parallel groups");
     // ---- implicit adjacency of table segments (nsk_compile.h seg_aff)
     {
