@@ -574,6 +574,47 @@ static int build_ep_groups(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     return NSK_OK;
 }
 
+// Implicit adjacency of table segments (nsk_compile.h seg_aff): per tile the base ids of its member runs when the
+// lanes' members are consecutive (a regular grid), so the sweep kernels need no stream there.
+static int build_segment_adjacency(Compiled &c, std::string &err) {
+    uint64_t ntile4 = 0;
+    const bool no_aff = diag_env("NSK_NO_AFFINE") != nullptr;
+    for (Compiled::Segment &sg : c.segments) {
+        sg.aff = -1;
+        if (sg.ztab < 0 || no_aff) continue;
+        sg.aff = (int64_t)ntile4;
+        ntile4 += (uint64_t)sg.ntiles * (sg.nslots > 4 ? 2 : 1);
+    }
+    if (ntile4 >= ((uint64_t)1 << 30)) { err = "implicit adjacency table too large"; return NSK_E_RANGE; }
+    c.seg_aff.assign((size_t)ntile4 * 4 + 4, 0xFFFFFFFFu);
+    for (const Compiled::Segment &sg : c.segments) {
+        if (sg.aff < 0) continue;
+        const int nch = sg.nslots > 4 ? 2 : 1;
+        parallel_for(sg.ntiles, [&](int64_t tb0, int64_t tb1, int) {
+            for (int64_t t = tb0; t < tb1; t++) {
+                const uint64_t wbase = ((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4;
+                int64_t first = -1;                         // first live lane
+                for (int64_t i = 0; i < 64 && first < 0; i++) if (c.p_vid[sg.pos0 + 64 * t + i] >= 0) first = i;
+                if (first < 0) continue;
+                bool ok = true;
+                uint32_t base[8];
+                for (uint32_t j = 0; j < (uint32_t)(4 * nch) && ok; j++) {
+                    const uint64_t wj = wbase + 256 * (j / 4) + (j % 4);
+                    const int64_t b0 = (int64_t)c.adj[wj + 4 * first] - first;
+                    if (b0 < 0 || b0 + 63 >= c.nid) { ok = false; break; }       // every lane reads a valid id
+                    for (int64_t i = 0; i < 64 && ok; i++)
+                        if (c.p_vid[sg.pos0 + 64 * t + i] >= 0 && (int64_t)c.adj[wj + 4 * i] != b0 + i) ok = false;
+                    base[j] = (uint32_t)b0;
+                }
+                if (!ok || base[0] == 0xFFFFFFFFu) continue;
+                for (int cidx = 0; cidx < nch; cidx++)
+                    for (int q = 0; q < 4; q++) c.seg_aff[((size_t)sg.aff + (size_t)t * nch + cidx) * 4 + q] = base[4 * cidx + q];
+            }
+        }, 64);
+    }
+    return NSK_OK;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1719,44 +1760,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     lap("tile fill (pass 2)");
     if (int erc = build_ep_groups(d, c, ncolors, general_words, lap, verbose, err)) return erc;
     lap("entry-parallel groups");
-    // ---- implicit adjacency of table segments (nsk_compile.h seg_aff)
-    {
-        uint64_t ntile4 = 0;
-        const bool no_aff = diag_env("NSK_NO_AFFINE") != nullptr;
-        for (Compiled::Segment &sg : c.segments) {
-            sg.aff = -1;
-            if (sg.ztab < 0 || no_aff) continue;
-            sg.aff = (int64_t)ntile4;
-            ntile4 += (uint64_t)sg.ntiles * (sg.nslots > 4 ? 2 : 1);
-        }
-        if (ntile4 >= ((uint64_t)1 << 30)) { err = "implicit adjacency table too large"; return NSK_E_RANGE; }
-        c.seg_aff.assign((size_t)ntile4 * 4 + 4, 0xFFFFFFFFu);
-        for (const Compiled::Segment &sg : c.segments) {
-            if (sg.aff < 0) continue;
-            const int nch = sg.nslots > 4 ? 2 : 1;
-            parallel_for(sg.ntiles, [&](int64_t tb0, int64_t tb1, int) {
-                for (int64_t t = tb0; t < tb1; t++) {
-                    const uint64_t wbase = ((uint64_t)sg.adj_off + (uint64_t)t * 64 * nch) * 4;
-                    int64_t first = -1;                         // first live lane
-                    for (int64_t i = 0; i < 64 && first < 0; i++) if (c.p_vid[sg.pos0 + 64 * t + i] >= 0) first = i;
-                    if (first < 0) continue;
-                    bool ok = true;
-                    uint32_t base[8];
-                    for (uint32_t j = 0; j < (uint32_t)(4 * nch) && ok; j++) {
-                        const uint64_t wj = wbase + 256 * (j / 4) + (j % 4);
-                        const int64_t b0 = (int64_t)c.adj[wj + 4 * first] - first;
-                        if (b0 < 0 || b0 + 63 >= c.nid) { ok = false; break; }       // every lane reads a valid id
-                        for (int64_t i = 0; i < 64 && ok; i++)
-                            if (c.p_vid[sg.pos0 + 64 * t + i] >= 0 && (int64_t)c.adj[wj + 4 * i] != b0 + i) ok = false;
-                        base[j] = (uint32_t)b0;
-                    }
-                    if (!ok || base[0] == 0xFFFFFFFFu) continue;
-                    for (int cidx = 0; cidx < nch; cidx++)
-                        for (int q = 0; q < 4; q++) c.seg_aff[((size_t)sg.aff + (size_t)t * nch + cidx) * 4 + q] = base[4 * cidx + q];
-                }
-            }, 64);
-        }
-    }
+    if (int arc = build_segment_adjacency(c, err)) return arc;
     // ---- entry-parallel hub streams: a hub (a long-list variable sampled by a whole wave) whose
     // factors are all of the general-tile kind gets its entries laid out one per LANE -- word j of
     // entry e of round r at hub_adj[off + (r * (2 + M) + j) * 64 + e] -- so that one coalesced row
