@@ -615,6 +615,97 @@ static int build_segment_adjacency(Compiled &c, std::string &err) {
     return NSK_OK;
 }
 
+// Hub streams: the long-list variables a whole wave (or workgroup) samples, laid out like the entry-parallel rows.
+// general_words(v, &out, hub, cap) is the compiler's per-variable entry list.
+template <typename WordsFn>
+static int build_hub_streams(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, WordsFn &&general_words, bool no_general,
+                             bool verbose, std::string &err) {
+    const int64_t nw = c.nweight, nvar = c.nvar;
+    (void)d; (void)nw; (void)nvar; (void)err; (void)verbose;
+    // ---- entry-parallel hub streams: a hub (a long-list variable sampled by a whole wave) whose
+    // factors are all of the general-tile kind gets its entries laid out one per LANE -- word j of
+    // entry e of round r at hub_adj[off + (r * (2 + M) + j) * 64 + e] -- so that one coalesced row
+    // load per word, one gather per member and a list-order sum over the lanes replace the
+    // dependent fidx -> factor -> edge -> value chain of the generic hub walk.
+    c.phase_hub_base.assign((size_t)ncolors + 1, 0);            // descriptors: hub ranges only, colour-major
+    for (int32_t k = 0; k < ncolors; k++)
+        c.phase_hub_base[k + 1] = c.phase_hub_base[k] + (c.phase_heavy_end[k] - c.phase_fast_end[k]);
+    c.hub_desc.assign((size_t)(c.phase_hub_base[ncolors] + 1) * 4, 0u);
+    c.phase_bighub_base.assign((size_t)ncolors + 1, 0);
+    std::vector<int32_t> hub_colour;
+    if (!diag_env("NSK_NO_HUB_EP") && !no_general) {
+        std::vector<int64_t> hubs;
+        for (int32_t k = 0; k < ncolors; k++)
+            for (int64_t p = c.phase_fast_end[k]; p < c.phase_heavy_end[k]; p++)
+                if (c.p_vid[p] >= 0) { hubs.push_back(p); hub_colour.push_back(k); }
+        std::vector<uint32_t> nent(hubs.size(), 0), mh(hubs.size(), 0);
+        parallel_for((int64_t)hubs.size(), [&](int64_t b0, int64_t b1, int) {
+            std::vector<uint32_t> w;
+            for (int64_t h = b0; h < b1; h++) {
+                // (a colour laid out as entry-parallel groups has the block-per-hub kernels for long lists)
+                if (!general_words(c.p_vid[hubs[h]], &w, true, c.phase_ep[hub_colour[h]] ? 16384 : 256)) continue;
+                uint32_t ne = 0, mo = 0;
+                for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) { ne++; mo = std::max(mo, (w[j + 1] >> 4) & 7u); }
+                nent[h] = ne; mh[h] = mo;
+            }
+        }, 4);
+        uint64_t total = 0;
+        std::vector<uint64_t> off(hubs.size(), 0);
+        for (size_t h = 0; h < hubs.size(); h++) {
+            if (!nent[h]) continue;
+            off[h] = total;
+            total += (uint64_t)((nent[h] + 63) / 64) * (2 + mh[h]) * 64;
+        }
+        if (total < ((uint64_t)1 << 31)) {
+            c.hub_adj.assign((size_t)total + 64, 0u);
+            parallel_for((int64_t)hubs.size(), [&](int64_t b0, int64_t b1, int) {
+                std::vector<uint32_t> w;
+                for (int64_t h = b0; h < b1; h++) {
+                    if (!nent[h]) continue;
+                    const int64_t p = hubs[h];
+                    const nsk_variable &var = d->variable[c.p_vid[p]];
+                    general_words(c.p_vid[p], &w, true, 16384);
+                    const uint32_t rows = 2 + mh[h], rounds = (nent[h] + 63) / 64;
+                    uint32_t *base = &c.hub_adj[off[h]];
+                    for (uint32_t r = 0; r < rounds; r++)              // padding entries: owned by no candidate
+                        for (uint32_t e = 0; e < 64; e++) {
+                            base[(r * rows + 0) * 64 + e] = 0u;
+                            base[(r * rows + 1) * 64 + e] = 14u << 14;
+                            for (uint32_t m = 0; m < mh[h]; m++) base[(r * rows + 2 + m) * 64 + e] = NSK_GEN_NULL;
+                        }
+                    uint32_t e = 0;
+                    for (size_t j = 0; j < w.size(); e++) {
+                        const uint32_t no = (w[j + 1] >> 4) & 7u, r = e / 64, l = e % 64;
+                        base[(r * rows + 0) * 64 + l] = w[j];
+                        base[(r * rows + 1) * 64 + l] = w[j + 1];
+                        for (uint32_t m = 0; m < no; m++)
+                            base[(r * rows + 2 + m) * 64 + l] = (uint32_t)c.iid[w[j + 2 + m] & NSK_GEN_NULL] | (w[j + 2 + m] & ~NSK_GEN_NULL);
+                        j += 2 + no;
+                    }
+                    const int32_t hk = hub_colour[h];
+                    uint32_t *hd = &c.hub_desc[(size_t)(c.phase_hub_base[hk] + (p - c.phase_fast_end[hk])) * 4];
+                    // hd[3] = 1: a long list, evaluated by a whole workgroup (k_gibbs_ep / k_learn_ep)
+                    hd[0] = (uint32_t)off[h]; hd[1] = nent[h]; hd[2] = mh[h] | ((uint32_t)var.cardinality << 8);
+                    hd[3] = (c.phase_ep[hk] && nent[h] > 128) ? 1u : 0u;
+                }
+            }, 4);
+            for (size_t h = 0; h < hubs.size(); h++) {          // (hubs are listed colour by colour)
+                const int32_t hk = hub_colour[h];
+                if (!c.hub_desc[(size_t)(c.phase_hub_base[hk] + (hubs[h] - c.phase_fast_end[hk])) * 4 + 3]) continue;
+                c.bighub_pos.push_back((uint32_t)hubs[h]);
+                c.phase_bighub_base[hk + 1]++;
+            }
+            c.nhub_ep = 0;
+            for (size_t h = 0; h < hubs.size(); h++) if (nent[h]) c.nhub_ep++;
+            if (verbose) fprintf(stderr, "[nsk] hubs %zu, entry-parallel %lld, stream %.1f MB\n", hubs.size(),
+                                 (long long)c.nhub_ep, (double)total * 4 / 1e6);
+        }
+    }
+    for (int32_t k = 0; k < ncolors; k++) c.phase_bighub_base[k + 1] += c.phase_bighub_base[k];
+    if (c.bighub_pos.empty()) c.bighub_pos.push_back(0);
+    return NSK_OK;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1761,87 +1852,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     if (int erc = build_ep_groups(d, c, ncolors, general_words, lap, verbose, err)) return erc;
     lap("entry-parallel groups");
     if (int arc = build_segment_adjacency(c, err)) return arc;
-    // ---- entry-parallel hub streams: a hub (a long-list variable sampled by a whole wave) whose
-    // factors are all of the general-tile kind gets its entries laid out one per LANE -- word j of
-    // entry e of round r at hub_adj[off + (r * (2 + M) + j) * 64 + e] -- so that one coalesced row
-    // load per word, one gather per member and a list-order sum over the lanes replace the
-    // dependent fidx -> factor -> edge -> value chain of the generic hub walk.
-    c.phase_hub_base.assign((size_t)ncolors + 1, 0);            // descriptors: hub ranges only, colour-major
-    for (int32_t k = 0; k < ncolors; k++)
-        c.phase_hub_base[k + 1] = c.phase_hub_base[k] + (c.phase_heavy_end[k] - c.phase_fast_end[k]);
-    c.hub_desc.assign((size_t)(c.phase_hub_base[ncolors] + 1) * 4, 0u);
-    c.phase_bighub_base.assign((size_t)ncolors + 1, 0);
-    std::vector<int32_t> hub_colour;
-    if (!diag_env("NSK_NO_HUB_EP") && !no_general) {
-        std::vector<int64_t> hubs;
-        for (int32_t k = 0; k < ncolors; k++)
-            for (int64_t p = c.phase_fast_end[k]; p < c.phase_heavy_end[k]; p++)
-                if (c.p_vid[p] >= 0) { hubs.push_back(p); hub_colour.push_back(k); }
-        std::vector<uint32_t> nent(hubs.size(), 0), mh(hubs.size(), 0);
-        parallel_for((int64_t)hubs.size(), [&](int64_t b0, int64_t b1, int) {
-            std::vector<uint32_t> w;
-            for (int64_t h = b0; h < b1; h++) {
-                // (a colour laid out as entry-parallel groups has the block-per-hub kernels for long lists)
-                if (!general_words(c.p_vid[hubs[h]], &w, true, c.phase_ep[hub_colour[h]] ? 16384 : 256)) continue;
-                uint32_t ne = 0, mo = 0;
-                for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) { ne++; mo = std::max(mo, (w[j + 1] >> 4) & 7u); }
-                nent[h] = ne; mh[h] = mo;
-            }
-        }, 4);
-        uint64_t total = 0;
-        std::vector<uint64_t> off(hubs.size(), 0);
-        for (size_t h = 0; h < hubs.size(); h++) {
-            if (!nent[h]) continue;
-            off[h] = total;
-            total += (uint64_t)((nent[h] + 63) / 64) * (2 + mh[h]) * 64;
-        }
-        if (total < ((uint64_t)1 << 31)) {
-            c.hub_adj.assign((size_t)total + 64, 0u);
-            parallel_for((int64_t)hubs.size(), [&](int64_t b0, int64_t b1, int) {
-                std::vector<uint32_t> w;
-                for (int64_t h = b0; h < b1; h++) {
-                    if (!nent[h]) continue;
-                    const int64_t p = hubs[h];
-                    const nsk_variable &var = d->variable[c.p_vid[p]];
-                    general_words(c.p_vid[p], &w, true, 16384);
-                    const uint32_t rows = 2 + mh[h], rounds = (nent[h] + 63) / 64;
-                    uint32_t *base = &c.hub_adj[off[h]];
-                    for (uint32_t r = 0; r < rounds; r++)              // padding entries: owned by no candidate
-                        for (uint32_t e = 0; e < 64; e++) {
-                            base[(r * rows + 0) * 64 + e] = 0u;
-                            base[(r * rows + 1) * 64 + e] = 14u << 14;
-                            for (uint32_t m = 0; m < mh[h]; m++) base[(r * rows + 2 + m) * 64 + e] = NSK_GEN_NULL;
-                        }
-                    uint32_t e = 0;
-                    for (size_t j = 0; j < w.size(); e++) {
-                        const uint32_t no = (w[j + 1] >> 4) & 7u, r = e / 64, l = e % 64;
-                        base[(r * rows + 0) * 64 + l] = w[j];
-                        base[(r * rows + 1) * 64 + l] = w[j + 1];
-                        for (uint32_t m = 0; m < no; m++)
-                            base[(r * rows + 2 + m) * 64 + l] = (uint32_t)c.iid[w[j + 2 + m] & NSK_GEN_NULL] | (w[j + 2 + m] & ~NSK_GEN_NULL);
-                        j += 2 + no;
-                    }
-                    const int32_t hk = hub_colour[h];
-                    uint32_t *hd = &c.hub_desc[(size_t)(c.phase_hub_base[hk] + (p - c.phase_fast_end[hk])) * 4];
-                    // hd[3] = 1: a long list, evaluated by a whole workgroup (k_gibbs_ep / k_learn_ep)
-                    hd[0] = (uint32_t)off[h]; hd[1] = nent[h]; hd[2] = mh[h] | ((uint32_t)var.cardinality << 8);
-                    hd[3] = (c.phase_ep[hk] && nent[h] > 128) ? 1u : 0u;
-                }
-            }, 4);
-            for (size_t h = 0; h < hubs.size(); h++) {          // (hubs are listed colour by colour)
-                const int32_t hk = hub_colour[h];
-                if (!c.hub_desc[(size_t)(c.phase_hub_base[hk] + (hubs[h] - c.phase_fast_end[hk])) * 4 + 3]) continue;
-                c.bighub_pos.push_back((uint32_t)hubs[h]);
-                c.phase_bighub_base[hk + 1]++;
-            }
-            c.nhub_ep = 0;
-            for (size_t h = 0; h < hubs.size(); h++) if (nent[h]) c.nhub_ep++;
-            if (verbose) fprintf(stderr, "[nsk] hubs %zu, entry-parallel %lld, stream %.1f MB\n", hubs.size(),
-                                 (long long)c.nhub_ep, (double)total * 4 / 1e6);
-        }
-    }
-    for (int32_t k = 0; k < ncolors; k++) c.phase_bighub_base[k + 1] += c.phase_bighub_base[k];
-    if (c.bighub_pos.empty()) c.bighub_pos.push_back(0);
+    if (int hrc = build_hub_streams(d, c, ncolors, general_words, no_general, verbose, err)) return hrc;
     lap("compact streams");
     {
     // learning launches: segments grouped by (kind, chunks) into tables of <= 8, the
