@@ -706,6 +706,61 @@ static int build_hub_streams(const nsk_graph_desc *d, Compiled &c, int32_t ncolo
     return NSK_OK;
 }
 
+// Learning launches over homogeneous segments: segments grouped by (kind, chunks) into tables of <= 8, the
+// NSK_LEARN_SEG_LAUNCHES largest tables of a colour become launches, the tiles of the others join the colour's
+// learning rest list.
+static void plan_learning_launches(Compiled &c, int32_t ncolors) {
+    // learning launches: segments grouped by (kind, chunks) into tables of <= 8, the
+    // NSK_LEARN_SEG_LAUNCHES largest tables of a colour become launches, the tiles of the
+    // others join the colour's rest list
+    c.phase_learn_rest_base.assign((size_t)ncolors + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++) {
+        std::vector<Compiled::SegLaunch> tabs;
+        for (int tab = 0; tab <= 1; tab++)                  // 0 no draw table, 1 table (compact stream or not)
+        for (int kind = 0; kind <= 4; kind++)
+            for (int nch = 1; nch <= 2; nch++) {
+                Compiled::SegLaunch t;
+                memset(&t, 0, sizeof(t));
+                t.phase = k; t.kind = tab ? 8 : kind; t.nch = nch; t.tab = tab;
+                std::vector<const Compiled::Segment *> mine;       // largest first (seg_of_tile's first probe)
+                for (const Compiled::Segment &sg : c.segments) {
+                    // table segments of any function share a launch (the table encodes the function)
+                    if (sg.phase != k || (sg.nslots > 4 ? 2 : 1) != nch || (sg.ztab < 0 ? 0 : 1) != tab ||
+                        (tab ? kind != 0 : (int)(sg.kind == 1 ? 3 : sg.kind) != kind))
+                        continue;
+                    mine.push_back(&sg);
+                }
+                std::stable_sort(mine.begin(), mine.end(), [](const Compiled::Segment *a, const Compiled::Segment *b) {
+                    return a->ntiles > b->ntiles; });
+                for (const Compiled::Segment *sgp : mine) {
+                    const Compiled::Segment &sg = *sgp;
+                    t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
+                    t.aff[t.n] = sg.aff >= 0 ? (uint32_t)sg.aff : 0xFFFFFFFFu;
+                    t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
+                    t.zmask[t.n] = (1u << sg.nslots) - 1u;
+                    t.ev[t.n] = sg.ev;
+                    t.tile_start[t.n + 1] = t.tile_start[t.n] + sg.ntiles;
+                    if (++t.n == 8) { tabs.push_back(t); t.n = 0; t.tile_start[0] = 0; }
+                }
+                if (t.n) tabs.push_back(t);
+            }
+        std::stable_sort(tabs.begin(), tabs.end(), [](const Compiled::SegLaunch &a, const Compiled::SegLaunch &b) {
+            return a.tile_start[a.n] > b.tile_start[b.n]; });
+        std::vector<uint32_t> extra;
+        for (size_t i = 0; i < tabs.size(); i++) {
+            if (i < NSK_LEARN_SEG_LAUNCHES && !diag_env("NSK_NO_LEARN_SEG")) { c.learn_seg.push_back(tabs[i]); continue; }
+            for (int j = 0; j < tabs[i].n; j++)
+                for (int32_t t = 0; t < tabs[i].tile_start[j + 1] - tabs[i].tile_start[j]; t++)
+                    extra.push_back((uint32_t)((tabs[i].pos0[j] - c.phase_start[k]) / 64 + t));
+        }
+        for (int64_t i = c.phase_rest_base[k]; i < c.phase_rest_base[k + 1]; i++) extra.push_back(c.rest_tiles[i]);
+        std::sort(extra.begin(), extra.end());
+        c.learn_rest_tiles.insert(c.learn_rest_tiles.end(), extra.begin(), extra.end());
+        c.phase_learn_rest_base[k + 1] = (int64_t)c.learn_rest_tiles.size();
+    }
+    if (c.learn_rest_tiles.empty()) c.learn_rest_tiles.push_back(0);
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1854,57 +1909,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     if (int arc = build_segment_adjacency(c, err)) return arc;
     if (int hrc = build_hub_streams(d, c, ncolors, general_words, no_general, verbose, err)) return hrc;
     lap("compact streams");
-    {
-    // learning launches: segments grouped by (kind, chunks) into tables of <= 8, the
-    // NSK_LEARN_SEG_LAUNCHES largest tables of a colour become launches, the tiles of the
-    // others join the colour's rest list
-    c.phase_learn_rest_base.assign((size_t)ncolors + 1, 0);
-    for (int32_t k = 0; k < ncolors; k++) {
-        std::vector<Compiled::SegLaunch> tabs;
-        for (int tab = 0; tab <= 1; tab++)                  // 0 no draw table, 1 table (compact stream or not)
-        for (int kind = 0; kind <= 4; kind++)
-            for (int nch = 1; nch <= 2; nch++) {
-                Compiled::SegLaunch t;
-                memset(&t, 0, sizeof(t));
-                t.phase = k; t.kind = tab ? 8 : kind; t.nch = nch; t.tab = tab;
-                std::vector<const Compiled::Segment *> mine;       // largest first (seg_of_tile's first probe)
-                for (const Compiled::Segment &sg : c.segments) {
-                    // table segments of any function share a launch (the table encodes the function)
-                    if (sg.phase != k || (sg.nslots > 4 ? 2 : 1) != nch || (sg.ztab < 0 ? 0 : 1) != tab ||
-                        (tab ? kind != 0 : (int)(sg.kind == 1 ? 3 : sg.kind) != kind))
-                        continue;
-                    mine.push_back(&sg);
-                }
-                std::stable_sort(mine.begin(), mine.end(), [](const Compiled::Segment *a, const Compiled::Segment *b) {
-                    return a->ntiles > b->ntiles; });
-                for (const Compiled::Segment *sgp : mine) {
-                    const Compiled::Segment &sg = *sgp;
-                    t.pos0[t.n] = (int32_t)sg.pos0; t.adj_off[t.n] = sg.adj_off; t.prog[t.n] = sg.prog;
-                    t.aff[t.n] = sg.aff >= 0 ? (uint32_t)sg.aff : 0xFFFFFFFFu;
-                    t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
-                    t.zmask[t.n] = (1u << sg.nslots) - 1u;
-                    t.ev[t.n] = sg.ev;
-                    t.tile_start[t.n + 1] = t.tile_start[t.n] + sg.ntiles;
-                    if (++t.n == 8) { tabs.push_back(t); t.n = 0; t.tile_start[0] = 0; }
-                }
-                if (t.n) tabs.push_back(t);
-            }
-        std::stable_sort(tabs.begin(), tabs.end(), [](const Compiled::SegLaunch &a, const Compiled::SegLaunch &b) {
-            return a.tile_start[a.n] > b.tile_start[b.n]; });
-        std::vector<uint32_t> extra;
-        for (size_t i = 0; i < tabs.size(); i++) {
-            if (i < NSK_LEARN_SEG_LAUNCHES && !diag_env("NSK_NO_LEARN_SEG")) { c.learn_seg.push_back(tabs[i]); continue; }
-            for (int j = 0; j < tabs[i].n; j++)
-                for (int32_t t = 0; t < tabs[i].tile_start[j + 1] - tabs[i].tile_start[j]; t++)
-                    extra.push_back((uint32_t)((tabs[i].pos0[j] - c.phase_start[k]) / 64 + t));
-        }
-        for (int64_t i = c.phase_rest_base[k]; i < c.phase_rest_base[k + 1]; i++) extra.push_back(c.rest_tiles[i]);
-        std::sort(extra.begin(), extra.end());
-        c.learn_rest_tiles.insert(c.learn_rest_tiles.end(), extra.begin(), extra.end());
-        c.phase_learn_rest_base[k + 1] = (int64_t)c.learn_rest_tiles.size();
-    }
-    if (c.learn_rest_tiles.empty()) c.learn_rest_tiles.push_back(0);
-    }
+    plan_learning_launches(c, ncolors);
     // per position: first slot and first list entry (exclusive prefix sums of the per-position counts)
     std::vector<int64_t> pos_si((size_t)c.npos + 1, 0), pos_li((size_t)c.npos + 1, 0);
     parallel_for(c.npos, [&](int64_t pb0, int64_t pb1, int) {
