@@ -761,6 +761,151 @@ static void plan_learning_launches(Compiled &c, int32_t ncolors) {
     if (c.learn_rest_tiles.empty()) c.learn_rest_tiles.push_back(0);
 }
 
+// Homogeneous segments: runs of uniform tiles with one program (and one evidence flag) become segment launches,
+// with a draw table when their members are binary; the other uniform / shape tiles of a colour form its rest
+// list.  Also the colour's all-binary general tiles and its tiles with per-lane headers.  lane_words(v, out) is
+// the compiler's per-variable word list of the fast path.
+template <typename LaneWordsFn>
+static int plan_segments(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, LaneWordsFn &&lane_words,
+                         const std::vector<uint8_t> &fast, bool verbose, std::string &err) {
+    const int64_t nw = c.nweight, nvar = c.nvar;
+    (void)d; (void)nw; (void)nvar; (void)err; (void)verbose;
+    c.phase_gen_bin_tile.assign((size_t)ncolors, 0);
+    for (int32_t k = 0; k < ncolors; k++) {
+        int64_t t = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
+        while (t > c.phase_gen_tile[k] && ((c.tiles[4 * (c.phase_wb_base[k] + t - 1) + 3] >> 12) & 15u) <= 2u) t--;
+        c.phase_gen_bin_tile[k] = t;
+    }
+    c.phase_dyn_base.assign((size_t)ncolors + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++) {
+        for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++)
+            if (c.tiles[4 * (c.phase_wb_base[k] + b) + 2] == 0xFFFFFFFFu)
+                c.dyn_tiles.push_back((uint32_t)(c.phase_start[k] + 64 * b));
+        c.phase_dyn_base[k + 1] = (int64_t)c.dyn_tiles.size();
+    }
+    if (c.dyn_tiles.empty()) c.dyn_tiles.push_back(0);
+    // homogeneous segments and the rest list
+    const int64_t SEG_MIN = 1;
+    std::map<uint32_t, int64_t> ztab_of;                        // program -> first table entry
+    c.phase_rest_base.assign((size_t)ncolors + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++) {
+        const int64_t nt = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
+        auto tile_ev = [&](int64_t b, bool &full) -> int {     // common isEvidence of a tile or -999
+            const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+            full = true;                                       // padding lanes are masked in-kernel
+            int ev = -999;
+            for (int64_t p = p0; p < p1; p++) {
+                if (c.p_vid[p] < 0) continue;
+                const int e2 = d->variable[c.p_vid[p]].isEvidence;
+                if (ev == -999) ev = e2;
+                else if (e2 != ev) return -999;
+            }
+            return ev;
+        };
+        int64_t b = 0;
+        while (b < nt) {
+            const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+            bool full;
+            const int ev = tile_ev(b, full);
+            int64_t e = b + 1;
+            const bool seg_ok = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u && full && ev != -999 &&
+                                (td[3] & 0xFFu) > 0;
+            if (seg_ok) {
+                while (e < nt) {
+                    const uint32_t *te = &c.tiles[4 * (c.phase_wb_base[k] + e)];
+                    bool f2;
+                    if (te[2] != td[2] || te[3] != td[3] || te[1] != td[1] || tile_ev(e, f2) != ev || !f2) break;
+                    e++;
+                }
+            }
+            if (e - b >= SEG_MIN && seg_ok) {
+                Compiled::Segment sg;
+                sg.phase = k; sg.pos0 = c.phase_start[k] + 64 * b; sg.ntiles = (int32_t)(e - b);
+                sg.adj_off = td[0]; sg.prog = td[2]; sg.nslots = td[3] & 0xFFu; sg.kind = (td[3] >> 8) & 7u;
+                sg.ev = ev;
+                sg.ztab = -1;
+                if ((td[3] >> 11) & 1u) {                      // draw table of the program (shared)
+                    auto zi = ztab_of.find(sg.prog);
+                    if (zi == ztab_of.end() && c.nztab + ((int64_t)1 << sg.nslots) <= ((int64_t)1 << 20)) {
+                        zi = ztab_of.emplace(sg.prog, c.nztab).first;
+                        c.zprogs.push_back({sg.prog, sg.nslots, (uint32_t)c.nztab, 0u});
+                        c.nztab += (int64_t)1 << sg.nslots;
+                    }
+                    if (zi != ztab_of.end()) sg.ztab = zi->second;
+                }
+                c.segments.push_back(sg);
+            } else if (td[2] == 0xFFFFFFFFu || ((td[3] >> 8) & 7u) != 6u) {      // general tiles: own kernel
+                for (int64_t t = b; t < e; t++) c.rest_tiles.push_back((uint32_t)t);
+            }
+            b = e;
+        }
+        c.phase_rest_base[k + 1] = (int64_t)c.rest_tiles.size();
+    }
+    if (c.rest_tiles.empty()) c.rest_tiles.push_back(0);
+    if (getenv("NSK_VERBOSE")) {                 // layout report: tiles by kind, per colour
+        for (int32_t k = 0; k < ncolors; k++) {
+            int64_t kinds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
+                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                kinds[td[2] == 0xFFFFFFFFu ? 8 : (td[3] >> 8) & 7u]++;
+            }
+            if (getenv("NSK_DEBUG_TILES"))
+                for (int64_t b = 0, shown = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k] && shown < 3; b++) {
+                    const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                    if (td[2] != 0xFFFFFFFFu) continue;
+                    shown++;
+                    fprintf(stderr, "  per-lane tile %lld (gen tiles start %lld):", (long long)b, (long long)c.phase_gen_tile[k]);
+                    for (int64_t p = c.phase_start[k] + 64 * b; p < c.phase_start[k] + 64 * b + 64; p += 9) {
+                        const int64_t v = c.p_vid[p];
+                        if (v < 0) { fprintf(stderr, " pad"); continue; }
+                        std::vector<uint32_t> ww;
+                        lane_words(v, ww);
+                        fprintf(stderr, " v%lld f%d ev%d [", (long long)v, (int)fast[v], (int)d->variable[v].isEvidence);
+                        for (size_t j = 0; j < ww.size(); j += 1 + ((ww[j] >> 24) & 7u))
+                            fprintf(stderr, "%u:%u:%u ", ww[j] >> 27, (ww[j] >> 24) & 7u, ww[j] & 0xFFFFFFu);
+                        fprintf(stderr, "]");
+                    }
+                    fprintf(stderr, "\n");
+                }
+            fprintf(stderr, "[nsk] colour %d: %lld positions, tiles uniform %lld pair %lld general %lld shape %lld "
+                            "per-lane %lld; generic %lld (hub-style %lld)\n", (int)k,
+                    (long long)(c.phase_start[k + 1] - c.phase_start[k]),
+                    (long long)kinds[0], (long long)(kinds[2] + kinds[3] + kinds[4]), (long long)kinds[6],
+                    (long long)kinds[7], (long long)kinds[8],
+                    (long long)(c.phase_start[k + 1] - c.phase_fast_end[k]),
+                    (long long)(c.phase_heavy_end[k] - c.phase_fast_end[k]));
+        }
+    }
+    if (const char *dv = diag_env("NSK_DEBUG_VAR")) {       // (diagnostic: where a variable landed)
+        for (const char *q = dv; *q;) {
+            const int64_t v = atoll(q);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+            if (v < 0 || v >= nvar || c.color[v] < 0) continue;
+            const int64_t p = c.iid[v];
+            const int32_t k = c.color[v];
+            const int64_t b = (p - c.phase_start[k]) / 64;
+            const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+            fprintf(stderr, "[nsk] var %lld: colour %d position %lld tile %lld td {%u, %u, %u, %#x} kind %u slots %u",
+                    (long long)v, (int)k, (long long)p, (long long)b, td[0], td[1], td[2], td[3], (td[3] >> 8) & 7u, td[3] & 0xFFu);
+            for (const Compiled::Segment &sg : c.segments)
+                if (p >= sg.pos0 && p < sg.pos0 + 64 * (int64_t)sg.ntiles)
+                    fprintf(stderr, " | segment pos0 %lld ntiles %d prog %u nslots %u kind %u ev %d ztab %lld", (long long)sg.pos0,
+                            sg.ntiles, sg.prog, sg.nslots, sg.kind, sg.ev, (long long)sg.ztab);
+            if (td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u) {
+                fprintf(stderr, " | program:");
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t w_ = c.tile_hdr[td[2] + j];
+                    fprintf(stderr, " [w%u c%u F%u cl%u ig%u fx%u]", w_ & 0xFFFFFFu, (w_ >> 24) & 7u, (w_ >> 27) & 1u, (w_ >> 28) & 1u,
+                            (w_ >> 29) & 1u, (w_ >> 30) & 1u);
+                }
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+    return NSK_OK;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1703,139 +1848,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
         find_direct_weights(d, c, nwb, verbose);
         if (number_direct_weights(d, c)) lap("weight numbering");
-        c.phase_gen_bin_tile.assign((size_t)ncolors, 0);
-        for (int32_t k = 0; k < ncolors; k++) {
-            int64_t t = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
-            while (t > c.phase_gen_tile[k] && ((c.tiles[4 * (c.phase_wb_base[k] + t - 1) + 3] >> 12) & 15u) <= 2u) t--;
-            c.phase_gen_bin_tile[k] = t;
-        }
-        c.phase_dyn_base.assign((size_t)ncolors + 1, 0);
-        for (int32_t k = 0; k < ncolors; k++) {
-            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++)
-                if (c.tiles[4 * (c.phase_wb_base[k] + b) + 2] == 0xFFFFFFFFu)
-                    c.dyn_tiles.push_back((uint32_t)(c.phase_start[k] + 64 * b));
-            c.phase_dyn_base[k + 1] = (int64_t)c.dyn_tiles.size();
-        }
-        if (c.dyn_tiles.empty()) c.dyn_tiles.push_back(0);
-        // homogeneous segments and the rest list
-        const int64_t SEG_MIN = 1;
-        std::map<uint32_t, int64_t> ztab_of;                        // program -> first table entry
-        c.phase_rest_base.assign((size_t)ncolors + 1, 0);
-        for (int32_t k = 0; k < ncolors; k++) {
-            const int64_t nt = c.phase_wb_base[k + 1] - c.phase_wb_base[k];
-            auto tile_ev = [&](int64_t b, bool &full) -> int {     // common isEvidence of a tile or -999
-                const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
-                full = true;                                       // padding lanes are masked in-kernel
-                int ev = -999;
-                for (int64_t p = p0; p < p1; p++) {
-                    if (c.p_vid[p] < 0) continue;
-                    const int e2 = d->variable[c.p_vid[p]].isEvidence;
-                    if (ev == -999) ev = e2;
-                    else if (e2 != ev) return -999;
-                }
-                return ev;
-            };
-            int64_t b = 0;
-            while (b < nt) {
-                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
-                bool full;
-                const int ev = tile_ev(b, full);
-                int64_t e = b + 1;
-                const bool seg_ok = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u && full && ev != -999 &&
-                                    (td[3] & 0xFFu) > 0;
-                if (seg_ok) {
-                    while (e < nt) {
-                        const uint32_t *te = &c.tiles[4 * (c.phase_wb_base[k] + e)];
-                        bool f2;
-                        if (te[2] != td[2] || te[3] != td[3] || te[1] != td[1] || tile_ev(e, f2) != ev || !f2) break;
-                        e++;
-                    }
-                }
-                if (e - b >= SEG_MIN && seg_ok) {
-                    Compiled::Segment sg;
-                    sg.phase = k; sg.pos0 = c.phase_start[k] + 64 * b; sg.ntiles = (int32_t)(e - b);
-                    sg.adj_off = td[0]; sg.prog = td[2]; sg.nslots = td[3] & 0xFFu; sg.kind = (td[3] >> 8) & 7u;
-                    sg.ev = ev;
-                    sg.ztab = -1;
-                    if ((td[3] >> 11) & 1u) {                      // draw table of the program (shared)
-                        auto zi = ztab_of.find(sg.prog);
-                        if (zi == ztab_of.end() && c.nztab + ((int64_t)1 << sg.nslots) <= ((int64_t)1 << 20)) {
-                            zi = ztab_of.emplace(sg.prog, c.nztab).first;
-                            c.zprogs.push_back({sg.prog, sg.nslots, (uint32_t)c.nztab, 0u});
-                            c.nztab += (int64_t)1 << sg.nslots;
-                        }
-                        if (zi != ztab_of.end()) sg.ztab = zi->second;
-                    }
-                    c.segments.push_back(sg);
-                } else if (td[2] == 0xFFFFFFFFu || ((td[3] >> 8) & 7u) != 6u) {      // general tiles: own kernel
-                    for (int64_t t = b; t < e; t++) c.rest_tiles.push_back((uint32_t)t);
-                }
-                b = e;
-            }
-            c.phase_rest_base[k + 1] = (int64_t)c.rest_tiles.size();
-        }
-        if (c.rest_tiles.empty()) c.rest_tiles.push_back(0);
-        if (getenv("NSK_VERBOSE")) {                 // layout report: tiles by kind, per colour
-            for (int32_t k = 0; k < ncolors; k++) {
-                int64_t kinds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
-                    const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
-                    kinds[td[2] == 0xFFFFFFFFu ? 8 : (td[3] >> 8) & 7u]++;
-                }
-                if (getenv("NSK_DEBUG_TILES"))
-                    for (int64_t b = 0, shown = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k] && shown < 3; b++) {
-                        const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
-                        if (td[2] != 0xFFFFFFFFu) continue;
-                        shown++;
-                        fprintf(stderr, "  per-lane tile %lld (gen tiles start %lld):", (long long)b, (long long)c.phase_gen_tile[k]);
-                        for (int64_t p = c.phase_start[k] + 64 * b; p < c.phase_start[k] + 64 * b + 64; p += 9) {
-                            const int64_t v = c.p_vid[p];
-                            if (v < 0) { fprintf(stderr, " pad"); continue; }
-                            std::vector<uint32_t> ww;
-                            lane_words(v, ww);
-                            fprintf(stderr, " v%lld f%d ev%d [", (long long)v, (int)fast[v], (int)d->variable[v].isEvidence);
-                            for (size_t j = 0; j < ww.size(); j += 1 + ((ww[j] >> 24) & 7u))
-                                fprintf(stderr, "%u:%u:%u ", ww[j] >> 27, (ww[j] >> 24) & 7u, ww[j] & 0xFFFFFFu);
-                            fprintf(stderr, "]");
-                        }
-                        fprintf(stderr, "\n");
-                    }
-                fprintf(stderr, "[nsk] colour %d: %lld positions, tiles uniform %lld pair %lld general %lld shape %lld "
-                                "per-lane %lld; generic %lld (hub-style %lld)\n", (int)k,
-                        (long long)(c.phase_start[k + 1] - c.phase_start[k]),
-                        (long long)kinds[0], (long long)(kinds[2] + kinds[3] + kinds[4]), (long long)kinds[6],
-                        (long long)kinds[7], (long long)kinds[8],
-                        (long long)(c.phase_start[k + 1] - c.phase_fast_end[k]),
-                        (long long)(c.phase_heavy_end[k] - c.phase_fast_end[k]));
-            }
-        }
-        if (const char *dv = diag_env("NSK_DEBUG_VAR")) {       // (diagnostic: where a variable landed)
-            for (const char *q = dv; *q;) {
-                const int64_t v = atoll(q);
-                while (*q && *q != ',') q++;
-                if (*q == ',') q++;
-                if (v < 0 || v >= nvar || c.color[v] < 0) continue;
-                const int64_t p = c.iid[v];
-                const int32_t k = c.color[v];
-                const int64_t b = (p - c.phase_start[k]) / 64;
-                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
-                fprintf(stderr, "[nsk] var %lld: colour %d position %lld tile %lld td {%u, %u, %u, %#x} kind %u slots %u",
-                        (long long)v, (int)k, (long long)p, (long long)b, td[0], td[1], td[2], td[3], (td[3] >> 8) & 7u, td[3] & 0xFFu);
-                for (const Compiled::Segment &sg : c.segments)
-                    if (p >= sg.pos0 && p < sg.pos0 + 64 * (int64_t)sg.ntiles)
-                        fprintf(stderr, " | segment pos0 %lld ntiles %d prog %u nslots %u kind %u ev %d ztab %lld", (long long)sg.pos0,
-                                sg.ntiles, sg.prog, sg.nslots, sg.kind, sg.ev, (long long)sg.ztab);
-                if (td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u) {
-                    fprintf(stderr, " | program:");
-                    for (uint32_t j = 0; j < 8; j++) {
-                        const uint32_t w_ = c.tile_hdr[td[2] + j];
-                        fprintf(stderr, " [w%u c%u F%u cl%u ig%u fx%u]", w_ & 0xFFFFFFu, (w_ >> 24) & 7u, (w_ >> 27) & 1u, (w_ >> 28) & 1u,
-                                (w_ >> 29) & 1u, (w_ >> 30) & 1u);
-                    }
-                }
-                fprintf(stderr, "\n");
-            }
-        }
+        if (int src = plan_segments(d, c, ncolors, lane_words, fast, verbose, err)) return src;
         lap("segments");
         // pass 2: fill the tiles.  Padding: member slots read the always-zero id (c.zero_id) in uniform
         // tiles, 0xFFFFFFFF in tiles with per-lane headers.
