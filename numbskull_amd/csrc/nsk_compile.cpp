@@ -906,6 +906,79 @@ static int plan_segments(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, 
     return NSK_OK;
 }
 
+// Pass 2 over the tiles: the lanes' words into the stream `adj` (total4 = its size in 16-byte units), chunk-major
+// per tile.  general_words / lane_words are the compiler's per-variable word lists (general tiles / fast path).
+template <typename WordsFn, typename LaneWordsFn>
+static void fill_tiles(const nsk_graph_desc *d, Compiled &c, int64_t nwb, uint64_t total4, const std::vector<int32_t> &tile_colour,
+                       WordsFn &&general_words, LaneWordsFn &&lane_words) {
+    (void)d;
+    // pass 2: fill the tiles.  Padding: member slots read the always-zero id (c.zero_id) in uniform
+    // tiles, 0xFFFFFFFF in tiles with per-lane headers.
+    c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);
+    std::vector<int64_t> nfast_part((size_t)compile_threads() + 1, 0);
+    parallel_for(nwb, [&](int64_t tb0, int64_t tb1, int tix) {
+        std::vector<uint32_t> words;
+        int64_t nfast_here = 0;
+        for (int64_t t = tb0; t < tb1; t++) {
+            const int32_t k = tile_colour[t];
+            const int64_t b = t - c.phase_wb_base[k];
+            const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+            const uint32_t *td = &c.tiles[4 * t];
+            const uint64_t base = (uint64_t)td[0] * 4;
+            const bool uniform = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u;
+            const bool general = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 6u;
+            const bool shape = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 7u;
+            if (td[2] != 0xFFFFFFFFu) {     // padding: uniform tiles read the always-zero id, shape tiles variable / weight 0
+                const uint32_t padw = uniform ? (uint32_t)c.zero_id : 0u;
+                for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = padw;
+            }
+            for (int64_t p = p0; p < p1; p++) {
+                if (c.p_vid[p] < 0) continue;
+                size_t out = 0;
+                auto put = [&](uint32_t word) {
+                    c.adj[base + 256 * (out / 4) + 4 * (uint64_t)(p - p0) + (out % 4)] = word;
+                    out++;
+                };
+                if (general && c.phase_ep[k]) { nfast_here++; continue; }     // laid out by groups, below
+                if (general) {               // entries padded to M member slots, then E entries
+                    general_words(c.p_vid[p], &words);
+                    const uint32_t M = (td[3] >> 16) & 7u, E = (td[3] & 0xFFu) / (2 + M);
+                    uint32_t ne = 0;
+                    for (size_t j = 0; j < words.size(); ne++) {
+                        const uint32_t no = (words[j + 1] >> 4) & 7u;
+                        put(words[j]); put(words[j + 1]);
+                        for (uint32_t m = 2; m < 2 + no; m++)        // member: internal id | deo << 27
+                            put((uint32_t)c.iid[words[j + m] & NSK_GEN_NULL] | (words[j + m] & ~NSK_GEN_NULL));
+                        for (uint32_t m = no; m < M; m++) put(NSK_GEN_NULL);
+                        j += 2 + no;
+                    }
+                    for (; ne < E; ne++) {                        // an entry no candidate value owns
+                        put(0u);
+                        put(14u << 14);
+                        for (uint32_t m = 0; m < M; m++) put(NSK_GEN_NULL);
+                    }
+                    nfast_here++;
+                    continue;
+                }
+                lane_words(c.p_vid[p], words);
+                for (size_t j = 0; j < words.size();) {
+                    const uint32_t nother = (words[j] >> 24) & 7u;
+                    if (!uniform) put(words[j]);
+                    else if (nother == 0) put((uint32_t)c.zero_id);      // the ignored slot of a member-less entry
+                    for (uint32_t m = 1; m <= nother; m++) put((uint32_t)c.iid[words[j + m]]);
+                    // shape tile: the member slots of the tile's layout that this lane's entry lacks
+                    while (shape && out < (size_t)td[1] && (c.tile_hdr[td[2] + out] & 0x80000010u) == 0x80000010u)
+                        put(NSK_SHAPE_NULL);
+                    j += 1 + nother;
+                }
+                nfast_here++;
+            }
+        }
+        nfast_part[tix] = nfast_here;
+    }, 64);
+    for (int64_t x : nfast_part) c.nfast += x;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1850,71 +1923,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         if (number_direct_weights(d, c)) lap("weight numbering");
         if (int src = plan_segments(d, c, ncolors, lane_words, fast, verbose, err)) return src;
         lap("segments");
-        // pass 2: fill the tiles.  Padding: member slots read the always-zero id (c.zero_id) in uniform
-        // tiles, 0xFFFFFFFF in tiles with per-lane headers.
-        c.adj.assign((size_t)total4 * 4 + 4, 0xFFFFFFFFu);
-        std::vector<int64_t> nfast_part((size_t)compile_threads() + 1, 0);
-        parallel_for(nwb, [&](int64_t tb0, int64_t tb1, int tix) {
-            std::vector<uint32_t> words;
-            int64_t nfast_here = 0;
-            for (int64_t t = tb0; t < tb1; t++) {
-                const int32_t k = tile_colour[t];
-                const int64_t b = t - c.phase_wb_base[k];
-                const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
-                const uint32_t *td = &c.tiles[4 * t];
-                const uint64_t base = (uint64_t)td[0] * 4;
-                const bool uniform = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) < 6u;
-                const bool general = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 6u;
-                const bool shape = td[2] != 0xFFFFFFFFu && ((td[3] >> 8) & 7u) == 7u;
-                if (td[2] != 0xFFFFFFFFu) {     // padding: uniform tiles read the always-zero id, shape tiles variable / weight 0
-                    const uint32_t padw = uniform ? (uint32_t)c.zero_id : 0u;
-                    for (uint64_t j = 0; j < (uint64_t)td[1] * 64; j++) c.adj[base + j] = padw;
-                }
-                for (int64_t p = p0; p < p1; p++) {
-                    if (c.p_vid[p] < 0) continue;
-                    size_t out = 0;
-                    auto put = [&](uint32_t word) {
-                        c.adj[base + 256 * (out / 4) + 4 * (uint64_t)(p - p0) + (out % 4)] = word;
-                        out++;
-                    };
-                    if (general && c.phase_ep[k]) { nfast_here++; continue; }     // laid out by groups, below
-                    if (general) {               // entries padded to M member slots, then E entries
-                        general_words(c.p_vid[p], &words);
-                        const uint32_t M = (td[3] >> 16) & 7u, E = (td[3] & 0xFFu) / (2 + M);
-                        uint32_t ne = 0;
-                        for (size_t j = 0; j < words.size(); ne++) {
-                            const uint32_t no = (words[j + 1] >> 4) & 7u;
-                            put(words[j]); put(words[j + 1]);
-                            for (uint32_t m = 2; m < 2 + no; m++)        // member: internal id | deo << 27
-                                put((uint32_t)c.iid[words[j + m] & NSK_GEN_NULL] | (words[j + m] & ~NSK_GEN_NULL));
-                            for (uint32_t m = no; m < M; m++) put(NSK_GEN_NULL);
-                            j += 2 + no;
-                        }
-                        for (; ne < E; ne++) {                        // an entry no candidate value owns
-                            put(0u);
-                            put(14u << 14);
-                            for (uint32_t m = 0; m < M; m++) put(NSK_GEN_NULL);
-                        }
-                        nfast_here++;
-                        continue;
-                    }
-                    lane_words(c.p_vid[p], words);
-                    for (size_t j = 0; j < words.size();) {
-                        const uint32_t nother = (words[j] >> 24) & 7u;
-                        if (!uniform) put(words[j]);
-                        else if (nother == 0) put((uint32_t)c.zero_id);      // the ignored slot of a member-less entry
-                        for (uint32_t m = 1; m <= nother; m++) put((uint32_t)c.iid[words[j + m]]);
-                        // shape tile: the member slots of the tile's layout that this lane's entry lacks
-                        while (shape && out < (size_t)td[1] && (c.tile_hdr[td[2] + out] & 0x80000010u) == 0x80000010u)
-                            put(NSK_SHAPE_NULL);
-                        j += 1 + nother;
-                    }
-                    nfast_here++;
-                }
-            }
-            nfast_part[tix] = nfast_here;
-        }, 64);
-        for (int64_t x : nfast_part) c.nfast += x;
+        fill_tiles(d, c, nwb, total4, tile_colour, general_words, lane_words);
     }
     lap("tile fill (pass 2)");
     if (int erc = build_ep_groups(d, c, ncolors, general_words, lap, verbose, err)) return erc;
