@@ -979,6 +979,241 @@ static void fill_tiles(const nsk_graph_desc *d, Compiled &c, int64_t nwb, uint64
     for (int64_t x : nfast_part) c.nfast += x;
 }
 
+// The generic path's index (slots, inverted index, CSR byte model), the inline generic stream, the gradient format
+// and the census of what one sweep must move in the compiled layout (alg_bytes_*, layout_bytes_*).
+template <typename ReadFn, typename LapFn>
+static int build_index_and_census(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, bool head_by_vid,
+                                  ReadFn &&for_each_read, LapFn &&lap, std::string &err) {
+    const int64_t nvar = c.nvar, nfac = c.nfactor, nedge = c.nedge, nw = c.nweight;
+    const int64_t LIM = (int64_t)1 << 31;
+    (void)nvar; (void)nfac; (void)nedge; (void)nw; (void)head_by_vid; (void)LIM;
+    // per position: first slot and first list entry (exclusive prefix sums of the per-position counts)
+    std::vector<int64_t> pos_si((size_t)c.npos + 1, 0), pos_li((size_t)c.npos + 1, 0);
+    parallel_for(c.npos, [&](int64_t pb0, int64_t pb1, int) {
+        for (int64_t p = pb0; p < pb1; p++) {
+            if (c.p_vid[p] < 0) continue;
+            const nsk_variable &var = d->variable[c.p_vid[p]];
+            const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+            int64_t nl = 0;
+            for (int64_t k = 0; k < nslots; k++) nl += d->vmap[var.vtf_offset + k].factor_index_length;
+            pos_si[p + 1] = nslots;
+            pos_li[p + 1] = nl;
+        }
+    });
+    for (int64_t p = 0; p < c.npos; p++) { pos_si[p + 1] += pos_si[p]; pos_li[p + 1] += pos_li[p]; }
+    const int64_t nslot = pos_si[c.npos], nlist = pos_li[c.npos];
+    if (nslot >= LIM - 1 || nlist >= LIM - 1) {
+        err = "inverted index too large for 32-bit device indices";
+        return NSK_E_RANGE;
+    }
+    c.nslot = nslot;
+    c.slot_off.resize(nslot + 1);
+    c.fidx.resize(nlist);
+    const int64_t s_i = 4, s_v = c.vbytes, s_c = 4;
+    const bool big_w = nw * 8 > (4 << 20);
+    std::vector<uint8_t> generic_pos((size_t)c.npos + 1, 0);
+    for (int32_t k = 0; k < ncolors; k++)
+        for (int64_t p = c.phase_fast_end[k]; p < c.phase_start[k + 1]; p++) generic_pos[p] = 1;
+    // (all byte counts are integers far below 2^53: the partial sums add up exactly in any order)
+    std::vector<double> part_bytes((size_t)(compile_threads() + 1) * 4, 0.0);
+    parallel_for(c.npos, [&](int64_t pb0, int64_t pb1, int tix) {
+        std::vector<int64_t> uni;
+        double bytes_inf = 0, bytes_learn = 0, lay_inf = 0, lay_learn = 0;
+        for (int64_t p = pb0; p < pb1; p++) {
+            const int64_t v = c.p_vid[p];
+            int64_t si = pos_si[p], li = pos_li[p];
+            if (v < 0) { c.p_slot[p] = (int32_t)si; c.p_init[p] = -1; continue; }      // padding position (-1: the learning
+                                                                                   // table kernel's validity test)
+            const nsk_variable &var = d->variable[v];
+            const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+            c.p_info[p] = ((uint32_t)var.cardinality << 9) | ((var.dataType != 0) ? 0x100u : 0u) |
+                          (uint32_t)(uint8_t)var.isEvidence;
+            c.p_slot[p] = (int32_t)si;
+            c.p_cnt[p] = (int32_t)c.cstart[v];
+            c.p_init[p] = var.isEvidence == 1 ? c.v_init[v] : 0;         // read by the evidence chain only (learning.py:61-62)
+            uni.clear();
+            for (int64_t k = 0; k < nslots; k++) {
+                const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
+                c.slot_off[si++] = (int32_t)li;
+                for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                    const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                    c.fidx[li++] = (int32_t)f;
+                    uni.push_back(f);
+                }
+            }
+            if (nslots > 1) {
+                std::sort(uni.begin(), uni.end());
+                uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+            }
+            // algorithmic bytes of this update, SURVEY.md section 8(d)
+            double bi = 2 + s_i + s_v, bl = 0;
+            for (int64_t f : uni) {
+                const nsk_factor &fa = d->factor[f];
+                const double ar = (double)std::max<int64_t>(fa.arity, 0);
+                bi += s_i + 10 + ar * s_i + (is_cat_function(fa.factorFunction) ? ar * s_i : 0) +
+                      (ar - 1) * s_v + (big_w ? 8 : 0);
+                bl += (ar - 1) * s_v + 8 + 1 +
+                      ((big_w && fa.weightId >= 0 && fa.weightId < nw && !c.w_fixed[fa.weightId]) ? 16 : 0);
+            }
+            bytes_inf += bi + 2 * s_c;
+            bytes_learn += bi + bl + s_v;
+            if (generic_pos[p]) { lay_inf += bi + 2 * s_c; lay_learn += bi + bl + s_v; }
+        }
+        part_bytes[4 * tix] = bytes_inf; part_bytes[4 * tix + 1] = bytes_learn;
+        part_bytes[4 * tix + 2] = lay_inf; part_bytes[4 * tix + 3] = lay_learn;
+    });
+    double bytes_inf = 0, bytes_learn = 0;
+    double lay_inf = 0, lay_learn = 0;         // generic-path positions: the CSR model is their layout
+    for (size_t t = 0; t * 4 < part_bytes.size(); t++) {
+        bytes_inf += part_bytes[4 * t]; bytes_learn += part_bytes[4 * t + 1];
+        lay_inf += part_bytes[4 * t + 2]; lay_learn += part_bytes[4 * t + 3];
+    }
+    c.slot_off[nslot] = (int32_t)nlist;
+
+    lap("slots + CSR bytes");
+    // ---- inline generic stream: for the positions handled by the one-lane generic kernels, every
+    // factor record of every slot copied in list order, members included, so that a lane reads its
+    // update sequentially instead of chasing fidx -> factor -> fmap through three arrays
+    c.gs_off.assign((size_t)nslot + 1, 0);
+    {
+        auto members_stored = [&](const nsk_factor &fa) -> int64_t {   // edges the function may read
+            const int fn = fa.factorFunction;
+            int64_t need = (fn == 21 || fn == 22 || fn == 25 || fn == 26) ? 2 : (fn == 23 || fn == 24) ? 3
+                         : (fn >= 18 && fn <= 20) ? 1 : (fn == 3 ? 1 : 0);
+            int64_t n = std::max<int64_t>(std::max<int64_t>(fa.arity, 0), need);
+            if (fn == 30 && fa.ftv_offset >= 0 && fa.ftv_offset < nedge)
+                n = std::max<int64_t>(n, d->variable[d->fmap[fa.ftv_offset].vid].cardinality - 1);
+            if (fn == -1) n = 0;
+            return n;
+        };
+        uint64_t units = 2;                       // unit 0/1 unused so that offset 0 means "none"
+        for (int32_t k = 0; k < ncolors; k++)
+            for (int64_t p = c.phase_heavy_end[k]; p < c.phase_start[k + 1]; p++) {
+                const int64_t v = c.p_vid[p];
+                if (v < 0) continue;
+                const nsk_variable &var = d->variable[v];
+                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+                for (int64_t kk = 0; kk < nslots; kk++) {
+                    const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
+                    for (int64_t j = 0; j < vt.factor_index_length; j++)
+                        units += 4 + (uint64_t)members_stored(d->factor[d->factor_index[vt.factor_index_offset + j]]);
+                }
+            }
+        if (units >= ((uint64_t)1 << 32)) { err = "inline generic stream too large"; return NSK_E_RANGE; }
+        c.gstream.assign((size_t)units * 2, 0);
+        uint64_t at = 2;
+        for (int32_t k = 0; k < ncolors; k++)
+            for (int64_t p = c.phase_heavy_end[k]; p < c.phase_start[k + 1]; p++) {
+                const int64_t v = c.p_vid[p];
+                if (v < 0) continue;
+                const nsk_variable &var = d->variable[v];
+                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+                for (int64_t kk = 0; kk < nslots; kk++) {
+                    const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
+                    c.gs_off[c.p_slot[p] + kk] = (uint32_t)at;
+                    for (int64_t j = 0; j < vt.factor_index_length; j++) {
+                        const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                        const nsk_factor &fa = d->factor[f];
+                        const int64_t nm = members_stored(fa);
+                        uint32_t *u = &c.gstream[at * 2];
+                        u[0] = c.f_rec[4 * f]; u[1] = c.f_rec[4 * f + 2];              // head, weightId
+                        u[2] = c.f_rec[4 * f + 1]; u[3] = (uint32_t)f;                 // ftv_offset, factor id
+                        memcpy(&u[4], &fa.featureValue, 8);
+                        u[6] = (uint32_t)nm; u[7] = 0;
+                        for (int64_t m = 0; m < nm; m++) {
+                            const int64_t l = fa.ftv_offset + m;
+                            u[8 + 2 * m] = (uint32_t)c.m_rec[2 * l];
+                            u[9 + 2 * m] = (uint32_t)c.m_rec[2 * l + 1];
+                        }
+                        at += 4 + (uint64_t)nm;
+                    }
+                }
+            }
+    }
+    lap("generic stream");
+    choose_gradient_format(d, c);
+    c.alg_bytes_inference = bytes_inf;
+    c.alg_bytes_learning = bytes_learn;
+    lap("packed-gradient check");
+    // ---- layout bytes: what one sweep must move in the compiled layout.  Tile words (padding
+    // included), position arrays, the distinct neighbour values a colour class reads, the stores and
+    // the tally read-modify-write; materialised weight rows / gathered weights when the table
+    // exceeds the L2; generic-path positions as in the CSR model above.
+    {
+        std::vector<uint64_t> seen((size_t)(nvar + 63) / 64);           // bit b: the class reads variable b
+        for (int32_t k = 0; k < ncolors; k++) {
+            double words = 0, wrows = 0, ep_wt_bytes = 0;
+            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
+                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
+                const uint32_t kind = td[2] == 0xFFFFFFFFu ? 8u : (td[3] >> 8) & 7u;
+                words += (double)td[1] * 64 * 4;
+                const bool seg_like = kind < 6u;                 // uniform tiles: p_vid + tally only
+                lay_inf += 64.0 * (4 + (seg_like ? 0 : 4));
+                lay_learn += 64.0 * (4 + 4 + s_v);               // p_vid, p_info, p_init
+                if (big_w && kind == 6u) wrows += (double)((td[3] & 0xFFu) / (2 + ((td[3] >> 16) & 7u))) * 64 * 8;
+                if (big_w && kind == 7u) wrows += (double)(td[3] & 0xFFu) * 64 * 8 / 2;   // ~ one header per two words
+            }
+            if (c.phase_ep[k])                         // entry-parallel groups: their rows instead of tile words;
+                for (int64_t gi = c.phase_ep_base[k]; gi < c.phase_ep_base[k + 1]; gi++) {
+                    const uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
+                    double sr = 0;
+                    double rows = 0;
+                    for (uint32_t m = 0; m < 4; m++) {
+                        const double r = (double)((gd[1] >> (8 * m)) & 255u) + (double)((gd[3] >> (8 * m)) & 255u);
+                        sr += r * (2 + m);
+                        rows += r;
+                    }
+                    words += sr * 256;
+                    ep_wt_bytes += rows * 64 * 8;                      // inference: the materialised weight of every entry
+                    if (big_w) wrows += rows * 64 * 8;                 // learning: one gathered weight per entry
+                }
+            lay_inf += words + (c.phase_ep[k] ? ep_wt_bytes : wrows);
+            lay_learn += words + 3 * wrows;            // weight gathers + one 16-byte atomic per visit
+            int64_t distinct = 0, nfastpos = 0, ncatpos = 0;
+            std::fill(seen.begin(), seen.end(), 0ull);
+            {   // the class's positions over the host threads; a neighbour counts for the thread that sets its bit
+                const int64_t pa = c.phase_start[k], pb = c.phase_fast_end[k];
+                std::vector<int64_t> part((size_t)compile_threads() * 3, 0);
+                parallel_for(pb - pa, [&](int64_t b0, int64_t b1, int t) {
+                    int64_t dn = 0, nf = 0, nc = 0;
+                    for (int64_t p = pa + b0; p < pa + b1; p++) {
+                        const int64_t v = c.p_vid[p];
+                        if (v < 0) continue;
+                        if (d->variable[v].cardinality == 2) nf++; else nc++;
+                        for_each_read(v, [&](int64_t b) {
+                            if (b == v) return;
+                            const uint64_t bit = 1ull << (b & 63);
+                            if (!(__atomic_fetch_or(&seen[(size_t)b >> 6], bit, __ATOMIC_RELAXED) & bit)) dn++;
+                        });
+                    }
+                    part[(size_t)t * 3] = dn; part[(size_t)t * 3 + 1] = nf; part[(size_t)t * 3 + 2] = nc;
+                });
+                for (size_t t = 0; t < part.size(); t += 3) { distinct += part[t]; nfastpos += part[t + 1]; ncatpos += part[t + 2]; }
+            }
+            lay_inf += (double)distinct * s_v + (double)(nfastpos + ncatpos) * s_v + 2.0 * nfastpos + 2.0 * s_c * ncatpos;
+            lay_learn += 2.0 * distinct * s_v + 2.0 * (nfastpos + ncatpos) * s_v;
+        }
+        for (const Compiled::Segment &sg : c.segments) {    // inference over table segments: a tile with implicit
+            if (sg.aff < 0) continue;                        // adjacency reads 16 bytes per chunk, not 64 x 16
+            const int nch = sg.nslots > 4 ? 2 : 1;
+            for (int64_t t = 0; t < sg.ntiles; t++)
+                if (c.seg_aff[((size_t)sg.aff + (size_t)t * nch) * 4] != 0xFFFFFFFFu) {
+                    lay_inf -= (double)nch * (64 * 16 - 16);
+                    lay_learn -= (double)nch * (64 * 16 - 16);
+                }
+        }
+        for (const Compiled::Segment &sg : c.segments)      // the table kernels key their generators by
+            if (sg.ztab >= 0) {                              // position: no p_vid read; learning: no p_info either
+                lay_inf -= (double)sg.ntiles * 64 * 4;
+                lay_learn -= (double)sg.ntiles * 64 * 8;
+            }
+        c.layout_bytes_inference = lay_inf;
+        c.layout_bytes_learning = lay_learn;
+    }
+    lap("layout bytes");
+    return NSK_OK;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1932,231 +2167,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     if (int hrc = build_hub_streams(d, c, ncolors, general_words, no_general, verbose, err)) return hrc;
     lap("compact streams");
     plan_learning_launches(c, ncolors);
-    // per position: first slot and first list entry (exclusive prefix sums of the per-position counts)
-    std::vector<int64_t> pos_si((size_t)c.npos + 1, 0), pos_li((size_t)c.npos + 1, 0);
-    parallel_for(c.npos, [&](int64_t pb0, int64_t pb1, int) {
-        for (int64_t p = pb0; p < pb1; p++) {
-            if (c.p_vid[p] < 0) continue;
-            const nsk_variable &var = d->variable[c.p_vid[p]];
-            const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-            int64_t nl = 0;
-            for (int64_t k = 0; k < nslots; k++) nl += d->vmap[var.vtf_offset + k].factor_index_length;
-            pos_si[p + 1] = nslots;
-            pos_li[p + 1] = nl;
-        }
-    });
-    for (int64_t p = 0; p < c.npos; p++) { pos_si[p + 1] += pos_si[p]; pos_li[p + 1] += pos_li[p]; }
-    const int64_t nslot = pos_si[c.npos], nlist = pos_li[c.npos];
-    if (nslot >= LIM - 1 || nlist >= LIM - 1) {
-        err = "inverted index too large for 32-bit device indices";
-        return NSK_E_RANGE;
-    }
-    c.nslot = nslot;
-    c.slot_off.resize(nslot + 1);
-    c.fidx.resize(nlist);
-    const int64_t s_i = 4, s_v = c.vbytes, s_c = 4;
-    const bool big_w = nw * 8 > (4 << 20);
-    std::vector<uint8_t> generic_pos((size_t)c.npos + 1, 0);
-    for (int32_t k = 0; k < ncolors; k++)
-        for (int64_t p = c.phase_fast_end[k]; p < c.phase_start[k + 1]; p++) generic_pos[p] = 1;
-    // (all byte counts are integers far below 2^53: the partial sums add up exactly in any order)
-    std::vector<double> part_bytes((size_t)(compile_threads() + 1) * 4, 0.0);
-    parallel_for(c.npos, [&](int64_t pb0, int64_t pb1, int tix) {
-        std::vector<int64_t> uni;
-        double bytes_inf = 0, bytes_learn = 0, lay_inf = 0, lay_learn = 0;
-        for (int64_t p = pb0; p < pb1; p++) {
-            const int64_t v = c.p_vid[p];
-            int64_t si = pos_si[p], li = pos_li[p];
-            if (v < 0) { c.p_slot[p] = (int32_t)si; c.p_init[p] = -1; continue; }      // padding position (-1: the learning
-                                                                                   // table kernel's validity test)
-            const nsk_variable &var = d->variable[v];
-            const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-            c.p_info[p] = ((uint32_t)var.cardinality << 9) | ((var.dataType != 0) ? 0x100u : 0u) |
-                          (uint32_t)(uint8_t)var.isEvidence;
-            c.p_slot[p] = (int32_t)si;
-            c.p_cnt[p] = (int32_t)c.cstart[v];
-            c.p_init[p] = var.isEvidence == 1 ? c.v_init[v] : 0;         // read by the evidence chain only (learning.py:61-62)
-            uni.clear();
-            for (int64_t k = 0; k < nslots; k++) {
-                const nsk_vtf &vt = d->vmap[var.vtf_offset + k];
-                c.slot_off[si++] = (int32_t)li;
-                for (int64_t j = 0; j < vt.factor_index_length; j++) {
-                    const int64_t f = d->factor_index[vt.factor_index_offset + j];
-                    c.fidx[li++] = (int32_t)f;
-                    uni.push_back(f);
-                }
-            }
-            if (nslots > 1) {
-                std::sort(uni.begin(), uni.end());
-                uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
-            }
-            // algorithmic bytes of this update, SURVEY.md section 8(d)
-            double bi = 2 + s_i + s_v, bl = 0;
-            for (int64_t f : uni) {
-                const nsk_factor &fa = d->factor[f];
-                const double ar = (double)std::max<int64_t>(fa.arity, 0);
-                bi += s_i + 10 + ar * s_i + (is_cat_function(fa.factorFunction) ? ar * s_i : 0) +
-                      (ar - 1) * s_v + (big_w ? 8 : 0);
-                bl += (ar - 1) * s_v + 8 + 1 +
-                      ((big_w && fa.weightId >= 0 && fa.weightId < nw && !c.w_fixed[fa.weightId]) ? 16 : 0);
-            }
-            bytes_inf += bi + 2 * s_c;
-            bytes_learn += bi + bl + s_v;
-            if (generic_pos[p]) { lay_inf += bi + 2 * s_c; lay_learn += bi + bl + s_v; }
-        }
-        part_bytes[4 * tix] = bytes_inf; part_bytes[4 * tix + 1] = bytes_learn;
-        part_bytes[4 * tix + 2] = lay_inf; part_bytes[4 * tix + 3] = lay_learn;
-    });
-    double bytes_inf = 0, bytes_learn = 0;
-    double lay_inf = 0, lay_learn = 0;         // generic-path positions: the CSR model is their layout
-    for (size_t t = 0; t * 4 < part_bytes.size(); t++) {
-        bytes_inf += part_bytes[4 * t]; bytes_learn += part_bytes[4 * t + 1];
-        lay_inf += part_bytes[4 * t + 2]; lay_learn += part_bytes[4 * t + 3];
-    }
-    c.slot_off[nslot] = (int32_t)nlist;
-
-    lap("slots + CSR bytes");
-    // ---- inline generic stream: for the positions handled by the one-lane generic kernels, every
-    // factor record of every slot copied in list order, members included, so that a lane reads its
-    // update sequentially instead of chasing fidx -> factor -> fmap through three arrays
-    c.gs_off.assign((size_t)nslot + 1, 0);
-    {
-        auto members_stored = [&](const nsk_factor &fa) -> int64_t {   // edges the function may read
-            const int fn = fa.factorFunction;
-            int64_t need = (fn == 21 || fn == 22 || fn == 25 || fn == 26) ? 2 : (fn == 23 || fn == 24) ? 3
-                         : (fn >= 18 && fn <= 20) ? 1 : (fn == 3 ? 1 : 0);
-            int64_t n = std::max<int64_t>(std::max<int64_t>(fa.arity, 0), need);
-            if (fn == 30 && fa.ftv_offset >= 0 && fa.ftv_offset < nedge)
-                n = std::max<int64_t>(n, d->variable[d->fmap[fa.ftv_offset].vid].cardinality - 1);
-            if (fn == -1) n = 0;
-            return n;
-        };
-        uint64_t units = 2;                       // unit 0/1 unused so that offset 0 means "none"
-        for (int32_t k = 0; k < ncolors; k++)
-            for (int64_t p = c.phase_heavy_end[k]; p < c.phase_start[k + 1]; p++) {
-                const int64_t v = c.p_vid[p];
-                if (v < 0) continue;
-                const nsk_variable &var = d->variable[v];
-                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-                for (int64_t kk = 0; kk < nslots; kk++) {
-                    const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
-                    for (int64_t j = 0; j < vt.factor_index_length; j++)
-                        units += 4 + (uint64_t)members_stored(d->factor[d->factor_index[vt.factor_index_offset + j]]);
-                }
-            }
-        if (units >= ((uint64_t)1 << 32)) { err = "inline generic stream too large"; return NSK_E_RANGE; }
-        c.gstream.assign((size_t)units * 2, 0);
-        uint64_t at = 2;
-        for (int32_t k = 0; k < ncolors; k++)
-            for (int64_t p = c.phase_heavy_end[k]; p < c.phase_start[k + 1]; p++) {
-                const int64_t v = c.p_vid[p];
-                if (v < 0) continue;
-                const nsk_variable &var = d->variable[v];
-                const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-                for (int64_t kk = 0; kk < nslots; kk++) {
-                    const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
-                    c.gs_off[c.p_slot[p] + kk] = (uint32_t)at;
-                    for (int64_t j = 0; j < vt.factor_index_length; j++) {
-                        const int64_t f = d->factor_index[vt.factor_index_offset + j];
-                        const nsk_factor &fa = d->factor[f];
-                        const int64_t nm = members_stored(fa);
-                        uint32_t *u = &c.gstream[at * 2];
-                        u[0] = c.f_rec[4 * f]; u[1] = c.f_rec[4 * f + 2];              // head, weightId
-                        u[2] = c.f_rec[4 * f + 1]; u[3] = (uint32_t)f;                 // ftv_offset, factor id
-                        memcpy(&u[4], &fa.featureValue, 8);
-                        u[6] = (uint32_t)nm; u[7] = 0;
-                        for (int64_t m = 0; m < nm; m++) {
-                            const int64_t l = fa.ftv_offset + m;
-                            u[8 + 2 * m] = (uint32_t)c.m_rec[2 * l];
-                            u[9 + 2 * m] = (uint32_t)c.m_rec[2 * l + 1];
-                        }
-                        at += 4 + (uint64_t)nm;
-                    }
-                }
-            }
-    }
-    lap("generic stream");
-    choose_gradient_format(d, c);
-    c.alg_bytes_inference = bytes_inf;
-    c.alg_bytes_learning = bytes_learn;
-    lap("packed-gradient check");
-    // ---- layout bytes: what one sweep must move in the compiled layout.  Tile words (padding
-    // included), position arrays, the distinct neighbour values a colour class reads, the stores and
-    // the tally read-modify-write; materialised weight rows / gathered weights when the table
-    // exceeds the L2; generic-path positions as in the CSR model above.
-    {
-        std::vector<uint64_t> seen((size_t)(nvar + 63) / 64);           // bit b: the class reads variable b
-        for (int32_t k = 0; k < ncolors; k++) {
-            double words = 0, wrows = 0, ep_wt_bytes = 0;
-            for (int64_t b = 0; b < c.phase_wb_base[k + 1] - c.phase_wb_base[k]; b++) {
-                const uint32_t *td = &c.tiles[4 * (c.phase_wb_base[k] + b)];
-                const uint32_t kind = td[2] == 0xFFFFFFFFu ? 8u : (td[3] >> 8) & 7u;
-                words += (double)td[1] * 64 * 4;
-                const bool seg_like = kind < 6u;                 // uniform tiles: p_vid + tally only
-                lay_inf += 64.0 * (4 + (seg_like ? 0 : 4));
-                lay_learn += 64.0 * (4 + 4 + s_v);               // p_vid, p_info, p_init
-                if (big_w && kind == 6u) wrows += (double)((td[3] & 0xFFu) / (2 + ((td[3] >> 16) & 7u))) * 64 * 8;
-                if (big_w && kind == 7u) wrows += (double)(td[3] & 0xFFu) * 64 * 8 / 2;   // ~ one header per two words
-            }
-            if (c.phase_ep[k])                         // entry-parallel groups: their rows instead of tile words;
-                for (int64_t gi = c.phase_ep_base[k]; gi < c.phase_ep_base[k + 1]; gi++) {
-                    const uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
-                    double sr = 0;
-                    double rows = 0;
-                    for (uint32_t m = 0; m < 4; m++) {
-                        const double r = (double)((gd[1] >> (8 * m)) & 255u) + (double)((gd[3] >> (8 * m)) & 255u);
-                        sr += r * (2 + m);
-                        rows += r;
-                    }
-                    words += sr * 256;
-                    ep_wt_bytes += rows * 64 * 8;                      // inference: the materialised weight of every entry
-                    if (big_w) wrows += rows * 64 * 8;                 // learning: one gathered weight per entry
-                }
-            lay_inf += words + (c.phase_ep[k] ? ep_wt_bytes : wrows);
-            lay_learn += words + 3 * wrows;            // weight gathers + one 16-byte atomic per visit
-            int64_t distinct = 0, nfastpos = 0, ncatpos = 0;
-            std::fill(seen.begin(), seen.end(), 0ull);
-            {   // the class's positions over the host threads; a neighbour counts for the thread that sets its bit
-                const int64_t pa = c.phase_start[k], pb = c.phase_fast_end[k];
-                std::vector<int64_t> part((size_t)compile_threads() * 3, 0);
-                parallel_for(pb - pa, [&](int64_t b0, int64_t b1, int t) {
-                    int64_t dn = 0, nf = 0, nc = 0;
-                    for (int64_t p = pa + b0; p < pa + b1; p++) {
-                        const int64_t v = c.p_vid[p];
-                        if (v < 0) continue;
-                        if (d->variable[v].cardinality == 2) nf++; else nc++;
-                        for_each_read(v, [&](int64_t b) {
-                            if (b == v) return;
-                            const uint64_t bit = 1ull << (b & 63);
-                            if (!(__atomic_fetch_or(&seen[(size_t)b >> 6], bit, __ATOMIC_RELAXED) & bit)) dn++;
-                        });
-                    }
-                    part[(size_t)t * 3] = dn; part[(size_t)t * 3 + 1] = nf; part[(size_t)t * 3 + 2] = nc;
-                });
-                for (size_t t = 0; t < part.size(); t += 3) { distinct += part[t]; nfastpos += part[t + 1]; ncatpos += part[t + 2]; }
-            }
-            lay_inf += (double)distinct * s_v + (double)(nfastpos + ncatpos) * s_v + 2.0 * nfastpos + 2.0 * s_c * ncatpos;
-            lay_learn += 2.0 * distinct * s_v + 2.0 * (nfastpos + ncatpos) * s_v;
-        }
-        for (const Compiled::Segment &sg : c.segments) {    // inference over table segments: a tile with implicit
-            if (sg.aff < 0) continue;                        // adjacency reads 16 bytes per chunk, not 64 x 16
-            const int nch = sg.nslots > 4 ? 2 : 1;
-            for (int64_t t = 0; t < sg.ntiles; t++)
-                if (c.seg_aff[((size_t)sg.aff + (size_t)t * nch) * 4] != 0xFFFFFFFFu) {
-                    lay_inf -= (double)nch * (64 * 16 - 16);
-                    lay_learn -= (double)nch * (64 * 16 - 16);
-                }
-        }
-        for (const Compiled::Segment &sg : c.segments)      // the table kernels key their generators by
-            if (sg.ztab >= 0) {                              // position: no p_vid read; learning: no p_info either
-                lay_inf -= (double)sg.ntiles * 64 * 4;
-                lay_learn -= (double)sg.ntiles * 64 * 8;
-            }
-        c.layout_bytes_inference = lay_inf;
-        c.layout_bytes_learning = lay_learn;
-    }
-    lap("layout bytes");
-    return NSK_OK;
+    return build_index_and_census(d, c, ncolors, head_by_vid, for_each_read, lap, err);
 }
 
 }  // namespace nsk
