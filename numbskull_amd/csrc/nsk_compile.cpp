@@ -1214,6 +1214,321 @@ static int build_index_and_census(const nsk_graph_desc *d, Compiled &c, int32_t 
     return NSK_OK;
 }
 
+// Positions: colour-major.  Inside a colour the fast variables grouped by class -- exact program, exact shape, padded
+// shape (per id range) -- so that the 64 lanes of a tile share one slot program / word layout; every class with at
+// least 64 members starts on a tile boundary (the gap is padded with empty positions, p_vid = -1); smaller classes
+// share a tail in id order; then the general tiles' variables (sorted), then the generic-path variables (binned by
+// work).  fast[v]: 1 fast path, 2 general tile, 0 generic (variables that fit no class move from 1 to 2 or 0 here).
+// [shape_at[k], shape_end[k]) = the positions of colour k's shape classes.
+template <typename WordsFn>
+static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, std::vector<uint8_t> &fast,
+                           WordsFn &&general_words, bool no_general, int64_t shape_words, int64_t shape_words_ep,
+                           std::vector<int64_t> &shape_at, std::vector<int64_t> &shape_end, std::string &err) {
+    const int64_t nvar = c.nvar, nfac = c.nfactor, nedge = c.nedge, nw = c.nweight;
+    const int64_t LIM = (int64_t)1 << 31;
+    (void)nfac; (void)nedge; (void)nw; (void)LIM; (void)err;
+    // id blocks of the general tiles' sort order (per-lane walk / entry-parallel groups)
+    const int64_t gen_block = diag_env("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(diag_env("NSK_GEN_BLOCK"))) : 262144;
+    const int64_t ep_block = diag_env("NSK_EP_BLOCK") ? std::max<int64_t>(64, atoll(diag_env("NSK_EP_BLOCK"))) : 1024;
+    // sig: exact program (function, member count, weight id per entry, evidence flag);
+    // shp: shape only (member count per entry, evidence flag), 0 when the stream would exceed
+    //      16 words.  General-tile variables are not classed: they are sorted (below).
+    // pshp: the shape with every entry's member count rounded up to even ("padded" shape): variables whose
+    //      exact shape is rare share tiles with near shapes, the missing member slots filled with null
+    //      words (NSK_SHAPE_NULL) -- with individual weights and lists of 7+ entries the exact shapes
+    //      (2^(entries-1) of them on the weighted boolean graph) no longer fill tiles
+    std::vector<uint64_t> sig(nvar, 0), shp(nvar, 0), pshp(nvar, 0);
+    // Shape classes are formed per id range ("part") of the graph: the lanes of a shape tile then come from
+    // one part, and the values and weights they gather -- mostly those of id neighbours -- from a
+    // correspondingly narrow stretch of every colour's positions (the kernels hand an XCD a contiguous
+    // eighth of the colour's tiles, so one L2 serves those gathers).  One class over the whole id range
+    // put 64 unrelated variables into a tile: the learning sweep of the 4M-variable weighted boolean
+    // graph missed the L2 11 times per variable.  Parts of >= 2^18 ids keep the leftovers (< 64 members
+    // of a shape in a part, general tiles) few: that graph's learning sweep, 8 / 16 / 32 parts: 3.71 / 4.07 /
+    // 4.06e9 updates/s (tools/sessions/r4_s26.sh).
+    const bool no_pshape = diag_env("NSK_NO_PAD_SHAPE") != nullptr || diag_env("NSK_NO_SHAPE") != nullptr;
+    const int64_t shape_parts = diag_env("NSK_SHAPE_PARTS") ? std::max<int64_t>(1, atoll(diag_env("NSK_SHAPE_PARTS")))
+                                                            : std::max<int64_t>(1, std::min<int64_t>(64, (nvar + (1 << 18) - 1) >> 18));
+    std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0), ngt_of((size_t)ncolors, 0);
+    for (int64_t v = 0; v < nvar; v++) {
+        if (c.color[v] < 0) continue;
+        if (fast[v] == 2) ngt_of[c.color[v]]++;
+        else if (!fast[v]) ngen_of[c.color[v]]++;
+        else nfast_of[c.color[v]]++;
+    }
+    parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
+    for (int64_t v = vb0; v < vb1; v++) {
+        if (c.color[v] < 0 || fast[v] != 1) continue;
+        const nsk_variable &var = d->variable[v];
+        const nsk_vtf &vt = d->vmap[var.vtf_offset];
+        // (the evidence flag is multiplied in before the first word: a plain xor would cancel
+        // against the low bit of the first weight id / member count)
+        uint64_t h = (0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence) * 0x100000001b3ull;
+        uint64_t h2 = (h ^ 0x9e3779b97f4a7c15ull ^ ((uint64_t)(v * shape_parts / std::max<int64_t>(nvar, 1)) << 40)) * 0x100000001b3ull;
+        uint64_t h3 = (h2 ^ 0xd6e8feb86659fd93ull) * 0x100000001b3ull;
+        int64_t nwords = 0, pwords = 0;
+        uint64_t maxo = 0;
+        for (int64_t j = 0; j < vt.factor_index_length; j++) {
+            const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
+            uint64_t others = 0;
+            if (fa.factorFunction != -1)
+                for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++)
+                    if (d->fmap[l].vid != v) others++;
+            const uint64_t word = ((uint64_t)(fa.factorFunction + 1) << 27) | (others << 24) | (uint64_t)fa.weightId;
+            h = (h ^ word) * 0x100000001b3ull;
+            h ^= h >> 29;
+            h2 = (h2 ^ (others + 1)) * 0x100000001b3ull;
+            h2 ^= h2 >> 31;
+            const uint64_t padded = (others + 1) & ~(uint64_t)1;
+            maxo = std::max(maxo, others);
+            h3 = (h3 ^ (padded + 1)) * 0x100000001b3ull;
+            h3 ^= h3 >> 31;
+            nwords += 1 + (int64_t)others;
+            pwords += 1 + (int64_t)padded;
+        }
+        sig[v] = h | 1;
+        // (a variable the entry-parallel groups can take -- <= 3 other members per entry, <= 16 entries -- joins a
+        //  shape class only with a list of a few words, shape_words_ep)
+        const int64_t lim = (maxo <= 3 && vt.factor_index_length <= 16) ? shape_words_ep : shape_words;
+        shp[v] = nwords <= lim ? (h2 | 1) : 0;
+        pshp[v] = (pwords <= lim && !no_pshape) ? (h3 | 1) : 0;
+    }
+    });
+    // (hash maps: with one weight per factor every variable is a class of its own -- millions of keys;
+    //  nothing below depends on their iteration order.  The colours are independent: one thread each.)
+    typedef std::unordered_map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
+    std::vector<ClassMap> classes((size_t)ncolors), shapes((size_t)ncolors), pshapes((size_t)ncolors);
+    // a class gets tiles of its own when it fills at least one (64 members) -- or whatever its
+    // size when the colour has only a few small classes (then padding them costs nothing
+    // and no tile is left with mixed programs, e.g. the corner cells of a grid)
+    std::vector<int64_t> min_class((size_t)ncolors, 64);
+    parallel_for(ncolors, [&](int64_t kb0, int64_t kb1, int) {
+    for (int32_t k = (int32_t)kb0; k < (int32_t)kb1; k++) {
+        ClassMap &cls = classes[k], &shs = shapes[k], &pss = pshapes[k];
+        cls.reserve((size_t)nfast_of[k]);
+        for (int64_t v = 0; v < nvar; v++) {
+            if (c.color[v] != k || fast[v] != 1) continue;
+            auto &e = cls[sig[v]];
+            if (e.first++ == 0) e.second = v;
+        }
+        int64_t nsmall = 0;
+        for (auto &kv : cls) if (kv.second.first < 64) nsmall++;
+        if (nsmall <= 16) min_class[k] = 1;
+        // variables outside the big exact classes are grouped by shape
+        for (int64_t v = 0; v < nvar; v++) {
+            if (c.color[v] != k || fast[v] != 1 || shp[v] == 0 || cls[sig[v]].first >= min_class[k]) continue;
+            auto &e = shs[shp[v]];
+            if (e.first++ == 0) e.second = v;
+        }
+        // ... and the ones whose exact shape fills no tile by padded shape
+        for (int64_t v = 0; v < nvar; v++) {
+            if (c.color[v] != k || fast[v] != 1 || pshp[v] == 0 || cls[sig[v]].first >= min_class[k]) continue;
+            if (shp[v] != 0 && shs[shp[v]].first >= 64) continue;
+            auto &e = pss[pshp[v]];
+            if (e.first++ == 0) e.second = v;
+        }
+        // what neither an exact nor a shape class can take would end in mixed tiles with per-lane
+        // parsing: the general tiles' sorted layout serves those variables better
+        for (int64_t v = 0; v < nvar && !no_general; v++) {
+            if (c.color[v] != k || fast[v] != 1 || cls[sig[v]].first >= min_class[k]) continue;
+            if (shp[v] != 0 && shs[shp[v]].first >= 64) continue;
+            if (pshp[v] != 0 && pss[pshp[v]].first >= 64) continue;
+            if (shp[v] != 0) shs[shp[v]].first--;
+            if (pshp[v] != 0) pss[pshp[v]].first--;
+            nfast_of[k]--;
+            if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
+            else { fast[v] = 0; ngen_of[k]++; }          // long lists: wave-per-variable / generic kernels
+        }
+    }
+    }, 1);
+    // a colour whose exact / shape classes are a sliver next to its general tiles gives them up:
+    // their few tiles would cost two or three extra launches per class and sweep
+    for (int32_t k = 0; k < ncolors && !no_general; k++) {
+        if (nfast_of[k] == 0 || nfast_of[k] * 20 >= ngt_of[k]) continue;
+        for (int64_t v = 0; v < nvar; v++) {
+            if (c.color[v] != k || fast[v] != 1) continue;
+            nfast_of[k]--;
+            if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
+            else { fast[v] = 0; ngen_of[k]++; }
+        }
+        classes[k].clear();
+        shapes[k].clear();
+        pshapes[k].clear();
+    }
+    std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
+    std::vector<std::vector<int64_t>> gen_bin_start;
+    std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors), start3((size_t)ncolors);
+    int64_t pos = 0;
+    for (int32_t k = 0; k < ncolors; k++) {
+        pos = (pos + 127) / 128 * 128;      // tiles sit on multiples of 64, tile pairs on multiples of
+        c.phase_start[k] = pos;             // 128: a lane's position & 63 is its lane (generator ids)
+        int64_t nbig = 0;
+        for (int level = 0; level < 3; level++) {
+            if (level == 1) shape_at[k] = pos;
+            ClassMap &cm = level == 0 ? classes[k] : level == 1 ? shapes[k] : pshapes[k];
+            std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, key)
+            const int64_t need = level == 0 ? min_class[k] : 64;
+            for (auto &kv : cm)
+                if (kv.second.first >= need) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
+            std::sort(big.begin(), big.end());
+            for (auto &bc : big) {
+                (level == 0 ? start[k] : level == 1 ? start2[k] : start3[k])[bc.second] = pos;
+                pos += cm[bc.second].first;
+                pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
+            }
+            cm.clear();
+        }
+        tail_at[k] = pos;
+        shape_end[k] = pos;
+        pos += nfast_of[k] - nbig;
+        pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
+        gt_at[k] = pos;                                                     // general tiles
+        c.phase_gen_tile[k] = (pos - c.phase_start[k]) / 64;
+        pos += ngt_of[k];
+        pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
+        c.phase_fast_end[k] = pos;
+        next_gen[k] = pos;
+        pos += ngen_of[k];
+        c.phase_end[k] = pos;               // (the next colour starts at the next multiple of 128)
+    }
+    c.phase_start[ncolors] = pos;
+    c.npos = pos;
+    if (c.npos >= LIM - 1) { err = "too many positions"; return NSK_E_RANGE; }
+    c.p_vid.assign(c.npos, -1); c.p_info.assign(c.npos, 0); c.p_slot.assign(c.npos, 0);
+    c.p_cnt.assign(c.npos, 0); c.p_init.assign(c.npos, 0);
+    // generic-path variables of a colour are ordered by the work of one update (factor-list
+    // lengths x arities over all candidate values, binned) so that the 64 lanes of a wave finish
+    // together; inside a bin: variable id.
+    std::vector<uint32_t> gw;
+    std::vector<uint8_t> work_bin(nvar, 0);
+    for (int64_t v = 0; v < nvar; v++) {
+        if (c.color[v] < 0 || fast[v]) continue;
+        const nsk_variable &var = d->variable[v];
+        const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
+        int64_t work = 0, listlen = 0;
+        for (int64_t kk = 0; kk < nslots; kk++) {
+            const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
+            listlen += vt.factor_index_length;
+            for (int64_t j = 0; j < vt.factor_index_length; j++)
+                work += 2 + std::max<int64_t>(d->factor[d->factor_index[vt.factor_index_offset + j]].arity, 0);
+        }
+        if (var.dataType == 0) work *= var.cardinality;
+        int bin = 0;
+        while (work > 8 && bin < 39) { work = work * 3 / 4; bin++; }     // ~log_{4/3} bins
+        work_bin[v] = (uint8_t)(40 - bin);                               // heavier variables first
+        // hubs: a whole wave works on one such variable (heavy_update in k_gibbs_general / k_learn_heavy)
+        if (listlen >= NSK_HEAVY_LIST && !diag_env("NSK_NO_HEAVY")) work_bin[v] = 0;
+    }
+    // a colour with few generic-path variables gives every one of them a wave: the one-lane
+    // kernel's run time is the latency of its longest serial walk however few lanes are busy
+    if (!diag_env("NSK_NO_HEAVY"))
+        for (int64_t v = 0; v < nvar; v++)
+            if (c.color[v] >= 0 && !fast[v] && ngen_of[c.color[v]] <= NSK_FEW_GENERIC) work_bin[v] = 0;
+    {
+        std::vector<std::vector<int64_t>> bin_count((size_t)ncolors, std::vector<int64_t>(42, 0));
+        for (int64_t v = 0; v < nvar; v++)
+            if (c.color[v] >= 0 && !fast[v]) bin_count[c.color[v]][work_bin[v] + 1]++;
+        gen_bin_start.assign((size_t)ncolors, std::vector<int64_t>(42, 0));
+        c.phase_heavy_end.assign((size_t)ncolors, 0);
+        for (int32_t k = 0; k < ncolors; k++) {
+            gen_bin_start[k][0] = next_gen[k];
+            for (int b = 0; b < 41; b++) gen_bin_start[k][b + 1] = gen_bin_start[k][b] + bin_count[k][b + 1];
+            c.phase_heavy_end[k] = gen_bin_start[k][1];              // bin 0 = the hubs
+        }
+    }
+    // general-tile variables of a colour: sorted by (entries, most other members of an entry),
+    // largest first, and cut into tiles of 64 -- a tile's layout is the maximum over its lanes,
+    // so neighbours in this order waste the least padding (SELL-C-sigma)
+    {
+        std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (key, vid)
+        std::vector<uint8_t> g_ne(nvar, 0), g_mo(nvar, 0);      // entries / widest entry of a general lane
+        parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
+            std::vector<uint32_t> w;
+            for (int64_t v = vb0; v < vb1; v++) {
+                if (c.color[v] < 0 || fast[v] != 2) continue;
+                general_words(v, &w);
+                int64_t ne = 0, mo = 0;
+                for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) {
+                    ne++;
+                    mo = std::max<int64_t>(mo, (w[j + 1] >> 4) & 7u);
+                }
+                g_ne[v] = (uint8_t)ne; g_mo[v] = (uint8_t)mo;
+            }
+        });
+        // entry-parallel groups (nsk_compile.h ep_desc) serve a colour whose general variables all
+        // have entries of at most 3 other members and at most 16 entries (ordinal: 5 bits, LDS slots)
+        c.phase_ep.assign((size_t)ncolors, 0);
+        c.phase_ep_emax.assign((size_t)ncolors, 0);
+        if (!diag_env("NSK_NO_EP") && nw < ((int64_t)1 << 27)) {
+            for (int32_t k = 0; k < ncolors; k++) c.phase_ep[k] = ngt_of[k] > 0 ? 1 : 0;
+            for (int64_t v = 0; v < nvar; v++) {
+                if (c.color[v] < 0 || fast[v] != 2) continue;
+                if (g_mo[v] > 3 || g_ne[v] > 16) c.phase_ep[c.color[v]] = 0;
+                c.phase_ep_emax[c.color[v]] = std::max<int32_t>(c.phase_ep_emax[c.color[v]], g_ne[v]);
+            }
+        }
+        // key: categorical lanes first (their tiles form a launch of their own), then blocks
+        // of gen_block consecutive ids (sigma of SELL-C-sigma: each XCD walks a contiguous
+        // run of tiles, so its L2 then sees one slice of the value array instead of all of
+        // it), largest layouts first inside a block.  Entry-parallel groups carry no padding to the
+        // widest lane, so their colours are cut into small id blocks -- a group's member values then
+        // share cache lines --, with the variables of more than 8 entries (two LDS passes per group)
+        // in front of the others.  One colour per thread: collect its variables, sort them.
+        auto collect = [&](int32_t k) {
+            std::vector<std::pair<int64_t, int64_t>> &ord = order[(size_t)k];
+            ord.reserve((size_t)ngt_of[k]);
+            const bool epk = c.phase_ep[k] != 0;
+            const int64_t gb = epk ? ep_block : gen_block;
+            for (int64_t v = 0; v < nvar; v++) {
+                if (c.color[v] != k || fast[v] != 2) continue;
+                const int64_t ne = g_ne[v], mo = g_mo[v];
+                const int64_t catv = d->variable[v].cardinality > 2 ? 0 : 1;
+                const int64_t small = (epk && ne <= 8) ? 1 : 0;
+                ord.push_back({(small << 51) | (catv << 50) | ((v / gb) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
+            }
+            std::sort(ord.begin(), ord.end());
+        };
+        {
+            std::vector<std::thread> sorters;             // (few colours only)
+            for (int32_t k = 0; k < ncolors; k++) {
+                if (ncolors <= 64 && compile_threads() > 1) sorters.emplace_back([&, k] { collect(k); });
+                else collect(k);
+            }
+            for (auto &t : sorters) t.join();
+        }
+        for (int32_t k = 0; k < ncolors; k++) {
+            for (auto &o : order[k]) {
+                const int64_t p = gt_at[k]++;
+                c.p_vid[p] = (int32_t)o.second;
+                c.v_pos[o.second] = (int32_t)p;
+                c.nsampled++;
+            }
+        }
+    }
+    for (int64_t v = 0; v < nvar; v++) {
+        const int32_t k = c.color[v];
+        if (k < 0 || fast[v] == 2) continue;
+        int64_t p;
+        if (!fast[v]) p = gen_bin_start[k][work_bin[v]]++;
+        else {
+            auto it = start[k].find(sig[v]);
+            if (it != start[k].end()) p = it->second++;
+            else {
+                auto it2 = shp[v] ? start2[k].find(shp[v]) : start2[k].end();
+                if (it2 != start2[k].end()) p = it2->second++;
+                else {
+                    auto it3 = pshp[v] ? start3[k].find(pshp[v]) : start3[k].end();
+                    p = (it3 != start3[k].end()) ? it3->second++ : tail_at[k]++;
+                }
+            }
+        }
+        c.p_vid[p] = (int32_t)v;
+        c.v_pos[v] = (int32_t)p;
+        c.nsampled++;
+    }
+    return NSK_OK;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1461,8 +1776,6 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const bool no_general = diag_env("NSK_NO_GENERAL") != nullptr || nvar >= (int64_t)100000000;
     // longer lists go to the wave-per-variable kernel: a tile is walked by one wave, so its longest
     // lane sets a serial chain of memory round trips and the longest tile the kernel's run time
-    const int64_t gen_block = diag_env("NSK_GEN_BLOCK") ? std::max<int64_t>(64, atoll(diag_env("NSK_GEN_BLOCK"))) : 262144;
-    const int64_t ep_block = diag_env("NSK_EP_BLOCK") ? std::max<int64_t>(64, atoll(diag_env("NSK_EP_BLOCK"))) : 1024;
     const int64_t gen_max_entries = diag_env("NSK_GEN_MAX_ENTRIES") ? std::max(1, std::min(24, atoi(diag_env("NSK_GEN_MAX_ENTRIES")))) : 16;
     // (hub = true lifts the per-lane size caps: the entry-parallel hub kernels take up to 256 entries)
     //
@@ -1601,304 +1914,8 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t shape_words_ep = diag_env("NSK_SHAPE_MAX_WORDS") ? shape_words : NSK_SHAPE_WORDS_EP;
     // [shape_at[k], shape_end[k]): the positions of colour k's shape classes (tile shapes, pass 1)
     std::vector<int64_t> shape_at((size_t)ncolors, 0), shape_end((size_t)ncolors, 0);
-    {
-        // sig: exact program (function, member count, weight id per entry, evidence flag);
-        // shp: shape only (member count per entry, evidence flag), 0 when the stream would exceed
-        //      16 words.  General-tile variables are not classed: they are sorted (below).
-        // pshp: the shape with every entry's member count rounded up to even ("padded" shape): variables whose
-        //      exact shape is rare share tiles with near shapes, the missing member slots filled with null
-        //      words (NSK_SHAPE_NULL) -- with individual weights and lists of 7+ entries the exact shapes
-        //      (2^(entries-1) of them on the weighted boolean graph) no longer fill tiles
-        std::vector<uint64_t> sig(nvar, 0), shp(nvar, 0), pshp(nvar, 0);
-        // Shape classes are formed per id range ("part") of the graph: the lanes of a shape tile then come from
-        // one part, and the values and weights they gather -- mostly those of id neighbours -- from a
-        // correspondingly narrow stretch of every colour's positions (the kernels hand an XCD a contiguous
-        // eighth of the colour's tiles, so one L2 serves those gathers).  One class over the whole id range
-        // put 64 unrelated variables into a tile: the learning sweep of the 4M-variable weighted boolean
-        // graph missed the L2 11 times per variable.  Parts of >= 2^18 ids keep the leftovers (< 64 members
-        // of a shape in a part, general tiles) few: that graph's learning sweep, 8 / 16 / 32 parts: 3.71 / 4.07 /
-        // 4.06e9 updates/s (tools/sessions/r4_s26.sh).
-        const bool no_pshape = diag_env("NSK_NO_PAD_SHAPE") != nullptr || diag_env("NSK_NO_SHAPE") != nullptr;
-        const int64_t shape_parts = diag_env("NSK_SHAPE_PARTS") ? std::max<int64_t>(1, atoll(diag_env("NSK_SHAPE_PARTS")))
-                                                                : std::max<int64_t>(1, std::min<int64_t>(64, (nvar + (1 << 18) - 1) >> 18));
-        std::vector<int64_t> nfast_of((size_t)ncolors, 0), ngen_of((size_t)ncolors, 0), ngt_of((size_t)ncolors, 0);
-        for (int64_t v = 0; v < nvar; v++) {
-            if (c.color[v] < 0) continue;
-            if (fast[v] == 2) ngt_of[c.color[v]]++;
-            else if (!fast[v]) ngen_of[c.color[v]]++;
-            else nfast_of[c.color[v]]++;
-        }
-        parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
-        for (int64_t v = vb0; v < vb1; v++) {
-            if (c.color[v] < 0 || fast[v] != 1) continue;
-            const nsk_variable &var = d->variable[v];
-            const nsk_vtf &vt = d->vmap[var.vtf_offset];
-            // (the evidence flag is multiplied in before the first word: a plain xor would cancel
-            // against the low bit of the first weight id / member count)
-            uint64_t h = (0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)var.isEvidence) * 0x100000001b3ull;
-            uint64_t h2 = (h ^ 0x9e3779b97f4a7c15ull ^ ((uint64_t)(v * shape_parts / std::max<int64_t>(nvar, 1)) << 40)) * 0x100000001b3ull;
-            uint64_t h3 = (h2 ^ 0xd6e8feb86659fd93ull) * 0x100000001b3ull;
-            int64_t nwords = 0, pwords = 0;
-            uint64_t maxo = 0;
-            for (int64_t j = 0; j < vt.factor_index_length; j++) {
-                const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
-                uint64_t others = 0;
-                if (fa.factorFunction != -1)
-                    for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++)
-                        if (d->fmap[l].vid != v) others++;
-                const uint64_t word = ((uint64_t)(fa.factorFunction + 1) << 27) | (others << 24) | (uint64_t)fa.weightId;
-                h = (h ^ word) * 0x100000001b3ull;
-                h ^= h >> 29;
-                h2 = (h2 ^ (others + 1)) * 0x100000001b3ull;
-                h2 ^= h2 >> 31;
-                const uint64_t padded = (others + 1) & ~(uint64_t)1;
-                maxo = std::max(maxo, others);
-                h3 = (h3 ^ (padded + 1)) * 0x100000001b3ull;
-                h3 ^= h3 >> 31;
-                nwords += 1 + (int64_t)others;
-                pwords += 1 + (int64_t)padded;
-            }
-            sig[v] = h | 1;
-            // (a variable the entry-parallel groups can take -- <= 3 other members per entry, <= 16 entries -- joins a
-            //  shape class only with a list of a few words, shape_words_ep)
-            const int64_t lim = (maxo <= 3 && vt.factor_index_length <= 16) ? shape_words_ep : shape_words;
-            shp[v] = nwords <= lim ? (h2 | 1) : 0;
-            pshp[v] = (pwords <= lim && !no_pshape) ? (h3 | 1) : 0;
-        }
-        });
-        // (hash maps: with one weight per factor every variable is a class of its own -- millions of keys;
-        //  nothing below depends on their iteration order.  The colours are independent: one thread each.)
-        typedef std::unordered_map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
-        std::vector<ClassMap> classes((size_t)ncolors), shapes((size_t)ncolors), pshapes((size_t)ncolors);
-        // a class gets tiles of its own when it fills at least one (64 members) -- or whatever its
-        // size when the colour has only a few small classes (then padding them costs nothing
-        // and no tile is left with mixed programs, e.g. the corner cells of a grid)
-        std::vector<int64_t> min_class((size_t)ncolors, 64);
-        parallel_for(ncolors, [&](int64_t kb0, int64_t kb1, int) {
-        for (int32_t k = (int32_t)kb0; k < (int32_t)kb1; k++) {
-            ClassMap &cls = classes[k], &shs = shapes[k], &pss = pshapes[k];
-            cls.reserve((size_t)nfast_of[k]);
-            for (int64_t v = 0; v < nvar; v++) {
-                if (c.color[v] != k || fast[v] != 1) continue;
-                auto &e = cls[sig[v]];
-                if (e.first++ == 0) e.second = v;
-            }
-            int64_t nsmall = 0;
-            for (auto &kv : cls) if (kv.second.first < 64) nsmall++;
-            if (nsmall <= 16) min_class[k] = 1;
-            // variables outside the big exact classes are grouped by shape
-            for (int64_t v = 0; v < nvar; v++) {
-                if (c.color[v] != k || fast[v] != 1 || shp[v] == 0 || cls[sig[v]].first >= min_class[k]) continue;
-                auto &e = shs[shp[v]];
-                if (e.first++ == 0) e.second = v;
-            }
-            // ... and the ones whose exact shape fills no tile by padded shape
-            for (int64_t v = 0; v < nvar; v++) {
-                if (c.color[v] != k || fast[v] != 1 || pshp[v] == 0 || cls[sig[v]].first >= min_class[k]) continue;
-                if (shp[v] != 0 && shs[shp[v]].first >= 64) continue;
-                auto &e = pss[pshp[v]];
-                if (e.first++ == 0) e.second = v;
-            }
-            // what neither an exact nor a shape class can take would end in mixed tiles with per-lane
-            // parsing: the general tiles' sorted layout serves those variables better
-            for (int64_t v = 0; v < nvar && !no_general; v++) {
-                if (c.color[v] != k || fast[v] != 1 || cls[sig[v]].first >= min_class[k]) continue;
-                if (shp[v] != 0 && shs[shp[v]].first >= 64) continue;
-                if (pshp[v] != 0 && pss[pshp[v]].first >= 64) continue;
-                if (shp[v] != 0) shs[shp[v]].first--;
-                if (pshp[v] != 0) pss[pshp[v]].first--;
-                nfast_of[k]--;
-                if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
-                else { fast[v] = 0; ngen_of[k]++; }          // long lists: wave-per-variable / generic kernels
-            }
-        }
-        }, 1);
-        // a colour whose exact / shape classes are a sliver next to its general tiles gives them up:
-        // their few tiles would cost two or three extra launches per class and sweep
-        for (int32_t k = 0; k < ncolors && !no_general; k++) {
-            if (nfast_of[k] == 0 || nfast_of[k] * 20 >= ngt_of[k]) continue;
-            for (int64_t v = 0; v < nvar; v++) {
-                if (c.color[v] != k || fast[v] != 1) continue;
-                nfast_of[k]--;
-                if (general_words(v, nullptr)) { fast[v] = 2; ngt_of[k]++; }
-                else { fast[v] = 0; ngen_of[k]++; }
-            }
-            classes[k].clear();
-            shapes[k].clear();
-            pshapes[k].clear();
-        }
-        std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
-        std::vector<std::vector<int64_t>> gen_bin_start;
-        std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors), start3((size_t)ncolors);
-        int64_t pos = 0;
-        for (int32_t k = 0; k < ncolors; k++) {
-            pos = (pos + 127) / 128 * 128;      // tiles sit on multiples of 64, tile pairs on multiples of
-            c.phase_start[k] = pos;             // 128: a lane's position & 63 is its lane (generator ids)
-            int64_t nbig = 0;
-            for (int level = 0; level < 3; level++) {
-                if (level == 1) shape_at[k] = pos;
-                ClassMap &cm = level == 0 ? classes[k] : level == 1 ? shapes[k] : pshapes[k];
-                std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, key)
-                const int64_t need = level == 0 ? min_class[k] : 64;
-                for (auto &kv : cm)
-                    if (kv.second.first >= need) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
-                std::sort(big.begin(), big.end());
-                for (auto &bc : big) {
-                    (level == 0 ? start[k] : level == 1 ? start2[k] : start3[k])[bc.second] = pos;
-                    pos += cm[bc.second].first;
-                    pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
-                }
-                cm.clear();
-            }
-            tail_at[k] = pos;
-            shape_end[k] = pos;
-            pos += nfast_of[k] - nbig;
-            pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
-            gt_at[k] = pos;                                                     // general tiles
-            c.phase_gen_tile[k] = (pos - c.phase_start[k]) / 64;
-            pos += ngt_of[k];
-            pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
-            c.phase_fast_end[k] = pos;
-            next_gen[k] = pos;
-            pos += ngen_of[k];
-            c.phase_end[k] = pos;               // (the next colour starts at the next multiple of 128)
-        }
-        c.phase_start[ncolors] = pos;
-        c.npos = pos;
-        if (c.npos >= LIM - 1) { err = "too many positions"; return NSK_E_RANGE; }
-        c.p_vid.assign(c.npos, -1); c.p_info.assign(c.npos, 0); c.p_slot.assign(c.npos, 0);
-        c.p_cnt.assign(c.npos, 0); c.p_init.assign(c.npos, 0);
-        // generic-path variables of a colour are ordered by the work of one update (factor-list
-        // lengths x arities over all candidate values, binned) so that the 64 lanes of a wave finish
-        // together; inside a bin: variable id.
-        std::vector<uint32_t> gw;
-        std::vector<uint8_t> work_bin(nvar, 0);
-        for (int64_t v = 0; v < nvar; v++) {
-            if (c.color[v] < 0 || fast[v]) continue;
-            const nsk_variable &var = d->variable[v];
-            const int64_t nslots = var.dataType == 0 ? 1 : var.cardinality;
-            int64_t work = 0, listlen = 0;
-            for (int64_t kk = 0; kk < nslots; kk++) {
-                const nsk_vtf &vt = d->vmap[var.vtf_offset + kk];
-                listlen += vt.factor_index_length;
-                for (int64_t j = 0; j < vt.factor_index_length; j++)
-                    work += 2 + std::max<int64_t>(d->factor[d->factor_index[vt.factor_index_offset + j]].arity, 0);
-            }
-            if (var.dataType == 0) work *= var.cardinality;
-            int bin = 0;
-            while (work > 8 && bin < 39) { work = work * 3 / 4; bin++; }     // ~log_{4/3} bins
-            work_bin[v] = (uint8_t)(40 - bin);                               // heavier variables first
-            // hubs: a whole wave works on one such variable (heavy_update in k_gibbs_general / k_learn_heavy)
-            if (listlen >= NSK_HEAVY_LIST && !diag_env("NSK_NO_HEAVY")) work_bin[v] = 0;
-        }
-        // a colour with few generic-path variables gives every one of them a wave: the one-lane
-        // kernel's run time is the latency of its longest serial walk however few lanes are busy
-        if (!diag_env("NSK_NO_HEAVY"))
-            for (int64_t v = 0; v < nvar; v++)
-                if (c.color[v] >= 0 && !fast[v] && ngen_of[c.color[v]] <= NSK_FEW_GENERIC) work_bin[v] = 0;
-        {
-            std::vector<std::vector<int64_t>> bin_count((size_t)ncolors, std::vector<int64_t>(42, 0));
-            for (int64_t v = 0; v < nvar; v++)
-                if (c.color[v] >= 0 && !fast[v]) bin_count[c.color[v]][work_bin[v] + 1]++;
-            gen_bin_start.assign((size_t)ncolors, std::vector<int64_t>(42, 0));
-            c.phase_heavy_end.assign((size_t)ncolors, 0);
-            for (int32_t k = 0; k < ncolors; k++) {
-                gen_bin_start[k][0] = next_gen[k];
-                for (int b = 0; b < 41; b++) gen_bin_start[k][b + 1] = gen_bin_start[k][b] + bin_count[k][b + 1];
-                c.phase_heavy_end[k] = gen_bin_start[k][1];              // bin 0 = the hubs
-            }
-        }
-        // general-tile variables of a colour: sorted by (entries, most other members of an entry),
-        // largest first, and cut into tiles of 64 -- a tile's layout is the maximum over its lanes,
-        // so neighbours in this order waste the least padding (SELL-C-sigma)
-        {
-            std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (key, vid)
-            std::vector<uint8_t> g_ne(nvar, 0), g_mo(nvar, 0);      // entries / widest entry of a general lane
-            parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
-                std::vector<uint32_t> w;
-                for (int64_t v = vb0; v < vb1; v++) {
-                    if (c.color[v] < 0 || fast[v] != 2) continue;
-                    general_words(v, &w);
-                    int64_t ne = 0, mo = 0;
-                    for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) {
-                        ne++;
-                        mo = std::max<int64_t>(mo, (w[j + 1] >> 4) & 7u);
-                    }
-                    g_ne[v] = (uint8_t)ne; g_mo[v] = (uint8_t)mo;
-                }
-            });
-            // entry-parallel groups (nsk_compile.h ep_desc) serve a colour whose general variables all
-            // have entries of at most 3 other members and at most 16 entries (ordinal: 5 bits, LDS slots)
-            c.phase_ep.assign((size_t)ncolors, 0);
-            c.phase_ep_emax.assign((size_t)ncolors, 0);
-            if (!diag_env("NSK_NO_EP") && nw < ((int64_t)1 << 27)) {
-                for (int32_t k = 0; k < ncolors; k++) c.phase_ep[k] = ngt_of[k] > 0 ? 1 : 0;
-                for (int64_t v = 0; v < nvar; v++) {
-                    if (c.color[v] < 0 || fast[v] != 2) continue;
-                    if (g_mo[v] > 3 || g_ne[v] > 16) c.phase_ep[c.color[v]] = 0;
-                    c.phase_ep_emax[c.color[v]] = std::max<int32_t>(c.phase_ep_emax[c.color[v]], g_ne[v]);
-                }
-            }
-            // key: categorical lanes first (their tiles form a launch of their own), then blocks
-            // of gen_block consecutive ids (sigma of SELL-C-sigma: each XCD walks a contiguous
-            // run of tiles, so its L2 then sees one slice of the value array instead of all of
-            // it), largest layouts first inside a block.  Entry-parallel groups carry no padding to the
-            // widest lane, so their colours are cut into small id blocks -- a group's member values then
-            // share cache lines --, with the variables of more than 8 entries (two LDS passes per group)
-            // in front of the others.  One colour per thread: collect its variables, sort them.
-            auto collect = [&](int32_t k) {
-                std::vector<std::pair<int64_t, int64_t>> &ord = order[(size_t)k];
-                ord.reserve((size_t)ngt_of[k]);
-                const bool epk = c.phase_ep[k] != 0;
-                const int64_t gb = epk ? ep_block : gen_block;
-                for (int64_t v = 0; v < nvar; v++) {
-                    if (c.color[v] != k || fast[v] != 2) continue;
-                    const int64_t ne = g_ne[v], mo = g_mo[v];
-                    const int64_t catv = d->variable[v].cardinality > 2 ? 0 : 1;
-                    const int64_t small = (epk && ne <= 8) ? 1 : 0;
-                    ord.push_back({(small << 51) | (catv << 50) | ((v / gb) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
-                }
-                std::sort(ord.begin(), ord.end());
-            };
-            {
-                std::vector<std::thread> sorters;             // (few colours only)
-                for (int32_t k = 0; k < ncolors; k++) {
-                    if (ncolors <= 64 && compile_threads() > 1) sorters.emplace_back([&, k] { collect(k); });
-                    else collect(k);
-                }
-                for (auto &t : sorters) t.join();
-            }
-            for (int32_t k = 0; k < ncolors; k++) {
-                for (auto &o : order[k]) {
-                    const int64_t p = gt_at[k]++;
-                    c.p_vid[p] = (int32_t)o.second;
-                    c.v_pos[o.second] = (int32_t)p;
-                    c.nsampled++;
-                }
-            }
-        }
-        for (int64_t v = 0; v < nvar; v++) {
-            const int32_t k = c.color[v];
-            if (k < 0 || fast[v] == 2) continue;
-            int64_t p;
-            if (!fast[v]) p = gen_bin_start[k][work_bin[v]]++;
-            else {
-                auto it = start[k].find(sig[v]);
-                if (it != start[k].end()) p = it->second++;
-                else {
-                    auto it2 = shp[v] ? start2[k].find(shp[v]) : start2[k].end();
-                    if (it2 != start2[k].end()) p = it2->second++;
-                    else {
-                        auto it3 = pshp[v] ? start3[k].find(pshp[v]) : start3[k].end();
-                        p = (it3 != start3[k].end()) ? it3->second++ : tail_at[k]++;
-                    }
-                }
-            }
-            c.p_vid[p] = (int32_t)v;
-            c.v_pos[v] = (int32_t)p;
-            c.nsampled++;
-        }
-    }
+        if (int prc = place_variables(d, c, ncolors, fast, general_words, no_general, shape_words, shape_words_ep, shape_at, shape_end, err))
+        return prc;
     // ---- internal ids: a positioned variable's id is its position; the others (ghosts, isEvidence
     // == 4 -- read but never sampled here) follow.  Every variable id stored for the device from
     // here on is internal (m_rec, tiles, gstream, v_card): values are kept in this order, so the
