@@ -1529,6 +1529,224 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     return NSK_OK;
 }
 
+// Pass 1 over the tiles: the shape of every tile.  Uniform tile = all its lanes have the same header sequence
+// (slot program, draw-table candidate); shape tile = same word layout, per-lane functions and weights; general tile =
+// E entries x (2 + M) words.  Phase A (parallel over tiles) classifies the tile and reduces its program to a short
+// key; phase B (sequential) pools the programs, assigns stream offsets and weight rows.  Out: tile_colour[t], total4
+// (the stream's size in 16-byte units).
+template <typename WordsFn, typename LaneWordsFn>
+static int shape_tiles(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, int64_t nwb, WordsFn &&general_words,
+                       LaneWordsFn &&lane_words, const std::vector<int64_t> &shape_at, const std::vector<int64_t> &shape_end,
+                       int64_t shape_words, const std::vector<uint8_t> &fast, std::vector<int32_t> &tile_colour,
+                       uint64_t &total4, std::string &err) {
+    const int64_t nw = c.nweight, nvar = c.nvar;
+    (void)nw; (void)nvar; (void)d;
+    auto headers_of = [&](const std::vector<uint32_t> &w, std::vector<uint32_t> &h) {
+        h.clear();
+        for (size_t j = 0; j < w.size(); j += 1 + ((w[j] >> 24) & 7u)) h.push_back(w[j]);
+    };
+    // pass 1: shape of every tile.  Uniform tile = all its lanes have the same header sequence.
+    // Phase A (parallel over tiles): classify the tile and reduce its program to a short key;
+    // phase B (sequential): pool the programs, assign stream offsets and weight rows.
+    struct TileShape {
+        uint8_t cls;            // 0 per-lane headers, 1 general, 2 uniform, 3 shape
+        uint8_t nkey;
+        int32_t len;            // words per lane before rounding to chunks
+        uint32_t flags;         // td[3]
+        uint32_t nrows;         // materialised weight rows the tile needs
+        uint32_t key[32];       // uniform / shape: the program words (NSK_SHAPE_WORDS); general: {E, M}
+    };
+    std::vector<TileShape> shapes_of((size_t)nwb);
+    tile_colour.assign((size_t)nwb, 0);
+    for (int32_t k = 0; k < ncolors; k++)
+        for (int64_t t = c.phase_wb_base[k]; t < c.phase_wb_base[k + 1]; t++) tile_colour[t] = k;
+    const bool no_shape = diag_env("NSK_NO_SHAPE") != nullptr, no_ztab = diag_env("NSK_NO_ZTAB") != nullptr;
+    parallel_for(nwb, [&](int64_t tb0, int64_t tb1, int) {
+        std::vector<uint32_t> words, hdrs, hdrs0;
+        for (int64_t t = tb0; t < tb1; t++) {
+            const int32_t k = tile_colour[t];
+            const int64_t b = t - c.phase_wb_base[k];
+            const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
+            TileShape &ts = shapes_of[t];
+            memset(&ts, 0, sizeof(ts));
+            bool gen_tile = false;                             // general tile (kind 6)
+            for (int64_t p = p0; p < p1 && !gen_tile; p++)
+                if (c.p_vid[p] >= 0 && fast[c.p_vid[p]] == 2) gen_tile = true;
+            if (gen_tile) {
+                // layout shared by the 64 lanes: E entries of 2 + M words, E and M the maxima over
+                // the lanes
+                uint32_t E = 0, M = 0, maxcard = 2;
+                for (int64_t p = p0; p < p1; p++) {
+                    if (c.p_vid[p] < 0) continue;
+                    general_words(c.p_vid[p], &words);
+                    uint32_t ne = 0;
+                    for (size_t j = 0; j < words.size(); j += 2 + ((words[j + 1] >> 4) & 7u)) {
+                        ne++;
+                        M = std::max(M, (words[j + 1] >> 4) & 7u);
+                    }
+                    E = std::max(E, ne);
+                    maxcard = std::max(maxcard, (uint32_t)d->variable[c.p_vid[p]].cardinality);
+                }
+                // the walk is specialised on M and eats whole 16-byte chunks: E is a multiple of
+                // the entries per super-group (general_walk_m, nsk_kernels_gibbs.h)
+                const uint32_t EG = ((2 + M) % 4 == 0) ? 1u : ((2 + M) % 2 == 0) ? 2u : 4u;
+                E = (E + EG - 1) / EG * EG;
+                if (c.phase_ep[k]) {            // entry-parallel group layout: no per-tile stream
+                    ts.cls = 1; ts.nkey = 2; ts.key[0] = 0; ts.key[1] = M;
+                    ts.len = 0;
+                    ts.flags = (6u << 8) | (maxcard << 12) | (M << 16);
+                    continue;
+                }
+                ts.cls = 1; ts.nkey = 2; ts.key[0] = E; ts.key[1] = M;
+                ts.len = (int32_t)(E * (2 + M));
+                ts.flags = (uint32_t)ts.len | (6u << 8) | (maxcard << 12) | (M << 16);
+                if (nw * 8 > (4 << 20) && E > 0) { ts.flags |= 1u << 19; ts.nrows = E; }
+                continue;
+            }
+            int64_t len = 0;
+            bool uniform = true, have0 = false, same_shape = true;
+            bool binmem = true;                // every member the lanes read is a binary variable
+            // same shape: the lanes have the same number of entries and agree on which entries have members
+            // at all; an entry's member slots are the most any lane has there (lanes with fewer leave null
+            // words, NSK_SHAPE_NULL).  The classes of the position stage keep that padding small: exact
+            // shapes first, member counts rounded up to even for the rest.
+            uint32_t slots[32];
+            size_t nent = 0;
+            for (int64_t p = p0; p < p1; p++) {
+                if (c.p_vid[p] < 0) continue;                  // padding position
+                lane_words(c.p_vid[p], words);
+                for (size_t j = 0; j < words.size(); j += 1 + ((words[j] >> 24) & 7u))
+                    for (uint32_t m = 1; m <= ((words[j] >> 24) & 7u); m++)
+                        if (d->variable[words[j + m]].cardinality != 2) binmem = false;
+                len = std::max<int64_t>(len, (int64_t)words.size());
+                headers_of(words, have0 ? hdrs : hdrs0);
+                if (have0 && hdrs != hdrs0) {
+                    uniform = false;
+                    if (hdrs.size() != hdrs0.size()) same_shape = false;
+                }
+                {
+                    const std::vector<uint32_t> &hh = have0 ? hdrs : hdrs0;
+                    if (!have0) { nent = std::min<size_t>(hh.size(), 32); if (hh.size() > 32) same_shape = false; }
+                    for (size_t j = 0; j < nent && j < hh.size() && same_shape; j++) {
+                        const uint32_t no = (hh[j] >> 24) & 7u;
+                        if (!have0) slots[j] = no;
+                        else if ((no == 0) != (slots[j] == 0)) same_shape = false;
+                        else slots[j] = std::max(slots[j], no);
+                    }
+                }
+                have0 = true;
+            }
+            if (!have0) { hdrs0.clear(); uniform = false; same_shape = false; }
+            // (the last tile of a shape class, left with one or two lanes, is no uniform tile: a segment
+            //  launch of its own per such tile costs more than the shape walk of its lanes)
+            if (p0 >= shape_at[k] && p0 < shape_end[k] && same_shape) uniform = false;
+            // slot program of a uniform tile: one word per member slot (an entry without other
+            // members still gets one, ignored, slot):
+            //   weightId | code << 24 | first << 27 | last << 28 | ignore << 29 | weight fixed << 30
+            //   code: 0 NOOP, 1 IMPLY_NATURAL, 2 OR, 3 AND/ISTRUE, 4 EQUAL
+            int64_t nslots = 0;
+            for (uint32_t h : hdrs0) nslots += std::max<int64_t>(1, (h >> 24) & 7u);
+            ts.cls = 0; ts.len = (int32_t)len;
+            if (uniform && nslots <= 8 && p1 > p0) {
+                uint32_t n = 0;
+                for (uint32_t h : hdrs0) {
+                    const int fn = (int)(h >> 27) - 1;
+                    const uint32_t code = fn == 3 ? 4u : (fn == 2 || fn == 4) ? 3u : fn == 1 ? 2u : fn == 0 ? 1u : 0u;
+                    const uint32_t no = (h >> 24) & 7u, wid = h & 0xFFFFFFu;
+                    for (uint32_t m = 0; m < std::max(1u, no); m++)
+                        ts.key[n++] = wid | (code << 24) | ((m == 0 ? 1u : 0u) << 27) |
+                                      ((m + 1 >= no ? 1u : 0u) << 28) | ((no == 0 ? 1u : 0u) << 29) |
+                                      ((c.w_fixed[wid] ? 1u : 0u) << 30);
+                }
+                ts.nkey = (uint8_t)n;
+                // kind: every entry has exactly one other member and the same function code ->
+                // the kernel runs a specialised, table-free step (code in bits 8..10)
+                uint32_t kind = n == 0 ? 0u : (ts.key[0] >> 24) & 7u;
+                for (uint32_t j = 0; j < n; j++)
+                    if (((ts.key[j] >> 24) & 7u) != kind || ((ts.key[j] >> 27) & 7u) != 3u) kind = 0;   // first+last, not ignored
+                // bit 11: draw-table candidate (padding slots read the always-zero id and are masked off by nslots)
+                ts.cls = 2;
+                ts.flags = (uint32_t)nslots | (kind << 8) | ((binmem && !no_ztab) ? 1u << 11 : 0u);
+                ts.len = (int32_t)nslots;
+            } else if (same_shape && len > 0 && !no_shape && [&] {
+                           int64_t pl = 0;
+                           for (size_t j = 0; j < nent; j++) pl += 1 + (int64_t)slots[j];
+                           len = pl;                                   // (the padded length from here on)
+                           return pl <= shape_words; }()) {
+                // shape tile: per-lane headers (own function and weight) but one word layout for the
+                // 64 lanes.  Role program, one word per stream word: 1 header | 8 header of an
+                // entry without other members | 16 member | 2 first member | 4 last member; kind 7.
+                uint32_t n = 0;
+                for (size_t e = 0; e < nent; e++) {
+                    const uint32_t no = slots[e];
+                    ts.key[n++] = 1u | (no == 0 ? 8u : 0u) | 0x80000000u;   // bit 31 marks role words
+                    for (uint32_t m = 0; m < no; m++)
+                        ts.key[n++] = 16u | (m == 0 ? 2u : 0u) | (m + 1 == no ? 4u : 0u) | 0x80000000u;
+                }
+                ts.nkey = (uint8_t)n;
+                ts.cls = 3;
+                ts.len = (int32_t)len;
+                ts.flags = (uint32_t)len | (7u << 8);
+                ts.nrows = (uint32_t)hdrs0.size();
+            }
+        }
+    }, 64);
+    std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
+    std::vector<uint32_t> words, prog;
+    total4 = 0;                      // stream size in 16-byte units
+    const TileShape *last_ts = nullptr;
+    uint32_t last_prog = 0;
+    for (int64_t t = 0; t < nwb; t++) {
+        const TileShape &ts = shapes_of[t];
+        uint32_t *td = &c.tiles[4 * t];
+        int64_t len = ts.len;
+        td[2] = 0xFFFFFFFFu;
+        if (ts.cls != 0) {
+            if (last_ts && last_ts->cls == ts.cls && last_ts->nkey == ts.nkey &&
+                !memcmp(last_ts->key, ts.key, sizeof(uint32_t) * ts.nkey)) {
+                td[2] = last_prog;                              // same program as the previous tile
+            } else {
+                prog.clear();
+                if (ts.cls == 1) {
+                    // role program: 1 weight word | 32 descriptor word (8: no member slots) | 16 member
+                    // slot | 2 first slot | 4 last slot
+                    const uint32_t E = ts.key[0], M = ts.key[1];
+                    for (uint32_t e = 0; e < E; e++) {
+                        prog.push_back(1u | 0x80000000u);
+                        prog.push_back(32u | (M == 0 ? 8u : 0u) | 0x80000000u);
+                        for (uint32_t m = 0; m < M; m++)
+                            prog.push_back(16u | (m == 0 ? 2u : 0u) | (m + 1 == M ? 4u : 0u) | 0x80000000u);
+                    }
+                } else {
+                    prog.assign(ts.key, ts.key + ts.nkey);
+                }
+                auto it = hdr_pool.find(prog);
+                if (it == hdr_pool.end()) {
+                    it = hdr_pool.emplace(prog, (uint32_t)c.tile_hdr.size()).first;
+                    c.tile_hdr.insert(c.tile_hdr.end(), prog.begin(), prog.end());
+                    c.tile_hdr.resize((c.tile_hdr.size() + 7) / 8 * 8, 0u);   // pad: NOOP, weight 0
+                }
+                td[2] = it->second;
+                last_ts = &ts; last_prog = td[2];
+            }
+            td[3] = ts.flags;
+            if (ts.nrows) {
+                // a weight table beyond the L2 (general tiles) / per-lane weights (shape tiles):
+                // inference reads materialised weight rows, one coalesced row per entry
+                c.tile_wrow[t] = (uint32_t)c.nwrows;
+                c.nwrows += (int64_t)ts.nrows;
+                if (c.nwrows >= ((int64_t)1 << 31)) { err = "weight stream too large"; return NSK_E_RANGE; }
+            }
+        }
+        len = (len + 3) / 4 * 4;
+        td[0] = (uint32_t)total4;
+        td[1] = (uint32_t)len;
+        total4 += (uint64_t)(len / 4) * 64;
+        if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
+    }
+    return NSK_OK;
+}
+
 int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t nvar = d->nvar, nfac = d->nfactor, nedge = d->nedge, nw = d->nweight;
     const int64_t nvtf = d->nvtf, nfi = d->nfactor_index;
@@ -1966,209 +2184,10 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
                 out[at] = ((uint32_t)(fa.factorFunction + 1) << 27) | (others << 24) | slot_of_weight(fa.weightId);
             }
         };
-        auto headers_of = [&](const std::vector<uint32_t> &w, std::vector<uint32_t> &h) {
-            h.clear();
-            for (size_t j = 0; j < w.size(); j += 1 + ((w[j] >> 24) & 7u)) h.push_back(w[j]);
-        };
-        // pass 1: shape of every tile.  Uniform tile = all its lanes have the same header sequence.
-        // Phase A (parallel over tiles): classify the tile and reduce its program to a short key;
-        // phase B (sequential): pool the programs, assign stream offsets and weight rows.
-        struct TileShape {
-            uint8_t cls;            // 0 per-lane headers, 1 general, 2 uniform, 3 shape
-            uint8_t nkey;
-            int32_t len;            // words per lane before rounding to chunks
-            uint32_t flags;         // td[3]
-            uint32_t nrows;         // materialised weight rows the tile needs
-            uint32_t key[32];       // uniform / shape: the program words (NSK_SHAPE_WORDS); general: {E, M}
-        };
-        std::vector<TileShape> shapes_of((size_t)nwb);
-        std::vector<int32_t> tile_colour((size_t)nwb);
-        for (int32_t k = 0; k < ncolors; k++)
-            for (int64_t t = c.phase_wb_base[k]; t < c.phase_wb_base[k + 1]; t++) tile_colour[t] = k;
-        const bool no_shape = diag_env("NSK_NO_SHAPE") != nullptr, no_ztab = diag_env("NSK_NO_ZTAB") != nullptr;
-        parallel_for(nwb, [&](int64_t tb0, int64_t tb1, int) {
-            std::vector<uint32_t> words, hdrs, hdrs0;
-            for (int64_t t = tb0; t < tb1; t++) {
-                const int32_t k = tile_colour[t];
-                const int64_t b = t - c.phase_wb_base[k];
-                const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
-                TileShape &ts = shapes_of[t];
-                memset(&ts, 0, sizeof(ts));
-                bool gen_tile = false;                             // general tile (kind 6)
-                for (int64_t p = p0; p < p1 && !gen_tile; p++)
-                    if (c.p_vid[p] >= 0 && fast[c.p_vid[p]] == 2) gen_tile = true;
-                if (gen_tile) {
-                    // layout shared by the 64 lanes: E entries of 2 + M words, E and M the maxima over
-                    // the lanes
-                    uint32_t E = 0, M = 0, maxcard = 2;
-                    for (int64_t p = p0; p < p1; p++) {
-                        if (c.p_vid[p] < 0) continue;
-                        general_words(c.p_vid[p], &words);
-                        uint32_t ne = 0;
-                        for (size_t j = 0; j < words.size(); j += 2 + ((words[j + 1] >> 4) & 7u)) {
-                            ne++;
-                            M = std::max(M, (words[j + 1] >> 4) & 7u);
-                        }
-                        E = std::max(E, ne);
-                        maxcard = std::max(maxcard, (uint32_t)d->variable[c.p_vid[p]].cardinality);
-                    }
-                    // the walk is specialised on M and eats whole 16-byte chunks: E is a multiple of
-                    // the entries per super-group (general_walk_m, nsk_kernels_gibbs.h)
-                    const uint32_t EG = ((2 + M) % 4 == 0) ? 1u : ((2 + M) % 2 == 0) ? 2u : 4u;
-                    E = (E + EG - 1) / EG * EG;
-                    if (c.phase_ep[k]) {            // entry-parallel group layout: no per-tile stream
-                        ts.cls = 1; ts.nkey = 2; ts.key[0] = 0; ts.key[1] = M;
-                        ts.len = 0;
-                        ts.flags = (6u << 8) | (maxcard << 12) | (M << 16);
-                        continue;
-                    }
-                    ts.cls = 1; ts.nkey = 2; ts.key[0] = E; ts.key[1] = M;
-                    ts.len = (int32_t)(E * (2 + M));
-                    ts.flags = (uint32_t)ts.len | (6u << 8) | (maxcard << 12) | (M << 16);
-                    if (nw * 8 > (4 << 20) && E > 0) { ts.flags |= 1u << 19; ts.nrows = E; }
-                    continue;
-                }
-                int64_t len = 0;
-                bool uniform = true, have0 = false, same_shape = true;
-                bool binmem = true;                // every member the lanes read is a binary variable
-                // same shape: the lanes have the same number of entries and agree on which entries have members
-                // at all; an entry's member slots are the most any lane has there (lanes with fewer leave null
-                // words, NSK_SHAPE_NULL).  The classes of the position stage keep that padding small: exact
-                // shapes first, member counts rounded up to even for the rest.
-                uint32_t slots[32];
-                size_t nent = 0;
-                for (int64_t p = p0; p < p1; p++) {
-                    if (c.p_vid[p] < 0) continue;                  // padding position
-                    lane_words(c.p_vid[p], words);
-                    for (size_t j = 0; j < words.size(); j += 1 + ((words[j] >> 24) & 7u))
-                        for (uint32_t m = 1; m <= ((words[j] >> 24) & 7u); m++)
-                            if (d->variable[words[j + m]].cardinality != 2) binmem = false;
-                    len = std::max<int64_t>(len, (int64_t)words.size());
-                    headers_of(words, have0 ? hdrs : hdrs0);
-                    if (have0 && hdrs != hdrs0) {
-                        uniform = false;
-                        if (hdrs.size() != hdrs0.size()) same_shape = false;
-                    }
-                    {
-                        const std::vector<uint32_t> &hh = have0 ? hdrs : hdrs0;
-                        if (!have0) { nent = std::min<size_t>(hh.size(), 32); if (hh.size() > 32) same_shape = false; }
-                        for (size_t j = 0; j < nent && j < hh.size() && same_shape; j++) {
-                            const uint32_t no = (hh[j] >> 24) & 7u;
-                            if (!have0) slots[j] = no;
-                            else if ((no == 0) != (slots[j] == 0)) same_shape = false;
-                            else slots[j] = std::max(slots[j], no);
-                        }
-                    }
-                    have0 = true;
-                }
-                if (!have0) { hdrs0.clear(); uniform = false; same_shape = false; }
-                // (the last tile of a shape class, left with one or two lanes, is no uniform tile: a segment
-                //  launch of its own per such tile costs more than the shape walk of its lanes)
-                if (p0 >= shape_at[k] && p0 < shape_end[k] && same_shape) uniform = false;
-                // slot program of a uniform tile: one word per member slot (an entry without other
-                // members still gets one, ignored, slot):
-                //   weightId | code << 24 | first << 27 | last << 28 | ignore << 29 | weight fixed << 30
-                //   code: 0 NOOP, 1 IMPLY_NATURAL, 2 OR, 3 AND/ISTRUE, 4 EQUAL
-                int64_t nslots = 0;
-                for (uint32_t h : hdrs0) nslots += std::max<int64_t>(1, (h >> 24) & 7u);
-                ts.cls = 0; ts.len = (int32_t)len;
-                if (uniform && nslots <= 8 && p1 > p0) {
-                    uint32_t n = 0;
-                    for (uint32_t h : hdrs0) {
-                        const int fn = (int)(h >> 27) - 1;
-                        const uint32_t code = fn == 3 ? 4u : (fn == 2 || fn == 4) ? 3u : fn == 1 ? 2u : fn == 0 ? 1u : 0u;
-                        const uint32_t no = (h >> 24) & 7u, wid = h & 0xFFFFFFu;
-                        for (uint32_t m = 0; m < std::max(1u, no); m++)
-                            ts.key[n++] = wid | (code << 24) | ((m == 0 ? 1u : 0u) << 27) |
-                                          ((m + 1 >= no ? 1u : 0u) << 28) | ((no == 0 ? 1u : 0u) << 29) |
-                                          ((c.w_fixed[wid] ? 1u : 0u) << 30);
-                    }
-                    ts.nkey = (uint8_t)n;
-                    // kind: every entry has exactly one other member and the same function code ->
-                    // the kernel runs a specialised, table-free step (code in bits 8..10)
-                    uint32_t kind = n == 0 ? 0u : (ts.key[0] >> 24) & 7u;
-                    for (uint32_t j = 0; j < n; j++)
-                        if (((ts.key[j] >> 24) & 7u) != kind || ((ts.key[j] >> 27) & 7u) != 3u) kind = 0;   // first+last, not ignored
-                    // bit 11: draw-table candidate (padding slots read the always-zero id and are masked off by nslots)
-                    ts.cls = 2;
-                    ts.flags = (uint32_t)nslots | (kind << 8) | ((binmem && !no_ztab) ? 1u << 11 : 0u);
-                    ts.len = (int32_t)nslots;
-                } else if (same_shape && len > 0 && !no_shape && [&] {
-                               int64_t pl = 0;
-                               for (size_t j = 0; j < nent; j++) pl += 1 + (int64_t)slots[j];
-                               len = pl;                                   // (the padded length from here on)
-                               return pl <= shape_words; }()) {
-                    // shape tile: per-lane headers (own function and weight) but one word layout for the
-                    // 64 lanes.  Role program, one word per stream word: 1 header | 8 header of an
-                    // entry without other members | 16 member | 2 first member | 4 last member; kind 7.
-                    uint32_t n = 0;
-                    for (size_t e = 0; e < nent; e++) {
-                        const uint32_t no = slots[e];
-                        ts.key[n++] = 1u | (no == 0 ? 8u : 0u) | 0x80000000u;   // bit 31 marks role words
-                        for (uint32_t m = 0; m < no; m++)
-                            ts.key[n++] = 16u | (m == 0 ? 2u : 0u) | (m + 1 == no ? 4u : 0u) | 0x80000000u;
-                    }
-                    ts.nkey = (uint8_t)n;
-                    ts.cls = 3;
-                    ts.len = (int32_t)len;
-                    ts.flags = (uint32_t)len | (7u << 8);
-                    ts.nrows = (uint32_t)hdrs0.size();
-                }
-            }
-        }, 64);
-        std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
-        std::vector<uint32_t> words, prog;
-        uint64_t total4 = 0;                      // stream size in 16-byte units
-        const TileShape *last_ts = nullptr;
-        uint32_t last_prog = 0;
-        for (int64_t t = 0; t < nwb; t++) {
-            const TileShape &ts = shapes_of[t];
-            uint32_t *td = &c.tiles[4 * t];
-            int64_t len = ts.len;
-            td[2] = 0xFFFFFFFFu;
-            if (ts.cls != 0) {
-                if (last_ts && last_ts->cls == ts.cls && last_ts->nkey == ts.nkey &&
-                    !memcmp(last_ts->key, ts.key, sizeof(uint32_t) * ts.nkey)) {
-                    td[2] = last_prog;                              // same program as the previous tile
-                } else {
-                    prog.clear();
-                    if (ts.cls == 1) {
-                        // role program: 1 weight word | 32 descriptor word (8: no member slots) | 16 member
-                        // slot | 2 first slot | 4 last slot
-                        const uint32_t E = ts.key[0], M = ts.key[1];
-                        for (uint32_t e = 0; e < E; e++) {
-                            prog.push_back(1u | 0x80000000u);
-                            prog.push_back(32u | (M == 0 ? 8u : 0u) | 0x80000000u);
-                            for (uint32_t m = 0; m < M; m++)
-                                prog.push_back(16u | (m == 0 ? 2u : 0u) | (m + 1 == M ? 4u : 0u) | 0x80000000u);
-                        }
-                    } else {
-                        prog.assign(ts.key, ts.key + ts.nkey);
-                    }
-                    auto it = hdr_pool.find(prog);
-                    if (it == hdr_pool.end()) {
-                        it = hdr_pool.emplace(prog, (uint32_t)c.tile_hdr.size()).first;
-                        c.tile_hdr.insert(c.tile_hdr.end(), prog.begin(), prog.end());
-                        c.tile_hdr.resize((c.tile_hdr.size() + 7) / 8 * 8, 0u);   // pad: NOOP, weight 0
-                    }
-                    td[2] = it->second;
-                    last_ts = &ts; last_prog = td[2];
-                }
-                td[3] = ts.flags;
-                if (ts.nrows) {
-                    // a weight table beyond the L2 (general tiles) / per-lane weights (shape tiles):
-                    // inference reads materialised weight rows, one coalesced row per entry
-                    c.tile_wrow[t] = (uint32_t)c.nwrows;
-                    c.nwrows += (int64_t)ts.nrows;
-                    if (c.nwrows >= ((int64_t)1 << 31)) { err = "weight stream too large"; return NSK_E_RANGE; }
-                }
-            }
-            len = (len + 3) / 4 * 4;
-            td[0] = (uint32_t)total4;
-            td[1] = (uint32_t)len;
-            total4 += (uint64_t)(len / 4) * 64;
-            if (total4 >= ((uint64_t)1 << 31)) { err = "adjacency stream too large"; return NSK_E_RANGE; }
-        }
+        std::vector<int32_t> tile_colour;
+        uint64_t total4 = 0;
+        if (int trc = shape_tiles(d, c, ncolors, nwb, general_words, lane_words, shape_at, shape_end, shape_words, fast, tile_colour, total4, err))
+            return trc;
         lap("tile shapes (pass 1)");
         c.tile_hdr.resize(c.tile_hdr.size() + 8, 0u);
         find_direct_weights(d, c, nwb, verbose);
