@@ -164,6 +164,8 @@ typedef struct {
     int64_t direct_weights;           /* weights with a single factor that the learning kernels update in
                                          place at their one visit per class (no accumulator, no update
                                          launch for them); 0: none                                 */
+    int64_t weight_slots;             /* 1: the device table keeps the single-factor weights in layout order
+                                         (nsk_graph_get_weight_slots is not the identity); 0: caller's order */
     int64_t layout_hash;              /* with NSK_LAYOUT_HASH=1 in the environment: a 64-bit hash of every
                                          array of the compiled layout (colours, positions, tile and group
                                          streams, programs, weight slots ...) -- what a check that two builds /

@@ -700,6 +700,7 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->acc_copies = 0;
     info->learn_lag = (c.nweight > 0 && c.nweight <= NSK_SMALLW) ? 1 : 0;
     info->direct_weights = c.ndirect;
+    info->weight_slots = c.wmap.empty() ? 0 : 1;
     info->layout_hash = getenv("NSK_LAYOUT_HASH") ? layout_hash(c) : 0;
 }
 

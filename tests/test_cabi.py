@@ -357,3 +357,19 @@ def test_graph_compiler_is_independent_of_the_thread_count():
     assert outs[0]["boolw"][1]["direct_weights"] > 0 and outs[0]["lr"][1]["ncolors"] >= 2
     assert all(outs[0][k][1]["layout_hash"] != 0 for k in outs[0])        # every array of the layout, hashed
     assert len({outs[0][k][1]["layout_hash"] for k in outs[0]}) == 3
+
+
+def test_weight_slots_only_on_whole_graph_handles_with_single_factor_weights():
+    """Single-factor weights get slots in layout order (nsk_graph_info.weight_slots) on a handle that owns the
+    whole graph; a handle that samples a range keeps the caller's numbering (the ranks of a distributed run add
+    their weight tables element by element), and so does a graph whose weights are shared."""
+    bw = list(graphgen.boolean_weighted_graph(20000, seed=2))
+    bw[0]["isFixed"] = False
+    whole = session(tuple(bw))[1].plan()[1]
+    assert whole["direct_weights"] > 0 and whole["weight_slots"] == 1
+    ns = numbskull_amd.NumbSkull(quiet=True)
+    ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in bw[:5]], int(bw[5]), own_range=(0, 10000))
+    part = ns.factorGraphs[0].plan()[1]
+    assert part["direct_weights"] > 0 and part["weight_slots"] == 0
+    lr = session(graphgen.mixed_lr_graph(20000, seed=3, nweights=500), head_by_vid=True)[1].plan()[1]
+    assert lr["direct_weights"] == 0 and lr["weight_slots"] == 0
