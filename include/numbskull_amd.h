@@ -116,9 +116,9 @@ int nsk_set_scan(nsk_graph *g, int scan);
  * step = cap / k in that class (same fixed point).  Default 0.5; cap <= 0 switches clipping off.
  * nsk_graph_info.learn_clipped counts the clipped updates. */
 int nsk_set_learn_cap(nsk_graph *g, double cap);
-/* Chromatic learning, one-class lag (default on): the weight update of colour class c runs on a second
- * stream beside the sampling of class c + 1, which therefore sees the weights as of the end of class
- * c - 1 -- milder than the staleness of the reference's own Hogwild threads and of its distributed merge
+/* Chromatic learning, one-class lag (default on): the weight update of colour class c is applied beside
+ * the sampling of class c + 1 (it rides in block 0 of that class's launch), which therefore sees the weights
+ * as of the end of class c - 1 -- milder than the staleness of the reference's own Hogwild threads and of its distributed merge
  * (one epoch, salt/src/numbskull_master.py:223-224).  The pipeline is drained at the end of every
  * nsk_learn_sweeps call (the weights it leaves include every update).  It applies to handles with at most
  * 256 weights (they accumulate in LDS and the update rides in the next class's launch: the grids); with a

@@ -73,7 +73,11 @@ def lib():
             if not hasattr(L, name):
                 if not os.environ.get("NSK_LIB"):      # (an older ablation build under NSK_LIB may lack newer entry points)
                     raise AttributeError("libnumbskull_amd.so lacks %s: header and library disagree" % name)
-                setattr(L, name, lambda *a: 0)
+                # a call of a missing entry point FAILS (it used to report success: an A/B run against
+                # an older build then compared different semantics without saying so)
+                def missing(*a, _name=name):
+                    raise AttributeError("%s lacks %s (an older build under NSK_LIB)" % (LIB_PATH, _name))
+                setattr(L, name, missing)
         L.nsk_gibbs_sweeps.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.nsk_learn_sweeps.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int,
                                        C.c_double, C.c_int64, C.c_int]

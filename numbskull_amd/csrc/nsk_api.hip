@@ -647,7 +647,16 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
         if (!done && nc)
             HIPCHECK(hipMemcpyAsync(count, g->cnt_total, (size_t)nc * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
     }
+    // a peer-to-peer exchange that timed out since the last check left ghost values (and merged weights)
+    // incomplete: the state handed back is then not a result -- say so here too, not only in nsk_p2p_check
+    unsigned int p2p_err = 0;
+    if (g->p2p_err) HIPCHECK(hipMemcpyAsync(&p2p_err, g->p2p_err, sizeof(p2p_err), hipMemcpyDeviceToHost, g->stream));
     HIPCHECK(hipStreamSynchronize(g->stream));
+    if (p2p_err) {
+        HIPCHECK(hipMemsetAsync(g->p2p_err, 0, sizeof(unsigned int), g->stream));          // reported once
+        return fail(NSK_E_DEVICE, "peer-to-peer exchange: a peer's boundary values did not arrive within "
+                                  "NSK_P2P_TIMEOUT_S; the downloaded state is incomplete");
+    }
     return NSK_OK;
 }
 

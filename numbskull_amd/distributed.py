@@ -294,6 +294,7 @@ class PartitionedSampler(object):
             _lib.check(self.L.nsk_gibbs_sweeps(self.h, nsweeps, int(sample_evidence), int(burnin)))
         elif self.p2p:
             _lib.check(self.L.nsk_gibbs_sweeps_p2p(self.h, nsweeps, int(sample_evidence), int(burnin)))
+            self.check()        # (one stream synchronisation per call: a timed-out peer raises here, not later)
         elif self.native:
             _lib.check(self.L.nsk_gibbs_sweeps_exchange(self.h, nsweeps, int(sample_evidence), int(burnin)))
         else:
@@ -350,6 +351,7 @@ class PartitionedSampler(object):
             _lib.check(self.L.nsk_learn_sweeps(self.h, nsweeps, float(step), float(decay), *args))
         elif self.p2p:
             _lib.check(self.L.nsk_learn_sweeps_p2p(self.h, nsweeps, float(step), float(decay), *args))
+            self.check()
         elif self.native:
             _lib.check(self.L.nsk_learn_sweeps_exchange(self.h, nsweeps, float(step), float(decay), *args))
         else:

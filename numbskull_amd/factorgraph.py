@@ -220,13 +220,17 @@ class FactorGraph(object):
         """Download state into the arrays the caller sees.  Straight into their memory when it is a
         C-contiguous array of the right type (the usual case: rows of ``var_value`` etc.) -- a fresh
         buffer per call costs more in page faults than the transfer itself (240 MB at 10M variables)."""
-        def target(a, dtype):
-            ok = isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.c_contiguous and a.flags.writeable
-            return (a, None) if ok else (np.empty(a.shape, dtype), a)
-        vv, vv_to = target(self.var_value[var_copy], np.int64) if values else (None, None)
-        ve, ve_to = target(self.var_value_evid[var_copy], np.int64) if values else (None, None)
-        wv, wv_to = target(self.weight_value[weight_copy], np.float64) if weights else (None, None)
-        cnt, cnt_to = target(self.count, np.int64) if count else (None, None)
+        def target(a, dtype, n):
+            # (the library writes n elements: an array the caller replaced by a shorter one takes the
+            # temporary buffer and fails in the assignment below, as it did in the reference)
+            ok = (isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.c_contiguous and a.flags.writeable
+                  and a.shape == (n,))
+            return (a, None) if ok else (np.empty(n, dtype), a)
+        nv, nw, nc = self.variable.shape[0], self.weight.shape[0], int(self.cstart[-1]) if len(self.cstart) else 0
+        vv, vv_to = target(self.var_value[var_copy], np.int64, nv) if values else (None, None)
+        ve, ve_to = target(self.var_value_evid[var_copy], np.int64, nv) if values else (None, None)
+        wv, wv_to = target(self.weight_value[weight_copy], np.float64, nw) if weights else (None, None)
+        cnt, cnt_to = target(self.count, np.int64, nc) if count else (None, None)
         _lib.check(_lib.lib().nsk_state_download(self._engine(), _lib.ptr(vv), _lib.ptr(ve),
                                                  _lib.ptr(wv), _lib.ptr(cnt)))
         for buf, to in ((vv, vv_to), (ve, ve_to), (wv, wv_to), (cnt, cnt_to)):

@@ -72,8 +72,9 @@ for WL in ${NSK_PROFILE_BENCH_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr
 done
 for WL in ${NSK_PROFILE_BENCH_ONLY:-ising40m ising100m lr50m lr50m_learn}; do
   NSK_VERBOSE=1 python bench.py --workload $WL --steps 10 --warmup 3 --no-extra > $OUT/${RT}_${WL}_bench.json 2> $OUT/${RT}_${WL}_bench.err
+  rc=$?
   grep "compile " $OUT/${RT}_${WL}_bench.err > $OUT/${RT}_${WL}_compile_laps.txt
-  echo "bench $WL rc $?"
+  echo "bench $WL rc $rc"
 done
 [ -z "$NSK_PROFILE_SKIP_DEFAULT" ] && NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_bench.json 2>/dev/null
 [ -z "$NSK_PROFILE_SKIP_DEFAULT" ] && NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload lr5m_learn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_lr5m_learn_bench.json 2>/dev/null
