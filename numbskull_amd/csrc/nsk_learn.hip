@@ -25,9 +25,36 @@ static void refresh_after_update(nsk_graph *g, int set, hipStream_t st) {
     }
 }
 
+// The chromatic learning sweep is instantiated four times (value type x accumulator flavour) and every
+// instantiation carries a dozen kernels: the Makefile compiles this file once per instantiation
+// (-DNSK_LEARN_PART=0..3, in parallel; part 0 also holds the entry point) -- one translation unit with all four
+// (NSK_LEARN_PART undefined: the ablation builds) takes six minutes.
+#ifndef NSK_LEARN_PART
+#define NSK_LEARN_PART -1
+#endif
+#define NSK_LEARN_HAS(P) (NSK_LEARN_PART == -1 || NSK_LEARN_PART == (P))
+#define NSK_LEARN_SIG nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization, \
+                      double reg_param, int64_t truncation, int learn_non_evidence
 template <typename VT, bool SMALLW>
-static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
-                           double reg_param, int64_t truncation, int learn_non_evidence) {
+int nsk_learn_chromatic(NSK_LEARN_SIG);
+#if NSK_LEARN_PART != -1        // the instantiations of the other parts are theirs
+#if !NSK_LEARN_HAS(0)
+extern template int nsk_learn_chromatic<int8_t, false>(NSK_LEARN_SIG);
+#endif
+#if !NSK_LEARN_HAS(1)
+extern template int nsk_learn_chromatic<int8_t, true>(NSK_LEARN_SIG);
+#endif
+#if !NSK_LEARN_HAS(2)
+extern template int nsk_learn_chromatic<int32_t, false>(NSK_LEARN_SIG);
+#endif
+#if !NSK_LEARN_HAS(3)
+extern template int nsk_learn_chromatic<int32_t, true>(NSK_LEARN_SIG);
+#endif
+#endif
+
+template <typename VT, bool SMALLW>
+int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
+                        double reg_param, int64_t truncation, int learn_non_evidence) {
     const size_t nphase = g->c.phase_start.size() - 1;
     const int nw = (int)g->c.nweight;
     const size_t shmem = SMALLW ? (size_t)nw * 16 : 0;
@@ -281,6 +308,22 @@ static int learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double de
     return NSK_OK;
 }
 
+#if NSK_LEARN_PART != -1
+#if NSK_LEARN_HAS(0)
+template int nsk_learn_chromatic<int8_t, false>(NSK_LEARN_SIG);
+#endif
+#if NSK_LEARN_HAS(1)
+template int nsk_learn_chromatic<int8_t, true>(NSK_LEARN_SIG);
+#endif
+#if NSK_LEARN_HAS(2)
+template int nsk_learn_chromatic<int32_t, false>(NSK_LEARN_SIG);
+#endif
+#if NSK_LEARN_HAS(3)
+template int nsk_learn_chromatic<int32_t, true>(NSK_LEARN_SIG);
+#endif
+#endif
+
+#if NSK_LEARN_PART <= 0         // the sequential validation scan and the entry point
 template <typename VT>
 static int learn_impl(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
                       double reg_param, int64_t truncation, int learn_non_evidence) {
@@ -293,10 +336,10 @@ static int learn_impl(nsk_graph *g, int64_t nsweeps, double step, double decay, 
         g->launches++;
         g->sweep += (uint64_t)nsweeps;
     } else {
-        int rc = g->smallw ? learn_chromatic<VT, true>(g, nsweeps, step, decay, regularization, reg_param,
-                                                       truncation, learn_non_evidence)
-                           : learn_chromatic<VT, false>(g, nsweeps, step, decay, regularization, reg_param,
-                                                        truncation, learn_non_evidence);
+        int rc = g->smallw ? nsk_learn_chromatic<VT, true>(g, nsweeps, step, decay, regularization, reg_param,
+                                                           truncation, learn_non_evidence)
+                           : nsk_learn_chromatic<VT, false>(g, nsweeps, step, decay, regularization, reg_param,
+                                                            truncation, learn_non_evidence);
         if (rc) return rc;
     }
     g->sweeps_done += nsweeps;
@@ -320,3 +363,4 @@ extern "C" int nsk_learn_sweeps(nsk_graph *g, int64_t nsweeps, double step, doub
                ? learn_impl<int8_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence)
                : learn_impl<int32_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence);
 }
+#endif
