@@ -261,9 +261,12 @@ int nsk_synchronize(nsk_graph *g);
  * the boundary values each peer reads straight into that peer's buffer (device memory the peer exposes
  * with hipIpc; over xGMI between GPUs) and raises a flag there; a rank waits for the flags of its peers
  * and scatters their values -- no collective, no host round trip per sweep (the reference's per-epoch
- * owner -> replica copy, salt/src/numbskull_master.py:165-224).  Learning epochs send both chains and the
- * epoch's weight deltas the same way and merge them as w = w_start + (d_0 + d_1 + ...) in rank order on
- * every rank (the master's rule, numbskull_master.py:223-224; minions' deltas numbskull_minion.py:260-280).
+ * owner -> replica copy, salt/src/numbskull_master.py:165-224).  Learning epochs send both chains the same
+ * way and merge the epoch's weight deltas as w = w_start + (d_0 + d_1 + ...) in rank order (the master's
+ * rule, numbskull_master.py:223-224; minions' deltas numbskull_minion.py:260-280) by reduce-scatter +
+ * all-gather over the same buffers: rank q owns slice [q nw / W, (q + 1) nw / W) of the weight vector, every
+ * rank writes slice q of its deltas to rank q only, the owner adds them in rank order and writes the merged
+ * slice to every rank -- one owner per weight, so all ranks end up with bit-identical weights.
  *   nsk_p2p_setup   PAIRWISE lists: send_vids[send_off[q] .. send_off[q+1]) = the owned variables rank q
  *                   reads, recv_vids[recv_off[q] ..) = the variables this handle reads from rank q, both in
  *                   the order the two sides agreed on (ascending global id); peer_base[q] = where this
@@ -276,9 +279,16 @@ int nsk_synchronize(nsk_graph *g);
  *   nsk_gibbs_sweeps_p2p / nsk_learn_sweeps_p2p  `nsweeps` x (sweep, push to peers, wait + unpack [+ weight
  *                   merge]) enqueued on the library's stream; asynchronous like nsk_gibbs_sweeps
  *   nsk_p2p_exchange  one exchange alone (learn != 0: both chains + weight deltas); part 0 = all of it,
- *                   1 = the pushes, 2 = flags + wait + unpack (set-up self-test, phase timings)
+ *                   1 = the pushes, 2 = wait + unpack (+ the owner's half of the weight merge), 3 = the closing
+ *                   half of the weight merge (phase timings; several handles driven by one process issue the
+ *                   parts breadth-first)
+ *   nsk_p2p_selftest  the same kernels with a payload pattern that depends on sender, element, exchange and
+ *                   chain instead of the state, compared on the receiving side instead of stored (state and
+ *                   weights are left alone): checks that peer WRITES are visible, not only the flags; a
+ *                   mismatch is reported by nsk_p2p_check.  Same `learn` / `part` arguments
  *   nsk_p2p_check   synchronises and returns NSK_E_DEVICE when a peer's flag did not arrive within
- *                   NSK_P2P_TIMEOUT_S seconds (default 30) in any exchange since the last check */
+ *                   NSK_P2P_TIMEOUT_S seconds (default 30), or a self-test payload differed, since the last
+ *                   check (nsk_state_download reports a time-out too) */
 int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, const int64_t *send_off,
                   const int32_t *recv_vids, const int64_t *recv_off, const int64_t *peer_base,
                   const int64_t *peer_total);
@@ -289,6 +299,7 @@ int nsk_gibbs_sweeps_p2p(nsk_graph *g, int64_t nsweeps, int sample_evidence, int
 int nsk_learn_sweeps_p2p(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
                          double reg_param, int64_t truncation, int learn_non_evidence);
 int nsk_p2p_exchange(nsk_graph *g, int learn, int part);
+int nsk_p2p_selftest(nsk_graph *g, int learn, int part);
 int nsk_p2p_check(nsk_graph *g);
 
 /* ---- host-side index build and file parsing (no GPU needed) ---- */

@@ -1020,6 +1020,7 @@ int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, c
     g->p2p_ready = false;
     g->pworld = world; g->prank = rank; g->p_nsend = nsend; g->p_nrecv = nrecv;
     g->p_soff.assign(send_off, send_off + world + 1);
+    g->p_roff.assign(recv_off, recv_off + world + 1);
     g->p_dbase.assign(peer_base, peer_base + world);
     g->p_dtotal.assign(peer_total, peer_total + world);
     g->p2p_peer_mask = 0;
@@ -1033,8 +1034,8 @@ int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, c
         if ((rc = dev_alloc(g, &g->w_delta, (size_t)g->c.nweight))) return rc;
     }
     if (!g->p2p_err) {
-        if ((rc = dev_alloc(g, &g->p2p_err, 2))) return rc;          // [0] time-out mark, [1] the push kernel's ticket
-        HIPCHECK(hipMemsetAsync(g->p2p_err, 0, 2 * sizeof(unsigned int), g->stream));
+        if ((rc = dev_alloc(g, &g->p2p_err, 4))) return rc;          // [0] error mark, [1] [2] the kernels' tickets
+        HIPCHECK(hipMemsetAsync(g->p2p_err, 0, 4 * sizeof(unsigned int), g->stream));
     }
     if (const char *t = getenv("NSK_P2P_TIMEOUT_S")) {
         const double sec = atof(t);
@@ -1057,7 +1058,7 @@ int nsk_p2p_export(nsk_graph *g, void *handle64, void **base) {
     if (g->pworld == 0) return fail(NSK_E_INVALID, "nsk_p2p_setup has not been called");
     HIPCHECK(hipSetDevice(g->device));
     const size_t vb = (size_t)g->c.vbytes, nw = (size_t)g->c.nweight;
-    const size_t bytes = nsk_p2p_wbuf_off(g->pworld, (size_t)g->p_nrecv, vb) + 2 * (size_t)g->pworld * nw * sizeof(double) + 256;
+    const size_t bytes = nsk_p2p_bytes(g->pworld, (size_t)g->p_nrecv, vb, nw);
     if (g->p2p_base && g->p2p_bytes < bytes) {          // a later set-up with longer lists: a new allocation
         HIPCHECK(hipStreamSynchronize(g->stream));
         g->allocs.erase(std::remove(g->allocs.begin(), g->allocs.end(), g->p2p_base), g->allocs.end());
@@ -1073,7 +1074,7 @@ int nsk_p2p_export(nsk_graph *g, void *handle64, void **base) {
         g->device_bytes += (int64_t)bytes;
     }
     HIPCHECK(hipMemsetAsync(g->p2p_base, 0, g->p2p_bytes, g->stream));
-    HIPCHECK(hipMemsetAsync(g->p2p_err, 0, 2 * sizeof(unsigned int), g->stream));
+    HIPCHECK(hipMemsetAsync(g->p2p_err, 0, 4 * sizeof(unsigned int), g->stream));
     HIPCHECK(hipStreamSynchronize(g->stream));
     g->p2p_tag = 0;
     g->p2p_ready = false;
@@ -1126,67 +1127,59 @@ int nsk_p2p_import_local(nsk_graph *g, void *const *bases) {
 
 }  // extern "C"
 
+// part 0 = one whole exchange (the sweep loops); 1 = the pushes, 2 = wait + unpack (+ the owner's half of the
+// weight merge), 3 = the closing half of the weight merge -- the parts on their own serve the tests that drive
+// several handles from one process (issued breadth-first) and the phase timings
 template <typename VT>
-static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off, bool learn, int part) {
+static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off, bool learn, int part, int selftest = 0) {
     const int world = g->pworld, me = g->prank;
-    const size_t vb = (size_t)g->c.vbytes;
     const int nw = (int)g->c.nweight;
-    if (part != 2 && !tag_base) ++g->p2p_tag;
+    if ((part == 0 || part == 1) && !tag_base) ++g->p2p_tag;
     const unsigned int tag = tag_base ? tag_off : g->p2p_tag;
+    const bool weights = learn && nw > 0 && world > 1;
     // a learning epoch's weight deltas go to every rank, so every rank is a peer of every other
-    const unsigned int mask = (learn && nw > 0 && world > 1) ? (((1u << world) - 1u) & ~(1u << me)) : g->p2p_peer_mask;
+    const unsigned int mask = weights ? (((1u << world) - 1u) & ~(1u << me)) : g->p2p_peer_mask;
+    if (!mask) return NSK_OK;
     P2PPlan plan;
     memset(&plan, 0, sizeof(plan));
     for (int q = 0; q < world; q++) {
         plan.base[q] = g->p2p_peer_base[q];
         plan.soff[q] = (unsigned long long)g->p_soff[q];
+        plan.roff[q] = (unsigned long long)g->p_roff[q];
         plan.dbase[q] = (unsigned long long)g->p_dbase[q];
         plan.dtotal[q] = (unsigned long long)g->p_dtotal[q];
     }
-    for (int q = world; q <= 16; q++) plan.soff[q] = (unsigned long long)g->p_nsend;
-    auto push_dw = [&]() {                      // a learning epoch's weight deltas, before the flags go up
-        P2PWeights pw;
-        memset(&pw, 0, sizeof(pw));
-        for (int q = 0; q < world; q++)
-            pw.wbuf[q] = (double *)((char *)g->p2p_peer_base[q] + nsk_p2p_wbuf_off(world, (size_t)g->p_dtotal[q], vb));
+    for (int q = world; q <= 16; q++) { plan.soff[q] = (unsigned long long)g->p_nsend; plan.roff[q] = (unsigned long long)g->p_nrecv; }
+    P2PWeights pw;
+    pw.w = weights ? g->w : nullptr; pw.w_start = weights ? g->w_start : nullptr; pw.nw = weights ? nw : 0; pw.pad_ = 0;
+    const int64_t wwork = weights ? ((int64_t)nw + 3) / 4 : 0;          // (a block's threads take a few weights each)
+    auto blocks = [&](int64_t work) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, (work + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK))); };
+    auto gather = [&]() {
+        if (!weights) return;
         const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
-        k_p2p_push_dw<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, pw, world, me, nw, tag);
+        k_p2p_gather_w<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, nw, g->p2p_base, (long long)g->p_nrecv, world,
+                                                                       mask, tag, g->p2p_err, g->p2p_timeout_ticks, selftest);
+        if (!selftest) g->weights_dirty = true;
     };
-    auto merge_w = [&]() {
-        const double *wb = (const double *)((const char *)g->p2p_base + nsk_p2p_wbuf_off(world, (size_t)g->p_nrecv, vb));
-        const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
-        k_p2p_merge_w<<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, wb, world, nw, tag);
-        g->weights_dirty = true;
-    };
-    if (part == 0 && mask) {                    // the sweep loops: push, flags, wait and unpack in one launch
-        if (learn && nw > 0) push_dw();
-        const int64_t work = std::max(g->p_nsend, g->p_nrecv);
-        const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (work + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK)));
-        k_p2p_exchange<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
-            (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->p_send_iid, (long long)g->p_nsend, plan, g->p_recv_iid,
-            (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks);
-        if (learn && nw > 0) merge_w();
-        HIPCHECK(hipGetLastError());
-        return NSK_OK;
-    }
-    if (part != 2) {                            // (the parts on their own: tests with several handles in one process, phase timings)
-        if (learn && nw > 0) push_dw();
-        if (mask) {
-            // at most 64 blocks (grid-stride): the closing ticket adds must not queue up
-            const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (g->p_nsend + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK)));
-            k_p2p_push<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const VT *)g->val, learn ? (const VT *)g->val_evid : nullptr,
-                                                                       g->p_send_iid, (long long)g->p_nsend, plan, world, me, mask,
-                                                                       g->p2p_err + 1, tag, tag_base);
-        }
-    }
-    if (part != 1) {
-        if (mask) {
-            const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (g->p_nrecv + NSK_BLOCK - 1) / NSK_BLOCK));
-            k_p2p_wait_unpack<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
-                (VT *)g->val, learn ? (VT *)g->val_evid : nullptr, g->p_recv_iid, (long long)g->p_nrecv, g->p2p_base, world,
-                mask, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks);
-        }
-        if (learn && nw > 0) merge_w();
+    if (part == 0) {                            // the sweep loops: push, flags, wait and unpack in one launch
+        const int nb = blocks(std::max(std::max(g->p_nsend, g->p_nrecv), wwork));
+        k_p2p_exchange<VT, true><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
+            (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->p_send_iid, (long long)g->p_nsend, plan, pw, g->p_recv_iid,
+            (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks, selftest);
+        gather();
+    } else if (part == 1) {
+        // at most 64 blocks (grid-stride): the closing ticket adds must not queue up
+        const int nb = blocks(std::max(g->p_nsend, wwork));
+        k_p2p_push<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const VT *)g->val, (const VT *)g->val_evid, learn ? 1 : 0,
+                                                                   g->p_send_iid, (long long)g->p_nsend, plan, pw, world, me, mask,
+                                                                   g->p2p_err + 1, tag, tag_base, selftest);
+    } else if (part == 2) {
+        const int nb = blocks(std::max(g->p_nrecv, wwork));
+        k_p2p_exchange<VT, false><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
+            (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->p_send_iid, (long long)g->p_nsend, plan, pw, g->p_recv_iid,
+            (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks, selftest);
+    } else {
+        gather();
     }
     HIPCHECK(hipGetLastError());
     return NSK_OK;
@@ -1208,16 +1201,28 @@ int nsk_p2p_check(nsk_graph *g) {
     HIPCHECK(hipStreamSynchronize(g->stream));
     if (err) {
         HIPCHECK(hipMemsetAsync(g->p2p_err, 0, sizeof(unsigned int), g->stream));      // reported once
+        if (err & NSK_P2P_ERR_PAYLOAD)
+            return fail(NSK_E_DEVICE, "peer-to-peer self-test: a peer's flag arrived but the payload read back differs from "
+                                      "what the peer wrote (peer writes are not visible to this device's kernels)");
         return fail(NSK_E_DEVICE, "peer-to-peer exchange: a peer's boundary values did not arrive within "
                                   "NSK_P2P_TIMEOUT_S; the ghost values of this handle are incomplete");
     }
     return NSK_OK;
 }
 
+int nsk_p2p_selftest(nsk_graph *g, int learn, int part) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
+    if (part < 0 || part > 3) return fail(NSK_E_INVALID, "bad part");
+    HIPCHECK(hipSetDevice(g->device));
+    return g->c.vbytes == 1 ? p2p_exchange<int8_t>(g, nullptr, 0, learn != 0, part, 1)
+                            : p2p_exchange<int32_t>(g, nullptr, 0, learn != 0, part, 1);
+}
+
 int nsk_p2p_exchange(nsk_graph *g, int learn, int part) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
-    if (part < 0 || part > 2) return fail(NSK_E_INVALID, "bad part");
+    if (part < 0 || part > 3) return fail(NSK_E_INVALID, "bad part");
     HIPCHECK(hipSetDevice(g->device));
     return nsk_p2p_enqueue(g, nullptr, 0, learn != 0, part);
 }

@@ -121,7 +121,7 @@ struct nsk_graph {
     // peers' mappings of theirs, the exchange counter
     int pworld = 0, prank = 0;
     int64_t p_nsend = 0, p_nrecv = 0;
-    std::vector<int64_t> p_soff, p_dbase, p_dtotal;
+    std::vector<int64_t> p_soff, p_roff, p_dbase, p_dtotal;
     int32_t *p_send_iid = nullptr, *p_recv_iid = nullptr;
     void *p2p_base = nullptr;
     size_t p2p_bytes = 0;
@@ -260,7 +260,8 @@ int nsk_ensure_lag_sets(nsk_graph *g);                 // second set of weights 
 #define NSK_GRAPH_SWEEPS 16
 // one peer-to-peer exchange on the library's stream; tag_base != null: a captured launch whose tag is
 // the device counter + tag_off; learn: both chains + the weight deltas; part 0 = all of it, 1 = the
-// pushes only, 2 = flags + wait + unpack (+ weight merge) only (nsk_api.hip)
+// pushes only, 2 = wait + unpack (+ the owner's half of the weight merge), 3 = the closing half of the
+// weight merge (nsk_api.hip)
 int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off, bool learn = false, int part = 0);
 void nsk_drop_sweep_graph(nsk_graph *g);            // the captured sweep sequence bakes exchange pointers: drop it when they change
 int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p);   // nsk_gibbs.hip

@@ -82,183 +82,240 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_exchange_unpack(VT *val, const in
 // ---- peer-to-peer boundary exchange (one node: xGMI between GPUs / one device shared by ranks) ------
 // Every rank owns ONE fine-grained allocation its peers have mapped (hipIpc, or plain pointers when the
 // ranks live in one process):
-//     flags[2][world]                     tag of the last exchange rank q completed towards this rank
+//     flags[2][2][world]                  per parity: [0] tag of the last exchange whose VALUES (and weight-delta
+//                                         slices) rank q has written here, [1] ... whose MERGED weight slice
 //     recv[2][2][nrecv]                   per parity, per chain (var_value, var_value_evid): the values this
 //                                         rank reads from others, segment of source q at roff[q]
-//     wbuf[2][world][nweight]             per parity: every rank's weight deltas of a learning epoch
+//     sbuf[2][world][slice_max]           per parity: every rank's weight deltas of a learning epoch FOR THE
+//                                         SLICE OF THE WEIGHT VECTOR THIS RANK OWNS (rank q owns [q nw / W, (q+1) nw / W))
+//     gbuf[2][nweight]                    per parity: the merged weights, slice q written by its owner q
 // Boundary lists are PAIRWISE: rank s sends rank d exactly the variables d reads from s (ascending global
 // id on both sides), so nothing travels that its receiver does not read.  After a sweep a rank WRITES its
-// boundary values (k_p2p_push: a grid of workgroups over the concatenated per-reader lists) -- and, after
-// a learning epoch, its weight deltas first (k_p2p_push_dw) -- straight into the peers' buffers; the last
-// block of k_p2p_push raises this rank's flag at every peer; k_p2p_wait_unpack waits for the peers' flags
-// and scatters their values.  No collective, no host in the loop.  Peers are symmetric (q is a peer when either side reads from the other), so two ranks that
-// exchange anything wait for each other in every exchange and a peer runs at most one exchange ahead:
-// two parities suffice.
+// boundary values straight into the peers' buffers; the last block to finish raises this rank's flag at every
+// peer; a rank waits for the flags of its peers and scatters their values.  No collective, no host in the
+// loop.  Peers are symmetric (q is a peer when either side reads from the other), so two ranks that exchange
+// anything wait for each other in every exchange and a peer runs at most one exchange ahead: two parities
+// suffice.
+// A learning epoch's weight deltas travel as REDUCE-SCATTER + ALL-GATHER over the same buffers (SURVEY 8(e);
+// the master's rule w = w_start + sum of deltas, salt/src/numbskull_master.py:223-224, numbskull_minion.py:
+// 270-279): with the values, every rank writes slice q of its deltas to rank q only; the owner adds the W
+// contributions IN RANK ORDER, forms w_start + sum and writes the merged slice to every rank; a rank waits
+// for the W owners' second flags and takes the merged vector -- 2 x 7 x nw / 8 doubles per rank and epoch
+// instead of 7 x nw, the same additions in the same order on ONE owner, hence bit-identical weights on all.
 struct P2PPlan {                        // (one node: at most 16 ranks)
     void *base[16];                     // peer q's allocation
     unsigned long long soff[17];        // this rank's send list = concatenation over q of what q reads: [soff[q], soff[q+1])
     unsigned long long dbase[16];       // where this rank's segment starts inside q's per-chain block
     unsigned long long dtotal[16];      // elements of q's per-chain block (q's receive total)
+    unsigned long long roff[17];        // this rank's receive block: segment of source q = [roff[q], roff[q+1])
 };
 #define NSK_P2P_ALIGN 256ull
+#define NSK_P2P_ERR_TIMEOUT 1u
+#define NSK_P2P_ERR_PAYLOAD 2u
+__host__ __device__ inline size_t nsk_p2p_align(size_t x) { return (x + NSK_P2P_ALIGN - 1) / NSK_P2P_ALIGN * NSK_P2P_ALIGN; }
 __host__ __device__ inline size_t nsk_p2p_recv_off(int world) {           // byte offset of recv[] in an allocation
-    return ((size_t)(2 * world) * sizeof(unsigned int) + NSK_P2P_ALIGN - 1) / NSK_P2P_ALIGN * NSK_P2P_ALIGN;
+    return nsk_p2p_align((size_t)(4 * world) * sizeof(unsigned int));
 }
-__host__ __device__ inline size_t nsk_p2p_wbuf_off(int world, size_t nrecv, size_t vbytes) {
-    return nsk_p2p_recv_off(world) + (4 * nrecv * vbytes + NSK_P2P_ALIGN - 1) / NSK_P2P_ALIGN * NSK_P2P_ALIGN;
+__host__ __device__ inline size_t nsk_p2p_sbuf_off(int world, size_t nrecv, size_t vbytes) {
+    return nsk_p2p_recv_off(world) + nsk_p2p_align(4 * nrecv * vbytes);
+}
+__host__ __device__ inline size_t nsk_p2p_slice_lo(int q, int world, size_t nw) { return (size_t)q * nw / (size_t)world; }
+__host__ __device__ inline size_t nsk_p2p_slice_max(int world, size_t nw) { return (nw + (size_t)world - 1) / (size_t)world; }
+__host__ __device__ inline size_t nsk_p2p_gbuf_off(int world, size_t nrecv, size_t vbytes, size_t nw) {
+    return nsk_p2p_sbuf_off(world, nrecv, vbytes) + nsk_p2p_align(2 * (size_t)world * nsk_p2p_slice_max(world, nw) * sizeof(double));
+}
+__host__ __device__ inline size_t nsk_p2p_bytes(int world, size_t nrecv, size_t vbytes, size_t nw) {
+    return nsk_p2p_gbuf_off(world, nrecv, vbytes, nw) + nsk_p2p_align(2 * nw * sizeof(double)) + 256;
 }
 
+// The set-up self-test runs the very kernels of the sweep loops with `selftest` set: they then push a pattern
+// that depends on the sender, the element, the exchange tag and the chain instead of the state, and the
+// receiving side compares instead of storing -- payload visibility across devices is checked, not only the flags.
 template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push(const VT *val, const VT *val_evid, const int32_t *send_iid,
-                                                        long long nsend, P2PPlan pl, int world, int me,
-                                                        unsigned int peer_mask, unsigned int *ticket, unsigned int tag,
-                                                        const unsigned long long *tag_base) {
-    if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
+__device__ __forceinline__ VT p2p_pattern(int src, unsigned long long k, unsigned int tag, int chain) {
+    return (VT)(((unsigned int)(src * 37 + 1) * 7u + (unsigned int)k * 11u + tag * 5u + (unsigned int)chain * 3u) & 127u);
+}
+__device__ __forceinline__ double p2p_pattern_dw(int src, int i, unsigned int tag) {
+    return (double)((src + 1) * 1000 + (i % 997)) * 0.25 + (double)(tag & 255u);
+}
+
+// weights of a learning exchange (null w: an inference exchange)
+struct P2PWeights {
+    const double *w, *w_start;          // this rank's weights now / at the start of the epoch
+    int nw;
+    int pad_;
+};
+
+// push: boundary values into the readers' receive blocks, and (learning) slice q of the weight deltas into
+// block `me` of rank q's sbuf -- this rank's own slice included
+template <typename VT>
+__device__ __forceinline__ void p2p_push(const VT *val, const VT *val_evid, int both, const int32_t *send_iid, long long nsend,
+                                         const P2PPlan &pl, const P2PWeights &pw, int world, int me, unsigned int tag, int selftest) {
     const size_t par = tag & 1u;
     const size_t roff = nsk_p2p_recv_off(world);
-    for (long long k = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; k < nsend; k += (long long)gridDim.x * NSK_BLOCK) {
+    const long long stride = (long long)gridDim.x * NSK_BLOCK;
+    for (long long k = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; k < nsend; k += stride) {
         int q = 0;
         while (q + 1 < world && (unsigned long long)k >= pl.soff[q + 1]) q++;
         const size_t tot = (size_t)pl.dtotal[q];
-        VT *dst = (VT *)((char *)pl.base[q] + roff) + par * 2 * tot + (size_t)pl.dbase[q] + (size_t)((unsigned long long)k - pl.soff[q]);
+        const unsigned long long kl = (unsigned long long)k - pl.soff[q];
+        VT *dst = (VT *)((char *)pl.base[q] + roff) + par * 2 * tot + (size_t)pl.dbase[q] + (size_t)kl;
         const int id = send_iid[k];
-        dst[0] = val[id];
-        if (val_evid) dst[tot] = val_evid[id];
+        dst[0] = selftest ? p2p_pattern<VT>(me, kl, tag, 0) : val[id];
+        if (both) dst[tot] = selftest ? p2p_pattern<VT>(me, kl, tag, 1) : val_evid[id];
     }
-    // the last block to finish raises this rank's flag at every peer (a handful of blocks: the ticket adds
-    // do not queue up); everything this rank pushed in this exchange -- earlier kernels on the stream
-    // included -- is then visible to a peer that has seen the flag
+    if (pw.w) {
+        const size_t nw = (size_t)pw.nw, smax = nsk_p2p_slice_max(world, nw);
+        for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < (long long)nw; i += stride) {
+            int q = (int)(((size_t)i * (size_t)world + (size_t)world - 1) / nw);          // owner of weight i: the q with lo(q) <= i < lo(q + 1)
+            while (q > 0 && nsk_p2p_slice_lo(q, world, nw) > (size_t)i) q--;
+            while (q + 1 < world && nsk_p2p_slice_lo(q + 1, world, nw) <= (size_t)i) q++;
+            double *sb = (double *)((char *)pl.base[q] + nsk_p2p_sbuf_off(world, (size_t)pl.dtotal[q], sizeof(VT)));
+            sb[(par * (size_t)world + (size_t)me) * smax + ((size_t)i - nsk_p2p_slice_lo(q, world, nw))] =
+                selftest ? p2p_pattern_dw(me, (int)i, tag) : pw.w[i] - pw.w_start[i];
+        }
+    }
+}
+
+// true in every thread of the LAST block of the launch to get here (a handful of blocks: the ticket adds do not
+// queue up); everything the launch -- and earlier kernels on the stream -- wrote is then visible to a peer that
+// sees a flag raised afterwards
+__device__ __forceinline__ bool p2p_last_block(unsigned int *ticket) {
+    __shared__ unsigned int last;
     __threadfence_system();
     __syncthreads();
-    __shared__ unsigned int last;
     if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
-    if (!last) return;
-    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool l = last != 0u;
+    if (l && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return l;
+}
+__device__ __forceinline__ void p2p_raise(const P2PPlan &pl, int kind, int world, int me, unsigned int peer_mask, unsigned int tag) {
     __threadfence_system();
     if (threadIdx.x < (unsigned)world && ((peer_mask >> threadIdx.x) & 1u))
-        __hip_atomic_store((unsigned int *)pl.base[threadIdx.x] + par * (size_t)world + (size_t)me, tag, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned int *)pl.base[threadIdx.x] + ((size_t)(tag & 1u) * 2 + (size_t)kind) * (size_t)world + (size_t)me, tag,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// waits (bounded: timeout_ticks of the 100 MHz wall clock, then *err |= time-out) for the tags of the peers;
+// block-uniform result; an acquire fence at system scope follows (the payload was written by another agent)
+__device__ __forceinline__ bool p2p_wait(const void *mine, int kind, int world, unsigned int peer_mask, unsigned int tag,
+                                         unsigned int *err, unsigned long long timeout_ticks) {
+    __shared__ int ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ok = 1;
+        const unsigned long long t0 = wall_clock64();
+        const unsigned int *flags = (const unsigned int *)mine + ((size_t)(tag & 1u) * 2 + (size_t)kind) * (size_t)world;
+        for (int q = 0; q < world && ok; q++) {
+            if (!((peer_mask >> q) & 1u)) continue;
+            while (__hip_atomic_load(flags + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+                if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (!ok) (void)__hip_atomic_fetch_or(err, NSK_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool r = ok != 0;
+    if (r) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    return r;
+}
+template <typename VT>
+__device__ __forceinline__ void p2p_unpack(VT *val, VT *val_evid, int both, const int32_t *recv_iid, long long nrecv, const void *mine,
+                                           const P2PPlan &pl, int world, unsigned int tag, int selftest, unsigned int *err) {
+    const VT *rb = (const VT *)((const char *)mine + nsk_p2p_recv_off(world)) + (size_t)(tag & 1u) * 2 * (size_t)nrecv;
+    for (long long j = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; j < nrecv; j += (long long)gridDim.x * NSK_BLOCK) {
+        const VT a = __builtin_nontemporal_load(rb + j);
+        const VT b = both ? __builtin_nontemporal_load(rb + (size_t)nrecv + j) : (VT)0;
+        if (selftest) {
+            int q = 0;
+            while (q + 1 < world && (unsigned long long)j >= pl.roff[q + 1]) q++;
+            const unsigned long long jl = (unsigned long long)j - pl.roff[q];
+            if (a != p2p_pattern<VT>(q, jl, tag, 0) || (both && b != p2p_pattern<VT>(q, jl, tag, 1)))
+                (void)__hip_atomic_fetch_or(err, NSK_P2P_ERR_PAYLOAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        const int id = recv_iid[j];
+        val[id] = a;
+        if (both) val_evid[id] = b;
+    }
+}
+// the owner's half of the weight merge: this rank's slice = w_start + (d_0 + d_1 + ...) in rank order, written
+// to the gbuf of every rank (its own included)
+template <typename VT>
+__device__ __forceinline__ void p2p_reduce_slice(const void *mine, long long nrecv, const P2PPlan &pl, const P2PWeights &pw,
+                                                 int world, int me, unsigned int tag, int selftest) {
+    const size_t nw = (size_t)pw.nw, smax = nsk_p2p_slice_max(world, nw), par = tag & 1u;
+    const size_t lo = nsk_p2p_slice_lo(me, world, nw), hi = nsk_p2p_slice_lo(me + 1, world, nw);
+    const double *sb = (const double *)((const char *)mine + nsk_p2p_sbuf_off(world, (size_t)nrecv, sizeof(VT))) + par * (size_t)world * smax;
+    for (size_t i = lo + (size_t)blockIdx.x * NSK_BLOCK + threadIdx.x; i < hi; i += (size_t)gridDim.x * NSK_BLOCK) {
+        double t = __builtin_nontemporal_load(sb + (i - lo));
+        for (int r = 1; r < world; r++) t += __builtin_nontemporal_load(sb + (size_t)r * smax + (i - lo));
+        const double x = (selftest ? 0.0 : pw.w_start[i]) + t;
+        for (int q = 0; q < world; q++) {
+            double *gb = (double *)((char *)pl.base[q] + nsk_p2p_gbuf_off(world, (size_t)pl.dtotal[q], sizeof(VT), nw));
+            gb[par * nw + i] = x;
+        }
+    }
+}
+
+// the pushes alone (tests that drive several handles from one process, phase timings)
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push(const VT *val, const VT *val_evid, int both, const int32_t *send_iid,
+                                                        long long nsend, P2PPlan pl, P2PWeights pw, int world, int me,
+                                                        unsigned int peer_mask, unsigned int *ticket, unsigned int tag,
+                                                        const unsigned long long *tag_base, int selftest) {
+    if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
+    p2p_push<VT>(val, val_evid, both, send_iid, nsend, pl, pw, world, me, tag, selftest);
+    if (p2p_last_block(ticket)) p2p_raise(pl, 0, world, me, peer_mask, tag);
 }
 
 // One exchange in ONE launch (what the sweep loops enqueue): every block pushes its share, the last one to
 // finish raises the flags, then every block goes on to wait for the peers' flags and unpacks its share --
 // the wait depends on the peers' pushes only, so no block waits for another block of this launch.  A shard
 // of the metric config is a few 4 us kernels per sweep: one kernel less per sweep is worth having.
-template <typename VT>
+// Learning: the blocks then add up this rank's slice of the weight deltas and write the merged slice to
+// every rank; the last block to finish raises the second flag (k_p2p_gather_w waits for those).
+// PUSH = false: the wait / unpack / reduce half alone.
+template <typename VT, bool PUSH>
 __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_exchange(VT *val, VT *val_evid, int both, const int32_t *send_iid, long long nsend,
-                                                            P2PPlan pl, const int32_t *recv_iid, long long nrecv, const void *mine,
-                                                            int world, int me, unsigned int peer_mask, unsigned int *ticket,
-                                                            unsigned int tag, unsigned int *err, const unsigned long long *tag_base,
-                                                            unsigned long long timeout_ticks) {
+                                                            P2PPlan pl, P2PWeights pw, const int32_t *recv_iid, long long nrecv,
+                                                            const void *mine, int world, int me, unsigned int peer_mask,
+                                                            unsigned int *ticket, unsigned int tag, unsigned int *err,
+                                                            const unsigned long long *tag_base, unsigned long long timeout_ticks,
+                                                            int selftest) {
     if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
-    const size_t par = tag & 1u;
-    const size_t roff = nsk_p2p_recv_off(world);
-    for (long long k = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; k < nsend; k += (long long)gridDim.x * NSK_BLOCK) {
-        int q = 0;
-        while (q + 1 < world && (unsigned long long)k >= pl.soff[q + 1]) q++;
-        const size_t tot = (size_t)pl.dtotal[q];
-        VT *dst = (VT *)((char *)pl.base[q] + roff) + par * 2 * tot + (size_t)pl.dbase[q] + (size_t)((unsigned long long)k - pl.soff[q]);
-        const int id = send_iid[k];
-        dst[0] = val[id];
-        if (both) dst[tot] = val_evid[id];
+    if (PUSH) {
+        p2p_push<VT>(val, val_evid, both, send_iid, nsend, pl, pw, world, me, tag, selftest);
+        if (p2p_last_block(ticket)) p2p_raise(pl, 0, world, me, peer_mask, tag);
     }
-    __threadfence_system();
-    __syncthreads();
-    __shared__ unsigned int last;
-    __shared__ int ok;
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (last) {
-        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_system();
-        if (threadIdx.x < (unsigned)world && ((peer_mask >> threadIdx.x) & 1u))
-            __hip_atomic_store((unsigned int *)pl.base[threadIdx.x] + par * (size_t)world + (size_t)me, tag, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!p2p_wait(mine, 0, world, peer_mask, tag, err, timeout_ticks)) return;
+    p2p_unpack<VT>(val, val_evid, both, recv_iid, nrecv, mine, pl, world, tag, selftest, err);
+    if (pw.w) {
+        p2p_reduce_slice<VT>(mine, nrecv, pl, pw, world, me, tag, selftest);
+        if (p2p_last_block(ticket + 1)) p2p_raise(pl, 1, world, me, peer_mask, tag);
     }
-    if (threadIdx.x == 0) {
-        ok = 1;
-        const unsigned long long t0 = wall_clock64();
-        const unsigned int *flags = (const unsigned int *)mine;
-        for (int q = 0; q < world && ok; q++) {
-            if (!((peer_mask >> q) & 1u)) continue;
-            const unsigned int *f = flags + par * (size_t)world + (size_t)q;
-            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
-                if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
+}
+
+// the closing half of a learning exchange: wait for the owners' merged slices, then w = w_start = merged
+// (the same vector on every rank)
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_gather_w(double *w, double *w_start, int nw, const void *mine, long long nrecv,
+                                                            int world, unsigned int peer_mask, unsigned int tag, unsigned int *err,
+                                                            unsigned long long timeout_ticks, int selftest) {
+    if (!p2p_wait(mine, 1, world, peer_mask, tag, err, timeout_ticks)) return;
+    const double *gb = (const double *)((const char *)mine + nsk_p2p_gbuf_off(world, (size_t)nrecv, sizeof(VT), (size_t)nw)) +
+                       (size_t)(tag & 1u) * (size_t)nw;
+    for (int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x); i < nw; i += (int)(gridDim.x * NSK_BLOCK)) {
+        const double x = __builtin_nontemporal_load(gb + i);
+        if (selftest) {
+            double t = p2p_pattern_dw(0, i, tag);
+            for (int r = 1; r < world; r++) t += p2p_pattern_dw(r, i, tag);
+            if (x != 0.0 + t) (void)__hip_atomic_fetch_or(err, NSK_P2P_ERR_PAYLOAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
         }
-        if (!ok) *err = 1u;
-    }
-    __syncthreads();
-    if (!ok) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the payload was written by another agent
-    const VT *rb = (const VT *)((const char *)mine + roff) + par * 2 * (size_t)nrecv;
-    for (long long j = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; j < nrecv; j += (long long)gridDim.x * NSK_BLOCK) {
-        const int id = recv_iid[j];
-        val[id] = __builtin_nontemporal_load(rb + j);
-        if (both) val_evid[id] = __builtin_nontemporal_load(rb + (size_t)nrecv + j);
-    }
-}
-
-// weight deltas of a learning epoch (w - w_start) into block `me` of every rank's wbuf, this rank's included
-struct P2PWeights { double *wbuf[16]; };
-static __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push_dw(const double *w, const double *w_start, P2PWeights pw,
-                                                                  int world, int me, int nw, unsigned int tag) {
-    const size_t blk = ((size_t)(tag & 1u) * (size_t)world + (size_t)me) * (size_t)nw;
-    for (int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x); i < nw; i += (int)(gridDim.x * NSK_BLOCK)) {
-        const double d = w[i] - w_start[i];
-        for (int q = 0; q < world; q++) pw.wbuf[q][blk + (size_t)i] = d;
-    }
-}
-
-// w = w_start + (d_0 + d_1 + ... ) in rank order -- the master's merge rule (numbskull_master.py:223-224),
-// the same additions on every rank -- and w_start = w for the next epoch
-static __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_merge_w(double *w, double *w_start, const double *wbuf, int world,
-                                                                  int nw, unsigned int tag) {
-    const double *b = wbuf + (size_t)(tag & 1u) * (size_t)world * (size_t)nw;
-    for (int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x); i < nw; i += (int)(gridDim.x * NSK_BLOCK)) {
-        double t = __builtin_nontemporal_load(b + i);
-        for (int q = 1; q < world; q++) t += __builtin_nontemporal_load(b + (size_t)q * (size_t)nw + i);
-        const double x = w_start[i] + t;
         w[i] = x;
         w_start[i] = x;
-    }
-}
-
-// waits (bounded: timeout_ticks of the 100 MHz wall clock, then *err = 1) for the tags of the peers, then
-// scatters the received values of one or both chains
-template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_wait_unpack(VT *val, VT *val_evid, const int32_t *recv_iid, long long nrecv,
-                                                               const void *mine, int world, unsigned int peer_mask,
-                                                               unsigned int tag, unsigned int *err,
-                                                               const unsigned long long *tag_base,
-                                                               unsigned long long timeout_ticks) {
-    if (tag_base) tag += (unsigned int)tag_base[1];        // captured launch: tag = device counter + offset
-    const size_t par = tag & 1u;
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-        ok = 1;
-        const unsigned long long t0 = wall_clock64();
-        const unsigned int *flags = (const unsigned int *)mine;
-        for (int q = 0; q < world && ok; q++) {
-            if (!((peer_mask >> q) & 1u)) continue;
-            const unsigned int *f = flags + par * (size_t)world + (size_t)q;
-            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
-                if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        if (!ok) *err = 1u;
-    }
-    __syncthreads();
-    if (!ok) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the payload was written by another agent
-    const VT *rb = (const VT *)((const char *)mine + nsk_p2p_recv_off(world)) + par * 2 * (size_t)nrecv;
-    for (long long j = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; j < nrecv; j += (long long)gridDim.x * NSK_BLOCK) {
-        const int id = recv_iid[j];
-        val[id] = __builtin_nontemporal_load(rb + j);
-        if (val_evid) val_evid[id] = __builtin_nontemporal_load(rb + (size_t)nrecv + j);
     }
 }
 

@@ -22,6 +22,9 @@ Drivers for the per-sweep loop:
     epoch's weight deltas -- straight into buffers of its peers (device memory mapped with hipIpc; xGMI
     between GPUs) and raises a flag there; a rank waits for the flags of its peers and scatters their
     values (nsk_gibbs_sweeps_p2p / nsk_learn_sweeps_p2p) -- no collective, no host round trip per sweep.
+    The weight deltas of a learning epoch are merged by reduce-scatter + all-gather over the same buffers
+    (rank q owns a slice of the weight vector, adds the ranks' deltas in rank order and hands the merged
+    slice to everyone: bit-identical weights on all ranks).
     A peer whose flag does not arrive within NSK_P2P_TIMEOUT_S (default 30 s) is reported by
     ``check()``.  Exercised with several ranks sharing ONE device only (tests/); across devices it
     relies on hipIpc peer mappings and system-scope flags over xGMI;
@@ -267,12 +270,13 @@ class PartitionedSampler(object):
         table = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(r[:64] for r in raw))
         if not agreed(self.L.nsk_p2p_import(self.h, table) == 0):
             return False
-        # self-test: the boundary values are still the initial ones every rank already holds and the
-        # weight deltas are zero, so two learning-mode exchanges change nothing -- but they run the very
-        # kernels, mappings and flags of the sweep loops, one exchange per buffer parity
+        # self-test: two learning-mode exchanges -- the very kernels, mappings and flags of the sweep loops,
+        # one exchange per buffer parity -- whose payload is a pattern that depends on sender, element,
+        # exchange and chain, compared on the receiving side (values, weight-delta slices and merged
+        # weights): a peer's WRITES must be visible here, not only its flags.  State and weights untouched
         rc = 0
         for _ in range(2):
-            rc = rc or self.L.nsk_p2p_exchange(self.h, 1, 0)
+            rc = rc or self.L.nsk_p2p_selftest(self.h, 1, 0)
         rc = rc or self.L.nsk_p2p_check(self.h)
         return agreed(rc == 0)
 

@@ -79,6 +79,14 @@ def wire_p2p(parts):
     for p in parts:
         _lib.check(L.nsk_p2p_import_local(p.h, bases))
         p.p2p = True
+    # the set-up self-test of PartitionedSampler._init_p2p (pattern payload, compared on the receiving side),
+    # breadth-first like the exchanges below, one round per buffer parity
+    for _ in range(2):
+        for part in (1, 2, 3):
+            for p in parts:
+                _lib.check(L.nsk_p2p_selftest(p.h, 1, part))
+    for p in parts:
+        p.check()
     return needs
 
 
@@ -109,8 +117,9 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
             else:
                 _lib.check(L.nsk_gibbs_sweeps(p.h, 1, 1, 0))
             _lib.check(L.nsk_p2p_exchange(p.h, int(learn), 1))
-        for p in parts:
-            _lib.check(L.nsk_p2p_exchange(p.h, int(learn), 2))
+        for part in (2, 3):                     # (3: the closing half of the weight merge; nothing in inference)
+            for p in parts:
+                _lib.check(L.nsk_p2p_exchange(p.h, int(learn), part))
         st *= decay
     for p in parts:
         p.check()
@@ -164,7 +173,7 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
 
     # phase timings per shard: the sweep kernels alone, then all pushes, then all flag/wait/unpack
     # (+ weight merge) kernels -- each rank's bracket on its own stream, marked first, read afterwards
-    timing = {"sweep_us": [], "push_us": [], "wait_unpack_us": []}
+    timing = {"sweep_us": [], "push_us": [], "wait_unpack_us": [], "gather_w_us": []}
     ms, nl = C.c_double(), C.c_int64()
     for _ in range(3):
         row = []
@@ -177,7 +186,7 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
             _lib.check(L.nsk_profile_end(p.h, C.byref(ms), C.byref(nl)))
             row.append(ms.value * 1e3)
         timing["sweep_us"].append(row)
-        for part, key in ((1, "push_us"), (2, "wait_unpack_us")):
+        for part, key in ((1, "push_us"), (2, "wait_unpack_us"), (3, "gather_w_us")):
             for p in parts:
                 _lib.check(L.nsk_profile_begin(p.h))
                 _lib.check(L.nsk_p2p_exchange(p.h, int(learn), part))
@@ -193,7 +202,8 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
     owned = [p.fg.own_range[1] - p.fg.own_range[0] for p in parts]
     out = {"config": "%s in 8 range shards, all on one MI355X, %s, peer-to-peer exchange" % (tag, "learning" if learn else "inference"),
            "owned_per_rank": owned, "values_sent_per_rank": sends, "ghosts_per_rank": [len(n) for n in needs],
-           "exchange_fraction": float(np.mean([np.mean(a) + np.mean(b) for a, b in zip(timing["push_us"][1:], timing["wait_unpack_us"][1:])])
+           "exchange_fraction": float(np.mean([np.mean(a) + np.mean(b) + np.mean(c) for a, b, c in
+                                               zip(timing["push_us"][1:], timing["wait_unpack_us"][1:], timing["gather_w_us"][1:])])
                                       / np.mean([np.mean(a) for a in timing["sweep_us"][1:]])),
            "per_shard_us": {k: {"mean": float(np.mean(v[1:])), "max": float(np.max(v[1:]))} for k, v in timing.items()},
            "note": "one shard's kernels alone on the device (HIP events on the shard's stream); the push / wait brackets of "

@@ -985,6 +985,13 @@ def test_peer_to_peer_timeout_is_reported_once(monkeypatch):
             _lib.check(L.nsk_p2p_exchange(p.h, 0, part))
     for p in parts:
         p.check()
+    # the payload self-test (pattern pushed, compared on the receiving side) passes on both parities
+    for _ in range(2):
+        for part in (1, 2, 3):
+            for p in parts:
+                _lib.check(L.nsk_p2p_selftest(p.h, 1, part))
+    for p in parts:
+        p.check()
     send = np.zeros(3, np.int32)
     off = np.array([0, 0, 3], np.int64)
     zero = np.zeros(3, np.int64)
