@@ -246,7 +246,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
             if (c.phase_end[k] > c.phase_fast_end[k]) generic_needed = true;
         if (generic_needed || nsk::diag_env("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
     }
-    UP(w_fixed); UP(logtab); UP(adj); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
+    UP(w_fixed); UP(logtab); UP(adj); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_win); UP(ep_win_off); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     if (c.ndirect > 0) {
@@ -256,8 +256,9 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes, nid = (size_t)c.nid;
     uint8_t *tmp = nullptr;
     rc = dev_alloc(g, &tmp, npos * vb); if (rc) return rc; g->p_init = tmp;
-    rc = dev_alloc(g, &tmp, nid * vb); if (rc) return rc; g->val = tmp;
-    rc = dev_alloc(g, &tmp, nid * vb); if (rc) return rc; g->val_evid = tmp;
+    // (+ 16 bytes: the value windows of the entry-parallel groups are copied in whole 16-byte chunks)
+    rc = dev_alloc(g, &tmp, nid * vb + 16); if (rc) return rc; g->val = tmp;
+    rc = dev_alloc(g, &tmp, nid * vb + 16); if (rc) return rc; g->val_evid = tmp;
     rc = upload_values(g, g->p_init, c.p_init.data(), npos); if (rc) return rc;
     {   // values live at internal ids (padding positions hold 0 and are never read as a variable)
         std::vector<int32_t> init_i(nid, 0);
@@ -678,7 +679,7 @@ static int64_t layout_hash(const Compiled &c) {
         hash_array(c.hub_desc), hash_array(c.hub_adj), hash_array(c.phase_hub_base), hash_array(c.bighub_pos),
         hash_array(c.tile_hdr), hash_array(c.dyn_tiles), hash_array(c.seg_aff), hash_array(c.rest_tiles),
         hash_array(c.learn_rest_tiles), hash_array(c.phase_gen_tile), hash_array(c.ep_desc), hash_array(c.ep_adj),
-        hash_array(c.ep_wrow), hash_array(c.ep_kstat), hash_array(c.phase_ep_base), hash_array(c.phase_ep),
+        hash_array(c.ep_wrow), hash_array(c.ep_win), hash_array(c.ep_win_off), hash_array(c.ep_kstat), hash_array(c.phase_ep_base), hash_array(c.phase_ep),
         hash_array(c.p_vid), hash_array(c.p_slot), hash_array(c.p_cnt), hash_array(c.p_info), hash_array(c.p_init),
         hash_array(c.slot_off), hash_array(c.fidx), hash_array(c.gstream), hash_array(c.gs_off), hash_array(c.f_rec),
         hash_array(c.m_rec), hash_array(c.iid), hash_array(c.w_init), hash_array(c.w_fixed), hash_array(c.w_direct),

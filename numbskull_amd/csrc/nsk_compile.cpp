@@ -567,6 +567,75 @@ static int build_ep_groups(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
                 }
             }
         }, 8);
+        // ---- value windows (nsk_compile.h ep_win): per group the 16-byte chunks of the value array its members
+        // lie in; member ids inside the kept chunks become offsets into the group's LDS copy
+        c.ep_win.clear();
+        c.ep_win_off.assign((size_t)ngroups + 1, 0u);
+        const bool want_win = ngroups > 0 && c.vbytes == 1 && !diag_env("NSK_NO_EP_WIN") && c.nid < (int64_t)NSK_EP_WIN_BASE;
+        if (want_win) {
+            std::vector<std::vector<uint32_t>> kept((size_t)ngroups);
+            std::vector<int64_t> st((size_t)compile_threads() * 2, 0);     // members in a window / members
+            parallel_for(ngroups, [&](int64_t g0, int64_t g1, int t) {
+                std::vector<uint32_t> ch;
+                std::vector<std::pair<uint32_t, uint32_t>> cnt;        // (uses, chunk)
+                for (int64_t gi = g0; gi < g1; gi++) {
+                    const uint32_t *gd = &c.ep_desc[(size_t)gi * 4];
+                    // every member word of the group's rows
+                    ch.clear();
+                    auto each_member = [&](auto &&fn) {
+                        uint64_t sr = subrows[gi];
+                        for (uint32_t cl = 0; cl < 8; cl++) {
+                            const uint32_t m = cl & 3u, rows = (gd[cl < 4 ? 1 : 3] >> (8 * m)) & 255u;
+                            for (uint64_t r = 0; r < rows; r++)
+                                for (uint32_t mm = 0; mm < m; mm++) {
+                                    uint32_t *row = &c.ep_adj[(sr + r * (2 + m) + 2 + mm) * 64];
+                                    for (uint32_t e = 0; e < 64; e++) if ((row[e] & NSK_GEN_NULL) != NSK_GEN_NULL) fn(row[e]);
+                                }
+                            sr += (uint64_t)rows * (2 + m);
+                        }
+                    };
+                    each_member([&](uint32_t &wd) { ch.push_back((wd & NSK_GEN_NULL) >> 4); });
+                    std::sort(ch.begin(), ch.end());
+                    cnt.clear();
+                    for (size_t i = 0; i < ch.size();) {
+                        size_t j = i;
+                        while (j < ch.size() && ch[j] == ch[i]) j++;
+                        cnt.emplace_back((uint32_t)(j - i), ch[i]);
+                        i = j;
+                    }
+                    if (cnt.size() > NSK_EP_WIN_CHUNKS) {                // keep the most used chunks (ties: lowest id)
+                        std::sort(cnt.begin(), cnt.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
+                            return a.first != b.first ? a.first > b.first : a.second < b.second; });
+                        cnt.resize(NSK_EP_WIN_CHUNKS);
+                    }
+                    std::vector<uint32_t> &kp = kept[(size_t)gi];
+                    kp.clear();
+                    for (const auto &x : cnt) kp.push_back(x.second);
+                    std::sort(kp.begin(), kp.end());
+                    each_member([&](uint32_t &wd) {
+                        const uint32_t id = wd & NSK_GEN_NULL;
+                        const auto it = std::lower_bound(kp.begin(), kp.end(), id >> 4);
+                        st[2 * (size_t)t + 1]++;
+                        if (it == kp.end() || *it != (id >> 4)) return;
+                        wd = (wd & ~NSK_GEN_NULL) | (NSK_EP_WIN_BASE + (uint32_t)(it - kp.begin()) * 16u + (id & 15u));
+                        st[2 * (size_t)t]++;
+                    });
+                }
+            }, 8);
+            for (int64_t gi = 0; gi < ngroups; gi++) c.ep_win_off[gi + 1] = c.ep_win_off[gi] + (uint32_t)kept[(size_t)gi].size();
+            c.ep_win.resize((size_t)c.ep_win_off[ngroups]);
+            parallel_for(ngroups, [&](int64_t g0, int64_t g1, int) {
+                for (int64_t gi = g0; gi < g1; gi++)
+                    std::copy(kept[(size_t)gi].begin(), kept[(size_t)gi].end(), c.ep_win.begin() + c.ep_win_off[gi]);
+            }, 64);
+            if (verbose) {
+                int64_t in = 0, all = 0;
+                for (size_t t = 0; t < st.size(); t += 2) { in += st[t]; all += st[t + 1]; }
+                fprintf(stderr, "[nsk] value windows: %.1f chunks per group, %.2f %% of %lld members inside\n",
+                        (double)c.ep_win.size() / (double)ngroups, all ? 100.0 * (double)in / (double)all : 0.0, (long long)all);
+            }
+        }
+        lap("entry-parallel groups: value windows");
         if (verbose && ngroups)
             fprintf(stderr, "[nsk] entry-parallel groups %lld, stream %.1f MB\n", (long long)ngroups,
                     (double)subrows[ngroups] * 256 / 1e6);
@@ -2141,8 +2210,14 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     // in step with the lanes (DESIGN.md "internal numbering").
     c.iid.assign(nvar, -1);
     {
+        // (the ghosts the sampled variables READ come first among the others, in id order: the receive list of
+        // a peer-to-peer exchange -- all of them, ascending -- is then one contiguous run of internal ids, which
+        // lets a shard's kernels read ghost values straight from the exchange buffer, nsk_api.hip)
         int64_t next = c.npos;
-        for (int64_t v = 0; v < nvar; v++) c.iid[v] = c.v_pos[v] >= 0 ? c.v_pos[v] : (int32_t)next++;
+        for (int32_t v : c.ghost_needs) if (c.v_pos[v] < 0) c.iid[v] = (int32_t)next++;
+        for (int64_t v = 0; v < nvar; v++)
+            if (c.v_pos[v] >= 0) c.iid[v] = c.v_pos[v];
+            else if (c.iid[v] < 0) c.iid[v] = (int32_t)next++;
         // one more id that belongs to no variable and always holds 0: where the ignored member slots and the
         // padding of uniform tiles point.  The draw-table kernels take a member's value as its bit (values
         // are regular, members binary), so such a slot must not read a categorical variable's value --

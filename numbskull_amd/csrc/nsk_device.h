@@ -260,6 +260,7 @@ struct DevGraph {
     const uint4 *ep_desc;       // entry-parallel groups of general tiles (nsk_compile.h ep_desc): one per
     const uint32_t *ep_adj;     //  256 positions; ep_adj: sub-rows of 64 words
     const uint32_t *ep_wrow;    // [groups + 1] first row of a group in ep_wt
+    const uint32_t *ep_win, *ep_win_off;   // value windows of the groups (nsk_compile.h ep_win); null: none
     const uint32_t *ep_kstat;   // structural visit counts (nsk_compile.h ep_kstat) or null
     double *ep_wt;              // materialised weights of the groups' entries: row r, lane i at ep_wt[64 r + i]
     const int32_t *iid_of_vid;  // variable id -> internal id (position; ghosts after the positions): the

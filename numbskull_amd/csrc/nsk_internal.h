@@ -73,7 +73,7 @@ struct nsk_graph {
     uint8_t *sink = nullptr;            // scratch line for padding lanes' stores
     uint32_t *hub_desc = nullptr, *hub_adj = nullptr;   // entry-parallel hub streams
     uint32_t *ep_desc = nullptr, *ep_adj = nullptr;     // entry-parallel groups of general tiles
-    uint32_t *bighub_pos = nullptr, *ep_wrow = nullptr, *ep_kstat = nullptr;
+    uint32_t *bighub_pos = nullptr, *ep_wrow = nullptr, *ep_kstat = nullptr, *ep_win = nullptr, *ep_win_off = nullptr;
     double *ep_wt = nullptr;
     nsk::ZProgDev *zprogs = nullptr;
     bool values_regular = true;         // every value on the device lies in [0, cardinality): the
@@ -181,6 +181,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.hub_desc = (const uint4 *)g->hub_desc; d.hub_adj = g->hub_adj;
     d.ep_desc = (const uint4 *)g->ep_desc; d.ep_adj = g->ep_adj; d.bighub_pos = g->bighub_pos;
     d.ep_wrow = g->ep_wrow; d.ep_wt = g->ep_wt;
+    d.ep_win = g->c.ep_win.empty() ? nullptr : g->ep_win; d.ep_win_off = g->ep_win_off;
     d.ep_kstat = g->c.ep_kstat.empty() ? nullptr : g->ep_kstat;
     d.seg_aff = (const uint4 *)g->seg_aff;
     d.w_direct = g->c.ndirect > 0 ? g->w_direct : nullptr;

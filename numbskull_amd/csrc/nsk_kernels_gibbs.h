@@ -1034,9 +1034,11 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
 // their gathers are issued together and waited for once.
 // (measured on the 5M LR graph, per class: inference U = 1 58.5 us, 2 63.8, 3 64.9 -- the single-chain walk
 // keeps 6 waves per SIMD; learning, whose rows carry two chains, U = 1 159.8, 2 149.4, 3 164.2)
+// wa / wb: the group's value windows in LDS (ep_stage_window; `win`: in use) -- a member word whose id field is
+// NSK_EP_WIN_BASE + o reads byte o of the window instead of gathering from the value array
 template <typename VT, bool TWO, int WMODE, bool NT, bool MEMBERS, int U, typename FN>
 __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, const VT *vb, uint32_t sub0,
-                                        uint32_t rowsw, const double *wt, FN &&fn) {
+                                        uint32_t rowsw, const double *wt, const signed char *wa, const signed char *wb, bool win, FN &&fn) {
     const int wave = (int)(threadIdx.x >> 6);
     const int total = ep_pass_rows(rowsw);
     if (wave >= total) return;
@@ -1064,7 +1066,13 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
 #ifdef NSK_ABL_EPNOW
             w[u] = WMODE ? __longlong_as_double(0x3FB0000000000000ll | (long long)cur[u].w0) : 0.0;
 #else
+            // (learning gathers the weight: a table beyond the L2s is streamed through them -- non-temporal, so
+            // that its lines do not push the value lines and the rows out)
+#ifdef NSK_EP_W_TEMPORAL
             w[u] = WMODE == 1 ? g.w[NSK_EP_WID(cur[u].w0)] : (WMODE == 2 ? wc[u] : 0.0);
+#else
+            w[u] = WMODE == 1 ? __builtin_nontemporal_load(g.w + NSK_EP_WID(cur[u].w0)) : (WMODE == 2 ? wc[u] : 0.0);
+#endif
 #endif
             if (MEMBERS) {
 #pragma unroll
@@ -1076,8 +1084,13 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
                         xa[u][m] = (int)(at & 1u);
                         if (TWO) xb[u][m] = (int)((at >> 1) & 1u);
 #else
-                        xa[u][m] = (int)va[at];
-                        if (TWO) xb[u][m] = (int)vb[at];
+                        if (sizeof(VT) == 1 && win && id >= NSK_EP_WIN_BASE && id != NSK_GEN_NULL) {     // in the group's window
+                            xa[u][m] = (int)wa[id - NSK_EP_WIN_BASE];
+                            if (TWO) xb[u][m] = (int)wb[id - NSK_EP_WIN_BASE];
+                        } else {
+                            xa[u][m] = (int)va[at];
+                            if (TWO) xb[u][m] = (int)vb[at];
+                        }
 #endif
                     }
             }
@@ -1103,6 +1116,21 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
         for (int u = 0; u < U; u++) { cur[u] = nxt[u]; Mc[u] = Mn[u]; wc[u] = wn[u]; }
     }
 }
+
+// The value window of group `gidx` (nsk_compile.h ep_win) into LDS: 16-byte chunks of the value array(s), one
+// per thread and trip.  The caller's next barrier publishes it; nobody may still be reading the previous one.
+template <typename VT, bool TWO>
+__device__ __forceinline__ void ep_stage_window(const DevGraph<VT> &g, int gidx, nsk_u32x4 *wa, nsk_u32x4 *wb) {
+    if (sizeof(VT) != 1 || !g.ep_win) return;
+    const NSK_SCALAR uint32_t *op = (const NSK_SCALAR uint32_t *)(g.ep_win_off + gidx);
+    const uint32_t o0 = op[0], n = op[1] - o0;
+    for (uint32_t i = threadIdx.x; i < n; i += NSK_BLOCK) {
+        const uint32_t c = __builtin_nontemporal_load(g.ep_win + o0 + i);
+        wa[i] = *((const nsk_u32x4 *)g.val + c);
+        if (TWO) wb[i] = *((const nsk_u32x4 *)g.val_evid + c);
+    }
+}
+#define NSK_EP_WIN_LDS(VT) (sizeof(VT) == 1 ? NSK_EP_WIN_CHUNKS : 1)
 
 // ep_wt row <- the weights its entries name (run whenever weights may have changed, before an
 // inference call): one workgroup per group, its rows dealt to the waves
@@ -1231,6 +1259,7 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
     __shared__ __attribute__((aligned(16))) double ws[NSK_EP_LIST * 256];
     __shared__ __attribute__((aligned(16))) uint16_t fs[NSK_EP_LIST * 256];
     __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
+    __shared__ nsk_u32x4 wina[NSK_EP_WIN_LDS(VT)];                 // the group's value window (ep_stage_window)
     load_gen_lut(lut);
     // blocks [0, nbh): one long-list hub each; [nbh, hblocks): one wave per hub position; then the
     // resident group blocks; then the colour's rest tiles
@@ -1298,11 +1327,13 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
         for (int pass = 0; pass * NSK_EP_LIST < ne; pass++) {
             const uint32_t rowsw = pass ? grows1 : grows0;
             __syncthreads();                               // (the previous sums have been read)
+            if (pass == 0) ep_stage_window<VT, false>(g, group0 + gi, wina, wina);
             for (int i = (int)threadIdx.x; i < NSK_EP_LIST * 128; i += NSK_BLOCK)      // slots no entry writes:
                 ((uint32_t *)fs)[i] = 14u | (14u << 16);                                   // owned by no candidate
             __syncthreads();
 #ifndef NSK_ABL_EPNOP1
             ep_pass<VT, false, 2, true, true, 1>(g, g.val, g.val, sub, rowsw, g.ep_wt + (size_t)wrow * 64,
+                (const signed char *)wina, (const signed char *)wina, g.ep_win != nullptr,
                 [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &, double w) {
                     int cstar, A, B;
                     a.close(d1, lut, cstar, A, B);

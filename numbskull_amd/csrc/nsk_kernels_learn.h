@@ -1142,6 +1142,9 @@ __device__ __forceinline__ void block_hub_learn(const DevGraph<VT> &g, const Gra
 // A group with more than 8 entries per variable takes two passes of (1, 2); phase 3 then runs over the
 // second pass's entries (their facts are in LDS) and, after redoing phase 1 for them, over the first's.
 // Dynamic LDS: the SMALLW accumulators only.
+#ifndef NSK_EP_LEARN_NT
+#define NSK_EP_LEARN_NT false       // the rows of the learning launch: read twice per group (entries, gradients)
+#endif
 #ifdef NSK_EP_WPE_L
 #define NSK_EP_ATTR_L __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_L, NSK_EP_WPE_L)))
 #else
@@ -1157,6 +1160,9 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
     __shared__ __attribute__((aligned(16))) uint32_t fs[NSK_EP_LIST * 256];
     __shared__ uint16_t sel[256];
     __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
+    __shared__ nsk_u32x4 wina[NSK_EP_WIN_LDS(VT)], winb[NSK_EP_WIN_LDS(VT)];      // the group's value windows, both chains
+    const signed char *wa = (const signed char *)wina, *wb = (const signed char *)winb;
+    const bool win = g.ep_win != nullptr;
     load_gen_lut(lut);
     const GradSink sk = open_sink<SMALLW>(g, smem);
     if ((int)blockIdx.x < nbh) {                          // one long-list hub per block
@@ -1179,7 +1185,7 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
     auto entries = [&](uint32_t sub, uint32_t rowsw) {
         for (int i = (int)threadIdx.x; i < NSK_EP_LIST * 256; i += NSK_BLOCK) fs[i] = 14u;      // owned by no candidate
         __syncthreads();
-        ep_pass<VT, true, 1, false, true, 2>(g, g.val, g.val_evid, sub, rowsw, nullptr,
+        ep_pass<VT, true, 1, NSK_EP_LEARN_NT, true, 2>(g, g.val, g.val_evid, sub, rowsw, nullptr, wa, wb, win,
             [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &b, double w) {
                 int cstar, A, B;
                 a.close(d1, lut, cstar, A, B);
@@ -1197,7 +1203,7 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
     };
     // phase 3 of one pass: gradients of its entries from the facts in the slots
     auto gradients = [&](uint32_t sub, uint32_t rowsw) {
-        ep_pass<VT, false, 0, false, false, 2>(g, g.val, g.val, sub, rowsw, nullptr,
+        ep_pass<VT, false, 0, NSK_EP_LEARN_NT, false, 2>(g, g.val, g.val, sub, rowsw, nullptr, wa, wb, false,
             [&](uint32_t w0, uint32_t d1, const GenChain &, const GenChain &, double) {
                 const uint32_t sv = sel[(d1 >> 23) & 255u];
                 const int evidence = (int)(sv & 15u), proposal = (int)((sv >> 4) & 15u);
@@ -1243,6 +1249,7 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
             for (int pass = 0; pass * NSK_EP_LIST < ne; pass++) {
                 const uint32_t rowsw = pass ? grows1 : grows0;
                 __syncthreads();                           // (the previous group / pass is done with the slots)
+                if (pass == 0) ep_stage_window<VT, true>(g, group0 + gi, wina, winb);     // published by the barrier in entries()
                 entries(sub, rowsw);
                 const int nacc = min(NSK_EP_LIST, ne - pass * NSK_EP_LIST);
                 if (tile_ok)
