@@ -171,6 +171,11 @@ typedef struct {
                                          streams, programs, weight slots ...) -- what a check that two builds /
                                          thread counts / library versions compile a graph alike compares;
                                          0 otherwise (hashing the layout of a 50M-variable graph takes seconds) */
+    int64_t p2p_fused;                /* 1: after nsk_p2p_import(_local), the handle's inference sweeps exchange the
+                                         boundary INSIDE their table launches (nsk_gibbs_sweeps_p2p: border tiles read
+                                         the receive block, write into the readers' and raise the flags; no exchange
+                                         kernels per sweep) -- a shard whose sampled variables all live in table
+                                         segments and whose boundary values have one reader each; 0: exchange kernels */
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);

@@ -393,6 +393,7 @@ int nsk_set_stream(nsk_graph *g, void *hip_stream) {
 int nsk_synchronize(nsk_graph *g) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     HIPCHECK(hipStreamSynchronize(g->stream));
     return NSK_OK;
 }
@@ -525,6 +526,7 @@ int nsk_state_upload(nsk_graph *g, const int64_t *var_value, const int64_t *var_
                      const double *weight_value, const int64_t *count) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     const int64_t nvar = g->c.nvar;
     const size_t vb = (size_t)g->c.vbytes;
     const int64_t *srcs[2] = {var_value, var_value_evid};
@@ -607,6 +609,7 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
                        int64_t *count) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     int rc;
     if (var_value && (rc = download_values(g, g->val, var_value, 0))) return rc;
     if (var_value_evid && (rc = download_values(g, g->val_evid, var_value_evid, 1))) return rc;
@@ -712,6 +715,7 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->direct_weights = c.ndirect;
     info->weight_slots = c.wmap.empty() ? 0 : 1;
     info->layout_hash = getenv("NSK_LAYOUT_HASH") ? layout_hash(c) : 0;
+    info->p2p_fused = 0;
 }
 
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
@@ -729,6 +733,7 @@ int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
     info->compile_seconds = g->compile_seconds;
     info->acc_copies = g->acc_copies + (g->bins_xcd ? 16 : 0);
     info->learn_lag = (g->learn_lag && g->smallw) ? 1 : 0;
+    info->p2p_fused = g->p2p_fused ? 1 : 0;
     return NSK_OK;
 }
 
@@ -983,6 +988,7 @@ static int exchange_step(nsk_graph *g, int which, bool pack) {
     if (g->xworld == 0) return fail(NSK_E_INVALID, "nsk_exchange_setup has not been called");
     if (which != NSK_BUF_VALUE && which != NSK_BUF_VALUE_EVID) return fail(NSK_E_INVALID, "bad buffer id");
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     return g->c.vbytes == 1 ? exchange_kernels<int8_t>(g, which, pack) : exchange_kernels<int32_t>(g, which, pack);
 }
 
@@ -1030,6 +1036,9 @@ int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, c
     int rc;
     if ((rc = dev_upload(g, &g->p_send_iid, sv))) return rc;
     if ((rc = dev_upload(g, &g->p_recv_iid, rv))) return rc;
+    g->p_send_host = sv;
+    g->p_recv_host = rv;
+    g->p2p_fused = false;
     if (!g->w_start) {
         if ((rc = dev_alloc(g, &g->w_start, (size_t)g->c.nweight))) return rc;
         if ((rc = dev_alloc(g, &g->w_delta, (size_t)g->c.nweight))) return rc;
@@ -1089,12 +1098,93 @@ int nsk_p2p_export(nsk_graph *g, void *handle64, void **base) {
     return NSK_OK;
 }
 
+}  // extern "C"
+
+// Does every sampled variable of the handle live in a table segment (the grids and their shards)?
+bool nsk_tables_only(const nsk_graph *g) {
+    const nsk::Compiled &c = g->c;
+    const size_t nphase = c.phase_start.size() - 1;
+    if (g->scan != NSK_SCAN_CHROMATIC || nphase == 0) return false;
+    for (size_t ph = 0; ph < nphase; ph++) {
+        const int64_t ntiles = c.phase_wb_base[ph + 1] - c.phase_wb_base[ph];
+        if (c.phase_end[ph] > c.phase_fast_end[ph]) return false;                    // generic-path variables / hubs
+        if (ntiles > c.phase_gen_tile[ph]) return false;                             // general tiles
+        if (c.phase_rest_base[ph + 1] > c.phase_rest_base[ph]) return false;         // tiles outside segments
+    }
+    for (const nsk::Compiled::Segment &sg : c.segments) if (sg.ztab < 0) return false;
+    return true;
+}
+
+// Fused boundary exchange (nsk_internal.h p2p_fused): decide whether the handle qualifies and build the push map.
+// Conditions: every sampled variable in a table segment; the receive list is the run of ghost ids in order (the
+// compiler numbers the ghosts a handle reads first and ascending, so the receive block IS the ghost array); every
+// boundary value has exactly one reader (range shards of a grid; a value read by several ranks keeps the
+// exchange kernels).
+static int p2p_fuse_plan(nsk_graph *g) {
+    g->p2p_fused = false;
+    g->p2p_border_tiles.clear();
+    if (nsk::diag_env("NSK_NO_P2P_FUSE") || !nsk_tables_only(g)) return NSK_OK;
+    const nsk::Compiled &c = g->c;
+    const std::vector<int32_t> &sv = g->p_send_host, &rv = g->p_recv_host;
+    if (rv.empty() && sv.empty()) return NSK_OK;
+    const uint32_t ghost_lo = rv.empty() ? (uint32_t)c.nid : (uint32_t)rv[0];
+    for (size_t j = 0; j < rv.size(); j++) if ((uint32_t)rv[j] != ghost_lo + (uint32_t)j) return NSK_OK;
+    if (ghost_lo < (uint32_t)c.npos) return NSK_OK;
+    for (int q = 0; q < g->pworld; q++) if (g->p_dtotal[q] >= (1ll << 28)) return NSK_OK;
+    // tiles that read a ghost: slot bases of the implicit adjacency, or the stream words
+    std::vector<int32_t> tiles;
+    for (int32_t p : sv) tiles.push_back(p >> 6);
+    for (const nsk::Compiled::Segment &sg : c.segments) {
+        const int nch = sg.nslots > 4 ? 2 : 1;
+        for (int64_t t = 0; t < sg.ntiles; t++) {
+            bool reads = false;
+            const uint32_t *ab = sg.aff >= 0 ? &c.seg_aff[((size_t)sg.aff + (size_t)t * nch) * 4] : nullptr;
+            if (ab && ab[0] != 0xFFFFFFFFu) {
+                for (int j = 0; j < 4 * nch && !reads; j++) reads = ab[j] + 63u >= ghost_lo && ab[j] < ghost_lo + (uint32_t)rv.size();
+            } else {
+                const uint32_t *w = &c.adj[((size_t)sg.adj_off + (size_t)t * 64 * nch) * 4];
+                for (int i = 0; i < 256 * nch && !reads; i++) reads = w[i] - ghost_lo < (uint32_t)rv.size();
+            }
+            if (reads) tiles.push_back((int32_t)(sg.pos0 / 64 + t));
+        }
+    }
+    std::sort(tiles.begin(), tiles.end());
+    tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+    std::vector<uint32_t> pm(tiles.size() * 64, 0xFFFFFFFFu);
+    for (int q = 0; q < g->pworld; q++)
+        for (int64_t k = g->p_soff[q]; k < g->p_soff[q + 1]; k++) {
+            const int32_t pos = sv[(size_t)k];
+            const size_t row = (size_t)(std::lower_bound(tiles.begin(), tiles.end(), pos >> 6) - tiles.begin());
+            uint32_t &e = pm[row * 64 + (size_t)(pos & 63)];
+            if (e != 0xFFFFFFFFu) return NSK_OK;                                     // a second reader
+            e = ((uint32_t)q << 28) | (uint32_t)(g->p_dbase[q] + (k - g->p_soff[q]));
+        }
+    if (g->p2p_push_map) {
+        g->allocs.erase(std::remove(g->allocs.begin(), g->allocs.end(), (void *)g->p2p_push_map), g->allocs.end());
+        (void)hipFree(g->p2p_push_map);
+        g->p2p_push_map = nullptr;
+    }
+    int rc = dev_upload(g, &g->p2p_push_map, pm);
+    if (rc) return rc;
+    if (!g->d_counters) {}      // (the border counter lives behind the error mark: p2p_err[3])
+    g->p2p_border_tiles.swap(tiles);
+    g->p2p_ghost_lo = ghost_lo;
+    g->p2p_fused = true;
+    g->seg_plans_key = -1;          // the segment plans split at the border tiles
+    return NSK_OK;
+}
+
+extern "C" {
+
 static int p2p_finish_import(nsk_graph *g) {
     if (g->c.nweight)       // the weights every rank starts the next learning epoch from
         HIPCHECK(hipMemcpyAsync(g->w_start, g->w, (size_t)g->c.nweight * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+    int rc = p2p_fuse_plan(g);
+    if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(g->stream));
     nsk_drop_sweep_graph(g);
     g->p2p_tag = 0;
+    g->p2p_close_pending = false;
     g->p2p_ready = true;
     return NSK_OK;
 }
@@ -1191,12 +1281,64 @@ int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned i
                             : p2p_exchange<int32_t>(g, tag_base, tag_off, learn, part);
 }
 
+// kernel argument of a fused table launch
+void nsk_p2p_fill(nsk_graph *g, nsk::TabP2P &px, const unsigned long long *tag_base, unsigned int tag) {
+    memset(&px, 0, sizeof(px));
+    px.mine = g->p2p_base;
+    for (int q = 0; q < g->pworld; q++) { px.peer[q] = g->p2p_peer_base[q]; px.dtotal[q] = (unsigned long long)g->p_dtotal[q]; }
+    px.push_map = g->p2p_push_map;
+    px.counter = g->p2p_err + 3;
+    px.err = g->p2p_err;
+    px.tag_base = tag_base;
+    px.timeout_ticks = g->p2p_timeout_ticks;
+    px.ghost_lo = g->p2p_ghost_lo;
+    px.nrecv = (uint32_t)g->p_nrecv;
+    px.border_total = g->p2p_border_total;
+    px.tag = tag;
+    px.peer_mask = g->p2p_peer_mask;
+    px.world = g->pworld;
+    px.me = g->prank;
+}
+
+// the ghost values of the value array into the receive block of the LAST exchange's parity: what the first fused
+// sweep of a call reads (the caller may have uploaded a state since)
+template <typename VT>
+static __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_ghost_pack(const VT *val, const int32_t *recv_iid, long long nrecv, void *mine,
+                                                                      int world, unsigned int tag) {
+    VT *rb = (VT *)((char *)mine + nsk_p2p_recv_off(world)) + (size_t)(tag & 1u) * 2 * (size_t)nrecv;
+    for (long long j = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; j < nrecv; j += (long long)gridDim.x * NSK_BLOCK)
+        rb[j] = val[recv_iid[j]];
+}
+int nsk_p2p_ghost_pack(nsk_graph *g) {
+    if (g->p_nrecv == 0) return NSK_OK;
+    const int nb = (int)std::min<int64_t>(64, (g->p_nrecv + NSK_BLOCK - 1) / NSK_BLOCK);
+    if (g->c.vbytes == 1)
+        k_p2p_ghost_pack<int8_t><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const int8_t *)g->val, g->p_recv_iid, (long long)g->p_nrecv,
+                                                                             g->p2p_base, g->pworld, g->p2p_tag);
+    else
+        k_p2p_ghost_pack<int32_t><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const int32_t *)g->val, g->p_recv_iid, (long long)g->p_nrecv,
+                                                                              g->p2p_base, g->pworld, g->p2p_tag);
+    HIPCHECK(hipGetLastError());
+    return NSK_OK;
+}
+
+// A fused sweep sequence ends with its last class launch; the wait for the peers' last flags and the copy of the
+// received values into the value array's ghost ids (what downloads, the other kernels and the next call's pack
+// read) is enqueued lazily -- before the next thing that needs it -- so that a caller driving several ranks from
+// one process can issue every rank's sweeps before any rank's wait.
+int nsk_p2p_flush(nsk_graph *g) {
+    if (!g || !g->p2p_close_pending) return NSK_OK;
+    g->p2p_close_pending = false;
+    return nsk_p2p_enqueue(g, nullptr, 0, false, 2);          // wait for tag p2p_tag + unpack
+}
+
 extern "C" {
 
 int nsk_p2p_check(nsk_graph *g) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (!g->p2p_err) return NSK_OK;
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     unsigned int err = 0;
     HIPCHECK(hipMemcpyAsync(&err, g->p2p_err, sizeof(err), hipMemcpyDeviceToHost, g->stream));
     HIPCHECK(hipStreamSynchronize(g->stream));
@@ -1225,6 +1367,7 @@ int nsk_p2p_exchange(nsk_graph *g, int learn, int part) {
     if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
     if (part < 0 || part > 3) return fail(NSK_E_INVALID, "bad part");
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     return nsk_p2p_enqueue(g, nullptr, 0, learn != 0, part);
 }
 
@@ -1233,7 +1376,7 @@ int nsk_gibbs_sweeps_p2p(nsk_graph *g, int64_t nsweeps, int sample_evidence, int
     if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
     if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
     HIPCHECK(hipSetDevice(g->device));
-    return nsk_gibbs_run(g, nsweeps, sample_evidence, burnin, true);
+    return nsk_gibbs_run(g, nsweeps, sample_evidence, burnin, true);      // (flushes a pending close unless it continues it)
 }
 
 int nsk_learn_sweeps_p2p(nsk_graph *g, int64_t nsweeps, double step, double decay, int regularization,
@@ -1242,6 +1385,7 @@ int nsk_learn_sweeps_p2p(nsk_graph *g, int64_t nsweeps, double step, double deca
     if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
     if (nsweeps < 0 || nsweeps > INT32_MAX) return fail(NSK_E_INVALID, "bad sweep count");
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     const int nw = (int)g->c.nweight;
     // the caller may have written the weight buffer since the last epoch: this call starts from what is there
     if (nw && nsweeps) HIPCHECK(hipMemcpyAsync(g->w_start, g->w, (size_t)nw * sizeof(double), hipMemcpyDeviceToDevice, g->stream));

@@ -10,6 +10,95 @@
 
 using namespace nsk;
 
+// The segment launches of every colour, prepared once and kept in the handle (a small graph's sweep is two
+// 4 us kernels: rebuilding the tables per sweep made the host the bottleneck): segments batched by (kind,
+// chunks) into tables of <= NSK_SEG_MAX; kind 8 = segments with draw tables (any function: the table encodes
+// it).  A handle that exchanges its boundary inside the table launches (p2p_fused) gets its segments split
+// into runs of border tiles (SegEntry.push_off = their first row in the push map) and runs of interior tiles.
+void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
+    typedef NskSegPlan SegPlan;
+    const size_t nphase = g->c.phase_start.size() - 1;
+    std::vector<std::vector<SegPlan>> &seg_plans = g->seg_plans;
+    const int plans_key = (sample_evidence ? 1 : 0) | (g->values_regular ? 2 : 0) | (g->p2p_fused ? 4 : 0);
+    if (g->seg_plans_key == plans_key) return;
+    g->seg_plans_key = plans_key;
+    seg_plans.assign(nphase, std::vector<SegPlan>());
+    const bool use_tab = g->values_regular;
+    struct Run { const Compiled::Segment *sg; int t0, nt; uint32_t push_off; };
+    const std::vector<int32_t> &bt = g->p2p_border_tiles;
+    uint32_t border_total = 0;
+    bool border_all = true;
+    if (g->p2p_fused)          // border tiles of segments this call does not sample: the fused exchange cannot run
+        for (const Compiled::Segment &sg : g->c.segments)
+            if (!(sg.ev == 0 || sample_evidence)) {
+                const int32_t f = (int32_t)(sg.pos0 / 64);
+                const auto it = std::lower_bound(bt.begin(), bt.end(), f);
+                if (it != bt.end() && *it < f + sg.ntiles) border_all = false;
+            }
+    for (size_t ph = 0; ph < nphase; ph++)
+        for (int kind = 0; kind <= 8; kind++) {
+            if (kind == 1 || (kind > 4 && kind < 8)) continue;   // IMPLY_NATURAL shares the AND step (3)
+            for (int nch = 1; nch <= 2; nch++) {
+                SegTable tab;
+                memset(&tab, 0, sizeof(tab));
+                auto flush = [&]() {
+                    if (tab.n == 0) return;
+                    for (int i = tab.n; i < NSK_SEG_MAX; i++) tab.e[i].tile_start = tab.ntiles;
+                    seg_plans[ph].push_back(SegPlan{kind, nch, tab});
+                    memset(&tab, 0, sizeof(tab));
+                };
+                // largest segments first: the kernels find a tile's segment with a scan
+                // whose first probe is the table's first entry
+                std::vector<Run> mine;
+                for (const Compiled::Segment &sg : g->c.segments) {
+                    if (sg.phase != (int)ph) continue;
+                    const int k3 = (use_tab && sg.ztab >= 0) ? 8 : sg.kind == 1 ? 3 : (int)sg.kind;
+                    if (k3 != kind || (sg.nslots > 4 ? 2 : 1) != nch) continue;
+                    if (!(sg.ev == 0 || sample_evidence)) continue;      // inference.py:24
+                    if (!g->p2p_fused || kind < 8) { mine.push_back(Run{&sg, 0, sg.ntiles, NSK_NO_STREAM}); continue; }
+                    // runs of border / interior tiles (a tile's rank among the border tiles = its push-map row)
+                    const int32_t f = (int32_t)(sg.pos0 / 64);
+                    size_t bi = (size_t)(std::lower_bound(bt.begin(), bt.end(), f) - bt.begin());
+                    for (int t = 0; t < sg.ntiles;) {
+                        const bool isb = bi < bt.size() && bt[bi] == f + t;
+                        int e = t + 1;
+                        if (isb) { while (e < sg.ntiles && bi + (size_t)(e - t) < bt.size() && bt[bi + (size_t)(e - t)] == f + e) e++; }
+                        else e = (bi < bt.size() && bt[bi] < f + sg.ntiles) ? bt[bi] - f : sg.ntiles;
+                        mine.push_back(Run{&sg, t, e - t, isb ? (uint32_t)bi : NSK_NO_STREAM});
+                        if (isb) { bi += (size_t)(e - t); border_total += (uint32_t)(e - t); }
+                        t = e;
+                    }
+                }
+                std::stable_sort(mine.begin(), mine.end(), [](const Run &a, const Run &b) { return a.nt > b.nt; });
+                for (const Run &rn : mine) {
+                    const Compiled::Segment &sg = *rn.sg;
+                    SegEntry &en = tab.e[tab.n];
+                    const int64_t pos0 = sg.pos0 + 64 * (int64_t)rn.t0;
+                    // table launches number their tiles virtually: a segment starts on a quad
+                    // boundary (positions 256 m), with up to three dead tiles in front
+                    const int lead = kind >= 8 ? (int)((pos0 / 64) & 3) : 0;
+                    const int vtiles = kind >= 8 ? ((rn.nt + lead + 3) & ~3) : rn.nt;
+                    en.ntiles_lead = (uint32_t)rn.nt | ((uint32_t)lead << 30);
+                    en.tile_start = tab.ntiles;
+                    en.pos0 = (int)pos0;
+                    en.adj_off = sg.adj_off + (uint32_t)rn.t0 * 64u * (uint32_t)nch;
+                    en.prog = sg.prog;
+                    en.zoff = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
+                    // (bit 16: the positions of a segment with a draw table draw from the quad
+                    // scheme whichever kernel samples them, nsk_device.h quad_block)
+                    en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8) | (sg.ztab >= 0 ? 1u << 16 : 0u);
+                    en.aff_off = (kind >= 8 && sg.aff >= 0) ? (uint32_t)sg.aff + (uint32_t)rn.t0 * (uint32_t)nch : NSK_NO_STREAM;
+                    en.push_off = rn.push_off;
+                    tab.ntiles += vtiles;
+                    if (++tab.n == NSK_SEG_MAX) flush();
+                }
+                flush();
+            }
+        }
+    g->p2p_border_total = border_total;
+    g->p2p_border_all = border_all && border_total == (uint32_t)bt.size();
+}
+
 template <typename VT>
 static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin) {
     DevGraph<VT> d = view<VT>(g);
@@ -22,66 +111,11 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
     } else {
         const size_t nphase = g->c.phase_start.size() - 1;
         nsk_refresh_prog_weights(g);
-        // The segment launches of every colour, prepared once per call (a small graph's sweep is two
-        // 4 us kernels: rebuilding the tables per sweep made the host the bottleneck): segments batched
-        // by (kind, chunks) into tables of <= NSK_SEG_MAX; kind 8 = segments with draw tables (any
-        // function: the table encodes it)
+        nsk_ensure_seg_plans(g, sample_evidence);
+        std::vector<std::vector<NskSegPlan>> &seg_plans = g->seg_plans;
         typedef NskSegPlan SegPlan;
-        std::vector<std::vector<SegPlan>> &seg_plans = g->seg_plans;
-        const int plans_key = (sample_evidence ? 1 : 0) | (g->values_regular ? 2 : 0);
-        if (g->seg_plans_key != plans_key) {
-            g->seg_plans_key = plans_key;
-            seg_plans.assign(nphase, std::vector<SegPlan>());
-            const bool use_tab = g->values_regular;
-            for (size_t ph = 0; ph < nphase; ph++)
-                for (int kind = 0; kind <= 8; kind++) {
-                    if (kind == 1 || (kind > 4 && kind < 8)) continue;   // IMPLY_NATURAL shares the AND step (3)
-                    for (int nch = 1; nch <= 2; nch++) {
-                        SegTable tab;
-                        memset(&tab, 0, sizeof(tab));
-                        auto flush = [&]() {
-                            if (tab.n == 0) return;
-                            for (int i = tab.n; i < NSK_SEG_MAX; i++) tab.e[i].tile_start = tab.ntiles;
-                            seg_plans[ph].push_back(SegPlan{kind, nch, tab});
-                            memset(&tab, 0, sizeof(tab));
-                        };
-                        // largest segments first: the kernels find a tile's segment with a scan
-                        // whose first probe is the table's first entry
-                        std::vector<const Compiled::Segment *> mine;
-                        for (const Compiled::Segment &sg : g->c.segments) {
-                            if (sg.phase != (int)ph) continue;
-                            const int k3 = (use_tab && sg.ztab >= 0) ? 8 : sg.kind == 1 ? 3 : (int)sg.kind;
-                            if (k3 != kind || (sg.nslots > 4 ? 2 : 1) != nch) continue;
-                            if (!(sg.ev == 0 || sample_evidence)) continue;      // inference.py:24
-                            mine.push_back(&sg);
-                        }
-                        std::stable_sort(mine.begin(), mine.end(), [](const Compiled::Segment *a, const Compiled::Segment *b) {
-                            return a->ntiles > b->ntiles; });
-                        for (const Compiled::Segment *sgp : mine) {
-                            const Compiled::Segment &sg = *sgp;
-                            SegEntry &en = tab.e[tab.n];
-                            // table launches number their tiles virtually: a segment starts on a quad
-                            // boundary (positions 256 m), with up to three dead tiles in front
-                            const int lead = kind >= 8 ? (int)((sg.pos0 / 64) & 3) : 0;
-                            const int vtiles = kind >= 8 ? ((sg.ntiles + lead + 3) & ~3) : sg.ntiles;
-                            en.ntiles_lead = (uint32_t)sg.ntiles | ((uint32_t)lead << 30);
-                            en.tile_start = tab.ntiles;
-                            en.pos0 = (int)sg.pos0;
-                            en.adj_off = sg.adj_off;
-                            en.prog = sg.prog;
-                            en.zoff = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
-                            // (bit 16: the positions of a segment with a draw table draw from the quad
-                            // scheme whichever kernel samples them, nsk_device.h quad_block)
-                            en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8) | (sg.ztab >= 0 ? 1u << 16 : 0u);
-                            en.aff_off = (kind >= 8 && sg.aff >= 0) ? (uint32_t)sg.aff : NSK_NO_STREAM;
-                            tab.ntiles += vtiles;
-                            if (++tab.n == NSK_SEG_MAX) flush();
-                        }
-                        flush();
-                    }
-                }
-        }
         for (int64_t s = 0; s < nsweeps; s++) {
+            if (g->p2p_fused_now) ++g->p2p_tag;            // the exchange rides in this sweep's table launches
             for (size_t ph = 0; ph < nphase; ph++) {
                 const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
                 const int e = (int)g->c.phase_end[ph];
@@ -181,7 +215,13 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                         if (kind >= 8) {
                             // a wave per tile pair while that fits the resident grid, else its waves loop over quads
                             const int nbp = nsk_tab_grid(tab.ntiles);
-                            if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
+                            if (g->p2p_fused_now) {
+                                TabP2P px;
+                                nsk_p2p_fill(g, px, nullptr, g->p2p_tag);
+                                if (nch == 1) k_gibbs_seg_tab_p2p<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, px);
+                                else k_gibbs_seg_tab_p2p<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, px);
+                            }
+                            else if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
                             else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
                         }
                         else if (kind == 4) { if (nch == 1) NSK_SEG(4, 1); else NSK_SEG(4, 2); }
@@ -234,21 +274,12 @@ static int gibbs_eager(nsk_graph *g, int64_t nsweeps, int sample_evidence, int b
 static bool graph_eligible(const nsk_graph *g, bool p2p) {
     if (g->scan != NSK_SCAN_CHROMATIC || !g->values_regular || nsk::diag_env("NSK_NO_GRAPH")) return false;
     const nsk::Compiled &c = g->c;
-    const size_t nphase = c.phase_start.size() - 1;
-    if (nphase == 0) return false;
     // launches set the pace only while the class kernels are short: beyond a few million variables per
     // handle (10M grid: 12 us per class) a replay saves nothing and its launch latency shows in short runs.
     // A handle that exchanges peer to peer adds two tiny kernels per sweep: its sequences are captured up
     // to twice the size (the two shards of the 10M grid)
     if (c.nsampled > (p2p ? 6000000 : 3000000)) return false;
-    for (size_t ph = 0; ph < nphase; ph++) {
-        const int64_t ntiles = c.phase_wb_base[ph + 1] - c.phase_wb_base[ph];
-        if (c.phase_end[ph] > c.phase_fast_end[ph]) return false;                    // generic-path variables / hubs
-        if (ntiles > c.phase_gen_tile[ph]) return false;                             // general tiles
-        if (c.phase_rest_base[ph + 1] > c.phase_rest_base[ph]) return false;         // tiles outside segments
-    }
-    for (const nsk::Compiled::Segment &sg : c.segments) if (sg.ztab < 0) return false;
-    return true;
+    return nsk_tables_only(g);
 }
 
 template <typename VT>
@@ -267,7 +298,17 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
         for (size_t ph = 0; ph < g->seg_plans.size(); ph++)
             for (const NskSegPlan &pl : g->seg_plans[ph]) {
                 const int nbp = nsk_tab_grid(pl.tab.ntiles);
-                if (pl.nch == 1)
+                if (g->p2p_fused_now) {          // the exchange inside the launch: tag = counter + i + 1
+                    TabP2P px;
+                    nsk_p2p_fill(g, px, g->d_counters, (unsigned int)(i + 1));
+                    if (pl.nch == 1)
+                        k_gibbs_seg_tab_p2p<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
+                                                                                                 g->d_counters, (uint32_t)i, px);
+                    else
+                        k_gibbs_seg_tab_p2p<VT, 2><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
+                                                                                                 g->d_counters, (uint32_t)i, px);
+                }
+                else if (pl.nch == 1)
                     k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
                                                                                          g->d_counters, (uint32_t)i);
                 else
@@ -275,7 +316,7 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
                                                                                          g->d_counters, (uint32_t)i);
                 launches++;
             }
-        if (p2p) {
+        if (p2p && !g->p2p_fused_now) {
             int rc = nsk_p2p_enqueue(g, g->d_counters, (unsigned int)(i + 1));
             if (rc) { (void)hipStreamEndCapture(g->stream, &graph); if (graph) (void)hipGraphDestroy(graph); return rc; }
         }
@@ -294,15 +335,34 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
 
 int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p) {
     int64_t left = nsweeps;
+    // A shard whose sweep is table launches only exchanges its boundary INSIDE them (nsk_internal.h p2p_fused): the
+    // ghosts the first sweep reads are packed into the receive block here, the wait for the peers' last flags and
+    // the unpack into the value array are enqueued lazily (nsk_p2p_flush)
+    bool fuse = false;
+    if (p2p && g->p2p_fused && g->scan == NSK_SCAN_CHROMATIC && g->values_regular && nsweeps > 0) {
+        nsk_ensure_seg_plans(g, sample_evidence);
+        fuse = g->p2p_border_all;
+        for (const auto &v : g->seg_plans) for (const NskSegPlan &pl : v) fuse = fuse && pl.kind >= 8;
+        // (a fused call right behind a fused call continues it: the receive block already holds what the first
+        // sweep reads -- nothing to unpack into the value array and pack back)
+        if (fuse && !g->p2p_close_pending) {
+            int rc = nsk_p2p_ghost_pack(g);
+            if (rc) return rc;
+        }
+    }
+    if (!fuse) { int frc = nsk_p2p_flush(g); if (frc) return frc; }
+    g->p2p_close_pending = false;
+    g->p2p_fused_now = fuse;
+    struct Done { nsk_graph *g; bool fuse; ~Done() { g->p2p_fused_now = false; if (fuse) g->p2p_close_pending = true; } } done{g, fuse};
     if (left >= NSK_GRAPH_SWEEPS && graph_eligible(g, p2p)) {
         // the plans of this (sample_evidence, tables) combination: one eager sweep builds / refreshes them
         int rc = gibbs_eager(g, 1, sample_evidence, burnin);
         if (rc) return rc;
-        if (p2p && (rc = nsk_p2p_enqueue(g, nullptr, 0))) return rc;
+        if (p2p && !fuse && (rc = nsk_p2p_enqueue(g, nullptr, 0))) return rc;
         left--;
         bool all_tab = true;
         for (const auto &v : g->seg_plans) for (const NskSegPlan &pl : v) all_tab = all_tab && pl.kind >= 8;
-        const int key = g->seg_plans_key | (burnin ? 4 : 0) | (p2p ? 8 : 0);
+        const int key = g->seg_plans_key | (burnin ? 8 : 0) | (p2p ? 16 : 0) | (fuse ? 32 : 0);
         if (all_tab && left >= NSK_GRAPH_SWEEPS) {
             if (g->sweep_graph_key != key && !g->sweep_graph_off) {
                 rc = g->c.vbytes == 1 ? graph_build<int8_t>(g, sample_evidence, burnin, p2p, key)
@@ -327,10 +387,10 @@ int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin
             HIPCHECK(hipGetLastError());
         }
     }
-    for (; left > 0; left--) {              // the rest eagerly (one sweep at a time when exchanging)
-        int rc = gibbs_eager(g, p2p ? 1 : left, sample_evidence, burnin);
+    for (; left > 0; left--) {              // the rest eagerly (one sweep at a time when exchanging with kernels of their own)
+        int rc = gibbs_eager(g, (p2p && !fuse) ? 1 : left, sample_evidence, burnin);
         if (rc) return rc;
-        if (!p2p) break;
+        if (!p2p || fuse) break;
         if ((rc = nsk_p2p_enqueue(g, nullptr, 0))) return rc;
     }
     return NSK_OK;

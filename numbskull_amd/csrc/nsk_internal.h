@@ -131,6 +131,18 @@ struct nsk_graph {
     unsigned int p2p_peer_mask = 0, p2p_tag = 0;
     unsigned long long p2p_timeout_ticks = 3000000000ull;      // 30 s of the 100 MHz wall clock (NSK_P2P_TIMEOUT_S)
     bool p2p_ready = false;
+    // Fused boundary exchange of the table launches (nsk_api.hip p2p_fuse_plan, nsk_kernels_gibbs.h TabP2P): the
+    // inference sweeps of a handle that lives in table segments read their ghosts from the receive block and
+    // push their boundary values from inside the class launches -- no exchange kernels per sweep
+    bool p2p_fused = false;                 // the handle qualifies (decided when the peers' buffers are imported)
+    bool p2p_fused_now = false;             // ... and the running nsk_gibbs_sweeps_p2p call sweeps that way
+    bool p2p_close_pending = false;         // the closing wait + unpack of the last fused sweep is not enqueued yet
+    std::vector<int32_t> p2p_border_tiles;  // sorted: tiles (position >> 6) that own a value a peer reads or read a ghost;
+                                            //   a tile's rank here is its row in the push map
+    uint32_t *p2p_push_map = nullptr;       // [rows][64] reader << 28 | index in the reader's receive block; NSK_NO_STREAM
+    uint32_t p2p_ghost_lo = 0, p2p_border_total = 0;   // first ghost id; border tiles one sweep of the current plans samples
+    bool p2p_border_all = true;             // ... and that is every border tile (else the call takes the exchange kernels)
+    std::vector<int32_t> p_send_host, p_recv_host;      // the send / receive lists (internal ids), host copies
     // native RCCL
     void *rccl_lib = nullptr, *rccl_comm = nullptr;
     long long *cnt_total = nullptr, *G = nullptr;
@@ -264,6 +276,11 @@ int nsk_ensure_lag_sets(nsk_graph *g);                 // second set of weights 
 // pushes only, 2 = wait + unpack (+ the owner's half of the weight merge), 3 = the closing half of the
 // weight merge (nsk_api.hip)
 int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned int tag_off, bool learn = false, int part = 0);
+bool nsk_tables_only(const nsk_graph *g);           // every sampled variable lives in a table segment (nsk_api.hip)
+void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence);    // nsk_gibbs.hip
+int nsk_p2p_ghost_pack(nsk_graph *g);
+int nsk_p2p_flush(nsk_graph *g);                   // enqueue the pending closing wait + unpack of a fused sweep sequence, if any
+void nsk_p2p_fill(nsk_graph *g, nsk::TabP2P &px, const unsigned long long *tag_base, unsigned int tag);   // kernel argument of a fused launch
 void nsk_drop_sweep_graph(nsk_graph *g);            // the captured sweep sequence bakes exchange pointers: drop it when they change
 int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p);   // nsk_gibbs.hip
 void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);

@@ -1422,7 +1422,9 @@ struct SegEntry {                         // 48 bytes: two scalar loads per tile
     uint32_t ntiles_lead;                 // table launches: tiles of the segment | lead << 30 (dead virtual
                                           //   tiles in front: the segment does not start a quad)
     uint32_t aff_off;                     // first entry of the segment's tiles in seg_aff, NSK_NO_STREAM: none
-    uint32_t pad_[4];
+    uint32_t push_off;                    // fused boundary exchange (TabP2P): first row of the segment's tiles in the
+                                          //   push map, NSK_NO_STREAM: no tile of the segment touches the boundary
+    uint32_t pad_[3];
 };
 struct SegTable {
     int n, ntiles;                        // segments, tiles of the launch; e[i].tile_start = ntiles for i >= n
@@ -1551,16 +1553,65 @@ __device__ __forceinline__ unsigned long long ztab_K(const uint4 &e) { return ((
 //   tally fold skips them.
 // Round 2/3: instruction issue bounds the kernel, 63 of its 107 vector instructions
 // per tile pair were the Philox rounds.
+// ---- fused boundary exchange of a shard's table launches (N ranks, peer to peer; nsk_api.hip p2p_fuse_plan) ----
+// The shard's ghosts are read straight from its receive block of the exchange allocation (parity of the last
+// exchange) and the border tiles write their new values into the readers' blocks themselves (the other parity):
+// a sweep of a shard is its class launches and nothing else -- no push, wait or unpack kernels.  Segments are
+// split so that tiles that touch the boundary (own a value a peer reads, or read a ghost) form segments of their
+// own (SegEntry.push_off): their waves wait for the peers' flags of the previous exchange before they read,
+// interior tiles never wait; the wave that completes the sweep's last border tile raises this rank's flag at the
+// peers.  Ghost values are one sweep old inside a sweep, as with the exchange kernels (and the reference's
+// distributed loop, salt/src/numbskull_master.py:165-224): same samples, bit for bit.
+struct TabP2P {
+    const void *mine;                   // this rank's exchange allocation (flags | receive blocks | ...)
+    void *peer[16];                     // the peers' allocations
+    unsigned long long dtotal[16];      // length of peer q's per-chain receive block
+    const uint32_t *push_map;           // per border tile and lane: reader << 28 | index in the reader's block; NSK_NO_STREAM
+    unsigned int *counter;              // border tiles done in the running sweep
+    unsigned int *err;
+    const unsigned long long *tag_base; // captured launches: tag = tag_base[1] + tag
+    unsigned long long timeout_ticks;
+    uint32_t ghost_lo, nrecv;           // internal id of the first ghost = element 0 of the receive block
+    uint32_t border_total;              // border tiles of one sweep, all classes
+    uint32_t tag;                       // this sweep's exchange tag
+    uint32_t peer_mask;
+    int world, me;
+};
+__host__ __device__ inline size_t nsk_p2p_recv_off_(int world) { return ((size_t)(4 * world) * 4 + 255) / 256 * 256; }   // = nsk_p2p_recv_off
+
 #ifndef NSK_TAB_BATCH
 #define NSK_TAB_BATCH 4       // tiles of a quad whose loads are in flight together (4: the whole quad; 2: pair by pair)
 #endif
 // NT consecutive tiles of one quad, first tile = segment tile `t0` (word `w0` of the quad's blocks): every
 // load of the NT tiles is requested before the first draw, the draws' stores come last
-template <typename VT, int NCH, int NT>
+template <typename VT, int NCH, int NT, bool P2P>
 __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry &en, int t0, int w0, int lane, int burnin,
                                           const u32x4 &ra, u32x4 &rb, bool &have_b, uint32_t qb,
-                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1, const TabP2P &px, uint32_t ptag) {
     const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
+    const bool border = P2P && en.push_off != NSK_NO_STREAM;           // (wave-uniform)
+    const VT *ghost = nullptr;
+    if (P2P) {
+        // ghosts: this rank's receive block of the previous exchange (tag - 1); a border wave first waits for
+        // the peers' flags of that exchange (bounded), then takes a system-scope acquire fence
+        ghost = (const VT *)((const char *)px.mine + nsk_p2p_recv_off_(px.world)) + (size_t)((ptag - 1u) & 1u) * 2 * (size_t)px.nrecv;
+        if (border) {
+            if (lane == 0) {
+                const unsigned int *flags = (const unsigned int *)px.mine + (size_t)((ptag - 1u) & 1u) * 2 * (size_t)px.world;
+                const unsigned long long tw0 = wall_clock64();
+                bool ok = true;
+                for (int q = 0; q < px.world && ok; q++) {
+                    if (!((px.peer_mask >> q) & 1u)) continue;
+                    while (__hip_atomic_load(flags + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ptag - 1u) {
+                        if (wall_clock64() - tw0 > px.timeout_ticks) { ok = false; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                if (!ok) (void)__hip_atomic_fetch_or(px.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        }
+    }
     const bool haff = en.aff_off != NSK_NO_STREAM;                      // implicit adjacency (nsk_compile.h seg_aff)
     const uint32_t zoff = en.zoff, zmask = en.zmask_ev & 0xFFu;
     bool live[NT];
@@ -1606,8 +1657,29 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         idx[k] = 0;
+        if (!P2P) {
 #pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
+            for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
+        } else if (ab[k][0] != NSK_NO_STREAM) {          // implicit adjacency: a slot's run lies in the values or in the ghosts
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) {
+                const uint32_t b = ab[k][j], gb = b - px.ghost_lo;                  // (ghost ids: [ghost_lo, ghost_lo + nrecv))
+                if (gb + 63u < px.nrecv && gb < px.nrecv) {                        // scalar: the whole run is ghosts
+                    idx[k] |= (uint32_t)(uint8_t)(ghost + gb)[lane] << j;
+                } else if (b + 63u < px.ghost_lo || gb >= px.nrecv) {              // scalar: none of it
+                    idx[k] |= (uint32_t)(uint8_t)(g.val + b)[lane] << j;
+                } else {
+                    const uint32_t i = id[k][j];
+                    idx[k] |= (uint32_t)(uint8_t)(i - px.ghost_lo < px.nrecv ? ghost[i - px.ghost_lo] : g.val[i]) << j;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) {
+                const uint32_t i = id[k][j];
+                idx[k] |= (uint32_t)(uint8_t)(i - px.ghost_lo < px.nrecv ? ghost[i - px.ghost_lo] : g.val[i]) << j;
+            }
+        }
     }
     uint2 e[NT];
 #pragma unroll
@@ -1637,16 +1709,46 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
             *td = (uint8_t)(tally[k] + nv[k]);
         }
     }
+    if (border) {
+        // the boundary values of these tiles into their readers' receive blocks (this exchange's parity); then the
+        // tiles are counted, and the wave that completes the sweep's last border tile raises the flags
+        uint32_t nlive = 0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            if (!live[k]) continue;                                     // wave-uniform
+            nlive++;
+            const uint32_t pm = px.push_map[((size_t)en.push_off + (size_t)(t0 + k)) * 64 + lane];
+            for (int q = 0; q < px.world; q++) {
+                if (!((px.peer_mask >> q) & 1u)) continue;              // (scalar loop: a shard of a grid has two readers)
+                VT *dst = (VT *)((char *)px.peer[q] + nsk_p2p_recv_off_(px.world)) + (size_t)(ptag & 1u) * 2 * (size_t)px.dtotal[q];
+                if (pm != NSK_NO_STREAM && (int)(pm >> 28) == q) dst[pm & 0x0FFFFFFFu] = (VT)nv[k];
+            }
+        }
+        __threadfence_system();
+        if (lane == 0) {
+            const unsigned int old = __hip_atomic_fetch_add(px.counter, nlive, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + nlive == px.border_total) {
+                __hip_atomic_store(px.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                for (int q = 0; q < px.world; q++)
+                    if ((px.peer_mask >> q) & 1u)
+                        __hip_atomic_store((unsigned int *)px.peer[q] + (size_t)(ptag & 1u) * 2 * (size_t)px.world + (size_t)px.me, ptag,
+                                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // The quads of an XCD's eighth are dealt to its waves in whole rounds -- a wave's trip is a quad --; what is
 // left after the last whole round (fewer quads than waves) is dealt as tile PAIRS, two waves to a quad (each
 // evaluates the quad's block): the closing trip of a launch is then half as long, and a launch with fewer
 // quads than waves (small grids: one wave lifetime long) runs entirely in pairs.
-template <typename VT, int NCH>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
-                                                             uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
-                                                             const unsigned long long *sweep_base, uint32_t sweep_off) {
+template <typename VT, int NCH, bool P2P>
+__device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const SegTable &tab, int burnin,
+                                                   uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
+                                                   const unsigned long long *sweep_base, uint32_t sweep_off, const TabP2P &px) {
+    uint32_t ptag = P2P ? px.tag : 0u;
+    if (P2P && px.tag_base) ptag += (uint32_t)((const NSK_SCALAR unsigned long long *)px.tag_base)[1];
     if (sweep_base) {             // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
         const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
         const unsigned long long sw = cb[0] + sweep_off, key = cb[2];
@@ -1690,14 +1792,29 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
         u32x4 rb = {0u, 0u, 0u, 0u};
         bool have_b = false;
         if (h >= 0) {                                                   // wave-uniform
-            tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            tab_tiles<VT, NCH, 2, P2P>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         } else if (NSK_TAB_BATCH == 4) {
-            tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            tab_tiles<VT, NCH, 4, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         } else {
-            tab_tiles<VT, NCH, 2>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
-            tab_tiles<VT, NCH, 2>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            tab_tiles<VT, NCH, 2, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
+            tab_tiles<VT, NCH, 2, P2P>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         }
     }
+}
+template <typename VT, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
+                                                             uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
+                                                             const unsigned long long *sweep_base, uint32_t sweep_off) {
+    TabP2P none;                                                        // (unused: P2P = false)
+    none.tag = 0u; none.tag_base = nullptr;
+    gibbs_seg_tab_body<VT, NCH, false>(g, tab, burnin, k0, k1, s0, s1, sweep_base, sweep_off, none);
+}
+// the same for a shard that exchanges its boundary inside the launch (TabP2P)
+template <typename VT, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab_p2p(DevGraph<VT> g, SegTable tab, int burnin,
+                                                                 uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
+                                                                 const unsigned long long *sweep_base, uint32_t sweep_off, TabP2P px) {
+    gibbs_seg_tab_body<VT, NCH, true>(g, tab, burnin, k0, k1, s0, s1, sweep_base, sweep_off, px);
 }
 
 template <typename VT, int KIND, int NCH>

@@ -359,6 +359,7 @@ extern "C" int nsk_learn_sweeps(nsk_graph *g, int64_t nsweeps, double step, doub
                                  "accumulator (|featureValue| x visits >= 2^62); rescale featureValue or "
                                  "use the sequential scan");
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     return g->c.vbytes == 1
                ? learn_impl<int8_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence)
                : learn_impl<int32_t>(g, nsweeps, step, decay, regularization, reg_param, truncation, learn_non_evidence);

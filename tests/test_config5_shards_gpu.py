@@ -90,7 +90,7 @@ def wire_p2p(parts):
     return needs
 
 
-def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
+def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1), fused=False):
     import torch
     from numbskull_amd.distributed import shard_range, plan_pairs
     seed = 20240601
@@ -110,7 +110,15 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
     # processes with queues of their own: tests/test_multirank_gpu.py runs those loops as they are)
     step, decay = hyper[0], hyper[1]
     st = step
-    for s in range(nsweeps):
+    if fused:
+        # the shard's own loop, nsk_gibbs_sweeps_p2p: a shard that lives in table segments exchanges its boundary
+        # INSIDE its class launches (border tiles read the receive block and write into the readers'; no exchange
+        # kernels).  One sweep per call, breadth-first: a call right behind a fused call continues it
+        assert not learn and all(p.fg.info()["p2p_fused"] == 1 for p in parts), "the shards do not qualify for the fused exchange"
+        for s in range(nsweeps):
+            for p in parts:
+                _lib.check(L.nsk_gibbs_sweeps_p2p(p.h, 1, 1, 0))
+    for s in range(0 if fused else nsweeps):
         for p in parts:
             if learn:
                 _lib.check(L.nsk_learn_sweeps(p.h, 1, st, 1.0, hyper[2], hyper[3], hyper[4], 0))
@@ -174,6 +182,32 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1)):
     # phase timings per shard: the sweep kernels alone, then all pushes, then all flag/wait/unpack
     # (+ weight merge) kernels -- each rank's bracket on its own stream, marked first, read afterwards
     timing = {"sweep_us": [], "push_us": [], "wait_unpack_us": [], "gather_w_us": []}
+    if fused:
+        # a fused sweep is its class launches and nothing else: timed per shard over consecutive one-sweep calls
+        ms, nl = C.c_double(), C.c_int64()
+        for rep in range(6):
+            row = []
+            for p in parts:
+                _lib.check(L.nsk_profile_begin(p.h))
+                _lib.check(L.nsk_gibbs_sweeps_p2p(p.h, 1, 1, 1))
+                _lib.check(L.nsk_profile_mark(p.h))
+            for p in parts:
+                _lib.check(L.nsk_profile_read(p.h, C.byref(ms), C.byref(nl)))
+                row.append(ms.value * 1e3)
+            timing["sweep_us"].append(row)
+        for p in parts:
+            p.check()
+        out = {"config": "%s in 8 range shards, all on one MI355X, inference, boundary exchange fused into the class launches" % tag,
+               "per_shard_us": {"sweep_incl_exchange_us": {"mean": float(np.mean(timing["sweep_us"][1:])), "max": float(np.max(timing["sweep_us"][1:]))}},
+               "launches_per_sweep": int(nl.value),
+               "note": "one shard's class launches (HIP events on the shard's stream, one launch latency included); border tiles "
+                       "push into the readers' receive blocks and raise the flags themselves, the next sweep's border tiles wait"}
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/config5_shards_%s_inference_fused.json" % tag.split()[0], "w") as f:
+            json.dump(out, f, indent=1)
+        for p in parts:
+            p.fg.close()
+        return out
     ms, nl = C.c_double(), C.c_int64()
     for _ in range(3):
         row = []
@@ -225,6 +259,12 @@ def test_lr5m_eight_shards_p2p_match_emulation(learn):
 @pytest.mark.parametrize("learn", [False, True])
 def test_grid10m_eight_shards_p2p_match_emulation(learn):
     run_case("grid", (2500, 4000), learn, "ising10m (2500x4000 grid)", hyper=(1e-7, 0.95, 2, 0.01, 1))
+
+
+def test_grid10m_eight_shards_fused_exchange_matches_emulation():
+    """Config #4 through the shards' own loop: the boundary exchange rides in the table launches."""
+    out = run_case("grid", (2500, 4000), False, "ising10m (2500x4000 grid)", nsweeps=5, fused=True)
+    assert out["launches_per_sweep"] == 2, out
 
 
 def test_lr50m_eight_shards_learning_p2p():
