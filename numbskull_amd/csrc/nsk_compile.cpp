@@ -571,7 +571,11 @@ static int build_ep_groups(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
         // lie in; member ids inside the kept chunks become offsets into the group's LDS copy
         c.ep_win.clear();
         c.ep_win_off.assign((size_t)ngroups + 1, 0u);
+#ifdef NSK_EP_WIN
         const bool want_win = ngroups > 0 && c.vbytes == 1 && !diag_env("NSK_NO_EP_WIN") && c.nid < (int64_t)NSK_EP_WIN_BASE;
+#else
+        const bool want_win = false;            // (measured and not kept: nsk_compile.h ep_win)
+#endif
         if (want_win) {
             std::vector<std::vector<uint32_t>> kept((size_t)ngroups);
             std::vector<int64_t> st((size_t)compile_threads() * 2, 0);     // members in a window / members

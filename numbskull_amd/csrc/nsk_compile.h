@@ -15,6 +15,7 @@
 
 #define NSK_LEARN_SEG_LAUNCHES 4       // segment launches of the learning sweep per colour class
 #define NSK_GEN_NULL 0x7FFFFFFu     // member id of an empty slot in a general tile (kind 6)
+// (value windows of the entry-parallel groups: measured and NOT kept -- compiled in only with -DNSK_EP_WIN, see ep_win below)
 #define NSK_EP_WIN_CHUNKS 512       // 16-byte chunks of a group's value window (8 KB per chain in LDS)
 #define NSK_EP_WIN_BASE 0x7FF0000u  // member ids from here on (below NSK_GEN_NULL) are offsets into the window
 
@@ -150,14 +151,16 @@ struct Compiled {
     // slot, row-major: the inference kernels read an entry's weight next to its words; refreshed
     // whenever weights change); ep_wrow[ngroups] = rows in total
     std::vector<uint32_t> ep_desc, ep_adj, ep_wrow;
-    // Value windows of the groups (int8 values only): the members of a group's entries lie -- the generator's
-    // and most real graphs' locality -- in a few short runs of every other colour.  ep_win[ep_win_off[g] ..
-    // ep_win_off[g + 1]) lists the 16-byte chunks (internal id >> 4) that hold them, ascending, at most
-    // NSK_EP_WIN_CHUNKS; the kernels copy them into LDS once per group (both chains) and a member word whose id
-    // field is NSK_EP_WIN_BASE + o reads byte o of that copy instead of gathering from the value array (a
-    // group's 1500 byte gathers re-fetched its ~100 value lines from a thrashed L2 again and again: 1.8 of
-    // the 5.5 GB a 50M-variable learning class read).  Members outside the kept chunks (the generator's 1 %
-    // of global edges) keep their internal id and are gathered as before.
+    // Value windows of the groups (int8 values only; -DNSK_EP_WIN builds, NSK_DIAG=1 NSK_NO_EP_WIN=1 switches them
+    // off again): the members of a group's entries lie in a few short runs of every other colour.  ep_win[
+    // ep_win_off[g] .. ep_win_off[g + 1]) lists the 16-byte chunks (internal id >> 4) that hold them, ascending, at
+    // most NSK_EP_WIN_CHUNKS; the kernels copy them into LDS once per group (both chains) and a member word whose
+    // id field is NSK_EP_WIN_BASE + o reads byte o of that copy instead of gathering from the value array.
+    // MEASURED, round 5 (tools/sessions/r5_s02.sh; 91 % of the LR graphs' members inside a 512-chunk window): no
+    // fewer bytes fetched (inference 50M: FETCH_SIZE 6.93e5 against 6.95e5 -- the value lines were never what
+    // missed; what the value gathers cost the learning launch is L2 room for the 8 MB weight table) and slower
+    // launches (5M LR: inference 50.8 -> 52.0 us per class, learning 114.5 -> 120.6; 50M inference 468 -> 497):
+    // the 8 / 16 KB of LDS per workgroup cost more residency than the LDS reads save.  Not in the default build.
     std::vector<uint32_t> ep_win, ep_win_off;
     // Structural visit counts of the entry-parallel groups (learning): an entry of a dataType-0 variable
     // is visited by sample_and_sgd in EVERY sweep its variable takes part in (learning.py:76-95: one

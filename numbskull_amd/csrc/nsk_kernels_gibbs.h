@@ -1034,6 +1034,11 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
 // their gathers are issued together and waited for once.
 // (measured on the 5M LR graph, per class: inference U = 1 58.5 us, 2 63.8, 3 64.9 -- the single-chain walk
 // keeps 6 waves per SIMD; learning, whose rows carry two chains, U = 1 159.8, 2 149.4, 3 164.2)
+#ifdef NSK_EP_WIN
+#define NSK_EP_WIN_ON true
+#else
+#define NSK_EP_WIN_ON false         // (value windows: measured, not in the default build -- nsk_compile.h ep_win)
+#endif
 // wa / wb: the group's value windows in LDS (ep_stage_window; `win`: in use) -- a member word whose id field is
 // NSK_EP_WIN_BASE + o reads byte o of the window instead of gathering from the value array
 template <typename VT, bool TWO, int WMODE, bool NT, bool MEMBERS, int U, typename FN>
@@ -1066,12 +1071,14 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
 #ifdef NSK_ABL_EPNOW
             w[u] = WMODE ? __longlong_as_double(0x3FB0000000000000ll | (long long)cur[u].w0) : 0.0;
 #else
-            // (learning gathers the weight: a table beyond the L2s is streamed through them -- non-temporal, so
-            // that its lines do not push the value lines and the rows out)
-#ifdef NSK_EP_W_TEMPORAL
-            w[u] = WMODE == 1 ? g.w[NSK_EP_WID(cur[u].w0)] : (WMODE == 2 ? wc[u] : 0.0);
-#else
+            // (learning gathers the weight -- 68 % of the bytes a 50M-variable class fetches: the 8 MB table does
+            // not stay in a 4 MB L2 next to the rows and values.  A non-temporal gather, so that the weight lines
+            // would at least not evict the others, was measured (-DNSK_EP_W_NT, tools/sessions/r5_s02.sh): 5M LR
+            // 120.6 -> 144.1 us per class, 50M 1088 -> 1306 -- the hot low ids DO hit the L2 when they may stay)
+#ifdef NSK_EP_W_NT
             w[u] = WMODE == 1 ? __builtin_nontemporal_load(g.w + NSK_EP_WID(cur[u].w0)) : (WMODE == 2 ? wc[u] : 0.0);
+#else
+            w[u] = WMODE == 1 ? g.w[NSK_EP_WID(cur[u].w0)] : (WMODE == 2 ? wc[u] : 0.0);
 #endif
 #endif
             if (MEMBERS) {
@@ -1084,7 +1091,7 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
                         xa[u][m] = (int)(at & 1u);
                         if (TWO) xb[u][m] = (int)((at >> 1) & 1u);
 #else
-                        if (sizeof(VT) == 1 && win && id >= NSK_EP_WIN_BASE && id != NSK_GEN_NULL) {     // in the group's window
+                        if (NSK_EP_WIN_ON && sizeof(VT) == 1 && win && id >= NSK_EP_WIN_BASE && id != NSK_GEN_NULL) {     // in the group's window
                             xa[u][m] = (int)wa[id - NSK_EP_WIN_BASE];
                             if (TWO) xb[u][m] = (int)wb[id - NSK_EP_WIN_BASE];
                         } else {
@@ -1121,7 +1128,7 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
 // per thread and trip.  The caller's next barrier publishes it; nobody may still be reading the previous one.
 template <typename VT, bool TWO>
 __device__ __forceinline__ void ep_stage_window(const DevGraph<VT> &g, int gidx, nsk_u32x4 *wa, nsk_u32x4 *wb) {
-    if (sizeof(VT) != 1 || !g.ep_win) return;
+    if (!NSK_EP_WIN_ON || sizeof(VT) != 1 || !g.ep_win) return;
     const NSK_SCALAR uint32_t *op = (const NSK_SCALAR uint32_t *)(g.ep_win_off + gidx);
     const uint32_t o0 = op[0], n = op[1] - o0;
     for (uint32_t i = threadIdx.x; i < n; i += NSK_BLOCK) {
@@ -1130,7 +1137,11 @@ __device__ __forceinline__ void ep_stage_window(const DevGraph<VT> &g, int gidx,
         if (TWO) wb[i] = *((const nsk_u32x4 *)g.val_evid + c);
     }
 }
+#ifdef NSK_EP_WIN
 #define NSK_EP_WIN_LDS(VT) (sizeof(VT) == 1 ? NSK_EP_WIN_CHUNKS : 1)
+#else
+#define NSK_EP_WIN_LDS(VT) 1          // (value windows are not in the default build: nsk_compile.h ep_win)
+#endif
 
 // ep_wt row <- the weights its entries name (run whenever weights may have changed, before an
 // inference call): one workgroup per group, its rows dealt to the waves
@@ -1553,6 +1564,32 @@ __device__ __forceinline__ unsigned long long ztab_K(const uint4 &e) { return ((
 //   tally fold skips them.
 // Round 2/3: instruction issue bounds the kernel, 63 of its 107 vector instructions
 // per tile pair were the Philox rounds.
+// Buffer addressing for the table kernels: base (128-bit descriptor in scalar registers) + a SCALAR offset + a
+// per-lane offset.  A tile's member run "base of the slot + lane", its tally bytes and its stores are then
+// addressed without a single vector instruction (the flat form cost one v_add per gather and, for the stores
+// that a dead tile of a quad must not perform, a 64-bit add and two selects each: 64 of the 175 vector
+// instructions of a quad, ISA count round 5), and a store with an out-of-range lane offset is dropped by the
+// hardware's bounds check -- which is how dead tiles skip theirs.
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void *)nullptr, (short)0, 0, 0)) nsk_rsrc;
+#define NSK_BUF_OOB 0xFFFFFFFFu            // >= num_records of every descriptor below
+__device__ __forceinline__ nsk_rsrc nsk_make_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, (short)0, (int)0xFFFFFFFFu, 0x00020000);
+}
+template <typename VT> __device__ __forceinline__ uint32_t nsk_buf_ld(nsk_rsrc r, uint32_t voff, uint32_t soff);      // low byte of element
+template <> __device__ __forceinline__ uint32_t nsk_buf_ld<signed char>(nsk_rsrc r, uint32_t voff, uint32_t soff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)voff, (int)soff, 0);
+}
+template <> __device__ __forceinline__ uint32_t nsk_buf_ld<int32_t>(nsk_rsrc r, uint32_t voff, uint32_t soff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)(voff * 4u), (int)(soff * 4u), 0) & 0xFFu;
+}
+template <typename VT> __device__ __forceinline__ void nsk_buf_st(nsk_rsrc r, uint32_t voff, uint32_t soff, int x);
+template <> __device__ __forceinline__ void nsk_buf_st<signed char>(nsk_rsrc r, uint32_t voff, uint32_t soff, int x) {
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)x, r, (int)voff, (int)soff, 0);
+}
+template <> __device__ __forceinline__ void nsk_buf_st<int32_t>(nsk_rsrc r, uint32_t voff, uint32_t soff, int x) {
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)x, r, (int)(voff == NSK_BUF_OOB ? voff : voff * 4u), (int)(soff * 4u), 0);
+}
+
 // ---- fused boundary exchange of a shard's table launches (N ranks, peer to peer; nsk_api.hip p2p_fuse_plan) ----
 // The shard's ghosts are read straight from its receive block of the exchange allocation (parity of the last
 // exchange) and the border tiles write their new values into the readers' blocks themselves (the other parity):
@@ -1614,17 +1651,16 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     }
     const bool haff = en.aff_off != NSK_NO_STREAM;                      // implicit adjacency (nsk_compile.h seg_aff)
     const uint32_t zoff = en.zoff, zmask = en.zmask_ev & 0xFFu;
+    const nsk_rsrc rv = nsk_make_rsrc(g.val), rc = nsk_make_rsrc(g.cnt_pos);
     bool live[NT];
-    int p[NT], pl[NT], tt[NT];
-    uint8_t tally[NT];
+    int tt[NT];
+    uint32_t tally[NT];
     uint32_t id[NT][4 * NCH], ab[NT][4 * NCH];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int t = t0 + k;
         live[k] = t >= 0 && t < nt;                                     // wave-uniform
         tt[k] = live[k] ? t : (t < 0 ? 0 : nt - 1);                     // (a dead tile reads a real one's data)
-        p[k] = en.pos0 + t * 64 + lane;
-        pl[k] = en.pos0 + tt[k] * 64 + lane;
         ab[k][0] = NSK_NO_STREAM;
     }
     if (haff) {                        // the tiles' slot bases: scalar loads, issued together
@@ -1636,13 +1672,11 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
         }
     }
 #pragma unroll
-    for (int k = 0; k < NT; k++) tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[k]];
+    for (int k = 0; k < NT; k++)
+        tally[k] = burnin ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, en.pos0 + tt[k] * 64, 0);
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        if (ab[k][0] != NSK_NO_STREAM) {                                // wave-uniform: member = base + lane
-#pragma unroll
-            for (int j = 0; j < 4 * NCH; j++) id[k][j] = ab[k][j] + (uint32_t)lane;
-        } else {
+        if (ab[k][0] == NSK_NO_STREAM) {                                // wave-uniform: the tile reads its stream
             const uint4 *sp = g.adj + en.adj_off + (size_t)tt[k] * (64 * NCH) + lane;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
@@ -1657,27 +1691,30 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         idx[k] = 0;
-        if (!P2P) {
-#pragma unroll
-            for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
-        } else if (ab[k][0] != NSK_NO_STREAM) {          // implicit adjacency: a slot's run lies in the values or in the ghosts
+        if (ab[k][0] != NSK_NO_STREAM) {                 // implicit adjacency: member = base of the slot (scalar) + lane
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
-                const uint32_t b = ab[k][j], gb = b - px.ghost_lo;                  // (ghost ids: [ghost_lo, ghost_lo + nrecv))
-                if (gb + 63u < px.nrecv && gb < px.nrecv) {                        // scalar: the whole run is ghosts
-                    idx[k] |= (uint32_t)(uint8_t)(ghost + gb)[lane] << j;
-                } else if (b + 63u < px.ghost_lo || gb >= px.nrecv) {              // scalar: none of it
-                    idx[k] |= (uint32_t)(uint8_t)(g.val + b)[lane] << j;
-                } else {
-                    const uint32_t i = id[k][j];
-                    idx[k] |= (uint32_t)(uint8_t)(i - px.ghost_lo < px.nrecv ? ghost[i - px.ghost_lo] : g.val[i]) << j;
+                const uint32_t b = ab[k][j];
+                if (!P2P) {
+                    idx[k] |= nsk_buf_ld<VT>(rv, (uint32_t)lane, b) << j;
+                } else {                                 // ... a run of the values or of the ghosts ([ghost_lo, ghost_lo + nrecv))
+                    const uint32_t gb = b - px.ghost_lo;
+                    if (gb + 63u < px.nrecv && gb < px.nrecv) {                        // scalar: the whole run is ghosts
+                        idx[k] |= (uint32_t)(uint8_t)(ghost + gb)[lane] << j;
+                    } else if (b + 63u < px.ghost_lo || gb >= px.nrecv) {              // scalar: none of it
+                        idx[k] |= nsk_buf_ld<VT>(rv, (uint32_t)lane, b) << j;
+                    } else {
+                        const uint32_t i = b + (uint32_t)lane;
+                        idx[k] |= (uint32_t)(uint8_t)(i - px.ghost_lo < px.nrecv ? ghost[i - px.ghost_lo] : g.val[i]) << j;
+                    }
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
                 const uint32_t i = id[k][j];
-                idx[k] |= (uint32_t)(uint8_t)(i - px.ghost_lo < px.nrecv ? ghost[i - px.ghost_lo] : g.val[i]) << j;
+                if (!P2P) idx[k] |= nsk_buf_ld<VT>(rv, i, 0u) << j;
+                else idx[k] |= (uint32_t)(uint8_t)(i - px.ghost_lo < px.nrecv ? ghost[i - px.ghost_lo] : g.val[i]) << j;
             }
         }
     }
@@ -1702,12 +1739,12 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     }
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        VT *dst = live[k] ? g.val + p[k] : (VT *)g.sink + lane;         // (no branch: see seg_of_tile's note)
-        *dst = (VT)nv[k];
-        if (!burnin) {
-            uint8_t *td = live[k] ? g.cnt_pos + p[k] : g.sink + 256 + lane;
-            *td = (uint8_t)(tally[k] + nv[k]);
-        }
+        // a dead tile's stores carry an out-of-range lane offset: dropped by the bounds check (no branch, no select
+        // of addresses)
+        const uint32_t voff = live[k] ? (uint32_t)lane : NSK_BUF_OOB;
+        const uint32_t soff = live[k] ? (uint32_t)(en.pos0 + (t0 + k) * 64) : 0u;
+        nsk_buf_st<VT>(rv, voff, soff, nv[k]);
+        if (!burnin) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(tally[k] + (uint32_t)nv[k]), rc, (int)voff, (int)soff, 0);
     }
     if (border) {
         // the boundary values of these tiles into their readers' receive blocks (this exchange's parity); then the
