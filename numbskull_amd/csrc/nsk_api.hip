@@ -1150,6 +1150,23 @@ static int p2p_fuse_plan(nsk_graph *g) {
     }
     std::sort(tiles.begin(), tiles.end());
     tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+    // fewer, longer runs (a launch carries at most NSK_SEG_MAX segment entries): a short segment with a border
+    // tile is border as a whole, and so are gaps of a few tiles between border tiles of one segment -- such a tile
+    // pushes nothing (its row of the map is empty), it only waits and counts like its neighbours
+    {
+        std::vector<int32_t> extra;
+        for (const nsk::Compiled::Segment &sg : c.segments) {
+            const int32_t f = (int32_t)(sg.pos0 / 64), e = f + sg.ntiles;
+            auto lo = std::lower_bound(tiles.begin(), tiles.end(), f), hi = std::lower_bound(tiles.begin(), tiles.end(), e);
+            if (lo == hi) continue;
+            if (sg.ntiles <= 64) { for (int32_t t = f; t < e; t++) extra.push_back(t); continue; }
+            for (auto it = lo; it + 1 < hi; ++it)
+                if (it[1] - it[0] > 1 && it[1] - it[0] <= 16) for (int32_t t = it[0] + 1; t < it[1]; t++) extra.push_back(t);
+        }
+        tiles.insert(tiles.end(), extra.begin(), extra.end());
+        std::sort(tiles.begin(), tiles.end());
+        tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+    }
     std::vector<uint32_t> pm(tiles.size() * 64, 0xFFFFFFFFu);
     for (int q = 0; q < g->pworld; q++)
         for (int64_t k = g->p_soff[q]; k < g->p_soff[q + 1]; k++) {

@@ -1582,6 +1582,24 @@ template <> __device__ __forceinline__ uint32_t nsk_buf_ld<signed char>(nsk_rsrc
 template <> __device__ __forceinline__ uint32_t nsk_buf_ld<int32_t>(nsk_rsrc r, uint32_t voff, uint32_t soff) {
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)(voff * 4u), (int)(soff * 4u), 0) & 0xFFu;
 }
+// system-coherent flavours (cache policy sc0 sc1): what a peer wrote is read from / what a peer will read is
+// written through to memory, whatever this device's caches hold -- no acquire / release fence (a system-scope fence
+// invalidates / writes back whole caches: with one per border wave a shard's class launch took 27 instead of 7 us)
+#define NSK_AUX_SYS 17
+template <typename VT> __device__ __forceinline__ uint32_t nsk_buf_ld_sys(nsk_rsrc r, uint32_t voff, uint32_t soff);
+template <> __device__ __forceinline__ uint32_t nsk_buf_ld_sys<signed char>(nsk_rsrc r, uint32_t voff, uint32_t soff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)voff, (int)soff, NSK_AUX_SYS);
+}
+template <> __device__ __forceinline__ uint32_t nsk_buf_ld_sys<int32_t>(nsk_rsrc r, uint32_t voff, uint32_t soff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)(voff * 4u), (int)(soff * 4u), NSK_AUX_SYS) & 0xFFu;
+}
+template <typename VT> __device__ __forceinline__ void nsk_buf_st_sys(nsk_rsrc r, uint32_t voff, int x);
+template <> __device__ __forceinline__ void nsk_buf_st_sys<signed char>(nsk_rsrc r, uint32_t voff, int x) {
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)x, r, (int)voff, 0, NSK_AUX_SYS);
+}
+template <> __device__ __forceinline__ void nsk_buf_st_sys<int32_t>(nsk_rsrc r, uint32_t voff, int x) {
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)x, r, (int)(voff == NSK_BUF_OOB ? voff : voff * 4u), 0, NSK_AUX_SYS);
+}
 template <typename VT> __device__ __forceinline__ void nsk_buf_st(nsk_rsrc r, uint32_t voff, uint32_t soff, int x);
 template <> __device__ __forceinline__ void nsk_buf_st<signed char>(nsk_rsrc r, uint32_t voff, uint32_t soff, int x) {
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)x, r, (int)voff, (int)soff, 0);
@@ -1627,11 +1645,12 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
                                           uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1, const TabP2P &px, uint32_t ptag) {
     const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
     const bool border = P2P && en.push_off != NSK_NO_STREAM;           // (wave-uniform)
-    const VT *ghost = nullptr;
+    nsk_rsrc rg = nsk_make_rsrc(g.val);
     if (P2P) {
-        // ghosts: this rank's receive block of the previous exchange (tag - 1); a border wave first waits for
-        // the peers' flags of that exchange (bounded), then takes a system-scope acquire fence
-        ghost = (const VT *)((const char *)px.mine + nsk_p2p_recv_off_(px.world)) + (size_t)((ptag - 1u) & 1u) * 2 * (size_t)px.nrecv;
+        // ghosts: this rank's receive block of the previous exchange (tag - 1), read with system-coherent loads; a
+        // border wave first waits (bounded) for the peers' flags of that exchange -- relaxed polls: what the flag
+        // guards is read past the caches anyway
+        rg = nsk_make_rsrc((const VT *)((const char *)px.mine + nsk_p2p_recv_off_(px.world)) + (size_t)((ptag - 1u) & 1u) * 2 * (size_t)px.nrecv);
         if (border) {
             if (lane == 0) {
                 const unsigned int *flags = (const unsigned int *)px.mine + (size_t)((ptag - 1u) & 1u) * 2 * (size_t)px.world;
@@ -1639,14 +1658,14 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
                 bool ok = true;
                 for (int q = 0; q < px.world && ok; q++) {
                     if (!((px.peer_mask >> q) & 1u)) continue;
-                    while (__hip_atomic_load(flags + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ptag - 1u) {
+                    while (__hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ptag - 1u) {
                         if (wall_clock64() - tw0 > px.timeout_ticks) { ok = false; break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
                 }
                 if (!ok) (void)__hip_atomic_fetch_or(px.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            __builtin_amdgcn_wave_barrier();               // (the lanes' ghost loads stay behind lane 0's wait)
         }
     }
     const bool haff = en.aff_off != NSK_NO_STREAM;                      // implicit adjacency (nsk_compile.h seg_aff)
@@ -1686,26 +1705,27 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
         }
     }
     // member values -> neighbourhood bits -> table entries (the table kernels run only while every value on
-    // the device lies in its domain -- values_regular -- and their members are binary: a value IS its bit)
-    uint32_t idx[NT];
+    // the device lies in its domain -- values_regular -- and their members are binary: a value IS its bit).
+    // Every load of the NT tiles is issued first (the two tile kinds take different paths: only the requests sit
+    // inside the wave-uniform branches, the shifts and ors that use them follow behind all of them -- with the
+    // uses inside the branches a tile's loads were waited for before the next tile's were requested: 12.0 ->
+    // 15.3 us per 10M-grid class, tools/sessions/r5_s03.sh)
+    uint32_t x[NT][4 * NCH];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        idx[k] = 0;
         if (ab[k][0] != NSK_NO_STREAM) {                 // implicit adjacency: member = base of the slot (scalar) + lane
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
                 const uint32_t b = ab[k][j];
                 if (!P2P) {
-                    idx[k] |= nsk_buf_ld<VT>(rv, (uint32_t)lane, b) << j;
+                    x[k][j] = nsk_buf_ld<VT>(rv, (uint32_t)lane, b);
                 } else {                                 // ... a run of the values or of the ghosts ([ghost_lo, ghost_lo + nrecv))
                     const uint32_t gb = b - px.ghost_lo;
-                    if (gb + 63u < px.nrecv && gb < px.nrecv) {                        // scalar: the whole run is ghosts
-                        idx[k] |= (uint32_t)(uint8_t)(ghost + gb)[lane] << j;
-                    } else if (b + 63u < px.ghost_lo || gb >= px.nrecv) {              // scalar: none of it
-                        idx[k] |= nsk_buf_ld<VT>(rv, (uint32_t)lane, b) << j;
-                    } else {
+                    if (gb + 63u < px.nrecv && gb < px.nrecv) x[k][j] = nsk_buf_ld_sys<VT>(rg, (uint32_t)lane, gb);       // scalar: all ghosts
+                    else if (b + 63u < px.ghost_lo || gb >= px.nrecv) x[k][j] = nsk_buf_ld<VT>(rv, (uint32_t)lane, b);   // scalar: none
+                    else {
                         const uint32_t i = b + (uint32_t)lane;
-                        idx[k] |= (uint32_t)(uint8_t)(i - px.ghost_lo < px.nrecv ? ghost[i - px.ghost_lo] : g.val[i]) << j;
+                        x[k][j] = i - px.ghost_lo < px.nrecv ? nsk_buf_ld_sys<VT>(rg, i - px.ghost_lo, 0u) : nsk_buf_ld<VT>(rv, i, 0u);
                     }
                 }
             }
@@ -1713,10 +1733,17 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
                 const uint32_t i = id[k][j];
-                if (!P2P) idx[k] |= nsk_buf_ld<VT>(rv, i, 0u) << j;
-                else idx[k] |= (uint32_t)(uint8_t)(i - px.ghost_lo < px.nrecv ? ghost[i - px.ghost_lo] : g.val[i]) << j;
+                if (!P2P) x[k][j] = nsk_buf_ld<VT>(rv, i, 0u);
+                else x[k][j] = i - px.ghost_lo < px.nrecv ? nsk_buf_ld_sys<VT>(rg, i - px.ghost_lo, 0u) : nsk_buf_ld<VT>(rv, i, 0u);
             }
         }
+    }
+    uint32_t idx[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        idx[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 4 * NCH; j++) idx[k] |= x[k][j] << j;
     }
     uint2 e[NT];
 #pragma unroll
@@ -1747,8 +1774,9 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
         if (!burnin) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(tally[k] + (uint32_t)nv[k]), rc, (int)voff, (int)soff, 0);
     }
     if (border) {
-        // the boundary values of these tiles into their readers' receive blocks (this exchange's parity); then the
-        // tiles are counted, and the wave that completes the sweep's last border tile raises the flags
+        // the boundary values of these tiles into their readers' receive blocks (this exchange's parity), written
+        // through to memory (system-coherent stores); once they are acknowledged the tiles are counted, and the wave
+        // that completes the sweep's last border tile raises the flags
         uint32_t nlive = 0;
 #pragma unroll
         for (int k = 0; k < NT; k++) {
@@ -1757,16 +1785,15 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
             const uint32_t pm = px.push_map[((size_t)en.push_off + (size_t)(t0 + k)) * 64 + lane];
             for (int q = 0; q < px.world; q++) {
                 if (!((px.peer_mask >> q) & 1u)) continue;              // (scalar loop: a shard of a grid has two readers)
-                VT *dst = (VT *)((char *)px.peer[q] + nsk_p2p_recv_off_(px.world)) + (size_t)(ptag & 1u) * 2 * (size_t)px.dtotal[q];
-                if (pm != NSK_NO_STREAM && (int)(pm >> 28) == q) dst[pm & 0x0FFFFFFFu] = (VT)nv[k];
+                const nsk_rsrc rp = nsk_make_rsrc((VT *)((char *)px.peer[q] + nsk_p2p_recv_off_(px.world)) + (size_t)(ptag & 1u) * 2 * (size_t)px.dtotal[q]);
+                nsk_buf_st_sys<VT>(rp, (pm != NSK_NO_STREAM && (int)(pm >> 28) == q) ? (pm & 0x0FFFFFFFu) : NSK_BUF_OOB, nv[k]);
             }
         }
-        __threadfence_system();
+        __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the stores above have been acknowledged
         if (lane == 0) {
-            const unsigned int old = __hip_atomic_fetch_add(px.counter, nlive, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int old = __hip_atomic_fetch_add(px.counter, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old + nlive == px.border_total) {
                 __hip_atomic_store(px.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence_system();
                 for (int q = 0; q < px.world; q++)
                     if ((px.peer_mask >> q) & 1u)
                         __hip_atomic_store((unsigned int *)px.peer[q] + (size_t)(ptag & 1u) * 2 * (size_t)px.world + (size_t)px.me, ptag,
@@ -1776,10 +1803,6 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     }
 }
 
-// The quads of an XCD's eighth are dealt to its waves in whole rounds -- a wave's trip is a quad --; what is
-// left after the last whole round (fewer quads than waves) is dealt as tile PAIRS, two waves to a quad (each
-// evaluates the quad's block): the closing trip of a launch is then half as long, and a launch with fewer
-// quads than waves (small grids: one wave lifetime long) runs entirely in pairs.
 template <typename VT, int NCH, bool P2P>
 __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const SegTable &tab, int burnin,
                                                    uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,

@@ -1130,22 +1130,22 @@ __device__ __forceinline__ void block_hub_learn(const DevGraph<VT> &g, const Gra
     }
 }
 
+// (Round 5 measured three variants of this launch, none kept -- tools/sessions/r5_s02.sh, r5_s03.sh: the gradient pass
+// one lane per VARIABLE from facts / weight ids kept in the slots, no second read of the rows and no third barrier:
+// 5M LR 114.5 -> 122.7 us per class, 50M 1125 -> 1121; LDS value windows and non-temporal weight gathers:
+// nsk_compile.h ep_win, ep_pass.)
 // Learning over the entry-parallel groups of a colour class (k_gibbs_ep's layout, passes and phases):
 //   1. one lane per list entry, BOTH chains: (weight, owner, free-chain facts, evidence-chain facts)
 //      into the LDS slot [position in the list][variable];
 //   2. one lane per variable: free-chain and evidence-chain potentials in list order -> proposal and
-//      evidence (learning.py:54-70), stores;
-//   3. the same lane walks its variable's list positions again: the entry's gradient value(proposal | free
-//      chain) - value(evidence | evidence chain) from the facts, weight id and weight phase 1 left in the slots,
-//      for the entries sample_and_sgd visits (entry_visited), into the wave-aggregated accumulators.  (Round 4
-//      ran this pass one lane per ENTRY over the rows again -- 8 bytes per entry re-read, the draws published
-//      through LDS behind a third barrier.)
+//      evidence (learning.py:54-70), stores, and (evidence, proposal, takes part, truncation coin)
+//      into LDS;
+//   3. one lane per list entry again: the entry's gradient value(proposal | free chain) -
+//      value(evidence | evidence chain) from the saved facts, for the entries sample_and_sgd visits
+//      (entry_visited), into the wave-aggregated accumulators.
 // A group with more than 8 entries per variable takes two passes of (1, 2); phase 3 then runs over the
-// second pass's slots and, after redoing phase 1 for the first pass, over the first's.
+// second pass's entries (their facts are in LDS) and, after redoing phase 1 for them, over the first's.
 // Dynamic LDS: the SMALLW accumulators only.
-#ifndef NSK_EP_LEARN_NT
-#define NSK_EP_LEARN_NT true        // the rows of the learning launch are read once per pass: streamed past the caches
-#endif
 #ifdef NSK_EP_WPE_L
 #define NSK_EP_ATTR_L __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_L, NSK_EP_WPE_L)))
 #else
@@ -1159,12 +1159,8 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) double ws[NSK_EP_LIST * 256];
     __shared__ __attribute__((aligned(16))) uint32_t fs[NSK_EP_LIST * 256];
-    __shared__ uint16_t sel[256];                         // (the long-list hub blocks')
-    __shared__ uint32_t wl[NSK_EP_LIST * 256];             // weight id of every slot (gradient pass)
+    __shared__ uint16_t sel[256];
     __shared__ __attribute__((aligned(16))) uint8_t lut[2048];
-    __shared__ nsk_u32x4 wina[NSK_EP_WIN_LDS(VT)], winb[NSK_EP_WIN_LDS(VT)];      // the group's value windows, both chains
-    const signed char *wa = (const signed char *)wina, *wb = (const signed char *)winb;
-    const bool win = g.ep_win != nullptr;
     load_gen_lut(lut);
     const GradSink sk = open_sink<SMALLW>(g, smem);
     if ((int)blockIdx.x < nbh) {                          // one long-list hub per block
@@ -1183,11 +1179,11 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
     }
     const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x - hblocks) * (NSK_BLOCK / 64) + (threadIdx.x >> 6)));
     const int nwaves = gblocks * (NSK_BLOCK / 64);
-    // phase 1 of one pass: both chains' facts, the weight and its id into the slots
+    // phase 1 of one pass: both chains' facts and the weight into the slots
     auto entries = [&](uint32_t sub, uint32_t rowsw) {
         for (int i = (int)threadIdx.x; i < NSK_EP_LIST * 256; i += NSK_BLOCK) fs[i] = 14u;      // owned by no candidate
         __syncthreads();
-        ep_pass<VT, true, 1, NSK_EP_LEARN_NT, true, 2>(g, g.val, g.val_evid, sub, rowsw, nullptr, wa, wb, win,
+        ep_pass<VT, true, 1, false, true, 2>(g, g.val, g.val_evid, sub, rowsw, nullptr, nullptr, nullptr, false,
             [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &b, double w) {
                 int cstar, A, B;
                 a.close(d1, lut, cstar, A, B);
@@ -1198,41 +1194,34 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
                 if (ks != 14u) {
                     const uint32_t slot = NSK_EP_SLOT(w0, d1);
                     ws[slot] = w;
-                    // + what the gradient pass needs of the descriptor: bits 19-22 (a partner entry in another of
-                    // the variable's lists, entry_visited) at 20-23, the weight's fixed flag at 24
-                    fs[slot] = ks | fx | (((d1 >> 19) & 15u) << 20) | ((d1 >> 31) << 24);
-                    wl[slot] = NSK_EP_WID(w0);
+                    fs[slot] = ks | fx;
                 }
             });
         __syncthreads();
     };
-    // phase 3 of one pass: one lane per VARIABLE walks its own list positions -- facts, weight id and weight are in
-    // the slots since phase 1, (evidence, proposal) in its registers: no row is read again, nothing to publish
-    auto gradients = [&](int nacc, bool tile_ok, int evidence, int proposal, bool part, bool truncate) {
-        if (!tile_ok) return;                                  // (wave-uniform)
-        for (int o = 0; o < nacc; o++) {
-            const int slot = o * 256 + (int)threadIdx.x;
-            const uint32_t f = fs[slot];
-            const uint32_t ks = f & 15u;
-            const int cf = (int)((f >> 4) & 15u), Af = (int)((f >> 8) & 3u) - 1, Bf = (int)((f >> 10) & 3u) - 1;
-            const int ce = (int)((f >> 12) & 15u), Ae = (int)((f >> 16) & 3u) - 1, Be = (int)((f >> 18) & 3u) - 1;
-            const long long diff = (long long)(proposal == cf ? Af : Bf) - (long long)(evidence == ce ? Ae : Be);
-            // learning.py:76-95 (entry_visited, from the bits saved in the slot)
-            const int partner = (int)((f >> 21) & 7u);
-            const bool dup = ((f >> 20) & 1u) != 0u && (partner == evidence || partner == proposal);
-            const bool visited = ks == 15u || (((int)ks == evidence || (int)ks == proposal) && !dup);
-            // (a dataType-0 entry's visit is counted structurally: with a zero gradient -- the common
-            // case -- it has nothing to add)
-            const bool counted = lp.kstat && ks == 15u;
-            const bool have = part && ks != 14u && visited && !((f >> 24) & 1u) && !(counted && diff == 0);     // 100-101
+    // phase 3 of one pass: gradients of its entries from the facts in the slots
+    auto gradients = [&](uint32_t sub, uint32_t rowsw) {
+        ep_pass<VT, false, 0, false, false, 2>(g, g.val, g.val, sub, rowsw, nullptr, nullptr, nullptr, false,
+            [&](uint32_t w0, uint32_t d1, const GenChain &, const GenChain &, double) {
+                const uint32_t sv = sel[(d1 >> 23) & 255u];
+                const int evidence = (int)(sv & 15u), proposal = (int)((sv >> 4) & 15u);
+                const uint32_t f = fs[NSK_EP_SLOT(w0, d1)];
+                const int cf = (int)((f >> 4) & 15u), Af = (int)((f >> 8) & 3u) - 1, Bf = (int)((f >> 10) & 3u) - 1;
+                const int ce = (int)((f >> 12) & 15u), Ae = (int)((f >> 16) & 3u) - 1, Be = (int)((f >> 18) & 3u) - 1;
+                const long long diff = (long long)(proposal == cf ? Af : Bf) - (long long)(evidence == ce ? Ae : Be);
+                // (a dataType-0 entry's visit is counted structurally: with a zero gradient -- the common
+                // case -- it has nothing to add)
+                const bool counted = lp.kstat && ((d1 >> 14) & 15u) == 15u;
+                const bool have = (sv & 256u) && ((d1 >> 14) & 15u) != 14u && entry_visited(d1, evidence, proposal) &&
+                                  !(d1 >> 31) && !(counted && diff == 0);                    // 100-101
 #ifdef NSK_ABL_NOATOMIC
-            if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
+                if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
 #else
-            // (the entry's weight is still in its LDS slot from phase 1: a weight updated in place needs no reload)
-            accumulate_gradient(sk, have, (int)wl[slot], diff * g.grad_mul, truncate, !counted,
-                                sk.w_direct != nullptr, sk.w_direct ? ws[slot] : 0.0);
+                // (the entry's weight is still in its LDS slot from phase 1: a weight updated in place needs no reload)
+                accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * g.grad_mul, (sv & 512u) != 0u, !counted,
+                                    sk.w_direct != nullptr, sk.w_direct ? ws[NSK_EP_SLOT(w0, d1)] : 0.0);
 #endif
-        }
+            });
     };
     if ((int)blockIdx.x < hblocks + gblocks) {
         const EpWalk wk = ep_walk(ngroups, hblocks, gblocks);
@@ -1258,7 +1247,6 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
             for (int pass = 0; pass * NSK_EP_LIST < ne; pass++) {
                 const uint32_t rowsw = pass ? grows1 : grows0;
                 __syncthreads();                           // (the previous group / pass is done with the slots)
-                if (pass == 0) ep_stage_window<VT, true>(g, group0 + gi, wina, winb);     // published by the barrier in entries()
                 entries(sub, rowsw);
                 const int nacc = min(NSK_EP_LIST, ne - pass * NSK_EP_LIST);
                 if (tile_ok)
@@ -1271,32 +1259,34 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
                     }
                 if (pass == 0 && two) sub += (uint32_t)ep_pass_subrows(rowsw);
             }
-            int evidence = 0, proposal = 0;
-            bool part = false, truncate = false;
+            uint32_t mysel = 0;
             if (tile_ok) {
                 const u32x4 r = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
-                proposal = pf.draw(maxcard, card, u53(r.x, r.y));                              // 66-70
-                evidence = valid ? (int)g.p_init[p] : 0;                                       // 61-62
+                const int proposal = pf.draw(maxcard, card, u53(r.x, r.y));                    // 66-70
+                int evidence = valid ? (int)g.p_init[p] : 0;                                   // 61-62
                 if (need_evid && ev != 1) evidence = pe.draw(maxcard, card, u53(r.z, r.w));    // 54-58
                 if (valid) {
                     g.val_evid[p] = (VT)evidence;
                     g.val[p] = (VT)proposal;
                 }
-                part = valid && (lp.learn_non_evidence || ev == 1);                            // 71-72
+                const bool part = valid && (lp.learn_non_evidence || ev == 1);                 // 71-72
+                bool truncate = false;
                 if (lp.regularization == 1) {                                                  // 90
                     const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
                     truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
                 }
+                mysel = ((uint32_t)evidence & 15u) | (((uint32_t)proposal & 15u) << 4) | (part ? 256u : 0u) | (truncate ? 512u : 0u);
             }
+            sel[threadIdx.x] = (uint16_t)mysel;
+            __syncthreads();
 #ifdef NSK_ABL_EPNOP3
             if (lp.k0 != 0xDEADBEEFu) continue;
 #endif
-            // the last pass's facts are in the slots
-            gradients(min(NSK_EP_LIST, ne - (two ? NSK_EP_LIST : 0)), tile_ok, evidence, proposal, part, truncate);
+            gradients(sub, two ? grows1 : grows0);         // the last pass's facts are in the slots
             if (two) {                                     // the first pass's entries: their facts again, then their gradients
                 __syncthreads();
                 entries(gsub, grows0);
-                gradients(NSK_EP_LIST, tile_ok, evidence, proposal, part, truncate);
+                gradients(gsub, grows0);
             }
         }
     }

@@ -171,6 +171,20 @@ def lf_graph(prior, accuracy, copies, seed=0):
 LR_BLOCK = 65536     # ids per generator block of mixed_lr_graph: every block draws from streams of its own
 
 
+def _block_map(fn, items):
+    """``[fn(x) for x in items]`` over a pool of host threads (numpy's generators and array kernels release the
+    GIL): every id block of the LR generator draws from streams of its own, so the blocks are independent and
+    the result does not depend on the thread count.  NSK_GEN_THREADS (default: the hardware's, at most 32)."""
+    items = list(items)
+    import os
+    nthreads = int(os.environ.get("NSK_GEN_THREADS", "0")) or min(32, os.cpu_count() or 1)
+    if nthreads <= 1 or len(items) <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(nthreads, len(items))) as pool:
+        return list(pool.map(fn, items))
+
+
 def _lr_variables(nvar, seed, cat_frac, evidence_frac, block):
     """Compact per-variable attributes of the WHOLE graph (4 bytes per variable): every id block has a
     stream of its own, so any rank reproduces them without the factors."""
@@ -178,7 +192,9 @@ def _lr_variables(nvar, seed, cat_frac, evidence_frac, block):
     ev = np.empty(nvar, np.bool_)
     init = np.empty(nvar, np.uint8)
     nf_of = np.empty(nvar, np.uint8)
-    for b, v0 in enumerate(range(0, nvar, block)):
+
+    def one(bv):
+        b, v0 = bv
         n = min(block, nvar - v0)
         rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), 0, b])))
         is_cat = rng.random(n) < cat_frac
@@ -188,6 +204,7 @@ def _lr_variables(nvar, seed, cat_frac, evidence_frac, block):
         ev[v0:v0 + n] = e
         init[v0:v0 + n] = np.where(e, (rng.random(n) * c).astype(np.int64), 0)
         nf_of[v0:v0 + n] = 1 + np.minimum(rng.poisson(2.0, n), 15)
+    _block_map(one, enumerate(range(0, nvar, block)))
     return card, ev, init, nf_of
 
 
@@ -220,15 +237,30 @@ def _lr_factor_block(seed, b, v0, nf_of_b, card, nvar, nweights, window, global_
 
 
 def _lr_records(func, wid, arity, vid, deo):
-    factor = np.zeros(len(func), Factor)
-    factor["factorFunction"] = func
-    factor["weightId"] = wid
-    factor["featureValue"] = 1.0
-    factor["arity"] = arity
-    factor["ftv_offset"] = np.cumsum(arity) - arity
-    fmap = np.zeros(len(vid), FactorToVar)
-    fmap["vid"] = vid
-    fmap["dense_equal_to"] = deo
+    """The packed reference records (numbskulltypes.py:11-39) from the columns; filled chunk by chunk over the
+    host threads (strided stores into 34- and 16-byte records: the largest serial lap of the generator)."""
+    nf, ne = len(func), len(vid)
+    factor = np.empty(nf, Factor)
+    fmap = np.empty(ne, FactorToVar)
+    ftv = np.cumsum(arity) - arity
+    step = 1 << 20
+
+    def fill_f(a):
+        b = min(nf, a + step)
+        f = factor[a:b]
+        f["factorFunction"] = func[a:b]
+        f["weightId"] = wid[a:b]
+        f["featureValue"] = 1.0
+        f["arity"] = arity[a:b]
+        f["ftv_offset"] = ftv[a:b]
+
+    def fill_e(a):
+        b = min(ne, a + step)
+        m = fmap[a:b]
+        m["vid"] = vid[a:b]
+        m["dense_equal_to"] = deo[a:b]
+    _block_map(lambda t: (fill_f if t[0] == 0 else fill_e)(t[1]),
+               [(0, a) for a in range(0, nf, step)] + [(1, a) for a in range(0, ne, step)])
     return factor, fmap
 
 
@@ -262,10 +294,12 @@ def mixed_lr_graph(nvar, seed=20240603, nweights=None, window=1024, global_frac=
     variable["cardinality"] = card
     variable["isEvidence"] = ev
     variable["initialValue"] = init
-    parts = [_lr_factor_block(seed, b, v0, nf_of[v0:v0 + block], card, nvar, nweights, window, global_frac)
-             for b, v0 in enumerate(range(0, nvar, block))]
+    parts = _block_map(lambda bv: _lr_factor_block(seed, bv[0], bv[1], nf_of[bv[1]:bv[1] + block], card, nvar, nweights,
+                                                   window, global_frac), enumerate(range(0, nvar, block)))
     cat = lambda i: np.concatenate([p_[i] for p_ in parts]) if parts else np.zeros(0, np.int64)
-    factor, fmap = _lr_records(cat(0), cat(1), cat(2), cat(4), cat(5))
+    cols = _block_map(cat, (0, 1, 2, 4, 5))
+    del parts
+    factor, fmap = _lr_records(*cols)
     wrec = np.zeros(nweights, Weight)
     return wrec, variable, factor, fmap, np.zeros(nvar, np.bool_), len(fmap)
 
@@ -295,16 +329,22 @@ def mixed_lr_shards(nvar, ranges, seed=20240603, nweights=None, window=1024, glo
     ranges = [(int(lo), int(hi)) for lo, hi in ranges]
     nweights = _lr_nweights(nvar, nweights)
     card, ev, init, nf_of = _lr_variables(nvar, seed, cat_frac, evidence_frac, block)
-    kept = [[] for _ in ranges]
-    for b, v0 in enumerate(range(0, nvar, block)):
+    def one(bv):
+        b, v0 = bv
         func, wid, arity, off, vid, deo = _lr_factor_block(seed, b, v0, nf_of[v0:v0 + block], card, nvar,
                                                            nweights, window, global_frac)
-        for r, (lo, hi) in enumerate(ranges):
+        out = []
+        for lo, hi in ranges:
             keep_f = np.add.reduceat(((vid >= lo) & (vid < hi)).astype(np.int32), off) > 0
             if not keep_f.any():
+                out.append(None)
                 continue
             keep_e = np.repeat(keep_f, arity)
-            kept[r].append((func[keep_f], wid[keep_f], arity[keep_f], vid[keep_e], deo[keep_e]))
+            out.append((func[keep_f], wid[keep_f], arity[keep_f], vid[keep_e], deo[keep_e]))
+        return out
+    per_block = _block_map(one, enumerate(range(0, nvar, block)))
+    kept = [[pb[r] for pb in per_block if pb[r] is not None] for r in range(len(ranges))]
+    del per_block
     return [_lr_shard_from(kept[r], card, ev, init, lo, hi, nweights) for r, (lo, hi) in enumerate(ranges)]
 
 
@@ -316,15 +356,16 @@ def mixed_lr_shard(nvar, lo, hi, seed=20240603, nweights=None, window=1024, glob
     nvar, lo, hi = int(nvar), int(lo), int(hi)
     nweights = _lr_nweights(nvar, nweights)
     card, ev, init, nf_of = _lr_variables(nvar, seed, cat_frac, evidence_frac, block)
-    kept = []
-    for b, v0 in enumerate(range(0, nvar, block)):
+    def one(bv):
+        b, v0 = bv
         func, wid, arity, off, vid, deo = _lr_factor_block(seed, b, v0, nf_of[v0:v0 + block], card, nvar,
                                                            nweights, window, global_frac)
         keep_f = np.add.reduceat(((vid >= lo) & (vid < hi)).astype(np.int32), off) > 0
         if not keep_f.any():
-            continue
+            return None
         keep_e = np.repeat(keep_f, arity)
-        kept.append((func[keep_f], wid[keep_f], arity[keep_f], vid[keep_e], deo[keep_e]))
+        return func[keep_f], wid[keep_f], arity[keep_f], vid[keep_e], deo[keep_e]
+    kept = [k for k in _block_map(one, enumerate(range(0, nvar, block))) if k is not None]
     return _lr_shard_from(kept, card, ev, init, lo, hi, nweights)
 
 

@@ -11,7 +11,7 @@
 # lines and the 8-shard runs only (they read profiles/traffic.json / issue.json as installed from a profile
 # stage: a gpurun call is limited to an hour and the whole collection takes longer); default: both.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-RT=${NSK_ROUND_TAG:-r4}
+RT=${NSK_ROUND_TAG:-r5}
 STAGE=${NSK_PROFILE_STAGE:-all}
 OUT=$R/gpurun_out/profiles_$RT
 rm -rf $OUT; mkdir -p $OUT
@@ -27,7 +27,7 @@ for WL in ${NSK_PROFILE_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_lea
   echo "profiled $WL: $(grep -h 'dominant kernel' $P/summary.txt)"
 done
 # config #5 at size: kernel stats and HBM traffic only (minutes per run)
-for WL in ${NSK_PROFILE_LIGHT_WORKLOADS:-lr50m lr50m_learn}; do
+for WL in ${NSK_PROFILE_LIGHT_WORKLOADS:-lr50m lr50m_learn ising100m}; do      # (ising100m: the one grid whose sweep is beyond the Infinity Cache)
   NSK_PROFILE_LIGHT=1 NSK_PROFILE_STEPS=10 bash tools/profile_gpu.sh $WL > /dev/null 2>&1
   P=$R/gpurun_out/prof_$WL
   cp $P/summary.txt $OUT/${RT}_${WL}_summary.txt 2>/dev/null

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Run HERE after `git rev-parse HEAD > gpurun_out/profiles_r4_commit.txt; gpurun -- bash tools/collect_profiles.sh`:
+# Run HERE after `git rev-parse HEAD > gpurun_out/profiles_r5_commit.txt; gpurun -- bash tools/collect_profiles.sh`:
 # earlier rounds' files go to profiles/history/, the freshly collected set (gpurun_out/profiles_$RT/) becomes profiles/.
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p profiles/history
-RT=${NSK_ROUND_TAG:-r4}
-for f in profiles/r2_* profiles/r3_*; do [ -e "$f" ] && git mv -f "$f" profiles/history/ 2>/dev/null || true; done
+RT=${NSK_ROUND_TAG:-r5}
+for f in profiles/r2_* profiles/r3_* profiles/r4_*; do [ -e "$f" ] && git mv -f "$f" profiles/history/ 2>/dev/null || true; done
 # (NSK_PROFILE_PARTIAL=1: a partial collection replaces only the files it produced)
 [ -z "$NSK_PROFILE_PARTIAL" ] && for f in profiles/${RT}_*; do [ -e "$f" ] && rm -f "$f"; done
 cp gpurun_out/profiles_$RT/${RT}_* profiles/
