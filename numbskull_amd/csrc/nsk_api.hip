@@ -773,9 +773,17 @@ int nsk_graph_get_generators(nsk_graph *g, int64_t *gen) {
     for (const Compiled::Segment &sg : c.segments)
         if (sg.ztab >= 0)
             for (int64_t p = sg.pos0; p < sg.pos0 + (int64_t)sg.ntiles * 64 && p < c.npos; p++) quad[(size_t)p] = 1;
+    // bit 41: learning sweeps draw the free chain of the position from the quad scheme too -- the all-evidence
+    // segments of the learning sweep's table launches (one uniform per variable there)
+    for (const Compiled::SegLaunch &sl : c.learn_seg)
+        if (sl.tab)
+            for (int i = 0; i < sl.n; i++)
+                if (sl.ev[i] == 1)
+                    for (int64_t p = sl.pos0[i]; p < (int64_t)sl.pos0[i] + (int64_t)(sl.tile_start[i + 1] - sl.tile_start[i]) * 64 && p < c.npos; p++)
+                        quad[(size_t)p] |= 2;
     for (int64_t v = 0; v < c.nvar; v++) {
         const int64_t p = c.color[v] >= 0 ? (int64_t)c.iid[v] : -1;
-        gen[v] = p < 0 ? -1 : (p | ((p < c.npos && quad[(size_t)p]) ? (1ll << 40) : 0ll));
+        gen[v] = p < 0 ? -1 : (p | ((p < c.npos && (quad[(size_t)p] & 1)) ? (1ll << 40) : 0ll) | ((p < c.npos && (quad[(size_t)p] & 2)) ? (1ll << 41) : 0ll));
     }
     return NSK_OK;
 }
@@ -1299,8 +1307,9 @@ int nsk_p2p_enqueue(nsk_graph *g, const unsigned long long *tag_base, unsigned i
 }
 
 // kernel argument of a fused table launch
-void nsk_p2p_fill(nsk_graph *g, nsk::TabP2P &px, const unsigned long long *tag_base, unsigned int tag) {
+void nsk_p2p_fill(nsk_graph *g, nsk::TabP2P &px, const unsigned long long *tag_base, unsigned int tag, bool wait) {
     memset(&px, 0, sizeof(px));
+    px.wait = wait ? 1 : 0;
     px.mine = g->p2p_base;
     for (int q = 0; q < g->pworld; q++) { px.peer[q] = g->p2p_peer_base[q]; px.dtotal[q] = (unsigned long long)g->p_dtotal[q]; }
     px.push_map = g->p2p_push_map;

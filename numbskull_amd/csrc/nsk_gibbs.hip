@@ -35,6 +35,13 @@ void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
                 const auto it = std::lower_bound(bt.begin(), bt.end(), f);
                 if (it != bt.end() && *it < f + sg.ntiles) border_all = false;
             }
+    int first_phase = -1, last_phase = -1;            // classes with sampled segments
+    for (const Compiled::Segment &sg : g->c.segments)
+        if (sg.ev == 0 || sample_evidence) {
+            if (first_phase < 0 || sg.phase < first_phase) first_phase = sg.phase;
+            if (sg.phase > last_phase) last_phase = sg.phase;
+        }
+    g->p2p_first_phase = first_phase;
     for (size_t ph = 0; ph < nphase; ph++)
         for (int kind = 0; kind <= 8; kind++) {
             if (kind == 1 || (kind > 4 && kind < 8)) continue;   // IMPLY_NATURAL shares the AND step (3)
@@ -69,7 +76,14 @@ void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
                         t = e;
                     }
                 }
-                std::stable_sort(mine.begin(), mine.end(), [](const Run &a, const Run &b) { return a.nt > b.nt; });
+                // largest first -- and, for a shard that exchanges inside its launches, the border runs of the sweep's
+                // LAST class in front (their pushes leave early: the peers' next sweep waits for them) and those of
+                // its FIRST class behind (they wait for the peers' flags: the later they start the shorter)
+                const bool border_front = g->p2p_fused && (int)ph == last_phase && last_phase != first_phase;
+                std::stable_sort(mine.begin(), mine.end(), [&](const Run &a, const Run &b) {
+                    const bool ba = a.push_off != NSK_NO_STREAM, bb = b.push_off != NSK_NO_STREAM;
+                    if (ba != bb) return border_front ? ba : bb;
+                    return a.nt > b.nt; });
                 for (const Run &rn : mine) {
                     const Compiled::Segment &sg = *rn.sg;
                     SegEntry &en = tab.e[tab.n];
@@ -217,7 +231,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                             const int nbp = nsk_tab_grid(tab.ntiles);
                             if (g->p2p_fused_now) {
                                 TabP2P px;
-                                nsk_p2p_fill(g, px, nullptr, g->p2p_tag);
+                                nsk_p2p_fill(g, px, nullptr, g->p2p_tag, (int)ph == g->p2p_first_phase);
                                 if (nch == 1) k_gibbs_seg_tab_p2p<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, px);
                                 else k_gibbs_seg_tab_p2p<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, px);
                             }
@@ -300,7 +314,7 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
                 const int nbp = nsk_tab_grid(pl.tab.ntiles);
                 if (g->p2p_fused_now) {          // the exchange inside the launch: tag = counter + i + 1
                     TabP2P px;
-                    nsk_p2p_fill(g, px, g->d_counters, (unsigned int)(i + 1));
+                    nsk_p2p_fill(g, px, g->d_counters, (unsigned int)(i + 1), (int)ph == g->p2p_first_phase);
                     if (pl.nch == 1)
                         k_gibbs_seg_tab_p2p<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
                                                                                                  g->d_counters, (uint32_t)i, px);

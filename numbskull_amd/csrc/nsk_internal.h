@@ -141,6 +141,7 @@ struct nsk_graph {
                                             //   a tile's rank here is its row in the push map
     uint32_t *p2p_push_map = nullptr;       // [rows][64] reader << 28 | index in the reader's receive block; NSK_NO_STREAM
     uint32_t p2p_ghost_lo = 0, p2p_border_total = 0;   // first ghost id; border tiles one sweep of the current plans samples
+    int p2p_first_phase = -1;               // the sweep's first class with table launches: its border tiles wait for the flags
     bool p2p_border_all = true;             // ... and that is every border tile (else the call takes the exchange kernels)
     std::vector<int32_t> p_send_host, p_recv_host;      // the send / receive lists (internal ids), host copies
     // native RCCL
@@ -280,7 +281,7 @@ bool nsk_tables_only(const nsk_graph *g);           // every sampled variable li
 void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence);    // nsk_gibbs.hip
 int nsk_p2p_ghost_pack(nsk_graph *g);
 int nsk_p2p_flush(nsk_graph *g);                   // enqueue the pending closing wait + unpack of a fused sweep sequence, if any
-void nsk_p2p_fill(nsk_graph *g, nsk::TabP2P &px, const unsigned long long *tag_base, unsigned int tag);   // kernel argument of a fused launch
+void nsk_p2p_fill(nsk_graph *g, nsk::TabP2P &px, const unsigned long long *tag_base, unsigned int tag, bool wait);   // kernel argument of a fused launch
 void nsk_drop_sweep_graph(nsk_graph *g);            // the captured sweep sequence bakes exchange pointers: drop it when they change
 int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin, bool p2p);   // nsk_gibbs.hip
 void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);

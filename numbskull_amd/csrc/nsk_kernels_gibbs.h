@@ -1631,6 +1631,8 @@ struct TabP2P {
     uint32_t tag;                       // this sweep's exchange tag
     uint32_t peer_mask;
     int world, me;
+    int wait;                           // this launch's border tiles wait for the peers' flags (the sweep's first class:
+                                        //   later classes find them raised -- the stream is in order)
 };
 __host__ __device__ inline size_t nsk_p2p_recv_off_(int world) { return ((size_t)(4 * world) * 4 + 255) / 256 * 256; }   // = nsk_p2p_recv_off
 
@@ -1651,7 +1653,7 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
         // border wave first waits (bounded) for the peers' flags of that exchange -- relaxed polls: what the flag
         // guards is read past the caches anyway
         rg = nsk_make_rsrc((const VT *)((const char *)px.mine + nsk_p2p_recv_off_(px.world)) + (size_t)((ptag - 1u) & 1u) * 2 * (size_t)px.nrecv);
-        if (border) {
+        if (border && px.wait) {
             if (lane == 0) {
                 const unsigned int *flags = (const unsigned int *)px.mine + (size_t)((ptag - 1u) & 1u) * 2 * (size_t)px.world;
                 const unsigned long long tw0 = wall_clock64();
@@ -1692,7 +1694,11 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     }
 #pragma unroll
     for (int k = 0; k < NT; k++)
+#ifdef NSK_TAB_FLAT_LD
+        tally[k] = burnin ? 0u : (uint32_t)g.cnt_pos[en.pos0 + tt[k] * 64 + lane];
+#else
         tally[k] = burnin ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, en.pos0 + tt[k] * 64, 0);
+#endif
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         if (ab[k][0] == NSK_NO_STREAM) {                                // wave-uniform: the tile reads its stream
@@ -1718,7 +1724,11 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
             for (int j = 0; j < 4 * NCH; j++) {
                 const uint32_t b = ab[k][j];
                 if (!P2P) {
+#ifdef NSK_TAB_FLAT_LD
+                    x[k][j] = (uint32_t)(uint8_t)g.val[b + (uint32_t)lane];
+#else
                     x[k][j] = nsk_buf_ld<VT>(rv, (uint32_t)lane, b);
+#endif
                 } else {                                 // ... a run of the values or of the ghosts ([ghost_lo, ghost_lo + nrecv))
                     const uint32_t gb = b - px.ghost_lo;
                     if (gb + 63u < px.nrecv && gb < px.nrecv) x[k][j] = nsk_buf_ld_sys<VT>(rg, (uint32_t)lane, gb);       // scalar: all ghosts
@@ -1733,7 +1743,11 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
                 const uint32_t i = id[k][j];
+#ifdef NSK_TAB_FLAT_LD
+                if (!P2P) x[k][j] = (uint32_t)(uint8_t)g.val[i];
+#else
                 if (!P2P) x[k][j] = nsk_buf_ld<VT>(rv, i, 0u);
+#endif
                 else x[k][j] = i - px.ghost_lo < px.nrecv ? nsk_buf_ld_sys<VT>(rg, i - px.ghost_lo, 0u) : nsk_buf_ld<VT>(rv, i, 0u);
             }
         }
@@ -1768,10 +1782,20 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     for (int k = 0; k < NT; k++) {
         // a dead tile's stores carry an out-of-range lane offset: dropped by the bounds check (no branch, no select
         // of addresses)
+#ifdef NSK_TAB_FLAT_ST
+        const int pk = en.pos0 + (t0 + k) * 64 + lane;
+        VT *dst = live[k] ? g.val + pk : (VT *)g.sink + lane;
+        *dst = (VT)nv[k];
+        if (!burnin) {
+            uint8_t *td = live[k] ? g.cnt_pos + pk : g.sink + 256 + lane;
+            *td = (uint8_t)(tally[k] + (uint32_t)nv[k]);
+        }
+#else
         const uint32_t voff = live[k] ? (uint32_t)lane : NSK_BUF_OOB;
         const uint32_t soff = live[k] ? (uint32_t)(en.pos0 + (t0 + k) * 64) : 0u;
         nsk_buf_st<VT>(rv, voff, soff, nv[k]);
         if (!burnin) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(tally[k] + (uint32_t)nv[k]), rc, (int)voff, (int)soff, 0);
+#endif
     }
     if (border) {
         // the boundary values of these tiles into their readers' receive blocks (this exchange's parity), written
