@@ -1272,7 +1272,7 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
     auto blocks = [&](int64_t work) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, (work + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK))); };
     auto gather = [&]() {
         if (!weights) return;
-        const int nb = std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK);
+        const int nb = blocks(wwork);                       // (few blocks, grid-stride: every block waits for the flags itself)
         k_p2p_gather_w<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, nw, g->p2p_base, (long long)g->p_nrecv, world,
                                                                        mask, tag, g->p2p_err, g->p2p_timeout_ticks, selftest);
         if (!selftest) g->weights_dirty = true;

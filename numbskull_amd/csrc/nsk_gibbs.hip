@@ -76,13 +76,14 @@ void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
                         t = e;
                     }
                 }
-                // largest first -- and, for a shard that exchanges inside its launches, the border runs of the sweep's
-                // LAST class in front (their pushes leave early: the peers' next sweep waits for them) and those of
-                // its FIRST class behind (they wait for the peers' flags: the later they start the shorter)
-                const bool border_front = g->p2p_fused && (int)ph == last_phase && last_phase != first_phase;
+                // largest first -- but, for a shard that exchanges inside its launches, the border runs in front: their
+                // chain (flag, system-coherent ghost loads, pushes, acknowledgement, counter) is twice a trip long and
+                // overlaps the interior trips when it starts first; behind them it was a tail of every launch (a
+                // border wave that waits for a peer holds one of 6144 wave slots, nothing else)
+                (void)last_phase;
                 std::stable_sort(mine.begin(), mine.end(), [&](const Run &a, const Run &b) {
                     const bool ba = a.push_off != NSK_NO_STREAM, bb = b.push_off != NSK_NO_STREAM;
-                    if (ba != bb) return border_front ? ba : bb;
+                    if (ba != bb) return ba;
                     return a.nt > b.nt; });
                 for (const Run &rn : mine) {
                     const Compiled::Segment &sg = *rn.sg;

@@ -1641,8 +1641,159 @@ __host__ __device__ inline size_t nsk_p2p_recv_off_(int world) { return ((size_t
 #endif
 // NT consecutive tiles of one quad, first tile = segment tile `t0` (word `w0` of the quad's blocks): every
 // load of the NT tiles is requested before the first draw, the draws' stores come last
-template <typename VT, int NCH, int NT, bool P2P>
+template <typename VT, int NCH, int NT>
 __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry &en, int t0, int w0, int lane, int burnin,
+                                          const u32x4 &ra, u32x4 &rb, bool &have_b, uint32_t qb,
+                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+    const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
+    const bool haff = en.aff_off != NSK_NO_STREAM;                      // implicit adjacency (nsk_compile.h seg_aff)
+    const uint32_t zoff = en.zoff, zmask = en.zmask_ev & 0xFFu;
+    bool live[NT];
+    int p[NT], pl[NT], tt[NT];
+    uint8_t tally[NT];
+    uint32_t id[NT][4 * NCH], ab[NT][4 * NCH];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int t = t0 + k;
+        live[k] = t >= 0 && t < nt;                                     // wave-uniform
+        tt[k] = live[k] ? t : (t < 0 ? 0 : nt - 1);                     // (a dead tile reads a real one's data)
+        p[k] = en.pos0 + t * 64 + lane;
+        pl[k] = en.pos0 + tt[k] * 64 + lane;
+        ab[k][0] = NSK_NO_STREAM;
+    }
+    if (haff) {                        // the tiles' slot bases: scalar loads, issued together
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const NSK_SCALAR uint32_t *ap = (const NSK_SCALAR uint32_t *)(g.seg_aff + en.aff_off + (size_t)tt[k] * NCH);
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) ab[k][j] = ap[j];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NT; k++) tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[k]];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        if (ab[k][0] != NSK_NO_STREAM) {                                // wave-uniform: member = base + lane
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) id[k][j] = ab[k][j] + (uint32_t)lane;
+        } else {
+            const uint4 *sp = g.adj + en.adj_off + (size_t)tt[k] * (64 * NCH) + lane;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint4 w = sp[c * 64];
+                id[k][4 * c] = w.x; id[k][4 * c + 1] = w.y; id[k][4 * c + 2] = w.z; id[k][4 * c + 3] = w.w;
+            }
+        }
+    }
+    // member values -> neighbourhood bits -> table entries (the table kernels run only while every value on
+    // the device lies in its domain -- values_regular -- and their members are binary: a value IS its bit)
+    uint32_t idx[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        idx[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
+    }
+    uint2 e[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) e[k] = *(const uint2 *)(g.ztab + zoff + (idx[k] & zmask));
+    // draws: the high 27 bits decide unless they tie with the threshold's
+    uint32_t hi[NT];
+    int nv[NT];
+    bool tie = false;
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        hi[k] = word_of(ra, (uint32_t)(w0 + k)) >> 5;
+        nv[k] = hi[k] > e[k].x ? 1 : 0;
+        tie = tie || hi[k] == e[k].x;
+    }
+    if (__builtin_expect(__any(tie), 0)) {
+        if (!have_b) { rb = philox4x32(k0, k1, qb, 3u, s0, s1); have_b = true; }
+#pragma unroll
+        for (int k = 0; k < NT; k++)
+            if (hi[k] == e[k].x) nv[k] = (word_of(rb, (uint32_t)(w0 + k)) >> 6) > e[k].y ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        VT *dst = live[k] ? g.val + p[k] : (VT *)g.sink + lane;         // (no branch: see seg_of_tile's note)
+        *dst = (VT)nv[k];
+        if (!burnin) {
+            uint8_t *td = live[k] ? g.cnt_pos + p[k] : g.sink + 256 + lane;
+            *td = (uint8_t)(tally[k] + nv[k]);
+        }
+    }
+}
+
+// The quads of an XCD's eighth are dealt to its waves in whole rounds -- a wave's trip is a quad --; what is
+// left after the last whole round (fewer quads than waves) is dealt as tile PAIRS, two waves to a quad (each
+// evaluates the quad's block): the closing trip of a launch is then half as long, and a launch with fewer
+// quads than waves (small grids: one wave lifetime long) runs entirely in pairs.
+template <typename VT, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
+                                                             uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
+                                                             const unsigned long long *sweep_base, uint32_t sweep_off) {
+    if (sweep_base) {             // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
+        const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
+        const unsigned long long sw = cb[0] + sweep_off, key = cb[2];
+        s0 = (uint32_t)sw;
+        s1 = (uint32_t)(sw >> 32) ^ (uint32_t)cb[3];
+        k0 = (uint32_t)key;
+        k1 = (uint32_t)(key >> 32);
+    }
+    const int lane = (int)(threadIdx.x & 63);
+    const int nquads = tab.ntiles >> 2;                                 // virtual tiles: a multiple of 4
+    const int per = (nquads + 7) >> 3;                                  // quads per XCD
+    const int xcd = (int)(blockIdx.x & 7);
+    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
+    const int q0 = min(nquads, xcd * per), q1 = min(nquads, (xcd + 1) * per);
+    const int qr = q0 + ((q1 - q0) / wpx) * wpx;                        // first quad dealt as pairs
+    // the segment of the last located quad stays in scalar registers: most launches have one
+    int c_lo = 0, c_hi = -1;
+    SegEntry en = tab.e[0];
+    // units: quads [q0, qr) one per trip, then the pairs of quads [qr, q1)
+    for (int U = wx; ; U += wpx) {
+        int Q, h = -1;
+        if (q0 + U < qr) Q = q0 + U;
+        else {
+            const int u = U - (qr - q0);                                // pair unit of the remainder
+            if (u >= 2 * (q1 - qr)) break;
+            Q = qr + (u >> 1);
+            h = u & 1;
+        }
+        if (4 * Q < c_lo || 4 * Q >= c_hi) {                            // wave-uniform, rare
+            const int sidx = seg_of_tile(tab, 4 * Q);
+            en = tab.e[sidx];
+            c_lo = en.tile_start;
+            c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
+        }
+        const int lead = (int)(en.ntiles_lead >> 30);
+        const int t0q = 4 * Q - en.tile_start - lead;                   // segment tile of the quad's first tile
+        // the quad's block: en.pos0 - 64 lead is a multiple of 256, so (pos >> 8, lane) names it
+        const uint32_t qb = quad_block((uint32_t)(en.pos0 + t0q * 64 + lane));
+        const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
+        u32x4 rb = {0u, 0u, 0u, 0u};
+        bool have_b = false;
+        if (h >= 0) {                                                   // wave-uniform
+            tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+        } else if (NSK_TAB_BATCH == 4) {
+            tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+        } else {
+            tab_tiles<VT, NCH, 2>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            tab_tiles<VT, NCH, 2>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+        }
+    }
+}
+
+// The fused-exchange flavour of tab_tiles / k_gibbs_seg_tab below (P2P = true is the only instantiation; buffer
+// addressing: scalar base + lane offset, a dead tile's stores dropped by the bounds check).  The single-GPU kernel keeps
+// the round-4 body above: the same restructuring there cost 1.5-2.4 us per 10M-grid class (tools/sessions/r5_s03.sh ..
+// r5_s05.sh: buffer loads + stores 14.3 us, flat loads 14.1, flat stores 14.15, both flat in this structure 13.85,
+// round-4 body 12.0).
+// NT consecutive tiles of one quad, first tile = segment tile `t0` (word `w0` of the quad's blocks): every
+// load of the NT tiles is requested before the first draw, the draws' stores come last
+template <typename VT, int NCH, int NT, bool P2P>
+__device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntry &en, int t0, int w0, int lane, int burnin,
                                           const u32x4 &ra, u32x4 &rb, bool &have_b, uint32_t qb,
                                           uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1, const TabP2P &px, uint32_t ptag) {
     const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
@@ -1876,22 +2027,14 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
         u32x4 rb = {0u, 0u, 0u, 0u};
         bool have_b = false;
         if (h >= 0) {                                                   // wave-uniform
-            tab_tiles<VT, NCH, 2, P2P>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
+            tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         } else if (NSK_TAB_BATCH == 4) {
-            tab_tiles<VT, NCH, 4, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
+            tab_tiles_x<VT, NCH, 4, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         } else {
-            tab_tiles<VT, NCH, 2, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
-            tab_tiles<VT, NCH, 2, P2P>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
+            tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
+            tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         }
     }
-}
-template <typename VT, int NCH>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, SegTable tab, int burnin,
-                                                             uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
-                                                             const unsigned long long *sweep_base, uint32_t sweep_off) {
-    TabP2P none;                                                        // (unused: P2P = false)
-    none.tag = 0u; none.tag_base = nullptr;
-    gibbs_seg_tab_body<VT, NCH, false>(g, tab, burnin, k0, k1, s0, s1, sweep_base, sweep_off, none);
 }
 // the same for a shard that exchanges its boundary inside the launch (TabP2P)
 template <typename VT, int NCH>

@@ -208,7 +208,9 @@ __device__ __forceinline__ bool p2p_wait(const void *mine, int kind, int world, 
         const unsigned int *flags = (const unsigned int *)mine + ((size_t)(tag & 1u) * 2 + (size_t)kind) * (size_t)world;
         for (int q = 0; q < world && ok; q++) {
             if (!((peer_mask >> q) & 1u)) continue;
-            while (__hip_atomic_load(flags + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+            // (relaxed polls, ONE acquire fence behind the wait: an acquire load at system scope invalidates the
+            // caches at every iteration -- with a waiting thread per block of a 391-block launch that was 90 us)
+            while (__hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
                 if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
