@@ -67,6 +67,10 @@ static void find_direct_weights(const nsk_graph_desc *d, Compiled &c, int64_t nw
             const int64_t wid = d->factor[f].weightId;
             if (wid >= 0 && wid < nw && nfac_of[(size_t)wid] < 2) nfac_of[(size_t)wid]++;
         }
+        for (int64_t f : c.repeated_factors) {                       // a factor listed twice by one variable: two visits per class
+            const int64_t wid = d->factor[f].weightId;
+            if (wid >= 0 && wid < nw) nfac_of[(size_t)wid] = 2;
+        }
         for (int64_t t = 0; t < nwb; t++) {                          // weights named by uniform tiles' programs
             const uint32_t *td = &c.tiles[4 * t];
             if (td[2] == 0xFFFFFFFFu || ((td[3] >> 8) & 7u) >= 6u) continue;
@@ -270,7 +274,13 @@ static int validate_reachable(const nsk_graph_desc *d, Compiled &c, const std::v
                             is.rc = NSK_E_INDEX;
                             break;
                         }
-                        checked[f] = 1;                   // (several threads may store the same 1)
+                        // a factor twice in ONE list (compute_var_map never produces that, dataloading.py:68-81; a
+                        // caller of the C-ABI may): its weight is then visited twice by one variable in one class and
+                        // must not be updated in place at "its one visit" (find_direct_weights); 2 marks it
+                        bool twice = false;
+                        for (int64_t i = std::max<int64_t>(0, j - 64); i < j && !twice; i++)
+                            twice = d->factor_index[vt.factor_index_offset + i] == f;
+                        checked[f] = twice ? 2 : (checked[f] == 2 ? 2 : 1);     // (several threads may store the same values)
                     }
                 }
             }
@@ -282,6 +292,8 @@ static int validate_reachable(const nsk_graph_desc *d, Compiled &c, const std::v
             for (int64_t f = fb0; f < fb1 && !is.rc; f++)
                 if (checked[f]) is.rc = check_factor(f, is);
         });
+        c.repeated_factors.clear();
+        for (int64_t f = 0; f < nfac; f++) if (checked[f] == 2) c.repeated_factors.push_back(f);
         for (const Issue &is : issues) {
             if (is.rc) { err = is.msg; return is.rc; }
             c.has_ufo = c.has_ufo || is.ufo;

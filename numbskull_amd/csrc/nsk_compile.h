@@ -204,6 +204,7 @@ struct Compiled {
     // other weights, the only ones the update launch then walks.  Weights that a uniform tile's program
     // names stay with the accumulators (those kernels sum per tile, not per visit).
     std::vector<uint32_t> w_direct;
+    std::vector<int64_t> repeated_factors;     // factors some variable lists twice in one list (never direct: two visits per class)
     std::vector<int32_t> multi_wids;
     int64_t ndirect = 0;
     // Internal numbering of the direct weights (whole-graph handles): with one weight per factor the table

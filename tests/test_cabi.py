@@ -373,3 +373,26 @@ def test_weight_slots_only_on_whole_graph_handles_with_single_factor_weights():
     assert part["direct_weights"] > 0 and part["weight_slots"] == 0
     lr = session(graphgen.mixed_lr_graph(20000, seed=3, nweights=500), head_by_vid=True)[1].plan()[1]
     assert lr["direct_weights"] == 0 and lr["weight_slots"] == 0
+
+
+def test_a_factor_listed_twice_by_one_variable_is_not_updated_in_place():
+    """compute_var_map never lists a factor twice for one (variable, value) (dataloading.py:68-81), but a caller that
+    hands prebuilt lists to loadFactorGraphRaw may: such a factor's weight is visited twice by one variable in one
+    colour class, so the compiler must keep it on the accumulators (nsk_graph_info.direct_weights)."""
+    bw = list(graphgen.boolean_weighted_graph(4000, seed=5))
+    bw[0]["isFixed"] = False
+    fg = session(tuple(bw))[1]
+    base = fg.plan()[1]["direct_weights"]
+    assert base > 0
+    # variable v's list with its first factor twice: append a second copy of the whole index with the duplicate
+    vm, fi = fg.vmap.copy(), fg.factor_index.copy()
+    v = int(np.argmax(vm["factor_index_length"] >= 1))
+    off, ln = int(vm["factor_index_offset"][v]), int(vm["factor_index_length"][v])
+    dup = np.concatenate([fi[off:off + ln], fi[off:off + 1]])
+    vm["factor_index_offset"][v] = len(fi)
+    vm["factor_index_length"][v] = ln + 1
+    fi2 = np.concatenate([fi, dup])
+    ns = numbskull_amd.NumbSkull(quiet=True)
+    ns.loadFactorGraphRaw(fg.weight, fg.variable, fg.factor, fg.fmap, vm, fi2)
+    again = ns.factorGraphs[0].plan()[1]["direct_weights"]
+    assert again == base - 1
