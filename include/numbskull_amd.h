@@ -309,6 +309,12 @@ int nsk_learn_sweeps_p2p(nsk_graph *g, int64_t nsweeps, double step, double deca
                          double reg_param, int64_t truncation, int learn_non_evidence);
 int nsk_p2p_exchange(nsk_graph *g, int learn, int part);
 int nsk_p2p_selftest(nsk_graph *g, int learn, int part);
+/* The fused exchange (nsk_graph_info.p2p_fused) reads and writes peer memory with system-coherent loads / stores
+ * and no fences.  nsk_p2p_selftest(g, 2, part) runs that protocol in isolation with a pattern payload (part 0: all
+ * of it; 1 / 2: the writing / the reading half); nsk_p2p_fuse(g, 0) makes the handle keep the exchange kernels
+ * (what PartitionedSampler does on every rank when any rank's test fails), nsk_p2p_fuse(g, 1) plans the fused
+ * exchange again.  Returns 1 / 0 = fused or not afterwards, < 0 on error. */
+int nsk_p2p_fuse(nsk_graph *g, int on);
 int nsk_p2p_check(nsk_graph *g);
 
 /* ---- host-side index build and file parsing (no GPU needed) ---- */

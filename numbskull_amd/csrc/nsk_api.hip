@@ -1379,13 +1379,61 @@ int nsk_p2p_check(nsk_graph *g) {
     return NSK_OK;
 }
 
+}  // extern "C"
+
+// learn == 2: the memory protocol of the fused exchange (k_p2p_fused_selftest)
+template <typename VT>
+static int p2p_fused_selftest(nsk_graph *g, int part) {
+    if (!g->p2p_peer_mask) return NSK_OK;
+    if (part != 2) ++g->p2p_tag;
+    P2PPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    for (int q = 0; q < g->pworld; q++) {
+        plan.base[q] = g->p2p_peer_base[q];
+        plan.soff[q] = (unsigned long long)g->p_soff[q];
+        plan.roff[q] = (unsigned long long)g->p_roff[q];
+        plan.dbase[q] = (unsigned long long)g->p_dbase[q];
+        plan.dtotal[q] = (unsigned long long)g->p_dtotal[q];
+    }
+    for (int q = g->pworld; q <= 16; q++) { plan.soff[q] = (unsigned long long)g->p_nsend; plan.roff[q] = (unsigned long long)g->p_nrecv; }
+    k_p2p_fused_selftest<VT><<<dim3(1), dim3(NSK_BLOCK), 0, g->stream>>>((long long)g->p_nsend, (long long)g->p_nrecv, plan, g->p2p_base,
+                                                                         g->pworld, g->prank, g->p2p_peer_mask, g->p2p_tag, g->p2p_err,
+                                                                         g->p2p_timeout_ticks, part);
+    HIPCHECK(hipGetLastError());
+    return NSK_OK;
+}
+
+extern "C" {
+
 int nsk_p2p_selftest(nsk_graph *g, int learn, int part) {
     if (!g) return fail(NSK_E_INVALID, "null graph");
     if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
     if (part < 0 || part > 3) return fail(NSK_E_INVALID, "bad part");
     HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
+    if (learn == 2) {
+        if (part == 3) return NSK_OK;
+        return g->c.vbytes == 1 ? p2p_fused_selftest<int8_t>(g, part) : p2p_fused_selftest<int32_t>(g, part);
+    }
     return g->c.vbytes == 1 ? p2p_exchange<int8_t>(g, nullptr, 0, learn != 0, part, 1)
                             : p2p_exchange<int32_t>(g, nullptr, 0, learn != 0, part, 1);
+}
+
+int nsk_p2p_fuse(nsk_graph *g, int on) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->p2p_ready) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export / nsk_p2p_import first");
+    HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
+    if (on) {
+        int rc = p2p_fuse_plan(g);
+        if (rc) return rc;
+    } else if (g->p2p_fused) {
+        g->p2p_fused = false;
+        g->p2p_border_tiles.clear();
+        g->seg_plans_key = -1;
+    }
+    nsk_drop_sweep_graph(g);
+    return g->p2p_fused ? 1 : 0;
 }
 
 int nsk_p2p_exchange(nsk_graph *g, int learn, int part) {

@@ -2026,13 +2026,15 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
         const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
         u32x4 rb = {0u, 0u, 0u, 0u};
         bool have_b = false;
-        if (h >= 0) {                                                   // wave-uniform
+        // interior runs (no tile of the segment touches the boundary: none reads a ghost, none pushes) take the
+        // single-GPU body as it is -- only the border runs, a percent of a shard's tiles, pay for the other one
+        if (en.push_off == NSK_NO_STREAM) {                             // wave-uniform
+            if (h >= 0) tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            else tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+        } else if (h >= 0) {
             tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
-        } else if (NSK_TAB_BATCH == 4) {
-            tab_tiles_x<VT, NCH, 4, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         } else {
-            tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
-            tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
+            tab_tiles_x<VT, NCH, 4, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         }
     }
 }

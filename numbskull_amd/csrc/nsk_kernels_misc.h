@@ -299,6 +299,59 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_exchange(VT *val, VT *val_evi
     }
 }
 
+// Set-up self-test of the FUSED exchange's memory protocol (nsk_kernels_gibbs.h TabP2P): what the border tiles of
+// the table launches do, in isolation -- system-coherent stores of a pattern into the readers' receive blocks, wait
+// for their acknowledgement, flag; then relaxed polls of the peers' flags and system-coherent loads of this rank's
+// receive block, compared with what the peers must have written.  No acquire / release fence anywhere: if this
+// device pair needs one for a peer's writes to become visible, the test fails and the ranks keep the exchange
+// kernels.  One workgroup.
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_fused_selftest(long long nsend, long long nrecv, P2PPlan pl, const void *mine, int world, int me,
+                                                                  unsigned int peer_mask, unsigned int tag, unsigned int *err,
+                                                                  unsigned long long timeout_ticks, int part) {
+    const size_t par = tag & 1u, roff = nsk_p2p_recv_off(world);
+    if (part != 2) {
+        for (long long k = threadIdx.x; k < nsend; k += NSK_BLOCK) {
+            int q = 0;
+            while (q + 1 < world && (unsigned long long)k >= pl.soff[q + 1]) q++;
+            const unsigned long long kl = (unsigned long long)k - pl.soff[q];
+            const nsk_rsrc rp = nsk_make_rsrc((VT *)((char *)pl.base[q] + roff) + par * 2 * (size_t)pl.dtotal[q]);
+            nsk_buf_st_sys<VT>(rp, (uint32_t)(pl.dbase[q] + kl), (int)p2p_pattern<VT>(me, kl, tag, 0));
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the stores have been acknowledged
+        __syncthreads();
+        if (threadIdx.x < (unsigned)world && ((peer_mask >> threadIdx.x) & 1u))
+            __hip_atomic_store((unsigned int *)pl.base[threadIdx.x] + (par * 2 + 0) * (size_t)world + (size_t)me, tag,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (part == 1) return;
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        ok = 1;
+        const unsigned long long t0 = wall_clock64();
+        const unsigned int *flags = (const unsigned int *)mine + (par * 2 + 0) * (size_t)world;
+        for (int q = 0; q < world && ok; q++) {
+            if (!((peer_mask >> q) & 1u)) continue;
+            while (__hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+                if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (!ok) (void)__hip_atomic_fetch_or(err, NSK_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!ok) return;
+    const nsk_rsrc rg = nsk_make_rsrc((const VT *)((const char *)mine + roff) + par * 2 * (size_t)nrecv);
+    for (long long j = threadIdx.x; j < nrecv; j += NSK_BLOCK) {
+        int q = 0;
+        while (q + 1 < world && (unsigned long long)j >= pl.roff[q + 1]) q++;
+        const unsigned long long jl = (unsigned long long)j - pl.roff[q];
+        const uint32_t got = nsk_buf_ld_sys<VT>(rg, (uint32_t)j, 0u);
+        if (got != ((uint32_t)(int)p2p_pattern<VT>(q, jl, tag, 0) & 0xFFu))
+            (void)__hip_atomic_fetch_or(err, NSK_P2P_ERR_PAYLOAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // the closing half of a learning exchange: wait for the owners' merged slices, then w = w_start = merged
 // (the same vector on every rank)
 template <typename VT>

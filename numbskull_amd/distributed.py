@@ -278,7 +278,22 @@ class PartitionedSampler(object):
         for _ in range(2):
             rc = rc or self.L.nsk_p2p_selftest(self.h, 1, 0)
         rc = rc or self.L.nsk_p2p_check(self.h)
-        return agreed(rc == 0)
+        if not agreed(rc == 0):
+            return False
+        # shards that live in table segments exchange INSIDE their class launches (nsk_graph_info.p2p_fused): system-
+        # coherent loads / stores of peer memory, no fences.  That protocol gets a self-test of its own, and every
+        # rank keeps the exchange kernels unless every rank passes it
+        fused = bool(self.fg.info()["p2p_fused"])
+        rc = 0
+        if fused:
+            for _ in range(2):
+                rc = rc or self.L.nsk_p2p_selftest(self.h, 2, 0)
+            rc = rc or self.L.nsk_p2p_check(self.h)
+            if rc:
+                self._lib.lib().nsk_last_error()
+        if not agreed(fused and rc == 0):
+            self.L.nsk_p2p_fuse(self.h, 0)
+        return True
 
     def check(self):
         """Raise if a peer-to-peer exchange since the last check timed out (synchronises the stream)."""

@@ -87,6 +87,14 @@ def wire_p2p(parts):
                 _lib.check(L.nsk_p2p_selftest(p.h, 1, part))
     for p in parts:
         p.check()
+    # ... and the fused exchange's own protocol (system-coherent loads / stores, no fences) where the shards qualify
+    if all(p.fg.info()["p2p_fused"] for p in parts):
+        for _ in range(2):
+            for part in (1, 2):
+                for p in parts:
+                    _lib.check(L.nsk_p2p_selftest(p.h, 2, part))
+        for p in parts:
+            p.check()
     return needs
 
 
