@@ -189,11 +189,7 @@ int nsk_graph_get_layout(nsk_graph *g, int32_t *iid, int64_t *nid);
  * draws come from the quad scheme -- positions inside segments with draw tables: ids q, q + 64, q + 128,
  * q + 192 with equal q >> 8 share two Philox blocks, counter ((q >> 8) * 64 + (q & 63), stream, sweep),
  * stream 2 word (q >> 6) & 3 = the draw's high word, stream 3 the same word its low word -- instead of
- * the pair scheme described at nsk_set_seed.  Bit 41: the variable's LEARNING free-chain draw comes from
- * that quad scheme too (same streams, same words) -- the all-evidence segments of the learning sweep's table
- * launches, where sample_and_sgd draws one uniform per variable (learning.py:61-70); every other learning draw
- * uses counter (id, stream 0, sweep), words 0-1 free chain / 2-3 evidence chain.  What a checker needs to
- * reproduce the samples. */
+ * the pair scheme described at nsk_set_seed.  What a checker needs to reproduce the samples. */
 int nsk_graph_get_generators(nsk_graph *g, int64_t *gen);
 
 /* Weight slots: where the device table (NSK_BUF_WEIGHT) keeps each weight, slot[w] for the caller's id w

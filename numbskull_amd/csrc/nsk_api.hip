@@ -246,8 +246,14 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
             if (c.phase_end[k] > c.phase_fast_end[k]) generic_needed = true;
         if (generic_needed || nsk::diag_env("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
     }
-    UP(w_fixed); UP(logtab); UP(adj); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_win); UP(ep_win_off); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
+    UP(w_fixed); UP(logtab); UP(adj); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
+    // (value windows, -DNSK_EP_WIN builds only: no allocation otherwise -- the default build's sequence of device
+    // allocations is round 4's, address for address)
+    if (!c.ep_win.empty()) {
+        rc = dev_upload(g, &g->ep_win, c.ep_win); if (rc) return rc;
+        rc = dev_upload(g, &g->ep_win_off, c.ep_win_off); if (rc) return rc;
+    }
     rc = dev_upload(g, &g->w, c.w_init); if (rc) return rc;
     if (c.ndirect > 0) {
         rc = dev_upload(g, &g->w_direct, c.w_direct); if (rc) return rc;
@@ -256,9 +262,10 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     const size_t nvar = (size_t)c.nvar, npos = (size_t)c.npos, vb = (size_t)c.vbytes, nid = (size_t)c.nid;
     uint8_t *tmp = nullptr;
     rc = dev_alloc(g, &tmp, npos * vb); if (rc) return rc; g->p_init = tmp;
-    // (+ 16 bytes: the value windows of the entry-parallel groups are copied in whole 16-byte chunks)
-    rc = dev_alloc(g, &tmp, nid * vb + 16); if (rc) return rc; g->val = tmp;
-    rc = dev_alloc(g, &tmp, nid * vb + 16); if (rc) return rc; g->val_evid = tmp;
+    // (+ 16 bytes with value windows: they are copied in whole 16-byte chunks)
+    const size_t vpad = c.ep_win.empty() ? 0 : 16;
+    rc = dev_alloc(g, &tmp, nid * vb + vpad); if (rc) return rc; g->val = tmp;
+    rc = dev_alloc(g, &tmp, nid * vb + vpad); if (rc) return rc; g->val_evid = tmp;
     rc = upload_values(g, g->p_init, c.p_init.data(), npos); if (rc) return rc;
     {   // values live at internal ids (padding positions hold 0 and are never read as a variable)
         std::vector<int32_t> init_i(nid, 0);
@@ -773,17 +780,9 @@ int nsk_graph_get_generators(nsk_graph *g, int64_t *gen) {
     for (const Compiled::Segment &sg : c.segments)
         if (sg.ztab >= 0)
             for (int64_t p = sg.pos0; p < sg.pos0 + (int64_t)sg.ntiles * 64 && p < c.npos; p++) quad[(size_t)p] = 1;
-    // bit 41: learning sweeps draw the free chain of the position from the quad scheme too -- the all-evidence
-    // segments of the learning sweep's table launches (one uniform per variable there)
-    for (const Compiled::SegLaunch &sl : c.learn_seg)
-        if (sl.tab)
-            for (int i = 0; i < sl.n; i++)
-                if (sl.ev[i] == 1)
-                    for (int64_t p = sl.pos0[i]; p < (int64_t)sl.pos0[i] + (int64_t)(sl.tile_start[i + 1] - sl.tile_start[i]) * 64 && p < c.npos; p++)
-                        quad[(size_t)p] |= 2;
     for (int64_t v = 0; v < c.nvar; v++) {
         const int64_t p = c.color[v] >= 0 ? (int64_t)c.iid[v] : -1;
-        gen[v] = p < 0 ? -1 : (p | ((p < c.npos && (quad[(size_t)p] & 1)) ? (1ll << 40) : 0ll) | ((p < c.npos && (quad[(size_t)p] & 2)) ? (1ll << 41) : 0ll));
+        gen[v] = p < 0 ? -1 : (p | ((p < c.npos && quad[(size_t)p]) ? (1ll << 40) : 0ll));
     }
     return NSK_OK;
 }

@@ -314,9 +314,7 @@ __device__ __forceinline__ void pair_sat(int x, bool &b0, bool &b1) {
 template <typename VT, int KIND>
 __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink &sk, const uint4 *sp,
                                            int len, uint32_t prog, int p, bool valid,
-                                           const LearnParams &lp, bool quad = false) {
-    // quad (wave-uniform): an all-evidence segment of a table launch sampled by the exp path -- its free chain
-    // draws from the quad scheme like k_learn_seg_tab does
+                                           const LearnParams &lp) {
     const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + prog);
     const NSK_SCALAR double *tw = (const NSK_SCALAR double *)(g.prog_w + 2 * (size_t)prog);
     const uint32_t info = valid ? g.p_info[p] : 0u;
@@ -364,9 +362,7 @@ __device__ __forceinline__ void learn_tile(const DevGraph<VT> &g, const GradSink
         evidence = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     }
     const double z0 = nsk_exp(p0), z1 = z0 + nsk_exp(p1);                 // 66-70
-    uint2 fw = uint2{r.x, r.y};
-    if (quad) fw = inf_words_quad(lp.k0, lp.k1, (uint32_t)p, lp.s0, lp.s1);
-    const double z = u53(fw.x, fw.y) * z1;
+    const double z = u53(r.x, r.y) * z1;
     const int proposal = (z0 >= z) ? 0 : ((z1 >= z) ? 1 : 0);
     if (valid) {
         g.val_evid[p] = (VT)evidence;
@@ -674,8 +670,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg(DevGraph<VT> g, SegTabl
         const int p = en.pos0 + t * 64 + lane;
         const bool valid = g.p_vid[p] >= 0;                  // -1: padding lane at a class end
         const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
-        learn_tile<VT, KIND>(g, sk, sp, 4 * NCH, en.prog, p, valid, lp,
-                             ((en.zmask_ev >> 16) & 1u) != 0u && (int)(int8_t)(en.zmask_ev >> 8) == 1);
+        learn_tile<VT, KIND>(g, sk, sp, 4 * NCH, en.prog, p, valid, lp);
     }
     close_sink<SMALLW>(g, sk);
 }
@@ -799,7 +794,6 @@ struct LearnTrip {                       // what a trip needs from memory before
 struct LearnTripInfo {                   // wave-uniform
     int pos, nt, t0, ev;
     uint32_t prog, zoff, zmask;
-    bool quad;                           // an all-evidence segment of a table launch: the free chain draws from the quad scheme
 };
 
 // SMALLW launches carry NSK_SERVICE_BLOCKS extra blocks in front (one round of XCDs, so the tile blocks keep
@@ -878,7 +872,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
         }
         ti.pos = c_pos; ti.nt = c_nt; ti.t0 = T0 - c_lo; ti.prog = c_prog; ti.zoff = c_zoff;
         ti.zmask = c_zmask_ev & 0xFFu; ti.ev = (int)(int8_t)(c_zmask_ev >> 8);
-        ti.quad = ((c_zmask_ev >> 16) & 1u) != 0u && ti.ev == 1;
         // implicit adjacency (nsk_compile.h seg_aff): slot bases by scalar loads, member = base + lane;
         // the bases of all the trip's tiles are requested before the first is looked at
         uint32_t ab[TPW][4 * NCH];
@@ -959,38 +952,19 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
         __builtin_amdgcn_sched_barrier(0);
 #endif
         if (ti.prog != cur_prog) { flush(); cur_prog = ti.prog; }             // uniform, rare
-        // An all-evidence segment (config #3's learning graph: every variable is evidence) needs ONE uniform per
-        // variable -- the evidence chain is not drawn (learning.py:61-62) -- and takes it from the inference sweep's
-        // quad scheme (nsk_device.h quad_block): the same lane of the four tiles of a position quad shares one Philox
-        // block, the top 27 bits decide unless they tie with the threshold's.  A block per variable spent three
-        // quarters of its words on nothing: 63 of the ~250 instructions of a tile.
-        u32x4 qa = {0u, 0u, 0u, 0u}, qb2 = {0u, 0u, 0u, 0u};
-        uint32_t qa_of = 0xFFFFFFFFu, qb_of = 0xFFFFFFFFu;                          // (wave-uniform) quads the blocks belong to
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             const bool valid = ti.t0 + k < ti.nt && r.init[k] >= 0;
             const int p = ti.pos + (ti.t0 + k) * 64 + lane;
-            int evidence = r.init[k];                                             // learning.py:61-62
-            int proposal;
-            if (ti.quad) {                                                        // (wave-uniform)
-                const uint32_t tq = (uint32_t)(ti.pos + (ti.t0 + k) * 64) >> 8, j = ((uint32_t)(ti.pos + (ti.t0 + k) * 64) >> 6) & 3u;
-                if (tq != qa_of) { qa = philox4x32(lp.k0, lp.k1, quad_block((uint32_t)p), 2u, lp.s0, lp.s1); qa_of = tq; }
-                const uint32_t hi = word_of(qa, j) >> 5;
-                proposal = hi > ef[k].x ? 1 : 0;                                  // 66-70
-                if (__builtin_expect(__any(hi == ef[k].x), 0)) {
-                    if (tq != qb_of) { qb2 = philox4x32(lp.k0, lp.k1, quad_block((uint32_t)p), 3u, lp.s0, lp.s1); qb_of = tq; }
-                    if (hi == ef[k].x) proposal = (word_of(qb2, j) >> 6) > ef[k].y ? 1 : 0;
-                }
-            } else {
 #ifdef NSK_ABL_NOPHILOX
-                const uint32_t hq = (uint32_t)p * 2654435761u ^ lp.s0;
-                const u32x4 rr = {hq, hq * 40503u, hq ^ 0x9E3779B9u, hq * 7u};
+            const uint32_t hq = (uint32_t)p * 2654435761u ^ lp.s0;
+            const u32x4 rr = {hq, hq * 40503u, hq ^ 0x9E3779B9u, hq * 7u};
 #else
-                const u32x4 rr = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
+            const u32x4 rr = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
 #endif
-                if (ti.ev != 1) evidence = k53(rr.z, rr.w) > ztab_K(ee[k]) ? 1 : 0;   // 54-58
-                proposal = k53(rr.x, rr.y) > ztab_K(ef[k]) ? 1 : 0;                   // 66-70
-            }
+            int evidence = r.init[k];                                             // learning.py:61-62
+            if (ti.ev != 1) evidence = k53(rr.z, rr.w) > ztab_K(ee[k]) ? 1 : 0;   // 54-58
+            const int proposal = k53(rr.x, rr.y) > ztab_K(ef[k]) ? 1 : 0;         // 66-70
             if (valid) {
 #ifndef NSK_ABL_LNOEVST
                 g.val_evid[p] = (VT)evidence;

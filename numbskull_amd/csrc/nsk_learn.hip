@@ -248,9 +248,7 @@ int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay
                     en.ntiles_lead = (uint32_t)nt_i;
                     en.pos0 = sl.pos0[i]; en.adj_off = sl.adj_off[i]; en.prog = sl.prog[i];
                     en.zoff = sl.zoff[i];
-                    // (bit 16: a table launch -- its all-evidence segments draw the free chain from the quad scheme
-                    // whichever kernel samples them, nsk_graph_get_generators bit 41)
-                    en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8) | (sl.tab ? 1u << 16 : 0u);
+                    en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
                     en.aff_off = use_tab ? sl.aff[i] : NSK_NO_STREAM;         // implicit adjacency (table kernel)
                 }
                 tab.ntiles = use_tab ? vt : sl.tile_start[sl.n];

@@ -702,25 +702,11 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             const orc_variable *var = &g->variable[v];
             if (var->isEvidence == 4) continue;
             /* learning sweep: one block per variable, counter (q, stream, sweep); stream 0 words 0-1
-             * free chain, 2-3 evidence chain; stream 1 words 0-1 the truncation coin.  Bit 41 of the
-             * generator id (the all-evidence segments of the library's learning table launches: one uniform
-             * per variable, the evidence chain is not drawn): the free chain's words come from the inference
-             * sweep's quad scheme -- streams 2 / 3, counter ((q >> 8) * 64 + (q & 63)), word (q >> 6) & 3 */
+             * free chain, 2-3 evidence chain; stream 1 words 0-1 the truncation coin */
             uint32_t r[4];
-            const uint64_t gid = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
-            const uint64_t q = gid & 0xFFFFFFFFFFull;
+            const uint64_t q = (g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v) & 0xFFFFFFFFFFull;
             orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)q, 0u,
                            (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
-            if ((gid >> 41) & 1u) {
-                uint32_t t4[4];
-                const uint32_t c0 = (uint32_t)(((q >> 8) << 6) | (q & 63u)), j = (uint32_t)((q >> 6) & 3u);
-                orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c0, 2u,
-                               (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, t4);
-                r[0] = t4[j];
-                orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c0, 3u,
-                               (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, t4);
-                r[1] = t4[j];
-            }
             int64_t evidence, proposal;
             if (var->isEvidence != 1) {
                 rc = draw_sample(g, v, Z, var_value_evid, weight_samp, orc_u53(r[2], r[3]), 1,
