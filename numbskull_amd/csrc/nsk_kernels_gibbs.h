@@ -1641,15 +1641,10 @@ __host__ __device__ inline size_t nsk_p2p_recv_off_(int world) { return ((size_t
 #endif
 // NT consecutive tiles of one quad, first tile = segment tile `t0` (word `w0` of the quad's blocks): every
 // load of the NT tiles is requested before the first draw, the draws' stores come last
-// tx / tlane: the wave carries the segment's table in a register -- lane l holds the top 27 bits of entry l & zmask
-// (tables of at most 64 entries: tlane) -- and a tile's lookup is a ds_bpermute, not a load: every wave of a launch
-// reading the same two cache lines made the launch time depend on WHERE the 256-byte table lies (its L2 channel):
-// 11.9 or 12.45 us per 10M-grid class, 36.6 or 38.5 per 40M-grid class, by the page the allocator happened to hand
-// out (tools/sessions/r5_s09.sh).  The low 26 bits are fetched on a tie only.
 template <typename VT, int NCH, int NT>
 __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry &en, int t0, int w0, int lane, int burnin,
                                           const u32x4 &ra, u32x4 &rb, bool &have_b, uint32_t qb,
-                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1, uint32_t tx, bool tlane) {
+                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
     const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
     const bool haff = en.aff_off != NSK_NO_STREAM;                      // implicit adjacency (nsk_compile.h seg_aff)
     const uint32_t zoff = en.zoff, zmask = en.zmask_ev & 0xFFu;
@@ -1700,19 +1695,8 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
         for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
     }
     uint2 e[NT];
-#ifndef NSK_TAB_NO_LANE_TABLE
-    if (tlane) {                                                        // (wave-uniform)
 #pragma unroll
-        for (int k = 0; k < NT; k++) {
-            e[k].x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx[k] & zmask) << 2), (int)tx);
-            e[k].y = 0u;
-        }
-    } else
-#endif
-    {
-#pragma unroll
-        for (int k = 0; k < NT; k++) e[k] = *(const uint2 *)(g.ztab + zoff + (idx[k] & zmask));
-    }
+    for (int k = 0; k < NT; k++) e[k] = *(const uint2 *)(g.ztab + zoff + (idx[k] & zmask));
     // draws: the high 27 bits decide unless they tie with the threshold's
     uint32_t hi[NT];
     int nv[NT];
@@ -1727,10 +1711,7 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
         if (!have_b) { rb = philox4x32(k0, k1, qb, 3u, s0, s1); have_b = true; }
 #pragma unroll
         for (int k = 0; k < NT; k++)
-            if (hi[k] == e[k].x) {
-                const uint32_t lowbits = tlane ? g.ztab[zoff + (idx[k] & zmask)].y : e[k].y;
-                nv[k] = (word_of(rb, (uint32_t)(w0 + k)) >> 6) > lowbits ? 1 : 0;
-            }
+            if (hi[k] == e[k].x) nv[k] = (word_of(rb, (uint32_t)(w0 + k)) >> 6) > e[k].y ? 1 : 0;
     }
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -1770,15 +1751,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     // the segment of the last located quad stays in scalar registers: most launches have one
     int c_lo = 0, c_hi = -1;
     SegEntry en = tab.e[0];
-    // ... and its draw table in a vector register (tab_tiles): lane l holds entry l & zmask
-    uint32_t tx = 0u;
-    bool tlane = false;
-    auto load_tx = [&]() {
-        const uint32_t zm = en.zmask_ev & 0xFFu;
-        tlane = zm < 64u;
-        tx = tlane ? g.ztab[en.zoff + ((uint32_t)lane & zm)].x : 0u;
-    };
-    load_tx();
     // units: quads [q0, qr) one per trip, then the pairs of quads [qr, q1)
     for (int U = wx; ; U += wpx) {
         int Q, h = -1;
@@ -1794,7 +1766,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
             en = tab.e[sidx];
             c_lo = en.tile_start;
             c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
-            load_tx();
         }
         const int lead = (int)(en.ntiles_lead >> 30);
         const int t0q = 4 * Q - en.tile_start - lead;                   // segment tile of the quad's first tile
@@ -1804,12 +1775,12 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
         u32x4 rb = {0u, 0u, 0u, 0u};
         bool have_b = false;
         if (h >= 0) {                                                   // wave-uniform
-            tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, tx, tlane);
+            tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
         } else if (NSK_TAB_BATCH == 4) {
-            tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, tx, tlane);
+            tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
         } else {
-            tab_tiles<VT, NCH, 2>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, tx, tlane);
-            tab_tiles<VT, NCH, 2>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, tx, tlane);
+            tab_tiles<VT, NCH, 2>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            tab_tiles<VT, NCH, 2>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
         }
     }
 }
@@ -2032,15 +2003,6 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
     // the segment of the last located quad stays in scalar registers: most launches have one
     int c_lo = 0, c_hi = -1;
     SegEntry en = tab.e[0];
-    // ... and its draw table in a vector register (tab_tiles): lane l holds entry l & zmask
-    uint32_t tx = 0u;
-    bool tlane = false;
-    auto load_tx = [&]() {
-        const uint32_t zm = en.zmask_ev & 0xFFu;
-        tlane = zm < 64u;
-        tx = tlane ? g.ztab[en.zoff + ((uint32_t)lane & zm)].x : 0u;
-    };
-    load_tx();
     // units: quads [q0, qr) one per trip, then the pairs of quads [qr, q1)
     for (int U = wx; ; U += wpx) {
         int Q, h = -1;
@@ -2056,7 +2018,6 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
             en = tab.e[sidx];
             c_lo = en.tile_start;
             c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
-            load_tx();
         }
         const int lead = (int)(en.ntiles_lead >> 30);
         const int t0q = 4 * Q - en.tile_start - lead;                   // segment tile of the quad's first tile
@@ -2068,8 +2029,8 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
         // interior runs (no tile of the segment touches the boundary: none reads a ghost, none pushes) take the
         // single-GPU body as it is -- only the border runs, a percent of a shard's tiles, pay for the other one
         if (en.push_off == NSK_NO_STREAM) {                             // wave-uniform
-            if (h >= 0) tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, tx, tlane);
-            else tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, tx, tlane);
+            if (h >= 0) tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            else tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
         } else if (h >= 0) {
             tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
         } else {
