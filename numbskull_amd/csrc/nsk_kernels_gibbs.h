@@ -1178,6 +1178,9 @@ __device__ __forceinline__ uint32_t ep_facts(int cstar, int A, int B) {
 // round-robin: neighbouring groups read the same value lines (one L2), and every XCD gets its share
 // of every region of the colour (the long-list groups come first).  `li` counts a workgroup's XCD-local
 // groups; ep_group() maps it to the group or -1.
+#ifndef NSK_EP_U_INF
+#define NSK_EP_U_INF 1            // rows a wave takes per step in the inference launch (ep_pass)
+#endif
 #define NSK_EP_CHUNK 16
 struct EpWalk { int li, lend, step, xcd; };
 __device__ __forceinline__ EpWalk ep_walk(int ngroups, int hblocks, int gblocks) {
@@ -1343,7 +1346,7 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
                 ((uint32_t *)fs)[i] = 14u | (14u << 16);                                   // owned by no candidate
             __syncthreads();
 #ifndef NSK_ABL_EPNOP1
-            ep_pass<VT, false, 2, true, true, 1>(g, g.val, g.val, sub, rowsw, g.ep_wt + (size_t)wrow * 64,
+            ep_pass<VT, false, 2, true, true, NSK_EP_U_INF>(g, g.val, g.val, sub, rowsw, g.ep_wt + (size_t)wrow * 64,
                 (const signed char *)wina, (const signed char *)wina, g.ep_win != nullptr,
                 [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &, double w) {
                     int cstar, A, B;

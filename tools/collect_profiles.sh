@@ -77,6 +77,8 @@ for WL in ${NSK_PROFILE_BENCH_ONLY:-ising40m ising100m lr50m lr50m_learn}; do
   echo "bench $WL rc $rc"
 done
 [ -z "$NSK_PROFILE_SKIP_DEFAULT" ] && NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_bench.json 2>/dev/null
+# (the same two ranks through the exchange kernels instead of the fused class launches, for comparison)
+[ -z "$NSK_PROFILE_SKIP_DEFAULT" ] && NSK_DIAG=1 NSK_NO_P2P_FUSE=1 NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_exchange_kernels_bench.json 2>/dev/null
 [ -z "$NSK_PROFILE_SKIP_DEFAULT" ] && NSK_BENCH_ONE_DEVICE=1 NSK_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload lr5m_learn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${RT}_two_ranks_one_device_lr5m_learn_bench.json 2>/dev/null
 # the 8-shard runs on one device (per-shard phase timings): config #4 through pack / unpack, configs #4 and #5
 # through the peer-to-peer kernels (the 50M graph included when the host has the memory)
