@@ -64,6 +64,8 @@ fi
 if [ -z "$NSK_PROFILE_SKIP_DEFAULT" ]; then      # (a partial collection of one kernel family skips the default and two-rank lines)
 python bench.py > $OUT/${RT}_default_bench.json 2> $OUT/${RT}_default_bench.err
 echo "default bench rc $?"
+python bench.py --steps 20 --warmup 5 > $OUT/${RT}_driver_flags_bench.json 2> /dev/null       # (the flags of the driver's own run)
+echo "driver-flags bench rc $?"
 fi
 for WL in ${NSK_PROFILE_BENCH_WORKLOADS:-ising10m ising10m_learn ising1m lr5m lr5m_learn boolw4m boolw4m_learn}; do
   [ $WL = ising10m ] && continue        # (the default line)
