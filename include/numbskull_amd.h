@@ -294,6 +294,15 @@ int nsk_synchronize(nsk_graph *g);
  *   nsk_p2p_check   synchronises and returns NSK_E_DEVICE when a peer's flag did not arrive within
  *                   NSK_P2P_TIMEOUT_S seconds (default 30), or a self-test payload differed, since the last
  *                   check (nsk_state_download reports a time-out too) */
+/* Partial factors (salt/src/messages.py:1333-1355 compute_pf_values / apply_pf_values): a reader shard that holds a
+ * factor OR / AND / ISTRUE with several members owned by THIS shard takes ONE aggregate of them instead of every
+ * member -- op 0: "some member is 1" (OR), op 1: "no member is 0" (AND, ISTRUE), a 1 / 0 value the reader keeps in a
+ * boolean ghost variable that stands in the factor for those members (numbskull_amd/graphgen.py partial_factors does
+ * the rewriting; the factor's value, hence every sample, is exactly what it is with the members themselves).
+ * nsk_pf_setup registers the aggregates this handle computes: members of aggregate j = member_vids[member_off[j] ..
+ * member_off[j+1]) (variables the handle holds).  A send list of nsk_p2p_setup (call it afterwards) names aggregate j
+ * as variable id nvar + j; every peer-to-peer exchange recomputes them (both chains in learning) before it pushes. */
+int nsk_pf_setup(nsk_graph *g, int64_t npf, const uint8_t *op, const int64_t *member_off, const int32_t *member_vids);
 int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, const int64_t *send_off,
                   const int32_t *recv_vids, const int64_t *recv_off, const int64_t *peer_base,
                   const int64_t *peer_total);
@@ -312,6 +321,19 @@ int nsk_p2p_selftest(nsk_graph *g, int learn, int part);
  * exchange again.  Returns 1 / 0 = fused or not afterwards, < 0 on error. */
 int nsk_p2p_fuse(nsk_graph *g, int on);
 int nsk_p2p_check(nsk_graph *g);
+
+/* ---- graph-aware partitioning (no GPU needed; salt/src/messages.py:542-670 find_connected_components /
+ * find_metis_parts).  A partition is a VARIABLE ORDER in front of the samplers' range partition
+ * (inference.py:17-18): nsk_graph_order keeps connected components together (method 0) and walks every component
+ * breadth first from a pseudo-peripheral variable (method 1, Cuthill-McKee), so that the shard formula's cut runs
+ * along a few BFS fronts; order[new id] = old id, cc_id[old id] = connected component (may be NULL), *ncc their
+ * number.  nsk_comm_volume: the communication volume -- (variable, foreign part) pairs read across the cut, i.e.
+ * the values one exchange moves, METIS' objtype = vol -- of the range partition into nparts <= 64 shards of the ids
+ * new_id[old id] (NULL: the caller's ids). ---- */
+int nsk_graph_order(int64_t nvar, int64_t nfactor, const nsk_factor *factor, int64_t nedge, const nsk_ftv *fmap,
+                    int method, int64_t *order, int64_t *cc_id, int64_t *ncc);
+int nsk_comm_volume(int64_t nvar, int64_t nfactor, const nsk_factor *factor, int64_t nedge, const nsk_ftv *fmap,
+                    const int64_t *new_id, int nparts, int64_t *volume);
 
 /* ---- host-side index build and file parsing (no GPU needed) ---- */
 /* dataloading.compute_var_map (dataloading.py:16-81), native and O(edges). */

@@ -1016,6 +1016,50 @@ int nsk_exchange_pack(nsk_graph *g, int which) { return exchange_step(g, which, 
 int nsk_exchange_unpack(nsk_graph *g, int which) { return exchange_step(g, which, false); }
 
 // ---- peer-to-peer exchange ------------------------------------------------------------------------
+// Partial factors (messages.py:1333-1355): `npf` aggregates over variables this handle holds; op 0 = "some member is
+// 1" (OR), 1 = "no member is 0" (AND / ISTRUE); members of aggregate j = member_vids[member_off[j] .. member_off[j+1]).
+// The value arrays grow by npf slots behind the internal ids; a peer-to-peer send list names aggregate j as variable
+// id nvar + j, and every exchange recomputes the aggregates (both chains in learning) before it pushes.
+int nsk_pf_setup(nsk_graph *g, int64_t npf, const uint8_t *op, const int64_t *member_off, const int32_t *member_vids) {
+    if (!g || npf < 0 || (npf && (!op || !member_off || !member_vids))) return fail(NSK_E_INVALID, "bad partial-factor description");
+    HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
+    std::vector<int32_t> off((size_t)npf + 1, 0), mem;
+    std::vector<uint8_t> ops((size_t)npf);
+    for (int64_t j = 0; j < npf; j++) {
+        if (op[j] > 1 || member_off[j + 1] < member_off[j] || member_off[0] != 0) return fail(NSK_E_INVALID, "bad partial-factor description");
+        ops[(size_t)j] = op[j];
+        for (int64_t k = member_off[j]; k < member_off[j + 1]; k++) {
+            if (member_vids[k] < 0 || member_vids[k] >= g->c.nvar) return fail(NSK_E_INDEX, "partial factor over a variable this handle does not hold");
+            mem.push_back(g->c.iid[member_vids[k]]);
+        }
+        off[(size_t)j + 1] = (int32_t)mem.size();
+    }
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    nsk_drop_sweep_graph(g);
+    // value arrays with npf more slots (contents kept)
+    const size_t vb = (size_t)g->c.vbytes, nid = (size_t)g->c.nid;
+    for (int chain = 0; chain < 2; chain++) {
+        void *&arr = chain ? g->val_evid : g->val;
+        uint8_t *bigger = nullptr;
+        int rc = dev_alloc(g, &bigger, (nid + (size_t)npf) * vb + 16);
+        if (rc) return rc;
+        HIPCHECK(hipMemsetAsync(bigger, 0, (nid + (size_t)npf) * vb + 16, g->stream));
+        HIPCHECK(hipMemcpyAsync(bigger, arr, nid * vb, hipMemcpyDeviceToDevice, g->stream));
+        HIPCHECK(hipStreamSynchronize(g->stream));
+        g->allocs.erase(std::remove(g->allocs.begin(), g->allocs.end(), arr), g->allocs.end());
+        (void)hipFree(arr);
+        arr = bigger;
+    }
+    int rc;
+    if ((rc = dev_upload(g, &g->pf_op, ops))) return rc;
+    if ((rc = dev_upload(g, &g->pf_off, off))) return rc;
+    if ((rc = dev_upload(g, &g->pf_mem, mem))) return rc;
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    g->npf = npf;
+    return NSK_OK;
+}
+
 int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, const int64_t *send_off,
                   const int32_t *recv_vids, const int64_t *recv_off, const int64_t *peer_base,
                   const int64_t *peer_total) {
@@ -1034,6 +1078,10 @@ int nsk_p2p_setup(nsk_graph *g, int world, int rank, const int32_t *send_vids, c
     if (peer_total[rank] != nrecv) return fail(NSK_E_INVALID, "peer_total[rank] must be this rank's receive total");
     std::vector<int32_t> sv((size_t)nsend), rv((size_t)nrecv);
     for (int64_t i = 0; i < nsend; i++) {
+        if (send_vids[i] >= g->c.nvar && send_vids[i] < g->c.nvar + g->npf) {       // partial-factor aggregate (nsk_pf_setup)
+            sv[(size_t)i] = (int32_t)(g->c.nid + (send_vids[i] - g->c.nvar));
+            continue;
+        }
         if (send_vids[i] < g->c.own_begin || send_vids[i] >= g->c.own_end)
             return fail(NSK_E_INDEX, "send list names a variable this handle does not own");
         sv[(size_t)i] = g->c.iid[send_vids[i]];               // the kernels address values by internal id
@@ -1289,6 +1337,9 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
                                                                        mask, tag, g->p2p_err, g->p2p_timeout_ticks, selftest);
         if (!selftest) g->weights_dirty = true;
     };
+    if ((part == 0 || part == 1) && g->npf > 0 && !selftest)         // the partial-factor aggregates this rank's readers take
+        k_pf_compute<VT><<<dim3((unsigned)((g->npf + NSK_BLOCK - 1) / NSK_BLOCK)), dim3(NSK_BLOCK), 0, g->stream>>>(
+            (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->pf_op, g->pf_off, g->pf_mem, (int)g->npf, (long long)g->c.nid);
     if (part == 0) {                            // the sweep loops: push, flags, wait and unpack in one launch
         const int nb = blocks(std::max(std::max(g->p_nsend, g->p_nrecv), wwork));
         k_p2p_exchange<VT, true><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(

@@ -131,6 +131,10 @@ struct nsk_graph {
     unsigned int p2p_peer_mask = 0, p2p_tag = 0;
     unsigned long long p2p_timeout_ticks = 3000000000ull;      // 30 s of the 100 MHz wall clock (NSK_P2P_TIMEOUT_S)
     bool p2p_ready = false;
+    // partial-factor aggregates this rank computes for its readers (nsk_pf_setup): value slots [nid, nid + npf)
+    int64_t npf = 0;
+    uint8_t *pf_op = nullptr;
+    int32_t *pf_off = nullptr, *pf_mem = nullptr;
     // Fused boundary exchange of the table launches (nsk_api.hip p2p_fuse_plan, nsk_kernels_gibbs.h TabP2P): the
     // inference sweeps of a handle that lives in table segments read their ghosts from the receive block and
     // push their boundary values from inside the class launches -- no exchange kernels per sweep

@@ -299,6 +299,28 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_exchange(VT *val, VT *val_evi
     }
 }
 
+// Partial-factor values (salt/src/messages.py:1333-1349 compute_pf_values): a reader shard that holds
+// a factor OR / AND / ISTRUE with several members owned by THIS shard reads ONE aggregate of them instead of every
+// member -- the factor's value over those members: "some member is 1" (OR) or "no member is 0" (AND, ISTRUE), stored as
+// 1 / 0 in an extra value slot behind the internal ids, from where the exchange pushes it like any boundary value
+// (the reader holds it as a boolean ghost variable in the members' place: f(a.., OR(b..)) = f(a.., b..) exactly).
+template <typename VT>
+__global__ __launch_bounds__(NSK_BLOCK) void k_pf_compute(VT *val, VT *val_evid, int both, const uint8_t *pf_op, const int32_t *pf_off,
+                                                          const int32_t *pf_mem, int npf, long long base) {
+    const int j = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);
+    if (j >= npf) return;
+    const bool is_or = pf_op[j] == 0;
+    bool a = !is_or, b = !is_or;
+    for (int k = pf_off[j]; k < pf_off[j + 1]; k++) {
+        const int id = pf_mem[k];
+        const int x = (int)val[id];
+        a = is_or ? (a || x == 1) : (a && x != 0);
+        if (both) { const int y = (int)val_evid[id]; b = is_or ? (b || y == 1) : (b && y != 0); }
+    }
+    val[base + j] = (VT)(a ? 1 : 0);
+    if (both) val_evid[base + j] = (VT)(b ? 1 : 0);
+}
+
 // Set-up self-test of the FUSED exchange's memory protocol (nsk_kernels_gibbs.h TabP2P): what the border tiles of
 // the table launches do, in isolation -- system-coherent stores of a pattern into the readers' receive blocks, wait
 // for their acknowledgement, flag; then relaxed polls of the peers' flags and system-coherent loads of this rank's

@@ -113,9 +113,14 @@ class PartitionedSampler(object):
     torch's current stream, so sweeps and collectives are ordered by the stream.
     """
 
-    def __init__(self, fg, dist, torch, rank, world, native=True, nvar_global=None, p2p=None):
+    def __init__(self, fg, dist, torch, rank, world, native=True, nvar_global=None, p2p=None, pf=None):
+        """``pf``: the partial factors of a shard rewritten by ``graphgen.partial_factors`` (its fourth return value):
+        aggregates over foreign members that this shard READS -- their owners compute and ship them (peer-to-peer
+        path only; SURVEY.md section 8 f3, salt/src/messages.py:1333-1355)."""
         from . import _lib
         self.fg, self.dist, self.torch, self.rank, self.world = fg, dist, torch, rank, world
+        self.pf = list(pf) if pf else []
+        self.all_pf = None              # every rank's requests (encoded), filled by setup_exchange
         self.L = _lib.lib()
         self._lib = _lib
         h = fg._engine()
@@ -149,6 +154,9 @@ class PartitionedSampler(object):
             # pass or none uses it (the collective loop stays as the fallback)
             if p2p if p2p is not None else os.environ.get("NSK_P2P", "1") != "0":
                 self.p2p = self._init_p2p()
+            if self.pf and not self.p2p:
+                raise RuntimeError("partial factors need the peer-to-peer exchange (their aggregates are computed by the "
+                                   "exchange kernels); it could not be set up")
 
     @property
     def val(self):
@@ -191,13 +199,35 @@ class PartitionedSampler(object):
         return np.where(len(self.gids) and self.gids[at] == ids, at, -1) if len(ids) else ids
 
     def global_needs(self):
-        """Sorted GLOBAL ids of the variables this shard reads but does not own."""
+        """Sorted GLOBAL ids of the variables this shard reads but does not own (the ghosts that stand for partial-
+        factor aggregates -- synthetic ids from ``nvar_global`` on -- are not variables of any rank: ``pf_requests``)."""
         needs = self.fg.ghost_needs()
-        return needs if self.gids is None else self.gids[needs].astype(np.int32)
+        if self.gids is None:
+            return needs
+        g = self.gids[needs]
+        return g[g < self.nvar_global].astype(np.int32)
+
+    def pf_requests(self):
+        """This shard's partial factors as one int32 array: per aggregate ``owner, op, count, member global ids...``."""
+        out = []
+        for q, op, members, _ in self.pf:
+            out += [int(q), int(op), len(members)] + [int(m) for m in members]
+        return np.asarray(out, np.int32)
+
+    @staticmethod
+    def _decode_pf(arr):
+        arr = np.asarray(arr, np.int64)
+        out, i = [], 0
+        while i < len(arr):
+            q, op, c = int(arr[i]), int(arr[i + 1]), int(arr[i + 2])
+            out.append((q, op, arr[i + 3:i + 3 + c].copy()))
+            i += 3 + c
+        return out
 
     def setup_exchange(self, native=True):
         needs = self.global_needs()
         self.all_needs = gather_needs(self.dist, self.torch, needs, self.world, self.dev)
+        self.all_pf = gather_needs(self.dist, self.torch, self.pf_requests(), self.world, self.dev)
         lists, slot = plan_boundaries(self.all_needs, self.world, self.nvar_global)
         self.install_boundaries(lists, slot)
         if native:
@@ -231,13 +261,26 @@ class PartitionedSampler(object):
         lies in every peer's receive list."""
         pairs = plan_pairs(self.all_needs, self.world, self.nvar_global)
         me, W = self.rank, self.world
-        send = [self._local(pairs[me][q]) for q in range(W)]
-        recv = [self._local(pairs[q][me]) for q in range(W)]
+        # partial factors: reader d's requests, in d's order, follow the plain values of every (owner, d) segment
+        reqs = [self._decode_pf(a) for a in (self.all_pf if self.all_pf is not None else [np.empty(0, np.int32)] * W)]
+        npf = [[sum(1 for q, _, _ in reqs[d] if q == s_) for d in range(W)] for s_ in range(W)]      # [owner][reader]
+        self.pf_out = []                # the aggregates this rank computes: (op, member global ids), slot = index
+        out_slots = [[] for _ in range(W)]
+        for d in range(W):
+            for q, op, members in reqs[d]:
+                if q == me:
+                    out_slots[d].append(len(self.pf_out))
+                    self.pf_out.append((op, members))
+        nloc = self.nvar
+        send = [np.concatenate([self._local(pairs[me][q]), nloc + np.asarray(out_slots[q], np.int64)]) for q in range(W)]
+        mine = [(q, lid) for q, _, _, lid in self.pf]
+        recv = [np.concatenate([self._local(pairs[q][me]), np.asarray([lid for o, lid in mine if o == q], np.int64)]) for q in range(W)]
         soff, roff = np.zeros(W + 1, np.int64), np.zeros(W + 1, np.int64)
         np.cumsum([len(x) for x in send], out=soff[1:])
         np.cumsum([len(x) for x in recv], out=roff[1:])
-        base = np.array([sum(len(pairs[s_][q]) for s_ in range(me)) for q in range(W)], np.int64)
-        total = np.array([sum(len(pairs[s_][q]) for s_ in range(W)) for q in range(W)], np.int64)
+        cnt = lambda s_, q: len(pairs[s_][q]) + npf[s_][q]
+        base = np.array([sum(cnt(s_, q) for s_ in range(me)) for q in range(W)], np.int64)
+        total = np.array([sum(cnt(s_, q) for s_ in range(W)) for q in range(W)], np.int64)
         cat = lambda xs: np.ascontiguousarray(np.concatenate(xs + [np.empty(0, np.int64)]), np.int32)
         return cat(send), soff, cat(recv), roff, base, total
 
@@ -245,6 +288,15 @@ class PartitionedSampler(object):
         _lib = self._lib
         send, soff, recv, roff, base, total = self.p2p_lists()
         assert (send >= 0).all() and (recv >= 0).all(), "a boundary list names a variable this shard does not hold"
+        if self.pf_out:                 # the aggregates this rank's readers asked for (before the lists that name them)
+            ops = np.asarray([op for op, _ in self.pf_out], np.uint8)
+            moff = np.zeros(len(self.pf_out) + 1, np.int64)
+            np.cumsum([len(m) for _, m in self.pf_out], out=moff[1:])
+            mem = np.ascontiguousarray(self._local(np.concatenate([m for _, m in self.pf_out])), np.int32)
+            assert (mem >= 0).all(), "a partial factor names a variable this shard does not hold"
+            rc = self.L.nsk_pf_setup(self.h, len(ops), _lib.ptr(ops), _lib.ptr(moff), _lib.ptr(mem))
+            if rc:
+                return rc
         return self.L.nsk_p2p_setup(self.h, self.world, self.rank, _lib.ptr(send), _lib.ptr(soff), _lib.ptr(recv),
                                     _lib.ptr(roff), _lib.ptr(base), _lib.ptr(total))
 

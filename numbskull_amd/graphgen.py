@@ -518,3 +518,122 @@ def write_graph(directory, weight, variable, factor, fmap, domains=None):
                 dom = np.asarray(domains[vid], np.int64)
                 np.array([vid, len(dom)], ">i8").tofile(f)
                 dom.astype(">i8").tofile(f)
+
+
+PF_FUNCS = {1: 0, 2: 1, 4: 1}      # OR -> "some member is 1"; AND, ISTRUE -> "no member is 0" (messages.py:1335-1337)
+
+
+def partial_factors(shard, gids, own, nvar_global, world):
+    """Partial factors for one shard of a range partition (the reference's PF surgery,
+    salt/src/messages.py:1083-1206, and its per-epoch values, :1333-1355).
+
+    ``shard, gids, own`` as returned by ``extract_shard`` / ``mixed_lr_shard``.  Every factor OR / AND / ISTRUE of the
+    shard that has TWO OR MORE members owned by one foreign shard q gets them replaced by ONE boolean ghost variable
+    (isEvidence 4) that stands for their aggregate -- "some member is 1" for OR, "no member is 0" for AND / ISTRUE --,
+    which q computes after every sweep and ships instead of the members' values (``nsk_pf_setup``).  The factor's
+    value is exactly what it is with the members themselves: OR(a.., b..) = OR(a.., OR(b..)), and AND likewise.
+    Factors with the same function class over the same foreign members share one aggregate.
+
+    Returns ``(shard', gids', own, pf)``: the rewritten shard; ``gids'`` = ``gids`` followed by synthetic global ids
+    ``nvar_global + k`` for the aggregates (they sort behind every real variable, like their local ids); ``pf`` = list of
+    ``(owner q, op, member global ids, local id of the ghost)`` in local-id order.  Ghost variables whose every use went
+    into an aggregate stay in the arrays unread (the library exchanges only what is read)."""
+    weight, variable, factor, fmap, domain_mask, edges = shard
+    gids = np.asarray(gids, np.int64)
+    l0, l1 = own
+    n = int(nvar_global)
+    bounds = (np.arange(world + 1, dtype=np.int64) * n) // world
+    owner_of = lambda g: int(np.searchsorted(bounds, g, side="right") - 1)
+    me = owner_of(int(gids[l0])) if l1 > l0 else -1
+    vid = fmap["vid"].astype(np.int64)
+    arity = factor["arity"].astype(np.int64)
+    off = factor["ftv_offset"].astype(np.int64)
+    fac_of_edge = np.repeat(np.arange(len(factor), dtype=np.int64), arity)
+    foreign_edge = (vid < l0) | (vid >= l1)
+    nforeign = np.bincount(fac_of_edge[foreign_edge], minlength=len(factor))
+    func = factor["factorFunction"].astype(np.int64)
+    cand = np.nonzero((nforeign >= 2) & np.isin(func, list(PF_FUNCS)))[0]
+    groups = {}                                 # (q, op, members) -> [(factor, member positions)]
+    for f in cand.tolist():
+        mem = vid[off[f]:off[f] + arity[f]]
+        by_owner = {}
+        for pos, m in enumerate(mem.tolist()):
+            if l0 <= m < l1:
+                continue
+            by_owner.setdefault(owner_of(int(gids[m])), []).append(pos)
+        for q, poss in by_owner.items():
+            if len(poss) < 2:
+                continue
+            key = (q, PF_FUNCS[int(func[f])], tuple(sorted(set(int(gids[mem[p]]) for p in poss))))
+            groups.setdefault(key, []).append((f, poss))
+    if not groups:
+        return shard, gids, own, []
+    keys = sorted(groups)
+    nloc = len(variable)
+    lvar = np.concatenate([variable, np.zeros(len(keys), variable.dtype)])
+    local_of = {}
+    pf = []
+    pos_of_gid = lambda g: int(np.searchsorted(gids[:nloc], g))
+    for k, key in enumerate(keys):
+        q, op, members = key
+        lid = nloc + k
+        local_of[key] = lid
+        inits = [int(variable["initialValue"][pos_of_gid(g)]) for g in members]
+        lvar[lid]["isEvidence"] = 4
+        lvar[lid]["dataType"] = 0
+        lvar[lid]["cardinality"] = 2
+        lvar[lid]["initialValue"] = int(any(x == 1 for x in inits)) if op == 0 else int(all(x != 0 for x in inits))
+        pf.append((q, op, np.asarray(members, np.int64), lid))
+    # rewrite the member lists of the factors concerned
+    drop = np.zeros(len(vid), np.bool_)
+    new_vid = vid.copy()
+    for key, uses in groups.items():
+        for f, poss in uses:
+            new_vid[off[f] + poss[0]] = local_of[key]          # the aggregate takes the first member's place
+            for p in poss[1:]:
+                drop[off[f] + p] = True
+    keep = ~drop
+    lfm = fmap[keep].copy()
+    lfm["vid"] = new_vid[keep]
+    lfm["dense_equal_to"][lfm["vid"] >= nloc] = 0
+    lfac = factor.copy()
+    lar = arity - np.bincount(fac_of_edge[drop], minlength=len(factor))
+    lfac["arity"] = lar
+    lfac["ftv_offset"] = np.cumsum(lar) - lar
+    dm = np.concatenate([np.asarray(domain_mask), np.zeros(len(keys), np.asarray(domain_mask).dtype)])
+    gids2 = np.concatenate([gids, n + np.arange(len(keys), dtype=np.int64)])
+    return (weight, lvar, lfac, lfm, dm, int(lar.sum())), gids2, own, pf
+
+
+def voter_graph(nheads, width=12, seed=0, nweights=8):
+    """"Voter" graph (the shape of the reference's experiments/ generators and of the graphs partial factors were made
+    for): ``nheads`` head variables, ids ``[0, nheads)``, each under ONE clause -- OR or AND -- over
+    ``width - 1`` voter variables of its own (ids ``nheads + i (width - 1) ...``, used by no other clause) and itself as
+    the last member; every voter also has an ISTRUE prior.  ``nweights`` shared free weights, half the heads evidence.
+    Range-partitioned, the shards that own the heads read every voter across the cut -- or one aggregate per clause."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nheads, k = int(nheads), int(width) - 1
+    nvar = nheads * (k + 1)
+    variable = np.zeros(nvar, Variable)
+    variable["cardinality"] = 2
+    variable["isEvidence"][:nheads] = rng.random(nheads) < 0.5
+    variable["initialValue"] = rng.integers(0, 2, nvar)
+    heads = np.arange(nheads, dtype=np.int64)
+    voters = nheads + heads[:, None] * k + np.arange(k, dtype=np.int64)[None, :]
+    clause_vid = np.concatenate([voters, heads[:, None]], axis=1).reshape(-1)
+    prior = np.arange(nheads, nvar, dtype=np.int64)
+    nf = nheads + len(prior)
+    factor = np.zeros(nf, Factor)
+    factor["factorFunction"][:nheads] = np.where(rng.random(nheads) < 0.5, 1, 2)        # OR / AND
+    factor["factorFunction"][nheads:] = FUNC_ISTRUE
+    factor["arity"][:nheads] = k + 1
+    factor["arity"][nheads:] = 1
+    factor["weightId"] = rng.integers(0, nweights, nf)
+    factor["featureValue"] = 1.0
+    ar = factor["arity"].astype(np.int64)
+    factor["ftv_offset"] = np.cumsum(ar) - ar
+    fmap = np.zeros(int(ar.sum()), FactorToVar)
+    fmap["vid"] = np.concatenate([clause_vid, prior])
+    weight = np.zeros(nweights, Weight)
+    weight["initialValue"] = rng.normal(0, 0.3, nweights)
+    return weight, variable, factor, fmap, np.zeros(nvar, np.bool_), len(fmap)

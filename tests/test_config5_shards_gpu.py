@@ -34,25 +34,37 @@ def make_parts(kind, nvar, learn, seed):
     from numbskull_amd.distributed import PartitionedSampler, shard_range
     parts, streams = [], []
     grid = None
-    if kind == "grid":
+    if kind in ("grid", "shuffled_grid"):
         rng = np.random.Generator(np.random.PCG64(20240602))
         rows, cols = nvar
         nvar = rows * cols
         grid = (graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True,
                                     evidence=rng.integers(0, 2, nvar)) if learn
                 else graphgen.ising_grid(rows, cols, weight=0.1))
+        if kind == "shuffled_grid":
+            # the grid under randomly permuted variable ids (a loader that numbers variables in arrival order), then
+            # repartitioned: numbskull_amd.partition puts a graph-aware variable order in front of the range partition
+            # (the reference's find_connected_components / find_metis_parts, salt/src/messages.py:542-670)
+            from numbskull_amd import partition
+            grid = partition.relabel(grid, rng.permutation(nvar))
+            lost = partition.comm_volume(nvar, grid[2], grid[3], WORLD)
+            _, order = partition.find_parts(nvar, grid[2], grid[3], WORLD)
+            found = partition.comm_volume(nvar, grid[2], grid[3], WORLD, order)
+            assert found < lost / 20, (lost, found)
+            grid = partition.relabel(grid, order)
+            kind = "grid"
     shards = None
-    if kind != "grid":      # all eight in one pass over the generator's blocks (a rank of a real run calls
+    if grid is None:      # all eight in one pass over the generator's blocks (a rank of a real run calls
         shards = graphgen.mixed_lr_shards(nvar, [shard_range(r, WORLD, nvar) for r in range(WORLD)],      # mixed_lr_shard)
                                           seed=LR_SEED)
     for r in range(WORLD):
         lo, hi = shard_range(r, WORLD, nvar)
-        if kind == "grid":
+        if grid is not None:
             sg, gids, own = graphgen.extract_shard(grid, lo, hi)
         else:
             sg, gids, own = shards[r]
             shards[r] = None
-        ns = numbskull_amd.NumbSkull(quiet=True, seed=seed, head_by_vid=kind != "grid")
+        ns = numbskull_amd.NumbSkull(quiet=True, seed=seed, head_by_vid=grid is None)
         ns.loadFactorGraph(*sg[:5], int(sg[5]), own_range=own, global_ids=gids)
         fg = ns.factorGraphs[0]
         st = torch.cuda.Stream()
@@ -103,7 +115,7 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1), 
     from numbskull_amd.distributed import shard_range, plan_pairs
     seed = 20240601
     parts, streams, nvar = make_parts(kind, size, learn, seed)
-    hbv = kind != "grid"
+    hbv = kind not in ("grid", "shuffled_grid")
     oracles = []
     for p in parts:
         og = oracle_of(p.fg, head_by_vid=hbv)           # checks the layout and the colouring of every shard
@@ -275,6 +287,15 @@ def test_grid10m_eight_shards_fused_exchange_matches_emulation():
     # one launch per colour class and nothing else (the grid's last shard holds the bottom row and the corners: more
     # segment entries than one launch carries, so one of its classes takes two)
     assert 2 <= out["launches_per_sweep"] <= 3, out
+
+
+def test_shuffled_grid_repartitioned_eight_shards_match_emulation():
+    """f4: a 1000x1000 grid whose variable ids arrive shuffled (the range partition then reads 88 % of all variables
+    across the cuts) is given a graph-aware variable order (numbskull_amd.partition, "auto": here the breadth-first
+    walk), cut by the reference's shard formula and sampled in 8 shards through the peer-to-peer exchange: bit-exact
+    against the partitioned oracle emulation like any other graph."""
+    out = run_case("shuffled_grid", (1000, 1000), False, "shuffled1m (1000x1000 grid, shuffled ids, repartitioned)", nsweeps=4)
+    assert sum(out["ghosts_per_rank"]) < 40000, out["ghosts_per_rank"]          # (880 000 under the shuffled ids)
 
 
 def test_lr50m_eight_shards_learning_p2p():

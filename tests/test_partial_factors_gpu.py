@@ -1,0 +1,147 @@
+"""Partial factors (salt/src/messages.py:1083-1206 the surgery, :1333-1355 compute_pf_values /
+apply_pf_values): shards of a range partition whose factors OR / AND / ISTRUE read several members of one foreign shard
+take ONE aggregate of them, computed by the owner and shipped by the peer-to-peer exchange.  Four shards on one device,
+bit-exact against the oracle's emulation of the same partitioned run (the oracle sees the rewritten shards; the
+aggregates are formed from the owners' emulated values)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from numbskull_amd import _lib, graphgen
+from numbskull_amd.distributed import PartitionedSampler, shard_range, plan_pairs
+from util import oracle_of, phases_from_colors
+import numbskull_amd
+
+pytestmark = pytest.mark.gpu
+WORLD = 4
+
+
+def build(g, nvar, use_pf, seed, hbv):
+    import torch
+    parts = []
+    for r in range(WORLD):
+        lo, hi = shard_range(r, WORLD, nvar)
+        sg, gids, own = graphgen.extract_shard(g, lo, hi)
+        pf = []
+        if use_pf:
+            sg, gids, own, pf = graphgen.partial_factors(sg, gids, own, nvar, WORLD)
+        ns = numbskull_amd.NumbSkull(quiet=True, seed=seed, head_by_vid=hbv)
+        ns.loadFactorGraph(*sg[:5], int(sg[5]), own_range=own, global_ids=gids)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            ps = PartitionedSampler(ns.factorGraphs[0], None, torch, r, 1, nvar_global=nvar, pf=pf)
+        ps.world = WORLD
+        parts.append(ps)
+    L = _lib.lib()
+    needs = [p.global_needs() for p in parts]
+    reqs = [p.pf_requests() for p in parts]
+    bases = (C.c_void_p * WORLD)()
+    for p in parts:
+        p.all_needs, p.all_pf = needs, reqs
+        _lib.check(p.p2p_setup())
+        b = C.c_void_p()
+        _lib.check(L.nsk_p2p_export(p.h, None, C.byref(b)))
+        bases[p.rank] = b.value
+    for p in parts:
+        _lib.check(L.nsk_p2p_import_local(p.h, bases))
+        p.p2p = True
+    return parts, needs
+
+
+def run(g, nvar, learn, seed=5, nsweeps=4, hbv=False):
+    import torch
+    L = _lib.lib()
+    plain, needs0 = build(g, nvar, False, seed, hbv)
+    shipped_plain = sum(len(n) for n in needs0)
+    for p in plain:
+        p.fg.close()
+    parts, needs = build(g, nvar, True, seed, hbv)
+    shipped = sum(len(n) for n in needs) + sum(len(p.pf) for p in parts)
+    npf = sum(len(p.pf) for p in parts)
+    oracles = []
+    for p in parts:
+        og = oracle_of(p.fg, head_by_vid=hbv)
+        oracles.append((og, phases_from_colors(p.fg.colors()), og.initial_state()))
+    pairs = plan_pairs(needs, WORLD, nvar)
+    step = 0.02
+    for s in range(nsweeps):
+        for p in parts:
+            if learn:
+                _lib.check(L.nsk_learn_sweeps(p.h, 1, step, 1.0, 2, 0.01, 1, 0))
+            else:
+                _lib.check(L.nsk_gibbs_sweeps(p.h, 1, 1, 0))
+            _lib.check(L.nsk_p2p_exchange(p.h, int(learn), 1))
+        for part in (2, 3):
+            for p in parts:
+                _lib.check(L.nsk_p2p_exchange(p.h, int(learn), part))
+        step *= 0.9
+    for p in parts:
+        p.check()
+    torch.cuda.synchronize()
+
+    def loc(r, ids):
+        at = np.searchsorted(parts[r].gids, ids)
+        assert np.array_equal(parts[r].gids[at], ids)
+        return at
+
+    step = 0.02
+    for s in range(nsweeps):
+        starts = [st[2].copy() for _, _, st in oracles]
+        for og, (order, ps_), (vv, ve, wv, cnt) in oracles:
+            if learn:
+                assert og.learn_call(order, ps_, vv, ve, wv, 1, step, 1.0, 2, 0.01, 1, False, seed, s) == 0
+            else:
+                assert og.gibbs_dev(order, ps_, vv, wv, cnt, seed, s, True) == 0
+        step *= 0.9
+        for r in range(WORLD):                   # owners publish what each peer reads of them: values ...
+            for q in range(WORLD):
+                if q != r and len(pairs[r][q]):
+                    b = pairs[r][q]
+                    oracles[q][2][0][loc(q, b)] = oracles[r][2][0][loc(r, b)]
+                    oracles[q][2][1][loc(q, b)] = oracles[r][2][1][loc(r, b)]
+        for r, p in enumerate(parts):            # ... and the aggregates of the partial factors (messages.py:1333-1349)
+            for q, op, members, lid in p.pf:
+                for chain in (0, 1):
+                    x = oracles[q][2][chain][loc(q, members)]
+                    oracles[r][2][chain][lid] = int((x == 1).any()) if op == 0 else int((x != 0).all())
+        if learn:
+            total = sum(st[2] - s0 for (_, _, st), s0 in zip(oracles, starts))
+            for (_, _, st), s0 in zip(oracles, starts):
+                st[2][:] = s0 + total
+    for r, p in enumerate(parts):
+        vv, ve, wv, cnt = oracles[r][2]
+        lo, hi = p.fg.own_range
+        got = p.val.cpu().numpy().astype(np.int64)
+        assert np.array_equal(got[lo:hi], vv[lo:hi]), ("owned values differ", r)
+        gh = loc(r, np.asarray(needs[r], np.int64))
+        assert np.array_equal(got[gh], vv[gh]), ("ghost values differ", r)
+        lids = np.asarray([lid for _, _, _, lid in p.pf], np.int64)
+        assert np.array_equal(got[lids], vv[lids]), ("partial-factor aggregates differ", r)
+        if learn:
+            gote = p.val_evid.cpu().numpy().astype(np.int64)
+            assert np.array_equal(gote[lo:hi], ve[lo:hi]) and np.array_equal(gote[lids], ve[lids]), ("evidence chain differs", r)
+            assert np.array_equal(p.w.cpu().numpy(), wv), ("merged weights differ", r)
+        else:
+            p.fg._pull(0, 0)
+            cs = p.fg.cstart
+            assert np.array_equal(p.fg.count[cs[lo]:cs[hi]], cnt[cs[lo]:cs[hi]]), ("tallies differ", r)
+    for p in parts:
+        p.fg.close()
+    return shipped_plain, shipped, npf
+
+
+@pytest.mark.parametrize("learn", [False, True])
+def test_voter_graph_in_four_shards_with_partial_factors(learn):
+    """2 000 clauses of 11 voters + head: the shard that owns the heads reads 16 500 foreign voters -- or 1 500 aggregates."""
+    g = graphgen.voter_graph(2000, width=12, seed=3)
+    nvar = len(g[1])
+    before, after, npf = run(g, nvar, learn)
+    assert npf > 1000 and after < 0.25 * before, (before, after, npf)         # values one exchange moves
+
+
+@pytest.mark.parametrize("learn", [False, True])
+def test_lr_graph_in_four_shards_with_partial_factors(learn):
+    nvar = 40000
+    g = graphgen.mixed_lr_graph(nvar, seed=5, nweights=100)
+    before, after, npf = run(g, nvar, learn, hbv=True)
+    assert npf > 50 and after <= before, (before, after, npf)                # (arity <= 4: little to aggregate)
