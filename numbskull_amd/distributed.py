@@ -140,8 +140,8 @@ class PartitionedSampler(object):
         nid = C.c_int64()
         _lib.check(self.L.nsk_graph_get_layout(h, _lib.ptr(iid), C.byref(nid)))
         self.iid = torch.as_tensor(iid.astype(np.int64), device=self.dev)
-        self.val_raw = self._wrap(_lib.BUF_VALUE, nid.value, self.typestr)
-        self.val_evid_raw = self._wrap(_lib.BUF_VALUE_EVID, nid.value, self.typestr)
+        self.nid = int(nid.value)
+        self._wrap_values()
         self.w = self._wrap(_lib.BUF_WEIGHT, fg.weight.shape[0], "<f8")
         self.native = False
         self.p2p = False
@@ -166,6 +166,11 @@ class PartitionedSampler(object):
     @property
     def val_evid(self):
         return self.val_evid_raw[self.iid] if self.nvar else self.val_evid_raw
+
+    def _wrap_values(self):
+        """(Again after nsk_pf_setup: the value arrays move when they grow by the aggregates' slots.)"""
+        self.val_raw = self._wrap(self._lib.BUF_VALUE, self.nid, self.typestr)
+        self.val_evid_raw = self._wrap(self._lib.BUF_VALUE_EVID, self.nid, self.typestr)
 
     def _wrap(self, which, nelem, ts):
         p, nb = C.c_void_p(), C.c_int64()
@@ -297,6 +302,7 @@ class PartitionedSampler(object):
             rc = self.L.nsk_pf_setup(self.h, len(ops), _lib.ptr(ops), _lib.ptr(moff), _lib.ptr(mem))
             if rc:
                 return rc
+            self._wrap_values()
         return self.L.nsk_p2p_setup(self.h, self.world, self.rank, _lib.ptr(send), _lib.ptr(soff), _lib.ptr(recv),
                                     _lib.ptr(roff), _lib.ptr(base), _lib.ptr(total))
 
