@@ -1327,12 +1327,23 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
     }
     for (int q = world; q <= 16; q++) { plan.soff[q] = (unsigned long long)g->p_nsend; plan.roff[q] = (unsigned long long)g->p_nrecv; }
     P2PWeights pw;
-    pw.w = weights ? g->w : nullptr; pw.w_start = weights ? g->w_start : nullptr; pw.nw = weights ? nw : 0; pw.pad_ = 0;
-    const int64_t wwork = weights ? ((int64_t)nw + 3) / 4 : 0;          // (a block's threads take a few weights each)
+    // (tables beyond 2^16 weights: the delta slices and the slice reduction in launches of their own, k_p2p_push_dw)
+    const bool bigw = weights && nw > 65536;
+    pw.w = weights ? g->w : nullptr; pw.w_start = weights ? g->w_start : nullptr; pw.nw = weights ? nw : 0; pw.inside = bigw ? 0 : 1;
+    const int64_t wwork = (weights && !bigw) ? ((int64_t)nw + 3) / 4 : 0;          // (a block's threads take a few weights each)
+    const int wblocks = std::max(1, std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK));
+    auto push_dw = [&]() {
+        if (bigw) k_p2p_push_dw<VT><<<dim3(wblocks), dim3(NSK_BLOCK), 0, g->stream>>>(plan, pw, world, me, tag, selftest);
+    };
+    auto reduce = [&]() {
+        if (!bigw) return;
+        k_p2p_reduce<VT><<<dim3(std::max(1, wblocks / world)), dim3(NSK_BLOCK), 0, g->stream>>>(g->p2p_base, (long long)g->p_nrecv, plan, pw, world, me, tag, selftest);
+        k_p2p_raise<<<dim3(1), dim3(64), 0, g->stream>>>(plan, 1, world, me, mask, tag);
+    };
     auto blocks = [&](int64_t work) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, (work + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK))); };
     auto gather = [&]() {
         if (!weights) return;
-        const int nb = blocks(wwork);                       // (few blocks, grid-stride: every block waits for the flags itself)
+        const int nb = bigw ? std::min(256, wblocks) : blocks(wwork);       // (every block waits for the flags itself: relaxed polls)
         k_p2p_gather_w<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, nw, g->p2p_base, (long long)g->p_nrecv, world,
                                                                        mask, tag, g->p2p_err, g->p2p_timeout_ticks, selftest);
         if (!selftest) g->weights_dirty = true;
@@ -1341,13 +1352,16 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
         k_pf_compute<VT><<<dim3((unsigned)((g->npf + NSK_BLOCK - 1) / NSK_BLOCK)), dim3(NSK_BLOCK), 0, g->stream>>>(
             (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->pf_op, g->pf_off, g->pf_mem, (int)g->npf, (long long)g->c.nid);
     if (part == 0) {                            // the sweep loops: push, flags, wait and unpack in one launch
+        push_dw();
         const int nb = blocks(std::max(std::max(g->p_nsend, g->p_nrecv), wwork));
         k_p2p_exchange<VT, true><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
             (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->p_send_iid, (long long)g->p_nsend, plan, pw, g->p_recv_iid,
             (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks, selftest);
+        reduce();
         gather();
     } else if (part == 1) {
         // at most 64 blocks (grid-stride): the closing ticket adds must not queue up
+        push_dw();
         const int nb = blocks(std::max(g->p_nsend, wwork));
         k_p2p_push<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const VT *)g->val, (const VT *)g->val_evid, learn ? 1 : 0,
                                                                    g->p_send_iid, (long long)g->p_nsend, plan, pw, world, me, mask,
@@ -1357,6 +1371,7 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
         k_p2p_exchange<VT, false><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
             (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->p_send_iid, (long long)g->p_nsend, plan, pw, g->p_recv_iid,
             (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks, selftest);
+        reduce();
     } else {
         gather();
     }
