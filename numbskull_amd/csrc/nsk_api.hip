@@ -313,7 +313,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     // global learning accumulators: one private copy per XCD (nsk_device.h sink_add); graphs with few
     // weights accumulate in LDS and never touch them.  A private copy pays while it stays in its XCD's L2
     // (4 MB): up to 2^18 weights (2 MB of sums).  Beyond, the adds miss the L2 either way and eight copies only
-    // multiply the update launch's reads -- 50M LR graph, 10^6 weights (tools/sessions/r4_s22.sh): eight copies
+    // multiply the update launch's reads -- 50M LR graph, 10^6 weights (tools/sessions/history/r4_s22.sh): eight copies
     // 5.22e9 updates/s, one copy with agent-scope adds 5.47e9; 5M LR graph, 10^5 weights: copies 262 us per
     // class against 300.
     g->acc_copies = (!g->smallw && c.nweight <= (1 << 18)) ? NSK_XCDS : 1;

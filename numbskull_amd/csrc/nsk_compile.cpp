@@ -22,13 +22,13 @@ static const int64_t NSK_HEAVY_LIST = 32;
 static const int64_t NSK_FEW_GENERIC = 32768;
 // stream words per lane of a shape tile at most (role program in TileShape::key, 32 words).  A lane walks its
 // words chunk by chunk, every chunk a load and then its gathers: longer lists belong to the entry-parallel
-// groups.  Measured on the 4M-variable weighted boolean graph (tools/sessions/r4_s24.sh, r4_s25.sh; learning /
+// groups.  Measured on the 4M-variable weighted boolean graph (tools/sessions/history/r4_s24.sh, r4_s25.sh; learning /
 // inference, updates/s): 16 words 3.68e9 / 1.28e10, 20 words 2.93e9 / 1.18e10, 24 words 1.72e9 / 1.11e10,
 // 32 words 2.2e8 / 5.3e9.
 static const int64_t NSK_SHAPE_WORDS = 16;
 // ... and the same limit for variables the entry-parallel groups can take.  Once the single-factor weights had
 // slots in layout order (nsk_compile.h wmap) the groups overtook the shape tiles at every list length; same
-// graph, every rest tile with a wave of its own (tools/sessions/r4_s31.sh .. r4_s33.sh), learning / inference:
+// graph, every rest tile with a wave of its own (tools/sessions/history/r4_s31.sh .. r4_s33.sh), learning / inference:
 // 20 words 4.20e9 / 1.20e10, 16 words 4.78e9 / 1.30e10, 12 words 5.25e9 / 1.56e10, 10 words 5.61e9 / 1.60e10,
 // 8 words 6.13e9 / 1.60e10, 6 words 6.35e9 / 1.59e10, 4 words 6.56e9 / 1.60e10.
 static const int64_t NSK_SHAPE_WORDS_EP = 4;
@@ -1330,7 +1330,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     // put 64 unrelated variables into a tile: the learning sweep of the 4M-variable weighted boolean
     // graph missed the L2 11 times per variable.  Parts of >= 2^18 ids keep the leftovers (< 64 members
     // of a shape in a part, general tiles) few: that graph's learning sweep, 8 / 16 / 32 parts: 3.71 / 4.07 /
-    // 4.06e9 updates/s (tools/sessions/r4_s26.sh).
+    // 4.06e9 updates/s (tools/sessions/history/r4_s26.sh).
     const bool no_pshape = diag_env("NSK_NO_PAD_SHAPE") != nullptr || diag_env("NSK_NO_SHAPE") != nullptr;
     const int64_t shape_parts = diag_env("NSK_SHAPE_PARTS") ? std::max<int64_t>(1, atoll(diag_env("NSK_SHAPE_PARTS")))
                                                             : std::max<int64_t>(1, std::min<int64_t>(64, (nvar + (1 << 18) - 1) >> 18));

@@ -195,7 +195,7 @@ int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay
                 // 3 workgroups per CU 142.4 us, 4 149.2, 5 139.5, 6 135.4, 7 134.2, 8 132.9, 10 134.7, 16 135.6;
                 // 50M LR graph: 4 1362 us, 7 1247, 10 1189
                 const char *pcu_env = nsk::diag_env("NSK_EP_PER_CU");            // (diagnostic: workgroups per CU)
-                // -- and at 5M, twice each (tools/sessions/r4_s26.sh): 10 per CU 4.95 / 4.97e9 updates/s, 7 per CU
+                // -- and at 5M, twice each (tools/sessions/history/r4_s26.sh): 10 per CU 4.95 / 4.97e9 updates/s, 7 per CU
                 // 5.04 / 5.06e9.  Hence 10 when a workgroup walks four groups or more, 7 otherwise (the shards
                 // of an 8-rank run of the 50M graph are of the second kind).
                 const int per_cu = pcu_env ? std::max(1, std::min(32, atoi(pcu_env))) : (ngroups >= 4 * 2560 ? 10 : 7);
