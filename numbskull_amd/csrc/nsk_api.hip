@@ -1327,51 +1327,63 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
     }
     for (int q = world; q <= 16; q++) { plan.soff[q] = (unsigned long long)g->p_nsend; plan.roff[q] = (unsigned long long)g->p_nrecv; }
     P2PWeights pw;
-    // (tables beyond 2^16 weights: the delta slices and the slice reduction in launches of their own, k_p2p_push_dw)
-    const bool bigw = weights && nw > 65536;
-    pw.w = weights ? g->w : nullptr; pw.w_start = weights ? g->w_start : nullptr; pw.nw = weights ? nw : 0; pw.inside = bigw ? 0 : 1;
-    const int64_t wwork = (weights && !bigw) ? ((int64_t)nw + 3) / 4 : 0;          // (a block's threads take a few weights each)
-    const int wblocks = std::max(1, std::min(1024, (nw + NSK_BLOCK - 1) / NSK_BLOCK));
-    auto push_dw = [&]() {
-        if (bigw) k_p2p_push_dw<VT><<<dim3(wblocks), dim3(NSK_BLOCK), 0, g->stream>>>(plan, pw, world, me, tag, selftest);
-    };
-    auto reduce = [&]() {
-        if (!bigw) return;
-        k_p2p_reduce<VT><<<dim3(std::max(1, wblocks / world)), dim3(NSK_BLOCK), 0, g->stream>>>(g->p2p_base, (long long)g->p_nrecv, plan, pw, world, me, tag, selftest);
-        k_p2p_raise<<<dim3(1), dim3(64), 0, g->stream>>>(plan, 1, world, me, mask, tag);
-    };
+    // big: lists beyond 2^16 values or tables beyond 2^16 weights -- many-block launches with one-wave flag kernels
+    // between them (k_p2p_push_big); otherwise one or two <= 64-block launches that raise and poll themselves
+    const char *big_env = nsk::diag_env("NSK_P2P_BIG_MIN");             // (diagnostic; read per exchange so that tests can set it)
+    const int64_t big_min = big_env ? atoll(big_env) : 65536;
+    const bool big = std::max(g->p_nsend, g->p_nrecv) > big_min || (weights && nw > big_min);
+    pw.w = weights ? g->w : nullptr; pw.w_start = weights ? g->w_start : nullptr; pw.nw = weights ? nw : 0;
+    const int64_t wwork = weights ? ((int64_t)nw + 3) / 4 : 0;          // (a block's threads take a few weights each)
     auto blocks = [&](int64_t work) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, (work + 4 * NSK_BLOCK - 1) / (4 * NSK_BLOCK))); };
+    auto many = [&](int64_t work) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (work + NSK_BLOCK - 1) / NSK_BLOCK))); };
+    VT *val = (VT *)g->val, *val_evid = (VT *)g->val_evid;
+    const int both = learn ? 1 : 0;
+    auto push_big = [&]() {
+        k_p2p_push_big<VT><<<many(std::max<int64_t>(g->p_nsend, pw.nw)), dim3(NSK_BLOCK), 0, g->stream>>>(
+            val, val_evid, both, g->p_send_iid, (long long)g->p_nsend, plan, pw, world, me, tag, tag_base, selftest);
+        k_p2p_raise<<<dim3(1), dim3(64), 0, g->stream>>>(plan, 0, world, me, mask, tag, tag_base);
+    };
+    auto unpack_big = [&]() {
+        k_p2p_wait<<<dim3(1), dim3(64), 0, g->stream>>>(g->p2p_base, 0, world, mask, tag, tag_base, g->p2p_err, g->p2p_timeout_ticks);
+        k_p2p_unpack_big<VT><<<many(std::max<int64_t>(g->p_nrecv, (pw.nw + world - 1) / world)), dim3(NSK_BLOCK), 0, g->stream>>>(
+            val, val_evid, both, g->p_recv_iid, (long long)g->p_nrecv, g->p2p_base, plan, pw, world, me, tag, tag_base, g->p2p_err, selftest);
+        if (weights) k_p2p_raise<<<dim3(1), dim3(64), 0, g->stream>>>(plan, 1, world, me, mask, tag, tag_base);
+    };
     auto gather = [&]() {
         if (!weights) return;
-        const int nb = bigw ? std::min(256, wblocks) : blocks(wwork);       // (every block waits for the flags itself: relaxed polls)
-        k_p2p_gather_w<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, nw, g->p2p_base, (long long)g->p_nrecv, world,
-                                                                       mask, tag, g->p2p_err, g->p2p_timeout_ticks, selftest);
+        const int nb = big ? (int)std::min<int64_t>(256, (nw + NSK_BLOCK - 1) / NSK_BLOCK) : blocks(wwork);       // (every block waits for the flags itself: relaxed polls)
+        k_p2p_gather_w<VT><<<dim3(std::max(1, nb)), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, nw, g->p2p_base, (long long)g->p_nrecv, world,
+                                                                                    mask, tag, g->p2p_err, g->p2p_timeout_ticks, selftest);
         if (!selftest) g->weights_dirty = true;
     };
     if ((part == 0 || part == 1) && g->npf > 0 && !selftest)         // the partial-factor aggregates this rank's readers take
         k_pf_compute<VT><<<dim3((unsigned)((g->npf + NSK_BLOCK - 1) / NSK_BLOCK)), dim3(NSK_BLOCK), 0, g->stream>>>(
-            (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->pf_op, g->pf_off, g->pf_mem, (int)g->npf, (long long)g->c.nid);
+            val, val_evid, both, g->pf_op, g->pf_off, g->pf_mem, (int)g->npf, (long long)g->c.nid);
     if (part == 0) {                            // the sweep loops: push, flags, wait and unpack in one launch
-        push_dw();
-        const int nb = blocks(std::max(std::max(g->p_nsend, g->p_nrecv), wwork));
-        k_p2p_exchange<VT, true><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
-            (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->p_send_iid, (long long)g->p_nsend, plan, pw, g->p_recv_iid,
-            (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks, selftest);
-        reduce();
+        if (big) { push_big(); unpack_big(); }
+        else {
+            const int nb = blocks(std::max(std::max(g->p_nsend, g->p_nrecv), wwork));
+            k_p2p_exchange<VT, true><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
+                val, val_evid, both, g->p_send_iid, (long long)g->p_nsend, plan, pw, g->p_recv_iid,
+                (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks, selftest);
+        }
         gather();
     } else if (part == 1) {
-        // at most 64 blocks (grid-stride): the closing ticket adds must not queue up
-        push_dw();
-        const int nb = blocks(std::max(g->p_nsend, wwork));
-        k_p2p_push<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>((const VT *)g->val, (const VT *)g->val_evid, learn ? 1 : 0,
-                                                                   g->p_send_iid, (long long)g->p_nsend, plan, pw, world, me, mask,
-                                                                   g->p2p_err + 1, tag, tag_base, selftest);
+        if (big) push_big();
+        else {
+            // at most 64 blocks (grid-stride): the closing ticket adds must not queue up
+            const int nb = blocks(std::max(g->p_nsend, wwork));
+            k_p2p_push<VT><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(val, val_evid, both, g->p_send_iid, (long long)g->p_nsend, plan, pw, world, me,
+                                                                       mask, g->p2p_err + 1, tag, tag_base, selftest);
+        }
     } else if (part == 2) {
-        const int nb = blocks(std::max(g->p_nrecv, wwork));
-        k_p2p_exchange<VT, false><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
-            (VT *)g->val, (VT *)g->val_evid, learn ? 1 : 0, g->p_send_iid, (long long)g->p_nsend, plan, pw, g->p_recv_iid,
-            (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks, selftest);
-        reduce();
+        if (big) unpack_big();
+        else {
+            const int nb = blocks(std::max(g->p_nrecv, wwork));
+            k_p2p_exchange<VT, false><<<dim3(nb), dim3(NSK_BLOCK), 0, g->stream>>>(
+                val, val_evid, both, g->p_send_iid, (long long)g->p_nsend, plan, pw, g->p_recv_iid,
+                (long long)g->p_nrecv, g->p2p_base, world, me, mask, g->p2p_err + 1, tag, g->p2p_err, tag_base, g->p2p_timeout_ticks, selftest);
+        }
     } else {
         gather();
     }

@@ -143,9 +143,6 @@ __device__ __forceinline__ double p2p_pattern_dw(int src, int i, unsigned int ta
 struct P2PWeights {
     const double *w, *w_start;          // this rank's weights now / at the start of the epoch
     int nw;
-    int inside;                         // 1: the exchange kernels push the delta slices and reduce this rank's slice
-                                        // themselves (small tables: two launches per exchange); 0: launches of their own
-                                        // with as many blocks as the table wants do (k_p2p_push_dw, k_p2p_reduce)
 };
 
 // push: boundary values into the readers' receive blocks, and (learning) slice q of the weight deltas into
@@ -166,7 +163,7 @@ __device__ __forceinline__ void p2p_push(const VT *val, const VT *val_evid, int 
         dst[0] = selftest ? p2p_pattern<VT>(me, kl, tag, 0) : val[id];
         if (both) dst[tot] = selftest ? p2p_pattern<VT>(me, kl, tag, 1) : val_evid[id];
     }
-    if (pw.w && pw.inside) {
+    if (pw.w) {
         const size_t nw = (size_t)pw.nw, smax = nsk_p2p_slice_max(world, nw);
         for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < (long long)nw; i += stride) {
             int q = (int)(((size_t)i * (size_t)world + (size_t)world - 1) / nw);          // owner of weight i: the q with lo(q) <= i < lo(q + 1)
@@ -295,36 +292,43 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_exchange(VT *val, VT *val_evi
     }
     if (!p2p_wait(mine, 0, world, peer_mask, tag, err, timeout_ticks)) return;
     p2p_unpack<VT>(val, val_evid, both, recv_iid, nrecv, mine, pl, world, tag, selftest, err);
-    if (pw.w && pw.inside) {
+    if (pw.w) {
         p2p_reduce_slice<VT>(mine, nrecv, pl, pw, world, me, tag, selftest);
         if (p2p_last_block(ticket + 1)) p2p_raise(pl, 1, world, me, peer_mask, tag);
     }
 }
 
-// Large weight tables (10^6 weights: 8 MB of deltas out, a 1 MB slice to reduce): the delta slices are pushed, and
-// this rank's slice reduced, by launches of their own with as many blocks as the table wants -- inside the exchange
-// kernels' <= 64 blocks (their closing tickets must not queue up) the two took 155 + 99 us on the 50M LR graph's
-// shards.  k_p2p_push_dw runs BEFORE the value push (whose last block's fence and flag cover it: the stream is in
-// order), k_p2p_reduce BEHIND the exchange kernel (which has waited for the peers' flags), k_p2p_raise behind that.
+// Large exchanges (send / receive lists beyond 2^16 values, weight tables beyond 2^16 weights: the 50M LR graph's
+// shards push 490 000 values of two chains and 8 MB of weight deltas): launches with as many blocks as the lists
+// want and NO ticket, fence or poll inside -- a one-wave k_p2p_raise / k_p2p_wait between them does those, and the
+// stream's order does the rest (a kernel has its stores acknowledged before the next one starts).  Inside the
+// exchange kernels' <= 64 blocks (their closing tickets, each behind a system-scope fence, must not queue up) the
+// lists are latency-bound loops: 30 dependent trips per thread, 155 + 99 us per exchange on those shards.
 template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push_dw(P2PPlan pl, P2PWeights pw, int world, int me, unsigned int tag, int selftest) {
-    const size_t par = tag & 1u, nw = (size_t)pw.nw, smax = nsk_p2p_slice_max(world, nw);
-    for (long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x; i < (long long)nw; i += (long long)gridDim.x * NSK_BLOCK) {
-        int q = (int)(((size_t)i * (size_t)world + (size_t)world - 1) / nw);
-        while (q > 0 && nsk_p2p_slice_lo(q, world, nw) > (size_t)i) q--;
-        while (q + 1 < world && nsk_p2p_slice_lo(q + 1, world, nw) <= (size_t)i) q++;
-        double *sb = (double *)((char *)pl.base[q] + nsk_p2p_sbuf_off(world, (size_t)pl.dtotal[q], sizeof(VT)));
-        sb[(par * (size_t)world + (size_t)me) * smax + ((size_t)i - nsk_p2p_slice_lo(q, world, nw))] =
-            selftest ? p2p_pattern_dw(me, (int)i, tag) : pw.w[i] - pw.w_start[i];
-    }
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_push_big(const VT *val, const VT *val_evid, int both, const int32_t *send_iid,
+                                                            long long nsend, P2PPlan pl, P2PWeights pw, int world, int me, unsigned int tag,
+                                                            const unsigned long long *tag_base, int selftest) {
+    if (tag_base) tag += (unsigned int)tag_base[1];
+    p2p_push<VT>(val, val_evid, both, send_iid, nsend, pl, pw, world, me, tag, selftest);
 }
 template <typename VT>
-__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_reduce(const void *mine, long long nrecv, P2PPlan pl, P2PWeights pw, int world, int me,
-                                                          unsigned int tag, int selftest) {
-    p2p_reduce_slice<VT>(mine, nrecv, pl, pw, world, me, tag, selftest);
+__global__ __launch_bounds__(NSK_BLOCK) void k_p2p_unpack_big(VT *val, VT *val_evid, int both, const int32_t *recv_iid, long long nrecv,
+                                                              const void *mine, P2PPlan pl, P2PWeights pw, int world, int me, unsigned int tag,
+                                                              const unsigned long long *tag_base, unsigned int *err, int selftest) {
+    if (tag_base) tag += (unsigned int)tag_base[1];
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & NSK_P2P_ERR_TIMEOUT) return;     // (k_p2p_wait gave up)
+    p2p_unpack<VT>(val, val_evid, both, recv_iid, nrecv, mine, pl, world, tag, selftest, err);
+    if (pw.w) p2p_reduce_slice<VT>(mine, nrecv, pl, pw, world, me, tag, selftest);
 }
-static __global__ void k_p2p_raise(P2PPlan pl, int kind, int world, int me, unsigned int peer_mask, unsigned int tag) {
+static __global__ void k_p2p_raise(P2PPlan pl, int kind, int world, int me, unsigned int peer_mask, unsigned int tag,
+                                   const unsigned long long *tag_base) {
+    if (tag_base) tag += (unsigned int)tag_base[1];
     p2p_raise(pl, kind, world, me, peer_mask, tag);
+}
+static __global__ void k_p2p_wait(const void *mine, int kind, int world, unsigned int peer_mask, unsigned int tag,
+                                  const unsigned long long *tag_base, unsigned int *err, unsigned long long timeout_ticks) {
+    if (tag_base) tag += (unsigned int)tag_base[1];
+    (void)p2p_wait(mine, kind, world, peer_mask, tag, err, timeout_ticks);
 }
 
 // Partial-factor values (salt/src/messages.py:1333-1349 compute_pf_values): a reader shard that holds
