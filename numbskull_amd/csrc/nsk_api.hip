@@ -1351,9 +1351,9 @@ static int p2p_exchange(nsk_graph *g, const unsigned long long *tag_base, unsign
     };
     auto gather = [&]() {
         if (!weights) return;
-        const int nb = big ? (int)std::min<int64_t>(256, (nw + NSK_BLOCK - 1) / NSK_BLOCK) : blocks(wwork);       // (every block waits for the flags itself: relaxed polls)
-        k_p2p_gather_w<VT><<<dim3(std::max(1, nb)), dim3(NSK_BLOCK), 0, g->stream>>>(g->w, g->w_start, nw, g->p2p_base, (long long)g->p_nrecv, world,
-                                                                                    mask, tag, g->p2p_err, g->p2p_timeout_ticks, selftest);
+        if (big) k_p2p_wait<<<dim3(1), dim3(64), 0, g->stream>>>(g->p2p_base, 1, world, mask, tag, tag_base, g->p2p_err, g->p2p_timeout_ticks);
+        k_p2p_gather_w<VT><<<big ? many(nw) : dim3((unsigned)blocks(wwork)), dim3(NSK_BLOCK), 0, g->stream>>>(
+            g->w, g->w_start, nw, g->p2p_base, (long long)g->p_nrecv, world, mask, tag, g->p2p_err, g->p2p_timeout_ticks, selftest, big ? 1 : 0);
         if (!selftest) g->weights_dirty = true;
     };
     if ((part == 0 || part == 1) && g->npf > 0 && !selftest)         // the partial-factor aggregates this rank's readers take

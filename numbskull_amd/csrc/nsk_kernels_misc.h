@@ -411,8 +411,11 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_fused_selftest(long long nsen
 template <typename VT>
 __global__ __launch_bounds__(NSK_BLOCK) void k_p2p_gather_w(double *w, double *w_start, int nw, const void *mine, long long nrecv,
                                                             int world, unsigned int peer_mask, unsigned int tag, unsigned int *err,
-                                                            unsigned long long timeout_ticks, int selftest) {
-    if (!p2p_wait(mine, 1, world, peer_mask, tag, err, timeout_ticks)) return;
+                                                            unsigned long long timeout_ticks, int selftest, int waited) {
+    // waited: a k_p2p_wait in front of this launch has seen the owners' flags (large tables: as many blocks as the
+    // table wants, none of them polling)
+    if (waited ? (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & NSK_P2P_ERR_TIMEOUT) != 0u
+               : !p2p_wait(mine, 1, world, peer_mask, tag, err, timeout_ticks)) return;
     const double *gb = (const double *)((const char *)mine + nsk_p2p_gbuf_off(world, (size_t)nrecv, sizeof(VT), (size_t)nw)) +
                        (size_t)(tag & 1u) * (size_t)nw;
     for (int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x); i < nw; i += (int)(gridDim.x * NSK_BLOCK)) {
