@@ -442,6 +442,11 @@ static int32_t colour_sampled(Compiled &c, const std::vector<uint8_t> &sampled, 
             for (int64_t v = 0; v < nvar; v++) {
                 if (!sampled[v]) continue;
                 const int32_t cur = c.color[v];
+                // (no class is more than one variable lighter than this one's: nothing below can move it, and its
+                // neighbours need not be looked at -- most variables once the classes are level)
+                int64_t lightest = load[0];
+                for (int32_t k = 1; k < ncolors; k++) lightest = std::min(lightest, load[k]);
+                if (lightest + 1 >= load[cur]) continue;
                 for_each_read(v, [&](int64_t b) {
                     if (b != v && c.color[b] >= 0) stamp[c.color[b]] = v;
                 });
@@ -1306,10 +1311,10 @@ static int build_index_and_census(const nsk_graph_desc *d, Compiled &c, int32_t 
 // share a tail in id order; then the general tiles' variables (sorted), then the generic-path variables (binned by
 // work).  fast[v]: 1 fast path, 2 general tile, 0 generic (variables that fit no class move from 1 to 2 or 0 here).
 // [shape_at[k], shape_end[k]) = the positions of colour k's shape classes.
-template <typename WordsFn>
+template <typename WordsFn, typename LapFn>
 static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, std::vector<uint8_t> &fast,
                            WordsFn &&general_words, bool no_general, int64_t shape_words, int64_t shape_words_ep,
-                           std::vector<int64_t> &shape_at, std::vector<int64_t> &shape_end, std::string &err) {
+                           std::vector<int64_t> &shape_at, std::vector<int64_t> &shape_end, LapFn &&lap, std::string &err) {
     const int64_t nvar = c.nvar, nfac = c.nfactor, nedge = c.nedge, nw = c.nweight;
     const int64_t LIM = (int64_t)1 << 31;
     (void)nfac; (void)nedge; (void)nw; (void)LIM; (void)err;
@@ -1323,7 +1328,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     //      exact shape is rare share tiles with near shapes, the missing member slots filled with null
     //      words (NSK_SHAPE_NULL) -- with individual weights and lists of 7+ entries the exact shapes
     //      (2^(entries-1) of them on the weighted boolean graph) no longer fill tiles
-    std::vector<uint64_t> sig(nvar, 0), shp(nvar, 0), pshp(nvar, 0);
+    std::vector<uint64_t> sig, shp, pshp;           // (sized below, when the graph has such variables at all)
     // Shape classes are formed per id range ("part") of the graph: the lanes of a shape tile then come from
     // one part, and the values and weights they gather -- mostly those of id neighbours -- from a
     // correspondingly narrow stretch of every colour's positions (the kernels hand an XCD a contiguous
@@ -1341,6 +1346,11 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
         if (fast[v] == 2) ngt_of[c.color[v]]++;
         else if (!fast[v]) ngen_of[c.color[v]]++;
         else nfast_of[c.color[v]]++;
+    }
+    {
+        int64_t nclassed = 0;
+        for (int32_t k = 0; k < ncolors; k++) nclassed += nfast_of[k];
+        if (nclassed > 0) { sig.assign((size_t)nvar, 0); shp.assign((size_t)nvar, 0); pshp.assign((size_t)nvar, 0); }
     }
     parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
     for (int64_t v = vb0; v < vb1; v++) {
@@ -1380,6 +1390,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
         pshp[v] = (pwords <= lim && !no_pshape) ? (h3 | 1) : 0;
     }
     });
+    lap("positions: signatures");
     // (hash maps: with one weight per factor every variable is a class of its own -- millions of keys;
     //  nothing below depends on their iteration order.  The colours are independent: one thread each.)
     typedef std::unordered_map<uint64_t, std::pair<int64_t, int64_t>> ClassMap;        // key -> (count, first vid)
@@ -1441,6 +1452,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
         shapes[k].clear();
         pshapes[k].clear();
     }
+    lap("positions: classes");
     std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
     std::vector<std::vector<int64_t>> gen_bin_start;
     std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors), start3((size_t)ncolors);
@@ -1485,6 +1497,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     // generic-path variables of a colour are ordered by the work of one update (factor-list
     // lengths x arities over all candidate values, binned) so that the 64 lanes of a wave finish
     // together; inside a bin: variable id.
+    lap("positions: arrays");
     std::vector<uint32_t> gw;
     std::vector<uint8_t> work_bin(nvar, 0);
     for (int64_t v = 0; v < nvar; v++) {
@@ -1525,6 +1538,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     // general-tile variables of a colour: sorted by (entries, most other members of an entry),
     // largest first, and cut into tiles of 64 -- a tile's layout is the maximum over its lanes,
     // so neighbours in this order waste the least padding (SELL-C-sigma)
+    lap("positions: work bins");
     {
         std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (key, vid)
         std::vector<uint8_t> g_ne(nvar, 0), g_mo(nvar, 0);      // entries / widest entry of a general lane
@@ -1541,6 +1555,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
                 g_ne[v] = (uint8_t)ne; g_mo[v] = (uint8_t)mo;
             }
         });
+        lap("positions: lane sizes");
         // entry-parallel groups (nsk_compile.h ep_desc) serve a colour whose general variables all
         // have entries of at most 3 other members and at most 16 entries (ordinal: 5 bits, LDS slots)
         c.phase_ep.assign((size_t)ncolors, 0);
@@ -1568,7 +1583,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
             for (int64_t v = 0; v < nvar; v++) {
                 if (c.color[v] != k || fast[v] != 2) continue;
                 const int64_t ne = g_ne[v], mo = g_mo[v];
-                const int64_t catv = d->variable[v].cardinality > 2 ? 0 : 1;
+                const int64_t catv = c.v_card[v] > 2 ? 0 : 1;
                 const int64_t small = (epk && ne <= 8) ? 1 : 0;
                 ord.push_back({(small << 51) | (catv << 50) | ((v / gb) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
             }
@@ -1582,6 +1597,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
             }
             for (auto &t : sorters) t.join();
         }
+        lap("positions: lane order");
         for (int32_t k = 0; k < ncolors; k++) {
             for (auto &o : order[k]) {
                 const int64_t p = gt_at[k]++;
@@ -2255,7 +2271,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     const int64_t shape_words_ep = diag_env("NSK_SHAPE_MAX_WORDS") ? shape_words : NSK_SHAPE_WORDS_EP;
     // [shape_at[k], shape_end[k]): the positions of colour k's shape classes (tile shapes, pass 1)
     std::vector<int64_t> shape_at((size_t)ncolors, 0), shape_end((size_t)ncolors, 0);
-        if (int prc = place_variables(d, c, ncolors, fast, general_words, no_general, shape_words, shape_words_ep, shape_at, shape_end, err))
+        if (int prc = place_variables(d, c, ncolors, fast, general_words, no_general, shape_words, shape_words_ep, shape_at, shape_end, lap, err))
         return prc;
     // ---- internal ids: a positioned variable's id is its position; the others (ghosts, isEvidence
     // == 4 -- read but never sampled here) follow.  Every variable id stored for the device from
