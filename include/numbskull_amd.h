@@ -341,6 +341,11 @@ int nsk_compute_var_map(int64_t nvar, const nsk_variable *variable, int64_t nfac
                         const nsk_factor *factor, int64_t nedge, const nsk_ftv *fmap,
                         int64_t nvtf, nsk_vtf *vmap, int64_t nfactor_index, int64_t *factor_index,
                         const uint8_t *domain_mask, const int64_t *factors_to_skip, int64_t nskip);
+/* FactorGraph.__init__'s arrays (factorgraph.py:41-53) from the packed records, over the host threads: cstart[nvar + 1]
+ * (cumulative tally slots: one for a binary variable, `cardinality` otherwise), init[nvar] (initialValue, dense),
+ * *max_card, *longest (the longest factor_index_length of vmap; both may be NULL). */
+int nsk_state_layout(int64_t nvar, const nsk_variable *variable, int64_t nvtf, const nsk_vtf *vmap,
+                     int64_t *cstart, int64_t *init, int64_t *max_card, int64_t *longest);
 /* dataloading.load_factors (dataloading.py:196-235) on the raw bytes of graph.factors. */
 int nsk_parse_factors(const uint8_t *data, int64_t nbytes, int64_t nfactor, int64_t nedge,
                       nsk_factor *factor, nsk_ftv *fmap, const uint8_t *domain_mask,

@@ -48,11 +48,23 @@ extern "C" int nsk_compute_var_map(int64_t nvar, const nsk_variable *variable, i
         }
         for (int64_t k = 0; k < variable[i].cardinality; k++) vmap[variable[i].vtf_offset + k].value = k;
     }
-    // lengths over EVERY edge (34-38), then exclusive prefix (41-46)
-    for (int64_t l = 0; l < nedge; l++) {
-        int64_t idx;
-        if (!slot_of(l, idx)) { nsk::set_error("compute_var_map: edge refers outside variables/vmap"); return NSK_E_INDEX; }
-        vmap[idx].factor_index_length += 1;
+    // lengths over EVERY edge (34-38), then exclusive prefix (41-46).  The edges go over the host threads (atomic
+    // increments: a slot's edges are spread over the factors): the counts do not depend on the order
+    {
+        std::vector<int64_t> added((size_t)nvtf, 0);          // (the caller's records are packed: count beside them)
+        std::vector<uint8_t> bad((size_t)nsk::compile_threads(), 0);
+        nsk::parallel_for(nedge, [&](int64_t l0, int64_t l1, int t) {
+            for (int64_t l = l0; l < l1; l++) {
+                int64_t idx;
+                if (!slot_of(l, idx)) { bad[(size_t)t] = 1; return; }
+                __atomic_fetch_add(&added[(size_t)idx], (int64_t)1, __ATOMIC_RELAXED);
+            }
+        }, 1 << 16);
+        for (uint8_t x : bad)
+            if (x) { nsk::set_error("compute_var_map: edge refers outside variables/vmap"); return NSK_E_INDEX; }
+        nsk::parallel_for(nvtf, [&](int64_t i0, int64_t i1, int) {
+            for (int64_t i = i0; i < i1; i++) vmap[i].factor_index_length += added[(size_t)i];
+        }, 1 << 16);
     }
     int64_t last_len = 0, last_off = 0;
     for (int64_t i = 0; i < nvtf; i++) {
@@ -60,36 +72,95 @@ extern "C" int nsk_compute_var_map(int64_t nvar, const nsk_variable *variable, i
         last_len = vmap[i].factor_index_length;
         last_off = vmap[i].factor_index_offset;
     }
-    // scatter factor ids in factor order, skipping factors_to_skip (49-65)
+    // scatter the factor ids, skipping factors_to_skip (49-65).  The reference walks the factors in order; every
+    // slot is sorted below, so only WHICH ids land in a slot matters, not the order they arrive in: the factors go
+    // over the host threads with an atomic cursor per slot.  (The skip list is consumed by the reference's own
+    // one-pointer walk -- an id out of order is never skipped -- into a flag per factor first.)
     std::vector<int64_t> cursor((size_t)nvtf);
-    for (int64_t i = 0; i < nvtf; i++) cursor[i] = vmap[i].factor_index_offset;
-    int64_t fts = 0;
-    for (int64_t f = 0; f < nfactor; f++) {
-        if (fts < nskip && factors_to_skip[fts] == f) { fts++; continue; }
-        const int64_t s = factor[f].ftv_offset, e = s + factor[f].arity;
-        if (s < 0 || e > nedge) { nsk::set_error("compute_var_map: factor members outside fmap"); return NSK_E_INDEX; }
-        for (int64_t l = s; l < e; l++) {
-            int64_t idx;
-            slot_of(l, idx);
-            if (cursor[idx] >= nfi) { nsk::set_error("compute_var_map: index out of bounds for factor_index (IndexError in the reference)"); return NSK_E_INDEX; }
-            factor_index[cursor[idx]++] = f;
+    nsk::parallel_for(nvtf, [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; i++) cursor[(size_t)i] = vmap[i].factor_index_offset;
+    }, 1 << 16);
+    std::vector<uint8_t> skipped;
+    if (nskip > 0) {
+        skipped.assign((size_t)nfactor, 0);
+        int64_t fts = 0;
+        for (int64_t f = 0; f < nfactor; f++)
+            if (fts < nskip && factors_to_skip[fts] == f) { skipped[(size_t)f] = 1; fts++; }
+    }
+    {
+        std::vector<uint8_t> bad((size_t)nsk::compile_threads(), 0);
+        nsk::parallel_for(nfactor, [&](int64_t f0, int64_t f1, int t) {
+            for (int64_t f = f0; f < f1; f++) {
+                if (!skipped.empty() && skipped[(size_t)f]) continue;
+                const int64_t s = factor[f].ftv_offset, e = s + factor[f].arity;
+                if (s < 0 || e > nedge) { bad[(size_t)t] = 1; return; }
+                for (int64_t l = s; l < e; l++) {
+                    int64_t idx;
+                    slot_of(l, idx);
+                    const int64_t at = __atomic_fetch_add(&cursor[(size_t)idx], (int64_t)1, __ATOMIC_RELAXED);
+                    if (at >= nfi) { bad[(size_t)t] = 2; return; }
+                    factor_index[at] = f;
+                }
+            }
+        }, 1 << 14);
+        for (uint8_t x : bad) {
+            if (x == 1) { nsk::set_error("compute_var_map: factor members outside fmap"); return NSK_E_INDEX; }
+            if (x == 2) { nsk::set_error("compute_var_map: index out of bounds for factor_index (IndexError in the reference)"); return NSK_E_INDEX; }
         }
     }
-    // per slot: sort, drop duplicates in place, shrink the length (68-81)
-    for (int64_t i = 0; i < nvtf; i++) {
-        int64_t off = vmap[i].factor_index_offset, len = vmap[i].factor_index_length;
-        if (off > nfi) off = nfi;
-        if (off + len > nfi) len = nfi - off;
-        int64_t *lst = factor_index + off;
-        if (!std::is_sorted(lst, lst + len)) std::sort(lst, lst + len);
-        int64_t n = 0, last = -1;
-        for (int64_t k = 0; k < len; k++) {
-            if (lst[k] == last) continue;
-            last = lst[k];
-            lst[n++] = last;
+    // per slot: sort, drop duplicates in place, shrink the length (68-81); the slots' ranges are disjoint
+    nsk::parallel_for(nvtf, [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; i++) {
+            int64_t off = vmap[i].factor_index_offset, len = vmap[i].factor_index_length;
+            if (off > nfi) off = nfi;
+            if (off + len > nfi) len = nfi - off;
+            int64_t *lst = factor_index + off;
+            if (!std::is_sorted(lst, lst + len)) std::sort(lst, lst + len);
+            int64_t n = 0, last = -1;
+            for (int64_t k = 0; k < len; k++) {
+                if (lst[k] == last) continue;
+                last = lst[k];
+                lst[n++] = last;
+            }
+            vmap[i].factor_index_length = n;
         }
-        vmap[i].factor_index_length = n;
-    }
+    }, 1 << 14);
+    return NSK_OK;
+}
+
+// FactorGraph.__init__'s arrays (factorgraph.py:41-53): cstart = cumulative tally slots (one for a binary variable,
+// `cardinality` otherwise), the variables' initial values as a dense vector (what var_value / var_value_evid are tiled
+// from), the largest cardinality (Z's width) and the longest factor list (fids' width).  The caller's records are
+// packed 27-byte structs: numpy's strided field reads take seconds at 50M variables; here the host threads walk them.
+extern "C" int nsk_state_layout(int64_t nvar, const nsk_variable *variable, int64_t nvtf, const nsk_vtf *vmap,
+                                int64_t *cstart, int64_t *init, int64_t *max_card, int64_t *longest) {
+    if (nvar < 0 || nvtf < 0 || (nvar && (!variable || !cstart || !init))) { nsk::set_error("nsk_state_layout: null argument"); return NSK_E_INVALID; }
+    const size_t T = (size_t)nsk::compile_threads();
+    std::vector<int64_t> part(T + 1, 0), mc(T, 0), ml(T, 0);
+    cstart[0] = 0;
+    auto slots = [&](int64_t v) { const int64_t c = variable[v].cardinality; return c == 2 ? (int64_t)1 : c; };
+    nsk::parallel_for(nvar, [&](int64_t v0, int64_t v1, int t) {
+        int64_t sum = 0, m = 0;
+        for (int64_t v = v0; v < v1; v++) {
+            sum += slots(v);
+            cstart[v + 1] = sum;                          // (local prefix; the block's base is added below)
+            init[v] = variable[v].initialValue;
+            m = std::max<int64_t>(m, variable[v].cardinality);
+        }
+        part[(size_t)t + 1] = sum; mc[(size_t)t] = m;
+    }, 1 << 16);
+    for (size_t t = 0; t < T; t++) part[t + 1] += part[t];
+    nsk::parallel_for(nvar, [&](int64_t v0, int64_t v1, int t) {
+        const int64_t base = part[(size_t)t];
+        if (base) for (int64_t v = v0; v < v1; v++) cstart[v + 1] += base;
+    }, 1 << 16);
+    nsk::parallel_for(nvtf, [&](int64_t i0, int64_t i1, int t) {
+        int64_t m = 0;
+        for (int64_t i = i0; i < i1; i++) m = std::max<int64_t>(m, vmap[i].factor_index_length);
+        ml[(size_t)t] = m;
+    }, 1 << 16);
+    if (max_card) { *max_card = 0; for (int64_t m : mc) *max_card = std::max(*max_card, m); }
+    if (longest) { *longest = 0; for (int64_t m : ml) *longest = std::max(*longest, m); }
     return NSK_OK;
 }
 

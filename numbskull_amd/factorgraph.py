@@ -43,22 +43,26 @@ class FactorGraph(object):
         self.fmap, self.vmap, self.factor_index = fmap, vmap, factor_index
 
         nvar = variable.shape[0]
-        card = variable["cardinality"].astype(np.int64)
-        # tally layout: one slot for a binary variable, `cardinality` slots otherwise
+        # tally layout: one slot for a binary variable, `cardinality` slots otherwise (native: the records are packed
+        # 27-byte structs, numpy's strided field reads take seconds at 50M variables)
         self.cstart = np.zeros(nvar + 1, np.int64)
-        np.cumsum(np.where(card == 2, 1, card), out=self.cstart[1:])
+        init = np.empty(nvar, np.int64)
+        max_card, longest = C.c_int64(), C.c_int64()
+        vc, mc = _lib.as_c(variable), _lib.as_c(vmap)
+        if vc.dtype.itemsize != 27 or mc.dtype.itemsize != 24:
+            raise TypeError("variable / vmap records of %d / %d bytes, expected 27 / 24 (numbskulltypes)" % (vc.dtype.itemsize, mc.dtype.itemsize))
+        _lib.check(_lib.lib().nsk_state_layout(nvar, _lib.ptr(vc), len(mc), _lib.ptr(mc), _lib.ptr(self.cstart), _lib.ptr(init),
+                                               C.byref(max_card), C.byref(longest)))
         ncount = int(self.cstart[nvar])
         self.count = np.zeros(ncount, np.int64)
 
-        init = variable["initialValue"]
         self.var_value_evid = np.tile(init, (var_copies, 1))
         self.var_value = np.tile(init, (var_copies, 1))
         self.weight_value = np.tile(weight["initialValue"], (weight_copies, 1))
 
         # scratch arrays of the reference's CPU threads; kept for attribute compatibility only
-        self.Z = np.zeros((workers, int(card.max()) if nvar else 0))
-        longest = int(vmap["factor_index_length"].max()) if vmap.size else 0
-        self.fids = np.zeros((workers, 2 * longest), factor_index.dtype)
+        self.Z = np.zeros((workers, int(max_card.value) if nvar else 0))
+        self.fids = np.zeros((workers, 2 * int(longest.value)), factor_index.dtype)
 
         self.fid = fid
         assert workers > 0

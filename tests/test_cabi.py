@@ -71,6 +71,41 @@ def test_compute_var_map_index_error_like_reference():
         dataloading.compute_var_map(v, f, fm, vmap, fi, dm, skip)
 
 
+def test_compute_var_map_does_not_depend_on_the_thread_count():
+    """The edges, factors and slots of the index build go over the host threads (atomic counts and cursors, every slot
+    sorted afterwards): 1 thread and 8 threads of a subprocess each build the same arrays as this process."""
+    import hashlib
+    import subprocess
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+            "from numbskull_amd import dataloading, graphgen\n"
+            "w, v, f, fm, dm, e = graphgen.mixed_lr_graph(30000, seed=3, nweights=50)\n"
+            "skip = np.array([5, 17, 17000], np.int64)\n"
+            "vmap, fi = dataloading.new_index(v, int(f['arity'].sum()))\n"
+            "dataloading.compute_var_map(v, f, fm, vmap, fi, dm, skip)\n"
+            "print(hashlib.md5(vmap.tobytes() + fi.tobytes()).hexdigest())\n") % REPO
+    out = set()
+    for threads in ("1", "8"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, NSK_COMPILE_THREADS=threads))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.add(r.stdout.strip())
+    assert len(out) == 1, out
+
+
+def test_state_layout_matches_the_reference_formulas():
+    """nsk_state_layout against factorgraph.py:41-53 written with numpy: cstart, initial values, Z's and fids' widths."""
+    w, v, f, fm, dm, e = graphgen.mixed_lr_graph(20000, seed=11, nweights=40)
+    ns = numbskull_amd.NumbSkull(quiet=True)
+    ns.loadFactorGraph(w, v, f, fm, dm, e)
+    fg = ns.factorGraphs[0]
+    card = fg.variable["cardinality"].astype(np.int64)
+    cstart = np.zeros(len(card) + 1, np.int64)
+    np.cumsum(np.where(card == 2, 1, card), out=cstart[1:])
+    assert np.array_equal(fg.cstart, cstart)
+    assert np.array_equal(fg.var_value[0], fg.variable["initialValue"]) and np.array_equal(fg.var_value_evid[0], fg.variable["initialValue"])
+    assert fg.Z.shape[1] == int(card.max()) and fg.fids.shape[1] == 2 * int(fg.vmap["factor_index_length"].max())
+    assert len(fg.count) == int(cstart[-1]) == len(fg.marginals)
+
+
 @pytest.mark.parametrize("name", ["coin", "domains"])
 def test_file_loader_matches_reference(golden, name):
     z = golden("g2_index_build.npz")
