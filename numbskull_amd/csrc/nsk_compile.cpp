@@ -1401,6 +1401,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     std::vector<int64_t> min_class((size_t)ncolors, 64);
     parallel_for(ncolors, [&](int64_t kb0, int64_t kb1, int) {
     for (int32_t k = (int32_t)kb0; k < (int32_t)kb1; k++) {
+        if (nfast_of[k] == 0) continue;                 // (nothing to class: four scans of the variables saved)
         ClassMap &cls = classes[k], &shs = shapes[k], &pss = pshapes[k];
         cls.reserve((size_t)nfast_of[k]);
         for (int64_t v = 0; v < nvar; v++) {

@@ -201,7 +201,10 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1), 
 
     # phase timings per shard: the sweep kernels alone, then all pushes, then all flag/wait/unpack
     # (+ weight merge) kernels -- each rank's bracket on its own stream, marked first, read afterwards
-    timing = {"sweep_us": [], "push_us": [], "wait_unpack_us": [], "gather_w_us": []}
+    # (inference has no closing weight gather: its part 3 enqueues nothing, and the bracket around nothing is what every
+    # other figure carries on top of its kernels -- recorded as such, not counted into the exchange)
+    last = "gather_w_us" if learn else "empty_bracket_us"
+    timing = {"sweep_us": [], "push_us": [], "wait_unpack_us": [], last: []}
     if fused:
         # a fused sweep is its class launches and nothing else: timed per shard over consecutive one-sweep calls
         ms, nl = C.c_double(), C.c_int64()
@@ -240,7 +243,7 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1), 
             _lib.check(L.nsk_profile_end(p.h, C.byref(ms), C.byref(nl)))
             row.append(ms.value * 1e3)
         timing["sweep_us"].append(row)
-        for part, key in ((1, "push_us"), (2, "wait_unpack_us"), (3, "gather_w_us")):
+        for part, key in ((1, "push_us"), (2, "wait_unpack_us"), (3, last)):
             for p in parts:
                 _lib.check(L.nsk_profile_begin(p.h))
                 _lib.check(L.nsk_p2p_exchange(p.h, int(learn), part))
@@ -256,8 +259,8 @@ def run_case(kind, size, learn, tag, nsweeps=3, hyper=(1e-3, 0.95, 2, 0.01, 1), 
     owned = [p.fg.own_range[1] - p.fg.own_range[0] for p in parts]
     out = {"config": "%s in 8 range shards, all on one MI355X, %s, peer-to-peer exchange" % (tag, "learning" if learn else "inference"),
            "owned_per_rank": owned, "values_sent_per_rank": sends, "ghosts_per_rank": [len(n) for n in needs],
-           "exchange_fraction": float(np.mean([np.mean(a) + np.mean(b) + np.mean(c) for a, b, c in
-                                               zip(timing["push_us"][1:], timing["wait_unpack_us"][1:], timing["gather_w_us"][1:])])
+           "exchange_fraction": float(np.mean([np.mean(a) + np.mean(b) + (np.mean(c) if learn else 0.0) for a, b, c in
+                                               zip(timing["push_us"][1:], timing["wait_unpack_us"][1:], timing[last][1:])])
                                       / np.mean([np.mean(a) for a in timing["sweep_us"][1:]])),
            "per_shard_us": {k: {"mean": float(np.mean(v[1:])), "max": float(np.max(v[1:]))} for k, v in timing.items()},
            "note": "one shard's kernels alone on the device (HIP events on the shard's stream); the push / wait brackets of "
