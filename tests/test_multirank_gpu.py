@@ -40,17 +40,20 @@ def test_two_ranks_one_gpu(kind, mode, layout):
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
 
-@pytest.mark.parametrize("mode", ["gibbs", "learn"])
-def test_two_ranks_large_exchange_launches(mode):
+@pytest.mark.parametrize("kind,mode", [("lr", "gibbs"), ("lr", "learn"), ("grid", "gibbs")])
+def test_two_ranks_large_exchange_launches(kind, mode):
     """The many-block launches of a large exchange (k_p2p_push_big / k_p2p_wait / k_p2p_unpack_big; lists beyond 2^16
-    values or 2^16 weights take them) on the small LR graph: NSK_P2P_BIG_MIN=0 sends every exchange that way."""
+    values or 2^16 weights take them) on the small graphs: NSK_P2P_BIG_MIN=0 sends every exchange that way.  The grid
+    run keeps the exchange kernels (NSK_NO_P2P_FUSE) and is long enough for captured sweep sequences: the launches then
+    take their tags from the device counter."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(HERE, "multirank_worker.py"), "lr", mode, "p2plocal"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, NSK_DIAG="1", NSK_P2P_BIG_MIN="0"))
+           os.path.join(HERE, "multirank_worker.py"), kind, mode, "p2plocal"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, NSK_DIAG="1", NSK_P2P_BIG_MIN="0", NSK_NO_P2P_FUSE="1"))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
