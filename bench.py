@@ -355,10 +355,23 @@ def spawn_ranks(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start it as a CHILD process (this
     parent has not touched the GPU, and a process that has must never exec), relay its output and
     exit with its code."""
+    import random
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # (a port outside the kernel's ephemeral range: one probed with bind(0) can be handed to an outgoing connection
+    #  before the rendezvous server binds it)
+    port = None
+    rng = random.Random(os.getpid() * 7919 + int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        cand = rng.randrange(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", cand))
+            except OSError:
+                continue
+        port = cand
+        break
+    if port is None:
+        sys.exit("bench.py: no free rendezvous port in 20000-31999")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__)] + sys.argv[1:]

@@ -15,17 +15,13 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from util import graphgen, session, oracle_of, phases_from_colors, check_coloring
+from util import graphgen, session, oracle_of, phases_from_colors, check_coloring, free_port
 from numbskull_amd.distributed import (shard_range, plan_boundaries, gather_needs,
                                        merge_weight_deltas)
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    return free_port()          # (outside the ephemeral range: util.free_port)
 
 
 def _graph(kind):

@@ -1171,12 +1171,9 @@ def test_rccl_all_gather_on_library_memory():
     import torch
     import torch.distributed as dist
     from numbskull_amd.distributed import PartitionedSampler, merge_weight_deltas
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    from util import free_port
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MASTER_PORT"] = str(free_port())
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:

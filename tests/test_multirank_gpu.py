@@ -4,11 +4,11 @@ per-sweep exchange through torch collectives on the library's own device buffers
 all-reduce -- against the oracle's emulation of the partitioned semantics.  (RCCL itself needs one
 device per rank: the 1-rank RCCL tests in test_hip_parity.py and the driver's 8-GPU run cover it.)"""
 import os
-import socket
-import subprocess
 import sys
 
 import pytest
+
+from util import run_ranks
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,14 +24,7 @@ def test_two_ranks_one_gpu(kind, mode, layout):
     layout "p2p": the sweeps exchange boundaries by peer writes into hipIpc-mapped buffers with flags
     (nsk_gibbs_sweeps_p2p; learning: both chains and the epoch's weight deltas, nsk_learn_sweeps_p2p)
     instead of collectives; "p2plocal": the same on shard-local graphs (what bench.py --gpus N runs)."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(HERE, "multirank_worker.py"), kind, mode, layout]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    r = run_ranks([os.path.join(HERE, "multirank_worker.py"), kind, mode, layout])
     if r.returncode != 0:                      # the workers' full output, for the session log
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/multirank_%s_%s_%s.log" % (kind, mode, layout), "w") as f:
@@ -46,14 +39,7 @@ def test_two_ranks_large_exchange_launches(kind, mode):
     values or 2^16 weights take them) on the small graphs: NSK_P2P_BIG_MIN=0 sends every exchange that way.  The grid
     run keeps the exchange kernels (NSK_NO_P2P_FUSE) and is long enough for captured sweep sequences: the launches then
     take their tags from the device counter."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(HERE, "multirank_worker.py"), kind, mode, "p2plocal"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, NSK_DIAG="1", NSK_P2P_BIG_MIN="0", NSK_NO_P2P_FUSE="1"))
+    r = run_ranks([os.path.join(HERE, "multirank_worker.py"), kind, mode, "p2plocal"],
+                  env=dict(os.environ, NSK_DIAG="1", NSK_P2P_BIG_MIN="0", NSK_NO_P2P_FUSE="1"))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -126,3 +126,36 @@ def exact_marginals(og, weight_value, sample_mask=None):
     for j, i in enumerate(free):
         out[i] = np.array([p[states[:, j] == k].sum() for k in range(cards[j])])
     return out
+
+
+def free_port():
+    """A TCP port for a rendezvous on 127.0.0.1, free now and OUTSIDE the kernel's ephemeral range (32768-60999):
+    a port probed with bind(0) can be handed to somebody's outgoing connection before the rendezvous server binds it
+    (seen once in 339 GPU tests: EADDRINUSE)."""
+    import random
+    import socket
+    rng = random.Random(os.getpid() * 7919 + int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        port = rng.randrange(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    raise RuntimeError("no free port in 20000-31999")
+
+
+def run_ranks(script_args, nproc=2, env=None, timeout=600, tries=3):
+    """`python -m torch.distributed.run --nproc-per-node nproc script_args...` on a fresh port; a rendezvous that
+    loses its port to another process all the same is started again (up to `tries` times).  Returns the
+    CompletedProcess of the last attempt."""
+    import subprocess
+    r = None
+    for _ in range(tries):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + list(script_args)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    return r
