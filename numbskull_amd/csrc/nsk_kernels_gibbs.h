@@ -1001,8 +1001,12 @@ __device__ __forceinline__ int ep_pass_rows(uint32_t rowsw) {
     return (int)(rowsw & 255u) + (int)((rowsw >> 8) & 255u) + (int)((rowsw >> 16) & 255u) + (int)(rowsw >> 24);
 }
 
-// words of row r (wave-uniform) of a pass; M = its member count
-template <bool NT, bool MEMBERS>
+// words of row r (wave-uniform) of a pass; M = its member count.  The number of loads does not depend on the row:
+// a row with fewer than three member sub-rows reads its last sub-row again (the line is on its way already) and
+// the words are replaced by the empty slot -- with a load count that varies from row to row the compiler cannot
+// count the loads in flight and waits for ALL of them (s_waitcnt vmcnt(0)) at the first use of a row, which is
+// where the prefetch of the next row had just been issued.
+template <bool NT, bool MEMBERS, bool WT>
 __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, uint32_t rowsw, int r, EpRow &q, int &M,
                                             const double *wt, double &w) {
     const int n0 = (int)(rowsw & 255u), n1 = (int)((rowsw >> 8) & 255u), n2 = (int)((rowsw >> 16) & 255u);
@@ -1016,12 +1020,15 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
     const uint32_t *row = adj + (size_t)(sub0 + (uint32_t)sub) * 64;
     const nsk_u32x2 h = NT ? __builtin_nontemporal_load((const nsk_u32x2 *)row + lane) : *((const nsk_u32x2 *)row + lane);
     q.w0 = h.x; q.d1 = h.y;
-    if (wt) w = __builtin_nontemporal_load(wt + (size_t)r * 64 + lane);     // the entry's materialised weight
+    if (WT) w = __builtin_nontemporal_load(wt + (size_t)r * 64 + lane);     // the entry's materialised weight
     q.m[0] = NSK_GEN_NULL; q.m[1] = NSK_GEN_NULL; q.m[2] = NSK_GEN_NULL;
     if (MEMBERS) {
 #pragma unroll
-        for (int m = 0; m < 3; m++)
-            if (M > m) q.m[m] = NT ? __builtin_nontemporal_load(row + (2 + m) * 64 + lane) : row[(2 + m) * 64 + lane];
+        for (int m = 0; m < 3; m++) {
+            const int mm = M > m ? 2 + m : 1 + M;                          // (wave-uniform: the sub-row to read)
+            const uint32_t x = NT ? __builtin_nontemporal_load(row + mm * 64 + lane) : row[mm * 64 + lane];
+            q.m[m] = M > m ? x : NSK_GEN_NULL;
+        }
     }
 }
 
@@ -1053,13 +1060,12 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
 #pragma unroll
     for (int u = 0; u < U; u++) {
         Mc[u] = 0; Mn[u] = 0; wc[u] = 0.0; wn[u] = 0.0;
-        if (wave + 4 * u < total) ep_load_row<NT, MEMBERS>(g.ep_adj, sub0, rowsw, wave + 4 * u, cur[u], Mc[u], WMODE == 2 ? wt : nullptr, wc[u]);
+        if (wave + 4 * u < total) ep_load_row<NT, MEMBERS, WMODE == 2>(g.ep_adj, sub0, rowsw, wave + 4 * u, cur[u], Mc[u], wt, wc[u]);
     }
     for (int r = wave; r < total; r += 4 * U) {
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (r + 4 * (U + u) < total)
-                ep_load_row<NT, MEMBERS>(g.ep_adj, sub0, rowsw, r + 4 * (U + u), nxt[u], Mn[u], WMODE == 2 ? wt : nullptr, wn[u]);
+        // this step's gathers FIRST, the next rows' words behind them (always the same number of loads: past the
+        // last row the last row again): the gathers are then complete when all but those loads are (vmcnt = their
+        // number), and the next rows' words have this step's arithmetic and the next step's gathers to arrive in
         double w[U];
         int xa[U][3], xb[U][3];
 #pragma unroll
@@ -1102,6 +1108,9 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
                     }
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            ep_load_row<NT, MEMBERS, WMODE == 2>(g.ep_adj, sub0, rowsw, min(r + 4 * (U + u), total - 1), nxt[u], Mn[u], wt, wn[u]);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (r + 4 * u >= total) continue;
@@ -1159,7 +1168,7 @@ static __global__ __launch_bounds__(NSK_BLOCK) void k_refresh_ep_weights(const u
             EpRow q;
             int M;
             double unused = 0.0;
-            ep_load_row<false, false>(ep_adj, sub, rowsw, r, q, M, nullptr, unused);
+            ep_load_row<false, false, false>(ep_adj, sub, rowsw, r, q, M, nullptr, unused);
             ep_wt[(size_t)(row + r) * 64 + lane] = w[NSK_EP_WID(q.w0)];
         }
         sub += (uint32_t)ep_pass_subrows(rowsw);
