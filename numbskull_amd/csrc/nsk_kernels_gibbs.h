@@ -1041,6 +1041,11 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
 // their gathers are issued together and waited for once.
 // (measured on the 5M LR graph, per class: inference U = 1 58.5 us, 2 63.8, 3 64.9 -- the single-chain walk
 // keeps 6 waves per SIMD; learning, whose rows carry two chains, U = 1 159.8, 2 149.4, 3 164.2)
+// (round 5, once the loads of a row could be counted -- ep_load_row --: inference at 50M 468.5 -> 412.7 us per class;
+// on top of that, rows two deep in flight -- words of row k + 2 and gathers of row k + 1 behind the arithmetic of
+// row k, three register sets rotating through a loop unrolled by three, every wait a counted one -- 421.5 us, the
+// 96-register variant of the small graphs spilling (5M: 49.6 -> 55.7 us); two rows per step 411.0 / 66.5 us:
+// what is left of a step is instruction issue, not latency.  tools/sessions/r5_s20.sh, r5_s21.sh)
 #ifdef NSK_EP_WIN
 #define NSK_EP_WIN_ON true
 #else
@@ -1355,9 +1360,7 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
                 ((uint32_t *)fs)[i] = 14u | (14u << 16);                                   // owned by no candidate
             __syncthreads();
 #ifndef NSK_ABL_EPNOP1
-            ep_pass<VT, false, 2, true, true, NSK_EP_U_INF>(g, g.val, g.val, sub, rowsw, g.ep_wt + (size_t)wrow * 64,
-                (const signed char *)wina, (const signed char *)wina, g.ep_win != nullptr,
-                [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &, double w) {
+            auto entry_done = [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &, double w) {
                     int cstar, A, B;
                     a.close(d1, lut, cstar, A, B);
                     const uint32_t ks = (d1 >> 14) & 15u;
@@ -1366,7 +1369,9 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
                         ws[slot] = w;
                         fs[slot] = (uint16_t)(ks | (ep_facts(cstar, A, B) << 4));
                     }
-                });
+                };
+            ep_pass<VT, false, 2, true, true, NSK_EP_U_INF>(g, g.val, g.val, sub, rowsw, g.ep_wt + (size_t)wrow * 64,
+                (const signed char *)wina, (const signed char *)wina, g.ep_win != nullptr, entry_done);
 #endif
 #ifdef NSK_ABL_TIMING
             if (pass == 0) dbg_t1 = __builtin_amdgcn_s_memtime();
