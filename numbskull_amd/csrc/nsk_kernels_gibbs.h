@@ -1687,8 +1687,6 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
         }
     }
 #pragma unroll
-    for (int k = 0; k < NT; k++) tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[k]];
-#pragma unroll
     for (int k = 0; k < NT; k++) {
         if (ab[k][0] != NSK_NO_STREAM) {                                // wave-uniform: member = base + lane
 #pragma unroll
@@ -1704,12 +1702,23 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     }
     // member values -> neighbourhood bits -> table entries (the table kernels run only while every value on
     // the device lies in its domain -- values_regular -- and their members are binary: a value IS its bit)
+    // (the tally bytes are requested BEHIND the gathers: in front of them -- where they stood until round 5 -- the
+    // wait that the stream words of a non-affine segment need, vmcnt(0) where the two paths meet, waited for the
+    // tallies as well, and an affine tile paid a round trip before its gathers were even issued)
     uint32_t idx[NT];
+    uint8_t raw[NT][4 * NCH];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+#pragma unroll
+        for (int j = 0; j < 4 * NCH; j++) raw[k][j] = (uint8_t)g.val[id[k][j]];
+    }
+#pragma unroll
+    for (int k = 0; k < NT; k++) tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[k]];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         idx[k] = 0;
 #pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
+        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)raw[k][j] << j;
     }
     uint2 e[NT];
 #pragma unroll
@@ -1861,13 +1870,6 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
         }
     }
 #pragma unroll
-    for (int k = 0; k < NT; k++)
-#ifdef NSK_TAB_FLAT_LD
-        tally[k] = burnin ? 0u : (uint32_t)g.cnt_pos[en.pos0 + tt[k] * 64 + lane];
-#else
-        tally[k] = burnin ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, en.pos0 + tt[k] * 64, 0);
-#endif
-#pragma unroll
     for (int k = 0; k < NT; k++) {
         if (ab[k][0] == NSK_NO_STREAM) {                                // wave-uniform: the tile reads its stream
             const uint4 *sp = g.adj + en.adj_off + (size_t)tt[k] * (64 * NCH) + lane;
@@ -1920,6 +1922,14 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
             }
         }
     }
+    // (the tally bytes behind the member loads: see tab_tiles)
+#pragma unroll
+    for (int k = 0; k < NT; k++)
+#ifdef NSK_TAB_FLAT_LD
+        tally[k] = burnin ? 0u : (uint32_t)g.cnt_pos[en.pos0 + tt[k] * 64 + lane];
+#else
+        tally[k] = burnin ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, en.pos0 + tt[k] * 64, 0);
+#endif
     uint32_t idx[NT];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
