@@ -1686,6 +1686,12 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
             for (int j = 0; j < 4 * NCH; j++) ab[k][j] = ap[j];
         }
     }
+    // (the tally bytes in front of the gathers: the wait the stream words of a non-affine segment need -- vmcnt(0)
+    // where the two paths meet -- then waits for them as well before an affine tile's gathers are issued.  Requesting
+    // them BEHIND the gathers, here and for k_learn_seg_tab's evidence values, changed nothing: 10M grid 12.7 / 12.7 us
+    // per class, learning 23.4 / 23.4, 40M grid 40.3 against 39.1 -- tools/sessions/r5_s23.sh; not kept)
+#pragma unroll
+    for (int k = 0; k < NT; k++) tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[k]];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         if (ab[k][0] != NSK_NO_STREAM) {                                // wave-uniform: member = base + lane
@@ -1702,23 +1708,12 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     }
     // member values -> neighbourhood bits -> table entries (the table kernels run only while every value on
     // the device lies in its domain -- values_regular -- and their members are binary: a value IS its bit)
-    // (the tally bytes are requested BEHIND the gathers: in front of them -- where they stood until round 5 -- the
-    // wait that the stream words of a non-affine segment need, vmcnt(0) where the two paths meet, waited for the
-    // tallies as well, and an affine tile paid a round trip before its gathers were even issued)
     uint32_t idx[NT];
-    uint8_t raw[NT][4 * NCH];
-#pragma unroll
-    for (int k = 0; k < NT; k++) {
-#pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) raw[k][j] = (uint8_t)g.val[id[k][j]];
-    }
-#pragma unroll
-    for (int k = 0; k < NT; k++) tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[k]];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         idx[k] = 0;
 #pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)raw[k][j] << j;
+        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
     }
     uint2 e[NT];
 #pragma unroll
@@ -1870,6 +1865,13 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
         }
     }
 #pragma unroll
+    for (int k = 0; k < NT; k++)
+#ifdef NSK_TAB_FLAT_LD
+        tally[k] = burnin ? 0u : (uint32_t)g.cnt_pos[en.pos0 + tt[k] * 64 + lane];
+#else
+        tally[k] = burnin ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, en.pos0 + tt[k] * 64, 0);
+#endif
+#pragma unroll
     for (int k = 0; k < NT; k++) {
         if (ab[k][0] == NSK_NO_STREAM) {                                // wave-uniform: the tile reads its stream
             const uint4 *sp = g.adj + en.adj_off + (size_t)tt[k] * (64 * NCH) + lane;
@@ -1922,14 +1924,6 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
             }
         }
     }
-    // (the tally bytes behind the member loads: see tab_tiles)
-#pragma unroll
-    for (int k = 0; k < NT; k++)
-#ifdef NSK_TAB_FLAT_LD
-        tally[k] = burnin ? 0u : (uint32_t)g.cnt_pos[en.pos0 + tt[k] * 64 + lane];
-#else
-        tally[k] = burnin ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, en.pos0 + tt[k] * 64, 0);
-#endif
     uint32_t idx[NT];
 #pragma unroll
     for (int k = 0; k < NT; k++) {

@@ -884,12 +884,10 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
                 for (int j = 0; j < 4 * NCH; j++) ab[k][j] = ap[j];
             }
-#ifdef NSK_LEARN_PREFETCH
 #ifdef NSK_ABL_LNOINIT
             r.init[k] = 1;
 #else
             r.init[k] = (int)g.p_init[c_pos + t * 64 + lane];          // -1: padding lane at a class end
-#endif
 #endif
         }
 #pragma unroll
@@ -918,40 +916,24 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #ifndef NSK_LEARN_PREFETCH
         issue(P, rn, in);       // (with implicit adjacency a trip's requests are scalar loads and coalesced rows:
 #endif                          //  requesting the next trip behind the table loads no longer pays -- 32.3 vs 31.9 us per class)
-        LearnTrip<NCH, TPW> r = rn;
+        const LearnTrip<NCH, TPW> r = rn;
         const LearnTripInfo ti = in;
         uint32_t idf[TPW], ide[TPW];
-        uint32_t xf[TPW][4 * NCH], xe[TPW][4 * NCH];
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
+            uint32_t xf[4 * NCH], xe[4 * NCH];
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
-                xf[k][j] = (uint32_t)(uint8_t)g.val[r.id[k][j]];
+                xf[j] = (uint32_t)(uint8_t)g.val[r.id[k][j]];
 #ifdef NSK_ABL_LNOEV
-                xe[k][j] = xf[k][j];
+                xe[j] = xf[j];
 #else
-                xe[k][j] = (uint32_t)(uint8_t)g.val_evid[r.id[k][j]];
+                xe[j] = (uint32_t)(uint8_t)g.val_evid[r.id[k][j]];
 #endif
             }
-        }
-#ifndef NSK_LEARN_PREFETCH
-        // the evidence values are requested BEHIND the gathers: in front of them (issue(), until round 5) the wait
-        // that the stream words of a non-affine segment need -- vmcnt(0) where the two paths meet -- waited for them
-        // too, and an affine trip paid a round trip before its gathers were even issued (k_gibbs_seg_tab's tallies)
-#pragma unroll
-        for (int k = 0; k < TPW; k++) {
-#ifdef NSK_ABL_LNOINIT
-            r.init[k] = 1;
-#else
-            r.init[k] = (int)g.p_init[ti.pos + min(ti.t0 + k, ti.nt - 1) * 64 + lane];      // -1: padding lane at a class end
-#endif
-        }
-#endif
-#pragma unroll
-        for (int k = 0; k < TPW; k++) {
             idf[k] = 0; ide[k] = 0;
 #pragma unroll
-            for (int j = 0; j < 4 * NCH; j++) { idf[k] |= xf[k][j] << j; ide[k] |= xe[k][j] << j; }    // (values are their bits: values_regular)
+            for (int j = 0; j < 4 * NCH; j++) { idf[k] |= xf[j] << j; ide[k] |= xe[j] << j; }    // (values are their bits: values_regular)
             idf[k] &= ti.zmask;
             ide[k] &= ti.zmask;
         }
