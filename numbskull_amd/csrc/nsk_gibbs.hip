@@ -162,26 +162,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep, nsk_sweep_hi(g)
                     // (value array within the L2s: the register-capped twin with a fifth wave per SIMD)
                     const bool in_l2 = (size_t)g->c.nid * (size_t)g->c.vbytes <= ((size_t)24 << 20);
-                    // The all-binary groups at the colour's end (nsk_compile.cpp: categorical lanes come first) in a
-                    // launch of their own with the two-candidate kernel -- 86 vector registers and five waves per SIMD
-                    // instead of 102 and four, no eight-candidate sums -- when the graph is too large for the
-                    // register-capped twin and there are enough of them to pay for a launch.
-                    const int gsplit = ((int)g->c.phase_gen_bin_tile[ph] - gt0 + 3) / 4;        // first all-binary group
-                    const bool split = cat8 && !in_l2 && ngroups - gsplit >= nsk_ep_split_min() && gsplit > 0;
-                    if (split) {
-                        const int gb8 = 8 * ((std::min(gsplit, 256 * pcu) + 7) / 8), gb2 = 8 * ((std::min(ngroups - gsplit, 256 * pcu) + 7) / 8);
-                        k_gibbs_ep<VT, 8><<<dim3(hblocks + gb8 + rblocks), dim3(NSK_BLOCK), smem, g->stream>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, 4 * gsplit, gsplit, (int)g->c.phase_ep_base[ph], gb8, fe, he, hblocks,
-                            (int)g->c.phase_hub_base[ph], nbh, (int)g->c.phase_bighub_base[ph], g->rest_tiles + g->c.phase_rest_base[ph], nrest_all,
-                            sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep, nsk_sweep_hi(g));
-                        k_gibbs_ep<VT, 2><<<dim3(gb2), dim3(NSK_BLOCK), smem, g->stream>>>(
-                            d, fb, fe, (int)g->c.phase_wb_base[ph], gt0 + 4 * gsplit, ngt - 4 * gsplit, ngroups - gsplit,
-                            (int)g->c.phase_ep_base[ph] + gsplit, gb2, fe, fe, 0, (int)g->c.phase_hub_base[ph], 0, (int)g->c.phase_bighub_base[ph],
-                            g->rest_tiles + g->c.phase_rest_base[ph], 0,
-                            sample_evidence, burnin, (uint32_t)g->seed, (uint32_t)(g->seed >> 32), (uint32_t)g->sweep, nsk_sweep_hi(g));
-                        g->launches++;
-                    }
-                    else if (cat8 && in_l2) k_gibbs_ep_w5<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
+                    if (cat8 && in_l2) k_gibbs_ep_w5<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
                     else if (cat8) k_gibbs_ep<VT, 8><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
                     else k_gibbs_ep<VT, 2><<<grid, dim3(NSK_BLOCK), smem, g->stream>>>(NSK_EP_ARGS);
 #undef NSK_EP_ARGS

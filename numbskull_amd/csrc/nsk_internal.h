@@ -235,14 +235,6 @@ struct ColourStreams {
     }
 };
 
-// all-binary groups a colour must end in for a launch of their own (k_gibbs_ep<2> / k_learn_ep<2> behind the
-// eight-candidate launch); diagnostic NSK_EP_SPLIT_MIN=n (0: never), read per launch so that tests can set it
-static inline int nsk_ep_split_min() {
-    const char *e = nsk::diag_env("NSK_EP_SPLIT_MIN");
-    if (!e) return 2048;
-    const int n = atoi(e);
-    return n <= 0 ? 0x7FFFFFFF : n;
-}
 // the fast path reads weights through prog_w (and the draw tables): rebuilt whenever weights may
 // have changed (nsk_api.hip)
 // Grid of a table-driven learning segment launch: resident -- the waves loop over their XCD's trips

@@ -214,21 +214,11 @@ int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay
 #define NSK_LEP(MAXC) k_learn_ep<VT, SMALLW, MAXC><<<dim3(grid), dim3(NSK_BLOCK), shmem, st>>>( \
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, ntiles - gt0, ngroups, (int)g->c.phase_ep_base[ph], gblocks, \
                     fe, he, hbl_ep, nbh, (int)g->c.phase_bighub_base[ph], lrest, rest_in_general ? nlrest : 0, lp)
-                // (the all-binary groups at the colour's end in a launch of their own with the two-candidate kernel: 114
-                // vector registers and four waves per SIMD instead of 152 and three -- nsk_gibbs.hip)
-                const int gsplit = (gtb - gt0 + 3) / 4;
-                if (one_lg && ngroups - gsplit >= nsk_ep_split_min() && gsplit > 0) {
-                    const int gb8 = 8 * ((std::min(256 * per_cu, gsplit) + 7) / 8), gb2 = 8 * ((std::min(256 * per_cu, ngroups - gsplit) + 7) / 8);
-                    const int rb8 = std::max(0, 8 * ((std::min(2560, (nrest_here + 3) / 4) + 7) / 8) - gb8);
-                    k_learn_ep<VT, SMALLW, 8><<<dim3(gb8 + rb8 + hbl_ep), dim3(NSK_BLOCK), shmem, st>>>(
-                        d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, 4 * gsplit, gsplit, (int)g->c.phase_ep_base[ph], gb8,
-                        fe, he, hbl_ep, nbh, (int)g->c.phase_bighub_base[ph], lrest, rest_in_general ? nlrest : 0, lp);
-                    k_learn_ep<VT, SMALLW, 2><<<dim3(gb2), dim3(NSK_BLOCK), shmem, st>>>(
-                        d, fb, fe, (int)g->c.phase_wb_base[ph], gt0 + 4 * gsplit, ntiles - gt0 - 4 * gsplit, ngroups - gsplit,
-                        (int)g->c.phase_ep_base[ph] + gsplit, gb2, fe, fe, 0, 0, (int)g->c.phase_bighub_base[ph], lrest, 0, lp);
-                    g->launches++;
-                }
-                else if (one_lg) NSK_LEP(8); else NSK_LEP(2);
+                // (a colour's all-binary groups -- its tail: categorical lanes come first -- in a launch of their own with the
+                // two-candidate kernel, 114 vector registers and four waves per SIMD instead of 152 and three: 50M LR graph
+                // 5.57 -> 5.73e9 updates/s, 5M 5.13 -> 4.17e9 with the split forced (two tails per class); inference, 86 / 5
+                // against 102 / 4: 1.540 / 1.540e10 -- tools/sessions/r5_s24.sh; not kept)
+                if (one_lg) NSK_LEP(8); else NSK_LEP(2);
 #undef NSK_LEP
                 g->launches++;
             }
