@@ -1337,10 +1337,6 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
         const NSK_SCALAR uint32_t *gdp = (const NSK_SCALAR uint32_t *)(g.ep_desc + group0 + gi);
         const uint32_t gsub = gdp[0], grows0 = gdp[1], gmax = gdp[2], grows1 = gdp[3];
         const int ne = (int)(gmax & 255u);
-#ifndef NSK_EP_BIN_SEL
-#define NSK_EP_BIN_SEL 1
-#endif
-        const bool bin = NSK_EP_BIN_SEL && ((gmax >> 8) & 255u) <= 2u;        // every variable of the group has two candidates (block-uniform)
 #ifdef NSK_ABL_TIMING
         const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
         unsigned long long dbg_t1 = dbg_t0;
@@ -1360,16 +1356,13 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
             const uint32_t rowsw = pass ? grows1 : grows0;
             __syncthreads();                               // (the previous sums have been read)
             if (pass == 0) ep_stage_window<VT, false>(g, group0 + gi, wina, wina);
-            // A group of two-candidate variables only (three quarters of config #5's) keeps, per slot, the weight and
-            // what each candidate's sum takes of it -- s0, s1 in {-1, 0, 1}: candidate c's term w * (c == cstar ? A : B),
-            // 0 when c does not own the entry -- decided by the entry's lane; the variable's lane then adds w, -w or
-            // nothing (the products w * 1, w * -1 are w and -w exactly, and a zero term of either sign leaves a sum that
-            // is never -0.0 unchanged): 16 instead of 45 vector instructions per list position and variable.  (Finite
-            // weights: inf * 0 is NaN in potential() and nothing here -- a graph with a non-finite weight samples garbage
-            // in the reference either way.)
-            const uint32_t none = bin ? (5u | (5u << 16)) : (14u | (14u << 16));
+            // (a group of two-candidate variables could keep, per slot, the weight and two selectors in {-1, 0, 1} -- what
+            // each candidate's sum takes of it, decided by the entry's lane -- so that the variable's lane adds w, -w or
+            // nothing: 16 instead of 45 vector instructions per list position and variable.  Measured: 50M LR 408.6
+            // against 404.2 us per class, weighted boolean graph 31.7 / 31.3, 5M LR 49.9 / 50.1 -- the arithmetic of
+            // phase 2 is not what a group waits for; tools/sessions/r5_s25.sh; not kept)
             for (int i = (int)threadIdx.x; i < NSK_EP_LIST * 128; i += NSK_BLOCK)      // slots no entry writes:
-                ((uint32_t *)fs)[i] = none;                                               // owned by no candidate / s0 = s1 = 0
+                ((uint32_t *)fs)[i] = 14u | (14u << 16);                                   // owned by no candidate
             __syncthreads();
 #ifndef NSK_ABL_EPNOP1
             auto entry_done = [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &, double w) {
@@ -1379,13 +1372,7 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
                     if (ks != 14u) {
                         const uint32_t slot = NSK_EP_SLOT(w0, d1);
                         ws[slot] = w;
-                        if (bin) {
-                            const int t0 = (ks == 15u || ks == 0u) ? (cstar == 0 ? A : B) : 0;
-                            const int t1 = (ks == 15u || ks == 1u) ? (cstar == 1 ? A : B) : 0;
-                            fs[slot] = (uint16_t)((uint32_t)(t0 + 1) | ((uint32_t)(t1 + 1) << 2));
-                        } else {
-                            fs[slot] = (uint16_t)(ks | (ep_facts(cstar, A, B) << 4));
-                        }
+                        fs[slot] = (uint16_t)(ks | (ep_facts(cstar, A, B) << 4));
                     }
                 };
             ep_pass<VT, false, 2, true, true, NSK_EP_U_INF>(g, g.val, g.val, sub, rowsw, g.ep_wt + (size_t)wrow * 64,
@@ -1397,16 +1384,7 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
             __syncthreads();
 #ifndef NSK_ABL_EPNOP2
             const int nacc = min(NSK_EP_LIST, ne - pass * NSK_EP_LIST);
-            if (tile_ok && bin) {
-                for (int o = 0; o < nacc; o++) {
-                    const uint32_t f = fs[o * 256 + (int)threadIdx.x];
-                    const double w = ws[o * 256 + (int)threadIdx.x];
-                    const uint32_t c0 = f & 3u, c1 = (f >> 2) & 3u;                  // s + 1
-                    const double t0 = c0 == 1u ? 0.0 : (c0 == 2u ? w : -w), t1 = c1 == 1u ? 0.0 : (c1 == 2u ? w : -w);
-                    pot.p[0] = pot.p[0] + t0;
-                    pot.p[1] = pot.p[1] + t1;
-                }
-            } else if (tile_ok)
+            if (tile_ok)
                 for (int o = 0; o < nacc; o++) {
                     const uint32_t f = fs[o * 256 + (int)threadIdx.x];
                     const double w = ws[o * 256 + (int)threadIdx.x];
