@@ -1045,7 +1045,8 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
 // on top of that, rows two deep in flight -- words of row k + 2 and gathers of row k + 1 behind the arithmetic of
 // row k, three register sets rotating through a loop unrolled by three, every wait a counted one -- 421.5 us, the
 // 96-register variant of the small graphs spilling (5M: 49.6 -> 55.7 us); two rows per step 411.0 / 66.5 us:
-// what is left of a step is instruction issue, not latency.  tools/sessions/r5_s20.sh, r5_s21.sh)
+// a step no longer waits for its own prefetch; what a group takes now is the serial structure of its pass.
+// tools/sessions/r5_s20.sh, r5_s21.sh)
 #ifdef NSK_EP_WIN
 #define NSK_EP_WIN_ON true
 #else
