@@ -1057,7 +1057,9 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
 template <typename VT, bool TWO, int WMODE, bool NT, bool MEMBERS, int U, typename FN>
 __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, const VT *vb, uint32_t sub0,
                                         uint32_t rowsw, const double *wt, const signed char *wa, const signed char *wb, bool win, FN &&fn) {
-    const int wave = (int)(threadIdx.x >> 6);
+    // (the wave's index as a SCALAR: row numbers, member counts, sub-row offsets and the branches on them are then
+    // scalar work -- from threadIdx alone the compiler must assume they differ from lane to lane)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int total = ep_pass_rows(rowsw);
     if (wave >= total) return;
     EpRow cur[U], nxt[U];
@@ -1343,7 +1345,7 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
         unsigned long long dbg_t1 = dbg_t0;
 #endif
         // this lane's variable (phase 2): requested now, needed after the entries
-        const int tile = tile0 + 4 * gi + (int)(threadIdx.x >> 6);
+        const int tile = tile0 + 4 * gi + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (a scalar: see ep_pass)
         const bool tile_ok = tile < tile0 + ntiles;                       // wave-uniform
         const int p = pbegin + tile * 64 + (int)(threadIdx.x & 63);
         const bool valid = tile_ok && p < pend && g.p_vid[p] >= 0;

@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
             const NSK_SCALAR uint32_t *gdp = (const NSK_SCALAR uint32_t *)(g.ep_desc + group0 + gi);
             const uint32_t gsub = gdp[0], grows0 = gdp[1], gmax = gdp[2], grows1 = gdp[3];
             const int ne = (int)(gmax & 255u);
-            const int tile = tile0 + 4 * gi + (int)(threadIdx.x >> 6);
+            const int tile = tile0 + 4 * gi + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (a scalar: ep_pass)
             const bool tile_ok = tile < tile0 + ntiles;                           // wave-uniform
             const int p = pbegin + tile * 64 + (int)(threadIdx.x & 63);
             const bool valid = tile_ok && p < pend && g.p_vid[p] >= 0;
