@@ -1146,11 +1146,14 @@ __device__ __forceinline__ void block_hub_learn(const DevGraph<VT> &g, const Gra
 // A group with more than 8 entries per variable takes two passes of (1, 2); phase 3 then runs over the
 // second pass's entries (their facts are in LDS) and, after redoing phase 1 for them, over the first's.
 // Dynamic LDS: the SMALLW accumulators only.
-#ifdef NSK_EP_WPE_L
-#define NSK_EP_ATTR_L __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_L, NSK_EP_WPE_L)))
-#else
-#define NSK_EP_ATTR_L
+// Four waves per SIMD: with the wave's index a scalar (ep_pass) the eight-candidate instantiation needs 139 vector
+// registers -- three waves --, and capped at 128 it spills 16 bytes: 5M LR graph 121.1 -> 113.3 us per class (5.16 ->
+// 5.52e9 updates/s), 50M 1114 -> 1051 (5.61 -> 5.94e9); tools/sessions/r5_s29.sh.  (The two-candidate instantiation
+// has 114 and is at four already; at 152 registers, before, the cap was measured slower.)
+#ifndef NSK_EP_WPE_L
+#define NSK_EP_WPE_L 4
 #endif
+#define NSK_EP_ATTR_L __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_L, NSK_EP_WPE_L)))
 template <typename VT, bool SMALLW, int MAXC>
 __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
                                                         int tile0, int ntiles, int ngroups, int group0, int gblocks,
