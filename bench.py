@@ -309,7 +309,7 @@ def roofline_bound(kernel):
     occupancy their registers allow (no unit saturated); the CSR / exp-per-update kernels by HBM."""
     if kernel.endswith("_seg_tab"):
         return "issue"
-    if kernel.endswith("_ep") or kernel.endswith("_ep_w5"):
+    if kernel.endswith("_ep") or kernel.endswith("_ep_w5") or kernel.endswith("_ep_w4"):
         return "latency"
     return "hbm"
 
@@ -342,7 +342,8 @@ def dominant_kernel(workload, learning, info):
         return "k_learn_phase" if learning else "k_gibbs_phase"
     if workload.startswith("lr") or workload.startswith("boolw"):
         if learning:
-            return "k_learn_ep"                                    # entry-parallel groups (+ hubs, rest tiles)
+            # entry-parallel groups (+ hubs, rest tiles); graphs with categorical variables: the four-waves-per-SIMD twin
+            return "k_learn_ep_w4" if workload.startswith("lr") else "k_learn_ep"
         # categorical graphs whose value array stays in the L2s run the register-capped twin (nsk_gibbs.hip)
         small = info["nvar"] * info["value_bytes"] <= (24 << 20)
         return "k_gibbs_ep_w5" if workload.startswith("lr") and small else "k_gibbs_ep"

@@ -1155,10 +1155,10 @@ __device__ __forceinline__ void block_hub_learn(const DevGraph<VT> &g, const Gra
 #endif
 #define NSK_EP_ATTR_L __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_L, NSK_EP_WPE_L)))
 template <typename VT, bool SMALLW, int MAXC>
-__global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<VT> g, int pbegin, int pend, int wb_base,
-                                                        int tile0, int ntiles, int ngroups, int group0, int gblocks,
-                                                        int hb, int he, int hblocks, int nbh, int bh0,
-                                                        const uint32_t *rest_list, int nrest, LearnParams lp) {
+__device__ __forceinline__ void learn_ep_body(const DevGraph<VT> &g, int pbegin, int pend, int wb_base,
+                                              int tile0, int ntiles, int ngroups, int group0, int gblocks,
+                                              int hb, int he, int hblocks, int nbh, int bh0,
+                                              const uint32_t *rest_list, int nrest, const LearnParams &lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) double ws[NSK_EP_LIST * 256];
     __shared__ __attribute__((aligned(16))) uint32_t fs[NSK_EP_LIST * 256];
@@ -1323,6 +1323,17 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep(DevGraph<V
     (void)nwaves;
     close_sink<SMALLW>(g, sk);
 }
+
+#define NSK_LEP_PARAMS DevGraph<VT> g, int pbegin, int pend, int wb_base, int tile0, int ntiles, int ngroups, int group0, int gblocks, \
+                       int hb, int he, int hblocks, int nbh, int bh0, const uint32_t *rest_list, int nrest, LearnParams lp
+#define NSK_LEP_FORWARD g, pbegin, pend, wb_base, tile0, ntiles, ngroups, group0, gblocks, hb, he, hblocks, nbh, bh0, rest_list, nrest, lp
+template <typename VT, bool SMALLW, int MAXC>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_ep(NSK_LEP_PARAMS) { learn_ep_body<VT, SMALLW, MAXC>(NSK_LEP_FORWARD); }
+// the same at four waves per SIMD (the eight-candidate instantiation: see NSK_EP_WPE_L above)
+template <typename VT, bool SMALLW, int MAXC>
+__global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_L void k_learn_ep_w4(NSK_LEP_PARAMS) { learn_ep_body<VT, SMALLW, MAXC>(NSK_LEP_FORWARD); }
+#undef NSK_LEP_PARAMS
+#undef NSK_LEP_FORWARD
 
 
 static __global__ __launch_bounds__(NSK_BLOCK) void k_apply_weights(double *w, const double *w_in, long long *G, uint32_t *K,

@@ -211,14 +211,14 @@ int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay
                 const int rblocks = std::max(0, 8 * ((std::min(2560, (nrest_here + 3) / 4) + 7) / 8) - gblocks);
                 const int grid = gblocks + rblocks + hbl_ep;
                 hipStream_t st = general_aside ? cs.side(0) : g->stream;
-#define NSK_LEP(MAXC) k_learn_ep<VT, SMALLW, MAXC><<<dim3(grid), dim3(NSK_BLOCK), shmem, st>>>( \
+#define NSK_LEP(KERNEL, MAXC) KERNEL<VT, SMALLW, MAXC><<<dim3(grid), dim3(NSK_BLOCK), shmem, st>>>( \
                     d, fb, fe, (int)g->c.phase_wb_base[ph], gt0, ntiles - gt0, ngroups, (int)g->c.phase_ep_base[ph], gblocks, \
                     fe, he, hbl_ep, nbh, (int)g->c.phase_bighub_base[ph], lrest, rest_in_general ? nlrest : 0, lp)
                 // (a colour's all-binary groups -- its tail: categorical lanes come first -- in a launch of their own with the
                 // two-candidate kernel, 114 vector registers and four waves per SIMD instead of 152 and three: 50M LR graph
                 // 5.57 -> 5.73e9 updates/s, 5M 5.13 -> 4.17e9 with the split forced (two tails per class); inference, 86 / 5
                 // against 102 / 4: 1.540 / 1.540e10 -- tools/sessions/r5_s24.sh; not kept)
-                if (one_lg) NSK_LEP(8); else NSK_LEP(2);
+                if (one_lg) NSK_LEP(k_learn_ep_w4, 8); else NSK_LEP(k_learn_ep, 2);
 #undef NSK_LEP
                 g->launches++;
             }
