@@ -1428,14 +1428,22 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
                       int sample_evidence, int burnin, uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1
 #define NSK_EP_FORWARD g, pbegin, pend, wb_base, tile0, ntiles, ngroups, group0, gblocks, hb, he, hblocks, hub0, nbh, bh0, rest_list, nrest, \
                        sample_evidence, burnin, k0, k1, s0, s1
+#ifdef NSK_EP_WPE_I            // (diagnostic builds: waves per SIMD of the inference launches, tools/sessions/r5_s34.sh)
+#define NSK_EP_ATTR_I __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_I, NSK_EP_WPE_I)))
+#else
+#define NSK_EP_ATTR_I
+#endif
 template <typename VT, int MAXC>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_ep(NSK_EP_PARAMS) { gibbs_ep_body<VT, MAXC>(NSK_EP_FORWARD); }
+__global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_I void k_gibbs_ep(NSK_EP_PARAMS) { gibbs_ep_body<VT, MAXC>(NSK_EP_FORWARD); }
 // The same with the vector registers capped at 96 (5 waves per SIMD instead of the categorical kernel's 4): for
 // graphs whose value array stays in the L2s the gathers are L2 hits and a fifth wave hides more of their
 // latency (5M LR graph: 55.4 -> 51.2 us per class); beyond them it is slower (50M LR graph: 472 -> 485 us) --
 // the launch picks by the size of the value array.
 template <typename VT, int MAXC>
-__global__ __launch_bounds__(NSK_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_gibbs_ep_w5(NSK_EP_PARAMS) {
+#ifndef NSK_EP_WPE_I
+#define NSK_EP_WPE_I 5
+#endif
+__global__ __launch_bounds__(NSK_BLOCK) __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_I, NSK_EP_WPE_I))) void k_gibbs_ep_w5(NSK_EP_PARAMS) {
     gibbs_ep_body<VT, MAXC>(NSK_EP_FORWARD);
 }
 #undef NSK_EP_PARAMS
