@@ -1428,7 +1428,10 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
                       int sample_evidence, int burnin, uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1
 #define NSK_EP_FORWARD g, pbegin, pend, wb_base, tile0, ntiles, ngroups, group0, gblocks, hb, he, hblocks, hub0, nbh, bh0, rest_list, nrest, \
                        sample_evidence, burnin, k0, k1, s0, s1
-#ifdef NSK_EP_WPE_I            // (diagnostic builds: waves per SIMD of the inference launches, tools/sessions/r5_s34.sh)
+// (diagnostic builds: waves per SIMD of the inference launches.  Six -- 80 vector registers, 12-28 bytes of scratch --
+// against the five the kernels reach on their own: 5M LR 49.1 -> 50.7 us per class, weighted boolean graph 30.7 -> 32.1,
+// 50M LR 402 -> 444; tools/sessions/r5_s34.sh)
+#ifdef NSK_EP_WPE_I
 #define NSK_EP_ATTR_I __attribute__((amdgpu_waves_per_eu(NSK_EP_WPE_I, NSK_EP_WPE_I)))
 #else
 #define NSK_EP_ATTR_I
