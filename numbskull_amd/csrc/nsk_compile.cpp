@@ -1453,6 +1453,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
         shapes[k].clear();
         pshapes[k].clear();
     }
+    if (getenv("NSK_VERBOSE")) { int64_t ng = 0, nf = 0; for (int32_t k = 0; k < ncolors; k++) { ng += ngt_of[k]; nf += nfast_of[k]; } fprintf(stderr, "[nsk] after the classes: %lld general-tile variables, %lld classed\n", (long long)ng, (long long)nf); }
     lap("positions: classes");
     std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
     std::vector<std::vector<int64_t>> gen_bin_start;
@@ -2256,6 +2257,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
         // (parallel_for hands out ascending ranges: gw_v0 is ascending, threads that took no part keep nvar at its end)
     }
 
+    if (verbose) { int64_t n2 = 0, n1 = 0; for (int64_t v = 0; v < nvar; v++) { n2 += fast[v] == 2; n1 += fast[v] == 1; } fprintf(stderr, "[nsk] eligibility: %lld general-tile variables (entry lists kept), %lld fast\n", (long long)n2, (long long)n1); }
     lap("general eligibility");
     // ---- positions: colour-major.  Inside a colour: the fast variables grouped by "shape class"
     // -- the sequence of (function, member count, weight id) of their factor lists plus their
