@@ -147,8 +147,9 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                     const int nrest_all = (int)(g->c.phase_rest_base[ph + 1] - g->c.phase_rest_base[ph]);
                     rest_in_general = nrest_all > 0;
                     const int rblocks = (nrest_all + 3) / 4;
-                    // grid: 7 workgroups per CU, whole rounds of XCDs.  Only 4 (categorical kernel: 101 vector
-                    // registers) or 5 of them are resident; the others start as those end, which deals the
+                    // grid: 7 workgroups per CU, whole rounds of XCDs.  Five of them are resident (90 / 86 vector
+                    // registers since the wave index is a scalar; the categorical kernel had 101 and four until round 5); the
+                    // others start as those end, which deals the
                     // groups' uneven costs out dynamically -- per class on the 5M LR graph (NSK_EP_PER_CU):
                     // 3 workgroups per CU 68.4 us, 4 58.6, 5 65.6, 6 66.8, 7 58.3
                     const bool cat8 = g->c.phase_gen_bin_tile[ph] > gt0;

@@ -1438,7 +1438,8 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
 #endif
 template <typename VT, int MAXC>
 __global__ __launch_bounds__(NSK_BLOCK) NSK_EP_ATTR_I void k_gibbs_ep(NSK_EP_PARAMS) { gibbs_ep_body<VT, MAXC>(NSK_EP_FORWARD); }
-// The same with the vector registers capped at 96 (5 waves per SIMD instead of the categorical kernel's 4): for
+// The same with the vector registers capped at 96 (5 waves per SIMD; the categorical kernel had 102 registers and 4
+// waves until the wave index became a scalar -- round 5: it now has 90 and the cap is a formality): for
 // graphs whose value array stays in the L2s the gathers are L2 hits and a fifth wave hides more of their
 // latency (5M LR graph: 55.4 -> 51.2 us per class); beyond them it is slower (50M LR graph: 472 -> 485 us) --
 // the launch picks by the size of the value array.

@@ -192,7 +192,7 @@ int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay
             lp.kstat = kstat_here ? 1 : 0;
             if (ep) {                   // entry-parallel groups: hubs, the general tiles and the rest tiles
                 const int ngroups = (int)(g->c.phase_ep_base[ph + 1] - g->c.phase_ep_base[ph]);
-                // grid: 10 workgroups per CU (3 or 4 are resident -- 153 / 111 vector registers --, the others
+                // grid: 10 workgroups per CU (4 are resident -- 128 with the cap of k_learn_ep_w4 / 114 vector registers; 153 / 111 and 3 or 4 until round 5 --, the others
                 // start as those end: dynamic dealing of uneven groups).  Per class (NSK_EP_PER_CU), 5M LR graph:
                 // 3 workgroups per CU 142.4 us, 4 149.2, 5 139.5, 6 135.4, 7 134.2, 8 132.9, 10 134.7, 16 135.6;
                 // 50M LR graph: 4 1362 us, 7 1247, 10 1189
