@@ -97,7 +97,7 @@ int nsk_state_download(nsk_graph *g, int64_t *var_value, int64_t *var_value_evid
  * always compiles to the same layout).  Learning sweeps: counter (id, stream, sweep index);
  * inference sweeps: ids q and q + 64 with equal q >> 7 share one block, counter
  * ((q >> 7) * 64 + (q & 63), 0, sweep index), words 0-1 / 2-3 (pair scheme), except inside segments with
- * draw tables, where four ids share two blocks (quad scheme, nsk_graph_get_generators).  The sweep index starts at `sweep0`
+ * draw tables, where four ids share two blocks (quad and wide schemes, nsk_graph_get_generators).  The sweep index starts at `sweep0`
  * and advances by one per sweep of any kind; its high half (counter word 3) is XORed with the
  * handle's shard tag (nsk_set_rng_tag; 0 for a handle that owns the whole graph).  Sequential scan seeds MT19937 like
  * np.random.seed(seed); random.seed(seed). */
@@ -176,6 +176,9 @@ typedef struct {
                                          the receive block, write into the readers' and raise the flags; no exchange
                                          kernels per sweep) -- a shard whose sampled variables all live in table
                                          segments and whose boundary values have one reader each; 0: exchange kernels */
+    int64_t tab_quads;                /* position quads (256 consecutive positions) of the segments with draw tables */
+    int64_t wide_quads;               /* ... of them the WIDE ones: one lane samples four consecutive positions from
+                                         dword loads (nsk_graph_get_generators bit 41)                              */
 } nsk_graph_info;
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info);
 int nsk_graph_get_colors(nsk_graph *g, int32_t *color /* nvar, -1 for ghosts */);
@@ -189,7 +192,11 @@ int nsk_graph_get_layout(nsk_graph *g, int32_t *iid, int64_t *nid);
  * draws come from the quad scheme -- positions inside segments with draw tables: ids q, q + 64, q + 128,
  * q + 192 with equal q >> 8 share two Philox blocks, counter ((q >> 8) * 64 + (q & 63), stream, sweep),
  * stream 2 word (q >> 6) & 3 = the draw's high word, stream 3 the same word its low word -- instead of
- * the pair scheme described at nsk_set_seed.  What a checker needs to reproduce the samples. */
+ * the pair scheme described at nsk_set_seed; bit 41 set instead when they come from the WIDE scheme -- positions
+ * inside wide quads (nsk_graph_info.wide_quads: 256 consecutive positions of a table segment whose members are
+ * consecutive positions too, so that one lane samples four of them from dword loads): ids 4 i .. 4 i + 3 with equal
+ * q >> 2 share the two blocks, counter ((q >> 8) * 64 + ((q >> 2) & 63), stream, sweep), word q & 3 of stream 2 / 3 =
+ * the draw's high / low word.  What a checker needs to reproduce the samples. */
 int nsk_graph_get_generators(nsk_graph *g, int64_t *gen);
 
 /* Weight slots: where the device table (NSK_BUF_WEIGHT) keeps each weight, slot[w] for the caller's id w

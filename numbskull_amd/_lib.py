@@ -51,7 +51,8 @@ class GraphInfo(C.Structure):
                 ("compile_seconds", C.c_double), ("learn_cap", C.c_double),
                 ("learn_clipped", C.c_int64), ("grad_shift", C.c_int64),
                 ("acc_copies", C.c_int64), ("learn_lag", C.c_int64), ("direct_weights", C.c_int64),
-                ("weight_slots", C.c_int64), ("layout_hash", C.c_int64), ("p2p_fused", C.c_int64)]
+                ("weight_slots", C.c_int64), ("layout_hash", C.c_int64), ("p2p_fused", C.c_int64),
+                ("tab_quads", C.c_int64), ("wide_quads", C.c_int64)]
 
 
 _lib = None

@@ -254,7 +254,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
             if (c.phase_end[k] > c.phase_fast_end[k]) generic_needed = true;
         if (generic_needed || nsk::diag_env("NSK_EAGER_GENERIC")) { rc = nsk_ensure_generic(g); if (rc) return rc; }
     }
-    UP(w_fixed); UP(logtab); UP(adj); UP(seg_aff); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
+    UP(w_fixed); UP(logtab); UP(adj); UP(seg_aff); UP(seg_wide); UP(wide_exc); UP(hub_desc); UP(hub_adj); UP(ep_desc); UP(ep_adj); UP(ep_wrow); UP(ep_kstat); UP(bighub_pos); UP(tiles); UP(tile_hdr); UP(dyn_tiles); UP(rest_tiles); UP(learn_rest_tiles); UP(tile_wrow);
 #undef UP
     // (value windows, -DNSK_EP_WIN builds only: no allocation otherwise -- the default build's sequence of device
     // allocations is round 4's, address for address)
@@ -706,7 +706,7 @@ static int64_t layout_hash(const Compiled &c) {
         hash_array(c.p_vid), hash_array(c.p_slot), hash_array(c.p_cnt), hash_array(c.p_info), hash_array(c.p_init),
         hash_array(c.slot_off), hash_array(c.fidx), hash_array(c.gstream), hash_array(c.gs_off), hash_array(c.f_rec),
         hash_array(c.m_rec), hash_array(c.iid), hash_array(c.w_init), hash_array(c.w_fixed), hash_array(c.w_direct),
-        hash_array(c.multi_wids), hash_array(c.wmap), hash_array(c.ghost_needs)};
+        hash_array(c.multi_wids), hash_array(c.wmap), hash_array(c.ghost_needs), hash_array(c.seg_wide), hash_array(c.wide_exc)};
     uint64_t h = 0x9e3779b97f4a7c15ull;
     for (uint64_t x : parts) { h = (h ^ x) * 0x100000001b3ull; h ^= h >> 31; }
     return (int64_t)(h >> 1);             // non-negative
@@ -736,6 +736,8 @@ static void fill_info(const Compiled &c, nsk_graph_info *info) {
     info->weight_slots = c.wmap.empty() ? 0 : 1;
     info->layout_hash = getenv("NSK_LAYOUT_HASH") ? layout_hash(c) : 0;
     info->p2p_fused = 0;
+    info->tab_quads = c.ntab_quads;
+    info->wide_quads = c.nwide_quads;
 }
 
 int nsk_graph_get_info(nsk_graph *g, nsk_graph_info *info) {
@@ -791,11 +793,19 @@ int nsk_graph_get_generators(nsk_graph *g, int64_t *gen) {
     const Compiled &c = g->c;
     std::vector<uint8_t> quad((size_t)c.npos, 0);
     for (const Compiled::Segment &sg : c.segments)
-        if (sg.ztab >= 0)
+        if (sg.ztab >= 0) {
             for (int64_t p = sg.pos0; p < sg.pos0 + (int64_t)sg.ntiles * 64 && p < c.npos; p++) quad[(size_t)p] = 1;
+            if (sg.wide < 0) continue;
+            const int stride = NSK_WIDE_STRIDE(sg.nslots > 4 ? 2 : 1);
+            const int64_t q0 = sg.pos0 >> 8, nq = ((sg.pos0 + 64 * (int64_t)sg.ntiles + 255) >> 8) - q0;
+            for (int64_t qi = 0; qi < nq; qi++)
+                if (c.seg_wide[(size_t)sg.wide + (size_t)qi * stride] != 0xFFFFFFFFu)
+                    for (int64_t p = (q0 + qi) << 8; p < ((q0 + qi + 1) << 8) && p < c.npos; p++) quad[(size_t)p] = 2;
+        }
     for (int64_t v = 0; v < c.nvar; v++) {
         const int64_t p = c.color[v] >= 0 ? (int64_t)c.iid[v] : -1;
-        gen[v] = p < 0 ? -1 : (p | ((p < c.npos && quad[(size_t)p]) ? (1ll << 40) : 0ll));
+        const int sch = (p >= 0 && p < c.npos) ? quad[(size_t)p] : 0;
+        gen[v] = p < 0 ? -1 : (p | (sch == 1 ? (1ll << 40) : sch == 2 ? (1ll << 41) : 0ll));
     }
     return NSK_OK;
 }

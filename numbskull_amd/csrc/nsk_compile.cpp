@@ -706,6 +706,122 @@ static int build_segment_adjacency(Compiled &c, std::string &err) {
     return NSK_OK;
 }
 
+// Wide quads of table segments (nsk_compile.h seg_wide): per quad the slot bases when one lane can take four
+// consecutive positions, plus the few positions whose member lies elsewhere (exceptions).
+static int build_segment_wide(Compiled &c, std::string &err) {
+    c.seg_wide.clear();
+    c.wide_exc.clear();
+    c.ntab_quads = c.nwide_quads = 0;
+    for (Compiled::Segment &sg : c.segments) sg.wide = -1;
+    if (c.vbytes != 1 || diag_env("NSK_NO_WIDE")) { c.seg_wide.assign(4, 0xFFFFFFFFu); c.wide_exc.assign(2, 0u); return NSK_OK; }
+    uint64_t ndw = 0;
+    for (Compiled::Segment &sg : c.segments) {
+        if (sg.ztab < 0) continue;
+        const int nch = sg.nslots > 4 ? 2 : 1;
+        const int64_t nq = ((sg.pos0 + 64 * (int64_t)sg.ntiles + 255) >> 8) - (sg.pos0 >> 8);
+        sg.wide = (int64_t)ndw;
+        ndw += (uint64_t)nq * NSK_WIDE_STRIDE(nch);
+        c.ntab_quads += nq;
+    }
+    if (ndw >= ((uint64_t)1 << 31)) { err = "wide-quad table too large"; return NSK_E_RANGE; }
+    c.seg_wide.assign((size_t)ndw + 4, 0xFFFFFFFFu);
+    const int T = compile_threads();
+    std::vector<std::vector<uint32_t>> exc_of((size_t)T);              // per thread: {descriptor dword, count, pairs ...}
+    std::vector<int64_t> nwide_of((size_t)T, 0);
+    for (const Compiled::Segment &sg : c.segments) {
+        if (sg.wide < 0) continue;
+        const int nch = sg.nslots > 4 ? 2 : 1, stride = NSK_WIDE_STRIDE(nch);
+        const int64_t q0 = sg.pos0 >> 8;
+        const int64_t nq = ((sg.pos0 + 64 * (int64_t)sg.ntiles + 255) >> 8) - q0;
+        parallel_for(nq, [&](int64_t qb0, int64_t qb1, int th) {
+            std::vector<uint32_t> &exo = exc_of[(size_t)th];
+            for (int64_t qi = qb0; qi < qb1; qi++) {
+                const int64_t P = (q0 + qi) << 8;                       // the quad's first position
+                if (P < sg.pos0 || P + 256 > sg.pos0 + 64 * (int64_t)sg.ntiles) continue;     // not wholly inside the segment
+                const int64_t t0 = (P - sg.pos0) >> 6;
+                // member id of slot j at offset o of the quad
+                auto member = [&](int64_t o, uint32_t j) -> int64_t {
+                    const uint64_t wbase = ((uint64_t)sg.adj_off + (uint64_t)(t0 + (o >> 6)) * 64 * nch) * 4;
+                    return (int64_t)c.adj[wbase + 256 * (j / 4) + (j % 4) + 4 * (uint64_t)(o & 63)];
+                };
+                int64_t first = -1, last = -1;
+                for (int64_t o = 0; o < 256; o++)
+                    if (c.p_vid[P + o] >= 0) { if (first < 0) first = o; last = o; }
+                if (first < 0) continue;
+                uint32_t base[8], smask = 0, nexc = 0, exc[2 * NSK_WIDE_MAXEXC];
+                bool ok = true;
+                for (uint32_t j = 0; j < sg.nslots && ok; j++) {
+                    // a slot that names the always-zero id in every lane is no member at all
+                    bool zero = true;
+                    for (int64_t o = first; o <= last && zero; o++)
+                        if (c.p_vid[P + o] >= 0 && member(o, j) != c.zero_id) zero = false;
+                    if (zero) { base[j] = 0xFFFFFFFFu; continue; }
+                    // the base most live positions agree on: the first's or the last's (an odd cell sits at a run's end)
+                    int64_t best = -1, best_miss = 1 << 30;
+                    const int64_t cand[3] = {member(first, j) - first, member(last, j) - last,
+                                             member((first + last) / 2, j) - (first + last) / 2};
+                    for (int k = 0; k < 3; k++) {
+                        const int64_t b = cand[k];
+                        if (b < 0 || b + 255 >= c.nid || (k > 0 && b == cand[0]) || (k > 1 && b == cand[1])) continue;
+                        int64_t miss = 0;
+                        for (int64_t o = first; o <= last && miss <= NSK_WIDE_MAXEXC; o++)
+                            if (c.p_vid[P + o] >= 0 && member(o, j) != b + o) miss++;
+                        if (miss < best_miss) { best_miss = miss; best = b; }
+                    }
+                    if (best < 0 || nexc + best_miss > NSK_WIDE_MAXEXC) {
+                        if (getenv("NSK_DEBUG_WIDE"))
+                            fprintf(stderr, "[nsk] quad at %lld (segment pos0 %lld): slot %u best %lld misses %lld (first %lld last %lld cand %lld %lld %lld)\n",
+                                    (long long)P, (long long)sg.pos0, j, (long long)best, (long long)best_miss, (long long)first, (long long)last,
+                                    (long long)cand[0], (long long)cand[1], (long long)cand[2]);
+                        if (getenv("NSK_DEBUG_WIDE")) {
+                            for (int64_t o = first; o <= last; o++)
+                                if (c.p_vid[P + o] >= 0 && member(o, j) != best + o) fprintf(stderr, " [o %lld vid %d member %lld]", (long long)o, c.p_vid[P + o], (long long)member(o, j));
+                            fprintf(stderr, "\n");
+                        }
+                        ok = false; break; }
+                    base[j] = (uint32_t)best;
+                    smask |= 1u << j;
+                    for (int64_t o = first; o <= last; o++)
+                        if (c.p_vid[P + o] >= 0 && member(o, j) != best + o) {
+                            exc[2 * nexc] = (uint32_t)o | (j << 8);
+                            exc[2 * nexc + 1] = (uint32_t)member(o, j);
+                            nexc++;
+                        }
+                }
+                if (!ok || smask == 0) continue;
+                uint32_t any = 0;
+                for (uint32_t j = 0; j < sg.nslots; j++) if ((smask >> j) & 1u) { any = base[j]; break; }
+                uint32_t *dq = &c.seg_wide[(size_t)sg.wide + (size_t)qi * stride];
+                for (uint32_t j = 0; j < (uint32_t)(4 * nch); j++) dq[j] = (j < sg.nslots && ((smask >> j) & 1u)) ? base[j] : any;
+                if (dq[0] == 0xFFFFFFFFu) { for (uint32_t j = 0; j < (uint32_t)(4 * nch); j++) dq[j] = 0xFFFFFFFFu; continue; }   // (cannot happen: ids < 2^31)
+                dq[4 * nch] = 0; dq[4 * nch + 1] = nexc; dq[4 * nch + 2] = smask; dq[4 * nch + 3] = 0;
+                nwide_of[(size_t)th]++;
+                if (nexc) {
+                    exo.push_back((uint32_t)(sg.wide + qi * stride));
+                    exo.push_back(nexc);
+                    exo.insert(exo.end(), exc, exc + 2 * nexc);
+                }
+            }
+        }, 16);
+        // the segment's exception lists: the threads hold ascending ranges of its quads, so thread order is quad
+        // order whatever the thread count
+        for (int th = 0; th < T; th++) {
+            std::vector<uint32_t> &exo = exc_of[(size_t)th];
+            for (size_t i = 0; i < exo.size();) {
+                const uint32_t dq = exo[i], n = exo[i + 1];
+                c.seg_wide[(size_t)dq + 4 * nch] = (uint32_t)(c.wide_exc.size() / 2);
+                c.wide_exc.insert(c.wide_exc.end(), exo.begin() + (long)i + 2, exo.begin() + (long)i + 2 + 2 * (long)n);
+                i += 2 + 2 * (size_t)n;
+            }
+            exo.clear();
+        }
+    }
+    c.nwide_quads = 0;
+    for (int th = 0; th < T; th++) c.nwide_quads += nwide_of[(size_t)th];
+    c.wide_exc.resize(c.wide_exc.size() + 2, 0u);
+    return NSK_OK;
+}
+
 // Hub streams: the long-list variables a whole wave (or workgroup) samples, laid out like the entry-parallel rows.
 // general_words(v, &out, hub, cap) is the compiler's per-variable entry list.
 template <typename WordsFn>
@@ -885,12 +1001,18 @@ static int plan_segments(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, 
             const int64_t p0 = c.phase_start[k] + 64 * b, p1 = std::min(p0 + 64, c.phase_fast_end[k]);
             full = true;                                       // padding lanes are masked in-kernel
             int ev = -999;
+            bool any = false;
             for (int64_t p = p0; p < p1; p++) {
                 if (c.p_vid[p] < 0) continue;
                 const int e2 = d->variable[c.p_vid[p]].isEvidence;
+                any = true;
                 if (ev == -999) ev = e2;
                 else if (e2 != ev) return -999;
             }
+            // (a tile of padding positions only -- run padding, place_variables -- goes with the tiles in front of it)
+            if (!any)
+                for (int64_t q = p0 - 1; q >= c.phase_start[k]; q--)
+                    if (c.p_vid[q] >= 0) return (int)d->variable[c.p_vid[q]].isEvidence;
             return ev;
         };
         int64_t b = 0;
@@ -1305,6 +1427,113 @@ static int build_index_and_census(const nsk_graph_desc *d, Compiled &c, int32_t 
     return NSK_OK;
 }
 
+// Affine runs of one exact class in a first layout (place_variables): the class holds `count` variables at positions
+// [start, start + count), id order, all with the same slot program.  B_j(r) = (position of member j of the r-th
+// variable) - r is constant along a run.  A position whose members disagree with the run's bases in some slot is an
+// EXCEPTION when its successors agree again (the end cell of a grid row: its neighbour lives in the border class), a
+// BREAK when they settle on other bases (the next grid row).  Out: the empty positions to put in front of ranks so
+// that every long run starts on a multiple of 256 (the class itself will start on one); false: nothing worth padding.
+static bool find_run_padding(const nsk_graph_desc *d, const Compiled &c, int64_t start, int64_t count,
+                             std::vector<std::pair<int64_t, int64_t>> &at, int64_t &total) {
+    at.clear();
+    total = 0;
+    // member slots of the class (its variables share one program: same factor functions and member counts)
+    int ns = 0;
+    {
+        const int64_t v = c.p_vid[start];
+        const nsk_vtf &vt = d->vmap[d->variable[v].vtf_offset];
+        for (int64_t j = 0; j < vt.factor_index_length; j++) {
+            const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
+            if (fa.factorFunction == -1) continue;
+            for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++) if (d->fmap[l].vid != v) ns++;
+        }
+    }
+    if (ns == 0 || ns > 8) return false;
+    // provisional ids: a sampled variable's position, the ghosts this handle reads behind them in id order
+    std::vector<int64_t> B((size_t)count * (size_t)ns);
+    const int64_t NONE = INT64_MIN / 2;
+    parallel_for(count, [&](int64_t rb0, int64_t rb1, int) {
+        for (int64_t r = rb0; r < rb1; r++) {
+            const int64_t v = c.p_vid[start + r];
+            const nsk_vtf &vt = d->vmap[d->variable[v].vtf_offset];
+            int s = 0;
+            for (int64_t j = 0; j < vt.factor_index_length && s <= ns; j++) {
+                const nsk_factor &fa = d->factor[d->factor_index[vt.factor_index_offset + j]];
+                if (fa.factorFunction == -1) continue;
+                for (int64_t l = fa.ftv_offset; l < fa.ftv_offset + fa.arity; l++) {
+                    const int64_t m = d->fmap[l].vid;
+                    if (m == v) continue;
+                    int64_t id = c.v_pos[m];
+                    if (id < 0) {
+                        const auto it = std::lower_bound(c.ghost_needs.begin(), c.ghost_needs.end(), (int32_t)m);
+                        id = (it != c.ghost_needs.end() && *it == m) ? c.npos + (it - c.ghost_needs.begin()) : NONE;
+                    }
+                    if (s < ns) B[(size_t)r * ns + s] = id == NONE ? NONE + r : id - r;     // (NONE + r: equal to nothing)
+                    s++;
+                }
+            }
+            for (; s < ns; s++) B[(size_t)r * ns + s] = NONE + r;
+        }
+    });
+    auto miss = [&](int64_t r, const int64_t *base) { int m = 0; for (int j = 0; j < ns; j++) m += B[(size_t)r * ns + j] != base[j]; return m; };
+    // per-slot mode over a short window ahead of r
+    auto settle = [&](int64_t r, int64_t *out) {
+        for (int j = 0; j < ns; j++) {
+            int64_t best = B[(size_t)r * ns + j];
+            int bestn = 0;
+            for (int64_t a = r; a < std::min(count, r + 5); a++) {
+                int n = 0;
+                for (int64_t b2 = r; b2 < std::min(count, r + 5); b2++) n += B[(size_t)b2 * ns + j] == B[(size_t)a * ns + j];
+                if (n > bestn) { bestn = n; best = B[(size_t)a * ns + j]; }
+            }
+            out[j] = best;
+        }
+    };
+    std::vector<int64_t> run_start;          // ranks
+    int64_t cur[8], nxt[8];
+    settle(0, cur);
+    run_start.push_back(0);
+    for (int64_t r = 1; r < count; r++) {
+        if (miss(r, cur) == 0) continue;
+        settle(r, nxt);
+        bool same = true;
+        for (int j = 0; j < ns; j++) same = same && nxt[j] == cur[j];
+        if (same) continue;                                           // an exception: its successors agree with the run
+        // a break: the new run starts at the first position that fits the new bases better than the old ones
+        int64_t rb = r;
+        while (rb < std::min(count, r + 4) && miss(rb, nxt) >= miss(rb, cur)) rb++;
+        if (rb >= std::min(count, r + 4)) rb = r;
+        if (rb > run_start.back()) run_start.push_back(rb);
+        for (int j = 0; j < ns; j++) cur[j] = nxt[j];
+        r = rb;
+    }
+    run_start.push_back(count);
+    // long runs start on multiples of 256 when that wastes little
+    int64_t posn = 0;                         // position relative to the class start (a multiple of 256)
+    int64_t padded = 0, covered = 0;
+    for (size_t i = 0; i + 1 < run_start.size(); i++) {
+        const int64_t len = run_start[i + 1] - run_start[i];
+        const int64_t waste = (256 - len % 256) % 256;
+        const bool good = len >= 384 && waste * 12 <= len;
+        if (good && posn % 256 != 0) {
+            const int64_t pad = 256 - posn % 256;
+            at.push_back({run_start[i], pad});
+            total += pad;
+            posn += pad;
+        }
+        if (good) { padded++; covered += len; }
+        posn += len;
+    }
+    if (getenv("NSK_DEBUG_WIDE")) {
+        fprintf(stderr, "[nsk] class at %lld (%lld variables, %d slots): %zu runs, %lld padded, %lld empty positions; runs start at", (long long)start,
+                (long long)count, ns, run_start.size() - 1, (long long)padded, (long long)total);
+        for (size_t i = 0; i + 1 < run_start.size() && i < 12; i++) fprintf(stderr, " %lld", (long long)run_start[i]);
+        fprintf(stderr, "\n");
+    }
+    if (padded == 0 || total * 10 > count || covered * 2 < count) { at.clear(); total = 0; return false; }
+    return true;
+}
+
 // Positions: colour-major.  Inside a colour the fast variables grouped by class -- exact program, exact shape, padded
 // shape (per id range) -- so that the 64 lanes of a tile share one slot program / word layout; every class with at
 // least 64 members starts on a tile boundary (the gap is padded with empty positions, p_vid = -1); smaller classes
@@ -1455,51 +1684,10 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     }
     if (getenv("NSK_VERBOSE")) { int64_t ng = 0, nf = 0; for (int32_t k = 0; k < ncolors; k++) { ng += ngt_of[k]; nf += nfast_of[k]; } fprintf(stderr, "[nsk] after the classes: %lld general-tile variables, %lld classed\n", (long long)ng, (long long)nf); }
     lap("positions: classes");
-    std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
-    std::vector<std::vector<int64_t>> gen_bin_start;
-    std::vector<std::map<uint64_t, int64_t>> start((size_t)ncolors), start2((size_t)ncolors), start3((size_t)ncolors);
-    int64_t pos = 0;
-    for (int32_t k = 0; k < ncolors; k++) {
-        pos = (pos + 127) / 128 * 128;      // tiles sit on multiples of 64, tile pairs on multiples of
-        c.phase_start[k] = pos;             // 128: a lane's position & 63 is its lane (generator ids)
-        int64_t nbig = 0;
-        for (int level = 0; level < 3; level++) {
-            if (level == 1) shape_at[k] = pos;
-            ClassMap &cm = level == 0 ? classes[k] : level == 1 ? shapes[k] : pshapes[k];
-            std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, key)
-            const int64_t need = level == 0 ? min_class[k] : 64;
-            for (auto &kv : cm)
-                if (kv.second.first >= need) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
-            std::sort(big.begin(), big.end());
-            for (auto &bc : big) {
-                (level == 0 ? start[k] : level == 1 ? start2[k] : start3[k])[bc.second] = pos;
-                pos += cm[bc.second].first;
-                pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
-            }
-            cm.clear();
-        }
-        tail_at[k] = pos;
-        shape_end[k] = pos;
-        pos += nfast_of[k] - nbig;
-        pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
-        gt_at[k] = pos;                                                     // general tiles
-        c.phase_gen_tile[k] = (pos - c.phase_start[k]) / 64;
-        pos += ngt_of[k];
-        pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
-        c.phase_fast_end[k] = pos;
-        next_gen[k] = pos;
-        pos += ngen_of[k];
-        c.phase_end[k] = pos;               // (the next colour starts at the next multiple of 128)
-    }
-    c.phase_start[ncolors] = pos;
-    c.npos = pos;
-    if (c.npos >= LIM - 1) { err = "too many positions"; return NSK_E_RANGE; }
-    c.p_vid.assign(c.npos, -1); c.p_info.assign(c.npos, 0); c.p_slot.assign(c.npos, 0);
-    c.p_cnt.assign(c.npos, 0); c.p_init.assign(c.npos, 0);
+    // ---- what does not depend on the positions: work bins of the generic-path variables, the general tiles' order ----
     // generic-path variables of a colour are ordered by the work of one update (factor-list
     // lengths x arities over all candidate values, binned) so that the 64 lanes of a wave finish
     // together; inside a bin: variable id.
-    lap("positions: arrays");
     std::vector<uint32_t> gw;
     std::vector<uint8_t> work_bin(nvar, 0);
     for (int64_t v = 0; v < nvar; v++) {
@@ -1525,10 +1713,141 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     if (!diag_env("NSK_NO_HEAVY"))
         for (int64_t v = 0; v < nvar; v++)
             if (c.color[v] >= 0 && !fast[v] && ngen_of[c.color[v]] <= NSK_FEW_GENERIC) work_bin[v] = 0;
+    std::vector<std::vector<int64_t>> bin_count((size_t)ncolors, std::vector<int64_t>(42, 0));
+    for (int64_t v = 0; v < nvar; v++)
+        if (c.color[v] >= 0 && !fast[v]) bin_count[c.color[v]][work_bin[v] + 1]++;
+    lap("positions: work bins");
+    // general-tile variables of a colour: sorted by (entries, most other members of an entry),
+    // largest first, and cut into tiles of 64 -- a tile's layout is the maximum over its lanes,
+    // so neighbours in this order waste the least padding (SELL-C-sigma)
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (key, vid)
+    std::vector<uint8_t> g_ne(nvar, 0), g_mo(nvar, 0);      // entries / widest entry of a general lane
+    parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
+        std::vector<uint32_t> w;
+        for (int64_t v = vb0; v < vb1; v++) {
+            if (c.color[v] < 0 || fast[v] != 2) continue;
+            general_words(v, &w);
+            int64_t ne = 0, mo = 0;
+            for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) {
+                ne++;
+                mo = std::max<int64_t>(mo, (w[j + 1] >> 4) & 7u);
+            }
+            g_ne[v] = (uint8_t)ne; g_mo[v] = (uint8_t)mo;
+        }
+    });
+    lap("positions: lane sizes");
+    // entry-parallel groups (nsk_compile.h ep_desc) serve a colour whose general variables all
+    // have entries of at most 3 other members and at most 16 entries (ordinal: 5 bits, LDS slots)
+    c.phase_ep.assign((size_t)ncolors, 0);
+    c.phase_ep_emax.assign((size_t)ncolors, 0);
+    if (!diag_env("NSK_NO_EP") && nw < ((int64_t)1 << 27)) {
+        for (int32_t k = 0; k < ncolors; k++) c.phase_ep[k] = ngt_of[k] > 0 ? 1 : 0;
+        for (int64_t v = 0; v < nvar; v++) {
+            if (c.color[v] < 0 || fast[v] != 2) continue;
+            if (g_mo[v] > 3 || g_ne[v] > 16) c.phase_ep[c.color[v]] = 0;
+            c.phase_ep_emax[c.color[v]] = std::max<int32_t>(c.phase_ep_emax[c.color[v]], g_ne[v]);
+        }
+    }
+    // key: categorical lanes first (their tiles form a launch of their own), then blocks
+    // of gen_block consecutive ids (sigma of SELL-C-sigma: each XCD walks a contiguous
+    // run of tiles, so its L2 then sees one slice of the value array instead of all of
+    // it), largest layouts first inside a block.  Entry-parallel groups carry no padding to the
+    // widest lane, so their colours are cut into small id blocks -- a group's member values then
+    // share cache lines --, with the variables of more than 8 entries (two LDS passes per group)
+    // in front of the others.  One colour per thread: collect its variables, sort them.
+    auto collect = [&](int32_t k) {
+        std::vector<std::pair<int64_t, int64_t>> &ord = order[(size_t)k];
+        ord.reserve((size_t)ngt_of[k]);
+        const bool epk = c.phase_ep[k] != 0;
+        const int64_t gb = epk ? ep_block : gen_block;
+        for (int64_t v = 0; v < nvar; v++) {
+            if (c.color[v] != k || fast[v] != 2) continue;
+            const int64_t ne = g_ne[v], mo = g_mo[v];
+            const int64_t catv = c.v_card[v] > 2 ? 0 : 1;
+            const int64_t small = (epk && ne <= 8) ? 1 : 0;
+            ord.push_back({(small << 51) | (catv << 50) | ((v / gb) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
+        }
+        std::sort(ord.begin(), ord.end());
+    };
     {
-        std::vector<std::vector<int64_t>> bin_count((size_t)ncolors, std::vector<int64_t>(42, 0));
-        for (int64_t v = 0; v < nvar; v++)
-            if (c.color[v] >= 0 && !fast[v]) bin_count[c.color[v]][work_bin[v] + 1]++;
+        std::vector<std::thread> sorters;             // (few colours only)
+        for (int32_t k = 0; k < ncolors; k++) {
+            if (ncolors <= 64 && compile_threads() > 1) sorters.emplace_back([&, k] { collect(k); });
+            else collect(k);
+        }
+        for (auto &t : sorters) t.join();
+    }
+    lap("positions: lane order");
+
+    // ---- positions.  Run padding (ClassPad): inside an exact class -- id order -- the members of consecutive variables
+    // are, on regular graphs, consecutive positions of another class (a grid row's neighbours are the rows above,
+    // below and beside it): an AFFINE RUN.  The table kernels take such positions four to a lane (nsk_compile.h
+    // seg_wide) when a run starts on a multiple of 256, so the positions are laid out twice when that pays: the
+    // first layout finds the runs (find_run_padding), the second starts every long run on a quad boundary, with
+    // empty positions (p_vid = -1) in front.
+    struct ClassPad { std::vector<std::pair<int64_t, int64_t>> at; int64_t total = 0; };     // (rank in the class, empty positions in front of it)
+    struct ClassAt { int32_t k; uint64_t key; int64_t start, count; };
+    struct Cursor { int64_t next, rank; size_t bi; const ClassPad *pad; };
+    std::vector<std::unordered_map<uint64_t, ClassPad>> pads((size_t)ncolors);
+    std::vector<ClassAt> exact_at;
+    auto lay = [&]() -> int {
+        std::vector<int64_t> next_gen((size_t)ncolors, 0), tail_at((size_t)ncolors, 0), gt_at((size_t)ncolors, 0);
+        std::vector<std::vector<int64_t>> gen_bin_start;
+        std::vector<std::unordered_map<uint64_t, Cursor>> start((size_t)ncolors);
+        std::vector<std::map<uint64_t, int64_t>> start2((size_t)ncolors), start3((size_t)ncolors);
+        exact_at.clear();
+        c.nsampled = 0;
+        int64_t pos = 0;
+        for (int32_t k = 0; k < ncolors; k++) {
+            pos = (pos + 127) / 128 * 128;      // tiles sit on multiples of 64, tile pairs on multiples of
+            if (!pads[k].empty()) pos = (pos + 255) / 256 * 256;
+            c.phase_start[k] = pos;             // 128: a lane's position & 63 is its lane (generator ids)
+            int64_t nbig = 0;
+            for (int level = 0; level < 3; level++) {
+                if (level == 1) shape_at[k] = pos;
+                ClassMap &cm = level == 0 ? classes[k] : level == 1 ? shapes[k] : pshapes[k];
+                std::vector<std::pair<int64_t, uint64_t>> big;        // (first vid, key)
+                const int64_t need = level == 0 ? min_class[k] : 64;
+                for (auto &kv : cm)
+                    if (kv.second.first >= need) { big.push_back({kv.second.second, kv.first}); nbig += kv.second.first; }
+                std::sort(big.begin(), big.end());
+                for (auto &bc : big) {
+                    const int64_t count = cm[bc.second].first;
+                    if (level == 0) {
+                        const auto pit = pads[k].find(bc.second);
+                        const ClassPad *pd = pit == pads[k].end() ? nullptr : &pit->second;
+                        if (pd) pos = (pos + 255) / 256 * 256;          // a padded class owns whole quads
+                        Cursor cu{pos, 0, 0, pd};
+                        if (pd && !pd->at.empty() && pd->at[0].first == 0) { cu.next += pd->at[0].second; cu.bi = 1; }
+                        start[k][bc.second] = cu;
+                        exact_at.push_back(ClassAt{k, bc.second, pos, count});
+                        pos += count + (pd ? pd->total : 0);
+                        if (pd) pos = (pos + 255) / 256 * 256;
+                    } else {
+                        (level == 1 ? start2[k] : start3[k])[bc.second] = pos;
+                        pos += count;
+                    }
+                    pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
+                }
+            }
+            tail_at[k] = pos;
+            shape_end[k] = pos;
+            pos += nfast_of[k] - nbig;
+            pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;   // tiles own all 64 positions
+            gt_at[k] = pos;                                                     // general tiles
+            c.phase_gen_tile[k] = (pos - c.phase_start[k]) / 64;
+            pos += ngt_of[k];
+            pos = c.phase_start[k] + (pos - c.phase_start[k] + 63) / 64 * 64;
+            c.phase_fast_end[k] = pos;
+            next_gen[k] = pos;
+            pos += ngen_of[k];
+            c.phase_end[k] = pos;               // (the next colour starts at the next multiple of 128)
+        }
+        c.phase_start[ncolors] = pos;
+        c.npos = pos;
+        if (c.npos >= LIM - 1) { err = "too many positions"; return NSK_E_RANGE; }
+        c.p_vid.assign(c.npos, -1); c.p_info.assign(c.npos, 0); c.p_slot.assign(c.npos, 0);
+        c.p_cnt.assign(c.npos, 0); c.p_init.assign(c.npos, 0);
         gen_bin_start.assign((size_t)ncolors, std::vector<int64_t>(42, 0));
         c.phase_heavy_end.assign((size_t)ncolors, 0);
         for (int32_t k = 0; k < ncolors; k++) {
@@ -1536,70 +1855,6 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
             for (int b = 0; b < 41; b++) gen_bin_start[k][b + 1] = gen_bin_start[k][b] + bin_count[k][b + 1];
             c.phase_heavy_end[k] = gen_bin_start[k][1];              // bin 0 = the hubs
         }
-    }
-    // general-tile variables of a colour: sorted by (entries, most other members of an entry),
-    // largest first, and cut into tiles of 64 -- a tile's layout is the maximum over its lanes,
-    // so neighbours in this order waste the least padding (SELL-C-sigma)
-    lap("positions: work bins");
-    {
-        std::vector<std::vector<std::pair<int64_t, int64_t>>> order((size_t)ncolors);   // (key, vid)
-        std::vector<uint8_t> g_ne(nvar, 0), g_mo(nvar, 0);      // entries / widest entry of a general lane
-        parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int) {
-            std::vector<uint32_t> w;
-            for (int64_t v = vb0; v < vb1; v++) {
-                if (c.color[v] < 0 || fast[v] != 2) continue;
-                general_words(v, &w);
-                int64_t ne = 0, mo = 0;
-                for (size_t j = 0; j < w.size(); j += 2 + ((w[j + 1] >> 4) & 7u)) {
-                    ne++;
-                    mo = std::max<int64_t>(mo, (w[j + 1] >> 4) & 7u);
-                }
-                g_ne[v] = (uint8_t)ne; g_mo[v] = (uint8_t)mo;
-            }
-        });
-        lap("positions: lane sizes");
-        // entry-parallel groups (nsk_compile.h ep_desc) serve a colour whose general variables all
-        // have entries of at most 3 other members and at most 16 entries (ordinal: 5 bits, LDS slots)
-        c.phase_ep.assign((size_t)ncolors, 0);
-        c.phase_ep_emax.assign((size_t)ncolors, 0);
-        if (!diag_env("NSK_NO_EP") && nw < ((int64_t)1 << 27)) {
-            for (int32_t k = 0; k < ncolors; k++) c.phase_ep[k] = ngt_of[k] > 0 ? 1 : 0;
-            for (int64_t v = 0; v < nvar; v++) {
-                if (c.color[v] < 0 || fast[v] != 2) continue;
-                if (g_mo[v] > 3 || g_ne[v] > 16) c.phase_ep[c.color[v]] = 0;
-                c.phase_ep_emax[c.color[v]] = std::max<int32_t>(c.phase_ep_emax[c.color[v]], g_ne[v]);
-            }
-        }
-        // key: categorical lanes first (their tiles form a launch of their own), then blocks
-        // of gen_block consecutive ids (sigma of SELL-C-sigma: each XCD walks a contiguous
-        // run of tiles, so its L2 then sees one slice of the value array instead of all of
-        // it), largest layouts first inside a block.  Entry-parallel groups carry no padding to the
-        // widest lane, so their colours are cut into small id blocks -- a group's member values then
-        // share cache lines --, with the variables of more than 8 entries (two LDS passes per group)
-        // in front of the others.  One colour per thread: collect its variables, sort them.
-        auto collect = [&](int32_t k) {
-            std::vector<std::pair<int64_t, int64_t>> &ord = order[(size_t)k];
-            ord.reserve((size_t)ngt_of[k]);
-            const bool epk = c.phase_ep[k] != 0;
-            const int64_t gb = epk ? ep_block : gen_block;
-            for (int64_t v = 0; v < nvar; v++) {
-                if (c.color[v] != k || fast[v] != 2) continue;
-                const int64_t ne = g_ne[v], mo = g_mo[v];
-                const int64_t catv = c.v_card[v] > 2 ? 0 : 1;
-                const int64_t small = (epk && ne <= 8) ? 1 : 0;
-                ord.push_back({(small << 51) | (catv << 50) | ((v / gb) << 20) | (0xFFFFF - (ne * 8 + mo)), v});
-            }
-            std::sort(ord.begin(), ord.end());
-        };
-        {
-            std::vector<std::thread> sorters;             // (few colours only)
-            for (int32_t k = 0; k < ncolors; k++) {
-                if (ncolors <= 64 && compile_threads() > 1) sorters.emplace_back([&, k] { collect(k); });
-                else collect(k);
-            }
-            for (auto &t : sorters) t.join();
-        }
-        lap("positions: lane order");
         for (int32_t k = 0; k < ncolors; k++) {
             for (auto &o : order[k]) {
                 const int64_t p = gt_at[k]++;
@@ -1608,27 +1863,48 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
                 c.nsampled++;
             }
         }
-    }
-    for (int64_t v = 0; v < nvar; v++) {
-        const int32_t k = c.color[v];
-        if (k < 0 || fast[v] == 2) continue;
-        int64_t p;
-        if (!fast[v]) p = gen_bin_start[k][work_bin[v]]++;
-        else {
-            auto it = start[k].find(sig[v]);
-            if (it != start[k].end()) p = it->second++;
+        for (int64_t v = 0; v < nvar; v++) {
+            const int32_t k = c.color[v];
+            if (k < 0 || fast[v] == 2) continue;
+            int64_t p;
+            if (!fast[v]) p = gen_bin_start[k][work_bin[v]]++;
             else {
-                auto it2 = shp[v] ? start2[k].find(shp[v]) : start2[k].end();
-                if (it2 != start2[k].end()) p = it2->second++;
-                else {
-                    auto it3 = pshp[v] ? start3[k].find(pshp[v]) : start3[k].end();
-                    p = (it3 != start3[k].end()) ? it3->second++ : tail_at[k]++;
+                auto it = start[k].find(sig[v]);
+                if (it != start[k].end()) {
+                    Cursor &cu = it->second;
+                    p = cu.next++;
+                    cu.rank++;
+                    if (cu.pad && cu.bi < cu.pad->at.size() && cu.pad->at[cu.bi].first == cu.rank) cu.next += cu.pad->at[cu.bi++].second;
+                } else {
+                    auto it2 = shp[v] ? start2[k].find(shp[v]) : start2[k].end();
+                    if (it2 != start2[k].end()) p = it2->second++;
+                    else {
+                        auto it3 = pshp[v] ? start3[k].find(pshp[v]) : start3[k].end();
+                        p = (it3 != start3[k].end()) ? it3->second++ : tail_at[k]++;
+                    }
                 }
             }
+            c.p_vid[p] = (int32_t)v;
+            c.v_pos[v] = (int32_t)p;
+            c.nsampled++;
         }
-        c.p_vid[p] = (int32_t)v;
-        c.v_pos[v] = (int32_t)p;
-        c.nsampled++;
+        return NSK_OK;
+    };
+    if (int rc = lay()) return rc;
+    lap("positions: arrays");
+    if (c.vbytes == 1 && !diag_env("NSK_NO_WIDE") && !diag_env("NSK_NO_RUN_PAD")) {
+        // the runs of the big exact classes in the layout just made
+        bool any = false;
+        for (const ClassAt &ca : exact_at) {
+            if (ca.count < 1024) continue;
+            ClassPad pd;
+            if (find_run_padding(d, c, ca.start, ca.count, pd.at, pd.total)) { pads[(size_t)ca.k][ca.key] = std::move(pd); any = true; }
+        }
+        lap("positions: runs");
+        if (any) {
+            if (int rc = lay()) return rc;
+            lap("positions: padded arrays");
+        }
     }
     return NSK_OK;
 }
@@ -1655,6 +1931,7 @@ static int shape_tiles(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, in
     struct TileShape {
         uint8_t cls;            // 0 per-lane headers, 1 general, 2 uniform, 3 shape
         uint8_t nkey;
+        uint8_t empty;          // no variable at all (run padding, place_variables): takes the shape of the tile in front
         int32_t len;            // words per lane before rounding to chunks
         uint32_t flags;         // td[3]
         uint32_t nrows;         // materialised weight rows the tile needs
@@ -1740,7 +2017,7 @@ static int shape_tiles(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, in
                 }
                 have0 = true;
             }
-            if (!have0) { hdrs0.clear(); uniform = false; same_shape = false; }
+            if (!have0) { hdrs0.clear(); uniform = false; same_shape = false; ts.empty = 1; }
             // (the last tile of a shape class, left with one or two lanes, is no uniform tile: a segment
             //  launch of its own per such tile costs more than the shape walk of its lanes)
             if (p0 >= shape_at[k] && p0 < shape_end[k] && same_shape) uniform = false;
@@ -1795,6 +2072,13 @@ static int shape_tiles(const nsk_graph_desc *d, Compiled &c, int32_t ncolors, in
             }
         }
     }, 64);
+    // a tile of padding positions only (in front of a run that starts on a quad boundary) continues the uniform tiles
+    // in front of it: the segment stays one segment, its lanes sample into their own never-read positions
+    for (int64_t t = 1; t < nwb; t++)
+        if (shapes_of[t].empty && tile_colour[t - 1] == tile_colour[t] && shapes_of[t - 1].cls == 2) {
+            shapes_of[t] = shapes_of[t - 1];
+            shapes_of[t].empty = 1;
+        }
     std::map<std::vector<uint32_t>, uint32_t> hdr_pool;
     std::vector<uint32_t> words, prog;
     total4 = 0;                      // stream size in 16-byte units
@@ -2348,6 +2632,7 @@ int compile_graph(const nsk_graph_desc *d, Compiled &c, std::string &err) {
     if (int erc = build_ep_groups(d, c, ncolors, general_words, lap, verbose, err)) return erc;
     lap("entry-parallel groups");
     if (int arc = build_segment_adjacency(c, err)) return arc;
+    if (int wrc = build_segment_wide(c, err)) return wrc;
     if (int hrc = build_hub_streams(d, c, ncolors, general_words, no_general, verbose, err)) return hrc;
     lap("compact streams");
     plan_learning_launches(c, ncolors);

@@ -14,6 +14,8 @@
 #include "../../include/numbskull_amd.h"
 
 #define NSK_LEARN_SEG_LAUNCHES 4       // segment launches of the learning sweep per colour class
+#define NSK_WIDE_STRIDE(nch) (4 * (nch) + 4)   // dwords of a quad descriptor in seg_wide
+#define NSK_WIDE_MAXEXC 8          // exceptions a wide quad may carry
 #define NSK_GEN_NULL 0x7FFFFFFu     // member id of an empty slot in a general tile (kind 6)
 // (value windows of the entry-parallel groups: measured and NOT kept -- compiled in only with -DNSK_EP_WIN, see ep_win below)
 #define NSK_EP_WIN_CHUNKS 512       // 16-byte chunks of a group's value window (8 KB per chain in LDS)
@@ -104,7 +106,8 @@ struct Compiled {
     // segment (rest_tiles, per phase) go through the descriptor-driven kernel.
     struct Segment { int32_t phase; int64_t pos0; int32_t ntiles; uint32_t adj_off, prog, nslots, kind; int32_t ev;
                      int64_t ztab;         // first entry of the program's draw table, -1 = none
-                     int64_t aff; };       // first entry of the segment's tiles in seg_aff (-1: none)
+                     int64_t aff;          // first entry of the segment's tiles in seg_aff (-1: none)
+                     int64_t wide = -1; }; // first dword of the segment's quad descriptors in seg_wide (-1: none)
     std::vector<Segment> segments;
     // Implicit adjacency of table segments: a tile whose every member slot holds position
     // (base of the slot) + lane -- the interior of a grid, where a class's neighbours are runs of the
@@ -112,6 +115,20 @@ struct Compiled {
     // (x = 0xFFFFFFFF: the tile is not of that form and reads its stream).  The member gathers of such
     // a tile are contiguous 64-byte reads.
     std::vector<uint32_t> seg_aff;
+    // Wide quads of table segments (int8 values).  A QUAD = the four tiles at positions 256 m .. 256 m + 255.  When
+    // all four belong to one segment and every member slot j of (almost) every position 256 m + o holds id
+    // base_j + o, ONE lane can take four consecutive positions: lane l loads the dword at base_j + 4 l per slot
+    // (four neighbour bytes at once, 256 bytes per wave-instruction instead of 64), packs four neighbourhoods with
+    // three shifts, and stores four new values / four tally bytes as dwords.  seg_wide holds per quad of the segment
+    // (quad i of a segment = absolute quad (pos0 >> 8) + i; NSK_WIDE_STRIDE(nch) dwords each):
+    //   [0 .. 4 nch) slot bases (word 0 = 0xFFFFFFFF: not a wide quad -- it is sampled tile by tile),
+    //   [4 nch] first exception in wide_exc, [4 nch + 1] number of exceptions, [4 nch + 2] mask of the real member
+    //   slots (a slot beyond the program's, or one that names the always-zero id, repeats base 0 and is masked out).
+    // wide_exc: pairs {offset in the quad | slot << 8, true member id} -- the few positions whose member is NOT at
+    // base + offset (the end cell of a grid row, whose neighbour lives in the border class); the owning lane
+    // patches that one bit after the wide loads.  A wide quad draws from the WIDE generator scheme (nsk_device.h).
+    std::vector<uint32_t> seg_wide, wide_exc;
+    int64_t ntab_quads = 0, nwide_quads = 0;    // quads of table segments / the wide ones among them
     // Draw tables (DESIGN.md "draw tables"): a uniform program whose lanes read binary members only
     // has 2^nslots possible neighbourhoods; per neighbourhood the draw threshold and the per-slot
     // satisfied bits are tabulated by k_refresh_ztab whenever weights change.

@@ -134,6 +134,26 @@ __device__ __forceinline__ uint2 inf_words_quad(uint32_t k0, uint32_t k1, uint32
     return uint2{word_of(a, j), word_of(b, j)};
 }
 
+// Positions inside WIDE quads (nsk_compile.h seg_wide: one lane samples four consecutive positions) use the same
+// two blocks per lane and quad, dealt the other way round (the WIDE scheme): ids 4 i .. 4 i + 3 with equal q >> 2
+// share them -- counter ((q >> 8) * 64 + ((q >> 2) & 63), stream, sweep), stream 2 word q & 3 the high word, stream
+// 3 the same word the low word.  A lane of the wide path then holds its four draws in its own block.
+__device__ __forceinline__ uint32_t wide_block(uint32_t q) { return ((q >> 8) << 6) | ((q >> 2) & 63u); }
+__device__ __forceinline__ uint2 inf_words_wide(uint32_t k0, uint32_t k1, uint32_t q, uint32_t s0, uint32_t s1) {
+    const u32x4 a = philox4x32(k0, k1, wide_block(q), 2u, s0, s1);
+    const u32x4 b = philox4x32(k0, k1, wide_block(q), 3u, s0, s1);
+    return uint2{word_of(a, q & 3u), word_of(b, q & 3u)};
+}
+// ... and a wave that samples such a quad tile by tile (lane l of tile k = offset 64 k + l of the quad) finds the word
+// of its position in the block lane 16 k + (l >> 2) computed -- `r` = this lane's block of the quad, (q >> 8, lane)
+__device__ __forceinline__ uint32_t wide_word_of_tile(const u32x4 &r, uint32_t k, uint32_t lane) {
+    const int src = (int)((16u * k + (lane >> 2)) << 2);
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r.x), w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r.y);
+    const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r.z), w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r.w);
+    const uint32_t j = lane & 3u;
+    return j == 0u ? w0 : (j == 1u ? w1 : (j == 2u ? w2 : w3));
+}
+
 // 53-bit uniform in [0,1) from two 32-bit words: the genrand_res53 construction that
 // np.random.rand() / random.random() use (inference.py:50, learning.py:90)
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
@@ -253,6 +273,8 @@ struct DevGraph {
     const uint32_t *hub_adj;    //  entries == 0: generic hub walk.  Rows of 64 words, one entry per lane
     uint8_t *sink;              // 1 KiB scratch: where padding lanes store (branch-free epilogues)
     const uint4 *seg_aff;       // implicit adjacency of table segments: slot bases per tile (nsk_compile.h)
+    const uint32_t *seg_wide;   // wide quads of table segments: slot bases per quad + exceptions (nsk_compile.h)
+    const uint2 *wide_exc;
     const uint4 *ztab;          // draw tables of the uniform programs whose members are all binary:
                                 //  entry (program, neighbourhood bits) = {K >> 26, K & (2^26 - 1), sat0 | sat1 << 8, 0}
                                 //  (k_refresh_ztab; DESIGN.md "draw tables")

@@ -51,6 +51,9 @@ void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
                 auto flush = [&]() {
                     if (tab.n == 0) return;
                     for (int i = tab.n; i < NSK_SEG_MAX; i++) tab.e[i].tile_start = tab.ntiles;
+                    // the wide-quad kernel takes the launch when at least half of its quads are wide ones (it samples
+                    // the others one tile at a time)
+                    tab.wide = (kind >= 8 && 8 * tab.wide >= tab.ntiles && !nsk::diag_env("NSK_NO_WIDE_KERNEL")) ? 1 : 0;
                     seg_plans[ph].push_back(SegPlan{kind, nch, tab});
                     memset(&tab, 0, sizeof(tab));
                 };
@@ -104,6 +107,20 @@ void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
                     en.zmask_ev = ((1u << sg.nslots) - 1u) | (((uint32_t)sg.ev & 0xFFu) << 8) | (sg.ztab >= 0 ? 1u << 16 : 0u);
                     en.aff_off = (kind >= 8 && sg.aff >= 0) ? (uint32_t)sg.aff + (uint32_t)rn.t0 * (uint32_t)nch : NSK_NO_STREAM;
                     en.push_off = rn.push_off;
+                    // quad descriptors (nsk_compile.h seg_wide) from the quad of the run's first position on; NCH of the
+                    // descriptors = the segment's own chunk count = this launch's
+                    en.wide_off = (sg.ztab >= 0 && sg.wide >= 0)
+                        ? (uint32_t)(sg.wide + ((pos0 >> 8) - (sg.pos0 >> 8)) * NSK_WIDE_STRIDE(nch)) : NSK_NO_STREAM;
+                    if (en.wide_off != NSK_NO_STREAM) {      // the wide quads the run touches; those it holds whole (SegTable.wide, flush)
+                        const int stride = NSK_WIDE_STRIDE(nch);
+                        int touched = 0;
+                        for (int64_t P = pos0 & ~(int64_t)255; P < pos0 + 64 * (int64_t)rn.nt; P += 256)
+                            if (g->c.seg_wide[(size_t)sg.wide + (size_t)((P >> 8) - (sg.pos0 >> 8)) * stride] != 0xFFFFFFFFu) {
+                                touched++;
+                                if (kind >= 8 && P >= pos0 && P + 256 <= pos0 + 64 * (int64_t)rn.nt) tab.wide++;
+                            }
+                        if (!touched) en.wide_off = NSK_NO_STREAM;       // (none: the kernels need not look)
+                    }
                     tab.ntiles += vtiles;
                     if (++tab.n == NSK_SEG_MAX) flush();
                 }
@@ -237,6 +254,12 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 if (nch == 1) k_gibbs_seg_tab_p2p<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, px);
                                 else k_gibbs_seg_tab_p2p<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u, px);
                             }
+                            else if (sizeof(VT) == 1 && tab.wide) {          // (mostly) wide quads: four positions to a lane
+                                const DevGraph<signed char> dw = view<signed char>(g);
+                                const int nbw = nsk_tabw_grid(tab.ntiles);
+                                if (nch == 1) k_gibbs_seg_tabw<1><<<dim3(nbw), block, 0, g->stream>>>(dw, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
+                                else k_gibbs_seg_tabw<2><<<dim3(nbw), block, 0, g->stream>>>(dw, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
+                            }
                             else if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
                             else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
                         }
@@ -323,6 +346,14 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
                     else
                         k_gibbs_seg_tab_p2p<VT, 2><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
                                                                                                  g->d_counters, (uint32_t)i, px);
+                }
+                else if (sizeof(VT) == 1 && pl.tab.wide) {
+                    const DevGraph<signed char> dw = view<signed char>(g);
+                    const int nbw = nsk_tabw_grid(pl.tab.ntiles);
+                    if (pl.nch == 1)
+                        k_gibbs_seg_tabw<1><<<dim3(nbw), dim3(NSK_BLOCK), 0, g->stream>>>(dw, pl.tab, burnin, 0u, 0u, 0u, 0u, g->d_counters, (uint32_t)i);
+                    else
+                        k_gibbs_seg_tabw<2><<<dim3(nbw), dim3(NSK_BLOCK), 0, g->stream>>>(dw, pl.tab, burnin, 0u, 0u, 0u, 0u, g->d_counters, (uint32_t)i);
                 }
                 else if (pl.nch == 1)
                     k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,

@@ -70,6 +70,7 @@ struct nsk_graph {
     uint32_t *tile_wrow = nullptr;
     uint4 *ztab = nullptr;              // draw tables (k_refresh_ztab)
     uint32_t *seg_aff = nullptr;        // implicit adjacency of table segments
+    uint32_t *seg_wide = nullptr, *wide_exc = nullptr;   // wide quads of table segments (nsk_compile.h)
     uint8_t *sink = nullptr;            // scratch line for padding lanes' stores
     uint32_t *hub_desc = nullptr, *hub_adj = nullptr;   // entry-parallel hub streams
     uint32_t *ep_desc = nullptr, *ep_adj = nullptr;     // entry-parallel groups of general tiles
@@ -201,6 +202,7 @@ static nsk::DevGraph<VT> view(nsk_graph *g) {
     d.ep_win = g->c.ep_win.empty() ? nullptr : g->ep_win; d.ep_win_off = g->ep_win_off;
     d.ep_kstat = g->c.ep_kstat.empty() ? nullptr : g->ep_kstat;
     d.seg_aff = (const uint4 *)g->seg_aff;
+    d.seg_wide = g->seg_wide; d.wide_exc = (const uint2 *)g->wide_exc;
     d.w_direct = g->c.ndirect > 0 ? g->w_direct : nullptr;
     d.upd_step = 0.0; d.upd_reg_param = 0.0; d.upd_truncation = 1.0; d.upd_cap = 0.0; d.upd_regularization = 0; d.upd_a1 = 1.0;
     d.upd_clipped = g->clip_count;
@@ -266,6 +268,18 @@ static inline int nsk_tab_grid(int vtiles) {
     const char *cap_env = nsk::diag_env("NSK_TAB_GRID_CAP");                // (diagnostic)
     const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : (need <= 2048 ? 2048 : 1536);
     return std::min(cap, need);        // (a launch that needs fewer blocks than 2048 runs in pairs: one trip per wave)
+}
+// Grid of a wide-quad table launch (k_gibbs_seg_tabw) over `vtiles` virtual tiles: a wave per quad while that fits the
+// resident grid (NSK_TABW_PER_CU blocks per CU), else the resident grid, whole rounds of XCDs
+#ifndef NSK_TABW_PER_CU
+#define NSK_TABW_PER_CU 6
+#endif
+static inline int nsk_tabw_grid(int vtiles) {
+    const int nquads = vtiles / 4;
+    const int need = std::max(8, 8 * ((((nquads + 3) / 4) + 7) / 8));
+    const char *cap_env = nsk::diag_env("NSK_TABW_GRID_CAP");               // (diagnostic)
+    const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : 256 * NSK_TABW_PER_CU;
+    return std::min(cap, need);
 }
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {
     const int ntiles = sl.tile_start[sl.n];

@@ -1472,10 +1472,13 @@ struct SegEntry {                         // 48 bytes: two scalar loads per tile
     uint32_t aff_off;                     // first entry of the segment's tiles in seg_aff, NSK_NO_STREAM: none
     uint32_t push_off;                    // fused boundary exchange (TabP2P): first row of the segment's tiles in the
                                           //   push map, NSK_NO_STREAM: no tile of the segment touches the boundary
-    uint32_t pad_[3];
+    uint32_t wide_off;                    // table launches: first dword of the quad descriptors (seg_wide) from the quad of
+                                          //   pos0 on, NSK_NO_STREAM: none (int32 values, NSK_NO_WIDE)
+    uint32_t pad_[2];
 };
 struct SegTable {
     int n, ntiles;                        // segments, tiles of the launch; e[i].tile_start = ntiles for i >= n
+    int wide, pad_;                       // table launches: some segment has quad descriptors (SegEntry.wide_off)
     SegEntry e[NSK_SEG_MAX];
 };
 
@@ -1681,7 +1684,7 @@ __host__ __device__ inline size_t nsk_p2p_recv_off_(int world) { return ((size_t
 template <typename VT, int NCH, int NT>
 __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry &en, int t0, int w0, int lane, int burnin,
                                           const u32x4 &ra, u32x4 &rb, bool &have_b, uint32_t qb,
-                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1, bool ws) {
     const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
     const bool haff = en.aff_off != NSK_NO_STREAM;                      // implicit adjacency (nsk_compile.h seg_aff)
     const uint32_t zoff = en.zoff, zmask = en.zmask_ev & 0xFFu;
@@ -1742,17 +1745,21 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     uint32_t hi[NT];
     int nv[NT];
     bool tie = false;
+    // (ws, wave-uniform: the quad is a WIDE one -- nsk_compile.h seg_wide -- that this launch samples tile by tile, a
+    // shard's run boundary cuts it: its positions keep the wide generator scheme, nsk_device.h wide_word_of_tile)
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        hi[k] = word_of(ra, (uint32_t)(w0 + k)) >> 5;
+        hi[k] = (ws ? wide_word_of_tile(ra, (uint32_t)(w0 + k), (uint32_t)lane) : word_of(ra, (uint32_t)(w0 + k))) >> 5;
         nv[k] = hi[k] > e[k].x ? 1 : 0;
         tie = tie || hi[k] == e[k].x;
     }
     if (__builtin_expect(__any(tie), 0)) {
         if (!have_b) { rb = philox4x32(k0, k1, qb, 3u, s0, s1); have_b = true; }
 #pragma unroll
-        for (int k = 0; k < NT; k++)
-            if (hi[k] == e[k].x) nv[k] = (word_of(rb, (uint32_t)(w0 + k)) >> 6) > e[k].y ? 1 : 0;
+        for (int k = 0; k < NT; k++) {
+            const uint32_t lo = (ws ? wide_word_of_tile(rb, (uint32_t)(w0 + k), (uint32_t)lane) : word_of(rb, (uint32_t)(w0 + k))) >> 6;
+            if (hi[k] == e[k].x) nv[k] = lo > e[k].y ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -1764,6 +1771,82 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
         }
     }
 }
+
+// ---- wide quads (nsk_compile.h seg_wide; int8 values): one lane samples FOUR consecutive positions ----
+// Lane l of the wave takes positions p0 + 4 l .. p0 + 4 l + 3 of the quad at p0 (a multiple of 256).  Per member slot
+// ONE dword load at (base of the slot) + 4 l brings the four neighbour bytes (256 contiguous bytes per wave-instruction:
+// a quarter of the memory instructions of the tile-by-tile body, each four times as wide); the four neighbourhoods are
+// packed by the same three shift-ors that used to pack one (SIMD within a register: a value is its bit); the four
+// thresholds come from the block's copy of the draw table in LDS (their top 27 bits: what decides all but 2^-27 of the
+// draws); the four new values and the four tally bytes leave as one dword each.  The lane's four draws are the four
+// words of its own Philox block (the WIDE generator scheme, nsk_device.h wide_block).  A position whose member is not
+// at base + offset -- the end cell of a grid row -- is patched from the quad's exception list by its lane.
+typedef uint32_t nsk_u32_una __attribute__((aligned(1)));
+#define NSK_ZT_BITS(NCH) (4 * (NCH))                  // log2 of the LDS table entries kept per segment of a launch
+template <int NCH>
+__device__ __forceinline__ void tab_quad_wide(const DevGraph<signed char> &g, const SegEntry &en, int p0,
+                                              const uint32_t (&wd)[NSK_WIDE_STRIDE(NCH)], const uint32_t *zt, int lane, int burnin,
+                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+    uint32_t base[4 * NCH];
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) base[j] = wd[j];
+    const uint32_t exc0 = wd[4 * NCH], nexc = wd[4 * NCH + 1], smask = wd[4 * NCH + 2];
+    const char *vb = (const char *)g.val + 4 * lane;
+    uint32_t x[4 * NCH];
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) x[j] = *(const nsk_u32_una *)(vb + base[j]);
+    uint32_t tally = 0;
+    if (!burnin) tally = *(const uint32_t *)(g.cnt_pos + p0 + 4 * lane);
+    // (the block is evaluated while the loads are in flight: without the fences the scheduler puts it behind the waits)
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t blk = (uint32_t)(p0 >> 2) + (uint32_t)lane;              // wide_block: ((p0 >> 8) << 6) | lane
+    const u32x4 ra = philox4x32(k0, k1, blk, 2u, s0, s1);
+    asm volatile("" :: "v"(ra.x), "v"(ra.y), "v"(ra.z), "v"(ra.w));       // (the words exist HERE: the optimiser sinks them to their uses otherwise)
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t idx4 = 0;
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) idx4 |= (x[j] & 0x01010101u) << j;    // (a member's value is its bit; what a lane reads for a
+    idx4 &= smask * 0x01010101u;                                            //  position that is an exception may be any value: masked)
+    for (uint32_t e = 0; e < nexc; e++) {                                   // scalar loop, rare: the odd cells of the quad
+        const NSK_SCALAR uint32_t *xp = (const NSK_SCALAR uint32_t *)g.wide_exc + 2 * (size_t)(exc0 + e);
+        const uint32_t ex = xp[0], eid = xp[1];
+        const uint32_t o = ex & 0xFFu, sh = 8u * (o & 3u) + ((ex >> 8) & 7u);
+        if ((uint32_t)lane == (o >> 2)) idx4 = (idx4 & ~(1u << sh)) | ((uint32_t)(uint8_t)g.val[eid] << sh);
+    }
+    uint32_t thr[4], hi[4], out = 0;
+    bool tie = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) thr[i] = zt[(idx4 >> (8 * i)) & 0xFFu];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        hi[i] = word_of(ra, (uint32_t)i) >> 5;
+        out |= (hi[i] > thr[i] ? 1u : 0u) << (8 * i);
+        tie = tie || hi[i] == thr[i];
+    }
+    if (__builtin_expect(__any(tie), 0)) {                                  // 2^-27 per draw: the low 26 bits decide
+        const u32x4 rb = philox4x32(k0, k1, blk, 3u, s0, s1);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (hi[i] == thr[i]) {
+                const uint32_t lo = g.ztab[en.zoff + ((idx4 >> (8 * i)) & 0xFFu)].y;
+                out = (out & ~(1u << (8 * i))) | (((word_of(rb, (uint32_t)i) >> 6) > lo ? 1u : 0u) << (8 * i));
+            }
+    }
+    *(uint32_t *)(g.val + p0 + 4 * lane) = out;
+    if (!burnin) *(uint32_t *)(g.cnt_pos + p0 + 4 * lane) = tally + out;   // (four byte tallies: folded before one reaches 255)
+}
+// the block's copy of the launch's draw tables (thresholds' top 27 bits), segment s at zt + (s << NSK_ZT_BITS(NCH))
+template <int NCH>
+__device__ __forceinline__ void tab_fill_lds(const uint4 *ztab, const SegTable &tab, uint32_t *zt) {
+    const int per = 1 << NSK_ZT_BITS(NCH);
+    for (int e = (int)threadIdx.x; e < tab.n * per; e += NSK_BLOCK) {
+        const int sI = e >> NSK_ZT_BITS(NCH), i = e & (per - 1);
+        const uint32_t zmask = tab.e[sI].zmask_ev & 0xFFu;
+        if ((uint32_t)i <= zmask) zt[e] = ztab[tab.e[sI].zoff + (uint32_t)i].x;
+    }
+    __syncthreads();
+}
+
 
 // The quads of an XCD's eighth are dealt to its waves in whole rounds -- a wave's trip is a quad --; what is
 // left after the last whole round (fewer quads than waves) is dealt as tile PAIRS, two waves to a quad (each
@@ -1810,18 +1893,93 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
         }
         const int lead = (int)(en.ntiles_lead >> 30);
         const int t0q = 4 * Q - en.tile_start - lead;                   // segment tile of the quad's first tile
+        // (a wide quad -- nsk_compile.h seg_wide -- in a launch that is not the wide kernel's, most of its quads being
+        // of the other kind: tile by tile with the wide scheme's words)
+        bool ws = false;
+        if (sizeof(VT) == 1 && en.wide_off != NSK_NO_STREAM)
+            ws = ((const NSK_SCALAR uint32_t *)(g.seg_wide + en.wide_off))[(size_t)(Q - (en.tile_start >> 2)) * NSK_WIDE_STRIDE(NCH)] != 0xFFFFFFFFu;
         // the quad's block: en.pos0 - 64 lead is a multiple of 256, so (pos >> 8, lane) names it
         const uint32_t qb = quad_block((uint32_t)(en.pos0 + t0q * 64 + lane));
         const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
         u32x4 rb = {0u, 0u, 0u, 0u};
         bool have_b = false;
         if (h >= 0) {                                                   // wave-uniform
-            tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, ws);
         } else if (NSK_TAB_BATCH == 4) {
-            tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, ws);
         } else {
-            tab_tiles<VT, NCH, 2>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
-            tab_tiles<VT, NCH, 2>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            tab_tiles<VT, NCH, 2>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, ws);
+            tab_tiles<VT, NCH, 2>(g, en, t0q + 2, 2, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, ws);
+        }
+    }
+}
+
+// The table launch of a class whose quads are (mostly) wide ones (SegTable.wide; int8 values).  Same resident grid, XCD
+// x walks the x-th eighth of the quads, a wave's trip is a quad.  The quad descriptor -- slot bases, exception list,
+// slot mask: what the value loads wait for -- is requested ONE TRIP AHEAD (scalar load into registers that the next trip
+// reads), so a trip is: value loads (bases on hand) -> Philox block while they fly -> pack -> four LDS look-ups ->
+// compares -> two dword stores.  A quad that is not wide (a class end, a row of mixed border cells) is sampled tile by
+// tile by the round-4 routine, one tile at a time (few scalar registers: such quads are a fraction of a percent).
+template <int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tabw(DevGraph<signed char> g, SegTable tab, int burnin,
+                                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
+                                                              const unsigned long long *sweep_base, uint32_t sweep_off) {
+    if (sweep_base) {             // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
+        const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
+        const unsigned long long sw = cb[0] + sweep_off, key = cb[2];
+        s0 = (uint32_t)sw;
+        s1 = (uint32_t)(sw >> 32) ^ (uint32_t)cb[3];
+        k0 = (uint32_t)key;
+        k1 = (uint32_t)(key >> 32);
+    }
+    const int lane = (int)(threadIdx.x & 63);
+    __shared__ uint32_t zt[NSK_SEG_MAX << NSK_ZT_BITS(NCH)];
+    tab_fill_lds<NCH>(g.ztab, tab, zt);
+    constexpr int ST = NSK_WIDE_STRIDE(NCH);
+    const int nquads = tab.ntiles >> 2;                                 // virtual tiles: a multiple of 4
+    const int per = (nquads + 7) >> 3;                                  // quads per XCD
+    const int xcd = (int)(blockIdx.x & 7);
+    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
+    const int q0 = min(nquads, xcd * per), q1 = min(nquads, (xcd + 1) * per);
+    for (int Q = q0 + wx; Q < q1;) {
+        // the segment of the quad, and the wave's quads inside it: Q, Q + wpx, ... < Qe (most launches have one segment)
+        const int sidx = seg_of_tile(tab, 4 * Q);
+        const SegEntry en = tab.e[sidx];
+        const int c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
+        const int Qe = min(q1, c_hi >> 2);                              // (virtual tiles: every segment is whole quads)
+        const int lead = (int)(en.ntiles_lead >> 30), nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
+        const int qs = en.tile_start >> 2;                              // the segment's first quad of the launch
+        const bool hasw = en.wide_off != NSK_NO_STREAM;
+        const NSK_SCALAR uint32_t *wseg = (const NSK_SCALAR uint32_t *)(g.seg_wide + (hasw ? en.wide_off : 0u));
+        const int qlast = (Qe - 1 - qs) * ST;                           // (the prefetch past the wave's last quad re-reads it)
+        const uint32_t *zts = zt + (sidx << NSK_ZT_BITS(NCH));
+        uint32_t wd[ST];
+#pragma unroll
+        for (int j = 0; j < ST; j++) wd[j] = hasw ? wseg[(size_t)(Q - qs) * ST + j] : 0xFFFFFFFFu;
+        for (; Q < Qe; Q += wpx) {
+            uint32_t cur[ST];
+#pragma unroll
+            for (int j = 0; j < ST; j++) cur[j] = wd[j];
+            if (hasw) {                                                 // the next trip's descriptor: a scalar round trip ahead
+                const int in = min((Q + wpx - qs) * ST, qlast);
+#pragma unroll
+                for (int j = 0; j < ST; j++) wd[j] = wseg[(size_t)in + j];
+            }
+            const int t0q = 4 * Q - en.tile_start - lead;               // segment tile of the quad's first tile
+            if (cur[0] != 0xFFFFFFFFu && t0q >= 0 && t0q + 4 <= nt) {
+                tab_quad_wide<NCH>(g, en, en.pos0 + t0q * 64, cur, zts, lane, burnin, k0, k1, s0, s1);
+                continue;
+            }
+            // not a wide quad (a class end, mixed border cells): tile by tile.  Its block: en.pos0 - 64 lead is a
+            // multiple of 256, so (pos >> 8, lane) names it
+            const uint32_t qb = quad_block((uint32_t)(en.pos0 + t0q * 64 + lane));
+            const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
+            u32x4 rb = {0u, 0u, 0u, 0u};
+            bool have_b = false;
+#pragma unroll 1
+            for (int k = 0; k < 4; k++)
+                tab_tiles<signed char, NCH, 1>(g, en, t0q + k, k, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, cur[0] != 0xFFFFFFFFu);
         }
     }
 }
@@ -1836,7 +1994,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
 template <typename VT, int NCH, int NT, bool P2P>
 __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntry &en, int t0, int w0, int lane, int burnin,
                                           const u32x4 &ra, u32x4 &rb, bool &have_b, uint32_t qb,
-                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1, const TabP2P &px, uint32_t ptag) {
+                                          uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1, const TabP2P &px, uint32_t ptag, bool ws) {
     const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
     const bool border = P2P && en.push_off != NSK_NO_STREAM;           // (wave-uniform)
     nsk_rsrc rg = nsk_make_rsrc(g.val);
@@ -1958,17 +2116,21 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
     uint32_t hi[NT];
     int nv[NT];
     bool tie = false;
+    // (ws, wave-uniform: the quad is a WIDE one -- nsk_compile.h seg_wide -- that this launch samples tile by tile, a
+    // shard's run boundary cuts it: its positions keep the wide generator scheme, nsk_device.h wide_word_of_tile)
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        hi[k] = word_of(ra, (uint32_t)(w0 + k)) >> 5;
+        hi[k] = (ws ? wide_word_of_tile(ra, (uint32_t)(w0 + k), (uint32_t)lane) : word_of(ra, (uint32_t)(w0 + k))) >> 5;
         nv[k] = hi[k] > e[k].x ? 1 : 0;
         tie = tie || hi[k] == e[k].x;
     }
     if (__builtin_expect(__any(tie), 0)) {
         if (!have_b) { rb = philox4x32(k0, k1, qb, 3u, s0, s1); have_b = true; }
 #pragma unroll
-        for (int k = 0; k < NT; k++)
-            if (hi[k] == e[k].x) nv[k] = (word_of(rb, (uint32_t)(w0 + k)) >> 6) > e[k].y ? 1 : 0;
+        for (int k = 0; k < NT; k++) {
+            const uint32_t lo = (ws ? wide_word_of_tile(rb, (uint32_t)(w0 + k), (uint32_t)lane) : word_of(rb, (uint32_t)(w0 + k))) >> 6;
+            if (hi[k] == e[k].x) nv[k] = lo > e[k].y ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -2034,6 +2196,9 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
         k1 = (uint32_t)(key >> 32);
     }
     const int lane = (int)(threadIdx.x & 63);
+    __shared__ uint32_t zt[NSK_SEG_MAX << NSK_ZT_BITS(NCH)];             // wide quads read their thresholds from LDS
+    constexpr bool WIDE = sizeof(VT) == 1;
+    if (WIDE && tab.wide) tab_fill_lds<NCH>(g.ztab, tab, zt);
     const int nquads = tab.ntiles >> 2;                                 // virtual tiles: a multiple of 4
     const int per = (nquads + 7) >> 3;                                  // quads per XCD
     const int xcd = (int)(blockIdx.x & 7);
@@ -2042,7 +2207,7 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
     const int q0 = min(nquads, xcd * per), q1 = min(nquads, (xcd + 1) * per);
     const int qr = q0 + ((q1 - q0) / wpx) * wpx;                        // first quad dealt as pairs
     // the segment of the last located quad stays in scalar registers: most launches have one
-    int c_lo = 0, c_hi = -1;
+    int c_lo = 0, c_hi = -1, sidx = 0;
     SegEntry en = tab.e[0];
     // units: quads [q0, qr) one per trip, then the pairs of quads [qr, q1)
     for (int U = wx; ; U += wpx) {
@@ -2055,13 +2220,31 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
             h = u & 1;
         }
         if (4 * Q < c_lo || 4 * Q >= c_hi) {                            // wave-uniform, rare
-            const int sidx = seg_of_tile(tab, 4 * Q);
+            sidx = seg_of_tile(tab, 4 * Q);
             en = tab.e[sidx];
             c_lo = en.tile_start;
             c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
         }
         const int lead = (int)(en.ntiles_lead >> 30);
         const int t0q = 4 * Q - en.tile_start - lead;                   // segment tile of the quad's first tile
+        // a wide quad (nsk_compile.h seg_wide) of an interior run goes four positions to a lane when the run holds all of
+        // it (of a quad dealt as two pairs the first wave takes it whole); one that a run boundary cuts, or a border
+        // run's, is sampled tile by tile with the wide scheme's words (ws)
+        bool ws = false;
+        if constexpr (WIDE) {
+            if (en.wide_off != NSK_NO_STREAM) {
+                const NSK_SCALAR uint32_t *wp = (const NSK_SCALAR uint32_t *)(g.seg_wide + en.wide_off +
+                                                                                (size_t)(Q - (en.tile_start >> 2)) * NSK_WIDE_STRIDE(NCH));
+                uint32_t wd[NSK_WIDE_STRIDE(NCH)];
+#pragma unroll
+                for (int j = 0; j < NSK_WIDE_STRIDE(NCH); j++) wd[j] = wp[j];
+                ws = wd[0] != 0xFFFFFFFFu;
+                if (ws && en.push_off == NSK_NO_STREAM && t0q >= 0 && t0q + 4 <= (int)(en.ntiles_lead & 0x3FFFFFFFu)) {
+                    if (h <= 0) tab_quad_wide<NCH>(g, en, en.pos0 + t0q * 64, wd, zt + (sidx << NSK_ZT_BITS(NCH)), lane, burnin, k0, k1, s0, s1);
+                    continue;
+                }
+            }
+        }
         // the quad's block: en.pos0 - 64 lead is a multiple of 256, so (pos >> 8, lane) names it
         const uint32_t qb = quad_block((uint32_t)(en.pos0 + t0q * 64 + lane));
         const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
@@ -2070,12 +2253,12 @@ __device__ __forceinline__ void gibbs_seg_tab_body(const DevGraph<VT> &g, const 
         // interior runs (no tile of the segment touches the boundary: none reads a ghost, none pushes) take the
         // single-GPU body as it is -- only the border runs, a percent of a shard's tiles, pay for the other one
         if (en.push_off == NSK_NO_STREAM) {                             // wave-uniform
-            if (h >= 0) tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
-            else tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1);
+            if (h >= 0) tab_tiles<VT, NCH, 2>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, ws);
+            else tab_tiles<VT, NCH, 4>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, ws);
         } else if (h >= 0) {
-            tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
+            tab_tiles_x<VT, NCH, 2, P2P>(g, en, t0q + 2 * h, 2 * h, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag, ws);
         } else {
-            tab_tiles_x<VT, NCH, 4, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag);
+            tab_tiles_x<VT, NCH, 4, P2P>(g, en, t0q, 0, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, px, ptag, ws);
         }
     }
 }
@@ -2127,8 +2310,15 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg(DevGraph<VT> g, SegTabl
     }
     // a segment with a draw table keeps its positions' quad scheme when the exp path runs instead of the
     // table kernel (a value outside its domain has been uploaded): wave-uniform
-    const uint2 rr = ((en.zmask_ev >> 16) & 1u) ? inf_words_quad(k0, k1, (uint32_t)p, s0, s1)
-                                                : inf_words(k0, k1, (uint32_t)p, s0, s1);
+    // ... and inside it the wide scheme where the quad is a wide one (nsk_compile.h seg_wide)
+    bool wq = false;
+    if (en.wide_off != NSK_NO_STREAM) {
+        const int qi = ((en.pos0 + t * 64) >> 8) - (en.pos0 >> 8);
+        wq = ((const NSK_SCALAR uint32_t *)g.seg_wide)[en.wide_off + (size_t)qi * NSK_WIDE_STRIDE(NCH)] != 0xFFFFFFFFu;
+    }
+    const uint2 rr = wq ? inf_words_wide(k0, k1, (uint32_t)p, s0, s1)
+                        : ((en.zmask_ev >> 16) & 1u) ? inf_words_quad(k0, k1, (uint32_t)p, s0, s1)
+                                                     : inf_words(k0, k1, (uint32_t)p, s0, s1);
     const double z0 = nsk_exp(p0);
     const double z1 = z0 + nsk_exp(p1);
     const double z = u53(rr.x, rr.y) * z1;

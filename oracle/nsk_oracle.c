@@ -621,8 +621,13 @@ int orc_gibbs_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             uint32_t r[4], a, b;
             const uint64_t gid = g->rng_id ? (uint64_t)g->rng_id[v] : (uint64_t)v;
             const uint64_t q = gid & 0xFFFFFFFFFFull;
-            if ((gid >> 40) & 1u) {
-                const uint32_t c0 = (uint32_t)(((q >> 8) << 6) | (q & 63u)), j = (uint32_t)((q >> 6) & 3u);
+            if ((gid >> 40) & 3u) {
+                /* bit 41: the WIDE scheme (positions inside wide quads: one lane of the library's kernel samples four
+                 * consecutive positions) -- the same two blocks per quad and lane dealt the other way round: ids
+                 * 4 i .. 4 i + 3 share counter ((q >> 8) * 64 + ((q >> 2) & 63), stream, sweep), word q & 3 */
+                const int wide = (int)((gid >> 41) & 1u);
+                const uint32_t c0 = wide ? (uint32_t)(((q >> 8) << 6) | ((q >> 2) & 63u)) : (uint32_t)(((q >> 8) << 6) | (q & 63u));
+                const uint32_t j = wide ? (uint32_t)(q & 3u) : (uint32_t)((q >> 6) & 3u);
                 orc_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c0, 2u,
                                (uint32_t)sweep, (uint32_t)(sweep >> 32) ^ g->rng_tag, r);
                 a = r[j];
