@@ -328,6 +328,11 @@ int nsk_p2p_selftest(nsk_graph *g, int learn, int part);
  * exchange again.  Returns 1 / 0 = fused or not afterwards, < 0 on error. */
 int nsk_p2p_fuse(nsk_graph *g, int on);
 int nsk_p2p_check(nsk_graph *g);
+/* After a failed self-test the peers have advanced their exchange tags and written patterns into this rank's receive
+ * blocks: nsk_p2p_reset zeroes this rank's exchange allocation (flags, both parities of the receive blocks, the
+ * weight-delta slices), its error words and its tag.  EVERY rank calls it, with a barrier of the caller's before and
+ * after (no peer may still be writing; none may start before all are clean): the mappings stay. */
+int nsk_p2p_reset(nsk_graph *g);
 
 /* ---- graph-aware partitioning (no GPU needed; salt/src/messages.py:542-670 find_connected_components /
  * find_metis_parts).  A partition is a VARIABLE ORDER in front of the samplers' range partition

@@ -70,9 +70,23 @@ static int dev_alloc(nsk_graph *g, T **ptr, size_t n) {
     if (e != hipSuccess) return fail(NSK_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     g->allocs.push_back(p);
     g->device_bytes += (int64_t)bytes;
-    if (al) p = (void *)(((uintptr_t)p + two - 1) / two * two);
+    if (al) {
+        void *raw = p;
+        p = (void *)(((uintptr_t)p + two - 1) / two * two);
+        if (p != raw) g->alloc_alias.push_back({p, raw});       // (dev_free must hand hipFree the allocation, not the aligned pointer)
+    }
     *ptr = (T *)p;
     return NSK_OK;
+}
+
+// frees an array dev_alloc handed out before the handle is destroyed (arrays that are re-allocated: nsk_pf_setup)
+static void dev_free(nsk_graph *g, void *p) {
+    if (!p) return;
+    void *raw = p;
+    for (size_t i = 0; i < g->alloc_alias.size(); i++)
+        if (g->alloc_alias[i].first == p) { raw = g->alloc_alias[i].second; g->alloc_alias.erase(g->alloc_alias.begin() + (long)i); break; }
+    g->allocs.erase(std::remove(g->allocs.begin(), g->allocs.end(), raw), g->allocs.end());
+    (void)hipFree(raw);
 }
 
 template <typename T>
@@ -272,8 +286,8 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     rc = dev_alloc(g, &tmp, npos * vb); if (rc) return rc; g->p_init = tmp;
     // (+ 16 bytes with value windows: they are copied in whole 16-byte chunks)
     const size_t vpad = c.ep_win.empty() ? 0 : 16;
-    rc = dev_alloc(g, &tmp, nid * vb + vpad); if (rc) return rc; g->val = tmp;
-    rc = dev_alloc(g, &tmp, nid * vb + vpad); if (rc) return rc; g->val_evid = tmp;
+    rc = dev_alloc(g, &tmp, nid * vb + vpad + 16); if (rc) return rc; g->val = tmp;      // (+ 16: k_unpack_tally walks 16-byte chunks)
+    rc = dev_alloc(g, &tmp, nid * vb + vpad + 16); if (rc) return rc; g->val_evid = tmp;
     rc = upload_values(g, g->p_init, c.p_init.data(), npos); if (rc) return rc;
     {   // values live at internal ids (padding positions hold 0 and are never read as a variable)
         std::vector<int32_t> init_i(nid, 0);
@@ -283,7 +297,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
     }
     rc = dev_alloc(g, &g->cnt, (size_t)c.ncount); if (rc) return rc;
     rc = dev_alloc(g, &g->cnt_total, (size_t)c.ncount); if (rc) return rc;
-    rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos); if (rc) return rc;
+    rc = dev_alloc(g, &g->cnt_pos, (size_t)c.npos + 16); if (rc) return rc;
     rc = dev_alloc(g, &g->prog_w, 2 * c.tile_hdr.size()); if (rc) return rc;
     rc = dev_alloc(g, &g->adj_wt, (size_t)c.nwrows * 64); if (rc) return rc;
     rc = dev_alloc(g, &g->ztab, (size_t)c.nztab); if (rc) return rc;
@@ -309,7 +323,7 @@ static int create_impl(const nsk_graph_desc *desc, nsk_graph *g) {
         HIPCHECK(hipMemsetAsync(g->part_K, 0, cells * sizeof(uint32_t), g->stream));
         HIPCHECK(hipMemsetAsync(g->part_T, 0, cells * sizeof(uint32_t), g->stream));
     }
-    HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (c.npos ? c.npos : 1), g->stream));
+    HIPCHECK(hipMemsetAsync(g->cnt_pos, 0, (size_t)c.npos + 16, g->stream));
     // global learning accumulators: one private copy per XCD (nsk_device.h sink_add); graphs with few
     // weights accumulate in LDS and never touch them.  A private copy pays while it stays in its XCD's L2
     // (4 MB): up to 2^18 weights (2 MB of sums).  Beyond, the adds miss the L2 either way and eight copies only
@@ -475,7 +489,18 @@ void nsk_refresh_prog_weights(nsk_graph *g, bool force) {
             (const uint4 *)g->tiles, (const uint4 *)g->adj, g->tile_hdr, g->tile_wrow, g->w, g->adj_wt, nt);
 }
 
+// the tally a packed-mode sweep sequence left inside the value bytes (nsk_gibbs.hip pack_tally) back into cnt_pos
+int nsk_unpack_tally(nsk_graph *g) {
+    if (g->packed_sweeps == 0) return NSK_OK;
+    const long long n16 = ((long long)g->c.npos + 15) / 16;
+    if (n16 > 0)
+        k_unpack_tally<<<dim3((unsigned)((n16 + NSK_BLOCK - 1) / NSK_BLOCK)), dim3(NSK_BLOCK), 0, g->stream>>>((uint4 *)g->val, (uint4 *)g->cnt_pos, n16);
+    g->packed_sweeps = 0;
+    return NSK_OK;
+}
+
 int nsk_fold_position_tally(nsk_graph *g) {
+    (void)nsk_unpack_tally(g);
     const int np = (int)g->c.npos;
     if (np > 0 && g->c.nfast > 0 && g->pos_tally_sweeps > 0)
         k_fold_counts_pos<<<dim3((np + NSK_BLOCK - 1) / NSK_BLOCK), dim3(NSK_BLOCK), 0, g->stream>>>(
@@ -1057,10 +1082,13 @@ int nsk_pf_setup(nsk_graph *g, int64_t npf, const uint8_t *op, const int64_t *me
         HIPCHECK(hipMemsetAsync(bigger, 0, (nid + (size_t)npf) * vb + 16, g->stream));
         HIPCHECK(hipMemcpyAsync(bigger, arr, nid * vb, hipMemcpyDeviceToDevice, g->stream));
         HIPCHECK(hipStreamSynchronize(g->stream));
-        g->allocs.erase(std::remove(g->allocs.begin(), g->allocs.end(), arr), g->allocs.end());
-        (void)hipFree(arr);
+        dev_free(g, arr);
         arr = bigger;
     }
+    // (a second set-up replaces the first one's descriptions)
+    dev_free(g, g->pf_op); g->pf_op = nullptr;
+    dev_free(g, g->pf_off); g->pf_off = nullptr;
+    dev_free(g, g->pf_mem); g->pf_mem = nullptr;
     int rc;
     if ((rc = dev_upload(g, &g->pf_op, ops))) return rc;
     if ((rc = dev_upload(g, &g->pf_off, off))) return rc;
@@ -1534,6 +1562,21 @@ int nsk_p2p_fuse(nsk_graph *g, int on) {
     }
     nsk_drop_sweep_graph(g);
     return g->p2p_fused ? 1 : 0;
+}
+
+int nsk_p2p_reset(nsk_graph *g) {
+    if (!g) return fail(NSK_E_INVALID, "null graph");
+    if (!g->p2p_base) return fail(NSK_E_INVALID, "nsk_p2p_setup / nsk_p2p_export first");
+    HIPCHECK(hipSetDevice(g->device));
+    { int frc = nsk_p2p_flush(g); if (frc) return frc; }
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    nsk_drop_sweep_graph(g);
+    HIPCHECK(hipMemsetAsync(g->p2p_base, 0, g->p2p_bytes, g->stream));
+    HIPCHECK(hipMemsetAsync(g->p2p_err, 0, 4 * sizeof(unsigned int), g->stream));
+    HIPCHECK(hipStreamSynchronize(g->stream));
+    g->p2p_tag = 0;
+    g->p2p_close_pending = false;
+    return NSK_OK;
 }
 
 int nsk_p2p_exchange(nsk_graph *g, int learn, int part) {

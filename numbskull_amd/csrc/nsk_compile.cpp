@@ -256,6 +256,7 @@ static int validate_reachable(const nsk_graph_desc *d, Compiled &c, const std::v
         std::vector<Issue> issues((size_t)compile_threads());
         parallel_for(nvar, [&](int64_t vb0, int64_t vb1, int t) {
             Issue &is = issues[(size_t)t];
+            std::vector<int64_t> sorted_list;
             for (int64_t v = vb0; v < vb1 && !is.rc; v++) {
                 if (!sampled[v]) continue;
                 const nsk_variable &var = d->variable[v];
@@ -268,20 +269,31 @@ static int validate_reachable(const nsk_graph_desc *d, Compiled &c, const std::v
                         is.rc = NSK_E_INDEX;
                         break;
                     }
+                    // a factor twice in ONE list (compute_var_map never produces that, dataloading.py:68-81; a
+                    // caller of the C-ABI may, and need not hand in sorted lists): its weight is then visited twice by
+                    // one variable in one class and must not be updated in place at "its one visit"
+                    // (find_direct_weights).  Bit 1 of checked[f] marks it: found on a sorted copy of the list when
+                    // the list is not ascending already; the marks are atomic ORs (several threads reach one factor).
+                    const int64_t *fl = d->factor_index + vt.factor_index_offset;
+                    bool ascending = true;
                     for (int64_t j = 0; j < vt.factor_index_length; j++) {
-                        const int64_t f = d->factor_index[vt.factor_index_offset + j];
+                        const int64_t f = fl[j];
                         if (f < 0 || f >= nfac) {
                             is.msg = fmt("variable %lld: factor id %lld outside factors", v, f);
                             is.rc = NSK_E_INDEX;
                             break;
                         }
-                        // a factor twice in ONE list (compute_var_map never produces that, dataloading.py:68-81; a
-                        // caller of the C-ABI may): its weight is then visited twice by one variable in one class and
-                        // must not be updated in place at "its one visit" (find_direct_weights); 2 marks it
-                        bool twice = false;
-                        for (int64_t i = std::max<int64_t>(0, j - 64); i < j && !twice; i++)
-                            twice = d->factor_index[vt.factor_index_offset + i] == f;
-                        checked[f] = twice ? 2 : (checked[f] == 2 ? 2 : 1);     // (several threads may store the same values)
+                        if (j > 0 && fl[j - 1] > f) ascending = false;
+                    }
+                    if (is.rc) break;
+                    if (ascending) {
+                        for (int64_t j = 0; j < vt.factor_index_length; j++)
+                            __atomic_fetch_or(&checked[fl[j]], (uint8_t)((j > 0 && fl[j - 1] == fl[j]) ? 3 : 1), __ATOMIC_RELAXED);
+                    } else {
+                        sorted_list.assign(fl, fl + vt.factor_index_length);
+                        std::sort(sorted_list.begin(), sorted_list.end());
+                        for (size_t j = 0; j < sorted_list.size(); j++)
+                            __atomic_fetch_or(&checked[sorted_list[j]], (uint8_t)((j > 0 && sorted_list[j - 1] == sorted_list[j]) ? 3 : 1), __ATOMIC_RELAXED);
                     }
                 }
             }
@@ -294,7 +306,7 @@ static int validate_reachable(const nsk_graph_desc *d, Compiled &c, const std::v
                 if (checked[f]) is.rc = check_factor(f, is);
         });
         c.repeated_factors.clear();
-        for (int64_t f = 0; f < nfac; f++) if (checked[f] == 2) c.repeated_factors.push_back(f);
+        for (int64_t f = 0; f < nfac; f++) if (checked[f] & 2) c.repeated_factors.push_back(f);
         for (const Issue &is : issues) {
             if (is.rc) { err = is.msg; return is.rc; }
             c.has_ufo = c.has_ufo || is.ufo;

@@ -127,6 +127,19 @@ void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
                 flush();
             }
         }
+    // The border waves of the sweep's first class THAT HAS BORDER TILES wait for the peers' flags of the previous
+    // exchange (later classes find them raised: the stream is in order).  Not simply the first class with sampled
+    // segments: a cut whose boundary variables all have the other colour (a chain, a bipartite cut) has no border tile
+    // there, and then nothing in the sweep would wait -- ghosts read before they arrived, pushes over a block a peer
+    // still reads.
+    if (g->p2p_fused) {
+        int first_border = -1;
+        for (size_t ph = 0; ph < nphase && first_border < 0; ph++)
+            for (const SegPlan &pl : seg_plans[ph])
+                for (int i = 0; i < pl.tab.n && first_border < 0; i++)
+                    if (pl.tab.e[i].push_off != NSK_NO_STREAM) first_border = (int)ph;
+        if (first_border >= 0) g->p2p_first_phase = first_border;
+    }
     g->p2p_border_total = border_total;
     g->p2p_border_all = border_all && border_total == (uint32_t)bt.size();
 }
@@ -147,6 +160,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
         std::vector<std::vector<NskSegPlan>> &seg_plans = g->seg_plans;
         typedef NskSegPlan SegPlan;
         for (int64_t s = 0; s < nsweeps; s++) {
+            if (g->pack_now && !burnin && g->packed_sweeps >= 127) (void)nsk_unpack_tally(g);       // 7 tally bits per value byte
             if (g->p2p_fused_now) ++g->p2p_tag;            // the exchange rides in this sweep's table launches
             for (size_t ph = 0; ph < nphase; ph++) {
                 const int fb = (int)g->c.phase_start[ph], fe = (int)g->c.phase_fast_end[ph];
@@ -257,8 +271,11 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                             else if (sizeof(VT) == 1 && tab.wide) {          // (mostly) wide quads: four positions to a lane
                                 const DevGraph<signed char> dw = view<signed char>(g);
                                 const int nbw = nsk_tabw_grid(tab.ntiles);
-                                if (nch == 1) k_gibbs_seg_tabw<1><<<dim3(nbw), block, 0, g->stream>>>(dw, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
-                                else k_gibbs_seg_tabw<2><<<dim3(nbw), block, 0, g->stream>>>(dw, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
+                                const int mode = burnin ? 1 : (g->pack_now ? 2 : 0);        // 2: the tally inside the value bytes
+#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nbw), block, 0, g->stream>>>(dw, tab, K0, K1, S0, S1, nullptr, 0u)
+                                if (nch == 1) { if (mode == 0) NSK_TABW(1, 0); else if (mode == 1) NSK_TABW(1, 1); else NSK_TABW(1, 2); }
+                                else { if (mode == 0) NSK_TABW(2, 0); else if (mode == 1) NSK_TABW(2, 1); else NSK_TABW(2, 2); }
+#undef NSK_TABW
                             }
                             else if (nch == 1) k_gibbs_seg_tab<VT, 1><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
                             else k_gibbs_seg_tab<VT, 2><<<dim3(nbp), block, 0, g->stream>>>(d, tab, burnin, K0, K1, S0, S1, nullptr, 0u);
@@ -283,6 +300,7 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                 cs.join();
             }
             g->sweep++;
+            if (!burnin && g->pack_now) g->packed_sweeps++;
             if (!burnin && ++g->pos_tally_sweeps == 255) nsk_fold_position_tally(g);   // uint8 tally is full
         }
         HIPCHECK(hipGetLastError());
@@ -350,10 +368,11 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
                 else if (sizeof(VT) == 1 && pl.tab.wide) {
                     const DevGraph<signed char> dw = view<signed char>(g);
                     const int nbw = nsk_tabw_grid(pl.tab.ntiles);
-                    if (pl.nch == 1)
-                        k_gibbs_seg_tabw<1><<<dim3(nbw), dim3(NSK_BLOCK), 0, g->stream>>>(dw, pl.tab, burnin, 0u, 0u, 0u, 0u, g->d_counters, (uint32_t)i);
-                    else
-                        k_gibbs_seg_tabw<2><<<dim3(nbw), dim3(NSK_BLOCK), 0, g->stream>>>(dw, pl.tab, burnin, 0u, 0u, 0u, 0u, g->d_counters, (uint32_t)i);
+                    const int mode = burnin ? 1 : (g->pack_now ? 2 : 0);
+#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nbw), dim3(NSK_BLOCK), 0, g->stream>>>(dw, pl.tab, 0u, 0u, 0u, 0u, g->d_counters, (uint32_t)i)
+                    if (pl.nch == 1) { if (mode == 0) NSK_TABW(1, 0); else if (mode == 1) NSK_TABW(1, 1); else NSK_TABW(1, 2); }
+                    else { if (mode == 0) NSK_TABW(2, 0); else if (mode == 1) NSK_TABW(2, 1); else NSK_TABW(2, 2); }
+#undef NSK_TABW
                 }
                 else if (pl.nch == 1)
                     k_gibbs_seg_tab<VT, 1><<<dim3(nbp), dim3(NSK_BLOCK), 0, g->stream>>>(d, pl.tab, burnin, 0u, 0u, 0u, 0u,
@@ -400,7 +419,18 @@ int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin
     if (!fuse) { int frc = nsk_p2p_flush(g); if (frc) return frc; }
     g->p2p_close_pending = false;
     g->p2p_fused_now = fuse;
-    struct Done { nsk_graph *g; bool fuse; ~Done() { g->p2p_fused_now = false; if (fuse) g->p2p_close_pending = true; } } done{g, fuse};
+    // Packed tally (nsk_internal.h): a whole-graph handle whose every launch of this call is the wide-quad kernel's keeps
+    // the tally inside the value bytes while the call runs; it is unpacked before the call returns
+    g->pack_now = false;
+    if (!p2p && !burnin && g->scan == NSK_SCAN_CHROMATIC && g->values_regular && g->c.vbytes == 1 && nsweeps > 0 &&
+        nsk_tables_only(g) && !nsk::diag_env("NSK_NO_PACK_TALLY")) {
+        nsk_ensure_seg_plans(g, sample_evidence);
+        bool all_wide = true;
+        for (const auto &v : g->seg_plans) for (const NskSegPlan &pl : v) all_wide = all_wide && pl.kind >= 8 && pl.tab.wide;
+        g->pack_now = all_wide;
+    }
+    struct Done { nsk_graph *g; bool fuse; ~Done() { g->p2p_fused_now = false; if (fuse) g->p2p_close_pending = true;
+                                                      (void)nsk_unpack_tally(g); g->pack_now = false; } } done{g, fuse};
     if (left >= NSK_GRAPH_SWEEPS && graph_eligible(g, p2p)) {
         // the plans of this (sample_evidence, tables) combination: one eager sweep builds / refreshes them
         int rc = gibbs_eager(g, 1, sample_evidence, burnin);
@@ -409,7 +439,7 @@ int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin
         left--;
         bool all_tab = true;
         for (const auto &v : g->seg_plans) for (const NskSegPlan &pl : v) all_tab = all_tab && pl.kind >= 8;
-        const int key = g->seg_plans_key | (burnin ? 8 : 0) | (p2p ? 16 : 0) | (fuse ? 32 : 0);
+        const int key = g->seg_plans_key | (burnin ? 8 : 0) | (p2p ? 16 : 0) | (fuse ? 32 : 0) | (g->pack_now ? 64 : 0);
         if (all_tab && left >= NSK_GRAPH_SWEEPS) {
             if (g->sweep_graph_key != key && !g->sweep_graph_off) {
                 rc = g->c.vbytes == 1 ? graph_build<int8_t>(g, sample_evidence, burnin, p2p, key)
@@ -423,10 +453,11 @@ int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin
                 k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, g->sweep, g->p2p_tag, 1, g->seed, g->rng_tag);
             while (left >= NSK_GRAPH_SWEEPS && g->sweep_graph_key == key && !g->sweep_graph_off) {
                 if (!burnin && g->pos_tally_sweeps + NSK_GRAPH_SWEEPS > 255) nsk_fold_position_tally(g);   // uint8 tally
+                if (g->pack_now && g->packed_sweeps + NSK_GRAPH_SWEEPS > 127) (void)nsk_unpack_tally(g);   // 7 bits in a value byte
                 HIPCHECK(hipGraphLaunch(g->sweep_graph, g->stream));
                 g->sweep += NSK_GRAPH_SWEEPS;
                 if (p2p) g->p2p_tag += NSK_GRAPH_SWEEPS;
-                if (!burnin) { g->pos_tally_sweeps += NSK_GRAPH_SWEEPS; g->cnt_dirty = true; }
+                if (!burnin) { g->pos_tally_sweeps += NSK_GRAPH_SWEEPS; g->cnt_dirty = true; if (g->pack_now) g->packed_sweeps += NSK_GRAPH_SWEEPS; }
                 g->sweeps_done += NSK_GRAPH_SWEEPS;
                 g->launches += g->sweep_graph_launches;
                 left -= NSK_GRAPH_SWEEPS;

@@ -49,6 +49,7 @@ struct nsk_graph {
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool no_overlap = nsk::diag_env("NSK_NO_OVERLAP") != nullptr;     // diagnostic: one stream
     std::vector<void *> allocs;
+    std::vector<std::pair<void *, void *>> alloc_alias;   // (aligned pointer handed out, allocation) where they differ (NSK_ALLOC_ALIGN)
     int64_t device_bytes = 0;
     // device arrays
     int32_t *p_vid = nullptr, *p_slot = nullptr, *p_cnt = nullptr, *slot_off = nullptr, *fidx = nullptr;
@@ -65,6 +66,12 @@ struct nsk_graph {
     int32_t *cnt = nullptr;
     uint8_t *cnt_pos = nullptr;
     int pos_tally_sweeps = 0;      // sweeps accumulated in the uint8 position tally
+    // Packed tally (k_gibbs_seg_tabw): while a nsk_gibbs_sweeps call runs on a handle whose every launch is the wide-quad
+    // kernel's, the tally of its sweeps lives in the value bytes (bit 0 value, bits 1-7 count): one store per trip
+    // instead of two.  packed_sweeps = tallied sweeps since the last k_unpack_tally (at most 127; 0 whenever the
+    // library returns to the caller: every other reader of values sees plain 0 / 1).
+    int packed_sweeps = 0;
+    bool pack_now = false;         // the running call sweeps in packed mode
     uint32_t *adj = nullptr, *tiles = nullptr, *tile_hdr = nullptr, *gstream = nullptr, *gs_off = nullptr;
     double *prog_w = nullptr, *adj_wt = nullptr;
     uint32_t *tile_wrow = nullptr;
@@ -275,8 +282,8 @@ static inline int nsk_tab_grid(int vtiles) {
 #define NSK_TABW_PER_CU 6
 #endif
 static inline int nsk_tabw_grid(int vtiles) {
-    const int nquads = vtiles / 4;
-    const int need = std::max(8, 8 * ((((nquads + 3) / 4) + 7) / 8));
+    const int nquads = vtiles / 4, ntrips = (nquads + NSK_TABW_NQ - 1) / NSK_TABW_NQ + 8;     // (+ 8: every XCD's share rounds up)
+    const int need = std::max(8, 8 * ((((ntrips + 3) / 4) + 7) / 8));
     const char *cap_env = nsk::diag_env("NSK_TABW_GRID_CAP");               // (diagnostic)
     const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : 256 * NSK_TABW_PER_CU;
     return std::min(cap, need);
@@ -305,3 +312,4 @@ int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin
 void nsk_refresh_prog_weights(nsk_graph *g, bool force = false);
 void nsk_refresh_ztab(nsk_graph *g, int set = 0, hipStream_t st = nullptr);
 int nsk_fold_position_tally(nsk_graph *g);
+int nsk_unpack_tally(nsk_graph *g);

@@ -1681,7 +1681,10 @@ __host__ __device__ inline size_t nsk_p2p_recv_off_(int world) { return ((size_t
 #endif
 // NT consecutive tiles of one quad, first tile = segment tile `t0` (word `w0` of the quad's blocks): every
 // load of the NT tiles is requested before the first draw, the draws' stores come last
-template <typename VT, int NCH, int NT>
+// (PK: the launch keeps the tally INSIDE the value bytes -- k_gibbs_seg_tabw's packed mode, below: bit 0 the value, bits
+//  1-7 the sweeps it was 1 since the last unpack -- so a member's byte is masked, the lane's own byte is its tally and the
+//  store carries both)
+template <typename VT, int NCH, int NT, bool PK = false>
 __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry &en, int t0, int w0, int lane, int burnin,
                                           const u32x4 &ra, u32x4 &rb, bool &have_b, uint32_t qb,
                                           uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1, bool ws) {
@@ -1714,7 +1717,7 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     // them BEHIND the gathers, here and for k_learn_seg_tab's evidence values, changed nothing: 10M grid 12.7 / 12.7 us
     // per class, learning 23.4 / 23.4, 40M grid 40.3 against 39.1 -- tools/sessions/r5_s23.sh; not kept)
 #pragma unroll
-    for (int k = 0; k < NT; k++) tally[k] = burnin ? (uint8_t)0 : g.cnt_pos[pl[k]];
+    for (int k = 0; k < NT; k++) tally[k] = burnin ? (uint8_t)0 : (PK ? (uint8_t)g.val[pl[k]] : g.cnt_pos[pl[k]]);
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         if (ab[k][0] != NSK_NO_STREAM) {                                // wave-uniform: member = base + lane
@@ -1736,7 +1739,7 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
     for (int k = 0; k < NT; k++) {
         idx[k] = 0;
 #pragma unroll
-        for (int j = 0; j < 4 * NCH; j++) idx[k] |= (uint32_t)(uint8_t)g.val[id[k][j]] << j;
+        for (int j = 0; j < 4 * NCH; j++) idx[k] |= ((uint32_t)(uint8_t)g.val[id[k][j]] & (PK ? 1u : 0xFFu)) << j;
     }
     uint2 e[NT];
 #pragma unroll
@@ -1764,6 +1767,10 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         VT *dst = live[k] ? g.val + p[k] : (VT *)g.sink + lane;         // (no branch: see seg_of_tile's note)
+        if (PK) {
+            *dst = (VT)(uint8_t)((burnin ? 0u : (uint32_t)(tally[k] & 0xFEu)) + 3u * (uint32_t)nv[k]);   // tally + value, value
+            continue;
+        }
         *dst = (VT)nv[k];
         if (!burnin) {
             uint8_t *td = live[k] ? g.cnt_pos + p[k] : g.sink + 256 + lane;
@@ -1784,34 +1791,53 @@ __device__ __forceinline__ void tab_tiles(const DevGraph<VT> &g, const SegEntry 
 typedef uint32_t nsk_u32_una __attribute__((aligned(1)));
 #define NSK_ZT_BITS(NCH) (4 * (NCH))                  // log2 of the LDS table entries kept per segment of a launch
 template <int NCH>
-__device__ __forceinline__ void tab_quad_wide(const DevGraph<signed char> &g, const SegEntry &en, int p0,
-                                              const uint32_t (&wd)[NSK_WIDE_STRIDE(NCH)], const uint32_t *zt, int lane, int burnin,
-                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
-    uint32_t base[4 * NCH];
+struct WideTrip { uint32_t x[4 * NCH], tally; };      // what a wide quad asks memory for: four neighbour bytes per slot, four tally bytes
+// the requests of the quad at p0 (bases: its descriptor's, or any readable ones for a trip that will not be finished)
+template <int NCH, int MODE>
+__device__ __forceinline__ void wide_issue(const DevGraph<signed char> &g, int p0, const uint32_t (&base)[4 * NCH], int lane,
+                                           WideTrip<NCH> &t) {
+    // (32-bit offsets from the arrays' bases: `global_load_dword v, v_offset, s[base]` -- one vector add per load, no
+    // 64-bit scalar pair per base)
+    const uint32_t l4 = 4u * (uint32_t)lane;
+#ifdef NSK_ABL_W_NOLOAD
 #pragma unroll
-    for (int j = 0; j < 4 * NCH; j++) base[j] = wd[j];
+    for (int j = 0; j < 4 * NCH; j++) t.x[j] = (base[j] + l4) * 0x9E3779B9u;
+    t.tally = (uint32_t)p0 + l4;
+#else
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) t.x[j] = *(const nsk_u32_una *)((const char *)g.val + (base[j] + l4));
+    // the quad's tally bytes: its own value bytes in packed mode (MODE 2), else the position tally (MODE 0; 1 = burn-in)
+    t.tally = 0;
+    if (MODE == 2) t.tally = *(const uint32_t *)((const char *)g.val + ((uint32_t)p0 + l4));
+    else if (MODE == 0) t.tally = *(const uint32_t *)((const char *)g.cnt_pos + ((uint32_t)p0 + l4));
+#endif
+}
+// ... and the rest of the trip: draws, look-ups, stores.  wd: the quad's descriptor (nsk_compile.h seg_wide)
+template <int NCH, int MODE>
+__device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, const SegEntry &en, int p0,
+                                            const uint32_t (&wd)[NSK_WIDE_STRIDE(NCH)], const WideTrip<NCH> &t, const uint32_t *zt,
+                                            int lane, uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
     const uint32_t exc0 = wd[4 * NCH], nexc = wd[4 * NCH + 1], smask = wd[4 * NCH + 2];
-    const char *vb = (const char *)g.val + 4 * lane;
-    uint32_t x[4 * NCH];
-#pragma unroll
-    for (int j = 0; j < 4 * NCH; j++) x[j] = *(const nsk_u32_una *)(vb + base[j]);
-    uint32_t tally = 0;
-    if (!burnin) tally = *(const uint32_t *)(g.cnt_pos + p0 + 4 * lane);
     // (the block is evaluated while the loads are in flight: without the fences the scheduler puts it behind the waits)
     __builtin_amdgcn_sched_barrier(0);
     const uint32_t blk = (uint32_t)(p0 >> 2) + (uint32_t)lane;              // wide_block: ((p0 >> 8) << 6) | lane
+#ifdef NSK_ABL_W_NOPHILOX
+    const uint32_t hq = blk * 2654435761u ^ s0;
+    const u32x4 ra = {hq, hq * 40503u, hq ^ 0x9E3779B9u, hq * 7u};
+#else
     const u32x4 ra = philox4x32(k0, k1, blk, 2u, s0, s1);
+#endif
     asm volatile("" :: "v"(ra.x), "v"(ra.y), "v"(ra.z), "v"(ra.w));       // (the words exist HERE: the optimiser sinks them to their uses otherwise)
     __builtin_amdgcn_sched_barrier(0);
     uint32_t idx4 = 0;
 #pragma unroll
-    for (int j = 0; j < 4 * NCH; j++) idx4 |= (x[j] & 0x01010101u) << j;    // (a member's value is its bit; what a lane reads for a
+    for (int j = 0; j < 4 * NCH; j++) idx4 |= (t.x[j] & 0x01010101u) << j;  // (a member's value is its bit; what a lane reads for a
     idx4 &= smask * 0x01010101u;                                            //  position that is an exception may be any value: masked)
     for (uint32_t e = 0; e < nexc; e++) {                                   // scalar loop, rare: the odd cells of the quad
         const NSK_SCALAR uint32_t *xp = (const NSK_SCALAR uint32_t *)g.wide_exc + 2 * (size_t)(exc0 + e);
         const uint32_t ex = xp[0], eid = xp[1];
         const uint32_t o = ex & 0xFFu, sh = 8u * (o & 3u) + ((ex >> 8) & 7u);
-        if ((uint32_t)lane == (o >> 2)) idx4 = (idx4 & ~(1u << sh)) | ((uint32_t)(uint8_t)g.val[eid] << sh);
+        if ((uint32_t)lane == (o >> 2)) idx4 = (idx4 & ~(1u << sh)) | (((uint32_t)(uint8_t)g.val[eid] & 1u) << sh);
     }
     uint32_t thr[4], hi[4], out = 0;
     bool tie = false;
@@ -1832,21 +1858,79 @@ __device__ __forceinline__ void tab_quad_wide(const DevGraph<signed char> &g, co
                 out = (out & ~(1u << (8 * i))) | (((word_of(rb, (uint32_t)i) >> 6) > lo ? 1u : 0u) << (8 * i));
             }
     }
-    *(uint32_t *)(g.val + p0 + 4 * lane) = out;
-    if (!burnin) *(uint32_t *)(g.cnt_pos + p0 + 4 * lane) = tally + out;   // (four byte tallies: folded before one reaches 255)
+#ifdef NSK_ABL_W_NOSTORE
+    if (out == 0x12345678u)
+#endif
+    {
+    // packed mode: ONE store -- per byte (tally << 1) + 2 * value | value; no carry between the bytes while a tally stays
+    // below 127 (the host unpacks before)
+#if defined(NSK_W_STORE_SC1)
+#define NSK_W_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#elif defined(NSK_W_STORE_NT)
+#define NSK_W_STORE(P, V) __builtin_nontemporal_store((V), (P))
+#else
+#define NSK_W_STORE(P, V) (*(P) = (V))
+#endif
+    if (MODE == 2) NSK_W_STORE((uint32_t *)((char *)g.val + ((uint32_t)p0 + 4u * (uint32_t)lane)), (t.tally & 0xFEFEFEFEu) + 3u * out);
+    else {
+    NSK_W_STORE((uint32_t *)((char *)g.val + ((uint32_t)p0 + 4u * (uint32_t)lane)), out);
+    if (MODE == 0) NSK_W_STORE((uint32_t *)((char *)g.cnt_pos + ((uint32_t)p0 + 4u * (uint32_t)lane)), t.tally + out); // (four byte tallies: folded before one reaches 255)
+    }
+    }
 }
-// the block's copy of the launch's draw tables (thresholds' top 27 bits), segment s at zt + (s << NSK_ZT_BITS(NCH))
 template <int NCH>
-__device__ __forceinline__ void tab_fill_lds(const uint4 *ztab, const SegTable &tab, uint32_t *zt) {
+__device__ __forceinline__ void tab_quad_wide(const DevGraph<signed char> &g, const SegEntry &en, int p0,
+                                              const uint32_t (&wd)[NSK_WIDE_STRIDE(NCH)], const uint32_t *zt, int lane, int burnin,
+                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
+    uint32_t base[4 * NCH];
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) base[j] = wd[j];
+    WideTrip<NCH> t;
+    if (burnin) {
+        wide_issue<NCH, 1>(g, p0, base, lane, t);
+        wide_finish<NCH, 1>(g, en, p0, wd, t, zt, lane, k0, k1, s0, s1);
+    } else {
+        wide_issue<NCH, 0>(g, p0, base, lane, t);
+        wide_finish<NCH, 0>(g, en, p0, wd, t, zt, lane, k0, k1, s0, s1);
+    }
+}
+// the block's copy of the launch's draw tables (thresholds' top 27 bits), segment s at zt + (s << NSK_ZT_BITS(NCH)).
+// Two halves so that a kernel can put its first trip's requests between them: tab_fill_request issues the loads
+// (per thread up to NSK_ZT_PER_THREAD entries; the segment entries come from the kernel arguments by scalar loads and a
+// select chain -- a per-lane index into them would be a vector load of its own in front of the table's), tab_fill_land
+// stores them to LDS and closes with the block's barrier.
+#define NSK_ZT_PER_THREAD(NCH) (((NSK_SEG_MAX << NSK_ZT_BITS(NCH)) + NSK_BLOCK - 1) / NSK_BLOCK)
+template <int NCH>
+__device__ __forceinline__ void tab_fill_request(const uint4 *ztab, const SegTable &tab, uint32_t (&v)[NSK_ZT_PER_THREAD(NCH)]) {
     const int per = 1 << NSK_ZT_BITS(NCH);
-    for (int e = (int)threadIdx.x; e < tab.n * per; e += NSK_BLOCK) {
+#pragma unroll
+    for (int r = 0; r < NSK_ZT_PER_THREAD(NCH); r++) {
+        const int e = (int)threadIdx.x + r * NSK_BLOCK;
         const int sI = e >> NSK_ZT_BITS(NCH), i = e & (per - 1);
-        const uint32_t zmask = tab.e[sI].zmask_ev & 0xFFu;
-        if ((uint32_t)i <= zmask) zt[e] = ztab[tab.e[sI].zoff + (uint32_t)i].x;
+        uint32_t zoff = 0u, zmask = 0u;
+        bool live = false;
+#pragma unroll
+        for (int q = 0; q < NSK_SEG_MAX; q++)
+            if (sI == q) { zoff = tab.e[q].zoff; zmask = tab.e[q].zmask_ev & 0xFFu; live = q < tab.n; }
+        v[r] = 0u;
+        if (live && (uint32_t)i <= zmask) v[r] = ztab[zoff + (uint32_t)i].x;
+    }
+}
+template <int NCH>
+__device__ __forceinline__ void tab_fill_land(uint32_t *zt, const uint32_t (&v)[NSK_ZT_PER_THREAD(NCH)]) {
+#pragma unroll
+    for (int r = 0; r < NSK_ZT_PER_THREAD(NCH); r++) {
+        const int e = (int)threadIdx.x + r * NSK_BLOCK;
+        if (e < (NSK_SEG_MAX << NSK_ZT_BITS(NCH))) zt[e] = v[r];
     }
     __syncthreads();
 }
-
+template <int NCH>
+__device__ __forceinline__ void tab_fill_lds(const uint4 *ztab, const SegTable &tab, uint32_t *zt) {
+    uint32_t v[NSK_ZT_PER_THREAD(NCH)];
+    tab_fill_request<NCH>(ztab, tab, v);
+    tab_fill_land<NCH>(zt, v);
+}
 
 // The quads of an XCD's eighth are dealt to its waves in whole rounds -- a wave's trip is a quad --; what is
 // left after the last whole round (fewer quads than waves) is dealt as tile PAIRS, two waves to a quad (each
@@ -1914,16 +1998,35 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     }
 }
 
+// `burnin` = 2 selects the PACKED mode (nsk_gibbs.hip pack_tally): the sweep's tally lives in the value bytes themselves
+// -- bit 0 the value, bits 1-7 the number of tallied sweeps it was 1 since the last unpack (k_unpack_tally; at most 127
+// sweeps apart) -- so a trip reads the quad's own bytes instead of a tally array and leaves with ONE store.  What a class
+// launch leaves dirty in its XCDs' L2s is written back at the kernel boundary (the L2s are not coherent with each
+// other): with both stores taken out the 10M-grid launch took 6.4 instead of 10.2 us (tools/sessions/r6_s06.sh), loads
+// and the Philox block together 0.6.  Every reader of values masks bit 0 while the mode is on: it is on only for
+// handles whose every launch is this kernel's.
 // The table launch of a class whose quads are (mostly) wide ones (SegTable.wide; int8 values).  Same resident grid, XCD
 // x walks the x-th eighth of the quads, a wave's trip is a quad.  The quad descriptor -- slot bases, exception list,
 // slot mask: what the value loads wait for -- is requested ONE TRIP AHEAD (scalar load into registers that the next trip
 // reads), so a trip is: value loads (bases on hand) -> Philox block while they fly -> pack -> four LDS look-ups ->
 // compares -> two dword stores.  A quad that is not wide (a class end, a row of mixed border cells) is sampled tile by
 // tile by the round-4 routine, one tile at a time (few scalar registers: such quads are a fraction of a percent).
-template <int NCH>
-__global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tabw(DevGraph<signed char> g, SegTable tab, int burnin,
+#ifndef NSK_TABW_NQ
+#define NSK_TABW_NQ 1               // quads per trip of the wide-quad kernel
+#endif
+#ifndef NSK_TABW_ATTR
+#define NSK_TABW_ATTR
+#endif
+template <int NCH, int MODE>
+__global__ __launch_bounds__(NSK_BLOCK) NSK_TABW_ATTR void k_gibbs_seg_tabw(DevGraph<signed char> g, SegTable tab,
                                                               uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
                                                               const unsigned long long *sweep_base, uint32_t sweep_off) {
+    const int lane = (int)(threadIdx.x & 63);
+    __shared__ uint32_t zt[NSK_SEG_MAX << NSK_ZT_BITS(NCH)];
+    // the table's loads go out first, the LDS stores and the block's barrier come behind the first descriptor request
+    uint32_t ztv[NSK_ZT_PER_THREAD(NCH)];
+    tab_fill_request<NCH>(g.ztab, tab, ztv);
+    bool landed = false;
     if (sweep_base) {             // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
         const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
         const unsigned long long sw = cb[0] + sweep_off, key = cb[2];
@@ -1932,9 +2035,6 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tabw(DevGraph<signed ch
         k0 = (uint32_t)key;
         k1 = (uint32_t)(key >> 32);
     }
-    const int lane = (int)(threadIdx.x & 63);
-    __shared__ uint32_t zt[NSK_SEG_MAX << NSK_ZT_BITS(NCH)];
-    tab_fill_lds<NCH>(g.ztab, tab, zt);
     constexpr int ST = NSK_WIDE_STRIDE(NCH);
     const int nquads = tab.ntiles >> 2;                                 // virtual tiles: a multiple of 4
     const int per = (nquads + 7) >> 3;                                  // quads per XCD
@@ -1942,46 +2042,111 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tabw(DevGraph<signed ch
     const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
     const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
     const int q0 = min(nquads, xcd * per), q1 = min(nquads, (xcd + 1) * per);
-    for (int Q = q0 + wx; Q < q1;) {
-        // the segment of the quad, and the wave's quads inside it: Q, Q + wpx, ... < Qe (most launches have one segment)
-        const int sidx = seg_of_tile(tab, 4 * Q);
+    // (the scalar unit is shared by the CU's waves, one instruction per cycle: the trip below is written for few scalar
+    // instructions -- one descriptor load, running position and quad counters, three compares -- and without
+    // wave-uniform branches around its loads and stores (MODE is a template parameter), so that every wait is counted)
+    // A trip is NQ consecutive quads of one segment (NSK_TABW_NQ): their requests go out together.  The XCD's quads are
+    // dealt segment by segment: inside a segment trip u of wave w is quads [Qs + NQ (w + u wpx), + NQ).
+    constexpr int NQ = NSK_TABW_NQ;
+    for (int sidx = 0; sidx < tab.n; sidx++) {
         const SegEntry en = tab.e[sidx];
         const int c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
-        const int Qe = min(q1, c_hi >> 2);                              // (virtual tiles: every segment is whole quads)
-        const int lead = (int)(en.ntiles_lead >> 30), nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
         const int qs = en.tile_start >> 2;                              // the segment's first quad of the launch
+        const int Qb = max(q0, qs), Qe = min(q1, c_hi >> 2);            // ... and its quads in this XCD's share
+        if (Qb >= Qe) continue;
+        const int lead = (int)(en.ntiles_lead >> 30), nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
+        // quads [qin_lo, qin_hi) of the launch lie wholly inside the run (all but a first one with dead lead tiles and a
+        // last one with fewer than four tiles)
+        const int qin_lo = qs + (lead ? 1 : 0), qin_hi = qs + ((lead + nt) >> 2);
         const bool hasw = en.wide_off != NSK_NO_STREAM;
         const NSK_SCALAR uint32_t *wseg = (const NSK_SCALAR uint32_t *)(g.seg_wide + (hasw ? en.wide_off : 0u));
-        const int qlast = (Qe - 1 - qs) * ST;                           // (the prefetch past the wave's last quad re-reads it)
+        const int ilast = (Qe - 1 - qs) * ST;                           // (a request past the share's last quad re-reads that one)
         const uint32_t *zts = zt + (sidx << NSK_ZT_BITS(NCH));
-        uint32_t wd[ST];
+        int Q = Qb + NQ * wx;
+        if (Q >= Qe) continue;
+        int p0 = en.pos0 + (4 * Q - en.tile_start - lead) * 64;         // the first quad's first position
+        uint32_t cur[NQ][ST];
 #pragma unroll
-        for (int j = 0; j < ST; j++) wd[j] = hasw ? wseg[(size_t)(Q - qs) * ST + j] : 0xFFFFFFFFu;
-        for (; Q < Qe; Q += wpx) {
-            uint32_t cur[ST];
+        for (int k = 0; k < NQ; k++) {
 #pragma unroll
-            for (int j = 0; j < ST; j++) cur[j] = wd[j];
-            if (hasw) {                                                 // the next trip's descriptor: a scalar round trip ahead
-                const int in = min((Q + wpx - qs) * ST, qlast);
+            for (int j = 0; j < ST; j++) cur[k][j] = 0xFFFFFFFFu;
+        }
+        if (hasw) {
 #pragma unroll
-                for (int j = 0; j < ST; j++) wd[j] = wseg[(size_t)in + j];
+            for (int k = 0; k < NQ; k++) {
+                const int in = min((Q + k - qs) * ST, ilast);
+#pragma unroll
+                for (int j = 0; j < ST; j++) cur[k][j] = wseg[(size_t)in + j];
             }
-            const int t0q = 4 * Q - en.tile_start - lead;               // segment tile of the quad's first tile
-            if (cur[0] != 0xFFFFFFFFu && t0q >= 0 && t0q + 4 <= nt) {
-                tab_quad_wide<NCH>(g, en, en.pos0 + t0q * 64, cur, zts, lane, burnin, k0, k1, s0, s1);
+        }
+        if (!landed) { tab_fill_land<NCH>(zt, ztv); landed = true; }
+        for (; Q < Qe; Q += NQ * wpx, p0 += 256 * NQ * wpx) {
+            bool wide[NQ], all = true;
+            uint32_t dsc[NQ][ST];
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                wide[k] = cur[k][0] != 0xFFFFFFFFu && Q + k >= qin_lo && Q + k < qin_hi && Q + k < Qe;
+                all = all && wide[k];
+#pragma unroll
+                for (int j = 0; j < ST; j++) dsc[k][j] = cur[k][j];
+            }
+            // the next trip's descriptors: a scalar round trip ahead
+            if (hasw) {
+#pragma unroll
+                for (int k = 0; k < NQ; k++) {
+                    const int in = min((Q + NQ * wpx + k - qs) * ST, ilast);
+#pragma unroll
+                    for (int j = 0; j < ST; j++) cur[k][j] = wseg[(size_t)in + j];
+                }
+            }
+            if (all) {              // the common trip: straight line -- all requests, then the quads one after the other
+                WideTrip<NCH> tc[NQ];
+#pragma unroll
+                for (int k = 0; k < NQ; k++) {
+                    uint32_t bc[4 * NCH];
+#pragma unroll
+                    for (int j = 0; j < 4 * NCH; j++) bc[j] = dsc[k][j];
+                    wide_issue<NCH, MODE>(g, p0 + 256 * k, bc, lane, tc[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < NQ; k++) wide_finish<NCH, MODE>(g, en, p0 + 256 * k, dsc[k], tc[k], zts, lane, k0, k1, s0, s1);
                 continue;
             }
-            // not a wide quad (a class end, mixed border cells): tile by tile.  Its block: en.pos0 - 64 lead is a
-            // multiple of 256, so (pos >> 8, lane) names it
-            const uint32_t qb = quad_block((uint32_t)(en.pos0 + t0q * 64 + lane));
-            const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
-            u32x4 rb = {0u, 0u, 0u, 0u};
-            bool have_b = false;
 #pragma unroll 1
-            for (int k = 0; k < 4; k++)
-                tab_tiles<signed char, NCH, 1>(g, en, t0q + k, k, lane, burnin, ra, rb, have_b, qb, k0, k1, s0, s1, cur[0] != 0xFFFFFFFFu);
+            for (int k = 0; k < NQ; k++) {
+                if (Q + k >= Qe) break;
+                uint32_t dk[ST];
+                bool wk = false;
+#pragma unroll
+                for (int kk = 0; kk < NQ; kk++)
+                    if (kk == k) {
+                        wk = wide[kk];
+#pragma unroll
+                        for (int j = 0; j < ST; j++) dk[j] = dsc[kk][j];
+                    }
+                if (wk) {
+                    WideTrip<NCH> t1;
+                    uint32_t bc[4 * NCH];
+#pragma unroll
+                    for (int j = 0; j < 4 * NCH; j++) bc[j] = dk[j];
+                    wide_issue<NCH, MODE>(g, p0 + 256 * k, bc, lane, t1);
+                    wide_finish<NCH, MODE>(g, en, p0 + 256 * k, dk, t1, zts, lane, k0, k1, s0, s1);
+                    continue;
+                }
+                // not a wide quad (a class end, mixed border cells): tile by tile.  Its block: en.pos0 - 64 lead is a
+                // multiple of 256, so (pos >> 8, lane) names it
+                const int t0q = 4 * (Q + k) - en.tile_start - lead;
+                const uint32_t qb = quad_block((uint32_t)(p0 + 256 * k + lane));
+                const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
+                u32x4 rb = {0u, 0u, 0u, 0u};
+                bool have_b = false;
+#pragma unroll 1
+                for (int t = 0; t < 4; t++)
+                    tab_tiles<signed char, NCH, 1, MODE == 2>(g, en, t0q + t, t, lane, MODE == 1 ? 1 : 0, ra, rb, have_b, qb, k0, k1, s0, s1, dk[0] != 0xFFFFFFFFu);
+            }
         }
     }
+    if (!landed) tab_fill_land<NCH>(zt, ztv);                            // (a wave without quads still meets its block's barrier)
 }
 
 // The fused-exchange flavour of tab_tiles / k_gibbs_seg_tab below (P2P = true is the only instantiation; buffer

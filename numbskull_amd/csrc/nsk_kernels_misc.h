@@ -250,8 +250,16 @@ __device__ __forceinline__ void p2p_reduce_slice(const void *mine, long long nre
     const size_t lo = nsk_p2p_slice_lo(me, world, nw), hi = nsk_p2p_slice_lo(me + 1, world, nw);
     const double *sb = (const double *)((const char *)mine + nsk_p2p_sbuf_off(world, (size_t)nrecv, sizeof(VT))) + par * (size_t)world * smax;
     for (size_t i = lo + (size_t)blockIdx.x * NSK_BLOCK + threadIdx.x; i < hi; i += (size_t)gridDim.x * NSK_BLOCK) {
-        double t = __builtin_nontemporal_load(sb + (i - lo));
-        for (int r = 1; r < world; r++) t += __builtin_nontemporal_load(sb + (size_t)r * smax + (i - lo));
+        // rank order, as ever; this rank's OWN contribution is computed here, not read from row `me` of sbuf: in the
+        // single-launch exchange that row is written by other blocks of the same launch (p2p_push deals weight i to
+        // another thread than this loop does), and a block waits for the PEERS' flags only -- the same double either
+        // way, so the sum is bit-identical, without the read-after-write across blocks
+        double t = 0.0;
+        for (int r = 0; r < world; r++) {
+            const double dr = r == me ? (selftest ? p2p_pattern_dw(me, (int)i, tag) : pw.w[i] - pw.w_start[i])
+                                      : __builtin_nontemporal_load(sb + (size_t)r * smax + (i - lo));
+            t = r == 0 ? dr : t + dr;
+        }
         const double x = (selftest ? 0.0 : pw.w_start[i]) + t;
         for (int q = 0; q < world; q++) {
             double *gb = (double *)((char *)pl.base[q] + nsk_p2p_gbuf_off(world, (size_t)pl.dtotal[q], sizeof(VT), nw));
@@ -474,6 +482,17 @@ static __global__ void k_selftest_philox(uint32_t k0, uint32_t k1, uint32_t stre
 }
 
 // position-indexed tally deltas of the fast path -> int64 master copy at cstart[vid]
+// packed tally (k_gibbs_seg_tabw, burnin == 2) back to the two arrays: cnt_pos += byte >> 1, value = byte & 1, sixteen
+// positions per thread
+static __global__ __launch_bounds__(NSK_BLOCK) void k_unpack_tally(uint4 *val, uint4 *cnt_pos, long long n16) {
+    const long long i = (long long)blockIdx.x * NSK_BLOCK + threadIdx.x;
+    if (i >= n16) return;
+    uint4 v = val[i], c = cnt_pos[i];
+    c.x += (v.x >> 1) & 0x7F7F7F7Fu; c.y += (v.y >> 1) & 0x7F7F7F7Fu; c.z += (v.z >> 1) & 0x7F7F7F7Fu; c.w += (v.w >> 1) & 0x7F7F7F7Fu;
+    v.x &= 0x01010101u; v.y &= 0x01010101u; v.z &= 0x01010101u; v.w &= 0x01010101u;
+    val[i] = v;
+    cnt_pos[i] = c;
+}
 static __global__ __launch_bounds__(NSK_BLOCK) void k_fold_counts_pos(uint8_t *cnt_pos, const int32_t *p_cnt,
                                                                const int32_t *p_vid, long long *total, int npos) {
     const int i = (int)(blockIdx.x * NSK_BLOCK + threadIdx.x);

@@ -36,6 +36,7 @@ Drivers for the per-sweep loop:
 """
 
 import ctypes as C
+import sys
 import os
 
 import numpy as np
@@ -332,11 +333,25 @@ class PartitionedSampler(object):
         # one exchange per buffer parity -- whose payload is a pattern that depends on sender, element,
         # exchange and chain, compared on the receiving side (values, weight-delta slices and merged
         # weights): a peer's WRITES must be visible here, not only its flags.  State and weights untouched
+        def why():
+            msg = self._lib.lib().nsk_last_error()
+            return msg.decode() if isinstance(msg, bytes) else str(msg)
+
+        def reset_all():
+            # a failed self-test leaves tags advanced and patterns in the receive blocks of the ranks that passed:
+            # every rank starts again from a clean allocation (nobody still writes / nobody starts early: barriers)
+            dist.barrier()
+            self.L.nsk_p2p_reset(self.h)
+            dist.barrier()
         rc = 0
         for _ in range(2):
             rc = rc or self.L.nsk_p2p_selftest(self.h, 1, 0)
         rc = rc or self.L.nsk_p2p_check(self.h)
+        if rc:
+            print("[numbskull_amd] rank %d: peer-to-peer self-test failed (%s): every rank takes the collective exchange"
+                  % (self.rank, why()), file=sys.stderr, flush=True)
         if not agreed(rc == 0):
+            reset_all()
             return False
         # shards that live in table segments exchange INSIDE their class launches (nsk_graph_info.p2p_fused): system-
         # coherent loads / stores of peer memory, no fences.  That protocol gets a self-test of its own, and every
@@ -348,9 +363,13 @@ class PartitionedSampler(object):
                 rc = rc or self.L.nsk_p2p_selftest(self.h, 2, 0)
             rc = rc or self.L.nsk_p2p_check(self.h)
             if rc:
-                self._lib.lib().nsk_last_error()
+                print("[numbskull_amd] rank %d: self-test of the fused exchange failed (%s): every rank keeps the exchange kernels"
+                      % (self.rank, why()), file=sys.stderr, flush=True)
+        any_fused = not agreed(not fused)
         if not agreed(fused and rc == 0):
             self.L.nsk_p2p_fuse(self.h, 0)
+            if any_fused:                       # (the fused self-test ran on some rank: its tags and the peers' blocks are used)
+                reset_all()
         return True
 
     def check(self):

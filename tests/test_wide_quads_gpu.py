@@ -122,3 +122,28 @@ def test_learning_on_a_padded_layout():
     assert og.learn_call(order, ps, vv, ve, wv, 3, 1e-3, 0.9, 2, 0.01, 1, False, 5, 0) == 0
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.array_equal(fg.weight_value[0], wv), (fg.weight_value[0], wv)
+
+
+@pytest.mark.parametrize("sweeps", [3, 140, 300])
+def test_packed_tally_equals_the_oracle(sweeps):
+    """A handle whose every launch is the wide kernel's keeps the tally inside the value bytes while a call runs (bit 0
+    the value, bits 1-7 the count; unpacked every <= 127 sweeps and before the call returns): values and counts as the
+    oracle's, across the unpack points, across calls, and with the mode switched off."""
+    g = graphgen.ising_grid(16, 1000, weight=0.25)
+    ns, fg = session(g, seed=13)
+    og = oracle_of(fg)
+    order, ps, vv, wv, cnt = _run_and_compare(fg, og, 13, 2, sweeps)
+    assert set(np.unique(fg.var_value[0])) <= {0, 1}
+    fg.inference(0, 5, True)                       # a second call continues from plain values and the same tallies
+    for s in range(2 + sweeps, 7 + sweeps):
+        assert og.gibbs_dev(order, ps, vv, wv, cnt, 13, s, True) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
+
+
+def test_packed_tally_switch(monkeypatch):
+    monkeypatch.setenv("NSK_DIAG", "1")
+    monkeypatch.setenv("NSK_NO_PACK_TALLY", "1")
+    g = graphgen.ising_grid(16, 1000, weight=0.25)
+    ns, fg = session(g, seed=13)
+    og = oracle_of(fg)
+    _run_and_compare(fg, og, 13, 2, 20)
