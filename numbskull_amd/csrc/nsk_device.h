@@ -105,6 +105,34 @@ __device__ __forceinline__ u32x4 philox4x32(uint32_t k0, uint32_t k1, uint32_t c
     return u32x4{c0, c1, c2, c3};
 }
 
+// The same block with the ten rounds' keys handed in (k0 + r * 0x9E3779B9, k1 + r * 0xBB67AE85): a kernel that evaluates
+// a block per trip keeps them in vector registers (philox_round_keys) -- the scalar file is the scarce one there, and the
+// compiler re-derives the keys with twenty scalar adds per block otherwise.
+struct PhiloxKeys { uint32_t a[10], b[10]; };
+__device__ __forceinline__ PhiloxKeys philox_round_keys(uint32_t k0, uint32_t k1) {
+    PhiloxKeys pk;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t ka = k0 + (uint32_t)r * 0x9E3779B9u, kb = k1 + (uint32_t)r * 0xBB67AE85u;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(pk.a[r]) : "s"(ka));      // (opaque: not re-derived from k0 / k1 later)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(pk.b[r]) : "s"(kb));
+    }
+    return pk;
+}
+__device__ __forceinline__ u32x4 philox4x32_keyed(const PhiloxKeys &pk, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+#pragma unroll
+    for (int round = 0; round < 10; round++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, pk.a[round], 0x96);
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, pk.b[round], 0x96);
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
 // Generator ids.  A variable's id q is its position in the compiled layout.
 // Inference sweeps: ids q and q + 64 with equal q >> 7 -- the same lane of two consecutive tiles --
 // share ONE Philox block: counter ((q >> 7) * 64 + (q & 63), 0, sweep), words 0-1 for the lower id

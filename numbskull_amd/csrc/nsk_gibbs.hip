@@ -10,6 +10,16 @@
 
 using namespace nsk;
 
+// hot arguments of k_gibbs_seg_tabw (nsk_kernels_gibbs.h NSK_TABW_HOT): the other arrays as 256-byte units from `val`
+static inline int tabw_delta(const void *p, const void *base) {
+    const long long d = (const char *)p - (const char *)base;
+    return (int)(d / 256);            // (device allocations are 256-byte aligned: checked once in nsk_ensure_seg_plans)
+}
+#define NSK_TABW_HOT_ARGS(G, T, NB, SB) (signed char *)(G)->val, tabw_delta((G)->cnt_pos, (G)->val), tabw_delta((G)->seg_wide, (G)->val),            \
+        tabw_delta((G)->ztab, (G)->val), (T).e[1].tile_start, (T).e[0].ntiles_lead, (T).e[0].pos0, (T).e[0].wide_off, (T).e[0].zoff,             \
+        (uint32_t)(T).ntiles | ((uint32_t)((T).n - 1) << 28), ((T).e[0].zmask_ev & 0xFFu) | ((uint32_t)(((NB) >> 3) * (NSK_BLOCK / 64)) << 8),   \
+        (const unsigned long long *)(SB)
+
 // The segment launches of every colour, prepared once and kept in the handle (a small graph's sweep is two
 // 4 us kernels: rebuilding the tables per sweep made the host the bottleneck): segments batched by (kind,
 // chunks) into tables of <= NSK_SEG_MAX; kind 8 = segments with draw tables (any function: the table encodes
@@ -53,7 +63,12 @@ void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
                     for (int i = tab.n; i < NSK_SEG_MAX; i++) tab.e[i].tile_start = tab.ntiles;
                     // the wide-quad kernel takes the launch when at least half of its quads are wide ones (it samples
                     // the others one tile at a time)
-                    tab.wide = (kind >= 8 && 8 * tab.wide >= tab.ntiles && !nsk::diag_env("NSK_NO_WIDE_KERNEL")) ? 1 : 0;
+                    const auto fits = [&](const void *p) {         // (the kernel's hot arguments: 256-byte units from val in 32 bits)
+                        const long long d = (const char *)p - (const char *)g->val;
+                        return d % 256 == 0 && d / 256 > -(1ll << 31) && d / 256 < (1ll << 31);
+                    };
+                    tab.wide = (kind >= 8 && 8 * tab.wide >= tab.ntiles && tab.ntiles < (1 << 28) && fits(g->cnt_pos) && fits(g->seg_wide) &&
+                                fits(g->ztab) && !nsk::diag_env("NSK_NO_WIDE_KERNEL")) ? 1 : 0;
                     seg_plans[ph].push_back(SegPlan{kind, nch, tab});
                     memset(&tab, 0, sizeof(tab));
                 };
@@ -272,7 +287,8 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 const DevGraph<signed char> dw = view<signed char>(g);
                                 const int nbw = nsk_tabw_grid(tab.ntiles);
                                 const int mode = burnin ? 1 : (g->pack_now ? 2 : 0);        // 2: the tally inside the value bytes
-#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nbw), block, 0, g->stream>>>(dw, tab, K0, K1, S0, S1, nullptr, 0u)
+                                const TabwCold cold{K0, K1, S0, S1, 0u, 0u, dw, tab};
+#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nbw), block, 0, g->stream>>>(NSK_TABW_HOT_ARGS(g, tab, nbw, nullptr), cold)
                                 if (nch == 1) { if (mode == 0) NSK_TABW(1, 0); else if (mode == 1) NSK_TABW(1, 1); else NSK_TABW(1, 2); }
                                 else { if (mode == 0) NSK_TABW(2, 0); else if (mode == 1) NSK_TABW(2, 1); else NSK_TABW(2, 2); }
 #undef NSK_TABW
@@ -369,7 +385,8 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
                     const DevGraph<signed char> dw = view<signed char>(g);
                     const int nbw = nsk_tabw_grid(pl.tab.ntiles);
                     const int mode = burnin ? 1 : (g->pack_now ? 2 : 0);
-#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nbw), dim3(NSK_BLOCK), 0, g->stream>>>(dw, pl.tab, 0u, 0u, 0u, 0u, g->d_counters, (uint32_t)i)
+                    const TabwCold cold{0u, 0u, 0u, 0u, (uint32_t)i, 0u, dw, pl.tab};
+#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nbw), dim3(NSK_BLOCK), 0, g->stream>>>(NSK_TABW_HOT_ARGS(g, pl.tab, nbw, g->d_counters), cold)
                     if (pl.nch == 1) { if (mode == 0) NSK_TABW(1, 0); else if (mode == 1) NSK_TABW(1, 1); else NSK_TABW(1, 2); }
                     else { if (mode == 0) NSK_TABW(2, 0); else if (mode == 1) NSK_TABW(2, 1); else NSK_TABW(2, 2); }
 #undef NSK_TABW

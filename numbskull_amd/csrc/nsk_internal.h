@@ -282,7 +282,7 @@ static inline int nsk_tab_grid(int vtiles) {
 #define NSK_TABW_PER_CU 6
 #endif
 static inline int nsk_tabw_grid(int vtiles) {
-    const int nquads = vtiles / 4, ntrips = (nquads + NSK_TABW_NQ - 1) / NSK_TABW_NQ + 8;     // (+ 8: every XCD's share rounds up)
+    const int nquads = vtiles / 4, ntrips = nquads + 8;                     // (+ 8: every XCD's share rounds up)
     const int need = std::max(8, 8 * ((((ntrips + 3) / 4) + 7) / 8));
     const char *cap_env = nsk::diag_env("NSK_TABW_GRID_CAP");               // (diagnostic)
     const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : 256 * NSK_TABW_PER_CU;

@@ -1814,10 +1814,10 @@ __device__ __forceinline__ void wide_issue(const DevGraph<signed char> &g, int p
 }
 // ... and the rest of the trip: draws, look-ups, stores.  wd: the quad's descriptor (nsk_compile.h seg_wide)
 template <int NCH, int MODE>
-__device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, const SegEntry &en, int p0,
-                                            const uint32_t (&wd)[NSK_WIDE_STRIDE(NCH)], const WideTrip<NCH> &t, const uint32_t *zt,
-                                            int lane, uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1) {
-    const uint32_t exc0 = wd[4 * NCH], nexc = wd[4 * NCH + 1], smask = wd[4 * NCH + 2];
+__device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, uint32_t zoff, int p0,
+                                            uint32_t exc0, uint32_t nexc, uint32_t smask, const WideTrip<NCH> &t, const uint32_t *zt,
+                                            int lane, uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
+                                            const char NSK_SCALAR *wexc_slot = nullptr, const PhiloxKeys *pk = nullptr) {
     // (the block is evaluated while the loads are in flight: without the fences the scheduler puts it behind the waits)
     __builtin_amdgcn_sched_barrier(0);
     const uint32_t blk = (uint32_t)(p0 >> 2) + (uint32_t)lane;              // wide_block: ((p0 >> 8) << 6) | lane
@@ -1825,7 +1825,7 @@ __device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, cons
     const uint32_t hq = blk * 2654435761u ^ s0;
     const u32x4 ra = {hq, hq * 40503u, hq ^ 0x9E3779B9u, hq * 7u};
 #else
-    const u32x4 ra = philox4x32(k0, k1, blk, 2u, s0, s1);
+    const u32x4 ra = pk ? philox4x32_keyed(*pk, blk, 2u, s0, s1) : philox4x32(k0, k1, blk, 2u, s0, s1);
 #endif
     asm volatile("" :: "v"(ra.x), "v"(ra.y), "v"(ra.z), "v"(ra.w));       // (the words exist HERE: the optimiser sinks them to their uses otherwise)
     __builtin_amdgcn_sched_barrier(0);
@@ -1834,7 +1834,10 @@ __device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, cons
     for (int j = 0; j < 4 * NCH; j++) idx4 |= (t.x[j] & 0x01010101u) << j;  // (a member's value is its bit; what a lane reads for a
     idx4 &= smask * 0x01010101u;                                            //  position that is an exception may be any value: masked)
     for (uint32_t e = 0; e < nexc; e++) {                                   // scalar loop, rare: the odd cells of the quad
-        const NSK_SCALAR uint32_t *xp = (const NSK_SCALAR uint32_t *)g.wide_exc + 2 * (size_t)(exc0 + e);
+        // (wexc_slot: where the kernel arguments hold the exception array's address -- read here, in the rare branch,
+        //  instead of living in two scalar registers through every trip; null: g.wide_exc)
+        const NSK_SCALAR uint32_t *xp = (wexc_slot ? *(const NSK_SCALAR uint32_t *const NSK_SCALAR *)wexc_slot
+                                                   : (const NSK_SCALAR uint32_t *)g.wide_exc) + 2 * (size_t)(exc0 + e);
         const uint32_t ex = xp[0], eid = xp[1];
         const uint32_t o = ex & 0xFFu, sh = 8u * (o & 3u) + ((ex >> 8) & 7u);
         if ((uint32_t)lane == (o >> 2)) idx4 = (idx4 & ~(1u << sh)) | (((uint32_t)(uint8_t)g.val[eid] & 1u) << sh);
@@ -1854,7 +1857,7 @@ __device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, cons
 #pragma unroll
         for (int i = 0; i < 4; i++)
             if (hi[i] == thr[i]) {
-                const uint32_t lo = g.ztab[en.zoff + ((idx4 >> (8 * i)) & 0xFFu)].y;
+                const uint32_t lo = g.ztab[zoff + ((idx4 >> (8 * i)) & 0xFFu)].y;
                 out = (out & ~(1u << (8 * i))) | (((word_of(rb, (uint32_t)i) >> 6) > lo ? 1u : 0u) << (8 * i));
             }
     }
@@ -1888,10 +1891,10 @@ __device__ __forceinline__ void tab_quad_wide(const DevGraph<signed char> &g, co
     WideTrip<NCH> t;
     if (burnin) {
         wide_issue<NCH, 1>(g, p0, base, lane, t);
-        wide_finish<NCH, 1>(g, en, p0, wd, t, zt, lane, k0, k1, s0, s1);
+        wide_finish<NCH, 1>(g, en.zoff, p0, wd[4 * NCH], wd[4 * NCH + 1], wd[4 * NCH + 2], t, zt, lane, k0, k1, s0, s1);
     } else {
         wide_issue<NCH, 0>(g, p0, base, lane, t);
-        wide_finish<NCH, 0>(g, en, p0, wd, t, zt, lane, k0, k1, s0, s1);
+        wide_finish<NCH, 0>(g, en.zoff, p0, wd[4 * NCH], wd[4 * NCH + 1], wd[4 * NCH + 2], t, zt, lane, k0, k1, s0, s1);
     }
 }
 // the block's copy of the launch's draw tables (thresholds' top 27 bits), segment s at zt + (s << NSK_ZT_BITS(NCH)).
@@ -1998,155 +2001,211 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
     }
 }
 
-// `burnin` = 2 selects the PACKED mode (nsk_gibbs.hip pack_tally): the sweep's tally lives in the value bytes themselves
-// -- bit 0 the value, bits 1-7 the number of tallied sweeps it was 1 since the last unpack (k_unpack_tally; at most 127
-// sweeps apart) -- so a trip reads the quad's own bytes instead of a tally array and leaves with ONE store.  What a class
-// launch leaves dirty in its XCDs' L2s is written back at the kernel boundary (the L2s are not coherent with each
-// other): with both stores taken out the 10M-grid launch took 6.4 instead of 10.2 us (tools/sessions/r6_s06.sh), loads
-// and the Philox block together 0.6.  Every reader of values masks bit 0 while the mode is on: it is on only for
-// handles whose every launch is this kernel's.
-// The table launch of a class whose quads are (mostly) wide ones (SegTable.wide; int8 values).  Same resident grid, XCD
-// x walks the x-th eighth of the quads, a wave's trip is a quad.  The quad descriptor -- slot bases, exception list,
-// slot mask: what the value loads wait for -- is requested ONE TRIP AHEAD (scalar load into registers that the next trip
-// reads), so a trip is: value loads (bases on hand) -> Philox block while they fly -> pack -> four LDS look-ups ->
-// compares -> two dword stores.  A quad that is not wide (a class end, a row of mixed border cells) is sampled tile by
-// tile by the round-4 routine, one tile at a time (few scalar registers: such quads are a fraction of a percent).
-#ifndef NSK_TABW_NQ
-#define NSK_TABW_NQ 1               // quads per trip of the wide-quad kernel
-#endif
+// ---- the table launch of a class whose quads are (mostly) wide ones (SegTable.wide; int8 values) ----
+// Resident grid, XCD x walks the x-th eighth of the launch's quads, a wave's trip is a quad: value loads (the quad's
+// descriptor -- slot bases, exception list, slot mask -- was requested one trip ahead by a scalar load) -> Philox block
+// while they fly -> pack -> four look-ups in the wave's LDS copy of the segment's draw table -> compares -> one or two
+// dword stores.  A quad that is not wide (a class end, a row of mixed border cells) is sampled tile by tile by the
+// round-4 routine, one tile at a time.
+// MODE 0: the tally in cnt_pos; 1: burn-in; 2: PACKED -- the sweep's tally lives in the value bytes themselves (bit 0 the
+// value, bits 1-7 the tallied sweeps it was 1 since the last k_unpack_tally, at most 127 apart): a trip reads the quad's
+// own bytes instead of a tally array and leaves with ONE store.  Every reader of values masks bit 0 while the mode is on:
+// it is on only for whole-graph handles whose every launch is this kernel's (nsk_gibbs.hip pack_now).
+// WHAT A WAVE'S LIFE IS MADE OF (per-wave s_memtime, tools/timing_tabw.py, 10M grid, r6_s10.sh): with the segment table in
+// the kernel arguments and a block-wide LDS table behind a barrier, 56 % of it lay in FRONT of the first trip -- five
+// dependent rounds of loads (kernel arguments -> segment entry -> table entries / descriptor -> ...) at ~1 us each: the
+// scalar cache and the L2s start every launch cold.  Hence:
+// * the arguments the first trip needs are the kernel's first 16 dwords and the translation unit is compiled with
+//   kernarg preloading (Makefile: -amdgpu-kernarg-preload-count=16): they are in scalar registers when the wave starts;
+//   the first segment's entry is among them (the largest segment comes first), other segments load theirs later;
+// * the draw table is copied per WAVE and segment (16 or 256 thresholds, lanes = entries): no block barrier, and the
+//   copy's loads go out with the first descriptor request;
+// * everything else in the arguments (the other segment entries, the fall-back's arrays) is touched behind the first
+//   trip's requests.
 #ifndef NSK_TABW_ATTR
 #define NSK_TABW_ATTR
 #endif
+// The hot arguments: 14 dwords (16 user scalar registers less the kernarg pointer's two).  The three other arrays are
+// given as 256-byte units from `val` (device allocations are 256-byte aligned and lie within 512 GB of each other).
+// A scalar that a (conditional) scalar load inside the trip loop produced, re-defined by an ALU move: the wait for the
+// load sits HERE.  Without it every later use inside the loop may find the register "possibly pending" (the compiler's
+// wait counters merge at the loop header; scalar loads return out of order, so the only wait is lgkmcnt(0)) -- and that
+// wait also drains the descriptor request a trip ahead right after it was issued.
+__device__ __forceinline__ uint32_t nsk_settled(uint32_t x) { uint32_t y; asm volatile("s_mov_b32 %0, %1" : "=s"(y) : "s"(x)); return y; }
+template <typename T> __device__ __forceinline__ T *nsk_settled_ptr(T *p) {
+    const unsigned long long v = (unsigned long long)p;
+    return (T *)(((unsigned long long)nsk_settled((uint32_t)(v >> 32)) << 32) | nsk_settled((uint32_t)v));
+}
+#define NSK_TABW_HOT signed char *val, int d_cnt, int d_wide, int d_ztab, int ts1, uint32_t ntl0, int pos00, uint32_t woff0,          \
+                     uint32_t zoff0, uint32_t ntiles_nseg, uint32_t zmask0_wpx, const unsigned long long *sweep_base
+struct TabwCold {                   // ... and the rest, read through a laundered pointer BEHIND the first trip's requests
+    uint32_t k0, k1, s0, s1;        //     (the compiler hoists every load of a kernel argument to the kernel's entry)
+    uint32_t sweep_off, pad_;
+    DevGraph<signed char> g;
+    SegTable tab;
+};
+#define NSK_TABW_COLD_OFFSET 56     // byte offset of the TabwCold argument in the kernarg segment (14 dwords in front, 8-aligned)
 template <int NCH, int MODE>
-__global__ __launch_bounds__(NSK_BLOCK) NSK_TABW_ATTR void k_gibbs_seg_tabw(DevGraph<signed char> g, SegTable tab,
-                                                              uint32_t k0, uint32_t k1, uint32_t s0, uint32_t s1,
-                                                              const unsigned long long *sweep_base, uint32_t sweep_off) {
+__global__ __launch_bounds__(NSK_BLOCK) NSK_TABW_ATTR void k_gibbs_seg_tabw(NSK_TABW_HOT, TabwCold cold_unused) {
     const int lane = (int)(threadIdx.x & 63);
-    __shared__ uint32_t zt[NSK_SEG_MAX << NSK_ZT_BITS(NCH)];
-    // the table's loads go out first, the LDS stores and the block's barrier come behind the first descriptor request
-    uint32_t ztv[NSK_ZT_PER_THREAD(NCH)];
-    tab_fill_request<NCH>(g.ztab, tab, ztv);
-    bool landed = false;
-    if (sweep_base) {             // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
-        const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
-        const unsigned long long sw = cb[0] + sweep_off, key = cb[2];
-        s0 = (uint32_t)sw;
-        s1 = (uint32_t)(sw >> 32) ^ (uint32_t)cb[3];
-        k0 = (uint32_t)key;
-        k1 = (uint32_t)(key >> 32);
-    }
-    constexpr int ST = NSK_WIDE_STRIDE(NCH);
-    const int nquads = tab.ntiles >> 2;                                 // virtual tiles: a multiple of 4
+#ifdef NSK_ABL_TIMING       // (instrumented build, tools/timing_tabw.py: per wave entry / first requests out / first trip done / exit)
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long dbg_t1 = 0, dbg_t2 = 0;
+    int dbg_trips = 0;
+#endif
+    constexpr int ST = NSK_WIDE_STRIDE(NCH), ZN = 1 << NSK_ZT_BITS(NCH), ZR = (ZN + 63) / 64;
+    __shared__ uint32_t zt_all[(NSK_BLOCK / 64) * ZN];                  // one table per wave
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *zt = zt_all + wv * ZN;
+    uint8_t *cnt_pos = (uint8_t *)val + (long long)d_cnt * 256;
+    const uint32_t *seg_wide = (const uint32_t *)((const char *)val + (long long)d_wide * 256);
+    const uint4 *ztab = (const uint4 *)((const char *)val + (long long)d_ztab * 256);
+    const int ntiles = (int)(ntiles_nseg & 0x0FFFFFFFu);          // (bits 28-31: segments - 1; tile_start = ntiles beyond them)
+    const uint32_t zmask0 = zmask0_wpx & 0xFFu;
+    const int wpx = (int)(zmask0_wpx >> 8);                             // waves per XCD
+    const int nquads = ntiles >> 2;                                     // virtual tiles: a multiple of 4
     const int per = (nquads + 7) >> 3;                                  // quads per XCD
     const int xcd = (int)(blockIdx.x & 7);
-    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64) + (int)(threadIdx.x >> 6));
-    const int wpx = (int)(gridDim.x >> 3) * (NSK_BLOCK / 64);           // waves per XCD
+    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64)) + wv;
     const int q0 = min(nquads, xcd * per), q1 = min(nquads, (xcd + 1) * per);
-    // (the scalar unit is shared by the CU's waves, one instruction per cycle: the trip below is written for few scalar
-    // instructions -- one descriptor load, running position and quad counters, three compares -- and without
-    // wave-uniform branches around its loads and stores (MODE is a template parameter), so that every wait is counted)
-    // A trip is NQ consecutive quads of one segment (NSK_TABW_NQ): their requests go out together.  The XCD's quads are
-    // dealt segment by segment: inside a segment trip u of wave w is quads [Qs + NQ (w + u wpx), + NQ).
-    constexpr int NQ = NSK_TABW_NQ;
-    for (int sidx = 0; sidx < tab.n; sidx++) {
-        const SegEntry en = tab.e[sidx];
-        const int c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
-        const int qs = en.tile_start >> 2;                              // the segment's first quad of the launch
-        const int Qb = max(q0, qs), Qe = min(q1, c_hi >> 2);            // ... and its quads in this XCD's share
-        if (Qb >= Qe) continue;
-        const int lead = (int)(en.ntiles_lead >> 30), nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
-        // quads [qin_lo, qin_hi) of the launch lie wholly inside the run (all but a first one with dead lead tiles and a
-        // last one with fewer than four tiles)
-        const int qin_lo = qs + (lead ? 1 : 0), qin_hi = qs + ((lead + nt) >> 2);
-        const bool hasw = en.wide_off != NSK_NO_STREAM;
-        const NSK_SCALAR uint32_t *wseg = (const NSK_SCALAR uint32_t *)(g.seg_wide + (hasw ? en.wide_off : 0u));
-        const int ilast = (Qe - 1 - qs) * ST;                           // (a request past the share's last quad re-reads that one)
-        const uint32_t *zts = zt + (sidx << NSK_ZT_BITS(NCH));
-        int Q = Qb + NQ * wx;
-        if (Q >= Qe) continue;
-        int p0 = en.pos0 + (4 * Q - en.tile_start - lead) * 64;         // the first quad's first position
-        uint32_t cur[NQ][ST];
-#pragma unroll
-        for (int k = 0; k < NQ; k++) {
-#pragma unroll
-            for (int j = 0; j < ST; j++) cur[k][j] = 0xFFFFFFFFu;
+    // the cold arguments: nothing of them is read before the first trip's requests are out (`keyed`)
+    const char NSK_SCALAR *ka = (const char NSK_SCALAR *)__builtin_amdgcn_kernarg_segment_ptr();
+    const TabwCold NSK_SCALAR *cold = nullptr;
+    uint32_t k0 = 0, k1 = 0, s0 = 0, s1 = 0;
+    DevGraph<signed char> gh;
+    gh.val = val; gh.cnt_pos = cnt_pos; gh.ztab = ztab; gh.seg_wide = seg_wide;
+    PhiloxKeys pk;
+    bool keyed = false;
+    (void)cold_unused;
+    // The wave's quads: Q = q0 + wx, + wpx, ... < q1, through the launch's segments in order.  The first segment's entry
+    // is in the preloaded arguments; a wave whose quad lies in a later one reads that entry from the kernel arguments
+    // (every segment is whole quads: no quad straddles two).  The trips inside a segment are the inner loop: the scalar
+    // unit is shared by the CU's waves, one instruction per cycle, so what a trip does not need to recompute is hoisted.
+    int sidx = 0, tstart = 0, tend = ts1, pos0s = pos00;
+    uint32_t ntl = ntl0, woff = woff0, zoff = zoff0, zmask = zmask0;
+    for (int Q = q0 + wx; Q < q1;) {
+        if (4 * Q >= tend) {                                            // (wave-uniform) on to the quad's segment
+            if (!cold) { asm volatile("" : "+s"(ka)); cold = (const TabwCold NSK_SCALAR *)(ka + NSK_TABW_COLD_OFFSET); }
+            const SegTable NSK_SCALAR *tb = &cold->tab;
+            do {
+                sidx++;
+                tend = sidx + 1 < NSK_SEG_MAX ? tb->e[sidx + 1].tile_start : ntiles;
+            } while (4 * Q >= tend);
+            tstart = (int)nsk_settled((uint32_t)tb->e[sidx].tile_start); pos0s = (int)nsk_settled((uint32_t)tb->e[sidx].pos0);
+            ntl = nsk_settled(tb->e[sidx].ntiles_lead); woff = nsk_settled(tb->e[sidx].wide_off);
+            zoff = nsk_settled(tb->e[sidx].zoff); zmask = nsk_settled(tb->e[sidx].zmask_ev) & 0xFFu;
+            tend = (int)nsk_settled((uint32_t)tend);
         }
-        if (hasw) {
+        const int qs = tstart >> 2;                                     // the segment's first quad of the launch
+        const int Qe = min(q1, tend >> 2);                              // ... and the end of its quads in this XCD's share
+        const int lead = (int)(ntl >> 30), nt = (int)(ntl & 0x3FFFFFFFu);
+        // quads [qin_lo, qin_lo + qin_n) of the launch lie wholly inside the run (all but a first one with dead lead tiles
+        // and a last one with fewer than four tiles)
+        const int qin_lo = qs + (lead ? 1 : 0);
+        const uint32_t qin_n = (uint32_t)(qs + ((lead + nt) >> 2) - qin_lo);
+        const bool hasw = woff != NSK_NO_STREAM;
+        // descriptor of quad Q (!hasw: words of the array's front, not looked at), its address advancing with the trips
+        const NSK_SCALAR uint32_t *wq = (const NSK_SCALAR uint32_t *)(seg_wide + (hasw ? woff : 0u)) + (hasw ? (size_t)(Q - qs) * ST : 0);
+        const size_t wstep = hasw ? (size_t)wpx * ST : 0;
+        int p0 = pos0s + (4 * Q - tstart - lead) * 64;                  // the quad's first position
+        uint32_t cur[ST];
 #pragma unroll
-            for (int k = 0; k < NQ; k++) {
-                const int in = min((Q + k - qs) * ST, ilast);
+        for (int j = 0; j < ST; j++) cur[j] = wq[j];
+        // the wave's copy of the segment's thresholds (their top 27 bits), lanes = entries: requested here, stored to LDS
+        // behind the first trip's value requests
+        uint32_t ztv[ZR];
 #pragma unroll
-                for (int j = 0; j < ST; j++) cur[k][j] = wseg[(size_t)in + j];
-            }
+        for (int r = 0; r < ZR; r++) {
+            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)r;
+            ztv[r] = e <= zmask ? ztab[zoff + e].x : 0u;
         }
-        if (!landed) { tab_fill_land<NCH>(zt, ztv); landed = true; }
-        for (; Q < Qe; Q += NQ * wpx, p0 += 256 * NQ * wpx) {
-            bool wide[NQ], all = true;
-            uint32_t dsc[NQ][ST];
+        bool land = true;
+        for (; Q < Qe; Q += wpx, p0 += 256 * wpx) {
+#ifdef NSK_ABL_TIMING
+            if (dbg_trips == 1) { __builtin_amdgcn_s_waitcnt(0); dbg_t2 = __builtin_amdgcn_s_memtime(); }
+            dbg_trips++;
+#endif
+            // (the descriptor's registers are free for the next one as soon as the bases are in the loads' addresses)
+            const bool flagged = hasw && cur[0] != 0xFFFFFFFFu, wide = flagged && (uint32_t)(Q - qin_lo) < qin_n;
+            const uint32_t exc0 = cur[4 * NCH], nexc = cur[4 * NCH + 1], smask = cur[4 * NCH + 2];
+            asm volatile("" :: "s"(cur[4 * NCH + 3])); // (the descriptor's spare word stays live while the request flies: its
+                                                       //  register handed to a temporary means a wait for the whole request)
+            WideTrip<NCH> tc;
+            if (wide) {
+                uint32_t bc[4 * NCH];
 #pragma unroll
-            for (int k = 0; k < NQ; k++) {
-                wide[k] = cur[k][0] != 0xFFFFFFFFu && Q + k >= qin_lo && Q + k < qin_hi && Q + k < Qe;
-                all = all && wide[k];
-#pragma unroll
-                for (int j = 0; j < ST; j++) dsc[k][j] = cur[k][j];
+                for (int j = 0; j < 4 * NCH; j++) bc[j] = cur[j];
+                wide_issue<NCH, MODE>(gh, p0, bc, lane, tc);
             }
-            // the next trip's descriptors: a scalar round trip ahead
-            if (hasw) {
+            // the next trip's descriptor, a scalar round trip ahead (always a load, into the registers the bases just
+            // left: past the segment's quads this quad's again)
+            if (Q + wpx < Qe) wq += wstep;
 #pragma unroll
-                for (int k = 0; k < NQ; k++) {
-                    const int in = min((Q + NQ * wpx + k - qs) * ST, ilast);
-#pragma unroll
-                    for (int j = 0; j < ST; j++) cur[k][j] = wseg[(size_t)in + j];
+            for (int j = 0; j < ST; j++) cur[j] = wq[j];
+            if (land) {
+                land = false;
+                if (!keyed) {             // the wave's first requests are out: now the cold arguments
+                    keyed = true;
+                    if (!cold) { asm volatile("" : "+s"(ka)); cold = (const TabwCold NSK_SCALAR *)(ka + NSK_TABW_COLD_OFFSET); }
+                    k0 = cold->k0; k1 = cold->k1; s0 = cold->s0; s1 = cold->s1;
+                    if (sweep_base) {     // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
+                        const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
+                        const unsigned long long sw = cb[0] + cold->sweep_off, key = cb[2];
+                        s0 = (uint32_t)sw;
+                        s1 = (uint32_t)(sw >> 32) ^ (uint32_t)cb[3];
+                        k0 = (uint32_t)key;
+                        k1 = (uint32_t)(key >> 32);
+                    }
+                    k0 = nsk_settled(k0); k1 = nsk_settled(k1); s0 = nsk_settled(s0); s1 = nsk_settled(s1);
+                    pk = philox_round_keys(k0, k1);
                 }
+#pragma unroll
+                for (int r = 0; r < ZR; r++)
+                    if (lane + 64 * r < ZN) zt[lane + 64 * r] = ztv[r];
+                asm volatile("" ::: "memory");                          // (LDS executes a wave's accesses in order: no barrier)
+#ifdef NSK_ABL_TIMING
+                if (!dbg_t1) dbg_t1 = __builtin_amdgcn_s_memtime();
+#endif
             }
-            if (all) {              // the common trip: straight line -- all requests, then the quads one after the other
-                WideTrip<NCH> tc[NQ];
-#pragma unroll
-                for (int k = 0; k < NQ; k++) {
-                    uint32_t bc[4 * NCH];
-#pragma unroll
-                    for (int j = 0; j < 4 * NCH; j++) bc[j] = dsc[k][j];
-                    wide_issue<NCH, MODE>(g, p0 + 256 * k, bc, lane, tc[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < NQ; k++) wide_finish<NCH, MODE>(g, en, p0 + 256 * k, dsc[k], tc[k], zts, lane, k0, k1, s0, s1);
+            if (wide) {
+                wide_finish<NCH, MODE>(gh, zoff, p0, exc0, nexc, smask, tc, zt, lane, k0, k1, s0, s1,
+                                       ka + NSK_TABW_COLD_OFFSET + offsetof(TabwCold, g) + offsetof(DevGraph<signed char>, wide_exc), &pk);
                 continue;
             }
-#pragma unroll 1
-            for (int k = 0; k < NQ; k++) {
-                if (Q + k >= Qe) break;
-                uint32_t dk[ST];
-                bool wk = false;
+            // not a wide quad (a class end, mixed border cells): tile by tile.  Its block: the run's first position less
+            // its lead tiles is a multiple of 256, so (pos >> 8, lane) names it
+            SegEntry en;
+            {
+                const NSK_SCALAR uint32_t *ep = (const NSK_SCALAR uint32_t *)(ka + NSK_TABW_COLD_OFFSET + offsetof(TabwCold, tab) +
+                                                                              offsetof(SegTable, e) + sizeof(SegEntry) * (size_t)sidx);
+                uint32_t ew[sizeof(SegEntry) / 4];
 #pragma unroll
-                for (int kk = 0; kk < NQ; kk++)
-                    if (kk == k) {
-                        wk = wide[kk];
-#pragma unroll
-                        for (int j = 0; j < ST; j++) dk[j] = dsc[kk][j];
-                    }
-                if (wk) {
-                    WideTrip<NCH> t1;
-                    uint32_t bc[4 * NCH];
-#pragma unroll
-                    for (int j = 0; j < 4 * NCH; j++) bc[j] = dk[j];
-                    wide_issue<NCH, MODE>(g, p0 + 256 * k, bc, lane, t1);
-                    wide_finish<NCH, MODE>(g, en, p0 + 256 * k, dk, t1, zts, lane, k0, k1, s0, s1);
-                    continue;
-                }
-                // not a wide quad (a class end, mixed border cells): tile by tile.  Its block: en.pos0 - 64 lead is a
-                // multiple of 256, so (pos >> 8, lane) names it
-                const int t0q = 4 * (Q + k) - en.tile_start - lead;
-                const uint32_t qb = quad_block((uint32_t)(p0 + 256 * k + lane));
-                const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
-                u32x4 rb = {0u, 0u, 0u, 0u};
-                bool have_b = false;
-#pragma unroll 1
-                for (int t = 0; t < 4; t++)
-                    tab_tiles<signed char, NCH, 1, MODE == 2>(g, en, t0q + t, t, lane, MODE == 1 ? 1 : 0, ra, rb, have_b, qb, k0, k1, s0, s1, dk[0] != 0xFFFFFFFFu);
+                for (int j = 0; j < (int)(sizeof(SegEntry) / 4); j++) ew[j] = ep[j];
+                __builtin_memcpy(&en, ew, sizeof(SegEntry));
             }
+            DevGraph<signed char> gf = gh;                              // (the fall-back's arrays: read here, not kept)
+            gf.adj = cold->g.adj; gf.seg_aff = cold->g.seg_aff; gf.sink = cold->g.sink;
+            const int t0q = 4 * Q - tstart - lead;
+            const uint32_t qb = quad_block((uint32_t)(p0 + lane));
+            const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
+            u32x4 rb = {0u, 0u, 0u, 0u};
+            bool have_b = false;
+#pragma unroll 1
+            for (int t = 0; t < 4; t++)
+                tab_tiles<signed char, NCH, 1, MODE == 2>(gf, en, t0q + t, t, lane, MODE == 1 ? 1 : 0, ra, rb, have_b, qb, k0, k1, s0, s1, flagged);
         }
     }
-    if (!landed) tab_fill_land<NCH>(zt, ztv);                            // (a wave without quads still meets its block's barrier)
+#ifdef NSK_ABL_TIMING
+    {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long dbg_t3 = __builtin_amdgcn_s_memtime();
+        const int slot = (int)((blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6)) & 16383u);
+        if (lane == 0) {
+            nsk_dbg[4 * slot] = dbg_t0; nsk_dbg[4 * slot + 1] = dbg_t1; nsk_dbg[4 * slot + 2] = dbg_t2;
+            nsk_dbg[4 * slot + 3] = dbg_t3 | ((unsigned long long)dbg_trips << 56);
+        }
+    }
+#endif
 }
 
 // The fused-exchange flavour of tab_tiles / k_gibbs_seg_tab below (P2P = true is the only instantiation; buffer

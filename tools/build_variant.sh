@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../numbskull_amd/csrc"
 mkdir -p ../variants build
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function ${NSK_PRELOAD--mllvm -amdgpu-kernarg-preload-count=16}"
 v=$1; extra=$2; TU=${3:-gibbs}
 LEARN="build/nsk_learn_p0.o build/nsk_learn_p1.o build/nsk_learn_p2.o build/nsk_learn_p3.o"
 if [ "$TU" = learn ]; then
