@@ -58,6 +58,7 @@ WORKLOADS = {
     # 4x / 10x the metric config.  With implicit adjacency a sweep of the 40M grid moves ~190 MB (it was
     # 800 MB in round 2) and fits the 256 MiB Infinity Cache again; the 100M grid (~450 MB per sweep) is
     # the one beyond it
+    "ising4m": (2000, 2000, False),
     "ising40m": (5000, 8000, False),
     "ising100m": (10000, 10000, False),
 }

@@ -718,6 +718,14 @@ static int build_segment_adjacency(Compiled &c, std::string &err) {
     return NSK_OK;
 }
 
+// Wide quads pay from a few million variables per handle on: a class launch of the 1M grid is one wave lifetime long
+// either way, and the tile-by-tile kernel's is shorter (one MI355X, tools/sessions/r6_s14.sh: 1M grid 9.1 against 10.9 us
+// per sweep, 4M grid 14.3 / 14.3, 10M grid 23.9 / 17.2).  NSK_DIAG=1 NSK_WIDE_MIN=n moves the bound (the tests use 0).
+static int64_t wide_min_variables() {
+    const char *e = diag_env("NSK_WIDE_MIN");
+    return e ? atoll(e) : 3000000;
+}
+
 // Wide quads of table segments (nsk_compile.h seg_wide): per quad the slot bases when one lane can take four
 // consecutive positions, plus the few positions whose member lies elsewhere (exceptions).
 static int build_segment_wide(Compiled &c, std::string &err) {
@@ -725,7 +733,9 @@ static int build_segment_wide(Compiled &c, std::string &err) {
     c.wide_exc.clear();
     c.ntab_quads = c.nwide_quads = 0;
     for (Compiled::Segment &sg : c.segments) sg.wide = -1;
-    if (c.vbytes != 1 || diag_env("NSK_NO_WIDE")) { c.seg_wide.assign(4, 0xFFFFFFFFu); c.wide_exc.assign(2, 0u); return NSK_OK; }
+    if (c.vbytes != 1 || diag_env("NSK_NO_WIDE") || c.nsampled < wide_min_variables()) {
+        c.seg_wide.assign(4, 0xFFFFFFFFu); c.wide_exc.assign(2, 0u); return NSK_OK;
+    }
     uint64_t ndw = 0;
     for (Compiled::Segment &sg : c.segments) {
         if (sg.ztab < 0) continue;
@@ -1904,7 +1914,7 @@ static int place_variables(const nsk_graph_desc *d, Compiled &c, int32_t ncolors
     };
     if (int rc = lay()) return rc;
     lap("positions: arrays");
-    if (c.vbytes == 1 && !diag_env("NSK_NO_WIDE") && !diag_env("NSK_NO_RUN_PAD")) {
+    if (c.vbytes == 1 && !diag_env("NSK_NO_WIDE") && !diag_env("NSK_NO_RUN_PAD") && c.nsampled >= wide_min_variables()) {
         // the runs of the big exact classes in the layout just made
         bool any = false;
         for (const ClassAt &ca : exact_at) {

@@ -326,7 +326,8 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
     return NSK_OK;
 }
 
-#ifdef NSK_ABL_TIMING
+
+#ifdef NSK_ABL_TIMING       // (instrumented build: the per-wave time stamps of the last wide-quad launch, tools/timing_tabw.py)
 extern "C" int nsk_debug_dump(unsigned long long *out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk::nsk_dbg), sizeof(unsigned long long) * (size_t)n);
 }

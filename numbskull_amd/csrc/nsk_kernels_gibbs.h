@@ -365,11 +365,7 @@ struct GenChain {
         const uint32_t idx = (d1 & 15u) | (((d1 >> 7) & 1u) << 4) | (nomember << 5) |
                              ((allnz ? 1u : 0u) << 6) | ((pv ? 1u : 0u) << 7) | ((any1 ? 1u : 0u) << 8) |
                              ((alleq ? 1u : 0u) << 9) | ((ln ? 1u : 0u) << 10);
-#ifdef NSK_ABL_NOLUT
-        const uint32_t e = idx & 0x3Fu;
-#else
         const uint32_t e = lut[idx];
-#endif
         A = (int)(e & 3u) - 1;
         B = (int)((e >> 2) & 3u) - 1;
         const uint32_t sel = e >> 4;                    // cstar: 0, 1, first member's value, own dense_equal_to
@@ -783,10 +779,6 @@ __device__ __forceinline__ void heavy_update_ep(const DevGraph<VT> &g, const uin
     }
 }
 
-#ifdef NSK_ABL_TIMING
-// instrumented build (tools/build_ablations.sh TIMING): per general tile {start, after walk, end, len}
-static __device__ unsigned long long nsk_dbg[4 * 65536];
-#endif
 
 template <typename VT, int MAXC>
 __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const uint8_t *lut, const uint4 *sp,
@@ -795,9 +787,6 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
                                                    int burnin, uint32_t k0, uint32_t k1, uint32_t s0,
                                                    uint32_t s1) {
     const int len = (int)(tdw & 0xFFu), maxcard = (int)((tdw >> 12) & 15u);
-#ifdef NSK_ABL_TIMING
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-#endif
     const uint32_t info = valid ? g.p_info[p] : (2u << 9);
     GenPot<MAXC> pot;
     pot.clear();
@@ -806,44 +795,21 @@ __device__ __forceinline__ void gibbs_tile_general(const DevGraph<VT> &g, const 
         a.close(d1, lut, cstar, A, B);
         pot.add(maxcard, d1, w, cstar, A, B);
     };
-#ifdef NSK_ABL_NOWALK
-    if (len < 0)
-#else
     if ((tdw >> 19) & 1u)                      // materialised weight rows (large weight tables)
-#endif
         general_walk<VT, false, 1, true>(g, g.val, g.val, sp, len, (int)((tdw >> 16) & 7u), prog,
                                    g.adj_wt + (size_t)wrow * 64 + (threadIdx.x & 63), on_entry);
-#ifndef NSK_ABL_NOWALK
     else
         general_walk<VT, false, 0, true>(g, g.val, g.val, sp, len, (int)((tdw >> 16) & 7u), prog, nullptr, on_entry);
-#endif
     const int ev = NSK_INFO_EV(info);
-#ifdef NSK_ABL_TIMING
-    const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime() + (unsigned long long)(pot.p[0] == 12345.678 ? 1 : 0);
-#endif
     if (!valid || !(ev == 0 || sample_evidence)) return;
     const int card = NSK_INFO_CARD(info);
-#ifdef NSK_ABL_NODRAW
-    const int nv = pot.p[0] > pot.p[1] ? 0 : 1;
-#else
     const uint2 rr = inf_words(k0, k1, (uint32_t)p, s0, s1);
     const int nv = pot.draw(maxcard, card, u53(rr.x, rr.y));
-#endif
     g.val[p] = (VT)nv;
     if (!burnin) {
         if (card == 2) g.cnt_pos[p] = (uint8_t)(g.cnt_pos[p] + nv);
         else g.cnt[g.p_cnt[p] + nv] += 1;
     }
-#ifdef NSK_ABL_TIMING
-    {
-        const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
-        const int slot = (p / 64) & 65535;
-        if ((threadIdx.x & 63) == 0) {
-            nsk_dbg[4 * slot] = dbg_t0; nsk_dbg[4 * slot + 1] = dbg_t1; nsk_dbg[4 * slot + 2] = dbg_t2;
-            nsk_dbg[4 * slot + 3] = (unsigned long long)len | ((unsigned long long)blockIdx.x << 32);
-        }
-    }
-#endif
 }
 
 template <typename VT>
@@ -926,24 +892,12 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_general(DevGraph<VT> g, int
     load_gen_lut(lut);
     if ((int)blockIdx.x < hblocks) {                      // block-uniform
         const int hp = hb + (int)(blockIdx.x * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
-#ifndef NSK_ABL_NOHUB
         if (hp < he) {
             const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + hub0 + (hp - hb));
             const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
-#ifdef NSK_ABL_TIMING
-            const unsigned long long hub_t0 = __builtin_amdgcn_s_memtime();
-#endif
             if (hd.y) heavy_update_ep(g, lut, hp, hd, sample_evidence, burnin, k0, k1, s0, s1);
             else heavy_update(g, hp, sample_evidence, burnin, k0, k1, s0, s1);
-#ifdef NSK_ABL_TIMING
-            if ((threadIdx.x & 63) == 0) {
-                const int slot = 60000 + ((hub0 + hp - hb) & 4095);
-                nsk_dbg[4 * slot] = hub_t0; nsk_dbg[4 * slot + 1] = hub_t0; nsk_dbg[4 * slot + 2] = __builtin_amdgcn_s_memtime();
-                nsk_dbg[4 * slot + 3] = 1000ull + hd.y;
-            }
-#endif
         }
-#endif
         return;
     }
     const int tblocks = 8 * ((nblocks + 7) / 8);
@@ -1047,11 +1001,7 @@ __device__ __forceinline__ void ep_load_row(const uint32_t *adj, uint32_t sub0, 
 // 96-register variant of the small graphs spilling (5M: 49.6 -> 55.7 us); two rows per step 411.0 / 66.5 us:
 // a step no longer waits for its own prefetch; what a group takes now is the serial structure of its pass.
 // tools/sessions/r5_s20.sh, r5_s21.sh)
-#ifdef NSK_EP_WIN
-#define NSK_EP_WIN_ON true
-#else
 #define NSK_EP_WIN_ON false         // (value windows: measured, not in the default build -- nsk_compile.h ep_win)
-#endif
 // wa / wb: the group's value windows in LDS (ep_stage_window; `win`: in use) -- a member word whose id field is
 // NSK_EP_WIN_BASE + o reads byte o of the window instead of gathering from the value array
 template <typename VT, bool TWO, int WMODE, bool NT, bool MEMBERS, int U, typename FN>
@@ -1082,29 +1032,17 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
 #pragma unroll
             for (int m = 0; m < 3; m++) { xa[u][m] = 0; xb[u][m] = 0; }
             if (r + 4 * u >= total) continue;                       // wave-uniform
-#ifdef NSK_ABL_EPNOW
-            w[u] = WMODE ? __longlong_as_double(0x3FB0000000000000ll | (long long)cur[u].w0) : 0.0;
-#else
             // (learning gathers the weight -- 68 % of the bytes a 50M-variable class fetches: the 8 MB table does
             // not stay in a 4 MB L2 next to the rows and values.  A non-temporal gather, so that the weight lines
             // would at least not evict the others, was measured (-DNSK_EP_W_NT, tools/sessions/r5_s02.sh): 5M LR
             // 120.6 -> 144.1 us per class, 50M 1088 -> 1306 -- the hot low ids DO hit the L2 when they may stay)
-#ifdef NSK_EP_W_NT
-            w[u] = WMODE == 1 ? __builtin_nontemporal_load(g.w + NSK_EP_WID(cur[u].w0)) : (WMODE == 2 ? wc[u] : 0.0);
-#else
             w[u] = WMODE == 1 ? g.w[NSK_EP_WID(cur[u].w0)] : (WMODE == 2 ? wc[u] : 0.0);
-#endif
-#endif
             if (MEMBERS) {
 #pragma unroll
                 for (int m = 0; m < 3; m++)
                     if (Mc[u] > m) {                                // wave-uniform
                         const uint32_t id = cur[u].m[m] & NSK_GEN_NULL;
                         const uint32_t at = id == NSK_GEN_NULL ? 0u : id;
-#ifdef NSK_ABL_EPNOVAL
-                        xa[u][m] = (int)(at & 1u);
-                        if (TWO) xb[u][m] = (int)((at >> 1) & 1u);
-#else
                         if (NSK_EP_WIN_ON && sizeof(VT) == 1 && win && id >= NSK_EP_WIN_BASE && id != NSK_GEN_NULL) {     // in the group's window
                             xa[u][m] = (int)wa[id - NSK_EP_WIN_BASE];
                             if (TWO) xb[u][m] = (int)wb[id - NSK_EP_WIN_BASE];
@@ -1112,7 +1050,6 @@ __device__ __forceinline__ void ep_pass(const DevGraph<VT> &g, const VT *va, con
                             xa[u][m] = (int)va[at];
                             if (TWO) xb[u][m] = (int)vb[at];
                         }
-#endif
                     }
             }
         }
@@ -1154,11 +1091,7 @@ __device__ __forceinline__ void ep_stage_window(const DevGraph<VT> &g, int gidx,
         if (TWO) wb[i] = *((const nsk_u32x4 *)g.val_evid + c);
     }
 }
-#ifdef NSK_EP_WIN
-#define NSK_EP_WIN_LDS(VT) (sizeof(VT) == 1 ? NSK_EP_WIN_CHUNKS : 1)
-#else
 #define NSK_EP_WIN_LDS(VT) 1          // (value windows are not in the default build: nsk_compile.h ep_win)
-#endif
 
 // ep_wt row <- the weights its entries name (run whenever weights may have changed, before an
 // inference call): one workgroup per group, its rows dealt to the waves
@@ -1295,34 +1228,20 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
     // blocks [0, nbh): one long-list hub each; [nbh, hblocks): one wave per hub position; then the
     // resident group blocks; then the colour's rest tiles
     if ((int)blockIdx.x < nbh) {
-#ifndef NSK_ABL_NOHUB
         const int hp = (int)__builtin_amdgcn_readfirstlane(g.bighub_pos[bh0 + (int)blockIdx.x]);
         const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + hub0 + (hp - hb));
         const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
         block_hub_update(g, lut, hp, hd, ws, fs, sample_evidence, burnin, k0, k1, s0, s1);
-#endif
         return;
     }
     if ((int)blockIdx.x < hblocks) {                      // hub blocks: as in k_gibbs_general
         const int hp = hb + (int)((blockIdx.x - nbh) * (NSK_BLOCK / 64) + (threadIdx.x >> 6));
-#ifndef NSK_ABL_NOHUB
         if (hp < he && !*(const NSK_SCALAR uint32_t *)((const uint32_t *)(g.hub_desc + hub0 + (hp - hb)) + 3)) {
             const NSK_SCALAR uint32_t *hdp = (const NSK_SCALAR uint32_t *)(g.hub_desc + hub0 + (hp - hb));
             const uint4 hd = {hdp[0], hdp[1], hdp[2], hdp[3]};
-#ifdef NSK_ABL_TIMING
-            const unsigned long long hub_t0 = __builtin_amdgcn_s_memtime();
-#endif
             if (hd.y) heavy_update_ep(g, lut, hp, hd, sample_evidence, burnin, k0, k1, s0, s1);
             else heavy_update(g, hp, sample_evidence, burnin, k0, k1, s0, s1);
-#ifdef NSK_ABL_TIMING
-            if ((threadIdx.x & 63) == 0) {
-                const int slot = 60000 + ((hub0 + hp - hb) & 4095);
-                nsk_dbg[4 * slot] = hub_t0; nsk_dbg[4 * slot + 1] = hub_t0; nsk_dbg[4 * slot + 2] = __builtin_amdgcn_s_memtime();
-                nsk_dbg[4 * slot + 3] = 1000ull + hd.y + ((unsigned long long)(g.slot_off[g.p_slot[hp] + 1] - g.slot_off[g.p_slot[hp]]) << 32);
-            }
-#endif
         }
-#endif
         return;
     }
     if ((int)blockIdx.x >= hblocks + gblocks) {           // the colour's uniform / shape tiles outside segments
@@ -1340,10 +1259,6 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
         const NSK_SCALAR uint32_t *gdp = (const NSK_SCALAR uint32_t *)(g.ep_desc + group0 + gi);
         const uint32_t gsub = gdp[0], grows0 = gdp[1], gmax = gdp[2], grows1 = gdp[3];
         const int ne = (int)(gmax & 255u);
-#ifdef NSK_ABL_TIMING
-        const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-        unsigned long long dbg_t1 = dbg_t0;
-#endif
         // this lane's variable (phase 2): requested now, needed after the entries
         const int tile = tile0 + 4 * gi + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (a scalar: see ep_pass)
         const bool tile_ok = tile < tile0 + ntiles;                       // wave-uniform
@@ -1367,7 +1282,6 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
             for (int i = (int)threadIdx.x; i < NSK_EP_LIST * 128; i += NSK_BLOCK)      // slots no entry writes:
                 ((uint32_t *)fs)[i] = 14u | (14u << 16);                                   // owned by no candidate
             __syncthreads();
-#ifndef NSK_ABL_EPNOP1
             auto entry_done = [&](uint32_t w0, uint32_t d1, const GenChain &a, const GenChain &, double w) {
                     int cstar, A, B;
                     a.close(d1, lut, cstar, A, B);
@@ -1380,12 +1294,7 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
                 };
             ep_pass<VT, false, 2, true, true, NSK_EP_U_INF>(g, g.val, g.val, sub, rowsw, g.ep_wt + (size_t)wrow * 64,
                 (const signed char *)wina, (const signed char *)wina, g.ep_win != nullptr, entry_done);
-#endif
-#ifdef NSK_ABL_TIMING
-            if (pass == 0) dbg_t1 = __builtin_amdgcn_s_memtime();
-#endif
             __syncthreads();
-#ifndef NSK_ABL_EPNOP2
             const int nacc = min(NSK_EP_LIST, ne - pass * NSK_EP_LIST);
             if (tile_ok)
                 for (int o = 0; o < nacc; o++) {
@@ -1393,33 +1302,20 @@ __device__ __forceinline__ void gibbs_ep_body(const DevGraph<VT> &g, int pbegin,
                     const double w = ws[o * 256 + (int)threadIdx.x];
                     pot.add_ks(maxcard, (int)(f & 15u), w, (int)((f >> 4) & 15u), (int)((f >> 8) & 3u) - 1, (int)((f >> 10) & 3u) - 1);
                 }
-#endif
             sub += (uint32_t)ep_pass_subrows(rowsw);
             wrow += (uint32_t)ep_pass_rows(rowsw);
         }
         const int ev = NSK_INFO_EV(info);
         if (valid && (ev == 0 || sample_evidence)) {
             const int card = NSK_INFO_CARD(info);
-#ifdef NSK_ABL_NODRAW
-            const int nv = pot.p[0] > pot.p[1] ? 0 : 1;
-#else
             const uint2 rr = inf_words(k0, k1, (uint32_t)p, s0, s1);
             const int nv = pot.draw(maxcard, card, u53(rr.x, rr.y));
-#endif
             g.val[p] = (VT)nv;
             if (!burnin) {
                 if (card == 2) g.cnt_pos[p] = (uint8_t)(g.cnt_pos[p] + nv);
                 else g.cnt[g.p_cnt[p] + nv] += 1;
             }
         }
-#ifdef NSK_ABL_TIMING
-        if (threadIdx.x == 0) {          // per group: {start, first pass's entries done (wave 0), end, entries}
-            const int slot = gi & 32767;
-            nsk_dbg[4 * slot] = dbg_t0; nsk_dbg[4 * slot + 1] = dbg_t1;
-            nsk_dbg[4 * slot + 2] = __builtin_amdgcn_s_memtime() + (unsigned long long)(pot.p[0] == 12345.678 ? 1 : 0);
-            nsk_dbg[4 * slot + 3] = (unsigned long long)ne;
-        }
-#endif
     }
 }
 
@@ -1799,18 +1695,12 @@ __device__ __forceinline__ void wide_issue(const DevGraph<signed char> &g, int p
     // (32-bit offsets from the arrays' bases: `global_load_dword v, v_offset, s[base]` -- one vector add per load, no
     // 64-bit scalar pair per base)
     const uint32_t l4 = 4u * (uint32_t)lane;
-#ifdef NSK_ABL_W_NOLOAD
-#pragma unroll
-    for (int j = 0; j < 4 * NCH; j++) t.x[j] = (base[j] + l4) * 0x9E3779B9u;
-    t.tally = (uint32_t)p0 + l4;
-#else
 #pragma unroll
     for (int j = 0; j < 4 * NCH; j++) t.x[j] = *(const nsk_u32_una *)((const char *)g.val + (base[j] + l4));
     // the quad's tally bytes: its own value bytes in packed mode (MODE 2), else the position tally (MODE 0; 1 = burn-in)
     t.tally = 0;
     if (MODE == 2) t.tally = *(const uint32_t *)((const char *)g.val + ((uint32_t)p0 + l4));
     else if (MODE == 0) t.tally = *(const uint32_t *)((const char *)g.cnt_pos + ((uint32_t)p0 + l4));
-#endif
 }
 // ... and the rest of the trip: draws, look-ups, stores.  wd: the quad's descriptor (nsk_compile.h seg_wide)
 template <int NCH, int MODE>
@@ -1821,12 +1711,7 @@ __device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, uint
     // (the block is evaluated while the loads are in flight: without the fences the scheduler puts it behind the waits)
     __builtin_amdgcn_sched_barrier(0);
     const uint32_t blk = (uint32_t)(p0 >> 2) + (uint32_t)lane;              // wide_block: ((p0 >> 8) << 6) | lane
-#ifdef NSK_ABL_W_NOPHILOX
-    const uint32_t hq = blk * 2654435761u ^ s0;
-    const u32x4 ra = {hq, hq * 40503u, hq ^ 0x9E3779B9u, hq * 7u};
-#else
     const u32x4 ra = pk ? philox4x32_keyed(*pk, blk, 2u, s0, s1) : philox4x32(k0, k1, blk, 2u, s0, s1);
-#endif
     asm volatile("" :: "v"(ra.x), "v"(ra.y), "v"(ra.z), "v"(ra.w));       // (the words exist HERE: the optimiser sinks them to their uses otherwise)
     __builtin_amdgcn_sched_barrier(0);
     uint32_t idx4 = 0;
@@ -1861,23 +1746,16 @@ __device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, uint
                 out = (out & ~(1u << (8 * i))) | (((word_of(rb, (uint32_t)i) >> 6) > lo ? 1u : 0u) << (8 * i));
             }
     }
-#ifdef NSK_ABL_W_NOSTORE
-    if (out == 0x12345678u)
-#endif
     {
     // packed mode: ONE store -- per byte (tally << 1) + 2 * value | value; no carry between the bytes while a tally stays
     // below 127 (the host unpacks before)
-#if defined(NSK_W_STORE_SC1)
-#define NSK_W_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#elif defined(NSK_W_STORE_NT)
-#define NSK_W_STORE(P, V) __builtin_nontemporal_store((V), (P))
-#else
-#define NSK_W_STORE(P, V) (*(P) = (V))
-#endif
-    if (MODE == 2) NSK_W_STORE((uint32_t *)((char *)g.val + ((uint32_t)p0 + 4u * (uint32_t)lane)), (t.tally & 0xFEFEFEFEu) + 3u * out);
+    // (write-through and non-temporal stores were measured too, tools/sessions/r6_s07.sh: 21.0 / 19.7 against 19.9 us per
+    // 10M-grid sweep -- plain stores stay)
+    uint32_t *const vq = (uint32_t *)((char *)g.val + ((uint32_t)p0 + 4u * (uint32_t)lane));
+    if (MODE == 2) *vq = (t.tally & 0xFEFEFEFEu) + 3u * out;
     else {
-    NSK_W_STORE((uint32_t *)((char *)g.val + ((uint32_t)p0 + 4u * (uint32_t)lane)), out);
-    if (MODE == 0) NSK_W_STORE((uint32_t *)((char *)g.cnt_pos + ((uint32_t)p0 + 4u * (uint32_t)lane)), t.tally + out); // (four byte tallies: folded before one reaches 255)
+        *vq = out;
+        if (MODE == 0) *(uint32_t *)((char *)g.cnt_pos + ((uint32_t)p0 + 4u * (uint32_t)lane)) = t.tally + out;   // (four byte tallies: folded before one reaches 255)
     }
     }
 }
@@ -2024,6 +1902,9 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_gibbs_seg_tab(DevGraph<VT> g, Seg
 //   trip's requests.
 #ifndef NSK_TABW_ATTR
 #define NSK_TABW_ATTR
+#endif
+#ifdef NSK_ABL_TIMING       // instrumented build (tools/build_variant.sh TIMING -DNSK_ABL_TIMING; tools/timing_tabw.py)
+static __device__ unsigned long long nsk_dbg[4 * 65536];
 #endif
 // The hot arguments: 14 dwords (16 user scalar registers less the kernarg pointer's two).  The three other arrays are
 // given as 256-byte units from `val` (device allocations are 256-byte aligned and lie within 512 GB of each other).
@@ -2268,11 +2149,7 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
     }
 #pragma unroll
     for (int k = 0; k < NT; k++)
-#ifdef NSK_TAB_FLAT_LD
-        tally[k] = burnin ? 0u : (uint32_t)g.cnt_pos[en.pos0 + tt[k] * 64 + lane];
-#else
         tally[k] = burnin ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, en.pos0 + tt[k] * 64, 0);
-#endif
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         if (ab[k][0] == NSK_NO_STREAM) {                                // wave-uniform: the tile reads its stream
@@ -2298,11 +2175,7 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
             for (int j = 0; j < 4 * NCH; j++) {
                 const uint32_t b = ab[k][j];
                 if (!P2P) {
-#ifdef NSK_TAB_FLAT_LD
-                    x[k][j] = (uint32_t)(uint8_t)g.val[b + (uint32_t)lane];
-#else
                     x[k][j] = nsk_buf_ld<VT>(rv, (uint32_t)lane, b);
-#endif
                 } else {                                 // ... a run of the values or of the ghosts ([ghost_lo, ghost_lo + nrecv))
                     const uint32_t gb = b - px.ghost_lo;
                     if (gb + 63u < px.nrecv && gb < px.nrecv) x[k][j] = nsk_buf_ld_sys<VT>(rg, (uint32_t)lane, gb);       // scalar: all ghosts
@@ -2317,11 +2190,7 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
                 const uint32_t i = id[k][j];
-#ifdef NSK_TAB_FLAT_LD
-                if (!P2P) x[k][j] = (uint32_t)(uint8_t)g.val[i];
-#else
                 if (!P2P) x[k][j] = nsk_buf_ld<VT>(rv, i, 0u);
-#endif
                 else x[k][j] = i - px.ghost_lo < px.nrecv ? nsk_buf_ld_sys<VT>(rg, i - px.ghost_lo, 0u) : nsk_buf_ld<VT>(rv, i, 0u);
             }
         }
@@ -2360,20 +2229,10 @@ __device__ __forceinline__ void tab_tiles_x(const DevGraph<VT> &g, const SegEntr
     for (int k = 0; k < NT; k++) {
         // a dead tile's stores carry an out-of-range lane offset: dropped by the bounds check (no branch, no select
         // of addresses)
-#ifdef NSK_TAB_FLAT_ST
-        const int pk = en.pos0 + (t0 + k) * 64 + lane;
-        VT *dst = live[k] ? g.val + pk : (VT *)g.sink + lane;
-        *dst = (VT)nv[k];
-        if (!burnin) {
-            uint8_t *td = live[k] ? g.cnt_pos + pk : g.sink + 256 + lane;
-            *td = (uint8_t)(tally[k] + (uint32_t)nv[k]);
-        }
-#else
         const uint32_t voff = live[k] ? (uint32_t)lane : NSK_BUF_OOB;
         const uint32_t soff = live[k] ? (uint32_t)(en.pos0 + (t0 + k) * 64) : 0u;
         nsk_buf_st<VT>(rv, voff, soff, nv[k]);
         if (!burnin) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(tally[k] + (uint32_t)nv[k]), rc, (int)voff, (int)soff, 0);
-#endif
     }
     if (border) {
         // the boundary values of these tiles into their readers' receive blocks (this exchange's parity), written

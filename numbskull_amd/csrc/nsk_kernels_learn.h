@@ -589,9 +589,6 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
         const u32x4 t = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
         truncate = part && (u53(t.x, t.y) < lp.inv_trunc);
     }
-#ifdef NSK_ABL_NOPASS2
-    if (lp.k0 != 0xDEADBEEFu) return;
-#endif
     if (__ballot(part) == 0) return;
     if (saved) {
         general_walk_ids(sp, len, Mslots, [&](int e, uint32_t wid, uint32_t d1) {
@@ -601,11 +598,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
             const int ce = (int)((fx >> 8) & 15u), Ae = (int)((fx >> 12) & 3u) - 1, Be = (int)((fx >> 14) & 3u) - 1;
             const long long diff = (long long)(proposal == cf ? Af : Bf) - (long long)(evidence == ce ? Ae : Be);
             const bool have = part && mine && !g.w_fixed[wid];          // 100-101
-#ifdef NSK_ABL_NOATOMIC
-            if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
-#else
             accumulate_gradient(sk, have, (int)wid, diff * g.grad_mul, truncate);
-#endif
         });
         return;
     }
@@ -618,11 +611,7 @@ __device__ __forceinline__ void learn_tile_general(const DevGraph<VT> &g, const 
                                const long long diff = (long long)(proposal == cf ? Af : Bf) -
                                                       (long long)(evidence == ce ? Ae : Be);
                                const bool have = part && mine && !g.w_fixed[wid];      // 100-101
-#ifdef NSK_ABL_NOATOMIC
-                               if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
-#else
                                accumulate_gradient(sk, have, (int)wid, diff * g.grad_mul, truncate);
-#endif
                            });
 }
 
@@ -832,11 +821,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
     for (int j = 0; j < 4 * NCH; j++) acc[j] = 0;
     auto flush = [&]() {
-#ifdef NSK_ABL_LNOSINK
-        if (cur_prog != 0xFFFFFFFFu && accK == 0xFFFFFFF1u) {
-#else
         if (cur_prog != 0xFFFFFFFFu && accK != 0u) {
-#endif
             const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + cur_prog);
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
@@ -884,11 +869,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
                 for (int j = 0; j < 4 * NCH; j++) ab[k][j] = ap[j];
             }
-#ifdef NSK_ABL_LNOINIT
-            r.init[k] = 1;
-#else
             r.init[k] = (int)g.p_init[c_pos + t * 64 + lane];          // -1: padding lane at a class end
-#endif
         }
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
@@ -909,13 +890,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
     LearnTrip<NCH, TPW> rn;
     LearnTripInfo in;
     int P = xcd * per + wx;
-#ifdef NSK_LEARN_PREFETCH
-    if (P < pend) issue(P, rn, in);
-#endif
     for (; P < pend; P += wpx) {
-#ifndef NSK_LEARN_PREFETCH
         issue(P, rn, in);       // (with implicit adjacency a trip's requests are scalar loads and coalesced rows:
-#endif                          //  requesting the next trip behind the table loads no longer pays -- 32.3 vs 31.9 us per class)
         const LearnTrip<NCH, TPW> r = rn;
         const LearnTripInfo ti = in;
         uint32_t idf[TPW], ide[TPW];
@@ -925,11 +901,7 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++) {
                 xf[j] = (uint32_t)(uint8_t)g.val[r.id[k][j]];
-#ifdef NSK_ABL_LNOEV
-                xe[j] = xf[j];
-#else
                 xe[j] = (uint32_t)(uint8_t)g.val_evid[r.id[k][j]];
-#endif
             }
             idf[k] = 0; ide[k] = 0;
 #pragma unroll
@@ -939,36 +911,20 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
         }
         uint4 ef[TPW], ee[TPW];
 #pragma unroll
-#ifdef NSK_ABL_LNOEV
-        for (int k = 0; k < TPW; k++) { ef[k] = g.ztab[ti.zoff + idf[k]]; ee[k] = ef[k]; }
-#else
         for (int k = 0; k < TPW; k++) { ef[k] = g.ztab[ti.zoff + idf[k]]; ee[k] = g.ztab[ti.zoff + ide[k]]; }
-#endif
         // the next trip's requests go out behind the table loads (vmcnt counts in order: waiting
         // for the entries then leaves these in flight)
-#ifdef NSK_LEARN_PREFETCH
-        __builtin_amdgcn_sched_barrier(0);
-        if (P + wpx < pend) issue(P + wpx, rn, in);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if (ti.prog != cur_prog) { flush(); cur_prog = ti.prog; }             // uniform, rare
 #pragma unroll
         for (int k = 0; k < TPW; k++) {
             const bool valid = ti.t0 + k < ti.nt && r.init[k] >= 0;
             const int p = ti.pos + (ti.t0 + k) * 64 + lane;
-#ifdef NSK_ABL_NOPHILOX
-            const uint32_t hq = (uint32_t)p * 2654435761u ^ lp.s0;
-            const u32x4 rr = {hq, hq * 40503u, hq ^ 0x9E3779B9u, hq * 7u};
-#else
             const u32x4 rr = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
-#endif
             int evidence = r.init[k];                                             // learning.py:61-62
             if (ti.ev != 1) evidence = k53(rr.z, rr.w) > ztab_K(ee[k]) ? 1 : 0;   // 54-58
             const int proposal = k53(rr.x, rr.y) > ztab_K(ef[k]) ? 1 : 0;         // 66-70
             if (valid) {
-#ifndef NSK_ABL_LNOEVST
                 g.val_evid[p] = (VT)evidence;
-#endif
                 g.val[p] = (VT)proposal;
             }
             const bool part = valid && (lp.learn_non_evidence || ti.ev == 1);     // 71-72
@@ -980,45 +936,12 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
             // the slots' satisfied bits of the two chains, zero for lanes that do not take part
             const uint32_t satf = part ? (proposal ? (ef[k].z >> 8) : ef[k].z) : 0u;
             const uint32_t sate = part ? (evidence ? (ee[k].z >> 8) : ee[k].z) : 0u;
-#ifdef NSK_ABL_LCHECK       // (debug build: the table's satisfied bits against the slot algebra, lane by lane)
-            if (part) {
-                const uint32_t *pq = g.tile_hdr + ti.prog;
-                SlotState sf = {0, true, false, true}, se = {0, true, false, true};
-                uint32_t B0 = 0, B1 = 0, C0 = 0, C1 = 0;
-                int ns = 0;
-                for (int j = 0; j < 4 * NCH; j++) if ((ti.zmask >> j) & 1u) ns = j + 1;
-                for (int j = 0; j < ns; j++) {
-                    bool b0, b1, c0, c1;
-                    slot_sat(sf, pq[j], (int)(uint8_t)g.val[r.id[k][j]], b0, b1);
-                    slot_sat(se, pq[j], (int)(uint8_t)g.val_evid[r.id[k][j]], c0, c1);
-                    B0 |= (b0 ? 1u : 0u) << j; B1 |= (b1 ? 1u : 0u) << j; C0 |= (c0 ? 1u : 0u) << j; C1 |= (c1 ? 1u : 0u) << j;
-                }
-                const uint32_t m = ti.zmask;
-                const uint32_t wf = (proposal ? B1 : B0) & m, we = (evidence ? C1 : C0) & m;
-                if ((satf & m) != wf || (sate & m) != we)
-                    printf("LCHECKIDS p %d ids %u %u %u %u %u %u %u %u now %d %d %d %d %d %d %d %d\n", p,
-                           r.id[k][0], r.id[k][1], r.id[k][2], r.id[k][3], r.id[k][(4 * NCH) - 4], r.id[k][(4 * NCH) - 3], r.id[k][(4 * NCH) - 2], r.id[k][(4 * NCH) - 1],
-                           (int)g.val[r.id[k][0]], (int)g.val[r.id[k][1]], (int)g.val[r.id[k][2]], (int)g.val[r.id[k][3]],
-                           (int)g.val[r.id[k][(4 * NCH) - 4]], (int)g.val[r.id[k][(4 * NCH) - 3]], (int)g.val[r.id[k][(4 * NCH) - 2]], (int)g.val[r.id[k][(4 * NCH) - 1]]);
-                if ((satf & m) != wf || (sate & m) != we || ti.prog == 56u)
-                    printf("LCHECK sweep %u p %d prog %u zmask %#x idf %#x ide %#x ef.z %#x ee.z %#x prop %d evid %d satf %#x want %#x sate %#x want %#x init %d ev %d%s\n",
-                           lp.s0, p, ti.prog, m, idf[k], ide[k], ef[k].z, ee[k].z, proposal, evidence, satf & m, wf, sate & m, we, r.init[k], ti.ev,
-                           ((satf & m) != wf || (sate & m) != we) ? " MISMATCH" : "");
-            }
-#endif
-#if defined(NSK_ABL_LNOBALLOT)
-            acc[0] += __popcll(__ballot((satf ^ sate) & 1u));
-#else
 #pragma unroll
             for (int j = 0; j < 4 * NCH; j++)
                 acc[j] += __popcll(__ballot((satf >> j) & 1u)) - __popcll(__ballot((sate >> j) & 1u));
-#endif
         }
     }
     flush();
-#ifdef NSK_ABL_LNOSINK
-    if (accK == 0xFFFFFFF1u)
-#endif
     close_sink<SMALLW>(g, sk);
 }
 
@@ -1217,13 +1140,9 @@ __device__ __forceinline__ void learn_ep_body(const DevGraph<VT> &g, int pbegin,
                 const bool counted = lp.kstat && ((d1 >> 14) & 15u) == 15u;
                 const bool have = (sv & 256u) && ((d1 >> 14) & 15u) != 14u && entry_visited(d1, evidence, proposal) &&
                                   !(d1 >> 31) && !(counted && diff == 0);                    // 100-101
-#ifdef NSK_ABL_NOATOMIC
-                if (have && diff == 77) g.sink[threadIdx.x & 63] = 1;
-#else
                 // (the entry's weight is still in its LDS slot from phase 1: a weight updated in place needs no reload)
                 accumulate_gradient(sk, have, (int)NSK_EP_WID(w0), diff * g.grad_mul, (sv & 512u) != 0u, !counted,
                                     sk.w_direct != nullptr, sk.w_direct ? ws[NSK_EP_SLOT(w0, d1)] : 0.0);
-#endif
             });
     };
     if ((int)blockIdx.x < hblocks + gblocks) {
@@ -1282,9 +1201,6 @@ __device__ __forceinline__ void learn_ep_body(const DevGraph<VT> &g, int pbegin,
             }
             sel[threadIdx.x] = (uint16_t)mysel;
             __syncthreads();
-#ifdef NSK_ABL_EPNOP3
-            if (lp.k0 != 0xDEADBEEFu) continue;
-#endif
             gradients(sub, two ? grows1 : grows0);         // the last pass's facts are in the slots
             if (two) {                                     // the first pass's entries: their facts again, then their gradients
                 __syncthreads();

@@ -106,9 +106,7 @@ int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay
     auto launch_update = [&](const Pending &u) {      // as launches of their own on the main stream
         const DevGraph<VT> &du = dv[u.set];
         if (SMALLW) {
-#ifndef NSK_ABL_NOAPPLY
             k_apply_bins<<<dim3(1), dim3(NSK_BLOCK), 0, g->stream>>>(u.aa);
-#endif
             if (g->c.nfast > 0 && !u.tabs_here) nsk_refresh_ztab(g, u.set, g->stream);   // big tables: own launch
         } else {
             // (with direct weights only the others are walked -- none at all when every weight has one factor)

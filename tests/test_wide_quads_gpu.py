@@ -14,6 +14,15 @@ from util import session, oracle_of, phases_from_colors
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _wide_quads_on_small_graphs(monkeypatch):
+    """The library lays out wide quads from 3M variables per handle on (below, a class launch is one wave lifetime long
+    and the tile-by-tile kernel's is shorter); these tests use grids the oracle walks in seconds, so they lower the
+    bound with the diagnostic switch.  The 10M grid of tests/test_config3_gpu.py takes the path at its default."""
+    monkeypatch.setenv("NSK_DIAG", "1")
+    monkeypatch.setenv("NSK_WIDE_MIN", "0")
+
+
 def _run_and_compare(fg, og, seed, burn, sweeps, sample_evidence=True, chunks=(None,)):
     order, ps = phases_from_colors(fg.colors())
     vv, _, wv, cnt = og.initial_state()
