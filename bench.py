@@ -103,6 +103,12 @@ def build_shard(rows, cols, learning, name, lo, hi):
     if name.startswith("lr"):
         g, gids, own_local = graphgen.mixed_lr_shard(rows * cols, lo, hi, seed=20240603)
         return g, gids, own_local, None, len(g[0]), time.time() - t0
+    if not learning:
+        # the grid's shard from its own rows (graphgen.ising_grid_shard == extract_shard of the whole grid): a rank of the
+        # 100M grid holds 12.5M cells, not 100M
+        g, gids, own_local = graphgen.ising_grid_shard(rows, cols, lo, hi, weight=0.1, fixed=True)
+        nf = (rows - 1) * cols + rows * (cols - 1)
+        return g, gids, own_local, nf, len(g[0]), time.time() - t0
     whole = build_graph(rows, cols, learning, name=name)
     nf, nw = len(whole[2]), len(whole[0])
     g, gids, own_local = graphgen.extract_shard(whole, lo, hi)
@@ -273,23 +279,31 @@ def side_run(name, seed, steps, warmup):
     import numbskull_amd
     from numbskull_amd import _lib
     rows, cols, learning = WORKLOADS[name]
-    w, v, f, fm, dm, edges = build_graph(rows, cols, learning)
-    ns = numbskull_amd.NumbSkull(quiet=True, seed=seed)
+    is_lr = name.startswith("lr")
+    t_gen = time.time()
+    w, v, f, fm, dm, edges = build_graph(rows, cols, learning, name=name)
+    t_gen = time.time() - t_gen
+    # (the LR generator's IMPLY_MLN / IMPLY_MLN_CAT factors use the intended head lookup fmap[l].vid: the reference's
+    #  literal indexing is out of bounds on this graph -- SURVEY.md section 8d, config #5)
+    ns = numbskull_amd.NumbSkull(quiet=True, seed=seed, head_by_vid=is_lr)
+    t_load = time.time()
     with redirect_stdout(io.StringIO()):
         ns.loadFactorGraph(w, v, f, fm, dm, int(edges))
+    t_load = time.time() - t_load
     fg = ns.factorGraphs[0]
     L, h = _lib.lib(), fg._engine()
     info = fg.info()
+    step = 1e-3 if is_lr else 1e-7       # config #3: step 1e-7, L2 0.01; the LR graphs: 1e-3
 
     def run(n, burnin=0):
-        if learning:                     # config #3 parameters: step 1e-7, L2 0.01
-            _lib.check(L.nsk_learn_sweeps(h, n, 1e-7, 1.0, 2, 0.01, 1, 0))
+        if learning:
+            _lib.check(L.nsk_learn_sweeps(h, n, step, 1.0, 2, 0.01, 1, 0))
         else:
             _lib.check(L.nsk_gibbs_sweeps(h, n, 1, burnin))
     run(warmup, 1)                       # warm-up = burn-in: the tallies start after the transient
     blocks = timed_blocks(run, torch.cuda.synchronize, L, h, steps, REPEATS)
     dt, ms, nl = median_block(blocks)
-    checks = state_checks(fg, info, steps * REPEATS, (rows, cols), learning)
+    checks = state_checks(fg, info, steps * REPEATS, (rows, cols) if not is_lr else None, learning)
     clipped = fg.info()["learn_clipped"] if learning else None
     fg.close()
     lay_sweep = info["layout_bytes_learning" if learning else "layout_bytes_inference"]
@@ -300,7 +314,89 @@ def side_run(name, seed, steps, warmup):
            "avg_launch_us": ms * 1e3 / max(1, nl), "parity": checks}
     if learning:
         out["learn_clipped"] = clipped   # weight updates whose step the per-class cap shrank
+    if is_lr:
+        out["config"] = {"workload": "mixed-arity LR graph: %d variables (25%% categorical), %d factors, %d weights, %s; "
+                                     "head_by_vid (SURVEY.md section 8d: the literal head index is out of bounds on this graph)"
+                                     % (rows * cols, len(f), len(w), "learning" if learning else "inference"),
+                         "generate_s": round(t_gen, 2), "load_and_compile_s": round(t_load, 2),
+                         "compile_s": round(info["compile_seconds"], 2), "colors": info["ncolors"]}
+        tr = profile_record("traffic.json", name)
+        if tr:                           # counter bytes per class launch / layout bytes per class launch (profiles/)
+            out["traffic_per_launch"] = tr
+            out["traffic_over_layout"] = tr / (lay_sweep * steps / max(1, nl))
     return out
+
+
+def multi_side_run(name, args, dist, torch, rank, world, local_rank, steps=20, warmup=5):
+    """A second workload on the same N ranks (inference grids only): shard-local graphs, the same exchange ladder, K sweeps
+    bracketed by barriers, the MAX over ranks; rank 0 gets the record."""
+    import io
+    from contextlib import redirect_stdout
+    import numbskull_amd
+    from numbskull_amd.distributed import PartitionedSampler, shard_range
+    rows, cols, learning = WORKLOADS[name]
+    nvar = rows * cols
+    own = shard_range(rank, world, nvar)
+    g, gids, own_local, _, _, t_gen = build_shard(rows, cols, learning, name, own[0], own[1])
+    ns = numbskull_amd.NumbSkull(quiet=True, device=local_rank, seed=args.seed)
+    with redirect_stdout(io.StringIO()):
+        ns.loadFactorGraph(g[0], g[1], g[2], g[3], g[4], int(g[5]), own_range=own_local, global_ids=gids)
+    fg = ns.factorGraphs[0]
+    sampler = PartitionedSampler(fg, dist, torch, rank, world, nvar_global=nvar)
+    sampler.gibbs(warmup, True, burnin=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        fence()
+        t0 = time.time()
+        sampler.gibbs(steps, True)
+        sampler.check()
+        fence()
+        times.append(time.time() - t0)
+    t = torch.tensor([sorted(times)[1]], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rec = {"value": nvar * steps / float(t.item()), "unit": "variable-updates/s", "n_gpus": world, "steps": steps,
+           "ms_per_step": float(t.item()) * 1e3 / steps, "exchange": sampler.ladder["rung"],
+           "config": {"workload": "%dx%d Ising grid (%d binary variables), inference only, %d range shards generated per rank"
+                                  % (rows, cols, nvar, world), "generate_s": round(t_gen, 2)}}
+    fg.close()
+    return rec
+
+
+def profile_record(fname, workload):
+    """A per-workload record of profiles/<fname> (tools/collect_profiles.sh), None when absent."""
+    tp = os.path.join(REPO, "profiles", fname)
+    try:
+        return json.load(open(tp)).get(workload)
+    except Exception:
+        return None
+
+
+def profiles_stale():
+    """True when profiles/ was collected at another library than the one that runs: profiles/r6_COMMIT.txt names the
+    library version string + source hash tools/collect_profiles.sh saw."""
+    from numbskull_amd import _lib
+    try:
+        want = open(os.path.join(REPO, "profiles", "r6_COMMIT.txt")).read()
+    except Exception:
+        return True
+    return library_fingerprint(_lib) not in want
+
+
+def library_fingerprint(_lib):
+    """nsk_version() + a hash of the kernel sources the in-tree library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(REPO, "numbskull_amd", "csrc")
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".h", ".hip", ".cpp")):
+            h.update(open(os.path.join(src, fn), "rb").read())
+    v = _lib.lib().nsk_version()
+    return "%s src=%s" % (v.decode() if isinstance(v, bytes) else v, h.hexdigest()[:16])
 
 
 def roofline_bound(kernel):
@@ -429,6 +525,9 @@ def dry_run(args, dist, rank, world, rows, cols, learning):
     if rank == 0:
         print(json.dumps({"metric": "variable-updates/sec", "value": 0.0, "unit": "variable-updates/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "exchange_ladder": [{"rank": r, "rung": "dry run (no GPU): fused into the table launches -> peer-to-peer "
+                                               "exchange kernels -> native RCCL loop -> torch.distributed loop, first that sets up and "
+                                               "self-tests on EVERY rank", "tried": [], "seconds": {}} for r in range(world)],
                           "config": {"name": args.workload, "sampled_total": sampled, "boundary_total": nb,
                                      "colors": info["ncolors"], "variables_held_by_rank0": int(len(v)),
                                      "peak_rss_gb_max_over_ranks": round(rss, 2)}}))
@@ -581,6 +680,15 @@ def main():
         sampler.check()
         phases["exchange_path"] = "peer-to-peer writes + flags" if sampler.p2p else (
             "native RCCL all-gather" if sampler.native else "torch.distributed all-gather")
+    # N ranks on the metric config: a second line that is not bound by launch latency -- the 100M grid (12.5M cells per
+    # rank at N = 8; a 1.25M-cell shard of the 10M grid cannot scale below one launch floor per class)
+    multi_also = None
+    if world > 1 and args.workload == "ising10m" and not args.no_extra:
+        multi_also = multi_side_run("ising100m", args, dist, torch, rank, world, local_rank)
+    ladder = None
+    if world > 1:                       # every rank's rung of the exchange ladder (numbskull_amd/distributed.py)
+        ladder = [None] * world
+        dist.all_gather_object(ladder, sampler.ladder)
     copy_gbs = None
     if rank == 0:
         cg = C.c_double()
@@ -656,6 +764,8 @@ def main():
         }
         if phases is not None:
             out["phases_us"] = phases      # rank 0's shard: sweep kernels / exchange, each with its launch latency
+        if ladder is not None:
+            out["exchange_ladder"] = ladder
         if learning:
             out["learn_clipped"] = fg.info()["learn_clipped"]
             out["learn_hyper"] = {"step": lr[0], "regularization": lr[2], "reg_param": lr[3],
@@ -678,7 +788,12 @@ def main():
         if world == 1 and args.workload == "ising10m" and not args.no_extra:
             out["also"] = {"ising1m": side_run("ising1m", args.seed, 400, 100),
                            "ising10m_learn": side_run("ising10m_learn", args.seed, 40, 10),
-                           "ising40m": side_run("ising40m", args.seed, 20, 5)}
+                           "ising40m": side_run("ising40m", args.seed, 20, 5),
+                           # BASELINE configs[4] on one GPU: the LR graph at a tenth of its size (both sweeps) and its
+                           # learning sweep at full size
+                           "lr5m": side_run("lr5m", args.seed, 20, 5),
+                           "lr5m_learn": side_run("lr5m_learn", args.seed, 10, 3),
+                           "lr50m_learn": side_run("lr50m_learn", args.seed, 5, 2)}
             out["roofline"]["frac_is"] = ("bytes the compiled layout moves per launch / launch time / HBM peak.  With implicit "
                                           "adjacency the table kernel reads no per-lane stream (4.8 B/update instead of round 2's "
                                           "20.0): it is bound by instruction issue along its chain of dependent steps (bound = "
@@ -686,7 +801,12 @@ def main():
                                           "while updates/s rose; csr_model_GBs prices the same sweep in SURVEY 8(d)'s CSR layout. "
                                           "Both grids' sweeps fit the Infinity Cache (stream_fits_infinity_cache); the 100M grid "
                                           "(--workload ising100m) is the one beyond it")
+        if multi_also is not None:
+            out["also"] = {"ising100m": multi_also}
         checks["ok"] = bool(ok_local)
+        # the counter figures above (roofline.traffic / .issue, also.*.traffic_per_launch) are read from profiles/, not
+        # measured by this run: say so at top level when they were collected at another library
+        out["traffic_stale"] = bool(profiles_stale())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

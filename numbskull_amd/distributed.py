@@ -98,6 +98,79 @@ def merge_weight_deltas(dist, weights, start, group=None):
     weights.copy_(start + delta)
 
 
+def weight_slice(q, world, nw):
+    """First weight of rank q's slice in the sliced merge: the device's nsk_p2p_slice_lo (q * nw // world)."""
+    return (int(q) * int(nw)) // int(world)
+
+
+def merge_weight_deltas_sliced(dist, weights, start, rank, world, group=None):
+    """The same merge as reduce-scatter + all-gather, the way the peer-to-peer path does it on the device
+    (nsk_kernels_misc.h p2p_push / p2p_reduce_slice): rank q owns weights [q nw // W, (q + 1) nw // W), adds the W ranks'
+    deltas of its slice IN RANK ORDER to w_start and hands the merged slice to everybody -- every rank ends with
+    bit-identical weights whatever the collective library's own summation order, and only nw / W weights per rank
+    cross the wire twice.  Slices of unequal length (nw not a multiple of W) are padded to the longest for the
+    collectives."""
+    torch = __import__("torch")
+    nw = int(weights.numel())
+    lo = [weight_slice(q, world, nw) for q in range(world + 1)]
+    smax = max(lo[q + 1] - lo[q] for q in range(world))
+    delta = weights - start
+    # scatter: rank r sends slice q of its deltas to rank q (padded rows)
+    send = [torch.zeros(smax, dtype=weights.dtype, device=weights.device) for _ in range(world)]
+    for q in range(world):
+        send[q][:lo[q + 1] - lo[q]] = delta[lo[q]:lo[q + 1]]
+    recv = [torch.zeros(smax, dtype=weights.dtype, device=weights.device) for _ in range(world)]
+    dist.all_to_all(recv, send, group=group) if dist.get_backend(group) != "gloo" else _all_to_all_by_gather(dist, torch, recv, send, rank, world, group)
+    n_me = lo[rank + 1] - lo[rank]
+    t = recv[0][:n_me].clone()
+    for r in range(1, world):                       # rank order, like the device's loop
+        t += recv[r][:n_me]
+    mine = torch.zeros(smax, dtype=weights.dtype, device=weights.device)
+    mine[:n_me] = start[lo[rank]:lo[rank + 1]] + t
+    out = [torch.zeros(smax, dtype=weights.dtype, device=weights.device) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    for q in range(world):
+        weights[lo[q]:lo[q + 1]] = out[q][:lo[q + 1] - lo[q]]
+
+
+def _all_to_all_by_gather(dist, torch, recv, send, rank, world, group):
+    """all_to_all for backends without it (gloo): W all-gathers of the padded rows."""
+    for q in range(world):
+        rows = [torch.zeros_like(send[q]) for _ in range(world)]
+        dist.all_gather(rows, send[q], group=group)
+        if q == rank:
+            for r in range(world):
+                recv[r].copy_(rows[r])
+
+
+class _Watchdog(object):
+    """Time box around one rung of the exchange set-up: a native call that never returns (a peer that died inside a
+    collective, an IPC import that blocks) cannot be interrupted from Python, so after `seconds` the rank says where it
+    hangs and exits with code 3 -- bench.py's ranks are CHILD processes of a parent that has not touched the GPU
+    (spawn_ranks), which relays the code; nothing re-execs."""
+
+    def __init__(self, seconds, what, ladder):
+        self.seconds, self.what, self.ladder, self.t = seconds, what, ladder, None
+
+    def __enter__(self):
+        import threading
+
+        def fire():
+            print("[numbskull_amd] rank %s: %s did not finish within %.0f s (NSK_RUNG_TIMEOUT_S); ladder so far: %s"
+                  % (self.ladder.get("rank"), self.what, self.seconds, self.ladder.get("tried")), file=sys.stderr, flush=True)
+            os._exit(3)
+        if self.seconds > 0:
+            self.t = threading.Timer(self.seconds, fire)
+            self.t.daemon = True
+            self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            self.t.cancel()
+        return False
+
+
 class _DevicePointer(object):
     """Expose a raw device allocation of the library to torch via __cuda_array_interface__."""
 
@@ -148,13 +221,35 @@ class PartitionedSampler(object):
         self.p2p = False
         self.lists, self.slot = None, 0
         self.all_needs = None
+        # which rung of the exchange ladder this rank ends on, and how it got there (bench.py prints it per rank):
+        # fused (inside the table launches) -> peer-to-peer exchange kernels -> native RCCL loop -> torch.distributed
+        self.ladder = {"rank": rank, "tried": [], "seconds": {}, "rung": "single rank" if world == 1 else None}
         if world > 1:
-            self.setup_exchange(native)
+            import time
+            box = float(os.environ.get("NSK_RUNG_TIMEOUT_S", "180"))      # a rung that hangs ends the rank, loudly
+            t0 = time.time()
+            with _Watchdog(box, "setting up the collective exchange (boundary lists, RCCL communicator)", self.ladder):
+                self.setup_exchange(native)
+            self.ladder["seconds"]["collective set-up"] = round(time.time() - t0, 3)
+            self.ladder["tried"].append("native RCCL loop: %s" % ("ready" if self.native else "not available (torch.distributed loop)"))
             # peer-to-peer exchange for inference and learning sweeps (NSK_P2P=0 or p2p=False: off).  Set-up
             # ends with a self-test -- two real exchanges, one per buffer parity -- and every rank must
             # pass or none uses it (the collective loop stays as the fallback)
             if p2p if p2p is not None else os.environ.get("NSK_P2P", "1") != "0":
-                self.p2p = self._init_p2p()
+                t0 = time.time()
+                with _Watchdog(box, "setting up the peer-to-peer exchange (hipIpc mappings, self-tests)", self.ladder):
+                    self.p2p = self._init_p2p()
+                self.ladder["seconds"]["peer-to-peer set-up + self-tests"] = round(time.time() - t0, 3)
+                self.ladder["tried"].append("peer-to-peer self-test: %s" % ("passed on every rank" if self.p2p else "failed on some rank"))
+                if self.p2p:
+                    fused = bool(fg.info()["p2p_fused"])
+                    self.ladder["tried"].append("fused exchange: %s" % ("planned and self-tested on every rank" if fused else
+                                                                        "not for this handle (not table launches only, or its self-test failed somewhere)"))
+            else:
+                self.ladder["tried"].append("peer-to-peer: switched off")
+            self.ladder["rung"] = ("fused into the table launches" if self.p2p and fg.info()["p2p_fused"] else
+                                   "peer-to-peer exchange kernels" if self.p2p else
+                                   "native RCCL loop" if self.native else "torch.distributed loop")
             if self.pf and not self.p2p:
                 raise RuntimeError("partial factors need the peer-to-peer exchange (their aggregates are computed by the "
                                    "exchange kernels); it could not be set up")

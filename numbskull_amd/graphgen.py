@@ -416,6 +416,68 @@ _V_DISK = np.dtype([("variableId", ">i8"), ("isEvidence", "u1"), ("initialValue"
 assert _W_DISK.itemsize == 17 and _V_DISK.itemsize == 27
 
 
+def ising_grid_shard(nrows, ncols, lo, hi, weight=0.1, fixed=True, two_weights=False, evidence=None):
+    """``extract_shard(ising_grid(nrows, ncols, ...), lo, hi)`` without the whole grid: the cells ``[lo, hi + ncols)`` are
+    the only ones whose up / left factors can touch an owned variable, so a rank of an N-rank run builds its shard from
+    O(shard) memory (the 100M grid on 8 ranks: 12.5M cells each instead of 8 x 100M).  ``evidence``: None, or a callable
+    ``global ids -> values`` (every variable evidence, config #3's learning variant)."""
+    n, m = int(nrows), int(ncols)
+    nvar = n * m
+    lo, hi = int(lo), int(hi)
+    me = np.arange(lo, min(nvar, hi + m), dtype=np.int64)               # candidate cells, row-major like ising_grid
+    exists = np.empty((len(me), 2), np.bool_)
+    exists[:, 0] = me >= m
+    exists[:, 1] = (me % m) != 0
+    other = np.empty((len(me), 2), np.int64)
+    other[:, 0] = me - m
+    other[:, 1] = me - 1
+    first = np.repeat(me, 2)
+    second = other.ravel()
+    wid = np.tile(np.array([0, 1], np.int64), len(me))
+    owned = lambda x: (x >= lo) & (x < hi)
+    keep = exists.ravel() & (owned(first) | owned(second))
+    first, second, wid = first[keep], second[keep], wid[keep]
+    nfactor = int(first.shape[0])
+    gids = np.unique(np.concatenate([np.arange(lo, hi, dtype=np.int64), first, second]))
+    variable = np.zeros(len(gids), Variable)
+    variable["cardinality"] = 2
+    if evidence is not None:
+        variable["isEvidence"] = 1
+        variable["initialValue"] = np.asarray(evidence(gids), np.int64)
+    variable["isEvidence"][(gids < lo) | (gids >= hi)] = 4
+    wrec = np.zeros(2 if two_weights else 1, Weight)
+    wrec["isFixed"] = bool(fixed)
+    wrec["initialValue"] = weight
+    factor = np.zeros(nfactor, Factor)
+    factor["factorFunction"] = FUNC_EQUAL
+    factor["featureValue"] = 1.0
+    factor["arity"] = 2
+    factor["ftv_offset"] = 2 * np.arange(nfactor, dtype=np.int64)
+    if two_weights:
+        factor["weightId"] = wid
+    vid = np.empty(2 * nfactor, np.int64)
+    vid[0::2] = first
+    vid[1::2] = second
+    fmap = np.zeros(2 * nfactor, FactorToVar)
+    fmap["vid"] = np.searchsorted(gids, vid)
+    l0, l1 = int(np.searchsorted(gids, lo)), int(np.searchsorted(gids, hi))
+    return (wrec, variable, factor, fmap, np.zeros(len(gids), np.bool_), 2 * nfactor), gids, (l0, l1)
+
+
+def replicate(g, initial_values):
+    """R disjoint copies of the graph `g` that share its weights; copy r takes its variables' initialValue from
+    initial_values[r] (evidence configurations of a small model: the learning tests)."""
+    w, v, f, fm, dm, edges = g
+    R, nv, nf, ne = len(initial_values), len(v), len(f), len(fm)
+    V = np.tile(v, R)
+    V["initialValue"] = np.concatenate([np.asarray(x, np.int64) for x in initial_values])
+    F = np.tile(f, R)
+    F["ftv_offset"] += np.repeat(np.arange(R, dtype=np.int64) * ne, nf)
+    FM = np.tile(fm, R)
+    FM["vid"] += np.repeat(np.arange(R, dtype=np.int64) * nv, ne)
+    return w.copy(), V, F, FM, np.tile(dm, R), R * int(edges)
+
+
 def extract_shard(g, lo, hi):
     """The part of a graph the shard that owns variables ``[lo, hi)`` needs -- what the reference's
     minions load (salt/src/numbskull_minion.py:185): the owned variables, the variables outside the

@@ -59,7 +59,14 @@ def lib():
         _lib.orc_mt_res53.restype = C.c_double
         _lib.orc_u53.restype = C.c_double
         _lib.orc_u53.argtypes = [C.c_uint32, C.c_uint32]
+        # the device-mode sweeps walk a colour class with the host's threads (same results whatever their number:
+        # tests/test_oracle_goldens.py::test_device_mode_is_thread_count_independent)
+        _lib.orc_set_threads(C.c_int(min(64, os.cpu_count() or 1)))
     return _lib
+
+
+def set_threads(n):
+    lib().orc_set_threads(C.c_int(int(n)))
 
 
 def _p(a):

@@ -598,14 +598,64 @@ static int64_t max_card(const orc_graph *g) {
     return m;
 }
 
+/* The variables of one colour class do not read each other (orc_check_coloring): the device-mode sweeps may walk a
+ * class with several threads -- same values, tallies and (integer) gradient sums whatever their number.  Test speed
+ * only: the walks of the 10M / 50M graphs dominated the GPU suite.  Default 1. */
+static int orc_dev_threads = 1;
+void orc_set_threads(int n) { orc_dev_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+typedef struct {
+    int (*fn)(void *ctx, int64_t i0, int64_t i1);
+    void *ctx;
+    int64_t i0, i1;
+    int rc;
+} orc_par_arg;
+static void *orc_par_worker(void *p) { orc_par_arg *a = (orc_par_arg *)p; a->rc = a->fn(a->ctx, a->i0, a->i1); return NULL; }
+/* fn(ctx, i0, i1) over [b, e) in contiguous chunks; the first error code in index order */
+static int orc_parallel_range(int64_t b, int64_t e, int (*fn)(void *, int64_t, int64_t), void *ctx) {
+    int T = orc_dev_threads;
+    if (e - b < 4096 || T <= 1) return fn(ctx, b, e);
+    if ((int64_t)T > (e - b) / 1024) T = (int)((e - b) / 1024);
+    pthread_t th[256];
+    orc_par_arg args[256];
+    for (int t = 0; t < T; t++) {
+        args[t].fn = fn; args[t].ctx = ctx; args[t].rc = ORC_OK;
+        args[t].i0 = b + (e - b) * t / T; args[t].i1 = b + (e - b) * (t + 1) / T;
+        pthread_create(&th[t], NULL, orc_par_worker, &args[t]);
+    }
+    int rc = ORC_OK;
+    for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); if (!rc) rc = args[t].rc; }
+    return rc;
+}
+
+typedef struct {
+    const orc_graph *g; const int64_t *order; const int64_t *cstart; int64_t *count; int64_t *var_value;
+    const double *weight_value; int sample_evidence, burnin; uint64_t seed, sweep;
+} orc_gibbs_ctx;
+static int orc_gibbs_range_dev(void *vctx, int64_t i0, int64_t i1);
+
 int orc_gibbs_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t *phase_start,
                         int64_t nphase, const int64_t *cstart, int64_t *count, int64_t *var_value,
                         const double *weight_value, int sample_evidence, int burnin,
                         uint64_t seed, uint64_t sweep) {
+    orc_gibbs_ctx ctx = {g, order, cstart, count, var_value, weight_value, sample_evidence, burnin, seed, sweep};
+    int rc = ORC_OK;
+    for (int64_t p = 0; p < nphase && !rc; p++)
+        rc = orc_parallel_range(phase_start[p], phase_start[p + 1], orc_gibbs_range_dev, &ctx);
+    return rc;
+}
+
+static int orc_gibbs_range_dev(void *vctx, int64_t i0, int64_t i1) {
+    const orc_gibbs_ctx *x = (const orc_gibbs_ctx *)vctx;
+    const orc_graph *g = x->g;
+    const int64_t *order = x->order, *cstart = x->cstart;
+    int64_t *count = x->count, *var_value = x->var_value;
+    const double *weight_value = x->weight_value;
+    const int sample_evidence = x->sample_evidence, burnin = x->burnin;
+    const uint64_t seed = x->seed, sweep = x->sweep;
     double *Z = (double *)malloc(sizeof(double) * (size_t)max_card(g));
     int rc = ORC_OK;
-    for (int64_t p = 0; p < nphase && !rc; p++) {
-        for (int64_t i = phase_start[p]; i < phase_start[p + 1]; i++) {
+    {
+        for (int64_t i = i0; i < i1; i++) {
             int64_t v = order[i];
             const orc_variable *var = &g->variable[v];
             if (var->isEvidence == 4) continue;
@@ -679,30 +729,31 @@ static int accumulate_visit(const orc_graph *g, int64_t fid, int64_t v, int64_t 
     rc = orc_eval_factor(g, fid, v, proposal, var_value, &p1);
     if (rc) return rc;
     double gradient = (p1 - p0) * g->factor[fid].featureValue;
-    G[wid] += (int64_t)llrint(gradient * ldexp(1.0, 32 - g->grad_shift));
-    K[wid] += 1;
-    if (truncate) T[wid] += 1;
+    /* (integer sums: the order of the adds does not matter, so the threads of a colour class -- orc_set_threads -- add
+     * atomically into the same arrays) */
+    __atomic_fetch_add(&G[wid], (int64_t)llrint(gradient * ldexp(1.0, 32 - g->grad_shift)), __ATOMIC_RELAXED);
+    __atomic_fetch_add(&K[wid], (int64_t)1, __ATOMIC_RELAXED);
+    if (truncate) __atomic_fetch_add(&T[wid], (int64_t)1, __ATOMIC_RELAXED);
     return ORC_OK;
 }
 
-int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t *phase_start,
-                        int64_t nphase, double step, int regularization, double reg_param,
-                        int64_t truncation, int64_t *var_value, int64_t *var_value_evid,
-                        double *weight_value, int learn_non_evidence, uint64_t seed,
-                        uint64_t sweep, double cap, double *weight_lag) {
-    /* weight_lag != NULL: the device's one-class lag (nsk_set_learn_lag) -- a class samples with the
-     * weights as of the end of the class before the previous one (weight_lag), its update moves
-     * weight_value on from the previous class's result; the caller sets weight_lag = weight_value at the
-     * start of every device call and carries it from sweep to sweep inside one */
-    const double *weight_samp = weight_lag ? weight_lag : weight_value;
+typedef struct {
+    const orc_graph *g; const int64_t *order; int regularization; int64_t truncation; int64_t *var_value, *var_value_evid;
+    const double *weight_samp; int learn_non_evidence; uint64_t seed, sweep; int64_t *G, *K, *T;
+} orc_learn_ctx;
+static int orc_learn_range_dev(void *vctx, int64_t i0, int64_t i1) {
+    const orc_learn_ctx *x = (const orc_learn_ctx *)vctx;
+    const orc_graph *g = x->g;
+    const int64_t *order = x->order;
+    const int regularization = x->regularization, learn_non_evidence = x->learn_non_evidence;
+    const int64_t truncation = x->truncation;
+    int64_t *var_value = x->var_value, *var_value_evid = x->var_value_evid, *G = x->G, *K = x->K, *T = x->T;
+    const double *weight_samp = x->weight_samp;
+    const uint64_t seed = x->seed, sweep = x->sweep;
     double *Z = (double *)malloc(sizeof(double) * (size_t)max_card(g));
-    int64_t *G = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
-    int64_t *K = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
-    int64_t *T = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
     int rc = ORC_OK;
-    for (int64_t p = 0; p < nphase && !rc; p++) {
-        if (phase_start[p] == phase_start[p + 1]) continue;     /* (an empty class is no class: no update, no lag step) */
-        for (int64_t i = phase_start[p]; i < phase_start[p + 1] && !rc; i++) {
+    {
+        for (int64_t i = i0; i < i1 && !rc; i++) {
             int64_t v = order[i];
             const orc_variable *var = &g->variable[v];
             if (var->isEvidence == 4) continue;
@@ -747,6 +798,32 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
                                       truncate, G, K, T);
             }
         }
+    }
+    free(Z);
+    return rc;
+}
+
+int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t *phase_start,
+                        int64_t nphase, double step, int regularization, double reg_param,
+                        int64_t truncation, int64_t *var_value, int64_t *var_value_evid,
+                        double *weight_value, int learn_non_evidence, uint64_t seed,
+                        uint64_t sweep, double cap, double *weight_lag) {
+    /* weight_lag != NULL: the device's one-class lag (nsk_set_learn_lag) -- a class samples with the
+     * weights as of the end of the class before the previous one (weight_lag), its update moves
+     * weight_value on from the previous class's result; the caller sets weight_lag = weight_value at the
+     * start of every device call and carries it from sweep to sweep inside one */
+    const double *weight_samp = weight_lag ? weight_lag : weight_value;
+    int64_t *G = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
+    int64_t *K = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
+    int64_t *T = (int64_t *)calloc((size_t)g->nweight, sizeof(int64_t));
+    int rc = ORC_OK;
+    for (int64_t p = 0; p < nphase && !rc; p++) {
+        if (phase_start[p] == phase_start[p + 1]) continue;     /* (an empty class is no class: no update, no lag step) */
+        {
+            orc_learn_ctx ctx = {g, order, regularization, truncation, var_value, var_value_evid, weight_samp,
+                                 learn_non_evidence, seed, sweep, G, K, T};
+            rc = orc_parallel_range(phase_start[p], phase_start[p + 1], orc_learn_range_dev, &ctx);
+        }
         if (rc) break;
         /* end of phase: apply the batch to every touched weight */
         for (int64_t w = 0; w < g->nweight; w++) {
@@ -778,7 +855,7 @@ int orc_learn_sweep_dev(const orc_graph *g, const int64_t *order, const int64_t 
             G[w] = 0; K[w] = 0; T[w] = 0;
         }
     }
-    free(Z); free(G); free(K); free(T);
+    free(G); free(K); free(T);
     return rc;
 }
 

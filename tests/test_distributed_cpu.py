@@ -294,3 +294,63 @@ def test_shard_local_graph_plans_like_the_whole_graph():
             assert np.array_equal(whole.ghost_needs(host_only=True), gids[part.ghost_needs(host_only=True)])
             total += len(sg[2])
         assert total < 2 * len(g[2])                      # factors are shared by at most the shards they touch
+
+
+def _merge_worker(rank, world, port, nw, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from numbskull_amd.distributed import merge_weight_deltas_sliced
+    rng = np.random.default_rng(100)
+    start = rng.normal(size=nw)
+    mine = start + np.random.default_rng(200 + rank).normal(size=nw) * 10.0 ** np.random.default_rng(300 + rank).integers(-12, 3, nw)
+    w = torch.from_numpy(mine.copy())
+    merge_weight_deltas_sliced(dist, w, torch.from_numpy(start), rank, world)
+    np.save(os.path.join(outdir, "w%d.npy" % rank), w.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nw", [(3, 7), (3, 2), (4, 10), (4, 1000003 % 4099)])
+def test_sliced_weight_merge_on_uneven_slices(tmp_path, world, nw):
+    """The reduce-scatter + all-gather merge of the weight deltas (the peer-to-peer path's, nsk_kernels_misc.h
+    p2p_reduce_slice; salt/src/numbskull_master.py:223-224 w = w0 + sum of the minions' deltas) with world sizes that are
+    not powers of two and weight counts they do not divide -- slices of unequal length, an empty slice (2 weights on 3
+    ranks): every rank ends with the SAME bits, equal to the rank-ordered sum."""
+    from numbskull_amd.distributed import weight_slice
+    mp.spawn(_merge_worker, args=(world, _free_port(), nw, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(100)
+    start = rng.normal(size=nw)
+    deltas = []
+    for r in range(world):
+        mine = start + np.random.default_rng(200 + r).normal(size=nw) * 10.0 ** np.random.default_rng(300 + r).integers(-12, 3, nw)
+        deltas.append(mine - start)
+    want = np.zeros(nw)
+    for q in range(world):
+        lo, hi = weight_slice(q, world, nw), weight_slice(q + 1, world, nw)
+        t = deltas[0][lo:hi].copy()
+        for r in range(1, world):
+            t += deltas[r][lo:hi]
+        want[lo:hi] = start[lo:hi] + t
+    got = [np.load(tmp_path / ("w%d.npy" % r)) for r in range(world)]
+    for r in range(world):
+        assert np.array_equal(got[r], want), r
+    assert [weight_slice(q, world, nw) for q in range(world + 1)][-1] == nw
+
+
+@pytest.mark.parametrize("two,ev", [(False, False), (True, True)])
+def test_grid_shard_generator_equals_the_cut_of_the_whole_grid(two, ev):
+    """graphgen.ising_grid_shard builds a rank's shard of a grid from its own cells (+ one row): record for record what
+    extract_shard cuts out of the whole grid -- ragged ranges that split rows, the first and the last shard, an empty one."""
+    n, m = 23, 17
+    rng = np.random.default_rng(4)
+    evid = rng.integers(0, 2, n * m)
+    whole = graphgen.ising_grid(n, m, weight=0.3, fixed=not two, two_weights=two, evidence=evid if ev else None)
+    for lo, hi in [(0, 50), (50, 51), (51, 200), (200, 391), (100, 100), (0, 391), (380, 391), (3, 20)]:
+        a, ga, oa = graphgen.extract_shard(whole, lo, hi)
+        b, gb, ob = graphgen.ising_grid_shard(n, m, lo, hi, weight=0.3, fixed=not two, two_weights=two,
+                                              evidence=(lambda ids: evid[ids]) if ev else None)
+        assert np.array_equal(ga, gb) and oa == ob, (lo, hi)
+        for x, y in zip(a[:5], b[:5]):
+            assert x.dtype == y.dtype and np.array_equal(x, y), (lo, hi)
+        assert a[5] == b[5]

@@ -113,3 +113,62 @@ def test_many_weight_lr_graph_chromatic_matches_sequential():
     assert np.corrcoef(w_seq, w_chr)[0, 1] > 0.95, np.corrcoef(w_seq, w_chr)[0, 1]
     assert d.mean() < 0.03 and d.max() < 0.15, (d.mean(), d.max())
     assert d.mean() < 1.5 * d2.mean() + 0.005, (d.mean(), d2.mean())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The tie in the north star's own unit: marginals.  Both scans climb the same (regularised) likelihood; what the
+# chromatic scan's per-class batches, step cap and one-class lag change is the path and the SGD noise, not the fixed
+# point.  Learn with the reference's own trajectory (scan="sequential" = sample_and_sgd, learning.py:46-125) and with
+# the production scan at the reference's CLI defaults, then compute the EXACT marginals of one unit of the model
+# (a pair, a labelled data point, the grid itself: enumeration, tests/util.py exact_marginals) under both weight
+# vectors: max |delta marginal| < 1e-3 once the decayed step has frozen both runs.
+def _unit_marginals(unit, w):
+    from oracle import binding as orc
+    from util import exact_marginals
+    import numbskull_amd
+    ns = numbskull_amd.NumbSkull(quiet=True)
+    ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in unit[:5]], int(unit[5]))
+    fg = ns.factorGraphs[0]
+    og = orc.Graph(fg.weight, fg.variable, fg.factor, fg.fmap, fg.vmap, fg.factor_index)
+    m = exact_marginals(og, np.asarray(w, np.float64))
+    return np.concatenate([m[i] for i in sorted(m)])
+
+
+def _tie(g, unit, epochs, **kw):
+    w_seq, _ = learn(g, "sequential", epochs, **kw)
+    w_chr, _ = learn(g, "chromatic", epochs, **kw)
+    d = np.abs(_unit_marginals(unit, w_seq) - _unit_marginals(unit, w_chr)).max()
+    print("tie: |dw| max %.5f, max |delta marginal| %.2e  (weights %s / %s)" % (np.abs(w_seq - w_chr).max(), d, w_seq, w_chr))
+    return d
+
+
+def test_marginals_under_both_scans_pairs():
+    g = graphgen.ising_pairs(20000, 1.0, 1.0, 0.5, seed=7)
+    unit = list(graphgen.ising_pairs(1, 1.0, 1.0, 0.5, seed=7))
+    unit[1] = unit[1].copy(); unit[1]["isEvidence"] = 0                    # the pair as a query: both variables free
+    assert _tie(g, tuple(unit), 400) < 1e-3
+
+
+def test_marginals_under_both_scans_lf():
+    g = graphgen.lf_graph(0.0, [1.5, 1.0, 0.5], 20000, seed=3)
+    unit = list(graphgen.lf_graph(0.0, [1.5, 1.0, 0.5], 1, seed=3))
+    unit[1] = unit[1].copy(); unit[1]["isEvidence"] = 0
+    assert _tie(g, tuple(unit), 400) < 1e-3
+
+
+def test_marginals_under_both_scans_small_grid():
+    """3 x 4 grid, two weights; the evidence: 4096 independent configurations of that grid sampled at planted weights
+    (0.3, 0.15) -- one 12-variable configuration alone has no maximum-likelihood weights worth comparing -- as 4096
+    disjoint copies that share the two weights; the marginals: those of the 12-variable grid itself."""
+    rows, cols, reps = 3, 4, 4096
+    g1 = graphgen.ising_grid(rows, cols, weight=0.0, fixed=True, two_weights=True)
+    g1[0]["initialValue"] = (0.3, 0.15)
+    ns, fg = session(g1, seed=11)
+    cfgs = []
+    for _ in range(reps):
+        fg.inference(0, 20, True)
+        cfgs.append(fg.var_value[0].copy())
+    one = graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True, evidence=cfgs[0])
+    g = graphgen.replicate(one, cfgs)
+    unit = graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True)
+    assert _tie(g, unit, 400) < 1e-3

@@ -165,3 +165,63 @@ def test_learning_trace(golden, tag, reg, lne, trunc):
         assert np.array_equal(vv, vvs[e + 1]), (name, e)
         assert np.array_equal(ve, ves[e + 1]), (name, e)
         assert np.array_equal(wv, ws[e + 1]), (name, e, wv, ws[e + 1])
+
+
+# ---------------------------------------------------------------- device mode: thread-count independence
+@pytest.mark.parametrize("reg", [0, 1, 2])
+def test_device_mode_is_thread_count_independent(reg):
+    """The device-mode sweeps walk a colour class with several host threads (orc_set_threads; the class's variables do
+    not read each other, the gradient sums are integers): values, tallies and weights must not depend on their number."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from numbskull_amd import graphgen
+    rng = np.random.default_rng(2)
+    g = graphgen.ising_grid(120, 130, weight=0.2, fixed=False, two_weights=True, evidence=rng.integers(0, 2, 120 * 130))
+    g[1]["isEvidence"] = (rng.random(120 * 130) < 0.5).astype(g[1]["isEvidence"].dtype)
+    import numbskull_amd                      # (its host-side index build: plain numpy + C++, no GPU)
+    ns = numbskull_amd.NumbSkull(quiet=True)
+    ns.loadFactorGraph(*[x.copy() if isinstance(x, np.ndarray) else x for x in g[:5]], int(g[5]))
+    fg = ns.factorGraphs[0]
+    og = orc.Graph(fg.weight, fg.variable, fg.factor, fg.fmap, fg.vmap, fg.factor_index)
+    i, j = np.divmod(np.arange(120 * 130), 130)
+    color = ((i + j) & 1).astype(np.int32)
+    assert og.check_coloring(color) == (-1, -1)
+    order = np.concatenate([np.flatnonzero(color == 0), np.flatnonzero(color == 1)]).astype(np.int64)
+    ps = np.array([0, int((color == 0).sum()), len(color)], np.int64)
+    out = []
+    for threads in (1, 7):
+        orc.set_threads(threads)
+        vv, ve, wv, cnt = og.initial_state()
+        for s in range(3):
+            assert og.gibbs_dev(order, ps, vv, wv, cnt, 5, s, True) == 0
+        assert og.learn_call(order, ps, vv, ve, wv, 3, 0.01, 0.9, reg, 0.05, 2, True, 5, 3) == 0
+        out.append((vv.copy(), ve.copy(), wv.copy(), cnt.copy()))
+    orc.set_threads(min(64, os.cpu_count() or 1))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert np.any(out[0][3] != 0) and (reg == 1 or np.any(out[0][2] != 0.0))
+
+
+# ---------------------------------------------------------------- f3: why UFO aggregation is not built
+def test_ufo_returns_its_first_member_on_binary_variables(golden):
+    """SURVEY.md section 8 f3 / salt/src/messages.py:1049-1080: the reference's UFO scheme ships, per boundary variable, the
+    summed factor-value differences of its remote factors and lets a two-member UFO factor (30) deliver them from a
+    helper variable.  eval_factor's UFO branch (inference.py:398-405) returns 0 for x_0 = 0 and member x_0 - 1 otherwise:
+    for x_0 = 1 that member is x_0 ITSELF, so on a binary variable -- every variable of BASELINE's partitioned configs --
+    the factor's value is x_0 whatever the helper holds: the aggregate cannot reach the potential.  Pinned here on the
+    REFERENCE's own table (tests/golden/g1_eval_factor.npz, generated by importing it) and on the oracle; DESIGN.md
+    section 5 closes the row with this test's name (partial factors, which do deliver their aggregates, are built)."""
+    z = golden("g1_eval_factor.npz")
+    variable, factor, fmap, states, cases = (z[k] for k in ("variable", "factor", "fmap", "states", "cases"))
+    n_seen = 0
+    for fid, s, var_samp, value, status, want in cases:
+        fa = factor[int(fid)]
+        if int(fa["factorFunction"]) != 30 or int(status) != 0:
+            continue
+        x0_vid = int(fmap[int(fa["ftv_offset"])]["vid"])
+        x0 = int(value) if x0_vid == int(var_samp) else int(states[int(s)][x0_vid])
+        if x0 in (0, 1):
+            assert int(want) == x0, (fid, s, var_samp, value, want)       # never the helper's value
+            n_seen += 1
+    assert n_seen >= 100
