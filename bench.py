@@ -60,6 +60,8 @@ WORKLOADS = {
     # the one beyond it
     "ising4m": (2000, 2000, False),
     "ising40m": (5000, 8000, False),
+    "ising4m_learn": (2000, 2000, True),
+    "ising40m_learn": (5000, 8000, True),
     "ising100m": (10000, 10000, False),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak

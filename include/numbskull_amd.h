@@ -346,6 +346,14 @@ int nsk_graph_order(int64_t nvar, int64_t nfactor, const nsk_factor *factor, int
                     int method, int64_t *order, int64_t *cc_id, int64_t *ncc);
 int nsk_comm_volume(int64_t nvar, int64_t nfactor, const nsk_factor *factor, int64_t nedge, const nsk_ftv *fmap,
                     const int64_t *new_id, int nparts, int64_t *volume);
+/* The multilevel partitioner (find_metis_parts, messages.py:593-670: nxmetis.partition with objtype = vol): heavy-edge
+ * matching, a partition of the coarsest graph, greedy k-way boundary refinement on the way up and, at the finest
+ * level, refinement of nsk_comm_volume itself with the parts held at exactly the shard formula's sizes.
+ * order[new id] = old id: range g of the new ids is part g; part[old id] = g (may be NULL); stats (may be NULL)
+ * receives 5 numbers: levels, coarsest vertices, edge cut after uncoarsening, communication volume before / after
+ * the last refinement.  Deterministic in (graph, nparts, seed); nparts <= 64, nvar < 2^31. */
+int nsk_graph_partition(int64_t nvar, int64_t nfactor, const nsk_factor *factor, int64_t nedge, const nsk_ftv *fmap,
+                        int nparts, uint64_t seed, int64_t *order, int64_t *part, int64_t *stats);
 
 /* ---- host-side index build and file parsing (no GPU needed) ---- */
 /* dataloading.compute_var_map (dataloading.py:16-81), native and O(edges). */

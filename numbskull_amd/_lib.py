@@ -27,7 +27,7 @@ SYMBOLS = (
     "nsk_set_stream", "nsk_synchronize", "nsk_ghost_needs", "nsk_exchange_setup", "nsk_exchange_pack",
     "nsk_exchange_unpack", "nsk_comm_unique_id", "nsk_comm_init", "nsk_gibbs_sweeps_exchange",
     "nsk_learn_sweeps_exchange", "nsk_pf_setup", "nsk_p2p_setup", "nsk_p2p_export", "nsk_p2p_import", "nsk_p2p_import_local",
-    "nsk_gibbs_sweeps_p2p", "nsk_learn_sweeps_p2p", "nsk_p2p_exchange", "nsk_p2p_selftest", "nsk_p2p_fuse", "nsk_p2p_check", "nsk_p2p_reset", "nsk_profile_mark", "nsk_profile_read", "nsk_graph_order", "nsk_comm_volume", "nsk_compute_var_map", "nsk_state_layout", "nsk_parse_factors", "nsk_parse_domains", "nsk_write_probabilities",
+    "nsk_gibbs_sweeps_p2p", "nsk_learn_sweeps_p2p", "nsk_p2p_exchange", "nsk_p2p_selftest", "nsk_p2p_fuse", "nsk_p2p_check", "nsk_p2p_reset", "nsk_profile_mark", "nsk_profile_read", "nsk_graph_order", "nsk_comm_volume", "nsk_graph_partition", "nsk_compute_var_map", "nsk_state_layout", "nsk_parse_factors", "nsk_parse_domains", "nsk_write_probabilities",
     "nsk_selftest_exp", "nsk_selftest_philox", "nsk_selftest_stream", "nsk_device_count", "nsk_last_error", "nsk_version",
 )
 
@@ -133,6 +133,8 @@ def lib():
                                       C.c_void_p, C.POINTER(C.c_int64)]
         L.nsk_comm_volume.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                       C.POINTER(C.c_int64)]
+        L.nsk_graph_partition.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_uint64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
         L.nsk_compute_var_map.argtypes = [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int64]

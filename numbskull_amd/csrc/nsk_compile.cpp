@@ -968,6 +968,7 @@ static void plan_learning_launches(Compiled &c, int32_t ncolors) {
                     t.zoff[t.n] = sg.ztab >= 0 ? (uint32_t)sg.ztab : 0u;
                     t.zmask[t.n] = (1u << sg.nslots) - 1u;
                     t.ev[t.n] = sg.ev;
+                    t.wide[t.n] = sg.wide;
                     t.tile_start[t.n + 1] = t.tile_start[t.n] + sg.ntiles;
                     if (++t.n == 8) { tabs.push_back(t); t.n = 0; t.tile_start[0] = 0; }
                 }

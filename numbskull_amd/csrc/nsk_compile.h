@@ -145,7 +145,8 @@ struct Compiled {
     // their own (at most NSK_LEARN_SEG_LAUNCHES per colour); every other non-general tile is on
     // the colour's learn_rest list
     struct SegLaunch { int32_t phase, kind, nch, n, tab; int32_t tile_start[9]; int32_t pos0[8];
-                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], aff[8]; int32_t ev[8]; };
+                       uint32_t adj_off[8], prog[8], zoff[8], zmask[8], aff[8]; int32_t ev[8];
+                       int64_t wide[8]; };    // first dword of the segment's quad descriptors in seg_wide (-1: none)
     std::vector<SegLaunch> learn_seg;
     std::vector<uint32_t> learn_rest_tiles;
     std::vector<int64_t> phase_learn_rest_base;   // [ncolors+1]

@@ -288,6 +288,19 @@ static inline int nsk_tabw_grid(int vtiles) {
     const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : 256 * NSK_TABW_PER_CU;
     return std::min(cap, need);
 }
+// Grid of a wide-quad learning launch (k_learn_seg_tabw) over `vtiles` virtual tiles, whole rounds of XCDs (the service
+// blocks in front come on top).  Measured on one MI355X (tools/sessions/r6_s16.sh, us per learning sweep): 10M grid
+// 46.1 / 50.5 / 52.0 / 42.3 / 42.5 / 53.8 / 50.2 / 43.5 / 56.4 at 768 / 1024 / 1280 / 1408 / 1536 / 1664 / 1792 / 2048 /
+// 2560 blocks (45.5 tile by tile); 40M grid 121.0 / 112.8 / 115.8 at 1536 / 2048 / 4096 (150.7 tile by tile); on the 4M
+// grid the tile-by-tile kernel wins (25.2 against 31.4), hence NSK_WIDE_LEARN_MIN_QUADS.
+#define NSK_WIDE_LEARN_MIN_QUADS 12000
+static inline int nsk_learn_tabw_grid(int vtiles) {
+    const int nquads = vtiles / 4 + 8;
+    const int need = std::max(8, 8 * ((((nquads + 3) / 4) + 7) / 8));
+    const char *cap_env = nsk::diag_env("NSK_LEARN_TABW_GRID_CAP");         // (diagnostic)
+    const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : (nquads >= 40000 ? 2048 : 1536);
+    return std::min(cap, need);
+}
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {
     const int ntiles = sl.tile_start[sl.n];
     if (sl.tab && use_tab) return nsk_learn_tab_grid(ntiles, nweight, smallw);

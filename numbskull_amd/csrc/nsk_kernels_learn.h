@@ -945,6 +945,246 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
     close_sink<SMALLW>(g, sk);
 }
 
+// ---- the learning launch of a class whose quads are (mostly) wide ones (nsk_compile.h seg_wide; int8 values) ----
+// sample_and_sgd (learning.py:46-125) for four consecutive positions per lane: per member slot ONE dword load from each
+// chain's value array brings the four neighbour bytes (k_gibbs_seg_tabw's trick), both chains' neighbourhoods are packed
+// by shifts, the eight table entries come from the wave's LDS copy of the segment's draw table, both chains' new values
+// leave as one dword each, and the gradient bookkeeping -- per slot: (satisfied under the proposal) - (satisfied under
+// the evidence), summed over the class's visits -- stays in per-LANE counters (popcounts of packed bytes) until the slot
+// program changes or the wave ends: no ballot, no cross-lane step per tile.  The generator is the learning sweeps' own:
+// one block per POSITION, counter (position, stream, sweep) -- the oracle's learning mode is untouched.
+// Quads that are not wide are sampled tile by tile (learn_tab_tile), as k_learn_seg_tab does.
+template <int NCH>
+struct WideLearnTrip { uint32_t xf[4 * NCH], xe[4 * NCH], init; };
+
+// one tile of a table segment, tile by tile (the fall-back of the wide kernel): acc / accK / accT are the wave's scalar
+// gradient counters
+template <int NCH>
+__device__ __forceinline__ void learn_tab_tile(const DevGraph<signed char> &g, const LearnParams &lp, const SegEntry &en, int t, int lane,
+                                               int (&acc)[4 * NCH], uint32_t &accK, uint32_t &accT) {
+    const int nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
+    if (t < 0 || t >= nt) return;                                       // (wave-uniform: a dead tile of the quad)
+    const uint32_t zmask = en.zmask_ev & 0xFFu;
+    const int ev = (int)(int8_t)(en.zmask_ev >> 8);
+    const int p = en.pos0 + t * 64 + lane;
+    const int init = (int)g.p_init[p];                                  // -1: padding lane
+    uint32_t id[4 * NCH];
+    bool aff = false;
+    if (en.aff_off != NSK_NO_STREAM) {
+        const NSK_SCALAR uint32_t *ap = (const NSK_SCALAR uint32_t *)(g.seg_aff + en.aff_off + (size_t)t * NCH);
+        aff = ap[0] != NSK_NO_STREAM;
+        if (aff) {
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) id[j] = ap[j] + (uint32_t)lane;
+        }
+    }
+    if (!aff) {
+        const uint4 *sp = g.adj + en.adj_off + (size_t)t * (64 * NCH) + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const uint4 q = sp[c * 64];
+            id[4 * c] = q.x; id[4 * c + 1] = q.y; id[4 * c + 2] = q.z; id[4 * c + 3] = q.w;
+        }
+    }
+    uint32_t idf = 0, ide = 0;
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) {
+        idf |= ((uint32_t)(uint8_t)g.val[id[j]] & 1u) << j;
+        ide |= ((uint32_t)(uint8_t)g.val_evid[id[j]] & 1u) << j;
+    }
+    const uint4 ef = g.ztab[en.zoff + (idf & zmask)], ee = g.ztab[en.zoff + (ide & zmask)];
+    const u32x4 rr = philox4x32(lp.k0, lp.k1, (uint32_t)p, 0u, lp.s0, lp.s1);
+    int evidence = init;                                                // learning.py:61-62
+    if (ev != 1) evidence = k53(rr.z, rr.w) > ztab_K(ee) ? 1 : 0;       // 54-58
+    const int proposal = k53(rr.x, rr.y) > ztab_K(ef) ? 1 : 0;          // 66-70
+    const bool valid = init >= 0;
+    if (valid) {
+        g.val_evid[p] = (signed char)evidence;
+        g.val[p] = (signed char)proposal;
+    }
+    const bool part = valid && (lp.learn_non_evidence || ev == 1);      // 71-72
+    if (lp.regularization == 1) {                                       // 90
+        const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)p, 1u, lp.s0, lp.s1);
+        accT += (uint32_t)__popcll(__ballot(part && (u53(tt.x, tt.y) < lp.inv_trunc)));
+    }
+    accK += (uint32_t)__popcll(__ballot(part));
+    const uint32_t satf = part ? (proposal ? (ef.z >> 8) : ef.z) : 0u;
+    const uint32_t sate = part ? (evidence ? (ee.z >> 8) : ee.z) : 0u;
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++)
+        acc[j] += __popcll(__ballot((satf >> j) & 1u)) - __popcll(__ballot((sate >> j) & 1u));
+}
+
+template <bool SMALLW, int NCH>
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tabw(DevGraph<signed char> g, SegTable tab, LearnParams lp, ApplyArgs prev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (SMALLW && blockIdx.x < NSK_SERVICE_BLOCKS) {                   // (block-uniform) the previous class's update rides here
+        if (blockIdx.x == 0 && prev.nweight > 0) apply_bins_block(prev);
+        return;
+    }
+    constexpr int ST = NSK_WIDE_STRIDE(NCH), ZN = 1 << NSK_ZT_BITS(NCH), ZR = (ZN + 63) / 64;
+    __shared__ uint4 zt_all[(NSK_BLOCK / 64) * ZN];                     // the wave's copy of its segment's table entries
+    const int bid = (int)blockIdx.x - (SMALLW ? NSK_SERVICE_BLOCKS : 0);
+    const int gdim = (int)gridDim.x - (SMALLW ? NSK_SERVICE_BLOCKS : 0);
+    const GradSink sk = open_sink<SMALLW>(g, smem);
+    const int lane = (int)(threadIdx.x & 63);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint4 *zt = zt_all + wv * ZN;
+    const int nquads = tab.ntiles >> 2;                                 // virtual tiles: every segment is whole quads
+    const int per = (nquads + 7) >> 3;                                  // quads per XCD
+    const int xcd = bid & 7;
+    const int wx = __builtin_amdgcn_readfirstlane((bid >> 3) * (NSK_BLOCK / 64)) + wv;
+    const int wpx = (gdim >> 3) * (NSK_BLOCK / 64);                     // waves per XCD (grid: multiple of 8)
+    const int q0 = min(nquads, xcd * per), q1 = min(nquads, (xcd + 1) * per);
+    // gradient counters: per lane while the quads are wide (accv: packed-byte popcounts), per wave for tiles (acc:
+    // ballots); they reach the sink when the slot program changes and at the end -- integer sums, any grouping
+    uint32_t cur_prog = 0xFFFFFFFFu;
+    int acc[4 * NCH], accv[4 * NCH];
+    uint32_t accK = 0u, accT = 0u, accKv = 0u, accTv = 0u;
+#pragma unroll
+    for (int j = 0; j < 4 * NCH; j++) { acc[j] = 0; accv[j] = 0; }
+    auto flush = [&]() {
+        if (cur_prog != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) {
+                int v = accv[j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                acc[j] += v;
+            }
+            uint32_t vk = accKv, vt = accTv;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { vk += __shfl_xor(vk, off, 64); vt += __shfl_xor(vt, off, 64); }
+            accK += vk; accT += vt;
+            if (accK != 0u) {
+                const NSK_SCALAR uint32_t *pp = (const NSK_SCALAR uint32_t *)(g.tile_hdr + cur_prog);
+#pragma unroll
+                for (int j = 0; j < 4 * NCH; j++) {
+                    const uint32_t s = pp[j];
+                    const bool closes = (s >> 28) & 1u, fixed = (s >> 30) & 1u;      // uniform
+                    if (closes && !fixed && lane == 0) {
+                        const uint32_t code = (s >> 24) & 7u;
+                        const long long span = code == 0u ? 0 : (code == 1u ? 1 : 2);            // hi - lo
+                        const long long dG = (span * (long long)acc[j]) * g.grad_mul;            // Q31.32
+                        const int wid = (int)(s & 0xFFFFFFu);
+                        sink_add(sk.local, (unsigned long long *)&sk.G[wid], (unsigned long long)(dG + (sk.packed ? (long long)accK : 0)));
+                        if (!sk.packed) sink_add(sk.local, &sk.K[wid], accK);
+                        if (accT) sink_add(sk.local, &sk.T[wid], accT);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * NCH; j++) { acc[j] = 0; accv[j] = 0; }
+        accK = 0u; accT = 0u; accKv = 0u; accTv = 0u;
+    };
+    for (int Q = q0 + wx; Q < q1;) {
+        // the segment of the quad, and the wave's quads inside it (every segment is whole quads of the launch)
+        const int sidx = seg_of_tile(tab, 4 * Q);
+        const SegEntry en = tab.e[sidx];
+        const int c_hi = sidx + 1 < NSK_SEG_MAX ? tab.e[sidx + 1].tile_start : tab.ntiles;
+        const int Qe = min(q1, c_hi >> 2);
+        const int lead = (int)(en.ntiles_lead >> 30), nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
+        const int qs = en.tile_start >> 2;
+        const int qin_lo = qs + (lead ? 1 : 0);
+        const uint32_t qin_n = (uint32_t)(qs + ((lead + nt) >> 2) - qin_lo);
+        const bool hasw = en.wide_off != NSK_NO_STREAM;
+        const uint32_t zmask = en.zmask_ev & 0xFFu;
+        const int ev = (int)(int8_t)(en.zmask_ev >> 8);
+        const NSK_SCALAR uint32_t *wq = (const NSK_SCALAR uint32_t *)(g.seg_wide + (hasw ? en.wide_off : 0u)) + (hasw ? (size_t)(Q - qs) * ST : 0);
+        const size_t wstep = hasw ? (size_t)wpx * ST : 0;
+        int p0 = en.pos0 + (4 * Q - en.tile_start - lead) * 64;
+        if (en.prog != cur_prog) { flush(); cur_prog = en.prog; }             // uniform, rare
+        uint32_t cur[ST];
+#pragma unroll
+        for (int j = 0; j < ST; j++) cur[j] = wq[j];
+        // the wave's copy of the segment's table entries (threshold: 27 + 26 bits, satisfied bits of both candidates)
+#pragma unroll
+        for (int r = 0; r < ZR; r++) {
+            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)r;
+            if (e < (uint32_t)ZN) zt[e] = e <= zmask ? g.ztab[en.zoff + e] : uint4{0u, 0u, 0u, 0u};
+        }
+        asm volatile("" ::: "memory");                                  // (LDS executes a wave's accesses in order: no barrier)
+        for (; Q < Qe; Q += wpx, p0 += 256 * wpx) {
+            const bool flagged = hasw && cur[0] != 0xFFFFFFFFu, wide = flagged && (uint32_t)(Q - qin_lo) < qin_n;
+            const uint32_t exc0 = cur[4 * NCH], nexc = cur[4 * NCH + 1], smask = cur[4 * NCH + 2];
+            asm volatile("" :: "s"(cur[4 * NCH + 3]));
+            WideLearnTrip<NCH> tr;
+            const uint32_t l4 = 4u * (uint32_t)lane;
+            if (wide) {
+#pragma unroll
+                for (int j = 0; j < 4 * NCH; j++) {
+                    tr.xf[j] = *(const nsk_u32_una *)((const char *)g.val + (cur[j] + l4));
+                    tr.xe[j] = *(const nsk_u32_una *)((const char *)g.val_evid + (cur[j] + l4));
+                }
+                tr.init = *(const uint32_t *)((const char *)g.p_init + ((uint32_t)p0 + l4));
+            }
+            if (Q + wpx < Qe) wq += wstep;                              // the next trip's descriptor, a scalar round trip ahead
+#pragma unroll
+            for (int j = 0; j < ST; j++) cur[j] = wq[j];
+            if (!wide) {                                                // tile by tile
+#pragma unroll 1
+                for (int t = 0; t < 4; t++) learn_tab_tile<NCH>(g, lp, en, 4 * Q - en.tile_start - lead + t, lane, acc, accK, accT);
+                continue;
+            }
+            // the four blocks of the lane's positions while the loads are in flight
+            u32x4 rr[4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) rr[i] = philox4x32(lp.k0, lp.k1, (uint32_t)p0 + l4 + (uint32_t)i, 0u, lp.s0, lp.s1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) asm volatile("" :: "v"(rr[i].x), "v"(rr[i].y), "v"(rr[i].z), "v"(rr[i].w));
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t idf4 = 0, ide4 = 0;
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++) { idf4 |= (tr.xf[j] & 0x01010101u) << j; ide4 |= (tr.xe[j] & 0x01010101u) << j; }
+            idf4 &= smask * 0x01010101u;
+            ide4 &= smask * 0x01010101u;
+            for (uint32_t e = 0; e < nexc; e++) {                       // scalar loop, rare: the odd cells of the quad
+                const NSK_SCALAR uint32_t *xp = (const NSK_SCALAR uint32_t *)g.wide_exc + 2 * (size_t)(exc0 + e);
+                const uint32_t ex = xp[0], eid = xp[1];
+                const uint32_t o = ex & 0xFFu, sh = 8u * (o & 3u) + ((ex >> 8) & 7u);
+                if ((uint32_t)lane == (o >> 2)) {
+                    idf4 = (idf4 & ~(1u << sh)) | (((uint32_t)(uint8_t)g.val[eid] & 1u) << sh);
+                    ide4 = (ide4 & ~(1u << sh)) | (((uint32_t)(uint8_t)g.val_evid[eid] & 1u) << sh);
+                }
+            }
+            uint32_t outf = 0, oute = 0, satf4 = 0, sate4 = 0, part4 = 0, trunc4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint4 ef = zt[(idf4 >> (8 * i)) & 0xFFu], ee = zt[(ide4 >> (8 * i)) & 0xFFu];
+                const int init = (int)(int8_t)(tr.init >> (8 * i));                       // -1: padding position
+                int evidence = init & 1;                                                  // learning.py:61-62
+                if (ev != 1) evidence = k53(rr[i].z, rr[i].w) > ztab_K(ee) ? 1 : 0;       // 54-58
+                const int proposal = k53(rr[i].x, rr[i].y) > ztab_K(ef) ? 1 : 0;          // 66-70
+                const bool part = init >= 0 && (lp.learn_non_evidence || ev == 1);        // 71-72
+                outf |= (uint32_t)proposal << (8 * i);
+                oute |= (uint32_t)evidence << (8 * i);
+                satf4 |= (part ? ((proposal ? (ef.z >> 8) : ef.z) & 0xFFu) : 0u) << (8 * i);
+                sate4 |= (part ? ((evidence ? (ee.z >> 8) : ee.z) & 0xFFu) : 0u) << (8 * i);
+                part4 |= (part ? 1u : 0u) << (8 * i);
+            }
+            if (lp.regularization == 1) {                                                 // 90
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const u32x4 tt = philox4x32(lp.k0, lp.k1, (uint32_t)p0 + l4 + (uint32_t)i, 1u, lp.s0, lp.s1);
+                    trunc4 |= (((part4 >> (8 * i)) & 1u) && u53(tt.x, tt.y) < lp.inv_trunc ? 1u : 0u) << (8 * i);
+                }
+            }
+            // (a padding position keeps what it holds: the stores cover whole dwords, so its bytes are written back)
+            *(uint32_t *)((char *)g.val + ((uint32_t)p0 + l4)) = outf;
+            *(uint32_t *)((char *)g.val_evid + ((uint32_t)p0 + l4)) = oute;
+            accKv += (uint32_t)__popc(part4);
+            accTv += (uint32_t)__popc(trunc4);
+#pragma unroll
+            for (int j = 0; j < 4 * NCH; j++)
+                accv[j] += __popc(satf4 & (0x01010101u << j)) - __popc(sate4 & (0x01010101u << j));
+        }
+    }
+    flush();
+    close_sink<SMALLW>(g, sk);
+}
+
 template <typename VT, bool SMALLW>
 __global__ __launch_bounds__(NSK_BLOCK) void k_learn_fast(DevGraph<VT> g, int pbegin, int pend,
                                                           int wb_base, const uint32_t *list, int ntiles,

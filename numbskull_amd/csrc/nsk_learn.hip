@@ -242,6 +242,47 @@ int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay
                 SegTable tab;
                 memset(&tab, 0, sizeof(tab));
                 tab.n = sl.n;
+                // (mostly) wide quads: the wide learning kernel, its tiles numbered in whole quads like the inference
+                // launches (lead = dead tiles in front of a segment that does not start on a quad boundary)
+                if constexpr (sizeof(VT) == 1) if (use_tab && !nsk::diag_env("NSK_NO_WIDE_LEARN")) {
+                    int vt = 0, nwide = 0;
+                    for (int i = 0; i < NSK_SEG_MAX; i++) {
+                        SegEntry &en = tab.e[i];
+                        en.tile_start = vt;
+                        if (i >= sl.n) continue;
+                        const int nt_i = sl.tile_start[i + 1] - sl.tile_start[i];
+                        const int64_t pos0 = sl.pos0[i];
+                        const int lead = (int)((pos0 / 64) & 3);
+                        en.ntiles_lead = (uint32_t)nt_i | ((uint32_t)lead << 30);
+                        en.pos0 = sl.pos0[i]; en.adj_off = sl.adj_off[i]; en.prog = sl.prog[i]; en.zoff = sl.zoff[i];
+                        en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
+                        en.aff_off = sl.aff[i];
+                        en.push_off = NSK_NO_STREAM;
+                        en.wide_off = sl.wide[i] >= 0 ? (uint32_t)sl.wide[i] : NSK_NO_STREAM;     // (the descriptors start at the quad of pos0)
+                        if (sl.wide[i] >= 0) {
+                            const int stride = NSK_WIDE_STRIDE(sl.nch);
+                            for (int64_t P = (pos0 + 255) & ~(int64_t)255; P + 256 <= pos0 + 64 * (int64_t)nt_i; P += 256)
+                                if (g->c.seg_wide[(size_t)sl.wide[i] + (size_t)((P >> 8) - (pos0 >> 8)) * stride] != 0xFFFFFFFFu) nwide++;
+                        }
+                        vt += (nt_i + lead + 3) & ~3;
+                    }
+                    tab.ntiles = vt;
+                    const char *min_env = nsk::diag_env("NSK_WIDE_LEARN_MIN");                 // (diagnostic; the small-grid tests use 0)
+                    const int min_quads = min_env ? atoi(min_env) : NSK_WIDE_LEARN_MIN_QUADS;
+                    if (8 * nwide >= vt && vt > 0 && vt / 4 >= min_quads) {
+                        const DevGraph<signed char> &dw = d;
+                        const bool fuse = SMALLW && pend.valid && pend.tabs_here;
+                        const ApplyArgs &prev = fuse ? pend.aa : no_update;
+                        const int grid = nsk_learn_tabw_grid(vt) + (SMALLW ? NSK_SERVICE_BLOCKS : 0);
+                        if (sl.nch == 1) k_learn_seg_tabw<SMALLW, 1><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(dw, tab, lp, prev);
+                        else k_learn_seg_tabw<SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(dw, tab, lp, prev);
+                        if (fuse) pend.valid = false;
+                        g->launches++;
+                        continue;
+                    }
+                    memset(&tab, 0, sizeof(tab));
+                    tab.n = sl.n;
+                }
                 // table launches number their tiles virtually: every segment is padded to whole trips
                 int vt = 0;
                 for (int i = 0; i < NSK_SEG_MAX; i++) {

@@ -21,6 +21,7 @@ def _wide_quads_on_small_graphs(monkeypatch):
     bound with the diagnostic switch.  The 10M grid of tests/test_config3_gpu.py takes the path at its default."""
     monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv("NSK_WIDE_MIN", "0")
+    monkeypatch.setenv("NSK_WIDE_LEARN_MIN", "0")
 
 
 def _run_and_compare(fg, og, seed, burn, sweeps, sample_evidence=True, chunks=(None,)):
