@@ -112,8 +112,6 @@ static bool coarsen(Level &f, Level &c, int64_t maxvw, Rng &rng) {
     const int64_t n = f.n;
     std::vector<int32_t> perm, match((size_t)n, -1);
     random_permutation(perm, n, rng);
-    f.cmap.assign((size_t)n, -1);
-    int64_t nc = 0;
     for (int64_t i = 0; i < n; i++) {
         const int32_t v = perm[(size_t)i];
         if (match[(size_t)v] >= 0) continue;
@@ -125,10 +123,39 @@ static bool coarsen(Level &f, Level &c, int64_t maxvw, Rng &rng) {
                 best = u; bw = f.ew[(size_t)j]; bvw = f.vw[(size_t)u];
             }
         }
-        match[(size_t)v] = best >= 0 ? best : v;
-        if (best >= 0) match[(size_t)best] = v;
+        if (best >= 0) { match[(size_t)v] = best; match[(size_t)best] = v; }
+    }
+    // what the matching left over: a vertex whose neighbours are all taken pairs up with another neighbour of one of
+    // them (two hops: leaves of a star), a vertex without neighbours with the next such vertex -- or the graph would
+    // stop shrinking at its isolated variables (a config-#5 variable that heads only unary factors)
+    int32_t lone = -1;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t v = perm[(size_t)i];
+        if (match[(size_t)v] >= 0) continue;
+        const int64_t d = f.xadj[(size_t)v + 1] - f.xadj[(size_t)v];
+        if (d == 0) {
+            if (lone >= 0 && (int64_t)f.vw[(size_t)lone] + f.vw[(size_t)v] <= maxvw) { match[(size_t)v] = lone; match[(size_t)lone] = v; lone = -1; }
+            else lone = v;
+            continue;
+        }
+        for (int64_t j = f.xadj[(size_t)v]; j < std::min(f.xadj[(size_t)v] + 4, f.xadj[(size_t)v + 1]) && match[(size_t)v] < 0; j++) {
+            const int32_t u = f.adj[(size_t)j];
+            for (int64_t j2 = f.xadj[(size_t)u]; j2 < std::min(f.xadj[(size_t)u] + 32, f.xadj[(size_t)u + 1]); j2++) {
+                const int32_t w = f.adj[(size_t)j2];
+                if (w == v || match[(size_t)w] >= 0 || (int64_t)f.vw[(size_t)v] + f.vw[(size_t)w] > maxvw) continue;
+                match[(size_t)v] = w; match[(size_t)w] = v;
+                break;
+            }
+        }
+    }
+    f.cmap.assign((size_t)n, -1);
+    int64_t nc = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t v = perm[(size_t)i];
+        if (f.cmap[(size_t)v] >= 0) continue;
+        if (match[(size_t)v] < 0) match[(size_t)v] = v;
         f.cmap[(size_t)v] = (int32_t)nc;
-        if (best >= 0) f.cmap[(size_t)best] = (int32_t)nc;
+        f.cmap[(size_t)match[(size_t)v]] = (int32_t)nc;
         nc++;
     }
     if (nc > n - n / 10) return false;
@@ -222,23 +249,25 @@ static void linear_order(const Level &g, std::vector<int32_t> &ord, int rounds) 
     std::vector<double> x((size_t)n), xn((size_t)n);
     auto place = [&]() { double cum = 0; for (int64_t i = 0; i < n; i++) { const int32_t v = ord[(size_t)i]; x[(size_t)v] = cum + 0.5 * g.vw[(size_t)v]; cum += g.vw[(size_t)v]; } };
     place();
-    std::vector<std::pair<double, int32_t>> nb;
     for (int r = 0; r < rounds; r++) {
-        for (int64_t v = 0; v < n; v++) {
-            nb.clear();
-            int64_t tot = 0;
-            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; j++) { nb.emplace_back(x[(size_t)g.adj[(size_t)j]], g.ew[(size_t)j]); tot += g.ew[(size_t)j]; }
-            double m = x[(size_t)v];
-            if (!nb.empty()) {
-                std::sort(nb.begin(), nb.end());
-                int64_t acc = 0;
-                for (size_t i = 0; i < nb.size(); i++) {
-                    acc += nb[i].second;
-                    if (2 * acc >= tot) { m = (2 * acc == tot && i + 1 < nb.size()) ? 0.5 * (nb[i].first + nb[i + 1].first) : nb[i].first; break; }
+        nsk::parallel_for(n, [&](int64_t b0, int64_t b1, int) {
+            std::vector<std::pair<double, int32_t>> nb;
+            for (int64_t v = b0; v < b1; v++) {
+                nb.clear();
+                int64_t tot = 0;
+                for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; j++) { nb.emplace_back(x[(size_t)g.adj[(size_t)j]], g.ew[(size_t)j]); tot += g.ew[(size_t)j]; }
+                double m = x[(size_t)v];
+                if (!nb.empty()) {
+                    std::sort(nb.begin(), nb.end());
+                    int64_t acc = 0;
+                    for (size_t i = 0; i < nb.size(); i++) {
+                        acc += nb[i].second;
+                        if (2 * acc >= tot) { m = (2 * acc == tot && i + 1 < nb.size()) ? 0.5 * (nb[i].first + nb[i + 1].first) : nb[i].first; break; }
+                    }
                 }
+                xn[(size_t)v] = 0.5 * x[(size_t)v] + 0.5 * m;
             }
-            xn[(size_t)v] = 0.5 * x[(size_t)v] + 0.5 * m;
-        }
+        }, 1024);
         for (int32_t k = 0; k < ncomp; k++)
             std::stable_sort(ord.begin() + (std::ptrdiff_t)cstart[(size_t)k], ord.begin() + (std::ptrdiff_t)cstart[(size_t)k + 1],
                              [&](int32_t a, int32_t b) { return xn[(size_t)a] < xn[(size_t)b]; });
@@ -303,18 +332,22 @@ static void refine_cut(const Level &g, std::vector<uint8_t> &where, Parts &P, do
     for (int64_t v = 0; v < n; v++) heaviest = std::max(heaviest, g.vw[(size_t)v]);
     for (int p = 0; p < k; p++) maxw[(size_t)p] = (int64_t)(P.target[(size_t)p] * (1.0 + eps)) + (heaviest > 1 ? heaviest / 2 : 0);
     std::vector<int64_t> conn((size_t)k, 0);
-    std::vector<int32_t> perm;
+    std::vector<int32_t> cand;
     for (int pass = 0; pass < passes; pass++) {
-        random_permutation(perm, n, rng);
-        int64_t moves = 0;
-        for (int64_t i = 0; i < n; i++) {
-            const int32_t v = perm[(size_t)i];
+        // the pass visits, in random order, the vertices that can move: boundary vertices and members of overweight parts
+        cand.clear();
+        for (int64_t v = 0; v < n; v++) {
             const int own = where[(size_t)v];
-            bool boundary = false;
-            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; j++)
-                if (where[(size_t)g.adj[(size_t)j]] != own) { boundary = true; break; }
+            bool take = P.pw[(size_t)own] > maxw[(size_t)own];
+            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1] && !take; j++) take = where[(size_t)g.adj[(size_t)j]] != own;
+            if (take) cand.push_back((int32_t)v);
+        }
+        for (int64_t i = (int64_t)cand.size() - 1; i > 0; i--) std::swap(cand[(size_t)i], cand[(size_t)rng.below((uint64_t)i + 1)]);
+        int64_t moves = 0;
+        for (size_t i = 0; i < cand.size(); i++) {
+            const int32_t v = cand[i];
+            const int own = where[(size_t)v];
             const bool over = P.pw[(size_t)own] > maxw[(size_t)own];
-            if (!boundary && !over) continue;
             std::fill(conn.begin(), conn.end(), 0);
             for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; j++) conn[(size_t)where[(size_t)g.adj[(size_t)j]]] += g.ew[(size_t)j];
             const int64_t vw = g.vw[(size_t)v];
@@ -361,13 +394,21 @@ static void move_between(const Level &g, std::vector<uint8_t> &where, Parts &P, 
         for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; j++) if (where[(size_t)g.adj[(size_t)j]] == to) { adj_to = true; break; }
         if (adj_to) heap.emplace(gain_of((int32_t)v), (int32_t)v); else rest.push_back((int32_t)v);
     }
+    // (members without any link cost nothing to move: they go as soon as the best linked vertex would cost something)
+    std::stable_sort(rest.begin(), rest.end(), [&](int32_t a, int32_t c) {
+        return g.xadj[(size_t)a + 1] - g.xadj[(size_t)a] < g.xadj[(size_t)c + 1] - g.xadj[(size_t)c]; });
     size_t rest_at = 0;
     while (need > 0) {
+        while (rest_at < rest.size() && where[(size_t)rest[rest_at]] != from) rest_at++;
+        const bool free_one = rest_at < rest.size() && g.xadj[(size_t)rest[rest_at] + 1] == g.xadj[(size_t)rest[rest_at]];
+        if (free_one && (heap.empty() || heap.top().first <= 0)) {
+            where[(size_t)rest[rest_at++]] = (uint8_t)to;
+            P.pw[(size_t)from]--; P.pw[(size_t)to]++;
+            need--;
+            continue;
+        }
         if (heap.empty()) {
-            // nothing of `from` touches `to` (any more): take the members with the fewest links first
-            if (rest_at == 0) std::stable_sort(rest.begin(), rest.end(), [&](int32_t a, int32_t c) {
-                return g.xadj[(size_t)a + 1] - g.xadj[(size_t)a] < g.xadj[(size_t)c + 1] - g.xadj[(size_t)c]; });
-            while (rest_at < rest.size() && where[(size_t)rest[rest_at]] != from) rest_at++;
+            // nothing of `from` touches `to` (any more): the members with the fewest links first
             if (rest_at >= rest.size()) break;                   // (cannot happen: `from` holds more than it gives)
             heap.emplace(gain_of(rest[rest_at]), rest[rest_at]);
             rest_at++;
@@ -388,11 +429,17 @@ static void move_between(const Level &g, std::vector<uint8_t> &where, Parts &P, 
     }
 }
 
+static bool balance_round(const Level &g, std::vector<uint8_t> &where, Parts &P);
 static void balance_tree(const Level &g, std::vector<uint8_t> &where, Parts &P) {
+    // (a part that has to pass on more than it holds when its turn comes is served in the next round)
+    for (int round = 0; round < P.k + 2; round++)
+        if (balance_round(g, where, P)) return;
+}
+static bool balance_round(const Level &g, std::vector<uint8_t> &where, Parts &P) {
     const int k = P.k;
     bool exact = true;
     for (int p = 0; p < k; p++) exact &= P.pw[(size_t)p] == P.target[(size_t)p];
-    if (exact) return;
+    if (exact) return true;
     std::vector<int64_t> conn((size_t)k * k, 0);
     for (int64_t v = 0; v < g.n; v++)
         for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; j++)
@@ -421,6 +468,7 @@ static void balance_tree(const Level &g, std::vector<uint8_t> &where, Parts &P) 
         if (f > 0) move_between(g, where, P, p, q, f);
         else if (f < 0) move_between(g, where, P, q, p, -f);
     }
+    return false;
 }
 
 // (5b) refinement of the communication volume itself, sizes kept.  Factor lists give the exact objective:
@@ -495,37 +543,59 @@ struct VolumeRefiner {
     }
 };
 
-static void refine_volume(VolumeRefiner &R, Parts &P, int passes, int64_t slack, Rng &rng) {
+static void refine_volume(const Level &g, VolumeRefiner &R, Parts &P, int passes, int64_t slack, Rng &rng) {
     const int64_t n = R.nvar;
     const int k = P.k;
     std::vector<int32_t> perm;
     std::vector<int64_t> aff, aff2;
+    std::vector<int8_t> hint;
     // a move into a part that is full is remembered per (from, to) pair and carried out when a move the other way
     // turns up with a combined improvement: sizes stay exact
     struct Pending { int64_t v, d; };
     std::vector<std::vector<Pending>> pend((size_t)k * k);
     for (int pass = 0; pass < passes; pass++) {
-        random_permutation(perm, n, rng);
-        for (auto &pl : pend) pl.clear();
-        int64_t moves = 0;
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t v = perm[(size_t)i];
+        // candidates: the boundary vertices of the variable graph (a variable with every co-member at home cannot gain)
+        perm.clear();
+        for (int64_t v = 0; v < n; v++) {
             const int own = R.where[(size_t)v];
-            uint64_t cand = R.touched_parts(v);
-            if (!cand) continue;
-            R.affected(v, aff);
-            int best = -1;
-            int64_t bd = 0;
-            int best_full = -1;
-            int64_t bd_full = 0;
-            while (cand) {
-                const int q = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                const int64_t d = R.delta(v, q, aff);
-                const bool room = P.pw[(size_t)q] + 1 <= P.target[(size_t)q] + slack;
-                if (room) { if (best < 0 || d < bd) { best = q; bd = d; } }
-                else if (best_full < 0 || d < bd_full) { best_full = q; bd_full = d; }
+            bool take = false;
+            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1] && !take; j++) take = R.where[(size_t)g.adj[(size_t)j]] != own;
+            if (take) perm.push_back((int32_t)v);
+        }
+        for (int64_t i = (int64_t)perm.size() - 1; i > 0; i--) std::swap(perm[(size_t)i], perm[(size_t)rng.below((uint64_t)i + 1)]);
+        for (auto &pl : pend) pl.clear();
+        // every candidate's best destination against the state at the start of the pass (read-only: host threads) ...
+        hint.assign(perm.size(), -1);
+        nsk::parallel_for((int64_t)perm.size(), [&](int64_t b0, int64_t b1, int) {
+            std::vector<int64_t> af;
+            for (int64_t i = b0; i < b1; i++) {
+                const int64_t v = perm[(size_t)i];
+                uint64_t cand = R.touched_parts(v);
+                if (!cand) continue;
+                R.affected(v, af);
+                int64_t bd = 0;
+                while (cand) {
+                    const int q = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    const int64_t d = R.delta(v, q, af);
+                    if (d < bd) { bd = d; hint[(size_t)i] = (int8_t)q; }
+                }
             }
+        }, 2048);
+        // ... then the promising ones one after the other, re-evaluated against the state as it is now
+        int64_t moves = 0;
+        for (size_t i = 0; i < perm.size(); i++) {
+            if (hint[i] < 0) continue;
+            const int64_t v = perm[i];
+            const int own = R.where[(size_t)v];
+            const int q = hint[i];
+            if (q == own) continue;
+            R.affected(v, aff);
+            const int64_t d = R.delta(v, q, aff);
+            if (d >= 0) continue;
+            const bool room = P.pw[(size_t)q] + 1 <= P.target[(size_t)q] + slack;
+            const int best = room ? q : -1, best_full = room ? -1 : q;
+            const int64_t bd = d, bd_full = d;
             // a plain move: must improve, and keep both parts within `slack` of their sizes
             if (best >= 0 && bd < 0 && P.pw[(size_t)own] - 1 >= P.target[(size_t)own] - slack) {
                 R.where[(size_t)v] = (uint8_t)best;
@@ -595,79 +665,117 @@ extern "C" int nsk_graph_partition(int64_t nvar, int64_t nfactor, const nsk_fact
         };
         std::vector<Level> lv(1);
         build_fine(nvar, nfactor, factor, fmap, lv[0]);
-        const int64_t coarsen_to = std::max<int64_t>(2000, 60 * (int64_t)k);
-        while (lv.back().n > coarsen_to && lv.size() < 48) {
+        // Coarsening goes all the way down (a few thousand vertices); the partition starts at TWO depths: the deepest
+        // level -- meshes: the cut of a very coarse graph is straight -- and a middle level of about nvar / 12 vertices --
+        // banded graphs laced with long edges (config #5): the coarse levels' greedy refinement cannot repair an
+        // arrangement, so the linear arrangement has to see the local structure itself (shuffled 1M-variable config-#5 graph,
+        // 8 parts, volume against the generator's own ids: 1.09 / 1.09 / 1.03 / 0.98 when it starts at 2 000 / 8 000 / 30 000 /
+        // 100 000 vertices).  The candidates are compared by edge cut at the middle level.
+        const char *ct_env = nsk::diag_env("NSK_PART_COARSEN_TO");
+        const int64_t deep_to = std::max<int64_t>(2000, 60 * (int64_t)k);
+        const int64_t mid_to = ct_env ? atoll(ct_env) : std::min<int64_t>(200000, std::max<int64_t>(deep_to, nvar / 12));
+        size_t mid = 0;
+        while (lv.back().n > deep_to && lv.size() < 48) {
+            if (lv.back().n > mid_to) mid = lv.size();
             Level c;
-            if (!coarsen(lv.back(), c, std::max<int64_t>(1, (3 * lv[0].totw) / (2 * coarsen_to)), rng)) break;
+            if (!coarsen(lv.back(), c, std::max<int64_t>(1, (3 * lv[0].totw) / (2 * deep_to)), rng)) break;
             lv.push_back(std::move(c));
+            if (verbose) fprintf(stderr, "[nsk] partition: level %d: %lld vertices, %lld edges\n", (int)lv.size() - 1, (long long)lv.back().n, (long long)lv.back().adj.size() / 2);
         }
+        mid = std::min(mid, lv.size() - 1);
         st[0] = (int64_t)lv.size();
         st[1] = lv.back().n;
         tick("variable graph + coarsening");
-        // (3) initial partition of the coarsest graph: the better (edge cut after refinement) of a chain -- one linear
-        // arrangement cut into k ranges: banded graphs -- and a recursive bisection -- every half re-arranged along its
-        // own long direction: meshes
-        {
-            const Level &g = lv.back();
-            std::vector<int64_t> bound((size_t)k + 1, 0);
-            for (int p = 0; p < k; p++) bound[(size_t)p + 1] = bound[(size_t)p] + P.target[(size_t)p];
-            std::vector<uint8_t> best;
-            int64_t best_cut = -1;
-            for (int variant = 0; variant < 2; variant++) {
-                std::vector<uint8_t> w((size_t)g.n, 0);
-                if (variant == 0) {
-                    std::vector<int32_t> ord;
-                    linear_order(g, ord, 20);
-                    int64_t cum = 0;
-                    int p = 0;
-                    for (int64_t i = 0; i < g.n; i++) {
-                        const int32_t v = ord[(size_t)i];
-                        const int64_t mid = cum + g.vw[(size_t)v] / 2;
-                        while (p + 1 < k && mid >= bound[(size_t)p + 1]) p++;
-                        w[(size_t)v] = (uint8_t)p;
-                        cum += g.vw[(size_t)v];
-                    }
-                } else {
-                    std::vector<int32_t> all((size_t)g.n);
-                    for (int64_t v = 0; v < g.n; v++) all[(size_t)v] = (int32_t)v;
-                    bisect(g, all, 0, k, bound, w);
+        std::vector<int64_t> bound((size_t)k + 1, 0);
+        for (int p = 0; p < k; p++) bound[(size_t)p + 1] = bound[(size_t)p] + P.target[(size_t)p];
+        // (3) a partition of level `at`: a chain -- one linear arrangement cut into k ranges -- or a recursive bisection --
+        // every half re-arranged along its own long direction
+        auto initial = [&](size_t at, int variant, std::vector<uint8_t> &w) {
+            const Level &g = lv[at];
+            w.assign((size_t)g.n, 0);
+            if (variant == 0) {
+                std::vector<int32_t> ord;
+                linear_order(g, ord, 20);
+                int64_t cum = 0;
+                int p = 0;
+                for (int64_t i = 0; i < g.n; i++) {
+                    const int32_t v = ord[(size_t)i];
+                    const int64_t midw = cum + g.vw[(size_t)v] / 2;
+                    while (p + 1 < k && midw >= bound[(size_t)p + 1]) p++;
+                    w[(size_t)v] = (uint8_t)p;
+                    cum += g.vw[(size_t)v];
                 }
-                Parts Q = P;
+            } else {
+                std::vector<int32_t> all((size_t)g.n);
+                for (int64_t v = 0; v < g.n; v++) all[(size_t)v] = (int32_t)v;
+                bisect(g, all, 0, k, bound, w);
+            }
+        };
+        // (4) refine w at level `from`, then project and refine down to level `to`
+        auto uncoarsen = [&](std::vector<uint8_t> &w, size_t from, size_t to, Parts &Q, Rng &r) {
+            for (size_t li = from + 1; li-- > to;) {
+                const Level &g = lv[li];
+                if (li < from) {
+                    std::vector<uint8_t> w2((size_t)g.n);
+                    for (int64_t v = 0; v < g.n; v++) w2[(size_t)v] = w[(size_t)g.cmap[(size_t)v]];
+                    w.swap(w2);
+                }
                 Q.pw.assign((size_t)k, 0);
                 for (int64_t v = 0; v < g.n; v++) Q.pw[(size_t)w[(size_t)v]] += g.vw[(size_t)v];
-                Rng r2{rng.s + 77u * (unsigned)variant};
-                refine_cut(g, w, Q, 0.03, 10, r2);
-                const int64_t cut = edge_cut(g, w);
-                if (verbose) fprintf(stderr, "[nsk] partition: coarsest graph %lld vertices, %s: edge cut %lld\n", (long long)g.n, variant ? "recursive bisection" : "chain", (long long)cut);
-                if (best_cut < 0 || cut < best_cut) { best_cut = cut; best.swap(w); }
+                refine_cut(g, w, Q, li == 0 ? 0.005 : 0.03, li == 0 ? 6 : 10, r);
             }
-            where.swap(best);
-        }
-        tick("initial partition");
-        // (4) uncoarsen + refine
-        for (int64_t li = (int64_t)lv.size() - 1; li >= 0; li--) {
-            const Level &g = lv[(size_t)li];
-            if (li + 1 < (int64_t)lv.size()) {
-                std::vector<uint8_t> w((size_t)g.n);
-                for (int64_t v = 0; v < g.n; v++) w[(size_t)v] = where[(size_t)g.cmap[(size_t)v]];
-                where.swap(w);
+        };
+        // two finalists -- the better start of either depth, by edge cut at the middle level -- go all the way up; the edge
+        // cut at the finest level decides (the cut at the middle level does not predict it across depths)
+        {
+            std::vector<uint8_t> fin[2];
+            int64_t fin_cut[2] = {-1, -1};
+            for (int c = 0; c < 4; c++) {
+                const size_t at = c < 2 ? lv.size() - 1 : mid;
+                if (c >= 2 && mid == lv.size() - 1) break;
+                std::vector<uint8_t> w;
+                initial(at, c & 1, w);
+                Parts Q = P;
+                Rng r2{rng.s + 77u * (unsigned)c};
+                uncoarsen(w, at, mid, Q, r2);
+                const int64_t cut = edge_cut(lv[mid], w);
+                if (verbose) fprintf(stderr, "[nsk] partition: %s at %lld vertices: edge cut %lld at %lld vertices\n", (c & 1) ? "recursive bisection" : "chain",
+                                     (long long)lv[at].n, (long long)cut, (long long)lv[mid].n);
+                if (fin_cut[c >> 1] < 0 || cut < fin_cut[c >> 1]) { fin_cut[c >> 1] = cut; fin[c >> 1].swap(w); }
             }
-            P.pw.assign((size_t)k, 0);
-            for (int64_t v = 0; v < g.n; v++) P.pw[(size_t)where[(size_t)v]] += g.vw[(size_t)v];
-            refine_cut(g, where, P, li == 0 ? 0.005 : 0.03, li == 0 ? 6 : 10, rng);
-            if (li > 0) { Level drop; std::swap(lv[(size_t)li], drop); }      // (free the coarse level)
+            tick("initial partitions");
+            int64_t best_cut = -1;
+            for (int c = 0; c < 2; c++) {
+                if (fin_cut[c] < 0) continue;
+                std::vector<uint8_t> &w = fin[c];
+                Parts Q = P;
+                Rng r2{rng.s + 1234u * (unsigned)(c + 1)};
+                if (mid > 0) {
+                    std::vector<uint8_t> w2((size_t)lv[mid - 1].n);
+                    for (int64_t v = 0; v < lv[mid - 1].n; v++) w2[(size_t)v] = w[(size_t)lv[mid - 1].cmap[(size_t)v]];
+                    w.swap(w2);
+                    uncoarsen(w, mid - 1, 0, Q, r2);
+                } else {
+                    Q.pw.assign((size_t)k, 0);
+                    for (int64_t v = 0; v < nvar; v++) Q.pw[(size_t)w[(size_t)v]]++;
+                }
+                const int64_t cut = edge_cut(lv[0], w);
+                if (verbose) fprintf(stderr, "[nsk] partition: finalist from the %s level: edge cut %lld\n", c ? "middle" : "deepest", (long long)cut);
+                if (best_cut < 0 || cut < best_cut) { best_cut = cut; where.swap(w); P.pw = Q.pw; }
+            }
         }
+        for (size_t li = lv.size() - 1; li > 0; li--) { Level drop; std::swap(lv[li], drop); }
         st[2] = edge_cut(lv[0], where);
         tick("uncoarsening");
         balance_tree(lv[0], where, P);
         tick("exact sizes");
         VolumeRefiner R(nvar, nfactor, factor, fmap, where, k);
         st[3] = R.total();
-        refine_volume(R, P, 3, std::max<int64_t>(1, nvar / k / 500), rng);
+        refine_volume(lv[0], R, P, 4, std::max<int64_t>(1, nvar / k / 500), rng);
         tick("volume refinement (slack)");
         // (back to exact sizes, then size-preserving exchanges only)
         balance_tree(lv[0], where, P);
-        refine_volume(R, P, 3, 0, rng);
+        refine_volume(lv[0], R, P, 4, 0, rng);
         st[4] = R.total();
         tick("volume refinement (exact sizes)");
     }

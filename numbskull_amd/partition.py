@@ -11,7 +11,13 @@ exactly the formula's sizes (a METIS part is balanced within a tolerance).  ``re
 new ids; every downstream piece -- ``FactorGraph(own_range=...)``, ``graphgen.extract_shard``, the peer-to-peer
 exchange -- works on the relabelled graph unchanged, and ``order`` maps results back.
 
-Native: ``nsk_graph_order`` / ``nsk_comm_volume`` (csrc/nsk_host.cpp), O(edges), no GPU.
+``method="multilevel"`` is the partitioner proper (``nsk_graph_partition``, csrc/nsk_partition.cpp): heavy-edge
+matching, a partition of the coarse graph, k-way boundary refinement on the way up and a last refinement of the
+communication volume itself with the parts held at exactly the shard formula's sizes -- what the reference asks
+METIS for (``objtype = vol``).
+
+Native: ``nsk_graph_order`` / ``nsk_comm_volume`` (csrc/nsk_host.cpp), ``nsk_graph_partition``
+(csrc/nsk_partition.cpp); O(edges) per level, host threads, no GPU.
 """
 
 import ctypes as C
@@ -41,6 +47,18 @@ def graph_order(nvar, factor, fmap, method="bfs"):
     return order, cc, int(ncc.value)
 
 
+def multilevel_order(nvar, factor, fmap, parts, seed=1):
+    """``(order, stats)`` of the multilevel partitioner for ``parts`` shards: ``order[new id] = old id`` and range g of the
+    new ids (the shard formula's) is part g.  ``stats``: levels, coarsest vertices, edge cut after uncoarsening,
+    communication volume before / after the last refinement.  Deterministic in (graph, parts, seed)."""
+    f, m = _records(factor, fmap)
+    order = np.empty(int(nvar), np.int64)
+    stats = np.zeros(5, np.int64)
+    _lib.check(_lib.lib().nsk_graph_partition(int(nvar), len(f), _lib.ptr(f), len(m), _lib.ptr(m), int(parts), int(seed),
+                                              _lib.ptr(order), C.c_void_p(0), _lib.ptr(stats)))
+    return order, dict(zip(("levels", "coarsest", "edge_cut", "volume_before", "volume"), stats.tolist()))
+
+
 def find_connected_components(nvar, factor, fmap):
     """``cc_id`` per variable -- the ``variable_to_cc`` table of messages.py:542-590."""
     return graph_order(nvar, factor, fmap, "components")[1]
@@ -50,16 +68,19 @@ def find_parts(nvar, factor, fmap, parts, method="auto"):
     """``(part id per variable, order)`` -- the ``variable_to_cc`` table of find_metis_parts (messages.py:593-670)
     for ``parts`` shards: variable ``order[i]`` belongs to the shard whose range holds ``i``.  ``method`` "auto":
     the order with the smallest communication volume among the caller's own ids (components together), the
-    breadth-first walk and the median-refined maximum-adjacency walk -- never worse than what came in."""
+    breadth-first walk and the multilevel partitioner -- never worse than what came in.  "multilevel" / "bfs" /
+    "mas" / "median" / "components": that order alone."""
     n = int(nvar)
     if method == "auto":
         best = None
-        for m in ("components", "bfs", "median"):
-            o = graph_order(n, factor, fmap, m)[0]
+        for m in ("components", "bfs", "multilevel"):
+            o = multilevel_order(n, factor, fmap, parts)[0] if m == "multilevel" else graph_order(n, factor, fmap, m)[0]
             vol = comm_volume(n, factor, fmap, parts, o)
             if best is None or vol < best[0]:
                 best = (vol, o)
         order = best[1]
+    elif method == "multilevel":
+        order = multilevel_order(n, factor, fmap, parts)[0]
     else:
         order, _, _ = graph_order(nvar, factor, fmap, method)
     bounds = (np.arange(parts + 1, dtype=np.int64) * n) // parts

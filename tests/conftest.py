@@ -16,6 +16,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The two 50M-variable cases (config #5 at its stated size: ~100 GB of host memory, minutes of generation)
+    run last: with -x, a box that cannot hold them must not hide the rows behind them."""
+    heavy = [it for it in items if "test_config5_gpu.py" in it.nodeid or "lr50m" in it.nodeid]
+    if heavy:
+        items[:] = [it for it in items if it not in heavy] + heavy
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

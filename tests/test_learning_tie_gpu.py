@@ -143,24 +143,24 @@ def _tie(g, unit, epochs, **kw):
 
 
 def test_marginals_under_both_scans_pairs():
-    g = graphgen.ising_pairs(20000, 1.0, 1.0, 0.5, seed=7)
+    g = graphgen.ising_pairs(8000, 1.0, 1.0, 0.5, seed=7)
     unit = list(graphgen.ising_pairs(1, 1.0, 1.0, 0.5, seed=7))
     unit[1] = unit[1].copy(); unit[1]["isEvidence"] = 0                    # the pair as a query: both variables free
-    assert _tie(g, tuple(unit), 400) < 1e-3
+    assert _tie(g, tuple(unit), 300) < 1e-3
 
 
 def test_marginals_under_both_scans_lf():
-    g = graphgen.lf_graph(0.0, [1.5, 1.0, 0.5], 20000, seed=3)
+    g = graphgen.lf_graph(0.0, [1.5, 1.0, 0.5], 8000, seed=3)
     unit = list(graphgen.lf_graph(0.0, [1.5, 1.0, 0.5], 1, seed=3))
     unit[1] = unit[1].copy(); unit[1]["isEvidence"] = 0
-    assert _tie(g, tuple(unit), 400) < 1e-3
+    assert _tie(g, tuple(unit), 300) < 1e-3
 
 
 def test_marginals_under_both_scans_small_grid():
-    """3 x 4 grid, two weights; the evidence: 4096 independent configurations of that grid sampled at planted weights
-    (0.3, 0.15) -- one 12-variable configuration alone has no maximum-likelihood weights worth comparing -- as 4096
+    """3 x 4 grid, two weights; the evidence: 2048 independent configurations of that grid sampled at planted weights
+    (0.3, 0.15) -- one 12-variable configuration alone has no maximum-likelihood weights worth comparing -- as 2048
     disjoint copies that share the two weights; the marginals: those of the 12-variable grid itself."""
-    rows, cols, reps = 3, 4, 4096
+    rows, cols, reps = 3, 4, 2048
     g1 = graphgen.ising_grid(rows, cols, weight=0.0, fixed=True, two_weights=True)
     g1[0]["initialValue"] = (0.3, 0.15)
     ns, fg = session(g1, seed=11)
@@ -171,4 +171,4 @@ def test_marginals_under_both_scans_small_grid():
     one = graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True, evidence=cfgs[0])
     g = graphgen.replicate(one, cfgs)
     unit = graphgen.ising_grid(rows, cols, weight=0.0, fixed=False, two_weights=True)
-    assert _tie(g, unit, 400) < 1e-3
+    assert _tie(g, unit, 300) < 1e-3
