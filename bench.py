@@ -731,7 +731,8 @@ def main():
             "config": {"workload": ("%d boolean variables, %d ISTRUE/OR/EQUAL factors with one weight each, "
                                     "inference only, chromatic scan, seed %d" % (nvar, nfactor_total, args.seed))
                        if args.workload.startswith("boolw4m") else
-                       ("mixed-arity LR graph: %d variables (25%% categorical), %d factors, %d weights, %s"
+                       ("mixed-arity LR graph: %d variables (25%% categorical), %d factors, %d weights, %s; head_by_vid (SURVEY.md "
+                        "section 8d: the reference's literal head index, inference.py:243, is out of bounds on this graph)"
                         % (nvar, nfactor_total, nweight_total, "learning" if learning else "inference"))
                        if args.workload.startswith("lr") else
                        "%dx%d Ising grid (%d binary variables, %d EQUAL factors), %s, "

@@ -3,7 +3,7 @@
 IMPLY_MLN_CAT / AND_CAT factors, 10^6 weights) on ONE GPU, against the CPU oracle's device mode on
 the FULL graph: one burn-in and one tallied inference sweep (values and tallies bit-exact,
 inference.py:10-33, 232-295) and one learning epoch (weights and both chains bit-exact,
-learning.py:46-125), plus determinism and tally bounds.
+learning.py:46-125), plus tally bounds.
 
 Needs ~100 GB of host memory for the reference-layout arrays (int64 records, numbskulltypes.py): a box
 that cannot hold them FAILS the test (config #5 must not silently leave the exercised set); tests/conftest.py
@@ -52,8 +52,6 @@ def test_config5_inference_and_learning_bit_exact_vs_oracle(lr50m):
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
     assert np.isfinite(fg.weight_value[0]).all()
 
-    # determinism: a second handle with the same seed repeats the trajectory
-    ns2, fg2 = session(lr50m, seed=20240603, head_by_vid=True)
-    fg2.inference(1, 1, True)
-    fg2.learn(0, 1, 1e-3, 0.95, 2, 0.01, 1)
-    assert np.array_equal(fg2.var_value, fg.var_value) and np.array_equal(fg2.weight_value, fg.weight_value)
+    # (determinism under the seed: both runs above equal the oracle's, which is a function of graph and seed alone; a
+    #  second 50M handle used to repeat the trajectory here for half a minute of compile time -- the 10M grid of
+    #  tests/test_config3_gpu.py and the 1M grid of tests/test_hip_parity.py keep that check)
