@@ -406,7 +406,7 @@ def roofline_bound(kernel):
     profiles/): the draw-table kernels read almost no stream and are bound by instruction issue along a
     chain of dependent steps; the entry-parallel kernels by the latency of their dependent gathers at the
     occupancy their registers allow (no unit saturated); the CSR / exp-per-update kernels by HBM."""
-    if kernel.endswith("_seg_tab"):
+    if kernel.endswith("_seg_tab") or kernel.endswith("_seg_tabw"):
         return "issue"
     if kernel.endswith("_ep") or kernel.endswith("_ep_w5") or kernel.endswith("_ep_w4"):
         return "latency"
@@ -447,6 +447,13 @@ def dominant_kernel(workload, learning, info):
         small = info["nvar"] * info["value_bytes"] <= (24 << 20)
         return "k_gibbs_ep_w5" if workload.startswith("lr") and small else "k_gibbs_ep"
     if info["ztab_entries"]:
+        # wide quads (one lane samples four consecutive positions): laid out from 3M sampled variables per handle on; the
+        # learning launches take them from 12 000 quads per class launch on (nsk_internal.h NSK_WIDE_LEARN_MIN_QUADS)
+        wide = info.get("wide_quads", 0) * 2 >= max(1, info.get("tab_quads", 0)) and info["value_bytes"] == 1
+        if wide and learning and info["wide_quads"] // max(1, info["ncolors"]) >= 12000:
+            return "k_learn_seg_tabw"
+        if wide and not learning:
+            return "k_gibbs_seg_tabw"
         return "k_learn_seg_tab" if learning else "k_gibbs_seg_tab"
     return "k_learn_seg" if learning else "k_gibbs_seg"
 
@@ -745,7 +752,9 @@ def main():
                        "generate_s": round(t_gen, 2), "load_and_compile_s": round(t_load, 2),
                        "compile_s": round(info["compile_seconds"], 2),
                        "device_bytes": info["device_bytes"]},
-            "roofline": {"bound": roofline_bound(dominant_kernel(args.workload, learning, info)),
+            # bound: the roofline the fraction is taken against (byte / integer work: HBM; there is no MFMA on this path);
+            # limited_by: what the profiles say keeps the kernel below it
+            "roofline": {"bound": "hbm", "limited_by": roofline_bound(dominant_kernel(args.workload, learning, info)),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # launch time / the time the launch's bytes (PMC traffic when collected, else the
@@ -797,13 +806,13 @@ def main():
                            "lr5m": side_run("lr5m", args.seed, 20, 5),
                            "lr5m_learn": side_run("lr5m_learn", args.seed, 10, 3),
                            "lr50m_learn": side_run("lr50m_learn", args.seed, 5, 2)}
-            out["roofline"]["frac_is"] = ("bytes the compiled layout moves per launch / launch time / HBM peak.  With implicit "
-                                          "adjacency the table kernel reads no per-lane stream (4.8 B/update instead of round 2's "
-                                          "20.0): it is bound by instruction issue along its chain of dependent steps (bound = "
-                                          "'issue'; roofline.issue, time_over_memory_floor), not by HBM, so this fraction fell "
-                                          "while updates/s rose; csr_model_GBs prices the same sweep in SURVEY 8(d)'s CSR layout. "
-                                          "Both grids' sweeps fit the Infinity Cache (stream_fits_infinity_cache); the 100M grid "
-                                          "(--workload ising100m) is the one beyond it")
+            out["roofline"]["frac_is"] = ("bytes the compiled layout moves per launch (layout_bytes_per_update x the launch's "
+                                          "updates) / launch time / HBM peak.  With implicit adjacency and wide quads the table "
+                                          "kernel reads one dword per member slot for four positions and no per-lane stream: it "
+                                          "sits on a chain of dependent round trips (limited_by = 'issue'; roofline.issue, "
+                                          "time_over_memory_floor), not on HBM; csr_model_GBs prices the same sweep in SURVEY "
+                                          "8(d)'s CSR layout.  Both grids' sweeps fit the Infinity Cache "
+                                          "(stream_fits_infinity_cache); the 100M grid (--workload ising100m) is the one beyond it")
         if multi_also is not None:
             out["also"] = {"ising100m": multi_also}
         checks["ok"] = bool(ok_local)

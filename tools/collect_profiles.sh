@@ -11,7 +11,7 @@
 # lines and the 8-shard runs only (they read profiles/traffic.json / issue.json as installed from a profile
 # stage: a gpurun call is limited to an hour and the whole collection takes longer); default: both.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-RT=${NSK_ROUND_TAG:-r5}
+RT=${NSK_ROUND_TAG:-r6}
 STAGE=${NSK_PROFILE_STAGE:-all}
 OUT=$R/gpurun_out/profiles_$RT
 rm -rf $OUT; mkdir -p $OUT
