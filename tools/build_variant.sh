@@ -15,5 +15,5 @@ else
   /opt/rocm/bin/hipcc $FLAGS $extra -c -o build/nsk_gibbs_$v.o nsk_gibbs.hip
   objs="build/nsk_gibbs_$v.o $LEARN"
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../variants/libnsk_$v.so build/nsk_api.o $objs build/nsk_compile.o build/nsk_host.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../variants/libnsk_$v.so build/nsk_api.o $objs build/nsk_compile.o build/nsk_host.o build/nsk_partition.o
 echo built ../variants/libnsk_$v.so
