@@ -1725,15 +1725,7 @@ __device__ __forceinline__ void wide_finish(const DevGraph<signed char> &g, uint
                                                    : (const NSK_SCALAR uint32_t *)g.wide_exc) + 2 * (size_t)(exc0 + e);
         const uint32_t ex = xp[0], eid = xp[1];
         const uint32_t o = ex & 0xFFu, sh = 8u * (o & 3u) + ((ex >> 8) & 7u);
-#ifdef NSK_TABW_PIPE
-        // (the member's byte through the scalar unit: a vector load here would make the trip wait for everything in flight,
-        //  the next quad's requests included; the byte belongs to the other colour -- nothing writes it in this launch)
-        const uint32_t mw = ((const NSK_SCALAR uint32_t *)g.val)[eid >> 2];
-        const uint32_t mbit = (mw >> (8u * (eid & 3u))) & 1u;
-        if ((uint32_t)lane == (o >> 2)) idx4 = (idx4 & ~(1u << sh)) | (mbit << sh);
-#else
         if ((uint32_t)lane == (o >> 2)) idx4 = (idx4 & ~(1u << sh)) | (((uint32_t)(uint8_t)g.val[eid] & 1u) << sh);
-#endif
     }
     uint32_t thr[4], hi[4], out = 0;
     bool tie = false;
@@ -2008,99 +2000,6 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_TABW_ATTR void k_gibbs_seg_tabw(NSK_
             const uint32_t e = (uint32_t)lane + 64u * (uint32_t)r;
             ztv[r] = e <= zmask ? ztab[zoff + e].x : 0u;
         }
-#ifdef NSK_TABW_PIPE
-        // SOFTWARE PIPELINE over the wave's quads of the segment: the value dwords of the NEXT quad are requested before
-        // this quad's are consumed (its descriptor came a trip ahead), the descriptor of the quad after that right behind
-        // them -- so a trip's memory latency lies under the previous trip's Philox block, look-ups and stores.  Two
-        // register sets take turns (a move of a register a load is still to write would wait for the load).
-        bool cflag = hasw && cur[0] != 0xFFFFFFFFu, cw = cflag && (uint32_t)(Q - qin_lo) < qin_n;
-        uint32_t cexc0 = cur[4 * NCH], cnexc = cur[4 * NCH + 1], csmask = cur[4 * NCH + 2];
-        asm volatile("" :: "s"(cur[4 * NCH + 3]));
-        WideTrip<NCH> tA, tB;
-        {
-            uint32_t bc[4 * NCH];
-#pragma unroll
-            for (int j = 0; j < 4 * NCH; j++) bc[j] = cw ? cur[j] : 0u;
-            wide_issue<NCH, MODE>(gh, p0, bc, lane, tA);
-        }
-        if (Q + wpx < Qe) wq += wstep;
-#pragma unroll
-        for (int j = 0; j < ST; j++) cur[j] = wq[j];
-        if (!keyed) {                 // the wave's first requests are out: now the cold arguments
-            keyed = true;
-            if (!cold) { asm volatile("" : "+s"(ka)); cold = (const TabwCold NSK_SCALAR *)(ka + NSK_TABW_COLD_OFFSET); }
-            k0 = cold->k0; k1 = cold->k1; s0 = cold->s0; s1 = cold->s1;
-            if (sweep_base) {         // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
-                const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
-                const unsigned long long sw = cb[0] + cold->sweep_off, key = cb[2];
-                s0 = (uint32_t)sw;
-                s1 = (uint32_t)(sw >> 32) ^ (uint32_t)cb[3];
-                k0 = (uint32_t)key;
-                k1 = (uint32_t)(key >> 32);
-            }
-            k0 = nsk_settled(k0); k1 = nsk_settled(k1); s0 = nsk_settled(s0); s1 = nsk_settled(s1);
-            pk = philox_round_keys(k0, k1);
-        }
-        auto step = [&](WideTrip<NCH> &ta, WideTrip<NCH> &tb, bool first) -> bool {
-            const bool has_next = Q + wpx < Qe;
-            bool nflag = false, nw = false;
-            uint32_t nexc0 = 0, nnexc = 0, nsmask = 0;
-            // the next quad's values, then the descriptor of the one after it.  ALWAYS issued -- past the wave's last quad
-            // and for a quad that is not wide from offsets that are merely readable: a conditional request would leave the
-            // compiler no count to wait for (it then waits for everything in flight, this request included)
-            nflag = has_next && hasw && cur[0] != 0xFFFFFFFFu;
-            nw = nflag && (uint32_t)(Q + wpx - qin_lo) < qin_n;
-            nexc0 = cur[4 * NCH]; nnexc = cur[4 * NCH + 1]; nsmask = cur[4 * NCH + 2];
-            asm volatile("" :: "s"(cur[4 * NCH + 3]));
-            {
-                uint32_t bn[4 * NCH];
-#pragma unroll
-                for (int j = 0; j < 4 * NCH; j++) bn[j] = nw ? cur[j] : 0u;
-                wide_issue<NCH, MODE>(gh, nw ? p0 + 256 * wpx : p0, bn, lane, tb);
-            }
-            if (Q + 2 * wpx < Qe) wq += wstep;
-#pragma unroll
-            for (int j = 0; j < ST; j++) cur[j] = wq[j];
-            if (first) {              // the wave's copy of the segment's thresholds: requested in front, stored here
-#pragma unroll
-                for (int r = 0; r < ZR; r++)
-                    if (lane + 64 * r < ZN) zt[lane + 64 * r] = ztv[r];
-                asm volatile("" ::: "memory");                          // (LDS executes a wave's accesses in order: no barrier)
-            }
-            if (cw) {
-                wide_finish<NCH, MODE>(gh, zoff, p0, cexc0, cnexc, csmask, ta, zt, lane, k0, k1, s0, s1,
-                                       ka + NSK_TABW_COLD_OFFSET + offsetof(TabwCold, g) + offsetof(DevGraph<signed char>, wide_exc), &pk);
-            } else {                  // not a wide quad (a class end, mixed border cells): tile by tile
-                SegEntry en;
-                {
-                    const NSK_SCALAR uint32_t *ep = (const NSK_SCALAR uint32_t *)(ka + NSK_TABW_COLD_OFFSET + offsetof(TabwCold, tab) +
-                                                                                  offsetof(SegTable, e) + sizeof(SegEntry) * (size_t)sidx);
-                    uint32_t ew[sizeof(SegEntry) / 4];
-#pragma unroll
-                    for (int j = 0; j < (int)(sizeof(SegEntry) / 4); j++) ew[j] = ep[j];
-                    __builtin_memcpy(&en, ew, sizeof(SegEntry));
-                }
-                DevGraph<signed char> gf = gh;                          // (the fall-back's arrays: read here, not kept)
-                gf.adj = cold->g.adj; gf.seg_aff = cold->g.seg_aff; gf.sink = cold->g.sink;
-                const int t0q = 4 * Q - tstart - lead;
-                const uint32_t qb = quad_block((uint32_t)(p0 + lane));
-                const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
-                u32x4 rb = {0u, 0u, 0u, 0u};
-                bool have_b = false;
-#pragma unroll 1
-                for (int t = 0; t < 4; t++)
-                    tab_tiles<signed char, NCH, 1, MODE == 2>(gf, en, t0q + t, t, lane, MODE == 1 ? 1 : 0, ra, rb, have_b, qb, k0, k1, s0, s1, cflag);
-            }
-            if (!has_next) return false;
-            Q += wpx; p0 += 256 * wpx;
-            cflag = nflag; cw = nw; cexc0 = nexc0; cnexc = nnexc; csmask = nsmask;
-            return true;
-        };
-        if (step(tA, tB, true))
-            while (step(tB, tA, false) && step(tA, tB, false)) {}
-        Q += wpx;
-    }
-#else
         bool land = true;
         for (; Q < Qe; Q += wpx, p0 += 256 * wpx) {
 #ifdef NSK_ABL_TIMING
@@ -2177,7 +2076,6 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_TABW_ATTR void k_gibbs_seg_tabw(NSK_
                 tab_tiles<signed char, NCH, 1, MODE == 2>(gf, en, t0q + t, t, lane, MODE == 1 ? 1 : 0, ra, rb, have_b, qb, k0, k1, s0, s1, flagged);
         }
     }
-#endif
 #ifdef NSK_ABL_TIMING
     {
         __builtin_amdgcn_s_waitcnt(0);
