@@ -406,7 +406,7 @@ def roofline_bound(kernel):
     profiles/): the draw-table kernels read almost no stream and are bound by instruction issue along a
     chain of dependent steps; the entry-parallel kernels by the latency of their dependent gathers at the
     occupancy their registers allow (no unit saturated); the CSR / exp-per-update kernels by HBM."""
-    if kernel.endswith("_seg_tab") or kernel.endswith("_seg_tabw"):
+    if kernel.endswith("_seg_tab") or kernel.endswith("_seg_tabw") or kernel.endswith("_seg_tab_p2p"):
         return "issue"
     if kernel.endswith("_ep") or kernel.endswith("_ep_w5") or kernel.endswith("_ep_w4"):
         return "latency"
@@ -437,6 +437,8 @@ def issue_side(workload, launch_s):
 
 def dominant_kernel(workload, learning, info):
     """Name of the kernel family the launch average is dominated by (profiles/*_kernel_stats.csv)."""
+    if info.get("p2p_fused") and not learning:
+        return "k_gibbs_seg_tab_p2p"     # a shard that exchanges its boundary inside its class launches
     if not info["nfast"]:
         return "k_learn_phase" if learning else "k_gibbs_phase"
     if workload.startswith("lr") or workload.startswith("boolw"):
@@ -754,7 +756,7 @@ def main():
                        "device_bytes": info["device_bytes"]},
             # bound: the roofline the fraction is taken against (byte / integer work: HBM; there is no MFMA on this path);
             # limited_by: what the profiles say keeps the kernel below it
-            "roofline": {"bound": "hbm", "limited_by": roofline_bound(dominant_kernel(args.workload, learning, info)),
+            "roofline": {"bound": "hbm", "limited_by": roofline_bound(dominant_kernel(args.workload, learning, dict(info, p2p_fused=fg.info()["p2p_fused"]))),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # launch time / the time the launch's bytes (PMC traffic when collected, else the
@@ -768,7 +770,7 @@ def main():
                          "stream_fits_infinity_cache": bool(lay_sweep < INFINITY_CACHE_BYTES),
                          "alg_bytes_per_update_csr": alg_sweep * world / nvar,
                          "csr_model_GBs": alg_sweep * args.steps / (ms_ev.value / 1e3) / 1e9,
-                         "kernel": dominant_kernel(args.workload, learning, info),
+                         "kernel": dominant_kernel(args.workload, learning, dict(info, p2p_fused=fg.info()["p2p_fused"])),
                          "stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "launches": nlaunch, "avg_launch_us": launch_s * 1e6},
@@ -799,8 +801,8 @@ def main():
                 ok_local = ok_local and (checks["edge_agreement_ok"] or not burnt_in)
         if world == 1 and args.workload == "ising10m" and not args.no_extra:
             out["also"] = {"ising1m": side_run("ising1m", args.seed, 400, 100),
-                           "ising10m_learn": side_run("ising10m_learn", args.seed, 40, 10),
-                           "ising40m": side_run("ising40m", args.seed, 20, 5),
+                           "ising10m_learn": side_run("ising10m_learn", args.seed, 100, 20),
+                           "ising40m": side_run("ising40m", args.seed, 50, 10),
                            # BASELINE configs[4] on one GPU: the LR graph at a tenth of its size (both sweeps) and its
                            # learning sweep at full size
                            "lr5m": side_run("lr5m", args.seed, 20, 5),
