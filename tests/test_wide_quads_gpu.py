@@ -157,3 +157,20 @@ def test_packed_tally_switch(monkeypatch):
     ns, fg = session(g, seed=13)
     og = oracle_of(fg)
     _run_and_compare(fg, og, 13, 2, 20)
+
+
+@pytest.mark.parametrize("learn,fused", [(False, False), (False, True), (True, False)])
+def test_two_shards_of_a_grid_with_wide_quads_match_emulation(monkeypatch, learn, fused):
+    """Shards big enough for wide quads (a 5M-variable half of the 10M grid in a real two-rank run; here a 768 x 1024
+    grid in two shards with the bounds lowered): the wide-quad inference kernel on a handle with ghosts, the fused
+    exchange's tile-by-tile walk over a layout whose positions draw from the wide scheme, and the wide learning kernel
+    on a shard -- through the real peer-to-peer path, bit-exact against the partitioned oracle emulation."""
+    import test_config5_shards_gpu as shards
+    monkeypatch.setattr(shards, "WORLD", 2)
+    probe, _, _ = shards.make_parts("grid", (768, 1024), learn, 1)
+    assert all(p.fg.info()["wide_quads"] > 0.9 * p.fg.info()["tab_quads"] > 0 for p in probe)      # the shards ARE laid out in wide quads
+    for p in probe:
+        p.fg.close()
+    out = shards.run_case("grid", (768, 1024), learn, "wide2shards (768x1024 grid, two shards)", nsweeps=3 if not fused else 4,
+                          hyper=(1e-4, 0.95, 2, 0.01, 1), fused=fused)
+    assert fused or sum(out["ghosts_per_rank"]) == 2 * 1024
