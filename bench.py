@@ -54,6 +54,8 @@ WORKLOADS = {
     "lr50m": (10000, 5000, False),
     "lr50m_learn": (10000, 5000, True),
     "ising64k": (256, 256, False),            # plumbing tests
+    "ising256k": (512, 512, False),           # (where wide quads start to pay: tools/sessions/r6_s25.sh)
+    "ising500k": (500, 1000, False),
     "lr300k_learn": (600, 500, True),
     # 4x / 10x the metric config.  With implicit adjacency a sweep of the 40M grid moves ~190 MB (it was
     # 800 MB in round 2) and fits the 256 MiB Infinity Cache again; the 100M grid (~450 MB per sweep) is

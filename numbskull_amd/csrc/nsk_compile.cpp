@@ -718,12 +718,14 @@ static int build_segment_adjacency(Compiled &c, std::string &err) {
     return NSK_OK;
 }
 
-// Wide quads pay from a few million variables per handle on: a class launch of the 1M grid is one wave lifetime long
-// either way, and the tile-by-tile kernel's is shorter (one MI355X, tools/sessions/r6_s14.sh: 1M grid 9.1 against 10.9 us
-// per sweep, 4M grid 14.3 / 14.3, 10M grid 23.9 / 17.2).  NSK_DIAG=1 NSK_WIDE_MIN=n moves the bound (the tests use 0).
+// Wide quads pay from a few hundred thousand variables per handle on (one MI355X, us per sweep, tile-by-tile kernel /
+// wide-quad kernel, tools/sessions/r6_s25.sh: 256 x 256 grid 6.63 / 6.60, 512 x 512 6.82 / 7.10, 500 x 1000 7.30 / 6.33, 1M grid
+// 9.00 / 6.64, 4M 13.8 / 10.2-11.9, 10M 23.9 / 15.4) -- since the launch's few quads that are NOT wide are sampled by workgroups
+// of their own (TabwCold.rest); while the waves whose turn they were sampled them in line, the bound was 3M (1M grid 9.1
+// against 10.9).  NSK_DIAG=1 NSK_WIDE_MIN=n moves the bound (the small-grid tests use 0).
 static int64_t wide_min_variables() {
     const char *e = diag_env("NSK_WIDE_MIN");
-    return e ? atoll(e) : 3000000;
+    return e ? atoll(e) : 400000;
 }
 
 // Wide quads of table segments (nsk_compile.h seg_wide): per quad the slot bases when one lane can take four

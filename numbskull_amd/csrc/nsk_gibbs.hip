@@ -15,9 +15,10 @@ static inline int tabw_delta(const void *p, const void *base) {
     const long long d = (const char *)p - (const char *)base;
     return (int)(d / 256);            // (device allocations are 256-byte aligned: checked once in nsk_ensure_seg_plans)
 }
-#define NSK_TABW_HOT_ARGS(G, T, NB, SB) (signed char *)(G)->val, tabw_delta((G)->cnt_pos, (G)->val), tabw_delta((G)->seg_wide, (G)->val),            \
+#define NSK_TABW_HOT_ARGS(G, T, NB, NF, SB) (signed char *)(G)->val, tabw_delta((G)->cnt_pos, (G)->val), tabw_delta((G)->seg_wide, (G)->val),            \
         tabw_delta((G)->ztab, (G)->val), (T).e[1].tile_start, (T).e[0].ntiles_lead, (T).e[0].pos0, (T).e[0].wide_off, (T).e[0].zoff,             \
-        (uint32_t)(T).ntiles | ((uint32_t)((T).n - 1) << 28), ((T).e[0].zmask_ev & 0xFFu) | ((uint32_t)(((NB) >> 3) * (NSK_BLOCK / 64)) << 8),   \
+        (uint32_t)(T).ntiles | ((uint32_t)((T).n - 1) << 28),                                                                                    \
+        ((T).e[0].zmask_ev & 0xFFu) | ((uint32_t)(((NB) >> 3) * (NSK_BLOCK / 64)) << 8) | ((uint32_t)(NF) << 24),                                \
         (const unsigned long long *)(SB)
 
 // The segment launches of every colour, prepared once and kept in the handle (a small graph's sweep is two
@@ -69,7 +70,9 @@ void nsk_ensure_seg_plans(nsk_graph *g, int sample_evidence) {
                     };
                     tab.wide = (kind >= 8 && 8 * tab.wide >= tab.ntiles && tab.ntiles < (1 << 28) && fits(g->cnt_pos) && fits(g->seg_wide) &&
                                 fits(g->ztab) && !nsk::diag_env("NSK_NO_WIDE_KERNEL")) ? 1 : 0;
-                    seg_plans[ph].push_back(SegPlan{kind, nch, tab});
+                    SegPlan pl{kind, nch, tab};
+                    if (tab.wide) nsk_tabw_rest_list(g->c, pl.tab, pl.nch, pl.nrest, pl.rest);
+                    seg_plans[ph].push_back(pl);
                     memset(&tab, 0, sizeof(tab));
                 };
                 // largest segments first: the kernels find a tile's segment with a scan
@@ -287,8 +290,10 @@ static int gibbs_impl(nsk_graph *g, int64_t nsweeps, int sample_evidence, int bu
                                 const DevGraph<signed char> dw = view<signed char>(g);
                                 const int nbw = nsk_tabw_grid(tab.ntiles);
                                 const int mode = burnin ? 1 : (g->pack_now ? 2 : 0);        // 2: the tally inside the value bytes
-                                const TabwCold cold{K0, K1, S0, S1, 0u, 0u, dw, tab};
-#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nbw), block, 0, g->stream>>>(NSK_TABW_HOT_ARGS(g, tab, nbw, nullptr), cold)
+                                TabwCold cold{K0, K1, S0, S1, 0u, 0u, dw, tab, pl.nrest, {}};
+                                memcpy(cold.rest, pl.rest, sizeof(cold.rest));
+                                const int nf = nsk_tabw_front_blocks(pl.nrest);
+#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nf + nbw), block, 0, g->stream>>>(NSK_TABW_HOT_ARGS(g, tab, nbw, nf, nullptr), cold)
                                 if (nch == 1) { if (mode == 0) NSK_TABW(1, 0); else if (mode == 1) NSK_TABW(1, 1); else NSK_TABW(1, 2); }
                                 else { if (mode == 0) NSK_TABW(2, 0); else if (mode == 1) NSK_TABW(2, 1); else NSK_TABW(2, 2); }
 #undef NSK_TABW
@@ -386,8 +391,10 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
                     const DevGraph<signed char> dw = view<signed char>(g);
                     const int nbw = nsk_tabw_grid(pl.tab.ntiles);
                     const int mode = burnin ? 1 : (g->pack_now ? 2 : 0);
-                    const TabwCold cold{0u, 0u, 0u, 0u, (uint32_t)i, 0u, dw, pl.tab};
-#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nbw), dim3(NSK_BLOCK), 0, g->stream>>>(NSK_TABW_HOT_ARGS(g, pl.tab, nbw, g->d_counters), cold)
+                    TabwCold cold{0u, 0u, 0u, 0u, (uint32_t)i, 0u, dw, pl.tab, pl.nrest, {}};
+                    memcpy(cold.rest, pl.rest, sizeof(cold.rest));
+                    const int nf = nsk_tabw_front_blocks(pl.nrest);
+#define NSK_TABW(NCH, MODE) k_gibbs_seg_tabw<NCH, MODE><<<dim3(nf + nbw), dim3(NSK_BLOCK), 0, g->stream>>>(NSK_TABW_HOT_ARGS(g, pl.tab, nbw, nf, g->d_counters), cold)
                     if (pl.nch == 1) { if (mode == 0) NSK_TABW(1, 0); else if (mode == 1) NSK_TABW(1, 1); else NSK_TABW(1, 2); }
                     else { if (mode == 0) NSK_TABW(2, 0); else if (mode == 1) NSK_TABW(2, 1); else NSK_TABW(2, 2); }
 #undef NSK_TABW

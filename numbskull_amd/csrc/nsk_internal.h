@@ -26,10 +26,16 @@ int fail(int code, const std::string &msg);       // records nsk_last_error, ret
             return nsk::fail(NSK_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));  \
     } while (0)
 
-struct NskSegPlan { int kind, nch; nsk::SegTable tab; };       // one prepared segment launch (nsk_gibbs.hip)
+struct NskSegPlan { int kind, nch; nsk::SegTable tab;         // one prepared segment launch (nsk_gibbs.hip)
+                    uint32_t nrest = 0, rest[NSK_TABW_REST_MAX] = {}; };      // wide launches: the quads that are not wide (TabwCold.rest)
+
+// a learning launch over (mostly) wide quads, prepared once (nsk_learn.hip): its segment table in whole quads, whether the
+// wide kernel takes it, and its quads that are not wide ones
+struct NskLearnWidePlan { int key = -1; bool wide = false; int vt = 0; nsk::SegTable tab; uint32_t nrest = 0, rest[NSK_TABW_REST_MAX] = {}; };
 
 struct nsk_graph {
     nsk::Compiled c;
+    std::vector<NskLearnWidePlan> learn_wide_plans;      // per Compiled::learn_seg entry
     // the inference sweep's segment launches per colour, kept across calls (the N-rank loops sweep one
     // epoch per call); key = sample_evidence | draw tables usable << 1
     std::vector<std::vector<NskSegPlan>> seg_plans;
@@ -288,17 +294,46 @@ static inline int nsk_tabw_grid(int vtiles) {
     const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : 256 * NSK_TABW_PER_CU;
     return std::min(cap, need);
 }
+// The quads of a wide launch that are not wide ones (TabwCold.rest / TabwRest; the kernels' own tests of a quad, mirrored):
+// each gets a workgroup in front of the grid.  More than NSK_TABW_REST_MAX of them: none listed, the waves sample them in
+// line (NSK_DIAG=1 NSK_NO_TABW_REST=1: likewise).
+static inline void nsk_tabw_rest_list(const nsk::Compiled &c, const nsk::SegTable &tab, int nch, uint32_t &nrest, uint32_t *out) {
+    const int ST = NSK_WIDE_STRIDE(nch);
+    std::vector<uint32_t> rest;
+    for (int i = 0; i < tab.n; i++) {
+        const nsk::SegEntry &en = tab.e[i];
+        const int tend = i + 1 < NSK_SEG_MAX ? tab.e[i + 1].tile_start : tab.ntiles;
+        const int lead = (int)(en.ntiles_lead >> 30), nt = (int)(en.ntiles_lead & 0x3FFFFFFFu);
+        const int qs = en.tile_start >> 2, qin_lo = qs + (lead ? 1 : 0);
+        const uint32_t qin_n = (uint32_t)(qs + ((lead + nt) >> 2) - qin_lo);
+        const bool hasw = en.wide_off != NSK_NO_STREAM;
+        for (int Q = qs; Q < (tend >> 2); Q++) {
+            const bool flagged = hasw && c.seg_wide[(size_t)en.wide_off + (size_t)(Q - qs) * ST] != 0xFFFFFFFFu;
+            if (flagged && (uint32_t)(Q - qin_lo) < qin_n) continue;     // a wide quad
+            rest.push_back((uint32_t)Q | (flagged ? 0x80000000u : 0u));
+        }
+    }
+    nrest = 0;
+    if (rest.size() <= NSK_TABW_REST_MAX && !nsk::diag_env("NSK_NO_TABW_REST")) {
+        nrest = (uint32_t)rest.size();
+        for (size_t k = 0; k < rest.size(); k++) out[k] = rest[k];
+    }
+}
+static inline int nsk_tabw_front_blocks(uint32_t nrest) { return (int)((nrest + 7u) & ~7u); }     // whole rounds of XCDs
+
 // Grid of a wide-quad learning launch (k_learn_seg_tabw) over `vtiles` virtual tiles, whole rounds of XCDs (the service
-// blocks in front come on top).  Measured on one MI355X (tools/sessions/r6_s16.sh, us per learning sweep): 10M grid
-// 46.1 / 50.5 / 52.0 / 42.3 / 42.5 / 53.8 / 50.2 / 43.5 / 56.4 at 768 / 1024 / 1280 / 1408 / 1536 / 1664 / 1792 / 2048 /
-// 2560 blocks (45.5 tile by tile); 40M grid 121.0 / 112.8 / 115.8 at 1536 / 2048 / 4096 (150.7 tile by tile); on the 4M
-// grid the tile-by-tile kernel wins (25.2 against 31.4), hence NSK_WIDE_LEARN_MIN_QUADS.
+// and front blocks come on top).  One MI355X, us per learning sweep (tools/sessions/r6_s26.sh): 10M grid 45.6 / 45.6 / 40.3 /
+// 42.6 / 41.8 / 43.7 / 43.3 at 512 / 640 / 768 / 896 / 1024 / 1152 / 1280 blocks (45.5 tile by tile; 41.0 at 1024 and 43.0 at 1536 in
+// r6_s25.sh); 40M grid 120.8 / 117.7 / 117.4 / 111.6 at 768 / 1024 / 1536 / 2048 (146.6 tile by tile).  (While the waves whose
+// turn they were sampled the launch's few quads that are not wide in line, these figures jumped by a quarter from one
+// grid size to the next -- whichever waves drew those quads ended the launch: r6_s16.sh.)  On the 4M grid the
+// tile-by-tile kernel wins (24.3 against 27.5), hence NSK_WIDE_LEARN_MIN_QUADS.
 #define NSK_WIDE_LEARN_MIN_QUADS 12000
 static inline int nsk_learn_tabw_grid(int vtiles) {
     const int nquads = vtiles / 4 + 8;
     const int need = std::max(8, 8 * ((((nquads + 3) / 4) + 7) / 8));
     const char *cap_env = nsk::diag_env("NSK_LEARN_TABW_GRID_CAP");         // (diagnostic)
-    const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : (nquads >= 40000 ? 2048 : 1536);
+    const int cap = cap_env ? std::max(8, std::abs(atoi(cap_env)) & ~7) : (nquads >= 40000 ? 2048 : 1024);
     return std::min(cap, need);
 }
 static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nweight, bool smallw, bool use_tab) {

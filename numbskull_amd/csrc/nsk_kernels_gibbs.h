@@ -1919,13 +1919,64 @@ template <typename T> __device__ __forceinline__ T *nsk_settled_ptr(T *p) {
 }
 #define NSK_TABW_HOT signed char *val, int d_cnt, int d_wide, int d_ztab, int ts1, uint32_t ntl0, int pos00, uint32_t woff0,          \
                      uint32_t zoff0, uint32_t ntiles_nseg, uint32_t zmask0_wpx, const unsigned long long *sweep_base
+#define NSK_TABW_REST_MAX 64        // quads of a launch that are not wide ones and get a workgroup of their own (below)
 struct TabwCold {                   // ... and the rest, read through a laundered pointer BEHIND the first trip's requests
     uint32_t k0, k1, s0, s1;        //     (the compiler hoists every load of a kernel argument to the kernel's entry)
     uint32_t sweep_off, pad_;
     DevGraph<signed char> g;
     SegTable tab;
+    // The launch's quads that are NOT wide ones (a grid's border columns, class ends): virtual quad | bit 31: its positions
+    // draw from the wide scheme all the same.  Each is sampled by a workgroup of its own IN FRONT of the grid (a wave per
+    // tile, blockIdx < zmask0_wpx >> 24), not by the wave whose turn it would be: sampled in line, tile after tile, these
+    // few quads -- 11 of a 10M-grid launch's 20 011 -- kept their waves busy long after the others had finished: 1.6 of the
+    // launch's 8.7 us (tools/sessions/r6_s21.sh, r6_s22.sh: the fall-back compiled in but never run 7.1 us, left out 7.1).
+    uint32_t nrest, rest[NSK_TABW_REST_MAX];
 };
 #define NSK_TABW_COLD_OFFSET 56     // byte offset of the TabwCold argument in the kernarg segment (14 dwords in front, 8-aligned)
+// One of the launch's quads that are not wide ones (TabwCold.rest), a wave per tile, by the round-4 routine; nothing here
+// is in a hurry: the waves of these workgroups live about as long as the others'.
+template <int NCH, int MODE>
+__device__ __forceinline__ void tabw_rest_quad(const char NSK_SCALAR *ka, const unsigned long long *sweep_base) {
+    const TabwCold NSK_SCALAR *cold = (const TabwCold NSK_SCALAR *)(ka + NSK_TABW_COLD_OFFSET);
+    if (blockIdx.x >= cold->nrest) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t ent = cold->rest[blockIdx.x];
+    const int Q = (int)(ent & 0x7FFFFFFFu);
+    const bool flagged = (ent >> 31) != 0u;
+    const SegTable NSK_SCALAR *tb = &cold->tab;
+    int sidx = 0;
+    for (int i = 1; i < NSK_SEG_MAX && 4 * Q >= tb->e[i].tile_start; i++) sidx = i;      // (tile_start = ntiles beyond the last segment)
+    SegEntry en;
+    {
+        const NSK_SCALAR uint32_t *ep = (const NSK_SCALAR uint32_t *)(ka + NSK_TABW_COLD_OFFSET + offsetof(TabwCold, tab) +
+                                                                      offsetof(SegTable, e) + sizeof(SegEntry) * (size_t)sidx);
+        uint32_t ew[sizeof(SegEntry) / 4];
+#pragma unroll
+        for (int j = 0; j < (int)(sizeof(SegEntry) / 4); j++) ew[j] = ep[j];
+        __builtin_memcpy(&en, ew, sizeof(SegEntry));
+    }
+    uint32_t k0 = cold->k0, k1 = cold->k1, s0 = cold->s0, s1 = cold->s1;
+    if (sweep_base) {                 // a captured launch (hipGraph): sweep index, key and shard tag live in device memory
+        const NSK_SCALAR unsigned long long *cb = (const NSK_SCALAR unsigned long long *)sweep_base;
+        const unsigned long long sw = cb[0] + cold->sweep_off, key = cb[2];
+        s0 = (uint32_t)sw;
+        s1 = (uint32_t)(sw >> 32) ^ (uint32_t)cb[3];
+        k0 = (uint32_t)key;
+        k1 = (uint32_t)(key >> 32);
+    }
+    DevGraph<signed char> gf;
+    gf.val = cold->g.val; gf.cnt_pos = cold->g.cnt_pos; gf.ztab = cold->g.ztab; gf.seg_wide = cold->g.seg_wide;
+    gf.adj = cold->g.adj; gf.seg_aff = cold->g.seg_aff; gf.sink = cold->g.sink;
+    const int lead = (int)(en.ntiles_lead >> 30);
+    const int t0q = 4 * Q - en.tile_start - lead;                       // segment tile of the quad's first tile
+    const int p0 = en.pos0 + t0q * 64;                                  // the quad's first position (a multiple of 256)
+    const uint32_t qb = quad_block((uint32_t)(p0 + lane));
+    const u32x4 ra = philox4x32(k0, k1, qb, 2u, s0, s1);
+    u32x4 rb = {0u, 0u, 0u, 0u};
+    bool have_b = false;
+    tab_tiles<signed char, NCH, 1, MODE == 2>(gf, en, t0q + wv, wv, lane, MODE == 1 ? 1 : 0, ra, rb, have_b, qb, k0, k1, s0, s1, flagged);
+}
 template <int NCH, int MODE>
 __global__ __launch_bounds__(NSK_BLOCK) NSK_TABW_ATTR void k_gibbs_seg_tabw(NSK_TABW_HOT, TabwCold cold_unused) {
     const int lane = (int)(threadIdx.x & 63);
@@ -1943,11 +1994,17 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_TABW_ATTR void k_gibbs_seg_tabw(NSK_
     const uint4 *ztab = (const uint4 *)((const char *)val + (long long)d_ztab * 256);
     const int ntiles = (int)(ntiles_nseg & 0x0FFFFFFFu);          // (bits 28-31: segments - 1; tile_start = ntiles beyond them)
     const uint32_t zmask0 = zmask0_wpx & 0xFFu;
-    const int wpx = (int)(zmask0_wpx >> 8);                             // waves per XCD
+    const int wpx = (int)((zmask0_wpx >> 8) & 0xFFFFu);                 // waves per XCD
+    const int nfront = (int)(zmask0_wpx >> 24);                         // workgroups in front that sample the quads that are not wide (a multiple of 8)
+    if ((int)blockIdx.x < nfront) {                                     // (block-uniform)
+        tabw_rest_quad<NCH, MODE>((const char NSK_SCALAR *)__builtin_amdgcn_kernarg_segment_ptr(), sweep_base);
+        return;
+    }
+    const int bid = (int)blockIdx.x - nfront;
     const int nquads = ntiles >> 2;                                     // virtual tiles: a multiple of 4
     const int per = (nquads + 7) >> 3;                                  // quads per XCD
-    const int xcd = (int)(blockIdx.x & 7);
-    const int wx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * (NSK_BLOCK / 64)) + wv;
+    const int xcd = bid & 7;
+    const int wx = __builtin_amdgcn_readfirstlane((bid >> 3) * (NSK_BLOCK / 64)) + wv;
     const int q0 = min(nquads, xcd * per), q1 = min(nquads, (xcd + 1) * per);
     // the cold arguments: nothing of them is read before the first trip's requests are out (`keyed`)
     const char NSK_SCALAR *ka = (const char NSK_SCALAR *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2053,8 +2110,10 @@ __global__ __launch_bounds__(NSK_BLOCK) NSK_TABW_ATTR void k_gibbs_seg_tabw(NSK_
                                        ka + NSK_TABW_COLD_OFFSET + offsetof(TabwCold, g) + offsetof(DevGraph<signed char>, wide_exc), &pk);
                 continue;
             }
-            // not a wide quad (a class end, mixed border cells): tile by tile.  Its block: the run's first position less
-            // its lead tiles is a multiple of 256, so (pos >> 8, lane) names it
+            // not a wide quad (a class end, mixed border cells): a workgroup in front has it -- or, in a launch with more
+            // such quads than those take, tile by tile here.  Its block: the run's first position less its lead tiles is
+            // a multiple of 256, so (pos >> 8, lane) names it
+            if (nfront) continue;
             SegEntry en;
             {
                 const NSK_SCALAR uint32_t *ep = (const NSK_SCALAR uint32_t *)(ka + NSK_TABW_COLD_OFFSET + offsetof(TabwCold, tab) +

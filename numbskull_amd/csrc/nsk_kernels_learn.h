@@ -954,6 +954,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tab(DevGraph<VT> g, Seg
 // program changes or the wave ends: no ballot, no cross-lane step per tile.  The generator is the learning sweeps' own:
 // one block per POSITION, counter (position, stream, sweep) -- the oracle's learning mode is untouched.
 // Quads that are not wide are sampled tile by tile (learn_tab_tile), as k_learn_seg_tab does.
+struct TabwRest { uint32_t n, q[NSK_TABW_REST_MAX]; };             // the launch's quads that are not wide ones (TabwCold.rest)
+__host__ __device__ inline int nsk_tabw_front(uint32_t n) { return (int)((n + 7u) & ~7u); }
 template <int NCH>
 struct WideLearnTrip { uint32_t xf[4 * NCH], xe[4 * NCH], init; };
 
@@ -1016,7 +1018,7 @@ __device__ __forceinline__ void learn_tab_tile(const DevGraph<signed char> &g, c
 }
 
 template <bool SMALLW, int NCH>
-__global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tabw(DevGraph<signed char> g, SegTable tab, LearnParams lp, ApplyArgs prev) {
+__global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tabw(DevGraph<signed char> g, SegTable tab, LearnParams lp, ApplyArgs prev, TabwRest rest) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (SMALLW && blockIdx.x < NSK_SERVICE_BLOCKS) {                   // (block-uniform) the previous class's update rides here
         if (blockIdx.x == 0 && prev.nweight > 0) apply_bins_block(prev);
@@ -1024,8 +1026,12 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tabw(DevGraph<signed ch
     }
     constexpr int ST = NSK_WIDE_STRIDE(NCH), ZN = 1 << NSK_ZT_BITS(NCH), ZR = (ZN + 63) / 64;
     __shared__ uint4 zt_all[(NSK_BLOCK / 64) * ZN];                     // the wave's copy of its segment's table entries
-    const int bid = (int)blockIdx.x - (SMALLW ? NSK_SERVICE_BLOCKS : 0);
-    const int gdim = (int)gridDim.x - (SMALLW ? NSK_SERVICE_BLOCKS : 0);
+    // behind the service blocks: a workgroup per quad that is not a wide one (TabwRest), a wave per tile -- see TabwCold.rest
+    const int nfront = nsk_tabw_front(rest.n);
+    const int bid0 = (int)blockIdx.x - (SMALLW ? NSK_SERVICE_BLOCKS : 0);
+    if (bid0 < nfront && (uint32_t)bid0 >= rest.n) return;             // (block-uniform: a front workgroup without a quad)
+    const int bid = bid0 - nfront;
+    const int gdim = (int)gridDim.x - (SMALLW ? NSK_SERVICE_BLOCKS : 0) - nfront;
     const GradSink sk = open_sink<SMALLW>(g, smem);
     const int lane = (int)(threadIdx.x & 63);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1078,6 +1084,15 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tabw(DevGraph<signed ch
         for (int j = 0; j < 4 * NCH; j++) { acc[j] = 0; accv[j] = 0; }
         accK = 0u; accT = 0u; accKv = 0u; accTv = 0u;
     };
+    if (bid0 < nfront) {                                                // (block-uniform) one quad that is not wide: this wave's tile of it
+        const int Qr = (int)(rest.q[bid0] & 0x7FFFFFFFu);
+        const SegEntry en = tab.e[seg_of_tile(tab, 4 * Qr)];
+        cur_prog = en.prog;
+        learn_tab_tile<NCH>(g, lp, en, 4 * Qr - en.tile_start - (int)(en.ntiles_lead >> 30) + wv, lane, acc, accK, accT);
+        flush();
+        close_sink<SMALLW>(g, sk);
+        return;
+    }
     for (int Q = q0 + wx; Q < q1;) {
         // the segment of the quad, and the wave's quads inside it (every segment is whole quads of the launch)
         const int sidx = seg_of_tile(tab, 4 * Q);
@@ -1122,7 +1137,8 @@ __global__ __launch_bounds__(NSK_BLOCK) void k_learn_seg_tabw(DevGraph<signed ch
             if (Q + wpx < Qe) wq += wstep;                              // the next trip's descriptor, a scalar round trip ahead
 #pragma unroll
             for (int j = 0; j < ST; j++) cur[j] = wq[j];
-            if (!wide) {                                                // tile by tile
+            if (!wide) {                                                // tile by tile -- unless a workgroup in front has the quad
+                if (nfront) continue;
 #pragma unroll 1
                 for (int t = 0; t < 4; t++) learn_tab_tile<NCH>(g, lp, en, 4 * Q - en.tile_start - lead + t, lane, acc, accK, accT);
                 continue;

@@ -244,44 +244,59 @@ int nsk_learn_chromatic(nsk_graph *g, int64_t nsweeps, double step, double decay
                 tab.n = sl.n;
                 // (mostly) wide quads: the wide learning kernel, its tiles numbered in whole quads like the inference
                 // launches (lead = dead tiles in front of a segment that does not start on a quad boundary)
-                if constexpr (sizeof(VT) == 1) if (use_tab && !nsk::diag_env("NSK_NO_WIDE_LEARN")) {
-                    int vt = 0, nwide = 0;
-                    for (int i = 0; i < NSK_SEG_MAX; i++) {
-                        SegEntry &en = tab.e[i];
-                        en.tile_start = vt;
-                        if (i >= sl.n) continue;
-                        const int nt_i = sl.tile_start[i + 1] - sl.tile_start[i];
-                        const int64_t pos0 = sl.pos0[i];
-                        const int lead = (int)((pos0 / 64) & 3);
-                        en.ntiles_lead = (uint32_t)nt_i | ((uint32_t)lead << 30);
-                        en.pos0 = sl.pos0[i]; en.adj_off = sl.adj_off[i]; en.prog = sl.prog[i]; en.zoff = sl.zoff[i];
-                        en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
-                        en.aff_off = sl.aff[i];
-                        en.push_off = NSK_NO_STREAM;
-                        en.wide_off = sl.wide[i] >= 0 ? (uint32_t)sl.wide[i] : NSK_NO_STREAM;     // (the descriptors start at the quad of pos0)
-                        if (sl.wide[i] >= 0) {
-                            const int stride = NSK_WIDE_STRIDE(sl.nch);
-                            for (int64_t P = (pos0 + 255) & ~(int64_t)255; P + 256 <= pos0 + 64 * (int64_t)nt_i; P += 256)
-                                if (g->c.seg_wide[(size_t)sl.wide[i] + (size_t)((P >> 8) - (pos0 >> 8)) * stride] != 0xFFFFFFFFu) nwide++;
+                if constexpr (sizeof(VT) == 1) if (use_tab) {
+                    // (prepared once per handle: walking the launch's quad descriptors on the host for every launch of every sweep
+                    //  cost more than the launch itself from a few million variables on)
+                    if (g->learn_wide_plans.size() != g->c.learn_seg.size()) g->learn_wide_plans.assign(g->c.learn_seg.size(), NskLearnWidePlan());
+                    NskLearnWidePlan &wp = g->learn_wide_plans[(size_t)(&sl - g->c.learn_seg.data())];
+                    if (wp.key != 1) {
+                        wp = NskLearnWidePlan();
+                        wp.key = 1;
+                        SegTable &wt = wp.tab;
+                        memset(&wt, 0, sizeof(wt));
+                        wt.n = sl.n;
+                        int vt = 0, nwide = 0;
+                        for (int i = 0; i < NSK_SEG_MAX; i++) {
+                            SegEntry &en = wt.e[i];
+                            en.tile_start = vt;
+                            if (i >= sl.n) continue;
+                            const int nt_i = sl.tile_start[i + 1] - sl.tile_start[i];
+                            const int64_t pos0 = sl.pos0[i];
+                            const int lead = (int)((pos0 / 64) & 3);
+                            en.ntiles_lead = (uint32_t)nt_i | ((uint32_t)lead << 30);
+                            en.pos0 = sl.pos0[i]; en.adj_off = sl.adj_off[i]; en.prog = sl.prog[i]; en.zoff = sl.zoff[i];
+                            en.zmask_ev = (sl.zmask[i] & 0xFFu) | (((uint32_t)sl.ev[i] & 0xFFu) << 8);
+                            en.aff_off = sl.aff[i];
+                            en.push_off = NSK_NO_STREAM;
+                            en.wide_off = sl.wide[i] >= 0 ? (uint32_t)sl.wide[i] : NSK_NO_STREAM;     // (the descriptors start at the quad of pos0)
+                            if (sl.wide[i] >= 0) {
+                                const int stride = NSK_WIDE_STRIDE(sl.nch);
+                                for (int64_t P = (pos0 + 255) & ~(int64_t)255; P + 256 <= pos0 + 64 * (int64_t)nt_i; P += 256)
+                                    if (g->c.seg_wide[(size_t)sl.wide[i] + (size_t)((P >> 8) - (pos0 >> 8)) * stride] != 0xFFFFFFFFu) nwide++;
+                            }
+                            vt += (nt_i + lead + 3) & ~3;
                         }
-                        vt += (nt_i + lead + 3) & ~3;
+                        wt.ntiles = vt;
+                        wp.vt = vt;
+                        const char *min_env = nsk::diag_env("NSK_WIDE_LEARN_MIN");                 // (diagnostic; the small-grid tests use 0)
+                        const int min_quads = min_env ? atoi(min_env) : NSK_WIDE_LEARN_MIN_QUADS;
+                        wp.wide = 8 * nwide >= vt && vt > 0 && vt / 4 >= min_quads && !nsk::diag_env("NSK_NO_WIDE_LEARN");
+                        if (wp.wide) nsk_tabw_rest_list(g->c, wt, sl.nch, wp.nrest, wp.rest);
                     }
-                    tab.ntiles = vt;
-                    const char *min_env = nsk::diag_env("NSK_WIDE_LEARN_MIN");                 // (diagnostic; the small-grid tests use 0)
-                    const int min_quads = min_env ? atoi(min_env) : NSK_WIDE_LEARN_MIN_QUADS;
-                    if (8 * nwide >= vt && vt > 0 && vt / 4 >= min_quads) {
+                    if (wp.wide) {
                         const DevGraph<signed char> &dw = d;
                         const bool fuse = SMALLW && pend.valid && pend.tabs_here;
                         const ApplyArgs &prev = fuse ? pend.aa : no_update;
-                        const int grid = nsk_learn_tabw_grid(vt) + (SMALLW ? NSK_SERVICE_BLOCKS : 0);
-                        if (sl.nch == 1) k_learn_seg_tabw<SMALLW, 1><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(dw, tab, lp, prev);
-                        else k_learn_seg_tabw<SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(dw, tab, lp, prev);
+                        TabwRest rest;
+                        rest.n = wp.nrest;
+                        memcpy(rest.q, wp.rest, sizeof(rest.q));
+                        const int grid = nsk_learn_tabw_grid(wp.vt) + (SMALLW ? NSK_SERVICE_BLOCKS : 0) + nsk_tabw_front_blocks(rest.n);
+                        if (sl.nch == 1) k_learn_seg_tabw<SMALLW, 1><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(dw, wp.tab, lp, prev, rest);
+                        else k_learn_seg_tabw<SMALLW, 2><<<dim3(grid), dim3(NSK_BLOCK), shmem, g->stream>>>(dw, wp.tab, lp, prev, rest);
                         if (fuse) pend.valid = false;
                         g->launches++;
                         continue;
                     }
-                    memset(&tab, 0, sizeof(tab));
-                    tab.n = sl.n;
                 }
                 // table launches number their tiles virtually: every segment is padded to whole trips
                 int vt = 0;

@@ -101,12 +101,13 @@ def test_wide_quads_keep_their_generators_on_the_exp_path():
     assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.count, cnt)
 
 
-@pytest.mark.parametrize("switch", ["NSK_NO_WIDE", "NSK_NO_RUN_PAD", "NSK_NO_WIDE_KERNEL"])
+@pytest.mark.parametrize("switch", ["NSK_NO_WIDE", "NSK_NO_RUN_PAD", "NSK_NO_WIDE_KERNEL", "NSK_NO_TABW_REST"])
 def test_wide_quad_switches(monkeypatch, switch):
     """The diagnostic switches that take the wide path out again: no descriptors at all, no run padding (half of a
     1000-column grid's quads stay wide), the tile-by-tile kernel over wide-flagged quads is NOT a valid combination
     (the scheme follows the descriptors), so NSK_NO_WIDE_KERNEL only moves the launch to k_gibbs_seg_tab when no quad
-    is wide."""
+    is wide.  NSK_NO_TABW_REST: the quads that are not wide sampled in line by the waves whose turn they are (what a
+    launch with more than NSK_TABW_REST_MAX of them does) instead of by workgroups of their own."""
     monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv(switch, "1")
     g = graphgen.ising_grid(24, 1000, weight=0.3)
@@ -116,6 +117,22 @@ def test_wide_quad_switches(monkeypatch, switch):
         assert info["wide_quads"] == 0
     og = oracle_of(fg)
     _run_and_compare(fg, og, 5, 1, 3)
+
+
+def test_learning_with_the_other_quads_in_line(monkeypatch):
+    """k_learn_seg_tabw with NSK_NO_TABW_REST (see above): same weights and chains."""
+    monkeypatch.setenv("NSK_DIAG", "1")
+    monkeypatch.setenv("NSK_NO_TABW_REST", "1")
+    rng = np.random.default_rng(2)
+    g = graphgen.ising_grid(24, 1000, weight=0.2, fixed=False, two_weights=True, evidence=rng.integers(0, 2, 24 * 1000))
+    ns, fg = session(g, seed=5)
+    og = oracle_of(fg)
+    order, ps = phases_from_colors(fg.colors())
+    vv, ve, wv, _ = og.initial_state()
+    fg.learn(0, 2, 1e-3, 0.9, 2, 0.01, 1)
+    assert og.learn_call(order, ps, vv, ve, wv, 2, 1e-3, 0.9, 2, 0.01, 1, False, 5, 0) == 0
+    assert np.array_equal(fg.var_value[0], vv) and np.array_equal(fg.var_value_evid[0], ve)
+    assert np.array_equal(fg.weight_value[0], wv), (fg.weight_value[0], wv)
 
 
 def test_learning_on_a_padded_layout():
