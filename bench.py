@@ -451,7 +451,7 @@ def dominant_kernel(workload, learning, info):
         small = info["nvar"] * info["value_bytes"] <= (24 << 20)
         return "k_gibbs_ep_w5" if workload.startswith("lr") and small else "k_gibbs_ep"
     if info["ztab_entries"]:
-        # wide quads (one lane samples four consecutive positions): laid out from 3M sampled variables per handle on; the
+        # wide quads (one lane samples four consecutive positions): laid out from 400 000 sampled variables per handle on; the
         # learning launches take them from 12 000 quads per class launch on (nsk_internal.h NSK_WIDE_LEARN_MIN_QUADS)
         wide = info.get("wide_quads", 0) * 2 >= max(1, info.get("tab_quads", 0)) and info["value_bytes"] == 1
         if wide and learning and info["wide_quads"] // max(1, info["ncolors"]) >= 12000:

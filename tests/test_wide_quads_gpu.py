@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _wide_quads_on_small_graphs(monkeypatch):
-    """The library lays out wide quads from 3M variables per handle on (below, a class launch is one wave lifetime long
-    and the tile-by-tile kernel's is shorter); these tests use grids the oracle walks in seconds, so they lower the
-    bound with the diagnostic switch.  The 10M grid of tests/test_config3_gpu.py takes the path at its default."""
+    """The library lays out wide quads from 400 000 variables per handle on, and its learning launches take them from 12 000
+    quads per launch on; these tests use grids the oracle walks in seconds, so they lower the bounds with the diagnostic
+    switches.  The 10M grid of tests/test_config3_gpu.py and the 1M grid of tests/test_hip_parity.py take the path at its
+    defaults."""
     monkeypatch.setenv("NSK_DIAG", "1")
     monkeypatch.setenv("NSK_WIDE_MIN", "0")
     monkeypatch.setenv("NSK_WIDE_LEARN_MIN", "0")
