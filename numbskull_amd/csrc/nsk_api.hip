@@ -199,6 +199,7 @@ int nsk_graph_destroy(nsk_graph *g) {
     for (int k = 0; k < 2; k++) if (g->xfer_host[k]) (void)hipHostFree(g->xfer_host[k]);
     if (g->cnt_host) (void)hipHostFree(g->cnt_host);
     if (g->sweep_graph) (void)hipGraphExecDestroy(g->sweep_graph);
+    if (g->sweep_graph_big) (void)hipGraphExecDestroy(g->sweep_graph_big);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)g->rccl_comm);
@@ -1014,6 +1015,8 @@ int nsk_exchange_setup(nsk_graph *g, int world, int rank, const int32_t *send_vi
 void nsk_drop_sweep_graph(nsk_graph *g) {
     if (g->sweep_graph) { (void)hipGraphExecDestroy(g->sweep_graph); g->sweep_graph = nullptr; }
     g->sweep_graph_key = -1;
+    if (g->sweep_graph_big) { (void)hipGraphExecDestroy(g->sweep_graph_big); g->sweep_graph_big = nullptr; }
+    g->sweep_graph_big_key = -1;
 }
 
 template <typename VT>

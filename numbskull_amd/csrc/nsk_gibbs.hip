@@ -362,9 +362,13 @@ static bool graph_eligible(const nsk_graph *g, bool p2p) {
 }
 
 template <typename VT>
-static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, int key) {
-    if (g->sweep_graph) { (void)hipGraphExecDestroy(g->sweep_graph); g->sweep_graph = nullptr; }
-    g->sweep_graph_key = -1;
+static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, int key, bool big) {
+    hipGraphExec_t &exec = big ? g->sweep_graph_big : g->sweep_graph;
+    int &exec_key = big ? g->sweep_graph_big_key : g->sweep_graph_key;
+    int &exec_launches = big ? g->sweep_graph_big_launches : g->sweep_graph_launches;
+    const int nsw = big ? NSK_GRAPH_SWEEPS_BIG : NSK_GRAPH_SWEEPS;
+    if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+    exec_key = -1;
     // the segment plans (kept in the handle) are built by an eager sweep-free call path: make sure they exist
     DevGraph<VT> d = view<VT>(g);
     hipGraph_t graph = nullptr;
@@ -373,7 +377,7 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
     if (g->stream == nullptr) return nsk::fail(NSK_E_DEVICE, "the default stream cannot be captured");
     HIPCHECK(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
     int launches = 0;
-    for (int i = 0; i < NSK_GRAPH_SWEEPS; i++) {
+    for (int i = 0; i < nsw; i++) {
         for (size_t ph = 0; ph < g->seg_plans.size(); ph++)
             for (const NskSegPlan &pl : g->seg_plans[ph]) {
                 const int nbp = nsk_tab_grid(pl.tab.ntiles);
@@ -412,14 +416,14 @@ static int graph_build(nsk_graph *g, int sample_evidence, int burnin, bool p2p, 
             if (rc) { (void)hipStreamEndCapture(g->stream, &graph); if (graph) (void)hipGraphDestroy(graph); return rc; }
         }
     }
-    k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, NSK_GRAPH_SWEEPS, p2p ? NSK_GRAPH_SWEEPS : 0, 0, 0ull, 0ull);
+    k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, (unsigned long long)nsw, p2p ? (unsigned long long)nsw : 0ull, 0, 0ull, 0ull);
     hipError_t e = hipStreamEndCapture(g->stream, &graph);
     if (e != hipSuccess || !graph) return nsk::fail(NSK_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    e = hipGraphInstantiate(&g->sweep_graph, graph, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) { g->sweep_graph = nullptr; return nsk::fail(NSK_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
-    g->sweep_graph_key = key;
-    g->sweep_graph_launches = launches;
+    if (e != hipSuccess) { exec = nullptr; return nsk::fail(NSK_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    exec_key = key;
+    exec_launches = launches;
     (void)sample_evidence;
     return NSK_OK;
 }
@@ -457,35 +461,43 @@ int nsk_gibbs_run(nsk_graph *g, int64_t nsweeps, int sample_evidence, int burnin
     struct Done { nsk_graph *g; bool fuse; ~Done() { g->p2p_fused_now = false; if (fuse) g->p2p_close_pending = true;
                                                       (void)nsk_unpack_tally(g); g->pack_now = false; } } done{g, fuse};
     if (left >= NSK_GRAPH_SWEEPS && graph_eligible(g, p2p)) {
-        // the plans of this (sample_evidence, tables) combination: one eager sweep builds / refreshes them
-        int rc = gibbs_eager(g, 1, sample_evidence, burnin);
-        if (rc) return rc;
-        if (p2p && !fuse && (rc = nsk_p2p_enqueue(g, nullptr, 0))) return rc;
-        left--;
+        // the plans of this (sample_evidence, tables) combination and the tables of the current weights (what an eager
+        // sweep does in front of its launches; an eager sweep in front of the replays cost a 400-sweep call of the 1M grid
+        // 16 sweeps outside them -- this one and the 15 that 399 leaves over)
+        int rc = NSK_OK;
+        nsk_refresh_prog_weights(g);
+        nsk_ensure_seg_plans(g, sample_evidence);
         bool all_tab = true;
         for (const auto &v : g->seg_plans) for (const NskSegPlan &pl : v) all_tab = all_tab && pl.kind >= 8;
         const int key = g->seg_plans_key | (burnin ? 8 : 0) | (p2p ? 16 : 0) | (fuse ? 32 : 0) | (g->pack_now ? 64 : 0);
         if (all_tab && left >= NSK_GRAPH_SWEEPS) {
-            if (g->sweep_graph_key != key && !g->sweep_graph_off) {
-                rc = g->c.vbytes == 1 ? graph_build<int8_t>(g, sample_evidence, burnin, p2p, key)
-                                      : graph_build<int32_t>(g, sample_evidence, burnin, p2p, key);
-                if (rc) {                   // capture is an optimisation: without it the eager loop runs
-                    g->sweep_graph_off = true;
-                    (void)hipGetLastError();
+            // two sizes: NSK_GRAPH_SWEEPS_BIG sweeps per replay while the call is long enough, NSK_GRAPH_SWEEPS for what is left
+            for (int big = (left >= NSK_GRAPH_SWEEPS_BIG && !nsk::diag_env("NSK_NO_BIG_GRAPH")) ? 1 : 0; big >= 0; big--) {
+                const int nsw = big ? NSK_GRAPH_SWEEPS_BIG : NSK_GRAPH_SWEEPS;
+                hipGraphExec_t &exec = big ? g->sweep_graph_big : g->sweep_graph;
+                int &exec_key = big ? g->sweep_graph_big_key : g->sweep_graph_key;
+                if (left < nsw || g->sweep_graph_off) continue;
+                if (exec_key != key) {
+                    rc = g->c.vbytes == 1 ? graph_build<int8_t>(g, sample_evidence, burnin, p2p, key, big != 0)
+                                          : graph_build<int32_t>(g, sample_evidence, burnin, p2p, key, big != 0);
+                    if (rc) {               // capture is an optimisation: without it the eager loop runs
+                        g->sweep_graph_off = true;
+                        (void)hipGetLastError();
+                        continue;
+                    }
                 }
-            }
-            if (g->sweep_graph_key == key && !g->sweep_graph_off)
                 k_graph_counters<<<dim3(1), dim3(1), 0, g->stream>>>(g->d_counters, g->sweep, g->p2p_tag, 1, g->seed, g->rng_tag);
-            while (left >= NSK_GRAPH_SWEEPS && g->sweep_graph_key == key && !g->sweep_graph_off) {
-                if (!burnin && g->pos_tally_sweeps + NSK_GRAPH_SWEEPS > 255) nsk_fold_position_tally(g);   // uint8 tally
-                if (g->pack_now && g->packed_sweeps + NSK_GRAPH_SWEEPS > 127) (void)nsk_unpack_tally(g);   // 7 bits in a value byte
-                HIPCHECK(hipGraphLaunch(g->sweep_graph, g->stream));
-                g->sweep += NSK_GRAPH_SWEEPS;
-                if (p2p) g->p2p_tag += NSK_GRAPH_SWEEPS;
-                if (!burnin) { g->pos_tally_sweeps += NSK_GRAPH_SWEEPS; g->cnt_dirty = true; if (g->pack_now) g->packed_sweeps += NSK_GRAPH_SWEEPS; }
-                g->sweeps_done += NSK_GRAPH_SWEEPS;
-                g->launches += g->sweep_graph_launches;
-                left -= NSK_GRAPH_SWEEPS;
+                while (left >= nsw && exec_key == key) {
+                    if (!burnin && g->pos_tally_sweeps + nsw > 255) nsk_fold_position_tally(g);   // uint8 tally
+                    if (g->pack_now && g->packed_sweeps + nsw > 127) (void)nsk_unpack_tally(g);   // 7 bits in a value byte
+                    HIPCHECK(hipGraphLaunch(exec, g->stream));
+                    g->sweep += (uint64_t)nsw;
+                    if (p2p) g->p2p_tag += (unsigned int)nsw;
+                    if (!burnin) { g->pos_tally_sweeps += nsw; g->cnt_dirty = true; if (g->pack_now) g->packed_sweeps += nsw; }
+                    g->sweeps_done += nsw;
+                    g->launches += big ? g->sweep_graph_big_launches : g->sweep_graph_launches;
+                    left -= nsw;
+                }
             }
             HIPCHECK(hipGetLastError());
         }

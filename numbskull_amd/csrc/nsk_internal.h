@@ -44,6 +44,10 @@ struct nsk_graph {
     // table launches only (+ the peer-to-peer exchange), replayed with the sweep index in device memory
     hipGraphExec_t sweep_graph = nullptr;
     int sweep_graph_key = -1, sweep_graph_launches = 0;
+    // ... and NSK_GRAPH_SWEEPS_BIG of them for long calls (the one-thread kernel that advances the counters and the
+    // replay's own latency are ~5 us per replay: 4 % of a 16-sweep replay of the 1M grid)
+    hipGraphExec_t sweep_graph_big = nullptr;
+    int sweep_graph_big_key = -1, sweep_graph_big_launches = 0;
     bool sweep_graph_off = false;                  // capture failed once (e.g. the legacy default stream): eager from then on
     unsigned long long *d_counters = nullptr;      // [0] sweep index, [1] exchange tag, [2] Philox key, [3] shard tag
     int device = 0;
@@ -345,6 +349,7 @@ static inline int nsk_learn_seg_grid(const nsk::Compiled::SegLaunch &sl, int nwe
 extern "C" int nsk_ensure_generic(nsk_graph *g);       // internal (not in the public header)
 int nsk_ensure_lag_sets(nsk_graph *g);                 // second set of weights / tables / accumulators (nsk_api.hip)
 #define NSK_GRAPH_SWEEPS 16
+#define NSK_GRAPH_SWEEPS_BIG 64
 // one peer-to-peer exchange on the library's stream; tag_base != null: a captured launch whose tag is
 // the device counter + tag_off; learn: both chains + the weight deltas; part 0 = all of it, 1 = the
 // pushes only, 2 = wait + unpack (+ the owner's half of the weight merge), 3 = the closing half of the

@@ -26,7 +26,7 @@ def graph(kind):
 def main():
     kind, learn, nsweeps = sys.argv[1], sys.argv[2] == "learn", 4
     if len(sys.argv) > 3 and sys.argv[3].startswith("p2p") and not learn:
-        nsweeps = 37                              # long enough for captured sweep sequences (grids)
+        nsweeps = 87                              # long enough for captured sweep sequences of both sizes (grids: 1 + 64 + 16 + 6)
     local = len(sys.argv) > 3 and sys.argv[3] in ("local", "p2plocal")   # every rank holds only its shard (+ ghosts)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
