@@ -1065,10 +1065,10 @@ def test_large_feature_values_widen_the_gradient_accumulator(reg):
 
 @pytest.mark.parametrize("burn", [0, 37])
 def test_captured_sweep_sequences_equal_the_oracle(burn):
-    """A handle whose sweep is table launches only replays NSK_GRAPH_SWEEPS = 16 sweeps per hipGraph
-    launch (sweep index in device memory + a per-node offset, nsk_gibbs.hip): 16-sweep replays, the
-    eager remainder, the position-tally fold between replays (300 tallied sweeps) and a burn-in graph
-    must leave values and tallies exactly where the oracle's sweep-by-sweep run leaves them."""
+    """A handle whose sweep is table launches only replays 64 or 16 sweeps per hipGraph launch (sweep index
+    in device memory + a per-node offset, nsk_gibbs.hip): 64- and 16-sweep replays, the eager remainder, the
+    position-tally fold between replays (300 tallied sweeps = 4 x 64 + 2 x 16 + 12) and a burn-in graph (37 = 2 x 16
+    + 5) must leave values and tallies exactly where the oracle's sweep-by-sweep run leaves them."""
     g = graphgen.ising_grid(48, 40, weight=0.3)
     ns, fg = session(g, seed=9)
     og = oracle_of(fg)
